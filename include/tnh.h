@@ -1,0 +1,220 @@
+/*
+ * tnh.h -- C ABI of libtnhip.so, the MI355X (gfx950) compute library behind
+ * the TensorNetwork "hip" backend.
+ *
+ * This is the drop-in boundary for the hot path of google/TensorNetwork:
+ * every entry point below is what an `AbstractBackend` method of the
+ * reference lowers to once tensors live in HBM.  Citations are to the
+ * reference tree (tensornetwork/...), interface file
+ * backends/abstract_backend.py and oracle backends/numpy/numpy_backend.py.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes; no C++/torch types.
+ *   - every function returns 0 on success, a negative tnh_status otherwise;
+ *     tnh_last_error() returns a human readable message for the last failure
+ *     on the calling thread.  Nothing in here aborts the process.
+ *   - all tensor pointers are DEVICE pointers unless the name says `host`.
+ *   - tensors are dense, C-contiguous (row-major); shapes/strides are
+ *     int64_t element counts.
+ *   - kernels never allocate or free; outputs are allocated by the caller
+ *     (tnh_malloc) and passed in.  Work is queued on one in-order HIP stream
+ *     per process (one process per GPU); only tnh_d2h / tnh_sync block.
+ */
+#ifndef TNH_H_
+#define TNH_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------ status */
+typedef enum {
+  TNH_OK = 0,
+  TNH_ERR_HIP = -1,          /* a HIP runtime call failed (see tnh_last_error) */
+  TNH_ERR_INVALID = -2,      /* bad argument (shape/dtype/rank/null pointer)    */
+  TNH_ERR_UNSUPPORTED = -3,  /* valid request this build has no kernel for      */
+  TNH_ERR_NOMEM = -4,        /* device allocation failed                        */
+  TNH_ERR_NOT_INIT = -5,     /* tnh_init has not been called                    */
+  TNH_ERR_NO_CONVERGE = -6   /* iterative kernel (SVD) hit its sweep limit      */
+} tnh_status;
+
+/* ------------------------------------------------------------------ dtypes */
+typedef enum {
+  TNH_F32 = 0,
+  TNH_F64 = 1,
+  TNH_BF16 = 2,
+  TNH_F16 = 3,
+  TNH_C64 = 4,   /* interleaved (re, im) float  */
+  TNH_C128 = 5,  /* interleaved (re, im) double */
+  TNH_I32 = 6,   /* data-movement kernels only  */
+  TNH_I64 = 7    /* data-movement kernels only  */
+} tnh_dtype;
+
+#define TNH_MAX_RANK 16
+
+/* ------------------------------------------------------- runtime / memory */
+/* Select `device`, create the process' stream and the block pool. Idempotent
+ * for the same device. */
+int tnh_init(int device);
+int tnh_shutdown(void);
+int tnh_device_count(int* count);
+/* name: caller buffer of `len` bytes; cus: compute units; hbm_bytes: total. */
+int tnh_device_info(char* name, int len, int* cus, int64_t* hbm_bytes);
+const char* tnh_last_error(void);
+const char* tnh_version(void);
+
+/* Pooled device allocator (size-bucketed free lists over hipMalloc; blocks are
+ * recycled in stream order, hipFree is only issued by tnh_trim / on OOM). */
+int tnh_malloc(void** ptr, size_t nbytes);
+int tnh_free(void* ptr);
+int tnh_trim(void);
+int tnh_mem_stats(int64_t* in_use, int64_t* cached, int64_t* peak);
+
+int tnh_h2d(void* dst, const void* host_src, size_t nbytes);
+int tnh_d2h(void* host_dst, const void* src, size_t nbytes); /* blocking */
+int tnh_d2d(void* dst, const void* src, size_t nbytes);
+int tnh_memset(void* dst, int byte, size_t nbytes);
+int tnh_sync(void);
+/* The hipStream_t all kernels are launched on (for interop / profiling). */
+int tnh_stream(void** stream);
+
+/* HIP events on that stream: bench.py times kernels with these. */
+int tnh_event_create(void** ev);
+int tnh_event_record(void* ev);
+int tnh_event_sync(void* ev);
+int tnh_event_elapsed_ms(void* start, void* stop, float* ms);
+int tnh_event_destroy(void* ev);
+
+/* hipGraph capture of a launch sequence (e.g. one contraction path): every
+ * tnh_* kernel call between begin/end is recorded instead of executed. */
+int tnh_graph_begin(void);
+int tnh_graph_end(void** graph_exec);
+int tnh_graph_launch(void* graph_exec);
+int tnh_graph_destroy(void* graph_exec);
+
+/* --------------------------------------------------------------- K1 layout */
+/* dst[i0..] = src permuted: numpy.transpose(src, perm).  Replaces
+ * AbstractBackend.transpose (abstract_backend.py:53-65; oracle
+ * numpy_backend.py:59-62).  Bit-exact for any itemsize in {1,2,4,8,16}. */
+int tnh_permute(void* dst, const void* src, int rank, const int64_t* shape,
+                const int32_t* perm, int itemsize);
+
+/* dst (contiguous, `shape`) gathers src[offset + sum_i idx_i*src_strides[i]]
+ * (strides in elements, 0 = broadcast).  Backs AbstractBackend.slice
+ * (abstract_backend.py:67-77; numpy_backend.py:64-72), diagonal (859-888)
+ * and broadcasting. */
+int tnh_strided_copy(void* dst, const void* src, int rank,
+                     const int64_t* shape, const int64_t* src_strides,
+                     int64_t src_offset, int itemsize);
+
+/* dst[offset + sum idx_i*dst_strides[i]] = src (contiguous, `shape`).
+ * Backs diagflat (abstract_backend.py:847-857) and slice assignment. */
+int tnh_strided_scatter(void* dst, const void* src, int rank,
+                        const int64_t* shape, const int64_t* dst_strides,
+                        int64_t dst_offset, int itemsize);
+
+/* ----------------------------------------------------------------- K2 GEMM */
+/* C[b] (M x N, row-major, ldc) = op(A[b]) (M x K) * op(B[b]) (K x N)
+ *   transA == 0: A[b] stored M x K row-major (lda >= K);  1: stored K x M.
+ *   transB == 0: B[b] stored K x N row-major (ldb >= N);  1: stored N x K.
+ * in_dtype in {F32,F64,BF16,F16,C64,C128}; accumulation is f32 for
+ * F32/BF16/F16/C64 and f64 for F64/C128; out_dtype == in_dtype, or F32 for
+ * BF16/F16 inputs.
+ * Replaces AbstractBackend.tensordot / matmul / outer_product after the
+ * transpose+reshape lowering (abstract_backend.py:27-38, 828-845, 202-205;
+ * oracle numpy_backend.py:35-54, 609-612, 99-100; lowering spec
+ * backends/tensorflow/tensordot2.py:22-250). */
+int tnh_gemm(int in_dtype, int out_dtype, int transA, int transB, int64_t M,
+             int64_t N, int64_t K, const void* A, int64_t lda, const void* B,
+             int64_t ldb, void* C, int64_t ldc, int64_t batch, int64_t strideA,
+             int64_t strideB, int64_t strideC);
+/* Name of the kernel variant the last tnh_gemm call dispatched to. */
+const char* tnh_gemm_last_kernel(void);
+/* Force a variant ("auto", "generic", "valu", "bf16_128", "bf16_256"): used by
+ * tests (second opinion) and bench.py (A/B); "auto" is the product setting. */
+int tnh_gemm_set_variant(const char* name);
+
+/* ------------------------------------------------------- K3/K4 reductions */
+/* dst[o] = sum_i src[o, i, i + offset]  over an (outer, n, m) view: the trace
+ * over the last two axes.  AbstractBackend.trace (abstract_backend.py:890-914;
+ * numpy_backend.py:684-707), called by ncon's partial trace
+ * (ncon_interface.py:265-274) and _contract_trace
+ * (network_components.py:1826-1827). */
+int tnh_trace_last2(void* dst, const void* src, int64_t outer, int64_t n,
+                    int64_t m, int64_t offset, int dtype);
+
+/* dst[o, i] = sum_r src[o, r, i] over an (outer, reduce, inner) view.
+ * AbstractBackend.sum (abstract_backend.py:812-826; numpy_backend.py:603-607;
+ * ncon_interface.py:419). */
+int tnh_sum_mid(void* dst, const void* src, int64_t outer, int64_t reduce,
+                int64_t inner, int dtype);
+
+/* dst[0] = sqrt(sum |src_i|^2) (Frobenius norm; numpy_backend.py:107-108). */
+int tnh_norm(void* dst, const void* src, int64_t n, int dtype);
+
+/* ------------------------------------------------------ K5/K6 elementwise */
+typedef enum {
+  TNH_OP_SQRT = 0, TNH_OP_CONJ = 1, TNH_OP_ABS = 2, TNH_OP_SIGN = 3,
+  TNH_OP_EXP = 4, TNH_OP_LOG = 5, TNH_OP_SIN = 6, TNH_OP_COS = 7,
+  TNH_OP_NEG = 8, TNH_OP_COPY = 9, TNH_OP_REAL = 10, TNH_OP_IMAG = 11
+} tnh_unary_op;
+typedef enum {
+  TNH_OP_ADD = 0, TNH_OP_SUB = 1, TNH_OP_MUL = 2, TNH_OP_DIV = 3,
+  TNH_OP_POW = 4
+} tnh_binary_op;
+
+/* dst_i = op(src_i); ABS/REAL/IMAG of a complex dtype write the real dtype. */
+int tnh_unary(int op, void* dst, const void* src, int64_t n, int dtype);
+
+/* dst (contiguous, `shape`) = a (op) b with numpy broadcasting expressed as
+ * per-operand element strides (0 on broadcast axes).  Covers
+ * addition/subtraction/multiply/divide (abstract_backend.py:633-683) and
+ * broadcast_right/left_multiplication (709-741; numpy_backend.py:560-575). */
+int tnh_binary(int op, void* dst, const void* a, const void* b, int rank,
+               const int64_t* shape, const int64_t* a_strides,
+               const int64_t* b_strides, int dtype);
+
+/* dst_i = src_i (op) (re + i*im) with the scalar on the right, or on the left
+ * when scalar_left != 0. */
+int tnh_binary_scalar(int op, void* dst, const void* src, double re, double im,
+                      int scalar_left, int64_t n, int dtype);
+
+/* dst_i = value. */
+int tnh_fill(void* dst, double re, double im, int64_t n, int dtype);
+/* dst (rows x cols) = identity-like with ones on diagonal k = 0. */
+int tnh_eye(void* dst, int64_t rows, int64_t cols, int dtype);
+/* dst_i = (dst_dtype) src_i  (F32/F64/BF16/F16 among each other, C64<->C128,
+ * real -> complex). */
+int tnh_cast(void* dst, int dst_dtype, const void* src, int src_dtype,
+             int64_t n);
+
+/* ------------------------------------------------------------------ K7 SVD */
+/* Thin SVD of the row-major m x n matrix A (dtype F32 or F64):
+ *   A = U diag(S) Vh,  r = min(m, n), S descending, ALL r values returned.
+ *   U  : m x k row-major (first k left vectors),
+ *   Vh : k x n row-major (first k right vectors), 0 <= k <= r.
+ * A is not modified.  `work` must hold tnh_svd_work_bytes() bytes.  One-sided
+ * (Hestenes) Jacobi; `sweeps_out` (host, may be NULL) receives the number of
+ * sweeps used.  Replaces the np.linalg.svd call inside
+ * backends/numpy/decompositions.py:36 behind AbstractBackend.svd
+ * (abstract_backend.py:79-137); the truncation bookkeeping (decompositions.py
+ * :38-74) stays on the host. */
+int tnh_svd_work_bytes(int dtype, int64_t m, int64_t n, size_t* nbytes);
+/* Two-phase form: tnh_svd_factor runs the sweeps and writes all singular
+ * values to S; the host then applies the reference's truncation rule
+ * (decompositions.py:38-57) to pick k and calls tnh_svd_vectors, which emits
+ * the leading k vectors from the state left in `work`. */
+int tnh_svd_factor(int dtype, int64_t m, int64_t n, const void* A, void* S,
+                   void* work, int* sweeps_out);
+int tnh_svd_vectors(int dtype, int64_t m, int64_t n, void* work, int64_t k,
+                    void* U, void* Vh);
+int tnh_svd(int dtype, int64_t m, int64_t n, const void* A, void* U, void* S,
+            void* Vh, int64_t k, void* work, int* sweeps_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TNH_H_ */

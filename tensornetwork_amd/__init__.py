@@ -1,0 +1,27 @@
+"""tensornetwork_amd -- MI355X (gfx950) native backend for google/TensorNetwork.
+
+``import tensornetwork_amd`` registers the backend name ``"hip"`` with
+TensorNetwork's backend factory when that library is importable, so that
+``tn.Node(x, backend="hip")``, ``tn.ncon(..., backend="hip")``,
+``tn.contractors.greedy`` and ``tn.split_node`` run on the GPU unchanged.  The
+same workloads also run stand-alone through ``tensornetwork_amd.ncon`` /
+``.network`` / ``.contractors`` on a machine that only has this repository.
+
+Compute lives in ``libtnhip.so`` (hand-written HIP kernels, C ABI in
+``include/tnh.h``); there is no CPU fallback.
+"""
+from tensornetwork_amd._lib import HipRuntimeError
+from tensornetwork_amd.device_tensor import DeviceTensor, bfloat16, round_to_bf16
+from tensornetwork_amd.hip_backend import (HipBackend, get_hip_backend,
+                                           register_with_tensornetwork)
+from tensornetwork_amd.ncon import ncon, einsum
+from tensornetwork_amd.network import (Node, Edge, connect, contract, contract_between,
+                                       contract_parallel, contract_trace_edges, outer_product,
+                                       split_node, split_node_full_svd, copy, slice_edge,
+                                       get_all_edges, get_subgraph_dangling, get_shared_edges,
+                                       reachable)
+from tensornetwork_amd import contractors, pathfinder
+
+__version__ = "0.1.0"
+
+REGISTERED = register_with_tensornetwork()

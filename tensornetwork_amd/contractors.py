@@ -1,0 +1,130 @@
+"""Path-driven contractors (``greedy``, ``optimal``, ``branch``, ``auto``, ``custom``).
+
+Mirror of ``tensornetwork/contractors/opt_einsum_paths/path_contractors.py``:
+``base`` (36-97) contracts trace edges, asks a path algorithm for the pairwise
+order over ``(input_sets, output_set, size_dict)`` built from the nodes' edges
+(``utils.get_path``, utils.py:29-46), then runs one ``contract_between`` per
+step.  The path algorithms come from ``tensornetwork_amd.pathfinder`` (the
+reference delegates to the absent third-party ``opt_einsum``).
+
+Works on ``tensornetwork_amd.network.Node`` objects; the search itself is pure
+host code, the pairwise steps are GEMMs on the backend.
+"""
+import functools
+from typing import Callable, Iterable, List, Optional, Sequence, Tuple
+
+from tensornetwork_amd import network, pathfinder
+
+
+def get_path(nodes: Iterable[network.Node], algorithm: Callable) -> Tuple[List[Tuple[int, int]], List[network.Node]]:
+  nodes = list(nodes)
+  input_sets = [set(node.edges) for node in nodes]
+  output_set = network.get_subgraph_dangling(nodes)
+  size_dict = {edge: edge.dimension for edge in network.get_all_edges(nodes)}
+  return algorithm(input_sets, output_set, size_dict), nodes
+
+
+def contract_path(path: Sequence[Tuple[int, ...]], nodes: Iterable[network.Node],
+                  output_edge_order: Optional[Sequence[network.Edge]] = None) -> network.Node:
+  """Run a linear path (path_contractors.py:354-403)."""
+  nodes = list(nodes)
+  if not nodes:
+    raise ValueError("No node was given to contract.")
+  edges = network.get_all_edges(nodes)
+  for edge in edges:
+    if not edge.is_dangling() and edge.is_trace():
+      node = edge.node1
+      if node in nodes:
+        new = network.contract_trace_edges(node)
+        nodes[nodes.index(node)] = new
+  for pair in path:
+    if len(pair) == 1:
+      continue
+    a, b = sorted(pair)
+    new = network.contract_between(nodes[a], nodes[b], allow_outer_product=True)
+    nodes = [n for i, n in enumerate(nodes) if i not in (a, b)] + [new]
+  final = nodes[0]
+  if len(nodes) != 1:
+    raise ValueError("the path did not reduce the network to a single node")
+  if output_edge_order is not None:
+    final.reorder_edges(list(output_edge_order))
+  return final
+
+
+def base(nodes: Iterable[network.Node], algorithm: Callable,
+         output_edge_order: Optional[Sequence[network.Edge]] = None,
+         ignore_edge_order: bool = False) -> network.Node:
+  nodes = list(nodes)
+  if not nodes:
+    raise ValueError("No node was given to contract.")
+  dangling = network.get_subgraph_dangling(nodes)
+  if output_edge_order is None:
+    output_edge_order = list(dangling)
+    if len(output_edge_order) > 1 and not ignore_edge_order:
+      raise ValueError("The final node after contraction has more than one remaining edge. In this "
+                       "case `output_edge_order` has to be provided.")
+  if set(output_edge_order) != dangling:
+    raise ValueError("output edges are not equal to the remaining non-contracted edges of the final node.")
+  # trace edges first (path_contractors.py:73-77)
+  for i, node in enumerate(nodes):
+    if any(e.is_trace() for e in node.edges):
+      nodes[i] = network.contract_trace_edges(node)
+  if len(nodes) == 1:
+    final = nodes[0]
+  else:
+    path, nodes = get_path(nodes, algorithm)
+    final = contract_path(path, nodes)
+  if not ignore_edge_order and len(final.edges) > 1:
+    final.reorder_edges(list(output_edge_order))
+  return final
+
+
+def greedy(nodes, output_edge_order=None, memory_limit: Optional[int] = None, ignore_edge_order: bool = False):
+  """path_contractors.py:165-193."""
+  alg = functools.partial(pathfinder.greedy, memory_limit=memory_limit)
+  return base(nodes, alg, output_edge_order, ignore_edge_order)
+
+
+def optimal(nodes, output_edge_order=None, memory_limit: Optional[int] = None, ignore_edge_order: bool = False):
+  """path_contractors.py:100-126."""
+  alg = functools.partial(pathfinder.optimal, memory_limit=memory_limit)
+  return base(nodes, alg, output_edge_order, ignore_edge_order)
+
+
+def branch(nodes, output_edge_order=None, memory_limit: Optional[int] = None, nbranch: Optional[int] = None,
+           ignore_edge_order: bool = False):
+  """path_contractors.py:129-162."""
+  alg = functools.partial(pathfinder.branch, memory_limit=memory_limit, nbranch=nbranch)
+  return base(nodes, alg, output_edge_order, ignore_edge_order)
+
+
+def auto(nodes, output_edge_order=None, memory_limit: Optional[int] = None, ignore_edge_order: bool = False):
+  """path_contractors.py:197-265."""
+  nodes = list(nodes)
+  if len(nodes) == 1 and output_edge_order is None:
+    output_edge_order = list(nodes[0].get_all_dangling()) if not ignore_edge_order else None
+  alg = functools.partial(pathfinder.auto, memory_limit=memory_limit)
+  return base(nodes, alg, output_edge_order, ignore_edge_order)
+
+
+def custom(nodes, optimizer: Callable, output_edge_order=None, memory_limit: Optional[int] = None,
+           ignore_edge_order: bool = False):
+  """Any callable with the opt_einsum path signature (path_contractors.py:268-296)."""
+  alg = functools.partial(optimizer, memory_limit=memory_limit)
+  return base(nodes, alg, output_edge_order, ignore_edge_order)
+
+
+def path_solver(algorithm: str, nodes, memory_limit: Optional[int] = None, nbranch: Optional[int] = None):
+  """Only compute the path (path_contractors.py:299-351)."""
+  if algorithm == "optimal":
+    alg = functools.partial(pathfinder.optimal, memory_limit=memory_limit)
+  elif algorithm == "branch":
+    alg = functools.partial(pathfinder.branch, memory_limit=memory_limit, nbranch=nbranch)
+  elif algorithm == "greedy":
+    alg = functools.partial(pathfinder.greedy, memory_limit=memory_limit)
+  elif algorithm == "auto":
+    alg = functools.partial(pathfinder.auto, memory_limit=memory_limit)
+  else:
+    raise ValueError("algorithm {algorithm} not implemented".format(algorithm=algorithm))
+  path, _ = get_path(list(nodes), alg)
+  return path

@@ -1,0 +1,449 @@
+// K5/K6: elementwise, broadcasting binary ops, fills and casts (HBM-bound).
+// Algorithmic bytes: (inputs + output) * itemsize per element.
+#include "tnh_types.h"
+
+namespace tnh {
+
+// ---- scalar math on compute types --------------------------------------------
+template <typename R> struct Cx { R re, im; };
+
+__device__ __forceinline__ float m_sqrt(float x) { return sqrtf(x); }
+__device__ __forceinline__ double m_sqrt(double x) { return sqrt(x); }
+__device__ __forceinline__ float m_exp(float x) { return expf(x); }
+__device__ __forceinline__ double m_exp(double x) { return exp(x); }
+__device__ __forceinline__ float m_log(float x) { return logf(x); }
+__device__ __forceinline__ double m_log(double x) { return log(x); }
+__device__ __forceinline__ float m_sin(float x) { return sinf(x); }
+__device__ __forceinline__ double m_sin(double x) { return sin(x); }
+__device__ __forceinline__ float m_cos(float x) { return cosf(x); }
+__device__ __forceinline__ double m_cos(double x) { return cos(x); }
+__device__ __forceinline__ float m_sinh(float x) { return sinhf(x); }
+__device__ __forceinline__ double m_sinh(double x) { return sinh(x); }
+__device__ __forceinline__ float m_cosh(float x) { return coshf(x); }
+__device__ __forceinline__ double m_cosh(double x) { return cosh(x); }
+__device__ __forceinline__ float m_hypot(float a, float b) { return hypotf(a, b); }
+__device__ __forceinline__ double m_hypot(double a, double b) { return hypot(a, b); }
+__device__ __forceinline__ float m_atan2(float a, float b) { return atan2f(a, b); }
+__device__ __forceinline__ double m_atan2(double a, double b) { return atan2(a, b); }
+__device__ __forceinline__ float m_pow(float a, float b) { return powf(a, b); }
+__device__ __forceinline__ double m_pow(double a, double b) { return pow(a, b); }
+__device__ __forceinline__ float m_abs(float a) { return fabsf(a); }
+__device__ __forceinline__ double m_abs(double a) { return fabs(a); }
+
+template <typename R>
+__device__ __forceinline__ R real_unary(int op, R x) {
+  switch (op) {
+    case TNH_OP_SQRT: return m_sqrt(x);
+    case TNH_OP_CONJ: return x;
+    case TNH_OP_ABS: return m_abs(x);
+    case TNH_OP_SIGN: return (x > R(0)) ? R(1) : ((x < R(0)) ? R(-1) : x);  // keeps 0 / nan
+    case TNH_OP_EXP: return m_exp(x);
+    case TNH_OP_LOG: return m_log(x);
+    case TNH_OP_SIN: return m_sin(x);
+    case TNH_OP_COS: return m_cos(x);
+    case TNH_OP_NEG: return -x;
+    case TNH_OP_REAL: return x;
+    case TNH_OP_IMAG: return R(0);
+    default: return x;
+  }
+}
+
+template <typename Z, typename R>
+__device__ __forceinline__ Z cplx_unary(int op, Z z) {
+  switch (op) {
+    case TNH_OP_SQRT: {
+      // principal branch, numerically stable form
+      const R m = m_hypot(z.re, z.im);
+      if (m == R(0)) return {R(0), z.im};
+      R a = m_sqrt((m + m_abs(z.re)) / R(2));
+      R b = z.im / (R(2) * a);
+      if (z.re >= R(0)) return {a, b};
+      return {m_abs(b), (z.im < R(0)) ? -a : a};
+    }
+    case TNH_OP_CONJ: return {z.re, -z.im};
+    case TNH_OP_SIGN: {
+      // numpy >= 2: z / |z|
+      const R m = m_hypot(z.re, z.im);
+      if (m == R(0)) return {R(0), R(0)};
+      return {z.re / m, z.im / m};
+    }
+    case TNH_OP_EXP: {
+      const R e = m_exp(z.re);
+      return {e * m_cos(z.im), e * m_sin(z.im)};
+    }
+    case TNH_OP_LOG: return {m_log(m_hypot(z.re, z.im)), m_atan2(z.im, z.re)};
+    case TNH_OP_SIN: return {m_sin(z.re) * m_cosh(z.im), m_cos(z.re) * m_sinh(z.im)};
+    case TNH_OP_COS: return {m_cos(z.re) * m_cosh(z.im), -m_sin(z.re) * m_sinh(z.im)};
+    case TNH_OP_NEG: return {-z.re, -z.im};
+    default: return z;
+  }
+}
+
+__device__ __forceinline__ float apply_unary(int op, float x) { return real_unary<float>(op, x); }
+__device__ __forceinline__ double apply_unary(int op, double x) { return real_unary<double>(op, x); }
+__device__ __forceinline__ cf32 apply_unary(int op, cf32 x) { return cplx_unary<cf32, float>(op, x); }
+__device__ __forceinline__ cf64 apply_unary(int op, cf64 x) { return cplx_unary<cf64, double>(op, x); }
+
+template <typename Z, typename R>
+__device__ __forceinline__ Z cplx_pow(Z a, Z b) {
+  if (a.re == R(0) && a.im == R(0)) {
+    if (b.re == R(0) && b.im == R(0)) return {R(1), R(0)};
+    return {R(0), R(0)};
+  }
+  const Z l = cplx_unary<Z, R>(TNH_OP_LOG, a);
+  const Z e = {b.re * l.re - b.im * l.im, b.re * l.im + b.im * l.re};
+  return cplx_unary<Z, R>(TNH_OP_EXP, e);
+}
+
+__device__ __forceinline__ float apply_binary(int op, float a, float b) {
+  switch (op) {
+    case TNH_OP_ADD: return a + b;
+    case TNH_OP_SUB: return a - b;
+    case TNH_OP_MUL: return a * b;
+    case TNH_OP_DIV: return a / b;
+    default: return m_pow(a, b);
+  }
+}
+__device__ __forceinline__ double apply_binary(int op, double a, double b) {
+  switch (op) {
+    case TNH_OP_ADD: return a + b;
+    case TNH_OP_SUB: return a - b;
+    case TNH_OP_MUL: return a * b;
+    case TNH_OP_DIV: return a / b;
+    default: return m_pow(a, b);
+  }
+}
+__device__ __forceinline__ cf32 apply_binary(int op, cf32 a, cf32 b) {
+  switch (op) {
+    case TNH_OP_ADD: return a + b;
+    case TNH_OP_SUB: return a - b;
+    case TNH_OP_MUL: return a * b;
+    case TNH_OP_DIV: return a / b;
+    default: return cplx_pow<cf32, float>(a, b);
+  }
+}
+__device__ __forceinline__ cf64 apply_binary(int op, cf64 a, cf64 b) {
+  switch (op) {
+    case TNH_OP_ADD: return a + b;
+    case TNH_OP_SUB: return a - b;
+    case TNH_OP_MUL: return a * b;
+    case TNH_OP_DIV: return a / b;
+    default: return cplx_pow<cf64, double>(a, b);
+  }
+}
+
+__device__ __forceinline__ float from_scalar(float, double re, double) { return (float)re; }
+__device__ __forceinline__ double from_scalar(double, double re, double) { return re; }
+__device__ __forceinline__ cf32 from_scalar(cf32, double re, double im) { return {(float)re, (float)im}; }
+__device__ __forceinline__ cf64 from_scalar(cf64, double re, double im) { return {re, im}; }
+
+// ---- kernels ---------------------------------------------------------------------
+template <int DT>
+__global__ __launch_bounds__(256) void unary_kernel(int op, typename Tr<DT>::S* __restrict__ dst,
+                                                    const typename Tr<DT>::S* __restrict__ src,
+                                                    int64_t n) {
+  const int64_t step = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += step)
+    Tr<DT>::st(dst, i, apply_unary(op, Tr<DT>::ld(src, i)));
+}
+
+// complex -> real outputs (abs / real / imag)
+template <int DT>
+__global__ __launch_bounds__(256) void unary_to_real_kernel(int op, typename Tr<DT>::R* __restrict__ dst,
+                                                            const typename Tr<DT>::S* __restrict__ src,
+                                                            int64_t n) {
+  using R = typename Tr<DT>::R;
+  const int64_t step = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += step) {
+    const auto z = Tr<DT>::ld(src, i);
+    R r;
+    if (op == TNH_OP_ABS) r = m_hypot(z.re, z.im);
+    else if (op == TNH_OP_REAL) r = z.re;
+    else r = z.im;
+    dst[i] = r;
+  }
+}
+
+struct BinParams {
+  int rank;
+  int64_t total;
+  int64_t shape[TNH_MAX_RANK];
+  int64_t sa[TNH_MAX_RANK];
+  int64_t sb[TNH_MAX_RANK];
+};
+
+template <int DT>
+__global__ __launch_bounds__(256) void binary_kernel(int op, typename Tr<DT>::S* __restrict__ dst,
+                                                     const typename Tr<DT>::S* __restrict__ a,
+                                                     const typename Tr<DT>::S* __restrict__ b,
+                                                     BinParams p) {
+  const int64_t step = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < p.total; i += step) {
+    int64_t rem = i, oa = 0, ob = 0;
+#pragma unroll 1
+    for (int d = p.rank - 1; d >= 0; --d) {
+      const int64_t q = rem / p.shape[d];
+      const int64_t c = rem - q * p.shape[d];
+      oa += c * p.sa[d];
+      ob += c * p.sb[d];
+      rem = q;
+    }
+    Tr<DT>::st(dst, i, apply_binary(op, Tr<DT>::ld(a, oa), Tr<DT>::ld(b, ob)));
+  }
+}
+
+// Fast path: dst[r, c] = a[r, c] (op) b[c]   or   a[r, c] (op) b[r]
+// (row / column scaling: broadcast_right / broadcast_left multiplication).
+template <int DT, bool BY_COL>
+__global__ __launch_bounds__(256) void binary_rowcol_kernel(int op, typename Tr<DT>::S* __restrict__ dst,
+                                                            const typename Tr<DT>::S* __restrict__ a,
+                                                            const typename Tr<DT>::S* __restrict__ v,
+                                                            int64_t rows, int64_t cols, int vec_left) {
+  const int64_t total = rows * cols;
+  const int64_t step = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += step) {
+    const int64_t r = i / cols;
+    const int64_t c = i - r * cols;
+    const auto x = Tr<DT>::ld(a, i);
+    const auto s = Tr<DT>::ld(v, BY_COL ? c : r);
+    Tr<DT>::st(dst, i, vec_left ? apply_binary(op, s, x) : apply_binary(op, x, s));
+  }
+}
+
+template <int DT>
+__global__ __launch_bounds__(256) void binary_scalar_kernel(int op, typename Tr<DT>::S* __restrict__ dst,
+                                                            const typename Tr<DT>::S* __restrict__ src,
+                                                            double re, double im, int left, int64_t n) {
+  using C = typename Tr<DT>::C;
+  const C s = from_scalar(C{}, re, im);
+  const int64_t step = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += step) {
+    const C x = Tr<DT>::ld(src, i);
+    Tr<DT>::st(dst, i, left ? apply_binary(op, s, x) : apply_binary(op, x, s));
+  }
+}
+
+template <int DT>
+__global__ __launch_bounds__(256) void fill_kernel(typename Tr<DT>::S* __restrict__ dst, double re,
+                                                   double im, int64_t n) {
+  using C = typename Tr<DT>::C;
+  const C s = from_scalar(C{}, re, im);
+  const int64_t step = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += step)
+    Tr<DT>::st(dst, i, s);
+}
+
+template <int DT>
+__global__ __launch_bounds__(256) void eye_kernel(typename Tr<DT>::S* __restrict__ dst, int64_t rows,
+                                                  int64_t cols) {
+  using C = typename Tr<DT>::C;
+  const int64_t n = rows * cols;
+  const int64_t step = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += step) {
+    const int64_t r = i / cols, c = i - r * cols;
+    Tr<DT>::st(dst, i, from_scalar(C{}, r == c ? 1.0 : 0.0, 0.0));
+  }
+}
+
+__device__ __forceinline__ double to_double(float x) { return (double)x; }
+__device__ __forceinline__ double to_double(double x) { return x; }
+
+template <int SRC, int DST>
+__global__ __launch_bounds__(256) void cast_kernel(typename Tr<DST>::S* __restrict__ dst,
+                                                   const typename Tr<SRC>::S* __restrict__ src,
+                                                   int64_t n) {
+  using CS = typename Tr<SRC>::C;
+  using CD = typename Tr<DST>::C;
+  constexpr bool src_cplx = (SRC == TNH_C64 || SRC == TNH_C128);
+  constexpr bool dst_cplx = (DST == TNH_C64 || DST == TNH_C128);
+  const int64_t step = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += step) {
+    const CS x = Tr<SRC>::ld(src, i);
+    double re, im;
+    if constexpr (src_cplx) { re = (double)x.re; im = (double)x.im; }
+    else { re = to_double(x); im = 0.0; }
+    CD y;
+    if constexpr (dst_cplx) y = from_scalar(CD{}, re, im);
+    else y = from_scalar(CD{}, re, 0.0);
+    Tr<DST>::st(dst, i, y);
+  }
+}
+
+static inline unsigned grid_for(int64_t n) {
+  int64_t blocks = (n + 255) / 256;
+  const int64_t cap = (int64_t)num_cus() * 16;
+  if (blocks > cap) blocks = cap;
+  if (blocks < 1) blocks = 1;
+  return (unsigned)blocks;
+}
+
+template <int SRC>
+static int cast_from(void* dst, int dst_dtype, const void* src, int64_t n) {
+  const unsigned g = grid_for(n);
+#define TNH_CAST_CASE(D)                                                                          \
+  case D:                                                                                         \
+    hipLaunchKernelGGL((cast_kernel<SRC, D>), dim3(g), dim3(256), 0, stream(),                    \
+                       (typename Tr<D>::S*)dst, (const typename Tr<SRC>::S*)src, n);              \
+    break;
+  switch (dst_dtype) {
+    TNH_CAST_CASE(TNH_F32)
+    TNH_CAST_CASE(TNH_F64)
+    TNH_CAST_CASE(TNH_BF16)
+    TNH_CAST_CASE(TNH_F16)
+    TNH_CAST_CASE(TNH_C64)
+    TNH_CAST_CASE(TNH_C128)
+    default:
+      set_error("unsupported cast target %d", dst_dtype);
+      return TNH_ERR_UNSUPPORTED;
+  }
+#undef TNH_CAST_CASE
+  TNH_LAUNCH_CHECK();
+  return TNH_OK;
+}
+
+}  // namespace tnh
+
+using namespace tnh;
+
+extern "C" {
+
+int tnh_unary(int op, void* dst, const void* src, int64_t n, int dtype) {
+  TNH_NEED_INIT();
+  TNH_REQUIRE(op >= TNH_OP_SQRT && op <= TNH_OP_IMAG, "bad unary op %d", op);
+  TNH_REQUIRE(n >= 0, "negative size");
+  if (n == 0) return TNH_OK;
+  TNH_REQUIRE(dst && src, "null pointer");
+  const unsigned g = grid_for(n);
+  const bool cplx = (dtype == TNH_C64 || dtype == TNH_C128);
+  if (cplx && (op == TNH_OP_ABS || op == TNH_OP_REAL || op == TNH_OP_IMAG)) {
+    if (dtype == TNH_C64)
+      hipLaunchKernelGGL((unary_to_real_kernel<TNH_C64>), dim3(g), dim3(256), 0, stream(), op,
+                         (float*)dst, (const cf32*)src, n);
+    else
+      hipLaunchKernelGGL((unary_to_real_kernel<TNH_C128>), dim3(g), dim3(256), 0, stream(), op,
+                         (double*)dst, (const cf64*)src, n);
+    TNH_LAUNCH_CHECK();
+    return TNH_OK;
+  }
+  TNH_DISPATCH_FLOAT(dtype, hipLaunchKernelGGL((unary_kernel<DT>), dim3(g), dim3(256), 0, stream(), op,
+                                               (typename Tr<DT>::S*)dst,
+                                               (const typename Tr<DT>::S*)src, n));
+  TNH_LAUNCH_CHECK();
+  return TNH_OK;
+}
+
+int tnh_binary(int op, void* dst, const void* a, const void* b, int rank, const int64_t* shape,
+               const int64_t* a_strides, const int64_t* b_strides, int dtype) {
+  TNH_NEED_INIT();
+  TNH_REQUIRE(op >= TNH_OP_ADD && op <= TNH_OP_POW, "bad binary op %d", op);
+  TNH_REQUIRE(rank >= 0 && rank <= TNH_MAX_RANK, "rank %d out of range", rank);
+  BinParams p;
+  p.rank = 0;
+  p.total = 1;
+  for (int d = 0; d < rank; ++d) {
+    TNH_REQUIRE(shape[d] >= 0, "negative dimension");
+    p.total *= shape[d];
+    if (shape[d] == 1) continue;
+    if (p.rank > 0 && p.sa[p.rank - 1] == a_strides[d] * shape[d] &&
+        p.sb[p.rank - 1] == b_strides[d] * shape[d]) {
+      p.shape[p.rank - 1] *= shape[d];
+      p.sa[p.rank - 1] = a_strides[d];
+      p.sb[p.rank - 1] = b_strides[d];
+    } else {
+      p.shape[p.rank] = shape[d];
+      p.sa[p.rank] = a_strides[d];
+      p.sb[p.rank] = b_strides[d];
+      ++p.rank;
+    }
+  }
+  if (p.total == 0) return TNH_OK;
+  TNH_REQUIRE(dst && a && b, "null pointer");
+  const unsigned g = grid_for(p.total);
+  // (rows, cols) op vector fast paths
+  if (p.rank == 2 && p.sa[0] == p.shape[1] && p.sa[1] == 1 && p.sb[0] == 0 && p.sb[1] == 1) {
+    TNH_DISPATCH_FLOAT(dtype, hipLaunchKernelGGL((binary_rowcol_kernel<DT, true>), dim3(g), dim3(256), 0,
+                                                 stream(), op, (typename Tr<DT>::S*)dst,
+                                                 (const typename Tr<DT>::S*)a,
+                                                 (const typename Tr<DT>::S*)b, p.shape[0], p.shape[1], 0));
+    TNH_LAUNCH_CHECK();
+    return TNH_OK;
+  }
+  if (p.rank == 2 && p.sb[0] == p.shape[1] && p.sb[1] == 1 && p.sa[0] == 1 && p.sa[1] == 0) {
+    TNH_DISPATCH_FLOAT(dtype, hipLaunchKernelGGL((binary_rowcol_kernel<DT, false>), dim3(g), dim3(256), 0,
+                                                 stream(), op, (typename Tr<DT>::S*)dst,
+                                                 (const typename Tr<DT>::S*)b,
+                                                 (const typename Tr<DT>::S*)a, p.shape[0], p.shape[1], 1));
+    TNH_LAUNCH_CHECK();
+    return TNH_OK;
+  }
+  if (p.rank == 0) {  // scalar (op) scalar
+    p.rank = 1;
+    p.shape[0] = 1;
+    p.sa[0] = 0;
+    p.sb[0] = 0;
+  }
+  TNH_DISPATCH_FLOAT(dtype, hipLaunchKernelGGL((binary_kernel<DT>), dim3(g), dim3(256), 0, stream(), op,
+                                               (typename Tr<DT>::S*)dst, (const typename Tr<DT>::S*)a,
+                                               (const typename Tr<DT>::S*)b, p));
+  TNH_LAUNCH_CHECK();
+  return TNH_OK;
+}
+
+int tnh_binary_scalar(int op, void* dst, const void* src, double re, double im, int scalar_left,
+                      int64_t n, int dtype) {
+  TNH_NEED_INIT();
+  TNH_REQUIRE(op >= TNH_OP_ADD && op <= TNH_OP_POW, "bad binary op %d", op);
+  TNH_REQUIRE(n >= 0, "negative size");
+  if (n == 0) return TNH_OK;
+  TNH_REQUIRE(dst && src, "null pointer");
+  const unsigned g = grid_for(n);
+  TNH_DISPATCH_FLOAT(dtype, hipLaunchKernelGGL((binary_scalar_kernel<DT>), dim3(g), dim3(256), 0, stream(),
+                                               op, (typename Tr<DT>::S*)dst,
+                                               (const typename Tr<DT>::S*)src, re, im, scalar_left, n));
+  TNH_LAUNCH_CHECK();
+  return TNH_OK;
+}
+
+int tnh_fill(void* dst, double re, double im, int64_t n, int dtype) {
+  TNH_NEED_INIT();
+  TNH_REQUIRE(n >= 0, "negative size");
+  if (n == 0) return TNH_OK;
+  TNH_REQUIRE(dst != nullptr, "null pointer");
+  const unsigned g = grid_for(n);
+  TNH_DISPATCH_FLOAT(dtype, hipLaunchKernelGGL((fill_kernel<DT>), dim3(g), dim3(256), 0, stream(),
+                                               (typename Tr<DT>::S*)dst, re, im, n));
+  TNH_LAUNCH_CHECK();
+  return TNH_OK;
+}
+
+int tnh_eye(void* dst, int64_t rows, int64_t cols, int dtype) {
+  TNH_NEED_INIT();
+  TNH_REQUIRE(rows >= 0 && cols >= 0, "negative size");
+  if (rows * cols == 0) return TNH_OK;
+  TNH_REQUIRE(dst != nullptr, "null pointer");
+  const unsigned g = grid_for(rows * cols);
+  TNH_DISPATCH_FLOAT(dtype, hipLaunchKernelGGL((eye_kernel<DT>), dim3(g), dim3(256), 0, stream(),
+                                               (typename Tr<DT>::S*)dst, rows, cols));
+  TNH_LAUNCH_CHECK();
+  return TNH_OK;
+}
+
+int tnh_cast(void* dst, int dst_dtype, const void* src, int src_dtype, int64_t n) {
+  TNH_NEED_INIT();
+  TNH_REQUIRE(n >= 0, "negative size");
+  if (n == 0) return TNH_OK;
+  TNH_REQUIRE(dst && src, "null pointer");
+  switch (src_dtype) {
+    case TNH_F32: return cast_from<TNH_F32>(dst, dst_dtype, src, n);
+    case TNH_F64: return cast_from<TNH_F64>(dst, dst_dtype, src, n);
+    case TNH_BF16: return cast_from<TNH_BF16>(dst, dst_dtype, src, n);
+    case TNH_F16: return cast_from<TNH_F16>(dst, dst_dtype, src, n);
+    case TNH_C64: return cast_from<TNH_C64>(dst, dst_dtype, src, n);
+    case TNH_C128: return cast_from<TNH_C128>(dst, dst_dtype, src, n);
+    default:
+      set_error("unsupported cast source %d", src_dtype);
+      return TNH_ERR_UNSUPPORTED;
+  }
+}
+
+}  // extern "C"

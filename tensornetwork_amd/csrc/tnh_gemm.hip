@@ -1,0 +1,427 @@
+// K2 (general part): strided-batched GEMM for every dtype/transpose/ragged
+// shape, plus the tnh_gemm dispatcher.
+//
+//   gemm_mfma_f32_kernel  f32 / bf16 / f16 inputs, f32 MFMA (v_mfma_f32_32x32x2_f32,
+//                         exact f32 fma chain), 128x128x16 tile, 4 waves.
+//   gemm_mfma_f64_kernel  f64, v_mfma_f64_16x16x4_f64, 64x64x16 tile.
+//   gemm_valu_kernel      any dtype incl. complex; 64x64x16 register-tiled VALU
+//                         kernel (also the on-device second opinion in tests).
+//
+// The bf16/f16 speed path (LDS-DMA staged, 16x16x32 MFMA) lives in
+// tnh_gemm_bf16.hip and is selected here when its alignment rules hold.
+//
+// Operands are addressed as A(m,k) = A[m*rsA + k*csA], B(k,n) = B[k*rsB + n*csB],
+// so the four transpose combinations are one kernel.  MFMA roofline: 2*M*N*K flop.
+#include "tnh_types.h"
+
+namespace tnh {
+
+struct GemmArgs {
+  const void* A;
+  const void* B;
+  void* C;
+  int64_t M, N, K;
+  int64_t rsA, csA, rsB, csB, ldc;
+  int64_t sA, sB, sC;
+  int out_dt;
+};
+
+// provided by tnh_gemm_bf16.hip
+int gemm_bf16_fast(int in_dt, int out_dt, int variant, int transA, int transB, int64_t M, int64_t N,
+                   int64_t K, const void* A, int64_t lda, const void* B, int64_t ldb, void* C,
+                   int64_t ldc, int64_t batch, int64_t sA, int64_t sB, int64_t sC, const char** name);
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void store_out_f32(void* C, int out_dt, int64_t idx, float v) {
+  if (out_dt == TNH_F32) ((float*)C)[idx] = v;
+  else if (out_dt == TNH_BF16) ((uint16_t*)C)[idx] = f32_to_bf16(v);
+  else ((uint16_t*)C)[idx] = f32_to_f16(v);
+}
+
+// ------------------------------------------------------------------ f32 MFMA
+template <int DT>
+__global__ __launch_bounds__(256) void gemm_mfma_f32_kernel(GemmArgs g) {
+  constexpr int BM = 128, BN = 128, BK = 16, LD = 129;
+  using S = typename Tr<DT>::S;
+  __shared__ float As[BK][LD];
+  __shared__ float Bs[BK][LD];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wid = tid >> 6;
+  const int wm = wid >> 1, wn = wid & 1;
+  const int64_t m0 = (int64_t)blockIdx.y * BM, n0 = (int64_t)blockIdx.x * BN;
+  const S* A = (const S*)g.A + (int64_t)blockIdx.z * g.sA;
+  const S* B = (const S*)g.B + (int64_t)blockIdx.z * g.sB;
+  const int64_t cbase = (int64_t)blockIdx.z * g.sC;
+
+  // thread -> (row-in-tile, k) mapping for the global loads, chosen so that
+  // consecutive lanes walk the contiguous direction of each operand.
+  const bool a_k_contig = (g.csA == 1);
+  const bool b_k_contig = (g.rsB == 1);
+  float ra[8], rb[8];
+  auto load_tile = [&](int64_t k0) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      int mm, kk;
+      if (a_k_contig) { kk = tid & 15; mm = (tid >> 4) + 16 * j; }
+      else { mm = tid & 127; kk = (tid >> 7) + 2 * j; }
+      const int64_t m = m0 + mm, k = k0 + kk;
+      ra[j] = (m < g.M && k < g.K) ? Tr<DT>::ld(A, m * g.rsA + k * g.csA) : 0.f;
+      int nn;
+      if (b_k_contig) { kk = tid & 15; nn = (tid >> 4) + 16 * j; }
+      else { nn = tid & 127; kk = (tid >> 7) + 2 * j; }
+      const int64_t n = n0 + nn;
+      const int64_t kb = k0 + kk;
+      rb[j] = (n < g.N && kb < g.K) ? Tr<DT>::ld(B, kb * g.rsB + n * g.csB) : 0.f;
+    }
+  };
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      int mm, kk;
+      if (a_k_contig) { kk = tid & 15; mm = (tid >> 4) + 16 * j; }
+      else { mm = tid & 127; kk = (tid >> 7) + 2 * j; }
+      As[kk][mm] = ra[j];
+      int nn;
+      if (b_k_contig) { kk = tid & 15; nn = (tid >> 4) + 16 * j; }
+      else { nn = tid & 127; kk = (tid >> 7) + 2 * j; }
+      Bs[kk][nn] = rb[j];
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int64_t nt = (g.K + BK - 1) / BK;
+  load_tile(0);
+  for (int64_t t = 0; t < nt; ++t) {
+    store_tile();
+    __syncthreads();
+    if (t + 1 < nt) load_tile((t + 1) * BK);
+    const int kl = lane >> 5, il = lane & 31;
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 2) {
+      const float a0 = As[kk + kl][wm * 64 + il];
+      const float a1 = As[kk + kl][wm * 64 + 32 + il];
+      const float b0 = Bs[kk + kl][wn * 64 + il];
+      const float b1 = Bs[kk + kl][wn * 64 + 32 + il];
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+
+  // C/D layout of 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int64_t n = n0 + wn * 64 + j * 32 + (lane & 31);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (m < g.M && n < g.N) store_out_f32(g.C, g.out_dt, cbase + m * g.ldc + n, acc[i][j][r]);
+      }
+    }
+}
+
+// ------------------------------------------------------------------ f64 MFMA
+__global__ __launch_bounds__(256) void gemm_mfma_f64_kernel(GemmArgs g) {
+  constexpr int BM = 64, BN = 64, BK = 16, LD = 80;
+  __shared__ double As[BK][LD];
+  __shared__ double Bs[BK][LD];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wid = tid >> 6;
+  const int wm = wid >> 1, wn = wid & 1;
+  const int64_t m0 = (int64_t)blockIdx.y * BM, n0 = (int64_t)blockIdx.x * BN;
+  const double* A = (const double*)g.A + (int64_t)blockIdx.z * g.sA;
+  const double* B = (const double*)g.B + (int64_t)blockIdx.z * g.sB;
+  double* C = (double*)g.C + (int64_t)blockIdx.z * g.sC;
+  const bool a_k_contig = (g.csA == 1);
+  const bool b_k_contig = (g.rsB == 1);
+  double ra[4], rb[4];
+  auto load_tile = [&](int64_t k0) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      int mm, kk;
+      if (a_k_contig) { kk = tid & 15; mm = (tid >> 4) + 16 * j; }
+      else { mm = tid & 63; kk = (tid >> 6) + 4 * j; }
+      const int64_t m = m0 + mm, k = k0 + kk;
+      ra[j] = (m < g.M && k < g.K) ? A[m * g.rsA + k * g.csA] : 0.0;
+      int nn;
+      if (b_k_contig) { kk = tid & 15; nn = (tid >> 4) + 16 * j; }
+      else { nn = tid & 63; kk = (tid >> 6) + 4 * j; }
+      const int64_t n = n0 + nn, kb = k0 + kk;
+      rb[j] = (n < g.N && kb < g.K) ? B[kb * g.rsB + n * g.csB] : 0.0;
+    }
+  };
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      int mm, kk;
+      if (a_k_contig) { kk = tid & 15; mm = (tid >> 4) + 16 * j; }
+      else { mm = tid & 63; kk = (tid >> 6) + 4 * j; }
+      As[kk][mm] = ra[j];
+      int nn;
+      if (b_k_contig) { kk = tid & 15; nn = (tid >> 4) + 16 * j; }
+      else { nn = tid & 63; kk = (tid >> 6) + 4 * j; }
+      Bs[kk][nn] = rb[j];
+    }
+  };
+  f64x4 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.0;
+
+  const int64_t nt = (g.K + BK - 1) / BK;
+  load_tile(0);
+  for (int64_t t = 0; t < nt; ++t) {
+    store_tile();
+    __syncthreads();
+    if (t + 1 < nt) load_tile((t + 1) * BK);
+    const int kl = lane >> 4, il = lane & 15;
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 4) {
+      const double a0 = As[kk + kl][wm * 32 + il];
+      const double a1 = As[kk + kl][wm * 32 + 16 + il];
+      const double b0 = Bs[kk + kl][wn * 32 + il];
+      const double b1 = Bs[kk + kl][wn * 32 + 16 + il];
+      acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  // f64 C/D layout: col = lane & 15, row = (lane >> 4) + 4 * r
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int64_t n = n0 + wn * 32 + j * 16 + (lane & 15);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int64_t m = m0 + wm * 32 + i * 16 + (lane >> 4) + 4 * r;
+        if (m < g.M && n < g.N) C[m * g.ldc + n] = acc[i][j][r];
+      }
+    }
+}
+
+// ---------------------------------------------------------------------- VALU
+__device__ __forceinline__ float fma_t(float a, float b, float c) { return fmaf(a, b, c); }
+__device__ __forceinline__ double fma_t(double a, double b, double c) { return fma(a, b, c); }
+__device__ __forceinline__ cf32 fma_t(cf32 a, cf32 b, cf32 c) {
+  return {fmaf(a.re, b.re, fmaf(-a.im, b.im, c.re)), fmaf(a.re, b.im, fmaf(a.im, b.re, c.im))};
+}
+__device__ __forceinline__ cf64 fma_t(cf64 a, cf64 b, cf64 c) {
+  return {fma(a.re, b.re, fma(-a.im, b.im, c.re)), fma(a.re, b.im, fma(a.im, b.re, c.im))};
+}
+
+template <int DT>
+__global__ __launch_bounds__(256) void gemm_valu_kernel(GemmArgs g) {
+  constexpr int BM = 64, BN = 64, BK = 16;
+  using S = typename Tr<DT>::S;
+  using C = typename Tr<DT>::C;
+  __shared__ C As[BK][BM + 1];
+  __shared__ C Bs[BK][BN + 1];
+  const int tid = threadIdx.x;
+  const int tx = tid & 15, ty = tid >> 4;
+  const int64_t m0 = (int64_t)blockIdx.y * BM, n0 = (int64_t)blockIdx.x * BN;
+  const S* A = (const S*)g.A + (int64_t)blockIdx.z * g.sA;
+  const S* B = (const S*)g.B + (int64_t)blockIdx.z * g.sB;
+  const int64_t cbase = (int64_t)blockIdx.z * g.sC;
+  const bool a_k_contig = (g.csA == 1);
+  const bool b_k_contig = (g.rsB == 1);
+  C acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = zero_of(C{});
+
+  for (int64_t k0 = 0; k0 < g.K; k0 += BK) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      int mm, kk;
+      if (a_k_contig) { kk = tid & 15; mm = (tid >> 4) + 16 * j; }
+      else { mm = tid & 63; kk = (tid >> 6) + 4 * j; }
+      const int64_t m = m0 + mm, k = k0 + kk;
+      As[kk][mm] = (m < g.M && k < g.K) ? Tr<DT>::ld(A, m * g.rsA + k * g.csA) : zero_of(C{});
+      int nn;
+      if (b_k_contig) { kk = tid & 15; nn = (tid >> 4) + 16 * j; }
+      else { nn = tid & 63; kk = (tid >> 6) + 4 * j; }
+      const int64_t n = n0 + nn, kb = k0 + kk;
+      Bs[kk][nn] = (n < g.N && kb < g.K) ? Tr<DT>::ld(B, kb * g.rsB + n * g.csB) : zero_of(C{});
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < BK; ++kk) {
+      C a[4], b[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a[i] = As[kk][ty + 16 * i];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) b[j] = Bs[kk][tx + 16 * j];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = fma_t(a[i], b[j], acc[i][j]);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int64_t m = m0 + ty + 16 * i, n = n0 + tx + 16 * j;
+      if (m < g.M && n < g.N) {
+        const int64_t idx = cbase + m * g.ldc + n;
+        if constexpr (DT == TNH_BF16 || DT == TNH_F16 || DT == TNH_F32)
+          store_out_f32(g.C, g.out_dt, idx, acc[i][j]);
+        else
+          Tr<DT>::st((S*)g.C, idx, acc[i][j]);
+      }
+    }
+}
+
+static thread_local const char* g_last_kernel = "none";
+static int g_variant = 0;  // 0 auto, 1 generic (mfma), 2 valu, 3 bf16_128, 4 bf16_256
+
+template <typename F>
+static int launch_batched(F launch, const GemmArgs& g0, int64_t batch, int BM, int BN) {
+  const int64_t gx = (g0.N + BN - 1) / BN, gy = (g0.M + BM - 1) / BM;
+  TNH_REQUIRE(gx < (int64_t(1) << 31) && gy < 65536, "GEMM grid too large (%lld x %lld tiles)",
+              (long long)gy, (long long)gx);
+  for (int64_t b0 = 0; b0 < batch; b0 += 65535) {
+    const int64_t nb = (batch - b0 < 65535) ? (batch - b0) : 65535;
+    const int rc = launch(g0, b0, dim3((unsigned)gx, (unsigned)gy, (unsigned)nb));
+    if (rc) return rc;
+    TNH_LAUNCH_CHECK();
+  }
+  return TNH_OK;
+}
+
+}  // namespace tnh
+
+using namespace tnh;
+
+extern "C" {
+
+const char* tnh_gemm_last_kernel(void) { return g_last_kernel; }
+
+int tnh_gemm_set_variant(const char* name) {
+  TNH_REQUIRE(name != nullptr, "null name");
+  if (!strcmp(name, "auto")) g_variant = 0;
+  else if (!strcmp(name, "generic")) g_variant = 1;
+  else if (!strcmp(name, "valu")) g_variant = 2;
+  else if (!strcmp(name, "bf16_128")) g_variant = 3;
+  else if (!strcmp(name, "bf16_256")) g_variant = 4;
+  else {
+    set_error("unknown gemm variant '%s'", name);
+    return TNH_ERR_INVALID;
+  }
+  return TNH_OK;
+}
+
+int tnh_gemm(int in_dtype, int out_dtype, int transA, int transB, int64_t M, int64_t N, int64_t K,
+             const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
+             int64_t batch, int64_t strideA, int64_t strideB, int64_t strideC) {
+  TNH_NEED_INIT();
+  TNH_REQUIRE(M >= 0 && N >= 0 && K >= 0 && batch >= 0, "negative GEMM extent");
+  TNH_REQUIRE(in_dtype >= TNH_F32 && in_dtype <= TNH_C128, "bad GEMM dtype %d", in_dtype);
+  const bool half_in = (in_dtype == TNH_BF16 || in_dtype == TNH_F16);
+  TNH_REQUIRE(out_dtype == in_dtype || (half_in && out_dtype == TNH_F32),
+              "unsupported GEMM output dtype %d for input dtype %d", out_dtype, in_dtype);
+  TNH_REQUIRE((transA == 0 || transA == 1) && (transB == 0 || transB == 1), "bad transpose flag");
+  if (M == 0 || N == 0 || batch == 0) return TNH_OK;
+  TNH_REQUIRE(C != nullptr, "null output");
+  TNH_REQUIRE(ldc >= N, "ldc (%lld) < N (%lld)", (long long)ldc, (long long)N);
+  const int esz_out = dtype_size(out_dtype);
+  if (K == 0) {
+    // empty contraction: C = 0 (numpy.tensordot over a zero-length axis)
+    for (int64_t b = 0; b < batch; ++b)
+      TNH_HIP(hipMemset2DAsync((char*)C + b * strideC * esz_out, (size_t)ldc * esz_out, 0,
+                               (size_t)N * esz_out, (size_t)M, stream()));
+    g_last_kernel = "memset";
+    return TNH_OK;
+  }
+  TNH_REQUIRE(A && B, "null operand");
+  TNH_REQUIRE(lda >= (transA ? M : K), "lda too small");
+  TNH_REQUIRE(ldb >= (transB ? K : N), "ldb too small");
+
+  if (half_in && (g_variant == 0 || g_variant >= 3)) {
+    const char* name = nullptr;
+    int rc = gemm_bf16_fast(in_dtype, out_dtype, g_variant, transA, transB, M, N, K, A, lda, B, ldb, C,
+                            ldc, batch, strideA, strideB, strideC, &name);
+    if (rc == TNH_OK) {
+      g_last_kernel = name;
+      return TNH_OK;
+    }
+    if (rc != TNH_ERR_UNSUPPORTED) return rc;
+    if (g_variant >= 3) return rc;  // forced variant cannot run this shape
+  }
+
+  GemmArgs g;
+  g.A = A; g.B = B; g.C = C;
+  g.M = M; g.N = N; g.K = K;
+  g.rsA = transA ? 1 : lda;  g.csA = transA ? lda : 1;
+  g.rsB = transB ? 1 : ldb;  g.csB = transB ? ldb : 1;
+  g.ldc = ldc;
+  g.sA = strideA; g.sB = strideB; g.sC = strideC;
+  g.out_dt = out_dtype;
+
+  const bool use_valu = (g_variant == 2) || in_dtype == TNH_C64 || in_dtype == TNH_C128;
+  const int esz_in = dtype_size(in_dtype);
+  auto shifted = [&](int64_t b0) {
+    GemmArgs h = g;
+    h.A = (const char*)g.A + b0 * strideA * esz_in;
+    h.B = (const char*)g.B + b0 * strideB * esz_in;
+    h.C = (char*)g.C + b0 * strideC * esz_out;
+    return h;
+  };
+  if (use_valu) {
+    g_last_kernel = "valu_64x64x16";
+    return launch_batched(
+        [&](const GemmArgs&, int64_t b0, dim3 grid) -> int {
+          GemmArgs h = shifted(b0);
+          TNH_DISPATCH_FLOAT(in_dtype, hipLaunchKernelGGL((gemm_valu_kernel<DT>), grid, dim3(256), 0,
+                                                          stream(), h));
+          return 0;
+        },
+        g, batch, 64, 64);
+  }
+  if (in_dtype == TNH_F64) {
+    g_last_kernel = "mfma_f64_64x64x16";
+    return launch_batched(
+        [&](const GemmArgs&, int64_t b0, dim3 grid) -> int {
+          GemmArgs h = shifted(b0);
+          hipLaunchKernelGGL(gemm_mfma_f64_kernel, grid, dim3(256), 0, stream(), h);
+          return 0;
+        },
+        g, batch, 64, 64);
+  }
+  g_last_kernel = "mfma_f32_128x128x16";
+  return launch_batched(
+      [&](const GemmArgs&, int64_t b0, dim3 grid) -> int {
+        GemmArgs h = shifted(b0);
+        if (in_dtype == TNH_F32)
+          hipLaunchKernelGGL((gemm_mfma_f32_kernel<TNH_F32>), grid, dim3(256), 0, stream(), h);
+        else if (in_dtype == TNH_BF16)
+          hipLaunchKernelGGL((gemm_mfma_f32_kernel<TNH_BF16>), grid, dim3(256), 0, stream(), h);
+        else
+          hipLaunchKernelGGL((gemm_mfma_f32_kernel<TNH_F16>), grid, dim3(256), 0, stream(), h);
+        return 0;
+      },
+      g, batch, 128, 128);
+}
+
+}  // extern "C"

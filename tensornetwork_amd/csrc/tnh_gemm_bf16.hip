@@ -1,0 +1,277 @@
+// K2 (speed path): bf16 / f16 GEMM on the gfx950 matrix cores.
+//
+//   C[M,N] = A[M,K] * B[N,K]^T   ("NT": both operands K-contiguous, which is
+//   what the transpose+reshape lowering of tensordot produces when a's
+//   contracted axes are trailing and b's are trailing; other layouts are
+//   brought here by one K1 permute on the host side).
+//
+// Structure (per workgroup, BM x BN x 64 tile, WAVES_M x WAVES_N wavefronts):
+//   * HBM -> LDS with global_load_lds_dwordx4 (16 B/lane, no VGPR round trip),
+//     two LDS stages; the load of tile t+1 is issued right after the barrier
+//     that publishes tile t, so it overlaps the MFMA work on tile t.
+//   * LDS image: rows of 64 bf16 (128 B); the eight 16-B chunks of a row are
+//     XOR-swizzled with (row & 7).  LDS-DMA writes lane-linear, so the swizzle
+//     is applied to the per-lane SOURCE chunk and again on the ds_read_b128
+//     address (same involution) -> conflict-free fragment reads.
+//   * v_mfma_f32_16x16x32_{bf16,f16}, fp32 accumulate, operands swapped
+//     (mfma(Bfrag, Afrag)) so every lane ends up with 4 consecutive n for one
+//     m: the epilogue stores 8-B (bf16/f16) or 16-B (f32) vectors.
+//   * workgroup ids are remapped XCD-aware (ids congruent mod 8 share an L2)
+//     and then grouped along M so that neighbouring tiles reuse B panels.
+//
+// MFMA roofline: 2*M*N*K flop against 2.5 PFLOP/s dense bf16.
+#include "tnh_internal.h"
+
+namespace tnh {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+struct NtArgs {
+  const uint16_t* A;
+  const uint16_t* B;
+  void* C;
+  int64_t M, N, K;
+  int64_t lda, ldb, ldc;
+  int64_t sA, sB, sC;
+  int tiles_m, tiles_n;
+};
+
+#define TNH_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+#define TNH_GLB_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
+
+// One 1-KiB LDS-DMA piece: lane l copies 16 B from its own global address to
+// LDS byte (lds_dst + 16*l); lds_dst is wave-uniform and travels in M0.
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %2\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, off\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(gsrc), "s"(lds_dst)
+      : "memory");
+}
+
+template <bool IS_BF16>
+__device__ __forceinline__ f32x4 mma16(const uint4& a, const uint4& b, f32x4 c) {
+  if constexpr (IS_BF16)
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)&a, *(const bf16x8*)&b, c, 0, 0, 0);
+  else
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(*(const f16x8*)&a, *(const f16x8*)&b, c, 0, 0, 0);
+}
+
+template <bool IS_BF16>
+__device__ __forceinline__ uint32_t pack2(float lo, float hi) {
+  if constexpr (IS_BF16) return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+  else return (uint32_t)f32_to_f16(lo) | ((uint32_t)f32_to_f16(hi) << 16);
+}
+
+// XCD-aware, M-grouped tile order.  `bid` -> (tile_m, tile_n), bijective for
+// any grid size.
+__device__ __forceinline__ void tile_of_block(int bid, int tiles_m, int tiles_n, int& tm, int& tn) {
+  const int nwg = tiles_m * tiles_n;
+  const int q = nwg >> 3, r = nwg & 7;
+  const int xcd = bid & 7, local = bid >> 3;
+  const int pid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+  constexpr int GROUP_M = 8;
+  const int per_group = GROUP_M * tiles_n;
+  const int group = pid / per_group;
+  const int first_m = group * GROUP_M;
+  const int gsize = (tiles_m - first_m < GROUP_M) ? (tiles_m - first_m) : GROUP_M;
+  const int in_group = pid - group * per_group;
+  tm = first_m + in_group % gsize;
+  tn = in_group / gsize;
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool IS_BF16, bool OUT_F32>
+__global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_kernel(NtArgs p) {
+  constexpr int BK = 64;
+  constexpr int NWAVES = WAVES_M * WAVES_N;
+  constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
+  constexpr int FM = WTM / 16, FN = WTN / 16;
+  constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2;
+  constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
+  constexpr int A_INSTR = BM / 8 / NWAVES;  // 1 KiB LDS-DMA pieces per wave per tile
+  constexpr int B_INSTR = BN / 8 / NWAVES;
+  __shared__ __attribute__((aligned(1024))) char smem[2 * STAGE_BYTES];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wid / WAVES_N, wn = wid % WAVES_N;
+
+  int tm, tn;
+  tile_of_block(blockIdx.x, p.tiles_m, p.tiles_n, tm, tn);
+  const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
+  const uint16_t* A = p.A + (int64_t)blockIdx.y * p.sA;
+  const uint16_t* B = p.B + (int64_t)blockIdx.y * p.sB;
+
+  // ---- per-lane global source pointers of the LDS-DMA pieces -----------------
+  // piece (i, wave): rows rb*8 .. rb*8+7 of the tile, rb = i*NWAVES + wid; lane l
+  // lands at LDS (row rb*8 + (l>>3), chunk l&7) and fetches global chunk
+  // (l&7) ^ (l>>3)   [row & 7 == l >> 3].
+  const int lrow = lane >> 3;
+  const int lchunk = (lane & 7) ^ lrow;
+  const uint16_t* ga[A_INSTR];
+  const uint16_t* gb[B_INSTR];
+#pragma unroll
+  for (int i = 0; i < A_INSTR; ++i) {
+    int64_t row = m0 + (i * NWAVES + wid) * 8 + lrow;
+    if (row >= p.M) row = p.M - 1;  // ragged edge: re-read the last row, never stored
+    ga[i] = A + row * p.lda + lchunk * 8;
+  }
+#pragma unroll
+  for (int i = 0; i < B_INSTR; ++i) {
+    int64_t row = n0 + (i * NWAVES + wid) * 8 + lrow;
+    if (row >= p.N) row = p.N - 1;
+    gb[i] = B + row * p.ldb + lchunk * 8;
+  }
+
+  // LDS-DMA is issued from inline asm so that hipcc's waitcnt pass does not
+  // see it: with the builtin it drains vmcnt(0) in front of the first ds_read
+  // of every tile, which serialises the prefetch behind the MFMA work.  The
+  // waits are therefore ours: s_waitcnt vmcnt(0) + barrier before a stage is read.
+  const unsigned lds0 = (unsigned)(size_t)TNH_LDS_PTR(smem);
+  auto stage = [&](int s, int64_t k0) {
+    const unsigned base = lds0 + s * STAGE_BYTES;
+#pragma unroll
+    for (int i = 0; i < A_INSTR; ++i)
+      glds16(ga[i] + k0, __builtin_amdgcn_readfirstlane(base + (i * NWAVES + wid) * 1024));
+#pragma unroll
+    for (int i = 0; i < B_INSTR; ++i)
+      glds16(gb[i] + k0, __builtin_amdgcn_readfirstlane(base + A_BYTES + (i * NWAVES + wid) * 1024));
+  };
+
+  // ---- fragment read offsets (bytes inside a tile image) ------------------------
+  // fragment row = 16*f + (l & 15): row & 7 == l & 7, so the swizzled chunk is a
+  // per-lane constant for each of the two k-steps.
+  int frag_off[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks)
+    frag_off[ks] = (lane & 15) * 128 + (((ks * 4 + (lane >> 4)) ^ (lane & 7)) * 16);
+
+  f32x4 acc[FM][FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nt = (int)(p.K / BK);
+  stage(0, 0);
+  for (int t = 0; t < nt; ++t) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();  // tile t visible to every wave; stage (t+1)&1 no longer read
+    if (t + 1 < nt) stage((t + 1) & 1, (int64_t)(t + 1) * BK);
+    const char* sa = smem + (t & 1) * STAGE_BYTES + (wm * WTM) * 128;
+    const char* sb = smem + (t & 1) * STAGE_BYTES + A_BYTES + (wn * WTN) * 128;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      uint4 af[FM], bf[FN];
+#pragma unroll
+      for (int i = 0; i < FM; ++i) af[i] = *(const uint4*)(sa + i * 2048 + frag_off[ks]);
+#pragma unroll
+      for (int j = 0; j < FN; ++j) bf[j] = *(const uint4*)(sb + j * 2048 + frag_off[ks]);
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = mma16<IS_BF16>(bf[j], af[i], acc[i][j]);
+    }
+  }
+
+  // ---- epilogue: lane holds C[m = l & 15][n = 4*(l >> 4) .. +3] of each 16x16 tile --
+  char* Cb = (char*)p.C + (int64_t)blockIdx.y * p.sC * (OUT_F32 ? 4 : 2);
+  const bool full = (m0 + BM <= p.M) && (n0 + BN <= p.N);
+#pragma unroll
+  for (int i = 0; i < FM; ++i) {
+    const int64_t m = m0 + wm * WTM + i * 16 + (lane & 15);
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+      const int64_t n = n0 + wn * WTN + j * 16 + (lane >> 4) * 4;
+      const f32x4 v = acc[i][j];
+      if (full || (m < p.M && n + 3 < p.N)) {
+        if constexpr (OUT_F32) {
+          *(float4*)(Cb + (m * p.ldc + n) * 4) = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+          uint2 o;
+          o.x = pack2<IS_BF16>(v[0], v[1]);
+          o.y = pack2<IS_BF16>(v[2], v[3]);
+          *(uint2*)(Cb + (m * p.ldc + n) * 2) = o;
+        }
+      } else if (m < p.M) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (n + r < p.N) {
+            if constexpr (OUT_F32) ((float*)Cb)[m * p.ldc + n + r] = v[r];
+            else ((uint16_t*)Cb)[m * p.ldc + n + r] = IS_BF16 ? f32_to_bf16(v[r]) : f32_to_f16(v[r]);
+          }
+        }
+      }
+    }
+  }
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N>
+static int launch_nt(bool is_bf16, bool out_f32, NtArgs p, int64_t batch) {
+  p.tiles_m = (int)((p.M + BM - 1) / BM);
+  p.tiles_n = (int)((p.N + BN - 1) / BN);
+  const int64_t nwg = (int64_t)p.tiles_m * p.tiles_n;
+  TNH_REQUIRE(nwg < (int64_t(1) << 31), "GEMM grid too large");
+  const int esz_out = out_f32 ? 4 : 2;
+  for (int64_t b0 = 0; b0 < batch; b0 += 65535) {
+    const int64_t nb = (batch - b0 < 65535) ? (batch - b0) : 65535;
+    NtArgs q = p;
+    q.A = p.A + b0 * p.sA;
+    q.B = p.B + b0 * p.sB;
+    q.C = (char*)p.C + b0 * p.sC * esz_out;
+    const dim3 grid((unsigned)nwg, (unsigned)nb), block(WAVES_M * WAVES_N * 64);
+    if (is_bf16) {
+      if (out_f32) hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, WAVES_M, WAVES_N, true, true>), grid, block, 0, stream(), q);
+      else hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, WAVES_M, WAVES_N, true, false>), grid, block, 0, stream(), q);
+    } else {
+      if (out_f32) hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, WAVES_M, WAVES_N, false, true>), grid, block, 0, stream(), q);
+      else hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, WAVES_M, WAVES_N, false, false>), grid, block, 0, stream(), q);
+    }
+    TNH_LAUNCH_CHECK();
+  }
+  return TNH_OK;
+}
+
+// Returns TNH_ERR_UNSUPPORTED (without setting an error the caller must
+// surface) when the shape/layout does not meet the speed path's rules; the
+// dispatcher then falls back to the general MFMA kernel.
+int gemm_bf16_fast(int in_dt, int out_dt, int variant, int transA, int transB, int64_t M, int64_t N,
+                   int64_t K, const void* A, int64_t lda, const void* B, int64_t ldb, void* C,
+                   int64_t ldc, int64_t batch, int64_t sA, int64_t sB, int64_t sC, const char** name) {
+  const bool ok = transA == 0 && transB == 1 && K % 64 == 0 && lda % 8 == 0 && ldb % 8 == 0 &&
+                  ldc % 4 == 0 && ((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0 &&
+                  ((uintptr_t)C % 16) == 0 && sA % 8 == 0 && sB % 8 == 0 && sC % 4 == 0 && M >= 16 &&
+                  N >= 16;
+  if (!ok) {
+    set_error("bf16 speed path needs NT layout, K%%64==0 and 16-B aligned rows");
+    return TNH_ERR_UNSUPPORTED;
+  }
+  NtArgs p;
+  p.A = (const uint16_t*)A;
+  p.B = (const uint16_t*)B;
+  p.C = C;
+  p.M = M; p.N = N; p.K = K;
+  p.lda = lda; p.ldb = ldb; p.ldc = ldc;
+  p.sA = sA; p.sB = sB; p.sC = sC;
+  const bool is_bf16 = (in_dt == TNH_BF16), out_f32 = (out_dt == TNH_F32);
+  // 256x256 tiles once there are enough of them to fill the 256 CUs.
+  bool big = (M >= 256 && N >= 256) && (((M + 255) / 256) * ((N + 255) / 256) * batch >= 192);
+  if (variant == 3) big = false;
+  if (variant == 4) big = true;
+  if (big) {
+    *name = "bf16_nt_256x256x64";
+    return launch_nt<256, 256, 2, 4>(is_bf16, out_f32, p, batch);
+  }
+  *name = "bf16_nt_128x128x64";
+  return launch_nt<128, 128, 2, 2>(is_bf16, out_f32, p, batch);
+}
+
+}  // namespace tnh

@@ -1,0 +1,351 @@
+// K1: index-permutation / strided gather-scatter kernels (HBM-bound, bit-exact).
+//
+//   tnh_permute        numpy.transpose semantics; host-side dimension merging,
+//                      then (a) memcpy, (b) row-preserving gather, or
+//                      (c) LDS-tiled 2-D transpose with the remaining dims as
+//                      batch, coalesced on both the read and the write side.
+//   tnh_strided_copy   dst contiguous <- arbitrary-strided src (slice,
+//                      diagonal, broadcast).
+//   tnh_strided_scatter  arbitrary-strided dst <- contiguous src (diagflat).
+//
+// Algorithmic HBM bytes: 2 * numel * itemsize per call.
+#include <algorithm>
+#include "tnh_internal.h"
+
+namespace tnh {
+
+struct GatherParams {
+  int rank;
+  int64_t total;
+  int64_t shape[TNH_MAX_RANK];    // output (iteration) shape, slowest first
+  int64_t stride[TNH_MAX_RANK];   // element stride on the strided side
+  int64_t offset;
+};
+
+// One element per thread-iteration; the contiguous side is indexed linearly so
+// it is always coalesced.  SCATTER=false: dst[i] = src[f(i)]; true: dst[f(i)] = src[i].
+template <typename T, typename IDX, bool SCATTER>
+__global__ __launch_bounds__(256) void gather_kernel(T* __restrict__ dst,
+                                                     const T* __restrict__ src,
+                                                     GatherParams p) {
+  const IDX total = (IDX)p.total;
+  const IDX step = (IDX)gridDim.x * blockDim.x;
+  for (IDX i = (IDX)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += step) {
+    IDX rem = i;
+    int64_t off = p.offset;
+#pragma unroll 1
+    for (int d = p.rank - 1; d >= 0; --d) {
+      const IDX s = (IDX)p.shape[d];
+      const IDX q = rem / s;
+      const IDX c = rem - q * s;
+      off += (int64_t)c * p.stride[d];
+      rem = q;
+    }
+    if (SCATTER) dst[off] = src[i];
+    else dst[i] = src[off];
+  }
+}
+
+struct TiledParams {
+  int64_t Na, Nb;          // a: fastest dim of src, b: fastest dim of dst
+  int64_t a_out_stride;    // stride of a in dst
+  int64_t b_in_stride;     // stride of b in src
+  int64_t tiles_a, tiles_b;
+  int nbatch;
+  int64_t bshape[TNH_MAX_RANK];
+  int64_t bin[TNH_MAX_RANK];
+  int64_t bout[TNH_MAX_RANK];
+};
+
+// 2-D transpose of a TILE x TILE patch through LDS (padded rows: no bank
+// conflicts on the transposed read).  Reads run along a (src-contiguous),
+// writes run along b (dst-contiguous): both sides coalesced.
+template <typename T, int TILE>
+__global__ __launch_bounds__(256) void permute_tiled_kernel(T* __restrict__ dst,
+                                                            const T* __restrict__ src,
+                                                            TiledParams p) {
+  __shared__ T tile[TILE][TILE + 1];
+  constexpr int ROWS_PER_PASS = 256 / TILE;
+  int64_t bid = blockIdx.x;
+  const int64_t ta = bid % p.tiles_a;
+  bid /= p.tiles_a;
+  const int64_t tb = bid % p.tiles_b;
+  bid /= p.tiles_b;
+  int64_t in_base = 0, out_base = 0;
+#pragma unroll 1
+  for (int d = p.nbatch - 1; d >= 0; --d) {
+    const int64_t q = bid / p.bshape[d];
+    const int64_t c = bid - q * p.bshape[d];
+    in_base += c * p.bin[d];
+    out_base += c * p.bout[d];
+    bid = q;
+  }
+  const int tx = threadIdx.x % TILE;
+  const int ty = threadIdx.x / TILE;
+  const int64_t a0 = ta * TILE, b0 = tb * TILE;
+  {
+    const int64_t a = a0 + tx;
+#pragma unroll
+    for (int k = 0; k < TILE / ROWS_PER_PASS; ++k) {
+      const int r = ty + k * ROWS_PER_PASS;
+      const int64_t b = b0 + r;
+      if (a < p.Na && b < p.Nb) tile[r][tx] = src[in_base + b * p.b_in_stride + a];
+    }
+  }
+  __syncthreads();
+  {
+    const int64_t b = b0 + tx;
+#pragma unroll
+    for (int k = 0; k < TILE / ROWS_PER_PASS; ++k) {
+      const int r = ty + k * ROWS_PER_PASS;
+      const int64_t a = a0 + r;
+      if (a < p.Na && b < p.Nb) dst[out_base + a * p.a_out_stride + b] = tile[tx][r];
+    }
+  }
+}
+
+template <typename T, bool SCATTER>
+static int launch_gather(void* dst, const void* src, const GatherParams& p) {
+  if (p.total == 0) return TNH_OK;
+  int64_t blocks = (p.total + 255) / 256;
+  const int64_t cap = (int64_t)num_cus() * 16;
+  if (blocks > cap) blocks = cap;
+  // 32-bit index math when every offset fits (the common case).
+  bool small = p.total < (int64_t(1) << 31);
+  int64_t span = p.offset;
+  for (int d = 0; d < p.rank; ++d) span += (p.shape[d] - 1) * (p.stride[d] < 0 ? -p.stride[d] : p.stride[d]);
+  if (span >= (int64_t(1) << 31)) small = false;
+  if (small)
+    hipLaunchKernelGGL((gather_kernel<T, uint32_t, SCATTER>), dim3((unsigned)blocks), dim3(256), 0,
+                       stream(), (T*)dst, (const T*)src, p);
+  else
+    hipLaunchKernelGGL((gather_kernel<T, int64_t, SCATTER>), dim3((unsigned)blocks), dim3(256), 0,
+                       stream(), (T*)dst, (const T*)src, p);
+  TNH_LAUNCH_CHECK();
+  return TNH_OK;
+}
+
+template <bool SCATTER>
+static int dispatch_gather(void* dst, const void* src, const GatherParams& p, int itemsize) {
+  switch (itemsize) {
+    case 1: return launch_gather<uint8_t, SCATTER>(dst, src, p);
+    case 2: return launch_gather<uint16_t, SCATTER>(dst, src, p);
+    case 4: return launch_gather<uint32_t, SCATTER>(dst, src, p);
+    case 8: return launch_gather<uint64_t, SCATTER>(dst, src, p);
+    case 16: return launch_gather<uint4, SCATTER>(dst, src, p);
+    default:
+      set_error("unsupported itemsize %d", itemsize);
+      return TNH_ERR_UNSUPPORTED;
+  }
+}
+
+template <typename T, int TILE>
+static int launch_tiled(void* dst, const void* src, const TiledParams& p, int64_t nblocks) {
+  hipLaunchKernelGGL((permute_tiled_kernel<T, TILE>), dim3((unsigned)nblocks), dim3(256), 0, stream(),
+                     (T*)dst, (const T*)src, p);
+  TNH_LAUNCH_CHECK();
+  return TNH_OK;
+}
+
+// Squeeze unit dims and fuse runs of output dims that are also adjacent (and
+// in order) in the input.  On return `shape`/`stride` describe the OUTPUT dims
+// (size, src element stride), slowest first.
+static int simplify(int rank, const int64_t* in_shape, const int32_t* perm, int64_t* shape,
+                    int64_t* stride) {
+  int64_t in_stride[TNH_MAX_RANK];
+  int64_t acc = 1;
+  for (int d = rank - 1; d >= 0; --d) {
+    in_stride[d] = acc;
+    acc *= in_shape[d];
+  }
+  int r = 0;
+  int prev_axis = -2;
+  for (int d = 0; d < rank; ++d) {
+    const int ax = perm[d];
+    if (in_shape[ax] == 1) continue;
+    if (r > 0 && ax == prev_axis + 1) {
+      // contiguous continuation of the previous output dim (unit dims between
+      // them were skipped, which keeps the stride relation intact).
+      shape[r - 1] *= in_shape[ax];
+      stride[r - 1] = in_stride[ax];
+    } else {
+      shape[r] = in_shape[ax];
+      stride[r] = in_stride[ax];
+      ++r;
+    }
+    prev_axis = ax;
+    // skip over unit input dims that directly follow `ax`
+    while (prev_axis + 1 < rank && in_shape[prev_axis + 1] == 1) ++prev_axis;
+  }
+  return r;
+}
+
+}  // namespace tnh
+
+using namespace tnh;
+
+extern "C" {
+
+int tnh_strided_copy(void* dst, const void* src, int rank, const int64_t* shape,
+                     const int64_t* src_strides, int64_t src_offset, int itemsize) {
+  TNH_NEED_INIT();
+  TNH_REQUIRE(rank >= 0 && rank <= TNH_MAX_RANK, "rank %d out of range", rank);
+  GatherParams p;
+  p.rank = 0;
+  p.total = 1;
+  p.offset = src_offset;
+  for (int d = 0; d < rank; ++d) {
+    TNH_REQUIRE(shape[d] >= 0, "negative dimension");
+    p.total *= shape[d];
+    if (shape[d] == 1) continue;
+    // fuse with previous dim when contiguous on the strided side too
+    if (p.rank > 0 && p.stride[p.rank - 1] == src_strides[d] * shape[d]) {
+      p.shape[p.rank - 1] *= shape[d];
+      p.stride[p.rank - 1] = src_strides[d];
+    } else {
+      p.shape[p.rank] = shape[d];
+      p.stride[p.rank] = src_strides[d];
+      ++p.rank;
+    }
+  }
+  if (p.total == 0) return TNH_OK;
+  TNH_REQUIRE(dst && src, "null pointer");
+  if (p.rank == 0 || (p.rank == 1 && p.stride[0] == 1)) {
+    TNH_HIP(hipMemcpyAsync(dst, (const char*)src + src_offset * itemsize,
+                           (size_t)p.total * itemsize, hipMemcpyDeviceToDevice, stream()));
+    return TNH_OK;
+  }
+  return dispatch_gather<false>(dst, src, p, itemsize);
+}
+
+int tnh_strided_scatter(void* dst, const void* src, int rank, const int64_t* shape,
+                        const int64_t* dst_strides, int64_t dst_offset, int itemsize) {
+  TNH_NEED_INIT();
+  TNH_REQUIRE(rank >= 0 && rank <= TNH_MAX_RANK, "rank %d out of range", rank);
+  GatherParams p;
+  p.rank = 0;
+  p.total = 1;
+  p.offset = dst_offset;
+  for (int d = 0; d < rank; ++d) {
+    TNH_REQUIRE(shape[d] >= 0, "negative dimension");
+    p.total *= shape[d];
+    if (shape[d] == 1) continue;
+    p.shape[p.rank] = shape[d];
+    p.stride[p.rank] = dst_strides[d];
+    ++p.rank;
+  }
+  if (p.total == 0) return TNH_OK;
+  TNH_REQUIRE(dst && src, "null pointer");
+  return dispatch_gather<true>(dst, src, p, itemsize);
+}
+
+int tnh_permute(void* dst, const void* src, int rank, const int64_t* shape, const int32_t* perm,
+                int itemsize) {
+  TNH_NEED_INIT();
+  TNH_REQUIRE(rank >= 0 && rank <= TNH_MAX_RANK, "rank %d out of range (max %d)", rank,
+              TNH_MAX_RANK);
+  TNH_REQUIRE(itemsize == 1 || itemsize == 2 || itemsize == 4 || itemsize == 8 || itemsize == 16,
+              "unsupported itemsize %d", itemsize);
+  int64_t total = 1;
+  {
+    bool seen[TNH_MAX_RANK] = {false};
+    for (int d = 0; d < rank; ++d) {
+      TNH_REQUIRE(perm[d] >= 0 && perm[d] < rank && !seen[perm[d]], "perm is not a permutation");
+      seen[perm[d]] = true;
+      TNH_REQUIRE(shape[d] >= 0, "negative dimension");
+      total *= shape[d];
+    }
+  }
+  if (total == 0) return TNH_OK;
+  TNH_REQUIRE(dst && src, "null pointer");
+
+  int64_t oshape[TNH_MAX_RANK], istride[TNH_MAX_RANK];
+  const int r = simplify(rank, shape, perm, oshape, istride);
+
+  // (a) identity after simplification
+  if (r <= 1) {
+    TNH_HIP(hipMemcpyAsync(dst, src, (size_t)total * itemsize, hipMemcpyDeviceToDevice, stream()));
+    return TNH_OK;
+  }
+
+  // (b) innermost dim preserved: rows stay contiguous -> widened gather.
+  if (istride[r - 1] == 1) {
+    GatherParams p;
+    p.rank = r;
+    p.offset = 0;
+    int64_t row = oshape[r - 1];
+    int wide = itemsize;
+    const uintptr_t align = (uintptr_t)dst | (uintptr_t)src;
+    while (wide < 16 && row % 2 == 0 && (align % (2 * wide)) == 0) {
+      // every other stride must stay a multiple of the widened element
+      bool ok = true;
+      for (int d = 0; d < r - 1; ++d)
+        if (istride[d] % 2 != 0) ok = false;
+      if (!ok) break;
+      for (int d = 0; d < r - 1; ++d) istride[d] /= 2;
+      row /= 2;
+      wide *= 2;
+    }
+    p.total = 1;
+    for (int d = 0; d < r; ++d) {
+      p.shape[d] = (d == r - 1) ? row : oshape[d];
+      p.stride[d] = istride[d];
+      p.total *= p.shape[d];
+    }
+    return dispatch_gather<false>(dst, src, p, wide);
+  }
+
+  // (c) the fastest src dim `a` moves: LDS-tiled transpose over (a, b).
+  int ia = -1;  // output position of the src-fastest dim
+  for (int d = 0; d < r; ++d)
+    if (istride[d] == 1) ia = d;
+  const int ib = r - 1;
+  if (ia >= 0 && oshape[ia] >= 16 && oshape[ib] >= 16) {
+    int64_t ostride[TNH_MAX_RANK];
+    int64_t acc = 1;
+    for (int d = r - 1; d >= 0; --d) {
+      ostride[d] = acc;
+      acc *= oshape[d];
+    }
+    TiledParams p;
+    p.Na = oshape[ia];
+    p.Nb = oshape[ib];
+    p.a_out_stride = ostride[ia];
+    p.b_in_stride = istride[ib];
+    const int TILE = (itemsize <= 4) ? 64 : 32;
+    p.tiles_a = (p.Na + TILE - 1) / TILE;
+    p.tiles_b = (p.Nb + TILE - 1) / TILE;
+    p.nbatch = 0;
+    int64_t nblocks = p.tiles_a * p.tiles_b;
+    for (int d = 0; d < r; ++d) {
+      if (d == ia || d == ib) continue;
+      p.bshape[p.nbatch] = oshape[d];
+      p.bin[p.nbatch] = istride[d];
+      p.bout[p.nbatch] = ostride[d];
+      ++p.nbatch;
+      nblocks *= oshape[d];
+    }
+    if (nblocks < (int64_t(1) << 31)) {
+      switch (itemsize) {
+        case 1: return launch_tiled<uint8_t, 64>(dst, src, p, nblocks);
+        case 2: return launch_tiled<uint16_t, 64>(dst, src, p, nblocks);
+        case 4: return launch_tiled<uint32_t, 64>(dst, src, p, nblocks);
+        case 8: return launch_tiled<uint64_t, 32>(dst, src, p, nblocks);
+        case 16: return launch_tiled<uint4, 32>(dst, src, p, nblocks);
+      }
+    }
+  }
+
+  // (d) general gather: coalesced writes, strided reads.
+  GatherParams p;
+  p.rank = r;
+  p.offset = 0;
+  p.total = total;
+  for (int d = 0; d < r; ++d) {
+    p.shape[d] = oshape[d];
+    p.stride[d] = istride[d];
+  }
+  return dispatch_gather<false>(dst, src, p, itemsize);
+}
+
+}  // extern "C"

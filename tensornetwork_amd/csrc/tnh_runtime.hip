@@ -1,0 +1,300 @@
+// Runtime of libtnhip.so: device selection, the in-order stream, a pooled
+// device allocator, host<->device copies, HIP events and hipGraph capture.
+// One process drives one MI355X (288 GB HBM3E); see include/tnh.h.
+#include <stdarg.h>
+#include <map>
+#include <mutex>
+#include <unordered_map>
+#include <vector>
+#include "tnh_internal.h"
+
+namespace tnh {
+
+static thread_local char g_err[1024] = "";
+static int g_device = -1;
+static hipStream_t g_stream = nullptr;
+static int g_cus = 256;
+static bool g_capturing = false;
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+hipStream_t stream() { return g_stream; }
+bool initialised() { return g_device >= 0; }
+int num_cus() { return g_cus; }
+
+// ---------------------------------------------------------------- block pool
+// Blocks are rounded to 512 B (small) or 2 MiB (>= 1 MiB) and recycled through
+// exact-size free lists.  All work runs on one in-order stream, so a block
+// handed back by tnh_free can be reused immediately: any kernel still reading
+// it was queued before the kernel that will next write it.
+struct Pool {
+  std::mutex mu;
+  std::multimap<size_t, void*> free_blocks;
+  std::unordered_map<void*, size_t> live;  // ptr -> rounded size
+  int64_t in_use = 0, cached = 0, peak = 0;
+
+  static size_t round(size_t n) {
+    if (n == 0) n = 1;
+    if (n < (1u << 20)) return (n + 511) & ~size_t(511);
+    const size_t g = size_t(2) << 20;
+    return (n + g - 1) / g * g;
+  }
+  void release_cached() {
+    for (auto& kv : free_blocks) (void)hipFree(kv.second);
+    free_blocks.clear();
+    cached = 0;
+  }
+};
+static Pool g_pool;
+
+}  // namespace tnh
+
+using namespace tnh;
+
+extern "C" {
+
+const char* tnh_last_error(void) { return g_err; }
+const char* tnh_version(void) { return "tnhip 0.1 (gfx950)"; }
+
+int tnh_device_count(int* count) {
+  TNH_REQUIRE(count != nullptr, "count is null");
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    n = 0;
+  }
+  *count = n;
+  return TNH_OK;
+}
+
+int tnh_init(int device) {
+  if (g_device == device && g_stream != nullptr) return TNH_OK;
+  TNH_REQUIRE(g_device < 0, "tnh_init(%d): already initialised on device %d",
+              device, g_device);
+  int n = 0;
+  TNH_HIP(hipGetDeviceCount(&n));
+  TNH_REQUIRE(device >= 0 && device < n, "device %d out of range (%d visible)",
+              device, n);
+  TNH_HIP(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  TNH_HIP(hipGetDeviceProperties(&prop, device));
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+    set_error("libtnhip is built for gfx950 only; device %d is %s", device,
+              prop.gcnArchName);
+    return TNH_ERR_UNSUPPORTED;
+  }
+  g_cus = prop.multiProcessorCount;
+  TNH_HIP(hipStreamCreateWithFlags(&g_stream, hipStreamDefault));
+  g_device = device;
+  return TNH_OK;
+}
+
+int tnh_shutdown(void) {
+  if (g_device < 0) return TNH_OK;
+  (void)hipStreamSynchronize(g_stream);
+  {
+    std::lock_guard<std::mutex> lk(g_pool.mu);
+    g_pool.release_cached();
+  }
+  (void)hipStreamDestroy(g_stream);
+  g_stream = nullptr;
+  g_device = -1;
+  return TNH_OK;
+}
+
+int tnh_device_info(char* name, int len, int* cus, int64_t* hbm_bytes) {
+  TNH_NEED_INIT();
+  hipDeviceProp_t prop;
+  TNH_HIP(hipGetDeviceProperties(&prop, g_device));
+  if (name && len > 0) snprintf(name, len, "%s (%s)", prop.name, prop.gcnArchName);
+  if (cus) *cus = prop.multiProcessorCount;
+  if (hbm_bytes) *hbm_bytes = (int64_t)prop.totalGlobalMem;
+  return TNH_OK;
+}
+
+int tnh_malloc(void** ptr, size_t nbytes) {
+  TNH_NEED_INIT();
+  TNH_REQUIRE(ptr != nullptr, "ptr is null");
+  const size_t sz = Pool::round(nbytes);
+  std::lock_guard<std::mutex> lk(g_pool.mu);
+  auto it = g_pool.free_blocks.find(sz);
+  void* p = nullptr;
+  if (it != g_pool.free_blocks.end()) {
+    p = it->second;
+    g_pool.free_blocks.erase(it);
+    g_pool.cached -= (int64_t)sz;
+  } else {
+    TNH_REQUIRE(!g_capturing, "pool miss (%zu B) during graph capture", sz);
+    hipError_t e = hipMalloc(&p, sz);
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      (void)hipStreamSynchronize(g_stream);
+      g_pool.release_cached();
+      e = hipMalloc(&p, sz);
+    }
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      set_error("out of device memory allocating %zu bytes (in use %lld)", sz,
+                (long long)g_pool.in_use);
+      return TNH_ERR_NOMEM;
+    }
+  }
+  g_pool.live[p] = sz;
+  g_pool.in_use += (int64_t)sz;
+  if (g_pool.in_use > g_pool.peak) g_pool.peak = g_pool.in_use;
+  *ptr = p;
+  return TNH_OK;
+}
+
+int tnh_free(void* ptr) {
+  if (ptr == nullptr) return TNH_OK;
+  if (g_device < 0) return TNH_OK;  // after shutdown: nothing to do
+  std::lock_guard<std::mutex> lk(g_pool.mu);
+  auto it = g_pool.live.find(ptr);
+  TNH_REQUIRE(it != g_pool.live.end(), "tnh_free(%p): not a live block", ptr);
+  const size_t sz = it->second;
+  g_pool.live.erase(it);
+  g_pool.in_use -= (int64_t)sz;
+  g_pool.free_blocks.emplace(sz, ptr);
+  g_pool.cached += (int64_t)sz;
+  return TNH_OK;
+}
+
+int tnh_trim(void) {
+  TNH_NEED_INIT();
+  TNH_HIP(hipStreamSynchronize(g_stream));
+  std::lock_guard<std::mutex> lk(g_pool.mu);
+  g_pool.release_cached();
+  return TNH_OK;
+}
+
+int tnh_mem_stats(int64_t* in_use, int64_t* cached, int64_t* peak) {
+  std::lock_guard<std::mutex> lk(g_pool.mu);
+  if (in_use) *in_use = g_pool.in_use;
+  if (cached) *cached = g_pool.cached;
+  if (peak) *peak = g_pool.peak;
+  return TNH_OK;
+}
+
+int tnh_h2d(void* dst, const void* host_src, size_t nbytes) {
+  TNH_NEED_INIT();
+  if (nbytes == 0) return TNH_OK;
+  TNH_REQUIRE(dst && host_src, "null pointer");
+  // Pageable source: hipMemcpyAsync stages it before returning, so the host
+  // buffer may be reused by the caller right away.
+  TNH_HIP(hipMemcpyAsync(dst, host_src, nbytes, hipMemcpyHostToDevice, g_stream));
+  TNH_HIP(hipStreamSynchronize(g_stream));
+  return TNH_OK;
+}
+
+int tnh_d2h(void* host_dst, const void* src, size_t nbytes) {
+  TNH_NEED_INIT();
+  if (nbytes == 0) return TNH_OK;
+  TNH_REQUIRE(host_dst && src, "null pointer");
+  TNH_HIP(hipMemcpyAsync(host_dst, src, nbytes, hipMemcpyDeviceToHost, g_stream));
+  TNH_HIP(hipStreamSynchronize(g_stream));
+  return TNH_OK;
+}
+
+int tnh_d2d(void* dst, const void* src, size_t nbytes) {
+  TNH_NEED_INIT();
+  if (nbytes == 0) return TNH_OK;
+  TNH_REQUIRE(dst && src, "null pointer");
+  TNH_HIP(hipMemcpyAsync(dst, src, nbytes, hipMemcpyDeviceToDevice, g_stream));
+  return TNH_OK;
+}
+
+int tnh_memset(void* dst, int byte, size_t nbytes) {
+  TNH_NEED_INIT();
+  if (nbytes == 0) return TNH_OK;
+  TNH_REQUIRE(dst != nullptr, "null pointer");
+  TNH_HIP(hipMemsetAsync(dst, byte, nbytes, g_stream));
+  return TNH_OK;
+}
+
+int tnh_sync(void) {
+  TNH_NEED_INIT();
+  TNH_HIP(hipStreamSynchronize(g_stream));
+  return TNH_OK;
+}
+
+int tnh_stream(void** s) {
+  TNH_NEED_INIT();
+  TNH_REQUIRE(s != nullptr, "null pointer");
+  *s = (void*)g_stream;
+  return TNH_OK;
+}
+
+// ----------------------------------------------------------------- events
+int tnh_event_create(void** ev) {
+  TNH_NEED_INIT();
+  TNH_REQUIRE(ev != nullptr, "null pointer");
+  hipEvent_t e;
+  TNH_HIP(hipEventCreate(&e));
+  *ev = (void*)e;
+  return TNH_OK;
+}
+int tnh_event_record(void* ev) {
+  TNH_NEED_INIT();
+  TNH_HIP(hipEventRecord((hipEvent_t)ev, g_stream));
+  return TNH_OK;
+}
+int tnh_event_sync(void* ev) {
+  TNH_NEED_INIT();
+  TNH_HIP(hipEventSynchronize((hipEvent_t)ev));
+  return TNH_OK;
+}
+int tnh_event_elapsed_ms(void* start, void* stop, float* ms) {
+  TNH_NEED_INIT();
+  TNH_REQUIRE(ms != nullptr, "null pointer");
+  TNH_HIP(hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop));
+  return TNH_OK;
+}
+int tnh_event_destroy(void* ev) {
+  if (ev == nullptr) return TNH_OK;
+  TNH_HIP(hipEventDestroy((hipEvent_t)ev));
+  return TNH_OK;
+}
+
+// ----------------------------------------------------------------- graphs
+int tnh_graph_begin(void) {
+  TNH_NEED_INIT();
+  TNH_REQUIRE(!g_capturing, "graph capture already in progress");
+  TNH_HIP(hipStreamBeginCapture(g_stream, hipStreamCaptureModeThreadLocal));
+  g_capturing = true;
+  return TNH_OK;
+}
+int tnh_graph_end(void** graph_exec) {
+  TNH_NEED_INIT();
+  TNH_REQUIRE(g_capturing, "no graph capture in progress");
+  TNH_REQUIRE(graph_exec != nullptr, "null pointer");
+  g_capturing = false;
+  hipGraph_t graph = nullptr;
+  TNH_HIP(hipStreamEndCapture(g_stream, &graph));
+  hipGraphExec_t exec = nullptr;
+  hipError_t e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(graph);
+  if (e != hipSuccess) {
+    set_error("hipGraphInstantiate failed: %s", hipGetErrorString(e));
+    return TNH_ERR_HIP;
+  }
+  *graph_exec = (void*)exec;
+  return TNH_OK;
+}
+int tnh_graph_launch(void* graph_exec) {
+  TNH_NEED_INIT();
+  TNH_HIP(hipGraphLaunch((hipGraphExec_t)graph_exec, g_stream));
+  return TNH_OK;
+}
+int tnh_graph_destroy(void* graph_exec) {
+  if (graph_exec == nullptr) return TNH_OK;
+  TNH_HIP(hipGraphExecDestroy((hipGraphExec_t)graph_exec));
+  return TNH_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,369 @@
+// K7: thin SVD by one-sided (Hestenes) Jacobi, f32 and f64.
+//
+// The row-major m x n input is orthogonalised ROW-wise on the smaller side:
+//   p = min(m, n) rows of length q = max(m, n)   (X = A if m <= n, else A^T)
+//   R X = diag(s) W,  R (p x p) = product of the plane rotations, W row-orthonormal
+//   => X = R^T diag(s) W.
+// Rotations within one round-robin round touch disjoint row pairs, so a round is
+// one launch of p/2 workgroups; a sweep is p-1 rounds.  Each workgroup streams
+// its two rows twice (Gram entries with f64 accumulation, then the rotation) and
+// the matching two rows of R.  All min(m,n) singular values come out (the
+// reference API returns the discarded ones too, decompositions.py:65); vectors
+// are emitted for the leading k only.
+//
+// This phase is not HBM-roofline work: a sweep moves ~(p-1) * 2 * (p*q + p*p)
+// elements through L2/Infinity-Cache; see DESIGN.md for the measured rates.
+#include <math.h>
+#include <algorithm>
+#include <numeric>
+#include <vector>
+#include "tnh_types.h"
+
+namespace tnh {
+
+// Work buffer layout (byte offsets, 256-B aligned pieces).
+struct SvdLayout {
+  int64_t p, q;
+  bool transposed;  // X = A^T
+  size_t off_X, off_R, off_norm, off_perm, off_flag, total;
+};
+
+static SvdLayout svd_layout(int dtype, int64_t m, int64_t n) {
+  SvdLayout L;
+  L.transposed = (m > n);
+  L.p = L.transposed ? n : m;
+  L.q = L.transposed ? m : n;
+  const size_t esz = (size_t)dtype_size(dtype);
+  auto al = [](size_t x) { return (x + 255) & ~size_t(255); };
+  size_t off = 0;
+  L.off_X = off; off += al((size_t)L.p * L.q * esz);
+  L.off_R = off; off += al((size_t)L.p * L.p * esz);
+  L.off_norm = off; off += al((size_t)L.p * sizeof(double));
+  L.off_perm = off; off += al((size_t)L.p * sizeof(int32_t));
+  L.off_flag = off; off += 256;
+  L.total = off;
+  return L;
+}
+
+// Circle-method round robin over P (even) players: pair `i` of round `r`.
+__device__ __forceinline__ void rr_pair(int64_t P, int64_t r, int64_t i, int64_t& a, int64_t& b) {
+  const int64_t Q = P - 1;
+  if (i == 0) {
+    a = Q;
+    b = r % Q;
+  } else {
+    a = (r + i) % Q;
+    b = (r - i + Q) % Q;
+  }
+  if (a > b) {
+    const int64_t t = a;
+    a = b;
+    b = t;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void jacobi_round_kernel(T* __restrict__ X, T* __restrict__ R,
+                                                           int64_t p, int64_t P, int64_t q,
+                                                           int64_t round, double tol,
+                                                           int* __restrict__ flag) {
+  int64_t a, b;
+  rr_pair(P, round, blockIdx.x, a, b);
+  if (b >= p) return;  // bye (odd p)
+  T* xa = X + a * q;
+  T* xb = X + b * q;
+  const int tid = threadIdx.x;
+  double aa = 0.0, bb = 0.0, ab = 0.0;
+  for (int64_t j = tid; j < q; j += 256) {
+    const double va = (double)xa[j], vb = (double)xb[j];
+    aa += va * va;
+    bb += vb * vb;
+    ab += va * vb;
+  }
+  __shared__ double red[4][3];
+  aa = wave_sum(aa);
+  bb = wave_sum(bb);
+  ab = wave_sum(ab);
+  if ((tid & 63) == 0) {
+    red[tid >> 6][0] = aa;
+    red[tid >> 6][1] = bb;
+    red[tid >> 6][2] = ab;
+  }
+  __syncthreads();
+  aa = red[0][0] + red[1][0] + red[2][0] + red[3][0];
+  bb = red[0][1] + red[1][1] + red[2][1] + red[3][1];
+  ab = red[0][2] + red[1][2] + red[2][2] + red[3][2];
+  if (!(fabs(ab) > tol * sqrt(aa * bb))) return;  // already orthogonal (or a zero row)
+  if (tid == 0) *flag = 1;
+  const double zeta = (bb - aa) / (2.0 * ab);
+  const double t = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+  const double cd = 1.0 / sqrt(1.0 + t * t);
+  const T c = (T)cd, s = (T)(cd * t);
+  for (int64_t j = tid; j < q; j += 256) {
+    const T va = xa[j], vb = xb[j];
+    xa[j] = c * va - s * vb;
+    xb[j] = s * va + c * vb;
+  }
+  T* ra = R + a * p;
+  T* rb = R + b * p;
+  for (int64_t j = tid; j < p; j += 256) {
+    const T va = ra[j], vb = rb[j];
+    ra[j] = c * va - s * vb;
+    rb[j] = s * va + c * vb;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void row_norm_kernel(const T* __restrict__ X, int64_t p, int64_t q,
+                                                       double* __restrict__ norms) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= p) return;
+  const T* x = X + row * q;
+  double acc = 0.0;
+  for (int64_t j = lane; j < q; j += 64) {
+    const double v = (double)x[j];
+    acc += v * v;
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) norms[row] = sqrt(acc);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void emit_s_kernel(T* __restrict__ S, const double* __restrict__ norms,
+                                                     const int32_t* __restrict__ perm, int64_t p) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < p) S[i] = (T)norms[perm[i]];
+}
+
+// out (k x len)  [TRANS=false]: out[i][j] = src[perm[i]][j] * scale_i
+// out (len x k)  [TRANS=true ]: out[j][i] = src[perm[i]][j] * scale_i
+// scale_i = 1/norm[perm[i]] when `normalize`, else 1; zero rows stay zero.
+template <typename T, bool TRANS>
+__global__ __launch_bounds__(256) void emit_rows_kernel(T* __restrict__ out, const T* __restrict__ src,
+                                                        const int32_t* __restrict__ perm,
+                                                        const double* __restrict__ norms, int64_t k,
+                                                        int64_t len, int64_t src_ld, int normalize) {
+  const int64_t total = k * len;
+  const int64_t step = (int64_t)gridDim.x * 256;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += step) {
+    int64_t i, j;
+    if (TRANS) { j = e / k; i = e - j * k; }
+    else { i = e / len; j = e - i * len; }
+    const int32_t r = perm[i];
+    double v = (double)src[(int64_t)r * src_ld + j];
+    if (normalize) {
+      const double nr = norms[r];
+      v = (nr > 0.0) ? v / nr : 0.0;
+    }
+    out[e] = (T)v;
+  }
+}
+
+template <typename T>
+static int svd_factor_t(const SvdLayout& L, int dtype, int64_t m, int64_t n, const void* A, void* S,
+                        char* work, int* sweeps_out) {
+  const int64_t p = L.p, q = L.q;
+  T* X = (T*)(work + L.off_X);
+  T* R = (T*)(work + L.off_R);
+  double* norms = (double*)(work + L.off_norm);
+  int32_t* perm = (int32_t*)(work + L.off_perm);
+  int* flag = (int*)(work + L.off_flag);
+  int rc;
+  if (L.transposed) {
+    const int64_t shape[2] = {m, n};
+    const int32_t pm[2] = {1, 0};
+    rc = tnh_permute(X, A, 2, shape, pm, (int)sizeof(T));
+  } else {
+    rc = tnh_d2d(X, A, (size_t)(p * q) * sizeof(T));
+  }
+  if (rc) return rc;
+  rc = tnh_eye(R, p, p, dtype);
+  if (rc) return rc;
+
+  const double eps = (sizeof(T) == 4) ? 5.9604644775390625e-08 : 1.1102230246251565e-16;
+  const double tol = eps * sqrt((double)q);
+  const int64_t P = (p + 1) & ~int64_t(1);
+  const int max_sweeps = 40;
+  int sweeps = 0;
+  bool converged = (p < 2);
+  while (!converged && sweeps < max_sweeps) {
+    TNH_HIP(hipMemsetAsync(flag, 0, sizeof(int), stream()));
+    for (int64_t r = 0; r < P - 1; ++r) {
+      hipLaunchKernelGGL((jacobi_round_kernel<T>), dim3((unsigned)(P / 2)), dim3(256), 0, stream(), X, R, p,
+                         P, q, r, tol, flag);
+    }
+    TNH_LAUNCH_CHECK();
+    int h = 0;
+    TNH_HIP(hipMemcpyAsync(&h, flag, sizeof(int), hipMemcpyDeviceToHost, stream()));
+    TNH_HIP(hipStreamSynchronize(stream()));
+    ++sweeps;
+    converged = (h == 0);
+  }
+  if (sweeps_out) *sweeps_out = sweeps;
+
+  hipLaunchKernelGGL((row_norm_kernel<T>), dim3((unsigned)((p + 3) / 4)), dim3(256), 0, stream(), X, p, q,
+                     norms);
+  TNH_LAUNCH_CHECK();
+  std::vector<double> hn((size_t)p);
+  TNH_HIP(hipMemcpyAsync(hn.data(), norms, (size_t)p * sizeof(double), hipMemcpyDeviceToHost, stream()));
+  TNH_HIP(hipStreamSynchronize(stream()));
+  std::vector<int32_t> hp((size_t)p);
+  std::iota(hp.begin(), hp.end(), 0);
+  std::stable_sort(hp.begin(), hp.end(), [&](int32_t x, int32_t y) { return hn[x] > hn[y]; });
+  TNH_HIP(hipMemcpyAsync(perm, hp.data(), (size_t)p * sizeof(int32_t), hipMemcpyHostToDevice, stream()));
+  TNH_HIP(hipStreamSynchronize(stream()));
+  if (p > 0) {
+    hipLaunchKernelGGL((emit_s_kernel<T>), dim3((unsigned)((p + 255) / 256)), dim3(256), 0, stream(), (T*)S,
+                       norms, perm, p);
+    TNH_LAUNCH_CHECK();
+  }
+  if (!converged) {
+    set_error("Jacobi SVD did not converge in %d sweeps (%lld x %lld)", max_sweeps, (long long)m,
+              (long long)n);
+    return TNH_ERR_NO_CONVERGE;
+  }
+  return TNH_OK;
+}
+
+// Replace zero rows of the row-orthonormal factor W (k x q, or its transpose
+// when `trans`, i.e. stored q x k) by unit vectors orthogonal to all other rows
+// so that the emitted factor is orthonormal even for rank-deficient input
+// (LAPACK's behaviour, which the reference relies on for u/vh of e.g. a zero
+// tensor).  Rare path, done on the host in f64.
+template <typename T>
+static int complete_basis(T* dW, int64_t k, int64_t q, bool trans, const std::vector<int>& zero_rows) {
+  if (zero_rows.empty()) return TNH_OK;
+  if ((int64_t)zero_rows.size() == k) {
+    // everything is zero: W = leading rows of the identity
+    if (trans) return tnh_eye(dW, q, k, sizeof(T) == 4 ? TNH_F32 : TNH_F64);
+    return tnh_eye(dW, k, q, sizeof(T) == 4 ? TNH_F32 : TNH_F64);
+  }
+  std::vector<T> h((size_t)(k * q));
+  TNH_HIP(hipMemcpyAsync(h.data(), dW, h.size() * sizeof(T), hipMemcpyDeviceToHost, stream()));
+  TNH_HIP(hipStreamSynchronize(stream()));
+  auto at = [&](int64_t i, int64_t j) -> T& { return trans ? h[(size_t)(j * k + i)] : h[(size_t)(i * q + j)]; };
+  std::vector<char> is_zero((size_t)k, 0);
+  for (int z : zero_rows) is_zero[(size_t)z] = 1;
+  std::vector<double> v((size_t)q);
+  int64_t trial = 0;
+  for (int z : zero_rows) {
+    for (;; ++trial) {
+      if (trial >= q) {
+        set_error("basis completion failed");
+        return TNH_ERR_INVALID;
+      }
+      std::fill(v.begin(), v.end(), 0.0);
+      v[(size_t)trial] = 1.0;
+      for (int pass = 0; pass < 2; ++pass)
+        for (int64_t i = 0; i < k; ++i) {
+          if (is_zero[(size_t)i]) continue;
+          double d = 0.0;
+          for (int64_t j = 0; j < q; ++j) d += v[(size_t)j] * (double)at(i, j);
+          for (int64_t j = 0; j < q; ++j) v[(size_t)j] -= d * (double)at(i, j);
+        }
+      double nr = 0.0;
+      for (int64_t j = 0; j < q; ++j) nr += v[(size_t)j] * v[(size_t)j];
+      nr = sqrt(nr);
+      if (nr > 0.5) {
+        for (int64_t j = 0; j < q; ++j) at(z, j) = (T)(v[(size_t)j] / nr);
+        is_zero[(size_t)z] = 0;
+        ++trial;
+        break;
+      }
+    }
+  }
+  TNH_HIP(hipMemcpyAsync(dW, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, stream()));
+  TNH_HIP(hipStreamSynchronize(stream()));
+  return TNH_OK;
+}
+
+template <typename T>
+static int svd_vectors_t(const SvdLayout& L, int64_t m, int64_t n, char* work, int64_t k, void* U, void* Vh) {
+  if (k == 0) return TNH_OK;
+  const int64_t p = L.p, q = L.q;
+  const T* X = (const T*)(work + L.off_X);
+  const T* R = (const T*)(work + L.off_R);
+  const double* norms = (const double*)(work + L.off_norm);
+  const int32_t* perm = (const int32_t*)(work + L.off_perm);
+  auto grid = [&](int64_t total) {
+    int64_t b = (total + 255) / 256;
+    const int64_t cap = (int64_t)num_cus() * 16;
+    return (unsigned)(b > cap ? cap : (b < 1 ? 1 : b));
+  };
+  // which of the leading k rows are exactly zero?
+  std::vector<double> hn((size_t)p);
+  std::vector<int32_t> hp((size_t)p);
+  TNH_HIP(hipMemcpyAsync(hn.data(), norms, (size_t)p * sizeof(double), hipMemcpyDeviceToHost, stream()));
+  TNH_HIP(hipMemcpyAsync(hp.data(), perm, (size_t)p * sizeof(int32_t), hipMemcpyDeviceToHost, stream()));
+  TNH_HIP(hipStreamSynchronize(stream()));
+  std::vector<int> zero_rows;
+  for (int64_t i = 0; i < k; ++i)
+    if (!(hn[(size_t)hp[(size_t)i]] > 0.0)) zero_rows.push_back((int)i);
+
+  if (!L.transposed) {
+    // A = R^T diag(s) W :  U[j][i] = R[perm i][j] (m x k),  Vh[i][:] = X[perm i][:] / s_i (k x n)
+    hipLaunchKernelGGL((emit_rows_kernel<T, true>), dim3(grid(k * p)), dim3(256), 0, stream(), (T*)U, R, perm,
+                       norms, k, p, p, 0);
+    hipLaunchKernelGGL((emit_rows_kernel<T, false>), dim3(grid(k * q)), dim3(256), 0, stream(), (T*)Vh, X, perm,
+                       norms, k, q, q, 1);
+    TNH_LAUNCH_CHECK();
+    return complete_basis<T>((T*)Vh, k, q, false, zero_rows);
+  }
+  // A^T = R^T diag(s) W  =>  A = W^T diag(s) R :
+  //   U[j][i] = X[perm i][j] / s_i (m x k),  Vh[i][:] = R[perm i][:] (k x n)
+  hipLaunchKernelGGL((emit_rows_kernel<T, true>), dim3(grid(k * q)), dim3(256), 0, stream(), (T*)U, X, perm,
+                     norms, k, q, q, 1);
+  hipLaunchKernelGGL((emit_rows_kernel<T, false>), dim3(grid(k * p)), dim3(256), 0, stream(), (T*)Vh, R, perm,
+                     norms, k, p, p, 0);
+  TNH_LAUNCH_CHECK();
+  (void)m; (void)n;
+  return complete_basis<T>((T*)U, k, q, true, zero_rows);
+}
+
+}  // namespace tnh
+
+using namespace tnh;
+
+extern "C" {
+
+int tnh_svd_work_bytes(int dtype, int64_t m, int64_t n, size_t* nbytes) {
+  TNH_REQUIRE(nbytes != nullptr, "null pointer");
+  TNH_REQUIRE(dtype == TNH_F32 || dtype == TNH_F64, "SVD supports f32/f64 (got dtype %d)", dtype);
+  TNH_REQUIRE(m >= 0 && n >= 0, "negative size");
+  *nbytes = svd_layout(dtype, m, n).total;
+  return TNH_OK;
+}
+
+int tnh_svd_factor(int dtype, int64_t m, int64_t n, const void* A, void* S, void* work, int* sweeps_out) {
+  TNH_NEED_INIT();
+  TNH_REQUIRE(dtype == TNH_F32 || dtype == TNH_F64, "SVD supports f32/f64 (got dtype %d)", dtype);
+  TNH_REQUIRE(m >= 0 && n >= 0, "negative size");
+  if (sweeps_out) *sweeps_out = 0;
+  if (m == 0 || n == 0) return TNH_OK;
+  TNH_REQUIRE(A && S && work, "null pointer");
+  TNH_REQUIRE(std::min(m, n) < (int64_t(1) << 31), "matrix too large");
+  const SvdLayout L = svd_layout(dtype, m, n);
+  if (dtype == TNH_F32) return svd_factor_t<float>(L, dtype, m, n, A, S, (char*)work, sweeps_out);
+  return svd_factor_t<double>(L, dtype, m, n, A, S, (char*)work, sweeps_out);
+}
+
+int tnh_svd_vectors(int dtype, int64_t m, int64_t n, void* work, int64_t k, void* U, void* Vh) {
+  TNH_NEED_INIT();
+  TNH_REQUIRE(dtype == TNH_F32 || dtype == TNH_F64, "SVD supports f32/f64 (got dtype %d)", dtype);
+  TNH_REQUIRE(k >= 0 && k <= std::min(m, n), "k out of range");
+  if (k == 0) return TNH_OK;
+  TNH_REQUIRE(U && Vh && work, "null pointer");
+  const SvdLayout L = svd_layout(dtype, m, n);
+  if (dtype == TNH_F32) return svd_vectors_t<float>(L, m, n, (char*)work, k, U, Vh);
+  return svd_vectors_t<double>(L, m, n, (char*)work, k, U, Vh);
+}
+
+int tnh_svd(int dtype, int64_t m, int64_t n, const void* A, void* U, void* S, void* Vh, int64_t k,
+            void* work, int* sweeps_out) {
+  int rc = tnh_svd_factor(dtype, m, n, A, S, work, sweeps_out);
+  if (rc) return rc;
+  return tnh_svd_vectors(dtype, m, n, work, k, U, Vh);
+}
+
+}  // extern "C"

@@ -1,0 +1,285 @@
+"""HBM-resident tensor type of the hip backend.
+
+The reference's callers only need ``.shape``/``.dtype`` from a backend tensor
+(``ncon_interface.py:634``, ``network_components.py:123``) and convert results
+with ``np.asarray`` in tests, so ``DeviceTensor`` is a thin handle: a ref-counted
+device block from libtnhip's pool + shape + dtype.  Tensors are always dense
+row-major; ``reshape`` shares the block, everything else produces a new one.
+"""
+import ctypes
+import numpy as np
+
+from tensornetwork_amd import _lib
+
+
+class _BFloat16Type:
+  """dtype tag for bfloat16 (NumPy has none). Host round-trips go via float32."""
+  name = "bfloat16"
+  itemsize = 2
+  kind = "f"
+
+  def __repr__(self):
+    return "bfloat16"
+
+  def __str__(self):
+    return "bfloat16"
+
+  def __eq__(self, other):
+    return other is self or (isinstance(other, str) and other in ("bfloat16", "bf16"))
+
+  def __hash__(self):
+    return hash("bfloat16")
+
+
+bfloat16 = _BFloat16Type()
+
+_NP_TO_TNH = {
+    np.dtype(np.float32): _lib.F32,
+    np.dtype(np.float64): _lib.F64,
+    np.dtype(np.float16): _lib.F16,
+    np.dtype(np.complex64): _lib.C64,
+    np.dtype(np.complex128): _lib.C128,
+    np.dtype(np.int32): _lib.I32,
+    np.dtype(np.int64): _lib.I64,
+}
+_TNH_TO_NP = {v: k for k, v in _NP_TO_TNH.items()}
+_ITEMSIZE = {_lib.F32: 4, _lib.F64: 8, _lib.BF16: 2, _lib.F16: 2, _lib.C64: 8,
+             _lib.C128: 16, _lib.I32: 4, _lib.I64: 8}
+_REAL_OF = {_lib.C64: _lib.F32, _lib.C128: _lib.F64}
+
+
+def tnh_dtype(dtype):
+  """Map a NumPy dtype / ``bfloat16`` tag / name to the tnh_dtype code."""
+  if dtype is bfloat16 or (isinstance(dtype, str) and dtype in ("bfloat16", "bf16")):
+    return _lib.BF16
+  try:
+    key = np.dtype(dtype)
+  except TypeError as exc:
+    raise TypeError(f"unsupported dtype {dtype!r} for the hip backend") from exc
+  if key not in _NP_TO_TNH:
+    raise TypeError(f"unsupported dtype {key} for the hip backend")
+  return _NP_TO_TNH[key]
+
+
+def public_dtype(code):
+  return bfloat16 if code == _lib.BF16 else _TNH_TO_NP[code]
+
+
+def f32_to_bf16_bits(x):
+  """float32 ndarray -> uint16 bf16 bit patterns, round-to-nearest-even."""
+  u = np.ascontiguousarray(x, dtype=np.float32).view(np.uint32)
+  nan = (u & np.uint32(0x7fffffff)) > np.uint32(0x7f800000)
+  r = (u + (np.uint32(0x7fff) + ((u >> np.uint32(16)) & np.uint32(1)))) >> np.uint32(16)
+  r = np.where(nan, (u >> np.uint32(16)) | np.uint32(0x40), r)
+  return r.astype(np.uint16)
+
+
+def bf16_bits_to_f32(bits):
+  return (np.ascontiguousarray(bits, dtype=np.uint16).astype(np.uint32) << np.uint32(16)).view(np.float32)
+
+
+def round_to_bf16(x):
+  """float array -> float32 array holding bf16-representable values."""
+  return bf16_bits_to_f32(f32_to_bf16_bits(np.asarray(x, dtype=np.float32)))
+
+
+class _Block:
+  """One allocation from libtnhip's pool; freed when the last tensor drops it."""
+  __slots__ = ("ptr", "nbytes")
+
+  def __init__(self, nbytes):
+    lib = _lib.lib()
+    p = ctypes.c_void_p()
+    _lib.check(lib.tnh_malloc(ctypes.byref(p), max(int(nbytes), 1)), "tnh_malloc")
+    self.ptr = p.value
+    self.nbytes = int(nbytes)
+
+  def __del__(self):
+    try:
+      if self.ptr and _lib._lib is not None:  # pylint: disable=protected-access
+        _lib._lib.tnh_free(ctypes.c_void_p(self.ptr))  # pylint: disable=protected-access
+    except Exception:  # pylint: disable=broad-except
+      pass
+    self.ptr = None
+
+
+class DeviceTensor:
+  """Dense row-major tensor in HBM."""
+  __slots__ = ("_block", "_offset", "_shape", "_code", "__weakref__")
+  __array_priority__ = 1000  # ndarray (op) DeviceTensor defers to us
+
+  def __init__(self, block, shape, code, offset=0):
+    self._block = block
+    self._offset = int(offset)
+    self._shape = tuple(int(s) for s in shape)
+    self._code = int(code)
+
+  # -- construction ----------------------------------------------------------
+  @classmethod
+  def empty(cls, shape, code):
+    shape = tuple(int(s) for s in shape)
+    if any(s < 0 for s in shape):
+      raise ValueError(f"negative dimensions are not allowed: {shape}")
+    n = int(np.prod(shape, dtype=np.int64)) if shape else 1
+    return cls(_Block(n * _ITEMSIZE[code]), shape, code)
+
+  @classmethod
+  def from_numpy(cls, array, dtype=None):
+    """H2D copy. ``dtype=bfloat16`` rounds a real array to bf16 on the host."""
+    array = np.asarray(array)
+    if dtype is not None and tnh_dtype(dtype) == _lib.BF16:
+      if array.dtype.kind not in "fiu":
+        raise TypeError(f"cannot convert {array.dtype} to bfloat16")
+      host = f32_to_bf16_bits(array.astype(np.float32))
+      code = _lib.BF16
+    else:
+      if dtype is not None:
+        array = array.astype(dtype)
+      if array.dtype == np.bool_ or array.dtype.kind in "u" or (
+          array.dtype.kind == "i" and array.dtype.itemsize < 4):
+        array = array.astype(np.int64)
+      code = tnh_dtype(array.dtype)
+      host = np.ascontiguousarray(array)
+    out = cls.empty(array.shape, code)
+    if host.size:
+      _lib.check(_lib.lib().tnh_h2d(ctypes.c_void_p(out.ptr),
+                                    host.ctypes.data_as(ctypes.c_void_p),
+                                    host.nbytes), "tnh_h2d")
+    return out
+
+  # -- metadata --------------------------------------------------------------
+  @property
+  def shape(self):
+    return self._shape
+
+  @property
+  def ndim(self):
+    return len(self._shape)
+
+  @property
+  def size(self):
+    return int(np.prod(self._shape, dtype=np.int64)) if self._shape else 1
+
+  @property
+  def dtype(self):
+    return public_dtype(self._code)
+
+  @property
+  def code(self):
+    return self._code
+
+  @property
+  def itemsize(self):
+    return _ITEMSIZE[self._code]
+
+  @property
+  def nbytes(self):
+    return self.size * self.itemsize
+
+  @property
+  def ptr(self):
+    return self._block.ptr + self._offset
+
+  @property
+  def is_complex(self):
+    return self._code in (_lib.C64, _lib.C128)
+
+  def view(self, shape):
+    """Metadata-only reshape sharing the device block."""
+    shape = tuple(int(s) for s in shape)
+    return DeviceTensor(self._block, shape, self._code, self._offset)
+
+  # -- host transfer -----------------------------------------------------------
+  def numpy(self):
+    """Blocking D2H copy. bfloat16 tensors come back as float32."""
+    if self._code == _lib.BF16:
+      host = np.empty(self._shape, dtype=np.uint16)
+    else:
+      host = np.empty(self._shape, dtype=_TNH_TO_NP[self._code])
+    if host.size:
+      _lib.check(_lib.lib().tnh_d2h(host.ctypes.data_as(ctypes.c_void_p),
+                                    ctypes.c_void_p(self.ptr), host.nbytes), "tnh_d2h")
+    if self._code == _lib.BF16:
+      return bf16_bits_to_f32(host).reshape(self._shape)
+    return host
+
+  def __array__(self, dtype=None, copy=None):  # pylint: disable=unused-argument
+    host = self.numpy()
+    return host if dtype is None else host.astype(dtype)
+
+  def item(self):
+    if self.size != 1:
+      raise ValueError("can only convert an array of size 1 to a Python scalar")
+    return self.numpy().reshape(()).item()
+
+  def __float__(self):
+    return float(self.item())
+
+  def __complex__(self):
+    return complex(self.item())
+
+  def __len__(self):
+    if not self._shape:
+      raise TypeError("len() of unsized object")
+    return self._shape[0]
+
+  def __repr__(self):
+    return f"DeviceTensor(shape={self._shape}, dtype={self.dtype}, device=hip:{_lib.current_device()})"
+
+  # -- operators: forwarded to the backend singleton ----------------------------
+  def _backend(self):
+    from tensornetwork_amd.hip_backend import get_hip_backend  # pylint: disable=import-outside-toplevel
+    return get_hip_backend()
+
+  def __add__(self, other):
+    return self._backend().addition(self, other)
+
+  def __radd__(self, other):
+    return self._backend().addition(other, self)
+
+  def __sub__(self, other):
+    return self._backend().subtraction(self, other)
+
+  def __rsub__(self, other):
+    return self._backend().subtraction(other, self)
+
+  def __mul__(self, other):
+    return self._backend().multiply(self, other)
+
+  def __rmul__(self, other):
+    return self._backend().multiply(other, self)
+
+  def __truediv__(self, other):
+    return self._backend().divide(self, other)
+
+  def __rtruediv__(self, other):
+    return self._backend().divide(other, self)
+
+  def __neg__(self):
+    return self._backend().multiply(self, -1.0)
+
+  def __pow__(self, other):
+    return self._backend().power(self, other)
+
+  def __matmul__(self, other):
+    return self._backend().matmul(self, other)
+
+  def conj(self):
+    return self._backend().conj(self)
+
+  def reshape(self, *shape):
+    if len(shape) == 1 and not np.isscalar(shape[0]):
+      shape = tuple(shape[0])
+    return self._backend().reshape(self, shape)
+
+  def transpose(self, *perm):
+    if len(perm) == 1 and not np.isscalar(perm[0]):
+      perm = perm[0]
+    return self._backend().transpose(self, perm if perm else None)
+
+  @property
+  def T(self):  # pylint: disable=invalid-name
+    return self._backend().transpose(self, None)
+
+  def __getitem__(self, key):
+    return self._backend().getitem(self, key)

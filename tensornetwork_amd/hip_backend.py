@@ -1,0 +1,753 @@
+"""``HipBackend`` -- the MI355X-native ``AbstractBackend`` for TensorNetwork.
+
+Mirrors ``tensornetwork/backends/abstract_backend.py`` (interface) and
+``backends/numpy/numpy_backend.py`` (semantics, error behaviour).  Every method
+that touches tensor data lowers to hand-written gfx950 kernels through the C ABI
+in ``include/tnh.h``; there is no NumPy/PyTorch compute path in here.  Shape
+arithmetic (``shape_*``), argument validation and the SVD truncation rule stay
+on the host, exactly as in the reference.
+"""
+import ctypes
+import io
+import numbers
+
+import numpy as np
+
+from tensornetwork_amd import _lib
+from tensornetwork_amd.abstract import BackendBase, HAVE_TENSORNETWORK
+from tensornetwork_amd.device_tensor import (DeviceTensor, bfloat16, public_dtype,
+                                             tnh_dtype)
+
+_FLOAT_CODES = (_lib.F32, _lib.F64, _lib.BF16, _lib.F16, _lib.C64, _lib.C128)
+_HALF = (_lib.BF16, _lib.F16)
+_REAL_OF = {_lib.C64: _lib.F32, _lib.C128: _lib.F64}
+# promotion lattice for mixed-dtype binary ops / contractions (numpy's rules,
+# with bf16 treated like float16: any mix with a wider float wins).
+_RANK = {_lib.BF16: 0, _lib.F16: 0, _lib.F32: 1, _lib.F64: 2, _lib.C64: 3, _lib.C128: 4}
+
+
+def _vp(t):
+  return ctypes.c_void_p(t.ptr)
+
+
+def _prod(xs):
+  out = 1
+  for x in xs:
+    out *= int(x)
+  return out
+
+
+def _promote(c1, c2):
+  if c1 == c2:
+    return c1
+  if c1 not in _RANK or c2 not in _RANK:
+    raise TypeError("integer tensors only support data-movement operations on the hip backend")
+  if {c1, c2} == {_lib.BF16, _lib.F16}:
+    return _lib.F32
+  hi = c1 if _RANK[c1] >= _RANK[c2] else c2
+  lo = c2 if hi == c1 else c1
+  if hi == _lib.C64 and lo == _lib.F64:
+    return _lib.C128
+  return hi
+
+
+def _row_major_strides(shape):
+  strides = [1] * len(shape)
+  for d in range(len(shape) - 2, -1, -1):
+    strides[d] = strides[d + 1] * int(shape[d + 1])
+  return strides
+
+
+class HipBackend(BackendBase):
+  """TensorNetwork backend running on one MI355X through libtnhip.so.
+
+  Args:
+    device: HIP device index for this process (default ``$LOCAL_RANK`` or 0).
+    half_output: dtype of bf16/f16 contraction results: ``"same"`` (default,
+      what NumPy semantics give) or ``"float32"`` (keep the fp32 accumulator).
+  """
+
+  def __init__(self, device=None, half_output="same"):
+    super().__init__()
+    self.name = "hip"
+    if half_output not in ("same", "float32"):
+      raise ValueError("half_output must be 'same' or 'float32'")
+    self.half_output = half_output
+    self._device = device
+    self._lib = None
+
+  # ------------------------------------------------------------------ plumbing
+  @property
+  def lib(self):
+    if self._lib is None:
+      self._lib = _lib.init(self._device)
+    return self._lib
+
+  def synchronize(self):
+    _lib.check(self.lib.tnh_sync(), "tnh_sync")
+
+  def _check_float(self, t, what):
+    if t.code not in _FLOAT_CODES:
+      raise NotImplementedError(f"{what} is not implemented for dtype {t.dtype} on the hip backend")
+
+  def _as_tensor(self, x):
+    if isinstance(x, DeviceTensor):
+      return x
+    return self.convert_to_tensor(x)
+
+  def cast(self, tensor, dtype):
+    """Device-side dtype conversion (bf16/f16/f32/f64, real->complex)."""
+    code = dtype if isinstance(dtype, int) else tnh_dtype(dtype)
+    if tensor.code == code:
+      return tensor
+    self._check_float(tensor, "cast")
+    out = DeviceTensor.empty(tensor.shape, code)
+    _lib.check(self.lib.tnh_cast(_vp(out), code, _vp(tensor), tensor.code, tensor.size), "tnh_cast")
+    return out
+
+  # -------------------------------------------------------------------- ingest
+  def convert_to_tensor(self, tensor):
+    # numpy_backend.py:92-97: ndarray or scalar, else TypeError.
+    if isinstance(tensor, DeviceTensor):
+      return tensor
+    if not isinstance(tensor, np.ndarray) and not np.isscalar(tensor):
+      raise TypeError("Expected a `np.array` or scalar. Got {}".format(type(tensor)))
+    self.lib  # pylint: disable=pointless-statement
+    return DeviceTensor.from_numpy(np.asarray(tensor))
+
+  def to_bfloat16(self, array):
+    """Host array -> bf16 tensor in HBM (round-to-nearest-even on the host)."""
+    self.lib  # pylint: disable=pointless-statement
+    if isinstance(array, DeviceTensor):
+      return self.cast(array, _lib.BF16)
+    return DeviceTensor.from_numpy(np.asarray(array), dtype=bfloat16)
+
+  # ------------------------------------------------------------ shape helpers
+  def shape_concat(self, values, axis):
+    return np.concatenate([np.asarray(v, dtype=np.int64).reshape(-1) for v in values], axis)
+
+  def shape_tensor(self, tensor):
+    return tensor.shape
+
+  def shape_tuple(self, tensor):
+    return tensor.shape
+
+  def sparse_shape(self, tensor):
+    return self.shape_tuple(tensor)
+
+  def shape_prod(self, values):
+    return np.prod(values)
+
+  # ------------------------------------------------------------------- layout
+  def reshape(self, tensor, shape):
+    tensor = self._as_tensor(tensor)
+    shape = [int(s) for s in np.asarray(shape).astype(np.int64).reshape(-1)]
+    neg = [i for i, s in enumerate(shape) if s == -1]
+    if len(neg) > 1:
+      raise ValueError("can only specify one unknown dimension")
+    if neg:
+      known = _prod(s for s in shape if s != -1)
+      if known == 0 or tensor.size % known:
+        raise ValueError(f"cannot reshape array of size {tensor.size} into shape {tuple(shape)}")
+      shape[neg[0]] = tensor.size // known
+    if _prod(shape) != tensor.size:
+      raise ValueError(f"cannot reshape array of size {tensor.size} into shape {tuple(shape)}")
+    return tensor.view(shape)
+
+  def transpose(self, tensor, perm=None):
+    tensor = self._as_tensor(tensor)
+    nd = tensor.ndim
+    if perm is None:
+      perm = tuple(range(nd - 1, -1, -1))
+    perm = tuple(int(p) + nd if int(p) < 0 else int(p) for p in perm)
+    if sorted(perm) != list(range(nd)):
+      raise ValueError("axes don't match array")
+    if perm == tuple(range(nd)):
+      return tensor
+    if nd > 16:
+      raise NotImplementedError("hip backend supports tensors up to rank 16")
+    out = DeviceTensor.empty([tensor.shape[p] for p in perm], tensor.code)
+    _lib.check(self.lib.tnh_permute(_vp(out), _vp(tensor), nd, _lib.i64_array(tensor.shape),
+                                    _lib.i32_array(perm), tensor.itemsize), "tnh_permute")
+    return out
+
+  def _strided_copy(self, tensor, shape, strides, offset):
+    out = DeviceTensor.empty(shape, tensor.code)
+    _lib.check(self.lib.tnh_strided_copy(_vp(out), _vp(tensor), len(shape), _lib.i64_array(shape),
+                                         _lib.i64_array(strides), int(offset), tensor.itemsize),
+               "tnh_strided_copy")
+    return out
+
+  def slice(self, tensor, start_indices, slice_sizes):
+    # numpy_backend.py:64-72
+    if len(start_indices) != len(slice_sizes):
+      raise ValueError("Lengths of start_indices and slice_sizes must be"
+                       "identical.")
+    tensor = self._as_tensor(tensor)
+    key = tuple(slice(int(s), int(s) + int(n)) for s, n in zip(start_indices, slice_sizes))
+    return self.getitem(tensor, key)
+
+  def getitem(self, tensor, key):
+    """Basic (int / slice / Ellipsis) indexing, materialised by one gather."""
+    if not isinstance(key, tuple):
+      key = (key,)
+    if any(k is Ellipsis for k in key):
+      i = [n for n, k in enumerate(key) if k is Ellipsis][0]
+      fill = tensor.ndim - (len(key) - 1)
+      key = key[:i] + (slice(None),) * fill + key[i + 1:]
+    if len(key) > tensor.ndim:
+      raise IndexError("too many indices for tensor")
+    key = key + (slice(None),) * (tensor.ndim - len(key))
+    in_strides = _row_major_strides(tensor.shape)
+    shape, strides, offset = [], [], 0
+    for dim, k, st in zip(tensor.shape, key, in_strides):
+      if isinstance(k, slice):
+        start, stop, step = k.indices(dim)
+        n = len(range(start, stop, step))
+        shape.append(n)
+        strides.append(st * step)
+        offset += start * st
+      elif isinstance(k, numbers.Integral):
+        k = int(k)
+        if k < -dim or k >= dim:
+          raise IndexError(f"index {k} is out of bounds for axis with size {dim}")
+        offset += (k % dim) * st
+      else:
+        raise NotImplementedError("hip backend supports int/slice indexing only")
+    return self._strided_copy(tensor, shape, strides, offset)
+
+  # -------------------------------------------------------------- contraction
+  def _gemm(self, a, b, trans_a, trans_b, m, n, k, lda, ldb, batch=1, stride_a=0, stride_b=0,
+            out_shape=None, out_code=None):
+    code = a.code
+    if out_code is None:
+      out_code = _lib.F32 if (code in _HALF and self.half_output == "float32") else code
+    out = DeviceTensor.empty(out_shape if out_shape is not None else (m, n), out_code)
+    _lib.check(self.lib.tnh_gemm(code, out_code, int(trans_a), int(trans_b), m, n, k, _vp(a), lda,
+                                 _vp(b), ldb, _vp(out), n, batch, stride_a, stride_b, m * n), "tnh_gemm")
+    return out
+
+  @staticmethod
+  def _normalize_axes(a, b, axes):
+    """numpy.tensordot's axes argument -> two equal-length lists of ints."""
+    try:
+      iter(axes)
+    except TypeError:
+      n = int(axes)
+      if n < 0:
+        raise ValueError("axes must be non-negative")  # pylint: disable=raise-missing-from
+      axes_a = list(range(a.ndim - n, a.ndim))
+      axes_b = list(range(0, n))
+    else:
+      axes_a, axes_b = axes
+      try:
+        axes_a = [int(x) for x in axes_a]
+      except TypeError:
+        axes_a = [int(axes_a)]
+      try:
+        axes_b = [int(x) for x in axes_b]
+      except TypeError:
+        axes_b = [int(axes_b)]
+    if len(axes_a) != len(axes_b):
+      raise ValueError("shape-mismatch for sum")
+    axes_a = [x + a.ndim if x < 0 else x for x in axes_a]
+    axes_b = [x + b.ndim if x < 0 else x for x in axes_b]
+    for x, y in zip(axes_a, axes_b):
+      if not (0 <= x < a.ndim and 0 <= y < b.ndim) or a.shape[x] != b.shape[y]:
+        raise ValueError("shape-mismatch for sum")
+    if len(set(axes_a)) != len(axes_a) or len(set(axes_b)) != len(axes_b):
+      raise ValueError("repeated axis in tensordot")
+    return axes_a, axes_b
+
+  def tensordot(self, a, b, axes):
+    """c[free_a..., free_b...] = sum_axes a*b (abstract_backend.py:27-38).
+
+    Lowered as transpose + reshape + ONE GEMM (the reference's own spec for this
+    is backends/tensorflow/tensordot2.py:22-250): an operand is used in place
+    when its contracted axes are already leading or trailing (the GEMM absorbs
+    the transpose through its row/column strides); otherwise one K1 permute
+    brings it to [free, contracted] form.  For bf16/f16 both operands are
+    brought to the K-contiguous form the MFMA speed path needs when the product
+    is large enough to pay for the extra pass.
+    """
+    a = self._as_tensor(a)
+    b = self._as_tensor(b)
+    axes_a, axes_b = self._normalize_axes(a, b, axes)
+    code = _promote(a.code, b.code)
+    a, b = self.cast(a, code), self.cast(b, code)
+    self._check_float(a, "tensordot")
+
+    free_a = [i for i in range(a.ndim) if i not in axes_a]
+    free_b = [i for i in range(b.ndim) if i not in axes_b]
+    out_shape = tuple(a.shape[i] for i in free_a) + tuple(b.shape[i] for i in free_b)
+    m = _prod(a.shape[i] for i in free_a)
+    n = _prod(b.shape[i] for i in free_b)
+    k = _prod(a.shape[i] for i in axes_a)
+    nc = len(axes_a)
+    if nc == 0:
+      return self._outer(a, b, out_shape)
+
+    # memory order of the contracted pairs on each side
+    order_a = sorted(range(nc), key=lambda i: axes_a[i])
+    order_b = sorted(range(nc), key=lambda i: axes_b[i])
+    sa, sb = sorted(axes_a), sorted(axes_b)
+    a_form = "MK" if sa == list(range(a.ndim - nc, a.ndim)) else (
+        "KM" if sa == list(range(nc)) else None)
+    b_form = "NK" if sb == list(range(b.ndim - nc, b.ndim)) else (
+        "KN" if sb == list(range(nc)) else None)
+    if a.ndim == nc:
+      a_form = "MK"  # M == 1: both readings are valid, prefer K-contiguous
+    if b.ndim == nc:
+      b_form = "NK"
+
+    half_fast = (code in _HALF and k % 64 == 0 and m >= 64 and n >= 64 and
+                 2 * m * n * k >= (1 << 27))
+    want_a = a_form if (a_form and not (half_fast and a_form != "MK")) else None
+    want_b = b_form if (b_form and not (half_fast and b_form != "NK")) else None
+
+    if want_a and want_b and order_a != order_b:
+      # contracted axes are paired in a different memory order on the two sides:
+      # re-order the smaller operand.
+      if a.size <= b.size:
+        want_a = None
+      else:
+        want_b = None
+    if want_a and not want_b:
+      pair_order = order_a
+    elif want_b and not want_a:
+      pair_order = order_b
+    else:
+      pair_order = order_a
+    if not want_a:
+      a = self.transpose(a, free_a + [axes_a[i] for i in pair_order])
+      a_form = "MK"
+    if not want_b:
+      b = self.transpose(b, free_b + [axes_b[i] for i in pair_order])
+      b_form = "NK"
+
+    trans_a = a_form == "KM"
+    trans_b = b_form == "NK"
+    lda = m if trans_a else k
+    ldb = k if trans_b else n
+    out = self._gemm(a, b, trans_a, trans_b, m, n, k, lda, ldb)
+    return out.view(out_shape)
+
+  def _outer(self, a, b, out_shape):
+    m, n = a.size, b.size
+    out = DeviceTensor.empty((m, n), a.code)
+    _lib.check(self.lib.tnh_binary(_lib.OP_MUL, _vp(out), _vp(a), _vp(b), 2, _lib.i64_array((m, n)),
+                                   _lib.i64_array((1, 0)), _lib.i64_array((0, 1)), a.code), "tnh_binary")
+    return out.view(out_shape)
+
+  def outer_product(self, tensor1, tensor2):
+    # numpy_backend.py:99-100: np.tensordot(a, b, 0)
+    return self.tensordot(tensor1, tensor2, 0)
+
+  def matmul(self, tensor1, tensor2):
+    tensor1 = self._as_tensor(tensor1)
+    tensor2 = self._as_tensor(tensor2)
+    if (tensor1.ndim <= 1) or (tensor2.ndim <= 1):
+      raise ValueError("inputs to `matmul` have to be a tensors of order > 1,")
+    code = _promote(tensor1.code, tensor2.code)
+    a, b = self.cast(tensor1, code), self.cast(tensor2, code)
+    self._check_float(a, "matmul")
+    m, k = a.shape[-2:]
+    k2, n = b.shape[-2:]
+    if k != k2:
+      raise ValueError(f"matmul: Input operand 1 has a mismatch in its core dimension 0 "
+                       f"(size {k2} is different from {k})")
+    ba, bb = a.shape[:-2], b.shape[:-2]
+    if ba == bb:
+      batch_shape, stride_a, stride_b = ba, m * k, k * n
+    elif not bb:
+      batch_shape, stride_a, stride_b = ba, m * k, 0
+    elif not ba:
+      batch_shape, stride_a, stride_b = bb, 0, k * n
+    else:
+      batch_shape = tuple(np.broadcast_shapes(ba, bb))
+      a = self._broadcast_to(a, batch_shape + (m, k))
+      b = self._broadcast_to(b, batch_shape + (k, n))
+      stride_a, stride_b = m * k, k * n
+    batch = _prod(batch_shape)
+    return self._gemm(a, b, False, False, m, n, k, k, n, batch, stride_a, stride_b,
+                      out_shape=tuple(batch_shape) + (m, n))
+
+  def _broadcast_to(self, t, shape):
+    if tuple(t.shape) == tuple(shape):
+      return t
+    pad = len(shape) - t.ndim
+    strides = [0] * pad + _row_major_strides(t.shape)
+    for d, (have, want) in enumerate(zip((1,) * pad + tuple(t.shape), shape)):
+      if have != want:
+        if have != 1:
+          raise ValueError(f"operands could not be broadcast together with shapes {t.shape} {shape}")
+        strides[d] = 0
+    return self._strided_copy(t, shape, strides, 0)
+
+  def einsum(self, expression, *tensors, optimize=True):  # pylint: disable=unused-argument
+    """einsum through the backend's own pairwise contraction (no NumPy compute)."""
+    from tensornetwork_amd.ncon import einsum as _einsum  # pylint: disable=import-outside-toplevel
+    return _einsum(expression, *[self._as_tensor(t) for t in tensors], backend=self)
+
+  # --------------------------------------------------------------- reductions
+  def trace(self, tensor, offset=0, axis1=-2, axis2=-1):
+    tensor = self._as_tensor(tensor)
+    self._check_float(tensor, "trace")
+    nd = tensor.ndim
+    if nd < 2:
+      raise ValueError("diag requires an array of at least two dimensions")
+    ax1, ax2 = axis1 % nd, axis2 % nd
+    if ax1 == ax2:
+      raise ValueError("axis1 and axis2 cannot be the same")
+    rest = [i for i in range(nd) if i not in (ax1, ax2)]
+    t = self.transpose(tensor, rest + [ax1, ax2])
+    outer = _prod(t.shape[:-2])
+    out = DeviceTensor.empty(t.shape[:-2], t.code)
+    _lib.check(self.lib.tnh_trace_last2(_vp(out), _vp(t), outer, t.shape[-2], t.shape[-1],
+                                        int(offset), t.code), "tnh_trace_last2")
+    return out
+
+  def sum(self, tensor, axis=None, keepdims=False):
+    tensor = self._as_tensor(tensor)
+    self._check_float(tensor, "sum")
+    nd = tensor.ndim
+    if axis is None:
+      axes = list(range(nd))
+    else:
+      if isinstance(axis, numbers.Integral):
+        axis = (axis,)
+      axes = sorted({int(x) % nd if nd else int(x) for x in tuple(axis)})
+    kept = [i for i in range(nd) if i not in axes]
+    final_shape = tuple(1 if i in axes else tensor.shape[i] for i in range(nd)) if keepdims else \
+        tuple(tensor.shape[i] for i in kept)
+    if not axes:
+      return tensor.view(final_shape)
+    contiguous_run = axes == list(range(axes[0], axes[-1] + 1))
+    if contiguous_run:
+      outer = _prod(tensor.shape[:axes[0]])
+      red = _prod(tensor.shape[axes[0]:axes[-1] + 1])
+      inner = _prod(tensor.shape[axes[-1] + 1:])
+      src = tensor
+    else:
+      src = self.transpose(tensor, kept + axes)
+      outer = _prod(tensor.shape[i] for i in kept)
+      red = _prod(tensor.shape[i] for i in axes)
+      inner = 1
+    out = DeviceTensor.empty(final_shape, tensor.code)
+    _lib.check(self.lib.tnh_sum_mid(_vp(out), _vp(src), outer, red, inner, tensor.code), "tnh_sum_mid")
+    return out
+
+  def norm(self, tensor):
+    tensor = self._as_tensor(tensor)
+    self._check_float(tensor, "norm")
+    out = DeviceTensor.empty((), tensor.code)
+    _lib.check(self.lib.tnh_norm(_vp(out), _vp(tensor), tensor.size, tensor.code), "tnh_norm")
+    if tensor.is_complex:
+      return self._unary(_lib.OP_REAL, out)
+    return out
+
+  # --------------------------------------------------------------- elementwise
+  def _unary(self, op, tensor):
+    tensor = self._as_tensor(tensor)
+    self._check_float(tensor, "elementwise math")
+    to_real = tensor.is_complex and op in (_lib.OP_ABS, _lib.OP_REAL, _lib.OP_IMAG)
+    out = DeviceTensor.empty(tensor.shape, _REAL_OF[tensor.code] if to_real else tensor.code)
+    _lib.check(self.lib.tnh_unary(op, _vp(out), _vp(tensor), tensor.size, tensor.code), "tnh_unary")
+    return out
+
+  def sqrt(self, tensor):
+    return self._unary(_lib.OP_SQRT, tensor)
+
+  def conj(self, tensor):
+    tensor = self._as_tensor(tensor)
+    if not tensor.is_complex:
+      return tensor
+    return self._unary(_lib.OP_CONJ, tensor)
+
+  def abs(self, tensor):
+    return self._unary(_lib.OP_ABS, tensor)
+
+  def sign(self, tensor):
+    return self._unary(_lib.OP_SIGN, tensor)
+
+  def exp(self, tensor):
+    return self._unary(_lib.OP_EXP, tensor)
+
+  def log(self, tensor):
+    return self._unary(_lib.OP_LOG, tensor)
+
+  def sin(self, tensor):
+    return self._unary(_lib.OP_SIN, tensor)
+
+  def cos(self, tensor):
+    return self._unary(_lib.OP_COS, tensor)
+
+  @staticmethod
+  def _is_scalar(x):
+    return isinstance(x, numbers.Number) or (isinstance(x, np.ndarray) and x.ndim == 0) or \
+        isinstance(x, np.generic)
+
+  def _binary(self, op, x, y):
+    xs, ys = self._is_scalar(x), self._is_scalar(y)
+    if xs and ys:
+      raise TypeError("at least one operand must be a tensor")
+    if xs or ys:
+      t = self._as_tensor(y if xs else x)
+      s = complex(x if xs else y)
+      self._check_float(t, "arithmetic")
+      code = t.code
+      if s.imag != 0.0 and not t.is_complex:
+        code = _lib.C128 if t.code == _lib.F64 else _lib.C64
+        t = self.cast(t, code)
+      out = DeviceTensor.empty(t.shape, code)
+      _lib.check(self.lib.tnh_binary_scalar(op, _vp(out), _vp(t), s.real, s.imag, 1 if xs else 0,
+                                            t.size, code), "tnh_binary_scalar")
+      return out
+    a, b = self._as_tensor(x), self._as_tensor(y)
+    code = _promote(a.code, b.code)
+    a, b = self.cast(a, code), self.cast(b, code)
+    self._check_float(a, "arithmetic")
+    try:
+      shape = tuple(np.broadcast_shapes(a.shape, b.shape))
+    except ValueError as exc:
+      raise ValueError(f"operands could not be broadcast together with shapes "
+                       f"{a.shape} {b.shape}") from exc
+    if len(shape) > 16:
+      raise NotImplementedError("hip backend supports tensors up to rank 16")
+
+    def bstrides(t):
+      pad = len(shape) - t.ndim
+      st = [0] * pad + _row_major_strides(t.shape)
+      dims = (1,) * pad + tuple(t.shape)
+      return [0 if dims[d] == 1 and shape[d] != 1 else st[d] for d in range(len(shape))]
+
+    out = DeviceTensor.empty(shape, code)
+    _lib.check(self.lib.tnh_binary(op, _vp(out), _vp(a), _vp(b), len(shape), _lib.i64_array(shape),
+                                   _lib.i64_array(bstrides(a)), _lib.i64_array(bstrides(b)), code),
+               "tnh_binary")
+    return out
+
+  def addition(self, tensor1, tensor2):
+    return self._binary(_lib.OP_ADD, tensor1, tensor2)
+
+  def subtraction(self, tensor1, tensor2):
+    return self._binary(_lib.OP_SUB, tensor1, tensor2)
+
+  def multiply(self, tensor1, tensor2):
+    return self._binary(_lib.OP_MUL, tensor1, tensor2)
+
+  def divide(self, tensor1, tensor2):
+    return self._binary(_lib.OP_DIV, tensor1, tensor2)
+
+  def power(self, a, b):
+    return self._binary(_lib.OP_POW, a, b)
+
+  def broadcast_right_multiplication(self, tensor1, tensor2):
+    tensor2 = self._as_tensor(tensor2)
+    if len(tensor2.shape) != 1:
+      raise ValueError("only order-1 tensors are allowed for `tensor2`,"
+                       " found `tensor2.shape = {}`".format(tensor2.shape))
+    return self._binary(_lib.OP_MUL, tensor1, tensor2)
+
+  def broadcast_left_multiplication(self, tensor1, tensor2):
+    tensor1 = self._as_tensor(tensor1)
+    tensor2 = self._as_tensor(tensor2)
+    if len(tensor1.shape) != 1:
+      raise ValueError("only order-1 tensors are allowed for `tensor1`,"
+                       " found `tensor1.shape = {}`".format(tensor1.shape))
+    t1_broadcast_shape = self.shape_concat(
+        [self.shape_tensor(tensor1), [1] * (len(tensor2.shape) - 1)], axis=-1)
+    return self._binary(_lib.OP_MUL, tensor2, self.reshape(tensor1, t1_broadcast_shape))
+
+  # ------------------------------------------------------------ initialisation
+  def _fill(self, shape, dtype, re, im=0.0):
+    dtype = dtype if dtype is not None else np.float64
+    code = tnh_dtype(dtype)
+    if code not in _FLOAT_CODES:
+      return DeviceTensor.from_numpy(np.full(shape, re, dtype=dtype))
+    self.lib  # pylint: disable=pointless-statement
+    out = DeviceTensor.empty(shape, code)
+    _lib.check(self.lib.tnh_fill(_vp(out), float(re), float(im), out.size, code), "tnh_fill")
+    return out
+
+  def ones(self, shape, dtype=None):
+    return self._fill(tuple(shape), dtype, 1.0)
+
+  def zeros(self, shape, dtype=None):
+    return self._fill(tuple(shape), dtype, 0.0)
+
+  def eye(self, N, dtype=None, M=None):
+    dtype = dtype if dtype is not None else np.float64
+    code = tnh_dtype(dtype)
+    self.lib  # pylint: disable=pointless-statement
+    cols = int(N) if M is None else int(M)
+    out = DeviceTensor.empty((int(N), cols), code)
+    _lib.check(self.lib.tnh_eye(_vp(out), int(N), cols, code), "tnh_eye")
+    return out
+
+  def randn(self, shape, dtype=None, seed=None):
+    # Same host generator and call order as numpy_backend.py:137-149, so that a
+    # seeded network is bit-identical to the NumPy backend's before upload.
+    if seed:
+      np.random.seed(seed)
+    dtype = dtype if dtype is not None else np.float64
+    if dtype is bfloat16:
+      return self.to_bfloat16(np.random.randn(*shape).astype(np.float32))
+    if np.dtype(dtype) in (np.dtype(np.complex128), np.dtype(np.complex64)):
+      host = np.random.randn(*shape).astype(dtype) + 1j * np.random.randn(*shape).astype(dtype)
+    else:
+      host = np.random.randn(*shape).astype(dtype)
+    return self.convert_to_tensor(np.asarray(host))
+
+  def random_uniform(self, shape, boundaries=(0.0, 1.0), dtype=None, seed=None):
+    if seed:
+      np.random.seed(seed)
+    dtype = dtype if dtype is not None else np.float64
+    lo, hi = boundaries
+    if dtype is bfloat16:
+      return self.to_bfloat16(np.random.uniform(lo, hi, shape).astype(np.float32))
+    if np.dtype(dtype) in (np.dtype(np.complex128), np.dtype(np.complex64)):
+      host = np.random.uniform(lo, hi, shape).astype(dtype) + \
+          1j * np.random.uniform(lo, hi, shape).astype(dtype)
+    else:
+      host = np.random.uniform(lo, hi, shape).astype(dtype)
+    return self.convert_to_tensor(np.asarray(host))
+
+  # ------------------------------------------------------------ diag helpers
+  def diagflat(self, tensor, k=0):
+    tensor = self._as_tensor(tensor)
+    n = tensor.size
+    side = n + abs(int(k))
+    out = DeviceTensor.empty((side, side), tensor.code)
+    _lib.check(self.lib.tnh_memset(_vp(out), 0, out.nbytes), "tnh_memset")
+    offset = int(k) if k >= 0 else -int(k) * side
+    _lib.check(self.lib.tnh_strided_scatter(_vp(out), _vp(tensor), 1, _lib.i64_array((n,)),
+                                            _lib.i64_array((side + 1,)), offset, tensor.itemsize),
+               "tnh_strided_scatter")
+    return out
+
+  def diagonal(self, tensor, offset=0, axis1=-2, axis2=-1):
+    tensor = self._as_tensor(tensor)
+    nd = tensor.ndim
+    if nd < 2:
+      raise ValueError("diag requires an array of at least two dimensions")
+    ax1, ax2 = axis1 % nd, axis2 % nd
+    if ax1 == ax2:
+      raise ValueError("axis1 and axis2 cannot be the same")
+    st = _row_major_strides(tensor.shape)
+    n, m = tensor.shape[ax1], tensor.shape[ax2]
+    if offset >= 0:
+      length, start = max(min(n, m - offset), 0), offset * st[ax2]
+    else:
+      length, start = max(min(n + offset, m), 0), -offset * st[ax1]
+    rest = [i for i in range(nd) if i not in (ax1, ax2)]
+    shape = [tensor.shape[i] for i in rest] + [length]
+    strides = [st[i] for i in rest] + [st[ax1] + st[ax2]]
+    return self._strided_copy(tensor, shape, strides, start if length else 0)
+
+  # ------------------------------------------------------------ decompositions
+  def svd(self, tensor, pivot_axis=-1, max_singular_values=None, max_truncation_error=None,
+          relative=False):
+    """Truncated SVD (abstract_backend.py:79-137; rule of decompositions.py:21-74).
+
+    The Jacobi factorisation runs on the GPU and returns ALL singular values;
+    the keep/discard decision below restates decompositions.py:38-57 on the
+    host; only the kept vectors are then emitted by the GPU.
+    """
+    tensor = self._as_tensor(tensor)
+    self._check_float(tensor, "svd")
+    if tensor.is_complex:
+      raise NotImplementedError("complex SVD is not implemented on the hip backend yet")
+    left_dims = tensor.shape[:pivot_axis]
+    right_dims = tensor.shape[pivot_axis:]
+    m, n = _prod(left_dims), _prod(right_dims)
+    orig_code = tensor.code
+    work_code = tensor.code if tensor.code in (_lib.F32, _lib.F64) else _lib.F32
+    mat = self.cast(tensor, work_code).view((m, n))
+    r = min(m, n)
+
+    nbytes = ctypes.c_size_t(0)
+    _lib.check(self.lib.tnh_svd_work_bytes(work_code, m, n, ctypes.byref(nbytes)), "tnh_svd_work_bytes")
+    work = DeviceTensor.empty((max(nbytes.value, 8) // 8 + 1,), _lib.F64)
+    s_all = DeviceTensor.empty((r,), work_code)
+    sweeps = ctypes.c_int(0)
+    _lib.check(self.lib.tnh_svd_factor(work_code, m, n, _vp(mat), _vp(s_all), _vp(work),
+                                       ctypes.byref(sweeps)), "tnh_svd_factor")
+    self.last_svd_sweeps = sweeps.value
+
+    if max_singular_values is None:
+      max_singular_values = r
+    if max_truncation_error is not None:
+      s_host = s_all.numpy().astype(np.float64)
+      # cumulative norms of the singular values in ascending order
+      trunc_errs = np.sqrt(np.cumsum(np.square(s_host[::-1])))
+      abs_err = max_truncation_error * (s_host[0] if r else 0.0) if relative else max_truncation_error
+      num_sing_vals_err = int(np.count_nonzero(trunc_errs > abs_err))
+    else:
+      num_sing_vals_err = max_singular_values
+    keep = int(min(max_singular_values, num_sing_vals_err, r))
+    keep = max(keep, 0)
+
+    u = DeviceTensor.empty((m, keep), work_code)
+    vh = DeviceTensor.empty((keep, n), work_code)
+    _lib.check(self.lib.tnh_svd_vectors(work_code, m, n, _vp(work), keep, _vp(u), _vp(vh)),
+               "tnh_svd_vectors")
+    s = self.getitem(s_all, slice(0, keep))
+    s_rest = self.getitem(s_all, slice(keep, r))
+    if orig_code != work_code:
+      u, vh = self.cast(u, orig_code), self.cast(vh, orig_code)
+      s, s_rest = self.cast(s, orig_code), self.cast(s_rest, orig_code)
+    u = u.view(tuple(left_dims) + (keep,))
+    vh = vh.view((keep,) + tuple(right_dims))
+    return u, s, vh, s_rest
+
+  # ------------------------------------------------------------------- misc
+  def jit(self, fun, *args, **kwargs):  # pylint: disable=unused-argument
+    return fun
+
+  def item(self, tensor):
+    return self._as_tensor(tensor).item()
+
+  def eps(self, dtype):
+    if dtype is bfloat16:
+      return 2.0**-7
+    return np.finfo(dtype).eps
+
+  def serialize_tensor(self, tensor):
+    # wire format of numpy_backend.py:732-744 (np.save bytes as latin-1 str)
+    m = io.BytesIO()
+    np.save(m, self._as_tensor(tensor).numpy(), allow_pickle=False)
+    m.seek(0)
+    return str(m.read(), encoding='latin-1')
+
+  def deserialize_tensor(self, s):
+    m = io.BytesIO()
+    m.write(s.encode('latin-1'))
+    m.seek(0)
+    return self.convert_to_tensor(np.load(m))
+
+
+_BACKEND = None
+
+
+def get_hip_backend():
+  """Process-wide singleton (backends are singletons per name, factory:42-46)."""
+  global _BACKEND
+  if _BACKEND is None:
+    _BACKEND = HipBackend()
+  return _BACKEND
+
+
+def register_with_tensornetwork():
+  """Insert ``"hip"`` into tensornetwork's backend registry (factory:22-28).
+
+  Needed because ``contract`` / Node arithmetic rebuild nodes from
+  ``backend.name`` (network_components.py:1879-1882) and
+  ``set_default_backend`` validates names (backend_contextmanager.py:47-48).
+  """
+  if not HAVE_TENSORNETWORK:
+    return False
+  from tensornetwork.backends import backend_factory  # pylint: disable=import-outside-toplevel
+  backend_factory._BACKENDS["hip"] = HipBackend  # pylint: disable=protected-access
+  backend_factory._INSTANTIATED_BACKENDS["hip"] = get_hip_backend()  # pylint: disable=protected-access
+  return True

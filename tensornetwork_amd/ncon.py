@@ -1,0 +1,274 @@
+"""``ncon`` and ``einsum`` drivers on top of an ``AbstractBackend``-shaped object.
+
+Behavioural mirror of ``tensornetwork/ncon_interface.py:523-663`` (the
+reference's ncon) written as a small label-bookkeeping engine: every operand is
+a ``(tensor, labels)`` pair; a step either traces a repeated label inside one
+operand, sums out a dangling label, or contracts two operands over every label
+they can close together -- ``backend.tensordot`` when no batch label is shared
+(``ncon_interface.py:483-489``), ``transpose -> reshape -> backend.matmul``
+when one is (``_batch_cont``, ``ncon_interface.py:280-354``).  It only calls
+backend methods, so it runs unchanged on the hip backend (GPU) and on the NumPy
+oracle backend (CPU tests).
+
+Label conventions (same as the reference): positive ints / plain strings are
+contracted, negative ints / strings starting with ``-`` are open and ordered
+-1, -2, ... in the result; a label on three or more operands (or an open label
+on two) is a batch label.
+"""
+from typing import Any, List, Optional, Sequence
+
+import numpy as np
+
+
+def _is_open(label) -> bool:
+  if isinstance(label, str):
+    return label.startswith("-")
+  return label < 0
+
+
+def _label_key(label):
+  # ints before strings, each in natural order (ncon_interface.py:100-115)
+  return (1, label) if isinstance(label, str) else (0, label)
+
+
+def _default_orders(network_structure):
+  flat = [l for labels in network_structure for l in labels]
+  cont = sorted({l for l in flat if not _is_open(l)}, key=_label_key)
+  out_int = sorted({l for l in flat if _is_open(l) and not isinstance(l, str)}, reverse=True)
+  out_str = sorted({l for l in flat if _is_open(l) and isinstance(l, str)})
+  return cont, out_int + out_str
+
+
+def _check(tensors, network_structure, con_order, out_order):
+  """Argument validation with the reference's error types (ValueError)."""
+  if len(tensors) != len(network_structure):
+    raise ValueError('len(tensors) != len(network_structure)')
+  flat = [l for labels in network_structure for l in labels]
+  for t, labels in zip(tensors, network_structure):
+    if len(t.shape) != len(labels):
+      raise ValueError(f"number of labels {list(labels)} does not match tensor rank {len(t.shape)}")
+  dims = {}
+  for t, labels in zip(tensors, network_structure):
+    for d, l in zip(t.shape, labels):
+      if l in dims and dims[l] != d:
+        raise ValueError(f"label {l!r} is attached to axes of different dimensions "
+                         f"({dims[l]} and {d})")
+      dims[l] = d
+  if con_order is not None:
+    want = {l for l in flat if not _is_open(l)}
+    if set(con_order) != want or len(set(con_order)) != len(con_order):
+      raise ValueError(f"con_order = {list(con_order)} is not a valid contraction order for "
+                       f"network_structure = {network_structure}")
+  if out_order is not None:
+    want = {l for l in flat if _is_open(l)}
+    if set(out_order) != want or len(set(out_order)) != len(out_order):
+      raise ValueError(f"out_order = {list(out_order)} is not a valid output order for "
+                       f"network_structure = {network_structure}")
+
+
+class _Engine:
+  """Mutable list of (tensor, labels) operands plus the contraction primitives."""
+
+  def __init__(self, backend, tensors, labels, keep):
+    self.be = backend
+    self.ops = [(t, list(l)) for t, l in zip(tensors, labels)]
+    self.keep = set(keep)  # labels that must survive (outputs)
+
+  def count(self, label) -> int:
+    return sum(labels.count(label) for _, labels in self.ops)
+
+  def holders(self, label) -> List[int]:
+    return [i for i, (_, labels) in enumerate(self.ops) if label in labels]
+
+  # -- single-operand steps -------------------------------------------------
+  def trace_repeated(self, idx) -> List[Any]:
+    """Trace every label that occurs twice on operand `idx` (partial trace)."""
+    tensor, labels = self.ops[idx]
+    rep = sorted({l for l in labels if labels.count(l) == 2 and l not in self.keep
+                  and self.count(l) == 2}, key=_label_key)
+    if not rep:
+      return []
+    first = [labels.index(l) for l in rep]
+    second = [len(labels) - 1 - labels[::-1].index(l) for l in rep]
+    free = [i for i in range(len(labels)) if i not in first + second]
+    shape = self.be.shape_tuple(tensor)
+    cdim = int(np.prod([shape[i] for i in first], dtype=np.int64))
+    t = self.be.transpose(tensor, tuple(free + first + second))
+    t = self.be.reshape(t, tuple(shape[i] for i in free) + (cdim, cdim))
+    self.ops[idx] = (self.be.trace(t), [labels[i] for i in free])
+    return rep
+
+  def sum_dangling(self, idx) -> List[Any]:
+    """Sum out contractible labels that live on this operand only (once)."""
+    tensor, labels = self.ops[idx]
+    axes = [i for i, l in enumerate(labels)
+            if l not in self.keep and labels.count(l) == 1 and self.count(l) == 1]
+    if not axes:
+      return []
+    gone = [labels[i] for i in axes]
+    self.ops[idx] = (self.be.sum(tensor, tuple(axes)),
+                     [l for i, l in enumerate(labels) if i not in axes])
+    return gone
+
+  # -- pairwise step -----------------------------------------------------------
+  def contract_pair(self, i, j) -> List[Any]:
+    """Contract operands i and j over every label they close; returns those labels."""
+    (t1, l1), (t2, l2) = self.ops[i], self.ops[j]
+    for k in sorted((i, j), reverse=True):
+      del self.ops[k]
+    shared = [l for l in l1 if l in l2]
+    closing = [l for l in shared if l not in self.keep and self.count(l) == 0]
+    batch = [l for l in shared if l not in closing]
+    be = self.be
+    if not batch:
+      if closing:
+        ax1 = [l1.index(l) for l in closing]
+        ax2 = [l2.index(l) for l in closing]
+        order = sorted(range(len(ax1)), key=lambda n: ax1[n])
+        result = be.tensordot(t1, t2, (tuple(ax1[n] for n in order), tuple(ax2[n] for n in order)))
+      else:
+        result = be.outer_product(t1, t2)
+      new_labels = [l for l in l1 if l not in closing] + [l for l in l2 if l not in closing]
+    else:
+      s1, s2 = be.shape_tuple(t1), be.shape_tuple(t2)
+      b1, b2 = [l1.index(l) for l in batch], [l2.index(l) for l in batch]
+      c1, c2 = [l1.index(l) for l in closing], [l2.index(l) for l in closing]
+      f1 = [n for n, l in enumerate(l1) if l not in shared]
+      f2 = [n for n, l in enumerate(l2) if l not in shared]
+      prod = lambda shape, pos: int(np.prod([shape[p] for p in pos], dtype=np.int64))
+      m1 = be.reshape(be.transpose(t1, tuple(b1 + f1 + c1)), (prod(s1, b1), prod(s1, f1), prod(s1, c1)))
+      m2 = be.reshape(be.transpose(t2, tuple(b2 + c2 + f2)), (prod(s2, b2), prod(s2, c2), prod(s2, f2)))
+      result = be.reshape(be.matmul(m1, m2),
+                          tuple(s1[p] for p in b1) + tuple(s1[p] for p in f1) + tuple(s2[p] for p in f2))
+      new_labels = [l1[p] for p in b1] + [l1[p] for p in f1] + [l2[p] for p in f2]
+    self.ops.append((result, new_labels))
+    return closing
+
+  def finish(self, out_order):
+    while len(self.ops) > 1:
+      # remaining operands share no closable label: outer products / batch merges
+      self.contract_pair(len(self.ops) - 2, len(self.ops) - 1)
+    tensor, labels = self.ops[0]
+    # an open label may still be repeated on the single survivor (batch diagonal)
+    if len(set(labels)) != len(labels):
+      raise ValueError(f"cannot resolve repeated open labels {labels}")
+    if len(labels) > 1 and list(labels) != list(out_order):
+      tensor = self.be.transpose(tensor, tuple(labels.index(l) for l in out_order))
+    return tensor
+
+
+def ncon(tensors: Sequence[Any], network_structure: Sequence[Sequence], con_order: Optional[Sequence] = None,
+         out_order: Optional[Sequence] = None, check_network: bool = True, backend=None):
+  """Contract ``tensors`` according to ncon-style labels.
+
+  Same call signature and label semantics as ``tensornetwork.ncon``
+  (``ncon_interface.py:523-606``).  ``backend`` is a backend object (or, when
+  google/TensorNetwork is importable, a backend name); default: the hip backend.
+  """
+  be = _resolve_backend(backend)
+  tensors = [be.convert_to_tensor(getattr(t, "array", t)) for t in tensors]
+  network_structure = [list(labels) for labels in network_structure]
+  if check_network:
+    _check(tensors, network_structure, con_order, out_order)
+  d_cont, d_out = _default_orders(network_structure)
+  con_order = list(con_order) if con_order is not None else d_cont
+  out_order = list(out_order) if out_order is not None else d_out
+
+  eng = _Engine(be, tensors, network_structure, keep=out_order)
+  done = set()
+  for idx in range(len(eng.ops)):
+    done.update(eng.trace_repeated(idx))
+  for idx in range(len(eng.ops)):
+    done.update(eng.sum_dangling(idx))
+  pending = [l for l in con_order if l not in done]
+  skipped = 0
+  while pending:
+    label = pending[0]
+    holders = eng.holders(label)
+    if len(holders) > 2 and skipped < len(pending):
+      # still a batch label: defer until the other contractions reduce it
+      pending.append(pending.pop(0))
+      skipped += 1
+      continue
+    skipped = 0
+    if len(holders) == 1:
+      closed = eng.trace_repeated(holders[0]) or eng.sum_dangling(holders[0])
+      if not closed:
+        raise ValueError(f"label {label!r} cannot be contracted")
+    else:
+      closed = eng.contract_pair(holders[0], holders[1])
+      if label not in closed:
+        # the pair only merged batch labels; the label closes on a later step
+        closed = closed or []
+        new_idx = len(eng.ops) - 1
+        closed += eng.trace_repeated(new_idx)
+    pending = [l for l in pending if l not in closed]
+  return eng.finish(out_order)
+
+
+def einsum(expression: str, *tensors, backend=None):
+  """``numpy.einsum``-style explicit/implicit expressions via pairwise contraction."""
+  be = _resolve_backend(backend)
+  expression = expression.replace(" ", "")
+  if "." in expression:
+    raise NotImplementedError("ellipsis in einsum is not supported")
+  if "->" in expression:
+    lhs, rhs = expression.split("->")
+  else:
+    lhs = expression
+    letters = lhs.replace(",", "")
+    rhs = "".join(sorted(c for c in set(letters) if letters.count(c) == 1))
+  terms = lhs.split(",")
+  if len(terms) != len(tensors):
+    raise ValueError("number of einsum subscripts does not match the number of operands")
+  tensors = [be.convert_to_tensor(t) for t in tensors]
+  for t, term in zip(tensors, terms):
+    if len(term) != len(be.shape_tuple(t)):
+      raise ValueError(f"einsum subscripts '{term}' do not match operand rank")
+  eng = _Engine(be, tensors, [list(t) for t in terms], keep=list(rhs))
+  for idx in range(len(eng.ops)):
+    eng.trace_repeated(idx)
+  for idx in range(len(eng.ops)):
+    eng.sum_dangling(idx)
+  while len(eng.ops) > 1:
+    # cheapest-result-first pairing among operands that share a label
+    best = None
+    for i in range(len(eng.ops)):
+      for j in range(i + 1, len(eng.ops)):
+        l1, l2 = eng.ops[i][1], eng.ops[j][1]
+        if not set(l1) & set(l2):
+          continue
+        s1, s2 = be.shape_tuple(eng.ops[i][0]), be.shape_tuple(eng.ops[j][0])
+        dims = dict(zip(l1, s1))
+        dims.update(zip(l2, s2))
+        others = set(rhs)
+        for k, (_, lk) in enumerate(eng.ops):
+          if k not in (i, j):
+            others |= set(lk)
+        size = int(np.prod([dims[l] for l in set(l1) | set(l2) if l in others], dtype=np.int64))
+        if best is None or size < best[0]:
+          best = (size, i, j)
+    if best is None:
+      best = (0, len(eng.ops) - 2, len(eng.ops) - 1)
+    eng.contract_pair(best[1], best[2])
+    eng.trace_repeated(len(eng.ops) - 1)
+    eng.sum_dangling(len(eng.ops) - 1)
+  tensor, labels = eng.ops[0]
+  if len(set(labels)) != len(labels):
+    raise NotImplementedError("einsum with repeated output subscripts (diagonals) is not supported")
+  if list(labels) != list(rhs):
+    tensor = be.transpose(tensor, tuple(labels.index(c) for c in rhs))
+  return tensor
+
+
+def _resolve_backend(backend):
+  if backend is None:
+    from tensornetwork_amd.hip_backend import get_hip_backend  # pylint: disable=import-outside-toplevel
+    return get_hip_backend()
+  if isinstance(backend, str):
+    if backend == "hip":
+      from tensornetwork_amd.hip_backend import get_hip_backend  # pylint: disable=import-outside-toplevel
+      return get_hip_backend()
+    from tensornetwork.backends import backend_factory  # pylint: disable=import-outside-toplevel
+    return backend_factory.get_backend(backend)
+  return backend

@@ -1,0 +1,434 @@
+"""Minimal Node/Edge graph layer over an ``AbstractBackend``-shaped backend.
+
+On a machine with google/TensorNetwork installed, use its own ``tn.Node`` with
+``backend="hip"`` -- the hip backend is a drop-in there.  This module exists so
+that the same workloads (``contract_between``, ``split_node``, the contractors)
+run stand-alone on a GPU box that only has this repository; it mirrors the
+reference's public behaviour for exactly those entry points:
+
+  * ``contract_between``  -- ``network_components.py:1984-2095``
+  * ``contract`` (one edge), trace edges -- ``:1834-1885``, ``:1802-1831``
+  * ``outer_product``     -- ``:2127-2186``
+  * ``split_node`` / ``split_node_full_svd`` -- ``network_operations.py:130-255, 446-588``
+  * ``copy`` / ``slice_edge`` -- ``network_operations.py:32-83``, ``network_components.py:1636-1682``
+
+All tensor math goes through ``node.backend``.
+"""
+from typing import Any, Dict, Iterable, List, Optional, Sequence, Set, Tuple
+
+import numpy as np
+
+
+def _resolve_backend(backend):
+  from tensornetwork_amd.ncon import _resolve_backend as _rb  # pylint: disable=import-outside-toplevel
+  return _rb(backend)
+
+
+class Edge:
+  """A (possibly dangling) connection between one or two node axes."""
+
+  def __init__(self, node1: "Node", axis1: int, name: Optional[str] = None,
+               node2: Optional["Node"] = None, axis2: Optional[int] = None):
+    self.node1, self.axis1 = node1, axis1
+    self.node2, self.axis2 = node2, axis2
+    self.name = name if name is not None else "__unnamed_edge__"
+
+  def is_dangling(self) -> bool:
+    return self.node2 is None
+
+  def is_trace(self) -> bool:
+    return self.node1 is self.node2
+
+  @property
+  def dimension(self) -> int:
+    return self.node1.shape[self.axis1]
+
+  def get_nodes(self):
+    return [self.node1, self.node2]
+
+  def ends(self):
+    out = [(self.node1, self.axis1)]
+    if self.node2 is not None:
+      out.append((self.node2, self.axis2))
+    return out
+
+  def _retarget(self, old_node, old_axis, new_node, new_axis):
+    """Point the end (old_node, old_axis) at (new_node, new_axis)."""
+    if self.node1 is old_node and self.axis1 == old_axis:
+      self.node1, self.axis1 = new_node, new_axis
+    elif self.node2 is old_node and self.axis2 == old_axis:
+      self.node2, self.axis2 = new_node, new_axis
+    else:
+      raise ValueError("edge end not found")
+
+  def __xor__(self, other: "Edge") -> "Edge":
+    return connect(self, other)
+
+  def __repr__(self):
+    return f"Edge({self.name!r}, dim={self.dimension}, dangling={self.is_dangling()})"
+
+
+class Node:
+  """A tensor with one edge per axis."""
+
+  def __init__(self, tensor: Any, name: Optional[str] = None, axis_names: Optional[List[str]] = None,
+               backend=None):
+    self.backend = _resolve_backend(backend)
+    if isinstance(tensor, Node):
+      tensor = tensor.tensor
+    self.tensor = self.backend.convert_to_tensor(tensor)
+    self.name = name if name is not None else "__unnamed_node__"
+    rank = len(self.backend.shape_tuple(self.tensor))
+    if axis_names is not None and len(axis_names) != rank:
+      raise ValueError("axis_names is not the same length as the tensor shape."
+                       f"axis_names length: {len(axis_names)}, shape length: {rank}")
+    self.axis_names = list(axis_names) if axis_names is not None else [str(i) for i in range(rank)]
+    self.edges: List[Edge] = [Edge(self, i, name=self.axis_names[i]) for i in range(rank)]
+
+  @property
+  def shape(self) -> Tuple[int, ...]:
+    return tuple(self.backend.shape_tuple(self.tensor))
+
+  @property
+  def dtype(self):
+    return self.tensor.dtype
+
+  def get_rank(self) -> int:
+    return len(self.shape)
+
+  def get_all_dangling(self) -> List[Edge]:
+    return [e for e in self.edges if e.is_dangling()]
+
+  def get_all_nondangling(self) -> Set[Edge]:
+    return {e for e in self.edges if not e.is_dangling()}
+
+  def get_edge(self, key) -> Edge:
+    if isinstance(key, str):
+      if key not in self.axis_names:
+        raise ValueError(f"Axis name '{key}' not found for node '{self.name}'")
+      key = self.axis_names.index(key)
+    return self.edges[key]
+
+  def __getitem__(self, key) -> Edge:
+    return self.get_edge(key)
+
+  def reorder_edges(self, edge_order: Sequence[Edge]) -> "Node":
+    """Permute the tensor so that its axes follow `edge_order` (network_components.py:212-252)."""
+    if set(edge_order) != set(self.edges) or len(edge_order) != len(self.edges):
+      raise ValueError("Given edge order does not match expected edges. "
+                       f"Found: {edge_order}, Expected: {self.edges}")
+    perm = []
+    for e in edge_order:
+      cands = [i for i, mine in enumerate(self.edges) if mine is e and i not in perm]
+      perm.append(cands[0])
+    return self.reorder_axes(perm)
+
+  def reorder_axes(self, perm: Sequence[int]) -> "Node":
+    perm = list(perm)
+    if sorted(perm) != list(range(len(self.edges))):
+      raise ValueError(f"Given perm does not match expected axes: {perm}")
+    old_edges = list(self.edges)
+    self.tensor = self.backend.transpose(self.tensor, tuple(perm))
+    self.edges = [old_edges[p] for p in perm]
+    self.axis_names = [self.axis_names[p] for p in perm]
+    done = set()
+    for new_axis, (old_axis, e) in enumerate(zip(perm, self.edges)):
+      # an edge may appear twice (trace edge): retarget each end once
+      key = (id(e), old_axis)
+      if key in done:
+        continue
+      done.add(key)
+      e._retarget(self, old_axis, self, -1 - new_axis)  # park on a temp axis  # pylint: disable=protected-access
+    for e in set(self.edges):
+      if e.node1 is self and e.axis1 < 0:
+        e.axis1 = -1 - e.axis1
+      if e.node2 is self and e.axis2 is not None and e.axis2 < 0:
+        e.axis2 = -1 - e.axis2
+    return self
+
+  def tensor_from_edge_order(self, edge_order: Sequence[Edge]):
+    perm = []
+    for e in edge_order:
+      cands = [i for i, mine in enumerate(self.edges) if mine is e and i not in perm]
+      if not cands:
+        raise ValueError("edge does not belong to this node")
+      perm.append(cands[0])
+    if sorted(perm) != list(range(len(self.edges))):
+      raise ValueError("edge_order must contain every edge of the node exactly once")
+    return self.backend.transpose(self.tensor, tuple(perm))
+
+  def __matmul__(self, other: "Node") -> "Node":
+    return contract_between(self, other)
+
+  def __repr__(self):
+    return f"Node(name={self.name!r}, shape={self.shape}, backend={self.backend.name!r})"
+
+
+# ---------------------------------------------------------------------- wiring
+def connect(edge1: Edge, edge2: Edge, name: Optional[str] = None) -> Edge:
+  """Join two dangling edges (network_components.py:1939-1981)."""
+  if edge1 is edge2:
+    raise ValueError(f"Cannot connect edge '{edge1}' to itself.")
+  for e in (edge1, edge2):
+    if not e.is_dangling():
+      raise ValueError(f"Edge '{e}' is not a dangling edge. This edge points to nodes: "
+                       f"'{e.node1}' and '{e.node2}'")
+  if edge1.dimension != edge2.dimension:
+    raise ValueError(f"Cannot connect edges of unequal dimension. Dimension of edge '{edge1}': "
+                     f"{edge1.dimension}, Dimension of edge '{edge2}': {edge2.dimension}.")
+  n1, a1, n2, a2 = edge1.node1, edge1.axis1, edge2.node1, edge2.axis1
+  new = Edge(n1, a1, name=name, node2=n2, axis2=a2)
+  n1.edges[a1] = new
+  n2.edges[a2] = new
+  return new
+
+
+def get_shared_edges(node1: Node, node2: Node) -> Set[Edge]:
+  return {e for e in node1.edges if e in node2.edges and not e.is_dangling()}
+
+
+def get_all_edges(nodes: Iterable[Node]) -> Set[Edge]:
+  return {e for n in nodes for e in n.edges}
+
+
+def get_subgraph_dangling(nodes: Iterable[Node]) -> Set[Edge]:
+  nodes = list(nodes)
+  inside = set(map(id, nodes))
+  out = set()
+  for n in nodes:
+    for e in n.edges:
+      if e.is_dangling() or not all(id(x) in inside for x in e.get_nodes()):
+        out.add(e)
+  return out
+
+
+def reachable(node: Node) -> Set[Node]:
+  seen, stack = {id(node): node}, [node]
+  while stack:
+    cur = stack.pop()
+    for e in cur.edges:
+      for nb in e.get_nodes():
+        if nb is not None and id(nb) not in seen:
+          seen[id(nb)] = nb
+          stack.append(nb)
+  return set(seen.values())
+
+
+def _adopt_edges(new_node: Node, sources: Sequence[Tuple[Node, int]]):
+  """Give `new_node` the (still live) edges that sat on the listed (node, axis) slots."""
+  for new_axis, (old_node, old_axis) in enumerate(sources):
+    e = old_node.edges[old_axis]
+    e._retarget(old_node, old_axis, new_node, new_axis)  # pylint: disable=protected-access
+    new_node.edges[new_axis] = e
+    new_node.axis_names[new_axis] = old_node.axis_names[old_axis]
+
+
+# ------------------------------------------------------------------ contraction
+def contract_trace_edges(node: Node) -> Node:
+  """Contract every trace edge of `node` (network_operations.py:737-751)."""
+  trace_edges = []
+  for e in node.edges:
+    if e.is_trace() and e not in trace_edges:
+      trace_edges.append(e)
+  if not trace_edges:
+    return node
+  be = node.backend
+  first = [e.axis1 for e in trace_edges]
+  second = [e.axis2 for e in trace_edges]
+  free = [i for i in range(len(node.edges)) if i not in first + second]
+  shape = node.shape
+  cdim = int(np.prod([shape[i] for i in first], dtype=np.int64))
+  t = be.transpose(node.tensor, tuple(free + first + second))
+  t = be.reshape(t, tuple(shape[i] for i in free) + (cdim, cdim))
+  out = Node(be.trace(t), name=node.name, backend=be)
+  _adopt_edges(out, [(node, i) for i in free])
+  return out
+
+
+def contract(edge: Edge, name: Optional[str] = None) -> Node:
+  """Contract a single edge (network_components.py:1834-1885)."""
+  if edge.is_dangling():
+    raise ValueError(f"Attempting to contract dangling edge '{edge}'")
+  if edge.is_trace():
+    node = edge.node1
+    be = node.backend
+    a1, a2 = edge.axis1, edge.axis2
+    free = [i for i in range(len(node.edges)) if i not in (a1, a2)]
+    t = be.trace(be.transpose(node.tensor, tuple(free + [a1, a2])))
+    out = Node(t, name=name, backend=be)
+    _adopt_edges(out, [(node, i) for i in free])
+    return out
+  n1, n2 = edge.node1, edge.node2
+  be = n1.backend
+  t = be.tensordot(n1.tensor, n2.tensor, [[edge.axis1], [edge.axis2]])
+  out = Node(t, name=name, backend=be)
+  sources = [(n1, i) for i in range(len(n1.edges)) if i != edge.axis1] + \
+            [(n2, i) for i in range(len(n2.edges)) if i != edge.axis2]
+  _adopt_edges(out, sources)
+  return out
+
+
+def outer_product(node1: Node, node2: Node, name: Optional[str] = None) -> Node:
+  """Tensor product of two nodes (network_components.py:2127-2186)."""
+  be = node1.backend
+  if node1.get_rank() == 0 or node2.get_rank() == 0:
+    t = be.multiply(node1.tensor, node2.tensor)
+  else:
+    t = be.outer_product(node1.tensor, node2.tensor)
+  out = Node(t, name=name, backend=be)
+  _adopt_edges(out, [(node1, i) for i in range(len(node1.edges))] +
+               [(node2, i) for i in range(len(node2.edges))])
+  return out
+
+
+def contract_between(node1: Node, node2: Node, name: Optional[str] = None,
+                     allow_outer_product: bool = False,
+                     output_edge_order: Optional[Sequence[Edge]] = None,
+                     axis_names: Optional[List[str]] = None) -> Node:
+  """Contract all edges shared by two nodes with ONE tensordot
+  (network_components.py:1984-2095)."""
+  if node1.backend.name != node2.backend.name:
+    raise ValueError(f"The backends of {node1} and {node2} do not match: "
+                     f"{node1.backend.name} vs {node2.backend.name}")
+  be = node1.backend
+  if node1 is node2:
+    out = contract_trace_edges(node1)
+    out.name = name if name is not None else out.name
+    if output_edge_order is not None:
+      out.reorder_edges(list(output_edge_order))
+    return out
+  shared = get_shared_edges(node1, node2)
+  if not shared:
+    if not allow_outer_product:
+      raise ValueError(f"No edges found between nodes '{node1}' and '{node2}' and "
+                       "allow_outer_product=False.")
+    out = outer_product(node1, node2, name=name)
+  else:
+    # (axis on node1, axis on node2) per shared edge, sorted by node1's axis so the
+    # contracted group is traversed in node1's memory order.
+    pairs = []
+    for e in shared:
+      if e.node1 is node1:
+        pairs.append((e.axis1, e.axis2))
+      else:
+        pairs.append((e.axis2, e.axis1))
+    pairs.sort()
+    axes1, axes2 = [p[0] for p in pairs], [p[1] for p in pairs]
+    t = be.tensordot(node1.tensor, node2.tensor, [axes1, axes2])
+    out = Node(t, name=name, backend=be)
+    sources = [(node1, i) for i in range(len(node1.edges)) if i not in axes1] + \
+              [(node2, i) for i in range(len(node2.edges)) if i not in axes2]
+    _adopt_edges(out, sources)
+  if output_edge_order is not None:
+    output_edge_order = list(output_edge_order)
+    if set(output_edge_order) != set(out.edges):
+      raise ValueError(f"output edges are not equal to the remaining non-contracted edges of the "
+                       f"final node. output_edge_order = {output_edge_order}, remaining = {out.edges}")
+    out.reorder_edges(output_edge_order)
+  if axis_names is not None:
+    if len(axis_names) != len(out.edges):
+      raise ValueError("axis_names does not match the rank of the result")
+    out.axis_names = list(axis_names)
+  return out
+
+
+def contract_parallel(edge: Edge) -> Node:
+  """Contract all edges parallel to `edge` (network_components.py:1923-1936)."""
+  if edge.is_dangling():
+    raise ValueError(f"Attempted to contract dangling edge: '{edge}'")
+  return contract_between(edge.node1, edge.node2)
+
+
+# -------------------------------------------------------------------- splitting
+def _split_bookkeeping(node, left_edges, right_edges):
+  if set(left_edges) | set(right_edges) != set(node.edges) or \
+      len(left_edges) + len(right_edges) != len(node.edges):
+    raise ValueError("left_edges and right_edges must partition the edges of the node")
+  return node.tensor_from_edge_order(list(left_edges) + list(right_edges))
+
+
+def split_node(node: Node, left_edges: List[Edge], right_edges: List[Edge],
+               max_singular_values: Optional[int] = None, max_truncation_err: Optional[float] = None,
+               relative: bool = False, left_name: Optional[str] = None, right_name: Optional[str] = None,
+               edge_name: Optional[str] = None) -> Tuple[Node, Node, Any]:
+  """SVD-split: node = (U sqrt(S)) -- (sqrt(S) Vh)  (network_operations.py:130-255).
+
+  Returns (left_node, right_node, truncated_singular_values)."""
+  be = node.backend
+  left_sources = [(node, node.edges.index(e)) for e in left_edges]
+  right_sources = [(node, node.edges.index(e)) for e in right_edges]
+  t = _split_bookkeeping(node, left_edges, right_edges)
+  u, s, vh, trun_vals = be.svd(t, len(left_edges), max_singular_values, max_truncation_err,
+                               relative=relative)
+  sqrt_s = be.sqrt(s)
+  u_s = be.broadcast_right_multiplication(u, sqrt_s)
+  vh_s = be.broadcast_left_multiplication(sqrt_s, vh)
+  left = Node(u_s, name=left_name, backend=be)
+  right = Node(vh_s, name=right_name, backend=be)
+  _adopt_edges(left, left_sources + [(left, len(left_edges))])
+  _adopt_edges(right, [(right, 0)] + right_sources)
+  connect(left.edges[-1], right.edges[0], name=edge_name)
+  node.edges = []  # the node is consumed, as in the reference (fresh_edges)
+  return left, right, trun_vals
+
+
+def split_node_full_svd(node: Node, left_edges: List[Edge], right_edges: List[Edge],
+                        max_singular_values: Optional[int] = None,
+                        max_truncation_err: Optional[float] = None, relative: bool = False,
+                        left_name: Optional[str] = None, middle_name: Optional[str] = None,
+                        right_name: Optional[str] = None) -> Tuple[Node, Node, Node, Any]:
+  """node = U -- S -- Vh with S a diagonal matrix node (network_operations.py:446-588)."""
+  be = node.backend
+  left_sources = [(node, node.edges.index(e)) for e in left_edges]
+  right_sources = [(node, node.edges.index(e)) for e in right_edges]
+  t = _split_bookkeeping(node, left_edges, right_edges)
+  u, s, vh, trun_vals = be.svd(t, len(left_edges), max_singular_values, max_truncation_err,
+                               relative=relative)
+  left = Node(u, name=left_name, backend=be)
+  mid = Node(be.diagflat(s), name=middle_name, backend=be)
+  right = Node(vh, name=right_name, backend=be)
+  _adopt_edges(left, left_sources + [(left, len(left_edges))])
+  _adopt_edges(right, [(right, 0)] + right_sources)
+  connect(left.edges[-1], mid.edges[0])
+  connect(mid.edges[1], right.edges[0])
+  node.edges = []
+  return left, mid, right, trun_vals
+
+
+# ------------------------------------------------------------------ copy / slice
+def copy(nodes: Iterable[Node], conjugate: bool = False) -> Tuple[Dict[Node, Node], Dict[Edge, Edge]]:
+  """Structure-preserving copy of a sub-network (network_operations.py:32-83).
+
+  Tensors are shared, not duplicated (they are immutable on the backend)."""
+  nodes = list(nodes)
+  node_map: Dict[Node, Node] = {}
+  for n in nodes:
+    t = n.backend.conj(n.tensor) if conjugate else n.tensor
+    node_map[n] = Node(t, name=n.name, axis_names=list(n.axis_names), backend=n.backend)
+  edge_map: Dict[Edge, Edge] = {}
+  for e in get_all_edges(nodes):
+    ends = [(nd, ax) for nd, ax in e.ends() if nd in node_map]
+    if len(ends) == 2:
+      new = connect(node_map[ends[0][0]].edges[ends[0][1]], node_map[ends[1][0]].edges[ends[1][1]],
+                    name=e.name)
+    else:
+      new = node_map[ends[0][0]].edges[ends[0][1]]
+      new.name = e.name
+    edge_map[e] = new
+  return node_map, edge_map
+
+
+def slice_edge(edge: Edge, start_index: int, length: int) -> Edge:
+  """Restrict `edge` to indices [start, start+length) in place
+  (network_components.py:1636-1682)."""
+  if start_index < 0 or length <= 0 or start_index + length > edge.dimension:
+    raise ValueError(f"slice [{start_index}, {start_index + length}) is out of range for "
+                     f"edge of dimension {edge.dimension}")
+  for node, axis in edge.ends():
+    shape = node.shape
+    starts = [0] * len(shape)
+    sizes = list(shape)
+    starts[axis] = start_index
+    sizes[axis] = length
+    node.tensor = node.backend.slice(node.tensor, tuple(starts), tuple(sizes))
+  return edge

@@ -1,0 +1,43 @@
+"""pytest configuration: markers, import paths and the golden-fixture loader."""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(HERE)
+for p in (REPO, HERE):
+  if p not in sys.path:
+    sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+  config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` on the GPU box)")
+
+
+class Golden:
+  """tests/golden/golden.npz + cases.json (made by tests/golden/make_golden.py)."""
+
+  def __init__(self):
+    self.arrays = np.load(os.path.join(HERE, "golden", "golden.npz"))
+    with open(os.path.join(HERE, "golden", "cases.json")) as f:
+      self.cases = json.load(f)
+
+  def __getitem__(self, name):
+    return self.arrays[name]
+
+
+@pytest.fixture(scope="session")
+def golden():
+  return Golden()
+
+
+@pytest.fixture(scope="session")
+def hip():
+  """The hip backend bound to cuda:0 -- fails loudly if libtnhip or the GPU is missing."""
+  import tensornetwork_amd as ta
+  be = ta.get_hip_backend()
+  be.lib  # initialise: raises HipRuntimeError without a gfx950 device  # pylint: disable=pointless-statement
+  return be

@@ -1,0 +1,75 @@
+"""The C-ABI shared library: it loads, exports every symbol include/tnh.h
+declares, the ctypes table covers them all, and the product path fails loudly
+(no CPU fallback) when no gfx950 device is present."""
+import os
+import re
+
+import pytest
+
+from tensornetwork_amd import _lib
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_symbols():
+  text = open(os.path.join(REPO, "include", "tnh.h")).read()
+  text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+  return sorted(set(re.findall(r"\b(tnh_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_header_symbol():
+  lib = _lib.load_library()
+  names = header_symbols()
+  assert len(names) >= 40
+  for name in names:
+    assert hasattr(lib, name), f"{name} declared in include/tnh.h but not exported"
+
+
+def test_ctypes_table_matches_header():
+  assert sorted(_lib.SIGNATURES) == header_symbols()
+
+
+def test_version_and_error_strings():
+  lib = _lib.load_library()
+  assert b"gfx950" in lib.tnh_version()
+  assert isinstance(_lib.last_error(), str)
+
+
+def test_status_codes_map_to_reference_exception_types():
+  # ValueError / NotImplementedError / MemoryError, never abort
+  with pytest.raises(ValueError):
+    _lib.check(_lib.ERR_INVALID, "x")
+  with pytest.raises(NotImplementedError):
+    _lib.check(_lib.ERR_UNSUPPORTED, "x")
+  with pytest.raises(MemoryError):
+    _lib.check(_lib.ERR_NOMEM, "x")
+  with pytest.raises(_lib.HipRuntimeError):
+    _lib.check(_lib.ERR_HIP, "x")
+
+
+def test_calls_before_init_return_status_not_crash():
+  lib = _lib.load_library()
+  if _lib.current_device() is not None:
+    pytest.skip("library already initialised in this process")
+  assert lib.tnh_sync() == _lib.ERR_NOT_INIT
+  assert "tnh_init" in _lib.last_error()
+
+
+def test_no_gpu_means_loud_failure_not_fallback():
+  if _lib.device_count() > 0:
+    pytest.skip("a GPU is visible")
+  import numpy as np
+  import tensornetwork_amd as ta
+  with pytest.raises(ta.HipRuntimeError):
+    ta.HipBackend().convert_to_tensor(np.ones(3))
+  with pytest.raises(ta.HipRuntimeError):
+    ta.ncon([np.ones((2, 2)), np.ones((2, 2))], [(-1, 1), (1, -2)])
+
+
+def test_product_package_never_imports_the_oracle():
+  pkg = os.path.join(REPO, "tensornetwork_amd")
+  for root, _, files in os.walk(pkg):
+    for f in files:
+      if f.endswith((".py", ".hip", ".h")):
+        text = open(os.path.join(root, f)).read()
+        assert "numpy_oracle" not in text and "from oracle" not in text and "import oracle" not in text, f

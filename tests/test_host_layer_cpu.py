@@ -1,0 +1,98 @@
+"""The host layers (ncon / network / contractors) driven by the CPU oracle backend
+must reproduce the reference's outputs on the golden cases.  The very same
+drivers (tests/cases.py) run on the hip backend in the GPU suite."""
+import numpy as np
+import pytest
+
+import tensornetwork_amd as ta
+from oracle.numpy_oracle import OracleBackend
+import cases as C
+
+
+@pytest.fixture(scope="module")
+def be():
+  return OracleBackend()
+
+
+def test_ncon_cases(be, golden):
+  for case in golden.cases["ncon"]:
+    C.assert_close(C.run_ncon(be, golden, case), golden[case["out"]])
+
+
+def test_contract_between_cases(be, golden):
+  for case in golden.cases["contract_between"]:
+    C.assert_close(C.run_contract_between(be, golden, case), golden[case["out"]])
+
+
+def test_split_node_cases(be, golden):
+  for case in golden.cases["split_node"]:
+    left, right, trun, recon = C.run_split(be, golden, case)
+    assert list(left.shape) == case["left_shape"]
+    assert list(right.shape) == case["right_shape"]
+    scale = float(np.max(np.abs(golden[case["x"]]))) + 1e-30
+    C.assert_close(trun, golden[case["trun"]], scale=scale)
+    C.assert_close(recon, golden[case["recon"]], scale=scale)
+
+
+def test_contractor_cases(be, golden):
+  for case in golden.cases["contractors"]:
+    C.assert_close(C.run_contractor(be, golden, case), golden[case["out"]])
+
+
+def test_ncon_readme_example(be):
+  # BASELINE config 1: ncon([a, b], [(-1, 1), (1, -2)]) on ones(10, 10)
+  a = np.ones((10, 10))
+  out = ta.ncon([a, a], [(-1, 1), (1, -2)], backend=be)
+  np.testing.assert_array_equal(out, 10 * np.ones((10, 10)))
+
+
+def test_ncon_errors(be):
+  a = np.ones((2, 3))
+  with pytest.raises(ValueError):
+    ta.ncon([a, a], [[-1, 1]], backend=be)
+  with pytest.raises(ValueError):
+    ta.ncon([a, a], [[-1, 1], [1, -2]], backend=be)  # dimension mismatch 3 vs 2
+  with pytest.raises(ValueError):
+    ta.ncon([a], [[-1, -2, -3]], backend=be)
+
+
+def test_einsum_matches_numpy(be):
+  rng = np.random.default_rng(3)
+  a, b, c = rng.standard_normal((3, 4)), rng.standard_normal((4, 5)), rng.standard_normal((5, 3))
+  for expr, ops in [("ij,jk->ik", (a, b)), ("ij,jk,ki->", (a, b, c)), ("ij,jk", (a, b)),
+                    ("ii->", (rng.standard_normal((4, 4)),)), ("ij->j", (a,)), ("bij,bjk->bik",
+                     (rng.standard_normal((2, 3, 4)), rng.standard_normal((2, 4, 5))))]:
+    np.testing.assert_allclose(ta.einsum(expr, *ops, backend=be), np.einsum(expr, *ops), rtol=1e-12,
+                               atol=1e-12)
+
+
+def test_node_edge_bookkeeping(be):
+  a = ta.Node(np.arange(24.0).reshape(2, 3, 4), backend=be)
+  b = ta.Node(np.arange(12.0).reshape(4, 3), backend=be)
+  e = a[2] ^ b[0]
+  assert not e.is_dangling() and e.dimension == 4
+  with pytest.raises(ValueError):
+    ta.connect(a[2], b[1])  # already connected
+  with pytest.raises(ValueError):
+    ta.connect(a[0], b[1])  # dimension mismatch
+  c = a @ b
+  assert c.shape == (2, 3, 3)
+  np.testing.assert_allclose(c.tensor, np.tensordot(a.tensor, b.tensor, [[2], [0]]))
+  c.reorder_edges([c[2], c[0], c[1]])
+  assert c.shape == (3, 2, 3)
+  with pytest.raises(ValueError):
+    ta.contract_between(c, ta.Node(np.ones(2), backend=be))  # no shared edge
+
+
+def test_slice_and_copy(be):
+  rng = np.random.default_rng(5)
+  a = ta.Node(rng.standard_normal((3, 4)), backend=be)
+  b = ta.Node(rng.standard_normal((4, 5)), backend=be)
+  e = a[1] ^ b[0]
+  full = (a.tensor @ b.tensor)
+  total = 0
+  for i in range(4):
+    node_map, edge_map = ta.copy([a, b])
+    ta.slice_edge(edge_map[e], i, 1)
+    total = total + ta.contract_between(node_map[a], node_map[b]).tensor
+  np.testing.assert_allclose(total, full, rtol=1e-12)
