@@ -1,0 +1,226 @@
+"""Headline benchmark: one JSON line per run (contract described in the task brief).
+
+Workload at N=1 (BASELINE.json configs[1]): ``contract_between`` of two rank-4
+bf16 nodes with two shared bonds of dimension D=256 (layout L0: a[2]^b[0],
+a[3]^b[1]) -> one 65536^3 GEMM on the MFMA path, operands generated in HBM.
+A "step" is one such contract_between through the product path
+(Node bookkeeping -> HipBackend.tensordot -> K1 permute of b -> K2 MFMA GEMM).
+``value`` = 2*M*N*K*steps / wall time, TFLOP/s, inputs resident in HBM.
+
+N>1 (one process per GPU, torch.distributed/RCCL for the barrier and the
+max-over-ranks reduction only): the pairwise contraction has no exchange step,
+so every rank contracts its own pair of nodes (weak scaling, no data-path
+collective) and ``value`` is the aggregate.
+
+Extra objects on the same line:
+  roofline     -- the dominant kernel (bf16 MFMA GEMM) timed with HIP events on
+                  the library's stream inside the timed region, vs 2.5 PFLOP/s.
+  cpu_baseline -- the NumPy oracle (port of the reference's tensordot) timed on
+                  this box's host cores on a bounded sample (same layout, smaller D).
+  svd          -- split_node truncated SVD (configs[2]) in the metric's GB/s.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+  sys.path.insert(0, ROOT)
+
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense, /opt/skills/guides/MI355X_MICROARCH.md:42
+
+
+def parse_args():
+  p = argparse.ArgumentParser()
+  p.add_argument("--gpus", type=int, default=1)
+  p.add_argument("--steps", type=int, default=5)
+  p.add_argument("--warmup", type=int, default=2)
+  p.add_argument("--bond", type=int, default=256, help="bond dimension D of the rank-4 nodes")
+  p.add_argument("--layout", default="L0", choices=["L0", "L1"])
+  p.add_argument("--svd-n", type=int, default=2048, help="side of the split_node matrix (0 = skip)")
+  p.add_argument("--no-cpu-baseline", action="store_true")
+  p.add_argument("--fill", default="normal", choices=["normal", "zeros"],
+                 help="operand fill (zeros shows the DVFS-inflated number; never the headline)")
+  return p.parse_args()
+
+
+def dist_setup(n_gpus):
+  """torch.distributed is plumbing here: barrier + max-over-ranks of the time."""
+  rank = int(os.environ.get("RANK", "0"))
+  world = int(os.environ.get("WORLD_SIZE", "1"))
+  local = int(os.environ.get("LOCAL_RANK", "0"))
+  if world == 1:
+    return rank, world, local, None
+  import torch  # pylint: disable=import-outside-toplevel
+  import torch.distributed as dist  # pylint: disable=import-outside-toplevel
+  os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+  os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+  torch.cuda.set_device(local)
+  dist.init_process_group(backend="nccl", rank=rank, world_size=world)
+  assert world == n_gpus, (world, n_gpus)
+  return rank, world, local, dist
+
+
+def sync_all(be, dist):
+  be.synchronize()
+  if dist is not None:
+    import torch  # pylint: disable=import-outside-toplevel
+    torch.cuda.synchronize()
+    dist.barrier()
+    torch.cuda.synchronize()
+
+
+def make_nodes(ta, be, D, layout, seed, fill):
+  if fill == "zeros":
+    A = be.zeros((D,) * 4, dtype=ta.bfloat16)
+    B = be.zeros((D,) * 4, dtype=ta.bfloat16)
+  else:
+    A = be.device_random((D,) * 4, dtype=ta.bfloat16, seed=2 * seed + 1, normal=True, a=0.0, b=1.0 / D)
+    B = be.device_random((D,) * 4, dtype=ta.bfloat16, seed=2 * seed + 2, normal=True, a=0.0, b=1.0 / D)
+  return A, B
+
+
+def one_step(ta, be, A, B, layout):
+  a, b = ta.Node(A, backend=be), ta.Node(B, backend=be)
+  if layout == "L0":
+    a[2] ^ b[0]  # pylint: disable=pointless-statement
+    a[3] ^ b[1]  # pylint: disable=pointless-statement
+  else:
+    a[1] ^ b[2]  # pylint: disable=pointless-statement
+    a[3] ^ b[0]  # pylint: disable=pointless-statement
+  return ta.contract_between(a, b)
+
+
+def cpu_baseline(layout):
+  """NumPy oracle (port of numpy_backend.tensordot) on a bounded sample: same
+  node layout, fp32 on bf16-rounded inputs, D chosen for ~10-30 s of CPU work."""
+  from oracle import numpy_oracle as orc  # pylint: disable=import-outside-toplevel
+  try:
+    from threadpoolctl import threadpool_info  # pylint: disable=import-outside-toplevel
+    threads = max([i.get("num_threads", 1) for i in threadpool_info()] or [1])
+  except Exception:  # pylint: disable=broad-except
+    threads = os.cpu_count() or 1
+  axes = [[2, 3], [0, 1]] if layout == "L0" else [[1, 3], [2, 0]]
+  rng = np.random.default_rng(2)
+
+  def run(D):
+    A = orc.round_bf16(rng.standard_normal((D,) * 4) / D)
+    B = orc.round_bf16(rng.standard_normal((D,) * 4) / D)
+    t0 = time.perf_counter()
+    orc.tensordot(A, B, axes)
+    return time.perf_counter() - t0
+
+  run(32)  # warm-up (BLAS thread pool)
+  t64 = run(64)
+  flops64 = 2.0 * 64**6
+  D = 64
+  for cand in (96, 128):
+    est = t64 * (cand / 64.0)**6
+    if est <= 30.0:
+      D = cand
+  t = run(D) if D != 64 else t64
+  flops = 2.0 * float(D)**6
+  return {"value": flops / t / 1e12, "unit": "TFLOP/s", "cores": int(threads), "kind": "port",
+          "sample": f"oracle tensordot, layout {layout}, D={D} (GEMM {D*D}^3), fp32 on bf16-rounded inputs, "
+                    f"{t:.2f} s; D=64 probe {flops64 / t64 / 1e12:.3f} TFLOP/s"}
+
+
+def svd_bench(ta, be, n, k):
+  """configs[2]: split_node of a rank-6 fp32 node reshaped n x n, keep k."""
+  side = round(n ** (1.0 / 3.0))
+  if side**3 != n:
+    shape, left_axes, right_axes = (n, n), [0], [1]
+  else:
+    shape, left_axes, right_axes = (side,) * 6, [0, 1, 2], [3, 4, 5]
+  x = be.device_random(shape, dtype=np.float32, seed=3, normal=True)
+  node = ta.Node(x, backend=be)
+  be.synchronize()
+  t0 = time.perf_counter()
+  left, right, trun = ta.split_node(node, [node[i] for i in left_axes], [node[i] for i in right_axes],
+                                    max_singular_values=k)
+  be.synchronize()
+  t = time.perf_counter() - t0
+  nbytes = 4 * (n * n + n * k + n + k * n)  # read A, write u_k, all s, vh_k
+  return {"n": n, "k": k, "seconds": t, "gbps": nbytes / t / 1e9, "sweeps": be.last_svd_sweeps,
+          "algorithmic_bytes": nbytes, "trunc_len": int(trun.shape[0]),
+          "note": "Jacobi sweeps are L2/Infinity-Cache traffic bound, not within reach of the "
+                  "algorithmic-bytes HBM bound (see DESIGN.md)"}
+
+
+def main():
+  args = parse_args()
+  rank, world, local, dist = dist_setup(args.gpus)
+  os.environ.setdefault("TNHIP_DEVICE", str(local))
+  import tensornetwork_amd as ta  # pylint: disable=import-outside-toplevel
+  from tensornetwork_amd import _lib  # pylint: disable=import-outside-toplevel
+
+  be = ta.get_hip_backend()
+  D = args.bond
+  M = N = K = D * D
+  flops_per_step = 2.0 * M * N * K
+  A, B = make_nodes(ta, be, D, args.layout, seed=rank, fill=args.fill)
+
+  for _ in range(args.warmup):
+    out = one_step(ta, be, A, B, args.layout)
+    del out
+  be.gemm_events = []          # HIP events around every GEMM launch in the timed region
+  sync_all(be, dist)
+  t0 = time.perf_counter()
+  for _ in range(args.steps):
+    out = one_step(ta, be, A, B, args.layout)
+    del out
+  sync_all(be, dist)
+  elapsed = time.perf_counter() - t0
+  events, be.gemm_events = be.gemm_events, None
+  kernel_name = be.lib.tnh_gemm_last_kernel().decode()
+
+  if dist is not None:
+    import torch  # pylint: disable=import-outside-toplevel
+    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+  gemm_ms = [s.elapsed_ms(e) for s, e in events]
+  gemm_avg_s = (sum(gemm_ms) / len(gemm_ms) / 1e3) if gemm_ms else float("nan")
+  achieved = flops_per_step / gemm_avg_s / 1e12 if gemm_ms else float("nan")
+
+  result = {
+      "metric": "contracted-elements/sec (TFLOP/s) + SVD GB/s, bond-dim sweep, 1/2/4/8 MI355X",
+      "value": flops_per_step * args.steps * world / elapsed / 1e12,
+      "unit": "TFLOP/s",
+      "n_gpus": world,
+      "steps": args.steps,
+      "warmup": args.warmup,
+      "ms_per_step": elapsed / args.steps * 1e3,
+      "higher_is_better": True,
+      "scaling": "weak",
+      "vs_baseline": None,
+      "dtype": "bf16",
+      "data": "synthetic" if args.fill == "normal" else "synthetic-zeros",
+      "config": {"workload": f"contract_between, two rank-4 bf16 nodes, bond D={D}, layout {args.layout} "
+                             f"(GEMM {M}x{N}x{K}, fp32 accumulate, bf16 out)",
+                 "parallelism": "1 GPU" if world == 1 else f"{world} independent pairwise contractions "
+                                                           "(no data-path collective)"},
+      "roofline": {"bound": "mfma", "achieved": achieved, "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                   "frac": achieved / BF16_MFMA_PEAK_TFLOPS, "traffic": None, "kernel": kernel_name,
+                   "kernel_ms": gemm_avg_s * 1e3, "launches": len(gemm_ms)},
+  }
+  if rank == 0:
+    if world == 1 and args.svd_n > 0:
+      del A, B
+      _lib.check(be.lib.tnh_trim())
+      result["svd"] = svd_bench(ta, be, args.svd_n, max(args.svd_n // 16, 1))
+    if world == 1 and not args.no_cpu_baseline:
+      result["cpu_baseline"] = cpu_baseline(args.layout)
+    print(json.dumps(result))
+  if dist is not None:
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+  main()

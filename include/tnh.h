@@ -186,6 +186,11 @@ int tnh_binary_scalar(int op, void* dst, const void* src, double re, double im,
 int tnh_fill(void* dst, double re, double im, int64_t n, int dtype);
 /* dst (rows x cols) = identity-like with ones on diagonal k = 0. */
 int tnh_eye(void* dst, int64_t rows, int64_t cols, int dtype);
+/* Synthetic operands generated in HBM (bench / large property tests only; the
+ * backend's randn reproduces NumPy's host stream instead): normal != 0 ->
+ * N(a, b^2), else uniform [a, b).  Counter-based, deterministic in (seed, i). */
+int tnh_random(void* dst, int64_t n, int dtype, uint64_t seed, int normal,
+               double a, double b);
 /* dst_i = (dst_dtype) src_i  (F32/F64/BF16/F16 among each other, C64<->C128,
  * real -> complex). */
 int tnh_cast(void* dst, int dst_dtype, const void* src, int src_dtype,

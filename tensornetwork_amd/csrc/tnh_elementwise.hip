@@ -245,6 +245,39 @@ __global__ __launch_bounds__(256) void eye_kernel(typename Tr<DT>::S* __restrict
   }
 }
 
+
+// Counter-based generator for synthetic benchmark operands (NOT the backend's
+// randn: that one reproduces NumPy's stream on the host).  splitmix64 of
+// (seed, index) -> two 24-bit uniforms -> Box-Muller.
+__device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
+  x += 0x9e3779b97f4a7c15ull;
+  x = (x ^ (x >> 30)) * 0xbf58476d1ce4e5b9ull;
+  x = (x ^ (x >> 27)) * 0x94d049bb133111ebull;
+  return x ^ (x >> 31);
+}
+
+template <int DT>
+__global__ __launch_bounds__(256) void random_kernel(typename Tr<DT>::S* __restrict__ dst, int64_t n,
+                                                     uint64_t seed, int normal, double a, double b) {
+  using C = typename Tr<DT>::C;
+  const int64_t step = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += step) {
+    const uint64_t h = splitmix64(seed * 0x100000001b3ull + (uint64_t)i);
+    const float u1 = ((float)((h >> 40) & 0xffffff) + 0.5f) * (1.0f / 16777216.0f);
+    const float u2 = ((float)((h >> 8) & 0xffffff) + 0.5f) * (1.0f / 16777216.0f);
+    double re, im = 0.0;
+    if (normal) {
+      const float r = sqrtf(-2.0f * logf(u1));
+      re = a + b * (double)(r * cosf(6.2831853071795864f * u2));
+      im = a + b * (double)(r * sinf(6.2831853071795864f * u2));
+    } else {
+      re = a + (b - a) * (double)u1;
+      im = a + (b - a) * (double)u2;
+    }
+    Tr<DT>::st(dst, i, from_scalar(C{}, re, im));
+  }
+}
+
 __device__ __forceinline__ double to_double(float x) { return (double)x; }
 __device__ __forceinline__ double to_double(double x) { return x; }
 
@@ -376,6 +409,14 @@ int tnh_binary(int op, void* dst, const void* a, const void* b, int rank, const 
     TNH_LAUNCH_CHECK();
     return TNH_OK;
   }
+  if (p.rank == 2 && p.sa[0] == p.shape[1] && p.sa[1] == 1 && p.sb[0] == 1 && p.sb[1] == 0) {
+    TNH_DISPATCH_FLOAT(dtype, hipLaunchKernelGGL((binary_rowcol_kernel<DT, false>), dim3(g), dim3(256), 0,
+                                                 stream(), op, (typename Tr<DT>::S*)dst,
+                                                 (const typename Tr<DT>::S*)a,
+                                                 (const typename Tr<DT>::S*)b, p.shape[0], p.shape[1], 0));
+    TNH_LAUNCH_CHECK();
+    return TNH_OK;
+  }
   if (p.rank == 0) {  // scalar (op) scalar
     p.rank = 1;
     p.shape[0] = 1;
@@ -424,6 +465,18 @@ int tnh_eye(void* dst, int64_t rows, int64_t cols, int dtype) {
   const unsigned g = grid_for(rows * cols);
   TNH_DISPATCH_FLOAT(dtype, hipLaunchKernelGGL((eye_kernel<DT>), dim3(g), dim3(256), 0, stream(),
                                                (typename Tr<DT>::S*)dst, rows, cols));
+  TNH_LAUNCH_CHECK();
+  return TNH_OK;
+}
+
+int tnh_random(void* dst, int64_t n, int dtype, uint64_t seed, int normal, double a, double b) {
+  TNH_NEED_INIT();
+  TNH_REQUIRE(n >= 0, "negative size");
+  if (n == 0) return TNH_OK;
+  TNH_REQUIRE(dst != nullptr, "null pointer");
+  const unsigned g = grid_for(n);
+  TNH_DISPATCH_FLOAT(dtype, hipLaunchKernelGGL((random_kernel<DT>), dim3(g), dim3(256), 0, stream(),
+                                               (typename Tr<DT>::S*)dst, n, seed, normal, a, b));
   TNH_LAUNCH_CHECK();
   return TNH_OK;
 }

@@ -223,8 +223,13 @@ class HipBackend(BackendBase):
     if out_code is None:
       out_code = _lib.F32 if (code in _HALF and self.half_output == "float32") else code
     out = DeviceTensor.empty(out_shape if out_shape is not None else (m, n), out_code)
+    events = getattr(self, "gemm_events", None)
+    if events is not None:  # bench.py: HIP events on the launch stream around the GEMM only
+      start = _lib.Event().record()
     _lib.check(self.lib.tnh_gemm(code, out_code, int(trans_a), int(trans_b), m, n, k, _vp(a), lda,
                                  _vp(b), ldb, _vp(out), n, batch, stride_a, stride_b, m * n), "tnh_gemm")
+    if events is not None:
+      events.append((start, _lib.Event().record()))
     return out
 
   @staticmethod
@@ -612,6 +617,17 @@ class HipBackend(BackendBase):
     else:
       host = np.random.uniform(lo, hi, shape).astype(dtype)
     return self.convert_to_tensor(np.asarray(host))
+
+  def device_random(self, shape, dtype=np.float32, seed=0, normal=True, a=0.0, b=1.0):
+    """Synthetic operand generated directly in HBM (benchmarks / large tests).
+
+    Not NumPy's stream -- use ``randn`` for reference-identical values."""
+    code = tnh_dtype(dtype)
+    self.lib  # pylint: disable=pointless-statement
+    out = DeviceTensor.empty(tuple(shape), code)
+    _lib.check(self.lib.tnh_random(_vp(out), out.size, code, int(seed), 1 if normal else 0, float(a),
+                                   float(b)), "tnh_random")
+    return out
 
   # ------------------------------------------------------------ diag helpers
   def diagflat(self, tensor, k=0):

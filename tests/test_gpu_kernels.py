@@ -1,0 +1,355 @@
+"""GPU parity tests, kernel level: every C-ABI kernel family against the CPU oracle
+on seeded inputs (bit-exact for layout work, stated tolerances for arithmetic).
+All calls go through HipBackend -> ctypes -> libtnhip.so."""
+import itertools
+
+import numpy as np
+import pytest
+
+import tensornetwork_amd as ta
+from tensornetwork_amd import _lib
+from oracle import numpy_oracle as orc
+import cases as C
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(hip, x, dtype=None):
+  if dtype is ta.bfloat16:
+    return hip.to_bfloat16(x)
+  return hip.convert_to_tensor(np.asarray(x))
+
+
+# ------------------------------------------------------------------ K1 permute
+def test_permute_golden_bit_exact(hip, golden):
+  for case in golden.cases["transpose"]:
+    out = np.asarray(C.run_transpose(hip, golden, case))
+    ref = golden[case["out"]]
+    assert out.dtype == ref.dtype and out.shape == ref.shape
+    assert out.tobytes() == ref.tobytes(), case
+
+
+@pytest.mark.parametrize("dtype", [np.float16, np.float32, np.float64, np.complex128, np.int32])
+def test_permute_all_perms_rank4(hip, dtype):
+  rng = np.random.default_rng(1)
+  shape = (5, 1, 18, 33)
+  x = rng.integers(-30000, 30000, size=shape).astype(dtype)
+  d = dev(hip, x)
+  for perm in itertools.permutations(range(4)):
+    out = np.asarray(hip.transpose(d, perm))
+    assert out.tobytes() == np.ascontiguousarray(np.transpose(x, perm)).tobytes(), perm
+
+
+@pytest.mark.parametrize("shape,perm", [
+    ((300, 200), (1, 0)), ((64, 48, 80), (2, 1, 0)), ((64, 48, 80), (1, 2, 0)), ((7, 130, 3, 70), (3, 2, 1, 0)),
+    ((16,) * 6, (0, 2, 4, 1, 3, 5)), ((2, 512, 2, 512), (3, 1, 2, 0)), ((1000, 3), (1, 0)), ((3, 1000), (1, 0)),
+    ((33, 65, 17), (0, 2, 1)), ((128, 128, 8), (1, 0, 2)),
+])
+@pytest.mark.parametrize("dtype", [np.float32, np.uint16, np.complex128])
+def test_permute_tiled_and_gather_paths(hip, shape, perm, dtype):
+  rng = np.random.default_rng(2)
+  if dtype is np.uint16:
+    x = rng.standard_normal(shape).astype(np.float32)
+    d = hip.to_bfloat16(x)
+    host = ta.round_to_bf16(x)
+  else:
+    x = (rng.standard_normal(shape) * 100).astype(dtype)
+    d = dev(hip, x)
+    host = x
+  out = np.asarray(hip.transpose(d, perm))
+  np.testing.assert_array_equal(out, np.transpose(host, perm))
+
+
+def test_slice_diagonal_diagflat_bit_exact(hip):
+  rng = np.random.default_rng(3)
+  x = rng.standard_normal((6, 7, 8)).astype(np.float32)
+  d = dev(hip, x)
+  np.testing.assert_array_equal(np.asarray(hip.slice(d, (1, 2, 3), (4, 3, 2))), x[1:5, 2:5, 3:5])
+  with pytest.raises(ValueError):
+    hip.slice(d, (1, 2), (1, 1, 1))
+  np.testing.assert_array_equal(np.asarray(d[2]), x[2])
+  np.testing.assert_array_equal(np.asarray(d[:, ::2, -1]), x[:, ::2, -1])
+  m = rng.standard_normal((3, 5, 6))
+  dm = dev(hip, m)
+  for off in (-2, 0, 1, 3):
+    np.testing.assert_array_equal(np.asarray(hip.diagonal(dm, offset=off)), np.diagonal(m, off, -2, -1))
+  np.testing.assert_array_equal(np.asarray(hip.diagonal(dm, axis1=0, axis2=2)), np.diagonal(m, 0, 0, 2))
+  v = rng.standard_normal(5)
+  for k in (0, 2, -1):
+    np.testing.assert_array_equal(np.asarray(hip.diagflat(dev(hip, v), k)), np.diagflat(v, k))
+  np.testing.assert_array_equal(np.asarray(hip.reshape(d, (-1, 8))), x.reshape(-1, 8))
+
+
+# --------------------------------------------------------------------- K2 GEMM
+def _gemm_case(hip, dtype, m, n, k, ta_, tb_, batch=None, variant="auto", rng=None):
+  """tensordot/matmul through the backend in the requested storage layout."""
+  rng = rng or np.random.default_rng(4)
+  bshape = () if batch is None else (batch,)
+  a_shape = bshape + ((k, m) if ta_ else (m, k))
+  b_shape = bshape + ((n, k) if tb_ else (k, n))
+  cplx = dtype in (np.complex64, np.complex128)
+  a = rng.standard_normal(a_shape) + (1j * rng.standard_normal(a_shape) if cplx else 0)
+  b = rng.standard_normal(b_shape) + (1j * rng.standard_normal(b_shape) if cplx else 0)
+  if dtype is ta.bfloat16:
+    a, b = orc.round_bf16(a), orc.round_bf16(b)
+    da, db = hip.to_bfloat16(a), hip.to_bfloat16(b)
+  else:
+    a, b = a.astype(dtype), b.astype(dtype)
+    da, db = dev(hip, a), dev(hip, b)
+  _lib.check(hip.lib.tnh_gemm_set_variant(variant.encode()))
+  try:
+    if batch is None:
+      out = hip.tensordot(da, db, [[0 if ta_ else 1], [1 if tb_ else 0]])
+    else:
+      ea = hip.transpose(da, (0, 2, 1)) if ta_ else da
+      eb = hip.transpose(db, (0, 2, 1)) if tb_ else db
+      out = hip.matmul(ea, eb)
+    kernel = hip.lib.tnh_gemm_last_kernel().decode()
+  finally:
+    _lib.check(hip.lib.tnh_gemm_set_variant(b"auto"))
+  a64 = a.astype(np.complex128 if cplx else np.float64)
+  b64 = b.astype(np.complex128 if cplx else np.float64)
+  ea = np.swapaxes(a64, -1, -2) if ta_ else a64
+  eb = np.swapaxes(b64, -1, -2) if tb_ else b64
+  ref = ea @ eb
+  return np.asarray(out), ref, kernel, np.sqrt(k)
+
+
+GEMM_TOL = {np.float32: 3e-6, np.float64: 1e-14, np.float16: 2e-3, ta.bfloat16: 1.6e-2,
+            np.complex64: 3e-6, np.complex128: 1e-14}
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64, np.float16, ta.bfloat16, np.complex64, np.complex128])
+@pytest.mark.parametrize("ta_,tb_", [(0, 0), (0, 1), (1, 0), (1, 1)])
+def test_gemm_all_layouts_ragged(hip, dtype, ta_, tb_):
+  for (m, n, k) in [(1, 1, 1), (5, 7, 3), (33, 65, 17), (130, 70, 129), (64, 64, 64), (257, 129, 40)]:
+    out, ref, kernel, sk = _gemm_case(hip, dtype, m, n, k, ta_, tb_)
+    # out is rounded to the storage dtype: tolerance = accumulate error + output rounding
+    tol = GEMM_TOL[dtype] * max(sk, 1.0)
+    np.testing.assert_allclose(out, ref, rtol=tol, atol=tol * np.sqrt(k), err_msg=f"{kernel} {m}x{n}x{k}")
+
+
+@pytest.mark.parametrize("variant", ["generic", "valu"])
+@pytest.mark.parametrize("dtype", [np.float32, np.float64, ta.bfloat16])
+def test_gemm_variants_agree(hip, variant, dtype):
+  out, ref, kernel, sk = _gemm_case(hip, dtype, 200, 136, 96, 0, 1, variant=variant)
+  tol = GEMM_TOL[dtype] * sk
+  np.testing.assert_allclose(out, ref, rtol=tol, atol=tol * np.sqrt(96))
+  assert ("valu" in kernel) == (variant == "valu")
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64, ta.bfloat16])
+def test_gemm_batched(hip, dtype):
+  out, ref, _, sk = _gemm_case(hip, dtype, 40, 24, 56, 0, 0, batch=5)
+  tol = GEMM_TOL[dtype] * sk
+  np.testing.assert_allclose(out, ref, rtol=tol, atol=tol * np.sqrt(56))
+
+
+@pytest.mark.parametrize("variant,expect", [("bf16_128", "bf16_nt_128x128x64"), ("bf16_256", "bf16_nt_256x256x64")])
+@pytest.mark.parametrize("dtype", [ta.bfloat16, np.float16])
+@pytest.mark.parametrize("m,n,k", [(128, 128, 64), (256, 256, 128), (512, 384, 256), (200, 136, 192), (1024, 768, 512)])
+def test_gemm_bf16_speed_path(hip, variant, expect, dtype, m, n, k):
+  """LDS-DMA + swizzled ds_read + 16x16x32 MFMA path; asymmetric random operands
+  (catch row/col swaps), ragged M/N edges, both tile sizes."""
+  out, ref, kernel, sk = _gemm_case(hip, dtype, m, n, k, 0, 1, variant=variant, rng=np.random.default_rng(m + n + k))
+  assert kernel == expect
+  tol = GEMM_TOL[dtype]
+  np.testing.assert_allclose(out, ref, rtol=tol, atol=tol * np.sqrt(k))
+
+
+def test_gemm_bf16_fp32_output_is_tighter(hip):
+  rng = np.random.default_rng(9)
+  a = orc.round_bf16(rng.standard_normal((256, 512)))
+  b = orc.round_bf16(rng.standard_normal((384, 512)))
+  be32 = ta.HipBackend(half_output="float32")
+  out = be32.tensordot(hip.to_bfloat16(a), hip.to_bfloat16(b), [[1], [1]])
+  assert out.dtype == np.float32
+  assert hip.lib.tnh_gemm_last_kernel().decode().startswith("bf16_nt")
+  ref = a.astype(np.float64) @ b.astype(np.float64).T
+  np.testing.assert_allclose(np.asarray(out), ref, rtol=2e-5, atol=2e-5 * np.sqrt(512))
+
+
+def test_gemm_bf16_auto_dispatch_uses_speed_path(hip):
+  rng = np.random.default_rng(10)
+  a = hip.to_bfloat16(rng.standard_normal((512, 256)))
+  b = hip.to_bfloat16(rng.standard_normal((256, 512)))   # KN storage: host permutes once, then NT kernel
+  out = hip.tensordot(a, b, 1)
+  assert hip.lib.tnh_gemm_last_kernel().decode().startswith("bf16_nt")
+  ref = np.asarray(a).astype(np.float64) @ np.asarray(b).astype(np.float64)
+  np.testing.assert_allclose(np.asarray(out), ref, rtol=1.6e-2, atol=1.6e-2 * 16)
+
+
+def test_tensordot_golden(hip, golden):
+  for case in golden.cases["tensordot"]:
+    C.assert_close(C.run_tensordot(hip, golden, case), golden[case["out"]])
+
+
+def test_tensordot_errors_and_empty(hip):
+  a, b = dev(hip, np.ones((2, 3))), dev(hip, np.ones((3, 2)))
+  with pytest.raises(ValueError, match="shape-mismatch for sum"):
+    hip.tensordot(a, b, [[0, 1], [0]])
+  with pytest.raises(ValueError, match="shape-mismatch for sum"):
+    hip.tensordot(a, b, [[0], [0]])
+  z = hip.tensordot(dev(hip, np.ones((4, 0))), dev(hip, np.ones((0, 5))), 1)
+  np.testing.assert_array_equal(np.asarray(z), np.zeros((4, 5)))
+  e = hip.tensordot(dev(hip, np.ones((0, 3))), dev(hip, np.ones((3, 5))), 1)
+  assert e.shape == (0, 5)
+  with pytest.raises(ValueError):
+    hip.matmul(dev(hip, np.ones(3)), dev(hip, np.ones((3, 3))))
+  with pytest.raises(TypeError):
+    hip.convert_to_tensor([1, 2, 3])
+
+
+# --------------------------------------------------------- K3-K6 helper kernels
+def test_misc_golden(hip, golden):
+  for case in golden.cases["misc"]:
+    res = C.run_misc(hip, golden, case)
+    for name, val in res.items():
+      C.assert_close(val, golden[case[name]])
+    x = dev(hip, golden[case["x"]])
+    v = dev(hip, golden[case["v"]])
+    C.assert_close(hip.norm(x), golden[case["norm"]])
+    C.assert_close(hip.sqrt(hip.abs(x)), golden[case["sqrtabs"]])
+    C.assert_close(hip.subtraction(x, v), golden[case["sub"]])
+    C.assert_close(hip.divide(x, v), golden[case["div"]])
+    C.assert_close(hip.diagonal(dev(hip, golden[case["m"]])), golden[case["diagonal"]])
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64, ta.bfloat16, np.complex128])
+def test_reductions_large(hip, dtype):
+  rng = np.random.default_rng(5)
+  x = rng.standard_normal((37, 1000, 19))
+  if dtype is np.complex128:
+    x = x + 1j * rng.standard_normal(x.shape)
+  if dtype is ta.bfloat16:
+    x = orc.round_bf16(x)
+    d = hip.to_bfloat16(x)
+    tol = dict(rtol=1e-2, atol=0.5)
+  else:
+    x = x.astype(dtype)
+    d = dev(hip, x)
+    tol = dict(rtol=1e-4, atol=1e-3) if dtype is np.float32 else dict(rtol=1e-12, atol=1e-10)
+  x64 = x.astype(np.complex128 if np.iscomplexobj(x) else np.float64)
+  for axis in [(0,), (1,), (2,), (0, 1), (1, 2), (0, 2), (0, 1, 2)]:
+    np.testing.assert_allclose(np.asarray(hip.sum(d, axis)), x64.sum(axis), **tol)
+  np.testing.assert_allclose(np.asarray(hip.sum(d, (1,), keepdims=True)), x64.sum(1, keepdims=True), **tol)
+  np.testing.assert_allclose(np.asarray(hip.norm(d)), np.linalg.norm(x64), rtol=tol["rtol"])
+  big = rng.standard_normal(3_000_001).astype(np.float32)
+  np.testing.assert_allclose(np.asarray(hip.sum(dev(hip, big), (0,))), big.astype(np.float64).sum(), rtol=1e-5, atol=1e-2)
+  t = rng.standard_normal((3, 2050, 2050)).astype(np.float32)
+  np.testing.assert_allclose(np.asarray(hip.trace(dev(hip, t))), np.trace(t.astype(np.float64), axis1=-2, axis2=-1),
+                             rtol=1e-5, atol=1e-3)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64, np.complex64, np.complex128])
+def test_elementwise_math(hip, dtype):
+  rng = np.random.default_rng(6)
+  x = rng.standard_normal((11, 13)) + 0.5
+  if np.dtype(dtype).kind == "c":
+    x = x + 1j * rng.standard_normal(x.shape)
+  x = x.astype(dtype)
+  d = dev(hip, x)
+  rt = 3e-6 if np.dtype(dtype).itemsize in (4, 8) and np.dtype(dtype) != np.float64 else 1e-13
+  for name, fn in [("sqrt", np.sqrt), ("exp", np.exp), ("log", np.log), ("sin", np.sin), ("cos", np.cos),
+                   ("abs", np.abs), ("sign", np.sign), ("conj", np.conj)]:
+    with np.errstate(all="ignore"):
+      ref = fn(x.astype(np.complex128) if np.dtype(dtype).kind == "c" else np.abs(x.astype(np.float64))
+               if name in ("sqrt", "log") else x.astype(np.float64))
+    arg = d if not (name in ("sqrt", "log") and np.dtype(dtype).kind != "c") else hip.abs(d)
+    np.testing.assert_allclose(np.asarray(getattr(hip, name)(arg)), ref, rtol=rt, atol=rt, err_msg=name)
+  np.testing.assert_allclose(np.asarray(d * 2.5 - d / 4 + 1.0), x * 2.5 - x / 4 + 1.0, rtol=rt, atol=rt)
+  np.testing.assert_allclose(np.asarray(3.0 / (d + 5.0)), 3.0 / (x + 5.0), rtol=rt, atol=rt)
+  np.testing.assert_allclose(np.asarray(hip.power(hip.abs(d), 1.5)), np.abs(x) ** 1.5, rtol=10 * rt, atol=rt)
+  y = rng.standard_normal((13,)).astype(dtype)
+  np.testing.assert_allclose(np.asarray(d + dev(hip, y)), x + y, rtol=rt, atol=rt)
+  np.testing.assert_allclose(np.asarray(dev(hip, y.reshape(1, 13)) * d), y * x, rtol=rt, atol=rt)
+  with pytest.raises(ValueError):
+    hip.addition(d, dev(hip, np.ones((4, 4), dtype=dtype)))
+  with pytest.raises(ValueError):
+    hip.broadcast_right_multiplication(d, d)
+  with pytest.raises(ValueError):
+    hip.broadcast_left_multiplication(d, d)
+
+
+def test_init_functions(hip):
+  np.testing.assert_array_equal(np.asarray(hip.eye(4, dtype=np.float32, M=6)), np.eye(4, 6, dtype=np.float32))
+  np.testing.assert_array_equal(np.asarray(hip.ones((2, 3), np.complex128)), np.ones((2, 3), np.complex128))
+  np.testing.assert_array_equal(np.asarray(hip.zeros((2, 3))), np.zeros((2, 3)))
+  a = np.asarray(hip.randn((4, 5), dtype=np.float64, seed=10))
+  np.random.seed(10)
+  np.testing.assert_array_equal(a, np.random.randn(4, 5))  # same stream as the NumPy backend
+  u = np.asarray(hip.random_uniform((100,), (-2, 3), dtype=np.float32, seed=3))
+  assert u.min() >= -2 and u.max() <= 3
+  s = hip.serialize_tensor(dev(hip, a))
+  np.testing.assert_array_equal(np.asarray(hip.deserialize_tensor(s)), a)
+  assert hip.item(hip.convert_to_tensor(3.5)) == 3.5
+  assert hip.eps(np.float32) == np.finfo(np.float32).eps
+
+
+def test_casts(hip):
+  rng = np.random.default_rng(7)
+  x = rng.standard_normal(1000).astype(np.float32)
+  d = dev(hip, x)
+  np.testing.assert_array_equal(np.asarray(hip.cast(d, ta.bfloat16)), orc.round_bf16(x))  # device RNE == host RNE
+  np.testing.assert_array_equal(np.asarray(hip.cast(d, np.float16)), x.astype(np.float16))
+  np.testing.assert_array_equal(np.asarray(hip.cast(d, np.float64)), x.astype(np.float64))
+  np.testing.assert_array_equal(np.asarray(hip.cast(d, np.complex64)), x.astype(np.complex64))
+
+
+# --------------------------------------------------------------------- K7 SVD
+def _check_svd(hip, a, rtol_s, otol, **kw):
+  u, s, vh, rest = hip.svd(dev(hip, a), 1, **kw)
+  u, s, vh, rest = (np.asarray(t) for t in (u, s, vh, rest))
+  ur, sr, vhr, restr = orc.svd(a.astype(np.float64), 1, **kw)
+  s0 = max(float(sr[0]) if sr.size else 0.0, float(np.abs(a).max()), 1e-30)
+  assert s.shape == sr.shape and rest.shape == restr.shape and u.shape == ur.shape and vh.shape == vhr.shape
+  np.testing.assert_allclose(s, sr, rtol=0, atol=rtol_s * s0)
+  np.testing.assert_allclose(rest, restr, rtol=0, atol=rtol_s * s0)
+  k = s.size
+  if k:
+    np.testing.assert_allclose(u.T @ u, np.eye(k), atol=otol)
+    np.testing.assert_allclose(vh @ vh.T, np.eye(k), atol=otol)
+    approx = (u * s) @ vh
+    best = (ur * sr) @ vhr
+    assert np.linalg.norm(approx - best) <= 10 * otol * max(np.linalg.norm(a), 1e-30)
+  return u, s, vh, rest
+
+
+@pytest.mark.parametrize("dtype,rtol_s,otol", [(np.float32, 1e-5, 1e-4), (np.float64, 1e-13, 1e-12)])
+@pytest.mark.parametrize("shape", [(1, 1), (2, 9), (9, 2), (17, 17), (64, 48), (48, 64), (130, 131), (257, 40)])
+def test_svd_random(hip, dtype, rtol_s, otol, shape):
+  rng = np.random.default_rng(shape[0] * 1000 + shape[1])
+  a = rng.standard_normal(shape).astype(dtype)
+  _check_svd(hip, a, rtol_s, otol)
+  _check_svd(hip, a, rtol_s, otol, max_singular_values=max(1, min(shape) // 3))
+  _check_svd(hip, a, rtol_s, otol, max_truncation_error=0.3, relative=True)
+
+
+@pytest.mark.parametrize("dtype,rtol_s,otol", [(np.float32, 1e-5, 1e-4), (np.float64, 1e-13, 1e-12)])
+def test_svd_rank_deficient_and_zero(hip, dtype, rtol_s, otol):
+  rng = np.random.default_rng(8)
+  b = (rng.standard_normal((40, 6)) @ rng.standard_normal((6, 30))).astype(dtype)
+  b[:, 3] = 0
+  b[7, :] = 0
+  _check_svd(hip, b, 20 * rtol_s, 20 * otol)
+  z = np.zeros((12, 20), dtype=dtype)
+  u, s, vh, _ = _check_svd(hip, z, rtol_s, otol)
+  assert np.all(s == 0)
+  d = np.diag([2.0, 1.0, 0.2, 0.1]).astype(dtype)  # decompositions_test.py:92-108
+  _, _, _, trunc = hip.svd(dev(hip, d), 1, max_truncation_error=0.2, relative=False)
+  np.testing.assert_allclose(np.asarray(trunc), [0.1], rtol=1e-5)
+  _, _, _, trunc = hip.svd(dev(hip, d), 1, max_truncation_error=0.2, relative=True)
+  np.testing.assert_allclose(np.asarray(trunc), [0.2, 0.1], rtol=1e-5)
+
+
+def test_svd_prescribed_spectrum_512(hip):
+  # SURVEY 8d config-3 input (ii): s_i = 2^(-i/32), Haar factors
+  rng = np.random.default_rng(4)
+  n = 512
+  q1, _ = np.linalg.qr(rng.standard_normal((n, n)))
+  q2, _ = np.linalg.qr(rng.standard_normal((n, n)))
+  spec = 2.0 ** (-np.arange(n) / 32)
+  a = ((q1 * spec) @ q2).astype(np.float32)
+  u, s, vh, rest = _check_svd(hip, a, 1e-5, 1e-4, max_singular_values=n // 16)
+  np.testing.assert_allclose(s, spec[:n // 16], rtol=1e-4)
+  np.testing.assert_allclose(rest, spec[n // 16:], atol=1e-5)

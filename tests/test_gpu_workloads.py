@@ -1,0 +1,180 @@
+"""GPU parity tests, workload level: ncon / contract_between / split_node /
+contractors through HipBackend against (a) the golden outputs of the reference,
+(b) the CPU oracle on seeded inputs, (c) size-independent properties at the
+BASELINE.json sizes where a full CPU check would take too long."""
+import numpy as np
+import pytest
+
+import tensornetwork_amd as ta
+from tensornetwork_amd import contractors, network
+from oracle import numpy_oracle as orc
+import cases as C
+
+pytestmark = pytest.mark.gpu
+
+
+def test_ncon_golden(hip, golden):
+  for case in golden.cases["ncon"]:
+    C.assert_close(C.run_ncon(hip, golden, case), golden[case["out"]])
+
+
+def test_contract_between_golden(hip, golden):
+  for case in golden.cases["contract_between"]:
+    C.assert_close(C.run_contract_between(hip, golden, case), golden[case["out"]])
+
+
+def test_split_node_golden(hip, golden):
+  for case in golden.cases["split_node"]:
+    left, right, trun, recon = C.run_split(hip, golden, case)
+    assert list(left.shape) == case["left_shape"], case["x"]
+    assert list(right.shape) == case["right_shape"], case["x"]
+    x = golden[case["x"]]
+    scale = float(np.max(np.abs(x))) * np.sqrt(x.size) + 1e-30
+    C.assert_close(trun, golden[case["trun"]], scale=scale)
+    C.assert_close(recon, golden[case["recon"]], scale=scale)
+
+
+def test_contractors_golden(hip, golden):
+  for case in golden.cases["contractors"]:
+    C.assert_close(C.run_contractor(hip, golden, case), golden[case["out"]])
+
+
+def test_config1_readme_ncon(hip):
+  # BASELINE config 1 on the new backend: exact
+  a = np.ones((10, 10))
+  out = ta.ncon([a, a], [(-1, 1), (1, -2)], backend=hip)
+  np.testing.assert_array_equal(np.asarray(out), 10 * np.ones((10, 10)))
+
+
+def _config2(hip, D, layout, seed=2):
+  """two rank-4 bf16 nodes, two shared bonds of dimension D."""
+  rng = np.random.default_rng(seed)
+  A = orc.round_bf16(rng.standard_normal((D,) * 4) / D)
+  B = orc.round_bf16(rng.standard_normal((D,) * 4) / D)
+  a = network.Node(hip.to_bfloat16(A), backend=hip)
+  b = network.Node(hip.to_bfloat16(B), backend=hip)
+  conn = [(2, 0), (3, 1)] if layout == "L0" else [(1, 2), (3, 0)]
+  for x, y in conn:
+    network.connect(a[x], b[y])
+  out = network.contract_between(a, b)
+  return A, B, conn, out
+
+
+@pytest.mark.parametrize("layout", ["L0", "L1"])
+@pytest.mark.parametrize("D", [16, 32])
+def test_config2_bf16_contract_between_full_check(hip, D, layout):
+  A, B, conn, out = _config2(hip, D, layout)
+  ref = np.tensordot(A.astype(np.float64), B.astype(np.float64), [[c[0] for c in conn], [c[1] for c in conn]])
+  got = np.asarray(out.tensor)
+  assert got.shape == ref.shape
+  # bf16 output: half an ulp (2^-9) of the value + fp32 accumulation noise
+  np.testing.assert_allclose(got, ref, rtol=2.0**-8, atol=2.0**-8 * np.abs(ref).max() * 0.05 + 1e-6)
+  if D >= 32:
+    assert hip.lib.tnh_gemm_last_kernel().decode().startswith("bf16_nt"), "MFMA speed path not taken"
+
+
+@pytest.mark.parametrize("layout", ["L0", "L1"])
+def test_config2_bf16_D64_sampled_entries(hip, layout):
+  D = 64
+  A, B, conn, out = _config2(hip, D, layout)
+  got = np.asarray(out.tensor)
+  rng = np.random.default_rng(0)
+  A64, B64 = A.astype(np.float64), B.astype(np.float64)
+  free_a = [i for i in range(4) if i not in [c[0] for c in conn]]
+  free_b = [i for i in range(4) if i not in [c[1] for c in conn]]
+  for _ in range(1024):
+    ia, ib = rng.integers(0, D, 2), rng.integers(0, D, 2)
+    sa = [slice(None)] * 4
+    sb = [slice(None)] * 4
+    for ax, v in zip(free_a, ia):
+      sa[ax] = int(v)
+    for ax, v in zip(free_b, ib):
+      sb[ax] = int(v)
+    va, vb = A64[tuple(sa)], B64[tuple(sb)]     # remaining axes: the contracted ones, in axis order
+    ids_a = [int(i) for i in np.argsort([c[0] for c in conn])]   # pair id carried by each axis of va
+    ids_b = [int(i) for i in np.argsort([c[1] for c in conn])]
+    ref = float(np.einsum(va, ids_a, vb, ids_b))
+    val = got[tuple(ia) + tuple(ib)]
+    assert abs(val - ref) <= 2.0**-8 * abs(ref) + 2e-4, (ia, ib, val, ref)
+  assert hip.lib.tnh_gemm_last_kernel().decode().startswith("bf16_nt")
+
+
+def test_tensordot_linearity_and_identity_large(hip):
+  """Size-independent properties at a GEMM size the CPU oracle would need minutes for."""
+  rng = np.random.default_rng(11)
+  M = N = K = 4096
+  a = hip.to_bfloat16(rng.standard_normal((M, K)).astype(np.float32))
+  eye = hip.cast(hip.eye(K, dtype=np.float32), ta.bfloat16)
+  out = hip.tensordot(a, eye, [[1], [1]])          # A . I^T == A exactly (one nonzero product per output)
+  assert hip.lib.tnh_gemm_last_kernel().decode().startswith("bf16_nt")
+  np.testing.assert_array_equal(np.asarray(out), np.asarray(a))
+  # linearity in fp32: (2A).B == 2(A.B) exactly (power-of-two scaling commutes with rounding)
+  b = hip.to_bfloat16(rng.standard_normal((N, K)).astype(np.float32))
+  c1 = np.asarray(hip.tensordot(a * 2.0, b, [[1], [1]]))
+  c2 = np.asarray(hip.tensordot(a, b, [[1], [1]]))
+  np.testing.assert_array_equal(c1, 2.0 * c2)
+  # a few sampled entries against fp64 dot products
+  ah, bh = np.asarray(a).astype(np.float64), np.asarray(b).astype(np.float64)
+  for i, j in rng.integers(0, 4096, (64, 2)):
+    ref = ah[i] @ bh[j]
+    assert abs(c2[i, j] - ref) <= 2.0**-8 * abs(ref) + 0.05
+
+
+def test_split_node_config3_small(hip):
+  """Config 3 at n = 256 (rank-6 node (4,)*6 ... scaled): mixed edge order + truncation."""
+  rng = np.random.default_rng(3)
+  x = rng.standard_normal((4,) * 8).astype(np.float32)  # 256 x 256 after the split
+  node = network.Node(x, backend=hip)
+  left_axes, right_axes = [0, 2, 4, 6], [1, 3, 5, 7]
+  k = 16
+  left, right, trun = network.split_node(node, [node[i] for i in left_axes], [node[i] for i in right_axes],
+                                         max_singular_values=k)
+  mat = np.transpose(x, left_axes + right_axes).reshape(256, 256).astype(np.float64)
+  u, s, vh = np.linalg.svd(mat)
+  np.testing.assert_allclose(np.asarray(trun), s[k:], atol=1e-5 * s[0])
+  assert left.shape == (4, 4, 4, 4, k) and right.shape == (k, 4, 4, 4, 4)
+  recon = np.asarray(network.contract_between(left, right).tensor).reshape(256, 256)
+  best = (u[:, :k] * s[:k]) @ vh[:k]
+  assert np.linalg.norm(recon - best) <= 1e-4 * np.linalg.norm(mat)
+
+
+def test_greedy_mps_chain_and_regular_graph(hip):
+  """Config-4 topology (MPS overlap) and the north-star random regular network, small bond."""
+  rng = np.random.default_rng(5)
+  n_sites, d, D = 10, 2, 16
+  dims = [1] + [D] * (n_sites - 1) + [1]
+  kets = [(rng.standard_normal((dims[i], d, dims[i + 1])) / np.sqrt(d * D)).astype(np.float32) for i in range(n_sites)]
+
+  def build(be):
+    nk = [network.Node(k, backend=be) for k in kets]
+    nb = [network.Node(np.conj(k), backend=be) for k in kets]
+    for i in range(n_sites):
+      network.connect(nk[i][1], nb[i][1])
+      if i + 1 < n_sites:
+        network.connect(nk[i][2], nk[i + 1][0])
+        network.connect(nb[i][2], nb[i + 1][0])
+    network.connect(nk[0][0], nb[0][0])
+    network.connect(nk[-1][2], nb[-1][2])
+    return nk + nb
+
+  got = np.asarray(contractors.greedy(build(hip)).tensor)
+  ref = contractors.greedy(build(orc.OracleBackend())).tensor
+  np.testing.assert_allclose(got, ref, rtol=1e-4)
+
+
+def test_reference_library_dropin_if_available(hip):
+  """When google/TensorNetwork itself is importable, drive IT with backend='hip'."""
+  tn = pytest.importorskip("tensornetwork")
+  assert "hip" in tn.backends.backend_factory._BACKENDS  # pylint: disable=protected-access
+  rng = np.random.default_rng(1)
+  a_val, b_val = rng.standard_normal((4, 5, 6)), rng.standard_normal((6, 5, 7))
+  a, b = tn.Node(a_val, backend="hip"), tn.Node(b_val, backend="hip")
+  a[2] ^ b[0]  # pylint: disable=pointless-statement
+  a[1] ^ b[1]  # pylint: disable=pointless-statement
+  c = a @ b
+  np.testing.assert_allclose(np.asarray(c.tensor), np.tensordot(a_val, b_val, [[2, 1], [0, 1]]), rtol=1e-12)
+  out = tn.ncon([a_val, b_val], [[-1, 1, 2], [2, 1, -2]], backend="hip")
+  np.testing.assert_allclose(np.asarray(out), np.tensordot(a_val, b_val, [[2, 1], [0, 1]]), rtol=1e-12)
+  n = tn.Node(rng.standard_normal((4, 5, 6)), backend="hip")
+  l, r, _ = tn.split_node(n, [n[0], n[1]], [n[2]])
+  np.testing.assert_allclose(np.asarray((l @ r).tensor), np.asarray(n.tensor), atol=1e-10)
