@@ -1,0 +1,185 @@
+"""Multi-GPU contraction by bond slicing (one process per GPU, RCCL over xGMI).
+
+The reference has no distributed path at all; its own primitive for restricting
+a bond to a sub-range is ``slice_edge`` (``network_components.py:1636-1682``).
+Fixing the values of ``s`` contracted bonds of dimensions ``d_1..d_s`` turns one
+network into ``d_1*...*d_s`` independent networks of identical topology whose
+results add up.  That is the natural partition of a contractor path:
+
+  * the pairwise order is searched ONCE on the sliced topology (host),
+  * slices are dealt round-robin to ranks; every rank contracts its slices with
+    the same path on its own GPU and accumulates the partial result locally,
+  * ONE all-reduce(sum) of the (small) result tensor finishes the job -- the
+    only data-path collective, and only because the partition has a genuine
+    exchange step.  On GPUs it is RCCL (torch.distributed backend "nccl"), in
+    the CPU test-suite it is gloo.
+
+Networks that do not partition (MPS chains zipped from a boundary, a single
+SVD) are run as independent replicas instead -- see bench.py.
+"""
+import itertools
+from typing import Callable, Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from tensornetwork_amd import contractors, network, pathfinder
+
+
+# ------------------------------------------------------------------ collectives
+class LocalComm:
+  """Single-process stand-in (world size 1)."""
+  rank, world = 0, 1
+
+  def all_reduce_sum(self, backend, tensor):  # pylint: disable=unused-argument
+    return tensor
+
+
+class TorchDistComm:
+  """all-reduce through an initialised ``torch.distributed`` process group.
+
+  GPU tensors of the hip backend are handed to RCCL zero-copy through
+  ``__cuda_array_interface__``; NumPy tensors (oracle backend, gloo) go through
+  ``torch.from_numpy``."""
+
+  def __init__(self):
+    import torch.distributed as dist  # pylint: disable=import-outside-toplevel
+    if not dist.is_initialized():
+      raise RuntimeError("torch.distributed process group is not initialised")
+    self._dist = dist
+    self.rank = dist.get_rank()
+    self.world = dist.get_world_size()
+
+  def all_reduce_sum(self, backend, tensor):
+    import torch  # pylint: disable=import-outside-toplevel
+    from tensornetwork_amd.device_tensor import DeviceTensor  # pylint: disable=import-outside-toplevel
+    if isinstance(tensor, DeviceTensor):
+      work = tensor
+      if tensor.dtype not in (np.dtype(np.float32), np.dtype(np.float64)):
+        work = backend.cast(tensor, np.float32)   # bf16/f16 partial sums travel as fp32
+      backend.synchronize()                        # our stream -> visible to RCCL's stream
+      view = torch.as_tensor(_CudaView(work), device=f"cuda:{torch.cuda.current_device()}")
+      self._dist.all_reduce(view, op=self._dist.ReduceOp.SUM)
+      torch.cuda.synchronize()
+      return work if work is tensor else backend.cast(work, tensor.dtype)
+    host = np.ascontiguousarray(np.asarray(tensor))
+    t = torch.from_numpy(host.reshape(-1).copy() if host.ndim == 0 else host.copy())
+    self._dist.all_reduce(t, op=self._dist.ReduceOp.SUM)
+    return t.numpy().reshape(host.shape)
+
+
+class _CudaView:
+  """Exposes a DeviceTensor through ``__cuda_array_interface__`` (zero-copy)."""
+
+  def __init__(self, tensor):
+    self._keep = tensor
+    self.__cuda_array_interface__ = {
+        "shape": tuple(tensor.shape) if tensor.shape else (1,),
+        "typestr": np.dtype(tensor.dtype).str,
+        "data": (tensor.ptr, False),
+        "version": 2,
+        "strides": None,
+    }
+
+
+# ---------------------------------------------------------------- slice planning
+def _index_problem(nodes: Sequence[network.Node]):
+  inputs = [set(n.edges) for n in nodes]
+  output = network.get_subgraph_dangling(nodes)
+  sizes = {e: e.dimension for e in network.get_all_edges(nodes)}
+  return inputs, output, sizes
+
+
+def choose_cut_edges(nodes: Sequence[network.Node], min_slices: int,
+                     algorithm: Callable = pathfinder.greedy) -> List[network.Edge]:
+  """Pick contracted edges to slice until there are >= min_slices slices.
+
+  Greedy rule: cut the edge whose removal (dimension -> 1) gives the cheapest
+  re-searched path; this keeps the redundant work introduced by slicing small."""
+  inputs, output, sizes = _index_problem(nodes)
+  sizes = dict(sizes)
+  cuts: List[network.Edge] = []
+  n_slices = 1
+  # deterministic candidate order (every rank must pick the same cuts): by the
+  # position of the edge's first end in `nodes`
+  pos = {id(n): i for i, n in enumerate(nodes)}
+  def edge_key(e):
+    return min((pos[id(nd)], ax) for nd, ax in e.ends())
+  candidates = sorted((e for e in sizes if e not in output and not e.is_trace() and sizes[e] > 1),
+                      key=edge_key)
+  while n_slices < min_slices and candidates:
+    best = None
+    for e in candidates:
+      trial = dict(sizes)
+      trial[e] = 1
+      path = algorithm(inputs, output, trial)
+      flops, peak = pathfinder.path_cost(inputs, output, trial, path)
+      key = (flops * sizes[e], peak)   # total work over all slices of this edge, then memory
+      if best is None or key < best[0]:
+        best = (key, e)   # strict '<': first candidate wins ties
+    e = best[1]
+    cuts.append(e)
+    n_slices *= sizes[e]
+    sizes[e] = 1
+    candidates.remove(e)
+  return cuts
+
+
+def contract_sliced(nodes: Sequence[network.Node], cut_edges: Sequence[network.Edge],
+                    comm=None, algorithm: Callable = pathfinder.greedy,
+                    output_edge_order: Optional[Sequence[network.Edge]] = None):
+  """Contract `nodes` by summing over all index values of `cut_edges`.
+
+  Returns the backend tensor of the full contraction (identical on every rank).
+  `output_edge_order` refers to edges of the ORIGINAL network."""
+  comm = comm or LocalComm()
+  nodes = list(nodes)
+  cut_edges = list(cut_edges)
+  for e in cut_edges:
+    if e.is_dangling():
+      raise ValueError("only contracted (non-dangling) edges can be sliced")
+  be = nodes[0].backend
+  dims = [e.dimension for e in cut_edges]
+  all_slices = list(itertools.product(*[range(d) for d in dims])) if cut_edges else [()]
+
+  # path on the sliced topology (cut bonds have dimension 1), searched once
+  inputs, output, sizes = _index_problem(nodes)
+  sliced_sizes = dict(sizes)
+  for e in cut_edges:
+    sliced_sizes[e] = 1
+  path = algorithm(inputs, output, sliced_sizes)
+
+  total = None
+  for idx in all_slices[comm.rank::comm.world]:
+    node_map, edge_map = network.copy(nodes)
+    for e, i in zip(cut_edges, idx):
+      network.slice_edge(edge_map[e], i, 1)
+    order = [edge_map[e] for e in output_edge_order] if output_edge_order is not None else None
+    part = contractors.contract_path(path, [node_map[n] for n in nodes], order).tensor
+    total = part if total is None else be.addition(total, part)
+  if total is None:
+    # this rank got no slice: contribute zeros of the right shape/dtype
+    node_map, edge_map = network.copy(nodes)
+    for e in cut_edges:
+      network.slice_edge(edge_map[e], 0, 1)
+    order = [edge_map[e] for e in output_edge_order] if output_edge_order is not None else None
+    part = contractors.contract_path(path, [node_map[n] for n in nodes], order).tensor
+    total = be.multiply(part, 0.0)
+  return comm.all_reduce_sum(be, total)
+
+
+def slicing_report(nodes: Sequence[network.Node], cut_edges: Sequence[network.Edge],
+                   algorithm: Callable = pathfinder.greedy) -> Dict[str, float]:
+  """Cost model of a slicing plan (host only): flops and peak intermediate, sliced vs unsliced."""
+  inputs, output, sizes = _index_problem(nodes)
+  path0 = algorithm(inputs, output, sizes)
+  flops0, peak0 = pathfinder.path_cost(inputs, output, sizes, path0)
+  sliced = dict(sizes)
+  n_slices = 1
+  for e in cut_edges:
+    n_slices *= sizes[e]
+    sliced[e] = 1
+  path1 = algorithm(inputs, output, sliced)
+  flops1, peak1 = pathfinder.path_cost(inputs, output, sliced, path1)
+  return {"n_slices": n_slices, "flops_unsliced": float(flops0), "peak_unsliced": float(peak0),
+          "flops_per_slice": float(flops1), "peak_per_slice": float(peak1),
+          "overhead": float(flops1) * n_slices / max(float(flops0), 1.0)}
