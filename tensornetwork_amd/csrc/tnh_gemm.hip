@@ -294,7 +294,7 @@ __global__ __launch_bounds__(256) void gemm_valu_kernel(GemmArgs g) {
 }
 
 static thread_local const char* g_last_kernel = "none";
-static int g_variant = 0;  // 0 auto, 1 generic (mfma), 2 valu, 3 bf16_128, 4 bf16_256
+static int g_variant = 0;  // 0 auto, 1 generic (mfma), 2 valu, 3 bf16_128, 4 bf16_256, 5 bf16_256pp
 
 template <typename F>
 static int launch_batched(F launch, const GemmArgs& g0, int64_t batch, int BM, int BN) {
@@ -325,6 +325,7 @@ int tnh_gemm_set_variant(const char* name) {
   else if (!strcmp(name, "valu")) g_variant = 2;
   else if (!strcmp(name, "bf16_128")) g_variant = 3;
   else if (!strcmp(name, "bf16_256")) g_variant = 4;
+  else if (!strcmp(name, "bf16_256pp")) g_variant = 5;
   else {
     set_error("unknown gemm variant '%s'", name);
     return TNH_ERR_INVALID;

@@ -28,6 +28,8 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
+static bool g_pp_default = true;  // ping-pong kernel won the A/B on MI355X (profiles/r01_sweep_v2.jsonl)
+
 struct NtArgs {
   const uint16_t* A;
   const uint16_t* B;
@@ -85,6 +87,43 @@ __device__ __forceinline__ void tile_of_block(int bid, int tiles_m, int tiles_n,
   const int in_group = pid - group * per_group;
   tm = first_m + in_group % gsize;
   tn = in_group / gsize;
+}
+
+// Epilogue shared by the speed-path kernels.  With the swapped-operand MFMA a
+// lane holds C[m = l & 15][n = 4*(l >> 4) .. +3] of each 16x16 tile: 8-B (bf16 /
+// f16) or 16-B (f32) stores, 64 contiguous bytes per row per tile.
+template <bool IS_BF16, bool OUT_F32, int FM, int FN>
+__device__ __forceinline__ void store_wave_tile(const f32x4 (&acc)[FM][FN], const NtArgs& p, char* Cb,
+                                                int64_t m0, int64_t n0, int BM, int BN, int wave_m,
+                                                int wave_n, int lane) {
+  const bool full = (m0 + BM <= p.M) && (n0 + BN <= p.N);
+#pragma unroll
+  for (int i = 0; i < FM; ++i) {
+    const int64_t m = m0 + wave_m + i * 16 + (lane & 15);
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+      const int64_t n = n0 + wave_n + j * 16 + (lane >> 4) * 4;
+      const f32x4 v = acc[i][j];
+      if (full || (m < p.M && n + 3 < p.N)) {
+        if constexpr (OUT_F32) {
+          *(float4*)(Cb + (m * p.ldc + n) * 4) = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+          uint2 o;
+          o.x = pack2<IS_BF16>(v[0], v[1]);
+          o.y = pack2<IS_BF16>(v[2], v[3]);
+          *(uint2*)(Cb + (m * p.ldc + n) * 2) = o;
+        }
+      } else if (m < p.M) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (n + r < p.N) {
+            if constexpr (OUT_F32) ((float*)Cb)[m * p.ldc + n + r] = v[r];
+            else ((uint16_t*)Cb)[m * p.ldc + n + r] = IS_BF16 ? f32_to_bf16(v[r]) : f32_to_f16(v[r]);
+          }
+        }
+      }
+    }
+  }
 }
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool IS_BF16, bool OUT_F32>
@@ -182,36 +221,190 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_kernel(NtArgs p
     }
   }
 
-  // ---- epilogue: lane holds C[m = l & 15][n = 4*(l >> 4) .. +3] of each 16x16 tile --
-  char* Cb = (char*)p.C + (int64_t)blockIdx.y * p.sC * (OUT_F32 ? 4 : 2);
-  const bool full = (m0 + BM <= p.M) && (n0 + BN <= p.N);
+  store_wave_tile<IS_BF16, OUT_F32, FM, FN>(acc, p, (char*)p.C + (int64_t)blockIdx.y * p.sC * (OUT_F32 ? 4 : 2),
+                                            m0, n0, BM, BN, wm * WTM, wn * WTN, lane);
+}
+
+// ---------------------------------------------------------------------------
+// 256x256x64 "ping-pong" kernel: the two halves of the workgroup (waves 0-3 own
+// rows 0-127, waves 4-7 rows 128-255) run the same phase sequence ONE barrier
+// interval apart, so that on every SIMD one wave is inside its 16-MFMA cluster
+// while the other issues its ds_reads / LDS-DMA.  A K-tile is consumed in 4
+// phases (one 64x32 quadrant of the wave's 128x64 output per phase); the tile
+// is staged as 4 half-tiles (A rows 0-127 / 128-255, B rows 0-127 / 128-255,
+// 16 KiB each), one per phase, 2 LDS buffers:
+//
+//   phase of tile t | ds_read (tile t)   | LDS-DMA issued          | MFMA cluster
+//   ----------------+--------------------+-------------------------+-------------
+//        0          | A sub0 (8) B sub0 (4) | A-half0 of tile t+1  | A0 x B0
+//        1          | B sub1 (4)         | A-half1 of tile t+1     | A0 x B1
+//        2          | A sub1 (8)         | B-half0 of tile t+2     | A1 x B1
+//        3          | -                  | B-half1 of tile t+2     | A1 x B0
+//
+// Hazards (interval = time between two workgroup barriers; group 1 lags group 0
+// by one interval):
+//   RAW  every wave waits `vmcnt(4)` at the end of phase 3's load segment (the 4
+//        pieces of tile t+2's B halves stay in flight), then a barrier is passed
+//        by everyone before the first ds_read of tile t+1.
+//   WAR  a half-tile buffer is restaged at least one full interval after the
+//        last ds_read of its previous content, and every load segment ends with
+//        lgkmcnt(0) BEFORE its barrier, so those reads have retired.
+// ---------------------------------------------------------------------------
+template <bool IS_BF16, bool OUT_F32>
+__global__ __launch_bounds__(512) void gemm_nt_pp_kernel(NtArgs p) {
+  constexpr int BM = 256, BN = 256, BK = 64;
+  constexpr int HALF_BYTES = 128 * BK * 2;   // 16 KiB
+  constexpr int BUF_BYTES = 4 * HALF_BYTES;  // A0 A1 B0 B1
+  __shared__ __attribute__((aligned(1024))) char smem[2 * BUF_BYTES];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wid >> 2, wc = wid & 3;
+
+  int tm, tn;
+  tile_of_block(blockIdx.x, p.tiles_m, p.tiles_n, tm, tn);
+  const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
+  const uint16_t* A = p.A + (int64_t)blockIdx.y * p.sA;
+  const uint16_t* B = p.B + (int64_t)blockIdx.y * p.sB;
+
+  // LDS-DMA source pointers: half-tile h, piece i -> rows h*128 + (i*8 + wid)*8 + (lane >> 3)
+  const int lrow = lane >> 3;
+  const int lchunk = (lane & 7) ^ lrow;
+  const uint16_t* ga[2][2];
+  const uint16_t* gb[2][2];
 #pragma unroll
-  for (int i = 0; i < FM; ++i) {
-    const int64_t m = m0 + wm * WTM + i * 16 + (lane & 15);
+  for (int h = 0; h < 2; ++h)
 #pragma unroll
-    for (int j = 0; j < FN; ++j) {
-      const int64_t n = n0 + wn * WTN + j * 16 + (lane >> 4) * 4;
-      const f32x4 v = acc[i][j];
-      if (full || (m < p.M && n + 3 < p.N)) {
-        if constexpr (OUT_F32) {
-          *(float4*)(Cb + (m * p.ldc + n) * 4) = make_float4(v[0], v[1], v[2], v[3]);
-        } else {
-          uint2 o;
-          o.x = pack2<IS_BF16>(v[0], v[1]);
-          o.y = pack2<IS_BF16>(v[2], v[3]);
-          *(uint2*)(Cb + (m * p.ldc + n) * 2) = o;
-        }
-      } else if (m < p.M) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          if (n + r < p.N) {
-            if constexpr (OUT_F32) ((float*)Cb)[m * p.ldc + n + r] = v[r];
-            else ((uint16_t*)Cb)[m * p.ldc + n + r] = IS_BF16 ? f32_to_bf16(v[r]) : f32_to_f16(v[r]);
-          }
-        }
-      }
+    for (int i = 0; i < 2; ++i) {
+      int64_t row = m0 + h * 128 + (i * 8 + wid) * 8 + lrow;
+      if (row >= p.M) row = p.M - 1;
+      ga[h][i] = A + row * p.lda + lchunk * 8;
+      row = n0 + h * 128 + (i * 8 + wid) * 8 + lrow;
+      if (row >= p.N) row = p.N - 1;
+      gb[h][i] = B + row * p.ldb + lchunk * 8;
     }
+  const unsigned lds0 = (unsigned)(size_t)TNH_LDS_PTR(smem);
+  // which: 0 = A-half0, 1 = A-half1, 2 = B-half0, 3 = B-half1
+  auto issue = [&](int buf, int which, int64_t k0) {
+    const unsigned base = lds0 + buf * BUF_BYTES + which * HALF_BYTES;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const uint16_t* g = (which < 2) ? ga[which & 1][i] : gb[which & 1][i];
+      glds16(g + k0, __builtin_amdgcn_readfirstlane(base + (i * 8 + wid) * 1024));
+    }
+  };
+
+  int frag_off[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks)
+    frag_off[ks] = (lane & 15) * 128 + (((ks * 4 + (lane >> 4)) ^ (lane & 7)) * 16);
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  uint4 af[2][4];     // [ks][16-row fragment] of the current A sub-tile
+  uint4 bf[2][2][2];  // [sub][ks][16-row fragment] of both B sub-tiles
+
+  auto read_a = [&](const char* buf_base, int sub) {
+    const char* sa = buf_base + wr * HALF_BYTES + (sub * 64) * 128;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int f = 0; f < 4; ++f) af[ks][f] = *(const uint4*)(sa + f * 2048 + frag_off[ks]);
+  };
+  auto read_b = [&](const char* buf_base, int sub) {
+    const char* sb = buf_base + (2 + (wc >> 1)) * HALF_BYTES + ((wc & 1) * 64 + sub * 32) * 128;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int f = 0; f < 2; ++f) bf[sub][ks][f] = *(const uint4*)(sb + f * 2048 + frag_off[ks]);
+  };
+  auto mma_quadrant = [&](int sa, int sb) {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[sa * 4 + i][sb * 2 + j] = mma16<IS_BF16>(bf[sb][ks][j], af[ks][i], acc[sa * 4 + i][sb * 2 + j]);
+    __builtin_amdgcn_s_setprio(0);
+  };
+  // end of a load segment: retire this wave's LDS reads, then meet the other waves
+#define TNH_SEG_LOAD_END()                                  \
+  do {                                                      \
+    __builtin_amdgcn_sched_barrier(0);                      \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      \
+    __builtin_amdgcn_s_barrier();                           \
+    __builtin_amdgcn_sched_barrier(0);                      \
+  } while (0)
+#define TNH_SEG_MMA_END()                                   \
+  do {                                                      \
+    __builtin_amdgcn_sched_barrier(0);                      \
+    __builtin_amdgcn_s_barrier();                           \
+    asm volatile("" ::: "memory");                          \
+    __builtin_amdgcn_sched_barrier(0);                      \
+  } while (0)
+
+  const int nt = (int)(p.K / BK);
+  // prologue: tile 0 complete, B halves of tile 1
+  issue(0, 0, 0);
+  issue(0, 1, 0);
+  issue(0, 2, 0);
+  issue(0, 3, 0);
+  if (nt > 1) {
+    issue(1, 2, BK);
+    issue(1, 3, BK);
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (wr == 1) __builtin_amdgcn_s_barrier();  // group 1 runs one interval behind group 0
+  __builtin_amdgcn_sched_barrier(0);
+
+  for (int t = 0; t < nt; ++t) {
+    const int b = t & 1;
+    const char* cur = smem + b * BUF_BYTES;
+    const bool n1 = (t + 1 < nt), n2 = (t + 2 < nt);
+    // ---- phase 0
+    read_a(cur, 0);
+    read_b(cur, 0);
+    if (n1) issue(b ^ 1, 0, (int64_t)(t + 1) * BK);
+    TNH_SEG_LOAD_END();
+    mma_quadrant(0, 0);
+    TNH_SEG_MMA_END();
+    // ---- phase 1
+    read_b(cur, 1);
+    if (n1) issue(b ^ 1, 1, (int64_t)(t + 1) * BK);
+    TNH_SEG_LOAD_END();
+    mma_quadrant(0, 1);
+    TNH_SEG_MMA_END();
+    // ---- phase 2
+    read_a(cur, 1);
+    if (n2) issue(b, 2, (int64_t)(t + 2) * BK);
+    TNH_SEG_LOAD_END();
+    mma_quadrant(1, 1);
+    TNH_SEG_MMA_END();
+    // ---- phase 3
+    if (n2) {
+      issue(b, 3, (int64_t)(t + 2) * BK);
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // tile t+1 landed; B halves of t+2 in flight
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    TNH_SEG_LOAD_END();
+    mma_quadrant(1, 0);
+    TNH_SEG_MMA_END();
+  }
+  if (wr == 0) __builtin_amdgcn_s_barrier();  // pairs with group 1's last barrier
+#undef TNH_SEG_LOAD_END
+#undef TNH_SEG_MMA_END
+
+  store_wave_tile<IS_BF16, OUT_F32, 8, 4>(acc, p, (char*)p.C + (int64_t)blockIdx.y * p.sC * (OUT_F32 ? 4 : 2),
+                                          m0, n0, BM, BN, wr * 128, wc * 64, lane);
 }
 
 template <int BM, int BN, int WAVES_M, int WAVES_N>
@@ -234,6 +427,31 @@ static int launch_nt(bool is_bf16, bool out_f32, NtArgs p, int64_t batch) {
     } else {
       if (out_f32) hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, WAVES_M, WAVES_N, false, true>), grid, block, 0, stream(), q);
       else hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, WAVES_M, WAVES_N, false, false>), grid, block, 0, stream(), q);
+    }
+    TNH_LAUNCH_CHECK();
+  }
+  return TNH_OK;
+}
+
+static int launch_pp(bool is_bf16, bool out_f32, NtArgs p, int64_t batch) {
+  p.tiles_m = (int)((p.M + 255) / 256);
+  p.tiles_n = (int)((p.N + 255) / 256);
+  const int64_t nwg = (int64_t)p.tiles_m * p.tiles_n;
+  TNH_REQUIRE(nwg < (int64_t(1) << 31), "GEMM grid too large");
+  const int esz_out = out_f32 ? 4 : 2;
+  for (int64_t b0 = 0; b0 < batch; b0 += 65535) {
+    const int64_t nb = (batch - b0 < 65535) ? (batch - b0) : 65535;
+    NtArgs q = p;
+    q.A = p.A + b0 * p.sA;
+    q.B = p.B + b0 * p.sB;
+    q.C = (char*)p.C + b0 * p.sC * esz_out;
+    const dim3 grid((unsigned)nwg, (unsigned)nb), block(512);
+    if (is_bf16) {
+      if (out_f32) hipLaunchKernelGGL((gemm_nt_pp_kernel<true, true>), grid, block, 0, stream(), q);
+      else hipLaunchKernelGGL((gemm_nt_pp_kernel<true, false>), grid, block, 0, stream(), q);
+    } else {
+      if (out_f32) hipLaunchKernelGGL((gemm_nt_pp_kernel<false, true>), grid, block, 0, stream(), q);
+      else hipLaunchKernelGGL((gemm_nt_pp_kernel<false, false>), grid, block, 0, stream(), q);
     }
     TNH_LAUNCH_CHECK();
   }
@@ -266,6 +484,10 @@ int gemm_bf16_fast(int in_dt, int out_dt, int variant, int transA, int transB, i
   bool big = (M >= 256 && N >= 256) && (((M + 255) / 256) * ((N + 255) / 256) * batch >= 192);
   if (variant == 3) big = false;
   if (variant == 4) big = true;
+  if (variant == 5 || (big && variant == 0 && g_pp_default)) {
+    *name = "bf16_nt_256x256x64_pp";
+    return launch_pp(is_bf16, out_f32, p, batch);
+  }
   if (big) {
     *name = "bf16_nt_256x256x64";
     return launch_nt<256, 256, 2, 4>(is_bf16, out_f32, p, batch);

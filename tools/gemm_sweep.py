@@ -65,17 +65,20 @@ def permute_gbps(be, shape, perm, dtype, iters):
 def main():
   ap = argparse.ArgumentParser()
   ap.add_argument("--quick", action="store_true")
+  ap.add_argument("--gemm-only", action="store_true")
   args = ap.parse_args()
   be = ta.get_hip_backend()
   sizes = [4096] if args.quick else [2048, 4096, 8192]
   for n in sizes:
-    for variant in ("bf16_128", "bf16_256"):
+    for variant in ("bf16_128", "bf16_256", "bf16_256pp"):
       for fill in ("uniform", "zeros"):
         print(json.dumps(gemm_tflops(be, _lib.BF16, _lib.BF16, 0, 1, n, n, n, variant, fill, 10)), flush=True)
   # north-star D=512 row: M=N=8192, K=262144
   if not args.quick:
-    for variant in ("bf16_128", "bf16_256"):
+    for variant in ("bf16_128", "bf16_256", "bf16_256pp"):
       print(json.dumps(gemm_tflops(be, _lib.BF16, _lib.BF16, 0, 1, 8192, 8192, 262144, variant, "uniform", 3)), flush=True)
+  if args.gemm_only:
+    return
   for n in ([2048] if args.quick else [2048, 4096]):
     print(json.dumps(gemm_tflops(be, _lib.F32, _lib.F32, 0, 0, n, n, n, "generic", "uniform", 5)), flush=True)
     print(json.dumps(gemm_tflops(be, _lib.F32, _lib.F32, 0, 1, n, n, n, "generic", "uniform", 5)), flush=True)
