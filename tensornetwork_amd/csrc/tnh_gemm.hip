@@ -12,6 +12,7 @@
 //
 // Operands are addressed as A(m,k) = A[m*rsA + k*csA], B(k,n) = B[k*rsB + n*csB],
 // so the four transpose combinations are one kernel.  MFMA roofline: 2*M*N*K flop.
+#include <stdlib.h>
 #include "tnh_types.h"
 
 namespace tnh {
@@ -27,6 +28,7 @@ struct GemmArgs {
 };
 
 // provided by tnh_gemm_bf16.hip
+extern int g_opt_raster, g_opt_phases;
 int gemm_bf16_fast(int in_dt, int out_dt, int variant, int transA, int transB, int64_t M, int64_t N,
                    int64_t K, const void* A, int64_t lda, const void* B, int64_t ldb, void* C,
                    int64_t ldc, int64_t batch, int64_t sA, int64_t sB, int64_t sC, const char** name);
@@ -318,8 +320,20 @@ extern "C" {
 
 const char* tnh_gemm_last_kernel(void) { return g_last_kernel; }
 
-int tnh_gemm_set_variant(const char* name) {
-  TNH_REQUIRE(name != nullptr, "null name");
+int tnh_gemm_set_variant(const char* full) {
+  TNH_REQUIRE(full != nullptr, "null name");
+  // "<variant>[:r<digit>][:p<digit>]" -- the suffixes set A/B knobs of the bf16 speed path
+  char name[64];
+  snprintf(name, sizeof(name), "%s", full);
+  tnh::g_opt_raster = 0;
+  tnh::g_opt_phases = 2;
+  for (char* c = strchr(name, ':'); c != nullptr;) {
+    *c = 0;
+    char* next = strchr(c + 1, ':');
+    if (c[1] == 'r') tnh::g_opt_raster = atoi(c + 2);
+    else if (c[1] == 'p') tnh::g_opt_phases = atoi(c + 2);
+    c = next;
+  }
   if (!strcmp(name, "auto")) g_variant = 0;
   else if (!strcmp(name, "generic")) g_variant = 1;
   else if (!strcmp(name, "valu")) g_variant = 2;

@@ -28,6 +28,8 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
+int g_opt_raster = 0;  // A/B knobs, set through tnh_gemm_set_variant("name:r<d>:p<d>")
+int g_opt_phases = 2;  // ping-pong kernel: MFMA clusters per K-tile (2 = 32-MFMA clusters, default; 4)
 static bool g_pp_default = true;  // ping-pong kernel won the A/B on MI355X (profiles/r01_sweep_v2.jsonl)
 
 struct NtArgs {
@@ -38,6 +40,7 @@ struct NtArgs {
   int64_t lda, ldb, ldc;
   int64_t sA, sB, sC;
   int tiles_m, tiles_n;
+  int raster;  // 0: per-XCD contiguous ranges, M-grouped; 1: 16x16 super-tiles shared by the 8 XCDs
 };
 
 #define TNH_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
@@ -74,8 +77,22 @@ __device__ __forceinline__ uint32_t pack2(float lo, float hi) {
 
 // XCD-aware, M-grouped tile order.  `bid` -> (tile_m, tile_n), bijective for
 // any grid size.
-__device__ __forceinline__ void tile_of_block(int bid, int tiles_m, int tiles_n, int& tm, int& tn) {
+__device__ __forceinline__ void tile_of_block(int bid, int tiles_m, int tiles_n, int raster, int& tm,
+                                              int& tn) {
   const int nwg = tiles_m * tiles_n;
+  if (raster == 1 && (tiles_m & 15) == 0 && (tiles_n & 15) == 0) {
+    // The 256 workgroups resident at one time (32 per XCD) cover one 16x16
+    // block of tiles; XCD x owns the 4x8 sub-block (x >> 1, x & 1) so its private
+    // L2 sees 4 A-panels x 8 B-panels, while the other XCDs' fetches of the same
+    // panels hit in the memory-side Infinity Cache.
+    const int xcd = bid & 7, j = bid >> 3;
+    const int sb = j >> 5, w = j & 31;
+    const int sbm = tiles_m >> 4;
+    const int sm = sb % sbm, sn = sb / sbm;
+    tm = sm * 16 + (xcd >> 1) * 4 + (w & 3);
+    tn = sn * 16 + (xcd & 1) * 8 + (w >> 2);
+    return;
+  }
   const int q = nwg >> 3, r = nwg & 7;
   const int xcd = bid & 7, local = bid >> 3;
   const int pid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
@@ -144,7 +161,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_kernel(NtArgs p
   const int wm = wid / WAVES_N, wn = wid % WAVES_N;
 
   int tm, tn;
-  tile_of_block(blockIdx.x, p.tiles_m, p.tiles_n, tm, tn);
+  tile_of_block(blockIdx.x, p.tiles_m, p.tiles_n, p.raster, tm, tn);
   const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
   const uint16_t* A = p.A + (int64_t)blockIdx.y * p.sA;
   const uint16_t* B = p.B + (int64_t)blockIdx.y * p.sB;
@@ -228,7 +245,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_kernel(NtArgs p
 // ---------------------------------------------------------------------------
 // 256x256x64 "ping-pong" kernel: the two halves of the workgroup (waves 0-3 own
 // rows 0-127, waves 4-7 rows 128-255) run the same phase sequence ONE barrier
-// interval apart, so that on every SIMD one wave is inside its 16-MFMA cluster
+// interval apart, so that on every SIMD one wave is inside its MFMA cluster
 // while the other issues its ds_reads / LDS-DMA.  A K-tile is consumed in 4
 // phases (one 64x32 quadrant of the wave's 128x64 output per phase); the tile
 // is staged as 4 half-tiles (A rows 0-127 / 128-255, B rows 0-127 / 128-255,
@@ -249,12 +266,32 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_kernel(NtArgs p
 //   WAR  a half-tile buffer is restaged at least one full interval after the
 //        last ds_read of its previous content, and every load segment ends with
 //        lgkmcnt(0) BEFORE its barrier, so those reads have retired.
+//
+// M32 = false: v_mfma_f32_16x16x32 (16 per phase), chunk swizzle row & 7.
+// M32 = true : v_mfma_f32_32x32x16 ( 8 per phase; 4x fewer operand-register
+//              reads per MAC), chunk swizzle (row >> 1) & 7 -- conflict-free for
+//              the 32-row x 2-chunk ds_read_b128 pattern.
 // ---------------------------------------------------------------------------
-template <bool IS_BF16, bool OUT_F32>
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+template <bool IS_BF16>
+__device__ __forceinline__ f32x16 mma32(const uint4& a, const uint4& b, f32x16 c) {
+  if constexpr (IS_BF16)
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)&a, *(const bf16x8*)&b, c, 0, 0, 0);
+  else
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(*(const f16x8*)&a, *(const f16x8*)&b, c, 0, 0, 0);
+}
+
+template <bool IS_BF16, bool OUT_F32, bool TWO>
 __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(NtArgs p) {
+  constexpr bool M32 = false;  // 32x32x16 MFMA lost the A/B (only 2 independent accumulators per phase)
   constexpr int BM = 256, BN = 256, BK = 64;
   constexpr int HALF_BYTES = 128 * BK * 2;   // 16 KiB
   constexpr int BUF_BYTES = 4 * HALF_BYTES;  // A0 A1 B0 B1
+  constexpr int KS = M32 ? 4 : 2;            // MFMA k-steps per K-tile
+  constexpr int FA = M32 ? 2 : 4;            // row fragments per 64-row A sub-tile
+  constexpr int FB = M32 ? 1 : 2;            // row fragments per 32-row B sub-tile
+  constexpr int FROWS = M32 ? 32 : 16;
   __shared__ __attribute__((aligned(1024))) char smem[2 * BUF_BYTES];
 
   const int tid = threadIdx.x;
@@ -263,24 +300,27 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(NtArgs p) {
   const int wr = wid >> 2, wc = wid & 3;
 
   int tm, tn;
-  tile_of_block(blockIdx.x, p.tiles_m, p.tiles_n, tm, tn);
+  tile_of_block(blockIdx.x, p.tiles_m, p.tiles_n, p.raster, tm, tn);
   const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
   const uint16_t* A = p.A + (int64_t)blockIdx.y * p.sA;
   const uint16_t* B = p.B + (int64_t)blockIdx.y * p.sB;
 
-  // LDS-DMA source pointers: half-tile h, piece i -> rows h*128 + (i*8 + wid)*8 + (lane >> 3)
+  // LDS-DMA source pointers: half-tile h, piece i -> rows h*128 + (i*8 + wid)*8 + (lane >> 3);
+  // the lane that lands in chunk slot (lane & 7) fetches global chunk slot ^ swz(row).
   const int lrow = lane >> 3;
-  const int lchunk = (lane & 7) ^ lrow;
   const uint16_t* ga[2][2];
   const uint16_t* gb[2][2];
 #pragma unroll
   for (int h = 0; h < 2; ++h)
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      int64_t row = m0 + h * 128 + (i * 8 + wid) * 8 + lrow;
+      const int trow = (i * 8 + wid) * 8 + lrow;  // row inside the half-tile
+      const int swz = M32 ? ((trow >> 1) & 7) : (trow & 7);
+      const int lchunk = (lane & 7) ^ swz;
+      int64_t row = m0 + h * 128 + trow;
       if (row >= p.M) row = p.M - 1;
       ga[h][i] = A + row * p.lda + lchunk * 8;
-      row = n0 + h * 128 + (i * 8 + wid) * 8 + lrow;
+      row = n0 + h * 128 + trow;
       if (row >= p.N) row = p.N - 1;
       gb[h][i] = B + row * p.ldb + lchunk * 8;
     }
@@ -295,43 +335,62 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(NtArgs p) {
     }
   };
 
-  int frag_off[2];
+  // fragment read offsets inside a half-tile image (row base is a multiple of FROWS)
+  int frag_off[KS];
 #pragma unroll
-  for (int ks = 0; ks < 2; ++ks)
-    frag_off[ks] = (lane & 15) * 128 + (((ks * 4 + (lane >> 4)) ^ (lane & 7)) * 16);
+  for (int ks = 0; ks < KS; ++ks) {
+    if constexpr (M32)
+      frag_off[ks] = (lane & 31) * 128 + (((ks * 2 + (lane >> 5)) ^ ((lane >> 1) & 7)) * 16);
+    else
+      frag_off[ks] = (lane & 15) * 128 + (((ks * 4 + (lane >> 4)) ^ (lane & 7)) * 16);
+  }
 
-  f32x4 acc[8][4];
+  f32x4 acc[M32 ? 1 : 8][M32 ? 1 : 4];
+  f32x16 acc32[M32 ? 4 : 1][M32 ? 2 : 1];
+  if constexpr (M32) {
 #pragma unroll
-  for (int i = 0; i < 8; ++i)
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc32[i][j][r] = 0.f;
+  } else {
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
 
-  uint4 af[2][4];     // [ks][16-row fragment] of the current A sub-tile
-  uint4 bf[2][2][2];  // [sub][ks][16-row fragment] of both B sub-tiles
+  uint4 af[KS][FA];     // [k-step][row fragment] of the current A sub-tile
+  uint4 bf[2][KS][FB];  // [sub][k-step][row fragment] of both B sub-tiles
 
   auto read_a = [&](const char* buf_base, int sub) {
     const char* sa = buf_base + wr * HALF_BYTES + (sub * 64) * 128;
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
+    for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-      for (int f = 0; f < 4; ++f) af[ks][f] = *(const uint4*)(sa + f * 2048 + frag_off[ks]);
+      for (int f = 0; f < FA; ++f) af[ks][f] = *(const uint4*)(sa + f * FROWS * 128 + frag_off[ks]);
   };
   auto read_b = [&](const char* buf_base, int sub) {
     const char* sb = buf_base + (2 + (wc >> 1)) * HALF_BYTES + ((wc & 1) * 64 + sub * 32) * 128;
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
+    for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-      for (int f = 0; f < 2; ++f) bf[sub][ks][f] = *(const uint4*)(sb + f * 2048 + frag_off[ks]);
+      for (int f = 0; f < FB; ++f) bf[sub][ks][f] = *(const uint4*)(sb + f * FROWS * 128 + frag_off[ks]);
   };
   auto mma_quadrant = [&](int sa, int sb) {
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
+    for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < FA; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-          acc[sa * 4 + i][sb * 2 + j] = mma16<IS_BF16>(bf[sb][ks][j], af[ks][i], acc[sa * 4 + i][sb * 2 + j]);
+        for (int j = 0; j < FB; ++j) {
+          if constexpr (M32)
+            acc32[sa * 2 + i][sb] = mma32<IS_BF16>(bf[sb][ks][j], af[ks][i], acc32[sa * 2 + i][sb]);
+          else
+            acc[sa * 4 + i][sb * 2 + j] = mma16<IS_BF16>(bf[sb][ks][j], af[ks][i], acc[sa * 4 + i][sb * 2 + j]);
+        }
     __builtin_amdgcn_s_setprio(0);
   };
   // end of a load segment: retire this wave's LDS reads, then meet the other waves
@@ -369,6 +428,33 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(NtArgs p) {
     const int b = t & 1;
     const char* cur = smem + b * BUF_BYTES;
     const bool n1 = (t + 1 < nt), n2 = (t + 2 < nt);
+    if constexpr (TWO) {
+      // two phases per K-tile, 32-MFMA clusters: half as many barriers per flop
+      read_a(cur, 0);
+      read_b(cur, 0);
+      read_b(cur, 1);
+      if (n1) {
+        issue(b ^ 1, 0, (int64_t)(t + 1) * BK);
+        issue(b ^ 1, 1, (int64_t)(t + 1) * BK);
+      }
+      TNH_SEG_LOAD_END();
+      mma_quadrant(0, 0);
+      mma_quadrant(0, 1);
+      TNH_SEG_MMA_END();
+      read_a(cur, 1);
+      if (n2) {
+        issue(b, 2, (int64_t)(t + 2) * BK);
+        issue(b, 3, (int64_t)(t + 2) * BK);
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      TNH_SEG_LOAD_END();
+      mma_quadrant(1, 1);
+      mma_quadrant(1, 0);
+      TNH_SEG_MMA_END();
+      continue;
+    }
     // ---- phase 0
     read_a(cur, 0);
     read_b(cur, 0);
@@ -403,8 +489,45 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(NtArgs p) {
 #undef TNH_SEG_LOAD_END
 #undef TNH_SEG_MMA_END
 
-  store_wave_tile<IS_BF16, OUT_F32, 8, 4>(acc, p, (char*)p.C + (int64_t)blockIdx.y * p.sC * (OUT_F32 ? 4 : 2),
-                                          m0, n0, BM, BN, wr * 128, wc * 64, lane);
+  char* Cb = (char*)p.C + (int64_t)blockIdx.y * p.sC * (OUT_F32 ? 4 : 2);
+  if constexpr (!M32) {
+    store_wave_tile<IS_BF16, OUT_F32, 8, 4>(acc, p, Cb, m0, n0, BM, BN, wr * 128, wc * 64, lane);
+  } else {
+    // 32x32 C/D layout (operands swapped): lane holds, for m = lane & 31,
+    // n = 8*q + 4*(lane >> 5) + (0..3) for q = 0..3  (registers 4q .. 4q+3).
+    const bool full = (m0 + BM <= p.M) && (n0 + BN <= p.N);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int64_t m = m0 + wr * 128 + i * 32 + (lane & 31);
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int64_t n = n0 + wc * 64 + j * 32 + 8 * q + 4 * (lane >> 5);
+          const float v0 = acc32[i][j][4 * q], v1 = acc32[i][j][4 * q + 1], v2 = acc32[i][j][4 * q + 2],
+                      v3 = acc32[i][j][4 * q + 3];
+          if (full || (m < p.M && n + 3 < p.N)) {
+            if constexpr (OUT_F32) {
+              *(float4*)(Cb + (m * p.ldc + n) * 4) = make_float4(v0, v1, v2, v3);
+            } else {
+              uint2 o;
+              o.x = pack2<IS_BF16>(v0, v1);
+              o.y = pack2<IS_BF16>(v2, v3);
+              *(uint2*)(Cb + (m * p.ldc + n) * 2) = o;
+            }
+          } else if (m < p.M) {
+            const float vv[4] = {v0, v1, v2, v3};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              if (n + r < p.N) {
+                if constexpr (OUT_F32) ((float*)Cb)[m * p.ldc + n + r] = vv[r];
+                else ((uint16_t*)Cb)[m * p.ldc + n + r] = IS_BF16 ? f32_to_bf16(vv[r]) : f32_to_f16(vv[r]);
+              }
+            }
+          }
+        }
+    }
+  }
 }
 
 template <int BM, int BN, int WAVES_M, int WAVES_N>
@@ -433,7 +556,7 @@ static int launch_nt(bool is_bf16, bool out_f32, NtArgs p, int64_t batch) {
   return TNH_OK;
 }
 
-static int launch_pp(bool is_bf16, bool out_f32, NtArgs p, int64_t batch) {
+static int launch_pp(bool is_bf16, bool out_f32, bool two, NtArgs p, int64_t batch) {
   p.tiles_m = (int)((p.M + 255) / 256);
   p.tiles_n = (int)((p.N + 255) / 256);
   const int64_t nwg = (int64_t)p.tiles_m * p.tiles_n;
@@ -446,13 +569,19 @@ static int launch_pp(bool is_bf16, bool out_f32, NtArgs p, int64_t batch) {
     q.B = p.B + b0 * p.sB;
     q.C = (char*)p.C + b0 * p.sC * esz_out;
     const dim3 grid((unsigned)nwg, (unsigned)nb), block(512);
+#define TNH_PP_LAUNCH(B16, O32)                                                                        \
+  do {                                                                                                \
+    if (two) hipLaunchKernelGGL((gemm_nt_pp_kernel<B16, O32, true>), grid, block, 0, stream(), q);    \
+    else hipLaunchKernelGGL((gemm_nt_pp_kernel<B16, O32, false>), grid, block, 0, stream(), q);       \
+  } while (0)
     if (is_bf16) {
-      if (out_f32) hipLaunchKernelGGL((gemm_nt_pp_kernel<true, true>), grid, block, 0, stream(), q);
-      else hipLaunchKernelGGL((gemm_nt_pp_kernel<true, false>), grid, block, 0, stream(), q);
+      if (out_f32) TNH_PP_LAUNCH(true, true);
+      else TNH_PP_LAUNCH(true, false);
     } else {
-      if (out_f32) hipLaunchKernelGGL((gemm_nt_pp_kernel<false, true>), grid, block, 0, stream(), q);
-      else hipLaunchKernelGGL((gemm_nt_pp_kernel<false, false>), grid, block, 0, stream(), q);
+      if (out_f32) TNH_PP_LAUNCH(false, true);
+      else TNH_PP_LAUNCH(false, false);
     }
+#undef TNH_PP_LAUNCH
     TNH_LAUNCH_CHECK();
   }
   return TNH_OK;
@@ -479,6 +608,7 @@ int gemm_bf16_fast(int in_dt, int out_dt, int variant, int transA, int transB, i
   p.M = M; p.N = N; p.K = K;
   p.lda = lda; p.ldb = ldb; p.ldc = ldc;
   p.sA = sA; p.sB = sB; p.sC = sC;
+  p.raster = g_opt_raster;
   const bool is_bf16 = (in_dt == TNH_BF16), out_f32 = (out_dt == TNH_F32);
   // 256x256 tiles once there are enough of them to fill the 256 CUs.
   bool big = (M >= 256 && N >= 256) && (((M + 255) / 256) * ((N + 255) / 256) * batch >= 192);
@@ -486,7 +616,7 @@ int gemm_bf16_fast(int in_dt, int out_dt, int variant, int transA, int transB, i
   if (variant == 4) big = true;
   if (variant == 5 || (big && variant == 0 && g_pp_default)) {
     *name = "bf16_nt_256x256x64_pp";
-    return launch_pp(is_bf16, out_f32, p, batch);
+    return launch_pp(is_bf16, out_f32, g_opt_phases != 4, p, batch);
   }
   if (big) {
     *name = "bf16_nt_256x256x64";

@@ -146,10 +146,11 @@ def test_gemm_batched(hip, dtype):
 
 
 @pytest.mark.parametrize("variant,expect", [("bf16_128", "bf16_nt_128x128x64"), ("bf16_256", "bf16_nt_256x256x64"),
-                                            ("bf16_256pp", "bf16_nt_256x256x64_pp")])
+                                            ("bf16_256pp", "bf16_nt_256x256x64_pp"),
+                                            ("bf16_256pp:r1:p4", "bf16_nt_256x256x64_pp")])
 @pytest.mark.parametrize("dtype", [ta.bfloat16, np.float16])
 @pytest.mark.parametrize("m,n,k", [(128, 128, 64), (256, 256, 128), (512, 384, 256), (200, 136, 192), (1024, 768, 512),
-                                   (2048, 2304, 1088)])
+                                   (2048, 2304, 1088), (4096, 4096, 128)])
 def test_gemm_bf16_speed_path(hip, variant, expect, dtype, m, n, k):
   """LDS-DMA + swizzled ds_read + 16x16x32 MFMA path; asymmetric random operands
   (catch row/col swaps), ragged M/N edges, both tile sizes."""

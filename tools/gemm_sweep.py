@@ -49,7 +49,7 @@ def gemm_tflops(be, code, out_code, ta_, tb_, m, n, k, variant, fill, iters):
     name = be.lib.tnh_gemm_last_kernel().decode()
   finally:
     _lib.check(be.lib.tnh_gemm_set_variant(b"auto"))
-  return {"op": "gemm", "kernel": name, "m": m, "n": n, "k": k, "fill": fill, "ms": ms,
+  return {"op": "gemm", "kernel": name, "variant": variant, "m": m, "n": n, "k": k, "fill": fill, "ms": ms,
           "tflops": 2.0 * m * n * k / ms / 1e9}
 
 
@@ -66,16 +66,19 @@ def main():
   ap = argparse.ArgumentParser()
   ap.add_argument("--quick", action="store_true")
   ap.add_argument("--gemm-only", action="store_true")
+  ap.add_argument("--variants", default="bf16_128,bf16_256,bf16_256pp")
   args = ap.parse_args()
+  global VARIANTS
+  VARIANTS = args.variants.split(',')
   be = ta.get_hip_backend()
   sizes = [4096] if args.quick else [2048, 4096, 8192]
   for n in sizes:
-    for variant in ("bf16_128", "bf16_256", "bf16_256pp"):
+    for variant in VARIANTS:
       for fill in ("uniform", "zeros"):
         print(json.dumps(gemm_tflops(be, _lib.BF16, _lib.BF16, 0, 1, n, n, n, variant, fill, 10)), flush=True)
   # north-star D=512 row: M=N=8192, K=262144
   if not args.quick:
-    for variant in ("bf16_128", "bf16_256", "bf16_256pp"):
+    for variant in VARIANTS:
       print(json.dumps(gemm_tflops(be, _lib.BF16, _lib.BF16, 0, 1, 8192, 8192, 262144, variant, "uniform", 3)), flush=True)
   if args.gemm_only:
     return
