@@ -14,6 +14,7 @@
 // This phase is not HBM-roofline work: a sweep moves ~(p-1) * 2 * (p*q + p*p)
 // elements through L2/Infinity-Cache; see DESIGN.md for the measured rates.
 #include <math.h>
+#include <stdlib.h>
 #include <algorithm>
 #include <numeric>
 #include <vector>
@@ -25,8 +26,21 @@ namespace tnh {
 struct SvdLayout {
   int64_t p, q;
   bool transposed;  // X = A^T
-  size_t off_X, off_R, off_norm, off_perm, off_flag, total;
+  bool block;       // f32 block-Jacobi speed path (tnh_svd_block.hip): X, R zero padded
+  int64_t ldx, ldr; // row pitch of X (>= q) and R (>= p); rows allocated: ldr
+  size_t off_X, off_R, off_norm, off_perm, off_flag, off_scratch, total;
 };
+
+// tnh_svd_block.hip
+int svd_block_pad_copy(float* Xp, int64_t P, int64_t Q, const float* A, int64_t m, int64_t n, bool trans);
+size_t svd_block_scratch_bytes(int64_t P, int64_t Q);
+int svd_block_sweeps(float* X, float* R, int64_t P, int64_t Q, char* scratch, int* flag, double tol,
+                     int max_sweeps, int* sweeps_out, bool* converged_out);
+
+static bool block_path_enabled() {
+  const char* e = getenv("TNH_SVD_BLOCK");
+  return !(e && e[0] == '0');
+}
 
 static SvdLayout svd_layout(int dtype, int64_t m, int64_t n) {
   SvdLayout L;
@@ -35,12 +49,16 @@ static SvdLayout svd_layout(int dtype, int64_t m, int64_t n) {
   L.q = L.transposed ? m : n;
   const size_t esz = (size_t)dtype_size(dtype);
   auto al = [](size_t x) { return (x + 255) & ~size_t(255); };
+  L.block = (dtype == TNH_F32 && L.p > 64 && block_path_enabled());
+  L.ldx = L.block ? ((L.q + 127) / 128) * 128 : L.q;
+  L.ldr = L.block ? ((L.p + 127) / 128) * 128 : L.p;
   size_t off = 0;
-  L.off_X = off; off += al((size_t)L.p * L.q * esz);
-  L.off_R = off; off += al((size_t)L.p * L.p * esz);
+  L.off_X = off; off += al((size_t)L.ldr * L.ldx * esz);
+  L.off_R = off; off += al((size_t)L.ldr * L.ldr * esz);
   L.off_norm = off; off += al((size_t)L.p * sizeof(double));
   L.off_perm = off; off += al((size_t)L.p * sizeof(int32_t));
   L.off_flag = off; off += 256;
+  L.off_scratch = off; off += L.block ? al(svd_block_scratch_bytes(L.ldr, L.ldx)) : 0;
   L.total = off;
   return L;
 }
@@ -115,11 +133,11 @@ __global__ __launch_bounds__(256) void jacobi_round_kernel(T* __restrict__ X, T*
 
 template <typename T>
 __global__ __launch_bounds__(256) void row_norm_kernel(const T* __restrict__ X, int64_t p, int64_t q,
-                                                       double* __restrict__ norms) {
+                                                       int64_t ld, double* __restrict__ norms) {
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= p) return;
-  const T* x = X + row * q;
+  const T* x = X + row * ld;
   double acc = 0.0;
   for (int64_t j = lane; j < q; j += 64) {
     const double v = (double)x[j];
@@ -161,15 +179,39 @@ __global__ __launch_bounds__(256) void emit_rows_kernel(T* __restrict__ out, con
 }
 
 template <typename T>
+static int svd_finish(const SvdLayout& L, int64_t m, int64_t n, void* S, char* work, bool converged,
+                      int max_sweeps);
+
+// f32 speed path: zero-padded copy, block-Jacobi sweeps (tnh_svd_block.hip).
+static int svd_factor_block(const SvdLayout& L, int64_t m, int64_t n, const void* A, void* S, char* work,
+                            int* sweeps_out) {
+  float* X = (float*)(work + L.off_X);
+  float* R = (float*)(work + L.off_R);
+  int* flag = (int*)(work + L.off_flag);
+  const int64_t P = L.ldr, Q = L.ldx;
+  int rc = svd_block_pad_copy(X, P, Q, (const float*)A, m, n, L.transposed);
+  if (rc) return rc;
+  rc = tnh_eye(R, P, P, TNH_F32);
+  if (rc) return rc;
+  const double tol = 5.9604644775390625e-08 * sqrt((double)L.q);
+  const int max_sweeps = 40;
+  int sweeps = 0;
+  bool converged = false;
+  rc = svd_block_sweeps(X, R, P, Q, work + L.off_scratch, flag, tol, max_sweeps, &sweeps, &converged);
+  if (rc) return rc;
+  if (sweeps_out) *sweeps_out = sweeps;
+  return svd_finish<float>(L, m, n, S, work, converged, max_sweeps);
+}
+
+template <typename T>
 static int svd_factor_t(const SvdLayout& L, int dtype, int64_t m, int64_t n, const void* A, void* S,
                         char* work, int* sweeps_out) {
   const int64_t p = L.p, q = L.q;
   T* X = (T*)(work + L.off_X);
   T* R = (T*)(work + L.off_R);
-  double* norms = (double*)(work + L.off_norm);
-  int32_t* perm = (int32_t*)(work + L.off_perm);
   int* flag = (int*)(work + L.off_flag);
   int rc;
+  if (L.block) return svd_factor_block(L, m, n, A, S, work, sweeps_out);
   if (L.transposed) {
     const int64_t shape[2] = {m, n};
     const int32_t pm[2] = {1, 0};
@@ -202,8 +244,19 @@ static int svd_factor_t(const SvdLayout& L, int dtype, int64_t m, int64_t n, con
   }
   if (sweeps_out) *sweeps_out = sweeps;
 
+  return svd_finish<T>(L, m, n, S, work, converged, max_sweeps);
+}
+
+// Row norms -> singular values, descending order, S.
+template <typename T>
+static int svd_finish(const SvdLayout& L, int64_t m, int64_t n, void* S, char* work, bool converged,
+                      int max_sweeps) {
+  const int64_t p = L.p, q = L.q;
+  T* X = (T*)(work + L.off_X);
+  double* norms = (double*)(work + L.off_norm);
+  int32_t* perm = (int32_t*)(work + L.off_perm);
   hipLaunchKernelGGL((row_norm_kernel<T>), dim3((unsigned)((p + 3) / 4)), dim3(256), 0, stream(), X, p, q,
-                     norms);
+                     L.ldx, norms);
   TNH_LAUNCH_CHECK();
   std::vector<double> hn((size_t)p);
   TNH_HIP(hipMemcpyAsync(hn.data(), norms, (size_t)p * sizeof(double), hipMemcpyDeviceToHost, stream()));
@@ -304,18 +357,18 @@ static int svd_vectors_t(const SvdLayout& L, int64_t m, int64_t n, char* work, i
   if (!L.transposed) {
     // A = R^T diag(s) W :  U[j][i] = R[perm i][j] (m x k),  Vh[i][:] = X[perm i][:] / s_i (k x n)
     hipLaunchKernelGGL((emit_rows_kernel<T, true>), dim3(grid(k * p)), dim3(256), 0, stream(), (T*)U, R, perm,
-                       norms, k, p, p, 0);
+                       norms, k, p, L.ldr, 0);
     hipLaunchKernelGGL((emit_rows_kernel<T, false>), dim3(grid(k * q)), dim3(256), 0, stream(), (T*)Vh, X, perm,
-                       norms, k, q, q, 1);
+                       norms, k, q, L.ldx, 1);
     TNH_LAUNCH_CHECK();
     return complete_basis<T>((T*)Vh, k, q, false, zero_rows);
   }
   // A^T = R^T diag(s) W  =>  A = W^T diag(s) R :
   //   U[j][i] = X[perm i][j] / s_i (m x k),  Vh[i][:] = R[perm i][:] (k x n)
   hipLaunchKernelGGL((emit_rows_kernel<T, true>), dim3(grid(k * q)), dim3(256), 0, stream(), (T*)U, X, perm,
-                     norms, k, q, q, 1);
+                     norms, k, q, L.ldx, 1);
   hipLaunchKernelGGL((emit_rows_kernel<T, false>), dim3(grid(k * p)), dim3(256), 0, stream(), (T*)Vh, R, perm,
-                     norms, k, p, p, 0);
+                     norms, k, p, L.ldr, 0);
   TNH_LAUNCH_CHECK();
   (void)m; (void)n;
   return complete_basis<T>((T*)U, k, q, true, zero_rows);

@@ -1,0 +1,625 @@
+// K7 (speed path): block one-sided Jacobi for f32, the sweeps of tnh_svd_factor
+// when min(m, n) > 64.
+//
+// The P x Q working matrix X (rows are orthogonalised; P, Q padded to multiples
+// of 128 with zeros) is cut into nb = P/32 row blocks.  A round pairs the blocks
+// by the circle method (nb/2 disjoint pairs, nb-1 rounds per sweep).  For every
+// pair Y = [X_I; X_J] (64 x Q) a round runs three launches:
+//
+//   bj_gram_kernel    G = Y Y^T (64 x 64) on the f32 MFMA (v_mfma_f32_32x32x2_f32),
+//                     operands straight from global memory (the A and B fragments
+//                     of a Gram product are the same 16-byte row pieces), K split
+//                     over waves and workgroups; partial tiles II / IJ / JJ are
+//                     written per split and summed in f64 by the next kernel
+//                     (fixed order: deterministic).
+//   bj_eig_kernel     two-sided cyclic Jacobi on G in LDS (f64, 2x2-tile
+//                     ownership: one barrier pair per inner round), giving the
+//                     64 x 64 orthogonal V with V^T G V diagonal.
+//   bj_update_kernel  Y <- V^T Y and the matching rows of the accumulated factor
+//                     R, again on the MFMA; each wave owns a 128-column strip of
+//                     all 64 rows, so the update is in place.
+//
+// Work per sweep: 8 p^2 q-ish flop on the matrix pipe instead of (p-1) launches of
+// 2-row rotations; X and R stay resident in L2 / Infinity Cache (2 x 67 MB at
+// 4096^2).  Bound: f32 MFMA (157 TF) for gram/update, LDS latency for the eig.
+#include <math.h>
+#include <stdlib.h>
+#include "tnh_types.h"
+
+namespace tnh {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// Circle-method pairing of `n` (even) players: pair `i` of round `r` (a < b).
+__device__ __forceinline__ void bj_pair(int n, int r, int i, int& a, int& b) {
+  const int q = n - 1;
+  if (i == 0) {
+    a = q;
+    b = r % q;
+  } else {
+    a = (r + i) % q;
+    b = (r - i + q) % q;
+  }
+  if (a > b) {
+    const int t = a;
+    a = b;
+    b = t;
+  }
+}
+
+// ---------------------------------------------------------------------- gram
+// grid (pairs, splits), 256 threads.  Wave w of split s covers the 8-column
+// chunks [(4 s + w) cpw, +cpw).  Gp[((pair*S + s)*3 + t)*1024 + row*32 + col],
+// t = 0: II, 1: IJ, 2: JJ.
+__global__ __launch_bounds__(256) void bj_gram_kernel(const float* __restrict__ X, int64_t ldx, int nb,
+                                                      int round, int chunks, int cpw,
+                                                      float* __restrict__ Gp) {
+  __shared__ float red[4][3][1024];
+  const int pair = blockIdx.x, split = blockIdx.y, S = gridDim.y;
+  int bi, bj;
+  bj_pair(nb, round, pair, bi, bj);
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const float* xi = X + ((int64_t)bi * 32 + (lane & 31)) * ldx + 4 * (lane >> 5);
+  const float* xj = X + ((int64_t)bj * 32 + (lane & 31)) * ldx + 4 * (lane >> 5);
+  int c0 = (split * 4 + wid) * cpw;
+  int c1 = c0 + cpw;
+  if (c1 > chunks) c1 = chunks;
+  f32x16 aII, aIJ, aJJ;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) aII[r] = aIJ[r] = aJJ[r] = 0.f;
+  // register ring of PF chunks in flight: the next loads are issued before the
+  // 12 MFMAs (768 cycles) that consume the current chunk
+  constexpr int PF = 4;
+  f32x4 ra[PF], rb[PF];
+#pragma unroll
+  for (int i = 0; i < PF; ++i)
+    if (c0 + i < c1) {
+      ra[i] = *(const f32x4*)(xi + 8 * (int64_t)(c0 + i));
+      rb[i] = *(const f32x4*)(xj + 8 * (int64_t)(c0 + i));
+    }
+  for (int c = c0; c < c1; c += PF) {
+#pragma unroll
+    for (int i = 0; i < PF; ++i) {
+      if (c + i < c1) {
+        const f32x4 a = ra[i], b = rb[i];
+        if (c + i + PF < c1) {
+          ra[i] = *(const f32x4*)(xi + 8 * (int64_t)(c + i + PF));
+          rb[i] = *(const f32x4*)(xj + 8 * (int64_t)(c + i + PF));
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          aII = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], a[e], aII, 0, 0, 0);
+          aIJ = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], b[e], aIJ, 0, 0, 0);
+          aJJ = __builtin_amdgcn_mfma_f32_32x32x2f32(b[e], b[e], aJJ, 0, 0, 0);
+        }
+      }
+    }
+  }
+  // C/D layout: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    const int idx = row * 32 + (lane & 31);
+    red[wid][0][idx] = aII[r];
+    red[wid][1][idx] = aIJ[r];
+    red[wid][2][idx] = aJJ[r];
+  }
+  __syncthreads();
+  float* out = Gp + ((int64_t)pair * S + split) * 3072;
+  const float* r0 = &red[0][0][0];
+  for (int e = tid; e < 3072; e += 256)
+    out[e] = (r0[e] + r0[3072 + e]) + (r0[2 * 3072 + e] + r0[3 * 3072 + e]);
+}
+
+// ----------------------------------------------------------------------- eig
+// One workgroup per pair.  V (64 x 64, row-major f32) -> Jout[pair]; pairflag
+// says whether any rotation was applied (the update skips identity pairs).
+__global__ __launch_bounds__(256) void bj_eig_kernel(const float* __restrict__ Gp, int S,
+                                                     float* __restrict__ Jout, int* __restrict__ pairflag,
+                                                     int* __restrict__ flag, double tol, int max_inner,
+                                                     int sort) {
+  constexpr int W = 64, LD = 65;
+  __shared__ int rank[64];
+  __shared__ double G[W * LD];
+  __shared__ double V[W * LD];
+  __shared__ double cs_c[32], cs_s[32];
+  __shared__ int rotated;
+  const int pair = blockIdx.x, tid = threadIdx.x;
+  const float* gp = Gp + (int64_t)pair * S * 3072;
+  for (int e = tid; e < W * W; e += 256) {
+    const int i = e >> 6, j = e & 63;
+    int t, idx;
+    if (i < 32 && j < 32) { t = 0; idx = i * 32 + j; }
+    else if (i < 32) { t = 1; idx = i * 32 + (j - 32); }
+    else if (j < 32) { t = 1; idx = j * 32 + (i - 32); }
+    else { t = 2; idx = (i - 32) * 32 + (j - 32); }
+    double acc = 0.0;
+    for (int s = 0; s < S; ++s) acc += (double)gp[(int64_t)s * 3072 + t * 1024 + idx];
+    G[i * LD + j] = acc;
+    V[i * LD + j] = (i == j) ? 1.0 : 0.0;
+  }
+  int any = 0;
+  const int l = tid & 31;  // column pair owned in the tile phase / pair in the rotation phase
+  for (int sweep = 0; sweep < max_inner; ++sweep) {
+    __syncthreads();
+    if (tid == 0) rotated = 0;
+    for (int r = 0; r < W - 1; ++r) {
+      __syncthreads();
+      if (tid < 32) {
+        int a, b;
+        bj_pair(W, r, tid, a, b);
+        const double gpp = G[a * LD + a], gqq = G[b * LD + b], gpq = G[a * LD + b];
+        double c = 1.0, s = 0.0;
+        if (fabs(gpq) > tol * sqrt(fabs(gpp * gqq))) {
+          const double zeta = (gqq - gpp) / (2.0 * gpq);
+          const double t = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+          c = 1.0 / sqrt(1.0 + t * t);
+          s = c * t;
+          rotated = 1;
+        }
+        cs_c[tid] = c;
+        cs_s[tid] = s;
+      }
+      __syncthreads();
+      int pl, ql;
+      bj_pair(W, r, l, pl, ql);
+      const double cl = cs_c[l], sl = cs_s[l];
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        const int k = (tid >> 5) + 8 * jj;
+        const double ck = cs_c[k], sk = cs_s[k];
+        if (sk == 0.0 && sl == 0.0) continue;
+        int pk, qk;
+        bj_pair(W, r, k, pk, qk);
+        const double t00 = G[pk * LD + pl], t01 = G[pk * LD + ql];
+        const double t10 = G[qk * LD + pl], t11 = G[qk * LD + ql];
+        const double u00 = ck * t00 - sk * t10, u01 = ck * t01 - sk * t11;
+        const double u10 = sk * t00 + ck * t10, u11 = sk * t01 + ck * t11;
+        double v00 = cl * u00 - sl * u01, v01 = sl * u00 + cl * u01;
+        double v10 = cl * u10 - sl * u11, v11 = sl * u10 + cl * u11;
+        if (k == l) v01 = v10 = 0.0;  // the annihilated element
+        G[pk * LD + pl] = v00;
+        G[pk * LD + ql] = v01;
+        G[qk * LD + pl] = v10;
+        G[qk * LD + ql] = v11;
+      }
+      if (sl != 0.0) {
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) {
+          const int i = (tid >> 5) + 8 * jj;
+          const double vp = V[i * LD + pl], vq = V[i * LD + ql];
+          V[i * LD + pl] = cl * vp - sl * vq;
+          V[i * LD + ql] = sl * vp + cl * vq;
+        }
+      }
+    }
+    __syncthreads();
+    const int rot = rotated;
+    if (!rot) break;
+    any = 1;
+  }
+  __syncthreads();
+  // de Rijk ordering: rows leave the pair sorted by decreasing norm (column i of V
+  // goes to position rank[i]), which speeds up the outer convergence
+  if (tid < W) {
+    int rk = tid;
+    if (sort && any) {
+      const double di = G[tid * LD + tid];
+      rk = 0;
+      for (int j = 0; j < W; ++j) {
+        const double dj = G[j * LD + j];
+        rk += (dj > di || (dj == di && j < tid)) ? 1 : 0;
+      }
+    }
+    rank[tid] = rk;
+  }
+  __syncthreads();
+  float* jo = Jout + (int64_t)pair * (W * W);
+  for (int e = tid; e < W * W; e += 256) jo[(e >> 6) * W + rank[e & 63]] = (float)V[(e >> 6) * LD + (e & 63)];
+  if (tid == 0) {
+    pairflag[pair] = any;
+    if (any) *flag = 1;
+  }
+}
+
+// Faster variant of bj_eig_kernel (the default): G in f32, double buffered so a
+// round needs ONE barrier (rotation parameters and tiles read G[cur], tiles write
+// G[cur^1]); every lane derives the rotation of pair (lane & 31) itself and the
+// row-pair rotations arrive by wave shuffles; the pairing table lives in LDS.
+// The angle comes from f32 data, but (c, s) are formed in f64 from t (c^2+s^2 = 1
+// to f64 accuracy) and V is accumulated in f64: errors in V are coherent across
+// all q columns of the update, so V must be orthogonal to much better than f32.
+template <int NT>
+__global__ __launch_bounds__(NT) void bj_eig2_kernel(const float* __restrict__ Gp, int S,
+                                                     float* __restrict__ Jout, int* __restrict__ pairflag,
+                                                     int* __restrict__ flag, float tol, int max_inner) {
+  constexpr int W = 64, LD = 65, NG = NT / 32, TPT = 32 / NG, VPT = 64 / NG;
+  __shared__ float G[2][W * LD];
+  __shared__ double V[W * LD];
+  __shared__ uint16_t tab[(W - 1) * 32];  // p | q << 8 of pair i in round r
+  __shared__ int rotated;
+  const int pair = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+  const float* gp = Gp + (int64_t)pair * S * 3072;
+  for (int e = tid; e < W * W; e += NT) {
+    const int i = e >> 6, j = e & 63;
+    int t, idx;
+    if (i < 32 && j < 32) { t = 0; idx = i * 32 + j; }
+    else if (i < 32) { t = 1; idx = i * 32 + (j - 32); }
+    else if (j < 32) { t = 1; idx = j * 32 + (i - 32); }
+    else { t = 2; idx = (i - 32) * 32 + (j - 32); }
+    double acc = 0.0;
+    for (int s = 0; s < S; ++s) acc += (double)gp[(int64_t)s * 3072 + t * 1024 + idx];
+    G[0][i * LD + j] = (float)acc;
+    V[i * LD + j] = (i == j) ? 1.0 : 0.0;
+  }
+  for (int e = tid; e < (W - 1) * 32; e += NT) {
+    int a, b;
+    bj_pair(W, e >> 5, e & 31, a, b);
+    tab[e] = (uint16_t)(a | (b << 8));
+  }
+  if (tid == 0) rotated = 0;
+  int any = 0, cur = 0;
+  const int l = tid & 31, g = tid >> 5;
+  const int src_half = lane & 32;
+  for (int sweep = 0; sweep < max_inner; ++sweep) {
+    for (int r = 0; r < W - 1; ++r) {
+      __syncthreads();
+      const float* Gc = G[cur];
+      float* Gn = G[cur ^ 1];
+      const uint16_t* tr = tab + r * 32;
+      const int pql = tr[l];
+      const int pl = pql & 255, ql = pql >> 8;
+      // rotation of pair l
+      const float gpp = Gc[pl * LD + pl], gqq = Gc[ql * LD + ql], gpq = Gc[pl * LD + ql];
+      double cl = 1.0, sl = 0.0;
+      if (fabsf(gpq) > tol * (sqrtf(fabsf(gpp)) * sqrtf(fabsf(gqq)))) {
+        const float zeta = (gqq - gpp) / (2.0f * gpq);
+        const float tf = (zeta >= 0.f ? 1.0f : -1.0f) / (fabsf(zeta) + sqrtf(1.0f + zeta * zeta));
+        const double t = (double)tf, x = 1.0 + t * t;
+        double y = (double)rsqrtf((float)x);
+        y = y * (1.5 - 0.5 * x * y * y);
+        y = y * (1.5 - 0.5 * x * y * y);
+        cl = y;
+        sl = y * t;
+        if (g == 0) rotated = 1;
+      }
+      const float clf = (float)cl, slf = (float)sl;
+#pragma unroll
+      for (int jj = 0; jj < TPT; ++jj) {
+        const int k = g + NG * jj;
+        const int pqk = tr[k];
+        const int pk = pqk & 255, qk = pqk >> 8;
+        const float ck = __shfl(clf, k | src_half, 64), sk = __shfl(slf, k | src_half, 64);
+        const float t00 = Gc[pk * LD + pl], t01 = Gc[pk * LD + ql];
+        const float t10 = Gc[qk * LD + pl], t11 = Gc[qk * LD + ql];
+        const float u00 = ck * t00 - sk * t10, u01 = ck * t01 - sk * t11;
+        const float u10 = sk * t00 + ck * t10, u11 = sk * t01 + ck * t11;
+        float v00 = clf * u00 - slf * u01, v01 = slf * u00 + clf * u01;
+        float v10 = clf * u10 - slf * u11, v11 = slf * u10 + clf * u11;
+        if (k == l && slf != 0.f) v01 = v10 = 0.f;  // the annihilated element
+        Gn[pk * LD + pl] = v00;
+        Gn[pk * LD + ql] = v01;
+        Gn[qk * LD + pl] = v10;
+        Gn[qk * LD + ql] = v11;
+      }
+      if (sl != 0.0) {
+#pragma unroll
+        for (int jj = 0; jj < VPT; ++jj) {
+          const int i = g + NG * jj;
+          const double vp = V[i * LD + pl], vq = V[i * LD + ql];
+          V[i * LD + pl] = cl * vp - sl * vq;
+          V[i * LD + ql] = sl * vp + cl * vq;
+        }
+      }
+      cur ^= 1;
+    }
+    __syncthreads();
+    const int rot = rotated;
+    __syncthreads();
+    if (!rot) break;
+    any = 1;
+    if (tid == 0) rotated = 0;
+  }
+  __syncthreads();
+  float* jo = Jout + (int64_t)pair * (W * W);
+  for (int e = tid; e < W * W; e += NT) jo[e] = (float)V[(e >> 6) * LD + (e & 63)];
+  if (tid == 0) {
+    pairflag[pair] = any;
+    if (any) *flag = 1;
+  }
+}
+
+// Position-space variant (default).  Pair k always sits at positions (2k, 2k+1);
+// after every round the rows/columns move by the fixed circle-method permutation
+// bj_next_pos (period 63, so whole sweeps end where they started).  A 2x2 tile is
+// one float4 in LDS (one ds_read_b128), results are scattered to destinations that
+// are fixed per thread for the whole kernel (precomputed), and V (f64, pairs of
+// columns as one 16-byte item) moves the same way.  Per round and thread:
+// 1 + TPT + VPT 16-byte reads, 4 TPT + 2 VPT scattered writes, 2 TPT shuffles,
+// one barrier.
+__device__ __forceinline__ int bj_next_pos(int p) {
+  if (p == 0) return 0;
+  const int k = p >> 1;
+  if ((p & 1) == 0) return k <= 30 ? 2 * (k + 1) : 63;
+  return k >= 1 ? 2 * (k - 1) + 1 : 2;
+}
+
+template <int NT>
+__global__ __launch_bounds__(NT) void bj_eig3_kernel(const float* __restrict__ Gp, int S,
+                                                     float* __restrict__ Jout, int* __restrict__ pairflag,
+                                                     int* __restrict__ flag, float tol, int max_inner,
+                                                     int cross) {
+  constexpr int W = 64, NG = NT / 32, TPT = 32 / NG, VPT = 64 / NG;
+  __shared__ f32x4 T[2][32 * 32];        // tile (k, l): (G[2k][2l], G[2k][2l+1], G[2k+1][2l], G[2k+1][2l+1])
+  __shared__ double Vt[2][W * W];        // V[i][pos], row-major
+  __shared__ int rotated;
+  const int pair = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+  const float* gp = Gp + (int64_t)pair * S * 3072;
+  float* T0 = (float*)&T[0][0];
+  // cross mode (only pairs with one row in each block are rotated, 32 rounds):
+  // position 2k = row k of block I, position 2k+1 = a row of block J; the J side
+  // shifts by one slot per round.  full mode: position == index, 63 rounds.
+  auto pos_of = [&](int i) { return cross ? (i < 32 ? 2 * i : 2 * (i - 32) + 1) : i; };
+  auto next_pos = [&](int p) {
+    if (!cross) return bj_next_pos(p);
+    return (p & 1) ? 2 * (((p >> 1) + 1) & 31) + 1 : p;
+  };
+  for (int e = tid; e < W * W; e += NT) {
+    const int i = e >> 6, j = e & 63;
+    int t, idx;
+    if (i < 32 && j < 32) { t = 0; idx = i * 32 + j; }
+    else if (i < 32) { t = 1; idx = i * 32 + (j - 32); }
+    else if (j < 32) { t = 1; idx = j * 32 + (i - 32); }
+    else { t = 2; idx = (i - 32) * 32 + (j - 32); }
+    double acc = 0.0;
+    for (int s = 0; s < S; ++s) acc += (double)gp[(int64_t)s * 3072 + t * 1024 + idx];
+    const int pi = pos_of(i), pj = pos_of(j);
+    T0[((pi >> 1) * 32 + (pj >> 1)) * 4 + (pi & 1) * 2 + (pj & 1)] = (float)acc;
+    Vt[0][i * W + pj] = (i == j) ? 1.0 : 0.0;
+  }
+  if (tid == 0) rotated = 0;
+  const int l = tid & 31, g = tid >> 5;
+  const int src_half = lane & 32;
+  // fixed scatter destinations (float offsets inside a T buffer / double offsets inside a V row)
+  const int nc0 = next_pos(2 * l), nc1 = next_pos(2 * l + 1);
+  int dst[TPT][4];
+#pragma unroll
+  for (int jj = 0; jj < TPT; ++jj) {
+    const int k = g + NG * jj;
+    const int nr0 = next_pos(2 * k), nr1 = next_pos(2 * k + 1);
+    dst[jj][0] = ((nr0 >> 1) * 32 + (nc0 >> 1)) * 4 + (nr0 & 1) * 2 + (nc0 & 1);
+    dst[jj][1] = ((nr0 >> 1) * 32 + (nc1 >> 1)) * 4 + (nr0 & 1) * 2 + (nc1 & 1);
+    dst[jj][2] = ((nr1 >> 1) * 32 + (nc0 >> 1)) * 4 + (nr1 & 1) * 2 + (nc0 & 1);
+    dst[jj][3] = ((nr1 >> 1) * 32 + (nc1 >> 1)) * 4 + (nr1 & 1) * 2 + (nc1 & 1);
+  }
+  const int nrounds = cross ? 32 : W - 1;
+  int any = 0, cur = 0;
+  for (int sweep = 0; sweep < max_inner; ++sweep) {
+    for (int r = 0; r < nrounds; ++r) {
+      __syncthreads();
+      const f32x4* Tc = T[cur];
+      float* Tn = (float*)T[cur ^ 1];
+      const double* Vc = Vt[cur];
+      double* Vn = Vt[cur ^ 1];
+      // rotation of pair l from its diagonal tile: f32 chain first (feeds the tiles)
+      const f32x4 d = Tc[l * 32 + l];
+      const float gpp = d[0], gpq = d[1], gqq = d[3];
+      float tf = 0.f;
+      if (fabsf(gpq) > tol * (__builtin_amdgcn_sqrtf(fabsf(gpp)) * __builtin_amdgcn_sqrtf(fabsf(gqq)))) {
+        const float zeta = (gqq - gpp) * __builtin_amdgcn_rcpf(2.0f * gpq);
+        const float den = fabsf(zeta) + __builtin_amdgcn_sqrtf(1.0f + zeta * zeta);
+        tf = __builtin_amdgcn_rcpf(den);
+        tf = (zeta >= 0.f) ? tf : -tf;
+        if (!(fabsf(tf) <= 1.0f)) tf = 0.f;  // inf / nan guard
+        if (g == 0 && tf != 0.f) rotated = 1;
+      }
+      const float clf = __builtin_amdgcn_rsqf(1.0f + tf * tf), slf = clf * tf;
+#pragma unroll
+      for (int jj = 0; jj < TPT; ++jj) {
+        const int k = g + NG * jj;
+        const float ck = __shfl(clf, k | src_half, 64), sk = __shfl(slf, k | src_half, 64);
+        const f32x4 t = Tc[k * 32 + l];
+        const float u00 = ck * t[0] - sk * t[2], u01 = ck * t[1] - sk * t[3];
+        const float u10 = sk * t[0] + ck * t[2], u11 = sk * t[1] + ck * t[3];
+        float v00 = clf * u00 - slf * u01, v01 = slf * u00 + clf * u01;
+        float v10 = clf * u10 - slf * u11, v11 = slf * u10 + clf * u11;
+        if (k == l && tf != 0.f) v01 = v10 = 0.f;  // the annihilated element
+        Tn[dst[jj][0]] = v00;
+        Tn[dst[jj][1]] = v01;
+        Tn[dst[jj][2]] = v10;
+        Tn[dst[jj][3]] = v11;
+      }
+      // (c, s) in f64 from t for V: c^2 + s^2 = 1 to f64 accuracy
+      const double t = (double)tf, x = 1.0 + t * t;
+      double y = (double)clf;
+      y = y * (1.5 - 0.5 * x * y * y);
+      y = y * (1.5 - 0.5 * x * y * y);
+      const double cl = y, sl = y * t;
+#pragma unroll
+      for (int jj = 0; jj < VPT; ++jj) {
+        const int i = g + NG * jj;
+        const double vp = Vc[i * W + 2 * l], vq = Vc[i * W + 2 * l + 1];
+        Vn[i * W + nc0] = cl * vp - sl * vq;
+        Vn[i * W + nc1] = sl * vp + cl * vq;
+      }
+      cur ^= 1;
+    }
+    __syncthreads();
+    const int rot = rotated;
+    __syncthreads();
+    if (!rot) break;
+    any = 1;
+    if (tid == 0) rotated = 0;
+  }
+  __syncthreads();
+  // whole sweeps = full periods of the permutation: positions are back where they started
+  const double* Vf = Vt[cur];
+  float* jo = Jout + (int64_t)pair * (W * W);
+  for (int e = tid; e < W * W; e += NT) jo[e] = (float)Vf[(e >> 6) * W + pos_of(e & 63)];
+  if (tid == 0) {
+    pairflag[pair] = any;
+    if (any) *flag = 1;
+  }
+}
+
+// -------------------------------------------------------------------- update
+// grid (pairs, ceil(nss / 4)), 256 threads; wave = one 128-column super-strip of
+// [X | R].  Y'[a][c] = sum_k V[k][a] Y[k][c].
+__global__ __launch_bounds__(256) void bj_update_kernel(float* __restrict__ X, int64_t ldx, int nssX,
+                                                        float* __restrict__ R, int64_t ldr, int nssR,
+                                                        int nb, int round, const float* __restrict__ J,
+                                                        const int* __restrict__ pairflag) {
+  const int pair = blockIdx.x;
+  if (!pairflag[pair]) return;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int ss = blockIdx.y * 4 + wid;
+  if (ss >= nssX + nssR) return;
+  int bi, bj;
+  bj_pair(nb, round, pair, bi, bj);
+  float* base;
+  int64_t ld;
+  if (ss < nssX) { base = X + (int64_t)ss * 128; ld = ldx; }
+  else { base = R + (int64_t)(ss - nssX) * 128; ld = ldr; }
+  const int i = lane & 31, kk = lane >> 5;
+  const float* Jp = J + (int64_t)pair * 4096;
+  auto grow = [&](int row) -> int64_t { return row < 32 ? (int64_t)bi * 32 + row : (int64_t)bj * 32 + (row - 32); };
+
+  float jf[2][32];
+#pragma unroll
+  for (int ks = 0; ks < 32; ++ks) {
+    jf[0][ks] = Jp[(2 * ks + kk) * 64 + i];
+    jf[1][ks] = Jp[(2 * ks + kk) * 64 + 32 + i];
+  }
+  f32x4 bv[32];
+#pragma unroll
+  for (int ks = 0; ks < 32; ++ks) bv[ks] = *(const f32x4*)(base + grow(2 * ks + kk) * ld + 4 * i);
+
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    f32x16 acc[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[s][r] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 32; ++ks)
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+        acc[s] = __builtin_amdgcn_mfma_f32_32x32x2f32(jf[it][ks], bv[ks][s], acc[s], 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = 32 * it + (r & 3) + 8 * (r >> 2) + 4 * kk;
+      f32x4 o;
+      o[0] = acc[0][r]; o[1] = acc[1][r]; o[2] = acc[2][r]; o[3] = acc[3][r];
+      *(f32x4*)(base + grow(row) * ld + 4 * i) = o;
+    }
+  }
+}
+
+// Xp (P x Q, zero padded) = A (m x n row-major) or its transpose.
+template <bool TRANS>
+__global__ __launch_bounds__(256) void bj_pad_copy_kernel(float* __restrict__ Xp, int64_t Q,
+                                                          const float* __restrict__ A, int64_t m, int64_t n) {
+  __shared__ float tile[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  const int64_t r0 = (int64_t)blockIdx.y * 32, c0 = (int64_t)blockIdx.x * 32;  // tile origin in Xp
+  if (!TRANS) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int64_t r = r0 + ty + 8 * j, c = c0 + tx;
+      Xp[r * Q + c] = (r < m && c < n) ? A[r * n + c] : 0.f;
+    }
+  } else {
+    // Xp[r][c] = A[c][r]; rows of Xp index columns of A (r < n), cols of Xp index rows of A (c < m)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int64_t ar = c0 + ty + 8 * j, ac = r0 + tx;
+      tile[ty + 8 * j][tx] = (ar < m && ac < n) ? A[ar * n + ac] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) Xp[(r0 + ty + 8 * j) * Q + c0 + tx] = tile[tx][ty + 8 * j];
+  }
+}
+
+int svd_block_pad_copy(float* Xp, int64_t P, int64_t Q, const float* A, int64_t m, int64_t n, bool trans) {
+  const dim3 grid((unsigned)(Q / 32), (unsigned)(P / 32));
+  if (trans) hipLaunchKernelGGL((bj_pad_copy_kernel<true>), grid, dim3(256), 0, stream(), Xp, Q, A, m, n);
+  else hipLaunchKernelGGL((bj_pad_copy_kernel<false>), grid, dim3(256), 0, stream(), Xp, Q, A, m, n);
+  TNH_LAUNCH_CHECK();
+  return TNH_OK;
+}
+
+size_t svd_block_scratch_bytes(int64_t P, int64_t Q) {
+  const int64_t pairs = P / 64;
+  (void)Q;
+  return (size_t)pairs * 16 * 3072 * sizeof(float)   // Gram partials (<= 16 splits)
+         + (size_t)pairs * 4096 * sizeof(float)      // V per pair
+         + (size_t)pairs * sizeof(int) + 256;        // pair flags
+}
+
+// Sweeps until a whole sweep applies no rotation.  X: P x Q (ld Q), R: P x P.
+int svd_block_sweeps(float* X, float* R, int64_t P, int64_t Q, char* scratch, int* flag, double tol,
+                     int max_sweeps, int* sweeps_out, bool* converged_out) {
+  const int nb = (int)(P / 32), pairs = nb / 2;
+  float* Gp = (float*)scratch;
+  float* J = Gp + (size_t)pairs * 16 * 3072;
+  int* pairflag = (int*)(J + (size_t)pairs * 4096);
+  const int chunks = (int)(Q / 8);
+  // splits: enough workgroups to fill the chip, each wave with >= 4 chunks of work
+  int S = (2 * num_cus() + pairs - 1) / pairs;
+  if (S > 16) S = 16;
+  while (S > 1 && chunks / (4 * S) < 4) --S;
+  if (S < 1) S = 1;
+  const int cpw = (chunks + 4 * S - 1) / (4 * S);
+  const int nssX = (int)(Q / 128), nssR = (int)(P / 128);
+  const char* env = getenv("TNH_SVD_INNER");
+  const int inner = env ? atoi(env) : 1;
+  const char* env0 = getenv("TNH_SVD_INNER0");
+  const int inner0 = env0 ? atoi(env0) : inner;
+  const char* envs = getenv("TNH_SVD_SORT");
+  const int sort = envs ? atoi(envs) : 0;
+  const char* enve = getenv("TNH_SVD_EIG");
+  const int eigv = enve ? atoi(enve) : 4;
+  const char* envc = getenv("TNH_SVD_CROSS");
+  const int crossv = envc ? atoi(envc) : 1;
+  int sweeps = 0;
+  bool converged = false;
+  while (!converged && sweeps < max_sweeps) {
+    TNH_HIP(hipMemsetAsync(flag, 0, sizeof(int), stream()));
+    for (int r = 0; r < nb - 1; ++r) {
+      hipLaunchKernelGGL(bj_gram_kernel, dim3((unsigned)pairs, (unsigned)S), dim3(256), 0, stream(), X, Q, nb, r,
+                         chunks, cpw, Gp);
+      const int mi = sweeps == 0 ? inner0 : inner;
+      if (eigv == 0)
+        hipLaunchKernelGGL(bj_eig_kernel, dim3((unsigned)pairs), dim3(256), 0, stream(), Gp, S, J, pairflag,
+                           flag, tol, mi, sort);
+      else if (eigv == 1)
+        hipLaunchKernelGGL((bj_eig2_kernel<256>), dim3((unsigned)pairs), dim3(256), 0, stream(), Gp, S, J,
+                           pairflag, flag, (float)tol, mi);
+      else if (eigv == 2)
+        hipLaunchKernelGGL((bj_eig2_kernel<512>), dim3((unsigned)pairs), dim3(512), 0, stream(), Gp, S, J,
+                           pairflag, flag, (float)tol, mi);
+      else if (eigv == 3)
+        hipLaunchKernelGGL((bj_eig3_kernel<512>), dim3((unsigned)pairs), dim3(512), 0, stream(), Gp, S, J,
+                           pairflag, flag, (float)tol, mi, (crossv && r > 0) ? 1 : 0);
+      else
+        hipLaunchKernelGGL((bj_eig3_kernel<1024>), dim3((unsigned)pairs), dim3(1024), 0, stream(), Gp, S, J,
+                           pairflag, flag, (float)tol, mi, (crossv && r > 0) ? 1 : 0);
+      hipLaunchKernelGGL(bj_update_kernel, dim3((unsigned)pairs, (unsigned)((nssX + nssR + 3) / 4)), dim3(256), 0,
+                         stream(), X, Q, nssX, R, P, nssR, nb, r, J, pairflag);
+    }
+    TNH_LAUNCH_CHECK();
+    int h = 0;
+    TNH_HIP(hipMemcpyAsync(&h, flag, sizeof(int), hipMemcpyDeviceToHost, stream()));
+    TNH_HIP(hipStreamSynchronize(stream()));
+    ++sweeps;
+    converged = (h == 0);
+  }
+  *sweeps_out = sweeps;
+  *converged_out = converged;
+  return TNH_OK;
+}
+
+}  // namespace tnh
