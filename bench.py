@@ -13,11 +13,18 @@ so every rank contracts its own pair of nodes (weak scaling, no data-path
 collective) and ``value`` is the aggregate.
 
 Extra objects on the same line:
-  roofline     -- the dominant kernel (bf16 MFMA GEMM) timed with HIP events on
-                  the library's stream inside the timed region, vs 2.5 PFLOP/s.
-  cpu_baseline -- the NumPy oracle (port of the reference's tensordot) timed on
-                  this box's host cores on a bounded sample (same layout, smaller D).
-  svd          -- split_node truncated SVD (configs[2]) in the metric's GB/s.
+  roofline       -- the dominant kernel (bf16 MFMA GEMM) timed with HIP events on
+                    the library's stream inside the timed region, vs 2.5 PFLOP/s;
+                    `traffic` = HBM bytes per launch from the committed rocprofv3 PMC
+                    pass of this same command (profiles/*_traffic.json), else null.
+  cpu_baseline   -- the NumPy oracle (port of the reference's tensordot) timed on
+                    this box's host cores on a bounded sample (same layout, smaller D).
+  svd            -- split_node truncated SVD (configs[2]: (16,)*6 node -> 4096 x 4096,
+                    keep 256) in the metric's GB/s, with the oracle's LAPACK SVD timed
+                    on a bounded sample beside it.
+  sliced_network -- the north-star scaling network (64-node random 3-regular graph, bond
+                    D, bf16): bond-sliced greedy contraction, slices dealt over the N
+                    ranks, ONE all-reduce of the scalar (strong scaling: fixed total work).
 """
 import argparse
 import json
@@ -41,7 +48,10 @@ def parse_args():
   p.add_argument("--warmup", type=int, default=2)
   p.add_argument("--bond", type=int, default=256, help="bond dimension D of the rank-4 nodes")
   p.add_argument("--layout", default="L0", choices=["L0", "L1"])
-  p.add_argument("--svd-n", type=int, default=2048, help="side of the split_node matrix (0 = skip)")
+  p.add_argument("--svd-n", type=int, default=4096, help="side of the split_node matrix (0 = skip)")
+  p.add_argument("--rr-bond", type=int, default=12,
+                 help="bond dimension of the 64-node random-regular network (0 = skip)")
+  p.add_argument("--rr-min-slices", type=int, default=64)
   p.add_argument("--no-cpu-baseline", action="store_true")
   p.add_argument("--fill", default="normal", choices=["normal", "zeros"],
                  help="operand fill (zeros shows the DVFS-inflated number; never the headline)")
@@ -147,8 +157,78 @@ def svd_bench(ta, be, n, k):
   nbytes = 4 * (n * n + n * k + n + k * n)  # read A, write u_k, all s, vh_k
   return {"n": n, "k": k, "seconds": t, "gbps": nbytes / t / 1e9, "sweeps": be.last_svd_sweeps,
           "algorithmic_bytes": nbytes, "trunc_len": int(trun.shape[0]),
-          "note": "Jacobi sweeps are L2/Infinity-Cache traffic bound, not within reach of the "
-                  "algorithmic-bytes HBM bound (see DESIGN.md)"}
+          "workload": f"split_node of a {shape} f32 node as {n}x{n}, max_singular_values={k} (second call; "
+                      "first call warms the allocator)",
+          "note": "block one-sided Jacobi: f32-MFMA gram/update + LDS eigensolver per block pair; bound by "
+                  "MFMA flops and LDS latency over ~17 sweeps, not by the algorithmic-bytes HBM figure "
+                  "(see DESIGN.md)"}
+
+
+def svd_cpu_baseline(n_full):
+  """The oracle's SVD (np.linalg.svd, the reference's decompositions.py:36) on a bounded sample."""
+  from oracle import numpy_oracle as orc  # pylint: disable=import-outside-toplevel
+  rng = np.random.default_rng(3)
+  n = min(n_full, 1024)
+  x = rng.standard_normal((n, n)).astype(np.float32)
+  t0 = time.perf_counter()
+  orc.svd(x, 1, max_singular_values=n // 16)
+  t = time.perf_counter() - t0
+  if n < n_full and t * (n_full / n) ** 3 < 25.0:   # full size affordable: time it for real
+    n = n_full
+    x = rng.standard_normal((n, n)).astype(np.float32)
+    t0 = time.perf_counter()
+    orc.svd(x, 1, max_singular_values=n // 16)
+    t = time.perf_counter() - t0
+  k = n // 16
+  nbytes = 4 * (n * n + n * k + n + k * n)
+  return {"value": nbytes / t / 1e9, "unit": "GB/s", "seconds": t, "kind": "port",
+          "sample": f"oracle svd (np.linalg.svd) of {n}x{n} f32, keep {k}"}
+
+
+def sliced_network_bench(ta, be, dist, rank, world, D, min_slices):
+  """64-node random 3-regular network, bf16, bond-sliced greedy contraction."""
+  from tensornetwork_amd import distributed, workloads  # pylint: disable=import-outside-toplevel
+  n = 64
+  tensors = workloads.random_regular_device_tensors(be, n, D, ta.bfloat16, seed=6)
+  nodes = workloads.random_regular_network(be, n=n, D=D, seed=6, tensors=tensors)
+  cuts = distributed.choose_cut_edges(nodes, min_slices=min_slices)
+  rep = distributed.slicing_report(nodes, cuts)
+  comm = distributed.TorchDistComm() if dist is not None else distributed.LocalComm()
+  # warm-up on a few slices (allocator, kernels), then the timed full contraction
+  class _Few(distributed.LocalComm):
+    rank, world = 0, max(1, int(rep["n_slices"]) // 2)
+  distributed.contract_sliced(nodes, cuts, comm=_Few())
+  sync_all(be, dist)
+  t0 = time.perf_counter()
+  out = distributed.contract_sliced(nodes, cuts, comm=comm)
+  sync_all(be, dist)
+  t = time.perf_counter() - t0
+  if dist is not None:
+    import torch  # pylint: disable=import-outside-toplevel
+    tt = torch.tensor([t], dtype=torch.float64, device="cuda")
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    t = float(tt.item())
+  total_flops = rep["flops_per_slice"] * rep["n_slices"]
+  return {"workload": f"64-node random 3-regular network (seed 6), bond D={D}, bf16, {len(cuts)} cut bonds",
+          "n_slices": int(rep["n_slices"]), "n_gpus": world, "seconds": t, "scaling": "strong",
+          "flops_total": total_flops, "tflops": total_flops / t / 1e12,
+          "peak_intermediate_elems": rep["peak_per_slice"],
+          "collective": "one all-reduce(sum) of the scalar" if world > 1 else "none",
+          "result": float(np.asarray(out).reshape(-1)[0])}
+
+
+def load_traffic(kernel_name, M, N, K):
+  """HBM bytes per launch of the headline kernel from the committed rocprofv3 PMC pass."""
+  import glob  # pylint: disable=import-outside-toplevel
+  for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")), reverse=True):
+    try:
+      with open(path) as f:
+        rec = json.load(f)
+    except (OSError, ValueError):
+      continue
+    if rec.get("kernel") == kernel_name and rec.get("shape") == [M, N, K]:
+      return rec.get("hbm_bytes"), os.path.basename(path)
+  return None, None
 
 
 def main():
@@ -188,6 +268,7 @@ def main():
   gemm_avg_s = (sum(gemm_ms) / len(gemm_ms) / 1e3) if gemm_ms else float("nan")
   achieved = flops_per_step / gemm_avg_s / 1e12 if gemm_ms else float("nan")
 
+  traffic, traffic_src = load_traffic(kernel_name, M, N, K)
   result = {
       "metric": "contracted-elements/sec (TFLOP/s) + SVD GB/s, bond-dim sweep, 1/2/4/8 MI355X",
       "value": flops_per_step * args.steps * world / elapsed / 1e12,
@@ -206,14 +287,24 @@ def main():
                  "parallelism": "1 GPU" if world == 1 else f"{world} independent pairwise contractions "
                                                            "(no data-path collective)"},
       "roofline": {"bound": "mfma", "achieved": achieved, "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                   "frac": achieved / BF16_MFMA_PEAK_TFLOPS, "traffic": None, "kernel": kernel_name,
+                   "frac": achieved / BF16_MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
+                   "algorithmic_bytes": 2.0 * (M * K + N * K + M * N), "kernel": kernel_name,
                    "kernel_ms": gemm_avg_s * 1e3, "launches": len(gemm_ms)},
   }
+  del A, B
+  _lib.check(be.lib.tnh_trim())
+  if args.rr_bond > 0:
+    try:
+      sliced = sliced_network_bench(ta, be, dist, rank, world, args.rr_bond, args.rr_min_slices)
+    except Exception as exc:  # pylint: disable=broad-except
+      sliced = {"error": f"{type(exc).__name__}: {exc}"}
+    result["sliced_network"] = sliced
   if rank == 0:
     if world == 1 and args.svd_n > 0:
-      del A, B
-      _lib.check(be.lib.tnh_trim())
+      svd_bench(ta, be, args.svd_n, max(args.svd_n // 16, 1))  # warm-up
       result["svd"] = svd_bench(ta, be, args.svd_n, max(args.svd_n // 16, 1))
+      if not args.no_cpu_baseline:
+        result["svd"]["cpu_baseline"] = svd_cpu_baseline(args.svd_n)
     if world == 1 and not args.no_cpu_baseline:
       result["cpu_baseline"] = cpu_baseline(args.layout)
     print(json.dumps(result))

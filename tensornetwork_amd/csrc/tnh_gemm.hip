@@ -325,7 +325,7 @@ int tnh_gemm_set_variant(const char* full) {
   // "<variant>[:r<digit>][:p<digit>]" -- the suffixes set A/B knobs of the bf16 speed path
   char name[64];
   snprintf(name, sizeof(name), "%s", full);
-  tnh::g_opt_raster = 0;
+  tnh::g_opt_raster = 1;
   tnh::g_opt_phases = 2;
   for (char* c = strchr(name, ':'); c != nullptr;) {
     *c = 0;

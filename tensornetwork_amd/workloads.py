@@ -1,0 +1,194 @@
+"""The BASELINE.json workloads as network builders (shared by bench.py, tools/ and tests/).
+
+Every builder takes a backend and returns freshly connected ``network.Node`` lists,
+so the same topology can be contracted by the hip backend and by the CPU oracle.
+
+  random_regular_network  north-star scaling network: one rank-3 tensor per vertex of a
+                          random 3-regular graph, closed -> scalar.
+  mps_overlap_network     BASELINE configs[3]: <psi|psi> of an open-boundary MPS
+                          (kets + conjugated bras), `contractors.greedy` target.
+  mera_layer_network      BASELINE configs[4]: the 12-node binary-MERA layer energy network
+                          of examples/simple_mera/simple_mera.py:54-112 ('left'/'right').
+"""
+from typing import Dict, List, Sequence, Tuple
+
+import numpy as np
+
+from tensornetwork_amd import network
+
+
+# ------------------------------------------------------------------ 3-regular graph
+def regular_graph_edges(n: int, degree: int = 3, seed: int = 6) -> List[Tuple[int, int]]:
+  """Edge list of a random `degree`-regular simple graph on n vertices, sorted.
+
+  networkx.random_regular_graph(degree, n, seed) when networkx is importable (the graph
+  SURVEY.md 8d names); otherwise a seeded pairing model with rejection (same properties,
+  different instance)."""
+  try:
+    import networkx as nx  # pylint: disable=import-outside-toplevel
+    return sorted(tuple(sorted(e)) for e in nx.random_regular_graph(degree, n, seed=seed).edges)
+  except ImportError:
+    pass
+  rng = np.random.default_rng(seed)
+  while True:
+    stubs = np.repeat(np.arange(n), degree)
+    rng.shuffle(stubs)
+    pairs = stubs.reshape(-1, 2)
+    edges = {tuple(sorted(p)) for p in pairs.tolist()}
+    if len(edges) == len(pairs) and all(a != b for a, b in edges):
+      return sorted(edges)
+
+
+def random_regular_network(be, n: int = 64, D: int = 4, seed: int = 6, dtype=np.float32,
+                           tensors: Sequence = None, scale: float = None):
+  """Closed network on a random 3-regular graph; entries N(0, scale^2), scale = D^(-3/4)
+  by default so that the contracted scalar is O(1) (variance D^(3n/2) scale^(2n))."""
+  edges = regular_graph_edges(n, 3, seed)
+  if tensors is None:
+    rng = np.random.default_rng(seed)
+    sc = float(D) ** -0.75 if scale is None else scale
+    tensors = [(rng.standard_normal((D, D, D)) * sc).astype(dtype) for _ in range(n)]
+  nodes = [network.Node(t, backend=be) for t in tensors]
+  slot = [0] * n
+  for x, y in edges:
+    network.connect(nodes[x][slot[x]], nodes[y][slot[y]])
+    slot[x] += 1
+    slot[y] += 1
+  return nodes
+
+
+def random_regular_device_tensors(be, n: int, D: int, dtype, seed: int = 6, scale: float = None):
+  """Operands of `random_regular_network` generated in HBM (bench sizes)."""
+  sc = float(D) ** -0.75 if scale is None else scale
+  return [be.device_random((D, D, D), dtype=dtype, seed=1000 * seed + v, normal=True, a=0.0, b=sc)
+          for v in range(n)]
+
+
+# ------------------------------------------------------------------------ MPS chain
+def mps_tensors(n_sites: int, d: int, D: int, seed: int = 5, dtype=np.float32):
+  rng = np.random.default_rng(seed)
+  dims = [1] + [D] * (n_sites - 1) + [1]
+  return [(rng.standard_normal((dims[i], d, dims[i + 1])) / np.sqrt(d * max(dims[i], 1))).astype(dtype)
+          for i in range(n_sites)]
+
+
+def mps_overlap_network(be, kets: Sequence):
+  """2 n nodes: kets A_i[l, p, r] and their conjugates, physical and bond legs connected."""
+  n = len(kets)
+  nk = [network.Node(k, backend=be) for k in kets]
+  nb = [network.Node(np.conj(k) if isinstance(k, np.ndarray) else be.conj(k), backend=be) for k in kets]
+  for i in range(n):
+    network.connect(nk[i][1], nb[i][1])
+    if i + 1 < n:
+      network.connect(nk[i][2], nk[i + 1][0])
+      network.connect(nb[i][2], nb[i + 1][0])
+  network.connect(nk[0][0], nb[0][0])
+  network.connect(nk[-1][2], nb[-1][2])
+  return nk + nb
+
+
+# ----------------------------------------------------------------------- MERA layer
+# (node, axis) -- (node, axis) tables restating the wiring of
+# examples/simple_mera/simple_mera.py:71-107.  Node names: w* isometries (rank 3:
+# two lower legs, one upper), u* disentanglers (rank 4), 'c' suffix = conjugate copy,
+# h = 3-site hamiltonian (rank 6), rho = 3-site reduced state (rank 6).
+_MERA_COMMON = [
+    ("wl", 2, "rho", 0), ("wc", 2, "rho", 1), ("wr", 2, "rho", 2),
+    ("wl", 0, "wlc", 0), ("wl", 1, "ul", 2), ("wc", 0, "ul", 3),
+    ("wc", 1, "ur", 2), ("wr", 0, "ur", 3), ("wr", 1, "wrc", 1),
+    ("ulc", 2, "wlc", 1), ("ulc", 3, "wcc", 0), ("urc", 2, "wcc", 1), ("urc", 3, "wrc", 0),
+    ("wlc", 2, "rho", 3), ("wcc", 2, "rho", 4), ("wrc", 2, "rho", 5),
+]
+_MERA_PLACEMENT = {
+    "right": [("ul", 0, "ulc", 0), ("ul", 1, "h", 3), ("ur", 0, "h", 4), ("ur", 1, "h", 5),
+              ("h", 0, "ulc", 1), ("h", 1, "urc", 0), ("h", 2, "urc", 1)],
+    "left": [("ul", 0, "h", 3), ("ul", 1, "h", 4), ("ur", 0, "h", 5), ("ur", 1, "urc", 1),
+             ("h", 0, "ulc", 0), ("h", 1, "ulc", 1), ("h", 2, "urc", 0)],
+}
+
+
+def mera_layer_network(be, hamiltonian, state, isometry, disentangler, placement: str):
+  """The 12 connected nodes of one binary-MERA layer energy term (closed network).
+
+  With ``hamiltonian=None`` the h node is left out and its six partner legs stay
+  dangling: contracting that network gives dE/dh, i.e. the descended state of
+  simple_mera.py:117-128 (the reference gets it from jax.grad); the second return value
+  is then the dangling edges in the order of h's axes."""
+  conj = lambda t: np.conj(t) if isinstance(t, np.ndarray) else be.conj(t)
+  mk = lambda t: network.Node(t, backend=be)
+  nodes: Dict[str, network.Node] = {
+      "wl": mk(isometry), "wc": mk(isometry), "wr": mk(isometry),
+      "wlc": mk(conj(isometry)), "wcc": mk(conj(isometry)), "wrc": mk(conj(isometry)),
+      "ul": mk(disentangler), "ur": mk(disentangler),
+      "ulc": mk(conj(disentangler)), "urc": mk(conj(disentangler)),
+      "rho": mk(state),
+  }
+  if hamiltonian is not None:
+    nodes["h"] = mk(hamiltonian)
+  open_legs = {}
+  for a, i, b, j in _MERA_COMMON + _MERA_PLACEMENT[placement]:
+    if hamiltonian is None and "h" in (a, b):
+      other, oax, hax = (b, j, i) if a == "h" else (a, i, j)
+      open_legs[hax] = nodes[other][oax]
+      continue
+    network.connect(nodes[a][i], nodes[b][j])
+  if hamiltonian is None:
+    return list(nodes.values()), [open_legs[ax] for ax in range(6)]
+  return list(nodes.values())
+
+
+def mera_energy(be, hamiltonian, state, isometry, disentangler, contractor):
+  """0.5 * (left + right) layer energy, simple_mera.py:53-112; `contractor(nodes)` -> Node."""
+  out = [contractor(mera_layer_network(be, hamiltonian, state, isometry, disentangler, pl)).tensor
+         for pl in ("left", "right")]
+  return be.multiply(be.addition(out[0], out[1]), 0.5)
+
+
+def mera_descend(be, state, isometry, disentangler, contractor):
+  """Descending super-operator: average over placements of the layer network with h removed.
+  `contractor(nodes, output_edge_order)` -> Node."""
+  out = []
+  for pl in ("left", "right"):
+    nodes, legs = mera_layer_network(be, None, state, isometry, disentangler, pl)
+    out.append(contractor(nodes, legs).tensor)
+  return be.multiply(be.addition(out[0], out[1]), 0.5)
+
+
+def ham_ising():
+  """3-site critical-Ising term  X Z X - (X X 1 + 1 X X)/2  (Evenbly & White 2016), as used by
+  simple_mera.py:298-309."""
+  E, X, Z = np.eye(2), np.array([[0., 1.], [1., 0.]]), np.diag([1., -1.])
+  k3 = lambda a, b, c: np.kron(a, np.kron(b, c))
+  return (k3(X, Z, X) - 0.5 * (k3(X, X, E) + k3(E, X, X))).reshape((2,) * 6)
+
+
+def wavelet_mera_tensors():
+  """D = 2 wavelet MERA (isometry, disentangler) of simple_mera_test.py:91-120, real form.
+  The reference writes them with Pauli products; X(x)Y and Y(x)X enter as i*X(x)Y, so with
+  iY = [[0, 1], [-1, 0]] everything is real."""
+  r2, r3 = np.sqrt(2.0), np.sqrt(3.0)
+  E, X, Z = np.eye(2), np.array([[0., 1.], [1., 0.]]), np.diag([1., -1.])
+  iY = np.array([[0., 1.], [-1., 0.]])
+  wmat = ((r3 + r2) / 4 * np.kron(E, E) + (r3 - r2) / 4 * np.kron(Z, Z)
+          + (1 + r2) / 4 * np.kron(X, iY) + (1 - r2) / 4 * np.kron(iY, X))
+  umat = ((r3 + 2) / 4 * np.kron(E, E) + (r3 - 2) / 4 * np.kron(Z, Z)
+          + 0.25 * np.kron(X, iY) + 0.25 * np.kron(iY, X))
+  w = np.transpose(wmat.reshape(2, 2, 2, 2)[:, 0, :, :], (1, 2, 0))
+  u = np.transpose(umat.reshape(2, 2, 2, 2), (2, 3, 0, 1))
+  return w, u
+
+
+def mera_random_tensors(chi: int, seed: int = 7, dtype=np.float32):
+  """Random isometry / unitary disentangler (QR of Gaussians), Hermitian hamiltonian and a
+  PSD unit-trace 3-site state -- the construction of simple_mera_test.py:69-88, real dtype."""
+  rng = np.random.default_rng(seed)
+  q, _ = np.linalg.qr(rng.standard_normal((chi * chi, chi)))
+  iso = q.reshape(chi, chi, chi).astype(dtype)
+  q, _ = np.linalg.qr(rng.standard_normal((chi * chi, chi * chi)))
+  dis = q.reshape(chi, chi, chi, chi).astype(dtype)
+  h = rng.standard_normal((chi**3, chi**3))
+  ham = (0.5 * (h + h.T)).reshape((chi,) * 6).astype(dtype)
+  r = rng.standard_normal((chi**3, chi**3))
+  rho = r @ r.T
+  rho = (rho / np.trace(rho)).reshape((chi,) * 6).astype(dtype)
+  return ham, rho, iso, dis

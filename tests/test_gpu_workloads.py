@@ -178,3 +178,38 @@ def test_reference_library_dropin_if_available(hip):
   n = tn.Node(rng.standard_normal((4, 5, 6)), backend="hip")
   l, r, _ = tn.split_node(n, [n[0], n[1]], [n[2]])
   np.testing.assert_allclose(np.asarray((l @ r).tensor), np.asarray(n.tensor), atol=1e-10)
+
+
+def test_regular_network_sliced_on_gpu(hip):
+  """North-star topology, small: sliced contraction on the GPU == greedy on the oracle."""
+  from tensornetwork_amd import distributed, workloads as wl
+  rng = np.random.default_rng(6)
+  tensors = [(rng.standard_normal((4, 4, 4)) * 4 ** -0.75).astype(np.float32) for _ in range(16)]
+  ref = float(np.asarray(contractors.greedy(wl.random_regular_network(orc.OracleBackend(), n=16, D=4,
+                                                                      tensors=[t.astype(np.float64) for t in tensors])).tensor))
+  nodes = wl.random_regular_network(hip, n=16, D=4, tensors=tensors)
+  cuts = distributed.choose_cut_edges(nodes, min_slices=8)
+  out = float(np.asarray(distributed.contract_sliced(nodes, cuts)))
+  assert abs(out - ref) <= 1e-4 * max(abs(ref), 1e-3)
+  got = float(np.asarray(contractors.greedy(wl.random_regular_network(hip, n=16, D=4, tensors=tensors)).tensor))
+  assert abs(got - ref) <= 1e-4 * max(abs(ref), 1e-3)
+
+
+def test_mera_layer_on_gpu(hip):
+  """Config 5 at chi = 4 (random isometric tensors) vs the oracle, and the D=2 wavelet KAT
+  (simple_mera_test.py:48-56: energy -1.242) entirely on the GPU in f64."""
+  from tensornetwork_amd import workloads as wl
+  ham, rho, iso, dis = wl.mera_random_tensors(4, dtype=np.float32)
+  ref = float(np.asarray(wl.mera_energy(orc.OracleBackend(), *(t.astype(np.float64) for t in (ham, rho, iso, dis)),
+                                        lambda nodes: contractors.branch(nodes, nbranch=2))))
+  dev = [hip.convert_to_tensor(t) for t in (ham, rho, iso, dis)]
+  got = float(np.asarray(wl.mera_energy(hip, *dev, lambda nodes: contractors.branch(nodes, nbranch=2))))
+  assert abs(got - ref) <= 1e-4 * max(abs(ref), 1.0)
+
+  h = hip.convert_to_tensor(wl.ham_ising())
+  w, u = (hip.convert_to_tensor(t) for t in wl.wavelet_mera_tensors())
+  s = hip.convert_to_tensor((np.eye(8) / 8).reshape((2,) * 6))
+  for _ in range(20):
+    s = wl.mera_descend(hip, s, w, u, lambda nodes, order: contractors.greedy(nodes, output_edge_order=order))
+  en = float(np.asarray(wl.mera_energy(hip, h, s, w, u, lambda nodes: contractors.branch(nodes, nbranch=2))))
+  assert np.isclose(en, -1.242, rtol=1e-3, atol=1e-3)

@@ -1,0 +1,39 @@
+"""Config 5: binary-MERA layer energy (12-node network, contractors.branch nbranch=2) on one GPU.
+  python tools/mera_probe.py --chi 4,8,16 [--dtype bf16|f32]"""
+import argparse, json, os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import tensornetwork_amd as ta
+from tensornetwork_amd import contractors, pathfinder, network, workloads as wl
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--chi", default="4,8,16")
+ap.add_argument("--dtype", default="bf16")
+ap.add_argument("--reps", type=int, default=2)
+a = ap.parse_args()
+be = ta.get_hip_backend()
+dt = ta.bfloat16 if a.dtype == "bf16" else np.float32
+for chi in [int(c) for c in a.chi.split(",")]:
+  # operands in HBM: random stand-ins of the right shape (isometry constraints do not change the cost)
+  sc = lambda n: float(n) ** -0.5
+  ham = be.device_random((chi,) * 6, dtype=dt, seed=1, normal=True, b=sc(chi**3))
+  rho = be.device_random((chi,) * 6, dtype=dt, seed=2, normal=True, b=sc(chi**3))
+  iso = be.device_random((chi,) * 3, dtype=dt, seed=3, normal=True, b=sc(chi))
+  dis = be.device_random((chi,) * 4, dtype=dt, seed=4, normal=True, b=sc(chi * chi))
+  nodes = wl.mera_layer_network(be, ham, rho, iso, dis, "left")
+  inputs = [set(n.edges) for n in nodes]
+  sizes = {e: e.dimension for e in network.get_all_edges(nodes)}
+  path = pathfinder.branch(inputs, set(), sizes, nbranch=2)
+  flops, peak = pathfinder.path_cost(inputs, set(), sizes, path)
+  best = None
+  for _ in range(a.reps + 1):
+    be.synchronize()
+    t0 = time.perf_counter()
+    e = wl.mera_energy(be, ham, rho, iso, dis, lambda nd: contractors.branch(nd, nbranch=2))
+    be.synchronize()
+    t = time.perf_counter() - t0
+    best = t if best is None else min(best, t)
+  print(json.dumps({"chi": chi, "dtype": a.dtype, "sec": best, "flops_2placements": 2 * float(flops),
+                    "tflops": 2 * float(flops) / best / 1e12, "peak_elems": float(peak),
+                    "energy": float(np.asarray(e).reshape(-1)[0])}), flush=True)
+  del ham, rho, nodes, e
