@@ -63,14 +63,16 @@ def dist_setup(n_gpus):
   rank = int(os.environ.get("RANK", "0"))
   world = int(os.environ.get("WORLD_SIZE", "1"))
   local = int(os.environ.get("LOCAL_RANK", "0"))
-  if world == 1:
-    return rank, world, local, None
+  if world == 1 and not os.environ.get("TNH_BENCH_FORCE_DIST"):
+    return rank, world, local, None   # (the env knob exercises the RCCL path on a 1-GPU box)
+  os.environ.setdefault("MASTER_PORT", "29511")
   import torch  # pylint: disable=import-outside-toplevel
   import torch.distributed as dist  # pylint: disable=import-outside-toplevel
   os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
   os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
   torch.cuda.set_device(local)
-  dist.init_process_group(backend="nccl", rank=rank, world_size=world)
+  dist.init_process_group(backend="nccl", rank=rank, world_size=world,
+                          device_id=torch.device("cuda", local))
   assert world == n_gpus, (world, n_gpus)
   return rank, world, local, dist
 
