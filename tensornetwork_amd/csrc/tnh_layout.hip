@@ -9,6 +9,7 @@
 //   tnh_strided_scatter  arbitrary-strided dst <- contiguous src (diagflat).
 //
 // Algorithmic HBM bytes: 2 * numel * itemsize per call.
+#include <stdlib.h>
 #include <algorithm>
 #include "tnh_internal.h"
 
@@ -100,6 +101,69 @@ __global__ __launch_bounds__(256) void permute_tiled_kernel(T* __restrict__ dst,
       const int r = ty + k * ROWS_PER_PASS;
       const int64_t a = a0 + r;
       if (a < p.Na && b < p.Nb) dst[out_base + a * p.a_out_stride + b] = tile[tx][r];
+    }
+  }
+}
+
+// 2-byte elements (bf16 / f16), full tiles, 16-byte aligned rows on both sides:
+// 64 (a) x 128 (b) tile.  A thread loads 8 a-consecutive elements of two
+// neighbouring b rows (2 x 16 B), transposes the eight 2x2 micro-blocks in
+// registers (v_perm) into dwords that hold (b, b+1) for one a, and stores them
+// to a dword tile T[a][b/2] (row pitch 65 dwords: conflict-free both ways).  The
+// write side reads 4 consecutive dwords and stores 16 B (8 b-consecutive
+// elements): 256-B contiguous runs per output row.
+__global__ __launch_bounds__(256) void permute_tiled16_kernel(uint16_t* __restrict__ dst,
+                                                              const uint16_t* __restrict__ src,
+                                                              TiledParams p) {
+  constexpr int TA = 64, TB = 128, LD = 65;
+  __shared__ uint32_t T[TA * LD];
+  int64_t bid = blockIdx.x;
+  const int64_t ta = bid % p.tiles_a;
+  bid /= p.tiles_a;
+  const int64_t tb = bid % p.tiles_b;
+  bid /= p.tiles_b;
+  int64_t in_base = 0, out_base = 0;
+#pragma unroll 1
+  for (int d = p.nbatch - 1; d >= 0; --d) {
+    const int64_t q = bid / p.bshape[d];
+    const int64_t c = bid - q * p.bshape[d];
+    in_base += c * p.bin[d];
+    out_base += c * p.bout[d];
+    bid = q;
+  }
+  const int tid = threadIdx.x;
+  const int64_t a0 = ta * TA, b0 = tb * TB;
+  {
+    const int q = tid & 7;  // a chunk: a = 8 q .. 8 q + 7
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int j = (tid >> 3) + 32 * h;  // b pair: rows 2 j, 2 j + 1
+      const uint16_t* s0 = src + in_base + (b0 + 2 * j) * p.b_in_stride + a0 + 8 * q;
+      const uint4 x = *(const uint4*)s0;
+      const uint4 y = *(const uint4*)(s0 + p.b_in_stride);
+      const uint32_t xs[4] = {x.x, x.y, x.z, x.w}, ys[4] = {y.x, y.y, y.z, y.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        // xs[e] = (a = 8q+2e, a+1) of row 2j ; ys[e] the same of row 2j+1
+        const uint32_t lo = (xs[e] & 0xffffu) | (ys[e] << 16);          // a = 8q+2e:   (b=2j, 2j+1)
+        const uint32_t hi = (xs[e] >> 16) | (ys[e] & 0xffff0000u);      // a = 8q+2e+1
+        T[(8 * q + 2 * e) * LD + j] = lo;
+        T[(8 * q + 2 * e + 1) * LD + j] = hi;
+      }
+    }
+  }
+  __syncthreads();
+  {
+    const int c = tid & 15;  // 16-byte chunk along b: dwords 4 c .. 4 c + 3
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+      const int a = (tid >> 4) + 16 * h;
+      uint4 o;
+      o.x = T[a * LD + 4 * c];
+      o.y = T[a * LD + 4 * c + 1];
+      o.z = T[a * LD + 4 * c + 2];
+      o.w = T[a * LD + 4 * c + 3];
+      *(uint4*)(dst + out_base + (a0 + a) * p.a_out_stride + b0 + 8 * c) = o;
     }
   }
 }
@@ -312,6 +376,31 @@ int tnh_permute(void* dst, const void* src, int rank, const int64_t* shape, cons
     p.Nb = oshape[ib];
     p.a_out_stride = ostride[ia];
     p.b_in_stride = istride[ib];
+    // 2-byte fast path: full 64 x 128 tiles, every row start 16-byte aligned on both sides
+    if (itemsize == 2 && p.Na % 64 == 0 && p.Nb % 128 == 0 && p.b_in_stride % 8 == 0 &&
+        p.a_out_stride % 8 == 0 && ((uintptr_t)dst % 16) == 0 && ((uintptr_t)src % 16) == 0) {
+      bool ok = true;
+      TiledParams f = p;
+      f.tiles_a = p.Na / 64;
+      f.tiles_b = p.Nb / 128;
+      f.nbatch = 0;
+      int64_t nblocks = f.tiles_a * f.tiles_b;
+      for (int d = 0; d < r; ++d) {
+        if (d == ia || d == ib) continue;
+        if (istride[d] % 8 != 0 || ostride[d] % 8 != 0) ok = false;
+        f.bshape[f.nbatch] = oshape[d];
+        f.bin[f.nbatch] = istride[d];
+        f.bout[f.nbatch] = ostride[d];
+        ++f.nbatch;
+        nblocks *= oshape[d];
+      }
+      if (ok && nblocks < (int64_t(1) << 31) && !getenv("TNH_PERMUTE_NO16")) {
+        hipLaunchKernelGGL(permute_tiled16_kernel, dim3((unsigned)nblocks), dim3(256), 0, stream(),
+                           (uint16_t*)dst, (const uint16_t*)src, f);
+        TNH_LAUNCH_CHECK();
+        return TNH_OK;
+      }
+    }
     const int TILE = (itemsize <= 4) ? 64 : 32;
     p.tiles_a = (p.Na + TILE - 1) / TILE;
     p.tiles_b = (p.Nb + TILE - 1) / TILE;

@@ -44,6 +44,9 @@ def test_permute_all_perms_rank4(hip, dtype):
     ((300, 200), (1, 0)), ((64, 48, 80), (2, 1, 0)), ((64, 48, 80), (1, 2, 0)), ((7, 130, 3, 70), (3, 2, 1, 0)),
     ((16,) * 6, (0, 2, 4, 1, 3, 5)), ((2, 512, 2, 512), (3, 1, 2, 0)), ((1000, 3), (1, 0)), ((3, 1000), (1, 0)),
     ((33, 65, 17), (0, 2, 1)), ((128, 128, 8), (1, 0, 2)),
+    # full 64 x 128 tiles with 16-byte aligned rows: the 2-byte vector kernel (permute_tiled16)
+    ((128, 256), (1, 0)), ((64, 128), (1, 0)), ((256, 4, 128), (2, 1, 0)), ((3, 64, 2, 128), (0, 3, 2, 1)),
+    ((128, 3, 64), (2, 1, 0)),  # odd batch stride -> falls back to the scalar tiled kernel
 ])
 @pytest.mark.parametrize("dtype", [np.float32, np.uint16, np.complex128])
 def test_permute_tiled_and_gather_paths(hip, shape, perm, dtype):
