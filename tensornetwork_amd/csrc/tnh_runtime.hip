@@ -31,10 +31,25 @@ int num_cus() { return g_cus; }
 // exact-size free lists.  All work runs on one in-order stream, so a block
 // handed back by tnh_free can be reused immediately: any kernel still reading
 // it was queued before the kernel that will next write it.
+//
+// Graph arenas: every block handed out while a hipGraph is being captured belongs
+// to that graph's arena.  Inside the capture a freed arena block may be reused
+// (the graph replays the captured order), but it never returns to the general
+// pool before tnh_graph_destroy: a replay writes to the captured addresses, so
+// nobody else may own them in between.  Blocks still referenced by the caller
+// (the outputs of the captured sequence) stay valid across replays.
+struct Arena {
+  std::multimap<size_t, void*> free_blocks;   // reusable inside the capture
+  std::unordered_map<void*, size_t> blocks;   // every block of the arena -> size
+};
+
 struct Pool {
   std::mutex mu;
   std::multimap<size_t, void*> free_blocks;
   std::unordered_map<void*, size_t> live;  // ptr -> rounded size
+  std::unordered_map<void*, Arena*> arena_of;  // blocks pinned by a graph arena
+  Arena* capturing = nullptr;
+  std::unordered_map<void*, Arena*> graphs;    // hipGraphExec_t -> arena
   int64_t in_use = 0, cached = 0, peak = 0;
 
   static size_t round(size_t n) {
@@ -122,14 +137,27 @@ int tnh_malloc(void** ptr, size_t nbytes) {
   TNH_REQUIRE(ptr != nullptr, "ptr is null");
   const size_t sz = Pool::round(nbytes);
   std::lock_guard<std::mutex> lk(g_pool.mu);
-  auto it = g_pool.free_blocks.find(sz);
   void* p = nullptr;
+  Arena* ar = g_pool.capturing;
+  if (ar != nullptr) {
+    auto ia = ar->free_blocks.find(sz);
+    if (ia != ar->free_blocks.end()) {
+      p = ia->second;
+      ar->free_blocks.erase(ia);
+      g_pool.live[p] = sz;
+      g_pool.in_use += (int64_t)sz;
+      if (g_pool.in_use > g_pool.peak) g_pool.peak = g_pool.in_use;
+      *ptr = p;
+      return TNH_OK;
+    }
+  }
+  auto it = g_pool.free_blocks.find(sz);
   if (it != g_pool.free_blocks.end()) {
     p = it->second;
     g_pool.free_blocks.erase(it);
     g_pool.cached -= (int64_t)sz;
   } else {
-    TNH_REQUIRE(!g_capturing, "pool miss (%zu B) during graph capture", sz);
+    // (relaxed capture mode: hipMalloc is legal while the stream is capturing)
     hipError_t e = hipMalloc(&p, sz);
     if (e != hipSuccess) {
       (void)hipGetLastError();
@@ -143,6 +171,10 @@ int tnh_malloc(void** ptr, size_t nbytes) {
                 (long long)g_pool.in_use);
       return TNH_ERR_NOMEM;
     }
+  }
+  if (ar != nullptr) {
+    ar->blocks[p] = sz;
+    g_pool.arena_of[p] = ar;
   }
   g_pool.live[p] = sz;
   g_pool.in_use += (int64_t)sz;
@@ -160,6 +192,12 @@ int tnh_free(void* ptr) {
   const size_t sz = it->second;
   g_pool.live.erase(it);
   g_pool.in_use -= (int64_t)sz;
+  auto ia = g_pool.arena_of.find(ptr);
+  if (ia != g_pool.arena_of.end()) {
+    // pinned by a graph: reusable only inside that graph's own capture
+    if (ia->second == g_pool.capturing) ia->second->free_blocks.emplace(sz, ptr);
+    return TNH_OK;
+  }
   g_pool.free_blocks.emplace(sz, ptr);
   g_pool.cached += (int64_t)sz;
   return TNH_OK;
@@ -265,8 +303,10 @@ int tnh_event_destroy(void* ev) {
 int tnh_graph_begin(void) {
   TNH_NEED_INIT();
   TNH_REQUIRE(!g_capturing, "graph capture already in progress");
-  TNH_HIP(hipStreamBeginCapture(g_stream, hipStreamCaptureModeThreadLocal));
+  TNH_HIP(hipStreamBeginCapture(g_stream, hipStreamCaptureModeRelaxed));
   g_capturing = true;
+  std::lock_guard<std::mutex> lk(g_pool.mu);
+  g_pool.capturing = new Arena();
   return TNH_OK;
 }
 int tnh_graph_end(void** graph_exec) {
@@ -274,14 +314,43 @@ int tnh_graph_end(void** graph_exec) {
   TNH_REQUIRE(g_capturing, "no graph capture in progress");
   TNH_REQUIRE(graph_exec != nullptr, "null pointer");
   g_capturing = false;
+  Arena* ar = nullptr;
+  {
+    std::lock_guard<std::mutex> lk(g_pool.mu);
+    ar = g_pool.capturing;
+    g_pool.capturing = nullptr;
+  }
+  auto drop_arena = [&]() {
+    std::lock_guard<std::mutex> lk(g_pool.mu);
+    for (auto& kv : ar->blocks) {
+      g_pool.arena_of.erase(kv.first);
+      if (g_pool.live.find(kv.first) == g_pool.live.end()) {
+        g_pool.free_blocks.emplace(kv.second, kv.first);
+        g_pool.cached += (int64_t)kv.second;
+      }
+    }
+    delete ar;
+  };
   hipGraph_t graph = nullptr;
-  TNH_HIP(hipStreamEndCapture(g_stream, &graph));
+  hipError_t e = hipStreamEndCapture(g_stream, &graph);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    drop_arena();
+    set_error("hipStreamEndCapture failed: %s", hipGetErrorString(e));
+    return TNH_ERR_HIP;
+  }
   hipGraphExec_t exec = nullptr;
-  hipError_t e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+  e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
   (void)hipGraphDestroy(graph);
   if (e != hipSuccess) {
+    (void)hipGetLastError();
+    drop_arena();
     set_error("hipGraphInstantiate failed: %s", hipGetErrorString(e));
     return TNH_ERR_HIP;
+  }
+  {
+    std::lock_guard<std::mutex> lk(g_pool.mu);
+    g_pool.graphs[(void*)exec] = ar;
   }
   *graph_exec = (void*)exec;
   return TNH_OK;
@@ -293,7 +362,24 @@ int tnh_graph_launch(void* graph_exec) {
 }
 int tnh_graph_destroy(void* graph_exec) {
   if (graph_exec == nullptr) return TNH_OK;
+  if (g_device < 0) return TNH_OK;
+  // replays still in flight read/write the arena: drain before the blocks go back
+  TNH_HIP(hipStreamSynchronize(g_stream));
   TNH_HIP(hipGraphExecDestroy((hipGraphExec_t)graph_exec));
+  std::lock_guard<std::mutex> lk(g_pool.mu);
+  auto it = g_pool.graphs.find(graph_exec);
+  if (it != g_pool.graphs.end()) {
+    Arena* ar = it->second;
+    for (auto& kv : ar->blocks) {
+      g_pool.arena_of.erase(kv.first);
+      if (g_pool.live.find(kv.first) == g_pool.live.end()) {  // not referenced by the caller any more
+        g_pool.free_blocks.emplace(kv.second, kv.first);
+        g_pool.cached += (int64_t)kv.second;
+      }
+    }
+    delete ar;
+    g_pool.graphs.erase(it);
+  }
   return TNH_OK;
 }
 

@@ -178,6 +178,41 @@ class HipBackend(BackendBase):
                "tnh_strided_copy")
     return out
 
+  def slice_into(self, out, tensor, start_indices):
+    """out[...] = tensor[start : start + out.shape] written into the EXISTING block of `out`
+    (one strided gather, no allocation): refreshes the fixed input buffers of a captured
+    hipGraph (see ``capture``)."""
+    tensor = self._as_tensor(tensor)
+    if len(start_indices) != tensor.ndim or out.ndim != tensor.ndim or out.code != tensor.code:
+      raise ValueError("slice_into: rank / dtype mismatch")
+    st = _row_major_strides(tensor.shape)
+    for s0, n, dim in zip(start_indices, out.shape, tensor.shape):
+      if s0 < 0 or s0 + n > dim:
+        raise ValueError("slice_into: window out of range")
+    offset = sum(int(s0) * int(t) for s0, t in zip(start_indices, st))
+    _lib.check(self.lib.tnh_strided_copy(_vp(out), _vp(tensor), out.ndim, _lib.i64_array(out.shape),
+                                         _lib.i64_array(st), int(offset), tensor.itemsize),
+               "tnh_strided_copy")
+    return out
+
+  def capture(self, fun, *args):
+    """Record every kernel launch of ``fun(*args)`` into a hipGraph instead of running it.
+
+    The MI355X-native stand-in for ``jit`` on launch-bound contraction sequences (many small
+    pairwise steps): ``g = backend.capture(f, *tensors)``, then ``g.launch()`` replays the
+    whole sequence with one submission and returns the same output tensors (same HBM
+    blocks) every time.  Inputs are read at their captured addresses: refresh them in
+    place (``slice_into`` / ``copy_into``) between launches.  ``fun`` must not read
+    results back to the host (no ``item``/``numpy``/``svd`` inside)."""
+    return DeviceGraph(self, fun, args)
+
+  def copy_into(self, out, tensor):
+    tensor = self._as_tensor(tensor)
+    if out.nbytes != tensor.nbytes or out.code != tensor.code:
+      raise ValueError("copy_into: size / dtype mismatch")
+    _lib.check(self.lib.tnh_d2d(_vp(out), _vp(tensor), out.nbytes), "tnh_d2d")
+    return out
+
   def slice(self, tensor, start_indices, slice_sizes):
     # numpy_backend.py:64-72
     if len(start_indices) != len(slice_sizes):
@@ -741,6 +776,42 @@ class HipBackend(BackendBase):
     m.write(s.encode('latin-1'))
     m.seek(0)
     return self.convert_to_tensor(np.load(m))
+
+
+class DeviceGraph:
+  """An instantiated hipGraph of one launch sequence plus the HBM arena it runs in
+  (``tnh_graph_*`` in include/tnh.h).  Every block the sequence touched stays pinned to
+  the graph until it is destroyed, so replays cannot collide with other tensors."""
+
+  def __init__(self, backend, fun, args):
+    self._lib = backend.lib
+    self._exec = None
+    self._args = args            # keep the captured input blocks alive
+    _lib.check(self._lib.tnh_graph_begin(), "tnh_graph_begin")
+    handle = ctypes.c_void_p()
+    try:
+      self.outputs = fun(*args)
+    except BaseException:
+      if self._lib.tnh_graph_end(ctypes.byref(handle)) == 0 and handle:
+        self._lib.tnh_graph_destroy(handle)
+      raise
+    _lib.check(self._lib.tnh_graph_end(ctypes.byref(handle)), "tnh_graph_end")
+    self._exec = handle
+
+  def launch(self):
+    _lib.check(self._lib.tnh_graph_launch(self._exec), "tnh_graph_launch")
+    return self.outputs
+
+  def close(self):
+    if self._exec is not None:
+      self._lib.tnh_graph_destroy(self._exec)
+      self._exec = None
+
+  def __del__(self):
+    try:
+      self.close()
+    except Exception:  # pylint: disable=broad-except
+      pass
 
 
 _BACKEND = None

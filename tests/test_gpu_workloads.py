@@ -213,3 +213,44 @@ def test_mera_layer_on_gpu(hip):
     s = wl.mera_descend(hip, s, w, u, lambda nodes, order: contractors.greedy(nodes, output_edge_order=order))
   en = float(np.asarray(wl.mera_energy(hip, h, s, w, u, lambda nodes: contractors.branch(nodes, nbranch=2))))
   assert np.isclose(en, -1.242, rtol=1e-3, atol=1e-3)
+
+
+def test_hipgraph_capture_replay(hip):
+  """backend.capture: a chain of small contractions recorded once, replayed on refreshed inputs."""
+  rng = np.random.default_rng(11)
+  a_host = [rng.standard_normal((12, 12)).astype(np.float32) for _ in range(3)]
+  x = hip.convert_to_tensor(a_host[0])
+  w1 = hip.convert_to_tensor(rng.standard_normal((12, 12)).astype(np.float32))
+  w2 = hip.convert_to_tensor(rng.standard_normal((12, 12)).astype(np.float32))
+
+  def chain(x, w1, w2):
+    y = hip.tensordot(x, w1, 1)
+    y = hip.transpose(hip.tensordot(y, w2, [[0], [1]]), (1, 0))
+    return hip.addition(y, x)
+
+  g = hip.capture(chain, x, w1, w2)
+  for host in a_host:
+    hip.copy_into(x, hip.convert_to_tensor(host))
+    out = np.asarray(g.launch())
+    h1, h2 = np.asarray(w1), np.asarray(w2)
+    ref = np.tensordot(host @ h1, h2, [[0], [1]]).T + host
+    np.testing.assert_allclose(out, ref, rtol=1e-4, atol=1e-4)
+  # blocks of a live graph are not handed to other tensors
+  junk = [hip.convert_to_tensor(rng.standard_normal((12, 12)).astype(np.float32)) for _ in range(16)]
+  hip.copy_into(x, hip.convert_to_tensor(a_host[1]))
+  out = np.asarray(g.launch())
+  np.testing.assert_allclose(out, np.tensordot(a_host[1] @ np.asarray(w1), np.asarray(w2), [[0], [1]]).T + a_host[1],
+                             rtol=1e-4, atol=1e-4)
+  g.close()
+  del junk
+
+
+def test_sliced_contraction_graph_equals_eager(hip):
+  from tensornetwork_amd import distributed, workloads as wl
+  rng = np.random.default_rng(6)
+  tensors = [(rng.standard_normal((4, 4, 4)) * 4 ** -0.75).astype(np.float32) for _ in range(16)]
+  nodes = wl.random_regular_network(hip, n=16, D=4, tensors=tensors)
+  cuts = distributed.choose_cut_edges(nodes, min_slices=16)
+  eager = float(np.asarray(distributed.contract_sliced(nodes, cuts, use_graph=False)))
+  graph = float(np.asarray(distributed.contract_sliced(nodes, cuts, use_graph=True)))
+  assert abs(eager - graph) <= 1e-5 * max(abs(eager), 1e-3)

@@ -13,6 +13,7 @@ ap.add_argument("--n", type=int, default=64)
 ap.add_argument("--min-slices", type=int, default=64)
 ap.add_argument("--max-slices", type=int, default=8)
 ap.add_argument("--dtype", default="bf16")
+ap.add_argument("--graph", type=int, default=-1)
 a = ap.parse_args()
 be = ta.get_hip_backend()
 import networkx as nx
@@ -45,14 +46,15 @@ class Sub(distributed.LocalComm):
 
 n_slices = int(rep["n_slices"])
 world = max(1, n_slices // a.max_slices)
-out = distributed.contract_sliced(nodes, cuts, comm=Sub(world))  # warm-up (also JIT-free path build)
+ug = None if a.graph < 0 else bool(a.graph)
+out = distributed.contract_sliced(nodes, cuts, comm=Sub(world), use_graph=ug)  # warm-up
 be.synchronize()
 t0 = time.perf_counter()
-out = distributed.contract_sliced(nodes, cuts, comm=Sub(world))
+out = distributed.contract_sliced(nodes, cuts, comm=Sub(world), use_graph=ug)
 be.synchronize()
 dt = time.perf_counter() - t0
 done = len(range(0, n_slices, world))
-print(json.dumps({"D": D, "dtype": a.dtype, "n_slices": n_slices, "slices_run": done, "plan_s": t_plan,
+print(json.dumps({"D": D, "dtype": a.dtype, "graph": a.graph, "n_slices": n_slices, "slices_run": done, "plan_s": t_plan,
                   "sec_per_slice": dt / done, "flops_per_slice": rep["flops_per_slice"],
                   "tflops": rep["flops_per_slice"] * done / dt / 1e12, "peak_elems": rep["peak_per_slice"],
                   "est_full_1gpu_s": dt / done * n_slices, "partial": float(np.asarray(out).reshape(-1)[0])}))
