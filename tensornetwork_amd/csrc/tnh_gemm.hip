@@ -301,7 +301,7 @@ static int g_variant = 0;  // 0 auto, 1 generic (mfma), 2 valu, 3 bf16_128, 4 bf
 template <typename F>
 static int launch_batched(F launch, const GemmArgs& g0, int64_t batch, int BM, int BN) {
   const int64_t gx = (g0.N + BN - 1) / BN, gy = (g0.M + BM - 1) / BM;
-  TNH_REQUIRE(gx < (int64_t(1) << 31) && gy < 65536, "GEMM grid too large (%lld x %lld tiles)",
+  TNH_REQUIRE(gx < (int64_t(1) << 24) && gy < 65536, "GEMM grid too large (%lld x %lld tiles)",
               (long long)gy, (long long)gx);
   for (int64_t b0 = 0; b0 < batch; b0 += 65535) {
     const int64_t nb = (batch - b0 < 65535) ? (batch - b0) : 65535;

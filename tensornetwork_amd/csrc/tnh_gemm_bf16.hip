@@ -535,7 +535,7 @@ static int launch_nt(bool is_bf16, bool out_f32, NtArgs p, int64_t batch) {
   p.tiles_m = (int)((p.M + BM - 1) / BM);
   p.tiles_n = (int)((p.N + BN - 1) / BN);
   const int64_t nwg = (int64_t)p.tiles_m * p.tiles_n;
-  TNH_REQUIRE(nwg < (int64_t(1) << 31), "GEMM grid too large");
+  TNH_REQUIRE(nwg < (int64_t(1) << 24), "GEMM grid too large");
   const int esz_out = out_f32 ? 4 : 2;
   for (int64_t b0 = 0; b0 < batch; b0 += 65535) {
     const int64_t nb = (batch - b0 < 65535) ? (batch - b0) : 65535;
@@ -560,7 +560,7 @@ static int launch_pp(bool is_bf16, bool out_f32, bool two, NtArgs p, int64_t bat
   p.tiles_m = (int)((p.M + 255) / 256);
   p.tiles_n = (int)((p.N + 255) / 256);
   const int64_t nwg = (int64_t)p.tiles_m * p.tiles_n;
-  TNH_REQUIRE(nwg < (int64_t(1) << 31), "GEMM grid too large");
+  TNH_REQUIRE(nwg < (int64_t(1) << 24), "GEMM grid too large");
   const int esz_out = out_f32 ? 4 : 2;
   for (int64_t b0 = 0; b0 < batch; b0 += 65535) {
     const int64_t nb = (batch - b0 < 65535) ? (batch - b0) : 65535;

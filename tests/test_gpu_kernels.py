@@ -359,3 +359,16 @@ def test_svd_prescribed_spectrum_512(hip):
   u, s, vh, rest = _check_svd(hip, a, 1e-5, 1e-4, max_singular_values=n // 16)
   np.testing.assert_allclose(s, spec[:n // 16], rtol=1e-4)
   np.testing.assert_allclose(rest, spec[n // 16:], atol=1e-5)
+
+
+def test_permute_more_than_2p24_tiles(hip):
+  """Regression: tiny (a, b) dims under a huge batch used to need > 2^24 workgroups, which the
+  runtime rejects (gridDim.x * blockDim.x must stay below 2^32); the kernels now grid-stride."""
+  B = (1 << 24) + 3
+  x = hip.device_random((16, B, 16), dtype=np.float16, seed=5, normal=True)
+  y = hip.transpose(x, (2, 1, 0))
+  assert y.shape == (16, B, 16)
+  for b in (0, 1, 12345, (1 << 22) + 7, (1 << 24) - 1, (1 << 24), B - 1):
+    xi = np.asarray(hip.getitem(x, (slice(None), slice(b, b + 1), slice(None))))
+    yi = np.asarray(hip.getitem(y, (slice(None), slice(b, b + 1), slice(None))))
+    np.testing.assert_array_equal(yi[:, 0, :], xi[:, 0, :].T)
