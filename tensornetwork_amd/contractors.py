@@ -16,12 +16,48 @@ from typing import Callable, Iterable, List, Optional, Sequence, Tuple
 from tensornetwork_amd import network, pathfinder
 
 
+# Path cache: the search depends only on the index structure (which node carries which
+# bond, bond sizes, which bonds stay open) and on the algorithm + its keyword arguments,
+# never on tensor values.  Iterative workloads (MERA sweeps, sliced networks, DMRG) ask
+# for the same topology thousands of times; the search costs ms, a small contraction us.
+_PATH_CACHE: dict = {}
+_PATH_CACHE_MAX = 256
+
+
+def _topology_key(input_sets, output_set, size_dict, algorithm):
+  label = {}
+  inputs = []
+  for node_edges in input_sets:   # edges relabelled by first appearance, in axis order
+    inputs.append(tuple(label.setdefault(e, len(label)) for e in node_edges))
+  sizes = tuple(size_dict[e] for e in label)
+  out = tuple(sorted(label[e] for e in output_set))
+  if isinstance(algorithm, functools.partial):
+    alg = (getattr(algorithm.func, "__qualname__", repr(algorithm.func)), id(algorithm.func),
+           algorithm.args, tuple(sorted(algorithm.keywords.items())))
+  else:
+    alg = (getattr(algorithm, "__qualname__", repr(algorithm)), id(algorithm))
+  return (tuple(inputs), sizes, out, alg)
+
+
 def get_path(nodes: Iterable[network.Node], algorithm: Callable) -> Tuple[List[Tuple[int, int]], List[network.Node]]:
   nodes = list(nodes)
-  input_sets = [set(node.edges) for node in nodes]
+  input_lists = [list(node.edges) for node in nodes]
+  input_sets = [set(edges) for edges in input_lists]
   output_set = network.get_subgraph_dangling(nodes)
   size_dict = {edge: edge.dimension for edge in network.get_all_edges(nodes)}
-  return algorithm(input_sets, output_set, size_dict), nodes
+  try:
+    key = _topology_key(input_lists, output_set, size_dict, algorithm)
+    hash(key)
+  except TypeError:
+    key = None
+  if key is not None and key in _PATH_CACHE:
+    return list(_PATH_CACHE[key]), nodes
+  path = algorithm(input_sets, output_set, size_dict)
+  if key is not None:
+    if len(_PATH_CACHE) >= _PATH_CACHE_MAX:
+      _PATH_CACHE.pop(next(iter(_PATH_CACHE)))
+    _PATH_CACHE[key] = [tuple(p) for p in path]
+  return path, nodes
 
 
 def contract_path(path: Sequence[Tuple[int, ...]], nodes: Iterable[network.Node],

@@ -32,9 +32,11 @@ struct SvdLayout {
 };
 
 // tnh_svd_block.hip
-int svd_block_pad_copy(float* Xp, int64_t P, int64_t Q, const float* A, int64_t m, int64_t n, bool trans);
-size_t svd_block_scratch_bytes(int64_t P, int64_t Q);
-int svd_block_sweeps(float* X, float* R, int64_t P, int64_t Q, char* scratch, int* flag, double tol,
+template <typename T>
+int svd_block_pad_copy(T* Xp, int64_t P, int64_t Q, const T* A, int64_t m, int64_t n, bool trans);
+size_t svd_block_scratch_bytes(int esz, int64_t P, int64_t Q);
+template <typename T>
+int svd_block_sweeps(T* X, T* R, int64_t P, int64_t Q, char* scratch, int* flag, double tol,
                      int max_sweeps, int* sweeps_out, bool* converged_out);
 
 static bool block_path_enabled() {
@@ -49,7 +51,7 @@ static SvdLayout svd_layout(int dtype, int64_t m, int64_t n) {
   L.q = L.transposed ? m : n;
   const size_t esz = (size_t)dtype_size(dtype);
   auto al = [](size_t x) { return (x + 255) & ~size_t(255); };
-  L.block = (dtype == TNH_F32 && L.p > 64 && block_path_enabled());
+  L.block = ((dtype == TNH_F32 || dtype == TNH_F64) && L.p > 64 && block_path_enabled());
   L.ldx = L.block ? ((L.q + 127) / 128) * 128 : L.q;
   L.ldr = L.block ? ((L.p + 127) / 128) * 128 : L.p;
   size_t off = 0;
@@ -58,7 +60,7 @@ static SvdLayout svd_layout(int dtype, int64_t m, int64_t n) {
   L.off_norm = off; off += al((size_t)L.p * sizeof(double));
   L.off_perm = off; off += al((size_t)L.p * sizeof(int32_t));
   L.off_flag = off; off += 256;
-  L.off_scratch = off; off += L.block ? al(svd_block_scratch_bytes(L.ldr, L.ldx)) : 0;
+  L.off_scratch = off; off += L.block ? al(svd_block_scratch_bytes((int)esz, L.ldr, L.ldx)) : 0;
   L.total = off;
   return L;
 }
@@ -182,25 +184,27 @@ template <typename T>
 static int svd_finish(const SvdLayout& L, int64_t m, int64_t n, void* S, char* work, bool converged,
                       int max_sweeps);
 
-// f32 speed path: zero-padded copy, block-Jacobi sweeps (tnh_svd_block.hip).
-static int svd_factor_block(const SvdLayout& L, int64_t m, int64_t n, const void* A, void* S, char* work,
-                            int* sweeps_out) {
-  float* X = (float*)(work + L.off_X);
-  float* R = (float*)(work + L.off_R);
+// Speed path (f32 / f64): zero-padded copy, block-Jacobi sweeps (tnh_svd_block.hip).
+template <typename T>
+static int svd_factor_block(const SvdLayout& L, int dtype, int64_t m, int64_t n, const void* A, void* S,
+                            char* work, int* sweeps_out) {
+  T* X = (T*)(work + L.off_X);
+  T* R = (T*)(work + L.off_R);
   int* flag = (int*)(work + L.off_flag);
   const int64_t P = L.ldr, Q = L.ldx;
-  int rc = svd_block_pad_copy(X, P, Q, (const float*)A, m, n, L.transposed);
+  int rc = svd_block_pad_copy<T>(X, P, Q, (const T*)A, m, n, L.transposed);
   if (rc) return rc;
-  rc = tnh_eye(R, P, P, TNH_F32);
+  rc = tnh_eye(R, P, P, dtype);
   if (rc) return rc;
-  const double tol = 5.9604644775390625e-08 * sqrt((double)L.q);
+  const double eps = (sizeof(T) == 4) ? 5.9604644775390625e-08 : 1.1102230246251565e-16;
+  const double tol = eps * sqrt((double)L.q);
   const int max_sweeps = 40;
   int sweeps = 0;
   bool converged = false;
-  rc = svd_block_sweeps(X, R, P, Q, work + L.off_scratch, flag, tol, max_sweeps, &sweeps, &converged);
+  rc = svd_block_sweeps<T>(X, R, P, Q, work + L.off_scratch, flag, tol, max_sweeps, &sweeps, &converged);
   if (rc) return rc;
   if (sweeps_out) *sweeps_out = sweeps;
-  return svd_finish<float>(L, m, n, S, work, converged, max_sweeps);
+  return svd_finish<T>(L, m, n, S, work, converged, max_sweeps);
 }
 
 template <typename T>
@@ -211,7 +215,7 @@ static int svd_factor_t(const SvdLayout& L, int dtype, int64_t m, int64_t n, con
   T* R = (T*)(work + L.off_R);
   int* flag = (int*)(work + L.off_flag);
   int rc;
-  if (L.block) return svd_factor_block(L, m, n, A, S, work, sweeps_out);
+  if (L.block) return svd_factor_block<T>(L, dtype, m, n, A, S, work, sweeps_out);
   if (L.transposed) {
     const int64_t shape[2] = {m, n};
     const int32_t pm[2] = {1, 0};

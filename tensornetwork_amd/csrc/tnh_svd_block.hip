@@ -113,12 +113,31 @@ __global__ __launch_bounds__(256) void bj_gram_kernel(const float* __restrict__ 
 }
 
 // ----------------------------------------------------------------------- eig
-// One workgroup per pair.  V (64 x 64, row-major f32) -> Jout[pair]; pairflag
-// says whether any rotation was applied (the update skips identity pairs).
-__global__ __launch_bounds__(256) void bj_eig_kernel(const float* __restrict__ Gp, int S,
-                                                     float* __restrict__ Jout, int* __restrict__ pairflag,
+// One workgroup per pair.  V (64 x 64, row-major) -> Jout[pair]; pairflag says
+// whether any rotation was applied (the update skips identity pairs).  Plain
+// f64 version (index-space pairing, two barriers per round): the eigensolver of
+// the f64 path; the f32 path uses bj_eig3_kernel below.  TILE = side of the Gram
+// partial tiles (32: II/IJ/JJ of the f32 gram kernel, 16: the 10 upper tiles of
+// the f64 gram kernel).
+template <typename TG, int TILE>
+__device__ __forceinline__ int bj_partial_index(int i, int j) {
+  // element (i, j) of the symmetric 64 x 64 G inside one split's partial block
+  constexpr int NT = 64 / TILE;
+  int a = i / TILE, b = j / TILE, ii = i % TILE, jj = j % TILE;
+  if (a > b) {
+    int t = a; a = b; b = t;
+    t = ii; ii = jj; jj = t;
+  }
+  const int tile = a * NT - a * (a - 1) / 2 + (b - a);   // upper-triangular tile number
+  return tile * TILE * TILE + ii * TILE + jj;
+}
+
+template <typename TG, int TILE>
+__global__ __launch_bounds__(256) void bj_eig_kernel(const TG* __restrict__ Gp, int S,
+                                                     TG* __restrict__ Jout, int* __restrict__ pairflag,
                                                      int* __restrict__ flag, double tol, int max_inner,
                                                      int sort) {
+  constexpr int PSZ = (64 / TILE) * (64 / TILE + 1) / 2 * TILE * TILE;   // partial block size
   constexpr int W = 64, LD = 65;
   __shared__ int rank[64];
   __shared__ double G[W * LD];
@@ -126,16 +145,12 @@ __global__ __launch_bounds__(256) void bj_eig_kernel(const float* __restrict__ G
   __shared__ double cs_c[32], cs_s[32];
   __shared__ int rotated;
   const int pair = blockIdx.x, tid = threadIdx.x;
-  const float* gp = Gp + (int64_t)pair * S * 3072;
+  const TG* gp = Gp + (int64_t)pair * S * PSZ;
   for (int e = tid; e < W * W; e += 256) {
     const int i = e >> 6, j = e & 63;
-    int t, idx;
-    if (i < 32 && j < 32) { t = 0; idx = i * 32 + j; }
-    else if (i < 32) { t = 1; idx = i * 32 + (j - 32); }
-    else if (j < 32) { t = 1; idx = j * 32 + (i - 32); }
-    else { t = 2; idx = (i - 32) * 32 + (j - 32); }
+    const int idx = bj_partial_index<TG, TILE>(i, j);
     double acc = 0.0;
-    for (int s = 0; s < S; ++s) acc += (double)gp[(int64_t)s * 3072 + t * 1024 + idx];
+    for (int s = 0; s < S; ++s) acc += (double)gp[(int64_t)s * PSZ + idx];
     G[i * LD + j] = acc;
     V[i * LD + j] = (i == j) ? 1.0 : 0.0;
   }
@@ -215,115 +230,8 @@ __global__ __launch_bounds__(256) void bj_eig_kernel(const float* __restrict__ G
     rank[tid] = rk;
   }
   __syncthreads();
-  float* jo = Jout + (int64_t)pair * (W * W);
-  for (int e = tid; e < W * W; e += 256) jo[(e >> 6) * W + rank[e & 63]] = (float)V[(e >> 6) * LD + (e & 63)];
-  if (tid == 0) {
-    pairflag[pair] = any;
-    if (any) *flag = 1;
-  }
-}
-
-// Faster variant of bj_eig_kernel (the default): G in f32, double buffered so a
-// round needs ONE barrier (rotation parameters and tiles read G[cur], tiles write
-// G[cur^1]); every lane derives the rotation of pair (lane & 31) itself and the
-// row-pair rotations arrive by wave shuffles; the pairing table lives in LDS.
-// The angle comes from f32 data, but (c, s) are formed in f64 from t (c^2+s^2 = 1
-// to f64 accuracy) and V is accumulated in f64: errors in V are coherent across
-// all q columns of the update, so V must be orthogonal to much better than f32.
-template <int NT>
-__global__ __launch_bounds__(NT) void bj_eig2_kernel(const float* __restrict__ Gp, int S,
-                                                     float* __restrict__ Jout, int* __restrict__ pairflag,
-                                                     int* __restrict__ flag, float tol, int max_inner) {
-  constexpr int W = 64, LD = 65, NG = NT / 32, TPT = 32 / NG, VPT = 64 / NG;
-  __shared__ float G[2][W * LD];
-  __shared__ double V[W * LD];
-  __shared__ uint16_t tab[(W - 1) * 32];  // p | q << 8 of pair i in round r
-  __shared__ int rotated;
-  const int pair = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
-  const float* gp = Gp + (int64_t)pair * S * 3072;
-  for (int e = tid; e < W * W; e += NT) {
-    const int i = e >> 6, j = e & 63;
-    int t, idx;
-    if (i < 32 && j < 32) { t = 0; idx = i * 32 + j; }
-    else if (i < 32) { t = 1; idx = i * 32 + (j - 32); }
-    else if (j < 32) { t = 1; idx = j * 32 + (i - 32); }
-    else { t = 2; idx = (i - 32) * 32 + (j - 32); }
-    double acc = 0.0;
-    for (int s = 0; s < S; ++s) acc += (double)gp[(int64_t)s * 3072 + t * 1024 + idx];
-    G[0][i * LD + j] = (float)acc;
-    V[i * LD + j] = (i == j) ? 1.0 : 0.0;
-  }
-  for (int e = tid; e < (W - 1) * 32; e += NT) {
-    int a, b;
-    bj_pair(W, e >> 5, e & 31, a, b);
-    tab[e] = (uint16_t)(a | (b << 8));
-  }
-  if (tid == 0) rotated = 0;
-  int any = 0, cur = 0;
-  const int l = tid & 31, g = tid >> 5;
-  const int src_half = lane & 32;
-  for (int sweep = 0; sweep < max_inner; ++sweep) {
-    for (int r = 0; r < W - 1; ++r) {
-      __syncthreads();
-      const float* Gc = G[cur];
-      float* Gn = G[cur ^ 1];
-      const uint16_t* tr = tab + r * 32;
-      const int pql = tr[l];
-      const int pl = pql & 255, ql = pql >> 8;
-      // rotation of pair l
-      const float gpp = Gc[pl * LD + pl], gqq = Gc[ql * LD + ql], gpq = Gc[pl * LD + ql];
-      double cl = 1.0, sl = 0.0;
-      if (fabsf(gpq) > tol * (sqrtf(fabsf(gpp)) * sqrtf(fabsf(gqq)))) {
-        const float zeta = (gqq - gpp) / (2.0f * gpq);
-        const float tf = (zeta >= 0.f ? 1.0f : -1.0f) / (fabsf(zeta) + sqrtf(1.0f + zeta * zeta));
-        const double t = (double)tf, x = 1.0 + t * t;
-        double y = (double)rsqrtf((float)x);
-        y = y * (1.5 - 0.5 * x * y * y);
-        y = y * (1.5 - 0.5 * x * y * y);
-        cl = y;
-        sl = y * t;
-        if (g == 0) rotated = 1;
-      }
-      const float clf = (float)cl, slf = (float)sl;
-#pragma unroll
-      for (int jj = 0; jj < TPT; ++jj) {
-        const int k = g + NG * jj;
-        const int pqk = tr[k];
-        const int pk = pqk & 255, qk = pqk >> 8;
-        const float ck = __shfl(clf, k | src_half, 64), sk = __shfl(slf, k | src_half, 64);
-        const float t00 = Gc[pk * LD + pl], t01 = Gc[pk * LD + ql];
-        const float t10 = Gc[qk * LD + pl], t11 = Gc[qk * LD + ql];
-        const float u00 = ck * t00 - sk * t10, u01 = ck * t01 - sk * t11;
-        const float u10 = sk * t00 + ck * t10, u11 = sk * t01 + ck * t11;
-        float v00 = clf * u00 - slf * u01, v01 = slf * u00 + clf * u01;
-        float v10 = clf * u10 - slf * u11, v11 = slf * u10 + clf * u11;
-        if (k == l && slf != 0.f) v01 = v10 = 0.f;  // the annihilated element
-        Gn[pk * LD + pl] = v00;
-        Gn[pk * LD + ql] = v01;
-        Gn[qk * LD + pl] = v10;
-        Gn[qk * LD + ql] = v11;
-      }
-      if (sl != 0.0) {
-#pragma unroll
-        for (int jj = 0; jj < VPT; ++jj) {
-          const int i = g + NG * jj;
-          const double vp = V[i * LD + pl], vq = V[i * LD + ql];
-          V[i * LD + pl] = cl * vp - sl * vq;
-          V[i * LD + ql] = sl * vp + cl * vq;
-        }
-      }
-      cur ^= 1;
-    }
-    __syncthreads();
-    const int rot = rotated;
-    __syncthreads();
-    if (!rot) break;
-    any = 1;
-    if (tid == 0) rotated = 0;
-  }
-  __syncthreads();
-  float* jo = Jout + (int64_t)pair * (W * W);
-  for (int e = tid; e < W * W; e += NT) jo[e] = (float)V[(e >> 6) * LD + (e & 63)];
+  TG* jo = Jout + (int64_t)pair * (W * W);
+  for (int e = tid; e < W * W; e += 256) jo[(e >> 6) * W + rank[e & 63]] = (TG)V[(e >> 6) * LD + (e & 63)];
   if (tid == 0) {
     pairflag[pair] = any;
     if (any) *flag = 1;
@@ -517,25 +425,123 @@ __global__ __launch_bounds__(256) void bj_update_kernel(float* __restrict__ X, i
   }
 }
 
+// ------------------------------------------------------------------ f64 path
+// Same three-launch round on the f64 matrix pipe (v_mfma_f64_16x16x4_f64).  A pair
+// is 4 row blocks of 16; the Gram kernel accumulates the 10 upper tiles of G.
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+
+__global__ __launch_bounds__(256) void bj_gram64_kernel(const double* __restrict__ X, int64_t ldx, int nb,
+                                                        int round, int chunks, int cpw,
+                                                        double* __restrict__ Gp) {
+  __shared__ double red[4][10 * 256];
+  const int pair = blockIdx.x, split = blockIdx.y, S = gridDim.y;
+  int bi, bj;
+  bj_pair(nb, round, pair, bi, bj);
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const double* xr[4];
+#pragma unroll
+  for (int rb = 0; rb < 4; ++rb) {
+    const int64_t row = (rb < 2 ? (int64_t)bi * 32 + rb * 16 : (int64_t)bj * 32 + (rb - 2) * 16) + (lane & 15);
+    xr[rb] = X + row * ldx + 2 * (lane >> 4);
+  }
+  int c0 = (split * 4 + wid) * cpw;
+  int c1 = c0 + cpw;
+  if (c1 > chunks) c1 = chunks;
+  f64x4 acc[10];
+#pragma unroll
+  for (int t = 0; t < 10; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[t][r] = 0.0;
+  for (int c = c0; c < c1; ++c) {
+    f64x2 f[4];
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb) f[rb] = *(const f64x2*)(xr[rb] + 8 * (int64_t)c);
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      int t = 0;
+#pragma unroll
+      for (int ra = 0; ra < 4; ++ra)
+#pragma unroll
+        for (int rbb = ra; rbb < 4; ++rbb) {
+          acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(f[ra][e], f[rbb][e], acc[t], 0, 0, 0);
+          ++t;
+        }
+    }
+  }
+  // C/D layout: col = lane & 15, row = (lane >> 4) + 4 r
+#pragma unroll
+  for (int t = 0; t < 10; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[wid][t * 256 + ((lane >> 4) + 4 * r) * 16 + (lane & 15)] = acc[t][r];
+  __syncthreads();
+  double* out = Gp + ((int64_t)pair * S + split) * 2560;
+  for (int e = tid; e < 2560; e += 256) out[e] = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
+}
+
+// grid (pairs, ceil(nss / 4)); wave = one 32-column strip of [X | R] (all 64 rows, in place).
+__global__ __launch_bounds__(256) void bj_update64_kernel(double* __restrict__ X, int64_t ldx, int nssX,
+                                                          double* __restrict__ R, int64_t ldr, int nssR,
+                                                          int nb, int round, const double* __restrict__ J,
+                                                          const int* __restrict__ pairflag) {
+  const int pair = blockIdx.x;
+  if (!pairflag[pair]) return;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int ss = blockIdx.y * 4 + wid;
+  if (ss >= nssX + nssR) return;
+  int bi, bj;
+  bj_pair(nb, round, pair, bi, bj);
+  double* base;
+  int64_t ld;
+  if (ss < nssX) { base = X + (int64_t)ss * 32; ld = ldx; }
+  else { base = R + (int64_t)(ss - nssX) * 32; ld = ldr; }
+  const int n = lane & 15, kk = lane >> 4;
+  const double* Jp = J + (int64_t)pair * 4096;
+  auto grow = [&](int row) -> int64_t { return row < 32 ? (int64_t)bi * 32 + row : (int64_t)bj * 32 + (row - 32); };
+  f64x2 bv[16];
+#pragma unroll
+  for (int ks = 0; ks < 16; ++ks) bv[ks] = *(const f64x2*)(base + grow(4 * ks + kk) * ld + 2 * n);
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    f64x4 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc0[r] = acc1[r] = 0.0;
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) {
+      const double jf = Jp[(4 * ks + kk) * 64 + 16 * it + n];   // A operand: V[k][a], a = 16 it + n
+      acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(jf, bv[ks][0], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(jf, bv[ks][1], acc1, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = 16 * it + kk + 4 * r;
+      f64x2 o;
+      o[0] = acc0[r];
+      o[1] = acc1[r];
+      *(f64x2*)(base + grow(row) * ld + 2 * n) = o;
+    }
+  }
+}
+
 // Xp (P x Q, zero padded) = A (m x n row-major) or its transpose.
-template <bool TRANS>
-__global__ __launch_bounds__(256) void bj_pad_copy_kernel(float* __restrict__ Xp, int64_t Q,
-                                                          const float* __restrict__ A, int64_t m, int64_t n) {
-  __shared__ float tile[32][33];
+template <typename T, bool TRANS>
+__global__ __launch_bounds__(256) void bj_pad_copy_kernel(T* __restrict__ Xp, int64_t Q,
+                                                          const T* __restrict__ A, int64_t m, int64_t n) {
+  __shared__ T tile[32][33];
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
   const int64_t r0 = (int64_t)blockIdx.y * 32, c0 = (int64_t)blockIdx.x * 32;  // tile origin in Xp
   if (!TRANS) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int64_t r = r0 + ty + 8 * j, c = c0 + tx;
-      Xp[r * Q + c] = (r < m && c < n) ? A[r * n + c] : 0.f;
+      Xp[r * Q + c] = (r < m && c < n) ? A[r * n + c] : (T)0;
     }
   } else {
     // Xp[r][c] = A[c][r]; rows of Xp index columns of A (r < n), cols of Xp index rows of A (c < m)
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int64_t ar = c0 + ty + 8 * j, ac = r0 + tx;
-      tile[ty + 8 * j][tx] = (ar < m && ac < n) ? A[ar * n + ac] : 0.f;
+      tile[ty + 8 * j][tx] = (ar < m && ac < n) ? A[ar * n + ac] : (T)0;
     }
     __syncthreads();
 #pragma unroll
@@ -543,28 +549,33 @@ __global__ __launch_bounds__(256) void bj_pad_copy_kernel(float* __restrict__ Xp
   }
 }
 
-int svd_block_pad_copy(float* Xp, int64_t P, int64_t Q, const float* A, int64_t m, int64_t n, bool trans) {
+template <typename T>
+int svd_block_pad_copy(T* Xp, int64_t P, int64_t Q, const T* A, int64_t m, int64_t n, bool trans) {
   const dim3 grid((unsigned)(Q / 32), (unsigned)(P / 32));
-  if (trans) hipLaunchKernelGGL((bj_pad_copy_kernel<true>), grid, dim3(256), 0, stream(), Xp, Q, A, m, n);
-  else hipLaunchKernelGGL((bj_pad_copy_kernel<false>), grid, dim3(256), 0, stream(), Xp, Q, A, m, n);
+  if (trans) hipLaunchKernelGGL((bj_pad_copy_kernel<T, true>), grid, dim3(256), 0, stream(), Xp, Q, A, m, n);
+  else hipLaunchKernelGGL((bj_pad_copy_kernel<T, false>), grid, dim3(256), 0, stream(), Xp, Q, A, m, n);
   TNH_LAUNCH_CHECK();
   return TNH_OK;
 }
+template int svd_block_pad_copy<float>(float*, int64_t, int64_t, const float*, int64_t, int64_t, bool);
+template int svd_block_pad_copy<double>(double*, int64_t, int64_t, const double*, int64_t, int64_t, bool);
 
-size_t svd_block_scratch_bytes(int64_t P, int64_t Q) {
+size_t svd_block_scratch_bytes(int esz, int64_t P, int64_t Q) {
   const int64_t pairs = P / 64;
   (void)Q;
-  return (size_t)pairs * 16 * 3072 * sizeof(float)   // Gram partials (<= 16 splits)
-         + (size_t)pairs * 4096 * sizeof(float)      // V per pair
-         + (size_t)pairs * sizeof(int) + 256;        // pair flags
+  return (size_t)pairs * 16 * 3072 * esz   // Gram partials (<= 16 splits; 2560 per split for f64)
+         + (size_t)pairs * 4096 * esz      // V per pair
+         + (size_t)pairs * sizeof(int) + 256;   // pair flags
 }
 
 // Sweeps until a whole sweep applies no rotation.  X: P x Q (ld Q), R: P x P.
-int svd_block_sweeps(float* X, float* R, int64_t P, int64_t Q, char* scratch, int* flag, double tol,
+template <typename T>
+int svd_block_sweeps(T* X, T* R, int64_t P, int64_t Q, char* scratch, int* flag, double tol,
                      int max_sweeps, int* sweeps_out, bool* converged_out) {
+  constexpr bool F64 = sizeof(T) == 8;
   const int nb = (int)(P / 32), pairs = nb / 2;
-  float* Gp = (float*)scratch;
-  float* J = Gp + (size_t)pairs * 16 * 3072;
+  T* Gp = (T*)scratch;
+  T* J = Gp + (size_t)pairs * 16 * 3072;
   int* pairflag = (int*)(J + (size_t)pairs * 4096);
   const int chunks = (int)(Q / 8);
   // splits: enough workgroups to fill the chip, each wave with >= 4 chunks of work
@@ -573,15 +584,10 @@ int svd_block_sweeps(float* X, float* R, int64_t P, int64_t Q, char* scratch, in
   while (S > 1 && chunks / (4 * S) < 4) --S;
   if (S < 1) S = 1;
   const int cpw = (chunks + 4 * S - 1) / (4 * S);
-  const int nssX = (int)(Q / 128), nssR = (int)(P / 128);
+  const int sw = F64 ? 32 : 128;    // strip width of the update kernel
+  const int nssX = (int)(Q / sw), nssR = (int)(P / sw);
   const char* env = getenv("TNH_SVD_INNER");
   const int inner = env ? atoi(env) : 1;
-  const char* env0 = getenv("TNH_SVD_INNER0");
-  const int inner0 = env0 ? atoi(env0) : inner;
-  const char* envs = getenv("TNH_SVD_SORT");
-  const int sort = envs ? atoi(envs) : 0;
-  const char* enve = getenv("TNH_SVD_EIG");
-  const int eigv = enve ? atoi(enve) : 4;
   const char* envc = getenv("TNH_SVD_CROSS");
   const int crossv = envc ? atoi(envc) : 1;
   int sweeps = 0;
@@ -589,26 +595,22 @@ int svd_block_sweeps(float* X, float* R, int64_t P, int64_t Q, char* scratch, in
   while (!converged && sweeps < max_sweeps) {
     TNH_HIP(hipMemsetAsync(flag, 0, sizeof(int), stream()));
     for (int r = 0; r < nb - 1; ++r) {
-      hipLaunchKernelGGL(bj_gram_kernel, dim3((unsigned)pairs, (unsigned)S), dim3(256), 0, stream(), X, Q, nb, r,
-                         chunks, cpw, Gp);
-      const int mi = sweeps == 0 ? inner0 : inner;
-      if (eigv == 0)
-        hipLaunchKernelGGL(bj_eig_kernel, dim3((unsigned)pairs), dim3(256), 0, stream(), Gp, S, J, pairflag,
-                           flag, tol, mi, sort);
-      else if (eigv == 1)
-        hipLaunchKernelGGL((bj_eig2_kernel<256>), dim3((unsigned)pairs), dim3(256), 0, stream(), Gp, S, J,
-                           pairflag, flag, (float)tol, mi);
-      else if (eigv == 2)
-        hipLaunchKernelGGL((bj_eig2_kernel<512>), dim3((unsigned)pairs), dim3(512), 0, stream(), Gp, S, J,
-                           pairflag, flag, (float)tol, mi);
-      else if (eigv == 3)
-        hipLaunchKernelGGL((bj_eig3_kernel<512>), dim3((unsigned)pairs), dim3(512), 0, stream(), Gp, S, J,
-                           pairflag, flag, (float)tol, mi, (crossv && r > 0) ? 1 : 0);
-      else
+      const dim3 ugrid((unsigned)pairs, (unsigned)((nssX + nssR + 3) / 4));
+      if constexpr (F64) {
+        hipLaunchKernelGGL(bj_gram64_kernel, dim3((unsigned)pairs, (unsigned)S), dim3(256), 0, stream(), X, Q, nb, r,
+                           chunks, cpw, Gp);
+        hipLaunchKernelGGL((bj_eig_kernel<double, 16>), dim3((unsigned)pairs), dim3(256), 0, stream(), Gp, S, J,
+                           pairflag, flag, tol, inner, 0);
+        hipLaunchKernelGGL(bj_update64_kernel, ugrid, dim3(256), 0, stream(), X, Q, nssX, R, P, nssR, nb, r, J,
+                           pairflag);
+      } else {
+        hipLaunchKernelGGL(bj_gram_kernel, dim3((unsigned)pairs, (unsigned)S), dim3(256), 0, stream(), X, Q, nb, r,
+                           chunks, cpw, Gp);
         hipLaunchKernelGGL((bj_eig3_kernel<1024>), dim3((unsigned)pairs), dim3(1024), 0, stream(), Gp, S, J,
-                           pairflag, flag, (float)tol, mi, (crossv && r > 0) ? 1 : 0);
-      hipLaunchKernelGGL(bj_update_kernel, dim3((unsigned)pairs, (unsigned)((nssX + nssR + 3) / 4)), dim3(256), 0,
-                         stream(), X, Q, nssX, R, P, nssR, nb, r, J, pairflag);
+                           pairflag, flag, (float)tol, inner, (crossv && r > 0) ? 1 : 0);
+        hipLaunchKernelGGL(bj_update_kernel, ugrid, dim3(256), 0, stream(), X, Q, nssX, R, P, nssR, nb, r, J,
+                           pairflag);
+      }
     }
     TNH_LAUNCH_CHECK();
     int h = 0;
@@ -621,5 +623,7 @@ int svd_block_sweeps(float* X, float* R, int64_t P, int64_t Q, char* scratch, in
   *converged_out = converged;
   return TNH_OK;
 }
+template int svd_block_sweeps<float>(float*, float*, int64_t, int64_t, char*, int*, double, int, int*, bool*);
+template int svd_block_sweeps<double>(double*, double*, int64_t, int64_t, char*, int*, double, int, int*, bool*);
 
 }  // namespace tnh

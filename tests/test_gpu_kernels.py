@@ -348,6 +348,22 @@ def test_svd_rank_deficient_and_zero(hip, dtype, rtol_s, otol):
   np.testing.assert_allclose(np.asarray(trunc), [0.2, 0.1], rtol=1e-5)
 
 
+@pytest.mark.parametrize("dtype,rtol_s,otol", [(np.float32, 1e-5, 1e-4), (np.float64, 1e-13, 1e-12)])
+@pytest.mark.parametrize("shape", [(65, 65), (200, 300), (300, 200), (384, 512), (96, 1000)])
+def test_svd_block_path(hip, dtype, rtol_s, otol, shape):
+  """min(m, n) > 64: block one-sided Jacobi on the MFMA (tnh_svd_block.hip), both dtypes."""
+  rng = np.random.default_rng(shape[0] * 7 + shape[1])
+  a = rng.standard_normal(shape).astype(dtype)
+  _check_svd(hip, a, rtol_s, otol)
+  _check_svd(hip, a, rtol_s, otol, max_singular_values=min(shape) // 4)
+  # rank-deficient: a zero row/column and an exactly repeated row
+  b = a.copy()
+  b[3, :] = 0
+  b[:, 5] = 0
+  b[10, :] = b[11, :]
+  _check_svd(hip, b, 20 * rtol_s, 20 * otol, max_singular_values=min(shape) // 4)
+
+
 def test_svd_prescribed_spectrum_512(hip):
   # SURVEY 8d config-3 input (ii): s_i = 2^(-i/32), Haar factors
   rng = np.random.default_rng(4)

@@ -11,6 +11,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--check", type=int, default=1)
 ap.add_argument("--sizes", default="1024,2048,4096")
 ap.add_argument("--reps", type=int, default=1)
+ap.add_argument("--dtype", default="f32")
 ap.add_argument("--verify-big", type=int, default=1, help="compare the largest size against numpy too")
 a = ap.parse_args()
 be = ta.get_hip_backend()
@@ -54,7 +55,7 @@ if a.check:
   allok &= check((384, 640), spectrum=lambda r: np.where(np.arange(r) < r // 2, 1.0, 0.0) * np.linspace(1, 2, r))
 
 for n in [int(v) for v in a.sizes.split(",") if v]:
-  x = be.device_random((n, n), dtype=np.float32, seed=3, normal=True)
+  x = be.device_random((n, n), dtype=np.float64 if a.dtype == 'f64' else np.float32, seed=3, normal=True)
   k = n // 16
   best = None
   for _ in range(a.reps + 1):
@@ -64,7 +65,7 @@ for n in [int(v) for v in a.sizes.split(",") if v]:
     be.synchronize()
     dt = time.perf_counter() - t0
     best = dt if best is None else min(best, dt)
-  nbytes = 4 * (n * n + n * k + n + k * n)
+  nbytes = x.itemsize * (n * n + n * k + n + k * n)
   rec = {"n": n, "k": k, "sec": best, "gbps": nbytes / best / 1e9, "sweeps": be.last_svd_sweeps}
   if a.verify_big and n <= 2048:
     xs = np.asarray(x).astype(np.float64)
