@@ -296,7 +296,8 @@ __global__ __launch_bounds__(256) void gemm_valu_kernel(GemmArgs g) {
 }
 
 static thread_local const char* g_last_kernel = "none";
-static int g_variant = 0;  // 0 auto, 1 generic (mfma), 2 valu, 3 bf16_128, 4 bf16_256, 5 bf16_256pp
+static int g_variant = 0;  // 0 auto, 1 generic (mfma), 2 valu, 3 bf16_128, 4 bf16_256, 5 bf16_256pp,
+                           // 6 bf16_ragged (auto shape), 7 .._128x128, 8 .._64x256, 9 .._256x64
 
 template <typename F>
 static int launch_batched(F launch, const GemmArgs& g0, int64_t batch, int BM, int BN) {
@@ -340,6 +341,10 @@ int tnh_gemm_set_variant(const char* full) {
   else if (!strcmp(name, "bf16_128")) g_variant = 3;
   else if (!strcmp(name, "bf16_256")) g_variant = 4;
   else if (!strcmp(name, "bf16_256pp")) g_variant = 5;
+  else if (!strcmp(name, "bf16_ragged")) g_variant = 6;
+  else if (!strcmp(name, "bf16_ragged_128x128")) g_variant = 7;
+  else if (!strcmp(name, "bf16_ragged_64x256")) g_variant = 8;
+  else if (!strcmp(name, "bf16_ragged_256x64")) g_variant = 9;
   else {
     set_error("unknown gemm variant '%s'", name);
     return TNH_ERR_INVALID;

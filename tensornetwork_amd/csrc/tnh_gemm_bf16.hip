@@ -20,28 +20,13 @@
 //     and then grouped along M so that neighbouring tiles reuse B panels.
 //
 // MFMA roofline: 2*M*N*K flop against 2.5 PFLOP/s dense bf16.
-#include "tnh_internal.h"
+#include "tnh_gemm_nt.h"
 
 namespace tnh {
-
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
-typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 int g_opt_raster = 1;  // A/B knobs, set through tnh_gemm_set_variant("name:r<d>:p<d>")
 int g_opt_phases = 2;  // ping-pong kernel: MFMA clusters per K-tile (2 = 32-MFMA clusters, default; 4)
 static bool g_pp_default = true;  // ping-pong kernel won the A/B on MI355X (profiles/r01_sweep_v2.jsonl)
-
-struct NtArgs {
-  const uint16_t* A;
-  const uint16_t* B;
-  void* C;
-  int64_t M, N, K;
-  int64_t lda, ldb, ldc;
-  int64_t sA, sB, sC;
-  int tiles_m, tiles_n;
-  int raster;  // 1 (default): 16x16 super-tiles shared by the 8 XCDs (3x less HBM traffic, +2%); 0: per-XCD ranges, M-grouped
-};
 
 #define TNH_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 #define TNH_GLB_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
@@ -59,88 +44,6 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
       : "=&s"(keep)
       : "v"(gsrc), "s"(lds_dst)
       : "memory");
-}
-
-template <bool IS_BF16>
-__device__ __forceinline__ f32x4 mma16(const uint4& a, const uint4& b, f32x4 c) {
-  if constexpr (IS_BF16)
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)&a, *(const bf16x8*)&b, c, 0, 0, 0);
-  else
-    return __builtin_amdgcn_mfma_f32_16x16x32_f16(*(const f16x8*)&a, *(const f16x8*)&b, c, 0, 0, 0);
-}
-
-template <bool IS_BF16>
-__device__ __forceinline__ uint32_t pack2(float lo, float hi) {
-  if constexpr (IS_BF16) return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
-  else return (uint32_t)f32_to_f16(lo) | ((uint32_t)f32_to_f16(hi) << 16);
-}
-
-// XCD-aware, M-grouped tile order.  `bid` -> (tile_m, tile_n), bijective for
-// any grid size.
-__device__ __forceinline__ void tile_of_block(int bid, int tiles_m, int tiles_n, int raster, int& tm,
-                                              int& tn) {
-  const int nwg = tiles_m * tiles_n;
-  if (raster == 1 && (tiles_m & 15) == 0 && (tiles_n & 15) == 0) {
-    // The 256 workgroups resident at one time (32 per XCD) cover one 16x16
-    // block of tiles; XCD x owns the 4x8 sub-block (x >> 1, x & 1) so its private
-    // L2 sees 4 A-panels x 8 B-panels, while the other XCDs' fetches of the same
-    // panels hit in the memory-side Infinity Cache.
-    const int xcd = bid & 7, j = bid >> 3;
-    const int sb = j >> 5, w = j & 31;
-    const int sbm = tiles_m >> 4;
-    const int sm = sb % sbm, sn = sb / sbm;
-    tm = sm * 16 + (xcd >> 1) * 4 + (w & 3);
-    tn = sn * 16 + (xcd & 1) * 8 + (w >> 2);
-    return;
-  }
-  const int q = nwg >> 3, r = nwg & 7;
-  const int xcd = bid & 7, local = bid >> 3;
-  const int pid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
-  constexpr int GROUP_M = 8;
-  const int per_group = GROUP_M * tiles_n;
-  const int group = pid / per_group;
-  const int first_m = group * GROUP_M;
-  const int gsize = (tiles_m - first_m < GROUP_M) ? (tiles_m - first_m) : GROUP_M;
-  const int in_group = pid - group * per_group;
-  tm = first_m + in_group % gsize;
-  tn = in_group / gsize;
-}
-
-// Epilogue shared by the speed-path kernels.  With the swapped-operand MFMA a
-// lane holds C[m = l & 15][n = 4*(l >> 4) .. +3] of each 16x16 tile: 8-B (bf16 /
-// f16) or 16-B (f32) stores, 64 contiguous bytes per row per tile.
-template <bool IS_BF16, bool OUT_F32, int FM, int FN>
-__device__ __forceinline__ void store_wave_tile(const f32x4 (&acc)[FM][FN], const NtArgs& p, char* Cb,
-                                                int64_t m0, int64_t n0, int BM, int BN, int wave_m,
-                                                int wave_n, int lane) {
-  const bool full = (m0 + BM <= p.M) && (n0 + BN <= p.N);
-#pragma unroll
-  for (int i = 0; i < FM; ++i) {
-    const int64_t m = m0 + wave_m + i * 16 + (lane & 15);
-#pragma unroll
-    for (int j = 0; j < FN; ++j) {
-      const int64_t n = n0 + wave_n + j * 16 + (lane >> 4) * 4;
-      const f32x4 v = acc[i][j];
-      if (full || (m < p.M && n + 3 < p.N)) {
-        if constexpr (OUT_F32) {
-          *(float4*)(Cb + (m * p.ldc + n) * 4) = make_float4(v[0], v[1], v[2], v[3]);
-        } else {
-          uint2 o;
-          o.x = pack2<IS_BF16>(v[0], v[1]);
-          o.y = pack2<IS_BF16>(v[2], v[3]);
-          *(uint2*)(Cb + (m * p.ldc + n) * 2) = o;
-        }
-      } else if (m < p.M) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          if (n + r < p.N) {
-            if constexpr (OUT_F32) ((float*)Cb)[m * p.ldc + n + r] = v[r];
-            else ((uint16_t*)Cb)[m * p.ldc + n + r] = IS_BF16 ? f32_to_bf16(v[r]) : f32_to_f16(v[r]);
-          }
-        }
-      }
-    }
-  }
 }
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool IS_BF16, bool OUT_F32>
@@ -588,18 +491,30 @@ static int launch_pp(bool is_bf16, bool out_f32, bool two, NtArgs p, int64_t bat
 }
 
 // Returns TNH_ERR_UNSUPPORTED (without setting an error the caller must
-// surface) when the shape/layout does not meet the speed path's rules; the
-// dispatcher then falls back to the general MFMA kernel.
+// surface) when the layout is not NT; the dispatcher then falls back to the
+// general (strided) MFMA kernel.
+int gemm_bf16_ragged(int in_dt, int out_dt, int shape, int64_t M, int64_t N, int64_t K, const void* A,
+                     int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int64_t batch,
+                     int64_t sA, int64_t sB, int64_t sC, const char** name);
+
 int gemm_bf16_fast(int in_dt, int out_dt, int variant, int transA, int transB, int64_t M, int64_t N,
                    int64_t K, const void* A, int64_t lda, const void* B, int64_t ldb, void* C,
                    int64_t ldc, int64_t batch, int64_t sA, int64_t sB, int64_t sC, const char** name) {
-  const bool ok = transA == 0 && transB == 1 && K % 64 == 0 && lda % 8 == 0 && ldb % 8 == 0 &&
-                  ldc % 4 == 0 && ((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0 &&
-                  ((uintptr_t)C % 16) == 0 && sA % 8 == 0 && sB % 8 == 0 && sC % 4 == 0 && M >= 16 &&
-                  N >= 16;
-  if (!ok) {
-    set_error("bf16 speed path needs NT layout, K%%64==0 and 16-B aligned rows");
+  if (!(transA == 0 && transB == 1)) {
+    set_error("bf16 matrix-core path needs the NT layout (both operands K-contiguous)");
     return TNH_ERR_UNSUPPORTED;
+  }
+  const bool dma_ok = K % 64 == 0 && lda % 8 == 0 && ldb % 8 == 0 && ldc % 4 == 0 &&
+                      ((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0 && ((uintptr_t)C % 16) == 0 &&
+                      sA % 8 == 0 && sB % 8 == 0 && sC % 4 == 0 && M >= 16 && N >= 16;
+  if (variant >= 6 || !dma_ok) {
+    if (variant >= 3 && variant <= 5) {
+      set_error("LDS-DMA bf16 kernels need K%%64==0 and 16-B aligned rows");
+      return TNH_ERR_UNSUPPORTED;
+    }
+    // ragged shapes / odd alignment: register-staged kernel (tnh_gemm_ragged.hip)
+    return gemm_bf16_ragged(in_dt, out_dt, variant >= 6 ? variant - 6 : 0, M, N, K, A, lda, B, ldb, C, ldc,
+                            batch, sA, sB, sC, name);
   }
   NtArgs p;
   p.A = (const uint16_t*)A;
@@ -609,6 +524,8 @@ int gemm_bf16_fast(int in_dt, int out_dt, int variant, int transA, int transB, i
   p.lda = lda; p.ldb = ldb; p.ldc = ldc;
   p.sA = sA; p.sB = sB; p.sC = sC;
   p.raster = g_opt_raster;
+  p.c_vec = 1;
+  p.a_vw = p.b_vw = 8;
   const bool is_bf16 = (in_dt == TNH_BF16), out_f32 = (out_dt == TNH_F32);
   // 256x256 tiles once there are enough of them to fill the 256 CUs.
   bool big = (M >= 256 && N >= 256) && (((M + 255) / 256) * ((N + 255) / 256) * batch >= 192);

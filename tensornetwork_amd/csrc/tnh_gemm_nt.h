@@ -1,0 +1,107 @@
+// Pieces shared by the bf16 / f16 "NT" GEMM kernels (C[M,N] = A[M,K] * B[N,K]^T, both
+// operands K-contiguous): argument block, MFMA wrapper, XCD-aware tile order, epilogue.
+#pragma once
+#include "tnh_internal.h"
+
+namespace tnh {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+struct NtArgs {
+  const uint16_t* A;
+  const uint16_t* B;
+  void* C;
+  int64_t M, N, K;
+  int64_t lda, ldb, ldc;
+  int64_t sA, sB, sC;
+  int tiles_m, tiles_n;
+  int c_vec;   // 1: C rows are 8-B (half out) / 16-B (f32 out) aligned at every n % 4 == 0 -> vector stores
+  int a_vw, b_vw;  // ragged kernel only: widest aligned load (elements: 8, 4, 2, 1) on rows of A / B
+  int raster;  // 1 (default): 16x16 super-tiles shared by the 8 XCDs (3x less HBM traffic, +2%); 0: per-XCD ranges, M-grouped
+};
+
+template <bool IS_BF16>
+__device__ __forceinline__ f32x4 mma16(const uint4& a, const uint4& b, f32x4 c) {
+  if constexpr (IS_BF16)
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)&a, *(const bf16x8*)&b, c, 0, 0, 0);
+  else
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(*(const f16x8*)&a, *(const f16x8*)&b, c, 0, 0, 0);
+}
+
+template <bool IS_BF16>
+__device__ __forceinline__ uint32_t pack2(float lo, float hi) {
+  if constexpr (IS_BF16) return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+  else return (uint32_t)f32_to_f16(lo) | ((uint32_t)f32_to_f16(hi) << 16);
+}
+
+// XCD-aware, M-grouped tile order.  `bid` -> (tile_m, tile_n), bijective for
+// any grid size.
+__device__ __forceinline__ void tile_of_block(int bid, int tiles_m, int tiles_n, int raster, int& tm,
+                                              int& tn) {
+  const int nwg = tiles_m * tiles_n;
+  if (raster == 1 && (tiles_m & 15) == 0 && (tiles_n & 15) == 0) {
+    // The 256 workgroups resident at one time (32 per XCD) cover one 16x16
+    // block of tiles; XCD x owns the 4x8 sub-block (x >> 1, x & 1) so its private
+    // L2 sees 4 A-panels x 8 B-panels, while the other XCDs' fetches of the same
+    // panels hit in the memory-side Infinity Cache.
+    const int xcd = bid & 7, j = bid >> 3;
+    const int sb = j >> 5, w = j & 31;
+    const int sbm = tiles_m >> 4;
+    const int sm = sb % sbm, sn = sb / sbm;
+    tm = sm * 16 + (xcd >> 1) * 4 + (w & 3);
+    tn = sn * 16 + (xcd & 1) * 8 + (w >> 2);
+    return;
+  }
+  const int q = nwg >> 3, r = nwg & 7;
+  const int xcd = bid & 7, local = bid >> 3;
+  const int pid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+  constexpr int GROUP_M = 8;
+  const int per_group = GROUP_M * tiles_n;
+  const int group = pid / per_group;
+  const int first_m = group * GROUP_M;
+  const int gsize = (tiles_m - first_m < GROUP_M) ? (tiles_m - first_m) : GROUP_M;
+  const int in_group = pid - group * per_group;
+  tm = first_m + in_group % gsize;
+  tn = in_group / gsize;
+}
+
+// Epilogue shared by the speed-path kernels.  With the swapped-operand MFMA a
+// lane holds C[m = l & 15][n = 4*(l >> 4) .. +3] of each 16x16 tile: 8-B (bf16 /
+// f16) or 16-B (f32) stores, 64 contiguous bytes per row per tile.
+template <bool IS_BF16, bool OUT_F32, int FM, int FN>
+__device__ __forceinline__ void store_wave_tile(const f32x4 (&acc)[FM][FN], const NtArgs& p, char* Cb,
+                                                int64_t m0, int64_t n0, int BM, int BN, int wave_m,
+                                                int wave_n, int lane) {
+  const bool full = (m0 + BM <= p.M) && (n0 + BN <= p.N);
+#pragma unroll
+  for (int i = 0; i < FM; ++i) {
+    const int64_t m = m0 + wave_m + i * 16 + (lane & 15);
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+      const int64_t n = n0 + wave_n + j * 16 + (lane >> 4) * 4;
+      const f32x4 v = acc[i][j];
+      if (p.c_vec && (full || (m < p.M && n + 3 < p.N))) {
+        if constexpr (OUT_F32) {
+          *(float4*)(Cb + (m * p.ldc + n) * 4) = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+          uint2 o;
+          o.x = pack2<IS_BF16>(v[0], v[1]);
+          o.y = pack2<IS_BF16>(v[2], v[3]);
+          *(uint2*)(Cb + (m * p.ldc + n) * 2) = o;
+        }
+      } else if (m < p.M) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (n + r < p.N) {
+            if constexpr (OUT_F32) ((float*)Cb)[m * p.ldc + n + r] = v[r];
+            else ((uint16_t*)Cb)[m * p.ldc + n + r] = IS_BF16 ? f32_to_bf16(v[r]) : f32_to_f16(v[r]);
+          }
+        }
+      }
+    }
+  }
+}
+
+}  // namespace tnh

@@ -307,8 +307,7 @@ class HipBackend(BackendBase):
     when its contracted axes are already leading or trailing (the GEMM absorbs
     the transpose through its row/column strides); otherwise one K1 permute
     brings it to [free, contracted] form.  For bf16/f16 both operands are
-    brought to the K-contiguous form the MFMA speed path needs when the product
-    is large enough to pay for the extra pass.
+    brought to the K-contiguous form the 16x16x32 MFMA kernels consume.
     """
     a = self._as_tensor(a)
     b = self._as_tensor(b)
@@ -340,10 +339,12 @@ class HipBackend(BackendBase):
     if b.ndim == nc:
       b_form = "NK"
 
-    half_fast = (code in _HALF and k % 64 == 0 and m >= 64 and n >= 64 and
-                 2 * m * n * k >= (1 << 27))
-    want_a = a_form if (a_form and not (half_fast and a_form != "MK")) else None
-    want_b = b_form if (b_form and not (half_fast and b_form != "NK")) else None
+    # bf16 / f16: the matrix-core kernels (LDS-DMA for aligned shapes, register-staged
+    # for ragged ones) take both operands K-contiguous ("NT"); any other storage form is
+    # brought there by one K1 permute.  Products too small to care stay in place.
+    half_nt = code in _HALF and 2 * m * n * k >= (1 << 18)
+    want_a = a_form if (a_form and not (half_nt and a_form != "MK")) else None
+    want_b = b_form if (b_form and not (half_nt and b_form != "NK")) else None
 
     if want_a and want_b and order_a != order_b:
       # contracted axes are paired in a different memory order on the two sides:

@@ -163,6 +163,45 @@ def test_gemm_bf16_speed_path(hip, variant, expect, dtype, m, n, k):
   np.testing.assert_allclose(out, ref, rtol=tol, atol=tol * np.sqrt(k))
 
 
+@pytest.mark.parametrize("variant,expect", [("bf16_ragged", "bf16_nt_ragged_"), ("bf16_ragged_128x128", "bf16_nt_ragged_128x128x64"),
+                                            ("bf16_ragged_64x256", "bf16_nt_ragged_64x256x64"),
+                                            ("bf16_ragged_256x64", "bf16_nt_ragged_256x64x64")])
+@pytest.mark.parametrize("dtype", [ta.bfloat16, np.float16])
+def test_gemm_bf16_ragged_path(hip, variant, expect, dtype):
+  """Register-staged matrix-core kernel: any M, N, K (K tail zero-filled, k-steps past K
+  skipped), every row alignment (K = 12 -> 8-B loads, 6 -> 4-B, 7 -> 2-B), scalar C stores
+  when N % 4 != 0, all three tile shapes."""
+  for (m, n, k) in [(1, 1, 1), (5, 7, 3), (33, 65, 17), (130, 70, 129), (144, 300, 144), (12, 1000, 12),
+                    (257, 129, 40), (200, 136, 192), (64, 64, 64), (300, 20, 100), (1, 1, 1728), (144, 1728, 6),
+                    (20, 36, 7), (513, 258, 72)]:
+    out, ref, kernel, sk = _gemm_case(hip, dtype, m, n, k, 0, 1, variant=variant, rng=np.random.default_rng(m + n + k))
+    assert kernel.startswith(expect), kernel
+    tol = GEMM_TOL[dtype]
+    np.testing.assert_allclose(out, ref, rtol=tol, atol=tol * np.sqrt(k), err_msg=f"{kernel} {m}x{n}x{k}")
+
+
+def test_gemm_bf16_ragged_auto_dispatch_and_batch(hip):
+  """Auto dispatch: NT products that break the LDS-DMA alignment rules take the ragged matrix-core
+  kernel (not the f32-MFMA fallback); strided batches with odd strides included."""
+  rng = np.random.default_rng(12)
+  a = orc.round_bf16(rng.standard_normal((144, 144)))
+  b = orc.round_bf16(rng.standard_normal((5000, 144)))
+  out = hip.tensordot(hip.to_bfloat16(a), hip.to_bfloat16(b), [[1], [1]])
+  assert hip.lib.tnh_gemm_last_kernel().decode() == "bf16_nt_ragged_64x256x64"
+  np.testing.assert_allclose(np.asarray(out), a @ b.T, rtol=1.6e-2, atol=1.6e-2 * 12)
+  # batched NT through the C ABI: batch 3, K = 10 (4-B loads), strides not multiples of 8
+  import ctypes
+  from tensornetwork_amd.device_tensor import DeviceTensor
+  A = orc.round_bf16(rng.standard_normal((3, 37, 10)))
+  B = orc.round_bf16(rng.standard_normal((3, 21, 10)))
+  da, db = hip.to_bfloat16(A), hip.to_bfloat16(B)
+  c = DeviceTensor.empty((3, 37, 21), _lib.F32)
+  _lib.check(hip.lib.tnh_gemm(_lib.BF16, _lib.F32, 0, 1, 37, 21, 10, ctypes.c_void_p(da.ptr), 10,
+                              ctypes.c_void_p(db.ptr), 10, ctypes.c_void_p(c.ptr), 21, 3, 370, 210, 37 * 21))
+  assert hip.lib.tnh_gemm_last_kernel().decode().startswith("bf16_nt_ragged")
+  np.testing.assert_allclose(np.asarray(c), np.einsum("bmk,bnk->bmn", A, B), rtol=1e-5, atol=1e-5)
+
+
 def test_gemm_bf16_fp32_output_is_tighter(hip):
   rng = np.random.default_rng(9)
   a = orc.round_bf16(rng.standard_normal((256, 512)))

@@ -66,11 +66,24 @@ def main():
   ap = argparse.ArgumentParser()
   ap.add_argument("--quick", action="store_true")
   ap.add_argument("--gemm-only", action="store_true")
+  ap.add_argument("--skinny", action="store_true",
+                  help="ragged / skinny NT shapes of the D=12 sliced network: generic vs ragged matrix-core kernel")
   ap.add_argument("--variants", default="bf16_128,bf16_256,bf16_256pp")
   args = ap.parse_args()
   global VARIANTS
   VARIANTS = args.variants.split(',')
   be = ta.get_hip_backend()
+  if args.skinny:
+    shapes = [(144, 2985984, 144), (144, 248832, 1728), (1728, 248832, 12), (144, 248832, 144), (20736, 20736, 1728),
+              (20736, 1728, 20736), (4000, 4000, 4000), (4096, 4096, 4100), (12, 20736, 1728), (144, 144, 144)]
+    for (m, n, k) in shapes:
+      for variant in ("generic", "bf16_ragged", "bf16_ragged_128x128", "auto"):
+        if variant == "generic" and 2.0 * m * n * k > 3e11:
+          continue
+        rec = gemm_tflops(be, _lib.BF16, _lib.BF16, 0, 1, m, n, k, variant, "uniform", 5)
+        rec["gbps"] = 2.0 * (m * k + n * k + m * n) / rec["ms"] / 1e6
+        print(json.dumps(rec), flush=True)
+    return
   sizes = [4096] if args.quick else [2048, 4096, 8192]
   for n in sizes:
     for variant in VARIANTS:

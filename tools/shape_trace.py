@@ -1,0 +1,84 @@
+"""Host-only dry run of the hip backend's lowering: records every GEMM / permute the
+tensordot lowering would launch for a workload (no GPU, no data).  Used to size kernels.
+  python tools/shape_trace.py --D 12"""
+import argparse, collections, os, sys
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import tensornetwork_amd as ta
+from tensornetwork_amd import _lib, hip_backend, device_tensor, distributed, network, contractors, pathfinder
+
+LOG = []
+
+class FakeTensor(device_tensor.DeviceTensor):
+  def __init__(self, shape, code):
+    self._shape = tuple(int(s) for s in shape); self._code = code; self._block = None; self._offset = 0
+  @classmethod
+  def empty(cls, shape, code):
+    return cls(shape, code)
+  def view(self, shape):
+    return FakeTensor(shape, self._code)
+  @property
+  def ptr(self):
+    return 0
+
+device_tensor.DeviceTensor.empty = FakeTensor.empty
+hip_backend.DeviceTensor.empty = FakeTensor.empty
+
+class TraceBackend(hip_backend.HipBackend):
+  @property
+  def lib(self):
+    return None
+  def cast(self, tensor, dtype):
+    return tensor
+  def transpose(self, tensor, perm=None):
+    nd = tensor.ndim
+    perm = tuple(range(nd - 1, -1, -1)) if perm is None else tuple(perm)
+    if perm == tuple(range(nd)):
+      return tensor
+    LOG.append(("permute", tensor.shape, perm))
+    return FakeTensor([tensor.shape[p] for p in perm], tensor.code)
+  def _gemm(self, a, b, trans_a, trans_b, m, n, k, lda, ldb, batch=1, stride_a=0, stride_b=0, out_shape=None, out_code=None):
+    LOG.append(("gemm", int(trans_a), int(trans_b), m, n, k, batch))
+    return FakeTensor(out_shape if out_shape is not None else (m, n), a.code)
+  def _outer(self, a, b, out_shape):
+    LOG.append(("outer", a.size, b.size))
+    return FakeTensor(out_shape, a.code)
+  def _strided_copy(self, tensor, shape, strides, offset):
+    LOG.append(("gather", tuple(shape)))
+    return FakeTensor(shape, tensor.code)
+  def addition(self, a, b):
+    return a
+  def multiply(self, a, b):
+    return a
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--D", type=int, default=12)
+ap.add_argument("--min-slices", type=int, default=64)
+a = ap.parse_args()
+be = TraceBackend()
+import networkx as nx
+g = nx.random_regular_graph(3, 64, seed=6)
+D = a.D
+nodes = {v: network.Node(FakeTensor((D, D, D), _lib.BF16), backend=be) for v in sorted(g.nodes)}
+slot = {v: 0 for v in g.nodes}
+for x, y in sorted(g.edges):
+  network.connect(nodes[x][slot[x]], nodes[y][slot[y]]); slot[x] += 1; slot[y] += 1
+nodes = [nodes[v] for v in sorted(g.nodes)]
+cuts = distributed.choose_cut_edges(nodes, min_slices=a.min_slices)
+class One(distributed.LocalComm):
+  rank, world = 0, 10**9
+distributed.contract_sliced(nodes, cuts, comm=One(), use_graph=False)
+tot = 0
+for rec in LOG:
+  if rec[0] == "gemm":
+    _, ta_, tb_, m, n, k, batch = rec
+    fl = 2.0 * m * n * k * batch; tot += fl
+for rec in LOG:
+  if rec[0] == "gemm":
+    _, ta_, tb_, m, n, k, batch = rec
+    fl = 2.0 * m * n * k * batch
+    if fl / tot > 0.002:
+      print(f"gemm tA={ta_} tB={tb_} M={m} N={n} K={k}  {fl:.3e} flop  {100*fl/tot:.1f}%")
+  elif rec[0] == "permute" and np.prod(rec[1]) > 1e6:
+    print("permute", rec[1], rec[2], f"{np.prod(rec[1]):.2e} elems")
+print("total flop", f"{tot:.3e}", "n_gemm", sum(1 for r in LOG if r[0] == "gemm"))
