@@ -17,7 +17,8 @@ struct NtArgs {
   int64_t lda, ldb, ldc;
   int64_t sA, sB, sC;
   int tiles_m, tiles_n;
-  int c_vec;   // 1: C rows are 8-B (half out) / 16-B (f32 out) aligned at every n % 4 == 0 -> vector stores
+  int c_vec;   // 1: C rows are 8-B (half out) / 16-B (f32 out) aligned at every n % 4 == 0 -> vector stores;
+               // 2 (ragged kernel, half out): also 16-B aligned at every n % 8 == 0 -> LDS-staged row stores
   int a_vw, b_vw;  // ragged kernel only: widest aligned load (elements: 8, 4, 2, 1) on rows of A / B
   int raster;  // 1 (default): 16x16 super-tiles shared by the 8 XCDs (3x less HBM traffic, +2%); 0: per-XCD ranges, M-grouped
 };

@@ -21,6 +21,10 @@
 
 namespace tnh {
 
+extern int g_opt_phases;  // A/B knob (tnh_gemm_set_variant ":p<d>"): p1 disables the small-K variant
+#define g_opt_smallk (g_opt_phases != 1)
+extern int g_opt_raster;  // ":r2" disables the LDS-staged epilogue (A/B)
+
 // 8 consecutive k of one operand row -> one 16-B register chunk (zero past K).
 // `vw` (elements per aligned load) is wave-uniform.
 __device__ __forceinline__ uint4 load_chunk8(const uint16_t* p, int64_t krem, int vw) {
@@ -50,7 +54,12 @@ __device__ __forceinline__ uint4 load_chunk8(const uint16_t* p, int64_t krem, in
   return v;
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool IS_BF16, bool OUT_F32>
+//
+// SMALLK (K <= 192, i.e. at most 3 K-tiles -- one or two small bonds): such products are
+// pure streaming (HBM-bound) and a block's life is a few dependent memory latencies, so
+// ALL K-tiles are requested up front into registers and passed through ONE LDS stage
+// (half the LDS, twice the resident blocks) instead of the load / compute ring.
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool IS_BF16, bool OUT_F32, bool SMALLK>
 __global__ __launch_bounds__(256) void gemm_nt_ragged_kernel(NtArgs p) {
   static_assert(WAVES_M * WAVES_N == 4, "256 threads");
   constexpr int BK = 64;
@@ -59,7 +68,12 @@ __global__ __launch_bounds__(256) void gemm_nt_ragged_kernel(NtArgs p) {
   constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2;
   constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
   constexpr int A_CH = BM * 8 / 256, B_CH = BN * 8 / 256;  // 16-B chunks per thread per K-tile
-  __shared__ __attribute__((aligned(1024))) char smem[2 * STAGE_BYTES];
+  constexpr int KT_MAX = 3;  // SMALLK: K-tiles held in registers
+  // epilogue staging image (half-precision output): BM rows of BN elements + 16 B pad
+  constexpr int EPI_PITCH = BN * 2 + 16;
+  constexpr int EPI_BYTES = OUT_F32 ? 0 : BM * EPI_PITCH;
+  constexpr int LOOP_BYTES = (SMALLK ? 1 : 2) * STAGE_BYTES;
+  __shared__ __attribute__((aligned(1024))) char smem[LOOP_BYTES > EPI_BYTES ? LOOP_BYTES : EPI_BYTES];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -120,15 +134,9 @@ __global__ __launch_bounds__(256) void gemm_nt_ragged_kernel(NtArgs p) {
 #pragma unroll
     for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int nt = (int)((p.K + BK - 1) / BK);
-  load_tile(0);
-  store_tile(0);
-  __syncthreads();
-  for (int t = 0; t < nt; ++t) {
-    if (t + 1 < nt) load_tile((int64_t)(t + 1) * BK);
-    const char* sa = smem + (t & 1) * STAGE_BYTES + (wm * WTM) * 128;
-    const char* sb = smem + (t & 1) * STAGE_BYTES + A_BYTES + (wn * WTN) * 128;
-    const int64_t kvalid = p.K - (int64_t)t * BK;
+  auto mma_tile = [&](int s, int64_t kvalid) {
+    const char* sa = smem + s * STAGE_BYTES + (wm * WTM) * 128;
+    const char* sb = smem + s * STAGE_BYTES + A_BYTES + (wn * WTN) * 128;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       if (ks * 32 < kvalid) {  // wave-uniform: skip a k-step that is all zero padding
@@ -143,15 +151,92 @@ __global__ __launch_bounds__(256) void gemm_nt_ragged_kernel(NtArgs p) {
           for (int j = 0; j < FN; ++j) acc[i][j] = mma16<IS_BF16>(bf[j], af[i], acc[i][j]);
       }
     }
-    if (t + 1 < nt) store_tile((t + 1) & 1);
+  };
+
+  const int nt = (int)((p.K + BK - 1) / BK);
+  if constexpr (SMALLK) {
+    uint4 qa[KT_MAX][A_CH], qb[KT_MAX][B_CH];
+#pragma unroll
+    for (int t = 0; t < KT_MAX; ++t) {
+      if (t < nt) {
+        const int64_t krem = p.K - (int64_t)t * BK - cchunk * 8;
+#pragma unroll
+        for (int j = 0; j < A_CH; ++j) qa[t][j] = load_chunk8(ga[j] + t * BK, krem, a_vw);
+#pragma unroll
+        for (int j = 0; j < B_CH; ++j) qb[t][j] = load_chunk8(gb[j] + t * BK, krem, b_vw);
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < KT_MAX; ++t) {
+      if (t < nt) {
+        if (t > 0) __syncthreads();  // everyone is done reading tile t-1
+        char* base = smem + st_off;
+#pragma unroll
+        for (int j = 0; j < A_CH; ++j) *(uint4*)(base + j * 32 * 128) = qa[t][j];
+#pragma unroll
+        for (int j = 0; j < B_CH; ++j) *(uint4*)(base + A_BYTES + j * 32 * 128) = qb[t][j];
+        __syncthreads();
+        mma_tile(0, p.K - (int64_t)t * BK);
+      }
+    }
+  } else {
+    load_tile(0);
+    store_tile(0);
     __syncthreads();
+    for (int t = 0; t < nt; ++t) {
+      if (t + 1 < nt) load_tile((int64_t)(t + 1) * BK);
+      mma_tile(t & 1, p.K - (int64_t)t * BK);
+      if (t + 1 < nt) store_tile((t + 1) & 1);
+      __syncthreads();
+    }
   }
 
-  store_wave_tile<IS_BF16, OUT_F32, FM, FN>(acc, p, (char*)p.C + (int64_t)blockIdx.y * p.sC * (OUT_F32 ? 4 : 2),
-                                            m0, n0, BM, BN, wm * WTM, wn * WTN, lane);
+  char* Cb = (char*)p.C + (int64_t)blockIdx.y * p.sC * (OUT_F32 ? 4 : 2);
+  if constexpr (!OUT_F32) {
+    if (p.c_vec == 2) {
+      // Half-precision output through LDS: the MFMA layout gives a lane 4 consecutive n of
+      // one row (32-B pieces, 16 rows per store); streaming products live on their C
+      // writes, so rows are re-assembled in LDS and written as 16 B per lane, a whole
+      // BN-wide row segment (up to 512 B) per 32 lanes.
+      __syncthreads();  // (SMALLK: the K loop does not end on a barrier) all fragment reads done
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+          const int row = wm * WTM + i * 16 + (lane & 15);
+          const int col = wn * WTN + j * 16 + (lane >> 4) * 4;
+          uint2 o;
+          o.x = pack2<IS_BF16>(acc[i][j][0], acc[i][j][1]);
+          o.y = pack2<IS_BF16>(acc[i][j][2], acc[i][j][3]);
+          *(uint2*)(smem + row * EPI_PITCH + col * 2) = o;
+        }
+      __syncthreads();
+      constexpr int ROW_CH = BN / 8;  // 16-B chunks per row
+#pragma unroll
+      for (int it = 0; it < BM * ROW_CH / 256; ++it) {
+        const int idx = it * 256 + tid;
+        const int row = idx / ROW_CH, ch = idx % ROW_CH;
+        const int64_t m = m0 + row, n = n0 + ch * 8;
+        if (m < p.M && n < p.N) {
+          const uint4 v = *(const uint4*)(smem + row * EPI_PITCH + ch * 16);
+          uint16_t* dst = (uint16_t*)Cb + m * p.ldc + n;
+          if (n + 8 <= p.N) {
+            *(uint4*)dst = v;
+          } else {
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+              if (n + e < p.N) dst[e] = (uint16_t)(w[e >> 1] >> (16 * (e & 1)));
+          }
+        }
+      }
+      return;
+    }
+  }
+  store_wave_tile<IS_BF16, OUT_F32, FM, FN>(acc, p, Cb, m0, n0, BM, BN, wm * WTM, wn * WTN, lane);
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N>
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool SMALLK>
 static int launch_ragged(bool is_bf16, bool out_f32, NtArgs p, int64_t batch) {
   p.tiles_m = (int)((p.M + BM - 1) / BM);
   p.tiles_n = (int)((p.N + BN - 1) / BN);
@@ -166,11 +251,11 @@ static int launch_ragged(bool is_bf16, bool out_f32, NtArgs p, int64_t batch) {
     q.C = (char*)p.C + b0 * p.sC * esz_out;
     const dim3 grid((unsigned)nwg, (unsigned)nb), block(256);
     if (is_bf16) {
-      if (out_f32) hipLaunchKernelGGL((gemm_nt_ragged_kernel<BM, BN, WAVES_M, WAVES_N, true, true>), grid, block, 0, stream(), q);
-      else hipLaunchKernelGGL((gemm_nt_ragged_kernel<BM, BN, WAVES_M, WAVES_N, true, false>), grid, block, 0, stream(), q);
+      if (out_f32) hipLaunchKernelGGL((gemm_nt_ragged_kernel<BM, BN, WAVES_M, WAVES_N, true, true, SMALLK>), grid, block, 0, stream(), q);
+      else hipLaunchKernelGGL((gemm_nt_ragged_kernel<BM, BN, WAVES_M, WAVES_N, true, false, SMALLK>), grid, block, 0, stream(), q);
     } else {
-      if (out_f32) hipLaunchKernelGGL((gemm_nt_ragged_kernel<BM, BN, WAVES_M, WAVES_N, false, true>), grid, block, 0, stream(), q);
-      else hipLaunchKernelGGL((gemm_nt_ragged_kernel<BM, BN, WAVES_M, WAVES_N, false, false>), grid, block, 0, stream(), q);
+      if (out_f32) hipLaunchKernelGGL((gemm_nt_ragged_kernel<BM, BN, WAVES_M, WAVES_N, false, true, SMALLK>), grid, block, 0, stream(), q);
+      else hipLaunchKernelGGL((gemm_nt_ragged_kernel<BM, BN, WAVES_M, WAVES_N, false, false, SMALLK>), grid, block, 0, stream(), q);
     }
     TNH_LAUNCH_CHECK();
   }
@@ -203,27 +288,39 @@ int gemm_bf16_ragged(int in_dt, int out_dt, int shape, int64_t M, int64_t N, int
   p.a_vw = row_vector_width(A, lda, sA, batch);
   p.b_vw = row_vector_width(B, ldb, sB, batch);
   p.c_vec = (ldc % 4 == 0) && ((uintptr_t)C % 16 == 0) && (batch == 1 || sC % 4 == 0);
+  // 2: rows are 16-B aligned at every n % 8 == 0 -> LDS-staged full-row stores (half output)
+  if (p.c_vec && ldc % 8 == 0 && (batch == 1 || sC % 8 == 0) && g_opt_raster != 2) p.c_vec = 2;
   const bool is_bf16 = (in_dt == TNH_BF16), out_f32 = (out_dt == TNH_F32);
+  const bool smallk = (K <= 192) && g_opt_smallk;
   if (shape == 0) {
-    // least padded work; ties go to the square tile
-    auto padded = [&](int64_t bm, int64_t bn) {
-      return (double)((M + bm - 1) / bm * bm) * (double)((N + bn - 1) / bn * bn);
-    };
-    const double sq = padded(128, 128), wide = padded(64, 256), tall = padded(256, 64);
-    shape = 1;
-    if (wide < sq && wide <= tall) shape = 2;
-    else if (tall < sq && tall < wide) shape = 3;
+    if (smallk) {
+      // streaming products: the square tile keeps the most blocks resident (measured:
+      // 144 x 3e6 x 144 0.64 ms vs 0.73 ms for 64x256); only a really short side switches
+      shape = (M <= 64 && N > 64) ? 2 : ((N <= 64 && M > 64) ? 3 : 1);
+    } else {
+      // least padded work; ties go to the square tile
+      auto padded = [&](int64_t bm, int64_t bn) {
+        return (double)((M + bm - 1) / bm * bm) * (double)((N + bn - 1) / bn * bn);
+      };
+      const double sq = padded(128, 128), wide = padded(64, 256), tall = padded(256, 64);
+      shape = 1;
+      if (wide < sq && wide <= tall) shape = 2;
+      else if (tall < sq && tall < wide) shape = 3;
+    }
   }
   if (shape == 2) {
-    *name = "bf16_nt_ragged_64x256x64";
-    return launch_ragged<64, 256, 1, 4>(is_bf16, out_f32, p, batch);
+    *name = smallk ? "bf16_nt_ragged_64x256x64_smallk" : "bf16_nt_ragged_64x256x64";
+    return smallk ? launch_ragged<64, 256, 1, 4, true>(is_bf16, out_f32, p, batch)
+                  : launch_ragged<64, 256, 1, 4, false>(is_bf16, out_f32, p, batch);
   }
   if (shape == 3) {
-    *name = "bf16_nt_ragged_256x64x64";
-    return launch_ragged<256, 64, 4, 1>(is_bf16, out_f32, p, batch);
+    *name = smallk ? "bf16_nt_ragged_256x64x64_smallk" : "bf16_nt_ragged_256x64x64";
+    return smallk ? launch_ragged<256, 64, 4, 1, true>(is_bf16, out_f32, p, batch)
+                  : launch_ragged<256, 64, 4, 1, false>(is_bf16, out_f32, p, batch);
   }
-  *name = "bf16_nt_ragged_128x128x64";
-  return launch_ragged<128, 128, 2, 2>(is_bf16, out_f32, p, batch);
+  *name = smallk ? "bf16_nt_ragged_128x128x64_smallk" : "bf16_nt_ragged_128x128x64";
+  return smallk ? launch_ragged<128, 128, 2, 2, true>(is_bf16, out_f32, p, batch)
+                : launch_ragged<128, 128, 2, 2, false>(is_bf16, out_f32, p, batch);
 }
 
 }  // namespace tnh

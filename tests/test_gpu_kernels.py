@@ -165,7 +165,8 @@ def test_gemm_bf16_speed_path(hip, variant, expect, dtype, m, n, k):
 
 @pytest.mark.parametrize("variant,expect", [("bf16_ragged", "bf16_nt_ragged_"), ("bf16_ragged_128x128", "bf16_nt_ragged_128x128x64"),
                                             ("bf16_ragged_64x256", "bf16_nt_ragged_64x256x64"),
-                                            ("bf16_ragged_256x64", "bf16_nt_ragged_256x64x64")])
+                                            ("bf16_ragged_256x64", "bf16_nt_ragged_256x64x64"),
+                                            ("bf16_ragged:p1", "bf16_nt_ragged_"), ("bf16_ragged:r2", "bf16_nt_ragged_")])
 @pytest.mark.parametrize("dtype", [ta.bfloat16, np.float16])
 def test_gemm_bf16_ragged_path(hip, variant, expect, dtype):
   """Register-staged matrix-core kernel: any M, N, K (K tail zero-filled, k-steps past K
@@ -173,7 +174,7 @@ def test_gemm_bf16_ragged_path(hip, variant, expect, dtype):
   when N % 4 != 0, all three tile shapes."""
   for (m, n, k) in [(1, 1, 1), (5, 7, 3), (33, 65, 17), (130, 70, 129), (144, 300, 144), (12, 1000, 12),
                     (257, 129, 40), (200, 136, 192), (64, 64, 64), (300, 20, 100), (1, 1, 1728), (144, 1728, 6),
-                    (20, 36, 7), (513, 258, 72)]:
+                    (20, 36, 7), (513, 258, 72), (70, 264, 33), (131, 520, 200)]:
     out, ref, kernel, sk = _gemm_case(hip, dtype, m, n, k, 0, 1, variant=variant, rng=np.random.default_rng(m + n + k))
     assert kernel.startswith(expect), kernel
     tol = GEMM_TOL[dtype]
@@ -187,7 +188,7 @@ def test_gemm_bf16_ragged_auto_dispatch_and_batch(hip):
   a = orc.round_bf16(rng.standard_normal((144, 144)))
   b = orc.round_bf16(rng.standard_normal((5000, 144)))
   out = hip.tensordot(hip.to_bfloat16(a), hip.to_bfloat16(b), [[1], [1]])
-  assert hip.lib.tnh_gemm_last_kernel().decode() == "bf16_nt_ragged_64x256x64"
+  assert hip.lib.tnh_gemm_last_kernel().decode() == "bf16_nt_ragged_128x128x64_smallk"
   np.testing.assert_allclose(np.asarray(out), a @ b.T, rtol=1.6e-2, atol=1.6e-2 * 12)
   # batched NT through the C ABI: batch 3, K = 10 (4-B loads), strides not multiples of 8
   import ctypes
@@ -200,6 +201,24 @@ def test_gemm_bf16_ragged_auto_dispatch_and_batch(hip):
                               ctypes.c_void_p(db.ptr), 10, ctypes.c_void_p(c.ptr), 21, 3, 370, 210, 37 * 21))
   assert hip.lib.tnh_gemm_last_kernel().decode().startswith("bf16_nt_ragged")
   np.testing.assert_allclose(np.asarray(c), np.einsum("bmk,bnk->bmn", A, B), rtol=1e-5, atol=1e-5)
+
+
+def test_gemm_bf16_ragged_padded_ldc(hip):
+  """C rows padded to ldc > N (N % 8 != 0, ldc % 8 == 0): LDS-staged epilogue with a partial last chunk;
+  the padding columns must stay untouched."""
+  import ctypes
+  from tensornetwork_amd.device_tensor import DeviceTensor
+  rng = np.random.default_rng(13)
+  m, n, k, ldc = 150, 21, 40, 24
+  A = orc.round_bf16(rng.standard_normal((m, k)))
+  B = orc.round_bf16(rng.standard_normal((n, k)))
+  c = hip.to_bfloat16(np.full((m, ldc), 7.0, dtype=np.float32))
+  _lib.check(hip.lib.tnh_gemm(_lib.BF16, _lib.BF16, 0, 1, m, n, k, ctypes.c_void_p(hip.to_bfloat16(A).ptr), k,
+                              ctypes.c_void_p(hip.to_bfloat16(B).ptr), k, ctypes.c_void_p(c.ptr), ldc, 1, 0, 0, 0))
+  assert hip.lib.tnh_gemm_last_kernel().decode().startswith("bf16_nt_ragged")
+  got = np.asarray(c)
+  np.testing.assert_allclose(got[:, :n], A @ B.T, rtol=1.6e-2, atol=1.6e-2 * 7)
+  np.testing.assert_array_equal(got[:, n:], 7.0)
 
 
 def test_gemm_bf16_fp32_output_is_tighter(hip):

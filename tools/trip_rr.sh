@@ -8,7 +8,7 @@ R=$PWD
 cd /tmp
 for D in ${RR_DS:-12 8}; do
   rm -rf $OUT/prof_stats_rr$D
-  rocprofv3 --kernel-trace --stats -d $OUT/prof_stats_rr$D -o rr -- python $R/tools/rr64_probe.py --D $D --min-slices 64 --max-slices 4 > $OUT/rr$D.log 2>&1
+  rocprofv3 --kernel-trace --stats -d $OUT/prof_stats_rr$D -o rr -- python $R/tools/rr64_probe.py --D $D --min-slices 64 --max-slices ${RR_SLICES:-16} > $OUT/rr$D.log 2>&1
   tail -1 $OUT/rr$D.log
 done
 cd $R
