@@ -131,6 +131,14 @@ int tnh_gemm(int in_dtype, int out_dtype, int transA, int transB, int64_t M,
              int64_t N, int64_t K, const void* A, int64_t lda, const void* B,
              int64_t ldb, void* C, int64_t ldc, int64_t batch, int64_t strideA,
              int64_t strideB, int64_t strideC);
+/* C = alpha * op(A) op(B) + beta * C with real scalars (beta == 0 never reads C).  The
+ * building block of the blocked Householder QR's trailing updates (LAPACK larfb);
+ * alpha != 1 or beta != 0 always runs the general strided kernels. */
+int tnh_gemm_ex(int in_dtype, int out_dtype, int transA, int transB, int64_t M,
+                int64_t N, int64_t K, const void* A, int64_t lda, const void* B,
+                int64_t ldb, void* C, int64_t ldc, int64_t batch, int64_t strideA,
+                int64_t strideB, int64_t strideC, double alpha, double beta);
+
 /* Name of the kernel variant the last tnh_gemm call dispatched to. */
 const char* tnh_gemm_last_kernel(void);
 /* Force a variant ("auto", "generic", "valu", "bf16_128", "bf16_256"): used by
@@ -218,6 +226,19 @@ int tnh_svd_vectors(int dtype, int64_t m, int64_t n, void* work, int64_t k,
                     void* U, void* Vh);
 int tnh_svd(int dtype, int64_t m, int64_t n, const void* A, void* U, void* S,
             void* Vh, int64_t k, void* work, int* sweeps_out);
+
+/* ---- K9: thin Householder QR --------------------------------------------------
+ * A (m x n, row-major, f32 / f64) = Q (m x k) R (k x n), k = min(m, n); blocked
+ * Householder (LAPACK geqrf + orgqr: same reflector sign convention, so R matches
+ * np.linalg.qr up to rounding).  A is not modified; `work` holds
+ * tnh_qr_work_bytes() bytes.
+ * Replaces AbstractBackend.qr / rq (abstract_backend.py:139-153; oracle
+ * backends/numpy/decompositions.py:77-124, np.linalg.qr in 'reduced' mode); the
+ * non_negative_diagonal phase fix and the rq transposes stay on the host side of
+ * the boundary, as in the reference. */
+int tnh_qr_work_bytes(int dtype, int64_t m, int64_t n, size_t* nbytes);
+int tnh_qr(int dtype, int64_t m, int64_t n, const void* A, void* Q, void* R,
+           void* work);
 
 #ifdef __cplusplus
 }

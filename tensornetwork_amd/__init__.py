@@ -17,7 +17,8 @@ from tensornetwork_amd.hip_backend import (HipBackend, get_hip_backend,
 from tensornetwork_amd.ncon import ncon, einsum
 from tensornetwork_amd.network import (Node, Edge, connect, contract, contract_between,
                                        contract_parallel, contract_trace_edges, outer_product,
-                                       split_node, split_node_full_svd, copy, slice_edge,
+                                       split_node, split_node_full_svd, split_node_qr, split_node_rq, copy,
+                                       slice_edge,
                                        get_all_edges, get_subgraph_dangling, get_shared_edges,
                                        reachable)
 from tensornetwork_amd import contractors, pathfinder

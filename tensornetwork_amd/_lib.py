@@ -66,6 +66,9 @@ SIGNATURES = {
     "tnh_gemm": (c_int, [c_int, c_int, c_int, c_int, c_int64, c_int64, c_int64,
                          c_void_p, c_int64, c_void_p, c_int64, c_void_p,
                          c_int64, c_int64, c_int64, c_int64, c_int64]),
+    "tnh_gemm_ex": (c_int, [c_int, c_int, c_int, c_int, c_int64, c_int64, c_int64,
+                            c_void_p, c_int64, c_void_p, c_int64, c_void_p,
+                            c_int64, c_int64, c_int64, c_int64, c_int64, c_double, c_double]),
     "tnh_gemm_last_kernel": (c_char_p, []),
     "tnh_gemm_set_variant": (c_int, [c_char_p]),
     "tnh_trace_last2": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64,
@@ -90,6 +93,8 @@ SIGNATURES = {
                                 c_void_p, c_void_p]),
     "tnh_svd": (c_int, [c_int, c_int64, c_int64, c_void_p, c_void_p, c_void_p,
                         c_void_p, c_int64, c_void_p, POINTER(c_int)]),
+    "tnh_qr_work_bytes": (c_int, [c_int, c_int64, c_int64, POINTER(c_size_t)]),
+    "tnh_qr": (c_int, [c_int, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
 }
 
 _lib = None

@@ -25,6 +25,7 @@ struct GemmArgs {
   int64_t rsA, csA, rsB, csB, ldc;
   int64_t sA, sB, sC;
   int out_dt;
+  double alpha, beta;  // C = alpha * A B + beta * C (real scalars; beta == 0 never reads C)
 };
 
 // provided by tnh_gemm_bf16.hip
@@ -36,6 +37,11 @@ int gemm_bf16_fast(int in_dt, int out_dt, int variant, int transA, int transB, i
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 
+__device__ __forceinline__ float load_out_f32(const void* C, int out_dt, int64_t idx) {
+  if (out_dt == TNH_F32) return ((const float*)C)[idx];
+  if (out_dt == TNH_BF16) return bf16_to_f32(((const uint16_t*)C)[idx]);
+  return f16_to_f32(((const uint16_t*)C)[idx]);
+}
 __device__ __forceinline__ void store_out_f32(void* C, int out_dt, int64_t idx, float v) {
   if (out_dt == TNH_F32) ((float*)C)[idx] = v;
   else if (out_dt == TNH_BF16) ((uint16_t*)C)[idx] = f32_to_bf16(v);
@@ -122,6 +128,7 @@ __global__ __launch_bounds__(256) void gemm_mfma_f32_kernel(GemmArgs g) {
   }
 
   // C/D layout of 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+  const float alpha = (float)g.alpha, beta = (float)g.beta;
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -130,7 +137,12 @@ __global__ __launch_bounds__(256) void gemm_mfma_f32_kernel(GemmArgs g) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int64_t m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (m < g.M && n < g.N) store_out_f32(g.C, g.out_dt, cbase + m * g.ldc + n, acc[i][j][r]);
+        if (m < g.M && n < g.N) {
+          const int64_t idx = cbase + m * g.ldc + n;
+          float v = alpha * acc[i][j][r];
+          if (beta != 0.f) v += beta * load_out_f32(g.C, g.out_dt, idx);
+          store_out_f32(g.C, g.out_dt, idx, v);
+        }
       }
     }
 }
@@ -215,7 +227,11 @@ __global__ __launch_bounds__(256) void gemm_mfma_f64_kernel(GemmArgs g) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int64_t m = m0 + wm * 32 + i * 16 + (lane >> 4) + 4 * r;
-        if (m < g.M && n < g.N) C[m * g.ldc + n] = acc[i][j][r];
+        if (m < g.M && n < g.N) {
+          double v = g.alpha * acc[i][j][r];
+          if (g.beta != 0.0) v += g.beta * C[m * g.ldc + n];
+          C[m * g.ldc + n] = v;
+        }
       }
     }
 }
@@ -229,6 +245,10 @@ __device__ __forceinline__ cf32 fma_t(cf32 a, cf32 b, cf32 c) {
 __device__ __forceinline__ cf64 fma_t(cf64 a, cf64 b, cf64 c) {
   return {fma(a.re, b.re, fma(-a.im, b.im, c.re)), fma(a.re, b.im, fma(a.im, b.re, c.im))};
 }
+
+__device__ __forceinline__ double scale_t(double a, double s) { return a * s; }
+__device__ __forceinline__ cf32 scale_t(cf32 a, double s) { return {a.re * (float)s, a.im * (float)s}; }
+__device__ __forceinline__ cf64 scale_t(cf64 a, double s) { return {a.re * s, a.im * s}; }
 
 template <int DT>
 __global__ __launch_bounds__(256) void gemm_valu_kernel(GemmArgs g) {
@@ -287,10 +307,15 @@ __global__ __launch_bounds__(256) void gemm_valu_kernel(GemmArgs g) {
       const int64_t m = m0 + ty + 16 * i, n = n0 + tx + 16 * j;
       if (m < g.M && n < g.N) {
         const int64_t idx = cbase + m * g.ldc + n;
-        if constexpr (DT == TNH_BF16 || DT == TNH_F16 || DT == TNH_F32)
-          store_out_f32(g.C, g.out_dt, idx, acc[i][j]);
-        else
-          Tr<DT>::st((S*)g.C, idx, acc[i][j]);
+        if constexpr (DT == TNH_BF16 || DT == TNH_F16 || DT == TNH_F32) {
+          float v = (float)g.alpha * acc[i][j];
+          if (g.beta != 0.0) v += (float)g.beta * load_out_f32(g.C, g.out_dt, idx);
+          store_out_f32(g.C, g.out_dt, idx, v);
+        } else {
+          C v = scale_t(acc[i][j], g.alpha);
+          if (g.beta != 0.0) v = v + scale_t(Tr<DT>::ld((const S*)g.C, idx), g.beta);
+          Tr<DT>::st((S*)g.C, idx, v);
+        }
       }
     }
 }
@@ -355,6 +380,14 @@ int tnh_gemm_set_variant(const char* full) {
 int tnh_gemm(int in_dtype, int out_dtype, int transA, int transB, int64_t M, int64_t N, int64_t K,
              const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
              int64_t batch, int64_t strideA, int64_t strideB, int64_t strideC) {
+  return tnh_gemm_ex(in_dtype, out_dtype, transA, transB, M, N, K, A, lda, B, ldb, C, ldc, batch, strideA,
+                     strideB, strideC, 1.0, 0.0);
+}
+
+int tnh_gemm_ex(int in_dtype, int out_dtype, int transA, int transB, int64_t M, int64_t N, int64_t K,
+                const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
+                int64_t batch, int64_t strideA, int64_t strideB, int64_t strideC, double alpha,
+                double beta) {
   TNH_NEED_INIT();
   TNH_REQUIRE(M >= 0 && N >= 0 && K >= 0 && batch >= 0, "negative GEMM extent");
   TNH_REQUIRE(in_dtype >= TNH_F32 && in_dtype <= TNH_C128, "bad GEMM dtype %d", in_dtype);
@@ -366,6 +399,10 @@ int tnh_gemm(int in_dtype, int out_dtype, int transA, int transB, int64_t M, int
   TNH_REQUIRE(C != nullptr, "null output");
   TNH_REQUIRE(ldc >= N, "ldc (%lld) < N (%lld)", (long long)ldc, (long long)N);
   const int esz_out = dtype_size(out_dtype);
+  if (K == 0 && beta != 0.0) {
+    set_error("tnh_gemm_ex: K == 0 with beta != 0 is not supported");
+    return TNH_ERR_UNSUPPORTED;
+  }
   if (K == 0) {
     // empty contraction: C = 0 (numpy.tensordot over a zero-length axis)
     for (int64_t b = 0; b < batch; ++b)
@@ -378,7 +415,8 @@ int tnh_gemm(int in_dtype, int out_dtype, int transA, int transB, int64_t M, int
   TNH_REQUIRE(lda >= (transA ? M : K), "lda too small");
   TNH_REQUIRE(ldb >= (transB ? K : N), "ldb too small");
 
-  if (half_in && (g_variant == 0 || g_variant >= 3)) {
+  const bool plain = (alpha == 1.0 && beta == 0.0);
+  if (half_in && plain && (g_variant == 0 || g_variant >= 3)) {
     const char* name = nullptr;
     int rc = gemm_bf16_fast(in_dtype, out_dtype, g_variant, transA, transB, M, N, K, A, lda, B, ldb, C,
                             ldc, batch, strideA, strideB, strideC, &name);
@@ -398,6 +436,8 @@ int tnh_gemm(int in_dtype, int out_dtype, int transA, int transB, int64_t M, int
   g.ldc = ldc;
   g.sA = strideA; g.sB = strideB; g.sC = strideC;
   g.out_dt = out_dtype;
+  g.alpha = alpha;
+  g.beta = beta;
 
   const bool use_valu = (g_variant == 2) || in_dtype == TNH_C64 || in_dtype == TNH_C128;
   const int esz_in = dtype_size(in_dtype);

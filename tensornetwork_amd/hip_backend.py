@@ -753,6 +753,139 @@ class HipBackend(BackendBase):
     vh = vh.view((keep,) + tuple(right_dims))
     return u, s, vh, s_rest
 
+  def _qr_matrix(self, mat):
+    """Thin Householder QR of a device matrix (f32 / f64) -> (q (m, k), r (k, n))."""
+    m, n = mat.shape
+    k = min(m, n)
+    nbytes = ctypes.c_size_t(0)
+    _lib.check(self.lib.tnh_qr_work_bytes(mat.code, m, n, ctypes.byref(nbytes)), "tnh_qr_work_bytes")
+    work = DeviceTensor.empty((max(nbytes.value, 8) // 8 + 1,), _lib.F64)
+    q = DeviceTensor.empty((m, k), mat.code)
+    r = DeviceTensor.empty((k, n), mat.code)
+    _lib.check(self.lib.tnh_qr(mat.code, m, n, _vp(mat), _vp(q), _vp(r), _vp(work)), "tnh_qr")
+    return q, r
+
+  def _qr_prepare(self, tensor, pivot_axis, what):
+    tensor = self._as_tensor(tensor)
+    self._check_float(tensor, what)
+    if tensor.is_complex:
+      raise NotImplementedError(f"complex {what} is not implemented on the hip backend yet")
+    left_dims = tensor.shape[:pivot_axis]
+    right_dims = tensor.shape[pivot_axis:]
+    work_code = tensor.code if tensor.code in (_lib.F32, _lib.F64) else _lib.F32
+    mat = self.cast(tensor, work_code).view((_prod(left_dims), _prod(right_dims)))
+    return tensor.code, mat, left_dims, right_dims
+
+  def _phase_fix(self, q, r):
+    # decompositions.py:92-95: phases = sign(diag(r)); q = q * phases; r = phases[:, None] * r
+    phases = self.sign(self.diagonal(r))
+    q = self._binary(_lib.OP_MUL, q, phases)
+    r = self._binary(_lib.OP_MUL, self.reshape(phases, (phases.shape[0], 1)), r)
+    return q, r
+
+  def qr(self, tensor, pivot_axis=-1, non_negative_diagonal=False):
+    """QR decomposition (abstract_backend.py:139-145; rule of decompositions.py:77-99):
+    reshape to (prod(left), prod(right)) at pivot_axis, thin Householder QR on the GPU
+    (tnh_qr: LAPACK's reflector convention, so R has np.linalg.qr's signs), optional
+    non-negative-diagonal phase fix, reshape back."""
+    orig, mat, left_dims, right_dims = self._qr_prepare(tensor, pivot_axis, "qr")
+    q, r = self._qr_matrix(mat)
+    if non_negative_diagonal:
+      q, r = self._phase_fix(q, r)
+    if orig != mat.code:
+      q, r = self.cast(q, orig), self.cast(r, orig)
+    center = q.shape[1]
+    return q.view(tuple(left_dims) + (center,)), r.view((center,) + tuple(right_dims))
+
+  def rq(self, tensor, pivot_axis=-1, non_negative_diagonal=False):
+    """RQ decomposition (abstract_backend.py:147-153; decompositions.py:102-124): QR of
+    the transposed matrix, phases fixed on that factorisation, then both factors
+    transposed back -- M = r q with q's rows orthonormal."""
+    orig, mat, left_dims, right_dims = self._qr_prepare(tensor, pivot_axis, "rq")
+    q, r = self._qr_matrix(self.transpose(mat, (1, 0)))
+    if non_negative_diagonal:
+      q, r = self._phase_fix(q, r)
+    r, q = self.transpose(r, (1, 0)), self.transpose(q, (1, 0))
+    if orig != mat.code:
+      q, r = self.cast(q, orig), self.cast(r, orig)
+    center = r.shape[1]
+    return r.view(tuple(left_dims) + (center,)), q.view((center,) + tuple(right_dims))
+
+  def eigh(self, matrix):
+    """Eigen-decomposition of a real symmetric matrix (abstract_backend.py:320-330; oracle
+    np.linalg.eigh): ascending eigenvalues w and eigenvectors as columns of v.
+
+    Runs on the Jacobi SVD kernels: B = A + sigma I with sigma = ||A||_F >= rho(A) is positive
+    semi-definite, so its right singular vectors are eigenvectors of A and its singular
+    values are lambda + sigma (no +/-lambda mixing, which a plain SVD of an indefinite A
+    would suffer).  The eigenvalues are then re-evaluated as Rayleigh quotients
+    v_i^T A v_i (one GEMM), which removes the O(sigma eps) shift error to second order."""
+    matrix = self._as_tensor(matrix)
+    self._check_float(matrix, "eigh")
+    if matrix.is_complex:
+      raise NotImplementedError("complex (Hermitian) eigh is not implemented on the hip backend yet")
+    if matrix.ndim != 2 or matrix.shape[0] != matrix.shape[1]:
+      raise ValueError("Last 2 dimensions of the array must be square")
+    n = matrix.shape[0]
+    orig = matrix.code
+    work_code = orig if orig in (_lib.F32, _lib.F64) else _lib.F32
+    a = self.cast(matrix, work_code)
+    if n == 0:
+      return DeviceTensor.empty((0,), orig), DeviceTensor.empty((0, 0), orig)
+    # symmetrise from the lower triangle semantics of LAPACK 'L': use (A + A^T) / 2, identical
+    # for symmetric input
+    a = self._binary(_lib.OP_MUL, self._binary(_lib.OP_ADD, a, self.transpose(a, (1, 0))), 0.5)
+    sigma = float(self.norm(a).item())
+    b = self._binary(_lib.OP_ADD, a, self._binary(_lib.OP_MUL, self.eye(n, dtype=public_dtype(work_code)), sigma))
+    _, _, vh, _ = self.svd(b, pivot_axis=1)
+    v = self.transpose(self.getitem(vh, (slice(None, None, -1), slice(None))), (1, 0))   # ascending order
+    av = self.tensordot(a, v, 1)
+    w = self.sum(self._binary(_lib.OP_MUL, v, av), axis=(0,))
+    if orig != work_code:
+      w, v = self.cast(w, orig), self.cast(v, orig)
+    return w, v
+
+  def inv(self, matrix):
+    """Matrix inverse (numpy_backend.py:554-558) through the Jacobi SVD:
+    A^-1 = V diag(1/s) U^T."""
+    matrix = self._as_tensor(matrix)
+    if len(matrix.shape) > 2:
+      raise ValueError("input to hip backend method `inv` has shape {}."
+                       " Only matrices are supported.".format(matrix.shape))
+    if matrix.ndim != 2 or matrix.shape[0] != matrix.shape[1]:
+      raise ValueError("Last 2 dimensions of the array must be square")
+    u, s, vh, _ = self.svd(matrix, pivot_axis=1)
+    return self.tensordot(vh, self._binary(_lib.OP_DIV, u, s), [[0], [1]])
+
+  def expm(self, matrix):
+    """Matrix exponential (numpy_backend.py:589-599) as GEMMs only: scaling and squaring
+    around a Taylor polynomial in Horner form, ||A / 2^s||_F <= 1/2, degree 18 (f64) /
+    10 (f32) -- remainder below the dtype's epsilon."""
+    matrix = self._as_tensor(matrix)
+    if len(matrix.shape) != 2:
+      raise ValueError("input to hip backend method `expm` has shape {}."
+                       " Only matrices are supported.".format(matrix.shape))
+    if matrix.shape[0] != matrix.shape[1]:
+      raise ValueError("input to hip backend method `expm` only supports"
+                       " N*N matrix, {x}*{y} matrix is given".format(
+                           x=matrix.shape[0], y=matrix.shape[1]))
+    self._check_float(matrix, "expm")
+    n = matrix.shape[0]
+    orig = matrix.code
+    work_code = orig if orig not in _HALF else _lib.F32
+    a = self.cast(matrix, work_code)
+    nrm = float(np.real(self.norm(a).item()))
+    squarings = 0 if not np.isfinite(nrm) or nrm <= 0.5 else int(np.ceil(np.log2(nrm))) + 1
+    x = self._binary(_lib.OP_MUL, a, 2.0 ** -squarings)
+    degree = 18 if work_code in (_lib.F64, _lib.C128) else 10
+    eye = self.eye(n, dtype=public_dtype(work_code))
+    p = self._binary(_lib.OP_ADD, eye, self._binary(_lib.OP_MUL, x, 1.0 / degree))
+    for j in range(degree - 1, 0, -1):
+      p = self._binary(_lib.OP_ADD, eye, self._binary(_lib.OP_MUL, self.tensordot(x, p, 1), 1.0 / j))
+    for _ in range(squarings):
+      p = self.tensordot(p, p, 1)
+    return self.cast(p, orig) if orig != work_code else p
+
   # ------------------------------------------------------------------- misc
   def jit(self, fun, *args, **kwargs):  # pylint: disable=unused-argument
     return fun

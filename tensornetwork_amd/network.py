@@ -395,6 +395,37 @@ def split_node_full_svd(node: Node, left_edges: List[Edge], right_edges: List[Ed
   return left, mid, right, trun_vals
 
 
+def _split_two(node, left_edges, right_edges, factor, left_name, right_name, edge_name):
+  be = node.backend
+  left_sources = [(node, node.edges.index(e)) for e in left_edges]
+  right_sources = [(node, node.edges.index(e)) for e in right_edges]
+  t = _split_bookkeeping(node, left_edges, right_edges)
+  lt, rt = factor(be, t, len(left_edges))
+  left = Node(lt, name=left_name, backend=be)
+  right = Node(rt, name=right_name, backend=be)
+  _adopt_edges(left, left_sources + [(left, len(left_edges))])
+  _adopt_edges(right, [(right, 0)] + right_sources)
+  connect(left.edges[-1], right.edges[0], name=edge_name)
+  node.edges = []
+  return left, right
+
+
+def split_node_qr(node: Node, left_edges: List[Edge], right_edges: List[Edge],
+                  left_name: Optional[str] = None, right_name: Optional[str] = None,
+                  edge_name: Optional[str] = None) -> Tuple[Node, Node]:
+  """node = Q -- R with Q orthonormal on the left edges (network_operations.py:258-349)."""
+  return _split_two(node, left_edges, right_edges, lambda be, t, p: be.qr(t, p), left_name, right_name,
+                    edge_name)
+
+
+def split_node_rq(node: Node, left_edges: List[Edge], right_edges: List[Edge],
+                  left_name: Optional[str] = None, right_name: Optional[str] = None,
+                  edge_name: Optional[str] = None) -> Tuple[Node, Node]:
+  """node = R -- Q with Q orthonormal on the right edges (network_operations.py:352-443)."""
+  return _split_two(node, left_edges, right_edges, lambda be, t, p: be.rq(t, p), left_name, right_name,
+                    edge_name)
+
+
 # ------------------------------------------------------------------ copy / slice
 def copy(nodes: Iterable[Node], conjugate: bool = False) -> Tuple[Dict[Node, Node], Dict[Edge, Edge]]:
   """Structure-preserving copy of a sub-network (network_operations.py:32-83).

@@ -135,3 +135,73 @@ def run_misc(be, g, case):
       "mul": be.multiply(x, v),
       "slice": be.slice(x, (1, 0, 2), (2, 3, 2)),
   }
+
+
+# ----------------------------------------------------------- QR / dense linalg
+def check_qr_case(be, g, case, tight=True):
+  """qr and rq of one fixture through backend `be`.  R is compared with the reference
+  element-wise (Householder QR is unique up to the reflector sign convention, which the
+  HIP kernel shares with LAPACK); Q through orthonormality and reconstruction, plus
+  element-wise where the matrix has full column rank."""
+  x = g[case["x"]]
+  scale = float(np.max(np.abs(x))) + 1e-30
+  q, r = be.qr(be.convert_to_tensor(x), case["pivot"], case["nnd"])
+  q, r = to_host(q), to_host(r)
+  assert q.shape == g[case["q"]].shape and r.shape == g[case["r"]].shape
+  k = q.shape[-1]
+  qm, rm = q.reshape(-1, k), r.reshape(k, -1)
+  t = tol(x.dtype, scale)
+  np.testing.assert_allclose(qm @ rm, x.reshape(qm.shape[0], rm.shape[1]), rtol=0, atol=10 * t["atol"])
+  np.testing.assert_allclose(qm.T @ qm, np.eye(k), rtol=0, atol=10 * tol(x.dtype)["atol"])
+  assert np.allclose(rm, np.triu(rm))
+  if tight:
+    assert_close(r, g[case["r"]], scale=scale * np.sqrt(qm.shape[0]))
+    assert_close(q, g[case["q"]], scale=10.0)
+  rr, qq = be.rq(be.convert_to_tensor(x), case["pivot"], case["nnd"])
+  rr, qq = to_host(rr), to_host(qq)
+  assert rr.shape == g[case["rq_r"]].shape and qq.shape == g[case["rq_q"]].shape
+  k = rr.shape[-1]
+  rm, qm = rr.reshape(-1, k), qq.reshape(k, -1)
+  np.testing.assert_allclose(rm @ qm, x.reshape(rm.shape[0], qm.shape[1]), rtol=0, atol=10 * t["atol"])
+  np.testing.assert_allclose(qm @ qm.T, np.eye(k), rtol=0, atol=10 * tol(x.dtype)["atol"])
+  if tight:
+    assert_close(rr, g[case["rq_r"]], scale=scale * np.sqrt(qm.shape[1]))
+    assert_close(qq, g[case["rq_q"]], scale=10.0)
+
+
+def check_split_qr_case(be, g, case):
+  x = g[case["x"]]
+  a = network.Node(be.convert_to_tensor(x), backend=be)
+  q, r = network.split_node_qr(a, [a[i] for i in case["left"]], [a[i] for i in case["right"]])
+  assert_close(q.tensor, g[case["q"]], scale=10.0)
+  assert_close(r.tensor, g[case["r"]], scale=float(np.max(np.abs(x))) * 10)
+  assert q.edges[-1] is r.edges[0]
+  b = network.Node(be.convert_to_tensor(x), backend=be)
+  r2, q2 = network.split_node_rq(b, [b[i] for i in case["left"]], [b[i] for i in case["right"]])
+  assert_close(r2.tensor, g[case["rq_r"]], scale=float(np.max(np.abs(x))) * 10)
+  assert_close(q2.tensor, g[case["rq_q"]], scale=10.0)
+  # the split network contracts back to the original tensor
+  back = network.contract_between(r2, q2)
+  assert_close(back.tensor, np.transpose(x, case["left"] + case["right"]), scale=float(np.max(np.abs(x))) * 10)
+
+
+def check_linalg_case(be, g, case):
+  if "h" in case:
+    h = g[case["h"]]
+    n = h.shape[0]
+    w, v = be.eigh(be.convert_to_tensor(h))
+    w, v = to_host(w), to_host(v)
+    scale = float(np.max(np.abs(h))) * max(n, 1) ** 0.5 + 1e-30
+    assert_close(w, g[case["w"]], scale=scale)
+    t = tol(h.dtype, scale)
+    np.testing.assert_allclose(h @ v, v * w, rtol=0, atol=30 * t["atol"])
+    np.testing.assert_allclose(v.T @ v, np.eye(n), rtol=0, atol=30 * tol(h.dtype)["atol"])
+  if "inv" in case:
+    a = g[case["a"]]
+    got = to_host(be.inv(be.convert_to_tensor(a)))
+    assert_close(got, g[case["inv"]], scale=float(np.max(np.abs(g[case["inv"]]))) * 10)
+  if "expm" in case:
+    e = g[case["e"]]
+    got = to_host(be.expm(be.convert_to_tensor(e)))
+    ref = g[case["expm"]]
+    assert_close(got, ref, scale=float(np.max(np.abs(ref))) * 100)

@@ -34,6 +34,20 @@ def golden():
   return Golden()
 
 
+class GoldenLinalg(Golden):
+  """tests/golden/golden_linalg.npz + cases_linalg.json (made by make_golden_linalg.py)."""
+
+  def __init__(self):  # pylint: disable=super-init-not-called
+    self.arrays = np.load(os.path.join(HERE, "golden", "golden_linalg.npz"))
+    with open(os.path.join(HERE, "golden", "cases_linalg.json")) as f:
+      self.cases = json.load(f)
+
+
+@pytest.fixture(scope="session")
+def golden_linalg():
+  return GoldenLinalg()
+
+
 @pytest.fixture(scope="session")
 def hip():
   """The hip backend bound to cuda:0 -- fails loudly if libtnhip or the GPU is missing."""
