@@ -174,6 +174,20 @@ typedef enum {
   TNH_OP_POW = 4
 } tnh_binary_op;
 
+typedef enum {
+  TNH_CMP_LT = 0, TNH_CMP_LE = 1, TNH_CMP_GT = 2, TNH_CMP_GE = 3,
+  TNH_CMP_EQ = 4, TNH_CMP_NE = 5
+} tnh_compare_op;
+
+/* mask_i (int32 0/1) = a_i (op) b_i, or a_i (op) scalar when b == NULL (real dtypes).
+ * With tnh_masked_fill: dst_i = mask_i ? (re, im) : src_i -- together the device
+ * form of AbstractBackend.index_update with a scalar assignee (abstract_backend.py:685-696;
+ * oracle numpy_backend.py:548-552: t = copy(tensor); t[mask] = assignee). */
+int tnh_compare(int op, void* dst, const void* a, const void* b, double scalar,
+                int64_t n, int dtype);
+int tnh_masked_fill(void* dst, const void* src, const void* mask, double re,
+                    double im, int64_t n, int dtype);
+
 /* dst_i = op(src_i); ABS/REAL/IMAG of a complex dtype write the real dtype. */
 int tnh_unary(int op, void* dst, const void* src, int64_t n, int dtype);
 

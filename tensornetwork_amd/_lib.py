@@ -82,6 +82,8 @@ SIGNATURES = {
     "tnh_binary_scalar": (c_int, [c_int, c_void_p, c_void_p, c_double,
                                   c_double, c_int, c_int64, c_int]),
     "tnh_fill": (c_int, [c_void_p, c_double, c_double, c_int64, c_int]),
+    "tnh_compare": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_double, c_int64, c_int]),
+    "tnh_masked_fill": (c_int, [c_void_p, c_void_p, c_void_p, c_double, c_double, c_int64, c_int]),
     "tnh_random": (c_int, [c_void_p, c_int64, c_int, ctypes.c_uint64, c_int, c_double, c_double]),
     "tnh_eye": (c_int, [c_void_p, c_int64, c_int64, c_int]),
     "tnh_cast": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int64]),

@@ -223,6 +223,44 @@ __global__ __launch_bounds__(256) void binary_scalar_kernel(int op, typename Tr<
   }
 }
 
+// Comparisons (real dtypes) -> int32 0/1 mask, and the select that consumes it: the two
+// halves of `tensor[tensor <= eps] = value` (AbstractBackend.index_update with a scalar
+// assignee, numpy_backend.py:548-552; caller infinite_mps.py:237-241).
+template <int DT>
+__global__ __launch_bounds__(256) void compare_kernel(int op, int32_t* __restrict__ dst,
+                                                      const typename Tr<DT>::S* __restrict__ a,
+                                                      const typename Tr<DT>::S* __restrict__ b, double scalar,
+                                                      int64_t n) {
+  using C = typename Tr<DT>::C;
+  const int64_t step = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += step) {
+    const C x = Tr<DT>::ld(a, i);
+    const C y = b ? Tr<DT>::ld(b, i) : (C)scalar;
+    bool r;
+    switch (op) {
+      case TNH_CMP_LT: r = x < y; break;
+      case TNH_CMP_LE: r = x <= y; break;
+      case TNH_CMP_GT: r = x > y; break;
+      case TNH_CMP_GE: r = x >= y; break;
+      case TNH_CMP_EQ: r = x == y; break;
+      default: r = x != y; break;
+    }
+    dst[i] = r ? 1 : 0;
+  }
+}
+
+template <int DT>
+__global__ __launch_bounds__(256) void masked_fill_kernel(typename Tr<DT>::S* __restrict__ dst,
+                                                          const typename Tr<DT>::S* __restrict__ src,
+                                                          const int32_t* __restrict__ mask, double re, double im,
+                                                          int64_t n) {
+  using C = typename Tr<DT>::C;
+  const C s = from_scalar(C{}, re, im);
+  const int64_t step = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += step)
+    Tr<DT>::st(dst, i, mask[i] ? s : Tr<DT>::ld(src, i));
+}
+
 template <int DT>
 __global__ __launch_bounds__(256) void fill_kernel(typename Tr<DT>::S* __restrict__ dst, double re,
                                                    double im, int64_t n) {
@@ -441,6 +479,38 @@ int tnh_binary_scalar(int op, void* dst, const void* src, double re, double im, 
   TNH_DISPATCH_FLOAT(dtype, hipLaunchKernelGGL((binary_scalar_kernel<DT>), dim3(g), dim3(256), 0, stream(),
                                                op, (typename Tr<DT>::S*)dst,
                                                (const typename Tr<DT>::S*)src, re, im, scalar_left, n));
+  TNH_LAUNCH_CHECK();
+  return TNH_OK;
+}
+
+int tnh_compare(int op, void* dst, const void* a, const void* b, double scalar, int64_t n, int dtype) {
+  TNH_NEED_INIT();
+  TNH_REQUIRE(op >= TNH_CMP_LT && op <= TNH_CMP_NE, "bad comparison op %d", op);
+  TNH_REQUIRE(dtype == TNH_F32 || dtype == TNH_F64 || dtype == TNH_BF16 || dtype == TNH_F16,
+              "comparisons need a real floating dtype (got %d)", dtype);
+  TNH_REQUIRE(n >= 0, "negative size");
+  if (n == 0) return TNH_OK;
+  TNH_REQUIRE(dst && a, "null pointer");
+  const unsigned g = grid_for(n);
+  switch (dtype) {
+    case TNH_F32: hipLaunchKernelGGL((compare_kernel<TNH_F32>), dim3(g), dim3(256), 0, stream(), op, (int32_t*)dst, (const float*)a, (const float*)b, scalar, n); break;
+    case TNH_F64: hipLaunchKernelGGL((compare_kernel<TNH_F64>), dim3(g), dim3(256), 0, stream(), op, (int32_t*)dst, (const double*)a, (const double*)b, scalar, n); break;
+    case TNH_BF16: hipLaunchKernelGGL((compare_kernel<TNH_BF16>), dim3(g), dim3(256), 0, stream(), op, (int32_t*)dst, (const uint16_t*)a, (const uint16_t*)b, scalar, n); break;
+    default: hipLaunchKernelGGL((compare_kernel<TNH_F16>), dim3(g), dim3(256), 0, stream(), op, (int32_t*)dst, (const uint16_t*)a, (const uint16_t*)b, scalar, n); break;
+  }
+  TNH_LAUNCH_CHECK();
+  return TNH_OK;
+}
+
+int tnh_masked_fill(void* dst, const void* src, const void* mask, double re, double im, int64_t n, int dtype) {
+  TNH_NEED_INIT();
+  TNH_REQUIRE(n >= 0, "negative size");
+  if (n == 0) return TNH_OK;
+  TNH_REQUIRE(dst && src && mask, "null pointer");
+  const unsigned g = grid_for(n);
+  TNH_DISPATCH_FLOAT(dtype, hipLaunchKernelGGL((masked_fill_kernel<DT>), dim3(g), dim3(256), 0, stream(),
+                                               (typename Tr<DT>::S*)dst, (const typename Tr<DT>::S*)src,
+                                               (const int32_t*)mask, re, im, n));
   TNH_LAUNCH_CHECK();
   return TNH_OK;
 }

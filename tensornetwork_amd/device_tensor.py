@@ -264,6 +264,20 @@ class DeviceTensor:
   def __matmul__(self, other):
     return self._backend().matmul(self, other)
 
+  # comparisons give an int32 0/1 mask in HBM (consumed by backend.index_update); identity-based
+  # hashing is kept so that tensors remain usable as dict keys
+  def __lt__(self, other):
+    return self._backend().compare("<", self, other)
+
+  def __le__(self, other):
+    return self._backend().compare("<=", self, other)
+
+  def __gt__(self, other):
+    return self._backend().compare(">", self, other)
+
+  def __ge__(self, other):
+    return self._backend().compare(">=", self, other)
+
   def conj(self):
     return self._backend().conj(self)
 

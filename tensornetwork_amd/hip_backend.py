@@ -886,6 +886,113 @@ class HipBackend(BackendBase):
       p = self.tensordot(p, p, 1)
     return self.cast(p, orig) if orig != work_code else p
 
+  # ------------------------------------------------------------- masks / select
+  def is_tensor(self, x):
+    return isinstance(x, DeviceTensor)
+
+  def compare(self, op, tensor, other):
+    """int32 0/1 mask of ``tensor <op> other`` (op in '<', '<=', '>', '>=', '==', '!='); `other`
+    is a real scalar or a tensor of the same shape.  Backs DeviceTensor's comparison operators."""
+    ops = {"<": 0, "<=": 1, ">": 2, ">=": 3, "==": 4, "!=": 5}
+    tensor = self._as_tensor(tensor)
+    if tensor.code not in (_lib.F32, _lib.F64, _lib.BF16, _lib.F16):
+      raise NotImplementedError(f"comparison is not implemented for dtype {tensor.dtype} on the hip backend")
+    out = DeviceTensor.empty(tensor.shape, _lib.I32)
+    if self._is_scalar(other):
+      _lib.check(self.lib.tnh_compare(ops[op], _vp(out), _vp(tensor), None, float(other), tensor.size,
+                                      tensor.code), "tnh_compare")
+      return out
+    other = self.cast(self._as_tensor(other), tensor.code)
+    if other.shape != tensor.shape:
+      other = self._broadcast_to(other, tensor.shape)
+    _lib.check(self.lib.tnh_compare(ops[op], _vp(out), _vp(tensor), _vp(other), 0.0, tensor.size,
+                                    tensor.code), "tnh_compare")
+    return out
+
+  def index_update(self, tensor, mask, assignee):
+    """``t = copy(tensor); t[mask] = assignee`` (abstract_backend.py:685-696; numpy_backend.py:548-552)
+    for a mask produced by a tensor comparison (or any array of the tensor's shape) and a scalar
+    assignee -- the form the reference's callers use (infinite_mps.py:237-241)."""
+    tensor = self._as_tensor(tensor)
+    self._check_float(tensor, "index_update")
+    if isinstance(assignee, DeviceTensor) and assignee.size == 1:
+      assignee = assignee.item()
+    elif isinstance(assignee, np.ndarray) and assignee.size == 1:
+      assignee = assignee.reshape(()).item()
+    if not self._is_scalar(assignee):
+      raise NotImplementedError("index_update on the hip backend takes a scalar assignee")
+    if not isinstance(mask, DeviceTensor):
+      mask = DeviceTensor.from_numpy(np.ascontiguousarray(np.asarray(mask) != 0, dtype=np.int32))
+    elif mask.code != _lib.I32:
+      mask = self.compare("!=", mask, 0.0)
+    if mask.shape != tensor.shape:
+      raise ValueError(f"mask shape {mask.shape} does not match tensor shape {tensor.shape}")
+    value = complex(assignee)
+    if value.imag != 0.0 and not tensor.is_complex:
+      raise TypeError("cannot assign a complex value into a real tensor")
+    out = DeviceTensor.empty(tensor.shape, tensor.code)
+    _lib.check(self.lib.tnh_masked_fill(_vp(out), _vp(tensor), _vp(mask), value.real, value.imag, tensor.size,
+                                        tensor.code), "tnh_masked_fill")
+    return out
+
+  # ------------------------------------------------------------------ Krylov
+  def eigsh_lanczos(self, A, args=None, initial_state=None, shape=None, dtype=None, num_krylov_vecs=20,
+                    numeig=1, tol=1E-8, delta=1E-8, ndiag=20, reorthogonalize=False):
+    """Lanczos on device vectors (abstract_backend.py:428-476; algorithm of
+    numpy_backend.py:415-534) -- see tensornetwork_amd/krylov.py."""
+    from tensornetwork_amd import krylov  # pylint: disable=import-outside-toplevel
+    if initial_state is not None and not isinstance(initial_state, DeviceTensor):
+      raise TypeError("Expected a `DeviceTensor`. Got {}".format(type(initial_state)))
+    return krylov.eigsh_lanczos(self, A, args, initial_state, shape, dtype, num_krylov_vecs, numeig, tol,
+                                delta, ndiag, reorthogonalize)
+
+  def eigsh(self, A, args=None, initial_state=None, shape=None, dtype=None, num_krylov_vecs=50, numeig=6,
+            tol=1E-8, which='LA', maxiter=None):
+    """Thick-restart Lanczos on device vectors (abstract_backend.py:380-426; the reference wraps
+    scipy.sparse.linalg.eigsh, numpy_backend.py:168-214)."""
+    from tensornetwork_amd import krylov  # pylint: disable=import-outside-toplevel
+    if initial_state is not None and not isinstance(initial_state, DeviceTensor):
+      raise TypeError("Expected a `DeviceTensor`. Got {}".format(type(initial_state)))
+    if (initial_state is not None and initial_state.is_complex) or \
+        (initial_state is None and dtype is not None and dtype is not bfloat16 and np.dtype(dtype).kind == "c"):
+      raise NotImplementedError("complex eigsh is not implemented on the hip backend yet")
+    return krylov.eigsh(self, A, args, initial_state, shape, dtype, num_krylov_vecs, numeig, tol, which, maxiter)
+
+  def gmres(self, A_mv, b, A_args=None, A_kwargs=None, x0=None, tol=1E-05, atol=None,
+            num_krylov_vectors=20, maxiter=1, M=None):
+    """GMRES on device vectors; argument checks of abstract_backend.py:560-616, solver in
+    tensornetwork_amd/krylov.py (the reference wraps scipy.sparse.linalg.gmres)."""
+    from tensornetwork_amd import krylov  # pylint: disable=import-outside-toplevel
+    b = self._as_tensor(b)
+    bshape = self.shape_tensor(b)
+    N = int(self.shape_prod(bshape)) if bshape else 1
+    dtype = b.dtype
+    if x0 is None:
+      x0 = self.zeros((N,), dtype)
+    else:
+      x0 = self._as_tensor(x0)
+      x0shape = self.shape_tensor(x0)
+      if x0shape != bshape:
+        raise ValueError(f"If x0 is supplied, its shape, {x0shape}, must match b's, {bshape}.")
+      if x0.dtype != dtype:
+        raise TypeError(f"If x0 is supplied, its dtype, {x0.dtype}, must match b's, {dtype}.")
+      x0 = self.reshape(x0, (N,))
+    if num_krylov_vectors > N:
+      num_krylov_vectors = N
+    if tol < 0:
+      raise ValueError(f"tol = {tol} must be positive.")
+    if atol is None:
+      atol = tol
+    elif atol < 0:
+      raise ValueError(f"atol = {atol} must be positive.")
+    if num_krylov_vectors <= 0:
+      raise ValueError(f"num_krylov_vectors must be positive, not{num_krylov_vectors}.")
+    if A_args is None:
+      A_args = []
+    if A_kwargs is None:
+      A_kwargs = {}
+    return krylov.gmres(self, A_mv, b, A_args, A_kwargs, x0, tol, atol, num_krylov_vectors, maxiter, M=M)
+
   # ------------------------------------------------------------------- misc
   def jit(self, fun, *args, **kwargs):  # pylint: disable=unused-argument
     return fun

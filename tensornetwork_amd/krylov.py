@@ -1,0 +1,277 @@
+"""Krylov solvers on backend tensors: ``eigsh_lanczos``, ``eigsh``, ``gmres``.
+
+The reference's NumPy backend implements Lanczos by hand
+(``backends/numpy/numpy_backend.py:415-534``) and wraps SciPy/ARPACK for ``eigsh``
+(168-214) and ``gmres`` (300-412).  Here every vector stays a backend tensor (in HBM
+for ``HipBackend``): the operator ``A`` is the caller's contraction, inner products,
+norms and axpys are backend ops, and only the Krylov coefficients -- a handful of
+scalars per iteration -- come back to the host.  The small projected matrices
+(``num_krylov_vecs`` x ``num_krylov_vecs``) are diagonalised with ``backend.eigh``.
+
+All functions take the backend object first; ``HipBackend`` binds them as methods, and
+the CPU test-suite runs the same code on the oracle backend.
+"""
+import numpy as np
+
+
+def _flat(be, x):
+  return be.reshape(x, (-1,))
+
+
+def _vdot(be, a, b):
+  """<a, b> with a conjugated, as a host scalar (one 1 x 1 GEMM + read-back)."""
+  return be.item(be.tensordot(be.conj(_flat(be, a)), _flat(be, b), 1))
+
+
+def _norm(be, x):
+  return float(np.real(be.item(be.norm(x))))
+
+
+def _axpy(be, y, alpha, x):
+  """y + alpha * x."""
+  return be.addition(y, be.multiply(x, alpha))
+
+
+def _tridiag(diag, off):
+  k = len(diag)
+  t = np.zeros((k, k), dtype=np.result_type(np.float64, *[np.asarray(d).dtype for d in diag]))
+  for i, d in enumerate(diag):
+    t[i, i] = d
+  for i, o in enumerate(off[:k - 1]):
+    t[i, i + 1] = o
+    t[i + 1, i] = np.conj(o)
+  return t
+
+
+def _small_eigh(be, matrix):
+  """Eigen-decomposition of a small host matrix of Krylov coefficients THROUGH the backend
+  (device Jacobi kernels for HipBackend); returns host arrays."""
+  w, u = be.eigh(be.convert_to_tensor(np.ascontiguousarray(np.real(matrix), dtype=np.float64)))
+  return np.asarray(w, dtype=np.float64), np.asarray(u, dtype=np.float64)
+
+
+def eigsh_lanczos(be, A, args=None, initial_state=None, shape=None, dtype=None, num_krylov_vecs=20,
+                  numeig=1, tol=1e-8, delta=1e-8, ndiag=20, reorthogonalize=False):
+  """Lowest eigenpairs of a Hermitian operator by the Lanczos iteration.
+
+  Same algorithm, arguments, stopping rules and error behaviour as
+  ``numpy_backend.py:415-534``: iterate until ``num_krylov_vecs`` vectors, until a Krylov
+  vector's norm drops below ``delta``, or until the ``numeig`` lowest Ritz values move by
+  less than ``tol`` between two diagonalisations (every ``ndiag`` iterations)."""
+  if args is None:
+    args = []
+  if num_krylov_vecs < numeig:
+    raise ValueError('`num_krylov_vecs` >= `numeig` required!')
+  if numeig > 1 and not reorthogonalize:
+    raise ValueError(
+        "Got numeig = {} > 1 and `reorthogonalize = False`. "
+        "Use `reorthogonalize=True` for `numeig > 1`".format(numeig))
+  if initial_state is None:
+    if (shape is None) or (dtype is None):
+      raise ValueError("if no `initial_state` is passed, then `shape` and"
+                       "`dtype` have to be provided")
+    initial_state = be.randn(shape, dtype)
+  if not be.is_tensor(initial_state):
+    raise TypeError("Expected a backend tensor. Got {}".format(type(initial_state)))
+
+  vector_n = be.divide(initial_state, _norm(be, initial_state))
+  norms, diags, krylov = [], [], []
+  first, eigvalsold = True, None
+  for it in range(num_krylov_vecs):
+    nrm = _norm(be, vector_n)
+    if abs(nrm) < delta:
+      break
+    norms.append(nrm)
+    vector_n = be.divide(vector_n, nrm)
+    if reorthogonalize:
+      for v in krylov:
+        vector_n = _axpy(be, vector_n, -_vdot(be, v, vector_n), v)
+    krylov.append(vector_n)
+    a_vec = A(vector_n, *args)
+    diags.append(_vdot(be, vector_n, a_vec))
+    if it > 0 and it % ndiag == 0 and len(diags) >= numeig:
+      eigvals, _ = _small_eigh(be, _tridiag(diags, norms[1:]))
+      if not first and np.linalg.norm(eigvals[:numeig] - eigvalsold[:numeig]) < tol:
+        break
+      first = False
+      eigvalsold = eigvals[:numeig]
+    a_vec = _axpy(be, a_vec, -diags[-1], krylov[-1])
+    if it > 0:
+      a_vec = _axpy(be, a_vec, -norms[-1], krylov[-2])
+    vector_n = a_vec
+
+  eigvals, u = _small_eigh(be, _tridiag(diags, norms[1:]))
+  eigenvectors = []
+  for n2 in range(min(numeig, len(eigvals))):
+    state = be.multiply(krylov[0], float(u[0, n2]))
+    for n1 in range(1, len(krylov)):
+      state = _axpy(be, state, float(u[n1, n2]), krylov[n1])
+    eigenvectors.append(be.divide(state, _norm(be, state)))
+  return eigvals[:numeig], eigenvectors
+
+
+def eigsh(be, A, args=None, initial_state=None, shape=None, dtype=None, num_krylov_vecs=50, numeig=6,
+          tol=1e-8, which='LA', maxiter=None):
+  """``numeig`` extremal eigenpairs of a Hermitian operator (interface of
+  ``numpy_backend.py:168-214``, which wraps ``scipy.sparse.linalg.eigsh``).
+
+  Thick-restart Lanczos with full re-orthogonalisation: a cycle grows the orthonormal
+  basis to ``num_krylov_vecs`` vectors, Rayleigh-Ritz on the projected matrix picks the
+  wanted Ritz pairs (``which`` in 'LA', 'SA', 'LM'), converged when every residual
+  ``||A y - theta y|| <= tol * max(|theta|, 1)``; otherwise the basis is compressed to the
+  wanted Ritz vectors plus the residual direction and the cycle repeats."""
+  if args is None:
+    args = []
+  if which in ('SI', 'LI'):
+    raise ValueError(f'which = {which} is currently not supported.')
+  if which not in ('LA', 'SA', 'LM'):
+    raise ValueError(f"which = {which} is not supported by the hip backend (use 'LA', 'SA' or 'LM').")
+  if numeig + 1 >= num_krylov_vecs:
+    raise ValueError('`num_krylov_vecs` > `numeig + 1` required!')
+  if initial_state is None:
+    if (shape is None) or (dtype is None):
+      raise ValueError("if no `initial_state` is passed, then `shape` and"
+                       "`dtype` have to be provided")
+    initial_state = be.randn(shape, dtype)
+  if not be.is_tensor(initial_state):
+    raise TypeError("Expected a backend tensor. Got {}".format(type(initial_state)))
+  size = int(np.prod(be.shape_tuple(initial_state)))
+  ncv = min(num_krylov_vecs, size)
+  numeig = min(numeig, size)
+  if maxiter is None:
+    maxiter = 10 * size
+
+  def wanted(theta):
+    if which == 'LA':
+      return np.argsort(-theta)[:numeig]
+    if which == 'SA':
+      return np.argsort(theta)[:numeig]
+    return np.argsort(-np.abs(theta))[:numeig]
+
+  basis = [be.divide(initial_state, _norm(be, initial_state))]
+  images = []                               # A applied to each basis vector
+  h = np.zeros((ncv, ncv), dtype=np.float64)  # projected matrix V^H A V (real symmetric part)
+  theta_sel, ritz = None, None
+  for _ in range(max(1, maxiter)):
+    # grow the basis to ncv vectors (or to an invariant subspace)
+    while True:
+      j = len(images)
+      w = A(basis[j], *args)
+      images.append(w)
+      for i in range(j + 1):
+        hij = float(np.real(_vdot(be, basis[i], w)))
+        h[i, j] = h[j, i] = hij
+      if len(basis) == ncv:
+        break
+      for _pass in range(2):                # classical Gram-Schmidt twice == full re-orthogonalisation
+        for v in basis:
+          w = _axpy(be, w, -_vdot(be, v, w), v)
+      nrm = _norm(be, w)
+      if nrm < 1e-14 * max(1.0, abs(h[j, j])):
+        break
+      basis.append(be.divide(w, nrm))
+    m = len(images)
+    theta, u = _small_eigh(be, h[:m, :m])
+    sel = wanted(theta)
+    theta_sel = theta[sel]
+    ritz, ritz_img, resid = [], [], []
+    for col in sel:
+      y = be.multiply(basis[0], float(u[0, col]))
+      ay = be.multiply(images[0], float(u[0, col]))
+      for i in range(1, m):
+        y = _axpy(be, y, float(u[i, col]), basis[i])
+        ay = _axpy(be, ay, float(u[i, col]), images[i])
+      ritz.append(y)
+      ritz_img.append(ay)
+      resid.append(_norm(be, _axpy(be, ay, -float(theta[col]), y)))
+    if all(r <= tol * max(abs(t), 1.0) for r, t in zip(resid, theta_sel)) or len(basis) < ncv or m >= size:
+      break
+    # thick restart: keep the wanted Ritz vectors, continue from the largest residual direction
+    k = len(ritz)
+    worst = int(np.argmax(resid))
+    nxt = _axpy(be, ritz_img[worst], -float(theta_sel[worst]), ritz[worst])
+    for _pass in range(2):
+      for v in ritz:
+        nxt = _axpy(be, nxt, -_vdot(be, v, nxt), v)
+    nrm = _norm(be, nxt)
+    h[:, :] = 0.0
+    for i in range(k):
+      h[i, i] = theta_sel[i]
+    basis, images = list(ritz), list(ritz_img)
+    if nrm < 1e-300:
+      break
+    basis.append(be.divide(nxt, nrm))
+  order = np.argsort(theta_sel) if which == 'SA' else np.argsort(-theta_sel if which == 'LA' else -np.abs(theta_sel))
+  vecs = [be.divide(ritz[i], _norm(be, ritz[i])) for i in order]
+  return theta_sel[order], vecs
+
+
+def gmres(be, A_mv, b, A_args, A_kwargs, x0, tol, atol, num_krylov_vectors, maxiter, M=None):
+  """Restarted GMRES(m) (interface of ``numpy_backend.py:300-412`` / ``abstract_backend.py:478-631``;
+  the reference wraps ``scipy.sparse.linalg.gmres``).  Arnoldi with modified Gram-Schmidt on backend
+  tensors, Givens rotations on the host for the (m+1) x m Hessenberg least-squares problem.
+  Stops when ``norm(residual) <= max(tol * norm(b), atol)``.  Returns ``(x, info)`` with info 0 on
+  convergence, else the number of restarts performed."""
+  if M is not None:
+    raise NotImplementedError("M is not supported by the hip backend.")
+  bshape = be.shape_tuple(b)
+  b_norm = _norm(be, b)
+  target = max(tol * b_norm, atol)
+  x = be.reshape(x0, bshape)
+  m = int(num_krylov_vectors)
+  maxiter = 1 if maxiter is None else int(maxiter)
+  if b_norm == 0.0:
+    return be.multiply(b, 0.0), 0
+  for restart in range(maxiter):
+    r = be.subtraction(b, A_mv(x, *A_args, **A_kwargs))
+    beta = _norm(be, r)
+    if beta <= target:
+      return x, 0
+    basis = [be.divide(r, beta)]
+    hess = np.zeros((m + 1, m), dtype=np.complex128)
+    cs, sn = np.zeros(m, dtype=np.complex128), np.zeros(m, dtype=np.complex128)
+    g = np.zeros(m + 1, dtype=np.complex128)
+    g[0] = beta
+    k_used, converged = 0, False
+    for j in range(m):
+      w = A_mv(basis[j], *A_args, **A_kwargs)
+      for i in range(j + 1):
+        hij = _vdot(be, basis[i], w)
+        hess[i, j] = hij
+        w = _axpy(be, w, -hij, basis[i])
+      hn = _norm(be, w)
+      hess[j + 1, j] = hn
+      for i in range(j):                      # previous rotations on the new column
+        t = cs[i] * hess[i, j] + sn[i] * hess[i + 1, j]
+        hess[i + 1, j] = -np.conj(sn[i]) * hess[i, j] + cs[i] * hess[i + 1, j]
+        hess[i, j] = t
+      denom = np.sqrt(abs(hess[j, j]) ** 2 + hn ** 2)
+      if denom == 0.0:
+        k_used = j
+        break
+      cs[j] = abs(hess[j, j]) / denom if hess[j, j] != 0 else 0.0
+      phase = hess[j, j] / abs(hess[j, j]) if hess[j, j] != 0 else 1.0
+      sn[j] = phase * hn / denom
+      hess[j, j] = cs[j] * hess[j, j] + sn[j] * hn
+      hess[j + 1, j] = 0.0
+      g[j + 1] = -np.conj(sn[j]) * g[j]
+      g[j] = cs[j] * g[j]
+      k_used = j + 1
+      if abs(g[j + 1]) <= target:
+        converged = True
+        break
+      if hn <= 1e-300:
+        break
+      basis.append(be.divide(w, hn))
+    # back substitution on the k_used x k_used triangle, then the update x += V y
+    y = np.zeros(k_used, dtype=np.complex128)
+    for i in range(k_used - 1, -1, -1):
+      acc = g[i] - np.dot(hess[i, i + 1:k_used], y[i + 1:])
+      y[i] = acc / hess[i, i]
+    for i in range(k_used):
+      coef = y[i] if abs(y[i].imag) > 0 else float(y[i].real)
+      x = _axpy(be, x, coef, basis[i])
+    if converged:
+      return x, 0
+  r = be.subtraction(b, A_mv(x, *A_args, **A_kwargs))
+  return x, (0 if _norm(be, r) <= target else maxiter)

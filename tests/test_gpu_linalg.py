@@ -84,3 +84,94 @@ def test_linalg_errors(hip):
     hip.expm(hip.ones((2, 2, 2), dtype=np.float32))
   with pytest.raises(ValueError, match="only supports N\\*N matrix"):
     hip.expm(hip.ones((2, 3), dtype=np.float32))
+
+
+# ------------------------------------------------------------------ Krylov / masks
+def _sym(n, seed, dtype):
+  rng = np.random.default_rng(seed)
+  a = rng.standard_normal((n, n))
+  return ((a + a.T) / 2).astype(dtype)
+
+
+@pytest.mark.parametrize("dtype,tol", [(np.float32, 2e-4), (np.float64, 1e-9)])
+def test_eigsh_lanczos_device_vectors(hip, dtype, tol):
+  """numpy_backend_test.py:371-470 on the hip backend: operator = device GEMV through tensordot."""
+  n = 64
+  h = _sym(n, 1, dtype)
+  hd = hip.convert_to_tensor(h)
+  init = hip.convert_to_tensor(np.random.default_rng(2).standard_normal(n).astype(dtype))
+
+  def mv(x, mat):
+    return hip.tensordot(mat, x, ([1], [0]))
+
+  eta, vecs = hip.eigsh_lanczos(mv, [hd], init, num_krylov_vecs=n, numeig=2, reorthogonalize=True)
+  w, v = np.linalg.eigh(h.astype(np.float64))
+  np.testing.assert_allclose(eta, w[:2], atol=tol * 10)
+  for e, vec in zip(eta, vecs):
+    assert isinstance(vec, ta.DeviceTensor) and vec.dtype == dtype
+    vh = np.asarray(vec).astype(np.float64)
+    np.testing.assert_allclose(h @ vh, e * vh, atol=tol * 100)
+  # random initial state from shape / dtype, tensor-shaped vectors
+  np.random.seed(3)
+  eta, vecs = hip.eigsh_lanczos(lambda x, mat: hip.reshape(hip.tensordot(mat, hip.reshape(x, (n,)), 1), (8, 8)),
+                                [hd], shape=(8, 8), dtype=dtype, num_krylov_vecs=n)
+  np.testing.assert_allclose(eta[0], w[0], atol=tol * 10)
+  assert vecs[0].shape == (8, 8)
+  with pytest.raises(TypeError, match="Expected a `DeviceTensor`"):
+    hip.eigsh_lanczos(mv, [hd], initial_state=np.ones(n))
+
+
+def test_eigsh_and_gmres_device_vectors(hip):
+  n = 100
+  h = _sym(n, 4, np.float64)
+  hd = hip.convert_to_tensor(h)
+  init = hip.convert_to_tensor(np.random.default_rng(5).standard_normal(n))
+  mv = lambda x, mat: hip.tensordot(mat, x, 1)
+  eta, vecs = hip.eigsh(mv, [hd], init, num_krylov_vecs=20, numeig=3, which="SA", tol=1e-10)
+  w = np.linalg.eigvalsh(h)
+  np.testing.assert_allclose(eta, w[:3], atol=1e-8)
+  for e, vec in zip(eta, vecs):
+    vh = np.asarray(vec)
+    np.testing.assert_allclose(h @ vh, e * vh, atol=1e-6)
+  # gmres: numpy_backend_test.py:880-897 known answer, then a tensor-shaped system
+  A = hip.convert_to_tensor(np.array([[1.0, 1.0], [3.0, -4.0]]))
+  b = hip.convert_to_tensor(np.array([3.0, 2.0]))
+  x, info = hip.gmres(lambda v, m: hip.tensordot(m, v, 1), b, A_args=[A], tol=1e-10, num_krylov_vectors=2)
+  assert info == 0
+  np.testing.assert_allclose(np.asarray(x), [2.0, 1.0], atol=1e-9)
+  rng = np.random.default_rng(6)
+  M = rng.standard_normal((n, n)) + 3.0 * np.sqrt(n) * np.eye(n)
+  Md = hip.convert_to_tensor(M)
+  rhs = rng.standard_normal((10, 10))
+  op = lambda v: hip.reshape(hip.tensordot(Md, hip.reshape(v, (n,)), 1), (10, 10))
+  x, info = hip.gmres(op, hip.convert_to_tensor(rhs), tol=1e-9, num_krylov_vectors=15, maxiter=20)
+  assert info == 0 and x.shape == (10, 10)
+  np.testing.assert_allclose((M @ np.asarray(x).reshape(-1)).reshape(10, 10), rhs, atol=1e-7)
+  with pytest.raises(ValueError, match="must match b's"):
+    hip.gmres(op, hip.convert_to_tensor(rhs), x0=hip.zeros((5,), dtype=np.float64))
+  with pytest.raises(TypeError, match="must match b's"):
+    hip.gmres(op, hip.convert_to_tensor(rhs), x0=hip.zeros((10, 10), dtype=np.float32))
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64, ta.bfloat16])
+def test_compare_and_index_update(hip, dtype):
+  """The reference's pattern (infinite_mps.py:237-241): mask = eigvals <= precision;
+  index_update(eigvals, mask, 0.0); index_update(1 / eigvals, mask, 0.0) -- inf under the mask
+  must not leak (a multiplicative blend would give nan)."""
+  x = np.array([[1.0, -2.0, 0.0, 1e-3], [0.5, 0.0, -1e-3, 4.0]], dtype=np.float32)
+  d = hip.to_bfloat16(x) if dtype is ta.bfloat16 else hip.convert_to_tensor(x.astype(dtype))
+  xr = np.asarray(d).astype(np.float64)
+  mask = d <= 1e-2
+  np.testing.assert_array_equal(np.asarray(mask), (xr <= 1e-2).astype(np.int32))
+  for op, fn in [("<", np.less), (">", np.greater), (">=", np.greater_equal), ("==", np.equal), ("!=", np.not_equal)]:
+    np.testing.assert_array_equal(np.asarray(hip.compare(op, d, 0.0)), fn(xr, 0.0).astype(np.int32))
+  np.testing.assert_array_equal(np.asarray(d > hip.multiply(d, 0.5)), (xr > 0.5 * xr).astype(np.int32))
+  upd = np.asarray(hip.index_update(d, mask, 0.0)).astype(np.float64)
+  np.testing.assert_array_equal(upd, np.where(xr <= 1e-2, 0.0, xr))
+  inv = hip.divide(1.0, d)
+  got = np.asarray(hip.index_update(inv, mask, 0.0)).astype(np.float64)
+  assert np.all(np.isfinite(got))
+  np.testing.assert_allclose(got, np.where(xr <= 1e-2, 0.0, 1.0 / np.where(xr == 0, 1, xr)), rtol=1e-2)
+  # host boolean mask (numpy_backend_test.py:720-727 passes `tensor > 0.1` computed anywhere)
+  got = np.asarray(hip.index_update(d, xr > 0.1, 9.0)).astype(np.float64)
+  np.testing.assert_array_equal(got, np.where(xr > 0.1, 9.0, xr))

@@ -1,0 +1,99 @@
+"""Host logic of tensornetwork_amd/krylov.py (Lanczos, thick-restart eigsh, GMRES) driven with the
+oracle backend; the GPU suite runs the same functions on HipBackend (tests/test_gpu_linalg.py).
+Known answers follow the reference's own tests: numpy_backend_test.py:371-470 (eigsh_lanczos on
+dense symmetric matrices vs np.linalg.eigh), :880-918 (gmres on a 2x2 system)."""
+import numpy as np
+import pytest
+
+from oracle import numpy_oracle as orc
+from tensornetwork_amd import krylov
+
+
+def _sym(n, seed):
+  rng = np.random.default_rng(seed)
+  a = rng.standard_normal((n, n))
+  return (a + a.T) / 2
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_eigsh_lanczos_lowest_pair(dtype):
+  be = orc.OracleBackend()
+  n = 10
+  h = _sym(n, 1).astype(dtype)
+  init = np.random.default_rng(2).standard_normal(n).astype(dtype)
+
+  def mv(x, mat):
+    return mat @ x
+
+  eta, vecs = krylov.eigsh_lanczos(be, mv, [h], init, num_krylov_vecs=n)
+  w, v = np.linalg.eigh(h.astype(np.float64))
+  tol = 1e-4 if dtype == np.float32 else 1e-10
+  np.testing.assert_allclose(eta[0], w[0], atol=tol * 10)
+  v0 = vecs[0] / np.sign(vecs[0][np.argmax(np.abs(v[:, 0]))]) * np.sign(v[np.argmax(np.abs(v[:, 0])), 0])
+  np.testing.assert_allclose(v0, v[:, 0], atol=tol * 100)
+
+
+def test_eigsh_lanczos_reorthogonalize_several_and_shape_dtype_init():
+  be = orc.OracleBackend()
+  n = 50
+  h = _sym(n, 3)
+  np.random.seed(10)
+  eta, vecs = krylov.eigsh_lanczos(be, lambda x, m: m @ x, [h], shape=(n,), dtype=np.float64,
+                                   num_krylov_vecs=n, numeig=3, reorthogonalize=True)
+  w = np.linalg.eigvalsh(h)
+  np.testing.assert_allclose(eta, w[:3], atol=1e-8)
+  for e, v in zip(eta, vecs):
+    np.testing.assert_allclose(h @ v, e * v, atol=1e-6)
+
+
+def test_eigsh_lanczos_errors():
+  be = orc.OracleBackend()
+  mv = lambda x: x
+  with pytest.raises(ValueError, match="`num_krylov_vecs` >= `numeig` required!"):
+    krylov.eigsh_lanczos(be, mv, numeig=10, num_krylov_vecs=9, initial_state=np.ones(3))
+  with pytest.raises(ValueError, match="Got numeig = 2 > 1 and `reorthogonalize = False`"):
+    krylov.eigsh_lanczos(be, mv, numeig=2, reorthogonalize=False, initial_state=np.ones(3))
+  with pytest.raises(ValueError, match="if no `initial_state` is passed, then `shape` and"):
+    krylov.eigsh_lanczos(be, mv, shape=(10,), dtype=None)
+  with pytest.raises(TypeError, match="Expected a backend tensor"):
+    krylov.eigsh_lanczos(be, mv, initial_state=[1, 2, 3])
+
+
+@pytest.mark.parametrize("which", ["LA", "SA", "LM"])
+def test_eigsh_thick_restart(which):
+  be = orc.OracleBackend()
+  n = 120
+  h = _sym(n, 4)
+  init = np.random.default_rng(5).standard_normal(n)
+  eta, vecs = krylov.eigsh(be, lambda x, m: m @ x, [h], init, num_krylov_vecs=24, numeig=4, which=which,
+                           tol=1e-10)
+  w = np.linalg.eigvalsh(h)
+  want = {"LA": w[::-1][:4], "SA": w[:4], "LM": w[np.argsort(-np.abs(w))[:4]]}[which]
+  np.testing.assert_allclose(eta, want, atol=1e-8)
+  for e, v in zip(eta, vecs):
+    np.testing.assert_allclose(h @ v, e * v, atol=1e-6)
+  with pytest.raises(ValueError, match="`num_krylov_vecs` > `numeig \\+ 1` required!"):
+    krylov.eigsh(be, lambda x: x, initial_state=init, numeig=5, num_krylov_vecs=6)
+  with pytest.raises(ValueError, match="which = SI is currently not supported."):
+    krylov.eigsh(be, lambda x: x, initial_state=init, which="SI")
+
+
+def test_gmres_known_answer_and_restarts():
+  be = orc.OracleBackend()
+  # numpy_backend_test.py:880-897: A = [[1, 1], [3, -4]], b = [3, 2] -> x = [2, 1]
+  A = np.array([[1.0, 1.0], [3.0, -4.0]])
+  b = np.array([3.0, 2.0])
+  x, info = krylov.gmres(be, lambda v, m: m @ v, b, [A], {}, np.zeros(2), 1e-10, 1e-10, 2, 1)
+  assert info == 0
+  np.testing.assert_allclose(x, [2.0, 1.0], atol=1e-9)
+  rng = np.random.default_rng(6)
+  n = 80
+  M = rng.standard_normal((n, n)) + 3.0 * np.sqrt(n) * np.eye(n)
+  rhs = rng.standard_normal((8, 10))                      # arbitrary tensor shape, as the interface allows
+  op = lambda v: (M @ v.reshape(-1)).reshape(v.shape)
+  x, info = krylov.gmres(be, op, rhs, [], {}, np.zeros(n), 1e-9, 1e-9, 15, 20)
+  assert info == 0 and x.shape == rhs.shape
+  np.testing.assert_allclose(op(x), rhs, atol=1e-7)
+  # not converged within the budget -> info = number of restarts
+  x, info = krylov.gmres(be, op, rhs, [], {}, np.zeros(n), 1e-14, 1e-14, 2, 1)
+  assert info == 1
