@@ -1,0 +1,398 @@
+"""Finite MPS, nearest-neighbour MPOs and two-/one-site DMRG on backend tensors.
+
+The heaviest real consumer of the hot path: every step is ``ncon`` (pairwise
+GEMMs), ``qr`` / ``rq`` (gauge moves), ``svd`` with truncation (two-site splits) and
+``eigsh_lanczos`` on vectors that never leave the device.  Behaviour follows the reference's
+``matrixproductstates`` package: tensor conventions of ``mpo.py:129-220`` (MPO tensors are
+(left bond, right bond, physical out, physical in)) and ``base_mps.py`` (MPS tensors are
+(left bond, physical, right bond)), environments and effective-Hamiltonian contractions of
+``dmrg.py:90-112``, gauge moves of ``base_mps.py:139-226``, local updates of
+``dmrg.py:184-343``, sweeps of ``dmrg.py:345-559``.  Only backend methods are called, so the
+same code runs on ``HipBackend`` (GPU suite) and on the oracle backend (CPU suite).
+"""
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+from tensornetwork_amd.ncon import ncon
+
+
+# ------------------------------------------------------------------------ MPOs
+def xxz_mpo(backend, Jz: Sequence[float], Jxy: Sequence[float], Bz: Sequence[float], dtype=np.float64):
+  """Heisenberg XXZ chain H = sum Jz Sz Sz + Jxy/2 (S+ S- + S- S+) + Bz Sz as a bond-5 MPO.
+
+  Same operator content and index convention as ``FiniteXXZ`` (mpo.py:129-220): row 4 / column 0
+  carry the identity strings, (Sm, Sp, Sz) open a bond term on columns 1-3 and close it on
+  rows 1-3.  Basis: index 0 = spin down (Sz = -1/2), 1 = spin up."""
+  n = len(Bz)
+  sz = np.array([[-0.5, 0.0], [0.0, 0.5]])
+  sp = np.array([[0.0, 0.0], [1.0, 0.0]])   # raises 0 -> 1  (element [out, in])
+  sm = np.array([[0.0, 1.0], [0.0, 0.0]])
+  one = np.eye(2)
+  tensors = []
+  for site in range(n):
+    w = np.zeros((5, 5, 2, 2), dtype=np.float64)
+    w[0, 0] = one
+    w[1, 0] = sp
+    w[2, 0] = sm
+    w[3, 0] = sz
+    w[4, 0] = Bz[site] * sz
+    if site < n - 1:
+      w[4, 1] = Jxy[site] / 2.0 * sm
+      w[4, 2] = Jxy[site] / 2.0 * sp
+      w[4, 3] = Jz[site] * sz
+    w[4, 4] = one
+    if site == 0:
+      w = w[4:5]
+    if site == n - 1:
+      w = w[:, 0:1]
+    tensors.append(backend.convert_to_tensor(np.ascontiguousarray(w).astype(dtype)))
+  return tensors
+
+
+def tfi_mpo(backend, Jx: Sequence[float], Bz: Sequence[float], dtype=np.float64):
+  """Transverse-field Ising chain H = sum Jx X X + Bz Z (``FiniteTFI``, mpo.py:223-288), bond 3."""
+  n = len(Bz)
+  sx = np.array([[0.0, 1.0], [1.0, 0.0]])
+  szz = np.array([[1.0, 0.0], [0.0, -1.0]])
+  one = np.eye(2)
+  tensors = []
+  for site in range(n):
+    w = np.zeros((3, 3, 2, 2), dtype=np.float64)
+    w[0, 0] = one
+    w[1, 0] = sx
+    w[2, 0] = Bz[site] * szz
+    if site < n - 1:
+      w[2, 1] = Jx[site] * sx
+    w[2, 2] = one
+    if site == 0:
+      w = w[2:3]
+    if site == n - 1:
+      w = w[:, 0:1]
+    tensors.append(backend.convert_to_tensor(np.ascontiguousarray(w).astype(dtype)))
+  return tensors
+
+
+def mpo_to_dense(mpo_host: Sequence[np.ndarray]) -> np.ndarray:
+  """Dense Hamiltonian of a (small) MPO given as host arrays -- test / oracle helper."""
+  acc = mpo_host[0][0]                       # (right bond, out, in)
+  acc = np.transpose(acc, (1, 2, 0))         # (out, in, bond)
+  for w in mpo_host[1:]:
+    acc = np.einsum("abk,klcd->acbdl", acc, w)
+    s = acc.shape
+    acc = acc.reshape(s[0] * s[1], s[2] * s[3], s[4])
+  return acc[:, :, 0]
+
+
+# ------------------------------------------------------------------------- MPS
+class FiniteMPS:
+  """Open-boundary MPS with one orthogonality centre (finite_mps.py:26-121, base_mps.py:29-226)."""
+
+  def __init__(self, tensors: List, backend, center_position: Optional[int] = None, canonicalize: bool = True):
+    self.backend = backend
+    self.tensors = [backend.convert_to_tensor(t) if not backend.is_tensor(t) else t for t in tensors]
+    if self.tensors[0].shape[0] != 1 or self.tensors[-1].shape[2] != 1:
+      raise ValueError("FiniteMPS needs boundary bond dimensions 1")
+    if center_position is None:
+      center_position = 0
+      canonicalize = True
+    if center_position < 0 or center_position >= len(self.tensors):
+      raise ValueError("center_position = {} not between 0 <= center_position < N = {}"
+                       .format(center_position, len(self.tensors)))
+    self.center_position = center_position
+    if canonicalize:
+      self.canonicalize()
+
+  @classmethod
+  def random(cls, d: Sequence[int], D: Sequence[int], dtype, backend, seed: Optional[int] = None):
+    """Random MPS (finite_mps.py:88-121): bond dimensions ``D`` (len N-1), tensors from the
+    backend's ``randn`` (NumPy's global stream, like the reference)."""
+    if len(D) != len(d) - 1:
+      raise ValueError("len(D) = {} is different from len(d) - 1 = {}".format(len(D), len(d) - 1))
+    if seed is not None:
+      np.random.seed(seed)
+    bonds = [1] + list(D) + [1]
+    tensors = [backend.randn((bonds[n], d[n], bonds[n + 1]), dtype=dtype) for n in range(len(d))]
+    return cls(tensors, backend, center_position=0, canonicalize=True)
+
+  def __len__(self):
+    return len(self.tensors)
+
+  @property
+  def dtype(self):
+    return self.tensors[0].dtype
+
+  @property
+  def bond_dimensions(self):
+    return [self.tensors[0].shape[0]] + [t.shape[2] for t in self.tensors]
+
+  def _norm(self, t):
+    return float(np.real(self.backend.item(self.backend.norm(t))))
+
+  def position(self, site: int, normalize: bool = True, D: Optional[int] = None,
+               max_truncation_err: Optional[float] = None):
+    """Move the orthogonality centre to ``site`` with QR / RQ steps, or truncating SVDs when
+    ``D`` / ``max_truncation_err`` ask for it (base_mps.py:139-226).  Returns the norm of the
+    centre tensor before the last normalisation."""
+    be = self.backend
+    if site >= len(self.tensors) or site < 0:
+      raise ValueError('site = {} not between values 0 < site < N = {}'.format(site, len(self)))
+    if max_truncation_err is not None and max_truncation_err >= 1.0:
+      raise ValueError("max_truncation_err should be 0 <= max_truncation_er < 1")
+    z = None
+    if site == self.center_position:
+      z = self._norm(self.tensors[site])
+      if normalize:
+        self.tensors[site] = be.divide(self.tensors[site], z)
+      return z
+    if site > self.center_position:
+      for n in range(self.center_position, site):
+        truncate = (D is not None and D < self.tensors[n].shape[2]) or max_truncation_err is not None
+        if not truncate:
+          iso, rest = be.qr(self.tensors[n], 2)
+        else:
+          iso, s, vh, _ = be.svd(self.tensors[n], 2, D, max_truncation_err)
+          rest = be.broadcast_left_multiplication(s, vh)
+        self.tensors[n] = iso
+        self.tensors[n + 1] = ncon([rest, self.tensors[n + 1]], [[-1, 1], [1, -2, -3]], backend=be)
+        z = self._norm(self.tensors[n + 1])
+        if normalize:
+          self.tensors[n + 1] = be.divide(self.tensors[n + 1], z)
+    else:
+      for n in range(self.center_position, site, -1):
+        truncate = (D is not None and D < self.tensors[n].shape[0]) or max_truncation_err is not None
+        if not truncate:
+          rest, iso = be.rq(self.tensors[n], 1)
+        else:
+          u, s, iso, _ = be.svd(self.tensors[n], 1, D, max_truncation_err)
+          rest = be.broadcast_right_multiplication(u, s)
+        self.tensors[n] = iso
+        self.tensors[n - 1] = ncon([self.tensors[n - 1], rest], [[-1, -2, 1], [1, -3]], backend=be)
+        z = self._norm(self.tensors[n - 1])
+        if normalize:
+          self.tensors[n - 1] = be.divide(self.tensors[n - 1], z)
+    self.center_position = site
+    return z
+
+  def canonicalize(self, normalize: bool = True):
+    """Bring the state into canonical form around ``center_position`` (finite_mps.py:123-146):
+    sweep the centre to the right end, back to the left end, then to where it was."""
+    pos = self.center_position
+    self.center_position = 0
+    self.position(len(self.tensors) - 1, normalize=False)
+    self.position(0, normalize=False)
+    return self.position(pos, normalize=normalize)
+
+  def check_orthonormality(self, which: str, site: int):
+    """|| A^dagger A - 1 || (left) or || B B^dagger - 1 || (right) (base_mps.py:616-650)."""
+    be = self.backend
+    t = self.tensors[site]
+    if which in ("l", "left"):
+      g = ncon([t, be.conj(t)], [[1, 2, -1], [1, 2, -2]], backend=be)
+    elif which in ("r", "right"):
+      g = ncon([t, be.conj(t)], [[-1, 1, 2], [-2, 1, 2]], backend=be)
+    else:
+      raise ValueError("which = {} is not recognized.".format(which))
+    return self._norm(be.subtraction(g, be.eye(g.shape[0], dtype=self.dtype)))
+
+  def apply_two_site_gate(self, gate, site1: int, site2: int, max_singular_values: Optional[int] = None,
+                          max_truncation_err: Optional[float] = None, relative: bool = False):
+    """Apply a (d, d, d, d) gate [out1, out2, in1, in2] to neighbouring sites and split the result
+    with a truncated SVD (base_mps.py:481-596).  The centre must sit on one of the two sites and
+    stays where it was (the singular values are absorbed into that site).  Returns the discarded
+    singular values."""
+    be = self.backend
+    if site2 != site1 + 1:
+      raise ValueError("site2 ={} != site1={}. Only nearest neighbor gates are currently supported"
+                       .format(site2, site1))
+    if self.center_position not in (site1, site2):
+      raise ValueError("center_position is not on site1 or site2")
+    theta = ncon([self.tensors[site1], self.tensors[site2], gate],
+                 [[-1, 1, 2], [2, 3, -4], [-2, -3, 1, 3]], backend=be)
+    u, s, vh, trunc = be.svd(theta, 2, max_singular_values, max_truncation_err, relative=relative)
+    if self.center_position == site1:
+      self.tensors[site1] = be.broadcast_right_multiplication(u, s)
+      self.tensors[site2] = vh
+    else:
+      self.tensors[site1] = u
+      self.tensors[site2] = be.broadcast_left_multiplication(s, vh)
+    return trunc
+
+  def measure_local_operator(self, ops: Sequence, sites: Sequence[int]):
+    """<psi| op_n |psi> for each (op, site) (base_mps.py:287-320); the centre is moved to each
+    site, where the expectation value is a single local contraction."""
+    be = self.backend
+    out = []
+    for op, site in zip(ops, sites):
+      self.position(site)
+      t = self.tensors[site]
+      val = ncon([t, op, be.conj(t)], [[1, 2, 3], [4, 2], [1, 4, 3]], backend=be)
+      out.append(be.item(val))
+    return out
+
+
+# ------------------------------------------------------------------------ DMRG
+class FiniteDMRG:
+  """Ground-state search for a finite MPO (dmrg.py:23-604).
+
+  Left / right environments are rank-3 tensors (MPO bond, ket bond, bra bond); the effective
+  Hamiltonian is applied by ``ncon`` (dmrg.py:90-112) inside ``backend.eigsh_lanczos``."""
+
+  def __init__(self, mps: FiniteMPS, mpo: List):
+    if len(mps) != len(mpo):
+      raise ValueError('len(mps) = {} is different from len(mpo) = {}'.format(len(mps), len(mpo)))
+    self.mps = mps
+    self.mpo = list(mpo)
+    self.backend = mps.backend
+    be = self.backend
+    if self.mpo[0].dtype != mps.dtype:
+      raise TypeError('mps.dtype = {} is different from mpo.dtype = {}'.format(mps.dtype, self.mpo[0].dtype))
+    self.left_envs = {0: be.ones((self.mpo[0].shape[0], 1, 1), dtype=mps.dtype)}
+    self.right_envs = {len(mps) - 1: be.ones((self.mpo[-1].shape[1], 1, 1), dtype=mps.dtype)}
+    self.last_truncation = None
+
+  # contractions (index strings of dmrg.py:90-112)
+  def single_site_matvec(self, t, L, w, R):
+    return ncon([L, t, w, R], [[3, 1, -1], [1, 2, 4], [3, 5, -2, 2], [5, 4, -3]], backend=self.backend)
+
+  def two_site_matvec(self, theta, L, wl, wr, R):
+    return ncon([L, theta, wl, wr, R],
+                [[3, 1, -1], [1, 2, 5, 6], [3, 4, -2, 2], [4, 7, -3, 5], [7, 6, -4]], backend=self.backend)
+
+  def add_left_layer(self, L, t, w):
+    return ncon([L, t, w, self.backend.conj(t)], [[2, 1, 5], [1, 3, -2], [2, -1, 4, 3], [5, 4, -3]],
+                backend=self.backend)
+
+  def add_right_layer(self, R, t, w):
+    return ncon([R, t, w, self.backend.conj(t)], [[2, 1, 5], [-2, 3, 1], [-1, 2, 4, 3], [-3, 4, 5]],
+                backend=self.backend)
+
+  def compute_right_envs(self):
+    for n in range(len(self.mps) - 1, self.mps.center_position, -1):
+      self.right_envs[n - 1] = self.add_right_layer(self.right_envs[n], self.mps.tensors[n], self.mpo[n])
+
+  def compute_left_envs(self):
+    for n in range(self.mps.center_position):
+      self.left_envs[n + 1] = self.add_left_layer(self.left_envs[n], self.mps.tensors[n], self.mpo[n])
+
+  def position(self, site: int):
+    """Move the MPS centre to ``site`` keeping the environments consistent (dmrg.py:114-157)."""
+    old = self.mps.center_position
+    if site >= len(self.mps) or site < 0:
+      raise IndexError("site {} is out of range".format(site))
+    if site == old:
+      return
+    self.mps.position(site)
+    if site > old:
+      for n in range(old, site):
+        self.left_envs[n + 1] = self.add_left_layer(self.left_envs[n], self.mps.tensors[n], self.mpo[n])
+    else:
+      for n in range(old, site, -1):
+        self.right_envs[n - 1] = self.add_right_layer(self.right_envs[n], self.mps.tensors[n], self.mpo[n])
+
+  def _lanczos(self, matvec, args, init, num_krylov_vecs, tol, delta, ndiag):
+    be = self.backend
+    energies, states = be.eigsh_lanczos(A=matvec, args=args, initial_state=init, num_krylov_vecs=num_krylov_vecs,
+                                        numeig=1, tol=tol, delta=delta, ndiag=ndiag, reorthogonalize=False)
+    state = states[0]
+    return energies[0], be.divide(state, float(np.real(be.item(be.norm(state)))))
+
+  def _optimize_2s_local(self, max_bond_dim, sweep_dir, num_krylov_vecs=10, tol=1e-5, delta=1e-6, ndiag=10):
+    """dmrg.py:251-343."""
+    be, mps = self.backend, self.mps
+    site = mps.center_position
+    left = site if sweep_dir == "right" else site - 1
+    theta = ncon([mps.tensors[left], mps.tensors[left + 1]], [[-1, -2, 1], [1, -3, -4]], backend=be)
+    energy, ground = self._lanczos(self.two_site_matvec,
+                                   [self.left_envs[left], self.mpo[left], self.mpo[left + 1],
+                                    self.right_envs[left + 1]], theta, num_krylov_vecs, tol, delta, ndiag)
+    u, s, vh, trunc = be.svd(ground, 2, max_bond_dim, None)
+    self.last_truncation = trunc
+    if sweep_dir == "right":
+      mps.tensors[left] = u
+      mps.tensors[left + 1] = be.broadcast_left_multiplication(s, vh)
+      mps.center_position = left + 1
+      self.left_envs[left + 1] = self.add_left_layer(self.left_envs[left], u, self.mpo[left])
+    else:
+      mps.tensors[left + 1] = vh
+      mps.tensors[left] = be.broadcast_right_multiplication(u, s)
+      mps.center_position = left
+      self.right_envs[left] = self.add_right_layer(self.right_envs[left + 1], vh, self.mpo[left + 1])
+    return energy
+
+  def _optimize_1s_local(self, sweep_dir, num_krylov_vecs=10, tol=1e-5, delta=1e-6, ndiag=10):
+    """dmrg.py:184-249."""
+    be, mps = self.backend, self.mps
+    site = mps.center_position
+    energy, ground = self._lanczos(self.single_site_matvec,
+                                   [self.left_envs[site], self.mpo[site], self.right_envs[site]],
+                                   mps.tensors[site], num_krylov_vecs, tol, delta, ndiag)
+    if sweep_dir == "right":
+      q, r = be.qr(ground, 2)
+      mps.tensors[site] = q
+      if site < len(mps) - 1:
+        mps.center_position += 1
+        mps.tensors[site + 1] = ncon([r, mps.tensors[site + 1]], [[-1, 1], [1, -2, -3]], backend=be)
+        self.left_envs[site + 1] = self.add_left_layer(self.left_envs[site], q, self.mpo[site])
+    else:
+      r, q = be.rq(ground, 1)
+      mps.tensors[site] = q
+      if site > 0:
+        mps.center_position -= 1
+        mps.tensors[site - 1] = ncon([mps.tensors[site - 1], r], [[-1, -2, 1], [1, -3]], backend=be)
+        self.right_envs[site - 1] = self.add_right_layer(self.right_envs[site], q, self.mpo[site])
+    return energy
+
+  def _prepare(self):
+    self.position(0)
+    self.compute_right_envs()
+
+  def run_two_site(self, max_bond_dim: int, num_sweeps: int = 4, precision: float = 1e-6,
+                   num_krylov_vecs: int = 10, tol: float = 1e-5, delta: float = 1e-6, ndiag: int = 10):
+    """Two-site DMRG sweeps (dmrg.py:445-559): right then left over all bonds, until the energy
+    changes by less than ``precision`` between sweeps or ``num_sweeps`` is reached.  Returns the
+    last local energy (the total energy: the local problem is the full projected Hamiltonian)."""
+    if num_sweeps == 0:
+      return self.compute_energy()
+    n = len(self.mps)
+    self._prepare()
+    energy, previous = None, 1e100
+    for _ in range(num_sweeps):
+      for _site in range(n - 2):
+        energy = self._optimize_2s_local(max_bond_dim, "right", num_krylov_vecs, tol, delta, ndiag)
+      # last bond (n-2, n-1): optimise while turning around
+      energy = self._optimize_2s_local(max_bond_dim, "right", num_krylov_vecs, tol, delta, ndiag)
+      for _site in range(n - 2):
+        energy = self._optimize_2s_local(max_bond_dim, "left", num_krylov_vecs, tol, delta, ndiag)
+      self.position(0)
+      if abs(float(np.real(energy)) - previous) < precision:
+        break
+      previous = float(np.real(energy))
+    return energy
+
+  def run_one_site(self, num_sweeps: int = 4, precision: float = 1e-6, num_krylov_vecs: int = 10,
+                   tol: float = 1e-5, delta: float = 1e-6, ndiag: int = 10):
+    """Single-site DMRG sweeps (dmrg.py:345-443); bond dimensions stay fixed."""
+    if num_sweeps == 0:
+      return self.compute_energy()
+    n = len(self.mps)
+    self._prepare()
+    energy, previous = None, 1e100
+    for _ in range(num_sweeps):
+      for _site in range(n - 1):
+        energy = self._optimize_1s_local("right", num_krylov_vecs, tol, delta, ndiag)
+      for _site in range(n - 1):
+        energy = self._optimize_1s_local("left", num_krylov_vecs, tol, delta, ndiag)
+      if abs(float(np.real(energy)) - previous) < precision:
+        break
+      previous = float(np.real(energy))
+    return energy
+
+  def compute_energy(self):
+    """<psi|H|psi> from the environments (dmrg.py:561-569)."""
+    be = self.backend
+    self._prepare()
+    t = self.mps.tensors[0]
+    val = ncon([self.left_envs[0], t, self.mpo[0], self.right_envs[0], be.conj(t)],
+               [[3, 1, 6], [1, 2, 4], [3, 5, 7, 2], [5, 4, 8], [6, 7, 8]], backend=be)
+    return be.item(val)

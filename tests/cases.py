@@ -205,3 +205,24 @@ def check_linalg_case(be, g, case):
     got = to_host(be.expm(be.convert_to_tensor(e)))
     ref = g[case["expm"]]
     assert_close(got, ref, scale=float(np.max(np.abs(ref))) * 100)
+
+
+# ------------------------------------------------------------------ MPS / DMRG
+def xxz_dense(n, jz, jxy, bz):
+  """Dense XXZ Hamiltonian built independently of the MPO (Kronecker products)."""
+  sz = np.diag([-0.5, 0.5])
+  sp = np.array([[0.0, 0.0], [1.0, 0.0]])
+  sm = sp.T
+  def op(o, i):
+    mats = [np.eye(2)] * n
+    mats[i] = o
+    out = mats[0]
+    for m in mats[1:]:
+      out = np.kron(out, m)
+    return out
+  h = np.zeros((2**n, 2**n))
+  for i in range(n - 1):
+    h += jz * op(sz, i) @ op(sz, i + 1) + jxy / 2 * (op(sp, i) @ op(sm, i + 1) + op(sm, i) @ op(sp, i + 1))
+  for i in range(n):
+    h += bz * op(sz, i)
+  return h

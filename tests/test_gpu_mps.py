@@ -1,0 +1,50 @@
+"""MPS / DMRG end to end on the GPU: gauge moves through the device QR / RQ,
+two-site splits through the Jacobi SVD, Lanczos on device vectors.  Known answers as in
+matrixproductstates/dmrg_test.py:160-191 (ground energy vs exact diagonalisation)."""
+import numpy as np
+import pytest
+
+import tensornetwork_amd as ta
+from tensornetwork_amd import mps as tmps
+from cases import xxz_dense
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("dtype,tol", [(np.float64, 1e-7), (np.float32, 2e-4)])
+def test_mps_canonical_form_on_device(hip, dtype, tol):
+  state = tmps.FiniteMPS.random([2] * 8, [6] * 7, dtype, hip, seed=3)
+  assert isinstance(state.tensors[0], ta.DeviceTensor)
+  for n in range(1, 8):
+    assert state.check_orthonormality("right", n) < tol
+  state.position(5)
+  for n in range(5):
+    assert state.check_orthonormality("left", n) < tol
+  np.testing.assert_allclose(np.linalg.norm(np.asarray(state.tensors[5])), 1.0, atol=tol)
+  state.position(0, D=3)
+  assert state.bond_dimensions[1:6] == [2, 3, 3, 3, 3]
+
+
+@pytest.mark.parametrize("n", [4, 7])
+def test_dmrg_ground_energy_vs_exact_f64(hip, n):
+  eta = np.linalg.eigvalsh(xxz_dense(n, 1.0, 1.0, 0.0))
+  mpo = tmps.xxz_mpo(hip, np.ones(n - 1), np.ones(n - 1), np.zeros(n))
+  state = tmps.FiniteMPS.random([2] * n, [32] * (n - 1), np.float64, hip, seed=16)
+  e1 = tmps.FiniteDMRG(state, mpo).run_one_site(num_sweeps=4, num_krylov_vecs=10)
+  np.testing.assert_allclose(e1, eta[0], atol=1e-7)
+  state = tmps.FiniteMPS.random([2] * n, [32] * (n - 1), np.float64, hip, seed=17)
+  dmrg = tmps.FiniteDMRG(state, mpo)
+  e2 = dmrg.run_two_site(max_bond_dim=32, num_sweeps=4, num_krylov_vecs=10)
+  np.testing.assert_allclose(e2, eta[0], atol=1e-7)
+  np.testing.assert_allclose(dmrg.compute_energy(), eta[0], atol=1e-7)
+
+
+def test_dmrg_f32_chain_of_12(hip):
+  n = 12
+  eta = np.linalg.eigvalsh(xxz_dense(n, 1.0, 1.0, 0.0))
+  mpo = tmps.xxz_mpo(hip, np.ones(n - 1), np.ones(n - 1), np.zeros(n), dtype=np.float32)
+  state = tmps.FiniteMPS.random([2] * n, [16] * (n - 1), np.float32, hip, seed=21)
+  dmrg = tmps.FiniteDMRG(state, mpo)
+  e = dmrg.run_two_site(max_bond_dim=48, num_sweeps=4, num_krylov_vecs=12)
+  np.testing.assert_allclose(e, eta[0], atol=2e-4 * abs(eta[0]))
+  assert max(state.bond_dimensions) <= 48

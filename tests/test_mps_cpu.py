@@ -1,0 +1,73 @@
+"""Host logic of tensornetwork_amd/mps.py (FiniteMPS gauge moves, MPOs, one-/two-site DMRG) on the
+oracle backend; known answers follow matrixproductstates/dmrg_test.py:160-191 (XXZ ground energy vs
+exact diagonalisation) and finite_mps_test.py (canonical form checks)."""
+import numpy as np
+import pytest
+
+from oracle import numpy_oracle as orc
+from tensornetwork_amd import mps as tmps
+from cases import xxz_dense
+
+
+def test_xxz_mpo_matches_kronecker_hamiltonian():
+  be = orc.OracleBackend()
+  n = 5
+  mpo = tmps.xxz_mpo(be, [1.0] * (n - 1), [0.7] * (n - 1), [0.3] * n)
+  np.testing.assert_allclose(tmps.mpo_to_dense([np.asarray(w) for w in mpo]), xxz_dense(n, 1.0, 0.7, 0.3), atol=1e-12)
+
+
+def test_mps_canonical_form_and_position():
+  be = orc.OracleBackend()
+  state = tmps.FiniteMPS.random([2] * 8, [6] * 7, np.float64, be, seed=3)
+  assert state.center_position == 0
+  for n in range(1, 8):
+    assert state.check_orthonormality("right", n) < 1e-12
+  state.position(5)
+  for n in range(5):
+    assert state.check_orthonormality("left", n) < 1e-12
+  for n in range(6, 8):
+    assert state.check_orthonormality("right", n) < 1e-12
+  np.testing.assert_allclose(np.linalg.norm(state.tensors[5]), 1.0, atol=1e-12)
+  # truncating move keeps the requested bond dimension
+  state.position(0, D=3)
+  assert max(state.bond_dimensions) <= 6 and state.bond_dimensions[1:6] == [2, 3, 3, 3, 3]
+  with pytest.raises(ValueError):
+    state.position(8)
+
+
+@pytest.mark.parametrize("n", [4, 6, 7])
+def test_dmrg_ground_energy_vs_exact(n):
+  # dmrg_test.py:160-191
+  be = orc.OracleBackend()
+  eta = np.linalg.eigvalsh(xxz_dense(n, 1.0, 1.0, 0.0))
+  mpo = tmps.xxz_mpo(be, np.ones(n - 1), np.ones(n - 1), np.zeros(n))
+  state = tmps.FiniteMPS.random([2] * n, [32] * (n - 1), np.float64, be, seed=16)
+  e1 = tmps.FiniteDMRG(state, mpo).run_one_site(num_sweeps=4, num_krylov_vecs=10)
+  np.testing.assert_allclose(e1, eta[0], atol=1e-7)
+  state = tmps.FiniteMPS.random([2] * n, [32] * (n - 1), np.float64, be, seed=17)
+  dmrg = tmps.FiniteDMRG(state, mpo)
+  e2 = dmrg.run_two_site(max_bond_dim=32, num_sweeps=4, num_krylov_vecs=10)
+  np.testing.assert_allclose(e2, eta[0], atol=1e-7)
+  np.testing.assert_allclose(dmrg.run_two_site(max_bond_dim=32, num_sweeps=0), e2, atol=1e-7)
+  np.testing.assert_allclose(dmrg.compute_energy(), eta[0], atol=1e-7)
+
+
+def test_two_site_gate_and_local_measurement():
+  be = orc.OracleBackend()
+  n = 6
+  state = tmps.FiniteMPS.random([2] * n, [8] * (n - 1), np.float64, be, seed=5)
+  sz = np.diag([-0.5, 0.5])
+  before = state.measure_local_operator([sz] * n, range(n))
+  # identity gate changes nothing; SWAP exchanges the two local expectation values
+  state.position(2)
+  ident = np.eye(4).reshape(2, 2, 2, 2)
+  state.apply_two_site_gate(ident, 2, 3)
+  np.testing.assert_allclose(state.measure_local_operator([sz] * n, range(n)), before, atol=1e-12)
+  swap = np.zeros((2, 2, 2, 2))
+  for a in range(2):
+    for b in range(2):
+      swap[b, a, a, b] = 1.0
+  state.position(2)
+  state.apply_two_site_gate(swap, 2, 3)
+  after = state.measure_local_operator([sz] * n, range(n))
+  np.testing.assert_allclose([after[3], after[2]], [before[2], before[3]], atol=1e-10)
