@@ -139,6 +139,14 @@ int tnh_gemm_ex(int in_dtype, int out_dtype, int transA, int transB, int64_t M,
                 int64_t ldb, void* C, int64_t ldc, int64_t batch, int64_t strideA,
                 int64_t strideB, int64_t strideC, double alpha, double beta);
 
+/* dst (2K x 2N reals, row-major) = 2x2-block real expansion of the complex K x N operand
+ * src (element (k, n) at src[k * row_stride + n * col_stride], strides in complex elements):
+ * [[re, im], [-im, re]] per element (conj != 0 conjugates first).  With it a complex product
+ * with a row-major left operand is ONE real tnh_gemm on the interleaved images of A and C
+ * (M x 2K times 2K x 2N): complex64 / complex128 tensordot on the f32 / f64 matrix cores. */
+int tnh_complex_expand(void* dst, const void* src, int64_t K, int64_t N,
+                       int64_t row_stride, int64_t col_stride, int conj, int dtype);
+
 /* Name of the kernel variant the last tnh_gemm call dispatched to. */
 const char* tnh_gemm_last_kernel(void);
 /* Force a variant ("auto", "generic", "valu", "bf16_128", "bf16_256"): used by

@@ -69,6 +69,7 @@ SIGNATURES = {
     "tnh_gemm_ex": (c_int, [c_int, c_int, c_int, c_int, c_int64, c_int64, c_int64,
                             c_void_p, c_int64, c_void_p, c_int64, c_void_p,
                             c_int64, c_int64, c_int64, c_int64, c_int64, c_double, c_double]),
+    "tnh_complex_expand": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_int, c_int]),
     "tnh_gemm_last_kernel": (c_char_p, []),
     "tnh_gemm_set_variant": (c_int, [c_char_p]),
     "tnh_trace_last2": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64,

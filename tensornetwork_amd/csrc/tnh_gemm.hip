@@ -320,6 +320,31 @@ __global__ __launch_bounds__(256) void gemm_valu_kernel(GemmArgs g) {
     }
 }
 
+// ------------------------------------------------------- complex via real MFMA
+// A complex product C = A B equals the REAL product  C_r = A_r B'  where A_r (M x 2K) and
+// C_r (M x 2N) are the interleaved (re, im) images of row-major A and C -- i.e. their own
+// memory, zero copy -- and B' (2K x 2N) is the 2x2-block expansion of B:
+//     B'[2k][2n] = re,  B'[2k][2n+1] = im,  B'[2k+1][2n] = -im,  B'[2k+1][2n+1] = re.
+// One expansion pass over B puts complex64 / complex128 contractions on the f32 / f64
+// matrix cores with exactly the 8 M N K real flops a complex GEMM needs.
+template <typename R>
+__global__ __launch_bounds__(256) void complex_expand_kernel(R* __restrict__ dst, const R* __restrict__ src,
+                                                             int64_t K, int64_t N, int64_t rs, int64_t cs,
+                                                             int conj) {
+  const int64_t total = K * N;
+  const int64_t step = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += step) {
+    const int64_t k = e / N, n = e - k * N;
+    const R re = src[2 * (k * rs + n * cs)];
+    R im = src[2 * (k * rs + n * cs) + 1];
+    if (conj) im = -im;
+    R* d0 = dst + (2 * k) * (2 * N) + 2 * n;
+    R* d1 = d0 + 2 * N;
+    d0[0] = re;  d0[1] = im;
+    d1[0] = -im; d1[1] = re;
+  }
+}
+
 static thread_local const char* g_last_kernel = "none";
 static int g_variant = 0;  // 0 auto, 1 generic (mfma), 2 valu, 3 bf16_128, 4 bf16_256, 5 bf16_256pp,
                            // 6 bf16_ragged (auto shape), 7 .._128x128, 8 .._64x256, 9 .._256x64
@@ -374,6 +399,25 @@ int tnh_gemm_set_variant(const char* full) {
     set_error("unknown gemm variant '%s'", name);
     return TNH_ERR_INVALID;
   }
+  return TNH_OK;
+}
+
+int tnh_complex_expand(void* dst, const void* src, int64_t K, int64_t N, int64_t row_stride,
+                       int64_t col_stride, int conj, int dtype) {
+  TNH_NEED_INIT();
+  TNH_REQUIRE(dtype == TNH_C64 || dtype == TNH_C128, "tnh_complex_expand needs a complex dtype (got %d)", dtype);
+  TNH_REQUIRE(K >= 0 && N >= 0, "negative extent");
+  if (K == 0 || N == 0) return TNH_OK;
+  TNH_REQUIRE(dst && src, "null pointer");
+  int64_t blocks = (K * N + 255) / 256;
+  if (blocks > 65536) blocks = 65536;
+  if (dtype == TNH_C64)
+    hipLaunchKernelGGL((complex_expand_kernel<float>), dim3((unsigned)blocks), dim3(256), 0, stream(), (float*)dst,
+                       (const float*)src, K, N, row_stride, col_stride, conj);
+  else
+    hipLaunchKernelGGL((complex_expand_kernel<double>), dim3((unsigned)blocks), dim3(256), 0, stream(), (double*)dst,
+                       (const double*)src, K, N, row_stride, col_stride, conj);
+  TNH_LAUNCH_CHECK();
   return TNH_OK;
 }
 

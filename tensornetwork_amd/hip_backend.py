@@ -370,8 +370,32 @@ class HipBackend(BackendBase):
     trans_b = b_form == "NK"
     lda = m if trans_a else k
     ldb = k if trans_b else n
+    if code in _REAL_OF and 8 * m * n * k >= (1 << 18):
+      return self._complex_gemm(a, b, trans_a, trans_b, m, n, k).view(out_shape)
     out = self._gemm(a, b, trans_a, trans_b, m, n, k, lda, ldb)
     return out.view(out_shape)
+
+  def _complex_gemm(self, a, b, trans_a, trans_b, m, n, k):
+    """complex64 / complex128 product on the f32 / f64 matrix cores: the interleaved (re, im)
+    memory of a row-major A (M x K) and of C (M x N) are real M x 2K / M x 2N matrices, and
+    C_r = A_r B' with B' the 2x2-block real expansion of B (tnh_complex_expand) -- one extra
+    pass over B, then ONE real GEMM with the 8 M N K flops a complex GEMM needs."""
+    code = a.code
+    real = _REAL_OF[code]
+    if trans_a:   # A must be row-major M x K for the zero-copy real image
+      a = self.transpose(a.view((k, m)), (1, 0))
+    bexp = DeviceTensor.empty((2 * k, 2 * n), real)
+    rs, cs = (1, k) if trans_b else (n, 1)
+    _lib.check(self.lib.tnh_complex_expand(_vp(bexp), _vp(b), k, n, rs, cs, 0, code), "tnh_complex_expand")
+    out = DeviceTensor.empty((m, n), code)
+    events = getattr(self, "gemm_events", None)
+    if events is not None:
+      start = _lib.Event().record()
+    _lib.check(self.lib.tnh_gemm(real, real, 0, 0, m, 2 * n, 2 * k, _vp(a), 2 * k, _vp(bexp), 2 * n,
+                                 _vp(out), 2 * n, 1, 0, 0, 0), "tnh_gemm")
+    if events is not None:
+      events.append((start, _lib.Event().record()))
+    return out
 
   def _outer(self, a, b, out_shape):
     m, n = a.size, b.size

@@ -243,6 +243,17 @@ def test_gemm_bf16_auto_dispatch_uses_speed_path(hip):
   np.testing.assert_allclose(np.asarray(out), ref, rtol=1.6e-2, atol=1.6e-2 * 16)
 
 
+@pytest.mark.parametrize("dtype,kernel,tol", [(np.complex64, "mfma_f32_128x128x16", 3e-6), (np.complex128, "mfma_f64_64x64x16", 1e-14)])
+@pytest.mark.parametrize("ta_,tb_", [(0, 0), (0, 1), (1, 0), (1, 1)])
+def test_gemm_complex_on_matrix_cores(hip, dtype, kernel, tol, ta_, tb_):
+  """complex64 / complex128 contraction = one real MFMA GEMM on the interleaved images of A and C
+  against the 2x2-block real expansion of B (tnh_complex_expand), every storage layout."""
+  for (m, n, k) in [(200, 136, 96), (64, 257, 33), (512, 384, 256)]:
+    out, ref, name, sk = _gemm_case(hip, dtype, m, n, k, ta_, tb_, rng=np.random.default_rng(m + n + k))
+    assert name == kernel, name
+    np.testing.assert_allclose(out, ref, rtol=tol * sk * 4, atol=tol * k * 2)
+
+
 def test_tensordot_golden(hip, golden):
   for case in golden.cases["tensordot"]:
     C.assert_close(C.run_tensordot(hip, golden, case), golden[case["out"]])

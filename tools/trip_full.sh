@@ -1,0 +1,10 @@
+#!/bin/bash
+# full GPU suite + smoke + bench (round-end rehearsal)
+set -u
+export TMPDIR=/tmp
+mkdir -p gpurun_out
+timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke.log 2>&1; echo "smoke rc=$?"; tail -2 gpurun_out/smoke.log
+timeout 1500 python -m pytest tests -m gpu -q -x --timeout 600 > gpurun_out/pytest_gpu.log 2>&1; echo "pytest rc=$?"
+tail -15 gpurun_out/pytest_gpu.log
+timeout 900 python bench.py ${BENCH_ARGS:-} > gpurun_out/bench.json 2> gpurun_out/bench.err; echo "bench rc=$?"
+cat gpurun_out/bench.json; tail -5 gpurun_out/bench.err
