@@ -22,6 +22,10 @@ Extra objects on the same line:
   svd            -- split_node truncated SVD (configs[2]: (16,)*6 node -> 4096 x 4096,
                     keep 256) in the metric's GB/s, with the oracle's LAPACK SVD timed
                     on a bounded sample beside it.
+  bond_sweep     -- the metric's bond-dimension sweep: contract_between of two rank-4 bf16
+                    nodes at D = 32 .. 256 in the favourable (L0) and the permute-needing (L1) layout,
+                    plus the north-star "D = 512" row A(64,128,512,512) . B(512,512,128,64)
+                    (GEMM 8192 x 8192 x 262144), whole-path TFLOP/s each.
   sliced_network -- the north-star scaling network (64-node random 3-regular graph, bond
                     D, bf16): bond-sliced greedy contraction, slices dealt over the N
                     ranks, ONE all-reduce of the scalar (strong scaling: fixed total work).
@@ -53,6 +57,7 @@ def parse_args():
                  help="bond dimension of the 64-node random-regular network (0 = skip)")
   p.add_argument("--rr-min-slices", type=int, default=64)
   p.add_argument("--no-cpu-baseline", action="store_true")
+  p.add_argument("--no-sweep", action="store_true", help="skip the bond-dimension sweep rows")
   p.add_argument("--fill", default="normal", choices=["normal", "zeros"],
                  help="operand fill (zeros shows the DVFS-inflated number; never the headline)")
   return p.parse_args()
@@ -219,6 +224,45 @@ def sliced_network_bench(ta, be, dist, rank, world, D, min_slices):
           "result": float(np.asarray(out).reshape(-1)[0])}
 
 
+def bond_sweep(ta, be):
+  """Whole-path TFLOP/s of contract_between over the bond-dimension sweep (rank 0, N = 1 only)."""
+  rows = []
+  for D in (32, 64, 96, 128, 192, 256):
+    A, B = make_nodes(ta, be, D, "L0", seed=7, fill="normal")
+    for layout in ("L0", "L1"):
+      reps = 3 if D >= 192 else 10
+      one_step(ta, be, A, B, layout)
+      be.synchronize()
+      t0 = time.perf_counter()
+      for _ in range(reps):
+        out = one_step(ta, be, A, B, layout)
+        del out
+      be.synchronize()
+      t = (time.perf_counter() - t0) / reps
+      rows.append({"D": D, "layout": layout, "gemm": [D * D] * 3, "ms": t * 1e3, "tflops": 2.0 * D**6 / t / 1e12,
+                   "kernel": be.lib.tnh_gemm_last_kernel().decode()})
+    del A, B
+  # north-star row: two shared D = 512 bonds, M = N = 8192, K = 262144
+  A = be.device_random((64, 128, 512, 512), dtype=ta.bfloat16, seed=11, normal=True, a=0.0, b=1.0 / 512)
+  B = be.device_random((512, 512, 128, 64), dtype=ta.bfloat16, seed=12, normal=True, a=0.0, b=1.0 / 512)
+  def step():
+    a, b = ta.Node(A, backend=be), ta.Node(B, backend=be)
+    a[2] ^ b[0]  # pylint: disable=pointless-statement
+    a[3] ^ b[1]  # pylint: disable=pointless-statement
+    return ta.contract_between(a, b)
+  step()
+  be.synchronize()
+  t0 = time.perf_counter()
+  for _ in range(3):
+    out = step()
+    del out
+  be.synchronize()
+  t = (time.perf_counter() - t0) / 3
+  rows.append({"D": 512, "layout": "A(64,128,512,512).B(512,512,128,64)", "gemm": [8192, 8192, 262144], "ms": t * 1e3,
+               "tflops": 2.0 * 8192 * 8192 * 262144 / t / 1e12, "kernel": be.lib.tnh_gemm_last_kernel().decode()})
+  return rows
+
+
 def load_traffic(kernel_name, M, N, K):
   """HBM bytes per launch of the headline kernel from the committed rocprofv3 PMC pass."""
   import glob  # pylint: disable=import-outside-toplevel
@@ -302,6 +346,12 @@ def main():
       sliced = {"error": f"{type(exc).__name__}: {exc}"}
     result["sliced_network"] = sliced
   if rank == 0:
+    if world == 1 and not args.no_sweep:
+      try:
+        result["bond_sweep"] = bond_sweep(ta, be)
+      except Exception as exc:  # pylint: disable=broad-except
+        result["bond_sweep"] = {"error": f"{type(exc).__name__}: {exc}"}
+      _lib.check(be.lib.tnh_trim())
     if world == 1 and args.svd_n > 0:
       svd_bench(ta, be, args.svd_n, max(args.svd_n // 16, 1))  # warm-up
       result["svd"] = svd_bench(ta, be, args.svd_n, max(args.svd_n // 16, 1))
