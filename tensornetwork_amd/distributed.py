@@ -33,6 +33,9 @@ class LocalComm:
   def all_reduce_sum(self, backend, tensor):  # pylint: disable=unused-argument
     return tensor
 
+  def all_gather_rows(self, backend, tensor, rows_per_rank):  # pylint: disable=unused-argument
+    return tensor
+
 
 class TorchDistComm:
   """all-reduce through an initialised ``torch.distributed`` process group.
@@ -48,6 +51,12 @@ class TorchDistComm:
     self._dist = dist
     self.rank = dist.get_rank()
     self.world = dist.get_world_size()
+
+  def all_gather_counts(self, n):
+    """Every rank's integer (host-side metadata exchange)."""
+    outs = [None] * self.world
+    self._dist.all_gather_object(outs, int(n))
+    return [int(x) for x in outs]
 
   def all_reduce_sum(self, backend, tensor):
     import torch  # pylint: disable=import-outside-toplevel
@@ -67,11 +76,58 @@ class TorchDistComm:
     return t.numpy().reshape(host.shape)
 
 
+  def all_gather_rows(self, backend, tensor, rows_per_rank):
+    """Concatenate the ranks' row blocks (leading axis) of a sharded result: ONE all-gather.
+
+    Blocks are padded to the largest block so that the collective is the plain
+    equal-size all-gather (RCCL's fast path); ``rows_per_rank`` lists every rank's
+    true row count."""
+    import torch  # pylint: disable=import-outside-toplevel
+    from tensornetwork_amd.device_tensor import DeviceTensor  # pylint: disable=import-outside-toplevel
+    rows = [int(r) for r in rows_per_rank]
+    pad = max(rows)
+    tail = tuple(tensor.shape[1:])
+    if isinstance(tensor, DeviceTensor):
+      full = DeviceTensor.empty((self.world * pad,) + tail, tensor.code)
+      mine = tensor
+      if rows[self.rank] != pad:
+        mine = DeviceTensor.empty((pad,) + tail, tensor.code)
+        backend.lib.tnh_memset(ctypes_ptr(mine), 0, mine.nbytes)
+        backend.copy_rows_into(mine, tensor, 0)
+      backend.synchronize()
+      dev = f"cuda:{torch.cuda.current_device()}"
+      src = torch.as_tensor(_CudaView(mine, raw=True), device=dev)
+      dst = torch.as_tensor(_CudaView(full, raw=True), device=dev)
+      self._dist.all_gather_into_tensor(dst, src)
+      torch.cuda.synchronize()
+      if all(r == pad for r in rows):
+        return full
+      parts = [backend.getitem(full, slice(k * pad, k * pad + rows[k])) for k in range(self.world)]
+      return backend.concat_rows(parts)
+    host = np.ascontiguousarray(np.asarray(tensor))
+    buf = np.zeros((pad,) + tail, dtype=host.dtype)
+    buf[:rows[self.rank]] = host
+    src = torch.from_numpy(buf.view(np.uint8).reshape(-1).copy())
+    outs = [torch.empty_like(src) for _ in range(self.world)]
+    self._dist.all_gather(outs, src)
+    blocks = [o.numpy().view(host.dtype).reshape((pad,) + tail)[:rows[k]] for k, o in enumerate(outs)]
+    return np.concatenate(blocks, axis=0)
+
+
+def ctypes_ptr(tensor):
+  import ctypes  # pylint: disable=import-outside-toplevel
+  return ctypes.c_void_p(tensor.ptr)
+
+
 class _CudaView:
   """Exposes a DeviceTensor through ``__cuda_array_interface__`` (zero-copy)."""
 
-  def __init__(self, tensor):
+  def __init__(self, tensor, raw=False):
     self._keep = tensor
+    if raw:   # byte view: lets dtypes torch does not know (bf16 tag, complex) ride a collective
+      self.__cuda_array_interface__ = {"shape": (int(tensor.nbytes),), "typestr": "|u1",
+                                       "data": (tensor.ptr, False), "version": 2, "strides": None}
+      return
     self.__cuda_array_interface__ = {
         "shape": tuple(tensor.shape) if tensor.shape else (1,),
         "typestr": np.dtype(tensor.dtype).str,
@@ -234,3 +290,53 @@ def slicing_report(nodes: Sequence[network.Node], cut_edges: Sequence[network.Ed
   return {"n_slices": n_slices, "flops_unsliced": float(flops0), "peak_unsliced": float(peak0),
           "flops_per_slice": float(flops1), "peak_per_slice": float(peak1),
           "overhead": float(flops1) * n_slices / max(float(flops0), 1.0)}
+
+
+# ------------------------------------------------------- one very large pairwise contraction
+def shard_rows(n_rows: int, world: int) -> List[Tuple[int, int]]:
+  """[start, stop) of every rank's block of a leading axis of length n_rows (balanced, contiguous)."""
+  base, extra = divmod(int(n_rows), int(world))
+  out, start = [], 0
+  for r in range(world):
+    stop = start + base + (1 if r < extra else 0)
+    out.append((start, stop))
+    start = stop
+  return out
+
+
+def tensordot_sharded(backend, a, b, axes, comm=None, a_is_local=False, gather=True):
+  """One big ``tensordot`` spread over the ranks by the FIRST free axis of ``a`` (the M side of
+  the flattened GEMM): rank r contracts rows [start_r, stop_r) of ``a`` with all of ``b`` on its
+  own GPU -- no exchange during the contraction -- and the row blocks of the result are
+  concatenated by ONE all-gather (RCCL over xGMI) only if the consumer needs the whole tensor
+  (``gather=True``); otherwise every rank keeps its block.  K is never sharded: a K split would
+  all-reduce the full M x N fp32 result (17 GB at D = 256) over 153 GB/s links.
+
+  ``a`` is either the full operand (replicated; each rank slices its block) or, with
+  ``a_is_local=True``, already this rank's block along that axis.  Requires the first axis of
+  ``a`` to be a free (uncontracted) axis.  Returns ``(tensor, (start, stop))``."""
+  comm = comm or LocalComm()
+  shape_a = tuple(backend.shape_tuple(a))
+  try:
+    iter(axes)
+    axes_a = axes[0]
+    axes_a = [int(x) for x in axes_a] if hasattr(axes_a, "__iter__") else [int(axes_a)]
+  except TypeError:
+    axes_a = list(range(len(shape_a) - int(axes), len(shape_a)))
+  if 0 in [x % max(len(shape_a), 1) for x in axes_a]:
+    raise ValueError("tensordot_sharded shards the first axis of `a`, which must not be contracted")
+  if a_is_local:
+    counts = comm.all_gather_counts(shape_a[0]) if hasattr(comm, "all_gather_counts") else [shape_a[0]]
+    start = sum(counts[:comm.rank])
+    bounds = (start, start + shape_a[0])
+    local = a
+  else:
+    blocks = shard_rows(shape_a[0], comm.world)
+    counts = [e - s for s, e in blocks]
+    bounds = blocks[comm.rank]
+    local = backend.slice(a, (bounds[0],) + (0,) * (len(shape_a) - 1),
+                          (bounds[1] - bounds[0],) + shape_a[1:])
+  part = backend.tensordot(local, b, axes)
+  if not gather or comm.world == 1:
+    return part, bounds
+  return comm.all_gather_rows(backend, part, counts), (0, sum(counts))

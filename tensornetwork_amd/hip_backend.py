@@ -213,6 +213,26 @@ class HipBackend(BackendBase):
     _lib.check(self.lib.tnh_d2d(_vp(out), _vp(tensor), out.nbytes), "tnh_d2d")
     return out
 
+  def copy_rows_into(self, out, tensor, row0):
+    """out[row0 : row0 + tensor.shape[0]] = tensor (leading-axis block copy, device to device)."""
+    tensor = self._as_tensor(tensor)
+    if out.code != tensor.code or tuple(out.shape[1:]) != tuple(tensor.shape[1:]) or \
+        row0 < 0 or row0 + tensor.shape[0] > out.shape[0]:
+      raise ValueError("copy_rows_into: block does not fit")
+    row_bytes = _prod(out.shape[1:]) * out.itemsize
+    _lib.check(self.lib.tnh_d2d(ctypes.c_void_p(out.ptr + row0 * row_bytes), _vp(tensor), tensor.nbytes), "tnh_d2d")
+    return out
+
+  def concat_rows(self, tensors):
+    """Concatenate along the leading axis (device-to-device block copies)."""
+    tensors = [self._as_tensor(t) for t in tensors]
+    out = DeviceTensor.empty((sum(t.shape[0] for t in tensors),) + tuple(tensors[0].shape[1:]), tensors[0].code)
+    row = 0
+    for t in tensors:
+      self.copy_rows_into(out, t, row)
+      row += t.shape[0]
+    return out
+
   def slice(self, tensor, start_indices, slice_sizes):
     # numpy_backend.py:64-72
     if len(start_indices) != len(slice_sizes):

@@ -71,6 +71,61 @@ def _worker(rank, world, port, out_path):
   dist.destroy_process_group()
 
 
+def _worker_sharded(rank, world, port, out_path):
+  os.environ["MASTER_ADDR"] = "127.0.0.1"
+  os.environ["MASTER_PORT"] = str(port)
+  sys.path.insert(0, os.path.dirname(HERE))
+  sys.path.insert(0, HERE)
+  import torch.distributed as dist
+  dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+  be = OracleBackend()
+  rng = np.random.default_rng(3)
+  a = rng.standard_normal((7, 4, 5, 6))          # 7 rows over 2 ranks: uneven blocks (4 + 3)
+  b = rng.standard_normal((6, 5, 3, 2))
+  comm = distributed.TorchDistComm()
+  full, bounds = distributed.tensordot_sharded(be, a, b, [[3, 2], [0, 1]], comm=comm)
+  part, pb = distributed.tensordot_sharded(be, a, b, [[3, 2], [0, 1]], comm=comm, gather=False)
+  lo, hi = distributed.shard_rows(7, world)[rank]
+  full2, _ = distributed.tensordot_sharded(be, a[lo:hi], b, [[3, 2], [0, 1]], comm=comm, a_is_local=True)
+  np.savez(out_path + f".{rank}.npz", full=np.asarray(full), part=np.asarray(part), pb=np.asarray(pb),
+           full2=np.asarray(full2))
+  dist.barrier()
+  dist.destroy_process_group()
+
+
+def test_sharded_tensordot_two_processes_gloo(tmp_path):
+  """M-sharded pairwise contraction, one all-gather of the result."""
+  import torch.multiprocessing as mp
+  with socket.socket() as s:
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+  out_path = str(tmp_path / "res")
+  mp.spawn(_worker_sharded, args=(2, port, out_path), nprocs=2, join=True)
+  rng = np.random.default_rng(3)
+  a = rng.standard_normal((7, 4, 5, 6))
+  b = rng.standard_normal((6, 5, 3, 2))
+  ref = np.tensordot(a, b, [[3, 2], [0, 1]])
+  for r in range(2):
+    got = np.load(out_path + f".{r}.npz")
+    np.testing.assert_allclose(got["full"], ref, rtol=1e-12)
+    np.testing.assert_allclose(got["full2"], ref, rtol=1e-12)
+    lo, hi = got["pb"]
+    assert (lo, hi) == distributed.shard_rows(7, 2)[r]
+    np.testing.assert_allclose(got["part"], ref[lo:hi], rtol=1e-12)
+
+
+def test_sharded_tensordot_single_process_and_errors():
+  be = OracleBackend()
+  rng = np.random.default_rng(4)
+  a, b = rng.standard_normal((5, 6)), rng.standard_normal((6, 3))
+  out, bounds = distributed.tensordot_sharded(be, a, b, 1)
+  np.testing.assert_allclose(out, a @ b)
+  assert bounds == (0, 5)
+  assert distributed.shard_rows(10, 4) == [(0, 3), (3, 6), (6, 8), (8, 10)]
+  with pytest.raises(ValueError):
+    distributed.tensordot_sharded(be, a, b, [[0], [0]])
+
+
 def test_sliced_two_processes_gloo(tmp_path):
   import torch.multiprocessing as mp
   with socket.socket() as s:
