@@ -254,6 +254,63 @@ def test_gemm_complex_on_matrix_cores(hip, dtype, kernel, tol, ta_, tb_):
     np.testing.assert_allclose(out, ref, rtol=tol * sk * 4, atol=tol * k * 2)
 
 
+# tolerance ladder of the reference's own property test (backends/tensorflow/tensordot2_test.py:143-159):
+# fp16 0.05, fp32 / complex64 1e-5, else 1e-12 -- bf16 gets 2^-6 (one bit less mantissa than fp16's 0.05 class)
+_TD_TOL = {np.float16: 5e-2, ta.bfloat16: 8e-2, np.float32: 1e-5, np.complex64: 1e-5, np.float64: 1e-12,
+           np.complex128: 1e-12}
+
+
+@pytest.mark.parametrize("dtype", [np.float16, ta.bfloat16, np.float32, np.float64, np.complex64, np.complex128])
+def test_tensordot_random_axes_property(hip, dtype):
+  """tensordot2_test.py:163-207 restated for the hip backend: random ranks (1-4), dims (1-9, plus a few
+  larger ones so the matrix-core kernels and every layout branch of the lowering are hit), random
+  axes subsets and scalar `axes`, against np.tensordot on the same (rounded) inputs."""
+  rng = np.random.default_rng(hash(str(dtype)) % 1000)
+  tol = _TD_TOL[dtype]
+  cplx = dtype in (np.complex64, np.complex128)
+  for trial in range(60):
+    big = trial % 5 == 0
+    rank_a, rank_b = int(rng.integers(1, 5)), int(rng.integers(1, 5))
+    nc = int(rng.integers(0, min(rank_a, rank_b) + 1))
+    hi = 40 if big else 10
+    cdims = [int(rng.integers(1, hi)) for _ in range(nc)]
+    shape_a = [int(rng.integers(1, hi)) for _ in range(rank_a)]
+    shape_b = [int(rng.integers(1, hi)) for _ in range(rank_b)]
+    axes_a = sorted(rng.choice(rank_a, nc, replace=False).tolist())
+    axes_b = rng.choice(rank_b, nc, replace=False).tolist()
+    rng.shuffle(axes_a)
+    for d, (xa, xb) in zip(cdims, zip(axes_a, axes_b)):
+      shape_a[xa] = d
+      shape_b[xb] = d
+    free = int(np.prod(shape_a)) // max(int(np.prod(cdims)), 1) * (int(np.prod(shape_b)) // max(int(np.prod(cdims)), 1))
+    if max(int(np.prod(shape_a)), int(np.prod(shape_b)), free) > 300_000:
+      continue   # keep every operand and the result small: this is a parity test, not a stress test
+    a = rng.standard_normal(shape_a) + (1j * rng.standard_normal(shape_a) if cplx else 0)
+    b = rng.standard_normal(shape_b) + (1j * rng.standard_normal(shape_b) if cplx else 0)
+    if dtype is ta.bfloat16:
+      a, b = orc.round_bf16(a), orc.round_bf16(b)
+      da, db = hip.to_bfloat16(a), hip.to_bfloat16(b)
+    else:
+      a, b = a.astype(dtype), b.astype(dtype)
+      da, db = dev(hip, a), dev(hip, b)
+    ref = np.tensordot(a.astype(np.complex128 if cplx else np.float64), b.astype(np.complex128 if cplx else np.float64),
+                       [axes_a, axes_b])
+    out = np.asarray(hip.tensordot(da, db, [axes_a, axes_b]))
+    k = max(int(np.prod(cdims)), 1)
+    assert out.shape == ref.shape, (shape_a, shape_b, axes_a, axes_b)
+    np.testing.assert_allclose(out, ref, rtol=tol, atol=tol * np.sqrt(k) * 4,
+                               err_msg=f"{shape_a} {shape_b} {axes_a} {axes_b} {hip.lib.tnh_gemm_last_kernel().decode()}")
+  # scalar axes (tensordot2_test.py:163-184): last n of a with first n of b
+  for n in (0, 1, 2):
+    a = rng.standard_normal((3, 4, 5)).astype(np.float32 if dtype is ta.bfloat16 else dtype)
+    b = rng.standard_normal((4, 5, 6)[2 - n:] + (7,) if n else (2, 3)).astype(a.dtype)
+    if n:
+      b = rng.standard_normal(a.shape[3 - n:] + (7,)).astype(a.dtype)
+    out = np.asarray(hip.tensordot(dev(hip, a), dev(hip, b), n))
+    np.testing.assert_allclose(out, np.tensordot(a.astype(np.float64) if not cplx else a, b.astype(np.float64) if not cplx else b, n),
+                               rtol=max(tol, 1e-5), atol=max(tol, 1e-5) * 10)
+
+
 def test_tensordot_golden(hip, golden):
   for case in golden.cases["tensordot"]:
     C.assert_close(C.run_tensordot(hip, golden, case), golden[case["out"]])
