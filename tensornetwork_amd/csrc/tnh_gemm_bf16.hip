@@ -185,9 +185,10 @@ __device__ __forceinline__ f32x16 mma32(const uint4& a, const uint4& b, f32x16 c
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(*(const f16x8*)&a, *(const f16x8*)&b, c, 0, 0, 0);
 }
 
-template <bool IS_BF16, bool OUT_F32, bool TWO>
+template <bool IS_BF16, bool OUT_F32, bool TWO, bool M32 = false>
 __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(NtArgs p) {
-  constexpr bool M32 = false;  // 32x32x16 MFMA lost the A/B (only 2 independent accumulators per phase)
+  // M32 (32x32x16 MFMA) lost the A/B with 4 phases per K-tile (only 2 independent accumulators per
+  // phase); variant ":p3" re-tests it with the 2-phase schedule (4 independent accumulators).
   constexpr int BM = 256, BN = 256, BK = 64;
   constexpr int HALF_BYTES = 128 * BK * 2;   // 16 KiB
   constexpr int BUF_BYTES = 4 * HALF_BYTES;  // A0 A1 B0 B1
@@ -459,7 +460,7 @@ static int launch_nt(bool is_bf16, bool out_f32, NtArgs p, int64_t batch) {
   return TNH_OK;
 }
 
-static int launch_pp(bool is_bf16, bool out_f32, bool two, NtArgs p, int64_t batch) {
+static int launch_pp(bool is_bf16, bool out_f32, bool two, NtArgs p, int64_t batch, bool m32 = false) {
   p.tiles_m = (int)((p.M + 255) / 256);
   p.tiles_n = (int)((p.N + 255) / 256);
   const int64_t nwg = (int64_t)p.tiles_m * p.tiles_n;
@@ -472,10 +473,11 @@ static int launch_pp(bool is_bf16, bool out_f32, bool two, NtArgs p, int64_t bat
     q.B = p.B + b0 * p.sB;
     q.C = (char*)p.C + b0 * p.sC * esz_out;
     const dim3 grid((unsigned)nwg, (unsigned)nb), block(512);
-#define TNH_PP_LAUNCH(B16, O32)                                                                        \
-  do {                                                                                                \
-    if (two) hipLaunchKernelGGL((gemm_nt_pp_kernel<B16, O32, true>), grid, block, 0, stream(), q);    \
-    else hipLaunchKernelGGL((gemm_nt_pp_kernel<B16, O32, false>), grid, block, 0, stream(), q);       \
+#define TNH_PP_LAUNCH(B16, O32)                                                                               \
+  do {                                                                                                       \
+    if (m32) hipLaunchKernelGGL((gemm_nt_pp_kernel<B16, O32, true, true>), grid, block, 0, stream(), q);      \
+    else if (two) hipLaunchKernelGGL((gemm_nt_pp_kernel<B16, O32, true>), grid, block, 0, stream(), q);      \
+    else hipLaunchKernelGGL((gemm_nt_pp_kernel<B16, O32, false>), grid, block, 0, stream(), q);              \
   } while (0)
     if (is_bf16) {
       if (out_f32) TNH_PP_LAUNCH(true, true);
@@ -533,7 +535,7 @@ int gemm_bf16_fast(int in_dt, int out_dt, int variant, int transA, int transB, i
   if (variant == 4) big = true;
   if (variant == 5 || (big && variant == 0 && g_pp_default)) {
     *name = "bf16_nt_256x256x64_pp";
-    return launch_pp(is_bf16, out_f32, g_opt_phases != 4, p, batch);
+    return launch_pp(is_bf16, out_f32, g_opt_phases != 4, p, batch, g_opt_phases == 3);
   }
   if (big) {
     *name = "bf16_nt_256x256x64";

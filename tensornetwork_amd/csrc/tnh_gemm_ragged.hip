@@ -23,6 +23,7 @@ namespace tnh {
 
 extern int g_opt_phases;  // A/B knob (tnh_gemm_set_variant ":p<d>"): p1 disables the small-K variant
 #define g_opt_smallk (g_opt_phases != 1)
+#define g_opt_persist (g_opt_phases != 5)   // ":p5" = one block per tile (A/B)
 extern int g_opt_raster;  // ":r2" disables the LDS-staged epilogue (A/B)
 
 // 8 consecutive k of one operand row -> one 16-B register chunk (zero past K).
@@ -60,7 +61,7 @@ __device__ __forceinline__ uint4 load_chunk8(const uint16_t* p, int64_t krem, in
 // ALL K-tiles are requested up front into registers and passed through ONE LDS stage
 // (half the LDS, twice the resident blocks) instead of the load / compute ring.
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool IS_BF16, bool OUT_F32, bool SMALLK>
-__global__ __launch_bounds__(256) void gemm_nt_ragged_kernel(NtArgs p) {
+__device__ __forceinline__ void ragged_one_tile(const NtArgs& p, int tile, char* smem) {
   static_assert(WAVES_M * WAVES_N == 4, "256 threads");
   constexpr int BK = 64;
   constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
@@ -71,9 +72,6 @@ __global__ __launch_bounds__(256) void gemm_nt_ragged_kernel(NtArgs p) {
   constexpr int KT_MAX = 3;  // SMALLK: K-tiles held in registers
   // epilogue staging image (half-precision output): BM rows of BN elements + 16 B pad
   constexpr int EPI_PITCH = BN * 2 + 16;
-  constexpr int EPI_BYTES = OUT_F32 ? 0 : BM * EPI_PITCH;
-  constexpr int LOOP_BYTES = (SMALLK ? 1 : 2) * STAGE_BYTES;
-  __shared__ __attribute__((aligned(1024))) char smem[LOOP_BYTES > EPI_BYTES ? LOOP_BYTES : EPI_BYTES];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -81,7 +79,7 @@ __global__ __launch_bounds__(256) void gemm_nt_ragged_kernel(NtArgs p) {
   const int wm = wid / WAVES_N, wn = wid % WAVES_N;
 
   int tm, tn;
-  tile_of_block(blockIdx.x, p.tiles_m, p.tiles_n, 0, tm, tn);
+  tile_of_block(tile, p.tiles_m, p.tiles_n, 0, tm, tn);
   const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
   const uint16_t* A = p.A + (int64_t)blockIdx.y * p.sA;
   const uint16_t* B = p.B + (int64_t)blockIdx.y * p.sB;
@@ -236,6 +234,26 @@ __global__ __launch_bounds__(256) void gemm_nt_ragged_kernel(NtArgs p) {
   store_wave_tile<IS_BF16, OUT_F32, FM, FN>(acc, p, Cb, m0, n0, BM, BN, wm * WTM, wn * WTN, lane);
 }
 
+
+// Persistent launcher: block b takes tiles b, b + gridDim.x, ...  The launch sizes the grid to the
+// tile count, or -- SMALLK -- to what is resident at once: blocks that live a few microseconds are
+// otherwise bound by the workgroup dispatch rate (measured on 144 x 3e6 x 144: ~3 resident waves
+// per CU with one block per tile).
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool IS_BF16, bool OUT_F32, bool SMALLK>
+__global__ __launch_bounds__(256) void gemm_nt_ragged_kernel(NtArgs p) {
+  constexpr int BK = 64;
+  constexpr int STAGE_BYTES = (BM + BN) * BK * 2;
+  constexpr int EPI_BYTES = OUT_F32 ? 0 : BM * (BN * 2 + 16);
+  constexpr int LOOP_BYTES = (SMALLK ? 1 : 2) * STAGE_BYTES;
+  __shared__ __attribute__((aligned(1024))) char smem[LOOP_BYTES > EPI_BYTES ? LOOP_BYTES : EPI_BYTES];
+  const int ntiles = p.tiles_m * p.tiles_n;
+#pragma clang loop unroll(disable)
+  for (int tile = blockIdx.x; tile < ntiles; tile += (int)gridDim.x) {
+    ragged_one_tile<BM, BN, WAVES_M, WAVES_N, IS_BF16, OUT_F32, SMALLK>(p, tile, smem);
+    __syncthreads();  // this tile's LDS reads are done before the next tile's stores
+  }
+}
+
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool SMALLK>
 static int launch_ragged(bool is_bf16, bool out_f32, NtArgs p, int64_t batch) {
   p.tiles_m = (int)((p.M + BM - 1) / BM);
@@ -249,14 +267,30 @@ static int launch_ragged(bool is_bf16, bool out_f32, NtArgs p, int64_t batch) {
     q.A = p.A + b0 * p.sA;
     q.B = p.B + b0 * p.sB;
     q.C = (char*)p.C + b0 * p.sC * esz_out;
-    const dim3 grid((unsigned)nwg, (unsigned)nb), block(256);
+    // SMALLK blocks live a few microseconds: a grid of one block per tile is bound by the workgroup
+    // dispatch rate, so the grid is what the occupancy API says is resident at once (rounded down to
+    // a multiple of 8, which keeps tile index and XCD congruent) and blocks loop over tiles.
+    auto launch = [&](auto kernel) -> int {
+      int64_t gx = nwg;
+      if (SMALLK && g_opt_persist) {
+        static int per_cu = 0;   // one query per kernel instantiation (generic lambda)
+        if (per_cu == 0) TNH_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, 0));
+        int64_t resident = (int64_t)num_cus() * (per_cu > 0 ? per_cu : 1);
+        resident -= resident % 8;
+        if (resident >= 8 && gx > resident) gx = resident;
+      }
+      hipLaunchKernelGGL(kernel, dim3((unsigned)gx, (unsigned)nb), dim3(256), 0, stream(), q);
+      return TNH_OK;
+    };
+    int rc;
     if (is_bf16) {
-      if (out_f32) hipLaunchKernelGGL((gemm_nt_ragged_kernel<BM, BN, WAVES_M, WAVES_N, true, true, SMALLK>), grid, block, 0, stream(), q);
-      else hipLaunchKernelGGL((gemm_nt_ragged_kernel<BM, BN, WAVES_M, WAVES_N, true, false, SMALLK>), grid, block, 0, stream(), q);
+      if (out_f32) rc = launch(gemm_nt_ragged_kernel<BM, BN, WAVES_M, WAVES_N, true, true, SMALLK>);
+      else rc = launch(gemm_nt_ragged_kernel<BM, BN, WAVES_M, WAVES_N, true, false, SMALLK>);
     } else {
-      if (out_f32) hipLaunchKernelGGL((gemm_nt_ragged_kernel<BM, BN, WAVES_M, WAVES_N, false, true, SMALLK>), grid, block, 0, stream(), q);
-      else hipLaunchKernelGGL((gemm_nt_ragged_kernel<BM, BN, WAVES_M, WAVES_N, false, false, SMALLK>), grid, block, 0, stream(), q);
+      if (out_f32) rc = launch(gemm_nt_ragged_kernel<BM, BN, WAVES_M, WAVES_N, false, true, SMALLK>);
+      else rc = launch(gemm_nt_ragged_kernel<BM, BN, WAVES_M, WAVES_N, false, false, SMALLK>);
     }
+    if (rc) return rc;
     TNH_LAUNCH_CHECK();
   }
   return TNH_OK;

@@ -74,10 +74,11 @@ def main():
   VARIANTS = args.variants.split(',')
   be = ta.get_hip_backend()
   if args.skinny:
-    shapes = [(144, 2985984, 144), (144, 248832, 1728), (1728, 248832, 12), (144, 248832, 144),
-              (4000, 4000, 4000), (12, 20736, 1728), (144, 144, 144)]
+    shapes = [(144, 2985984, 144), (2985984, 144, 144), (144, 248832, 1728), (248832, 144, 1728),
+              (1728, 248832, 12), (248832, 1728, 12), (144, 248832, 144), (248832, 144, 144),
+              (4000, 4000, 4000), (12, 20736, 1728), (20736, 12, 1728)]
     for (m, n, k) in shapes:
-      for variant in ("bf16_ragged:r2", "bf16_ragged", "bf16_ragged_128x128", "auto"):
+      for variant in ("bf16_ragged_128x128:p5", "bf16_ragged_128x128", "auto"):
         if variant == "generic" and 2.0 * m * n * k > 3e11:
           continue
         rec = gemm_tflops(be, _lib.BF16, _lib.BF16, 0, 1, m, n, k, variant, "uniform", 5)

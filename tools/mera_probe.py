@@ -10,6 +10,8 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--chi", default="4,8,16")
 ap.add_argument("--dtype", default="bf16")
 ap.add_argument("--reps", type=int, default=2)
+ap.add_argument("--slices", type=int, default=0, help="bond-slice each placement into >= this many slices (0 = unsliced)")
+ap.add_argument("--max-slices", type=int, default=0, help="with --slices: run only this many slices per placement (timing sample)")
 a = ap.parse_args()
 be = ta.get_hip_backend()
 dt = ta.bfloat16 if a.dtype == "bf16" else np.float32
@@ -26,14 +28,41 @@ for chi in [int(c) for c in a.chi.split(",")]:
   path = pathfinder.branch(inputs, set(), sizes, nbranch=2)
   flops, peak = pathfinder.path_cost(inputs, set(), sizes, path)
   best = None
+  extra = {}
+  if a.slices > 0:
+    import functools
+    from tensornetwork_amd import distributed
+    algo = functools.partial(pathfinder.branch, nbranch=2)
+    cuts = distributed.choose_cut_edges(nodes, min_slices=a.slices, algorithm=algo)
+    rep = distributed.slicing_report(nodes, cuts, algorithm=algo)
+    n_slices = int(rep["n_slices"])
+    world = max(1, n_slices // a.max_slices) if a.max_slices else 1
+    class Sub(distributed.LocalComm):
+      rank = 0
+    Sub.world = world
+    done = len(range(0, n_slices, world))
+    extra = {"n_slices": n_slices, "slices_run": done, "cut_bonds": len(cuts), "peak_per_slice": rep["peak_per_slice"],
+             "flops_per_slice": rep["flops_per_slice"], "slicing_overhead": rep["overhead"]}
+    def run():
+      outs = []
+      for pl in ("left", "right"):
+        nd = wl.mera_layer_network(be, ham, rho, iso, dis, pl)
+        c = distributed.choose_cut_edges(nd, min_slices=a.slices, algorithm=algo)
+        outs.append(distributed.contract_sliced(nd, c, comm=Sub(), algorithm=algo))
+      return be.multiply(be.addition(outs[0], outs[1]), 0.5)
+    flops = rep["flops_per_slice"] * done
+  else:
+    run = lambda: wl.mera_energy(be, ham, rho, iso, dis, lambda nd: contractors.branch(nd, nbranch=2))
   for _ in range(a.reps + 1):
     be.synchronize()
     t0 = time.perf_counter()
-    e = wl.mera_energy(be, ham, rho, iso, dis, lambda nd: contractors.branch(nd, nbranch=2))
+    e = run()
     be.synchronize()
     t = time.perf_counter() - t0
     best = t if best is None else min(best, t)
-  print(json.dumps({"chi": chi, "dtype": a.dtype, "sec": best, "flops_2placements": 2 * float(flops),
-                    "tflops": 2 * float(flops) / best / 1e12, "peak_elems": float(peak),
-                    "energy": float(np.asarray(e).reshape(-1)[0])}), flush=True)
+  rec = {"chi": chi, "dtype": a.dtype, "sec": best, "flops_2placements": 2 * float(flops),
+         "tflops": 2 * float(flops) / best / 1e12, "peak_elems": float(peak),
+         "energy": float(np.asarray(e).reshape(-1)[0])}
+  rec.update(extra)
+  print(json.dumps(rec), flush=True)
   del ham, rho, nodes, e
