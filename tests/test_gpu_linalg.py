@@ -175,3 +175,24 @@ def test_compare_and_index_update(hip, dtype):
   # host boolean mask (numpy_backend_test.py:720-727 passes `tensor > 0.1` computed anywhere)
   got = np.asarray(hip.index_update(d, xr > 0.1, 9.0)).astype(np.float64)
   np.testing.assert_array_equal(got, np.where(xr > 0.1, 9.0, xr))
+
+
+@pytest.mark.parametrize("dtype,tol", [(np.float32, 2e-5), (np.float64, 1e-12)])
+def test_qr_tall_panels_rank_deficient(hip, dtype, tol):
+  """Multi-workgroup panel path (m_j > 512) on inputs where reflectors degenerate: zeros (tau = 0,
+  Q = I_thin as LAPACK), a rank-1 matrix and duplicated columns -- Q stays orthonormal, Q R = A."""
+  rng = np.random.default_rng(11)
+  cases = [np.zeros((2000, 40)), np.outer(rng.standard_normal(1500), rng.standard_normal(33)),
+           np.repeat(rng.standard_normal((1300, 20)), 2, axis=1)]
+  for a in cases:
+    a = a.astype(dtype)
+    q, r = hip.qr(hip.convert_to_tensor(a), 1, False)
+    q, r = np.asarray(q).astype(np.float64), np.asarray(r).astype(np.float64)
+    k = min(a.shape)
+    scale = max(np.abs(a).max(), 1e-30) * np.sqrt(a.shape[0])
+    np.testing.assert_allclose(q.T @ q, np.eye(k), atol=tol * 50)
+    np.testing.assert_allclose(q @ r, a, atol=tol * scale * 50)
+    assert np.array_equal(r, np.triu(r))
+  q, r = hip.qr(hip.convert_to_tensor(np.zeros((2000, 40), dtype=dtype)), 1, False)
+  np.testing.assert_array_equal(np.asarray(q), np.eye(2000, 40))
+  np.testing.assert_array_equal(np.asarray(r), 0)
