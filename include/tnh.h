@@ -237,6 +237,8 @@ int tnh_cast(void* dst, int dst_dtype, const void* src, int src_dtype,
  * backends/numpy/decompositions.py:36 behind AbstractBackend.svd
  * (abstract_backend.py:79-137); the truncation bookkeeping (decompositions.py
  * :38-74) stays on the host. */
+/* dtype: TNH_F32 / TNH_F64 (block path for min(m, n) > 64) or TNH_C64 / TNH_C128 (unitary-rotation
+ * 2-row kernel); S always has the REAL dtype of the same precision. */
 int tnh_svd_work_bytes(int dtype, int64_t m, int64_t n, size_t* nbytes);
 /* Two-phase form: tnh_svd_factor runs the sweeps and writes all singular
  * values to S; the host then applies the reference's truncation rule

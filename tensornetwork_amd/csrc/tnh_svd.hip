@@ -378,6 +378,212 @@ static int svd_vectors_t(const SvdLayout& L, int64_t m, int64_t n, char* work, i
   return complete_basis<T>((T*)U, k, q, true, zero_rows);
 }
 
+// ---------------------------------------------------------------------------
+// complex64 / complex128: the same one-sided Jacobi with unitary plane rotations (no block path
+// yet).  For rows x_a, x_b with g = <x_a, x_b> = sum conj(x_a) x_b = |g| e^{i phi}:  x_b is first
+// turned by e^{-i phi} (the Gram entry becomes real), then the real rotation (c, s) of the real
+// algorithm is applied; the accumulated factor R receives the same unitary, so X_0 = R^H X.
+// ---------------------------------------------------------------------------
+template <typename Z, typename Rl>
+__global__ __launch_bounds__(256) void jacobi_round_cplx_kernel(Z* __restrict__ X, Z* __restrict__ R, int64_t p,
+                                                                int64_t P, int64_t q, int64_t round, double tol,
+                                                                int* __restrict__ flag) {
+  int64_t a, b;
+  rr_pair(P, round, blockIdx.x, a, b);
+  if (b >= p) return;  // bye (odd p)
+  Z* xa = X + a * q;
+  Z* xb = X + b * q;
+  const int tid = threadIdx.x;
+  double aa = 0.0, bb = 0.0, gr = 0.0, gi = 0.0;
+  for (int64_t j = tid; j < q; j += 256) {
+    const double ar = (double)xa[j].re, ai = (double)xa[j].im, br = (double)xb[j].re, bi = (double)xb[j].im;
+    aa += ar * ar + ai * ai;
+    bb += br * br + bi * bi;
+    gr += ar * br + ai * bi;   // conj(a) * b
+    gi += ar * bi - ai * br;
+  }
+  __shared__ double red[4][4];
+  aa = wave_sum(aa); bb = wave_sum(bb); gr = wave_sum(gr); gi = wave_sum(gi);
+  if ((tid & 63) == 0) {
+    red[tid >> 6][0] = aa; red[tid >> 6][1] = bb; red[tid >> 6][2] = gr; red[tid >> 6][3] = gi;
+  }
+  __syncthreads();
+  aa = red[0][0] + red[1][0] + red[2][0] + red[3][0];
+  bb = red[0][1] + red[1][1] + red[2][1] + red[3][1];
+  gr = red[0][2] + red[1][2] + red[2][2] + red[3][2];
+  gi = red[0][3] + red[1][3] + red[2][3] + red[3][3];
+  const double ab = sqrt(gr * gr + gi * gi);
+  if (!(ab > tol * sqrt(aa * bb))) return;  // already orthogonal (or a zero row)
+  if (tid == 0) *flag = 1;
+  const double pr = gr / ab, pi = -gi / ab;           // e^{-i phi}
+  const double zeta = (bb - aa) / (2.0 * ab);
+  const double t = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+  const double c = 1.0 / sqrt(1.0 + t * t), sn = c * t;
+  auto rotate = [&](Z* ra, Z* rb, int64_t len) {
+    for (int64_t j = tid; j < len; j += 256) {
+      const double ar = (double)ra[j].re, ai = (double)ra[j].im;
+      const double br0 = (double)rb[j].re, bi0 = (double)rb[j].im;
+      const double br = br0 * pr - bi0 * pi, bi = br0 * pi + bi0 * pr;   // e^{-i phi} b
+      ra[j].re = (Rl)(c * ar - sn * br);
+      ra[j].im = (Rl)(c * ai - sn * bi);
+      rb[j].re = (Rl)(sn * ar + c * br);
+      rb[j].im = (Rl)(sn * ai + c * bi);
+    }
+  };
+  rotate(xa, xb, q);
+  rotate(R + a * p, R + b * p, p);
+}
+
+template <typename Z>
+__global__ __launch_bounds__(256) void row_norm_cplx_kernel(const Z* __restrict__ X, int64_t p, int64_t q,
+                                                            double* __restrict__ norms) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= p) return;
+  const Z* x = X + row * q;
+  double acc = 0.0;
+  for (int64_t j = lane; j < q; j += 64) {
+    const double re = (double)x[j].re, im = (double)x[j].im;
+    acc += re * re + im * im;
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) norms[row] = sqrt(acc);
+}
+
+// complex variant of emit_rows_kernel with an optional conjugation
+template <typename Z, typename Rl, bool TRANS>
+__global__ __launch_bounds__(256) void emit_rows_cplx_kernel(Z* __restrict__ out, const Z* __restrict__ src,
+                                                             const int32_t* __restrict__ perm,
+                                                             const double* __restrict__ norms, int64_t k,
+                                                             int64_t len, int normalize, int conj) {
+  const int64_t total = k * len;
+  const int64_t step = (int64_t)gridDim.x * 256;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += step) {
+    int64_t i, j;
+    if (TRANS) { j = e / k; i = e - j * k; }
+    else { i = e / len; j = e - i * len; }
+    const int32_t r = perm[i];
+    double re = (double)src[(int64_t)r * len + j].re, im = (double)src[(int64_t)r * len + j].im;
+    if (conj) im = -im;
+    if (normalize) {
+      const double nr = norms[r];
+      re = (nr > 0.0) ? re / nr : 0.0;
+      im = (nr > 0.0) ? im / nr : 0.0;
+    }
+    out[e].re = (Rl)re;
+    out[e].im = (Rl)im;
+  }
+}
+
+template <typename Z, typename Rl>
+static int svd_factor_cplx(const SvdLayout& L, int dtype, int64_t m, int64_t n, const void* A, void* S, char* work,
+                           int* sweeps_out) {
+  const int64_t p = L.p, q = L.q;
+  Z* X = (Z*)(work + L.off_X);
+  Z* R = (Z*)(work + L.off_R);
+  int* flag = (int*)(work + L.off_flag);
+  int rc;
+  if (L.transposed) {
+    const int64_t shape[2] = {m, n};
+    const int32_t pm[2] = {1, 0};
+    rc = tnh_permute(X, A, 2, shape, pm, (int)sizeof(Z));   // plain transpose (no conjugation)
+  } else {
+    rc = tnh_d2d(X, A, (size_t)(p * q) * sizeof(Z));
+  }
+  if (rc) return rc;
+  rc = tnh_eye(R, p, p, dtype);
+  if (rc) return rc;
+  const double eps = (sizeof(Rl) == 4) ? 5.9604644775390625e-08 : 1.1102230246251565e-16;
+  const double tol = eps * sqrt((double)q);
+  const int64_t P = (p + 1) & ~int64_t(1);
+  const int max_sweeps = 40;
+  int sweeps = 0;
+  bool converged = (p < 2);
+  while (!converged && sweeps < max_sweeps) {
+    TNH_HIP(hipMemsetAsync(flag, 0, sizeof(int), stream()));
+    for (int64_t r = 0; r < P - 1; ++r)
+      hipLaunchKernelGGL((jacobi_round_cplx_kernel<Z, Rl>), dim3((unsigned)(P / 2)), dim3(256), 0, stream(), X, R, p,
+                         P, q, r, tol, flag);
+    TNH_LAUNCH_CHECK();
+    int h = 0;
+    TNH_HIP(hipMemcpyAsync(&h, flag, sizeof(int), hipMemcpyDeviceToHost, stream()));
+    TNH_HIP(hipStreamSynchronize(stream()));
+    ++sweeps;
+    converged = (h == 0);
+  }
+  if (sweeps_out) *sweeps_out = sweeps;
+  // row norms -> singular values (REAL dtype of the same precision), descending
+  double* norms = (double*)(work + L.off_norm);
+  int32_t* perm = (int32_t*)(work + L.off_perm);
+  hipLaunchKernelGGL((row_norm_cplx_kernel<Z>), dim3((unsigned)((p + 3) / 4)), dim3(256), 0, stream(), X, p, q, norms);
+  TNH_LAUNCH_CHECK();
+  std::vector<double> hn((size_t)p);
+  TNH_HIP(hipMemcpyAsync(hn.data(), norms, (size_t)p * sizeof(double), hipMemcpyDeviceToHost, stream()));
+  TNH_HIP(hipStreamSynchronize(stream()));
+  std::vector<int32_t> hp((size_t)p);
+  std::iota(hp.begin(), hp.end(), 0);
+  std::stable_sort(hp.begin(), hp.end(), [&](int32_t x, int32_t y) { return hn[x] > hn[y]; });
+  TNH_HIP(hipMemcpyAsync(perm, hp.data(), (size_t)p * sizeof(int32_t), hipMemcpyHostToDevice, stream()));
+  TNH_HIP(hipStreamSynchronize(stream()));
+  hipLaunchKernelGGL((emit_s_kernel<Rl>), dim3((unsigned)((p + 255) / 256)), dim3(256), 0, stream(), (Rl*)S, norms,
+                     perm, p);
+  TNH_LAUNCH_CHECK();
+  if (!converged) {
+    set_error("Jacobi SVD did not converge in %d sweeps (%lld x %lld)", max_sweeps, (long long)m, (long long)n);
+    return TNH_ERR_NO_CONVERGE;
+  }
+  return TNH_OK;
+}
+
+template <typename Z, typename Rl>
+static int svd_vectors_cplx(const SvdLayout& L, int dtype, int64_t m, int64_t n, char* work, int64_t k, void* U,
+                            void* Vh) {
+  if (k == 0) return TNH_OK;
+  const int64_t p = L.p, q = L.q;
+  const Z* X = (const Z*)(work + L.off_X);
+  const Z* R = (const Z*)(work + L.off_R);
+  const double* norms = (const double*)(work + L.off_norm);
+  const int32_t* perm = (const int32_t*)(work + L.off_perm);
+  auto grid = [&](int64_t total) {
+    int64_t b = (total + 255) / 256;
+    const int64_t cap = (int64_t)num_cus() * 16;
+    return (unsigned)(b > cap ? cap : (b < 1 ? 1 : b));
+  };
+  std::vector<double> hn((size_t)p);
+  std::vector<int32_t> hp((size_t)p);
+  TNH_HIP(hipMemcpyAsync(hn.data(), norms, (size_t)p * sizeof(double), hipMemcpyDeviceToHost, stream()));
+  TNH_HIP(hipMemcpyAsync(hp.data(), perm, (size_t)p * sizeof(int32_t), hipMemcpyDeviceToHost, stream()));
+  TNH_HIP(hipStreamSynchronize(stream()));
+  int64_t zeros = 0;
+  for (int64_t i = 0; i < k; ++i)
+    if (!(hn[(size_t)hp[(size_t)i]] > 0.0)) ++zeros;
+  if (zeros == k) {   // zero matrix: LAPACK's answer, leading rows / columns of the identity
+    int rc = tnh_eye(U, m, k, dtype);
+    if (rc) return rc;
+    return tnh_eye(Vh, k, n, dtype);
+  }
+  if (zeros > 0) {
+    set_error("complex SVD of an exactly rank-deficient matrix: basis completion is not implemented yet");
+    return TNH_ERR_UNSUPPORTED;
+  }
+  if (!L.transposed) {
+    // X_0 = A = R^H diag(s) W :  U[j][i] = conj(R[perm i][j]) (m x k),  Vh[i][:] = X[perm i][:] / s_i
+    hipLaunchKernelGGL((emit_rows_cplx_kernel<Z, Rl, true>), dim3(grid(k * p)), dim3(256), 0, stream(), (Z*)U, R, perm,
+                       norms, k, p, 0, 1);
+    hipLaunchKernelGGL((emit_rows_cplx_kernel<Z, Rl, false>), dim3(grid(k * q)), dim3(256), 0, stream(), (Z*)Vh, X, perm,
+                       norms, k, q, 1, 0);
+  } else {
+    // X_0 = A^T = R^H diag(s) W  =>  A = W^T diag(s) conj(R):
+    //   U[j][i] = X[perm i][j] / s_i (m x k),  Vh[i][:] = conj(R[perm i][:]) (k x n)
+    hipLaunchKernelGGL((emit_rows_cplx_kernel<Z, Rl, true>), dim3(grid(k * q)), dim3(256), 0, stream(), (Z*)U, X, perm,
+                       norms, k, q, 1, 0);
+    hipLaunchKernelGGL((emit_rows_cplx_kernel<Z, Rl, false>), dim3(grid(k * p)), dim3(256), 0, stream(), (Z*)Vh, R, perm,
+                       norms, k, p, 0, 1);
+  }
+  TNH_LAUNCH_CHECK();
+  return TNH_OK;
+}
+
 }  // namespace tnh
 
 using namespace tnh;
@@ -386,7 +592,8 @@ extern "C" {
 
 int tnh_svd_work_bytes(int dtype, int64_t m, int64_t n, size_t* nbytes) {
   TNH_REQUIRE(nbytes != nullptr, "null pointer");
-  TNH_REQUIRE(dtype == TNH_F32 || dtype == TNH_F64, "SVD supports f32/f64 (got dtype %d)", dtype);
+  TNH_REQUIRE(dtype == TNH_F32 || dtype == TNH_F64 || dtype == TNH_C64 || dtype == TNH_C128,
+              "SVD supports f32 / f64 / complex64 / complex128 (got dtype %d)", dtype);
   TNH_REQUIRE(m >= 0 && n >= 0, "negative size");
   *nbytes = svd_layout(dtype, m, n).total;
   return TNH_OK;
@@ -394,24 +601,30 @@ int tnh_svd_work_bytes(int dtype, int64_t m, int64_t n, size_t* nbytes) {
 
 int tnh_svd_factor(int dtype, int64_t m, int64_t n, const void* A, void* S, void* work, int* sweeps_out) {
   TNH_NEED_INIT();
-  TNH_REQUIRE(dtype == TNH_F32 || dtype == TNH_F64, "SVD supports f32/f64 (got dtype %d)", dtype);
+  TNH_REQUIRE(dtype == TNH_F32 || dtype == TNH_F64 || dtype == TNH_C64 || dtype == TNH_C128,
+              "SVD supports f32 / f64 / complex64 / complex128 (got dtype %d)", dtype);
   TNH_REQUIRE(m >= 0 && n >= 0, "negative size");
   if (sweeps_out) *sweeps_out = 0;
   if (m == 0 || n == 0) return TNH_OK;
   TNH_REQUIRE(A && S && work, "null pointer");
   TNH_REQUIRE(std::min(m, n) < (int64_t(1) << 31), "matrix too large");
   const SvdLayout L = svd_layout(dtype, m, n);
+  if (dtype == TNH_C64) return svd_factor_cplx<cf32, float>(L, dtype, m, n, A, S, (char*)work, sweeps_out);
+  if (dtype == TNH_C128) return svd_factor_cplx<cf64, double>(L, dtype, m, n, A, S, (char*)work, sweeps_out);
   if (dtype == TNH_F32) return svd_factor_t<float>(L, dtype, m, n, A, S, (char*)work, sweeps_out);
   return svd_factor_t<double>(L, dtype, m, n, A, S, (char*)work, sweeps_out);
 }
 
 int tnh_svd_vectors(int dtype, int64_t m, int64_t n, void* work, int64_t k, void* U, void* Vh) {
   TNH_NEED_INIT();
-  TNH_REQUIRE(dtype == TNH_F32 || dtype == TNH_F64, "SVD supports f32/f64 (got dtype %d)", dtype);
+  TNH_REQUIRE(dtype == TNH_F32 || dtype == TNH_F64 || dtype == TNH_C64 || dtype == TNH_C128,
+              "SVD supports f32 / f64 / complex64 / complex128 (got dtype %d)", dtype);
   TNH_REQUIRE(k >= 0 && k <= std::min(m, n), "k out of range");
   if (k == 0) return TNH_OK;
   TNH_REQUIRE(U && Vh && work, "null pointer");
   const SvdLayout L = svd_layout(dtype, m, n);
+  if (dtype == TNH_C64) return svd_vectors_cplx<cf32, float>(L, dtype, m, n, (char*)work, k, U, Vh);
+  if (dtype == TNH_C128) return svd_vectors_cplx<cf64, double>(L, dtype, m, n, (char*)work, k, U, Vh);
   if (dtype == TNH_F32) return svd_vectors_t<float>(L, m, n, (char*)work, k, U, Vh);
   return svd_vectors_t<double>(L, m, n, (char*)work, k, U, Vh);
 }

@@ -748,24 +748,24 @@ class HipBackend(BackendBase):
 
     The Jacobi factorisation runs on the GPU and returns ALL singular values;
     the keep/discard decision below restates decompositions.py:38-57 on the
-    host; only the kept vectors are then emitted by the GPU.
+    host; only the kept vectors are then emitted by the GPU.  complex64 / complex128
+    run the same one-sided Jacobi with unitary plane rotations (2-row kernel).
     """
     tensor = self._as_tensor(tensor)
     self._check_float(tensor, "svd")
-    if tensor.is_complex:
-      raise NotImplementedError("complex SVD is not implemented on the hip backend yet")
     left_dims = tensor.shape[:pivot_axis]
     right_dims = tensor.shape[pivot_axis:]
     m, n = _prod(left_dims), _prod(right_dims)
     orig_code = tensor.code
-    work_code = tensor.code if tensor.code in (_lib.F32, _lib.F64) else _lib.F32
+    work_code = tensor.code if tensor.code in (_lib.F32, _lib.F64, _lib.C64, _lib.C128) else _lib.F32
+    real_code = _REAL_OF.get(work_code, work_code)     # singular values come out real
     mat = self.cast(tensor, work_code).view((m, n))
     r = min(m, n)
 
     nbytes = ctypes.c_size_t(0)
     _lib.check(self.lib.tnh_svd_work_bytes(work_code, m, n, ctypes.byref(nbytes)), "tnh_svd_work_bytes")
     work = DeviceTensor.empty((max(nbytes.value, 8) // 8 + 1,), _lib.F64)
-    s_all = DeviceTensor.empty((r,), work_code)
+    s_all = DeviceTensor.empty((r,), real_code)
     sweeps = ctypes.c_int(0)
     _lib.check(self.lib.tnh_svd_factor(work_code, m, n, _vp(mat), _vp(s_all), _vp(work),
                                        ctypes.byref(sweeps)), "tnh_svd_factor")
@@ -792,6 +792,7 @@ class HipBackend(BackendBase):
     s_rest = self.getitem(s_all, slice(keep, r))
     if orig_code != work_code:
       u, vh = self.cast(u, orig_code), self.cast(vh, orig_code)
+    if orig_code != real_code:    # decompositions.py:58-62: s is recast to the tensor's dtype (complex included)
       s, s_rest = self.cast(s, orig_code), self.cast(s_rest, orig_code)
     u = u.view(tuple(left_dims) + (keep,))
     vh = vh.view((keep,) + tuple(right_dims))
@@ -799,6 +800,8 @@ class HipBackend(BackendBase):
 
   def _qr_matrix(self, mat):
     """Thin Householder QR of a device matrix (f32 / f64) -> (q (m, k), r (k, n))."""
+    if mat.is_complex:
+      return self._qr_complex(mat)
     m, n = mat.shape
     k = min(m, n)
     nbytes = ctypes.c_size_t(0)
@@ -809,14 +812,46 @@ class HipBackend(BackendBase):
     _lib.check(self.lib.tnh_qr(mat.code, m, n, _vp(mat), _vp(q), _vp(r), _vp(work)), "tnh_qr")
     return q, r
 
+  def _qr_complex(self, mat):
+    """Thin QR of a complex matrix through the REAL Householder kernels.
+
+    phi(z) = [[re, -im], [im, re]] is a ring homomorphism, so the interleaved real embedding
+    phi(A) (2m x 2n) satisfies phi(A) = phi(Q) phi(R); phi(R) is upper triangular with the real
+    non-negative diagonal of R doubled, and a full-column-rank matrix has exactly one QR with a
+    positive diagonal -- hence the real QR of phi(A), phase-fixed to a non-negative diagonal, IS
+    (phi(Q), phi(R)).  Column 2j of phi(X) is (re, im) of column j of X, which is read back with one
+    strided gather.  R therefore always comes out with a real non-negative diagonal (a valid QR;
+    LAPACK's complex reflectors fix a different phase).  Exactly rank-deficient inputs lose the
+    uniqueness argument; the all-zero matrix still gives Q = 1, R = 0 like LAPACK."""
+    m, n = mat.shape
+    k = min(m, n)
+    real = _REAL_OF[mat.code]
+    emb = DeviceTensor.empty((2 * m, 2 * n), real)
+    _lib.check(self.lib.tnh_complex_expand(_vp(emb), _vp(mat), m, n, n, 1, 1, mat.code), "tnh_complex_expand")
+    qh, rh = self._qr_matrix(emb)                            # (2m x 2k), (2k x 2n)
+    # flip reflector signs so that diag(R) >= 0; a zero diagonal entry (tau = 0 reflector) keeps +1
+    sgn = self.sign(self.diagonal(rh))
+    sgn = self._binary(_lib.OP_ADD, sgn, self._binary(_lib.OP_SUB, 1.0, self.abs(sgn)))
+    qh = self._binary(_lib.OP_MUL, qh, sgn)
+    rh = self._binary(_lib.OP_MUL, self.reshape(sgn, (sgn.shape[0], 1)), rh)
+
+    def extract(x, rows, cols):
+      # complex[i, j] = x[2i, 2j] + i x[2i+1, 2j]  ->  real (rows, cols, 2) gather, viewed as complex
+      ld = x.shape[1]
+      out = DeviceTensor.empty((rows, cols), mat.code)
+      _lib.check(self.lib.tnh_strided_copy(_vp(out), _vp(x), 3, _lib.i64_array((rows, cols, 2)),
+                                           _lib.i64_array((2 * ld, 2, ld)), 0, 4 if real == _lib.F32 else 8),
+                 "tnh_strided_copy")
+      return out
+
+    return extract(qh, m, k), extract(rh, k, n)
+
   def _qr_prepare(self, tensor, pivot_axis, what):
     tensor = self._as_tensor(tensor)
     self._check_float(tensor, what)
-    if tensor.is_complex:
-      raise NotImplementedError(f"complex {what} is not implemented on the hip backend yet")
     left_dims = tensor.shape[:pivot_axis]
     right_dims = tensor.shape[pivot_axis:]
-    work_code = tensor.code if tensor.code in (_lib.F32, _lib.F64) else _lib.F32
+    work_code = tensor.code if tensor.code in (_lib.F32, _lib.F64, _lib.C64, _lib.C128) else _lib.F32
     mat = self.cast(tensor, work_code).view((_prod(left_dims), _prod(right_dims)))
     return tensor.code, mat, left_dims, right_dims
 
@@ -824,7 +859,7 @@ class HipBackend(BackendBase):
     # decompositions.py:92-95: phases = sign(diag(r)); q = q * phases; r = phases[:, None] * r
     phases = self.sign(self.diagonal(r))
     q = self._binary(_lib.OP_MUL, q, phases)
-    r = self._binary(_lib.OP_MUL, self.reshape(phases, (phases.shape[0], 1)), r)
+    r = self._binary(_lib.OP_MUL, self.reshape(self.conj(phases), (phases.shape[0], 1)), r)
     return q, r
 
   def qr(self, tensor, pivot_axis=-1, non_negative_diagonal=False):
@@ -846,10 +881,10 @@ class HipBackend(BackendBase):
     the transposed matrix, phases fixed on that factorisation, then both factors
     transposed back -- M = r q with q's rows orthonormal."""
     orig, mat, left_dims, right_dims = self._qr_prepare(tensor, pivot_axis, "rq")
-    q, r = self._qr_matrix(self.transpose(mat, (1, 0)))
+    q, r = self._qr_matrix(self.conj(self.transpose(mat, (1, 0))))
     if non_negative_diagonal:
       q, r = self._phase_fix(q, r)
-    r, q = self.transpose(r, (1, 0)), self.transpose(q, (1, 0))
+    r, q = self.conj(self.transpose(r, (1, 0))), self.conj(self.transpose(q, (1, 0)))
     if orig != mat.code:
       q, r = self.cast(q, orig), self.cast(r, orig)
     center = r.shape[1]
@@ -866,25 +901,26 @@ class HipBackend(BackendBase):
     v_i^T A v_i (one GEMM), which removes the O(sigma eps) shift error to second order."""
     matrix = self._as_tensor(matrix)
     self._check_float(matrix, "eigh")
-    if matrix.is_complex:
-      raise NotImplementedError("complex (Hermitian) eigh is not implemented on the hip backend yet")
     if matrix.ndim != 2 or matrix.shape[0] != matrix.shape[1]:
       raise ValueError("Last 2 dimensions of the array must be square")
     n = matrix.shape[0]
     orig = matrix.code
-    work_code = orig if orig in (_lib.F32, _lib.F64) else _lib.F32
+    work_code = orig if orig in (_lib.F32, _lib.F64, _lib.C64, _lib.C128) else _lib.F32
     a = self.cast(matrix, work_code)
     if n == 0:
       return DeviceTensor.empty((0,), orig), DeviceTensor.empty((0, 0), orig)
     # symmetrise from the lower triangle semantics of LAPACK 'L': use (A + A^T) / 2, identical
     # for symmetric input
-    a = self._binary(_lib.OP_MUL, self._binary(_lib.OP_ADD, a, self.transpose(a, (1, 0))), 0.5)
-    sigma = float(self.norm(a).item())
+    a = self._binary(_lib.OP_MUL, self._binary(_lib.OP_ADD, a, self.conj(self.transpose(a, (1, 0)))), 0.5)
+    sigma = float(np.real(self.norm(a).item()))
     b = self._binary(_lib.OP_ADD, a, self._binary(_lib.OP_MUL, self.eye(n, dtype=public_dtype(work_code)), sigma))
     _, _, vh, _ = self.svd(b, pivot_axis=1)
-    v = self.transpose(self.getitem(vh, (slice(None, None, -1), slice(None))), (1, 0))   # ascending order
+    # B = V diag(s) V^H: the rows of vh are conj(eigenvectors); ascending order = reversed rows
+    v = self.conj(self.transpose(self.getitem(vh, (slice(None, None, -1), slice(None))), (1, 0)))
     av = self.tensordot(a, v, 1)
-    w = self.sum(self._binary(_lib.OP_MUL, v, av), axis=(0,))
+    w = self.sum(self._binary(_lib.OP_MUL, self.conj(v), av), axis=(0,))
+    if work_code in _REAL_OF:
+      w = self._unary(_lib.OP_REAL, w)       # eigenvalues of a Hermitian matrix are real (np.linalg.eigh)
     if orig != work_code:
       w, v = self.cast(w, orig), self.cast(v, orig)
     return w, v
@@ -899,7 +935,8 @@ class HipBackend(BackendBase):
     if matrix.ndim != 2 or matrix.shape[0] != matrix.shape[1]:
       raise ValueError("Last 2 dimensions of the array must be square")
     u, s, vh, _ = self.svd(matrix, pivot_axis=1)
-    return self.tensordot(vh, self._binary(_lib.OP_DIV, u, s), [[0], [1]])
+    # A^-1 = V diag(1/s) U^H  with V = vh^H
+    return self.tensordot(self.conj(vh), self.conj(self._binary(_lib.OP_DIV, u, s)), [[0], [1]])
 
   def expm(self, matrix):
     """Matrix exponential (numpy_backend.py:589-599) as GEMMs only: scaling and squaring

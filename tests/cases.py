@@ -152,7 +152,7 @@ def check_qr_case(be, g, case, tight=True):
   qm, rm = q.reshape(-1, k), r.reshape(k, -1)
   t = tol(x.dtype, scale)
   np.testing.assert_allclose(qm @ rm, x.reshape(qm.shape[0], rm.shape[1]), rtol=0, atol=10 * t["atol"])
-  np.testing.assert_allclose(qm.T @ qm, np.eye(k), rtol=0, atol=10 * tol(x.dtype)["atol"])
+  np.testing.assert_allclose(qm.conj().T @ qm, np.eye(k), rtol=0, atol=10 * tol(x.dtype)["atol"])
   assert np.allclose(rm, np.triu(rm))
   if tight:
     assert_close(r, g[case["r"]], scale=scale * np.sqrt(qm.shape[0]))
@@ -163,7 +163,7 @@ def check_qr_case(be, g, case, tight=True):
   k = rr.shape[-1]
   rm, qm = rr.reshape(-1, k), qq.reshape(k, -1)
   np.testing.assert_allclose(rm @ qm, x.reshape(rm.shape[0], qm.shape[1]), rtol=0, atol=10 * t["atol"])
-  np.testing.assert_allclose(qm @ qm.T, np.eye(k), rtol=0, atol=10 * tol(x.dtype)["atol"])
+  np.testing.assert_allclose(qm @ qm.conj().T, np.eye(k), rtol=0, atol=10 * tol(x.dtype)["atol"])
   if tight:
     assert_close(rr, g[case["rq_r"]], scale=scale * np.sqrt(qm.shape[1]))
     assert_close(qq, g[case["rq_q"]], scale=10.0)
@@ -195,7 +195,8 @@ def check_linalg_case(be, g, case):
     assert_close(w, g[case["w"]], scale=scale)
     t = tol(h.dtype, scale)
     np.testing.assert_allclose(h @ v, v * w, rtol=0, atol=30 * t["atol"])
-    np.testing.assert_allclose(v.T @ v, np.eye(n), rtol=0, atol=30 * tol(h.dtype)["atol"])
+    np.testing.assert_allclose(v.conj().T @ v, np.eye(n), rtol=0, atol=30 * tol(h.dtype)["atol"])
+    assert not np.iscomplexobj(w)
   if "inv" in case:
     a = g[case["a"]]
     got = to_host(be.inv(be.convert_to_tensor(a)))
@@ -226,3 +227,26 @@ def xxz_dense(n, jz, jxy, bz):
   for i in range(n):
     h += bz * op(sz, i)
   return h
+
+
+def check_svd_case(be, g, case):
+  """svd of one fixture (complex-aware): spectrum and discarded values element-wise, factors through
+  orthonormality and the truncated reconstruction (vectors are unique only up to phases)."""
+  x = g[case["x"]]
+  kw = case["kw"]
+  u, s, vh, rest = be.svd(be.convert_to_tensor(x), case["pivot"], kw.get("max_singular_values"),
+                          kw.get("max_truncation_error"), kw.get("relative", False))
+  u, s, vh, rest = to_host(u), to_host(s), to_host(vh), to_host(rest)
+  ur, sr, vr, rr = g[case["u"]], g[case["s"]], g[case["vh"]], g[case["rest"]]
+  assert u.shape == ur.shape and vh.shape == vr.shape and s.shape == sr.shape and rest.shape == rr.shape
+  assert s.dtype == sr.dtype and u.dtype == ur.dtype
+  scale = float(np.max(np.abs(x))) * np.sqrt(max(x.shape)) + 1e-30
+  assert_close(s, sr, scale=scale)
+  assert_close(rest, rr, scale=scale)
+  k = s.shape[0]
+  um, vm = u.reshape(-1, k), vh.reshape(k, -1)
+  t = tol(x.dtype)
+  np.testing.assert_allclose(um.conj().T @ um, np.eye(k), rtol=0, atol=20 * t["atol"])
+  np.testing.assert_allclose(vm @ vm.conj().T, np.eye(k), rtol=0, atol=20 * t["atol"])
+  ref = (ur.reshape(-1, k) * sr) @ vr.reshape(k, -1)
+  np.testing.assert_allclose((um * s) @ vm, ref, rtol=0, atol=50 * tol(x.dtype, scale)["atol"])

@@ -48,6 +48,20 @@ def golden_linalg():
   return GoldenLinalg()
 
 
+class GoldenComplex(Golden):
+  """tests/golden/golden_complex.npz + cases_complex.json (made by make_golden_complex.py)."""
+
+  def __init__(self):  # pylint: disable=super-init-not-called
+    self.arrays = np.load(os.path.join(HERE, "golden", "golden_complex.npz"))
+    with open(os.path.join(HERE, "golden", "cases_complex.json")) as f:
+      self.cases = json.load(f)
+
+
+@pytest.fixture(scope="session")
+def golden_complex():
+  return GoldenComplex()
+
+
 @pytest.fixture(scope="session")
 def hip():
   """The hip backend bound to cuda:0 -- fails loudly if libtnhip or the GPU is missing."""

@@ -43,6 +43,60 @@ def test_qr_large_vs_oracle(hip, dtype, otol, rtol, shape):
   assert np.array_equal(r, np.triu(r))
 
 
+def test_complex_svd_golden(hip, golden_complex):
+  """complex64 / complex128 svd (one-sided Jacobi with unitary rotations) vs the reference's outputs."""
+  for case in golden_complex.cases["svd"]:
+    C.check_svd_case(hip, golden_complex, case)
+  # zero matrix: LAPACK's completion (split_node_test.py:22-32 with a complex dtype)
+  u, s, vh, _ = hip.svd(hip.zeros((4, 6), dtype=np.complex64), 1)
+  np.testing.assert_array_equal(np.asarray(s), 0)
+  np.testing.assert_array_equal(np.asarray(u), np.eye(4))
+  np.testing.assert_array_equal(np.asarray(vh), np.eye(4, 6))
+
+
+def test_complex_qr_rq_golden(hip, golden_complex):
+  """Complex QR through the real Householder kernels on the interleaved embedding: with
+  non_negative_diagonal the factorisation is unique and is compared element-wise; without it only
+  Q^H Q = 1, Q R = A and the triangular shape (R comes out in the non-negative-diagonal gauge)."""
+  for case in golden_complex.cases["qr"]:
+    C.check_qr_case(hip, golden_complex, case, tight=bool(case["nnd"]))
+  q, r = hip.qr(hip.zeros((5, 3), dtype=np.complex128), 1, False)
+  np.testing.assert_array_equal(np.asarray(q), np.eye(5, 3))
+  np.testing.assert_array_equal(np.asarray(r), 0)
+
+
+def test_complex_eigh_inv_expm_golden(hip, golden_complex):
+  for case in golden_complex.cases["linalg"]:
+    C.check_linalg_case(hip, golden_complex, case)
+
+
+def test_complex_split_node_golden(hip, golden_complex):
+  from tensornetwork_amd import network
+  case = golden_complex.cases["split"][0]
+  x = golden_complex[case["x"]]
+  a = network.Node(hip.convert_to_tensor(x), backend=hip)
+  l, r, tr = network.split_node(a, [a[0], a[1]], [a[2], a[3]], max_singular_values=4)
+  C.assert_close(tr, golden_complex[case["trun"]], scale=float(np.abs(x).max()) * 10)
+  got = np.tensordot(np.asarray(l.tensor), np.asarray(r.tensor), [[2], [0]])
+  ref = np.tensordot(golden_complex[case["left"]], golden_complex[case["right"]], [[2], [0]])
+  np.testing.assert_allclose(got, ref, atol=1e-10)
+
+
+def test_complex_svd_larger_vs_oracle(hip):
+  rng = np.random.default_rng(5)
+  x = (rng.standard_normal((300, 200)) + 1j * rng.standard_normal((300, 200))).astype(np.complex64)
+  u, s, vh, rest = hip.svd(hip.convert_to_tensor(x), 1, max_singular_values=50)
+  so = np.linalg.svd(x.astype(np.complex128), compute_uv=False)
+  np.testing.assert_allclose(np.real(np.asarray(s)), so[:50], atol=2e-5 * so[0])
+  np.testing.assert_allclose(np.real(np.asarray(rest)), so[50:], atol=2e-5 * so[0])
+  um, vm = np.asarray(u), np.asarray(vh)
+  np.testing.assert_allclose(um.conj().T @ um, np.eye(50), atol=2e-4)
+  np.testing.assert_allclose(vm @ vm.conj().T, np.eye(50), atol=2e-4)
+  uo, _, vo = np.linalg.svd(x.astype(np.complex128), full_matrices=False)
+  ref = (uo[:, :50] * so[:50]) @ vo[:50]
+  np.testing.assert_allclose((um * np.asarray(s)) @ vm, ref, atol=2e-3)
+
+
 def test_qr_bf16_and_errors(hip):
   rng = np.random.default_rng(3)
   x = orc.round_bf16(rng.standard_normal((40, 12)))
@@ -51,8 +105,6 @@ def test_qr_bf16_and_errors(hip):
   qh, rh = np.asarray(q).astype(np.float64), np.asarray(r).astype(np.float64)
   np.testing.assert_allclose(qh @ rh, x, atol=0.05)
   assert np.all(np.diagonal(rh) >= 0)
-  with pytest.raises(NotImplementedError):
-    hip.qr(hip.convert_to_tensor((x + 1j * x).astype(np.complex64)), 1, False)
 
 
 def test_eigh_inv_expm_golden(hip, golden_linalg):
