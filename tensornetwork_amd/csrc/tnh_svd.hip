@@ -283,55 +283,81 @@ static int svd_finish(const SvdLayout& L, int64_t m, int64_t n, void* S, char* w
   return TNH_OK;
 }
 
-// Replace zero rows of the row-orthonormal factor W (k x q, or its transpose
-// when `trans`, i.e. stored q x k) by unit vectors orthogonal to all other rows
-// so that the emitted factor is orthonormal even for rank-deficient input
-// (LAPACK's behaviour, which the reference relies on for u/vh of e.g. a zero
-// tensor).  Rare path, done on the host in f64.
+// Replace zero rows of the row-orthonormal factor W (k x q, or its transpose when `trans`,
+// i.e. stored q x k) by unit vectors orthogonal to all other rows, so that the emitted factor
+// is orthonormal even for rank-deficient input (LAPACK's behaviour, which the reference relies
+// on for u / vh of e.g. a zero tensor).  Rare path, done ON THE DEVICE with the K9 kernels:
+// M (q x k) = [non-zero vectors | Gaussian columns]; the thin Householder QR of M leaves, in its
+// last columns, orthonormal vectors orthogonal to every non-zero vector; they are copied into the
+// zero slots.  (The non-zero vectors themselves are not touched.)
 template <typename T>
 static int complete_basis(T* dW, int64_t k, int64_t q, bool trans, const std::vector<int>& zero_rows) {
   if (zero_rows.empty()) return TNH_OK;
+  const int dt = sizeof(T) == 4 ? TNH_F32 : TNH_F64;
   if ((int64_t)zero_rows.size() == k) {
     // everything is zero: W = leading rows of the identity
-    if (trans) return tnh_eye(dW, q, k, sizeof(T) == 4 ? TNH_F32 : TNH_F64);
-    return tnh_eye(dW, k, q, sizeof(T) == 4 ? TNH_F32 : TNH_F64);
+    if (trans) return tnh_eye(dW, q, k, dt);
+    return tnh_eye(dW, k, q, dt);
   }
-  std::vector<T> h((size_t)(k * q));
-  TNH_HIP(hipMemcpyAsync(h.data(), dW, h.size() * sizeof(T), hipMemcpyDeviceToHost, stream()));
-  TNH_HIP(hipStreamSynchronize(stream()));
-  auto at = [&](int64_t i, int64_t j) -> T& { return trans ? h[(size_t)(j * k + i)] : h[(size_t)(i * q + j)]; };
   std::vector<char> is_zero((size_t)k, 0);
   for (int z : zero_rows) is_zero[(size_t)z] = 1;
-  std::vector<double> v((size_t)q);
-  int64_t trial = 0;
-  for (int z : zero_rows) {
-    for (;; ++trial) {
-      if (trial >= q) {
-        set_error("basis completion failed");
-        return TNH_ERR_INVALID;
-      }
-      std::fill(v.begin(), v.end(), 0.0);
-      v[(size_t)trial] = 1.0;
-      for (int pass = 0; pass < 2; ++pass)
-        for (int64_t i = 0; i < k; ++i) {
-          if (is_zero[(size_t)i]) continue;
-          double d = 0.0;
-          for (int64_t j = 0; j < q; ++j) d += v[(size_t)j] * (double)at(i, j);
-          for (int64_t j = 0; j < q; ++j) v[(size_t)j] -= d * (double)at(i, j);
-        }
-      double nr = 0.0;
-      for (int64_t j = 0; j < q; ++j) nr += v[(size_t)j] * v[(size_t)j];
-      nr = sqrt(nr);
-      if (nr > 0.5) {
-        for (int64_t j = 0; j < q; ++j) at(z, j) = (T)(v[(size_t)j] / nr);
-        is_zero[(size_t)z] = 0;
-        ++trial;
-        break;
-      }
+  const int64_t nz = (int64_t)zero_rows.size(), knz = k - nz;
+  size_t qr_bytes = 0;
+  int rc = tnh_qr_work_bytes(dt, q, k, &qr_bytes);
+  if (rc) return rc;
+  void *Mt = nullptr, *M = nullptr, *Q = nullptr, *Rr = nullptr, *work = nullptr;
+  auto cleanup = [&]() {
+    for (void* ptr : {Mt, M, Q, Rr, work})
+      if (ptr) tnh_free(ptr);
+  };
+#define TNH_CB(call)          \
+  do {                        \
+    rc = (call);              \
+    if (rc) {                 \
+      cleanup();              \
+      return rc;              \
+    }                         \
+  } while (0)
+  TNH_CB(tnh_malloc(&Mt, (size_t)k * q * sizeof(T)));
+  TNH_CB(tnh_malloc(&M, (size_t)k * q * sizeof(T)));
+  TNH_CB(tnh_malloc(&Q, (size_t)k * q * sizeof(T)));
+  TNH_CB(tnh_malloc(&Rr, (size_t)k * k * sizeof(T)));
+  TNH_CB(tnh_malloc(&work, qr_bytes));
+  // Mt (k x q, rows are vectors): the non-zero vectors first, then Gaussian rows
+  int64_t row = 0;
+  for (int64_t i = 0; i < k; ++i) {
+    if (is_zero[(size_t)i]) continue;
+    T* dst = (T*)Mt + row * q;
+    if (!trans) {
+      TNH_CB(tnh_d2d(dst, dW + i * q, (size_t)q * sizeof(T)));
+    } else {
+      const int64_t shape[1] = {q}, stride[1] = {k};
+      TNH_CB(tnh_strided_copy(dst, dW, 1, shape, stride, i, (int)sizeof(T)));
+    }
+    ++row;
+  }
+  TNH_CB(tnh_random((T*)Mt + knz * q, nz * q, dt, 0x5eedull + (uint64_t)k * 131 + (uint64_t)q, 1, 0.0, 1.0));
+  {
+    const int64_t shape[2] = {k, q};
+    const int32_t pm[2] = {1, 0};
+    TNH_CB(tnh_permute(M, Mt, 2, shape, pm, (int)sizeof(T)));
+  }
+  TNH_CB(tnh_qr(dt, q, k, M, Q, Rr, work));
+  // column knz + j of Q -> zero slot zero_rows[j]
+  for (int64_t j = 0; j < nz; ++j) {
+    const int z = zero_rows[(size_t)j];
+    const int64_t shape[1] = {q}, stride[1] = {k};
+    if (!trans) {
+      TNH_CB(tnh_strided_copy(dW + (int64_t)z * q, Q, 1, shape, stride, knz + j, (int)sizeof(T)));
+    } else {
+      // W stored q x k: column z <- column knz + j of Q (both with stride k): via a contiguous row of Mt
+      TNH_CB(tnh_strided_copy(Mt, Q, 1, shape, stride, knz + j, (int)sizeof(T)));
+      TNH_CB(tnh_strided_scatter(dW, Mt, 1, shape, stride, z, (int)sizeof(T)));
     }
   }
-  TNH_HIP(hipMemcpyAsync(dW, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, stream()));
-  TNH_HIP(hipStreamSynchronize(stream()));
+  TNH_HIP(hipStreamSynchronize(stream()));   // scratch is recycled in stream order, but be explicit
+  cleanup();
+#undef TNH_CB
   return TNH_OK;
 }
 
