@@ -7,6 +7,7 @@ device block from libtnhip's pool + shape + dtype.  Tensors are always dense
 row-major; ``reshape`` shares the block, everything else produces a new one.
 """
 import ctypes
+import math
 import numpy as np
 
 from tensornetwork_amd import _lib
@@ -120,7 +121,7 @@ class DeviceTensor:
     shape = tuple(int(s) for s in shape)
     if any(s < 0 for s in shape):
       raise ValueError(f"negative dimensions are not allowed: {shape}")
-    n = int(np.prod(shape, dtype=np.int64)) if shape else 1
+    n = math.prod(shape)
     return cls(_Block(n * _ITEMSIZE[code]), shape, code)
 
   @classmethod
@@ -158,7 +159,7 @@ class DeviceTensor:
 
   @property
   def size(self):
-    return int(np.prod(self._shape, dtype=np.int64)) if self._shape else 1
+    return math.prod(self._shape)
 
   @property
   def dtype(self):

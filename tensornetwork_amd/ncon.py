@@ -17,6 +17,8 @@ on two) is a batch label.
 """
 from typing import Any, List, Optional, Sequence
 
+import math
+
 import numpy as np
 
 
@@ -92,7 +94,7 @@ class _Engine:
     second = [len(labels) - 1 - labels[::-1].index(l) for l in rep]
     free = [i for i in range(len(labels)) if i not in first + second]
     shape = self.be.shape_tuple(tensor)
-    cdim = int(np.prod([shape[i] for i in first], dtype=np.int64))
+    cdim = math.prod(int(shape[i]) for i in first)
     t = self.be.transpose(tensor, tuple(free + first + second))
     t = self.be.reshape(t, tuple(shape[i] for i in free) + (cdim, cdim))
     self.ops[idx] = (self.be.trace(t), [labels[i] for i in free])
@@ -135,7 +137,7 @@ class _Engine:
       c1, c2 = [l1.index(l) for l in closing], [l2.index(l) for l in closing]
       f1 = [n for n, l in enumerate(l1) if l not in shared]
       f2 = [n for n, l in enumerate(l2) if l not in shared]
-      prod = lambda shape, pos: int(np.prod([shape[p] for p in pos], dtype=np.int64))
+      prod = lambda shape, pos: math.prod(int(shape[p]) for p in pos)
       m1 = be.reshape(be.transpose(t1, tuple(b1 + f1 + c1)), (prod(s1, b1), prod(s1, f1), prod(s1, c1)))
       m2 = be.reshape(be.transpose(t2, tuple(b2 + c2 + f2)), (prod(s2, b2), prod(s2, c2), prod(s2, f2)))
       result = be.reshape(be.matmul(m1, m2),
@@ -245,7 +247,7 @@ def einsum(expression: str, *tensors, backend=None):
         for k, (_, lk) in enumerate(eng.ops):
           if k not in (i, j):
             others |= set(lk)
-        size = int(np.prod([dims[l] for l in set(l1) | set(l2) if l in others], dtype=np.int64))
+        size = math.prod(int(dims[l]) for l in set(l1) | set(l2) if l in others)
         if best is None or size < best[0]:
           best = (size, i, j)
     if best is None:

@@ -16,6 +16,8 @@ All tensor math goes through ``node.backend``.
 """
 from typing import Any, Dict, Iterable, List, Optional, Sequence, Set, Tuple
 
+import math
+
 import numpy as np
 
 
@@ -237,7 +239,7 @@ def contract_trace_edges(node: Node) -> Node:
   second = [e.axis2 for e in trace_edges]
   free = [i for i in range(len(node.edges)) if i not in first + second]
   shape = node.shape
-  cdim = int(np.prod([shape[i] for i in first], dtype=np.int64))
+  cdim = math.prod(int(shape[i]) for i in first)
   t = be.transpose(node.tensor, tuple(free + first + second))
   t = be.reshape(t, tuple(shape[i] for i in free) + (cdim, cdim))
   out = Node(be.trace(t), name=node.name, backend=be)
