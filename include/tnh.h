@@ -250,6 +250,17 @@ int tnh_svd_vectors(int dtype, int64_t m, int64_t n, void* work, int64_t k,
                     void* U, void* Vh);
 int tnh_svd(int dtype, int64_t m, int64_t n, const void* A, void* U, void* S,
             void* Vh, int64_t k, void* work, int* sweeps_out);
+/* Top-k form for truncated calls (split_node with max_singular_values << min(m, n)): the sweeps
+ * do not accumulate the rotations (half the update work; *mode_out = 1) and
+ * tnh_svd_vectors_topk recovers the other side's k vectors from A with one GEMM
+ * (U_k = A Vh_k^T / s_k or Vh_k = U_k^T A / s_k) -- accurate to eps * s_1 / s_k, so only for
+ * leading triplets; the caller checks s_k / s_1 and otherwise re-runs tnh_svd_factor.
+ * *mode_out = 0 means the call fell through to tnh_svd_factor (small or complex input):
+ * use tnh_svd_vectors then. */
+int tnh_svd_factor_topk(int dtype, int64_t m, int64_t n, const void* A, void* S,
+                        void* work, int* sweeps_out, int* mode_out);
+int tnh_svd_vectors_topk(int dtype, int64_t m, int64_t n, const void* A,
+                         void* work, const void* S, int64_t k, void* U, void* Vh);
 
 /* ---- K9: thin Householder QR --------------------------------------------------
  * A (m x n, row-major, f32 / f64) = Q (m x k) R (k x n), k = min(m, n); blocked

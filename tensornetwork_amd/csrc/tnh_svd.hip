@@ -187,15 +187,17 @@ static int svd_finish(const SvdLayout& L, int64_t m, int64_t n, void* S, char* w
 // Speed path (f32 / f64): zero-padded copy, block-Jacobi sweeps (tnh_svd_block.hip).
 template <typename T>
 static int svd_factor_block(const SvdLayout& L, int dtype, int64_t m, int64_t n, const void* A, void* S,
-                            char* work, int* sweeps_out) {
+                            char* work, int* sweeps_out, bool accumulate = true) {
   T* X = (T*)(work + L.off_X);
-  T* R = (T*)(work + L.off_R);
+  T* R = accumulate ? (T*)(work + L.off_R) : nullptr;
   int* flag = (int*)(work + L.off_flag);
   const int64_t P = L.ldr, Q = L.ldx;
   int rc = svd_block_pad_copy<T>(X, P, Q, (const T*)A, m, n, L.transposed);
   if (rc) return rc;
-  rc = tnh_eye(R, P, P, dtype);
-  if (rc) return rc;
+  if (accumulate) {
+    rc = tnh_eye(R, P, P, dtype);
+    if (rc) return rc;
+  }
   const double eps = (sizeof(T) == 4) ? 5.9604644775390625e-08 : 1.1102230246251565e-16;
   const double tol = eps * sqrt((double)L.q);
   const int max_sweeps = 40;
@@ -610,6 +612,45 @@ static int svd_vectors_cplx(const SvdLayout& L, int dtype, int64_t m, int64_t n,
   return TNH_OK;
 }
 
+// Top-k mode (f32 / f64 block path): the sweeps ran WITHOUT accumulating the rotations (half the
+// update work); the orthogonalised side gives its vectors directly (rows of X / s), the other side
+// comes from A by one GEMM and a column / row scaling:
+//   m <= n:  Vh_k = X_k / s_k,   U_k  = A Vh_k^T diag(1 / s_k)
+//   m >  n:  U_k  = (X_k / s_k)^T,   Vh_k = diag(1 / s_k) U_k^T A
+// Accurate to eps * s_1 / s_k, i.e. for the LEADING singular triplets only -- the caller checks
+// s_k / s_1 before choosing this mode (HipBackend.svd).
+template <typename T>
+static int svd_vectors_topk_t(const SvdLayout& L, int dtype, int64_t m, int64_t n, const void* A, char* work,
+                              const void* S, int64_t k, void* U, void* Vh) {
+  if (k == 0) return TNH_OK;
+  const int64_t q = L.q;
+  const T* X = (const T*)(work + L.off_X);
+  const double* norms = (const double*)(work + L.off_norm);
+  const int32_t* perm = (const int32_t*)(work + L.off_perm);
+  auto grid = [&](int64_t total) {
+    int64_t b = (total + 255) / 256;
+    const int64_t cap = (int64_t)num_cus() * 16;
+    return (unsigned)(b > cap ? cap : (b < 1 ? 1 : b));
+  };
+  int rc;
+  if (!L.transposed) {
+    hipLaunchKernelGGL((emit_rows_kernel<T, false>), dim3(grid(k * q)), dim3(256), 0, stream(), (T*)Vh, X, perm,
+                       norms, k, q, L.ldx, 1);                                      // Vh (k x n)
+    TNH_LAUNCH_CHECK();
+    rc = tnh_gemm_ex(dtype, dtype, 0, 1, m, k, n, A, n, Vh, n, U, k, 1, 0, 0, 0, 1.0, 0.0);   // U = A Vh^T
+    if (rc) return rc;
+    const int64_t shape[2] = {m, k}, sa[2] = {k, 1}, sb[2] = {0, 1};
+    return tnh_binary(TNH_OP_DIV, U, U, S, 2, shape, sa, sb, dtype);                 // columns / s
+  }
+  hipLaunchKernelGGL((emit_rows_kernel<T, true>), dim3(grid(k * q)), dim3(256), 0, stream(), (T*)U, X, perm, norms,
+                     k, q, L.ldx, 1);                                               // U (m x k)
+  TNH_LAUNCH_CHECK();
+  rc = tnh_gemm_ex(dtype, dtype, 1, 0, k, n, m, U, k, A, n, Vh, n, 1, 0, 0, 0, 1.0, 0.0);     // Vh = U^T A
+  if (rc) return rc;
+  const int64_t shape[2] = {k, n}, sa[2] = {n, 1}, sb[2] = {1, 0};
+  return tnh_binary(TNH_OP_DIV, Vh, Vh, S, 2, shape, sa, sb, dtype);                 // rows / s
+}
+
 }  // namespace tnh
 
 using namespace tnh;
@@ -653,6 +694,35 @@ int tnh_svd_vectors(int dtype, int64_t m, int64_t n, void* work, int64_t k, void
   if (dtype == TNH_C128) return svd_vectors_cplx<cf64, double>(L, dtype, m, n, (char*)work, k, U, Vh);
   if (dtype == TNH_F32) return svd_vectors_t<float>(L, m, n, (char*)work, k, U, Vh);
   return svd_vectors_t<double>(L, m, n, (char*)work, k, U, Vh);
+}
+
+int tnh_svd_factor_topk(int dtype, int64_t m, int64_t n, const void* A, void* S, void* work, int* sweeps_out,
+                        int* mode_out) {
+  TNH_NEED_INIT();
+  TNH_REQUIRE(mode_out != nullptr, "null pointer");
+  *mode_out = 0;
+  const bool real = (dtype == TNH_F32 || dtype == TNH_F64);
+  if (!real || m <= 0 || n <= 0) return tnh_svd_factor(dtype, m, n, A, S, work, sweeps_out);
+  TNH_REQUIRE(A && S && work, "null pointer");
+  const SvdLayout L = svd_layout(dtype, m, n);
+  if (!L.block) return tnh_svd_factor(dtype, m, n, A, S, work, sweeps_out);   // small path: always accumulates
+  if (sweeps_out) *sweeps_out = 0;
+  *mode_out = 1;
+  if (dtype == TNH_F32) return svd_factor_block<float>(L, dtype, m, n, A, S, (char*)work, sweeps_out, false);
+  return svd_factor_block<double>(L, dtype, m, n, A, S, (char*)work, sweeps_out, false);
+}
+
+int tnh_svd_vectors_topk(int dtype, int64_t m, int64_t n, const void* A, void* work, const void* S, int64_t k,
+                         void* U, void* Vh) {
+  TNH_NEED_INIT();
+  TNH_REQUIRE(dtype == TNH_F32 || dtype == TNH_F64, "top-k SVD vectors support f32 / f64 (got dtype %d)", dtype);
+  TNH_REQUIRE(k >= 0 && k <= std::min(m, n), "k out of range");
+  if (k == 0) return TNH_OK;
+  TNH_REQUIRE(A && U && Vh && work && S, "null pointer");
+  const SvdLayout L = svd_layout(dtype, m, n);
+  TNH_REQUIRE(L.block, "top-k vectors need the block path (min(m, n) > 64)");
+  if (dtype == TNH_F32) return svd_vectors_topk_t<float>(L, dtype, m, n, A, (char*)work, S, k, U, Vh);
+  return svd_vectors_topk_t<double>(L, dtype, m, n, A, (char*)work, S, k, U, Vh);
 }
 
 int tnh_svd(int dtype, int64_t m, int64_t n, const void* A, void* U, void* S, void* Vh, int64_t k,

@@ -585,7 +585,9 @@ int svd_block_sweeps(T* X, T* R, int64_t P, int64_t Q, char* scratch, int* flag,
   if (S < 1) S = 1;
   const int cpw = (chunks + 4 * S - 1) / (4 * S);
   const int sw = F64 ? 32 : 128;    // strip width of the update kernel
-  const int nssX = (int)(Q / sw), nssR = (int)(P / sw);
+  // R == nullptr: the rotations are not accumulated (top-k mode: the other side's vectors are
+  // recovered from A by one GEMM, tnh_svd_vectors_topk) -- the update kernel then has half the strips
+  const int nssX = (int)(Q / sw), nssR = R ? (int)(P / sw) : 0;
   const char* env = getenv("TNH_SVD_INNER");
   const int inner = env ? atoi(env) : 1;
   const char* envc = getenv("TNH_SVD_CROSS");

@@ -767,14 +767,25 @@ class HipBackend(BackendBase):
     work = DeviceTensor.empty((max(nbytes.value, 8) // 8 + 1,), _lib.F64)
     s_all = DeviceTensor.empty((r,), real_code)
     sweeps = ctypes.c_int(0)
-    _lib.check(self.lib.tnh_svd_factor(work_code, m, n, _vp(mat), _vp(s_all), _vp(work),
-                                       ctypes.byref(sweeps)), "tnh_svd_factor")
+    # top-k mode: a call that keeps at most half of the spectrum does not need the accumulated
+    # rotations of the other side -- its k vectors come from A by one GEMM (tnh_svd_vectors_topk)
+    topk = (max_singular_values is not None and 2 * int(max_singular_values) <= r and
+            getattr(self, "svd_topk", True))
+    mode = ctypes.c_int(0)
+    if topk:
+      _lib.check(self.lib.tnh_svd_factor_topk(work_code, m, n, _vp(mat), _vp(s_all), _vp(work),
+                                              ctypes.byref(sweeps), ctypes.byref(mode)), "tnh_svd_factor_topk")
+    else:
+      _lib.check(self.lib.tnh_svd_factor(work_code, m, n, _vp(mat), _vp(s_all), _vp(work),
+                                         ctypes.byref(sweeps)), "tnh_svd_factor")
     self.last_svd_sweeps = sweeps.value
 
     if max_singular_values is None:
       max_singular_values = r
-    if max_truncation_error is not None:
+    s_host = None
+    if max_truncation_error is not None or mode.value == 1:
       s_host = s_all.numpy().astype(np.float64)
+    if max_truncation_error is not None:
       # cumulative norms of the singular values in ascending order
       trunc_errs = np.sqrt(np.cumsum(np.square(s_host[::-1])))
       abs_err = max_truncation_error * (s_host[0] if r else 0.0) if relative else max_truncation_error
@@ -786,8 +797,18 @@ class HipBackend(BackendBase):
 
     u = DeviceTensor.empty((m, keep), work_code)
     vh = DeviceTensor.empty((keep, n), work_code)
-    _lib.check(self.lib.tnh_svd_vectors(work_code, m, n, _vp(work), keep, _vp(u), _vp(vh)),
-               "tnh_svd_vectors")
+    if mode.value == 1 and keep > 0 and not (s_host[keep - 1] > 0.0 and s_host[keep - 1] * 100.0 >= s_host[0]):
+      # the kept triplets are not all leading ones (s_k < s_1 / 100): recover-from-A would lose
+      # eps * s_1 / s_k of orthogonality -- run the accumulating factorisation instead
+      _lib.check(self.lib.tnh_svd_factor(work_code, m, n, _vp(mat), _vp(s_all), _vp(work),
+                                         ctypes.byref(sweeps)), "tnh_svd_factor")
+      mode.value = 0
+    if mode.value == 1:
+      _lib.check(self.lib.tnh_svd_vectors_topk(work_code, m, n, _vp(mat), _vp(work), _vp(s_all), keep, _vp(u),
+                                               _vp(vh)), "tnh_svd_vectors_topk")
+    else:
+      _lib.check(self.lib.tnh_svd_vectors(work_code, m, n, _vp(work), keep, _vp(u), _vp(vh)),
+                 "tnh_svd_vectors")
     s = self.getitem(s_all, slice(0, keep))
     s_rest = self.getitem(s_all, slice(keep, r))
     if orig_code != work_code:

@@ -490,6 +490,39 @@ def test_svd_block_path(hip, dtype, rtol_s, otol, shape):
   _check_svd(hip, b, 20 * rtol_s, 20 * otol, max_singular_values=min(shape) // 4)
 
 
+@pytest.mark.parametrize("dtype,otol", [(np.float32, 1e-4), (np.float64, 1e-11)])
+@pytest.mark.parametrize("shape", [(384, 512), (600, 300)])
+def test_svd_topk_mode(hip, dtype, otol, shape):
+  """Truncated calls keeping <= half the spectrum skip the rotation accumulation and recover the other
+  side from A (tnh_svd_vectors_topk): same factors as the accumulating path, and the automatic
+  fallback when the kept values are not all leading ones."""
+  rng = np.random.default_rng(shape[0])
+  a = rng.standard_normal(shape).astype(dtype)
+  k = 40
+  d = dev(hip, a)
+  u, s, vh, rest = [np.asarray(x) for x in hip.svd(d, 1, max_singular_values=k)]
+  hip.svd_topk = False
+  try:
+    u0, s0, vh0, rest0 = [np.asarray(x) for x in hip.svd(d, 1, max_singular_values=k)]
+  finally:
+    hip.svd_topk = True
+  np.testing.assert_allclose(s, s0, rtol=1e-5 if dtype == np.float32 else 1e-12)
+  np.testing.assert_allclose(rest, rest0, rtol=1e-5 if dtype == np.float32 else 1e-12, atol=1e-6)
+  np.testing.assert_allclose(u.T @ u, np.eye(k), atol=otol)
+  np.testing.assert_allclose(vh @ vh.T, np.eye(k), atol=otol)
+  np.testing.assert_allclose((u * s) @ vh, (u0 * s0) @ vh0, atol=otol * np.abs(a).max() * 30)
+  # graded spectrum: s_k << s_1 -> the backend falls back to the accumulating factorisation by itself
+  q1, _ = np.linalg.qr(rng.standard_normal((shape[0], shape[0])))
+  q2, _ = np.linalg.qr(rng.standard_normal((shape[1], shape[1])))
+  r = min(shape)
+  spec = 10.0 ** (-np.arange(r) / 8.0)
+  g = ((q1[:, :r] * spec) @ q2[:r]).astype(dtype)
+  u, s, vh, _ = [np.asarray(x) for x in hip.svd(dev(hip, g), 1, max_singular_values=k)]
+  np.testing.assert_allclose(s, spec[:k], rtol=2e-3 if dtype == np.float32 else 1e-9, atol=1e-6 if dtype == np.float32 else 1e-14)
+  np.testing.assert_allclose(u.T @ u, np.eye(k), atol=otol * 3)
+  np.testing.assert_allclose(vh @ vh.T, np.eye(k), atol=otol * 3)
+
+
 def test_svd_prescribed_spectrum_512(hip):
   # SURVEY 8d config-3 input (ii): s_i = 2^(-i/32), Haar factors
   rng = np.random.default_rng(4)
