@@ -11,7 +11,7 @@ Works on ``tensornetwork_amd.network.Node`` objects; the search itself is pure
 host code, the pairwise steps are GEMMs on the backend.
 """
 import functools
-from typing import Callable, Iterable, List, Optional, Sequence, Tuple
+from typing import Dict, Callable, Iterable, List, Optional, Sequence, Tuple
 
 from tensornetwork_amd import network, pathfinder
 
@@ -60,6 +60,25 @@ def get_path(nodes: Iterable[network.Node], algorithm: Callable) -> Tuple[List[T
   return path, nodes
 
 
+def _edge_times(path: Sequence[Tuple[int, ...]], nodes: Sequence[network.Node]) -> Dict[network.Edge, int]:
+  """edge -> index of the path step that contracts it (host-only dry run of the path over sets of
+  original nodes).  Feeds the layout planning of network.contract_between."""
+  groups = [{id(n)} for n in nodes]
+  owner_edges = [set(n.edges) for n in nodes]
+  times: Dict[network.Edge, int] = {}
+  for step, pair in enumerate(path):
+    if len(pair) == 1:
+      continue
+    a, b = sorted(pair)
+    for e in owner_edges[a] & owner_edges[b]:
+      times[e] = step
+    merged_nodes = groups[a] | groups[b]
+    merged_edges = owner_edges[a] ^ owner_edges[b]
+    groups = [g for i, g in enumerate(groups) if i not in (a, b)] + [merged_nodes]
+    owner_edges = [g for i, g in enumerate(owner_edges) if i not in (a, b)] + [merged_edges]
+  return times
+
+
 def contract_path(path: Sequence[Tuple[int, ...]], nodes: Iterable[network.Node],
                   output_edge_order: Optional[Sequence[network.Edge]] = None) -> network.Node:
   """Run a linear path (path_contractors.py:354-403)."""
@@ -73,11 +92,12 @@ def contract_path(path: Sequence[Tuple[int, ...]], nodes: Iterable[network.Node]
       if node in nodes:
         new = network.contract_trace_edges(node)
         nodes[nodes.index(node)] = new
+  edge_time = _edge_times(path, nodes)
   for pair in path:
     if len(pair) == 1:
       continue
     a, b = sorted(pair)
-    new = network.contract_between(nodes[a], nodes[b], allow_outer_product=True)
+    new = network.contract_between(nodes[a], nodes[b], allow_outer_product=True, edge_time=edge_time)
     nodes = [n for i, n in enumerate(nodes) if i not in (a, b)] + [new]
   final = nodes[0]
   if len(nodes) != 1:

@@ -320,6 +320,20 @@ class HipBackend(BackendBase):
     return axes_a, axes_b
 
   def tensordot(self, a, b, axes):
+    return self._tensordot_impl(a, b, axes, None, None)[0]
+
+  def tensordot_planned(self, a, b, axes, free_order_a=None, free_order_b=None):
+    """``tensordot`` whose result may carry the free axes of an operand in a caller-chosen order
+    -- but only where that is FREE: an operand that needs a K1 permute anyway (its contracted axes
+    are neither leading nor trailing) is permuted straight into ``free_order_x + contracted``;
+    an operand consumed in place keeps its natural order.  Returns ``(tensor, used_a, used_b)``
+    with the free axes of ``a`` / ``b`` in result order.  The contractors use it to lay a big
+    intermediate out for the NEXT contractions while they pay for the current permute
+    (tensornetwork_amd.contractors.contract_path): permutes are HBM-bound, skipping one saves
+    2 x bytes of traffic."""
+    return self._tensordot_impl(a, b, axes, free_order_a, free_order_b)
+
+  def _tensordot_impl(self, a, b, axes, hint_a, hint_b):
     """c[free_a..., free_b...] = sum_axes a*b (abstract_backend.py:27-38).
 
     Lowered as transpose + reshape + ONE GEMM (the reference's own spec for this
@@ -338,13 +352,13 @@ class HipBackend(BackendBase):
 
     free_a = [i for i in range(a.ndim) if i not in axes_a]
     free_b = [i for i in range(b.ndim) if i not in axes_b]
-    out_shape = tuple(a.shape[i] for i in free_a) + tuple(b.shape[i] for i in free_b)
     m = _prod(a.shape[i] for i in free_a)
     n = _prod(b.shape[i] for i in free_b)
     k = _prod(a.shape[i] for i in axes_a)
     nc = len(axes_a)
     if nc == 0:
-      return self._outer(a, b, out_shape)
+      out_shape = tuple(a.shape[i] for i in free_a) + tuple(b.shape[i] for i in free_b)
+      return self._outer(a, b, out_shape), free_a, free_b
 
     # memory order of the contracted pairs on each side
     order_a = sorted(range(nc), key=lambda i: axes_a[i])
@@ -379,21 +393,27 @@ class HipBackend(BackendBase):
       pair_order = order_b
     else:
       pair_order = order_a
+    a_shape, b_shape = a.shape, b.shape
     if not want_a:
+      if hint_a is not None and sorted(hint_a) == free_a:
+        free_a = [int(i) for i in hint_a]       # the permute is paid anyway: any free order is free
       a = self.transpose(a, free_a + [axes_a[i] for i in pair_order])
       a_form = "MK"
     if not want_b:
+      if hint_b is not None and sorted(hint_b) == free_b:
+        free_b = [int(i) for i in hint_b]
       b = self.transpose(b, free_b + [axes_b[i] for i in pair_order])
       b_form = "NK"
+    out_shape = tuple(a_shape[i] for i in free_a) + tuple(b_shape[i] for i in free_b)
 
     trans_a = a_form == "KM"
     trans_b = b_form == "NK"
     lda = m if trans_a else k
     ldb = k if trans_b else n
     if code in _REAL_OF and 8 * m * n * k >= (1 << 18):
-      return self._complex_gemm(a, b, trans_a, trans_b, m, n, k).view(out_shape)
+      return self._complex_gemm(a, b, trans_a, trans_b, m, n, k).view(out_shape), free_a, free_b
     out = self._gemm(a, b, trans_a, trans_b, m, n, k, lda, ldb)
-    return out.view(out_shape)
+    return out.view(out_shape), free_a, free_b
 
   def _complex_gemm(self, a, b, trans_a, trans_b, m, n, k):
     """complex64 / complex128 product on the f32 / f64 matrix cores: the interleaved (re, im)

@@ -286,9 +286,17 @@ def outer_product(node1: Node, node2: Node, name: Optional[str] = None) -> Node:
 def contract_between(node1: Node, node2: Node, name: Optional[str] = None,
                      allow_outer_product: bool = False,
                      output_edge_order: Optional[Sequence[Edge]] = None,
-                     axis_names: Optional[List[str]] = None) -> Node:
+                     axis_names: Optional[List[str]] = None,
+                     edge_time: Optional[Dict[Edge, int]] = None) -> Node:
   """Contract all edges shared by two nodes with ONE tensordot
-  (network_components.py:1984-2095)."""
+  (network_components.py:1984-2095).
+
+  ``edge_time`` (from a contractor that knows the whole path: edge -> index of the step that
+  contracts it) turns on layout planning when the backend offers ``tensordot_planned``: the
+  operand whose legs are contracted soonest goes second, and the free axes of an operand are
+  requested latest-first / soonest-last, so that the legs of the NEXT contractions end up trailing
+  in the result -- the K-contiguous form the GEMM consumes without another permute.  The axis order
+  of an intermediate is bookkeeping here (edges follow their axes), so this is free to choose."""
   if node1.backend.name != node2.backend.name:
     raise ValueError(f"The backends of {node1} and {node2} do not match: "
                      f"{node1.backend.name} vs {node2.backend.name}")
@@ -316,10 +324,29 @@ def contract_between(node1: Node, node2: Node, name: Optional[str] = None,
         pairs.append((e.axis2, e.axis1))
     pairs.sort()
     axes1, axes2 = [p[0] for p in pairs], [p[1] for p in pairs]
-    t = be.tensordot(node1.tensor, node2.tensor, [axes1, axes2])
-    out = Node(t, name=name, backend=be)
-    sources = [(node1, i) for i in range(len(node1.edges)) if i not in axes1] + \
-              [(node2, i) for i in range(len(node2.edges)) if i not in axes2]
+    if edge_time is not None and output_edge_order is None and hasattr(be, "tensordot_planned"):
+      never = float("inf")
+
+      def plan(node, axes):
+        free = [i for i in range(len(node.edges)) if i not in axes]
+        when = {i: edge_time.get(node.edges[i], never) for i in free}
+        order = sorted(free, key=lambda i: -when[i] if when[i] != never else float("-inf"))
+        return order, min(when.values(), default=never)
+
+      order1, soon1 = plan(node1, axes1)
+      order2, soon2 = plan(node2, axes2)
+      if soon1 < soon2:   # node1's legs are needed first: it goes second so that they end up trailing
+        node1, node2, axes1, axes2, order1, order2 = node2, node1, axes2, axes1, order2, order1
+        pairs = sorted(zip(axes1, axes2))
+        axes1, axes2 = [p[0] for p in pairs], [p[1] for p in pairs]
+      t, used1, used2 = be.tensordot_planned(node1.tensor, node2.tensor, [axes1, axes2], order1, order2)
+      out = Node(t, name=name, backend=be)
+      sources = [(node1, i) for i in used1] + [(node2, i) for i in used2]
+    else:
+      t = be.tensordot(node1.tensor, node2.tensor, [axes1, axes2])
+      out = Node(t, name=name, backend=be)
+      sources = [(node1, i) for i in range(len(node1.edges)) if i not in axes1] + \
+                [(node2, i) for i in range(len(node2.edges)) if i not in axes2]
     _adopt_edges(out, sources)
   if output_edge_order is not None:
     output_edge_order = list(output_edge_order)
