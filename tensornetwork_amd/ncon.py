@@ -71,10 +71,13 @@ def _check(tensors, network_structure, con_order, out_order):
 class _Engine:
   """Mutable list of (tensor, labels) operands plus the contraction primitives."""
 
-  def __init__(self, backend, tensors, labels, keep):
+  def __init__(self, backend, tensors, labels, keep, when=None):
     self.be = backend
     self.ops = [(t, list(l)) for t, l in zip(tensors, labels)]
     self.keep = set(keep)  # labels that must survive (outputs)
+    # label -> position in the contraction order: lets contract_pair lay a result out for the
+    # contractions that follow (soonest-contracted labels trailing), see contractors.contract_path
+    self.when = when or {}
 
   def count(self, label) -> int:
     return sum(labels.count(label) for _, labels in self.ops)
@@ -123,6 +126,24 @@ class _Engine:
     batch = [l for l in shared if l not in closing]
     be = self.be
     if not batch:
+      if closing and self.when and hasattr(be, "tensordot_planned"):
+        never = float("inf")
+        def plan(labels):
+          free = [n for n, l in enumerate(labels) if l not in closing]
+          t = {n: self.when.get(labels[n], never) for n in free}
+          return sorted(free, key=lambda n: -t[n] if t[n] != never else float("-inf")), min(t.values(), default=never)
+        o1, soon1 = plan(l1)
+        o2, soon2 = plan(l2)
+        if soon1 < soon2:   # t1's labels are contracted first: it goes second so that they end up trailing
+          t1, t2, l1, l2, o1, o2 = t2, t1, l2, l1, o2, o1
+        ax1 = [l1.index(l) for l in closing]
+        ax2 = [l2.index(l) for l in closing]
+        order = sorted(range(len(ax1)), key=lambda n: ax1[n])
+        result, u1, u2 = be.tensordot_planned(t1, t2, (tuple(ax1[n] for n in order), tuple(ax2[n] for n in order)),
+                                              o1, o2)
+        new_labels = [l1[n] for n in u1] + [l2[n] for n in u2]
+        self.ops.append((result, new_labels))
+        return closing
       if closing:
         ax1 = [l1.index(l) for l in closing]
         ax2 = [l2.index(l) for l in closing]
@@ -176,7 +197,7 @@ def ncon(tensors: Sequence[Any], network_structure: Sequence[Sequence], con_orde
   con_order = list(con_order) if con_order is not None else d_cont
   out_order = list(out_order) if out_order is not None else d_out
 
-  eng = _Engine(be, tensors, network_structure, keep=out_order)
+  eng = _Engine(be, tensors, network_structure, keep=out_order, when={l: i for i, l in enumerate(con_order)})
   done = set()
   for idx in range(len(eng.ops)):
     done.update(eng.trace_repeated(idx))
