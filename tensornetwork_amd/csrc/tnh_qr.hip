@@ -223,11 +223,19 @@ __global__ __launch_bounds__(256) void qr_col_kernel(T* __restrict__ P, int64_t 
   __shared__ double colred[8][33];
   __shared__ double d_s[32];
   const int tid = threadIdx.x, tx = tid & 31, ty = tid >> 5, lane = tid & 63;
-  // 1. reduce the partial dots of column c (fixed order: deterministic)
-  if (tid < 32) {
+  // 1. reduce the partial dots of column c: 8 row lanes x 32 columns, each lane sums every 8th
+  //    workgroup's partial, then the lanes are combined (fixed order: deterministic)
+  {
     double s = 0.0;
-    for (int g = 0; g < nwg; ++g) s += part_in[(int64_t)g * 32 + tid];
-    d_s[tid] = s;
+    for (int g = ty; g < nwg; g += 8) s += part_in[(int64_t)g * 32 + tx];
+    colred[ty][tx] = s;
+    __syncthreads();
+    if (tid < 32) {
+      double r = 0.0;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) r += colred[i][tid];
+      d_s[tid] = r;
+    }
   }
   __syncthreads();
   // 2. larfg: every thread derives the same scalars.  The pivot row is read from row_in (written by
