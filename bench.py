@@ -135,8 +135,8 @@ def cpu_baseline(layout):
   t64 = run(64)
   flops64 = 2.0 * 64**6
   D = 64
-  for cand in (96, 128):
-    est = t64 * (cand / 64.0)**6
+  for cand in (96, 128, 160):
+    est = 2.5 * t64 * (cand / 64.0)**6   # the D=64 probe runs from cache: larger sizes are ~2.5x slower per flop
     if est <= 30.0:
       D = cand
   t = run(D) if D != 64 else t64
