@@ -236,6 +236,100 @@ __global__ __launch_bounds__(256) void gemm_mfma_f64_kernel(GemmArgs g) {
     }
 }
 
+// f64, large products: 128x128x32 tile, 4 waves of 64x64 (4x4 v_mfma_f64_16x16x4_f64, 8 LDS reads per 16
+// MFMAs instead of 4 per 4; 128 MFMAs per wave between barriers).  LDS image [row][k] with a 34-double
+// pitch: the fragment read (16 rows x 2 k per 32-lane half) and both global->LDS write patterns
+// (k-contiguous or row-contiguous operand) are bank-conflict free (row pitch 68 dwords = 4 mod 64: 16 rows
+// land on 16 distinct 4-bank groups).
+__global__ __launch_bounds__(256) void gemm_mfma_f64_128_kernel(GemmArgs g) {
+  constexpr int BM = 128, BN = 128, BK = 32, LD = 34;
+  __shared__ double As[BM][LD];
+  __shared__ double Bs[BN][LD];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wid = tid >> 6;
+  const int wm = wid >> 1, wn = wid & 1;
+  const int64_t m0 = (int64_t)blockIdx.y * BM, n0 = (int64_t)blockIdx.x * BN;
+  const double* A = (const double*)g.A + (int64_t)blockIdx.z * g.sA;
+  const double* B = (const double*)g.B + (int64_t)blockIdx.z * g.sB;
+  double* C = (double*)g.C + (int64_t)blockIdx.z * g.sC;
+  const bool a_k_contig = (g.csA == 1);
+  const bool b_k_contig = (g.rsB == 1);
+  double ra[16], rb[16];
+  auto load_tile = [&](int64_t k0) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      int mm, kk;
+      if (a_k_contig) { kk = tid & 31; mm = (tid >> 5) + 8 * j; }
+      else { mm = tid & 127; kk = (tid >> 7) + 2 * j; }
+      const int64_t m = m0 + mm, k = k0 + kk;
+      ra[j] = (m < g.M && k < g.K) ? A[m * g.rsA + k * g.csA] : 0.0;
+      int nn;
+      if (b_k_contig) { kk = tid & 31; nn = (tid >> 5) + 8 * j; }
+      else { nn = tid & 127; kk = (tid >> 7) + 2 * j; }
+      const int64_t n = n0 + nn, kb = k0 + kk;
+      rb[j] = (n < g.N && kb < g.K) ? B[kb * g.rsB + n * g.csB] : 0.0;
+    }
+  };
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      int mm, kk;
+      if (a_k_contig) { kk = tid & 31; mm = (tid >> 5) + 8 * j; }
+      else { mm = tid & 127; kk = (tid >> 7) + 2 * j; }
+      As[mm][kk] = ra[j];
+      int nn;
+      if (b_k_contig) { kk = tid & 31; nn = (tid >> 5) + 8 * j; }
+      else { nn = tid & 127; kk = (tid >> 7) + 2 * j; }
+      Bs[nn][kk] = rb[j];
+    }
+  };
+  f64x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.0;
+
+  const int64_t nt = (g.K + BK - 1) / BK;
+  load_tile(0);
+  const int kl = lane >> 4, il = lane & 15;
+  for (int64_t t = 0; t < nt; ++t) {
+    store_tile();
+    __syncthreads();
+    if (t + 1 < nt) load_tile((t + 1) * BK);
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 4) {
+      double a[4], b[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a[i] = As[wm * 64 + i * 16 + il][kk + kl];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) b[j] = Bs[wn * 64 + j * 16 + il][kk + kl];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  // f64 C/D layout: col = lane & 15, row = (lane >> 4) + 4 * r
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int64_t n = n0 + wn * 64 + j * 16 + (lane & 15);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int64_t m = m0 + wm * 64 + i * 16 + (lane >> 4) + 4 * r;
+        if (m < g.M && n < g.N) {
+          double v = g.alpha * acc[i][j][r];
+          if (g.beta != 0.0) v += g.beta * C[m * g.ldc + n];
+          C[m * g.ldc + n] = v;
+        }
+      }
+    }
+}
+
 // ---------------------------------------------------------------------- VALU
 __device__ __forceinline__ float fma_t(float a, float b, float c) { return fmaf(a, b, c); }
 __device__ __forceinline__ double fma_t(double a, double b, double c) { return fma(a, b, c); }
@@ -502,6 +596,18 @@ int tnh_gemm_ex(int in_dtype, int out_dtype, int transA, int transB, int64_t M, 
           return 0;
         },
         g, batch, 64, 64);
+  }
+  if (in_dtype == TNH_F64 && M >= 128 && N >= 128 && ((M + 127) / 128) * ((N + 127) / 128) * batch >= 128 &&
+      g_variant != 1) {
+    // enough 128x128 tiles to occupy the chip: the wider tile halves the LDS reads per MFMA
+    g_last_kernel = "mfma_f64_128x128x32";
+    return launch_batched(
+        [&](const GemmArgs&, int64_t b0, dim3 grid) -> int {
+          GemmArgs h = shifted(b0);
+          hipLaunchKernelGGL(gemm_mfma_f64_128_kernel, grid, dim3(256), 0, stream(), h);
+          return 0;
+        },
+        g, batch, 128, 128);
   }
   if (in_dtype == TNH_F64) {
     g_last_kernel = "mfma_f64_64x64x16";

@@ -311,6 +311,17 @@ def test_tensordot_random_axes_property(hip, dtype):
                                rtol=max(tol, 1e-5), atol=max(tol, 1e-5) * 10)
 
 
+@pytest.mark.parametrize("ta_,tb_", [(0, 0), (0, 1), (1, 0), (1, 1)])
+def test_gemm_f64_128_tile(hip, ta_, tb_):
+  """f64 products with >= 128 tiles of 128x128 take the wider MFMA kernel; ragged edges, every layout."""
+  out, ref, kernel, sk = _gemm_case(hip, np.float64, 1500, 1400, 203, ta_, tb_, rng=np.random.default_rng(3))
+  assert kernel == "mfma_f64_128x128x32", kernel
+  np.testing.assert_allclose(out, ref, rtol=1e-14 * sk, atol=1e-14 * 203)
+  out, ref, kernel, sk = _gemm_case(hip, np.complex128, 1400, 800, 160, ta_, tb_, rng=np.random.default_rng(4))
+  assert kernel == "mfma_f64_128x128x32", kernel     # complex128 rides the same kernel (real expansion)
+  np.testing.assert_allclose(out, ref, rtol=1e-14 * sk * 4, atol=1e-14 * 160 * 2)
+
+
 def test_tensordot_golden(hip, golden):
   for case in golden.cases["tensordot"]:
     C.assert_close(C.run_tensordot(hip, golden, case), golden[case["out"]])
