@@ -130,7 +130,7 @@ class FiniteMPS:
     return float(np.real(self.backend.item(self.backend.norm(t))))
 
   def position(self, site: int, normalize: bool = True, D: Optional[int] = None,
-               max_truncation_err: Optional[float] = None):
+               max_truncation_err: Optional[float] = None, norms_out: Optional[List[float]] = None):
     """Move the orthogonality centre to ``site`` with QR / RQ steps, or truncating SVDs when
     ``D`` / ``max_truncation_err`` ask for it (base_mps.py:139-226).  Returns the norm of the
     centre tensor before the last normalisation."""
@@ -156,6 +156,8 @@ class FiniteMPS:
         self.tensors[n] = iso
         self.tensors[n + 1] = ncon([rest, self.tensors[n + 1]], [[-1, 1], [1, -2, -3]], backend=be)
         z = self._norm(self.tensors[n + 1])
+        if norms_out is not None:
+          norms_out.append(z)
         if normalize:
           self.tensors[n + 1] = be.divide(self.tensors[n + 1], z)
     else:
@@ -169,6 +171,8 @@ class FiniteMPS:
         self.tensors[n] = iso
         self.tensors[n - 1] = ncon([self.tensors[n - 1], rest], [[-1, -2, 1], [1, -3]], backend=be)
         z = self._norm(self.tensors[n - 1])
+        if norms_out is not None:
+          norms_out.append(z)
         if normalize:
           self.tensors[n - 1] = be.divide(self.tensors[n - 1], z)
     self.center_position = site
@@ -176,12 +180,25 @@ class FiniteMPS:
 
   def canonicalize(self, normalize: bool = True):
     """Bring the state into canonical form around ``center_position`` (finite_mps.py:123-146):
-    sweep the centre to the right end, back to the left end, then to where it was."""
+    sweep the centre to the right end, back to the left end, then to where it was.  Every step is
+    normalised and the norms are multiplied up on the host in float64 -- the norm of a random
+    32-site state does not fit float32, and an un-normalised sweep would overflow inside the
+    tensors.  Returns the norm of the state; with ``normalize=False`` it is put back on the centre."""
+    be = self.backend
     pos = self.center_position
+    norms: List[float] = []
     self.center_position = 0
-    self.position(len(self.tensors) - 1, normalize=False)
-    self.position(0, normalize=False)
-    return self.position(pos, normalize=normalize)
+    self.position(len(self.tensors) - 1, normalize=True, norms_out=norms)
+    self.position(0, normalize=True, norms_out=norms)
+    self.position(pos, normalize=True, norms_out=norms)
+    z = self._norm(self.tensors[pos])
+    self.tensors[pos] = be.divide(self.tensors[pos], z)
+    total = z
+    for x in norms:
+      total *= x
+    if not normalize:
+      self.tensors[pos] = be.multiply(self.tensors[pos], total)
+    return total
 
   def check_orthonormality(self, which: str, site: int):
     """|| A^dagger A - 1 || (left) or || B B^dagger - 1 || (right) (base_mps.py:616-650)."""

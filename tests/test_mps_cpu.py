@@ -71,3 +71,19 @@ def test_two_site_gate_and_local_measurement():
   state.apply_two_site_gate(swap, 2, 3)
   after = state.measure_local_operator([sz] * n, range(n))
   np.testing.assert_allclose([after[3], after[2]], [before[2], before[3]], atol=1e-10)
+
+
+def test_canonicalize_long_chain_float32_and_norm_bookkeeping():
+  """A random 32-site state has a norm beyond float32: canonicalize normalises every step and keeps the
+  norm on the host; normalize=False puts it back on the centre (small chain, exact check)."""
+  be = orc.OracleBackend()
+  state = tmps.FiniteMPS.random([2] * 32, [16] * 31, np.float32, be, seed=1)
+  assert np.isfinite(np.asarray(state.tensors[0])).all()
+  np.testing.assert_allclose(np.linalg.norm(state.tensors[0]), 1.0, atol=1e-5)
+  rng = np.random.default_rng(0)
+  ts = [rng.standard_normal((1, 2, 3)), rng.standard_normal((3, 2, 3)), rng.standard_normal((3, 2, 1))]
+  full = np.einsum("aib,bjc,ckd->ijk", *ts)
+  st = tmps.FiniteMPS(ts, be, center_position=1, canonicalize=False)
+  z = st.canonicalize(normalize=False)
+  np.testing.assert_allclose(z, np.linalg.norm(full), rtol=1e-12)
+  np.testing.assert_allclose(np.einsum("aib,bjc,ckd->ijk", *st.tensors), full, atol=1e-12)
