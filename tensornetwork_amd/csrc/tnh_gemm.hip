@@ -13,6 +13,7 @@
 // Operands are addressed as A(m,k) = A[m*rsA + k*csA], B(k,n) = B[k*rsB + n*csB],
 // so the four transpose combinations are one kernel.  MFMA roofline: 2*M*N*K flop.
 #include <stdlib.h>
+#include <algorithm>
 #include "tnh_types.h"
 
 namespace tnh {
@@ -440,6 +441,7 @@ __global__ __launch_bounds__(256) void complex_expand_kernel(R* __restrict__ dst
 }
 
 static thread_local const char* g_last_kernel = "none";
+static thread_local bool g_in_splitk = false;   // re-entrancy guard of the split-K path
 static int g_variant = 0;  // 0 auto, 1 generic (mfma), 2 valu, 3 bf16_128, 4 bf16_256, 5 bf16_256pp,
                            // 6 bf16_ragged (auto shape), 7 .._128x128, 8 .._64x256, 9 .._256x64
 
@@ -554,6 +556,50 @@ int tnh_gemm_ex(int in_dtype, int out_dtype, int transA, int transB, int64_t M, 
   TNH_REQUIRE(ldb >= (transB ? K : N), "ldb too small");
 
   const bool plain = (alpha == 1.0 && beta == 0.0);
+
+  // ---- split-K: few output tiles and a long contraction (inner products <x, y>, environment
+  // updates with a small result ...).  One workgroup per tile would walk all of K alone -- a
+  // 262144-long dot product took 0.86 ms on ONE CU -- so K is cut into slices computed as one
+  // strided-batched GEMM into f32 / f64 partials, summed by the K4 reduction (fixed order).
+  const bool cplx_in = (in_dtype == TNH_C64 || in_dtype == TNH_C128);
+  if (plain && !cplx_in && batch == 1 && ldc == N && K >= 4096 && g_variant == 0 && !g_in_splitk) {
+    const int64_t tiles = ((M + 127) / 128) * ((N + 127) / 128);
+    int64_t splits = std::min<int64_t>({K / 1024, (2 * (int64_t)num_cus()) / tiles, 256});
+    if (tiles * 4 <= (int64_t)num_cus() && splits >= 2) {
+      int64_t kc = (K + splits - 1) / splits;
+      kc = (kc + 63) / 64 * 64;                       // keeps the bf16 kernels' K % 64 rule for full slices
+      const int64_t full = K / kc, rem = K - full * kc;
+      const int part_dt = half_in ? TNH_F32 : in_dtype;
+      const int esz_p = dtype_size(part_dt), esz_in = dtype_size(in_dtype);
+      const int64_t parts = full + (rem > 0 ? 1 : 0);
+      void* W = nullptr;
+      int rc = tnh_malloc(&W, (size_t)parts * M * N * esz_p);
+      if (rc) return rc;
+      g_in_splitk = true;
+      const int64_t sA = transA ? kc * lda : kc, sB = transB ? kc : kc * ldb;
+      rc = tnh_gemm_ex(in_dtype, part_dt, transA, transB, M, N, kc, A, lda, B, ldb, W, N, full, sA, sB, M * N, 1.0, 0.0);
+      if (!rc && rem > 0)
+        rc = tnh_gemm_ex(in_dtype, part_dt, transA, transB, M, N, rem, (const char*)A + (size_t)full * sA * esz_in, lda,
+                         (const char*)B + (size_t)full * sB * esz_in, ldb, (char*)W + (size_t)full * M * N * esz_p, N, 1,
+                         0, 0, 0, 1.0, 0.0);
+      g_in_splitk = false;
+      if (!rc) {
+        if (part_dt == out_dtype) {
+          rc = tnh_sum_mid(C, W, 1, parts, M * N, part_dt);
+        } else {   // half output: reduce in f32, then one cast
+          void* T32 = nullptr;
+          rc = tnh_malloc(&T32, (size_t)M * N * 4);
+          if (!rc) rc = tnh_sum_mid(T32, W, 1, parts, M * N, TNH_F32);
+          if (!rc) rc = tnh_cast(C, out_dtype, T32, TNH_F32, M * N);
+          if (T32) tnh_free(T32);
+        }
+      }
+      tnh_free(W);
+      if (!rc) g_last_kernel = "splitk";
+      return rc;
+    }
+  }
+
   if (half_in && plain && (g_variant == 0 || g_variant >= 3)) {
     const char* name = nullptr;
     int rc = gemm_bf16_fast(in_dtype, out_dtype, g_variant, transA, transB, M, N, K, A, lda, B, ldb, C,

@@ -322,6 +322,18 @@ def test_gemm_f64_128_tile(hip, ta_, tb_):
   np.testing.assert_allclose(out, ref, rtol=1e-14 * sk * 4, atol=1e-14 * 160 * 2)
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float64, ta.bfloat16, np.float16])
+def test_gemm_split_k_small_output(hip, dtype):
+  """Few output tiles + long K (inner products, small environments): K is split over workgroups and the
+  f32 / f64 partials are summed by the reduction kernel; every layout, ragged K tail."""
+  rng = np.random.default_rng(7)
+  for (m, n, k, ta_, tb_) in [(1, 1, 262144, 0, 1), (3, 5, 70001, 0, 0), (64, 130, 20000, 1, 1), (200, 100, 9000, 1, 0)]:
+    out, ref, kernel, sk = _gemm_case(hip, dtype, m, n, k, ta_, tb_, rng=rng)
+    assert kernel == "splitk", (kernel, m, n, k)
+    tol = {np.float32: 2e-6, np.float64: 1e-14, ta.bfloat16: 1.6e-2, np.float16: 2e-3}[dtype]
+    np.testing.assert_allclose(out, ref, rtol=tol * 4, atol=tol * np.sqrt(k) * 4, err_msg=f"{m}x{n}x{k}")
+
+
 def test_tensordot_golden(hip, golden):
   for case in golden.cases["tensordot"]:
     C.assert_close(C.run_tensordot(hip, golden, case), golden[case["out"]])
