@@ -20,7 +20,7 @@ from tensornetwork_amd.network import (Node, Edge, connect, contract, contract_b
                                        split_node, split_node_full_svd, split_node_qr, split_node_rq, copy,
                                        slice_edge,
                                        get_all_edges, get_subgraph_dangling, get_shared_edges,
-                                       reachable)
+                                       reachable, nodes_to_json, nodes_from_json)
 from tensornetwork_amd import contractors, pathfinder
 
 __version__ = "0.1.0"

@@ -492,3 +492,79 @@ def slice_edge(edge: Edge, start_index: int, length: int) -> Edge:
     sizes[axis] = length
     node.tensor = node.backend.slice(node.tensor, tuple(starts), tuple(sizes))
   return edge
+
+
+# ------------------------------------------------------------------ wire format (JSON)
+def nodes_to_json(nodes: Sequence[Node], edge_binding: Optional[Dict[str, Any]] = None) -> str:
+  """JSON string of a network: same schema as the reference's ``nodes_to_json``
+  (network_operations.py:880-941) -- nodes with name / axis_names / backend / serialised tensor
+  (``backend.serialize_tensor``: np.save bytes as a latin-1 string), edges with their two
+  (node id, axis) ends (``None`` for a dangling end or an end outside ``nodes``) and optional
+  named edge bindings -- so files travel between the two libraries."""
+  import json  # pylint: disable=import-outside-toplevel
+  nodes = list(nodes)
+  node_id = {id(n): i for i, n in enumerate(nodes)}
+  out = {"nodes": [], "edges": []}
+  for i, n in enumerate(nodes):
+    out["nodes"].append({"id": i, "attributes": {"name": n.name, "axis_names": list(n.axis_names),
+                                                 "backend": n.backend.name,
+                                                 "tensor": n.backend.serialize_tensor(n.tensor)}})
+  edges, seen = [], set()
+  for n in nodes:                     # deterministic order: by first appearance
+    for e in n.edges:
+      if id(e) not in seen:
+        seen.add(id(e))
+        edges.append(e)
+  edge_id = {id(e): i for i, e in enumerate(edges)}
+  for i, e in enumerate(edges):
+    ids = [node_id.get(id(e.node1)), node_id.get(id(e.node2)) if e.node2 is not None else None]
+    axes = [e.axis1 if ids[0] is not None else None, e.axis2 if ids[1] is not None else None]
+    out["edges"].append({"id": i, "node_ids": ids, "attributes": {"name": e.name, "axes": axes}})
+  if edge_binding:
+    binding = {}
+    for k, v in edge_binding.items():
+      if not isinstance(k, str):
+        raise TypeError("Edge binding dict must have string keys")
+      v = [v] if isinstance(v, Edge) else list(v)
+      if not all(isinstance(x, Edge) for x in v):
+        raise TypeError("Edge binding dict must have values of type Edge or Iterable[Edge]")
+      kept = [edge_id[id(x)] for x in v if id(x) in edge_id]
+      if kept:
+        binding[k] = kept
+    if binding:
+      out["edge_binding"] = binding
+  return json.dumps(out)
+
+
+def nodes_from_json(json_str: str, backend=None) -> Tuple[List[Node], Dict[str, Tuple[Edge, ...]]]:
+  """Rebuild a network from ``nodes_to_json`` output of this library OR of the reference
+  (network_operations.py:944-985).  Tensors are deserialised by ``backend`` when given (e.g. a
+  file written by the NumPy backend loaded straight into HBM), else by the backend named in the
+  file."""
+  import json  # pylint: disable=import-outside-toplevel
+  data = json.loads(json_str)
+  nodes, by_id = [], {}
+  for rec in data["nodes"]:
+    attr = rec["attributes"]
+    be = _resolve_backend(backend if backend is not None else attr["backend"])
+    node = Node(be.deserialize_tensor(attr["tensor"]), name=attr.get("name"), axis_names=attr.get("axis_names"),
+                backend=be)
+    nodes.append(node)
+    by_id[rec["id"]] = node
+  lookup = {}
+  for rec in data["edges"]:
+    ends = [(by_id.get(nid), ax) for nid, ax in zip(rec["node_ids"], rec["attributes"]["axes"])]
+    ends = [(n, ax) for n, ax in ends if n is not None and ax is not None]
+    name = rec["attributes"].get("name")
+    if len(ends) == 2:
+      (n1, a1), (n2, a2) = ends
+      edge = Edge(n1, a1, name=name, node2=n2, axis2=a2)
+      n1.edges[a1] = edge
+      n2.edges[a2] = edge
+    else:
+      (n1, a1), = ends
+      edge = Edge(n1, a1, name=name)
+      n1.edges[a1] = edge
+    lookup[rec["id"]] = edge
+  binding = {k: tuple(lookup[i] for i in v) for k, v in data.get("edge_binding", {}).items()}
+  return nodes, binding
