@@ -592,6 +592,8 @@ int svd_block_sweeps(T* X, T* R, int64_t P, int64_t Q, char* scratch, int* flag,
   const int inner = env ? atoi(env) : 1;
   const char* envc = getenv("TNH_SVD_CROSS");
   const int crossv = envc ? atoi(envc) : 1;
+  const char* envn = getenv("TNH_SVD_EIGNT");
+  const int eig_nt = envn ? atoi(envn) : 1024;   // workgroup size of the LDS eigensolver (A/B knob)
   int sweeps = 0;
   bool converged = false;
   while (!converged && sweeps < max_sweeps) {
@@ -608,8 +610,15 @@ int svd_block_sweeps(T* X, T* R, int64_t P, int64_t Q, char* scratch, int* flag,
       } else {
         hipLaunchKernelGGL(bj_gram_kernel, dim3((unsigned)pairs, (unsigned)S), dim3(256), 0, stream(), X, Q, nb, r,
                            chunks, cpw, Gp);
-        hipLaunchKernelGGL((bj_eig3_kernel<1024>), dim3((unsigned)pairs), dim3(1024), 0, stream(), Gp, S, J,
-                           pairflag, flag, (float)tol, inner, (crossv && r > 0) ? 1 : 0);
+        if (eig_nt == 512)
+          hipLaunchKernelGGL((bj_eig3_kernel<512>), dim3((unsigned)pairs), dim3(512), 0, stream(), Gp, S, J,
+                             pairflag, flag, (float)tol, inner, (crossv && r > 0) ? 1 : 0);
+        else if (eig_nt == 256)
+          hipLaunchKernelGGL((bj_eig3_kernel<256>), dim3((unsigned)pairs), dim3(256), 0, stream(), Gp, S, J,
+                             pairflag, flag, (float)tol, inner, (crossv && r > 0) ? 1 : 0);
+        else
+          hipLaunchKernelGGL((bj_eig3_kernel<1024>), dim3((unsigned)pairs), dim3(1024), 0, stream(), Gp, S, J,
+                             pairflag, flag, (float)tol, inner, (crossv && r > 0) ? 1 : 0);
         hipLaunchKernelGGL(bj_update_kernel, ugrid, dim3(256), 0, stream(), X, Q, nssX, R, P, nssR, nb, r, J,
                            pairflag);
       }
