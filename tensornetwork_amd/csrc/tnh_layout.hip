@@ -21,7 +21,32 @@ struct GatherParams {
   int64_t shape[TNH_MAX_RANK];    // output (iteration) shape, slowest first
   int64_t stride[TNH_MAX_RANK];   // element stride on the strided side
   int64_t offset;
+  uint32_t magic[TNH_MAX_RANK];   // 32-bit path: division by shape[d] as mulhi + shifts
+  uint32_t shift[TNH_MAX_RANK];   //   (q = mulhi(n, magic); ((n - q) >> 1) + q) >> shift)
 };
+
+// Unsigned division by an invariant d >= 2 (round-up method with a 33-bit multiplier):
+// exact for every 32-bit n.  The index chain of the gather kernel is ALU-bound with hardware
+// divisions (a rank-8 chain per 16-B element capped the kernel at ~1 TB/s).
+static void fastdiv_gen(uint32_t d, uint32_t* magic, uint32_t* shift) {
+  const uint32_t k = 31 - (uint32_t)__builtin_clz(d);
+  if ((d & (d - 1)) == 0) {
+    *magic = 0;
+    *shift = k - 1;
+    return;
+  }
+  const uint64_t num = (uint64_t)1 << (32 + k);
+  uint64_t m = num / d;
+  const uint64_t rem = num % d;
+  m += m;
+  if (rem + rem >= d) m += 1;
+  *magic = (uint32_t)(1 + m);
+  *shift = k;
+}
+__device__ __forceinline__ uint32_t fastdiv(uint32_t n, uint32_t magic, uint32_t shift) {
+  const uint32_t q = __umulhi(n, magic);
+  return (((n - q) >> 1) + q) >> shift;
+}
 
 // One element per thread-iteration; the contiguous side is indexed linearly so
 // it is always coalesced.  SCATTER=false: dst[i] = src[f(i)]; true: dst[f(i)] = src[i].
@@ -37,7 +62,9 @@ __global__ __launch_bounds__(256) void gather_kernel(T* __restrict__ dst,
 #pragma unroll 1
     for (int d = p.rank - 1; d >= 0; --d) {
       const IDX s = (IDX)p.shape[d];
-      const IDX q = rem / s;
+      IDX q;
+      if constexpr (sizeof(IDX) == 4) q = (IDX)fastdiv((uint32_t)rem, p.magic[d], p.shift[d]);
+      else q = rem / s;
       const IDX c = rem - q * s;
       off += (int64_t)c * p.stride[d];
       rem = q;
@@ -445,9 +472,14 @@ static int launch_gather(void* dst, const void* src, const GatherParams& p) {
   int64_t span = p.offset;
   for (int d = 0; d < p.rank; ++d) span += (p.shape[d] - 1) * (p.stride[d] < 0 ? -p.stride[d] : p.stride[d]);
   if (span >= (int64_t(1) << 31)) small = false;
-  if (small)
+  for (int d = 0; d < p.rank; ++d)
+    if (p.shape[d] < 2) small = false;   // fastdiv needs d >= 2 (unit dims are squeezed before; be safe)
+  if (small) {
+    GatherParams q = p;
+    for (int d = 0; d < q.rank; ++d) fastdiv_gen((uint32_t)q.shape[d], &q.magic[d], &q.shift[d]);
     hipLaunchKernelGGL((gather_kernel<T, uint32_t, SCATTER>), dim3((unsigned)blocks), dim3(256), 0,
-                       stream(), (T*)dst, (const T*)src, p);
+                       stream(), (T*)dst, (const T*)src, q);
+  }
   else
     hipLaunchKernelGGL((gather_kernel<T, int64_t, SCATTER>), dim3((unsigned)blocks), dim3(256), 0,
                        stream(), (T*)dst, (const T*)src, p);
