@@ -1,8 +1,10 @@
 """Two-site DMRG bond-dimension sweep: XXZ chain, GPU backend vs the NumPy oracle backend on the host.
-  python tools/dmrg_probe.py [--n 32] [--bonds 64,128,256] [--dtype float32] [--cpu-max 128]"""
+  python tests/perf_dmrg.py [--n 32] [--bonds 64,128,256] [--dtype float32] [--cpu-max 128]
+Lives under tests/ (not collected by pytest): it times the CPU oracle beside the GPU path, and only
+tests/, smoke() and bench.py's cpu_baseline leg may import oracle/."""
 import argparse, json, os, sys, time
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))   # repo root (oracle/ lives there)
 import tensornetwork_amd as ta
 from tensornetwork_amd import mps as tmps
 ap = argparse.ArgumentParser()

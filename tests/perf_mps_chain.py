@@ -1,10 +1,12 @@
 """configs[3]: <psi|psi> of a 16-site MPS (32 nodes: kets + conjugates), d = 2, bulk bond D, contracted
 with contractors.greedy -- launch-latency-bound (~1e9 flop at D = 512), so also the heavier
 d = 4 variant.  GPU (hip backend, with and without hipGraph replay) beside the NumPy oracle backend.
-  python tools/mps_chain_probe.py [--D 512] [--d 2,4]"""
+  python tests/perf_mps_chain.py [--D 512] [--d 2,4]
+Lives under tests/ (not collected by pytest): it times the CPU oracle beside the GPU path, and only
+tests/, smoke() and bench.py's cpu_baseline leg may import oracle/."""
 import argparse, json, os, sys, time
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))   # repo root (oracle/ lives there)
 import tensornetwork_amd as ta
 from tensornetwork_amd import contractors, workloads as wl
 from oracle import numpy_oracle as orc

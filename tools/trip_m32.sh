@@ -7,11 +7,10 @@ import numpy as np, sys, ctypes
 sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
 import tensornetwork_amd as ta
 from tensornetwork_amd import _lib
-from oracle import numpy_oracle as orc
 be = ta.get_hip_backend()
 rng = np.random.default_rng(0)
 for (m, n, k) in [(512, 384, 256), (1024, 768, 512), (2048, 2304, 1088)]:
-  a = orc.round_bf16(rng.standard_normal((m, k))); b = orc.round_bf16(rng.standard_normal((n, k)))
+  a = ta.round_to_bf16(rng.standard_normal((m, k))); b = ta.round_to_bf16(rng.standard_normal((n, k)))
   _lib.check(be.lib.tnh_gemm_set_variant(b"bf16_256pp:p3"))
   out = np.asarray(be.tensordot(be.to_bfloat16(a), be.to_bfloat16(b), [[1], [1]]))
   _lib.check(be.lib.tnh_gemm_set_variant(b"auto"))

@@ -7,7 +7,7 @@ cd /tmp
 run() { tag=$1; shift; rm -rf $OUT/prof2_$tag; timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/prof2_$tag -o p -- "$@" > $OUT/prof2_$tag.log 2>&1; echo "$tag rc=$?"; }
 run svd4096 python $R/tools/svd_probe.py --check 0 --sizes 4096 --reps 1
 run qr python $R/tools/qr_one.py 4096 4096
-run dmrg python $R/tools/dmrg_probe.py --n 24 --bonds 256 --cpu-max 0
+run dmrg python $R/tests/perf_dmrg.py --n 24 --bonds 256 --cpu-max 0
 run rr12 python $R/tools/rr64_probe.py --D 12 --min-slices 64 --max-slices 16
 cd $R
 python - <<'PY'
