@@ -817,15 +817,30 @@ class HipBackend(BackendBase):
 
     u = DeviceTensor.empty((m, keep), work_code)
     vh = DeviceTensor.empty((keep, n), work_code)
-    if mode.value == 1 and keep > 0 and not (s_host[keep - 1] > 0.0 and s_host[keep - 1] * 100.0 >= s_host[0]):
-      # the kept triplets are not all leading ones (s_k < s_1 / 100): recover-from-A would lose
-      # eps * s_1 / s_k of orthogonality -- run the accumulating factorisation instead
+    if mode.value == 1 and keep > 0 and not s_host[keep - 1] > 0.0:
+      # exactly rank-deficient inside the kept block: the orthogonalised side itself has zero rows, which
+      # only the accumulating path completes to an orthonormal basis (rare: zero / low-rank inputs)
       _lib.check(self.lib.tnh_svd_factor(work_code, m, n, _vp(mat), _vp(s_all), _vp(work),
                                          ctypes.byref(sweeps)), "tnh_svd_factor")
       mode.value = 0
     if mode.value == 1:
       _lib.check(self.lib.tnh_svd_vectors_topk(work_code, m, n, _vp(mat), _vp(work), _vp(s_all), keep, _vp(u),
                                                _vp(vh)), "tnh_svd_vectors_topk")
+      if keep > 0 and not s_host[keep - 1] * 100.0 >= s_host[0]:
+        # Not all kept triplets are leading ones: (A v_k) / s_k carries eps * s_1 / s_k of noise, i.e. the
+        # recovered vectors lose orthogonality.  Re-orthonormalise them with the Householder QR (K9) of
+        # Y = A Vh_k^T (resp. A^T U_k), WITHOUT the division: column k of Y is s_k u_k + O(eps s_1), QR
+        # orthogonalises it against the more accurate earlier columns, and a numerically zero column
+        # gets an orthonormal completion -- what LAPACK returns there too.  U S Vh stays within
+        # O(eps s_1) of A_k, the backward error of any SVD.
+        def unit(q_, r_):
+          sgn = self.sign(self.diagonal(r_))
+          sgn = self._binary(_lib.OP_ADD, sgn, self._binary(_lib.OP_SUB, 1.0, self.abs(sgn)))
+          return self._binary(_lib.OP_MUL, q_, sgn)
+        if m <= n:
+          u = unit(*self._qr_matrix(self._tensordot_impl(mat, vh, [[1], [1]], None, None)[0]))
+        else:
+          vh = self.transpose(unit(*self._qr_matrix(self._tensordot_impl(mat, u, [[0], [0]], None, None)[0])), (1, 0))
     else:
       _lib.check(self.lib.tnh_svd_vectors(work_code, m, n, _vp(work), keep, _vp(u), _vp(vh)),
                  "tnh_svd_vectors")

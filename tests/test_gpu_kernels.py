@@ -534,7 +534,7 @@ def test_svd_topk_mode(hip, dtype, otol, shape):
   np.testing.assert_allclose(u.T @ u, np.eye(k), atol=otol)
   np.testing.assert_allclose(vh @ vh.T, np.eye(k), atol=otol)
   np.testing.assert_allclose((u * s) @ vh, (u0 * s0) @ vh0, atol=otol * np.abs(a).max() * 30)
-  # graded spectrum: s_k << s_1 -> the backend falls back to the accumulating factorisation by itself
+  # graded spectrum: s_k << s_1 -> the recovered side is re-orthonormalised by the K9 QR (no second factorisation)
   q1, _ = np.linalg.qr(rng.standard_normal((shape[0], shape[0])))
   q2, _ = np.linalg.qr(rng.standard_normal((shape[1], shape[1])))
   r = min(shape)
@@ -544,6 +544,14 @@ def test_svd_topk_mode(hip, dtype, otol, shape):
   np.testing.assert_allclose(s, spec[:k], rtol=2e-3 if dtype == np.float32 else 1e-9, atol=1e-6 if dtype == np.float32 else 1e-14)
   np.testing.assert_allclose(u.T @ u, np.eye(k), atol=otol * 3)
   np.testing.assert_allclose(vh @ vh.T, np.eye(k), atol=otol * 3)
+  best = (q1[:, :k] * spec[:k]) @ q2[:k]                      # best rank-k approximation
+  np.testing.assert_allclose((u * s) @ vh, best, atol=otol * 3)   # backward error O(eps * s_1)
+  # exactly rank-deficient inside the kept block -> accumulating path with basis completion
+  low = (q1[:, :5] * spec[:5]) @ q2[:5]
+  u, s, vh, _ = [np.asarray(x) for x in hip.svd(dev(hip, low.astype(dtype)), 1, max_singular_values=k)]
+  np.testing.assert_allclose(u.T @ u, np.eye(k), atol=otol * 3)
+  np.testing.assert_allclose(vh @ vh.T, np.eye(k), atol=otol * 3)
+  np.testing.assert_allclose((u * s) @ vh, low, atol=otol * 3)
 
 
 def test_svd_prescribed_spectrum_512(hip):
