@@ -93,11 +93,18 @@ def contract_path(path: Sequence[Tuple[int, ...]], nodes: Iterable[network.Node]
         new = network.contract_trace_edges(node)
         nodes[nodes.index(node)] = new
   edge_time = _edge_times(path, nodes)
+  given = {id(n) for n in nodes}
   for pair in path:
     if len(pair) == 1:
       continue
     a, b = sorted(pair)
     new = network.contract_between(nodes[a], nodes[b], allow_outer_product=True, edge_time=edge_time)
+    for used in (nodes[a], nodes[b]):
+      if id(used) not in given:
+        # an intermediate this function created: nobody else holds it.  Node <-> Edge references are
+        # cycles, so without this its tensor (possibly many GB of HBM) would wait for the cyclic GC.
+        used.tensor = None
+        used.edges = []
     nodes = [n for i, n in enumerate(nodes) if i not in (a, b)] + [new]
   final = nodes[0]
   if len(nodes) != 1:

@@ -91,7 +91,14 @@ class _Block:
   def __init__(self, nbytes):
     lib = _lib.lib()
     p = ctypes.c_void_p()
-    _lib.check(lib.tnh_malloc(ctypes.byref(p), max(int(nbytes), 1)), "tnh_malloc")
+    status = lib.tnh_malloc(ctypes.byref(p), max(int(nbytes), 1))
+    if status == _lib.ERR_NOMEM:
+      # Node <-> Edge graphs are reference cycles: tensors of consumed nodes are released only by the
+      # cyclic collector, which counts objects, not HBM bytes.  Collect and retry once before giving up.
+      import gc  # pylint: disable=import-outside-toplevel
+      gc.collect()
+      status = lib.tnh_malloc(ctypes.byref(p), max(int(nbytes), 1))
+    _lib.check(status, "tnh_malloc")
     self.ptr = p.value
     self.nbytes = int(nbytes)
 

@@ -225,6 +225,9 @@ def contract_sliced(nodes: Sequence[network.Node], cut_edges: Sequence[network.E
     order = [edge_map[e] for e in output_edge_order] if output_edge_order is not None else None
     part = contractors.contract_path(path, [node_map[n] for n in nodes], order).tensor
     total = part if total is None else be.addition(total, part)
+    for n in node_map.values():     # this slice's copies are ours: drop their tensors now (Node <-> Edge
+      n.tensor = None               # cycles would otherwise keep the HBM until the cyclic GC runs)
+      n.edges = []
   if total is None:
     # this rank got no slice: contribute zeros of the right shape/dtype
     node_map, edge_map = network.copy(nodes)
