@@ -26,6 +26,7 @@ Extra objects on the same line:
                     nodes at D = 32 .. 256 in the favourable (L0) and the permute-needing (L1) layout,
                     plus the north-star "D = 512" row A(64,128,512,512) . B(512,512,128,64)
                     (GEMM 8192 x 8192 x 262144), whole-path TFLOP/s each.
+  mera           -- configs[4] shape on one GPU: binary-MERA layer energy at chi = 32 (68.7 GB intermediate).
   sliced_network -- the north-star scaling network (64-node random 3-regular graph, bond
                     D, bf16): bond-sliced greedy contraction, slices dealt over the N
                     ranks, ONE all-reduce of the scalar (strong scaling: fixed total work).
@@ -58,6 +59,7 @@ def parse_args():
   p.add_argument("--rr-min-slices", type=int, default=64)
   p.add_argument("--no-cpu-baseline", action="store_true")
   p.add_argument("--no-sweep", action="store_true", help="skip the bond-dimension sweep rows")
+  p.add_argument("--mera-chi", type=int, default=32, help="bond dimension of the MERA layer network (0 = skip)")
   p.add_argument("--fill", default="normal", choices=["normal", "zeros"],
                  help="operand fill (zeros shows the DVFS-inflated number; never the headline)")
   return p.parse_args()
@@ -217,7 +219,7 @@ def sliced_network_bench(ta, be, dist, rank, world, D, min_slices):
     tt = torch.tensor([t], dtype=torch.float64, device="cuda")
     dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     t = float(tt.item())
-  total_flops = rep["flops_per_slice"] * rep["n_slices"]
+  total_flops = 2.0 * rep["flops_per_slice"] * rep["n_slices"]   # the cost model counts multiply-adds
   return {"workload": f"64-node random 3-regular network (seed 6), bond D={D}, bf16, {len(cuts)} cut bonds",
           "n_slices": int(rep["n_slices"]), "n_gpus": world, "seconds": t, "scaling": "strong",
           "flops_total": total_flops, "tflops": total_flops / t / 1e12,
@@ -263,6 +265,32 @@ def bond_sweep(ta, be):
   rows.append({"D": 512, "layout": "A(64,128,512,512).B(512,512,128,64)", "gemm": [8192, 8192, 262144], "ms": t * 1e3,
                "tflops": 2.0 * 8192 * 8192 * 262144 / t / 1e12, "kernel": be.lib.tnh_gemm_last_kernel().decode()})
   return rows
+
+
+def mera_bench(ta, be, chi):
+  """configs[4] shape on one GPU: binary-MERA layer energy (12-node network, both placements,
+  contractors.branch nbranch=2), bf16 operands generated in HBM; flops from the path cost model."""
+  from tensornetwork_amd import contractors, network, pathfinder, workloads  # pylint: disable=import-outside-toplevel
+  sc = lambda n: float(n) ** -0.5
+  ham = be.device_random((chi,) * 6, dtype=ta.bfloat16, seed=1, normal=True, b=sc(chi**3))
+  rho = be.device_random((chi,) * 6, dtype=ta.bfloat16, seed=2, normal=True, b=sc(chi**3))
+  iso = be.device_random((chi,) * 3, dtype=ta.bfloat16, seed=3, normal=True, b=sc(chi))
+  dis = be.device_random((chi,) * 4, dtype=ta.bfloat16, seed=4, normal=True, b=sc(chi * chi))
+  nodes = workloads.mera_layer_network(be, ham, rho, iso, dis, "left")
+  inputs = [set(n.edges) for n in nodes]
+  sizes = {e: e.dimension for e in network.get_all_edges(nodes)}
+  macs, peak = pathfinder.path_cost(inputs, set(), sizes, pathfinder.branch(inputs, set(), sizes, nbranch=2))
+  del nodes
+  run = lambda: workloads.mera_energy(be, ham, rho, iso, dis, lambda nd: contractors.branch(nd, nbranch=2))
+  run()
+  be.synchronize()
+  t0 = time.perf_counter()
+  out = run()
+  be.synchronize()
+  t = time.perf_counter() - t0
+  return {"workload": f"binary-MERA layer energy, chi={chi}, bf16, left + right placement, contractors.branch(nbranch=2)",
+          "seconds": t, "flops": 4.0 * float(macs), "tflops": 4.0 * float(macs) / t / 1e12,
+          "peak_intermediate_elems": float(peak), "energy": float(np.asarray(out).reshape(-1)[0])}
 
 
 def load_traffic(kernel_name, M, N, K):
@@ -353,6 +381,12 @@ def main():
         result["bond_sweep"] = bond_sweep(ta, be)
       except Exception as exc:  # pylint: disable=broad-except
         result["bond_sweep"] = {"error": f"{type(exc).__name__}: {exc}"}
+      _lib.check(be.lib.tnh_trim())
+    if world == 1 and args.mera_chi > 0:
+      try:
+        result["mera"] = mera_bench(ta, be, args.mera_chi)
+      except Exception as exc:  # pylint: disable=broad-except
+        result["mera"] = {"error": f"{type(exc).__name__}: {exc}"}
       _lib.check(be.lib.tnh_trim())
     if world == 1 and args.svd_n > 0:
       svd_bench(ta, be, args.svd_n, max(args.svd_n // 16, 1))  # warm-up

@@ -60,8 +60,10 @@ for chi in [int(c) for c in a.chi.split(",")]:
     be.synchronize()
     t = time.perf_counter() - t0
     best = t if best is None else min(best, t)
-  rec = {"chi": chi, "dtype": a.dtype, "sec": best, "flops_2placements": 2 * float(flops),
-         "tflops": 2 * float(flops) / best / 1e12, "peak_elems": float(peak),
+  # path_cost counts multiply-adds per placement: x2 flop, x2 placements (sliced mode: `flops` already sums the slices run)
+  mult = 4.0 if a.slices == 0 else 2.0 * 2.0
+  rec = {"chi": chi, "dtype": a.dtype, "sec": best, "flops_2placements": mult * float(flops),
+         "tflops": mult * float(flops) / best / 1e12, "peak_elems": float(peak),
          "energy": float(np.asarray(e).reshape(-1)[0])}
   rec.update(extra)
   print(json.dumps(rec), flush=True)

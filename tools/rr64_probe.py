@@ -55,6 +55,6 @@ be.synchronize()
 dt = time.perf_counter() - t0
 done = len(range(0, n_slices, world))
 print(json.dumps({"D": D, "dtype": a.dtype, "graph": a.graph, "n_slices": n_slices, "slices_run": done, "plan_s": t_plan,
-                  "sec_per_slice": dt / done, "flops_per_slice": rep["flops_per_slice"],
-                  "tflops": rep["flops_per_slice"] * done / dt / 1e12, "peak_elems": rep["peak_per_slice"],
+                  "sec_per_slice": dt / done, "flops_per_slice": 2.0 * rep["flops_per_slice"],
+                  "tflops": 2.0 * rep["flops_per_slice"] * done / dt / 1e12, "peak_elems": rep["peak_per_slice"],
                   "est_full_1gpu_s": dt / done * n_slices, "partial": float(np.asarray(out).reshape(-1)[0])}))
