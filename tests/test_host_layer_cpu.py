@@ -127,3 +127,53 @@ def test_json_wire_format_interchange_with_reference():
   np.testing.assert_allclose(out2, ref, rtol=1e-6)
   with pytest.raises(TypeError):
     network.nodes_to_json(part, edge_binding={1: part[0][0]})
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_contractors_with_layout_planning_random_networks(seed):
+  """Layout planning (edge contraction times -> free-axis order hints + operand swaps) must never change a
+  result: random connected networks with open legs, greedy / optimal / branch, against np.einsum.  The
+  oracle backend's tensordot_planned ALWAYS applies the requested orders, the worst case for the edge
+  bookkeeping."""
+  import string
+  from tensornetwork_amd import contractors, network
+  rng = np.random.default_rng(100 + seed)
+  be = OracleBackend()
+  n_nodes = int(rng.integers(3, 7))
+  letters = iter(string.ascii_letters)
+  labels = [[] for _ in range(n_nodes)]
+  dims = {}
+  # a random spanning tree plus a few extra bonds keeps the network connected
+  pairs = [(i, int(rng.integers(0, i))) for i in range(1, n_nodes)]
+  pairs += [tuple(sorted(rng.choice(n_nodes, 2, replace=False).tolist())) for _ in range(int(rng.integers(0, 4)))]
+  for a, b in pairs:
+    l = next(letters)
+    dims[l] = int(rng.integers(2, 5))
+    labels[a].append(l)
+    labels[b].append(l)
+  open_labels = []
+  for i in range(n_nodes):
+    for _ in range(int(rng.integers(0, 3))):
+      l = next(letters)
+      dims[l] = int(rng.integers(2, 4))
+      labels[i].append(l)
+      open_labels.append(l)
+  for i in range(n_nodes):
+    rng.shuffle(labels[i])
+  arrays = [rng.standard_normal([dims[l] for l in labs]) for labs in labels]
+  rng.shuffle(open_labels)
+  ref = np.einsum(",".join("".join(l) for l in labels) + "->" + "".join(open_labels), *arrays)
+  for contractor in (contractors.greedy, contractors.optimal, lambda nd, **kw: contractors.branch(nd, nbranch=2, **kw)):
+    nodes = [network.Node(x, backend=be) for x in arrays]
+    first = {}
+    out_edges = {}
+    for i, labs in enumerate(labels):
+      for ax, l in enumerate(labs):
+        if l in open_labels:
+          out_edges[l] = nodes[i][ax]
+        elif l in first:
+          network.connect(first[l], nodes[i][ax])
+        else:
+          first[l] = nodes[i][ax]
+    res = contractor(nodes, output_edge_order=[out_edges[l] for l in open_labels])
+    np.testing.assert_allclose(res.tensor, ref, rtol=1e-10, atol=1e-10)
