@@ -177,3 +177,34 @@ def test_contractors_with_layout_planning_random_networks(seed):
           first[l] = nodes[i][ax]
     res = contractor(nodes, output_edge_order=[out_edges[l] for l in open_labels])
     np.testing.assert_allclose(res.tensor, ref, rtol=1e-10, atol=1e-10)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_ncon_with_layout_planning_random(seed):
+  """ncon's own use of tensordot_planned (labels' contraction order -> hints / operand swaps) vs np.einsum."""
+  import string
+  rng = np.random.default_rng(200 + seed)
+  be = OracleBackend()
+  n = int(rng.integers(3, 6))
+  struct = [[] for _ in range(n)]
+  dims, next_pos, next_neg = {}, 1, -1
+  for i in range(1, n):
+    j = int(rng.integers(0, i))
+    for _ in range(int(rng.integers(1, 3))):
+      dims[next_pos] = int(rng.integers(2, 5))
+      struct[i].append(next_pos)
+      struct[j].append(next_pos)
+      next_pos += 1
+  for i in range(n):
+    for _ in range(int(rng.integers(0, 2))):
+      dims[next_neg] = int(rng.integers(2, 4))
+      struct[i].append(next_neg)
+      next_neg -= 1
+  for s in struct:
+    rng.shuffle(s)
+  arrays = [rng.standard_normal([dims[l] for l in s]) for s in struct]
+  names = {l: string.ascii_letters[k] for k, l in enumerate(sorted(dims, key=lambda x: (x < 0, abs(x))))}
+  out = "".join(names[l] for l in sorted([l for l in dims if l < 0], reverse=True))
+  ref = np.einsum(",".join("".join(names[l] for l in s) for s in struct) + "->" + out, *arrays)
+  got = ta.ncon(arrays, struct, backend=be)
+  np.testing.assert_allclose(got, ref, rtol=1e-10, atol=1e-10)
