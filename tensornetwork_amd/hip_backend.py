@@ -1090,10 +1090,16 @@ class HipBackend(BackendBase):
     from tensornetwork_amd import krylov  # pylint: disable=import-outside-toplevel
     if initial_state is not None and not isinstance(initial_state, DeviceTensor):
       raise TypeError("Expected a `DeviceTensor`. Got {}".format(type(initial_state)))
-    if (initial_state is not None and initial_state.is_complex) or \
-        (initial_state is None and dtype is not None and dtype is not bfloat16 and np.dtype(dtype).kind == "c"):
-      raise NotImplementedError("complex eigsh is not implemented on the hip backend yet")
     return krylov.eigsh(self, A, args, initial_state, shape, dtype, num_krylov_vecs, numeig, tol, which, maxiter)
+
+  def eigs(self, A, args=None, initial_state=None, shape=None, dtype=None, num_krylov_vecs=50, numeig=6,
+           tol=1E-8, which='LR', maxiter=None):
+    """Krylov-Schur restarted Arnoldi on device vectors (abstract_backend.py:331-378; the reference
+    wraps scipy.sparse.linalg.eigs, numpy_backend.py:216-283)."""
+    from tensornetwork_amd import krylov  # pylint: disable=import-outside-toplevel
+    if initial_state is not None and not isinstance(initial_state, DeviceTensor):
+      raise TypeError("Expected a `DeviceTensor`. Got {}".format(type(initial_state)))
+    return krylov.eigs(self, A, args, initial_state, shape, dtype, num_krylov_vecs, numeig, tol, which, maxiter)
 
   def gmres(self, A_mv, b, A_args=None, A_kwargs=None, x0=None, tol=1E-05, atol=None,
             num_krylov_vectors=20, maxiter=1, M=None):
@@ -1129,6 +1135,24 @@ class HipBackend(BackendBase):
     if A_kwargs is None:
       A_kwargs = {}
     return krylov.gmres(self, A_mv, b, A_args, A_kwargs, x0, tol, atol, num_krylov_vectors, maxiter, M=M)
+
+  def _gmres(self, A_mv, b, A_args, A_kwargs, x0, tol, atol, num_krylov_vectors, maxiter, M=None):
+    """The solver behind `gmres` after argument checks (abstract_backend.py:618-631)."""
+    from tensornetwork_amd import krylov  # pylint: disable=import-outside-toplevel
+    return krylov.gmres(self, A_mv, b, A_args, A_kwargs, x0, tol, atol, num_krylov_vectors, maxiter, M=M)
+
+  def pivot(self, tensor, pivot_axis=-1):
+    """Tensor -> matrix about `pivot_axis` (abstract_backend.py:938-962): a view, no data movement."""
+    tensor = self._as_tensor(tensor)
+    ndim = len(tensor.shape)
+    if pivot_axis > ndim:
+      raise ValueError(f"pivot_axis = {pivot_axis} was invalid given ndim={ndim} array.")
+    left, right = tensor.shape[:pivot_axis], tensor.shape[pivot_axis:]
+    return self.reshape(tensor, [int(np.prod(left, dtype=np.int64)), int(np.prod(right, dtype=np.int64))])
+
+  def cholesky(self, tensor, pivot_axis=-1, non_negative_diagonal=False):
+    # abstract_backend.py:1026-1032: no reference backend implements cholesky either.
+    raise NotImplementedError(f"Backend {self.name} has not implemented cholesky.")
 
   # ------------------------------------------------------------------- misc
   def jit(self, fun, *args, **kwargs):  # pylint: disable=unused-argument

@@ -1,4 +1,4 @@
-"""Krylov solvers on backend tensors: ``eigsh_lanczos``, ``eigsh``, ``gmres``.
+"""Krylov solvers on backend tensors: ``eigsh_lanczos``, ``eigsh``, ``eigs``, ``gmres``.
 
 The reference's NumPy backend implements Lanczos by hand
 (``backends/numpy/numpy_backend.py:415-534``) and wraps SciPy/ARPACK for ``eigsh``
@@ -45,9 +45,37 @@ def _tridiag(diag, off):
 
 def _small_eigh(be, matrix):
   """Eigen-decomposition of a small host matrix of Krylov coefficients THROUGH the backend
-  (device Jacobi kernels for HipBackend); returns host arrays."""
+  (device Jacobi kernels for HipBackend); returns host arrays.  Real symmetric, or complex
+  Hermitian when ``matrix`` is complex."""
+  if np.iscomplexobj(matrix):
+    w, u = be.eigh(be.convert_to_tensor(np.ascontiguousarray(matrix, dtype=np.complex128)))
+    return np.asarray(w).real.astype(np.float64), np.asarray(u, dtype=np.complex128)
   w, u = be.eigh(be.convert_to_tensor(np.ascontiguousarray(np.real(matrix), dtype=np.float64)))
   return np.asarray(w, dtype=np.float64), np.asarray(u, dtype=np.float64)
+
+
+def _is_complex(x):
+  if hasattr(x, "is_complex"):
+    return bool(x.is_complex)
+  try:
+    return np.dtype(x.dtype).kind == "c"
+  except TypeError:
+    return False
+
+
+def _coef(c, cplx):
+  return complex(c) if cplx else float(np.real(c))
+
+
+def _combine(be, vectors, coefs, cplx):
+  """sum_i coefs[i] * vectors[i] (coefficients with |c| == 0 skipped)."""
+  out = None
+  for v, c in zip(vectors, coefs):
+    c = _coef(c, cplx)
+    if c == 0 and out is not None:
+      continue
+    out = be.multiply(v, c) if out is None else _axpy(be, out, c, v)
+  return out
 
 
 def eigsh_lanczos(be, A, args=None, initial_state=None, shape=None, dtype=None, num_krylov_vecs=20,
@@ -148,9 +176,11 @@ def eigsh(be, A, args=None, initial_state=None, shape=None, dtype=None, num_kryl
       return np.argsort(theta)[:numeig]
     return np.argsort(-np.abs(theta))[:numeig]
 
+  cplx = _is_complex(initial_state)
   basis = [be.divide(initial_state, _norm(be, initial_state))]
   images = []                               # A applied to each basis vector
-  h = np.zeros((ncv, ncv), dtype=np.float64)  # projected matrix V^H A V (real symmetric part)
+  # projected matrix V^H A V (its symmetric / Hermitian part)
+  h = np.zeros((ncv, ncv), dtype=np.complex128 if cplx else np.float64)
   theta_sel, ritz = None, None
   for _ in range(max(1, maxiter)):
     # grow the basis to ncv vectors (or to an invariant subspace)
@@ -159,8 +189,10 @@ def eigsh(be, A, args=None, initial_state=None, shape=None, dtype=None, num_kryl
       w = A(basis[j], *args)
       images.append(w)
       for i in range(j + 1):
-        hij = float(np.real(_vdot(be, basis[i], w)))
-        h[i, j] = h[j, i] = hij
+        hij = _coef(_vdot(be, basis[i], w), cplx)
+        h[i, j] = hij
+        h[j, i] = np.conj(hij)
+      h[j, j] = h[j, j].real
       if len(basis) == ncv:
         break
       for _pass in range(2):                # classical Gram-Schmidt twice == full re-orthogonalisation
@@ -176,11 +208,11 @@ def eigsh(be, A, args=None, initial_state=None, shape=None, dtype=None, num_kryl
     theta_sel = theta[sel]
     ritz, ritz_img, resid = [], [], []
     for col in sel:
-      y = be.multiply(basis[0], float(u[0, col]))
-      ay = be.multiply(images[0], float(u[0, col]))
+      y = be.multiply(basis[0], _coef(u[0, col], cplx))
+      ay = be.multiply(images[0], _coef(u[0, col], cplx))
       for i in range(1, m):
-        y = _axpy(be, y, float(u[i, col]), basis[i])
-        ay = _axpy(be, ay, float(u[i, col]), images[i])
+        y = _axpy(be, y, _coef(u[i, col], cplx), basis[i])
+        ay = _axpy(be, ay, _coef(u[i, col], cplx), images[i])
       ritz.append(y)
       ritz_img.append(ay)
       resid.append(_norm(be, _axpy(be, ay, -float(theta[col]), y)))
@@ -204,6 +236,126 @@ def eigsh(be, A, args=None, initial_state=None, shape=None, dtype=None, num_kryl
   order = np.argsort(theta_sel) if which == 'SA' else np.argsort(-theta_sel if which == 'LA' else -np.abs(theta_sel))
   vecs = [be.divide(ritz[i], _norm(be, ritz[i])) for i in order]
   return theta_sel[order], vecs
+
+
+def eigs(be, A, args=None, initial_state=None, shape=None, dtype=None, num_krylov_vecs=50, numeig=6,
+         tol=1e-8, which='LR', maxiter=None):
+  """``numeig`` eigenpairs of a general (non-Hermitian) operator: interface, argument checks and
+  return convention of ``numpy_backend.py:216-283`` (which wraps ``scipy.sparse.linalg.eigs``, i.e.
+  ARPACK's implicitly restarted Arnoldi).
+
+  Here: Arnoldi with a Krylov-Schur (thick) restart.  The orthonormal basis lives on the device; one
+  cycle extends it to ``num_krylov_vecs`` vectors with twice-iterated Gram-Schmidt, the projected
+  ``ncv x ncv`` coefficient matrix is diagonalised on the host (it is control data -- ARPACK does the
+  same on the host in the reference), the residual of Ritz pair i is ``|h[m+1,m]| |y_i[m]|``, and a
+  restart compresses the basis onto an orthonormal basis of the wanted Ritz vectors' span
+  (conjugate pairs kept together so a real operator keeps a real basis) followed by the Arnoldi
+  residual vector.  Eigenvalues and vectors come back complex, as from SciPy; a run that hits
+  ``maxiter`` restarts returns its current Ritz pairs."""
+  if args is None:
+    args = []
+  if which in ('SI', 'LI'):
+    raise ValueError(f'which = {which} is currently not supported.')
+  if which not in ('LM', 'SM', 'LR', 'SR'):
+    raise ValueError(f"which = {which} is not supported (use 'LM', 'SM', 'LR' or 'SR').")
+  if numeig + 1 >= num_krylov_vecs:
+    raise ValueError('`num_krylov_vecs` > `numeig + 1` required!')
+  if initial_state is None:
+    if (shape is None) or (dtype is None):
+      raise ValueError("if no `initial_state` is passed, then `shape` and"
+                       "`dtype` have to be provided")
+    initial_state = be.randn(shape, dtype)
+  if not be.is_tensor(initial_state):
+    raise TypeError("Expected a backend tensor. Got {}".format(type(initial_state)))
+  size = int(np.prod(be.shape_tuple(initial_state)))
+  ncv = min(int(num_krylov_vecs), size)
+  numeig = min(int(numeig), size)
+  if maxiter is None:
+    maxiter = 10 * size
+  cplx = _is_complex(initial_state)
+  eps = float(be.eps(initial_state.dtype)) if hasattr(be, "eps") else 2.2e-16
+  tol = eps if tol is None or tol <= 0 else float(tol)
+
+  def ranked(theta):
+    key = {'LM': -np.abs(theta), 'SM': np.abs(theta), 'LR': -theta.real, 'SR': theta.real}[which]
+    return np.argsort(key, kind="stable")
+
+  hmat = np.zeros((ncv + 1, ncv), dtype=np.complex128 if cplx else np.float64)
+  basis = [be.divide(initial_state, _norm(be, initial_state))]
+  kept = 0                                  # leading columns of hmat already filled by the last restart
+  theta = ymat = None
+  m = 0
+  for _ in range(max(1, int(maxiter))):
+    j, invariant = kept, False
+    while j < ncv:
+      w = A(basis[j], *args)
+      scale = _norm(be, w)
+      for _pass in range(2):
+        for i in range(j + 1):
+          hij = _coef(_vdot(be, basis[i], w), cplx)
+          hmat[i, j] += hij
+          w = _axpy(be, w, -hij, basis[i])
+      nrm = _norm(be, w)
+      hmat[j + 1, j] = nrm
+      j += 1
+      if nrm <= 100 * eps * max(scale, 1e-300):
+        invariant = True
+        break
+      basis.append(be.divide(w, nrm))
+    m = j
+    theta, ymat = np.linalg.eig(hmat[:m, :m])
+    order = ranked(theta)
+    sel = order[:numeig]
+    resid = abs(hmat[m, m - 1]) * np.abs(ymat[m - 1, :])
+    floor = eps ** (2.0 / 3.0)
+    done = resid[sel] <= tol * np.maximum(np.abs(theta[sel]), floor)
+    if invariant or m >= size or done.all() or m <= numeig + 1:
+      break
+    # ---- Krylov-Schur restart --------------------------------------------------------------
+    nkeep = min(m - 2, numeig + min(int(done.sum()), (m - numeig) // 2))
+    keep = list(order[:nkeep])
+    if cplx:
+      span = ymat[:, keep]
+    else:
+      cols, seen = [], set()
+      for idx in keep:
+        if idx in seen:
+          continue
+        seen.add(idx)
+        if theta[idx].imag == 0:
+          cols.append(ymat[:, idx].real)
+        else:
+          partner = int(np.argmin(np.abs(theta - np.conj(theta[idx])) + 1e300 * (np.arange(m) == idx)))
+          seen.add(partner)
+          cols.append(ymat[:, idx].real)
+          cols.append(ymat[:, idx].imag)
+      span = np.stack(cols, axis=1)
+      if span.shape[1] > m - 1:
+        span = span[:, :m - 1]
+    z, _ = np.linalg.qr(span)
+    nk = z.shape[1]
+    small = z.conj().T @ hmat[:m, :m] @ z
+    coupling = hmat[m, m - 1] * z[m - 1, :]
+    new_basis = [_combine(be, basis[:m], z[:, i], cplx) for i in range(nk)]
+    new_basis.append(basis[m])
+    hmat[:, :] = 0
+    hmat[:nk, :nk] = small
+    hmat[nk, :nk] = coupling
+    basis, kept = new_basis, nk
+
+  order = ranked(theta)[:numeig]
+  eta = np.asarray(theta[order], dtype=np.complex128)
+  vectors = []
+  for col in order:
+    y = ymat[:, col]
+    if cplx:
+      vec = _combine(be, basis[:m], y, True)
+    else:
+      re = _combine(be, basis[:m], y.real, False)
+      im = _combine(be, basis[:m], y.imag, False)
+      vec = be.addition(re, be.multiply(im, 1j))
+    vectors.append(be.divide(vec, _norm(be, vec)))
+  return eta, vectors
 
 
 def gmres(be, A_mv, b, A_args, A_kwargs, x0, tol, atol, num_krylov_vectors, maxiter, M=None):

@@ -126,6 +126,104 @@ class FiniteMPS:
   def bond_dimensions(self):
     return [self.tensors[0].shape[0]] + [t.shape[2] for t in self.tensors]
 
+  def bond_dimension(self, bond: int):
+    """Dimension of bond ``bond`` (bond n sits left of site n; base_mps.py:238-245)."""
+    if bond > len(self):
+      raise IndexError(f"bond {bond} out of bounds for an MPS of length {len(self)}")
+    if bond < len(self):
+      return self.tensors[bond].shape[0]
+    return self.tensors[-1].shape[2]
+
+  @property
+  def physical_dimensions(self):
+    return [t.shape[1] for t in self.tensors]
+
+  def get_tensor(self, site: int):
+    """The tensor at ``site`` (base_mps.py:676-700; a finite MPS has no connector matrix)."""
+    if site >= len(self):
+      raise IndexError('index `site` = {} is out of range for len(mps)= {}'.format(site, len(self)))
+    if site < 0:
+      raise ValueError('index `site` has to be larger than 0 (found `site`={}).'.format(site))
+    return self.tensors[site]
+
+  def save(self, path: str):
+    raise NotImplementedError()           # finite_mps.py:328-329: neither does the reference
+
+  # ------------------------------------------------------- transfer operators
+  def left_transfer_operator(self, A, l, Abar):
+    """l[a, a'] -> sum A[a, s, b] l[a, a'] Abar[a', s, b']  (base_mps.py:112-123)."""
+    return ncon([A, l, Abar], [[1, 2, -1], [1, 3], [3, 2, -2]], backend=self.backend)
+
+  def right_transfer_operator(self, B, r, Bbar):
+    """r[b, b'] -> sum B[a, s, b] r[b, b'] Bbar[a', s, b']  (base_mps.py:125-136)."""
+    return ncon([B, r, Bbar], [[-1, 2, 1], [1, 3], [-2, 2, 3]], backend=self.backend)
+
+  def apply_transfer_operator(self, site: int, direction, matrix):
+    """Left (1, 'l', 'left') or right (-1, 'r', 'right') action of the transfer operator of
+    ``site`` on ``matrix`` (base_mps.py:262-285)."""
+    t = self.tensors[site]
+    if direction in (1, 'l', 'left'):
+      return self.left_transfer_operator(t, matrix, self.backend.conj(t))
+    if direction in (-1, 'r', 'right'):
+      return self.right_transfer_operator(t, matrix, self.backend.conj(t))
+    raise ValueError(f'unknown value {direction} for direction')
+
+  def left_envs(self, sites: Sequence[int]):
+    """{site: left reduced density matrix on the bond left of ``site``} (finite_mps.py:167-243).
+    Identities up to and including the centre (the tensors there are left isometries), one
+    transfer-operator application per site beyond it."""
+    be = self.backend
+    sites = np.array(sites, dtype=np.int64)
+    if len(sites) == 0:
+      return {}
+    if not np.all(sites <= len(self)):
+      raise ValueError('all elements of `sites` have to be <= N = {}'.format(len(self)))
+    if not np.all(sites >= 0):
+      raise ValueError('all elements of `sites` have to be positive')
+    center = self.center_position
+    wanted = set(int(x) for x in sites)
+    envs = {}
+    for site in wanted:
+      if site <= center:
+        envs[site] = be.eye(self.bond_dimension(site), dtype=self.dtype)
+    last = max(wanted)
+    if last > center:
+      t = self.tensors[center]
+      env = ncon([t, be.conj(t)], [[1, 2, -1], [1, 2, -2]], backend=be)
+      for site in range(center + 1, last + 1):
+        if site in wanted:
+          envs[site] = env
+        if site < last:
+          env = self.apply_transfer_operator(site, 'left', env)
+    return envs
+
+  def right_envs(self, sites: Sequence[int]):
+    """{site: right reduced density matrix on the bond right of ``site``} (finite_mps.py:245-326)."""
+    be = self.backend
+    sites = np.array(sites, dtype=np.int64)
+    if len(sites) == 0:
+      return {}
+    if not np.all(sites < len(self)):
+      raise ValueError('all elements of `sites` have to be < N = {}'.format(len(self)))
+    if not np.all(sites >= -1):
+      raise ValueError('all elements of `sites` have to be >= -1')
+    center = self.center_position
+    wanted = set(int(x) for x in sites)
+    envs = {}
+    for site in wanted:
+      if site >= center:
+        envs[site] = be.eye(self.bond_dimension(site + 1), dtype=self.dtype)
+    first = min(wanted)
+    if first < center:
+      t = self.tensors[center]
+      env = ncon([t, be.conj(t)], [[-1, 1, 2], [-2, 1, 2]], backend=be)
+      for site in range(center - 1, first - 1, -1):
+        if site in wanted:
+          envs[site] = env
+        if site > first:
+          env = self.apply_transfer_operator(site, 'right', env)
+    return envs
+
   def _norm(self, t):
     return float(np.real(self.backend.item(self.backend.norm(t))))
 
@@ -212,6 +310,25 @@ class FiniteMPS:
       raise ValueError("which = {} is not recognized.".format(which))
     return self._norm(be.subtraction(g, be.eye(g.shape[0], dtype=self.dtype)))
 
+  def check_canonical(self):
+    """L2 norm of the per-site isometry deviations around the centre (finite_mps.py:148-165)."""
+    total = 0.0
+    for site in range(len(self.tensors)):
+      if site < self.center_position:
+        total += self.check_orthonormality('l', site) ** 2
+      elif site > self.center_position:
+        total += self.check_orthonormality('r', site) ** 2
+    return float(np.sqrt(total))
+
+  def apply_one_site_gate(self, gate, site: int):
+    """tensors[site][a, s, b] <- sum_t gate[s, t] tensors[site][a, t, b] (base_mps.py:597-614).
+    Generally breaks the canonical form; `position` restores it."""
+    if len(gate.shape) != 2:
+      raise ValueError('rank of gate is {} but has to be 2'.format(len(gate.shape)))
+    if site < 0 or site >= len(self):
+      raise ValueError('site = {} is not between 0 <= site < N={}'.format(site, len(self)))
+    self.tensors[site] = ncon([gate, self.tensors[site]], [[-2, 1], [-1, 1, -3]], backend=self.backend)
+
   def apply_two_site_gate(self, gate, site1: int, site2: int, max_singular_values: Optional[int] = None,
                           max_truncation_err: Optional[float] = None, relative: bool = False):
     """Apply a (d, d, d, d) gate [out1, out2, in1, in2] to neighbouring sites and split the result
@@ -236,16 +353,64 @@ class FiniteMPS:
     return trunc
 
   def measure_local_operator(self, ops: Sequence, sites: Sequence[int]):
-    """<psi| op_n |psi> for each (op, site) (base_mps.py:287-320); the centre is moved to each
-    site, where the expectation value is a single local contraction."""
+    """<psi| op_n |psi> for each (op, site) (base_mps.py:287-320): the site tensor sandwiched
+    between its left and right reduced density matrices; the gauge is left untouched."""
     be = self.backend
+    if len(ops) != len(sites):
+      raise ValueError('measure_1site_ops: len(ops) has to be len(sites)!')
+    rs = self.right_envs(sites)
+    ls = self.left_envs(sites)
     out = []
     for op, site in zip(ops, sites):
-      self.position(site)
+      site = int(site)
       t = self.tensors[site]
-      val = ncon([t, op, be.conj(t)], [[1, 2, 3], [4, 2], [1, 4, 3]], backend=be)
+      val = ncon([ls[site], t, op, be.conj(t), rs[site]],
+                 [[1, 2], [1, 3, 5], [4, 3], [2, 4, 6], [5, 6]], backend=be)
       out.append(be.item(val))
     return out
+
+  def measure_two_body_correlator(self, op1, op2, site1: int, sites2: Sequence[int]):
+    """<op1[site1] op2[s]> for every s in ``sites2``, returned in ascending order of s
+    (base_mps.py:322-479; for s == site1 the product op1 @ op2 is measured).  One environment
+    sweep to each side of ``site1``: the op1-dressed environment is pushed outwards with
+    transfer operators and closed with op2 and the far-side density matrix at each wanted site."""
+    be = self.backend
+    N = len(self)
+    if site1 < 0:
+      raise ValueError("Site site1 out of range: {} not between 0 <= site < N = {}.".format(site1, N))
+    sites2 = np.array(sites2, dtype=np.int64)
+    left_sites = sorted(set(int(x) for x in sites2[sites2 < site1]))
+    right_sites = sorted(set(int(x) for x in sites2[sites2 > site1]))
+    rs = self.right_envs([site1] + right_sites)
+    ls = self.left_envs(left_sites + [site1])
+    t1 = self.tensors[site1]
+    out = []
+    if left_sites:
+      # env[a, a']: everything right of the bond, with op1 inserted at site1
+      env = ncon([t1, op1, be.conj(t1), rs[site1]], [[-1, 1, 2], [3, 1], [-2, 3, 4], [2, 4]], backend=be)
+      vals = {}
+      for n in range(site1 - 1, left_sites[0] - 1, -1):
+        t = self.tensors[n]
+        if n in left_sites:
+          vals[n] = ncon([ls[n], t, op2, be.conj(t), env],
+                         [[1, 2], [1, 3, 5], [4, 3], [2, 4, 6], [5, 6]], backend=be)
+        if n > left_sites[0]:
+          env = self.apply_transfer_operator(n, 'right', env)
+      out.extend(vals[n] for n in left_sites)
+    if site1 in sites2:
+      op12 = ncon([op1, op2], [[-1, 1], [1, -2]], backend=be)
+      out.append(ncon([ls[site1], t1, op12, be.conj(t1), rs[site1]],
+                      [[1, 2], [1, 3, 5], [4, 3], [2, 4, 6], [5, 6]], backend=be))
+    if right_sites:
+      env = ncon([ls[site1], t1, op1, be.conj(t1)], [[1, 2], [1, 3, -1], [4, 3], [2, 4, -2]], backend=be)
+      for n in range(site1 + 1, right_sites[-1] + 1):
+        t = self.tensors[n]
+        if n in right_sites:
+          out.append(ncon([env, t, op2, be.conj(t), rs[n]],
+                          [[1, 2], [1, 3, 5], [4, 3], [2, 4, 6], [5, 6]], backend=be))
+        if n < right_sites[-1]:
+          env = self.apply_transfer_operator(n, 'left', env)
+    return [be.item(o) for o in out]
 
 
 # ------------------------------------------------------------------------ DMRG

@@ -250,3 +250,50 @@ def check_svd_case(be, g, case):
   np.testing.assert_allclose(vm @ vm.conj().T, np.eye(k), rtol=0, atol=20 * t["atol"])
   ref = (ur.reshape(-1, k) * sr) @ vr.reshape(k, -1)
   np.testing.assert_allclose((um * s) @ vm, ref, rtol=0, atol=50 * tol(x.dtype, scale)["atol"])
+
+
+# ------------------------------------------------------------------ MPS measurement goldens
+MPS_GOLDEN_TAGS = ("f64c3", "f64c0", "c128c7")
+
+
+def load_mps_golden():
+  import os
+  return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden_mps.npz"))
+
+
+def check_mps_golden_case(be, g, tag, atol):
+  """Everything tests/golden/make_golden_mps.py recorded from the reference's FiniteMPS, recomputed by
+  tensornetwork_amd.mps.FiniteMPS on backend `be` from the same (already canonical) tensors."""
+  from tensornetwork_amd import mps as tmps
+  n, center = [int(x) for x in g[f"{tag}_meta"]]
+  state = tmps.FiniteMPS([be.convert_to_tensor(g[f"{tag}_t{k}"]) for k in range(n)], be,
+                         center_position=center, canonicalize=False)
+  host = lambda x: np.asarray(x)
+  assert state.center_position == center
+  assert state.physical_dimensions == [g[f"{tag}_t{k}"].shape[1] for k in range(n)]
+  assert [state.bond_dimension(k) for k in range(n + 1)] == state.bond_dimensions
+  sites = list(range(n))
+  ls = state.left_envs(sites + [n])
+  rs = state.right_envs([-1] + sites)
+  assert sorted(ls) == list(range(n + 1)) and sorted(rs) == list(range(-1, n))
+  for k, v in ls.items():
+    np.testing.assert_allclose(host(v), g[f"{tag}_L{k}"], atol=atol)
+  for k, v in rs.items():
+    np.testing.assert_allclose(host(v), g[f"{tag}_R{k}"], atol=atol)
+  assert state.left_envs([]) == {} and state.right_envs([]) == {}
+  np.testing.assert_allclose(host(state.apply_transfer_operator(3, "left", be.convert_to_tensor(g[f"{tag}_ml"]))),
+                             g[f"{tag}_tl"], atol=atol)
+  np.testing.assert_allclose(host(state.apply_transfer_operator(3, -1, be.convert_to_tensor(g[f"{tag}_mr"]))),
+                             g[f"{tag}_tr"], atol=atol)
+  op1, op2 = be.convert_to_tensor(g[f"{tag}_op1"]), be.convert_to_tensor(g[f"{tag}_op2"])
+  np.testing.assert_allclose(state.measure_local_operator([op1] * n, sites), g[f"{tag}_local"], atol=atol)
+  assert state.center_position == center           # measuring does not move the gauge
+  for s1 in (0, 3, n - 1):
+    np.testing.assert_allclose(state.measure_two_body_correlator(op1, op2, s1, sites), g[f"{tag}_corr{s1}"],
+                               atol=atol)
+  np.testing.assert_allclose(state.measure_two_body_correlator(op1, op2, 4, [6, 1, 4, 6]), g[f"{tag}_corr_sub"],
+                             atol=atol)
+  np.testing.assert_allclose(state.check_canonical(), float(g[f"{tag}_canon"]), atol=atol)
+  state.apply_one_site_gate(op2, 2)
+  np.testing.assert_allclose(host(state.get_tensor(2)), g[f"{tag}_gated2"], atol=atol)
+  np.testing.assert_allclose(state.check_canonical(), float(g[f"{tag}_canon_after"]), atol=atol * 10)

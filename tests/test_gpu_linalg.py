@@ -205,6 +205,65 @@ def test_eigsh_and_gmres_device_vectors(hip):
     hip.gmres(op, hip.convert_to_tensor(rhs), x0=hip.zeros((10, 10), dtype=np.float32))
 
 
+@pytest.mark.parametrize("dtype", [np.float64, np.complex128, np.float32])
+def test_eigs_device_vectors(hip, dtype):
+  """numpy_backend_test.py:313-370 (eigs vs np.linalg.eig) with ncv << n: Krylov-Schur restarts on device vectors."""
+  n = 80
+  rng = np.random.default_rng(11)
+  mat = rng.standard_normal((n, n))
+  if np.dtype(dtype).kind == "c":
+    mat = mat + 1j * rng.standard_normal((n, n))
+  mat = mat.astype(dtype)
+  md = hip.convert_to_tensor(mat)
+  init = hip.convert_to_tensor(rng.standard_normal(n).astype(dtype))
+  seen = []
+
+  def mv(x, m):
+    seen.append(x.dtype)
+    return hip.tensordot(m, x, 1)
+
+  tol, atol = (1e-5, 2e-3) if dtype == np.float32 else (1e-10, 1e-7)
+  eta, vecs = hip.eigs(mv, [md], init, num_krylov_vecs=24, numeig=3, which="LM", tol=tol)
+  assert all(d == dtype for d in seen) and len(seen) > 24
+  w = np.linalg.eigvals(mat.astype(np.complex128))
+  want = w[np.argsort(-np.abs(w))][:3]
+  np.testing.assert_allclose(np.sort(np.abs(eta)), np.sort(np.abs(want)), atol=atol)
+  m128 = mat.astype(np.complex128)
+  for e, vec in zip(eta, vecs):
+    assert isinstance(vec, ta.DeviceTensor) and vec.is_complex
+    vh = np.asarray(vec).astype(np.complex128)
+    np.testing.assert_allclose(m128 @ vh, e * vh, atol=atol * 10)
+  with pytest.raises(ValueError, match="which = LI is currently not supported."):
+    hip.eigs(mv, [md], init, which="LI")
+  with pytest.raises(TypeError, match="Expected a `DeviceTensor`"):
+    hip.eigs(mv, [md], initial_state=np.ones(n))
+
+
+def test_eigsh_complex_hermitian_and_pivot(hip):
+  n = 48
+  rng = np.random.default_rng(12)
+  a = rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n))
+  h = (a + a.conj().T) / 2
+  hd = hip.convert_to_tensor(h)
+  init = hip.convert_to_tensor(rng.standard_normal(n) + 1j * rng.standard_normal(n))
+  eta, vecs = hip.eigsh(lambda x, m: hip.tensordot(m, x, 1), [hd], init, num_krylov_vecs=16, numeig=2,
+                        which="SA", tol=1e-10)
+  w = np.linalg.eigvalsh(h)
+  np.testing.assert_allclose(eta, w[:2], atol=1e-8)
+  for e, vec in zip(eta, vecs):
+    vh = np.asarray(vec)
+    np.testing.assert_allclose(h @ vh, e * vh, atol=1e-6)
+  # pivot (abstract_backend.py:938-962; backend_test / numpy_backend_test pivot cases)
+  t = hip.convert_to_tensor(np.arange(1 * 2 * 4 * 5, dtype=np.float64).reshape(1, 2, 4, 5))
+  assert hip.pivot(t, 2).shape == (2, 20)
+  assert hip.pivot(t).shape == (8, 5)
+  np.testing.assert_array_equal(np.asarray(hip.pivot(t, 1)), np.arange(40.0).reshape(1, 40))
+  with pytest.raises(ValueError, match="was invalid given ndim=4"):
+    hip.pivot(t, 5)
+  with pytest.raises(NotImplementedError):
+    hip.cholesky(t)
+
+
 @pytest.mark.parametrize("dtype", [np.float32, np.float64, ta.bfloat16])
 def test_compare_and_index_update(hip, dtype):
   """The reference's pattern (infinite_mps.py:237-241): mask = eigvals <= precision;

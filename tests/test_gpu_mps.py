@@ -6,6 +6,7 @@ import pytest
 
 import tensornetwork_amd as ta
 from tensornetwork_amd import mps as tmps
+import cases
 from cases import xxz_dense
 
 pytestmark = pytest.mark.gpu
@@ -48,3 +49,10 @@ def test_dmrg_f32_chain_of_12(hip):
   e = dmrg.run_two_site(max_bond_dim=48, num_sweeps=4, num_krylov_vecs=12)
   np.testing.assert_allclose(e, eta[0], atol=2e-4 * abs(eta[0]))
   assert max(state.bond_dimensions) <= 48
+
+
+@pytest.mark.parametrize("tag", cases.MPS_GOLDEN_TAGS)
+def test_mps_measurements_match_reference_golden_on_device(hip, tag):
+  """Reduced density matrices, transfer operators, <O>, <O1 O2>, one-site gates on device tensors vs the
+  numbers recorded from the reference's FiniteMPS (tests/golden/make_golden_mps.py)."""
+  cases.check_mps_golden_case(hip, cases.load_mps_golden(), tag, 1e-10)

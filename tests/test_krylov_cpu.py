@@ -97,3 +97,89 @@ def test_gmres_known_answer_and_restarts():
   # not converged within the budget -> info = number of restarts
   x, info = krylov.gmres(be, op, rhs, [], {}, np.zeros(n), 1e-14, 1e-14, 2, 1)
   assert info == 1
+
+
+def _nonsym(n, seed, cplx=False):
+  rng = np.random.default_rng(seed)
+  a = rng.standard_normal((n, n))
+  if cplx:
+    a = a + 1j * rng.standard_normal((n, n))
+  return a
+
+
+def _check_eigs(mat, eta, vecs, which, numeig, atol):
+  w = np.linalg.eigvals(mat)
+  key = {'LM': -np.abs(w), 'SM': np.abs(w), 'LR': -w.real, 'SR': w.real}[which]
+  want = w[np.argsort(key)][:numeig]
+  assert eta.dtype == np.complex128 and len(vecs) == numeig
+  # conjugate pairs tie in every `which` ordering: compare as sets of nearest matches
+  for e in eta:
+    assert np.min(np.abs(want - e)) < atol or np.min(np.abs(w - e)) < atol
+  key_got = {'LM': -np.abs(eta), 'SM': np.abs(eta), 'LR': -eta.real, 'SR': eta.real}[which]
+  np.testing.assert_allclose(np.sort(key_got), np.sort(key[np.argsort(key)][:numeig]), atol=atol)
+  for e, v in zip(eta, vecs):
+    assert np.iscomplexobj(v)
+    np.testing.assert_allclose(np.linalg.norm(v), 1.0, atol=1e-10)
+    np.testing.assert_allclose(mat @ v.reshape(-1), e * v.reshape(-1), atol=atol * 10)
+
+
+@pytest.mark.parametrize("which", ["LM", "LR", "SR"])
+@pytest.mark.parametrize("cplx", [False, True])
+def test_eigs_krylov_schur_restarts(which, cplx):
+  """numpy_backend_test.py:313-370 checks eigs against np.linalg.eig on a dense matrix; same here,
+  with ncv << n so the Krylov-Schur restart (and, for real input, conjugate-pair handling) is exercised."""
+  be = orc.OracleBackend()
+  n = 60
+  mat = _nonsym(n, 5, cplx)
+  init = np.random.default_rng(6).standard_normal(n).astype(mat.dtype)
+  calls = []
+
+  def mv(x, m):
+    calls.append(1)
+    assert x.dtype == mat.dtype     # a real operator only ever sees real vectors
+    return m @ x
+
+  eta, vecs = krylov.eigs(be, mv, [mat], init, num_krylov_vecs=20, numeig=3, which=which, tol=1e-10)
+  assert len(calls) > 20            # restarted at least once
+  _check_eigs(mat, eta, vecs, which, 3, 1e-7)
+
+
+def test_eigs_full_space_tensor_shaped_and_sm():
+  be = orc.OracleBackend()
+  n = 12
+  mat = _nonsym(n, 8)
+  np.random.seed(3)
+  eta, vecs = krylov.eigs(be, lambda x, m: (m @ x.reshape(-1)).reshape(3, 4), [mat], shape=(3, 4),
+                          dtype=np.float64, num_krylov_vecs=50, numeig=4, which="SM")
+  assert vecs[0].shape == (3, 4)
+  _check_eigs(mat, eta, vecs, "SM", 4, 1e-8)
+
+
+def test_eigs_errors():
+  be = orc.OracleBackend()
+  mv = lambda x: x
+  with pytest.raises(ValueError, match="which = LI is currently not supported."):
+    krylov.eigs(be, mv, initial_state=np.ones(3), which="LI")
+  with pytest.raises(ValueError, match="which = SI is currently not supported."):
+    krylov.eigs(be, mv, initial_state=np.ones(3), which="SI")
+  with pytest.raises(ValueError, match="`num_krylov_vecs` > `numeig \\+ 1` required!"):
+    krylov.eigs(be, mv, numeig=3, num_krylov_vecs=4, initial_state=np.ones(3))
+  with pytest.raises(ValueError, match="if no `initial_state` is passed, then `shape` and"):
+    krylov.eigs(be, mv, shape=(10,), dtype=None)
+  with pytest.raises(TypeError, match="Expected a backend tensor"):
+    krylov.eigs(be, mv, initial_state=[1, 2, 3])
+
+
+@pytest.mark.parametrize("which", ["SA", "LA"])
+def test_eigsh_complex_hermitian(which):
+  be = orc.OracleBackend()
+  n = 40
+  a = _nonsym(n, 9, True)
+  h = (a + a.conj().T) / 2
+  init = _nonsym(n, 10, True)[0]
+  eta, vecs = krylov.eigsh(be, lambda x, m: m @ x, [h], init, num_krylov_vecs=15, numeig=3, which=which, tol=1e-10)
+  w = np.linalg.eigvalsh(h)
+  want = w[:3] if which == "SA" else w[::-1][:3]
+  np.testing.assert_allclose(eta, want, atol=1e-8)
+  for e, v in zip(eta, vecs):
+    np.testing.assert_allclose(h @ v, e * v, atol=1e-6)

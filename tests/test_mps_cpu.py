@@ -6,6 +6,7 @@ import pytest
 
 from oracle import numpy_oracle as orc
 from tensornetwork_amd import mps as tmps
+import cases
 from cases import xxz_dense
 
 
@@ -87,3 +88,41 @@ def test_canonicalize_long_chain_float32_and_norm_bookkeeping():
   z = st.canonicalize(normalize=False)
   np.testing.assert_allclose(z, np.linalg.norm(full), rtol=1e-12)
   np.testing.assert_allclose(np.einsum("aib,bjc,ckd->ijk", *st.tensors), full, atol=1e-12)
+
+
+@pytest.mark.parametrize("tag", cases.MPS_GOLDEN_TAGS)
+def test_mps_measurements_match_reference_golden(tag):
+  """left/right_envs, transfer operators, local operators, two-body correlators, one-site gates:
+  numbers recorded from the reference's FiniteMPS (tests/golden/make_golden_mps.py)."""
+  cases.check_mps_golden_case(orc.OracleBackend(), cases.load_mps_golden(), tag, 1e-12)
+
+
+def test_mps_measurement_errors():
+  be = orc.OracleBackend()
+  state = tmps.FiniteMPS.random([2] * 5, [3] * 4, np.float64, be, seed=1)
+  with pytest.raises(ValueError, match="have to be <= N"):
+    state.left_envs([6])
+  with pytest.raises(ValueError, match="have to be positive"):
+    state.left_envs([-1])
+  with pytest.raises(ValueError, match="have to be < N"):
+    state.right_envs([5])
+  with pytest.raises(ValueError, match="have to be >= -1"):
+    state.right_envs([-2])
+  with pytest.raises(ValueError, match="unknown value up for direction"):
+    state.apply_transfer_operator(1, "up", np.eye(2))
+  with pytest.raises(ValueError, match="len\\(ops\\) has to be len\\(sites\\)"):
+    state.measure_local_operator([np.eye(2)], [0, 1])
+  with pytest.raises(ValueError, match="rank of gate is 3"):
+    state.apply_one_site_gate(np.zeros((2, 2, 2)), 0)
+  with pytest.raises(ValueError, match="is not between 0 <= site < N=5"):
+    state.apply_one_site_gate(np.eye(2), 5)
+  with pytest.raises(IndexError):
+    state.get_tensor(5)
+  with pytest.raises(ValueError):
+    state.get_tensor(-1)
+  with pytest.raises(IndexError):
+    state.bond_dimension(6)
+  with pytest.raises(ValueError, match="Site site1 out of range"):
+    state.measure_two_body_correlator(np.eye(2), np.eye(2), -1, [0])
+  with pytest.raises(NotImplementedError):
+    state.save("x")
