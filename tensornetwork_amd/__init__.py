@@ -20,7 +20,12 @@ from tensornetwork_amd.network import (Node, Edge, connect, contract, contract_b
                                        split_node, split_node_full_svd, split_node_qr, split_node_rq, copy,
                                        slice_edge,
                                        get_all_edges, get_subgraph_dangling, get_shared_edges,
-                                       reachable, nodes_to_json, nodes_from_json)
+                                       reachable, nodes_to_json, nodes_from_json,
+                                       get_parallel_edges, get_all_nondangling, get_all_dangling,
+                                       get_all_nodes, get_neighbors, check_connected, check_correct,
+                                       disconnect, remove_node, redirect_edge, flatten_edges,
+                                       flatten_edges_between, flatten_all_edges, split_edge,
+                                       replicate_nodes, reduced_density, from_topology, switch_backend)
 from tensornetwork_amd import contractors, pathfinder
 
 __version__ = "0.1.0"

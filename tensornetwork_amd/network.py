@@ -186,7 +186,10 @@ def connect(edge1: Edge, edge2: Edge, name: Optional[str] = None) -> Edge:
 
 
 def get_shared_edges(node1: Node, node2: Node) -> Set[Edge]:
-  return {e for e in node1.edges if e in node2.edges and not e.is_dangling()}
+  """Edges whose two ends are exactly {node1, node2} (network_components.py:1278-1299); for
+  node1 is node2 these are the node's trace edges."""
+  want = {id(node1), id(node2)}
+  return {e for e in node1.edges if not e.is_dangling() and {id(e.node1), id(e.node2)} == want}
 
 
 def get_all_edges(nodes: Iterable[Node]) -> Set[Edge]:
@@ -453,6 +456,272 @@ def split_node_rq(node: Node, left_edges: List[Edge], right_edges: List[Edge],
   """node = R -- Q with Q orthonormal on the right edges (network_operations.py:352-443)."""
   return _split_two(node, left_edges, right_edges, lambda be, t, p: be.rq(t, p), left_name, right_name,
                     edge_name)
+
+
+# ------------------------------------------------------------- graph surgery
+def get_parallel_edges(edge: Edge) -> Set[Edge]:
+  """All edges between the two nodes of ``edge``, itself included (network_components.py:1302-1312)."""
+  return get_shared_edges(edge.node1, edge.node2)
+
+
+def get_all_nondangling(nodes: Iterable[Node]) -> Set[Edge]:
+  return {e for n in nodes for e in n.edges if not e.is_dangling()}
+
+
+def get_all_dangling(nodes: Iterable[Node]) -> List[Edge]:
+  return [e for n in nodes for e in n.edges if e.is_dangling()]
+
+
+def get_all_nodes(edges: Iterable[Edge]) -> Set[Node]:
+  return {n for e in edges for n in e.get_nodes() if n is not None}
+
+
+def get_neighbors(node: Node) -> List[Node]:
+  """Nodes sharing an edge with ``node``, in axis order, without duplicates and never ``node``
+  itself (network_operations.py:823-846)."""
+  out: List[Node] = []
+  for e in node.edges:
+    if e.is_dangling() or e.is_trace():
+      continue
+    other = e.node2 if e.node1 is node else e.node1
+    if not any(other is o for o in out):
+      out.append(other)
+  return out
+
+
+def check_connected(nodes: Iterable[Node]) -> None:
+  """ValueError("Non-connected graph") unless every node is reachable from the first
+  (network_operations.py:680-694)."""
+  nodes = list(nodes)
+  if not set(nodes) <= reachable(nodes[0]):
+    raise ValueError("Non-connected graph")
+
+
+def check_correct(nodes: Iterable[Node], check_connections: bool = True) -> None:
+  """Every edge slot of every node must hold an edge that points back at that (node, axis)
+  (network_operations.py:641-677)."""
+  nodes = list(nodes)
+  for node in nodes:
+    for i, edge in enumerate(node.edges):
+      if edge.node1 is not node and edge.node2 is not node:
+        raise ValueError("Edge '{}' does not connect to node '{}'."
+                         "Edge's nodes: '{}', '{}'.".format(edge, node, edge.node1, edge.node2))
+      if not ((edge.node1 is node and edge.axis1 == i) or (edge.node2 is node and edge.axis2 == i)):
+        raise ValueError("Edge '{}' does not point to '{}' on the correct axis. "
+                         "Edge axes: {}, {}. Node axis: {}.".format(edge, node, edge.axis1, edge.axis2, i))
+  if check_connections:
+    check_connected(nodes)
+
+
+def disconnect(edge: Edge, edge1_name: Optional[str] = None, edge2_name: Optional[str] = None
+               ) -> Tuple[Edge, Edge]:
+  """Break a connected edge into two dangling ones (network_components.py:1225-1262, 2098-2113)."""
+  if edge.is_dangling():
+    raise ValueError("Cannot break dangling edge {}.".format(edge))
+  n1, a1, n2, a2 = edge.node1, edge.axis1, edge.node2, edge.axis2
+  e1 = Edge(n1, a1, name=edge1_name or '__disconnected_edge1_of_{}__'.format(edge.name))
+  e2 = Edge(n2, a2, name=edge2_name or '__disconnected_edge2_of_{}__'.format(edge.name))
+  n1.edges[a1] = e1
+  n2.edges[a2] = e2
+  return e1, e2
+
+
+def remove_node(node: Node) -> Tuple[Dict[str, Edge], Dict[int, Edge]]:
+  """Cut ``node`` out of its network (network_operations.py:103-127): every edge to ANOTHER node is
+  broken; returns the neighbours' new dangling edges keyed by ``node``'s axis name and axis number."""
+  by_name, by_axis = {}, {}
+  for i, name in enumerate(node.axis_names):
+    e = node.edges[i]
+    if e.is_dangling() or e.is_trace():
+      continue
+    e1, e2 = disconnect(e)
+    far = e1 if e1.node1 is not node else e2
+    by_axis[i] = far
+    by_name[name] = far
+  return by_name, by_axis
+
+
+def redirect_edge(edge: Edge, new_node: Node, old_node: Node) -> None:
+  """Move the end(s) of ``edge`` that sit on ``old_node`` over to the same axis of ``new_node``;
+  ``old_node`` gets a fresh dangling edge there (network_operations.py:988-1040)."""
+  ends = [(n, ax) for n, ax in edge.ends() if n is old_node]
+  if not ends or (edge.is_trace() and edge.node1 is not old_node):
+    raise ValueError(f"edge {edge} is not pointing to old_node {old_node}")
+  for _, ax in ends:
+    if edge.node1 is old_node and edge.axis1 == ax:
+      edge.node1 = new_node
+    else:
+      edge.node2 = new_node
+    new_node.edges[ax] = edge
+    old_node.edges[ax] = Edge(old_node, ax)
+
+
+def _fold_trailing(node: Node, back_axes: Sequence[int], back_shape: Sequence[int]) -> int:
+  """Permute ``back_axes`` (in this order) behind the other axes of ``node`` and reshape that
+  trailing block to ``back_shape``, in place.  The untouched leading axes keep edges and names;
+  every trailing axis gets a fresh dangling edge.  Returns the number of leading axes."""
+  be = node.backend
+  front = [i for i in range(len(node.edges)) if i not in back_axes]
+  node.reorder_axes(front + list(back_axes))
+  lead = tuple(node.shape[:len(front)])
+  node.tensor = be.reshape(node.tensor, lead + tuple(int(d) for d in back_shape))
+  node.edges = node.edges[:len(front)]
+  node.axis_names = node.axis_names[:len(front)]
+  for k in range(len(back_shape)):
+    node.edges.append(Edge(node, len(front) + k))
+    node.axis_names.append(str(len(front) + k))
+  return len(front)
+
+
+def _same_backend(nodes):
+  names = {n.backend.name for n in nodes if n is not None}
+  if len(names) > 1:
+    raise ValueError("Not all backends are the same.")
+
+
+def flatten_edges(edges: List[Edge], new_edge_name: Optional[str] = None) -> Edge:
+  """Merge several edges that join the same node(s) into one edge whose dimension is the product
+  (network_components.py:1367-1456; trace edges 1325-1364).  The node tensors are permuted
+  (merged axes last, in the order given) and reshaped in place."""
+  edges = list(edges)
+  if not edges:
+    raise ValueError("At least 1 edge must be given.")
+  _same_backend([n for e in edges for n in e.get_nodes()])
+  if len(edges) == 1:
+    return edges[0]
+  first = {id(n) for n in edges[0].get_nodes()}
+  for e in edges:
+    if {id(n) for n in e.get_nodes()} != first:
+      raise ValueError("Two edges do not share the same nodes. '{}'s nodes: '{}', '{}'. '{}'s nodes: '{}', '{}'"
+                       .format(edges[0], edges[0].node1, edges[0].node2, e, e.node1, e.node2))
+  dim = math.prod(int(e.dimension) for e in edges)
+  if edges[0].is_trace():
+    node = edges[0].node1
+    back = [min(e.axis1, e.axis2) for e in edges] + [max(e.axis1, e.axis2) for e in edges]
+    k = _fold_trailing(node, back, (dim, dim))
+    return connect(node.edges[k], node.edges[k + 1], new_edge_name)
+  fresh = []
+  for node in (edges[0].node1, edges[0].node2):
+    if node is None:
+      continue
+    back = [e.axis1 if e.node1 is node else e.axis2 for e in edges]
+    k = _fold_trailing(node, back, (dim,))
+    node.edges[k].name = new_edge_name if new_edge_name is not None else node.edges[k].name
+    fresh.append(node.edges[k])
+  if len(fresh) == 1:
+    return fresh[0]
+  return connect(fresh[0], fresh[1], new_edge_name)
+
+
+def flatten_edges_between(node1: Node, node2: Node) -> Optional[Edge]:
+  """One edge in place of all edges between two nodes; None if they share none
+  (network_components.py:1459-1477)."""
+  shared = get_shared_edges(node1, node2)
+  if not shared:
+    return None
+  owner = node1
+  return flatten_edges(sorted(shared, key=lambda e: e.axis1 if e.node1 is owner else e.axis2))
+
+
+def flatten_all_edges(nodes: Iterable[Node]) -> List[Edge]:
+  """Flatten every group of parallel (or parallel trace) edges in the network; returns one edge per
+  connected pair (network_components.py:1480-1492)."""
+  nodes = list(nodes)
+  out, done = [], set()
+  for node in nodes:
+    for e in list(node.edges):
+      if e.is_dangling():
+        continue
+      pair = frozenset((id(e.node1), id(e.node2)))
+      if pair in done:
+        continue
+      done.add(pair)
+      out.append(flatten_edges_between(e.node1, e.node2))
+  return out
+
+
+def split_edge(edge: Edge, shape: Tuple[int, ...], new_edge_names: Optional[List[str]] = None) -> List[Edge]:
+  """Inverse of flattening: replace ``edge`` by ``len(shape)`` edges of the given dimensions
+  (network_components.py:1495-1633).  Works for connected, dangling and trace edges."""
+  shape = tuple(int(d) for d in shape)
+  if math.prod(shape) != edge.dimension:
+    raise ValueError("Edge {} with dimension {} cannot be split according to shape {}."
+                     .format(edge, edge.dimension, shape))
+  if len(shape) == 1:
+    return [edge]
+  name = lambda i: new_edge_names[i] if new_edge_names is not None else None
+  if edge.is_trace():
+    node = edge.node1
+    k = _fold_trailing(node, [min(edge.axis1, edge.axis2), max(edge.axis1, edge.axis2)], shape + shape)
+    return [connect(node.edges[k + i], node.edges[k + len(shape) + i], name(i)) for i in range(len(shape))]
+  _same_backend(edge.get_nodes())
+  halves = []
+  for node in (edge.node1, edge.node2):
+    if node is None:
+      continue
+    k = _fold_trailing(node, [edge.axis1 if edge.node1 is node else edge.axis2], shape)
+    for i in range(len(shape)):
+      if name(i) is not None:
+        node.edges[k + i].name = name(i)
+        node.axis_names[k + i] = name(i)
+    halves.append(node.edges[k:])
+  if len(halves) == 1:
+    return list(halves[0])
+  return [connect(halves[0][i], halves[1][i], name(i)) for i in range(len(shape))]
+
+
+def replicate_nodes(nodes: Iterable[Node], conjugate: bool = False) -> List[Node]:
+  """Copies of ``nodes`` wired like the originals (network_operations.py:86-100)."""
+  nodes = list(nodes)
+  node_map, _ = copy(nodes, conjugate=conjugate)
+  return [node_map[n] for n in nodes]
+
+
+def reduced_density(traced_out_edges: Iterable[Edge]) -> Tuple[Dict[Node, Node], Dict[Edge, Edge]]:
+  """Turn a pure-state network into its reduced density matrix (network_operations.py:753-791): the
+  whole reachable network is copied conjugated and each edge in ``traced_out_edges`` is joined to
+  its copy.  Returns (node -> conjugate copy, edge -> copy) with the traced edges mapped to the new
+  connecting edges."""
+  traced = list(traced_out_edges)
+  if any(not e.is_dangling() for e in traced):
+    raise ValueError("traced_out_edges must only include dangling edges!")
+  seen: Dict[int, Node] = {}
+  for start in get_all_nodes(traced):
+    for n in reachable(start):
+      seen[id(n)] = n
+  node_map, edge_map = copy(seen.values(), conjugate=True)
+  for e in traced:
+    edge_map[e] = connect(edge_map[e], e)
+  return node_map, edge_map
+
+
+def from_topology(topology: str, tensors: Sequence[Any], backend=None) -> List[Node]:
+  """Nodes wired as the left side of an einsum expression says, e.g. ``"xy,yz,zx"`` (utils.py:115-158):
+  one letter per axis, equal letters are connected, axis names are the letters."""
+  parts = topology.split(",")
+  if len(parts) != len(tensors):
+    raise ValueError("topology and number of tensors is mismatched")
+  open_edges: Dict[str, Edge] = {}
+  nodes = []
+  for letters, tensor in zip(parts, tensors):
+    if len(letters) != len(tensor.shape):
+      raise ValueError(f"{letters} does not match shape {tensor.shape}")
+    node = Node(tensor, axis_names=list(letters), backend=backend)
+    for c in letters:
+      open_edges[c] = connect(open_edges[c], node[c]) if c in open_edges else node[c]
+    nodes.append(node)
+  return nodes
+
+
+def switch_backend(nodes: Iterable[Node], new_backend) -> None:
+  """Move the tensors of ``nodes`` to ``new_backend`` (network_operations.py:794-820): host copy out
+  of the old backend (``__array__``), ingest by the new one."""
+  be = _resolve_backend(new_backend)
+  for node in nodes:
+    if node.backend is be:
+      continue
+    node.tensor = be.convert_to_tensor(np.asarray(node.tensor))
+    node.backend = be
 
 
 # ------------------------------------------------------------------ copy / slice

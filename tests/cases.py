@@ -297,3 +297,176 @@ def check_mps_golden_case(be, g, tag, atol):
   state.apply_one_site_gate(op2, 2)
   np.testing.assert_allclose(host(state.get_tensor(2)), g[f"{tag}_gated2"], atol=atol)
   np.testing.assert_allclose(state.check_canonical(), float(g[f"{tag}_canon_after"]), atol=atol * 10)
+
+
+# ------------------------------------------------------------------ graph surgery (flatten / split / ...)
+def check_graph_surgery(be, rtol):
+  """The reference's own graph-operation tests, restated for a backend object `be`:
+  network_test.py:278-330 (flatten), 359-428 (split_edge), 431-470 (parallel / flatten_between / all),
+  587-594 + tensornetwork_test.py:661-720 (remove_node), 421-500 (flatten keeps results),
+  network_operations_test.py:331-374 (reduced_density), 471-560 (neighbors, redirect),
+  network_components_free_test.py:1120-1150 (disconnect)."""
+  import pytest
+  import tensornetwork_amd as tn
+  rng = np.random.default_rng(77)
+  N = lambda arr, **kw: tn.Node(np.asarray(arr, dtype=np.float64), backend=be, **kw)
+  host = lambda node: np.asarray(node.tensor)
+
+  # flatten: trace edges
+  a, c = N(np.zeros((2, 3, 4, 3, 5, 5))), N(np.zeros((2, 4)))
+  e1, e2 = tn.connect(a[1], a[3]), tn.connect(a[4], a[5])
+  x1, x2 = tn.connect(a[0], c[0]), tn.connect(c[1], a[2])
+  new = tn.flatten_edges([e1, e2], "New Edge")
+  tn.check_correct({a, c})
+  assert a.shape == (2, 4, 15, 15) and a.edges == [x1, x2, new, new] and new.name == "New Edge"
+  # flatten: standard
+  a, b = N(np.zeros((2, 3, 5)), name="A"), N(np.zeros((2, 3, 4, 5)), name="B")
+  e1, e2 = tn.connect(a[0], b[0], "Edge_1_1"), tn.connect(a[2], b[3], "Edge_2_3")
+  ea1, eb1, eb2 = a[1], b[1], b[2]
+  new = tn.flatten_edges([e1, e2], new_edge_name="New Edge")
+  assert a.shape == (3, 10) and b.shape == (3, 4, 10)
+  assert a.edges == [ea1, new] and b.edges == [eb1, eb2, new]
+  tn.check_correct({a, b})
+  # flatten: dangling
+  a = N(np.zeros((2, 3, 4, 5)), name="A")
+  d1, d2, d3, d4 = a[0], a[1], a[2], a[3]
+  new = tn.flatten_edges([d1, d3], new_edge_name="New Edge")
+  assert a.shape == (3, 5, 8) and a.edges == [d2, d4, new] and new.name == "New Edge"
+  tn.check_correct({a})
+  assert tn.flatten_edges([d2]) is d2
+  with pytest.raises(ValueError, match="At least 1 edge"):
+    tn.flatten_edges([])
+  a, b, c = N(np.eye(2)), N(np.eye(2)), N(np.eye(2))
+  e1, e2 = tn.connect(a[0], b[0]), tn.connect(a[1], c[0])
+  with pytest.raises(ValueError, match="do not share the same nodes"):
+    tn.flatten_edges([e1, e2])
+
+  # flatten keeps contraction results (tensornetwork_test.py:421-500), values through the backend
+  ta_, tb_ = rng.standard_normal((3, 5, 4, 6)), rng.standard_normal((6, 5, 7, 3))
+  a, b = N(ta_), N(tb_)
+  tn.connect(a[0], b[3]); tn.connect(b[1], a[1]); tn.connect(a[3], b[0])
+  want = np.einsum("abcd,dbea->ce", ta_, tb_)
+  flat = tn.flatten_edges_between(a, b)
+  tn.check_correct({a, b})
+  assert flat.dimension == 90 and a.shape == (4, 90) and b.shape == (7, 90)
+  np.testing.assert_allclose(host(tn.contract(flat)), want, rtol=rtol, atol=rtol)
+  tt = rng.standard_normal((3, 4, 3, 5, 4))
+  a = N(tt)
+  t1, t2 = tn.connect(a[0], a[2]), tn.connect(a[4], a[1])
+  flat = tn.flatten_edges([t1, t2])
+  assert a.shape == (5, 12, 12)
+  np.testing.assert_allclose(host(tn.contract(flat)), np.einsum("abaeb->e", tt), rtol=rtol, atol=rtol)
+
+  # split_edge: standard, then contract_between agrees with the unsplit network
+  ta_, tb_ = rng.standard_normal((6, 3, 5)), rng.standard_normal((2, 4, 6, 3))
+  a, b = N(ta_, name="A"), N(tb_, name="B")
+  e1, e2 = tn.connect(a[0], b[2], "Edge_1_1"), tn.connect(a[1], b[3], "Edge_1_2")
+  ea2, eb0, eb1 = a[2], b[0], b[1]
+  shape, names = (2, 1, 3), ["New Edge 2", "New Edge 1", "New Edge 3"]
+  new_edges = tn.split_edge(e1, shape, names)
+  assert a.shape == (3, 5) + shape and b.shape == (2, 4, 3) + shape
+  assert a.edges == [e2, ea2, *new_edges] and b.edges == [eb0, eb1, e2, *new_edges]
+  assert [e.dimension for e in new_edges] == list(shape) and [e.name for e in new_edges] == names
+  tn.check_correct({a, b})
+  np.testing.assert_allclose(host(tn.contract_between(a, b)), np.einsum("abc,deab->cde", ta_, tb_),
+                             rtol=rtol, atol=rtol)
+  # split_edge: dangling, trivial, trace, mismatch
+  a = N(np.zeros((2, 10, 4, 5)), name="A")
+  d1, d2, d3, d4 = a[0], a[1], a[2], a[3]
+  new_edges = tn.split_edge(d2, (2, 5), ["New Edge 2", "New Edge 5"])
+  assert a.shape == (2, 4, 5, 2, 5) and a.edges == [d1, d3, d4, *new_edges]
+  assert [e.dimension for e in new_edges] == [2, 5] and [e.name for e in new_edges] == ["New Edge 2", "New Edge 5"]
+  tn.check_correct({a})
+  assert tn.split_edge(d1, (2,)) == [d1]
+  tt = rng.standard_normal((6, 3, 6))
+  a = N(tt)
+  tr = tn.connect(a[0], a[2])
+  parts = tn.split_edge(tr, (2, 3))
+  assert a.shape == (3, 2, 3, 2, 3) and all(p.is_trace() for p in parts)
+  tn.check_correct({a})
+  np.testing.assert_allclose(host(tn.contract_trace_edges(a)), np.einsum("aba->b", tt), rtol=rtol, atol=rtol)
+  a = N(np.eye(5))
+  with pytest.raises(ValueError, match="cannot be split according to shape"):
+    tn.split_edge(tn.connect(a[0], a[1]), (2, 2))
+
+  # parallel edges, flatten_edges_between, flatten_all_edges
+  a, b = N(np.ones((2,) * 5)), N(np.ones((2,) * 5))
+  es = {tn.connect(a[i], b[i]) for i in (0, 1, 3)}
+  assert all(tn.get_parallel_edges(e) == es for e in es)
+  a, b = N(np.ones((3, 4, 5))), N(np.ones((5, 4, 3)))
+  tn.connect(a[0], b[2]); tn.connect(a[1], b[1]); tn.connect(a[2], b[0])
+  tn.flatten_edges_between(a, b)
+  tn.check_correct({a, b})
+  np.testing.assert_array_equal(host(a), np.ones(60)); np.testing.assert_array_equal(host(b), np.ones(60))
+  assert tn.flatten_edges_between(N(np.ones(3)), N(np.ones(3))) is None
+  a, b, c = N(np.ones((3, 3, 5, 6, 2, 2))), N(np.ones((5, 6, 7))), N(np.ones((7,)))
+  tn.connect(a[0], a[1]); tn.connect(a[4], a[5]); tn.connect(a[2], b[0]); tn.connect(a[3], b[1])
+  ok = tn.connect(b[2], c[0])
+  flat = tn.flatten_all_edges([a, b, c])
+  tn.check_correct({a, b, c})
+  assert len(flat) == 3 and ok in flat and a.shape == (6, 6, 30) and b.shape == (7, 30)
+  np.testing.assert_allclose(host(tn.contractors.greedy([a, b, c])), 6 * 30 * 7, rtol=rtol)
+
+  # disconnect / remove_node / neighbors / redirect / checks
+  a, b = N(np.eye(2)), N(np.eye(2))
+  e = tn.connect(a[0], b[0], name="bond")
+  l, r = tn.disconnect(e)
+  assert l.is_dangling() and r.is_dangling() and a[0] is l and b[0] is r
+  assert l.name == "__disconnected_edge1_of_bond__" and r.name == "__disconnected_edge2_of_bond__"
+  with pytest.raises(ValueError, match="Cannot break dangling edge"):
+    tn.disconnect(a[1])
+  a, b = N(np.eye(2)), N(np.eye(2))
+  tn.connect(a[0], b[0])
+  by_name, by_axis = tn.remove_node(b)
+  assert by_name == {"0": a[0]} and by_axis == {0: a[0]} and a[0].is_dangling()
+  a, b, c = N(np.ones((2, 2, 2)), axis_names=["x", "y", "z"]), N(np.ones((2, 2))), N(np.ones((2, 2, 2)))
+  tn.connect(a["x"], b[0]); tn.connect(a["y"], c[1]); tn.connect(c[0], c[2])
+  by_name, by_axis = tn.remove_node(a)
+  assert set(by_name) == {"x", "y"} and by_name["x"] is b[0] and by_axis[1] is c[1] and c[0].is_trace()
+  a, b, c = N(np.ones((2, 2, 2))), N(np.ones((2, 2, 2))), N(np.ones((2, 2, 2)))
+  tn.connect(a[0], b[0]); tn.connect(a[1], b[1]); tn.connect(a[2], c[0]); tn.connect(c[1], c[2])
+  assert tn.get_neighbors(a) == [b, c] and tn.get_neighbors(c) == [a]
+  assert tn.get_all_nodes(tn.get_all_edges([a])) == {a, b, c}
+  assert len(tn.get_all_nondangling([a, b, c])) == 4 and tn.get_all_dangling([a, b, c]) == [b[2]]
+  tn.check_connected([a, b, c])
+  with pytest.raises(ValueError, match="Non-connected graph"):
+    tn.check_connected([a, N(np.eye(2))])
+  a, b, c = N(np.ones((2, 3))), N(np.ones((3, 4))), N(np.ones((2, 3)))
+  e = tn.connect(a[1], b[0])
+  tn.redirect_edge(e, c, a)
+  tn.check_correct({b, c}); tn.check_correct({a}, check_connections=False)
+  assert c[1] is e and a[1].is_dangling() and set(map(id, e.get_nodes())) == {id(b), id(c)}
+  with pytest.raises(ValueError, match="is not pointing to old_node"):
+    tn.redirect_edge(e, a, a)
+  a, b = N(np.eye(2)), N(np.eye(2))
+  e = tn.connect(a[0], b[0])
+  e.axis1 = 1                                       # corrupt on purpose (network_operations_test.py:424-437)
+  with pytest.raises(ValueError, match="does not point to"):
+    tn.check_correct({a, b})
+
+  # reduced_density + replicate_nodes + from_topology
+  ta_, tb_ = rng.standard_normal((2, 3, 4)), rng.standard_normal((4, 5))
+  a, b = N(ta_, name="A"), N(tb_, name="B")
+  tn.connect(a[2], b[0])
+  keep0, keep1, traced = a[0], a[1], b[1]
+  node_map, edge_map = tn.reduced_density([traced])
+  assert set(node_map) == {a, b} and not edge_map[traced].is_dangling()
+  with pytest.raises(ValueError, match="must only include dangling edges"):
+    tn.reduced_density([edge_map[traced]])
+  nodes = [a, b, node_map[a], node_map[b]]
+  tn.check_correct(nodes)
+  rho = tn.contractors.greedy(nodes, output_edge_order=[keep0, keep1, edge_map[keep0], edge_map[keep1]])
+  psi = np.einsum("abc,cd->abd", ta_, tb_)
+  np.testing.assert_allclose(host(rho), np.einsum("abd,efd->abef", psi, psi), rtol=rtol, atol=rtol)
+  a, b = N(ta_), N(tb_)
+  tn.connect(a[2], b[0])
+  ra, rb = tn.replicate_nodes([a, b])
+  assert ra is not a and tn.get_shared_edges(ra, rb) and not tn.get_shared_edges(ra, b)
+  x, y, z = tn.from_topology("abc,bceg,adef", [np.ones((2,) * n) for n in (3, 4, 4)], backend=be)
+  assert x.axis_names == ["a", "b", "c"] and y.axis_names == ["b", "c", "e", "g"]
+  assert x["a"] is z["a"] and x["b"] is y["b"] and x["c"] is y["c"] and y["e"] is z["e"]
+  assert z["d"].is_dangling() and z["f"].is_dangling() and y["g"].is_dangling()
+  with pytest.raises(ValueError, match="mismatched"):
+    tn.from_topology("ab,bc", [np.ones((2, 2))], backend=be)
+  with pytest.raises(ValueError, match="does not match shape"):
+    tn.from_topology("abc", [np.ones((2, 2))], backend=be)

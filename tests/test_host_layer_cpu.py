@@ -208,3 +208,10 @@ def test_ncon_with_layout_planning_random(seed):
   ref = np.einsum(",".join("".join(names[l] for l in s) for s in struct) + "->" + out, *arrays)
   got = ta.ncon(arrays, struct, backend=be)
   np.testing.assert_allclose(got, ref, rtol=1e-10, atol=1e-10)
+
+
+def test_graph_surgery_reference_cases():
+  """flatten / split / disconnect / remove / redirect / reduced_density on the oracle backend
+  (the GPU suite runs the same checker on HipBackend)."""
+  import cases
+  cases.check_graph_surgery(OracleBackend(), 1e-12)
