@@ -572,6 +572,16 @@ class HipBackend(BackendBase):
   def abs(self, tensor):
     return self._unary(_lib.OP_ABS, tensor)
 
+  def real(self, tensor):
+    """Real part (a real tensor is returned as is)."""
+    tensor = self._as_tensor(tensor)
+    return self._unary(_lib.OP_REAL, tensor) if tensor.is_complex else tensor
+
+  def imag(self, tensor):
+    """Imaginary part (zeros for a real tensor)."""
+    tensor = self._as_tensor(tensor)
+    return self._unary(_lib.OP_IMAG, tensor) if tensor.is_complex else self.zeros(tensor.shape, tensor.dtype)
+
   def sign(self, tensor):
     return self._unary(_lib.OP_SIGN, tensor)
 

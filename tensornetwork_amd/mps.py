@@ -139,11 +139,15 @@ class FiniteMPS:
     return [t.shape[1] for t in self.tensors]
 
   def get_tensor(self, site: int):
-    """The tensor at ``site`` (base_mps.py:676-700; a finite MPS has no connector matrix)."""
+    """The tensor at ``site``; at the last site a connector matrix (InfiniteMPS) is absorbed from
+    the right (base_mps.py:676-700)."""
     if site >= len(self):
       raise IndexError('index `site` = {} is out of range for len(mps)= {}'.format(site, len(self)))
     if site < 0:
       raise ValueError('index `site` has to be larger than 0 (found `site`={}).'.format(site))
+    connector = getattr(self, "connector_matrix", None)
+    if site == len(self) - 1 and connector is not None:
+      return ncon([self.tensors[site], connector], [[-1, -2, 1], [1, -3]], backend=self.backend)
     return self.tensors[site]
 
   def save(self, path: str):
@@ -301,7 +305,7 @@ class FiniteMPS:
   def check_orthonormality(self, which: str, site: int):
     """|| A^dagger A - 1 || (left) or || B B^dagger - 1 || (right) (base_mps.py:616-650)."""
     be = self.backend
-    t = self.tensors[site]
+    t = self.get_tensor(site)
     if which in ("l", "left"):
       g = ncon([t, be.conj(t)], [[1, 2, -1], [1, 2, -2]], backend=be)
     elif which in ("r", "right"):
@@ -411,6 +415,136 @@ class FiniteMPS:
         if n < right_sites[-1]:
           env = self.apply_transfer_operator(n, 'left', env)
     return [be.item(o) for o in out]
+
+
+class InfiniteMPS(FiniteMPS):
+  """Translation-invariant MPS given by one unit cell (infinite_mps.py:26-307).  ``tensors`` is the
+  unit cell, ``connector_matrix`` (optional) sits between consecutive cells; ``canonicalize``
+  brings the state into Schmidt-canonical form from the dominant eigenvectors of the unit-cell
+  transfer matrix (``backend.eigs`` on device vectors)."""
+
+  def __init__(self, tensors: List, backend, center_position: Optional[int] = None, connector_matrix=None):
+    # pylint: disable=super-init-not-called
+    self.backend = backend
+    self.tensors = [backend.convert_to_tensor(t) if not backend.is_tensor(t) else t for t in tensors]
+    if center_position is not None and (center_position < 0 or center_position >= len(self.tensors)):
+      raise ValueError("`center_position = {}` is different from `None` and not between "
+                       "0 <= center_position < {}".format(center_position, len(self.tensors)))
+    self.center_position = center_position
+    self.connector_matrix = connector_matrix
+
+  @classmethod
+  def random(cls, d: Sequence[int], D: Sequence[int], dtype, backend, seed: Optional[int] = None):
+    """Random unit cell with bond dimensions ``D`` (len(d) + 1, periodic: D[0] == D[-1]); centre at 0
+    (infinite_mps.py:64-92)."""
+    if len(D) != len(d) + 1:
+      raise ValueError('len(D) = {} is different from len(d) + 1= {}'.format(len(D), len(d) + 1))
+    if D[-1] != D[0]:
+      raise ValueError('D[0]={} != D[-1]={}.'.format(D[0], D[-1]))
+    if seed is not None:
+      np.random.seed(seed)
+    return cls([backend.randn((D[n], d[n], D[n + 1]), dtype=dtype) for n in range(len(d))], backend,
+               center_position=0)
+
+  def left_envs(self, sites):
+    raise NotImplementedError()
+
+  def right_envs(self, sites):
+    raise NotImplementedError()
+
+  def position(self, site: int, normalize: bool = True, D: Optional[int] = None,
+               max_truncation_err: Optional[float] = None, norms_out: Optional[List[float]] = None):
+    if self.center_position is None:
+      raise ValueError("BaseMPS.center_position is `None`, cannot shift `center_position`."
+                       "Reset `center_position` manually or use `canonicalize`")
+    return super().position(site, normalize, D, max_truncation_err, norms_out)
+
+  def unit_cell_transfer_operator(self, direction, matrix):
+    """``matrix`` pushed through the whole unit cell, site by site (infinite_mps.py:94-101)."""
+    sites = range(len(self))
+    if direction in (-1, 'r', 'right'):
+      sites = reversed(sites)
+    for site in sites:
+      matrix = self.apply_transfer_operator(site, direction, matrix)
+    return matrix
+
+  def transfer_matrix_eigs(self, direction, initial_state=None, precision: float = 1e-10,
+                           num_krylov_vecs: int = 30, maxiter: Optional[int] = None):
+    """Dominant eigenvalue (host scalar) and eigenvector (D x D tensor) of the unit-cell transfer
+    matrix (infinite_mps.py:103-166).  For a real state both are real: the Arnoldi basis of a real
+    operator stays real and the dominant eigenvalue of a transfer matrix is real, so the complex
+    result ``eigs`` returns by convention is narrowed back to the state's dtype."""
+    be = self.backend
+    D = self.bond_dimensions[0]
+
+    def mv(vector):
+      return be.reshape(self.unit_cell_transfer_operator(direction, be.reshape(vector, (D, D))), (D * D,))
+
+    if initial_state is None:
+      initial_state = be.randn((D * D,), dtype=self.dtype)
+    else:
+      initial_state = be.reshape(initial_state, (D * D,))
+    if D == 1:
+      initial_state = be.divide(initial_state, self._norm(initial_state))
+      result = mv(initial_state)
+      return self._norm(result), be.reshape(result, (D, D))
+    ncv = min(num_krylov_vecs, D * D)
+    eta, vecs = be.eigs(A=mv, initial_state=initial_state, num_krylov_vecs=ncv, numeig=min(1, ncv - 2),
+                        tol=precision, which='LR', maxiter=maxiter, dtype=self.dtype)
+    vec, val = vecs[0], eta[0]
+    if np.dtype(self.dtype).kind != "c":
+      vec, val = be.real(vec), float(np.real(val))
+    return val, be.reshape(vec, (D, D))
+
+  def _psd_factors(self, mat, cutoff):
+    """For a (numerically) positive matrix ``mat``: normalise to unit trace, hermitise,
+    diagonalise; returns (u, sqrt(w), sqrt(1/w)) with eigenvalues at or below ``cutoff`` -- and their
+    inverses -- set to zero (the reference's pseudo-inverse, infinite_mps.py:229-241)."""
+    be = self.backend
+    mat = be.divide(mat, be.trace(mat))
+    mat = be.divide(be.addition(mat, be.transpose(be.conj(mat), (1, 0))), 2.0)
+    w, u = be.eigh(mat)
+    w = be.divide(w, be.norm(w))
+    mask = w <= cutoff
+    w = be.index_update(w, mask, 0.0)
+    winv = be.index_update(be.divide(1.0, w), mask, 0.0)
+    return u, be.sqrt(w), be.sqrt(winv)
+
+  def canonicalize(self, left_initial_state=None, right_initial_state=None, precision: float = 1e-10,  # pylint: disable=arguments-differ
+                   truncation_threshold: float = 1e-15, D: Optional[int] = None, num_krylov_vecs: int = 50,
+                   maxiter: Optional[int] = 1000, pseudo_inverse_cutoff: Optional[float] = None):
+    """Schmidt-canonical form (infinite_mps.py:178-307).  With ``l = X^dagger X`` and ``r = Y Y^dagger`` the
+    dominant left / right eigenvectors of the unit-cell transfer matrix, the SVD ``X Y = U lam V``
+    gives the Schmidt values ``lam`` on the cell boundary; the gauge ``lam V Y^-1`` is absorbed into the
+    first tensor and ``X^-1 U lam`` into the last, a QR sweep makes the cell left-orthonormal, and the
+    connector becomes ``lam^-1``.  Returns the norm of ``lam``."""
+    be = self.backend
+    if pseudo_inverse_cutoff is None:
+      pseudo_inverse_cutoff = be.eps(self.dtype)
+    if self.center_position is None:
+      self.center_position = 0
+    self.position(0)
+    eta, l = self.transfer_matrix_eigs('left', left_initial_state, precision, num_krylov_vecs, maxiter)
+    self.tensors[0] = be.divide(self.tensors[0], float(np.sqrt(abs(eta))))
+    u, sw, siw = self._psd_factors(l, pseudo_inverse_cutoff)
+    sqrtl = be.transpose(be.broadcast_right_multiplication(u, sw), (1, 0))        # sqrt(w) u^T
+    inv_sqrtl = be.broadcast_right_multiplication(be.conj(u), siw)                # conj(u) / sqrt(w)
+    _, r = self.transfer_matrix_eigs('right', right_initial_state, precision, num_krylov_vecs, maxiter)
+    u, sw, siw = self._psd_factors(r, pseudo_inverse_cutoff)
+    sqrtr = be.broadcast_right_multiplication(u, sw)                              # u sqrt(w)
+    inv_sqrtr = be.transpose(be.broadcast_right_multiplication(be.conj(u), siw), (1, 0))
+    U, singvals, V, _ = be.svd(be.tensordot(sqrtl, sqrtr, 1), 1, D, truncation_threshold, relative=True)
+    lam = be.diagflat(singvals)
+    self.tensors[0] = ncon([lam, V, inv_sqrtr, self.tensors[0]],
+                           [[-1, 1], [1, 2], [2, 3], [3, -2, -3]], backend=be)
+    self.tensors[-1] = ncon([self.get_tensor(len(self) - 1), inv_sqrtl, U, lam],
+                            [[-1, -2, 1], [1, 2], [2, 3], [3, -3]], backend=be)
+    self.connector_matrix = None               # absorbed just above
+    self.position(len(self) - 1)
+    lam_norm = self._norm(singvals)
+    self.center_position = len(self) - 1
+    self.connector_matrix = be.inv(be.divide(lam, lam_norm))
+    return lam_norm
 
 
 # ------------------------------------------------------------------------ DMRG

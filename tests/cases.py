@@ -470,3 +470,35 @@ def check_graph_surgery(be, rtol):
     tn.from_topology("ab,bc", [np.ones((2, 2))], backend=be)
   with pytest.raises(ValueError, match="does not match shape"):
     tn.from_topology("abc", [np.ones((2, 2))], backend=be)
+
+
+INFINITE_MPS_GOLDEN_TAGS = ("inf_f64", "inf_c128")
+
+
+def check_infinite_mps_golden_case(be, g, tag, rtol):
+  """InfiniteMPS on backend `be` vs the reference's InfiniteMPS on the same unit cell
+  (tests/golden/make_golden_mps.py:gen_infinite; infinite_mps_test.py:57-91): unit-cell transfer
+  operator, its dominant eigenpair, Schmidt-canonical form."""
+  from tensornetwork_amd import mps as tmps
+  n = int(g[f"{tag}_meta"][0])
+  imps = tmps.InfiniteMPS([be.convert_to_tensor(g[f"{tag}_t{k}"]) for k in range(n)], be, center_position=0)
+  dtype = g[f"{tag}_t0"].dtype
+  m = be.convert_to_tensor(g[f"{tag}_m"])
+  for direction, key in (("left", "uc_l"), (-1, "uc_r")):
+    ref = g[f"{tag}_{key}"]
+    np.testing.assert_allclose(np.asarray(imps.unit_cell_transfer_operator(direction, m)), ref,
+                               rtol=rtol, atol=rtol * np.abs(ref).max())
+  np.random.seed(1)
+  eta, l = imps.transfer_matrix_eigs("left")
+  np.testing.assert_allclose(eta, g[f"{tag}_eta"], rtol=max(rtol, 1e-9))
+  lh = np.asarray(l)
+  assert lh.dtype == dtype                          # a real state keeps a real eigenvector
+  np.testing.assert_allclose(np.asarray(imps.unit_cell_transfer_operator("left", l)), eta * lh,
+                             rtol=1e-6, atol=1e-7 * abs(eta) * np.abs(lh).max())
+  lam_norm = imps.canonicalize()
+  np.testing.assert_allclose(lam_norm, float(g[f"{tag}_lam_norm"]), rtol=1e-8)
+  schmidt = np.sort(np.abs(1.0 / np.diag(np.asarray(imps.connector_matrix))))[::-1]
+  np.testing.assert_allclose(schmidt, g[f"{tag}_schmidt"], rtol=1e-7, atol=1e-10)
+  assert imps.center_position == n - 1 and imps.tensors[0].dtype == dtype
+  assert imps.check_canonical() < 1e-10
+  assert imps.check_orthonormality("l", n - 1) < 1e-8   # last tensor x connector is a left isometry too

@@ -56,3 +56,11 @@ def test_mps_measurements_match_reference_golden_on_device(hip, tag):
   """Reduced density matrices, transfer operators, <O>, <O1 O2>, one-site gates on device tensors vs the
   numbers recorded from the reference's FiniteMPS (tests/golden/make_golden_mps.py)."""
   cases.check_mps_golden_case(hip, cases.load_mps_golden(), tag, 1e-10)
+
+
+@pytest.mark.parametrize("tag", cases.INFINITE_MPS_GOLDEN_TAGS)
+def test_infinite_mps_matches_reference_golden_on_device(hip, tag):
+  """InfiniteMPS.canonicalize end to end in HBM: Krylov-Schur `eigs` on device vectors for the dominant
+  transfer-matrix eigenvectors, Hermitian `eigh`, int32 masks + `index_update` for the pseudo-inverse,
+  truncated `svd`, `inv`; Schmidt spectrum vs the reference's (golden_mps.npz)."""
+  cases.check_infinite_mps_golden_case(hip, cases.load_mps_golden(), tag, 1e-11)

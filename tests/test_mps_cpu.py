@@ -126,3 +126,42 @@ def test_mps_measurement_errors():
     state.measure_two_body_correlator(np.eye(2), np.eye(2), -1, [0])
   with pytest.raises(NotImplementedError):
     state.save("x")
+
+
+class _KrylovSchurOracle(orc.OracleBackend):
+  """Oracle arithmetic, but `eigs` through tensornetwork_amd.krylov (the code HipBackend runs)."""
+
+  def eigs(self, *args, **kwargs):
+    from tensornetwork_amd import krylov
+    return krylov.eigs(self, *args, **kwargs)
+
+
+@pytest.mark.parametrize("tag", cases.INFINITE_MPS_GOLDEN_TAGS)
+@pytest.mark.parametrize("backend_cls", [orc.OracleBackend, _KrylovSchurOracle])
+def test_infinite_mps_matches_reference_golden(tag, backend_cls):
+  cases.check_infinite_mps_golden_case(backend_cls(), cases.load_mps_golden(), tag, 1e-12)
+
+
+def test_infinite_mps_errors_and_trivial_bond():
+  be = orc.OracleBackend()
+  ts = [np.random.randn(2, 2, 10)] + [np.random.randn(10, 2, 10) for _ in range(8)] + [np.random.randn(10, 2, 1)]
+  for pos in (-1, 10):
+    with pytest.raises(ValueError):                 # infinite_mps_test.py:47-54
+      tmps.InfiniteMPS(ts, be, center_position=pos)
+  with pytest.raises(ValueError, match="is different from len\\(d\\) \\+ 1"):
+    tmps.InfiniteMPS.random([2, 2], [3, 3], np.float64, be)
+  with pytest.raises(ValueError, match="D\\[0\\]=3 != D\\[-1\\]=4"):
+    tmps.InfiniteMPS.random([2, 2], [3, 3, 4], np.float64, be)
+  imps = tmps.InfiniteMPS.random([2, 2], [3, 3, 3], np.float64, be, seed=2)
+  with pytest.raises(NotImplementedError):
+    imps.left_envs([0])
+  with pytest.raises(NotImplementedError):
+    imps.right_envs([0])
+  imps.center_position = None
+  with pytest.raises(ValueError, match="cannot shift `center_position`"):
+    imps.position(1)
+  product = tmps.InfiniteMPS.random([3], [1, 1], np.float64, be, seed=4)   # D = 1: no boundary entanglement
+  eta, mat = product.transfer_matrix_eigs("left")
+  t = np.asarray(product.tensors[0]).reshape(3)
+  np.testing.assert_allclose(eta, t @ t, rtol=1e-12)
+  assert mat.shape == (1, 1)
