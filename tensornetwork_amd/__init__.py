@@ -27,6 +27,9 @@ from tensornetwork_amd.network import (Node, Edge, connect, contract, contract_b
                                        flatten_edges_between, flatten_all_edges, split_edge,
                                        replicate_nodes, reduced_density, from_topology, switch_backend)
 from tensornetwork_amd import contractors, pathfinder
+from tensornetwork_amd.mps import FiniteMPS, InfiniteMPS, FiniteDMRG
+from tensornetwork_amd.mpo import (BaseMPO, FiniteMPO, InfiniteMPO, FiniteXXZ, FiniteTFI,
+                                   FiniteFreeFermion2D)
 
 __version__ = "0.1.0"
 

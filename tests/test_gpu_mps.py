@@ -64,3 +64,22 @@ def test_infinite_mps_matches_reference_golden_on_device(hip, tag):
   transfer-matrix eigenvectors, Hermitian `eigh`, int32 masks + `index_update` for the pseudo-inverse,
   truncated `svd`, `inv`; Schmidt spectrum vs the reference's (golden_mps.npz)."""
   cases.check_infinite_mps_golden_case(hip, cases.load_mps_golden(), tag, 1e-11)
+
+
+def test_free_fermion_2d_one_site_dmrg_on_device(hip):
+  """mpo_test.py:94-128 on the GPU: FiniteFreeFermion2D (2 x 4 grid, ancillary dimension 6) + one-site DMRG."""
+  from tensornetwork_amd import mpo as tmpo
+  n1, n2, D = 2, 4, 16
+  model = tmpo.FiniteFreeFermion2D(-1.0, -1.0, -1.0, n1, n2, np.float64, backend=hip)
+  assert all(isinstance(t, ta.DeviceTensor) for t in model)
+  state = tmps.FiniteMPS.random([2] * (n1 * n2), [D] * (n1 * n2 - 1), np.float64, hip, seed=5)
+  energy = tmps.FiniteDMRG(state, model).run_one_site(num_sweeps=6, precision=1e-10)
+  n = n1 * n2
+  tij = -np.eye(n)
+  for s in range(n):
+    col, row = divmod(s, n1)
+    if row < n1 - 1:
+      tij[s, s + 1] = tij[s + 1, s] = -1.0
+    if col < n2 - 1:
+      tij[s, s + n1] = tij[s + n1, s] = -1.0
+  np.testing.assert_allclose(energy, min(np.cumsum(np.linalg.eigvalsh(tij))), rtol=1e-6)

@@ -165,3 +165,77 @@ def test_infinite_mps_errors_and_trivial_bond():
   t = np.asarray(product.tensors[0]).reshape(3)
   np.testing.assert_allclose(eta, t @ t, rtol=1e-12)
   assert mat.shape == (1, 1)
+
+
+def test_mpo_classes_match_reference_tensors():
+  """FiniteXXZ / FiniteTFI / FiniteFreeFermion2D tensors equal the reference's element for element
+  (goldens from mpo.py:129-387 via make_golden_mps.py)."""
+  from tensornetwork_amd import mpo as tmpo
+  be = orc.OracleBackend()
+  g = cases.load_mps_golden()
+  jz, jxy, bz = g["mpo_params"][0][:4], g["mpo_params"][1][:4], g["mpo_params"][2]
+  models = {"xxz": tmpo.FiniteXXZ(jz, jxy, bz, np.float64, backend=be),
+            "tfi": tmpo.FiniteTFI(jz, bz, np.complex128, backend=be)}
+  for n1, n2 in ((2, 2), (3, 2), (1, 4)):
+    models[f"ff{n1}x{n2}"] = tmpo.FiniteFreeFermion2D(-1.0, -0.7, 0.3, n1, n2, np.float64, backend=be)
+  for key, model in models.items():
+    assert model.bond_dimensions[0] == 1 and model.bond_dimensions[-1] == 1
+    for k, t in enumerate(model):
+      ref = g[f"mpo_{key}_{k}"]
+      assert t.dtype == ref.dtype and np.array_equal(np.asarray(t), ref), (key, k)
+    assert f"mpo_{key}_{len(model)}" not in g
+  assert models["xxz"].name == "XXZ_MPO" and models["tfi"].name == "TFI_MPO"
+
+
+def test_mpo_containers():
+  # mpo_test.py:33-92
+  from tensornetwork_amd import mpo as tmpo
+  be = orc.OracleBackend()
+  ts = [be.randn((1, 5, 2, 2), dtype=np.float64), be.randn((5, 5, 2, 2), dtype=np.float64),
+        be.randn((5, 1, 2, 2), dtype=np.float64)]
+  m = tmpo.BaseMPO(ts, backend=be, name="test")
+  assert m.backend is be and m.dtype == np.float64 and m.bond_dimensions == [1, 5, 5, 1] and len(m) == 3
+  bad = ts[:2] + [be.randn((5, 1, 2, 2), dtype=np.float32)]
+  with pytest.raises(TypeError):
+    tmpo.BaseMPO(bad, backend=be)
+  empty = tmpo.BaseMPO([], backend=be)
+  empty.tensors = bad
+  with pytest.raises(TypeError):
+    empty.dtype  # pylint: disable=pointless-statement
+  with pytest.raises(ValueError):
+    tmpo.FiniteMPO([np.random.rand(2, 5, 2, 2), np.random.rand(5, 1, 2, 2)], backend=be)
+  with pytest.raises(ValueError):
+    tmpo.FiniteMPO([np.random.rand(1, 5, 2, 2), np.random.rand(5, 2, 2, 2)], backend=be)
+  with pytest.raises(ValueError):
+    tmpo.InfiniteMPO([np.random.rand(2, 5, 2, 2), np.random.rand(5, 3, 2, 2)], backend=be)
+  pair = [np.random.rand(5, 5, 2, 2), np.random.rand(5, 5, 2, 2)]
+  inf = tmpo.InfiniteMPO(pair, backend=be)
+  inf.roll(1)
+  np.testing.assert_array_equal(inf.tensors[0], pair[1])
+  inf.roll(1)
+  np.testing.assert_array_equal(inf.tensors[0], pair[0])
+
+
+def free_fermion_ground_energy(n1, n2, t, v):
+  """Exact: fill the negative levels of the single-particle hopping matrix (mpo_test.py:95-117)."""
+  n = n1 * n2
+  tij = np.zeros((n, n))
+  for s in range(n):
+    col, row = divmod(s, n1)                         # snake: n1 sites per column
+    if row < n1 - 1:
+      tij[s, s + 1] = tij[s + 1, s] = t
+    if col < n2 - 1:
+      tij[s, s + n1] = tij[s + n1, s] = t
+  tij += v * np.eye(n)
+  return min(np.cumsum(np.linalg.eigvalsh(tij)))
+
+
+@pytest.mark.parametrize("n1,n2,D", [(2, 2, 4), (2, 4, 16)])
+def test_free_fermion_2d_dmrg_ground_energy(n1, n2, D):
+  # mpo_test.py:94-128: one-site DMRG on the snaked 2-D free-fermion MPO vs the filled Fermi sea
+  from tensornetwork_amd import mpo as tmpo
+  be = orc.OracleBackend()
+  model = tmpo.FiniteFreeFermion2D(-1.0, -1.0, -1.0, n1, n2, np.float64, backend=be)
+  state = tmps.FiniteMPS.random([2] * (n1 * n2), [D] * (n1 * n2 - 1), np.float64, be, seed=5)
+  energy = tmps.FiniteDMRG(state, model).run_one_site(num_sweeps=6, precision=1e-10)
+  np.testing.assert_allclose(energy, free_fermion_ground_energy(n1, n2, -1.0, -1.0), rtol=1e-6)
