@@ -21,6 +21,8 @@
 //
 // MFMA roofline: 2*M*N*K flop against 2.5 PFLOP/s dense bf16.
 #include "tnh_gemm_nt.h"
+#include <type_traits>
+#include <utility>
 
 namespace tnh {
 
@@ -434,6 +436,216 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(NtArgs p) {
   }
 }
 
+
+// ---------------------------------------------------------------------------
+// 256x256x64 "w4" kernel (A/B variant, knob ":p6", NOT the default): FOUR wavefronts (2 x 2),
+// each owning a 128x128 output block = 64 accumulator tiles = all 256 AGPRs of the lane, one wave
+// per SIMD.  Idea: 128x128 wave tiles read 4 x 256 rows x 128 B = 128 KiB of fragments per K-tile
+// instead of the 192 KiB of the 8-wave kernels (128x64 wave tiles), and have no second wave to
+// pay registers for.  Measured on MI355X (tools/w4_probe.py; bit-identical results to the
+// ping-pong kernel): 8192^3 zero-filled 1.71 PF vs 1.95 PF, random 1.44-1.47 vs 1.48-1.53;
+// 8192 x 8192 x 65536 (row stride 128 KiB) 1.17 PF vs 1.46-1.64 PF, identical for zero and random
+// operands -- i.e. bound by the latency of the K-tile fetch, which one wave per SIMD exposes
+// directly (a variant with four 32-deep stages and twice the prefetch distance was slower still:
+// 1.05 PF, the extra barrier per k-step costs more than the distance buys).  The ping-pong kernel,
+// whose partner wave keeps the matrix pipe busy across those waits, stays the default.
+//
+// One wave per SIMD means nobody else fills the matrix pipe while this wave waits,
+// so the overlap is software pipelining inside the wave, scheduled by hand: the
+// MFMAs and ds_reads are inline asm in the order they must issue (hipcc given the
+// builtins spreads the 256 accumulators over VGPRs and AGPRs and shuttles them with
+// ~200 v_accvgpr moves per K-tile; the "+a" constraint pins them).  Two fragment
+// register sets X / Y: while the 64 MFMAs of one k-step run on X, the 16
+// ds_read_b128 of the next k-step land in Y (1 read : 3 MFMA, last 16 MFMAs cover
+// the latency of the final read).  The workgroup barrier that publishes the next
+// K-tile sits between the two k-steps of the current one, where the second
+// k-step's fragments are already in registers -- only the barrier skew is exposed.
+//
+//   prologue: DMA tile 0 -> buf0, tile 1 -> buf1; wait tile 0; barrier; X <- (0, ks0)
+//   tile t:   Y <- (t, ks1)                      ||  MFMA X
+//             wait tile t+1; barrier
+//             X <- (t+1, ks0), DMA tile t+2 -> buf t&1 (its content is in X/Y)  ||  MFMA Y
+//
+// Waits are ours (the compiler does not see asm loads): lgkmcnt(0) after each
+// batch, before the fragments it fetched are used; vmcnt(0) before the barrier.
+// LDS: 2 stages x 64 KiB (dynamic), same XOR-swizzled image as the kernels above.
+// Needs M % 256 == 0 and N % 256 == 0 (no edge handling: every row/col is real).
+// ---------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;   // asm operands must be plain vectors
+
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+
+template <int OFF>
+__device__ __forceinline__ void lds_read16_asm(u32x4& dst, unsigned addr) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(dst) : "v"(addr), "n"(OFF));
+}
+
+template <bool IS_BF16>
+__device__ __forceinline__ void mma16_pinned(f32x4& c, const u32x4& a, const u32x4& b) {
+  if constexpr (IS_BF16) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+  else asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+}
+
+template <bool IS_BF16, bool OUT_F32>
+__global__ __launch_bounds__(256) void gemm_nt_w4_kernel(NtArgs p) {
+  constexpr int BM = 256, BN = 256, BK = 64;
+  constexpr int A_BYTES = BM * BK * 2, STAGE_BYTES = 2 * A_BYTES;
+  extern __shared__ __attribute__((aligned(1024))) char smem_w4[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wid >> 1, wn = wid & 1;
+
+  int tm, tn;
+  tile_of_block(blockIdx.x, p.tiles_m, p.tiles_n, p.raster, tm, tn);
+  const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
+  const uint16_t* A = p.A + (int64_t)blockIdx.y * p.sA;
+  const uint16_t* B = p.B + (int64_t)blockIdx.y * p.sB;
+
+  // LDS-DMA piece (i, wave): tile rows (4 i + wid) * 8 .. +7; lane l -> row + (l >> 3), source chunk
+  // (l & 7) ^ (l >> 3) (the swizzle, see gemm_nt_kernel).  Rows step by 32 between pieces.
+  const int lrow = lane >> 3;
+  const int lchunk = (lane & 7) ^ lrow;
+  const uint16_t* ga = A + (m0 + wid * 8 + lrow) * p.lda + lchunk * 8;
+  const uint16_t* gb = B + (n0 + wid * 8 + lrow) * p.ldb + lchunk * 8;
+  const int64_t step_a = 32 * p.lda, step_b = 32 * p.ldb;
+  const unsigned lds0 = (unsigned)(size_t)TNH_LDS_PTR(smem_w4);
+
+  // piece q of a stage: q < 8 -> A rows, else B rows
+  auto dma_piece = [&](int q, int s, int64_t k0) {
+    const unsigned dst = lds0 + s * STAGE_BYTES + wid * 1024 + (q & 7) * 4096 + (q >> 3) * A_BYTES;
+    const uint16_t* src = (q < 8) ? ga + (q & 7) * step_a : gb + (q & 7) * step_b;
+    glds16(src + k0, __builtin_amdgcn_readfirstlane(dst));
+  };
+
+  // fragment read addresses (LDS bytes, stage 0): row 16 f + (l & 15), swizzled chunk per k-step
+  unsigned fa_addr[2], fb_addr[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    const unsigned off = (lane & 15) * 128 + (((ks * 4 + (lane >> 4)) ^ (lane & 7)) * 16);
+    fa_addr[ks] = lds0 + wm * 16384 + off;
+    fb_addr[ks] = lds0 + A_BYTES + wn * 16384 + off;
+  }
+
+  f32x4 acc[8][8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  u32x4 xa[8], xb[8], ya[8], yb[8];
+  // fragment #g of a set: g < 8 -> B rows (needed by every MFMA of the first A row), else A rows
+  auto read_frag = [&](auto g, u32x4 (&fa)[8], u32x4 (&fb)[8], unsigned aaddr, unsigned baddr) {
+    constexpr int G = decltype(g)::value;
+    if constexpr (G < 8) lds_read16_asm<G * 2048>(fb[G], baddr);
+    else lds_read16_asm<(G - 8) * 2048>(fa[G - 8], aaddr);
+  };
+  auto mma4 = [&](auto q, const u32x4 (&fa)[8], const u32x4 (&fb)[8]) {   // MFMA #q of 64: acc[q / 8][q % 8]
+    constexpr int Q = decltype(q)::value;
+    mma16_pinned<IS_BF16>(acc[Q / 8][Q % 8], fb[Q % 8], fa[Q / 8]);
+  };
+
+  const int nt = (int)(p.K / BK);
+#pragma unroll
+  for (int q = 0; q < 16; ++q) dma_piece(q, 0, 0);
+#pragma unroll
+  for (int q = 0; q < 16; ++q) dma_piece(q, 1, (int64_t)(nt > 1 ? 1 : 0) * BK);
+  asm volatile("s_waitcnt vmcnt(16)" ::: "memory");   // tile 0 landed; the 16 pieces of tile 1 stay in flight
+  __syncthreads();
+  static_for<0, 16>([&](auto g) { read_frag(g, xa, xb, fa_addr[0], fb_addr[0]); });
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+
+  for (int t = 0; t + 1 < nt; ++t) {
+    const unsigned cur = (t & 1) * STAGE_BYTES, nxt = STAGE_BYTES - cur;
+    // ---- k-step 0 of tile t on X, fetching k-step 1 into Y
+    static_for<0, 16>([&](auto g) {
+      constexpr int G = decltype(g)::value;
+      read_frag(g, ya, yb, fa_addr[1] + cur, fb_addr[1] + cur);
+      static_for<3 * G, 3 * G + 3>([&](auto q) { mma4(q, xa, xb); });
+    });
+    static_for<48, 64>([&](auto q) { mma4(q, xa, xb); });
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // tile t+1 landed; Y complete; no reads of `cur` pending
+    __syncthreads();
+    // ---- k-step 1 of tile t on Y, fetching (t+1, ks0) into X and issuing the DMA of tile t+2 into `cur`
+    const int64_t k2 = (int64_t)((t + 2 < nt) ? t + 2 : nt - 1) * BK;   // tail: harmless re-load keeps the body branch-free
+    static_for<0, 16>([&](auto g) {
+      constexpr int G = decltype(g)::value;
+      read_frag(g, xa, xb, fa_addr[0] + nxt, fb_addr[0] + nxt);
+      dma_piece(G, t & 1, k2);
+      static_for<3 * G, 3 * G + 3>([&](auto q) { mma4(q, ya, yb); });
+    });
+    static_for<48, 64>([&](auto q) { mma4(q, ya, yb); });
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+  {
+    const unsigned cur = ((nt - 1) & 1) * STAGE_BYTES;
+    static_for<0, 16>([&](auto g) {
+      constexpr int G = decltype(g)::value;
+      read_frag(g, ya, yb, fa_addr[1] + cur, fb_addr[1] + cur);
+      static_for<3 * G, 3 * G + 3>([&](auto q) { mma4(q, xa, xb); });
+    });
+    static_for<48, 64>([&](auto q) { mma4(q, xa, xb); });
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    static_for<0, 64>([&](auto q) { mma4(q, ya, yb); });
+  }
+  // MFMA results -> VALU reads: the compiler cannot see the asm MFMAs, so the wait states are ours;
+  // and no DMA may outlive the workgroup's LDS allocation.
+  asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+
+  store_wave_tile<IS_BF16, OUT_F32, 8, 8>(acc, p, (char*)p.C + (int64_t)blockIdx.y * p.sC * (OUT_F32 ? 4 : 2), m0, n0,
+                                          BM, BN, wm * 128, wn * 128, lane);
+}
+
+static int launch_w4(bool is_bf16, bool out_f32, NtArgs p, int64_t batch) {
+  constexpr int LDS_BYTES = 2 * 2 * 256 * 64 * 2;   // 128 KiB of the CU's 160 KiB
+  p.tiles_m = (int)(p.M / 256);
+  p.tiles_n = (int)(p.N / 256);
+  const int64_t nwg = (int64_t)p.tiles_m * p.tiles_n;
+  TNH_REQUIRE(nwg < (int64_t(1) << 24), "GEMM grid too large");
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipSuccess;
+#define TNH_W4_ATTR(B16, O32)                                                                                   \
+  if (e == hipSuccess)                                                                                          \
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_w4_kernel<B16, O32>),                         \
+                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES)
+    TNH_W4_ATTR(true, true); TNH_W4_ATTR(true, false); TNH_W4_ATTR(false, true); TNH_W4_ATTR(false, false);
+#undef TNH_W4_ATTR
+    TNH_REQUIRE(e == hipSuccess, "hipFuncSetAttribute(128 KiB LDS) failed: %s", hipGetErrorString(e));
+    attr_set = true;
+  }
+  const int esz_out = out_f32 ? 4 : 2;
+  for (int64_t b0 = 0; b0 < batch; b0 += 65535) {
+    const int64_t nb = (batch - b0 < 65535) ? (batch - b0) : 65535;
+    NtArgs q = p;
+    q.A = p.A + b0 * p.sA;
+    q.B = p.B + b0 * p.sB;
+    q.C = (char*)p.C + b0 * p.sC * esz_out;
+    const dim3 grid((unsigned)nwg, (unsigned)nb), block(256);
+#define TNH_W4_LAUNCH(B16, O32)                                                                                  \
+  do {                                                                                                          \
+    hipLaunchKernelGGL((gemm_nt_w4_kernel<B16, O32>), grid, block, LDS_BYTES, stream(), q);                      \
+  } while (0)
+    if (is_bf16) {
+      if (out_f32) TNH_W4_LAUNCH(true, true);
+      else TNH_W4_LAUNCH(true, false);
+    } else {
+      if (out_f32) TNH_W4_LAUNCH(false, true);
+      else TNH_W4_LAUNCH(false, false);
+    }
+#undef TNH_W4_LAUNCH
+    TNH_LAUNCH_CHECK();
+  }
+  return TNH_OK;
+}
+
 template <int BM, int BN, int WAVES_M, int WAVES_N>
 static int launch_nt(bool is_bf16, bool out_f32, NtArgs p, int64_t batch) {
   p.tiles_m = (int)((p.M + BM - 1) / BM);
@@ -533,6 +745,10 @@ int gemm_bf16_fast(int in_dt, int out_dt, int variant, int transA, int transB, i
   bool big = (M >= 256 && N >= 256) && (((M + 255) / 256) * ((N + 255) / 256) * batch >= 192);
   if (variant == 3) big = false;
   if (variant == 4) big = true;
+  if (g_opt_phases == 6 && (big || variant == 5) && M % 256 == 0 && N % 256 == 0 && K >= 128) {   // A/B knob ":p6"
+    *name = "bf16_nt_256x256x64_w4";
+    return launch_w4(is_bf16, out_f32, p, batch);
+  }
   if (variant == 5 || (big && variant == 0 && g_pp_default)) {
     *name = "bf16_nt_256x256x64_pp";
     return launch_pp(is_bf16, out_f32, g_opt_phases != 4, p, batch, g_opt_phases == 3);

@@ -163,6 +163,21 @@ def test_gemm_bf16_speed_path(hip, variant, expect, dtype, m, n, k):
   np.testing.assert_allclose(out, ref, rtol=tol, atol=tol * np.sqrt(k))
 
 
+@pytest.mark.parametrize("dtype", [ta.bfloat16, np.float16])
+@pytest.mark.parametrize("m,n,k", [(256, 256, 128), (512, 768, 192), (1024, 768, 448), (2048, 2304, 1088)])
+def test_gemm_bf16_four_wave_variant(hip, dtype, m, n, k):
+  """A/B variant ':p6' (4 waves x 128x128 wave tiles, hand-scheduled asm MFMA / ds_read stream, 2 x 64 KiB
+  dynamic LDS): same tolerance as the default speed path, and the odd / even K-tile counts of its pipeline."""
+  out, ref, kernel, sk = _gemm_case(hip, dtype, m, n, k, 0, 1, variant="bf16_256pp:p6",
+                                    rng=np.random.default_rng(m + n + k))
+  assert kernel == "bf16_nt_256x256x64_w4"
+  tol = GEMM_TOL[dtype]
+  np.testing.assert_allclose(out, ref, rtol=tol, atol=tol * np.sqrt(k))
+  out2, _, kernel2, _ = _gemm_case(hip, dtype, m, n, k, 0, 1, variant="bf16_256pp", rng=np.random.default_rng(m + n + k))
+  assert kernel2 == "bf16_nt_256x256x64_pp"
+  np.testing.assert_array_equal(out, out2)          # same accumulation order: bit-identical
+
+
 @pytest.mark.parametrize("variant,expect", [("bf16_ragged", "bf16_nt_ragged_"), ("bf16_ragged_128x128", "bf16_nt_ragged_128x128x64"),
                                             ("bf16_ragged_64x256", "bf16_nt_ragged_64x256x64"),
                                             ("bf16_ragged_256x64", "bf16_nt_ragged_256x64x64"),
