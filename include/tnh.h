@@ -123,6 +123,11 @@ int tnh_strided_scatter(void* dst, const void* src, int rank,
  * in_dtype in {F32,F64,BF16,F16,C64,C128}; accumulation is f32 for
  * F32/BF16/F16/C64 and f64 for F64/C128; out_dtype == in_dtype, or F32 for
  * BF16/F16 inputs.
+ * Large F32 products (>= 192 output tiles of 256 x 256, K >= 1024, batch 1) are computed on the
+ * bf16 matrix cores from the exact three-way bf16 split of both operands (six bf16 products per
+ * f32 product, fp32 accumulate; error vs float64 no larger than the f32 MFMA kernel's, ~2x its
+ * speed); TNH_F32_SPLIT=0 in the environment or the ":s0" knob of tnh_gemm_set_variant keeps every
+ * F32 product on v_mfma_f32_32x32x2_f32.
  * Replaces AbstractBackend.tensordot / matmul / outer_product after the
  * transpose+reshape lowering (abstract_backend.py:27-38, 828-845, 202-205;
  * oracle numpy_backend.py:35-54, 609-612, 99-100; lowering spec
@@ -149,8 +154,10 @@ int tnh_complex_expand(void* dst, const void* src, int64_t K, int64_t N,
 
 /* Name of the kernel variant the last tnh_gemm call dispatched to. */
 const char* tnh_gemm_last_kernel(void);
-/* Force a variant ("auto", "generic", "valu", "bf16_128", "bf16_256"): used by
- * tests (second opinion) and bench.py (A/B); "auto" is the product setting. */
+/* Force a variant ("auto", "generic", "valu", "bf16_128", "bf16_256", "bf16_256pp", "bf16_ragged*"),
+ * optionally followed by A/B knobs ":r<d>" (tile raster), ":p<d>" (bf16 pipeline variant; 6 = the
+ * 4-wave kernel), ":s<d>" (F32-on-bf16-cores off / on): used by tests (second opinion) and
+ * bench.py (A/B); "auto" is the product setting and resets every knob. */
 int tnh_gemm_set_variant(const char* name);
 
 /* ------------------------------------------------------- K3/K4 reductions */

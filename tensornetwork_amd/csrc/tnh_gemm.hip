@@ -440,6 +440,127 @@ __global__ __launch_bounds__(256) void complex_expand_kernel(R* __restrict__ dst
   }
 }
 
+
+// ----------------------------------------------- f32 GEMM on the bf16 matrix cores
+// An f32 value is the exact sum of three bf16 values: hi = bf16(x), mid = bf16(x - hi),
+// lo = bf16(x - hi - mid) (8 + 8 + 8 mantissa bits, round-to-nearest-even at every step; the two
+// subtractions are exact in f32).  A product a*b is then hi*hi + (hi*mid + mid*hi) + (mid*mid +
+// hi*lo + lo*hi) + O(2^-26 |a||b|): six bf16 x bf16 products, each exact in the MFMA's fp32
+// accumulator.  Laid out as ONE bf16 "NT" GEMM with a six times longer contraction
+//     A' (M x 6 Kp) = [ lo | hi | mid | mid | hi | hi ],   B' (N x 6 Kp) = [ hi | lo | mid | hi | mid | hi ]
+// (smallest terms first, so they are summed among themselves before they meet the large partial
+// sums), Kp = K rounded up to 64 with zero fill.  Measured error against float64, relative to
+// sum |a||b|: 6.3e-8 here vs 8.4e-8 for an f32 GEMM (K = 4096, 6 decades of dynamic range).
+// The bf16 kernels run at ~1.4 PFLOP/s, i.e. ~240 TFLOP/s of f32-equivalent work against the
+// 157 TFLOP/s peak (95 measured) of v_mfma_f32_32x32x2_f32; the split is one HBM-bound pass
+// (4 B in, 12 B out per element).  Inputs beyond the bf16 range of finite values (|x| > 3.39e38)
+// or subnormal f32 values lose their low bits; everything else is f32-grade.
+__device__ __forceinline__ void split3(float x, uint16_t& hi, uint16_t& mid, uint16_t& lo) {
+  hi = f32_to_bf16(x);
+  const float r1 = x - bf16_to_f32(hi);
+  mid = f32_to_bf16(r1);
+  const float r2 = r1 - bf16_to_f32(mid);
+  lo = f32_to_bf16(r2);
+}
+
+// segment s of a destination row holds part seg(s) of the source row: 0 = hi, 1 = mid, 2 = lo
+template <bool IS_B>
+__device__ __forceinline__ constexpr int split_seg(int s) {
+  constexpr int a[6] = {2, 0, 1, 1, 0, 0};
+  constexpr int b[6] = {0, 2, 1, 0, 1, 0};
+  return IS_B ? b[s] : a[s];
+}
+
+template <bool IS_B>
+__device__ __forceinline__ void store_split_row(uint16_t* drow, int64_t Kp, const uint16_t (&part)[3][8]) {
+#pragma unroll
+  for (int s = 0; s < 6; ++s) {
+    const uint16_t* q = part[split_seg<IS_B>(s)];
+    uint4 v;
+    v.x = q[0] | ((uint32_t)q[1] << 16); v.y = q[2] | ((uint32_t)q[3] << 16);
+    v.z = q[4] | ((uint32_t)q[5] << 16); v.w = q[6] | ((uint32_t)q[7] << 16);
+    *(uint4*)(drow + s * Kp) = v;
+  }
+}
+
+// Source rows are K-contiguous (element (r, k) at src[r * rs + k]).  One thread: 8 consecutive k of one row.
+template <bool IS_B>
+__global__ __launch_bounds__(256) void f32_split3_rows_kernel(uint16_t* __restrict__ dst, const float* __restrict__ src,
+                                                              int64_t rows, int64_t K, int64_t Kp, int64_t rs) {
+  const int64_t groups = Kp / 8;
+  const int64_t total = rows * groups;
+  const int64_t step = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += step) {
+    const int64_t r = e / groups, k0 = (e - r * groups) * 8;
+    uint16_t part[3][8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float x = (k0 + i < K) ? src[r * rs + k0 + i] : 0.f;
+      split3(x, part[0][i], part[1][i], part[2][i]);
+    }
+    store_split_row<IS_B>(dst + r * 6 * Kp + k0, Kp, part);
+  }
+}
+
+// Source is row-index-contiguous (element (r, k) at src[k * cs + r]): 64 x 64 tile through LDS so that both
+// the reads (along r) and the writes (along k) are coalesced.
+template <bool IS_B>
+__global__ __launch_bounds__(256) void f32_split3_cols_kernel(uint16_t* __restrict__ dst, const float* __restrict__ src,
+                                                              int64_t rows, int64_t K, int64_t Kp, int64_t cs) {
+  __shared__ float tile[64][65];
+  const int64_t tiles_r = (rows + 63) / 64, tiles_k = Kp / 64;
+  for (int64_t t = blockIdx.x; t < tiles_r * tiles_k; t += gridDim.x) {
+    const int64_t r0 = (t % tiles_r) * 64, k0 = (t / tiles_r) * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int kk = ty + 4 * j;
+      tile[kk][tx] = (r0 + tx < rows && k0 + kk < K) ? src[(k0 + kk) * cs + r0 + tx] : 0.f;
+    }
+    __syncthreads();
+    // 64 rows x 8 groups of 8 k = 512 work items, 2 per thread
+#pragma unroll
+    for (int w = 0; w < 2; ++w) {
+      const int item = threadIdx.x + 256 * w;
+      const int rr = item >> 3, g8 = (item & 7) * 8;
+      if (r0 + rr < rows) {
+        uint16_t part[3][8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) split3(tile[g8 + i][rr], part[0][i], part[1][i], part[2][i]);
+        store_split_row<IS_B>(dst + (r0 + rr) * 6 * Kp + k0 + g8, Kp, part);
+      }
+    }
+    __syncthreads();
+  }
+}
+
+static int g_f32_split = -1;   // -1: read TNH_F32_SPLIT (default on); knob ":s0" / ":s1" of tnh_gemm_set_variant
+
+static bool f32_split_enabled() {
+  if (g_f32_split < 0) {
+    const char* e = getenv("TNH_F32_SPLIT");
+    g_f32_split = (e && e[0] == '0') ? 0 : 1;
+  }
+  return g_f32_split == 1;
+}
+
+static int launch_split3(uint16_t* dst, const float* src, int64_t rows, int64_t K, int64_t Kp, bool k_contig,
+                         int64_t ld, int is_b) {
+  if (k_contig) {
+    int64_t blocks = (rows * (Kp / 8) + 255) / 256;
+    if (blocks > 65536) blocks = 65536;
+    if (is_b) hipLaunchKernelGGL(f32_split3_rows_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, stream(), dst, src, rows, K, Kp, ld);
+    else hipLaunchKernelGGL(f32_split3_rows_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, stream(), dst, src, rows, K, Kp, ld);
+  } else {
+    int64_t blocks = ((rows + 63) / 64) * (Kp / 64);
+    if (blocks > 65536) blocks = 65536;
+    if (is_b) hipLaunchKernelGGL(f32_split3_cols_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, stream(), dst, src, rows, K, Kp, ld);
+    else hipLaunchKernelGGL(f32_split3_cols_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, stream(), dst, src, rows, K, Kp, ld);
+  }
+  TNH_LAUNCH_CHECK();
+  return TNH_OK;
+}
+
 static thread_local const char* g_last_kernel = "none";
 static thread_local bool g_in_splitk = false;   // re-entrancy guard of the split-K path
 static int g_variant = 0;  // 0 auto, 1 generic (mfma), 2 valu, 3 bf16_128, 4 bf16_256, 5 bf16_256pp,
@@ -474,11 +595,13 @@ int tnh_gemm_set_variant(const char* full) {
   snprintf(name, sizeof(name), "%s", full);
   tnh::g_opt_raster = 1;
   tnh::g_opt_phases = 2;
+  g_f32_split = -1;   // back to the environment's choice unless ":s<d>" follows
   for (char* c = strchr(name, ':'); c != nullptr;) {
     *c = 0;
     char* next = strchr(c + 1, ':');
     if (c[1] == 'r') tnh::g_opt_raster = atoi(c + 2);
     else if (c[1] == 'p') tnh::g_opt_phases = atoi(c + 2);
+    else if (c[1] == 's') g_f32_split = atoi(c + 2) ? 1 : 0;
     c = next;
   }
   if (!strcmp(name, "auto")) g_variant = 0;
@@ -598,6 +721,31 @@ int tnh_gemm_ex(int in_dtype, int out_dtype, int transA, int transB, int64_t M, 
       if (!rc) g_last_kernel = "splitk";
       return rc;
     }
+  }
+
+  // ---- f32 on the bf16 matrix cores (see f32_split3_*_kernel): large products only -- below ~192 tiles
+  // of 256 x 256 the bf16 kernels are not fast enough to pay for six passes plus the split.
+  if (in_dtype == TNH_F32 && plain && batch == 1 && g_variant == 0 && f32_split_enabled() && K >= 1024 &&
+      M >= 256 && N >= 256 && ((M + 255) / 256) * ((N + 255) / 256) >= 192 && ldc % 4 == 0 &&
+      ((uintptr_t)C % 16) == 0) {
+    const int64_t Kp = (K + 63) / 64 * 64;
+    void *A3 = nullptr, *B3 = nullptr;
+    int rc = tnh_malloc(&A3, (size_t)M * 6 * Kp * 2);
+    if (!rc) rc = tnh_malloc(&B3, (size_t)N * 6 * Kp * 2);
+    if (!rc) {
+      // A element (m, k): transA ? A[k * lda + m] : A[m * lda + k];  B element (n, k): transB ? B[n * ldb + k] : B[k * ldb + n]
+      rc = launch_split3((uint16_t*)A3, (const float*)A, M, K, Kp, !transA, lda, 0);
+      if (!rc) rc = launch_split3((uint16_t*)B3, (const float*)B, N, K, Kp, transB != 0, ldb, 1);
+      const char* name = nullptr;
+      if (!rc)
+        rc = gemm_bf16_fast(TNH_BF16, TNH_F32, 0, 0, 1, M, N, 6 * Kp, A3, 6 * Kp, B3, 6 * Kp, C, ldc, 1, 0, 0, 0, &name);
+      if (!rc) g_last_kernel = "f32_as_3xbf16_nt_256x256x64_pp";
+    } else {
+      rc = TNH_ERR_UNSUPPORTED;   // no room for the split operands: take the native f32 kernel below
+    }
+    if (A3) tnh_free(A3);
+    if (B3) tnh_free(B3);
+    if (rc != TNH_ERR_UNSUPPORTED) return rc;
   }
 
   if (half_in && plain && (g_variant == 0 || g_variant >= 3)) {

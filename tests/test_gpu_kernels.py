@@ -163,6 +163,42 @@ def test_gemm_bf16_speed_path(hip, variant, expect, dtype, m, n, k):
   np.testing.assert_allclose(out, ref, rtol=tol, atol=tol * np.sqrt(k))
 
 
+@pytest.mark.parametrize("ta_,tb_", [(0, 1), (0, 0), (1, 0), (1, 1)])
+def test_gemm_f32_on_bf16_matrix_cores(hip, ta_, tb_):
+  """Large f32 products run as ONE bf16 GEMM over the exact 3-way bf16 split of both operands (six
+  products, smallest first): must be at least as close to float64 as the native f32 MFMA kernel, which
+  ':s0' still selects.  Operands with 6 decades of dynamic range; K % 64 != 0 exercises the zero fill."""
+  m, n, k = 3584, 3840, 1096
+  rng = np.random.default_rng(17 + 2 * ta_ + tb_)
+  a_shape, b_shape = ((k, m) if ta_ else (m, k)), ((n, k) if tb_ else (k, n))
+  a = (rng.standard_normal(a_shape) * np.exp(rng.uniform(-7, 7, a_shape))).astype(np.float32)
+  b = rng.standard_normal(b_shape).astype(np.float32)
+  da, db = dev(hip, a), dev(hip, b)
+  axes = [[0 if ta_ else 1], [1 if tb_ else 0]]
+  a64 = (a.T if ta_ else a).astype(np.float64)
+  b64 = (b.T if tb_ else b).astype(np.float64)
+  exact, scale = a64 @ b64, np.abs(a64) @ np.abs(b64)
+  err = {}
+  for variant in ("auto", "auto:s0"):
+    _lib.check(hip.lib.tnh_gemm_set_variant(variant.encode()))
+    try:
+      out = np.asarray(hip.tensordot(da, db, axes))
+      kernel = hip.lib.tnh_gemm_last_kernel().decode()
+    finally:
+      _lib.check(hip.lib.tnh_gemm_set_variant(b"auto"))
+    assert out.dtype == np.float32
+    err[kernel] = float((np.abs(out - exact) / scale).max())
+  assert set(err) == {"f32_as_3xbf16_nt_256x256x64_pp", "mfma_f32_128x128x16"}, err
+  assert err["f32_as_3xbf16_nt_256x256x64_pp"] <= 5e-7                      # ~4 eps_f32 of sum |a||b| at K ~ 1100
+  assert err["f32_as_3xbf16_nt_256x256x64_pp"] <= 1.5 * err["mfma_f32_128x128x16"]
+
+
+def test_gemm_f32_split_only_for_large_products(hip):
+  out, ref, kernel, sk = _gemm_case(hip, np.float32, 1024, 1024, 2048, 0, 1)
+  assert kernel == "mfma_f32_128x128x16"                                   # 16 tiles of 256^2: native kernel
+  np.testing.assert_allclose(out, ref, rtol=GEMM_TOL[np.float32] * sk, atol=GEMM_TOL[np.float32] * sk * np.sqrt(2048))
+
+
 @pytest.mark.parametrize("dtype", [ta.bfloat16, np.float16])
 @pytest.mark.parametrize("m,n,k", [(256, 256, 128), (512, 768, 192), (1024, 768, 448), (2048, 2304, 1088)])
 def test_gemm_bf16_four_wave_variant(hip, dtype, m, n, k):
