@@ -72,6 +72,10 @@ int tnh_malloc(void** ptr, size_t nbytes);
 int tnh_free(void* ptr);
 int tnh_trim(void);
 int tnh_mem_stats(int64_t* in_use, int64_t* cached, int64_t* peak);
+/* *has = 1 if tnh_malloc(nbytes) would be served from the pool right now (no hipMalloc).  The host
+ * layer uses it to let its garbage collector return dead tensors' blocks before a large request
+ * would otherwise go to the driver. */
+int tnh_pool_has(size_t nbytes, int* has);
 
 int tnh_h2d(void* dst, const void* host_src, size_t nbytes);
 int tnh_d2h(void* host_dst, const void* src, size_t nbytes); /* blocking */

@@ -43,6 +43,7 @@ SIGNATURES = {
     "tnh_free": (c_int, [c_void_p]),
     "tnh_trim": (c_int, []),
     "tnh_mem_stats": (c_int, [_I64P, _I64P, _I64P]),
+    "tnh_pool_has": (c_int, [ctypes.c_size_t, ctypes.POINTER(c_int)]),
     "tnh_h2d": (c_int, [c_void_p, c_void_p, c_size_t]),
     "tnh_d2h": (c_int, [c_void_p, c_void_p, c_size_t]),
     "tnh_d2d": (c_int, [c_void_p, c_void_p, c_size_t]),

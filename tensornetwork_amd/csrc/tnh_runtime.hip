@@ -219,6 +219,16 @@ int tnh_mem_stats(int64_t* in_use, int64_t* cached, int64_t* peak) {
   return TNH_OK;
 }
 
+int tnh_pool_has(size_t nbytes, int* has) {
+  TNH_REQUIRE(has != nullptr, "has is null");
+  const size_t sz = Pool::round(nbytes);
+  std::lock_guard<std::mutex> lk(g_pool.mu);
+  Arena* ar = g_pool.capturing;
+  *has = ((ar != nullptr && ar->free_blocks.find(sz) != ar->free_blocks.end()) ||
+          g_pool.free_blocks.find(sz) != g_pool.free_blocks.end()) ? 1 : 0;
+  return TNH_OK;
+}
+
 int tnh_h2d(void* dst, const void* host_src, size_t nbytes) {
   TNH_NEED_INIT();
   if (nbytes == 0) return TNH_OK;

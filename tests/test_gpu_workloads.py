@@ -330,3 +330,33 @@ def test_json_network_from_reference_into_hbm(hip):
   back, _ = network.nodes_from_json(text, backend=orc.OracleBackend())
   for a, b in zip(back, network.nodes_from_json(fx["network"], backend=orc.OracleBackend())[0]):
     np.testing.assert_array_equal(a.tensor, b.tensor)      # serialisation is bit-exact
+
+
+def test_large_blocks_of_dead_nodes_return_to_the_pool(hip):
+  """A Node and its Edges are a reference cycle: `del node` alone does not free the tensor.  A large
+  request that the pool cannot serve collects Python's young generations first (device_tensor._Block), so
+  a contract-and-drop loop reuses ONE block instead of growing by a hipMalloc per step."""
+  import ctypes
+  import gc
+  from tensornetwork_amd import _lib
+
+  def footprint():
+    in_use, cached, peak = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
+    _lib.check(hip.lib.tnh_mem_stats(ctypes.byref(in_use), ctypes.byref(cached), ctypes.byref(peak)))
+    return in_use.value + cached.value
+
+  gc.collect()
+  gc.disable()                     # only the allocator's own collection may run
+  try:
+    sizes = []
+    for step in range(5):
+      node = ta.Node(hip.zeros((24 << 20,), dtype=np.float32), backend=hip)   # 96 MiB, unique size
+      assert node[0].node1 is node
+      del node
+      sizes.append(footprint())
+    assert sizes[-1] - sizes[1] == 0, sizes     # step 0 may allocate; afterwards the same block is reused
+    has = ctypes.c_int(-1)
+    _lib.check(hip.lib.tnh_pool_has(1 << 40, ctypes.byref(has)))
+    assert has.value == 0
+  finally:
+    gc.enable()
