@@ -84,26 +84,51 @@ def round_to_bf16(x):
   return bf16_bits_to_f32(f32_to_bf16_bits(np.asarray(x, dtype=np.float32)))
 
 
+# ---- HBM vs Python's cyclic collector -------------------------------------------------------------
+# A Node and its Edges reference each other (as in the reference library), so `del node` returns the
+# tensor's block to the pool only when the cyclic collector runs -- and that collector counts Python
+# objects, not HBM bytes: a dead 8.6 GB result can sit there while the next, equally large request
+# misses the pool and goes to hipMalloc (28 ms per GiB; measured +240 ms on a 380 ms contraction, and the
+# pool grows by one result per step).  Young-generation collections do not help: the first one promotes
+# the live operand nodes, whose edges the result then adopts, and an old object pointing into a young
+# cycle keeps it alive until a FULL collection.  So: a large request that the pool cannot serve runs a
+# full collection first.  To keep that cheap, the objects that exist when the backend initialises
+# (modules, classes: 40k-190k of them, 6-26 ms per full pass) are moved to the collector's permanent
+# generation once (`gc.freeze()`); later passes only walk what was created since (~0.1 ms for a few
+# thousand objects).  TNH_GC_FREEZE=0 leaves the collector untouched; full collections are then only
+# spent on requests of at least 1 GiB, where they are cheaper than the hipMalloc they avoid.
+_GC_FROZEN = False
+
+
+def freeze_collector_baseline():
+  """Called once when the backend initialises (see above)."""
+  global _GC_FROZEN  # pylint: disable=global-statement
+  import gc  # pylint: disable=import-outside-toplevel
+  import os  # pylint: disable=import-outside-toplevel
+  if _GC_FROZEN or os.environ.get("TNH_GC_FREEZE", "1") == "0":
+    return
+  gc.collect()
+  gc.freeze()
+  _GC_FROZEN = True
+
+
+def _gc_before_bytes():
+  return (64 << 20) if _GC_FROZEN else (1 << 30)
+
+
 class _Block:
   """One allocation from libtnhip's pool; freed when the last tensor drops it."""
   __slots__ = ("ptr", "nbytes")
 
-  # A Node and its Edges reference each other, so `del node` returns the tensor's block to the pool only
-  # at the next cyclic collection; until then an equally large request misses the pool and goes to
-  # hipMalloc (~25 ms for 8 GiB -- seen as +50 ms per step on a 380 ms contraction whenever the
-  # collector's own schedule happened to lag).  So a large request the pool cannot serve first lets
-  # Python collect its two young generations (~0.1 ms with a few thousand young objects).
-  GC_BEFORE_BYTES = 64 << 20
-
   def __init__(self, nbytes):
     lib = _lib.lib()
     p = ctypes.c_void_p()
-    if int(nbytes) >= _Block.GC_BEFORE_BYTES:
+    if int(nbytes) >= _gc_before_bytes():
       has = ctypes.c_int(1)
       lib.tnh_pool_has(int(nbytes), ctypes.byref(has))
       if not has.value:
         import gc  # pylint: disable=import-outside-toplevel
-        gc.collect(1)
+        gc.collect()
     status = lib.tnh_malloc(ctypes.byref(p), max(int(nbytes), 1))
     if status == _lib.ERR_NOMEM:
       # Node <-> Edge graphs are reference cycles: tensors of consumed nodes are released only by the

@@ -15,6 +15,7 @@ import numpy as np
 
 from tensornetwork_amd import _lib
 from tensornetwork_amd.abstract import BackendBase, HAVE_TENSORNETWORK
+from tensornetwork_amd import device_tensor
 from tensornetwork_amd.device_tensor import (DeviceTensor, bfloat16, public_dtype,
                                              tnh_dtype)
 
@@ -81,6 +82,7 @@ class HipBackend(BackendBase):
   def lib(self):
     if self._lib is None:
       self._lib = _lib.init(self._device)
+      device_tensor.freeze_collector_baseline()
     return self._lib
 
   def synchronize(self):
