@@ -26,7 +26,7 @@ Extra objects on the same line:
                     nodes at D = 32 .. 256 in the favourable (L0) and the permute-needing (L1) layout,
                     plus the north-star "D = 512" row A(64,128,512,512) . B(512,512,128,64)
                     (GEMM 8192 x 8192 x 262144), whole-path TFLOP/s each.
-  dtype_sweep    -- the same contraction at D = 64 (GEMM 4096^3) in f32 / f64 / complex64 / complex128, the
+  dtype_sweep    -- the same contraction (backend.tensordot) at D = 64 (GEMM 4096^3) in f32 / f64 / complex64 / complex128, the
                     dtypes of the reference's own tests (f32 runs on the bf16 cores via the exact 3 x bf16 split).
   mera           -- configs[4] shape on one GPU: binary-MERA layer energy at chi = 32 (68.7 GB intermediate).
   sliced_network -- the north-star scaling network (64-node random 3-regular graph, bond
@@ -270,20 +270,21 @@ def bond_sweep(ta, be):
 
 
 def dtype_sweep(ta, be, D=64):
-  """The same contract_between (two rank-4 nodes, layout L0, GEMM D^2 cubed) in the dtypes the reference's
-  own tests use: f32 (large products run on the bf16 matrix cores from the exact 3 x bf16 split), f64,
-  complex64 / complex128 (real-expansion GEMM).  TFLOP/s counts real flops: 2 MNK, 8 MNK for complex."""
+  """backend.tensordot(a, b, [[2, 3], [0, 1]]) -- the call contract_between makes for layout L0 -- on two
+  rank-4 tensors (GEMM D^2 cubed) in the dtypes the reference's own tests use: f32 (large products run on
+  the bf16 matrix cores from the exact 3 x bf16 split), f64, complex64 / complex128 (real-expansion GEMM).
+  TFLOP/s counts real flops: 2 MNK, 8 MNK for complex."""
   rows = []
   for name, dt, mult in (("f32", np.float32, 2.0), ("f64", np.float64, 2.0), ("complex64", np.complex64, 8.0),
                          ("complex128", np.complex128, 8.0)):
     A = be.device_random((D,) * 4, dtype=dt, seed=21, normal=True, b=1.0 / D)
     B = be.device_random((D,) * 4, dtype=dt, seed=22, normal=True, b=1.0 / D)
-    one_step(ta, be, A, B, "L0")
+    be.tensordot(A, B, [[2, 3], [0, 1]])
     be.synchronize()
-    reps = 3
+    reps = 5
     t0 = time.perf_counter()
     for _ in range(reps):
-      out = one_step(ta, be, A, B, "L0")
+      out = be.tensordot(A, B, [[2, 3], [0, 1]])
       del out
     be.synchronize()
     t = (time.perf_counter() - t0) / reps

@@ -95,9 +95,16 @@ def round_to_bf16(x):
 # full collection first.  To keep that cheap, the objects that exist when the backend initialises
 # (modules, classes: 40k-190k of them, 6-26 ms per full pass) are moved to the collector's permanent
 # generation once (`gc.freeze()`); later passes only walk what was created since (~0.1 ms for a few
-# thousand objects).  TNH_GC_FREEZE=0 leaves the collector untouched; full collections are then only
-# spent on requests of at least 1 GiB, where they are cheaper than the hipMalloc they avoid.
+# thousand objects).  A pass is only spent where it is cheaper than the hipMalloc it can avoid: its
+# duration is measured every time and compared with 28 ms/GiB x the request (an application that keeps
+# 400k live objects of its own pays 8 ms per pass -- fine in front of an 8 GiB request, not in front of
+# a 64 MiB one); a skipped opportunity decays the estimate so that it is re-measured eventually.
+# TNH_GC_FREEZE=0 leaves the collector untouched (the first estimate is then 30 ms, i.e. requests
+# of about 1 GiB and more).
 _GC_FROZEN = False
+_GC_MIN_BYTES = 64 << 20
+_MALLOC_SECONDS_PER_BYTE = 28e-3 / (1 << 30)
+_gc_cost_seconds = 30e-3
 
 
 def freeze_collector_baseline():
@@ -107,13 +114,31 @@ def freeze_collector_baseline():
   import os  # pylint: disable=import-outside-toplevel
   if _GC_FROZEN or os.environ.get("TNH_GC_FREEZE", "1") == "0":
     return
+  global _gc_cost_seconds  # pylint: disable=global-statement
   gc.collect()
   gc.freeze()
   _GC_FROZEN = True
+  _gc_cost_seconds = 0.0
 
 
-def _gc_before_bytes():
-  return (64 << 20) if _GC_FROZEN else (1 << 30)
+def _worth_collecting(nbytes):
+  """Policy above: is a full collection expected to cost less than a hipMalloc of `nbytes`?"""
+  global _gc_cost_seconds  # pylint: disable=global-statement
+  if nbytes < _GC_MIN_BYTES:
+    return False
+  if nbytes * _MALLOC_SECONDS_PER_BYTE >= _gc_cost_seconds:
+    return True
+  _gc_cost_seconds *= 0.95
+  return False
+
+
+def _collect_and_time():
+  global _gc_cost_seconds  # pylint: disable=global-statement
+  import gc  # pylint: disable=import-outside-toplevel
+  import time  # pylint: disable=import-outside-toplevel
+  t0 = time.perf_counter()
+  gc.collect()
+  _gc_cost_seconds = time.perf_counter() - t0
 
 
 class _Block:
@@ -123,12 +148,11 @@ class _Block:
   def __init__(self, nbytes):
     lib = _lib.lib()
     p = ctypes.c_void_p()
-    if int(nbytes) >= _gc_before_bytes():
+    if int(nbytes) >= _GC_MIN_BYTES:
       has = ctypes.c_int(1)
       lib.tnh_pool_has(int(nbytes), ctypes.byref(has))
-      if not has.value:
-        import gc  # pylint: disable=import-outside-toplevel
-        gc.collect()
+      if not has.value and _worth_collecting(int(nbytes)):
+        _collect_and_time()
     status = lib.tnh_malloc(ctypes.byref(p), max(int(nbytes), 1))
     if status == _lib.ERR_NOMEM:
       # Node <-> Edge graphs are reference cycles: tensors of consumed nodes are released only by the

@@ -215,3 +215,21 @@ def test_graph_surgery_reference_cases():
   (the GPU suite runs the same checker on HipBackend)."""
   import cases
   cases.check_graph_surgery(OracleBackend(), 1e-12)
+
+
+def test_collector_policy_before_large_allocations():
+  """device_tensor: a full collection in front of a pool miss only where it is cheaper than the hipMalloc."""
+  from tensornetwork_amd import device_tensor as dt
+  saved = dt._gc_cost_seconds
+  try:
+    dt._gc_cost_seconds = 8e-3                       # an application with a large live heap
+    assert not dt._worth_collecting(32 << 20)        # below the floor: never
+    assert not dt._worth_collecting(67 << 20)        # hipMalloc ~1.8 ms < 8 ms
+    assert dt._gc_cost_seconds < 8e-3                # skipped opportunities decay the estimate
+    assert dt._worth_collecting(8 << 30)             # ~224 ms of hipMalloc
+    dt._gc_cost_seconds = 0.0                        # frozen baseline, small heap
+    assert dt._worth_collecting(64 << 20)
+    dt._collect_and_time()
+    assert 0.0 < dt._gc_cost_seconds < 5.0
+  finally:
+    dt._gc_cost_seconds = saved
