@@ -15,7 +15,7 @@ from tensornetwork_amd.device_tensor import DeviceTensor, bfloat16, round_to_bf1
 from tensornetwork_amd.hip_backend import (HipBackend, get_hip_backend,
                                            register_with_tensornetwork)
 from tensornetwork_amd.ncon import ncon, einsum
-from tensornetwork_amd.network import (Node, Edge, connect, contract, contract_between,
+from tensornetwork_amd.network import (Node, Edge, CopyNode, contract_copy_node, connect, contract, contract_between,
                                        contract_parallel, contract_trace_edges, outer_product,
                                        split_node, split_node_full_svd, split_node_qr, split_node_rq, copy,
                                        slice_edge,
@@ -27,6 +27,8 @@ from tensornetwork_amd.network import (Node, Edge, connect, contract, contract_b
                                        flatten_edges_between, flatten_all_edges, split_edge,
                                        replicate_nodes, reduced_density, from_topology, switch_backend)
 from tensornetwork_amd import contractors, pathfinder
+from tensornetwork_amd.tensor import Tensor, NconBuilder, finalize
+from tensornetwork_amd import linalg
 from tensornetwork_amd.mps import FiniteMPS, InfiniteMPS, FiniteDMRG
 from tensornetwork_amd.mpo import (BaseMPO, FiniteMPO, InfiniteMPO, FiniteXXZ, FiniteTFI,
                                    FiniteFreeFermion2D)

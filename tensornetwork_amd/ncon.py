@@ -103,6 +103,22 @@ class _Engine:
     self.ops[idx] = (self.be.trace(t), [labels[i] for i in free])
     return rep
 
+  def diag_repeated(self, idx) -> List[Any]:
+    """A label that repeats on operand `idx` AND lives on (an output or another operand) is a
+    hyper-index: keep one copy of it by taking the diagonal of the repeated axes (np.einsum "ii,i->")."""
+    done = []
+    while True:
+      tensor, labels = self.ops[idx]
+      rep = [l for l in labels if labels.count(l) >= 2 and (l in self.keep or self.count(l) > labels.count(l))]
+      if not rep:
+        return done
+      lab = rep[0]
+      p = labels.index(lab)
+      q = labels.index(lab, p + 1)
+      rest = [l for i, l in enumerate(labels) if i not in (p, q)]
+      self.ops[idx] = (self.be.diagonal(tensor, offset=0, axis1=p, axis2=q), rest + [lab])   # diagonal axis goes last
+      done.append(lab)
+
   def sum_dangling(self, idx) -> List[Any]:
     """Sum out contractible labels that live on this operand only (once)."""
     tensor, labels = self.ops[idx]
@@ -250,6 +266,7 @@ def einsum(expression: str, *tensors, backend=None):
       raise ValueError(f"einsum subscripts '{term}' do not match operand rank")
   eng = _Engine(be, tensors, [list(t) for t in terms], keep=list(rhs))
   for idx in range(len(eng.ops)):
+    eng.diag_repeated(idx)
     eng.trace_repeated(idx)
   for idx in range(len(eng.ops)):
     eng.sum_dangling(idx)

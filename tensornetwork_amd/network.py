@@ -162,8 +162,117 @@ class Node:
   def __matmul__(self, other: "Node") -> "Node":
     return contract_between(self, other)
 
+  # Elementwise arithmetic with a scalar or another Node (network_components.py:586-631): the result is a
+  # new, unconnected Node carrying this node's name.
+  def _operand(self, other):
+    if isinstance(other, CopyNode) or isinstance(self, CopyNode):
+      raise NotImplementedError("CopyNode does not implement elementwise arithmetic")
+    if not isinstance(other, (int, float, complex, Node)):
+      raise TypeError("Operand should be one of int, float, Node type")
+    if isinstance(other, Node):
+      if self.backend.name != other.backend.name:
+        raise TypeError("Operands backend must match.\noperand 1 backend: {}\noperand 2 backend: {}"
+                        .format(self.backend.name, other.backend.name))
+      return other.tensor
+    return other
+
+  def __add__(self, other):
+    return Node(self.backend.addition(self.tensor, self._operand(other)), name=self.name, backend=self.backend)
+
+  def __sub__(self, other):
+    return Node(self.backend.subtraction(self.tensor, self._operand(other)), name=self.name, backend=self.backend)
+
+  def __mul__(self, other):
+    return Node(self.backend.multiply(self.tensor, self._operand(other)), name=self.name, backend=self.backend)
+
+  def __truediv__(self, other):
+    return Node(self.backend.divide(self.tensor, self._operand(other)), name=self.name, backend=self.backend)
+
+  def get_tensor(self):
+    return self.tensor
+
+  def set_tensor(self, tensor) -> None:
+    self.tensor = tensor
+
   def __repr__(self):
     return f"Node(name={self.name!r}, shape={self.shape}, backend={self.backend.name!r})"
+
+
+class CopyNode(Node):
+  """The rank-`rank` "copy" (generalised delta) tensor of leg dimension `dimension`: 1 where all indices
+  agree, else 0 (network_components.py:737-935).  The dense tensor is only built if somebody asks for
+  `.tensor`; `contract_copy_node` contracts it with ALL its neighbours as one hyper-index einsum instead."""
+
+  def __init__(self, rank: int, dimension: int, name: Optional[str] = None,
+               axis_names: Optional[List[str]] = None, backend=None, dtype=np.float64):
+    # pylint: disable=super-init-not-called
+    self.backend = _resolve_backend(backend)
+    self.rank, self.dimension, self.copy_node_dtype = rank, dimension, dtype
+    self._dense = None
+    self.name = name if name is not None else "__unnamed_node__"
+    if axis_names is not None and len(axis_names) != rank:
+      raise ValueError("axis_names is not the same length as the tensor shape."
+                       f"axis_names length: {len(axis_names)}, shape length: {rank}")
+    self.axis_names = list(axis_names) if axis_names is not None else [str(i) for i in range(rank)]
+    self.edges = [Edge(self, i, name=self.axis_names[i]) for i in range(rank)]
+
+  @staticmethod
+  def make_copy_tensor(rank: int, dimension: int, dtype) -> np.ndarray:
+    out = np.zeros((dimension,) * rank, dtype=dtype)
+    idx = np.arange(dimension)
+    out[(idx,) * rank] = 1
+    return out
+
+  @property
+  def tensor(self):
+    if self._dense is None:
+      self._dense = self.backend.convert_to_tensor(
+          self.make_copy_tensor(self.rank, self.dimension, self.copy_node_dtype))
+    return self._dense
+
+  @tensor.setter
+  def tensor(self, value):
+    self._dense = value
+
+  @property
+  def shape(self) -> Tuple[int, ...]:
+    return (self.dimension,) * self.rank
+
+  @property
+  def dtype(self):
+    return self.copy_node_dtype        # without building the dense tensor
+
+  def get_partners(self) -> Dict[Node, Set[int]]:
+    """{neighbour: axes of the neighbour that connect to this copy node} (trace edges of the copy
+    node itself are skipped; a dangling leg is an error)."""
+    partners: Dict[Node, Set[int]] = {}
+    for e in self.edges:
+      if e.is_dangling():
+        raise ValueError('Cannot contract copy tensor with dangling edges')
+      if e.node1 is self and e.node2 is self:
+        continue
+      other, axis = (e.node2, e.axis2) if e.node1 is self else (e.node1, e.axis1)
+      partners.setdefault(other, set()).add(axis)
+    return partners
+
+  def compute_contracted_tensor(self):
+    """einsum of all neighbours with ONE shared index in place of the copy tensor; free axes in
+    neighbour order (network_components.py:875-909)."""
+    from tensornetwork_amd.ncon import einsum as _einsum  # pylint: disable=import-outside-toplevel
+    letters = 'abcdefghijklmnopqrstuvwxyzABCDEFGHIJKLMNOPQRSTUVWXYZ'
+    partners = self.get_partners()
+    nxt, terms = 1, []
+    for node, shared in partners.items():
+      term = ""
+      for axis in range(node.get_rank()):
+        if axis in shared:
+          term += letters[0]
+        else:
+          term += letters[nxt]
+          nxt += 1
+      terms.append(term)
+    expr = ",".join(terms) + "->" + letters[1:nxt]
+    return _einsum(expr, *[n.tensor for n in partners], backend=self.backend)
 
 
 # ---------------------------------------------------------------------- wiring
@@ -361,6 +470,24 @@ def contract_between(node1: Node, node2: Node, name: Optional[str] = None,
     if len(axis_names) != len(out.edges):
       raise ValueError("axis_names does not match the rank of the result")
     out.axis_names = list(axis_names)
+  return out
+
+
+def contract_copy_node(copy_node: CopyNode, name: Optional[str] = None) -> Node:
+  """Contract a copy node with all of its neighbours at once (network_components.py:1888-1920): the
+  result has the neighbours' remaining axes, neighbour by neighbour; edges between two neighbours survive
+  (as trace edges of the result)."""
+  partners = copy_node.get_partners()
+  out = Node(copy_node.compute_contracted_tensor(), name=name, backend=copy_node.backend)
+  sources = []
+  for partner in partners:
+    for axis, e in enumerate(partner.edges):
+      if e.node1 is copy_node or e.node2 is copy_node:
+        continue
+      sources.append((partner, axis))
+  assert len(sources) == len(out.edges)
+  _adopt_edges(out, sources)
+  copy_node.edges = [Edge(copy_node, i, name=copy_node.axis_names[i]) for i in range(copy_node.rank)]
   return out
 
 

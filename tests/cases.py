@@ -471,6 +471,40 @@ def check_graph_surgery(be, rtol):
   with pytest.raises(ValueError, match="does not match shape"):
     tn.from_topology("abc", [np.ones((2, 2))], backend=be)
 
+  # CopyNode / contract_copy_node (tensornetwork_test.py:592-660) and Node arithmetic (network_components.py:586-631)
+  a, b, c, d = N([1, 2, 3]), N([10, 20, 30]), N([5, 6, 7]), N([1, -1, 1])
+  cn = tn.CopyNode(rank=4, dimension=3, backend=be)
+  assert cn.shape == (3, 3, 3, 3) and cn.dtype == np.float64 and cn._dense is None
+  es = [tn.connect(x[0], cn[i]) for i, x in enumerate((a, b, c, d))]
+  assert set(cn.get_partners()) == {a, b, c, d}
+  np.testing.assert_allclose(np.asarray(cn.compute_contracted_tensor()), 50 - 240 + 630, rtol=rtol)
+  assert cn._dense is None                                   # never materialised by the einsum route
+  for e in es:
+    val = tn.contract(e)                                     # the dense route: one edge at a time
+  np.testing.assert_allclose(host(val), 50 - 240 + 630, rtol=rtol)
+  np.testing.assert_array_equal(tn.CopyNode.make_copy_tensor(3, 2, np.float32), np.einsum("ij,jk->ijk", np.eye(2), np.eye(2)))
+  a, b, cn = N(np.diag([1.0, 2, 3])), N([10, 20, 30]), tn.CopyNode(rank=3, dimension=3, backend=be)
+  tn.connect(a[0], cn[0]); tn.connect(a[1], cn[1]); tn.connect(b[0], cn[2])
+  np.testing.assert_allclose(np.asarray(cn.compute_contracted_tensor()), 10 + 40 + 90, rtol=rtol)
+  a, b, c = N([[1, 2, 3], [10, 20, 30]]), N([[2, 1, 1], [2, 2, 2]]), N([3, 4, 4])
+  cn = tn.CopyNode(rank=3, dimension=3, backend=be)
+  tn.connect(a[0], b[0]); tn.connect(a[1], cn[0]); tn.connect(b[1], cn[1]); tn.connect(c[0], cn[2])
+  n = tn.contract_copy_node(cn)
+  assert len(n.edges) == 2 and n.edges[0] is n.edges[1] and all(e.is_dangling() for e in cn.edges)
+  np.testing.assert_allclose(host(tn.contract_parallel(n.edges[0])), 26 + 460, rtol=rtol)
+  with pytest.raises(ValueError, match="dangling edges"):
+    tn.CopyNode(rank=2, dimension=2, backend=be).compute_contracted_tensor()
+  x = N(rng.standard_normal((2, 3)), name="x")
+  xh = host(x)
+  y = (x * 3 + x - 1) / 2
+  np.testing.assert_allclose(host(y), (xh * 3 + xh - 1) / 2, rtol=rtol)
+  np.testing.assert_allclose(host(x * x - x / (x * x + 1)), xh * xh - xh / (xh * xh + 1), rtol=rtol)
+  assert y.name == "x" and all(e.is_dangling() for e in y.edges) and y is not x
+  with pytest.raises(TypeError, match="Operand should be one of"):
+    x + "1"  # pylint: disable=pointless-statement
+  with pytest.raises(NotImplementedError):
+    cn + 1  # pylint: disable=pointless-statement
+
 
 INFINITE_MPS_GOLDEN_TAGS = ("inf_f64", "inf_c128")
 
@@ -502,3 +536,92 @@ def check_infinite_mps_golden_case(be, g, tag, rtol):
   assert imps.center_position == n - 1 and imps.tensors[0].dtype == dtype
   assert imps.check_canonical() < 1e-10
   assert imps.check_orthonormality("l", n - 1) < 1e-8   # last tensor x connector is a left isometry too
+
+
+# ------------------------------------------------------------------ Tensor / functional API
+def check_tensor_api(be, rtol):
+  """`Tensor` operators and the functional API (tensor.py, linalg/operations.py, linalg/linalg.py,
+  linalg/initialization.py, linalg/krylov.py of the reference; its tests: tensor_test.py,
+  linalg/tests/*_test.py) on backend `be`, values against NumPy."""
+  import pytest
+  from tensornetwork_amd import tensor as tt, linalg as tl
+  rng = np.random.default_rng(123)
+  H = lambda t: np.asarray(t.array)
+  close = lambda got, want: np.testing.assert_allclose(got, want, rtol=rtol, atol=rtol)
+  xa, xb = rng.standard_normal((3, 4, 5)), rng.standard_normal((5, 4, 2))
+  a, b = tt.Tensor(xa, backend=be), tt.Tensor(xb, backend=be)
+  assert a.shape == (3, 4, 5) and a.ndim == 3 and a.size == 60 and a.dtype == np.float64 and a.backend is be
+  close(H(tl.tensordot(a, b, [[2, 1], [0, 1]])), np.tensordot(xa, xb, [[2, 1], [0, 1]]))
+  close(H(a.T), xa.T); close(H(a.transpose((1, 0, 2))), xa.transpose(1, 0, 2))
+  close(H(a.reshape((12, 5))), xa.reshape(12, 5)); close(H(a.ravel()), xa.ravel()); close(H(a.flatten()), xa.ravel())
+  assert tt.Tensor(np.ones((1, 3, 1)), backend=be).squeeze().shape == (3,)
+  close(H(a * 2.0 + 1.0 - a / 4.0), xa * 2 + 1 - xa / 4); close(H(3.0 - a), 3 - xa); close(H(2.0 * a), 2 * xa)
+  close(H(a + a), 2 * xa); close(H(a - a), 0 * xa); close(H(a * a), xa * xa); close(H(a / (a * a + 1.0)), xa / (xa * xa + 1))
+  m1, m2 = rng.standard_normal((4, 6)), rng.standard_normal((6, 3))
+  close(H(tt.Tensor(m1, backend=be) @ tt.Tensor(m2, backend=be)), m1 @ m2)
+  z = rng.standard_normal((3, 4)) + 1j * rng.standard_normal((3, 4))
+  zt = tt.Tensor(z, backend=be)
+  close(H(zt.conj()), z.conj()); close(H(zt.H), z.conj().T); close(H(zt.hconj()), z.conj().T)
+  close(H(tl.hconj(zt, (0, 1))), z.conj()); close(H(tl.conj(zt)), z.conj())
+  c = a.copy()
+  assert c.array is not a.array
+  close(H(c), xa)
+  # ncon builder syntax: A(labels) @ B(labels)
+  close(H(tt.finalize(a(-1, 1, 2) @ b(2, 1, -2))), np.einsum("abc,cbd->ad", xa, xb))
+  close(H(tl.einsum("abc,cbd->ad", a, b, optimize=True)), np.einsum("abc,cbd->ad", xa, xb))
+  # operations
+  assert tl.shape(a) == (3, 4, 5)
+  close(H(tl.reshape(a, (3, 20))), xa.reshape(3, 20)); close(H(tl.transpose(a)), xa.T)
+  close(H(tl.take_slice(a, (1, 0, 2), (2, 3, 2))), xa[1:3, 0:3, 2:4])
+  close(H(tl.outer(tt.Tensor(m1, backend=be), tt.Tensor(m2, backend=be))), np.multiply.outer(m1, m2))
+  pos = np.abs(xa) + 0.5
+  p = tt.Tensor(pos, backend=be)
+  for fn, ref in ((tl.sqrt, np.sqrt), (tl.log, np.log), (tl.exp, np.exp), (tl.sin, np.sin), (tl.cos, np.cos)):
+    close(H(fn(p)), ref(pos))
+  close(H(tl.sign(a)), np.sign(xa)); close(H(tl.abs(a)), np.abs(xa))
+  sq = rng.standard_normal((2, 5, 5))
+  s = tt.Tensor(sq, backend=be)
+  close(H(tl.trace(s)), np.trace(sq, axis1=-2, axis2=-1)); close(H(tl.diagonal(s)), np.diagonal(sq, axis1=-2, axis2=-1))
+  close(H(tl.diagflat(tt.Tensor(np.arange(4.0), backend=be))), np.diagflat(np.arange(4.0)))
+  assert tl.pivot(a, 1).shape == (3, 20) and tl.pivot(a).shape == (12, 5)
+  ka, kb = rng.standard_normal((2, 3, 4, 5)), rng.standard_normal((6, 7))
+  kr = tl.kron(tt.Tensor(ka, backend=be), tt.Tensor(kb, backend=be))
+  assert kr.shape == (2, 3, 6, 4, 5, 7)
+  close(H(kr).reshape(36, 140), np.kron(ka.reshape(6, 20), kb))
+  with pytest.raises(ValueError, match="even number of legs"):
+    tl.kron(a, tt.Tensor(kb, backend=be))
+  # decompositions
+  u, sv, vh, rest = tl.svd(a, 1)
+  close(np.einsum("ik,k,kbc->ibc", H(u), H(sv), H(vh)), xa)
+  assert rest.shape == (0,)
+  q, r = tl.qr(a, 2)
+  close(np.tensordot(H(q), H(r), 1), xa)
+  r2, q2 = tl.rq(a, 1)
+  close(np.tensordot(H(r2), H(q2), 1), xa)
+  sym = rng.standard_normal((6, 6)); sym = sym + sym.T
+  w, v = tl.eigh(tt.Tensor(sym, backend=be))
+  close(H(v) @ np.diag(H(w)) @ H(v).T, sym)
+  close(float(np.asarray(tl.norm(a))), np.linalg.norm(xa))
+  well = rng.standard_normal((5, 5)) + 5 * np.eye(5)
+  close(H(tl.inv(tt.Tensor(well, backend=be))) @ well, np.eye(5))
+  import scipy.linalg
+  close(H(tl.expm(tt.Tensor(sym / 10, backend=be))), scipy.linalg.expm(sym / 10))
+  # initialisation
+  assert H(tl.eye(3, backend=be)).tolist() == np.eye(3).tolist() and tl.eye(2, M=4, dtype=np.float32, backend=be).shape == (2, 4)
+  assert tl.zeros((2, 3), dtype=np.float32, backend=be).dtype == np.float32 and float(H(tl.ones((2, 2), backend=be)).sum()) == 4.0
+  assert tl.ones_like(a).shape == a.shape and tl.zeros_like(np.ones((2, 2), dtype=np.float32), backend=be).dtype == np.float32
+  r1, r2_ = tl.randn((4, 3), dtype=np.float64, seed=10, backend=be), tl.randn((4, 3), dtype=np.float64, seed=10, backend=be)
+  close(H(r1), H(r2_))
+  ru = H(tl.random_uniform((50,), boundaries=(-2.0, -1.0), seed=3, backend=be))
+  assert ru.min() >= -2.0 and ru.max() <= -1.0
+  # Krylov on Tensors
+  hd = tt.Tensor(sym, backend=be)
+  mv = lambda x, mat: tl.tensordot(mat, x, 1)
+  vals, vecs = tl.eigsh_lanczos(mv, args=[hd], x0=tt.Tensor(rng.standard_normal(6), backend=be), num_krylov_vecs=6,
+                                numeig=1)
+  close(vals[0], np.linalg.eigvalsh(sym)[0]); assert isinstance(vecs[0], tt.Tensor)
+  x, info = tl.gmres(mv, tt.Tensor(rng.standard_normal(5), backend=be), A_args=[tt.Tensor(well, backend=be)], tol=1e-12,
+                     num_krylov_vectors=5, maxiter=5)
+  assert info == 0 and isinstance(x, tt.Tensor)
+  with pytest.raises(ValueError, match="One of backend or x0 must be specified"):
+    tl.eigsh_lanczos(mv)

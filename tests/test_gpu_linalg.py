@@ -307,3 +307,10 @@ def test_qr_tall_panels_rank_deficient(hip, dtype, tol):
   q, r = hip.qr(hip.convert_to_tensor(np.zeros((2000, 40), dtype=dtype)), 1, False)
   np.testing.assert_array_equal(np.asarray(q), np.eye(2000, 40))
   np.testing.assert_array_equal(np.asarray(r), 0)
+
+
+def test_tensor_and_functional_api_on_device(hip):
+  """`Tensor` operators + tn.linalg-style functional API (tensor.py, linalg.py) on device tensors: the CPU
+  suite's checker (tests/cases.py:check_tensor_api) with HipBackend."""
+  import cases
+  cases.check_tensor_api(hip, 1e-9)
