@@ -11,7 +11,7 @@ Works on ``tensornetwork_amd.network.Node`` objects; the search itself is pure
 host code, the pairwise steps are GEMMs on the backend.
 """
 import functools
-from typing import Dict, Callable, Iterable, List, Optional, Sequence, Tuple
+from typing import Dict, Callable, Iterable, List, Optional, Sequence, Set, Tuple
 
 from tensornetwork_amd import network, pathfinder
 
@@ -191,3 +191,18 @@ def path_solver(algorithm: str, nodes, memory_limit: Optional[int] = None, nbran
     raise ValueError("algorithm {algorithm} not implemented".format(algorithm=algorithm))
   path, _ = get_path(list(nodes), alg)
   return path
+
+
+def bucket(nodes: Iterable[network.Node], contraction_order: Sequence["network.CopyNode"]) -> Set[network.Node]:
+  """Bucket elimination over copy tensors (bucket_contractor.py:21-57, arXiv:1712.05384): each copy node
+  in `contraction_order` is contracted with all of its neighbours in one hyper-index einsum
+  (`network.contract_copy_node`), never forming the dense copy tensor.  Returns the remaining nodes --
+  finish with another contractor if copy nodes alone do not close the network."""
+  remaining = {id(n): n for n in nodes}
+  for copy_node in contraction_order:
+    partners = copy_node.get_partners()
+    new_node = network.contract_copy_node(copy_node)
+    for gone in list(partners) + [copy_node]:
+      remaining.pop(id(gone), None)
+    remaining[id(new_node)] = new_node
+  return set(remaining.values())

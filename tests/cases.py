@@ -505,6 +505,25 @@ def check_graph_surgery(be, rtol):
   with pytest.raises(NotImplementedError):
     cn + 1  # pylint: disable=pointless-statement
 
+  # bucket elimination over copy tensors (bucket_contractor_test.py:24-98): CNOT = COPY on the control + XOR on the target
+  def add_cnot(q0, q1):
+    control = tn.CopyNode(rank=3, dimension=2, backend=be)
+    target = N([[[1, 0], [0, 1]], [[0, 1], [1, 0]]])
+    tn.connect(q0, control[0]); tn.connect(q1, target[0]); tn.connect(control[1], target[1])
+    return control, control[2], target[2]
+  q0_in, q1_in, q0_out, q1_out = N([0, 1]), N([0, 1]), N([0, 1]), N([1, 0])            # |11> -> |10>
+  cnot, t0, t1 = add_cnot(q0_in[0], q1_in[0])
+  tn.connect(t0, q0_out[0]); tn.connect(t1, q1_out[0])
+  net = tn.contractors.bucket([q0_in, q1_in, q0_out, q1_out, cnot], (cnot,))
+  np.testing.assert_allclose(host(tn.contractors.greedy(net)), 1.0, rtol=rtol)
+  q0_in, q1_in, q0_out, q1_out = N([0.6, 0.8]), N([1, 0]), N([1, 0]), N([0.6, 0.8])    # three CNOTs = SWAP
+  c1, a0, a1 = add_cnot(q0_in[0], q1_in[0])
+  c2, b1, b0 = add_cnot(a1, a0)
+  c3, d0, d1 = add_cnot(b0, b1)
+  tn.connect(d0, q0_out[0]); tn.connect(d1, q1_out[0])
+  net = tn.contractors.bucket([q0_in, q0_out, q1_in, q1_out, c1, c2, c3], (c1, c2, c3))
+  np.testing.assert_allclose(host(tn.contractors.greedy(net)), 1.0, rtol=rtol)
+
 
 INFINITE_MPS_GOLDEN_TAGS = ("inf_f64", "inf_c128")
 
