@@ -16,7 +16,10 @@ smallest first; optimal = exact minimum-flop search; branch = depth-first search
 over the ``nbranch`` best greedy candidates per step.  Host-only integer work.
 """
 import heapq
+import math
 import itertools
+
+import numpy as np
 from typing import Dict, Hashable, List, Optional, Sequence, Set, Tuple
 
 Path = List[Tuple[int, int]]
@@ -384,3 +387,77 @@ def path_cost(inputs, output, size_dict, path) -> Tuple[int, int]:
     peak = max(peak, _size(k12, size_dict))
     remaining = [k for t, k in enumerate(remaining) if t not in (i, j)] + [k12]
   return flops, peak
+
+
+# ----------------------------------------------------------------- ncon-style networks
+def _ncon_sets(tensors, labels):
+  """ncon label lists -> (index sets, output set, sizes); a label that repeats on one tensor is a partial
+  trace and costs nothing in the pairwise model, so it is dropped from that tensor's set."""
+  sizes, inputs = {}, []
+  for t, labs in zip(tensors, labels):
+    labs = [int(l) for l in labs]
+    if len(labs) != len(t.shape):
+      raise ValueError(f"labels {labs} do not match a tensor of shape {tuple(t.shape)}")
+    for l, d in zip(labs, t.shape):
+      sizes[l] = int(d)
+    inputs.append({l for l in labs if labs.count(l) == 1})
+  output = {l for s in inputs for l in s if l < 0}
+  return inputs, output, sizes
+
+
+def _ncon_order_from_path(inputs, path):
+  """Positive labels in the order a linear pairwise path closes them (the `con_order` of ncon)."""
+  remaining = [set(s) for s in inputs]
+  order = []
+  for pair in path:
+    if len(pair) == 1:
+      continue
+    i, j = sorted(pair)
+    k1, k2 = remaining[i], remaining[j]
+    closed = sorted(l for l in (k1 & k2) if l > 0)
+    order.extend(closed)
+    merged = (k1 | k2) - set(closed)
+    remaining = [k for t, k in enumerate(remaining) if t not in (i, j)] + [merged]
+  return order
+
+
+def ncon_cost_check(tensors, labels, con_order) -> float:
+  """log10 of the multiply count of contracting an ncon network in the given label order, pairwise, all
+  labels shared by a pair closing together (nconinterface.py:124-180)."""
+  inputs, _, sizes = _ncon_sets(tensors, labels)
+  remaining = [set(s) for s in inputs]
+  total = 0
+  todo = [int(l) for l in con_order]
+  while todo:
+    lab = todo[0]
+    holders = [t for t, k in enumerate(remaining) if lab in k]
+    if len(holders) != 2:                 # traced on one tensor (already dropped) or closed with a partner
+      todo.pop(0)
+      continue
+    i, j = holders
+    closed = {l for l in remaining[i] & remaining[j] if l > 0}
+    total += _size(remaining[i] | remaining[j], sizes)
+    merged = (remaining[i] | remaining[j]) - closed
+    remaining = [k for t, k in enumerate(remaining) if t not in (i, j)] + [merged]
+    todo = [l for l in todo if l not in closed]
+  while len(remaining) > 1:               # disconnected pieces: outer products
+    a, b = remaining.pop(), remaining.pop()
+    total += _size(a | b, sizes)
+    remaining.append(a | b)
+  return math.log10(total) if total > 0 else 0.0
+
+
+def ncon_solver(tensors, labels, max_branch: Optional[int] = None):
+  """Cheapest contraction order of an ncon-style network (nconinterface.py:21-45).  Returns
+  `(con_order, log10(multiply count), is_optimal)`: `max_branch=None` runs the exact dynamic programme,
+  otherwise a branch search over the `max_branch` best candidates per step (`max_branch=1`: greedy)."""
+  inputs, output, sizes = _ncon_sets(tensors, labels)
+  if max_branch is None:
+    path, exact = optimal(inputs, output, sizes), True
+  else:
+    path, exact = branch(inputs, output, sizes, nbranch=int(max_branch)), False
+  macs, _ = path_cost(inputs, output, sizes, path)
+  order = _ncon_order_from_path(inputs, path)
+  traced = sorted({int(l) for labs in labels for l in labs if list(labs).count(l) == 2})
+  con_order = np.array(traced + order, dtype=int)
+  return con_order, (math.log10(macs) if macs > 0 else 0.0), exact

@@ -233,3 +233,41 @@ def test_collector_policy_before_large_allocations():
     assert 0.0 < dt._gc_cost_seconds < 5.0
   finally:
     dt._gc_cost_seconds = saved
+
+
+def test_ncon_solver_known_mera_cost_and_consistency():
+  """nconinterface_test.py:22-66: the binary-MERA network has optimal cost 2 chi^9 + 4 chi^8 + 2 chi^6 +
+  2 chi^5 multiplications; on random networks the reported cost equals the cost of the returned order."""
+  from tensornetwork_amd import pathfinder
+  for chi in (2, 3, 5):
+    u, w, ham = np.zeros((chi,) * 4), np.zeros((chi,) * 3), np.zeros((chi,) * 6)
+    tensors = [u, u, w, w, w, ham, u, u, w, w, w]
+    connects = [[1, 3, 10, 11], [4, 7, 12, 13], [8, 10, -4], [11, 12, -5], [13, 14, -6], [2, 5, 6, 3, 4, 7],
+                [1, 2, 9, 17], [5, 6, 16, 15], [8, 9, -1], [17, 16, -2], [15, 14, -3]]
+    con_order, cost, is_optimal = pathfinder.ncon_solver(tensors, connects, max_branch=None)
+    assert is_optimal
+    np.testing.assert_allclose(cost, np.log10(2 * chi**9 + 4 * chi**8 + 2 * chi**6 + 2 * chi**5))
+    assert sorted(con_order) == list(range(1, 18))
+    np.testing.assert_allclose(pathfinder.ncon_cost_check(tensors, connects, con_order), cost)
+    # the order drives ncon to the same value as the default order
+    rng = np.random.default_rng(chi)
+    vals = [rng.standard_normal(t.shape) for t in tensors]
+    be = OracleBackend()
+    np.testing.assert_allclose(ta.ncon(vals, connects, con_order=list(con_order), backend=be),
+                               ta.ncon(vals, connects, backend=be), rtol=1e-9)
+  rng = np.random.default_rng(0)
+  chi, n = 4, 8
+  for num_closed in (1, 5, 9, 14):
+    num_open = 4 * n - 2 * num_closed
+    cl, op = 1 + np.arange(num_closed), -1 - np.arange(num_open)
+    comb = np.concatenate((op, cl, cl))[rng.permutation(4 * n)]
+    connects = []
+    for k in range(n):
+      ring = [num_closed + k + 1, num_closed + k + 2 if k < n - 1 else num_closed + 1]
+      labs = np.concatenate((comb[4 * k:4 * (k + 1)], ring))
+      connects.append([int(x) for x in labs[rng.permutation(6)]])
+    tensors = [np.zeros((chi,) * 6)] * n
+    for max_branch in (1, 3):
+      con_order, cost, _ = pathfinder.ncon_solver(tensors, connects, max_branch=max_branch)
+      assert sorted(con_order) == list(range(1, num_closed + n + 1))
+      np.testing.assert_allclose(pathfinder.ncon_cost_check(tensors, connects, con_order), cost)
