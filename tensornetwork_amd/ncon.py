@@ -301,14 +301,51 @@ def einsum(expression: str, *tensors, backend=None):
   return tensor
 
 
+# Default backend: "hip" unless changed with `set_default_backend` or inside a `DefaultBackend`
+# block (backend_contextmanager.py:14-52).  A default may be a backend name or a backend object.
+_DEFAULT_BACKEND = ["hip"]   # [process default, *context-manager stack]
+
+
+def get_default_backend():
+  return _DEFAULT_BACKEND[-1]
+
+
+def set_default_backend(backend) -> None:
+  if len(_DEFAULT_BACKEND) > 1:
+    raise AssertionError("The default backend should not be changed inside the backend context manager")
+  if not isinstance(backend, str) and not hasattr(backend, "tensordot"):
+    raise ValueError("Item passed to set_default_backend must be Text or BaseBackend")
+  if isinstance(backend, str):
+    _resolve_backend(backend)             # raises ValueError for an unknown name
+  _DEFAULT_BACKEND[0] = backend
+
+
+class DefaultBackend:
+  """`with DefaultBackend("numpy"): ...` -- nodes / tensors created inside use that backend by default."""
+
+  def __init__(self, backend) -> None:
+    if not isinstance(backend, str) and not hasattr(backend, "tensordot"):
+      raise ValueError("Item passed to DefaultBackend must be Text or BaseBackend")
+    self.backend = backend
+
+  def __enter__(self):
+    _DEFAULT_BACKEND.append(self.backend)
+
+  def __exit__(self, exc_type, exc_val, exc_tb):
+    _DEFAULT_BACKEND.pop()
+
+
 def _resolve_backend(backend):
   if backend is None:
-    from tensornetwork_amd.hip_backend import get_hip_backend  # pylint: disable=import-outside-toplevel
-    return get_hip_backend()
+    backend = get_default_backend()
   if isinstance(backend, str):
     if backend == "hip":
       from tensornetwork_amd.hip_backend import get_hip_backend  # pylint: disable=import-outside-toplevel
       return get_hip_backend()
-    from tensornetwork.backends import backend_factory  # pylint: disable=import-outside-toplevel
+    try:
+      from tensornetwork.backends import backend_factory  # pylint: disable=import-outside-toplevel
+    except ImportError as exc:
+      raise ValueError(f"Backend '{backend}' was not found (only 'hip' and backend objects are available "
+                       "without the tensornetwork package).") from exc
     return backend_factory.get_backend(backend)
   return backend

@@ -271,3 +271,30 @@ def test_ncon_solver_known_mera_cost_and_consistency():
       con_order, cost, _ = pathfinder.ncon_solver(tensors, connects, max_branch=max_branch)
       assert sorted(con_order) == list(range(1, num_closed + n + 1))
       np.testing.assert_allclose(pathfinder.ncon_cost_check(tensors, connects, con_order), cost)
+
+
+def test_default_backend_stack():
+  # backend_contextmanager.py:14-52 / tests/backend_contextmanager_test.py
+  be = OracleBackend()
+  assert ta.get_default_backend() == "hip"
+  with ta.DefaultBackend(be):
+    assert ta.Node(np.eye(2)).backend is be
+    inner = OracleBackend()
+    with ta.DefaultBackend(inner):
+      assert ta.Node(np.eye(2)).backend is inner
+      with pytest.raises(AssertionError, match="should not be changed inside"):
+        ta.set_default_backend(be)
+    assert ta.Node(np.eye(2)).backend is be
+    np.testing.assert_allclose(ta.ncon([np.eye(2), np.ones(2)], [[-1, 1], [1]]), np.ones(2))
+  assert ta.get_default_backend() == "hip"
+  ta.set_default_backend(be)
+  try:
+    assert ta.Node(np.eye(2)).backend is be and ta.Tensor(np.eye(2)).backend is be
+  finally:
+    ta.set_default_backend("hip")
+  with pytest.raises(ValueError):
+    ta.set_default_backend(-1)
+  with pytest.raises(ValueError, match="was not found"):
+    ta.set_default_backend("BAD_NAME")
+  with pytest.raises(ValueError):
+    ta.DefaultBackend(-1)
