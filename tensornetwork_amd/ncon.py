@@ -19,7 +19,6 @@ from typing import Any, List, Optional, Sequence
 
 import math
 
-import numpy as np
 
 
 def _is_open(label) -> bool:
