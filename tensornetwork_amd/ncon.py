@@ -40,31 +40,65 @@ def _default_orders(network_structure):
   return cont, out_int + out_str
 
 
+def _repeats(seq):
+  out = []
+  for l in seq:
+    if seq.count(l) != 1 and l not in out:
+      out.append(l)
+  return out
+
+
 def _check(tensors, network_structure, con_order, out_order):
-  """Argument validation with the reference's error types (ValueError)."""
+  """Argument validation: the conditions, their order and the messages of the reference's
+  `_check_network` (ncon_interface.py:118-240), which its tests match on."""
   if len(tensors) != len(network_structure):
-    raise ValueError('len(tensors) != len(network_structure)')
-  flat = [l for labels in network_structure for l in labels]
-  for t, labels in zip(tensors, network_structure):
+    raise ValueError("number of tensors does not match the number of network connections.")
+  for n, (t, labels) in enumerate(zip(tensors, network_structure)):
     if len(t.shape) != len(labels):
-      raise ValueError(f"number of labels {list(labels)} does not match tensor rank {len(t.shape)}")
-  dims = {}
-  for t, labels in zip(tensors, network_structure):
-    for d, l in zip(t.shape, labels):
-      if l in dims and dims[l] != d:
-        raise ValueError(f"label {l!r} is attached to axes of different dimensions "
-                         f"({dims[l]} and {d})")
-      dims[l] = d
+      raise ValueError(f"number of indices does not match number of labels on tensor {n}.")
+  flat = [l for labels in network_structure for l in labels]
+  cont, out = _default_orders(network_structure)
+  names = [l for l in cont if isinstance(l, str)] + [l[1:] for l in out if isinstance(l, str)]
+  bad = [l for l in names if not l.isalnum()]
+  if bad:
+    raise ValueError(f"only alphanumeric values allowed for string labels, found {bad}")
+  if any(not isinstance(l, str) and l == 0 for l in flat):
+    raise ValueError("only nonzero values are allowed to specify network structure.")
+
+  def check_order(order, which, wanted, sign_ok, sign_msg, hyphen_ok, hyphen_msg, length_msg, missing_msg):
+    order = list(order)
+    wrong = [o for o in order if not isinstance(o, str) and not sign_ok(o)]
+    if wrong:
+      raise ValueError(f"all number type labels in `{which}` have to be {sign_msg}, found {wrong}")
+    wrong = [o for o in order if isinstance(o, str) and not hyphen_ok(o)]
+    if wrong:
+      raise ValueError(f"all string type labels in `{which}` {hyphen_msg}, found {wrong}")
+    rep = _repeats(order)
+    if rep:
+      raise ValueError(f"labels {rep} appear more than once in `{which}`.")
+    if len(order) != len(wanted):
+      raise ValueError(length_msg.format(order=order, wanted=wanted))
+    missing = [o for o in order if o not in flat]
+    if missing:
+      raise ValueError(missing_msg.format(missing=missing))
+
   if con_order is not None:
-    want = {l for l in flat if not _is_open(l)}
-    if set(con_order) != want or len(set(con_order)) != len(con_order):
-      raise ValueError(f"con_order = {list(con_order)} is not a valid contraction order for "
-                       f"network_structure = {network_structure}")
+    check_order(con_order, "con_order", cont, lambda o: o > 0, "positive", lambda o: o[0] != '-',
+                "must be unhyphenized",
+                "`con_order = {order} is not a valid contraction order for contracted labels {wanted}",
+                "labels {missing} in `con_order` do not appear as contracted labels in `network_structure`.")
   if out_order is not None:
-    want = {l for l in flat if _is_open(l)}
-    if set(out_order) != want or len(set(out_order)) != len(out_order):
-      raise ValueError(f"out_order = {list(out_order)} is not a valid output order for "
-                       f"network_structure = {network_structure}")
+    check_order(out_order, "out_order", out, lambda o: o < 0, "negative", lambda o: o[0] == '-',
+                "have to be hyphenized",
+                "`out_order` = {order} is not a valid output order for open labels {wanted}",
+                "labels {missing} in `out_order` do not appear in `network_structure`.")
+  mismatched = []
+  for lab in cont:
+    dims = {t.shape[n] for t, labels in zip(tensors, network_structure) for n, l in enumerate(labels) if l == lab}
+    if len(dims) > 1:
+      mismatched.append(lab)
+  if mismatched:
+    raise ValueError(f"tensor dimensions for labels {mismatched} are mismatching")
 
 
 class _Engine:
@@ -211,6 +245,10 @@ def ncon(tensors: Sequence[Any], network_structure: Sequence[Sequence], con_orde
   d_cont, d_out = _default_orders(network_structure)
   con_order = list(con_order) if con_order is not None else d_cont
   out_order = list(out_order) if out_order is not None else d_out
+  if set(con_order) != set(d_cont):
+    # only reachable with check_network=False; the reference's loop never terminates on such input and says so
+    raise ValueError(f"ncon seems stuck in an infinite loop. \nPlease check if `con_order` = {con_order} is a valid "
+                     f"contraction order for \n`network_structure` = {network_structure}")
 
   eng = _Engine(be, tensors, network_structure, keep=out_order, when={l: i for i, l in enumerate(con_order)})
   done = set()

@@ -56,6 +56,49 @@ def test_ncon_errors(be):
     ta.ncon([a], [[-1, -2, -3]], backend=be)
 
 
+def test_ncon_invalid_network_messages(be):
+  """ncon_interface_test.py:630-765: every malformed call and the message the reference's tests match on."""
+  a, b, c = np.ones((2, 2)), np.ones((2, 3, 4, 2)), np.ones((2, 4, 4, 3))
+  cases_ = [
+      (([a, a], [('megan!', 'henry@'), ('henry@', 'megan!')]), {},
+       r"only alphanumeric values allowed for string labels, found \['henry@', 'megan!'\]"),
+      (([a, a], [(1, 2), (2, 1), (1, 2)]), {}, "number of tensors does not match the number of network connections."),
+      (([a, a], [(1,), (1, 2)]), {}, "number of indices does not match number of labels on tensor 0."),
+      (([a, a], [(0, 1), (1, 0)]), {}, "only nonzero values are allowed to specify network structure."),
+      (([a, a], [(1, 2), (2, 1)]), {"con_order": [-1, 2]},
+       r"all number type labels in `con_order` have to be positive, found \[-1\]"),
+      (([a, a], [(1, 2), (2, 1)]), {"con_order": ['-hi', 2]},
+       r"all string type labels in `con_order` must be unhyphenized, found \['-hi'\]"),
+      (([a, a], [(1, 2), (2, 1)]), {"con_order": ['hi', 'hi', 1, 1]},
+       r"labels \['hi', 1\] appear more than once in `con_order`."),
+      (([a, a], [(1, 2), (2, 1)]), {"con_order": [3, 4, 5]},
+       r"`con_order = \[3, 4, 5\] is not a valid contraction order for contracted labels \[1, 2\]"),
+      (([a, a], [(1, 2), (2, 1)]), {"con_order": [3, 4]},
+       r"labels \[3, 4\] in `con_order` do not appear as contracted labels in `network_structure`."),
+      (([a, a], [(-1, 1), (1, -2)]), {"out_order": [-1, 2]},
+       r"all number type labels in `out_order` have to be negative, found \[2\]"),
+      (([a, a], [('-hi', 1), (1, -2)]), {"out_order": ['hi', -2]},
+       r"all string type labels in `out_order` have to be hyphenized, found \['hi'\]"),
+      (([a, a], [(1, 2), (2, 1)]), {"out_order": ['-hi', '-hi', -1, -1]},
+       r"labels \['-hi', -1\] appear more than once in `out_order`."),
+      (([a, a], [(-1, 2), (2, -2)]), {"out_order": [-1, -2, -3]},
+       r"`out_order` = \[-1, -2, -3\] is not a valid output order for open labels \[-1, -2\]"),
+      (([a, a], [(-1, 2), (2, -2)]), {"out_order": [-3, -4]},
+       r"labels \[-3, -4\] in `out_order` do not appear in `network_structure`."),
+      (([b, c], [(1, 2, 3, 4), (1, 2, 3, 4)]), {}, r"tensor dimensions for labels \[2, 4\] are mismatching"),
+  ]
+  for args, kwargs, message in cases_:
+    with pytest.raises(ValueError, match=message):
+      ta.ncon(*args, backend=be, **kwargs)
+    wrapped = [ta.Tensor(t, backend=be) for t in args[0]]          # test_node_invalid_network: Tensor operands
+    with pytest.raises(ValueError, match=message):
+      ta.ncon(wrapped, args[1], backend=be, **kwargs)
+  ones3, ones2 = np.ones((2, 2, 2)), np.ones((2, 2))
+  with pytest.raises(ValueError, match=r"ncon seems stuck in an infinite loop. \nPlease check if `con_order` = \[3\] is a "
+                     r"valid contraction order for \n`network_structure` = \[\[3, 1, 2\], \[3, 1\], \[3, 2\]\]"):
+    ta.ncon([ones3, ones2, ones2], [[3, 1, 2], [3, 1], [3, 2]], con_order=[3], check_network=False, backend=be)
+
+
 def test_einsum_matches_numpy(be):
   rng = np.random.default_rng(3)
   a, b, c = rng.standard_normal((3, 4)), rng.standard_normal((4, 5)), rng.standard_normal((5, 3))
