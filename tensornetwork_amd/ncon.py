@@ -253,6 +253,7 @@ def ncon(tensors: Sequence[Any], network_structure: Sequence[Sequence], con_orde
   eng = _Engine(be, tensors, network_structure, keep=out_order, when={l: i for i, l in enumerate(con_order)})
   done = set()
   for idx in range(len(eng.ops)):
+    eng.diag_repeated(idx)          # "ii,i": a repeated label that also lives elsewhere keeps one copy
     done.update(eng.trace_repeated(idx))
   for idx in range(len(eng.ops)):
     done.update(eng.sum_dangling(idx))

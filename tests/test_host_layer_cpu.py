@@ -341,3 +341,45 @@ def test_default_backend_stack():
     ta.set_default_backend("BAD_NAME")
   with pytest.raises(ValueError):
     ta.DefaultBackend(-1)
+
+
+@pytest.mark.parametrize("seed", range(150))
+def test_ncon_fuzz_against_einsum(seed):
+  """Random ncon calls with everything the reference's tests exercise at once (ncon_interface_test.py:
+  outer products, partial and batched traces, batched matmuls, hyper-indices, explicit orders):
+  ncon == einsum with the negative labels as output and every positive label summed."""
+  import string
+  rng = np.random.default_rng(1000 + seed)
+  be = OracleBackend()
+  n_t = int(rng.integers(1, 5))
+  n_pos, n_neg = int(rng.integers(0, 5)), int(rng.integers(0, 4))
+  labels = [int(x) for x in range(1, n_pos + 1)] + [-int(x) for x in range(1, n_neg + 1)]
+  dims = {l: int(rng.integers(2, 4)) for l in labels}
+  structure = [[] for _ in range(n_t)]
+  for l in labels:
+    copies = int(rng.integers(2, 4)) if l > 0 else int(rng.integers(1, 3))
+    for _ in range(copies):
+      structure[int(rng.integers(0, n_t))].append(l)
+  for s in structure:
+    # at most two copies of a label per tensor (a trace / a batched diagonal), ranks <= 6
+    for l in set(s):
+      while s.count(l) > 2:
+        s.remove(l)
+    del s[6:]
+    rng.shuffle(s)
+  used = [l for s in structure for l in s]
+  pos = sorted({l for l in used if l > 0})
+  neg = sorted({l for l in used if l < 0}, reverse=True)
+  if any(used.count(l) == 1 for l in pos):
+    pytest.skip("a positive label on a single axis is a plain sum: the reference rejects it")
+  if any(s.count(l) == 2 for s in structure for l in neg):
+    pytest.skip("repeated open label on one tensor")
+  tensors = [rng.standard_normal([dims[l] for l in s]) for s in structure]
+  letter = {l: string.ascii_letters[k] for k, l in enumerate(pos + neg)}
+  out_order = list(rng.permutation(neg)) if neg and rng.random() < 0.5 else None
+  con_order = [int(x) for x in rng.permutation(pos)] if pos and rng.random() < 0.5 else None
+  final = [int(x) for x in out_order] if out_order is not None else neg
+  expr = ",".join("".join(letter[l] for l in s) for s in structure) + "->" + "".join(letter[l] for l in final)
+  want = np.einsum(expr, *tensors)
+  got = ta.ncon(tensors, structure, con_order=con_order, out_order=None if out_order is None else final, backend=be)
+  np.testing.assert_allclose(got, want, rtol=1e-10, atol=1e-10)
