@@ -63,6 +63,41 @@ class Edge:
     else:
       raise ValueError("edge end not found")
 
+  def update_axis(self, old_axis: int, old_node: "Node", new_axis: int, new_node: "Node") -> None:
+    """Repoint the end (old_node, old_axis) to (new_node, new_axis) (network_components.py:1075-1094)."""
+    try:
+      self._retarget(old_node, old_axis, new_node, new_axis)
+    except ValueError as err:
+      raise ValueError("Edge '{}' did not contain node '{}' on axis {}. node1: '{}', axis1: {}, node2: '{}', "
+                       "axis2: {}".format(self, old_node, old_axis, self.node1, self.axis1, self.node2,
+                                          self.axis2)) from err
+
+  def is_being_used(self) -> bool:
+    """True while the edge still sits in an edge slot of one of its nodes."""
+    return any(n is not None and any(e is self for e in n.edges) for n in (self.node1, self.node2))
+
+  def set_name(self, name: str) -> None:
+    if not isinstance(name, str):
+      raise TypeError("Edge name should be str type")
+    self.name = name
+
+  def disconnect(self, edge1_name: Optional[str] = None, edge2_name: Optional[str] = None):
+    return disconnect(self, edge1_name, edge2_name)
+
+  def __or__(self, other: "Edge"):
+    """`edge | edge` breaks a connected edge into its two dangling halves (1263-1266)."""
+    if other is not self:
+      raise ValueError('Cannot break two unconnected edges')
+    return self.disconnect()
+
+  def __lt__(self, other) -> bool:
+    if not isinstance(other, Edge):
+      raise TypeError("Cannot compare 'Edge' with type {}".format(type(other)))
+    return id(self) < id(other)
+
+  def __str__(self) -> str:
+    return self.name if self.name else '__unnamed_edge__'
+
   def __xor__(self, other: "Edge") -> "Edge":
     return connect(self, other)
 
@@ -104,15 +139,83 @@ class Node:
   def get_all_nondangling(self) -> Set[Edge]:
     return {e for e in self.edges if not e.is_dangling()}
 
-  def get_edge(self, key) -> Edge:
-    if isinstance(key, str):
-      if key not in self.axis_names:
-        raise ValueError(f"Axis name '{key}' not found for node '{self.name}'")
-      key = self.axis_names.index(key)
-    return self.edges[key]
+  def get_axis_number(self, axis) -> int:
+    if isinstance(axis, int):
+      return axis
+    if axis not in self.axis_names:
+      raise ValueError(f"Axis name '{axis}' not found for node '{self.name}'")
+    return self.axis_names.index(axis)
 
-  def __getitem__(self, key) -> Edge:
+  def get_dimension(self, axis) -> int:
+    num = self.get_axis_number(axis)
+    if num < 0 or num >= len(self.shape):
+      raise ValueError("Axis must be positive and less than rank of the tensor")
+    return self.shape[num]
+
+  def get_edge(self, key) -> Edge:
+    return self.edges[self.get_axis_number(key)]
+
+  def get_all_edges(self) -> List[Edge]:
+    return list(self.edges)
+
+  def has_nondangling_edge(self) -> bool:
+    return any(not e.is_dangling() for e in self.edges)
+
+  def has_dangling_edge(self) -> bool:
+    return any(e.is_dangling() for e in self.edges)
+
+  def set_name(self, name: str) -> None:
+    if not isinstance(name, str):
+      raise TypeError("Node name should be str type")
+    self.name = name
+
+  def add_axis_names(self, axis_names: List[str]) -> None:
+    """Name the axes (network_components.py:128-148): unique strings, one per axis."""
+    if len(axis_names) != len(set(axis_names)):
+      raise ValueError("Not all axis names are unique.")
+    if len(axis_names) != len(self.shape):
+      raise ValueError("axis_names is not the same length as the tensor shape."
+                       "axis_names length: {}, tensor.shape length: {}".format(len(axis_names), len(self.shape)))
+    if any(not isinstance(n, str) for n in axis_names):
+      raise TypeError("axis_names should be str type")
+    self.axis_names = list(axis_names)
+
+  def add_edge(self, edge: Edge, axis, override: bool = False) -> None:
+    """Put `edge` into the slot of `axis` (150-173); an occupied (non-dangling) slot needs `override`."""
+    num = self.get_axis_number(axis)
+    if num < 0 or num >= len(self.shape):
+      raise ValueError("Axis must be positive and less than rank of the tensor")
+    if not self.edges[num].is_dangling() and not override:
+      raise ValueError("Node '{}' already has a non-dangling edge for axis {}".format(self, axis))
+    self.edges[num] = edge
+
+  @property
+  def sparse_shape(self):
+    return self.backend.sparse_shape(self.tensor)
+
+  def copy(self, conjugate: bool = False) -> "Node":
+    """A node with the same (optionally conjugated) tensor and names, all edges dangling except its own
+    trace edges (network_components.py:637-660)."""
+    tensor = self.backend.conj(self.tensor) if conjugate else self.tensor
+    new = Node(tensor, name=self.name, axis_names=list(self.axis_names), backend=self.backend)
+    for i, e in enumerate(self.edges):
+      new.edges[i].name = e.name
+      if e.node1 is self and e.node2 is self and i == e.axis1:
+        connect(new.edges[e.axis1], new.edges[e.axis2], name=e.name)
+    return new
+
+  def __getitem__(self, key):
+    if isinstance(key, slice):
+      return self.edges[key]
     return self.get_edge(key)
+
+  def __str__(self) -> str:
+    return self.name
+
+  def __lt__(self, other) -> bool:
+    if not isinstance(other, Node):
+      raise ValueError("Object {} is not a Node type.".format(other))
+    return id(self) < id(other)
 
   def reorder_edges(self, edge_order: Sequence[Edge]) -> "Node":
     """Permute the tensor so that its axes follow `edge_order` (network_components.py:212-252)."""
@@ -160,6 +263,8 @@ class Node:
     return self.backend.transpose(self.tensor, tuple(perm))
 
   def __matmul__(self, other: "Node") -> "Node":
+    if not isinstance(other, Node):
+      raise TypeError("Cannot use '@' with type '{}'".format(type(other)))
     return contract_between(self, other)
 
   # Elementwise arithmetic with a scalar or another Node (network_components.py:586-631): the result is a

@@ -383,3 +383,64 @@ def test_ncon_fuzz_against_einsum(seed):
   want = np.einsum(expr, *tensors)
   got = ta.ncon(tensors, structure, con_order=con_order, out_order=None if out_order is None else final, backend=be)
   np.testing.assert_allclose(got, want, rtol=1e-10, atol=1e-10)
+
+
+def test_node_and_edge_accessors(be):
+  """network_components_free_test.py: the small Node / Edge API (axis names, add_edge, get_dimension, slices,
+  ordering, copy, update_axis, is_being_used, `edge | edge`)."""
+  n = ta.Node(np.arange(24.0).reshape(2, 3, 4), name="n", axis_names=["a", "b", "c"], backend=be)
+  assert n.get_rank() == 3 and n.get_axis_number("b") == 1 and n.get_axis_number(2) == 2
+  assert n.get_dimension("c") == 4 and n.get_dimension(0) == 2 and n["b"] is n[1] and n[0:2] == n.edges[:2]
+  assert n.get_all_edges() == n.edges and n.get_all_edges() is not n.edges
+  assert str(n) == "n" and n.has_dangling_edge() and not n.has_nondangling_edge() and n.sparse_shape == (2, 3, 4)
+  with pytest.raises(ValueError, match="Axis name 'zz' not found"):
+    n.get_axis_number("zz")
+  with pytest.raises(ValueError, match="Axis must be positive and less than rank"):
+    n.get_dimension(5)
+  n.add_axis_names(["x", "y", "z"])
+  assert n.axis_names == ["x", "y", "z"]
+  with pytest.raises(ValueError, match="Not all axis names are unique"):
+    n.add_axis_names(["x", "x", "z"])
+  with pytest.raises(ValueError, match="axis_names is not the same length"):
+    n.add_axis_names(["x"])
+  with pytest.raises(TypeError, match="axis_names should be str type"):
+    n.add_axis_names(["x", "y", 3])
+  n.set_name("m")
+  assert n.name == "m"
+  with pytest.raises(TypeError):
+    n.set_name(3)
+  other = ta.Node(np.ones((4, 2)), backend=be)
+  e = ta.connect(n[2], other[0], name="bond")
+  assert n.has_nondangling_edge() and e.is_being_used() and str(e) == "bond" and sorted([n, other])[0] in (n, other)
+  with pytest.raises(ValueError, match="is not a Node type"):
+    n < 3  # pylint: disable=pointless-statement
+  with pytest.raises(TypeError):
+    e < 3  # pylint: disable=pointless-statement
+  with pytest.raises(TypeError, match="Cannot use '@' with type"):
+    n @ 3  # pylint: disable=pointless-statement
+  with pytest.raises(ValueError, match="already has a non-dangling edge"):
+    n.add_edge(ta.Edge(n, 2), 2)
+  with pytest.raises(ValueError, match="Axis must be positive"):
+    n.add_edge(ta.Edge(n, 0), 7)
+  fresh = ta.Edge(n, 0, name="fresh")
+  n.add_edge(fresh, "x")
+  assert n[0] is fresh
+  e.set_name("renamed")
+  assert e.name == "renamed"
+  with pytest.raises(TypeError):
+    e.set_name(1)
+  with pytest.raises(ValueError, match="Cannot break two unconnected edges"):
+    e | fresh  # pylint: disable=pointless-statement
+  left, right = e | e
+  assert left.is_dangling() and right.is_dangling() and n[2] is left and other[0] is right and not e.is_being_used()
+  with pytest.raises(ValueError, match="did not contain node"):
+    left.update_axis(0, other, 1, other)
+  left.update_axis(2, n, 2, n)
+  # copy: trace edges survive, everything else dangles; conjugation
+  z = ta.Node(np.arange(8.0).reshape(2, 2, 2) * (1 + 1j), name="z", backend=be)
+  tr = ta.connect(z[0], z[2], name="loop")
+  ta.connect(z[1], ta.Node(np.ones(2), backend=be)[0])
+  zc = z.copy(conjugate=True)
+  assert zc is not z and zc.name == "z" and zc[0] is zc[2] and zc[0].is_trace() and zc[0].name == "loop" and zc[1].is_dangling()
+  np.testing.assert_allclose(np.asarray(zc.tensor), np.conj(np.asarray(z.tensor)))
+  assert tr.is_trace()
