@@ -26,10 +26,11 @@ from tensornetwork_amd.network import (Node, Edge, CopyNode, contract_copy_node,
                                        get_all_nodes, get_neighbors, check_connected, check_correct,
                                        disconnect, remove_node, redirect_edge, flatten_edges,
                                        flatten_edges_between, flatten_all_edges, split_edge,
-                                       replicate_nodes, reduced_density, from_topology, switch_backend)
+                                       replicate_nodes, reduced_density, from_topology, switch_backend,
+                                       outer_product_final_nodes)
 from tensornetwork_amd import contractors, pathfinder
 from tensornetwork_amd.tensor import Tensor, NconBuilder, finalize
-from tensornetwork_amd import linalg
+from tensornetwork_amd import linalg, node_linalg
 from tensornetwork_amd.mps import FiniteMPS, InfiniteMPS, FiniteDMRG
 from tensornetwork_amd.mpo import (BaseMPO, FiniteMPO, InfiniteMPO, FiniteXXZ, FiniteTFI,
                                    FiniteFreeFermion2D)

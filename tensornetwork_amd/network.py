@@ -500,6 +500,19 @@ def outer_product(node1: Node, node2: Node, name: Optional[str] = None) -> Node:
   return out
 
 
+def outer_product_final_nodes(nodes: Iterable[Node], edge_order: List[Edge]) -> Node:
+  """Outer product of fully contracted (all edges dangling) nodes, axes in `edge_order`
+  (network_components.py:2098-2124)."""
+  nodes = list(nodes)
+  for node in nodes:
+    if node.has_nondangling_edge():
+      raise ValueError("Node '{}' has a non-dangling edge remaining.".format(node))
+  final = nodes[0]
+  for node in nodes[1:]:
+    final = outer_product(final, node)
+  return final.reorder_edges(list(edge_order))
+
+
 def contract_between(node1: Node, node2: Node, name: Optional[str] = None,
                      allow_outer_product: bool = False,
                      output_edge_order: Optional[Sequence[Edge]] = None,
