@@ -31,6 +31,7 @@ from tensornetwork_amd.network import (Node, Edge, CopyNode, contract_copy_node,
 from tensornetwork_amd import contractors, pathfinder
 from tensornetwork_amd.tensor import Tensor, NconBuilder, finalize
 from tensornetwork_amd import linalg, node_linalg
+from tensornetwork_amd.decorators import jit
 from tensornetwork_amd.mps import FiniteMPS, InfiniteMPS, FiniteDMRG
 from tensornetwork_amd.mpo import (BaseMPO, FiniteMPO, InfiniteMPO, FiniteXXZ, FiniteTFI,
                                    FiniteFreeFermion2D)

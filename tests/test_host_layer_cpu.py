@@ -444,3 +444,18 @@ def test_node_and_edge_accessors(be):
   assert zc is not z and zc.name == "z" and zc[0] is zc[2] and zc[0].is_trace() and zc[0].name == "loop" and zc[1].is_dangling()
   np.testing.assert_allclose(np.asarray(zc.tensor), np.conj(np.asarray(z.tensor)))
   assert tr.is_trace()
+
+
+def test_jit_decorator(be):
+  # backends/decorators_test.py: fixed backend, backend from an argument, error cases
+  def fun(x, backend_arg, y):
+    return x * 2 + y
+  assert ta.jit(fun, backend=be)(1, None, 3) == 5
+  by_arg = ta.jit(fun, backend_argnum=1)
+  assert by_arg(1, be, 3) == 5 and by_arg.__name__ == "fun"
+  with pytest.raises(ValueError, match="backend must be None if backend_argnum is specified"):
+    ta.jit(fun, backend=be, backend_argnum=1)
+  with pytest.raises(ValueError, match="did not specify a backend"):
+    by_arg(1, "BAD_NAME", 3)
+  with pytest.raises(ValueError, match="did not specify a backend"):
+    by_arg(1, 7, 3)
