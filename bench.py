@@ -420,13 +420,20 @@ def main():
       except Exception as exc:  # pylint: disable=broad-except
         result["mera"] = {"error": f"{type(exc).__name__}: {exc}"}
       _lib.check(be.lib.tnh_trim())
+    # every secondary leg is fenced: whatever happens in one of them, the headline line is printed
     if world == 1 and args.svd_n > 0:
-      svd_bench(ta, be, args.svd_n, max(args.svd_n // 16, 1))  # warm-up
-      result["svd"] = svd_bench(ta, be, args.svd_n, max(args.svd_n // 16, 1))
-      if not args.no_cpu_baseline:
-        result["svd"]["cpu_baseline"] = svd_cpu_baseline(args.svd_n)
+      try:
+        svd_bench(ta, be, args.svd_n, max(args.svd_n // 16, 1))  # warm-up
+        result["svd"] = svd_bench(ta, be, args.svd_n, max(args.svd_n // 16, 1))
+        if not args.no_cpu_baseline:
+          result["svd"]["cpu_baseline"] = svd_cpu_baseline(args.svd_n)
+      except Exception as exc:  # pylint: disable=broad-except
+        result.setdefault("svd", {})["error"] = f"{type(exc).__name__}: {exc}"
     if world == 1 and not args.no_cpu_baseline:
-      result["cpu_baseline"] = cpu_baseline(args.layout)
+      try:
+        result["cpu_baseline"] = cpu_baseline(args.layout)
+      except Exception as exc:  # pylint: disable=broad-except
+        result["cpu_baseline"] = {"error": f"{type(exc).__name__}: {exc}"}
     print(json.dumps(result))
   if dist is not None:
     dist.barrier()
