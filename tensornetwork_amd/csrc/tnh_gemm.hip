@@ -454,7 +454,9 @@ __global__ __launch_bounds__(256) void complex_expand_kernel(R* __restrict__ dst
 // The bf16 kernels run at ~1.4 PFLOP/s, i.e. ~240 TFLOP/s of f32-equivalent work against the
 // 157 TFLOP/s peak (95 measured) of v_mfma_f32_32x32x2_f32; the split is one HBM-bound pass
 // (4 B in, 12 B out per element).  Inputs beyond the bf16 range of finite values (|x| > 3.39e38)
-// or subnormal f32 values lose their low bits; everything else is f32-grade.
+// or subnormal f32 values lose their low bits, and an infinite input turns its row / column of the
+// result into NaN (inf - inf in the split) where the f32 kernel would give +-inf; everything else is
+// f32-grade.  TNH_F32_SPLIT=0 / ":s0" select the f32 kernel for such data.
 __device__ __forceinline__ void split3(float x, uint16_t& hi, uint16_t& mid, uint16_t& lo) {
   hi = f32_to_bf16(x);
   const float r1 = x - bf16_to_f32(hi);
