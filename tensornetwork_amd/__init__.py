@@ -16,7 +16,7 @@ from tensornetwork_amd.hip_backend import (HipBackend, get_hip_backend,
                                            register_with_tensornetwork)
 from tensornetwork_amd.ncon import (ncon, einsum, DefaultBackend, set_default_backend,
                                     get_default_backend)
-from tensornetwork_amd.network import (Node, Edge, CopyNode, contract_copy_node, connect, contract, contract_between,
+from tensornetwork_amd.network import (Node, Edge, NodeCollection, CopyNode, contract_copy_node, connect, contract, contract_between,
                                        contract_parallel, contract_trace_edges, outer_product,
                                        split_node, split_node_full_svd, split_node_qr, split_node_rq, copy,
                                        slice_edge,

@@ -26,6 +26,34 @@ def _resolve_backend(backend):
   return _rb(backend)
 
 
+class NodeCollection:
+  """`with NodeCollection(container):` -- every node created inside the block is added to `container`
+  (a list or a set); nested blocks collect into the innermost one (network_components.py:2189-2240)."""
+  _stack: List["NodeCollection"] = []
+
+  def __init__(self, container):
+    if not isinstance(container, (list, set)):
+      raise ValueError("Item passed to NodeCollection must be list or set")
+    self._container = container
+
+  def add(self, node) -> None:
+    if isinstance(self._container, set):
+      self._container.add(node)
+    else:
+      self._container.append(node)
+
+  def __enter__(self):
+    NodeCollection._stack.append(self)
+
+  def __exit__(self, exc_type, exc_val, exc_tb):
+    NodeCollection._stack.pop()
+
+  @classmethod
+  def _register(cls, node) -> None:
+    if cls._stack:
+      cls._stack[-1].add(node)
+
+
 class Edge:
   """A (possibly dangling) connection between one or two node axes."""
 
@@ -121,6 +149,7 @@ class Node:
                        f"axis_names length: {len(axis_names)}, shape length: {rank}")
     self.axis_names = list(axis_names) if axis_names is not None else [str(i) for i in range(rank)]
     self.edges: List[Edge] = [Edge(self, i, name=self.axis_names[i]) for i in range(rank)]
+    NodeCollection._register(self)  # pylint: disable=protected-access
 
   @property
   def shape(self) -> Tuple[int, ...]:
@@ -320,6 +349,7 @@ class CopyNode(Node):
                        f"axis_names length: {len(axis_names)}, shape length: {rank}")
     self.axis_names = list(axis_names) if axis_names is not None else [str(i) for i in range(rank)]
     self.edges = [Edge(self, i, name=self.axis_names[i]) for i in range(rank)]
+    NodeCollection._register(self)  # pylint: disable=protected-access
 
   @staticmethod
   def make_copy_tensor(rank: int, dimension: int, dtype) -> np.ndarray:

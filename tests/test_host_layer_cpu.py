@@ -459,3 +459,26 @@ def test_jit_decorator(be):
     by_arg(1, "BAD_NAME", 3)
   with pytest.raises(ValueError, match="did not specify a backend"):
     by_arg(1, 7, 3)
+
+
+def test_node_collection(be):
+  # network_components_free_test.py:1232-1275
+  box = []
+  with ta.NodeCollection(box):
+    a = ta.Node(np.eye(2), backend=be)
+    b = ta.Node(np.eye(3), backend=be)
+  c = ta.Node(np.eye(2), backend=be)
+  assert box == [a, b] and c not in box
+  bag = set()
+  with ta.NodeCollection(bag):
+    a = ta.CopyNode(rank=4, dimension=3, name="copier1", backend=be)
+    b = ta.Node(np.eye(3), backend=be)
+  assert bag == {a, b}
+  outer, inner = set(), set()
+  with ta.NodeCollection(outer):
+    with ta.NodeCollection(inner):
+      a, b = ta.Node(np.eye(2), backend=be), ta.Node(np.eye(3), backend=be)
+    d = ta.Node(np.eye(2), backend=be)
+  assert inner == {a, b} and outer == {d}
+  with pytest.raises(ValueError, match="must be list or set"):
+    ta.NodeCollection({})
