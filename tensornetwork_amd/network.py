@@ -142,6 +142,10 @@ class Node:
     if isinstance(tensor, Node):
       tensor = tensor.tensor
     self.tensor = self.backend.convert_to_tensor(tensor)
+    if name is not None and not isinstance(name, str):
+      raise TypeError("Node name should be str type")
+    if axis_names is not None and any(not isinstance(n, str) for n in axis_names):
+      raise TypeError("axis_names should be str type")
     self.name = name if name is not None else "__unnamed_node__"
     rank = len(self.backend.shape_tuple(self.tensor))
     if axis_names is not None and len(axis_names) != rank:

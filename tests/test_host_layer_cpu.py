@@ -482,3 +482,15 @@ def test_node_collection(be):
   assert inner == {a, b} and outer == {d}
   with pytest.raises(ValueError, match="must be list or set"):
     ta.NodeCollection({})
+
+
+def test_node_name_type_checks(be):
+  # network_components_free_test.py:1290-1330
+  with pytest.raises(TypeError, match="Node name should be str type"):
+    ta.Node(np.eye(2), name=["A"], backend=be)
+  with pytest.raises(TypeError, match="Node name should be str type"):
+    ta.Node(np.eye(2), name=1, backend=be)
+  with pytest.raises(TypeError, match="axis_names should be str type"):
+    ta.Node(np.eye(2), axis_names=[0, 1], backend=be)
+  with pytest.raises(ValueError, match="axis_names is not the same length"):
+    ta.Node(np.eye(2), axis_names=["a"], backend=be)
