@@ -273,3 +273,22 @@ def test_tfi_dmrg_and_correlators_vs_exact_diagonalisation(n, field):
   mid = n // 2
   xx_mid = [gs @ site_op(sx, mid) @ site_op(sx, j) @ gs for j in range(n)]
   np.testing.assert_allclose(state.measure_two_body_correlator(sx, sx, mid, range(n)), xx_mid, atol=1e-5)
+
+
+@pytest.mark.parametrize("backend_cls", [orc.OracleBackend, _KrylovSchurOracle])
+def test_infinite_mps_aklt_known_answer(backend_cls):
+  """The AKLT state as a one-site unit cell, scrambled by a random gauge: the transfer matrix has dominant
+  eigenvalue 1 and canonicalize() must find the two equal Schmidt values 1/sqrt(2) again."""
+  be = backend_cls()
+  sp, sm, sz = np.array([[0.0, 1.0], [0.0, 0.0]]), np.array([[0.0, 0.0], [1.0, 0.0]]), np.diag([1.0, -1.0])
+  aklt = np.stack([np.sqrt(2 / 3) * sp, -np.sqrt(1 / 3) * sz, -np.sqrt(2 / 3) * sm], axis=1)   # (D, d, D)
+  g = np.random.default_rng(5).standard_normal((2, 2)) + 2.0 * np.eye(2)
+  scrambled = np.einsum("ab,bsc,cd->asd", np.linalg.inv(g), aklt, g)
+  imps = tmps.InfiniteMPS([scrambled], be, center_position=0)
+  np.random.seed(2)
+  eta, _ = imps.transfer_matrix_eigs("left")
+  np.testing.assert_allclose(eta, 1.0, atol=1e-9)
+  imps.canonicalize()
+  schmidt = np.sort(np.abs(1.0 / np.diag(np.asarray(imps.connector_matrix))))
+  np.testing.assert_allclose(schmidt, [np.sqrt(0.5)] * 2, atol=1e-8)
+  assert imps.check_orthonormality("l", 0) < 1e-8
