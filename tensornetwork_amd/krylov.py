@@ -138,6 +138,89 @@ def eigsh_lanczos(be, A, args=None, initial_state=None, shape=None, dtype=None, 
   return eigvals[:numeig], eigenvectors
 
 
+def eigsh_lanczos_deferred(be, A, args=None, initial_state=None, shape=None, dtype=None, num_krylov_vecs=20,
+                           numeig=1, tol=1e-8, delta=1e-8, ndiag=20, reorthogonalize=False):
+  """`eigsh_lanczos` with the Krylov coefficients kept ON THE DEVICE between convergence checks.
+
+  The reference's loop reads two scalars back per iteration (the norm of the new vector and the diagonal
+  element): on a GPU that is two pipeline drains per matvec.  Here the recurrence divides / scales by the
+  0-d device tensors themselves, so nothing is read back until a convergence check (every `ndiag`
+  iterations) or the end, where all pending coefficients come back in one burst.  The `delta` test
+  (norm of a Krylov vector below `delta` = invariant subspace) is applied at those points too: vectors
+  built past such a breakdown are garbage, but they are cut off before anything uses them, so the
+  returned eigenpairs are the ones `eigsh_lanczos` returns.  Same arguments, errors and results.
+  Opt-in (see `FiniteDMRG.deferred_lanczos`) until it has been measured on the GPU."""
+  if args is None:
+    args = []
+  if num_krylov_vecs < numeig:
+    raise ValueError('`num_krylov_vecs` >= `numeig` required!')
+  if numeig > 1 and not reorthogonalize:
+    raise ValueError(
+        "Got numeig = {} > 1 and `reorthogonalize = False`. "
+        "Use `reorthogonalize=True` for `numeig > 1`".format(numeig))
+  if initial_state is None:
+    if (shape is None) or (dtype is None):
+      raise ValueError("if no `initial_state` is passed, then `shape` and"
+                       "`dtype` have to be provided")
+    initial_state = be.randn(shape, dtype)
+  if not be.is_tensor(initial_state):
+    raise TypeError("Expected a backend tensor. Got {}".format(type(initial_state)))
+
+  dev_dot = lambda a, b: be.tensordot(be.conj(_flat(be, a)), _flat(be, b), 1)      # 0-d device tensor
+  vector_n = be.divide(initial_state, be.norm(initial_state))
+  norms_dev, diags_dev, krylov = [], [], []       # device scalars of iterations not yet read back
+  norms, diags = [], []                           # host copies (same meaning as in eigsh_lanczos)
+  first, eigvalsold = True, None
+
+  def flush():
+    """Read the pending coefficients back; returns the number of usable Krylov vectors."""
+    for n_t, d_t in zip(norms_dev, diags_dev):
+      norms.append(float(np.real(be.item(n_t))))
+      diags.append(be.item(d_t))
+    del norms_dev[:], diags_dev[:]
+    for j, nrm in enumerate(norms):
+      if abs(nrm) < delta:
+        return j
+    return len(norms)
+
+  usable = None
+  for it in range(num_krylov_vecs):
+    nrm_t = be.norm(vector_n)
+    vector_n = be.divide(vector_n, nrm_t)
+    if reorthogonalize:
+      for v in krylov:
+        vector_n = be.subtraction(vector_n, be.multiply(v, dev_dot(v, vector_n)))
+    krylov.append(vector_n)
+    a_vec = A(vector_n, *args)
+    diag_t = dev_dot(vector_n, a_vec)
+    norms_dev.append(nrm_t)
+    diags_dev.append(diag_t)
+    if it > 0 and it % ndiag == 0 and it + 1 >= numeig:
+      usable = flush()
+      if usable < len(norms):
+        break
+      eigvals, _ = _small_eigh(be, _tridiag(diags, norms[1:]))
+      if not first and np.linalg.norm(eigvals[:numeig] - eigvalsold[:numeig]) < tol:
+        break
+      first = False
+      eigvalsold = eigvals[:numeig]
+    a_vec = be.subtraction(a_vec, be.multiply(krylov[-1], diag_t))
+    if it > 0:
+      a_vec = be.subtraction(a_vec, be.multiply(krylov[-2], nrm_t))
+    vector_n = a_vec
+
+  usable = flush()
+  norms, diags, krylov = norms[:usable], diags[:usable], krylov[:usable]
+  eigvals, u = _small_eigh(be, _tridiag(diags, norms[1:]))
+  eigenvectors = []
+  for n2 in range(min(numeig, len(eigvals))):
+    state = be.multiply(krylov[0], float(u[0, n2]))
+    for n1 in range(1, len(krylov)):
+      state = _axpy(be, state, float(u[n1, n2]), krylov[n1])
+    eigenvectors.append(be.divide(state, _norm(be, state)))
+  return eigvals[:numeig], eigenvectors
+
+
 def eigsh(be, A, args=None, initial_state=None, shape=None, dtype=None, num_krylov_vecs=50, numeig=6,
           tol=1e-8, which='LA', maxiter=None):
   """``numeig`` extremal eigenpairs of a Hermitian operator (interface of

@@ -565,8 +565,14 @@ class FiniteDMRG:
 
   def _lanczos(self, matvec, args, init, num_krylov_vecs, tol, delta, ndiag):
     be = self.backend
-    energies, states = be.eigsh_lanczos(A=matvec, args=args, initial_state=init, num_krylov_vecs=num_krylov_vecs,
-                                        numeig=1, tol=tol, delta=delta, ndiag=ndiag, reorthogonalize=False)
+    if getattr(self, "deferred_lanczos", False):
+      # opt-in: coefficients stay on the device between convergence checks (krylov.eigsh_lanczos_deferred)
+      from tensornetwork_amd import krylov  # pylint: disable=import-outside-toplevel
+      energies, states = krylov.eigsh_lanczos_deferred(be, matvec, args, init, None, None, num_krylov_vecs, 1, tol,
+                                                       delta, ndiag, False)
+    else:
+      energies, states = be.eigsh_lanczos(A=matvec, args=args, initial_state=init, num_krylov_vecs=num_krylov_vecs,
+                                          numeig=1, tol=tol, delta=delta, ndiag=ndiag, reorthogonalize=False)
     state = states[0]
     return energies[0], be.divide(state, float(np.real(be.item(be.norm(state)))))
 

@@ -12,6 +12,7 @@ ap.add_argument("--n", type=int, default=32)
 ap.add_argument("--bonds", default="64,128,256")
 ap.add_argument("--dtype", default="float32")
 ap.add_argument("--cpu-max", type=int, default=128)
+ap.add_argument("--deferred", action="store_true", help="device-resident Lanczos coefficients (krylov.eigsh_lanczos_deferred)")
 a = ap.parse_args()
 dt = np.dtype(a.dtype).type
 n = a.n
@@ -20,6 +21,7 @@ def run(be, D, sweeps):
   mpo = tmps.xxz_mpo(be, np.ones(n - 1), np.ones(n - 1), np.zeros(n), dtype=dt)
   state = tmps.FiniteMPS.random([2] * n, [min(D, 16)] * (n - 1), dt, be, seed=1)
   dm = tmps.FiniteDMRG(state, mpo)
+  dm.deferred_lanczos = a.deferred
   dm.run_two_site(max_bond_dim=D, num_sweeps=2, num_krylov_vecs=10)   # grow the bonds to D
   if hasattr(be, "synchronize"): be.synchronize()
   t0 = time.perf_counter()

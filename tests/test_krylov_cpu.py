@@ -183,3 +183,36 @@ def test_eigsh_complex_hermitian(which):
   np.testing.assert_allclose(eta, want, atol=1e-8)
   for e, v in zip(eta, vecs):
     np.testing.assert_allclose(h @ v, e * v, atol=1e-6)
+
+
+@pytest.mark.parametrize("reorth,numeig", [(False, 1), (True, 3)])
+@pytest.mark.parametrize("ndiag", [3, 20])
+def test_deferred_lanczos_matches_immediate(reorth, numeig, ndiag):
+  """The deferred-readback variant returns what eigsh_lanczos returns (same coefficients, read later)."""
+  be = orc.OracleBackend()
+  n = 40
+  h = _sym(n, 21)
+  init = np.random.default_rng(22).standard_normal(n)
+  mv = lambda x, m: m @ x
+  kw = dict(num_krylov_vecs=25, numeig=numeig, reorthogonalize=reorth, ndiag=ndiag, tol=1e-12)
+  e1, v1 = krylov.eigsh_lanczos(be, mv, [h], init, **kw)
+  e2, v2 = krylov.eigsh_lanczos_deferred(be, mv, [h], init, **kw)
+  np.testing.assert_allclose(e2, e1, rtol=1e-10, atol=1e-10)
+  for a, b in zip(v1, v2):
+    np.testing.assert_allclose(np.abs(a @ b), 1.0, atol=1e-8)
+
+
+def test_deferred_lanczos_invariant_subspace_and_errors():
+  be = orc.OracleBackend()
+  # the start vector spans a 2-dimensional invariant subspace: the third Krylov vector has norm ~ 0
+  h = np.diag([1.0, 2.0, 3.0, 4.0, 5.0])
+  init = np.array([1.0, 1.0, 0.0, 0.0, 0.0])
+  e1, _ = krylov.eigsh_lanczos(be, lambda x: h @ x, initial_state=init, num_krylov_vecs=5, delta=1e-8)
+  e2, v2 = krylov.eigsh_lanczos_deferred(be, lambda x: h @ x, initial_state=init, num_krylov_vecs=5, delta=1e-8)
+  np.testing.assert_allclose(e2, e1, atol=1e-12)
+  np.testing.assert_allclose(e2[0], 1.0, atol=1e-12)
+  assert np.all(np.isfinite(v2[0]))
+  with pytest.raises(ValueError, match="`num_krylov_vecs` >= `numeig` required!"):
+    krylov.eigsh_lanczos_deferred(be, lambda x: x, numeig=10, num_krylov_vecs=9, initial_state=np.ones(3))
+  with pytest.raises(TypeError, match="Expected a backend tensor"):
+    krylov.eigsh_lanczos_deferred(be, lambda x: x, initial_state=[1, 2, 3])

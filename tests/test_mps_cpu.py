@@ -292,3 +292,15 @@ def test_infinite_mps_aklt_known_answer(backend_cls):
   schmidt = np.sort(np.abs(1.0 / np.diag(np.asarray(imps.connector_matrix))))
   np.testing.assert_allclose(schmidt, [np.sqrt(0.5)] * 2, atol=1e-8)
   assert imps.check_orthonormality("l", 0) < 1e-8
+
+
+def test_dmrg_with_deferred_lanczos_readbacks():
+  """FiniteDMRG.deferred_lanczos = True (device-resident Krylov coefficients) reaches the same ground energy."""
+  be = orc.OracleBackend()
+  n = 6
+  eta = np.linalg.eigvalsh(xxz_dense(n, 1.0, 1.0, 0.0))
+  mpo = tmps.xxz_mpo(be, np.ones(n - 1), np.ones(n - 1), np.zeros(n))
+  state = tmps.FiniteMPS.random([2] * n, [16] * (n - 1), np.float64, be, seed=16)
+  dmrg = tmps.FiniteDMRG(state, mpo)
+  dmrg.deferred_lanczos = True
+  np.testing.assert_allclose(dmrg.run_two_site(max_bond_dim=16, num_sweeps=4, num_krylov_vecs=10), eta[0], atol=1e-7)
