@@ -52,3 +52,35 @@ def test_inv_expm_errors():
     orc.expm(np.ones((2, 2, 2)))
   with pytest.raises(ValueError, match="only supports N\\*N matrix"):
     orc.expm(np.ones((2, 3)))
+
+
+def test_three_way_bf16_split_arithmetic():
+  """The arithmetic behind the f32-on-bf16-cores GEMM (csrc/tnh_gemm.hip, f32_split3_*): hi = bf16(x),
+  mid = bf16(x - hi), lo = bf16(x - hi - mid) reproduce a normal float32 exactly, and the six products kept by
+  the kernel approximate a * b to ~2^-25 |a||b| -- restated with the oracle's bf16 rounding."""
+  from oracle import numpy_oracle as orc
+  rng = np.random.default_rng(5)
+  x = (rng.standard_normal(200000) * np.exp(rng.uniform(-60, 60, 200000))).astype(np.float32)
+  x = np.concatenate([x, np.float32([0.0, -0.0, 1.0, -1.0, 3.0e38, 1.1754944e-38, 1 + 2**-23, 1 - 2**-24])])
+
+  def split(v):
+    hi = orc.round_bf16(v).astype(np.float32)
+    r1 = (v - hi).astype(np.float32)
+    mid = orc.round_bf16(r1).astype(np.float32)
+    r2 = (r1 - mid).astype(np.float32)
+    lo = orc.round_bf16(r2).astype(np.float32)
+    return hi, mid, lo
+
+  hi, mid, lo = split(x)
+  # the two subtractions are exact in float32, so this is an identity for every normal input
+  assert np.array_equal(hi.astype(np.float64) + mid.astype(np.float64) + lo.astype(np.float64), x.astype(np.float64))
+  assert np.all(np.abs(mid) <= np.abs(hi) * 2.0**-8 + 1e-45) and np.all(np.abs(lo) <= np.abs(hi) * 2.0**-16 + 1e-45)
+  y = rng.standard_normal(x.size).astype(np.float32)
+  yh, ym, yl = split(y)
+  f = lambda p, q: p.astype(np.float64) * q.astype(np.float64)
+  six = f(lo, yh) + f(hi, yl) + f(mid, ym) + f(mid, yh) + f(hi, ym) + f(hi, yh)
+  exact = f(x, y)
+  ok = np.abs(exact) > 0
+  assert np.max(np.abs(six - exact)[ok] / np.abs(exact)[ok]) < 2.0**-24     # dropped terms: mid*lo, lo*mid, lo*lo
+  three = f(mid, yh) + f(hi, ym) + f(hi, yh)
+  assert np.max(np.abs(three - exact)[ok] / np.abs(exact)[ok]) > 2.0**-18    # why six products and not three
