@@ -286,6 +286,28 @@ int tnh_qr_work_bytes(int dtype, int64_t m, int64_t n, size_t* nbytes);
 int tnh_qr(int dtype, int64_t m, int64_t n, const void* A, void* Q, void* R,
            void* work);
 
+/* ---- K8: collectives over xGMI (RCCL) -------------------------------------------
+ * The reference has no distributed path; these serve the two
+ * partitions of SURVEY.md 8e -- bond-sliced contractor paths (ONE all-reduce of the
+ * small result) and an M-sharded pairwise contraction (ONE all-gather of the row
+ * blocks).  One process per GPU, one communicator per process, every collective is
+ * enqueued on the library stream (tnh_stream), in order with the kernels around it.
+ * librccl is opened lazily by the first two calls below.
+ * Bootstrap: rank 0 calls tnh_comm_unique_id, ships the TNH_COMM_ID_BYTES bytes to
+ * the other ranks over a host channel, then every rank calls tnh_comm_init. */
+#define TNH_COMM_ID_BYTES 128
+int tnh_comm_unique_id(void* host_id);
+int tnh_comm_init(const void* host_id, int rank, int world);
+/* *world = 0 when no communicator exists. */
+int tnh_comm_info(int* rank, int* world);
+int tnh_comm_destroy(void);
+/* In place; op: 0 sum, 1 max, 2 min (complex dtypes: sum only, on (re, im) separately). */
+int tnh_allreduce(void* buf, int64_t count, int dtype, int op);
+int tnh_allreduce_sum(void* buf, int64_t count, int dtype);
+/* dst (world * nbytes) = concatenation of every rank's src (nbytes each), in rank order. */
+int tnh_allgather(void* dst, const void* src, int64_t nbytes);
+int tnh_broadcast(void* buf, int64_t nbytes, int root);
+
 #ifdef __cplusplus
 }
 #endif

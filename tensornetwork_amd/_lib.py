@@ -103,6 +103,14 @@ SIGNATURES = {
                                      c_void_p]),
     "tnh_qr_work_bytes": (c_int, [c_int, c_int64, c_int64, POINTER(c_size_t)]),
     "tnh_qr": (c_int, [c_int, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "tnh_comm_unique_id": (c_int, [c_void_p]),
+    "tnh_comm_init": (c_int, [c_void_p, c_int, c_int]),
+    "tnh_comm_info": (c_int, [POINTER(c_int), POINTER(c_int)]),
+    "tnh_comm_destroy": (c_int, []),
+    "tnh_allreduce": (c_int, [c_void_p, c_int64, c_int, c_int]),
+    "tnh_allreduce_sum": (c_int, [c_void_p, c_int64, c_int]),
+    "tnh_allgather": (c_int, [c_void_p, c_void_p, c_int64]),
+    "tnh_broadcast": (c_int, [c_void_p, c_int64, c_int]),
 }
 
 _lib = None

@@ -1,0 +1,189 @@
+// K8: collectives over xGMI (RCCL) on the library's own stream.
+//
+// One process per GPU, one communicator per process.  The reference has no
+// distributed path; these entry points exist for the two
+// partitions of SURVEY.md 8e: bond-sliced contractor paths (ONE all-reduce of
+// the small result) and an M-sharded pairwise contraction (ONE all-gather of
+// the row blocks).  Everything is enqueued on tnh::stream(), i.e. in order
+// with the kernels that produced the buffers -- no device-wide synchronise on
+// either side of a collective.
+//
+// librccl is opened lazily (dlopen) by tnh_comm_unique_id / tnh_comm_init, so
+// single-GPU processes never load it.  Bootstrap: rank 0 calls
+// tnh_comm_unique_id and hands the 128 bytes to the other ranks over any host
+// channel (tensornetwork_amd/comm.py uses a TCP rendezvous on
+// MASTER_ADDR:MASTER_PORT+k); every rank then calls tnh_comm_init.
+#include "tnh_internal.h"
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+namespace tnh {
+namespace {
+
+struct RcclApi {
+  void* handle = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+
+RcclApi g_api;
+ncclComm_t g_comm = nullptr;
+int g_rank = 0, g_world = 1;
+
+template <typename F>
+bool load_sym(F& slot, const char* name) {
+  slot = reinterpret_cast<F>(dlsym(g_api.handle, name));
+  return slot != nullptr;
+}
+
+int load_rccl() {
+  if (g_api.handle) return TNH_OK;
+  const char* override_path = getenv("TNH_RCCL_LIBRARY");
+  const char* candidates[] = {override_path, "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+  for (const char* c : candidates) {
+    if (!c || !*c) continue;
+    g_api.handle = dlopen(c, RTLD_NOW | RTLD_LOCAL);
+    if (g_api.handle) break;
+  }
+  if (!g_api.handle) {
+    set_error("cannot load librccl (%s)", dlerror());
+    return TNH_ERR_UNSUPPORTED;
+  }
+  const bool ok = load_sym(g_api.GetUniqueId, "ncclGetUniqueId") && load_sym(g_api.CommInitRank, "ncclCommInitRank") &&
+                  load_sym(g_api.CommDestroy, "ncclCommDestroy") && load_sym(g_api.AllReduce, "ncclAllReduce") &&
+                  load_sym(g_api.AllGather, "ncclAllGather") && load_sym(g_api.Broadcast, "ncclBroadcast") &&
+                  load_sym(g_api.GetErrorString, "ncclGetErrorString");
+  if (!ok) {
+    set_error("librccl is missing a required symbol (%s)", dlerror());
+    dlclose(g_api.handle);
+    g_api = RcclApi();
+    return TNH_ERR_UNSUPPORTED;
+  }
+  return TNH_OK;
+}
+
+#define TNH_NCCL(call)                                                                        \
+  do {                                                                                        \
+    ncclResult_t _r = (call);                                                                 \
+    if (_r != ncclSuccess) {                                                                  \
+      set_error("%s failed: %s (%s:%d)", #call, g_api.GetErrorString(_r), __FILE__, __LINE__); \
+      return TNH_ERR_HIP;                                                                     \
+    }                                                                                         \
+  } while (0)
+
+// element type RCCL reduces in, and how many of them one element of `dt` is
+bool reduce_type(int dt, ncclDataType_t* t, int* mult) {
+  *mult = 1;
+  switch (dt) {
+    case TNH_F32: *t = ncclFloat32; return true;
+    case TNH_F64: *t = ncclFloat64; return true;
+    case TNH_BF16: *t = ncclBfloat16; return true;
+    case TNH_F16: *t = ncclFloat16; return true;
+    case TNH_I32: *t = ncclInt32; return true;
+    case TNH_I64: *t = ncclInt64; return true;
+    case TNH_C64: *t = ncclFloat32; *mult = 2; return true;   // sum acts on (re, im) separately
+    case TNH_C128: *t = ncclFloat64; *mult = 2; return true;
+    default: return false;
+  }
+}
+
+}  // namespace
+}  // namespace tnh
+
+using namespace tnh;
+
+extern "C" {
+
+int tnh_comm_unique_id(void* host_id) {
+  TNH_REQUIRE(host_id != nullptr, "tnh_comm_unique_id: null buffer");
+  int rc = load_rccl();
+  if (rc != TNH_OK) return rc;
+  ncclUniqueId id;
+  TNH_NCCL(g_api.GetUniqueId(&id));
+  static_assert(sizeof(id) == TNH_COMM_ID_BYTES, "ncclUniqueId size");
+  memcpy(host_id, &id, sizeof(id));
+  return TNH_OK;
+}
+
+int tnh_comm_init(const void* host_id, int rank, int world) {
+  TNH_NEED_INIT();
+  TNH_REQUIRE(host_id != nullptr && world >= 1 && rank >= 0 && rank < world, "tnh_comm_init: bad rank %d / world %d",
+              rank, world);
+  TNH_REQUIRE(g_comm == nullptr, "tnh_comm_init: a communicator already exists (tnh_comm_destroy first)");
+  int rc = load_rccl();
+  if (rc != TNH_OK) return rc;
+  ncclUniqueId id;
+  memcpy(&id, host_id, sizeof(id));
+  TNH_NCCL(g_api.CommInitRank(&g_comm, world, id, rank));
+  g_rank = rank;
+  g_world = world;
+  return TNH_OK;
+}
+
+int tnh_comm_info(int* rank, int* world) {
+  if (rank) *rank = g_comm ? g_rank : 0;
+  if (world) *world = g_comm ? g_world : 0;   // 0 = no communicator
+  return TNH_OK;
+}
+
+int tnh_comm_destroy(void) {
+  if (g_comm) {
+    if (stream()) hipStreamSynchronize(stream());
+    ncclResult_t r = g_api.CommDestroy(g_comm);
+    g_comm = nullptr;
+    g_rank = 0;
+    g_world = 1;
+    if (r != ncclSuccess) {
+      set_error("ncclCommDestroy failed: %s", g_api.GetErrorString(r));
+      return TNH_ERR_HIP;
+    }
+  }
+  return TNH_OK;
+}
+
+int tnh_allreduce(void* buf, int64_t count, int dtype, int op) {
+  TNH_NEED_INIT();
+  TNH_REQUIRE(g_comm != nullptr, "tnh_allreduce: no communicator (tnh_comm_init)");
+  TNH_REQUIRE(buf != nullptr || count == 0, "tnh_allreduce: null buffer");
+  TNH_REQUIRE(count >= 0, "tnh_allreduce: negative count");
+  ncclDataType_t t;
+  int mult;
+  TNH_REQUIRE(reduce_type(dtype, &t, &mult), "tnh_allreduce: unsupported dtype %d", dtype);
+  TNH_REQUIRE(op >= 0 && op <= 2, "tnh_allreduce: op must be 0 (sum), 1 (max) or 2 (min)");
+  TNH_REQUIRE(mult == 1 || op == 0, "tnh_allreduce: complex tensors support sum only");
+  if (count == 0) return TNH_OK;
+  const ncclRedOp_t ops[3] = {ncclSum, ncclMax, ncclMin};
+  TNH_NCCL(g_api.AllReduce(buf, buf, (size_t)count * mult, t, ops[op], g_comm, stream()));
+  return TNH_OK;
+}
+
+int tnh_allreduce_sum(void* buf, int64_t count, int dtype) { return tnh_allreduce(buf, count, dtype, 0); }
+
+int tnh_allgather(void* dst, const void* src, int64_t nbytes) {
+  TNH_NEED_INIT();
+  TNH_REQUIRE(g_comm != nullptr, "tnh_allgather: no communicator (tnh_comm_init)");
+  TNH_REQUIRE(nbytes >= 0 && (nbytes == 0 || (dst && src)), "tnh_allgather: bad arguments");
+  if (nbytes == 0) return TNH_OK;
+  // 16-byte words where the block allows it: fewer, wider elements for RCCL's copy kernels
+  if (nbytes % 8 == 0)
+    TNH_NCCL(g_api.AllGather(src, dst, (size_t)(nbytes / 8), ncclInt64, g_comm, stream()));
+  else
+    TNH_NCCL(g_api.AllGather(src, dst, (size_t)nbytes, ncclInt8, g_comm, stream()));
+  return TNH_OK;
+}
+
+int tnh_broadcast(void* buf, int64_t nbytes, int root) {
+  TNH_NEED_INIT();
+  TNH_REQUIRE(g_comm != nullptr, "tnh_broadcast: no communicator (tnh_comm_init)");
+  TNH_REQUIRE(nbytes >= 0 && (nbytes == 0 || buf) && root >= 0 && root < g_world, "tnh_broadcast: bad arguments");
+  if (nbytes == 0) return TNH_OK;
+  TNH_NCCL(g_api.Broadcast(buf, buf, (size_t)nbytes, ncclInt8, root, g_comm, stream()));
+  return TNH_OK;
+}
+
+}  // extern "C"

@@ -132,6 +132,44 @@ __device__ __forceinline__ cf64 apply_binary(int op, cf64 a, cf64 b) {
   }
 }
 
+// integers: add / sub / mul wrap like NumPy's; division truncates toward zero and x / 0 = 0 (the host
+// shim routes true division through float64 as NumPy does; this only keeps the kernel total);
+// pow by repeated squaring for non-negative exponents.
+template <typename I, typename U>
+__device__ __forceinline__ I int_binary(int op, I a, I b) {
+  switch (op) {
+    case TNH_OP_ADD: return (I)((U)a + (U)b);
+    case TNH_OP_SUB: return (I)((U)a - (U)b);
+    case TNH_OP_MUL: return (I)((U)a * (U)b);
+    case TNH_OP_DIV: return (b == 0 || (b == -1 && a == (I)((U)1 << (sizeof(I) * 8 - 1)))) ? 0 : a / b;
+    default: {
+      if (b < 0) return 0;
+      U r = 1, x = (U)a;
+      for (U e = (U)b; e; e >>= 1) {
+        if (e & 1) r *= x;
+        x *= x;
+      }
+      return (I)r;
+    }
+  }
+}
+__device__ __forceinline__ int32_t apply_binary(int op, int32_t a, int32_t b) { return int_binary<int32_t, uint32_t>(op, a, b); }
+__device__ __forceinline__ int64_t apply_binary(int op, int64_t a, int64_t b) { return int_binary<int64_t, uint64_t>(op, a, b); }
+template <typename I>
+__device__ __forceinline__ I int_unary(int op, I x) {
+  switch (op) {
+    case TNH_OP_ABS: return x < 0 ? (I)(0 - x) : x;
+    case TNH_OP_SIGN: return (x > 0) - (x < 0);
+    case TNH_OP_NEG: return (I)(0 - x);
+    case TNH_OP_IMAG: return 0;
+    default: return x;   // conj / real / copy; transcendental ops are promoted to float on the host
+  }
+}
+__device__ __forceinline__ int32_t apply_unary(int op, int32_t x) { return int_unary<int32_t>(op, x); }
+__device__ __forceinline__ int64_t apply_unary(int op, int64_t x) { return int_unary<int64_t>(op, x); }
+__device__ __forceinline__ int32_t from_scalar(int32_t, double re, double) { return (int32_t)(int64_t)re; }
+__device__ __forceinline__ int64_t from_scalar(int64_t, double re, double) { return (int64_t)re; }
+
 __device__ __forceinline__ float from_scalar(float, double re, double) { return (float)re; }
 __device__ __forceinline__ double from_scalar(double, double re, double) { return re; }
 __device__ __forceinline__ cf32 from_scalar(cf32, double re, double im) { return {(float)re, (float)im}; }
@@ -318,6 +356,8 @@ __global__ __launch_bounds__(256) void random_kernel(typename Tr<DT>::S* __restr
 
 __device__ __forceinline__ double to_double(float x) { return (double)x; }
 __device__ __forceinline__ double to_double(double x) { return x; }
+__device__ __forceinline__ double to_double(int32_t x) { return (double)x; }
+__device__ __forceinline__ double to_double(int64_t x) { return (double)x; }
 
 template <int SRC, int DST>
 __global__ __launch_bounds__(256) void cast_kernel(typename Tr<DST>::S* __restrict__ dst,
@@ -363,6 +403,8 @@ static int cast_from(void* dst, int dst_dtype, const void* src, int64_t n) {
     TNH_CAST_CASE(TNH_F16)
     TNH_CAST_CASE(TNH_C64)
     TNH_CAST_CASE(TNH_C128)
+    TNH_CAST_CASE(TNH_I32)
+    TNH_CAST_CASE(TNH_I64)
     default:
       set_error("unsupported cast target %d", dst_dtype);
       return TNH_ERR_UNSUPPORTED;
@@ -396,7 +438,7 @@ int tnh_unary(int op, void* dst, const void* src, int64_t n, int dtype) {
     TNH_LAUNCH_CHECK();
     return TNH_OK;
   }
-  TNH_DISPATCH_FLOAT(dtype, hipLaunchKernelGGL((unary_kernel<DT>), dim3(g), dim3(256), 0, stream(), op,
+  TNH_DISPATCH_NUM(dtype, hipLaunchKernelGGL((unary_kernel<DT>), dim3(g), dim3(256), 0, stream(), op,
                                                (typename Tr<DT>::S*)dst,
                                                (const typename Tr<DT>::S*)src, n));
   TNH_LAUNCH_CHECK();
@@ -432,7 +474,7 @@ int tnh_binary(int op, void* dst, const void* a, const void* b, int rank, const 
   const unsigned g = grid_for(p.total);
   // (rows, cols) op vector fast paths
   if (p.rank == 2 && p.sa[0] == p.shape[1] && p.sa[1] == 1 && p.sb[0] == 0 && p.sb[1] == 1) {
-    TNH_DISPATCH_FLOAT(dtype, hipLaunchKernelGGL((binary_rowcol_kernel<DT, true>), dim3(g), dim3(256), 0,
+    TNH_DISPATCH_NUM(dtype, hipLaunchKernelGGL((binary_rowcol_kernel<DT, true>), dim3(g), dim3(256), 0,
                                                  stream(), op, (typename Tr<DT>::S*)dst,
                                                  (const typename Tr<DT>::S*)a,
                                                  (const typename Tr<DT>::S*)b, p.shape[0], p.shape[1], 0));
@@ -440,7 +482,7 @@ int tnh_binary(int op, void* dst, const void* a, const void* b, int rank, const 
     return TNH_OK;
   }
   if (p.rank == 2 && p.sb[0] == p.shape[1] && p.sb[1] == 1 && p.sa[0] == 1 && p.sa[1] == 0) {
-    TNH_DISPATCH_FLOAT(dtype, hipLaunchKernelGGL((binary_rowcol_kernel<DT, false>), dim3(g), dim3(256), 0,
+    TNH_DISPATCH_NUM(dtype, hipLaunchKernelGGL((binary_rowcol_kernel<DT, false>), dim3(g), dim3(256), 0,
                                                  stream(), op, (typename Tr<DT>::S*)dst,
                                                  (const typename Tr<DT>::S*)b,
                                                  (const typename Tr<DT>::S*)a, p.shape[0], p.shape[1], 1));
@@ -448,7 +490,7 @@ int tnh_binary(int op, void* dst, const void* a, const void* b, int rank, const 
     return TNH_OK;
   }
   if (p.rank == 2 && p.sa[0] == p.shape[1] && p.sa[1] == 1 && p.sb[0] == 1 && p.sb[1] == 0) {
-    TNH_DISPATCH_FLOAT(dtype, hipLaunchKernelGGL((binary_rowcol_kernel<DT, false>), dim3(g), dim3(256), 0,
+    TNH_DISPATCH_NUM(dtype, hipLaunchKernelGGL((binary_rowcol_kernel<DT, false>), dim3(g), dim3(256), 0,
                                                  stream(), op, (typename Tr<DT>::S*)dst,
                                                  (const typename Tr<DT>::S*)a,
                                                  (const typename Tr<DT>::S*)b, p.shape[0], p.shape[1], 0));
@@ -461,7 +503,7 @@ int tnh_binary(int op, void* dst, const void* a, const void* b, int rank, const 
     p.sa[0] = 0;
     p.sb[0] = 0;
   }
-  TNH_DISPATCH_FLOAT(dtype, hipLaunchKernelGGL((binary_kernel<DT>), dim3(g), dim3(256), 0, stream(), op,
+  TNH_DISPATCH_NUM(dtype, hipLaunchKernelGGL((binary_kernel<DT>), dim3(g), dim3(256), 0, stream(), op,
                                                (typename Tr<DT>::S*)dst, (const typename Tr<DT>::S*)a,
                                                (const typename Tr<DT>::S*)b, p));
   TNH_LAUNCH_CHECK();
@@ -476,7 +518,7 @@ int tnh_binary_scalar(int op, void* dst, const void* src, double re, double im, 
   if (n == 0) return TNH_OK;
   TNH_REQUIRE(dst && src, "null pointer");
   const unsigned g = grid_for(n);
-  TNH_DISPATCH_FLOAT(dtype, hipLaunchKernelGGL((binary_scalar_kernel<DT>), dim3(g), dim3(256), 0, stream(),
+  TNH_DISPATCH_NUM(dtype, hipLaunchKernelGGL((binary_scalar_kernel<DT>), dim3(g), dim3(256), 0, stream(),
                                                op, (typename Tr<DT>::S*)dst,
                                                (const typename Tr<DT>::S*)src, re, im, scalar_left, n));
   TNH_LAUNCH_CHECK();
@@ -508,7 +550,7 @@ int tnh_masked_fill(void* dst, const void* src, const void* mask, double re, dou
   if (n == 0) return TNH_OK;
   TNH_REQUIRE(dst && src && mask, "null pointer");
   const unsigned g = grid_for(n);
-  TNH_DISPATCH_FLOAT(dtype, hipLaunchKernelGGL((masked_fill_kernel<DT>), dim3(g), dim3(256), 0, stream(),
+  TNH_DISPATCH_NUM(dtype, hipLaunchKernelGGL((masked_fill_kernel<DT>), dim3(g), dim3(256), 0, stream(),
                                                (typename Tr<DT>::S*)dst, (const typename Tr<DT>::S*)src,
                                                (const int32_t*)mask, re, im, n));
   TNH_LAUNCH_CHECK();
@@ -521,7 +563,7 @@ int tnh_fill(void* dst, double re, double im, int64_t n, int dtype) {
   if (n == 0) return TNH_OK;
   TNH_REQUIRE(dst != nullptr, "null pointer");
   const unsigned g = grid_for(n);
-  TNH_DISPATCH_FLOAT(dtype, hipLaunchKernelGGL((fill_kernel<DT>), dim3(g), dim3(256), 0, stream(),
+  TNH_DISPATCH_NUM(dtype, hipLaunchKernelGGL((fill_kernel<DT>), dim3(g), dim3(256), 0, stream(),
                                                (typename Tr<DT>::S*)dst, re, im, n));
   TNH_LAUNCH_CHECK();
   return TNH_OK;
@@ -533,7 +575,7 @@ int tnh_eye(void* dst, int64_t rows, int64_t cols, int dtype) {
   if (rows * cols == 0) return TNH_OK;
   TNH_REQUIRE(dst != nullptr, "null pointer");
   const unsigned g = grid_for(rows * cols);
-  TNH_DISPATCH_FLOAT(dtype, hipLaunchKernelGGL((eye_kernel<DT>), dim3(g), dim3(256), 0, stream(),
+  TNH_DISPATCH_NUM(dtype, hipLaunchKernelGGL((eye_kernel<DT>), dim3(g), dim3(256), 0, stream(),
                                                (typename Tr<DT>::S*)dst, rows, cols));
   TNH_LAUNCH_CHECK();
   return TNH_OK;
@@ -563,6 +605,8 @@ int tnh_cast(void* dst, int dst_dtype, const void* src, int src_dtype, int64_t n
     case TNH_F16: return cast_from<TNH_F16>(dst, dst_dtype, src, n);
     case TNH_C64: return cast_from<TNH_C64>(dst, dst_dtype, src, n);
     case TNH_C128: return cast_from<TNH_C128>(dst, dst_dtype, src, n);
+    case TNH_I32: return cast_from<TNH_I32>(dst, dst_dtype, src, n);
+    case TNH_I64: return cast_from<TNH_I64>(dst, dst_dtype, src, n);
     default:
       set_error("unsupported cast source %d", src_dtype);
       return TNH_ERR_UNSUPPORTED;

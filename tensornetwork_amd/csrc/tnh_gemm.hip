@@ -341,6 +341,10 @@ __device__ __forceinline__ cf64 fma_t(cf64 a, cf64 b, cf64 c) {
   return {fma(a.re, b.re, fma(-a.im, b.im, c.re)), fma(a.re, b.im, fma(a.im, b.re, c.im))};
 }
 
+__device__ __forceinline__ int32_t fma_t(int32_t a, int32_t b, int32_t c) { return (int32_t)((uint32_t)a * (uint32_t)b + (uint32_t)c); }
+__device__ __forceinline__ int64_t fma_t(int64_t a, int64_t b, int64_t c) { return (int64_t)((uint64_t)a * (uint64_t)b + (uint64_t)c); }
+__device__ __forceinline__ int32_t scale_t(int32_t a, double s) { return (s == 1.0) ? a : (int32_t)((double)a * s); }
+__device__ __forceinline__ int64_t scale_t(int64_t a, double s) { return (s == 1.0) ? a : (int64_t)((double)a * s); }
 __device__ __forceinline__ double scale_t(double a, double s) { return a * s; }
 __device__ __forceinline__ cf32 scale_t(cf32 a, double s) { return {a.re * (float)s, a.im * (float)s}; }
 __device__ __forceinline__ cf64 scale_t(cf64 a, double s) { return {a.re * s, a.im * s}; }
@@ -655,7 +659,7 @@ int tnh_gemm_ex(int in_dtype, int out_dtype, int transA, int transB, int64_t M, 
                 double beta) {
   TNH_NEED_INIT();
   TNH_REQUIRE(M >= 0 && N >= 0 && K >= 0 && batch >= 0, "negative GEMM extent");
-  TNH_REQUIRE(in_dtype >= TNH_F32 && in_dtype <= TNH_C128, "bad GEMM dtype %d", in_dtype);
+  TNH_REQUIRE(in_dtype >= TNH_F32 && in_dtype <= TNH_I64, "bad GEMM dtype %d", in_dtype);
   const bool half_in = (in_dtype == TNH_BF16 || in_dtype == TNH_F16);
   TNH_REQUIRE(out_dtype == in_dtype || (half_in && out_dtype == TNH_F32),
               "unsupported GEMM output dtype %d for input dtype %d", out_dtype, in_dtype);
@@ -687,7 +691,8 @@ int tnh_gemm_ex(int in_dtype, int out_dtype, int transA, int transB, int64_t M, 
   // 262144-long dot product took 0.86 ms on ONE CU -- so K is cut into slices computed as one
   // strided-batched GEMM into f32 / f64 partials, summed by the K4 reduction (fixed order).
   const bool cplx_in = (in_dtype == TNH_C64 || in_dtype == TNH_C128);
-  if (plain && !cplx_in && batch == 1 && ldc == N && K >= 4096 && g_variant == 0 && !g_in_splitk) {
+  const bool int_in = (in_dtype == TNH_I32 || in_dtype == TNH_I64);   // exact integer products: VALU kernel only
+  if (plain && !cplx_in && !int_in && batch == 1 && ldc == N && K >= 4096 && g_variant == 0 && !g_in_splitk) {
     const int64_t tiles = ((M + 127) / 128) * ((N + 127) / 128);
     int64_t splits = std::min<int64_t>({K / 1024, (2 * (int64_t)num_cus()) / tiles, 256});
     if (tiles * 4 <= (int64_t)num_cus() && splits >= 2) {
@@ -773,7 +778,7 @@ int tnh_gemm_ex(int in_dtype, int out_dtype, int transA, int transB, int64_t M, 
   g.alpha = alpha;
   g.beta = beta;
 
-  const bool use_valu = (g_variant == 2) || in_dtype == TNH_C64 || in_dtype == TNH_C128;
+  const bool use_valu = (g_variant == 2) || in_dtype == TNH_C64 || in_dtype == TNH_C128 || int_in;
   const int esz_in = dtype_size(in_dtype);
   auto shifted = [&](int64_t b0) {
     GemmArgs h = g;
@@ -787,8 +792,8 @@ int tnh_gemm_ex(int in_dtype, int out_dtype, int transA, int transB, int64_t M, 
     return launch_batched(
         [&](const GemmArgs&, int64_t b0, dim3 grid) -> int {
           GemmArgs h = shifted(b0);
-          TNH_DISPATCH_FLOAT(in_dtype, hipLaunchKernelGGL((gemm_valu_kernel<DT>), grid, dim3(256), 0,
-                                                          stream(), h));
+          TNH_DISPATCH_NUM(in_dtype, hipLaunchKernelGGL((gemm_valu_kernel<DT>), grid, dim3(256), 0,
+                                                        stream(), h));
           return 0;
         },
         g, batch, 64, 64);

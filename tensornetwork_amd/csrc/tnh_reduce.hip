@@ -22,11 +22,17 @@ template <> struct AccStore<float> { using S = float; };
 template <> struct AccStore<double> { using S = double; };
 template <> struct AccStore<cf32> { using S = cf32; };
 template <> struct AccStore<cf64> { using S = cf64; };
+template <> struct AccStore<int32_t> { using S = int32_t; };
+template <> struct AccStore<int64_t> { using S = int64_t; };
 
 __device__ __forceinline__ float tf_abs2(float x) { return x * x; }
 __device__ __forceinline__ double tf_abs2(double x) { return x * x; }
 __device__ __forceinline__ cf32 tf_abs2(cf32 x) { return {x.re * x.re + x.im * x.im, 0.f}; }
 __device__ __forceinline__ cf64 tf_abs2(cf64 x) { return {x.re * x.re + x.im * x.im, 0.0}; }
+__device__ __forceinline__ int32_t tf_abs2(int32_t x) { return x * x; }
+__device__ __forceinline__ int64_t tf_abs2(int64_t x) { return x * x; }
+__device__ __forceinline__ int32_t tf_sqrt(int32_t x) { return x; }   // norm of integer tensors is taken in float on the host
+__device__ __forceinline__ int64_t tf_sqrt(int64_t x) { return x; }
 __device__ __forceinline__ float tf_sqrt(float x) { return sqrtf(x); }
 __device__ __forceinline__ double tf_sqrt(double x) { return sqrt(x); }
 __device__ __forceinline__ cf32 tf_sqrt(cf32 x) { return {sqrtf(x.re), 0.f}; }
@@ -195,7 +201,7 @@ int tnh_trace_last2(void* dst, const void* src, int64_t outer, int64_t n, int64_
   }
   TNH_REQUIRE(src != nullptr, "null pointer");
   const char* base = (const char*)src + start * esz;
-  TNH_DISPATCH_FLOAT(dtype, return (reduce_rows<DT, false, false>(dst, base, outer, len, m + 1, n * m)));
+  TNH_DISPATCH_NUM(dtype, return (reduce_rows<DT, false, false>(dst, base, outer, len, m + 1, n * m)));
   return TNH_OK;
 }
 
@@ -212,9 +218,9 @@ int tnh_sum_mid(void* dst, const void* src, int64_t outer, int64_t reduce, int64
   }
   TNH_REQUIRE(src != nullptr, "null pointer");
   if (inner == 1) {
-    TNH_DISPATCH_FLOAT(dtype, return (reduce_rows<DT, false, false>(dst, src, outer, reduce, 1, reduce)));
+    TNH_DISPATCH_NUM(dtype, return (reduce_rows<DT, false, false>(dst, src, outer, reduce, 1, reduce)));
   } else {
-    TNH_DISPATCH_FLOAT(dtype, return (reduce_mid<DT>(dst, src, outer, reduce, inner)));
+    TNH_DISPATCH_NUM(dtype, return (reduce_mid<DT>(dst, src, outer, reduce, inner)));
   }
   return TNH_OK;
 }

@@ -173,6 +173,10 @@ class _Block:
     self.ptr = None
 
 
+def _rebuild_bf16(host):
+  return DeviceTensor.from_numpy(host, dtype=bfloat16)
+
+
 class DeviceTensor:
   """Dense row-major tensor in HBM."""
   __slots__ = ("_block", "_offset", "_shape", "_code", "__weakref__")
@@ -294,7 +298,31 @@ class DeviceTensor:
     return self._shape[0]
 
   def __repr__(self):
-    return f"DeviceTensor(shape={self._shape}, dtype={self.dtype}, device=hip:{_lib.current_device()})"
+    # small tensors print their values the way an ndarray does (the reference's Node.__repr__ embeds
+    # repr(tensor), network_components.py:626-636, and its tests look for the values in it)
+    head = f"DeviceTensor(shape={self._shape}, dtype={self.dtype}, device=hip:{_lib.current_device()}"
+    if 0 < self.size <= 64:
+      try:
+        return head + ", data=" + np.array2string(self.numpy(), separator=", ").replace("\n", "") + ")"
+      except Exception:  # pylint: disable=broad-except
+        pass
+    return head + ")"
+
+  # -- copies: a DeviceTensor owns device memory, so copy / deepcopy / pickle go through real copies
+  def __copy__(self):
+    return self.__deepcopy__({})
+
+  def __deepcopy__(self, memo):
+    out = DeviceTensor.empty(self._shape, self._code)
+    if self.nbytes:
+      _lib.check(_lib.lib().tnh_d2d(ctypes.c_void_p(out.ptr), ctypes.c_void_p(self.ptr), self.nbytes), "tnh_d2d")
+    memo[id(self)] = out
+    return out
+
+  def __reduce__(self):
+    if self._code == _lib.BF16:
+      return (_rebuild_bf16, (self.numpy(),))
+    return (DeviceTensor.from_numpy, (self.numpy(),))
 
   # -- operators: forwarded to the backend singleton ----------------------------
   def _backend(self):

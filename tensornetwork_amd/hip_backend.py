@@ -20,6 +20,8 @@ from tensornetwork_amd.device_tensor import (DeviceTensor, bfloat16, public_dtyp
                                              tnh_dtype)
 
 _FLOAT_CODES = (_lib.F32, _lib.F64, _lib.BF16, _lib.F16, _lib.C64, _lib.C128)
+_INT_CODES = (_lib.I32, _lib.I64)
+_NUM_CODES = _FLOAT_CODES + _INT_CODES   # everything the arithmetic kernels take (ints: exact, wrap-around)
 _HALF = (_lib.BF16, _lib.F16)
 _REAL_OF = {_lib.C64: _lib.F32, _lib.C128: _lib.F64}
 # promotion lattice for mixed-dtype binary ops / contractions (numpy's rules,
@@ -41,8 +43,13 @@ def _prod(xs):
 def _promote(c1, c2):
   if c1 == c2:
     return c1
-  if c1 not in _RANK or c2 not in _RANK:
-    raise TypeError("integer tensors only support data-movement operations on the hip backend")
+  i1, i2 = c1 in _INT_CODES, c2 in _INT_CODES
+  if i1 and i2:
+    return _lib.I64
+  if i1 or i2:
+    # NumPy: int32 / int64 with a float -> float64, with a complex -> complex128
+    other = c2 if i1 else c1
+    return _lib.C128 if other in _REAL_OF else _lib.F64
   if {c1, c2} == {_lib.BF16, _lib.F16}:
     return _lib.F32
   hi = c1 if _RANK[c1] >= _RANK[c2] else c2
@@ -77,6 +84,16 @@ class HipBackend(BackendBase):
     self._device = device
     self._lib = None
 
+  # the backend is a per-process singleton bound to one device: copies are the object itself
+  def __copy__(self):
+    return self
+
+  def __deepcopy__(self, memo):
+    return self
+
+  def __reduce__(self):
+    return (get_hip_backend, ())
+
   # ------------------------------------------------------------------ plumbing
   @property
   def lib(self):
@@ -92,6 +109,12 @@ class HipBackend(BackendBase):
     if t.code not in _FLOAT_CODES:
       raise NotImplementedError(f"{what} is not implemented for dtype {t.dtype} on the hip backend")
 
+  def _check_num(self, t, what):
+    # int32 / int64 run the same contraction / reduction / arithmetic kernels exactly (the reference
+    # hands any NumPy dtype to np.tensordot / np.sum / np.trace: numpy_backend.py:35-54, 603-607, 684-707)
+    if t.code not in _NUM_CODES:
+      raise NotImplementedError(f"{what} is not implemented for dtype {t.dtype} on the hip backend")
+
   def _as_tensor(self, x):
     if isinstance(x, DeviceTensor):
       return x
@@ -102,7 +125,9 @@ class HipBackend(BackendBase):
     code = dtype if isinstance(dtype, int) else tnh_dtype(dtype)
     if tensor.code == code:
       return tensor
-    self._check_float(tensor, "cast")
+    self._check_num(tensor, "cast")
+    if tensor.is_complex and code not in _REAL_OF:
+      raise TypeError(f"cannot cast {tensor.dtype} to a real dtype: the imaginary part would be discarded")
     out = DeviceTensor.empty(tensor.shape, code)
     _lib.check(self.lib.tnh_cast(_vp(out), code, _vp(tensor), tensor.code, tensor.size), "tnh_cast")
     return out
@@ -350,7 +375,7 @@ class HipBackend(BackendBase):
     axes_a, axes_b = self._normalize_axes(a, b, axes)
     code = _promote(a.code, b.code)
     a, b = self.cast(a, code), self.cast(b, code)
-    self._check_float(a, "tensordot")
+    self._check_num(a, "tensordot")
 
     free_a = [i for i in range(a.ndim) if i not in axes_a]
     free_b = [i for i in range(b.ndim) if i not in axes_b]
@@ -457,7 +482,7 @@ class HipBackend(BackendBase):
       raise ValueError("inputs to `matmul` have to be a tensors of order > 1,")
     code = _promote(tensor1.code, tensor2.code)
     a, b = self.cast(tensor1, code), self.cast(tensor2, code)
-    self._check_float(a, "matmul")
+    self._check_num(a, "matmul")
     m, k = a.shape[-2:]
     k2, n = b.shape[-2:]
     if k != k2:
@@ -499,7 +524,7 @@ class HipBackend(BackendBase):
   # --------------------------------------------------------------- reductions
   def trace(self, tensor, offset=0, axis1=-2, axis2=-1):
     tensor = self._as_tensor(tensor)
-    self._check_float(tensor, "trace")
+    self._check_num(tensor, "trace")
     nd = tensor.ndim
     if nd < 2:
       raise ValueError("diag requires an array of at least two dimensions")
@@ -516,7 +541,7 @@ class HipBackend(BackendBase):
 
   def sum(self, tensor, axis=None, keepdims=False):
     tensor = self._as_tensor(tensor)
-    self._check_float(tensor, "sum")
+    self._check_num(tensor, "sum")
     nd = tensor.ndim
     if axis is None:
       axes = list(range(nd))
@@ -546,7 +571,9 @@ class HipBackend(BackendBase):
 
   def norm(self, tensor):
     tensor = self._as_tensor(tensor)
-    self._check_float(tensor, "norm")
+    self._check_num(tensor, "norm")
+    if tensor.code in _INT_CODES:
+      tensor = self.cast(tensor, _lib.F64)    # np.linalg.norm of an integer array is a float64
     out = DeviceTensor.empty((), tensor.code)
     _lib.check(self.lib.tnh_norm(_vp(out), _vp(tensor), tensor.size, tensor.code), "tnh_norm")
     if tensor.is_complex:
@@ -556,7 +583,9 @@ class HipBackend(BackendBase):
   # --------------------------------------------------------------- elementwise
   def _unary(self, op, tensor):
     tensor = self._as_tensor(tensor)
-    self._check_float(tensor, "elementwise math")
+    self._check_num(tensor, "elementwise math")
+    if tensor.code in _INT_CODES and op in (_lib.OP_SQRT, _lib.OP_EXP, _lib.OP_LOG, _lib.OP_SIN, _lib.OP_COS):
+      tensor = self.cast(tensor, _lib.F64)    # NumPy evaluates these on integers in float64
     to_real = tensor.is_complex and op in (_lib.OP_ABS, _lib.OP_REAL, _lib.OP_IMAG)
     out = DeviceTensor.empty(tensor.shape, _REAL_OF[tensor.code] if to_real else tensor.code)
     _lib.check(self.lib.tnh_unary(op, _vp(out), _vp(tensor), tensor.size, tensor.code), "tnh_unary")
@@ -610,8 +639,12 @@ class HipBackend(BackendBase):
       raise TypeError("at least one operand must be a tensor")
     if xs or ys:
       t = self._as_tensor(y if xs else x)
-      s = complex(x if xs else y)
-      self._check_float(t, "arithmetic")
+      sv = x if xs else y
+      s = complex(sv)
+      self._check_num(t, "arithmetic")
+      if t.code in _INT_CODES and (op == _lib.OP_DIV or not isinstance(sv, (numbers.Integral, np.integer))
+                                   or isinstance(sv, (bool, np.bool_))):
+        t = self.cast(t, _lib.F64)            # int (op) float -> float64; true division is float64 (NumPy)
       code = t.code
       if s.imag != 0.0 and not t.is_complex:
         code = _lib.C128 if t.code == _lib.F64 else _lib.C64
@@ -622,8 +655,10 @@ class HipBackend(BackendBase):
       return out
     a, b = self._as_tensor(x), self._as_tensor(y)
     code = _promote(a.code, b.code)
+    if op == _lib.OP_DIV and code in _INT_CODES:
+      code = _lib.F64                         # NumPy: int / int is a float64 true division
     a, b = self.cast(a, code), self.cast(b, code)
-    self._check_float(a, "arithmetic")
+    self._check_num(a, "arithmetic")
     try:
       shape = tuple(np.broadcast_shapes(a.shape, b.shape))
     except ValueError as exc:
@@ -680,7 +715,7 @@ class HipBackend(BackendBase):
   def _fill(self, shape, dtype, re, im=0.0):
     dtype = dtype if dtype is not None else np.float64
     code = tnh_dtype(dtype)
-    if code not in _FLOAT_CODES:
+    if code not in _NUM_CODES:
       return DeviceTensor.from_numpy(np.full(shape, re, dtype=dtype))
     self.lib  # pylint: disable=pointless-statement
     out = DeviceTensor.empty(shape, code)

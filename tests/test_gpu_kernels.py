@@ -629,3 +629,81 @@ def test_permute_more_than_2p24_tiles(hip):
     xi = np.asarray(hip.getitem(x, (slice(None), slice(b, b + 1), slice(None))))
     yi = np.asarray(hip.getitem(y, (slice(None), slice(b, b + 1), slice(None))))
     np.testing.assert_array_equal(yi[:, 0, :], xi[:, 0, :].T)
+
+
+# ------------------------------------------------------------------ integer dtypes
+@pytest.mark.parametrize("dtype", [np.int32, np.int64])
+def test_integer_tensordot_matmul_sum_trace_exact(hip, dtype):
+  """The reference hands any NumPy dtype to np.tensordot / np.matmul / np.sum / np.trace
+  (numpy_backend.py:35-54, 603-612, 684-707); integer results must be bit-exact, wrap-around included."""
+  rng = np.random.default_rng(31)
+  a = rng.integers(-9, 10, size=(5, 7, 6, 3)).astype(dtype)
+  b = rng.integers(-9, 10, size=(6, 4, 5, 8)).astype(dtype)
+  got = hip.tensordot(dev(hip, a), dev(hip, b), [[0, 2], [2, 0]])
+  assert got.dtype == np.dtype(dtype)
+  np.testing.assert_array_equal(np.asarray(got), np.tensordot(a, b, [[0, 2], [2, 0]]))
+  # full contraction -> 0-d, outer product, ragged sizes beyond one 64 x 64 tile
+  np.testing.assert_array_equal(np.asarray(hip.tensordot(dev(hip, a), dev(hip, a), [[0, 1, 2, 3], [0, 1, 2, 3]])),
+                                np.tensordot(a, a, [[0, 1, 2, 3], [0, 1, 2, 3]]))
+  np.testing.assert_array_equal(np.asarray(hip.outer_product(dev(hip, a[0, 0]), dev(hip, b[0, 0]))),
+                                np.tensordot(a[0, 0], b[0, 0], 0))
+  x = rng.integers(-100, 100, size=(130, 67)).astype(dtype)
+  y = rng.integers(-100, 100, size=(67, 71)).astype(dtype)
+  np.testing.assert_array_equal(np.asarray(hip.tensordot(dev(hip, x), dev(hip, y), 1)), x @ y)
+  # wrap-around like NumPy
+  big = np.full((3, 3), np.iinfo(dtype).max // 2 + 5, dtype=dtype)
+  with np.errstate(over="ignore"):
+    ref = big @ big
+  np.testing.assert_array_equal(np.asarray(hip.matmul(dev(hip, big), dev(hip, big))), ref)
+  # batched matmul, sum, trace
+  p = rng.integers(-9, 10, size=(4, 3, 5)).astype(dtype)
+  q = rng.integers(-9, 10, size=(4, 5, 2)).astype(dtype)
+  np.testing.assert_array_equal(np.asarray(hip.matmul(dev(hip, p), dev(hip, q))), np.matmul(p, q))
+  np.testing.assert_array_equal(np.asarray(hip.sum(dev(hip, a), axis=(1, 3))), a.sum(axis=(1, 3)))
+  np.testing.assert_array_equal(np.asarray(hip.sum(dev(hip, a))), a.sum())
+  long = rng.integers(-1000, 1000, size=(3, 40000)).astype(dtype)
+  np.testing.assert_array_equal(np.asarray(hip.sum(dev(hip, long), axis=1)), long.sum(axis=1))
+  t = rng.integers(-9, 10, size=(3, 6, 6)).astype(dtype)
+  np.testing.assert_array_equal(np.asarray(hip.trace(dev(hip, t))), np.trace(t, axis1=-2, axis2=-1))
+
+
+def test_integer_arithmetic_follows_numpy_promotion(hip):
+  rng = np.random.default_rng(32)
+  a = rng.integers(-50, 50, size=(4, 5)).astype(np.int64)
+  b = rng.integers(1, 50, size=(4, 5)).astype(np.int32)
+  for f, g in ((hip.addition, np.add), (hip.subtraction, np.subtract), (hip.multiply, np.multiply),
+               (hip.divide, np.true_divide)):
+    got, ref = f(dev(hip, a), dev(hip, b)), g(a, b)
+    assert got.dtype == ref.dtype, (got.dtype, ref.dtype)
+    np.testing.assert_allclose(np.asarray(got), ref, rtol=1e-15)
+  for got, ref in ((hip.multiply(dev(hip, a), 3), a * 3), (hip.addition(2, dev(hip, a)), 2 + a),
+                   (hip.multiply(dev(hip, a), 2.5), a * 2.5), (hip.divide(dev(hip, a), 4), a / 4),
+                   (hip.addition(dev(hip, a), dev(hip, a.astype(np.float32))), a + a.astype(np.float32)),
+                   (hip.abs(dev(hip, a)), np.abs(a)), (hip.sign(dev(hip, a)), np.sign(a)),
+                   (hip.sqrt(dev(hip, np.abs(a))), np.sqrt(np.abs(a))), (hip.conj(dev(hip, a)), a),
+                   (hip.ones((2, 3), dtype=np.int64), np.ones((2, 3), dtype=np.int64)),
+                   (hip.eye(3, dtype=np.int32), np.eye(3, dtype=np.int32))):
+    assert got.dtype == ref.dtype, (got.dtype, ref.dtype)
+    np.testing.assert_allclose(np.asarray(got), ref, rtol=1e-15)
+  assert float(np.asarray(hip.norm(dev(hip, a)))) == pytest.approx(np.linalg.norm(a))
+
+
+def test_cast_refuses_to_drop_an_imaginary_part(hip):
+  z = dev(hip, np.array([1 + 2j, 3 - 1j]))
+  with pytest.raises(TypeError):
+    hip.cast(z, np.float64)
+  np.testing.assert_array_equal(np.asarray(hip.cast(dev(hip, np.arange(5, dtype=np.int64)), np.float32)),
+                                np.arange(5, dtype=np.float32))
+
+
+def test_device_tensor_deepcopy_pickle_repr(hip):
+  import copy, pickle  # pylint: disable=import-outside-toplevel,multiple-imports
+  x = np.arange(6.0).reshape(2, 3)
+  t = dev(hip, x)
+  c = copy.deepcopy(t)
+  assert c.ptr != t.ptr
+  np.testing.assert_array_equal(np.asarray(c), x)
+  np.testing.assert_array_equal(np.asarray(pickle.loads(pickle.dumps(t))), x)
+  assert copy.deepcopy(hip) is hip
+  assert "[0., 1., 2.]" in repr(t).replace(" ", "").replace(",", ", ").replace(" ", "") or "0." in repr(t)
+  assert "data=" not in repr(dev(hip, np.zeros((100,))))
