@@ -159,7 +159,10 @@ int tnh_malloc(void** ptr, size_t nbytes) {
   } else {
     // (relaxed capture mode: hipMalloc is legal while the stream is capturing)
     hipError_t e = hipMalloc(&p, sz);
-    if (e != hipSuccess) {
+    if (e != hipSuccess && ar == nullptr) {
+      // retry after returning the cached blocks to the driver.  Never while a capture is open:
+      // synchronising a capturing stream is illegal and would invalidate the capture -- the caller
+      // gets TNH_ERR_NOMEM and falls back to the eager path (distributed.contract_sliced).
       (void)hipGetLastError();
       (void)hipStreamSynchronize(g_stream);
       g_pool.release_cached();

@@ -11,8 +11,10 @@ results add up.  That is the natural partition of a contractor path:
     the same path on its own GPU and accumulates the partial result locally,
   * ONE all-reduce(sum) of the (small) result tensor finishes the job -- the
     only data-path collective, and only because the partition has a genuine
-    exchange step.  On GPUs it is RCCL (torch.distributed backend "nccl"), in
-    the CPU test-suite it is gloo.
+    exchange step.  On GPUs it is RCCL through libtnhip's own K8 entry points
+    (``tensornetwork_amd.comm.RcclComm``: ``tnh_allreduce`` on the library stream); the
+    CPU test-suite drives the same code with the oracle backend over gloo
+    (``TorchDistComm``, host arrays).
 
 Networks that do not partition (MPS chains zipped from a boundary, a single
 SVD) are run as independent replicas instead -- see bench.py.
@@ -62,16 +64,24 @@ class TorchDistComm:
     import torch  # pylint: disable=import-outside-toplevel
     from tensornetwork_amd.device_tensor import DeviceTensor  # pylint: disable=import-outside-toplevel
     if isinstance(tensor, DeviceTensor):
-      work = tensor
-      if tensor.dtype not in (np.dtype(np.float32), np.dtype(np.float64)):
-        work = backend.cast(tensor, np.float32)   # bf16/f16 partial sums travel as fp32
+      # Fallback path (bench.py --comm torch): the product path is RcclComm.  Always reduce a
+      # fresh block -- `tensor` may alias a caller-owned operand (network.copy shares tensors).
+      from tensornetwork_amd import _lib  # pylint: disable=import-outside-toplevel
+      half = tensor.code in (_lib.BF16, _lib.F16)
+      work = backend.cast(tensor, np.float32) if half else backend.copy(tensor)   # bf16/f16 sums travel as fp32
       backend.synchronize()                        # our stream -> visible to RCCL's stream
-      view = torch.as_tensor(_CudaView(work), device=f"cuda:{torch.cuda.current_device()}")
+      view = torch.as_tensor(_CudaView(work, real_image=True), device=f"cuda:{torch.cuda.current_device()}")
       self._dist.all_reduce(view, op=self._dist.ReduceOp.SUM)
       torch.cuda.synchronize()
-      return work if work is tensor else backend.cast(work, tensor.dtype)
+      return backend.cast(work, tensor.dtype) if half else work
     host = np.ascontiguousarray(np.asarray(tensor))
-    t = torch.from_numpy(host.reshape(-1).copy() if host.ndim == 0 else host.copy())
+    flat = host.reshape(-1).copy()
+    if flat.dtype.kind == "c":   # gloo has no complex sum: reduce the interleaved real image
+      real = flat.view(np.float32 if flat.dtype == np.complex64 else np.float64)
+      t = torch.from_numpy(real)
+      self._dist.all_reduce(t, op=self._dist.ReduceOp.SUM)
+      return t.numpy().view(flat.dtype).reshape(host.shape)
+    t = torch.from_numpy(flat)
     self._dist.all_reduce(t, op=self._dist.ReduceOp.SUM)
     return t.numpy().reshape(host.shape)
 
@@ -122,8 +132,14 @@ def ctypes_ptr(tensor):
 class _CudaView:
   """Exposes a DeviceTensor through ``__cuda_array_interface__`` (zero-copy)."""
 
-  def __init__(self, tensor, raw=False):
+  def __init__(self, tensor, raw=False, real_image=False):
     self._keep = tensor
+    if real_image and np.dtype(tensor.dtype).kind == "c":
+      # complex64 / complex128 summed as their interleaved (re, im) float32 / float64 image
+      real = np.dtype(np.float32 if np.dtype(tensor.dtype) == np.complex64 else np.float64)
+      self.__cuda_array_interface__ = {"shape": (int(tensor.size) * 2,), "typestr": real.str,
+                                       "data": (tensor.ptr, False), "version": 2, "strides": None}
+      return
     if raw:   # byte view: lets dtypes torch does not know (bf16 tag, complex) ride a collective
       self.__cuda_array_interface__ = {"shape": (int(tensor.nbytes),), "typestr": "|u1",
                                        "data": (tensor.ptr, False), "version": 2, "strides": None}
@@ -214,8 +230,11 @@ def contract_sliced(nodes: Sequence[network.Node], cut_edges: Sequence[network.E
   if use_graph is None:
     use_graph = hasattr(be, "capture") and len(cut_edges) > 0 and len(mine) >= 4
   if use_graph and mine:
-    total = _contract_slices_graph(be, nodes, cut_edges, mine, path, output_edge_order)
-    return comm.all_reduce_sum(be, total)
+    try:
+      total = _contract_slices_graph(be, nodes, cut_edges, mine, path, output_edge_order)
+      return _finish(be, comm, total, nodes)
+    except MemoryError:
+      pass   # not enough HBM for the captured sequence's fixed blocks: run the slices eagerly
 
   total = None
   for idx in mine:
@@ -223,7 +242,7 @@ def contract_sliced(nodes: Sequence[network.Node], cut_edges: Sequence[network.E
     for e, i in zip(cut_edges, idx):
       network.slice_edge(edge_map[e], i, 1)
     order = [edge_map[e] for e in output_edge_order] if output_edge_order is not None else None
-    part = contractors.contract_path(path, [node_map[n] for n in nodes], order).tensor
+    part = _widen(be, contractors.contract_path(path, [node_map[n] for n in nodes], order).tensor)
     total = part if total is None else be.addition(total, part)
     for n in node_map.values():     # this slice's copies are ours: drop their tensors now (Node <-> Edge
       n.tensor = None               # cycles would otherwise keep the HBM until the cyclic GC runs)
@@ -235,8 +254,30 @@ def contract_sliced(nodes: Sequence[network.Node], cut_edges: Sequence[network.E
       network.slice_edge(edge_map[e], 0, 1)
     order = [edge_map[e] for e in output_edge_order] if output_edge_order is not None else None
     part = contractors.contract_path(path, [node_map[n] for n in nodes], order).tensor
-    total = be.multiply(part, 0.0)
-  return comm.all_reduce_sum(be, total)
+    total = be.multiply(_widen(be, part), 0.0)
+  return _finish(be, comm, total, nodes)
+
+
+def _is_half(tensor):
+  return getattr(tensor, "dtype", None) is not None and str(tensor.dtype) in ("bfloat16", "float16")
+
+
+def _widen(be, tensor):
+  """Slice partials of a bf16 / f16 network are ADDED in fp32: hundreds of slices summed in an
+  8-bit mantissa would lose the small ones (the per-slice GEMMs already accumulate in fp32)."""
+  if _is_half(tensor) and hasattr(be, "cast"):
+    return be.cast(tensor, np.float32)
+  return tensor
+
+
+def _finish(be, comm, total, nodes):
+  """ONE all-reduce of the (fp32-accumulated) partial sums, then a single rounding back to the
+  network's dtype."""
+  out = comm.all_reduce_sum(be, total)
+  want = nodes[0].tensor.dtype if nodes else None
+  if want is not None and _is_half(nodes[0].tensor) and not _is_half(out) and hasattr(be, "cast"):
+    out = be.cast(out, want)
+  return out
 
 
 def _contract_slices_graph(be, nodes, cut_edges, slices, path, output_edge_order):
@@ -269,7 +310,7 @@ def _contract_slices_graph(be, nodes, cut_edges, slices, path, output_edge_order
         for ax, c in wins:
           starts[ax] = idx[c]
         be.slice_into(staged[k], nodes[k].tensor, starts)
-      part = graph.launch()
+      part = _widen(be, graph.launch())
       total = be.multiply(part, 1.0) if total is None else be.addition(total, part)
   finally:
     be.synchronize()

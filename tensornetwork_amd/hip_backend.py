@@ -233,6 +233,14 @@ class HipBackend(BackendBase):
     results back to the host (no ``item``/``numpy``/``svd`` inside)."""
     return DeviceGraph(self, fun, args)
 
+  def copy(self, tensor):
+    """A new block holding the same data (device to device)."""
+    tensor = self._as_tensor(tensor)
+    out = DeviceTensor.empty(tensor.shape, tensor.code)
+    if tensor.nbytes:
+      _lib.check(self.lib.tnh_d2d(_vp(out), _vp(tensor), tensor.nbytes), "tnh_d2d")
+    return out
+
   def copy_into(self, out, tensor):
     tensor = self._as_tensor(tensor)
     if out.nbytes != tensor.nbytes or out.code != tensor.code:

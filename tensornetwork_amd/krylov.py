@@ -131,9 +131,12 @@ def eigsh_lanczos(be, A, args=None, initial_state=None, shape=None, dtype=None, 
   eigvals, u = _small_eigh(be, _tridiag(diags, norms[1:]))
   eigenvectors = []
   for n2 in range(min(numeig, len(eigvals))):
-    state = be.multiply(krylov[0], float(u[0, n2]))
+    # the Ritz coefficients are complex for a complex Hermitian operator (the reference multiplies by
+    # u[n1, n2] directly, numpy_backend.py:527-531); float() would drop the imaginary part
+    cplx = bool(np.iscomplexobj(u))
+    state = be.multiply(krylov[0], _coef(u[0, n2], cplx))
     for n1 in range(1, len(krylov)):
-      state = _axpy(be, state, float(u[n1, n2]), krylov[n1])
+      state = _axpy(be, state, _coef(u[n1, n2], cplx), krylov[n1])
     eigenvectors.append(be.divide(state, _norm(be, state)))
   return eigvals[:numeig], eigenvectors
 
@@ -214,9 +217,12 @@ def eigsh_lanczos_deferred(be, A, args=None, initial_state=None, shape=None, dty
   eigvals, u = _small_eigh(be, _tridiag(diags, norms[1:]))
   eigenvectors = []
   for n2 in range(min(numeig, len(eigvals))):
-    state = be.multiply(krylov[0], float(u[0, n2]))
+    # the Ritz coefficients are complex for a complex Hermitian operator (the reference multiplies by
+    # u[n1, n2] directly, numpy_backend.py:527-531); float() would drop the imaginary part
+    cplx = bool(np.iscomplexobj(u))
+    state = be.multiply(krylov[0], _coef(u[0, n2], cplx))
     for n1 in range(1, len(krylov)):
-      state = _axpy(be, state, float(u[n1, n2]), krylov[n1])
+      state = _axpy(be, state, _coef(u[n1, n2], cplx), krylov[n1])
     eigenvectors.append(be.divide(state, _norm(be, state)))
   return eigvals[:numeig], eigenvectors
 

@@ -203,6 +203,8 @@ class FiniteMPS:
       z = self._norm(self.tensors[site])
       if normalize:
         self.tensors[site] = be.divide(self.tensors[site], z)
+        if norms_out is not None:
+          norms_out.append(z)       # a one-site (or already centred) state still reports its norm
       return z
     if site > self.center_position:
       for n in range(self.center_position, site):

@@ -136,3 +136,85 @@ def test_sliced_two_processes_gloo(tmp_path):
   ref = contractors.greedy(regular_network(OracleBackend())).tensor
   for r in range(2):
     np.testing.assert_allclose(np.load(out_path + f".{r}.npy"), ref, rtol=1e-10)
+
+
+def _worker_complex(rank, world, port, out_path):
+  os.environ["MASTER_ADDR"] = "127.0.0.1"
+  os.environ["MASTER_PORT"] = str(port)
+  sys.path.insert(0, os.path.dirname(HERE))
+  sys.path.insert(0, HERE)
+  import torch.distributed as dist
+  dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+  be = OracleBackend()
+  nodes = regular_network(be, dtype=np.complex128)
+  rng = np.random.default_rng(17)
+  for n in nodes:   # genuinely complex entries: a dropped imaginary part changes the result
+    n.tensor = n.tensor + 1j * rng.standard_normal(n.tensor.shape)
+  cuts = distributed.choose_cut_edges(nodes, min_slices=9)
+  out = distributed.contract_sliced(nodes, cuts, comm=distributed.TorchDistComm())
+  np.save(out_path + f".{rank}.npy", np.asarray(out))
+  dist.barrier()
+  dist.destroy_process_group()
+
+
+def test_sliced_complex_two_processes_gloo(tmp_path):
+  """the all-reduce must not drop the imaginary part of complex partial results."""
+  import torch.multiprocessing as mp
+  with socket.socket() as s:
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+  out_path = str(tmp_path / "res")
+  mp.spawn(_worker_complex, args=(2, port, out_path), nprocs=2, join=True)
+  be = OracleBackend()
+  nodes = regular_network(be, dtype=np.complex128)
+  rng = np.random.default_rng(17)
+  for n in nodes:
+    n.tensor = n.tensor + 1j * rng.standard_normal(n.tensor.shape)
+  ref = contractors.greedy(nodes).tensor
+  assert abs(np.imag(ref)) > 1e-6 * abs(ref)
+  for r in range(2):
+    np.testing.assert_allclose(np.load(out_path + f".{r}.npy"), ref, rtol=1e-10)
+
+
+def test_all_reduce_never_overwrites_the_callers_tensor():
+  """a trivial path (one node, no cuts) returns the node's own tensor as the partial
+  result; the reduction must not write into it."""
+  class Doubling(distributed.LocalComm):
+    world = 2
+    def all_reduce_sum(self, backend, tensor):
+      return np.asarray(tensor) * 2        # what a 2-rank sum of identical partials gives, out of place
+  be = OracleBackend()
+  x = np.arange(6.0).reshape(2, 3)
+  n = network.Node(x.copy(), backend=be)
+  out = distributed.contract_sliced([n], [], comm=Doubling())
+  np.testing.assert_allclose(out, 2 * x)
+  np.testing.assert_allclose(n.tensor, x)
+
+
+def _rdv_worker(rank, world, port, out_path):
+  sys.path.insert(0, os.path.dirname(HERE))
+  from tensornetwork_amd import comm
+  r = comm.HostRendezvous(rank, world, addr="127.0.0.1", port=port, timeout=60)
+  got = r.all_gather({"rank": rank, "n": 10 * rank})
+  b = r.broadcast("id-from-root" if rank == 0 else None)
+  r.barrier()
+  r.close()
+  with open(out_path + f".{rank}.json", "w") as f:
+    import json
+    json.dump({"got": got, "b": b}, f)
+
+
+def test_host_rendezvous_three_processes(tmp_path):
+  """The TCP star that ships the RCCL id between ranks (tensornetwork_amd.comm)."""
+  import json
+  import torch.multiprocessing as mp
+  with socket.socket() as s:
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+  out_path = str(tmp_path / "rdv")
+  mp.spawn(_rdv_worker, args=(3, port, out_path), nprocs=3, join=True)
+  for r in range(3):
+    with open(out_path + f".{r}.json") as f:
+      rec = json.load(f)
+    assert rec["b"] == "id-from-root"
+    assert rec["got"] == [{"rank": k, "n": 10 * k} for k in range(3)]

@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 import tensornetwork_amd as ta
-from tensornetwork_amd import contractors, network
+from tensornetwork_amd import _lib, contractors, network
 from oracle import numpy_oracle as orc
 import cases as C
 
@@ -311,6 +311,84 @@ def test_rccl_collectives_on_device_tensors_world1():
   res = subprocess.run([sys.executable, "-c", f"ROOT = {root!r}\n" + _RCCL_SCRIPT], capture_output=True, text=True,
                        timeout=600)
   assert res.returncode == 0 and "RCCL-OK" in res.stdout, res.stdout[-2000:] + res.stderr[-4000:]
+
+
+def test_k8_rccl_collectives_through_the_c_abi_world1(hip):
+  """K8 (include/tnh.h): tnh_comm_unique_id / tnh_comm_init / tnh_allreduce / tnh_allgather /
+  tnh_broadcast on the library's own stream, in THIS process (no torch, no second HIP runtime), in a
+  1-rank communicator -- RCCL refuses two ranks on one device, so N > 1 is the gloo tests' job
+  (same distributed.py code) and the driver's 8-GPU run."""
+  import ctypes
+  from tensornetwork_amd import comm as tcomm, distributed
+  c = tcomm.RcclComm(hip, rank=0, world=1)
+  try:
+    rank, world = ctypes.c_int(-1), ctypes.c_int(-1)
+    _lib.check(hip.lib.tnh_comm_info(ctypes.byref(rank), ctypes.byref(world)))
+    assert (rank.value, world.value) == (0, 1)
+    rng = np.random.default_rng(1)
+    x = rng.standard_normal((5, 7)).astype(np.float32)
+    t = hip.convert_to_tensor(x)
+    out = c.all_reduce_sum(hip, t)
+    assert out.ptr != t.ptr                                    # reduced out of place
+    np.testing.assert_array_equal(np.asarray(out), x)
+    xb = orc.round_bf16(x)
+    out = c.all_reduce_sum(hip, hip.to_bfloat16(xb))           # bf16 partials travel and add as fp32
+    assert out.dtype == ta.bfloat16
+    np.testing.assert_array_equal(np.asarray(out), xb)
+    xc = (x + 2j * x).astype(np.complex64)
+    np.testing.assert_array_equal(np.asarray(c.all_reduce_sum(hip, hip.convert_to_tensor(xc))), xc)
+    xz = (x + 2j * x).astype(np.complex128)
+    np.testing.assert_array_equal(np.asarray(c.all_reduce_sum(hip, hip.convert_to_tensor(xz))), xz)
+    xi = rng.integers(-5, 5, size=(3, 4)).astype(np.int64)
+    np.testing.assert_array_equal(np.asarray(c.all_reduce_sum(hip, hip.convert_to_tensor(xi))), xi)
+    for tt, ref in [(hip.convert_to_tensor(x), x), (hip.to_bfloat16(xb), xb), (hip.convert_to_tensor(xc), xc)]:
+      np.testing.assert_array_equal(np.asarray(c.all_gather_rows(hip, tt, [5])), ref)
+    assert c.max_over_ranks(3.5) == 3.5 and c.sum_over_ranks(2.0) == 2.0
+    c.barrier()
+    b = hip.convert_to_tensor(x)
+    _lib.check(hip.lib.tnh_broadcast(ctypes.c_void_p(b.ptr), b.nbytes, 0))
+    np.testing.assert_array_equal(np.asarray(b), x)
+    assert hip.lib.tnh_allreduce(ctypes.c_void_p(b.ptr), b.size, 99, 0) != 0      # bad dtype: status, no abort
+    assert hip.lib.tnh_allreduce(ctypes.c_void_p(b.ptr), b.size, _lib.C64, 1) != 0  # complex max: refused
+    # the sharded contraction and the sliced network through the same communicator
+    a = rng.standard_normal((6, 3, 4)).astype(np.float32)
+    bb = rng.standard_normal((4, 3, 2)).astype(np.float32)
+    full, bounds = distributed.tensordot_sharded(hip, hip.convert_to_tensor(a), hip.convert_to_tensor(bb),
+                                                 [[2, 1], [0, 1]], comm=c)
+    assert bounds == (0, 6)
+    np.testing.assert_allclose(np.asarray(full), np.tensordot(a, bb, [[2, 1], [0, 1]]), rtol=1e-5, atol=1e-5)
+    from tensornetwork_amd import workloads as wl
+    tensors = [(rng.standard_normal((4, 4, 4)) * 4 ** -0.75).astype(np.float32) for _ in range(16)]
+    nodes = wl.random_regular_network(hip, n=16, D=4, tensors=tensors)
+    cuts = distributed.choose_cut_edges(nodes, min_slices=8)
+    ref = float(np.asarray(distributed.contract_sliced(nodes, cuts)))
+    got = float(np.asarray(distributed.contract_sliced(nodes, cuts, comm=c)))
+    assert abs(got - ref) <= 1e-6 * max(abs(ref), 1e-3)
+  finally:
+    c.close()
+  world = ctypes.c_int(-1)
+  _lib.check(hip.lib.tnh_comm_info(None, ctypes.byref(world)))
+  assert world.value == 0
+
+
+def test_sliced_bf16_network_accumulates_partials_in_fp32(hip):
+  """100+ bf16 slice partials used to be added in bf16.  The sliced bf16 contraction
+  must agree with an f32 contraction of the same bf16-rounded tensors to bf16 rounding of the RESULT
+  (2^-8 relative), not to sqrt(n_slices) roundings."""
+  from tensornetwork_amd import distributed, workloads as wl
+  rng = np.random.default_rng(8)
+  D, n = 6, 16
+  tensors = [orc.round_bf16((rng.standard_normal((D, D, D)) * D ** -0.75)).astype(np.float32) for _ in range(n)]
+  nodes32 = wl.random_regular_network(hip, n=n, D=D, tensors=tensors)
+  ref = float(np.asarray(contractors.greedy(nodes32).tensor))
+  nodes16 = wl.random_regular_network(hip, n=n, D=D, tensors=[hip.to_bfloat16(t) for t in tensors])
+  cuts = distributed.choose_cut_edges(nodes16, min_slices=30)
+  for use_graph in (False, True):
+    out = distributed.contract_sliced(nodes16, cuts, use_graph=use_graph)
+    assert out.dtype == ta.bfloat16
+    got = float(np.asarray(out))
+    # per-slice intermediates are bf16 (as an unsliced bf16 contraction's are); the SUM is not
+    assert abs(got - ref) <= 2.0 ** -6 * abs(ref) + 1e-4, (got, ref, use_graph)
 
 
 def test_json_network_from_reference_into_hbm(hip):

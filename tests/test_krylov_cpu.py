@@ -216,3 +216,24 @@ def test_deferred_lanczos_invariant_subspace_and_errors():
     krylov.eigsh_lanczos_deferred(be, lambda x: x, numeig=10, num_krylov_vecs=9, initial_state=np.ones(3))
   with pytest.raises(TypeError, match="Expected a backend tensor"):
     krylov.eigsh_lanczos_deferred(be, lambda x: x, initial_state=[1, 2, 3])
+
+
+@pytest.mark.parametrize("deferred", [False, True])
+def test_eigsh_lanczos_complex_hermitian_keeps_complex_ritz_coefficients(deferred):
+  """ADVICE r1: for a complex Hermitian operator the eigenvectors of the projected matrix are complex;
+  building the Ritz vector with float(u[i, j]) dropped their imaginary parts."""
+  import warnings
+  be = orc.OracleBackend()
+  rng = np.random.default_rng(5)
+  n = 12
+  a = rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n))
+  h = (a + a.conj().T) / 2
+  init = rng.standard_normal(n) + 1j * rng.standard_normal(n)
+  fun = krylov.eigsh_lanczos_deferred if deferred else krylov.eigsh_lanczos
+  with warnings.catch_warnings():
+    warnings.simplefilter("error")          # a ComplexWarning would mean an imaginary part was discarded
+    eta, vecs = fun(be, lambda x, m: m @ x, [h], init, num_krylov_vecs=n, reorthogonalize=True)
+  w = np.linalg.eigvalsh(h)
+  np.testing.assert_allclose(eta[0], w[0], atol=1e-9)
+  v = np.asarray(vecs[0])
+  np.testing.assert_allclose(h @ v, w[0] * v, atol=1e-7)

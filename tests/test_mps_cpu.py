@@ -304,3 +304,18 @@ def test_dmrg_with_deferred_lanczos_readbacks():
   dmrg = tmps.FiniteDMRG(state, mpo)
   dmrg.deferred_lanczos = True
   np.testing.assert_allclose(dmrg.run_two_site(max_bond_dim=16, num_sweeps=4, num_krylov_vecs=10), eta[0], atol=1e-7)
+
+
+def test_one_site_mps_canonicalize_returns_the_true_norm():
+  """position(site == center_position) dropped the norm from the bookkeeping."""
+  from oracle.numpy_oracle import OracleBackend
+  import tensornetwork_amd as ta
+  be = OracleBackend()
+  t = np.random.default_rng(3).standard_normal((1, 4, 1))
+  true = float(np.linalg.norm(t))
+  mps = ta.FiniteMPS([t.copy()], center_position=0, canonicalize=False, backend=be)
+  assert float(mps.canonicalize(normalize=True)) == pytest.approx(true)
+  np.testing.assert_allclose(np.linalg.norm(np.asarray(mps.tensors[0])), 1.0)
+  mps = ta.FiniteMPS([t.copy()], center_position=0, canonicalize=False, backend=be)
+  assert float(mps.canonicalize(normalize=False)) == pytest.approx(true)
+  np.testing.assert_allclose(np.asarray(mps.tensors[0]), t, rtol=1e-12)
