@@ -4,34 +4,41 @@ Workload at N=1 (BASELINE.json configs[1]): ``contract_between`` of two rank-4
 bf16 nodes with two shared bonds of dimension D=256 (layout L0: a[2]^b[0],
 a[3]^b[1]) -> one 65536^3 GEMM on the MFMA path, operands generated in HBM.
 A "step" is one such contract_between through the product path
-(Node bookkeeping -> HipBackend.tensordot -> K1 permute of b -> K2 MFMA GEMM).
+(Node bookkeeping -> HipBackend.tensordot -> tnh_gemm_view: both operands read in place).
 ``value`` = 2*M*N*K*steps / wall time, TFLOP/s, inputs resident in HBM.
 
-N>1 (one process per GPU, torch.distributed/RCCL for the barrier and the
-max-over-ranks reduction only): the pairwise contraction has no exchange step,
-so every rank contracts its own pair of nodes (weak scaling, no data-path
+N>1 (one process per GPU; RCCL through libtnhip's own K8 entry points for the barrier, the
+max-over-ranks reduction and the sliced network's all-reduce): the pairwise contraction has no
+exchange step, so every rank contracts its own pair of nodes (weak scaling, no data-path
 collective) and ``value`` is the aggregate.
 
 Extra objects on the same line:
-  roofline       -- the dominant kernel (bf16 MFMA GEMM) timed with HIP events on
-                    the library's stream inside the timed region, vs 2.5 PFLOP/s;
-                    `traffic` = HBM bytes per launch from the committed rocprofv3 PMC
-                    pass of this same command (profiles/*_traffic.json), else null.
-  cpu_baseline   -- the NumPy oracle (port of the reference's tensordot) timed on
-                    this box's host cores on a bounded sample (same layout, smaller D).
-  svd            -- split_node truncated SVD (configs[2]: (16,)*6 node -> 4096 x 4096,
-                    keep 256) in the metric's GB/s, with the oracle's LAPACK SVD timed
-                    on a bounded sample beside it.
-  bond_sweep     -- the metric's bond-dimension sweep: contract_between of two rank-4 bf16
-                    nodes at D = 32 .. 256 in the favourable (L0) and the permute-needing (L1) layout,
-                    plus the north-star "D = 512" row A(64,128,512,512) . B(512,512,128,64)
-                    (GEMM 8192 x 8192 x 262144), whole-path TFLOP/s each.
-  dtype_sweep    -- the same contraction (backend.tensordot) at D = 64 (GEMM 4096^3) in f32 / f64 / complex64 / complex128, the
-                    dtypes of the reference's own tests (f32 runs on the bf16 cores via the exact 3 x bf16 split).
+  roofline       -- the dominant kernel (bf16 MFMA GEMM) timed with HIP events on the library's stream inside
+                    the timed region, vs 2.5 PFLOP/s; board power and shader clock sampled from sysfs over the
+                    same region give `frac_at_observed_clock`; `traffic` = HBM bytes per launch from the
+                    committed rocprofv3 PMC pass of this same command (profiles/*_traffic.json), else null.
+  verified       -- value checks of the BASELINE-size outputs, OUTSIDE the timed regions: 1024 sampled
+                    entries of the D=256 L0 / L1 results and of the D=512 row vs float64 dot products of the
+                    device operands; configs[2] at 4096^2 vs LAPACK (all 4096 singular values incl. s_rest,
+                    orthonormality, reconstruction vs the best rank-k error); the bf16 sliced network vs an f32
+                    run of the same tensors; the MERA layer at chi = 16 vs the float64 oracle.
+  cpu_baseline   -- the NumPy oracle (port of the reference's tensordot) timed on this box's host cores on a
+                    bounded sample (same layout, smaller D).
+  svd            -- split_node truncated SVD (configs[2]: (16,)*6 node -> 4096 x 4096, keep 256) in the metric's
+                    GB/s, with the oracle's LAPACK SVD timed on a bounded sample beside it.
+  bond_sweep     -- the metric's bond-dimension sweep: contract_between of two rank-4 bf16 nodes at
+                    D = 32 .. 256 in the favourable (L0) and the permute-needing (L1) layout, plus the
+                    north-star "D = 512" row A(64,128,512,512) . B(512,512,128,64) (GEMM 8192 x 8192 x 262144),
+                    whole-path TFLOP/s each, with the K1 permute launches per contraction.
+  dtype_sweep    -- the same contraction at D = 64 in f32 / f64 / complex64 / complex128.
+  mps_chain      -- configs[3]: <psi|psi> of a 16-site MPS, bulk D = 512, contractors.greedy (d = 2 and d = 4;
+                    eager and hipGraph replay) with the NumPy oracle backend's time beside it.
   mera           -- configs[4] shape on one GPU: binary-MERA layer energy at chi = 32 (68.7 GB intermediate).
-  sliced_network -- the north-star scaling network (64-node random 3-regular graph, bond
-                    D, bf16): bond-sliced greedy contraction, slices dealt over the N
-                    ranks, ONE all-reduce of the scalar (strong scaling: fixed total work).
+  mera_chi64     -- configs[4] at chi = 64: measured per-slice cost x slice count (labelled extrapolated).
+  helpers        -- HBM-bound helper kernels (K1 permute, K3/K4 reductions, K5 scaling) in GB/s vs 8 TB/s.
+  sliced_network -- the north-star scaling network (64-node random 3-regular graph, bond D, bf16):
+                    bond-sliced greedy contraction, slices dealt over the N ranks, ONE all-reduce of
+                    the scalar (strong scaling: fixed total work); per-rank compute and all-reduce times.
 """
 import argparse
 import json
@@ -46,6 +53,8 @@ if ROOT not in sys.path:
   sys.path.insert(0, ROOT)
 
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense, /opt/skills/guides/MI355X_MICROARCH.md:42
+HBM_PEAK_GBPS = 8000.0          # spec, MI355X_MICROARCH.md:35 (about 6.3 TB/s achievable)
+MAX_CLOCK_MHZ = 2400.0
 
 
 def parse_args():
@@ -61,40 +70,70 @@ def parse_args():
   p.add_argument("--rr-min-slices", type=int, default=64)
   p.add_argument("--no-cpu-baseline", action="store_true")
   p.add_argument("--no-sweep", action="store_true", help="skip the bond-dimension sweep rows")
+  p.add_argument("--no-verify", action="store_true", help="skip the value checks (verified object)")
+  p.add_argument("--no-extras", action="store_true", help="skip mps_chain / mera_chi64 / helpers")
   p.add_argument("--mera-chi", type=int, default=32, help="bond dimension of the MERA layer network (0 = skip)")
+  p.add_argument("--comm", default=os.environ.get("TNH_BENCH_COMM", "rccl"), choices=["rccl", "torch"],
+                 help="N > 1: collectives through libtnhip's K8 entry points (default) or torch.distributed")
   p.add_argument("--fill", default="normal", choices=["normal", "zeros"],
                  help="operand fill (zeros shows the DVFS-inflated number; never the headline)")
   return p.parse_args()
 
 
-def dist_setup(n_gpus):
-  """torch.distributed is plumbing here: barrier + max-over-ranks of the time."""
-  rank = int(os.environ.get("RANK", "0"))
-  world = int(os.environ.get("WORLD_SIZE", "1"))
-  local = int(os.environ.get("LOCAL_RANK", "0"))
-  if world == 1 and not os.environ.get("TNH_BENCH_FORCE_DIST"):
-    return rank, world, local, None   # (the env knob exercises the RCCL path on a 1-GPU box)
-  os.environ.setdefault("MASTER_PORT", "29511")
-  import torch  # pylint: disable=import-outside-toplevel
-  import torch.distributed as dist  # pylint: disable=import-outside-toplevel
-  os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-  os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-  torch.cuda.set_device(local)
-  dist.init_process_group(backend="nccl", rank=rank, world_size=world,
-                          device_id=torch.device("cuda", local))
-  assert world == n_gpus, (world, n_gpus)
-  return rank, world, local, dist
+# --------------------------------------------------------------------------- communicators
+class TorchComm:
+  """Fall-back communicator (--comm torch): torch.distributed process group, same method names as
+  tensornetwork_amd.comm.RcclComm.  torch's bundled HIP runtime has to come up before libtnhip.so,
+  which is why this one is built before the backend is touched."""
 
-
-def sync_all(be, dist):
-  be.synchronize()
-  if dist is not None:
+  def __init__(self, rank, world, local):
     import torch  # pylint: disable=import-outside-toplevel
-    torch.cuda.synchronize()
-    dist.barrier()
-    torch.cuda.synchronize()
+    import torch.distributed as dist  # pylint: disable=import-outside-toplevel
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29511")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(local)
+    dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    self._torch, self._dist = torch, dist
+    self.rank, self.world = rank, world
+    self._inner = None
+
+  def bind(self):
+    from tensornetwork_amd import distributed  # pylint: disable=import-outside-toplevel
+    self._inner = distributed.TorchDistComm()
+
+  def all_reduce_sum(self, backend, tensor):
+    return self._inner.all_reduce_sum(backend, tensor)
+
+  def all_gather_rows(self, backend, tensor, rows):
+    return self._inner.all_gather_rows(backend, tensor, rows)
+
+  def all_gather_counts(self, n):
+    return self._inner.all_gather_counts(n)
+
+  def barrier(self):
+    self._torch.cuda.synchronize()
+    self._dist.barrier()
+    self._torch.cuda.synchronize()
+
+  def max_over_ranks(self, value):
+    t = self._torch.tensor([value], dtype=self._torch.float64, device="cuda")
+    self._dist.all_reduce(t, op=self._dist.ReduceOp.MAX)
+    return float(t.item())
+
+  def close(self):
+    self._dist.barrier()
+    self._dist.destroy_process_group()
 
 
+def sync_all(be, comm):
+  be.synchronize()
+  if comm is not None:
+    comm.barrier()        # device-level: a 1-element all-reduce on the library stream, then a stream sync
+    be.synchronize()
+
+
+# --------------------------------------------------------------------------- headline pieces
 def make_nodes(ta, be, D, layout, seed, fill):
   if fill == "zeros":
     A = be.zeros((D,) * 4, dtype=ta.bfloat16)
@@ -114,6 +153,49 @@ def one_step(ta, be, A, B, layout):
     a[1] ^ b[2]  # pylint: disable=pointless-statement
     a[3] ^ b[0]  # pylint: disable=pointless-statement
   return ta.contract_between(a, b)
+
+
+def host64(t):
+  return np.asarray(t).astype(np.float64)
+
+
+def verify_pair(be, A, B, out, layout, n_side=32, seed=0):
+  """>= 1024 sampled entries of a rank-4 x rank-4 contraction against float64 dot products of the DEVICE
+  operands.  Only the needed slabs are read back: n_side (row pair) slabs of A, n_side (column
+  pair) slabs of B and n_side slabs of the result.
+    L0: C[i0,i1,j2,j3] = sum_{k2,k3} A[i0,i1,k2,k3] B[k2,k3,j2,j3]
+    L1: C[i0,i2,j1,j3] = sum_{k1,k3} A[i0,k1,i2,k3] B[k3,j1,k1,j3]
+  Tolerance: bf16 rounding of the result (2^-9 relative, tested at 2^-8) + 2^-10 of the rms entry (fp32
+  accumulation over K terms is far below that)."""
+  rng = np.random.default_rng(seed)
+  sa, sb = A.shape, B.shape
+  if layout == "L0":
+    rdims, cdims = (sa[0], sa[1]), (sb[2], sb[3])
+  else:
+    rdims, cdims = (sa[0], sa[2]), (sb[1], sb[3])
+  rows = [(int(rng.integers(rdims[0])), int(rng.integers(rdims[1]))) for _ in range(n_side)]
+  cols = [(int(rng.integers(cdims[0])), int(rng.integers(cdims[1]))) for _ in range(n_side)]
+  # always include the four corners of the output (first / last tile of the launch)
+  rows[0], rows[-1] = (0, 0), (rdims[0] - 1, rdims[1] - 1)
+  cols[0], cols[-1] = (0, 0), (cdims[0] - 1, cdims[1] - 1)
+  sl = slice(None)
+  if layout == "L0":
+    a_rows = np.stack([host64(be.getitem(A, (r0, r1))).reshape(-1) for r0, r1 in rows])
+    b_cols = np.stack([host64(be.getitem(B, (sl, sl, c0, c1))).reshape(-1) for c0, c1 in cols])
+  else:
+    a_rows = np.stack([host64(be.getitem(A, (r0, sl, r1, sl))).reshape(-1) for r0, r1 in rows])
+    b_cols = np.stack([host64(be.getitem(B, (sl, c0, sl, c1))).T.reshape(-1) for c0, c1 in cols])
+  ref = a_rows @ b_cols.T                                            # (n_side, n_side) float64
+  got = np.empty_like(ref)
+  for i, (r0, r1) in enumerate(rows):
+    slab = host64(be.getitem(out, (r0, r1)))                         # [c0, c1]
+    got[i] = [slab[c0, c1] for c0, c1 in cols]
+  rms = float(np.sqrt(np.mean(ref**2)))
+  tol = 2.0**-8 * np.abs(ref) + 2.0**-10 * rms
+  err = np.abs(got - ref)
+  return {"entries": int(ref.size), "max_abs_err": float(err.max()), "rms_ref": rms,
+          "max_err_over_tol": float((err / tol).max()), "tol": "2^-8 |ref| + 2^-10 rms(ref)",
+          "ok": bool((err <= tol).all())}
 
 
 def cpu_baseline(layout):
@@ -146,11 +228,14 @@ def cpu_baseline(layout):
   t = run(D) if D != 64 else t64
   flops = 2.0 * float(D)**6
   return {"value": flops / t / 1e12, "unit": "TFLOP/s", "cores": int(threads), "kind": "port",
-          "sample": f"oracle tensordot, layout {layout}, D={D} (GEMM {D*D}^3), fp32 on bf16-rounded inputs, "
-                    f"{t:.2f} s; D=64 probe {flops64 / t64 / 1e12:.3f} TFLOP/s"}
+          "sample": f"oracle tensordot (NumPy restatement of the reference's numpy_backend.tensordot; the reference "
+                    f"itself is not installed on this box), layout {layout}, D={D} (GEMM {D*D}^3), fp32 on "
+                    f"bf16-rounded inputs, {t:.2f} s; D=64 probe {flops64 / t64 / 1e12:.3f} TFLOP/s; the D=256 "
+                    f"headline shape would take ~{2.0 * 256.0**6 / (flops / t) / 60.0:.0f} min at this rate (extrapolated)"}
 
 
-def svd_bench(ta, be, n, k):
+# --------------------------------------------------------------------------- configs[2]
+def svd_bench(ta, be, n, k, keep_outputs=False):
   """configs[2]: split_node of a rank-6 fp32 node reshaped n x n, keep k."""
   side = round(n ** (1.0 / 3.0))
   if side**3 != n:
@@ -166,13 +251,49 @@ def svd_bench(ta, be, n, k):
   be.synchronize()
   t = time.perf_counter() - t0
   nbytes = 4 * (n * n + n * k + n + k * n)  # read A, write u_k, all s, vh_k
-  return {"n": n, "k": k, "seconds": t, "gbps": nbytes / t / 1e9, "sweeps": be.last_svd_sweeps,
-          "algorithmic_bytes": nbytes, "trunc_len": int(trun.shape[0]),
-          "workload": f"split_node of a {shape} f32 node as {n}x{n}, max_singular_values={k} (second call; "
-                      "first call warms the allocator)",
-          "note": "block one-sided Jacobi: f32-MFMA gram/update + LDS eigensolver per block pair; bound by "
-                  "MFMA flops and LDS latency over ~17 sweeps, not by the algorithmic-bytes HBM figure "
-                  "(see DESIGN.md)"}
+  rec = {"n": n, "k": k, "seconds": t, "gbps": nbytes / t / 1e9, "sweeps": be.last_svd_sweeps,
+         "algorithmic_bytes": nbytes, "trunc_len": int(trun.shape[0]),
+         "hbm_roofline_frac": nbytes / t / 1e9 / HBM_PEAK_GBPS,
+         "workload": f"split_node of a {shape} f32 node as {n}x{n}, max_singular_values={k} (second call; "
+                     "first call warms the allocator)",
+         "note": "block one-sided Jacobi: MFMA gram/update + LDS eigensolver per block pair; bound by "
+                 "MFMA flops and LDS latency over the sweeps, not by the algorithmic-bytes HBM figure "
+                 "(see DESIGN.md)"}
+  if keep_outputs:
+    return rec, (x, left.tensor, right.tensor, trun)
+  return rec
+
+
+def verify_svd(be, n, k, outputs):
+  """configs[2] at full size against LAPACK (SURVEY 8c tolerances): split_node returns left = u sqrt(s),
+  right = sqrt(s) vh (network_operations.py:219-226) and the discarded values.  Checked: the discarded
+  values against np.linalg.svd's (all n - k of them), the kept ones through the column norms of `left`
+  (= sqrt(s_i)), orthogonality of the kept vectors, and the reconstruction error against the best
+  rank-k error sqrt(sum s_rest^2)."""
+  x, left, right, trun = outputs
+  t0 = time.perf_counter()
+  a = host64(x).reshape(n, n)
+  s_ref = np.linalg.svd(a, compute_uv=False)
+  t_lapack = time.perf_counter() - t0
+  lw = host64(left).reshape(n, k)          # u sqrt(s)
+  rw = host64(right).reshape(k, n)         # sqrt(s) vh
+  s_rest = host64(trun).reshape(-1)
+  s_kept = np.sum(lw * lw, axis=0)         # column norms^2 of u sqrt(s) = s_i
+  s_all = np.concatenate([s_kept, s_rest])
+  s_err = float(np.max(np.abs(s_all - s_ref)) / s_ref[0])
+  u = lw / np.sqrt(s_kept)[None, :]
+  vh = rw / np.sqrt(s_kept)[:, None]
+  orth_u = float(np.max(np.abs(u.T @ u - np.eye(k))))
+  orth_v = float(np.max(np.abs(vh @ vh.T - np.eye(k))))
+  recon = float(np.linalg.norm(a - lw @ rw))
+  best = float(np.sqrt(np.sum(s_ref[k:] ** 2)))
+  norm_a = float(np.linalg.norm(a))
+  rec_excess = (recon - best) / norm_a
+  ok = s_err <= 1e-5 and orth_u <= 1e-4 and orth_v <= 1e-4 and abs(rec_excess) <= 1e-4 and len(s_rest) == n - k
+  return {"n": n, "k": k, "s_max_err_over_s0": s_err, "s_rest_len": int(len(s_rest)), "orth_u": orth_u, "orth_vh": orth_v,
+          "recon_minus_best_over_normA": rec_excess, "lapack_values_only_seconds": t_lapack,
+          "tol": "|s - s_lapack| <= 1e-5 s0 (all n values), orthonormality <= 1e-4, (||A - L R||_F - best rank-k) <= 1e-4 ||A||_F",
+          "ok": bool(ok)}
 
 
 def svd_cpu_baseline(n_full):
@@ -198,7 +319,8 @@ def svd_cpu_baseline(n_full):
           "sample": f"oracle svd (np.linalg.svd) of {n}x{n} f32, keep {k}"}
 
 
-def sliced_network_bench(ta, be, dist, rank, world, D, min_slices):
+# --------------------------------------------------------------------------- sliced network
+def sliced_network_bench(ta, be, comm, rank, world, D, min_slices, verify):
   """64-node random 3-regular network, bf16, bond-sliced greedy contraction."""
   from tensornetwork_amd import distributed, workloads  # pylint: disable=import-outside-toplevel
   n = 64
@@ -206,67 +328,109 @@ def sliced_network_bench(ta, be, dist, rank, world, D, min_slices):
   nodes = workloads.random_regular_network(be, n=n, D=D, seed=6, tensors=tensors)
   cuts = distributed.choose_cut_edges(nodes, min_slices=min_slices)
   rep = distributed.slicing_report(nodes, cuts)
-  comm = distributed.TorchDistComm() if dist is not None else distributed.LocalComm()
-  # warm-up on a few slices (allocator, kernels), then the timed full contraction
-  class _Few(distributed.LocalComm):
+
+  class _Timed:
+    """wraps the communicator: separates this rank's compute time from the all-reduce"""
+    def __init__(self, inner):
+      self.inner, self.rank, self.world = inner, (inner.rank if inner else 0), (inner.world if inner else 1)
+      self.t_compute_end = self.t_reduce_end = None
+    def all_reduce_sum(self, backend, tensor):
+      backend.synchronize()
+      self.t_compute_end = time.perf_counter()
+      out = self.inner.all_reduce_sum(backend, tensor) if self.inner is not None else tensor
+      backend.synchronize()
+      self.t_reduce_end = time.perf_counter()
+      return out
+
+  class _Few(distributed.LocalComm):   # warm-up on half of the slices (allocator, kernels)
     rank, world = 0, max(1, int(rep["n_slices"]) // 2)
   distributed.contract_sliced(nodes, cuts, comm=_Few())
-  sync_all(be, dist)
+  sync_all(be, comm)
+  timed = _Timed(comm)
   t0 = time.perf_counter()
-  out = distributed.contract_sliced(nodes, cuts, comm=comm)
-  sync_all(be, dist)
+  out = distributed.contract_sliced(nodes, cuts, comm=timed)
+  sync_all(be, comm)
   t = time.perf_counter() - t0
-  if dist is not None:
-    import torch  # pylint: disable=import-outside-toplevel
-    tt = torch.tensor([t], dtype=torch.float64, device="cuda")
-    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-    t = float(tt.item())
+  t_compute = timed.t_compute_end - t0
+  t_reduce = timed.t_reduce_end - timed.t_compute_end
+  if comm is not None:
+    t = comm.max_over_ranks(t)
+    t_compute_max = comm.max_over_ranks(t_compute)
+    t_reduce_max = comm.max_over_ranks(t_reduce)
+  else:
+    t_compute_max, t_reduce_max = t_compute, t_reduce
   total_flops = 2.0 * rep["flops_per_slice"] * rep["n_slices"]   # the cost model counts multiply-adds
-  return {"workload": f"64-node random 3-regular network (seed 6), bond D={D}, bf16, {len(cuts)} cut bonds",
-          "n_slices": int(rep["n_slices"]), "n_gpus": world, "seconds": t, "scaling": "strong",
-          "flops_total": total_flops, "tflops": total_flops / t / 1e12,
-          "peak_intermediate_elems": rep["peak_per_slice"],
-          "collective": "one all-reduce(sum) of the scalar" if world > 1 else "none",
-          "result": float(np.asarray(out).reshape(-1)[0])}
+  result = float(np.asarray(out).reshape(-1)[0])
+  rec = {"workload": f"64-node random 3-regular network (seed 6), bond D={D}, bf16, {len(cuts)} cut bonds",
+         "n_slices": int(rep["n_slices"]), "n_gpus": world, "seconds": t, "scaling": "strong",
+         "flops_total": total_flops, "tflops": total_flops / t / 1e12,
+         "peak_intermediate_elems": rep["peak_per_slice"],
+         "slowest_rank_compute_seconds": t_compute_max, "allreduce_seconds": t_reduce_max,
+         "collective": "one all-reduce(sum) of the fp32-accumulated scalar (tnh_allreduce, RCCL)" if world > 1 else "none",
+         "accumulation": "slice partials added in fp32, rounded to bf16 once", "result": result}
+  if verify and world == 1:
+    # the same slices in f32 on the same (bf16-valued) tensors: what the bf16 network should equal up to
+    # the bf16 rounding of its intermediates
+    t32 = [be.cast(x, np.float32) for x in tensors]
+    nodes32 = workloads.random_regular_network(be, n=n, D=D, seed=6, tensors=t32)
+    cuts32 = distributed.choose_cut_edges(nodes32, min_slices=min_slices)
+    t0 = time.perf_counter()
+    ref = float(np.asarray(distributed.contract_sliced(nodes32, cuts32)).reshape(-1)[0])
+    be.synchronize()
+    rec["verified"] = {"f32_same_slices": ref, "bf16": result, "rel_err": abs(result - ref) / max(abs(ref), 1e-30),
+                       "f32_seconds": time.perf_counter() - t0,
+                       "tol": "bf16 intermediates over a 63-contraction path: 5e-2 relative",
+                       "ok": bool(abs(result - ref) <= 5e-2 * abs(ref))}
+  return rec
 
 
-def bond_sweep(ta, be):
+# --------------------------------------------------------------------------- sweeps
+def timed_steps(be, fn, reps):
+  fn()
+  be.synchronize()
+  p0 = be.permute_launches
+  t0 = time.perf_counter()
+  for _ in range(reps):
+    out = fn()
+    del out
+  be.synchronize()
+  return (time.perf_counter() - t0) / reps, (be.permute_launches - p0) / reps
+
+
+def bond_sweep(ta, be, verify):
   """Whole-path TFLOP/s of contract_between over the bond-dimension sweep (rank 0, N = 1 only)."""
-  rows = []
+  rows, checks = [], {}
   for D in (32, 64, 96, 128, 192, 256):
     A, B = make_nodes(ta, be, D, "L0", seed=7, fill="normal")
     for layout in ("L0", "L1"):
       reps = 3 if D >= 192 else 10
-      one_step(ta, be, A, B, layout)
-      be.synchronize()
-      t0 = time.perf_counter()
-      for _ in range(reps):
-        out = one_step(ta, be, A, B, layout)
-        del out
-      be.synchronize()
-      t = (time.perf_counter() - t0) / reps
+      t, permutes = timed_steps(be, lambda: one_step(ta, be, A, B, layout), reps)   # pylint: disable=cell-var-from-loop
       rows.append({"D": D, "layout": layout, "gemm": [D * D] * 3, "ms": t * 1e3, "tflops": 2.0 * D**6 / t / 1e12,
-                   "kernel": be.lib.tnh_gemm_last_kernel().decode()})
+                   "kernel": be.lib.tnh_gemm_last_kernel().decode(), "permute_launches": permutes})
+      if verify and D in (192, 256) and not (D == 256 and layout == "L0"):   # D=256 L0 is the headline's own check
+        out = one_step(ta, be, A, B, layout)
+        checks[f"D{D}_{layout}"] = verify_pair(be, A, B, out.tensor, layout, seed=D)
+        del out
     del A, B
   # north-star row: two shared D = 512 bonds, M = N = 8192, K = 262144
   A = be.device_random((64, 128, 512, 512), dtype=ta.bfloat16, seed=11, normal=True, a=0.0, b=1.0 / 512)
   B = be.device_random((512, 512, 128, 64), dtype=ta.bfloat16, seed=12, normal=True, a=0.0, b=1.0 / 512)
+
   def step():
     a, b = ta.Node(A, backend=be), ta.Node(B, backend=be)
     a[2] ^ b[0]  # pylint: disable=pointless-statement
     a[3] ^ b[1]  # pylint: disable=pointless-statement
     return ta.contract_between(a, b)
-  step()
-  be.synchronize()
-  t0 = time.perf_counter()
-  for _ in range(3):
-    out = step()
-    del out
-  be.synchronize()
-  t = (time.perf_counter() - t0) / 3
+  t, permutes = timed_steps(be, step, 3)
+  tf = 2.0 * 8192 * 8192 * 262144 / t / 1e12
   rows.append({"D": 512, "layout": "A(64,128,512,512).B(512,512,128,64)", "gemm": [8192, 8192, 262144], "ms": t * 1e3,
-               "tflops": 2.0 * 8192 * 8192 * 262144 / t / 1e12, "kernel": be.lib.tnh_gemm_last_kernel().decode()})
-  return rows
+               "tflops": tf, "frac_of_bf16_peak": tf / BF16_MFMA_PEAK_TFLOPS,
+               "kernel": be.lib.tnh_gemm_last_kernel().decode(), "permute_launches": permutes})
+  if verify:
+    out = step()
+    checks["D512_row"] = verify_pair(be, A, B, out.tensor, "L0", seed=512)
+    del out
+  return rows, checks
 
 
 def dtype_sweep(ta, be, D=64):
@@ -279,21 +443,61 @@ def dtype_sweep(ta, be, D=64):
                          ("complex128", np.complex128, 8.0)):
     A = be.device_random((D,) * 4, dtype=dt, seed=21, normal=True, b=1.0 / D)
     B = be.device_random((D,) * 4, dtype=dt, seed=22, normal=True, b=1.0 / D)
-    be.tensordot(A, B, [[2, 3], [0, 1]])
-    be.synchronize()
-    reps = 5
-    t0 = time.perf_counter()
-    for _ in range(reps):
-      out = be.tensordot(A, B, [[2, 3], [0, 1]])
-      del out
-    be.synchronize()
-    t = (time.perf_counter() - t0) / reps
+    t, _ = timed_steps(be, lambda: be.tensordot(A, B, [[2, 3], [0, 1]]), 5)   # pylint: disable=cell-var-from-loop
     rows.append({"dtype": name, "D": D, "gemm": [D * D] * 3, "ms": t * 1e3, "tflops": mult * D**6 / t / 1e12,
                  "kernel": be.lib.tnh_gemm_last_kernel().decode()})
     del A, B
   return rows
 
 
+# --------------------------------------------------------------------------- configs[3]
+def mps_chain_bench(ta, be, cpu):
+  """configs[3]: <psi|psi> of a 16-site MPS (32 nodes: kets + conjugates), bulk bond D = 512, f32,
+  contractors.greedy -- launch-latency-bound (about 1e9 flop at d = 2), so also the heavier d = 4 variant;
+  eager and hipGraph replay.  No exchange step: N GPUs run N independent replicas."""
+  from tensornetwork_amd import contractors, workloads as wl  # pylint: disable=import-outside-toplevel
+  rows = []
+  for d in (2, 4):
+    kets = wl.mps_tensors(16, d, 512, seed=5, dtype=np.float32)
+    dev = [be.convert_to_tensor(k) for k in kets]
+    run = lambda b, ts: contractors.greedy(wl.mps_overlap_network(b, ts)).tensor
+    out = run(be, dev)
+    be.synchronize()
+    reps = 5
+    t0 = time.perf_counter()
+    for _ in range(reps):
+      out = run(be, dev)
+    be.synchronize()
+    t_eager = (time.perf_counter() - t0) / reps
+    g = be.capture(lambda *ts: run(be, list(ts)), *dev)
+    try:
+      g.launch()
+      be.synchronize()
+      t0 = time.perf_counter()
+      for _ in range(reps):
+        o2 = g.launch()
+      be.synchronize()
+      t_graph = (time.perf_counter() - t0) / reps
+      v_graph = float(np.asarray(o2[0] if isinstance(o2, (list, tuple)) else o2))
+    finally:
+      g.close()
+    rec = {"sites": 16, "d": d, "D": 512, "dtype": "f32", "gpu_eager_ms": t_eager * 1e3, "gpu_graph_replay_ms": t_graph * 1e3,
+           "value_gpu": float(np.asarray(out)), "value_graph": v_graph}
+    if cpu:
+      from oracle import numpy_oracle as orc  # pylint: disable=import-outside-toplevel
+      ob = orc.OracleBackend()
+      run(ob, kets)
+      t0 = time.perf_counter()
+      ref = float(run(ob, kets))
+      rec["cpu_ms"] = (time.perf_counter() - t0) * 1e3
+      rec["value_cpu"] = ref
+      rec["rel_err_vs_cpu"] = abs(rec["value_gpu"] - ref) / abs(ref)
+      rec["ok"] = bool(rec["rel_err_vs_cpu"] <= 1e-4 and abs(v_graph - ref) <= 1e-4 * abs(ref))
+    rows.append(rec)
+  return rows
+
+
+# --------------------------------------------------------------------------- configs[4]
 def mera_bench(ta, be, chi):
   """configs[4] shape on one GPU: binary-MERA layer energy (12-node network, both placements,
   contractors.branch nbranch=2), bf16 operands generated in HBM; flops from the path cost model."""
@@ -311,13 +515,99 @@ def mera_bench(ta, be, chi):
   run = lambda: workloads.mera_energy(be, ham, rho, iso, dis, lambda nd: contractors.branch(nd, nbranch=2))
   run()
   be.synchronize()
+  p0 = be.permute_launches
   t0 = time.perf_counter()
   out = run()
   be.synchronize()
   t = time.perf_counter() - t0
   return {"workload": f"binary-MERA layer energy, chi={chi}, bf16, left + right placement, contractors.branch(nbranch=2)",
           "seconds": t, "flops": 4.0 * float(macs), "tflops": 4.0 * float(macs) / t / 1e12,
-          "peak_intermediate_elems": float(peak), "energy": float(np.asarray(out).reshape(-1)[0])}
+          "peak_intermediate_elems": float(peak), "permute_launches": be.permute_launches - p0,
+          "energy": float(np.asarray(out).reshape(-1)[0])}
+
+
+def verify_mera(ta, be, chi=16):
+  """The MERA layer energy at chi = 16 from the SAME device-generated tensors three ways: float64 on the
+  oracle backend (host), f32 on the GPU, bf16 on the GPU."""
+  from oracle import numpy_oracle as orc  # pylint: disable=import-outside-toplevel
+  from tensornetwork_amd import contractors, workloads  # pylint: disable=import-outside-toplevel
+  sc = lambda n: float(n) ** -0.5
+  shapes = [((chi,) * 6, sc(chi**3)), ((chi,) * 6, sc(chi**3)), ((chi,) * 3, sc(chi)), ((chi,) * 4, sc(chi * chi))]
+  dev16 = [be.device_random(s, dtype=ta.bfloat16, seed=31 + i, normal=True, b=b) for i, (s, b) in enumerate(shapes)]
+  contractor = lambda nd: contractors.branch(nd, nbranch=2)
+  e16 = float(np.asarray(workloads.mera_energy(be, *dev16, contractor)).reshape(-1)[0])
+  dev32 = [be.cast(t, np.float32) for t in dev16]
+  e32 = float(np.asarray(workloads.mera_energy(be, *dev32, contractor)).reshape(-1)[0])
+  host = [host64(t) for t in dev16]
+  t0 = time.perf_counter()
+  ref = float(workloads.mera_energy(orc.OracleBackend(), *host, contractor))
+  t_cpu = time.perf_counter() - t0
+  # scale: the energy is a sum of products with cancellations; judge the error against the rms of the
+  # two placement terms' magnitude proxy |ref| + tiny
+  rel32 = abs(e32 - ref) / max(abs(ref), 1e-30)
+  rel16 = abs(e16 - ref) / max(abs(ref), 1e-30)
+  return {"chi": chi, "oracle_f64": ref, "hip_f32": e32, "hip_bf16": e16, "rel_err_f32": rel32, "rel_err_bf16": rel16,
+          "oracle_seconds": t_cpu, "tol": "f32 1e-3, bf16 (11 bf16-rounded intermediates) 1e-1 relative",
+          "ok": bool(rel32 <= 1e-3 and rel16 <= 1e-1)}
+
+
+def mera_chi64_bench(ta, be, n_gpus=8):
+  from tensornetwork_amd import workloads  # pylint: disable=import-outside-toplevel
+  per = workloads.mera_sliced_sample(be, 64, ta.bfloat16, reps=2)
+  total = sum(v["sec_per_slice"] * v["n_slices"] for v in per.values())
+  flops = sum(2.0 * v["macs_per_slice"] * v["n_slices"] for v in per.values())
+  return {"workload": "binary-MERA layer energy at chi = 64, bf16: two cut bonds per placement -> 4096 slices each "
+                      "(the dense network needs 137 GB rank-6 inputs and chi^7 intermediates)",
+          "placements": per, "flops_total": flops,
+          "layer_seconds_1gpu_extrapolated": total, f"layer_seconds_{n_gpus}gpu_extrapolated": total / n_gpus,
+          "tflops_1gpu": flops / total / 1e12,
+          "label": "EXTRAPOLATED: measured seconds per slice (one slice per placement, best of 3) x slice count; "
+                   "slices are independent, one scalar all-reduce at the end"}
+
+
+# --------------------------------------------------------------------------- helper kernels
+def helpers_bench(ta, be):
+  """HBM-bound helper kernels at the shapes the BASELINE configs produce; GB/s = algorithmic bytes / time."""
+  rows = []
+
+  def add(name, fn, nbytes, reps=10):
+    fn()
+    be.synchronize()
+    from tensornetwork_amd import _lib  # pylint: disable=import-outside-toplevel
+    s = _lib.Event().record()
+    for _ in range(reps):
+      out = fn()
+      del out
+    e = _lib.Event().record()
+    e.synchronize()
+    ms = s.elapsed_ms(e) / reps
+    rows.append({"op": name, "ms": ms, "algorithmic_bytes": nbytes, "gbps": nbytes / ms / 1e6,
+                 "hbm_roofline_frac": nbytes / ms / 1e6 / HBM_PEAK_GBPS})
+
+  x = be.device_random((16,) * 6, dtype=np.float32, seed=41)
+  add("K1 permute f32 (16,)*6 -> (0,2,4,1,3,5)  [configs[2] mixed edge order]", lambda: be.transpose(x, (0, 2, 4, 1, 3, 5)),
+      2 * x.nbytes)
+  del x
+  x = be.device_random((128,) * 4, dtype=ta.bfloat16, seed=42)
+  add("K1 permute bf16 (128,)*4 -> (0,2,1,3)  [configs[1] L1 operand, D = 128]", lambda: be.transpose(x, (0, 2, 1, 3)),
+      2 * x.nbytes)
+  add("K1 permute bf16 (128,)*4 -> (2,3,0,1)  [[K][N] -> [N][K]]", lambda: be.transpose(x, (2, 3, 0, 1)), 2 * x.nbytes)
+  del x
+  x = be.device_random((4096, 4096, 16), dtype=np.float32, seed=43)
+  add("K4 sum f32 (4096,4096,16) over axis 1", lambda: be.sum(x, axis=1), x.nbytes + x.nbytes // 4096)
+  add("K4 sum f32 (4096,4096,16) over all axes", lambda: be.sum(x), x.nbytes)
+  del x
+  x = be.device_random((4096, 256, 256), dtype=np.float32, seed=44)
+  add("K3 trace f32 (4096,256,256) over the last two axes", lambda: be.trace(x), 4096 * 256 * 4 + 4096 * 4)
+  del x
+  x = be.device_random((4096, 4096), dtype=np.float32, seed=45)
+  v = be.device_random((4096,), dtype=np.float32, seed=46)
+  add("K5 broadcast_right_multiplication f32 4096^2 x (4096,)  [u sqrt(s)]", lambda: be.broadcast_right_multiplication(x, v),
+      2 * x.nbytes)
+  add("K5 broadcast_left_multiplication f32 (4096,) x 4096^2  [sqrt(s) vh]", lambda: be.broadcast_left_multiplication(v, x),
+      2 * x.nbytes)
+  add("K6 sqrt f32 4096^2", lambda: be.sqrt(x), 2 * x.nbytes)
+  return rows
 
 
 def load_traffic(kernel_name, M, N, K):
@@ -334,14 +624,39 @@ def load_traffic(kernel_name, M, N, K):
   return None, None
 
 
+def fenced(result, key, fn):
+  """every secondary leg is fenced: whatever happens in one of them, the headline line is printed"""
+  try:
+    result[key] = fn()
+  except Exception as exc:  # pylint: disable=broad-except
+    result[key] = {"error": f"{type(exc).__name__}: {exc}"}
+
+
 def main():
   args = parse_args()
-  rank, world, local, dist = dist_setup(args.gpus)
+  rank = int(os.environ.get("RANK", "0"))
+  world = int(os.environ.get("WORLD_SIZE", "1"))
+  local = int(os.environ.get("LOCAL_RANK", "0"))
+  use_dist = world > 1 or bool(os.environ.get("TNH_BENCH_FORCE_DIST"))
+  if use_dist:
+    assert world == args.gpus or os.environ.get("TNH_BENCH_FORCE_DIST"), (world, args.gpus)
+  comm, comm_name = None, "none"
+  if use_dist and args.comm == "torch":
+    comm = TorchComm(rank, world, local)      # torch's HIP runtime first (see TorchComm)
+    comm_name = "torch.distributed (nccl = RCCL)"
   os.environ.setdefault("TNHIP_DEVICE", str(local))
   import tensornetwork_amd as ta  # pylint: disable=import-outside-toplevel
-  from tensornetwork_amd import _lib  # pylint: disable=import-outside-toplevel
+  from tensornetwork_amd import _lib, telemetry  # pylint: disable=import-outside-toplevel
 
   be = ta.get_hip_backend()
+  be.lib  # pylint: disable=pointless-statement
+  if use_dist and args.comm == "rccl":
+    from tensornetwork_amd import comm as tcomm  # pylint: disable=import-outside-toplevel
+    comm = tcomm.RcclComm(be, rank=rank, world=world)
+    comm_name = "libtnhip K8 (tnh_allreduce / tnh_allgather over RCCL), TCP rendezvous for the id"
+  elif comm is not None:
+    comm.bind()
+
   D = args.bond
   M = N = K = D * D
   flops_per_step = 2.0 * M * N * K
@@ -350,26 +665,29 @@ def main():
   for _ in range(args.warmup):
     out = one_step(ta, be, A, B, args.layout)
     del out
+  tel = telemetry.Telemetry(be.lib) if rank == 0 else None
   be.gemm_events = []          # HIP events around every GEMM launch in the timed region
-  sync_all(be, dist)
-  t0 = time.perf_counter()
-  for _ in range(args.steps):
-    out = one_step(ta, be, A, B, args.layout)
-    del out
-  sync_all(be, dist)
-  elapsed = time.perf_counter() - t0
+  p0 = be.permute_launches
+  sync_all(be, comm)
+  with telemetry.Sampler(tel) as sampler:
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+      out = one_step(ta, be, A, B, args.layout)
+      if _ < args.steps - 1:
+        del out
+    sync_all(be, comm)
+    elapsed = time.perf_counter() - t0
   events, be.gemm_events = be.gemm_events, None
+  permutes_per_step = (be.permute_launches - p0) / max(args.steps, 1)
   kernel_name = be.lib.tnh_gemm_last_kernel().decode()
-
-  if dist is not None:
-    import torch  # pylint: disable=import-outside-toplevel
-    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
+  if comm is not None:
+    elapsed = comm.max_over_ranks(elapsed)
 
   gemm_ms = [s.elapsed_ms(e) for s, e in events]
   gemm_avg_s = (sum(gemm_ms) / len(gemm_ms) / 1e3) if gemm_ms else float("nan")
   achieved = flops_per_step / gemm_avg_s / 1e12 if gemm_ms else float("nan")
+  power = sampler.summary() if rank == 0 else {}
+  clock = power.get("sclk_mean_mhz")
 
   traffic, traffic_src = load_traffic(kernel_name, M, N, K)
   result = {
@@ -388,56 +706,76 @@ def main():
       "config": {"workload": f"contract_between, two rank-4 bf16 nodes, bond D={D}, layout {args.layout} "
                              f"(GEMM {M}x{N}x{K}, fp32 accumulate, bf16 out)",
                  "parallelism": "1 GPU" if world == 1 else f"{world} independent pairwise contractions "
-                                                           "(no data-path collective)"},
+                                                           "(no data-path collective)",
+                 "comm": comm_name, "permute_launches_per_step": permutes_per_step},
       "roofline": {"bound": "mfma", "achieved": achieved, "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                    "frac": achieved / BF16_MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
                    "algorithmic_bytes": 2.0 * (M * K + N * K + M * N), "kernel": kernel_name,
-                   "kernel_ms": gemm_avg_s * 1e3, "launches": len(gemm_ms)},
+                   "kernel_ms": gemm_avg_s * 1e3, "launches": len(gemm_ms),
+                   "observed_clock_mhz": clock, "board_power_w": power.get("power_mean_w"),
+                   "board_power_cap_w": power.get("power_cap_w"),
+                   "peak_at_observed_clock": (BF16_MFMA_PEAK_TFLOPS * clock / MAX_CLOCK_MHZ) if clock else None,
+                   "frac_at_observed_clock": (achieved / (BF16_MFMA_PEAK_TFLOPS * clock / MAX_CLOCK_MHZ)) if clock else None},
   }
-  del A, B
+  verified = {}
+  if rank == 0 and not args.no_verify and args.fill == "normal":
+    try:
+      verified["headline_D%d_%s" % (D, args.layout)] = verify_pair(be, A, B, out.tensor, args.layout, seed=1)
+    except Exception as exc:  # pylint: disable=broad-except
+      verified["headline"] = {"error": f"{type(exc).__name__}: {exc}"}
+  del out, A, B
   _lib.check(be.lib.tnh_trim())
   if args.rr_bond > 0:
-    try:
-      sliced = sliced_network_bench(ta, be, dist, rank, world, args.rr_bond, args.rr_min_slices)
-    except Exception as exc:  # pylint: disable=broad-except
-      sliced = {"error": f"{type(exc).__name__}: {exc}"}
-    result["sliced_network"] = sliced
+    fenced(result, "sliced_network", lambda: sliced_network_bench(ta, be, comm, rank, world, args.rr_bond, args.rr_min_slices,
+                                                                  not args.no_verify))
+    if isinstance(result["sliced_network"], dict) and "verified" in result["sliced_network"]:
+      verified["sliced_network_bf16_vs_f32"] = result["sliced_network"].pop("verified")
   if rank == 0:
-    if world == 1 and not args.no_sweep:
+    single = world == 1
+    if single and not args.no_sweep:
       try:
-        result["bond_sweep"] = bond_sweep(ta, be)
+        result["bond_sweep"], checks = bond_sweep(ta, be, not args.no_verify)
+        verified.update(checks)
       except Exception as exc:  # pylint: disable=broad-except
         result["bond_sweep"] = {"error": f"{type(exc).__name__}: {exc}"}
       _lib.check(be.lib.tnh_trim())
-      try:
-        result["dtype_sweep"] = dtype_sweep(ta, be)
-      except Exception as exc:  # pylint: disable=broad-except
-        result["dtype_sweep"] = {"error": f"{type(exc).__name__}: {exc}"}
+      fenced(result, "dtype_sweep", lambda: dtype_sweep(ta, be))
       _lib.check(be.lib.tnh_trim())
-    if world == 1 and args.mera_chi > 0:
-      try:
-        result["mera"] = mera_bench(ta, be, args.mera_chi)
-      except Exception as exc:  # pylint: disable=broad-except
-        result["mera"] = {"error": f"{type(exc).__name__}: {exc}"}
+    if single and args.mera_chi > 0:
+      fenced(result, "mera", lambda: mera_bench(ta, be, args.mera_chi))
       _lib.check(be.lib.tnh_trim())
-    # every secondary leg is fenced: whatever happens in one of them, the headline line is printed
-    if world == 1 and args.svd_n > 0:
+    if single and not args.no_extras:
+      fenced(result, "mera_chi64", lambda: mera_chi64_bench(ta, be))
+      _lib.check(be.lib.tnh_trim())
+      fenced(result, "mps_chain", lambda: mps_chain_bench(ta, be, not args.no_cpu_baseline))
+      fenced(result, "helpers", lambda: helpers_bench(ta, be))
+      _lib.check(be.lib.tnh_trim())
+    if single and args.svd_n > 0:
       try:
-        svd_bench(ta, be, args.svd_n, max(args.svd_n // 16, 1))  # warm-up
-        result["svd"] = svd_bench(ta, be, args.svd_n, max(args.svd_n // 16, 1))
+        k = max(args.svd_n // 16, 1)
+        svd_bench(ta, be, args.svd_n, k)  # warm-up
+        result["svd"], outputs = svd_bench(ta, be, args.svd_n, k, keep_outputs=True)
+        if not args.no_verify:
+          try:
+            verified["svd"] = verify_svd(be, args.svd_n, k, outputs)
+          except Exception as exc:  # pylint: disable=broad-except
+            verified["svd"] = {"error": f"{type(exc).__name__}: {exc}"}
+        del outputs
         if not args.no_cpu_baseline:
           result["svd"]["cpu_baseline"] = svd_cpu_baseline(args.svd_n)
       except Exception as exc:  # pylint: disable=broad-except
         result.setdefault("svd", {})["error"] = f"{type(exc).__name__}: {exc}"
-    if world == 1 and not args.no_cpu_baseline:
-      try:
-        result["cpu_baseline"] = cpu_baseline(args.layout)
-      except Exception as exc:  # pylint: disable=broad-except
-        result["cpu_baseline"] = {"error": f"{type(exc).__name__}: {exc}"}
+    if single and not args.no_verify and not args.no_cpu_baseline:
+      fenced(verified, "mera_chi16", lambda: verify_mera(ta, be, 16))
+    if single and not args.no_cpu_baseline:
+      fenced(result, "cpu_baseline", lambda: cpu_baseline(args.layout))
+    if verified:
+      verified["all_ok"] = bool(all(v.get("ok", False) for v in verified.values() if isinstance(v, dict)))
+      result["verified"] = verified
     print(json.dumps(result))
-  if dist is not None:
-    dist.barrier()
-    dist.destroy_process_group()
+  if comm is not None:
+    comm.barrier()
+    comm.close()
 
 
 if __name__ == "__main__":

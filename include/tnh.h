@@ -63,6 +63,8 @@ int tnh_shutdown(void);
 int tnh_device_count(int* count);
 /* name: caller buffer of `len` bytes; cus: compute units; hbm_bytes: total. */
 int tnh_device_info(char* name, int len, int* cus, int64_t* hbm_bytes);
+/* PCI address of the device ("0000:c1:00.0"), to find its sysfs telemetry (power, clocks). */
+int tnh_device_pci_bus_id(char* buf, int len);
 const char* tnh_last_error(void);
 const char* tnh_version(void);
 
@@ -157,6 +159,24 @@ int tnh_complex_expand(void* dst, const void* src, int64_t K, int64_t N,
                        int64_t row_stride, int64_t col_stride, int conj, int dtype);
 
 /* Name of the kernel variant the last tnh_gemm call dispatched to. */
+/* bf16 / f16 contraction with BOTH operands read in place through two-level strides -- the
+ * "transpose absorbed into the GEMM" lowering of tensordot (spec: the reference's own
+ * backends/tensorflow/tensordot2.py:62-88, 128-143, which picks transpose flags instead of moving
+ * data; generalised here to operands whose free / contracted axes each form up to two memory runs,
+ * e.g. a[i0, k1, i2, k3]).  Element (r, k) of an operand lives at
+ *     (r / r0) * sr1 + (r % r0) * sr0  +  (k / k0) * sk1 + (k % k0) * sk0      (elements)
+ * with exactly one of sk0 / sr0 equal to 1 ("K-contiguous" or "k-major"), k0 % 64 == 0 and
+ * K % k0 == 0; strides multiples of 8 elements, bases 16-byte aligned.  C is row-major M x N (ldc).
+ * Returns TNH_ERR_UNSUPPORTED (nothing launched) when the shape is outside the 256 x 256 tile
+ * kernel's range or an alignment rule fails: the caller then materialises a permuted copy and
+ * calls tnh_gemm.  Results are bit-identical to that fallback (same MFMA sequence). */
+typedef struct {
+  int64_t r0, sr0, sr1;
+  int64_t k0, sk0, sk1;
+} tnh_operand_view;
+int tnh_gemm_view(int in_dtype, int out_dtype, int64_t M, int64_t N, int64_t K, const void* A,
+                  const tnh_operand_view* va, const void* B, const tnh_operand_view* vb, void* C,
+                  int64_t ldc);
 const char* tnh_gemm_last_kernel(void);
 /* Force a variant ("auto", "generic", "valu", "bf16_128", "bf16_256", "bf16_256pp", "bf16_ragged*"),
  * optionally followed by A/B knobs ":r<d>" (tile raster), ":p<d>" (bf16 pipeline variant; 6 = the

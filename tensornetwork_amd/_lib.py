@@ -28,6 +28,12 @@ F32, F64, BF16, F16, C64, C128, I32, I64 = range(8)
  OP_COPY, OP_REAL, OP_IMAG) = range(12)
 OP_ADD, OP_SUB, OP_MUL, OP_DIV, OP_POW = range(5)
 
+class OperandView(ctypes.Structure):
+  """tnh_operand_view (include/tnh.h): two-level row / contraction strides of one GEMM operand."""
+  _fields_ = [("r0", c_int64), ("sr0", c_int64), ("sr1", c_int64),
+              ("k0", c_int64), ("sk0", c_int64), ("sk1", c_int64)]
+
+
 _I64P = POINTER(c_int64)
 _I32P = POINTER(c_int32)
 
@@ -37,6 +43,7 @@ SIGNATURES = {
     "tnh_shutdown": (c_int, []),
     "tnh_device_count": (c_int, [POINTER(c_int)]),
     "tnh_device_info": (c_int, [c_char_p, c_int, POINTER(c_int), _I64P]),
+    "tnh_device_pci_bus_id": (c_int, [c_char_p, c_int]),
     "tnh_last_error": (c_char_p, []),
     "tnh_version": (c_char_p, []),
     "tnh_malloc": (c_int, [POINTER(c_void_p), c_size_t]),
@@ -70,6 +77,8 @@ SIGNATURES = {
     "tnh_gemm_ex": (c_int, [c_int, c_int, c_int, c_int, c_int64, c_int64, c_int64,
                             c_void_p, c_int64, c_void_p, c_int64, c_void_p,
                             c_int64, c_int64, c_int64, c_int64, c_int64, c_double, c_double]),
+    "tnh_gemm_view": (c_int, [c_int, c_int, c_int64, c_int64, c_int64, c_void_p, POINTER(OperandView),
+                              c_void_p, POINTER(OperandView), c_void_p, c_int64]),
     "tnh_complex_expand": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_int, c_int]),
     "tnh_gemm_last_kernel": (c_char_p, []),
     "tnh_gemm_set_variant": (c_int, [c_char_p]),

@@ -15,6 +15,7 @@
 #include <stdlib.h>
 #include <algorithm>
 #include "tnh_types.h"
+#include "tnh_gemm_nt.h"
 
 namespace tnh {
 
@@ -34,6 +35,9 @@ extern int g_opt_raster, g_opt_phases;
 int gemm_bf16_fast(int in_dt, int out_dt, int variant, int transA, int transB, int64_t M, int64_t N,
                    int64_t K, const void* A, int64_t lda, const void* B, int64_t ldb, void* C,
                    int64_t ldc, int64_t batch, int64_t sA, int64_t sB, int64_t sC, const char** name);
+
+int gemm_bf16_view(int in_dt, int out_dt, int64_t M, int64_t N, int64_t K, const void* A, const OpView& va,
+                   const void* B, const OpView& vb, void* C, int64_t ldc, const char** name);
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef double f64x4 __attribute__((ext_vector_type(4)));
@@ -644,6 +648,35 @@ int tnh_complex_expand(void* dst, const void* src, int64_t K, int64_t N, int64_t
                        (const double*)src, K, N, row_stride, col_stride, conj);
   TNH_LAUNCH_CHECK();
   return TNH_OK;
+}
+
+int tnh_gemm_view(int in_dtype, int out_dtype, int64_t M, int64_t N, int64_t K, const void* A,
+                  const tnh_operand_view* va, const void* B, const tnh_operand_view* vb, void* C, int64_t ldc) {
+  TNH_NEED_INIT();
+  TNH_REQUIRE(in_dtype == TNH_BF16 || in_dtype == TNH_F16, "tnh_gemm_view: bf16 / f16 operands only (got %d)", in_dtype);
+  TNH_REQUIRE(out_dtype == in_dtype || out_dtype == TNH_F32, "tnh_gemm_view: bad output dtype %d", out_dtype);
+  TNH_REQUIRE(M > 0 && N > 0 && K > 0 && A && B && C && va && vb, "tnh_gemm_view: bad arguments");
+  TNH_REQUIRE(ldc >= N, "ldc (%lld) < N (%lld)", (long long)ldc, (long long)N);
+  auto conv = [](const tnh_operand_view* v, int64_t K, OpView* o) -> bool {
+    if (v->k0 <= 0 || v->r0 <= 0 || v->k0 % 64 != 0 || K % v->k0 != 0) return false;
+    o->r0 = v->r0; o->sr0 = v->sr0; o->sr1 = v->sr1;
+    o->sk0 = v->sk0; o->sk1 = v->sk1;
+    o->tpi = (int)(v->k0 / 64);
+    return v->k0 / 64 < (int64_t(1) << 30);
+  };
+  if (g_variant != 0) {   // a kernel forced through tnh_gemm_set_variant (tests, A/B): the caller's fallback path runs it
+    set_error("tnh_gemm_view: a GEMM variant is forced");
+    return TNH_ERR_UNSUPPORTED;
+  }
+  OpView a, b;
+  if (!conv(va, K, &a) || !conv(vb, K, &b)) {
+    set_error("tnh_gemm_view: the inner contraction run of an operand is not a multiple of 64 that divides K");
+    return TNH_ERR_UNSUPPORTED;
+  }
+  const char* name = nullptr;
+  int rc = gemm_bf16_view(in_dtype, out_dtype, M, N, K, A, a, B, b, C, ldc, &name);
+  if (rc == TNH_OK) g_last_kernel = name;
+  return rc;
 }
 
 int tnh_gemm(int in_dtype, int out_dtype, int transA, int transB, int64_t M, int64_t N, int64_t K,

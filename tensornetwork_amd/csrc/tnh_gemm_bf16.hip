@@ -187,8 +187,47 @@ __device__ __forceinline__ f32x16 mma32(const uint4& a, const uint4& b, f32x16 c
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(*(const f16x8*)&a, *(const f16x8*)&b, c, 0, 0, 0);
 }
 
-template <bool IS_BF16, bool OUT_F32, bool TWO, bool M32 = false>
+// VIEW = true (tnh_gemm_view; needs TWO, not M32): operands are read IN PLACE through an OpView --
+// two-level row / contraction strides, and per operand either K-contiguous (the LDS image and the
+// ds_read_b128 fragments above) or k-major (A_KM / B_KN: the operand is stored [k][row], rows
+// contiguous -- what tensordot's [K][N] operand is).  A k-major half-tile is staged as [64 k][128 rows]
+// (256-B LDS rows, 4 k-rows per LDS-DMA piece) and its MFMA fragments -- 8 consecutive k of one row per
+// lane -- come from two ds_read_b64_tr_b16 (the LDS transpose read: each 16-lane group fetches a
+// [4 k][16 rows] block and lane i receives column i; semantics pinned by tools/tr_probe.hip).  Bank
+// conflicts: a 32-lane half of one transpose read touches 8 k-rows (k & 3, bit 3 of k) x 32 B; the
+// 32-B unit index of every row is XOR-ed with h(k) = (k & 3) | ((k >> 3) & 1) << 2, on the LDS-DMA
+// source side and again on the read address, so the 8 segments fall on 8 different 32-B bank windows.
+// Same MFMA sequence as the NT kernel, so results are bit-identical to permute + NT.
+typedef short v4i16 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) v4i16 lds_v4i16;
+typedef __attribute__((address_space(3))) char lds_char;
+
+// walks the element offset of consecutive K-tiles of one operand (wave-uniform, SALU only)
+struct KWalk {
+  int64_t off, step, wrap;
+  int in, tpi;
+  __device__ __forceinline__ void init(const OpView& v, int tile) {
+    tpi = v.tpi;
+    step = 64 * v.sk0;
+    wrap = v.sk1 - (int64_t)v.tpi * step;
+    in = tile % v.tpi;
+    off = (int64_t)(tile / v.tpi) * v.sk1 + (int64_t)in * step;
+  }
+  __device__ __forceinline__ void advance() {
+    ++in;
+    off += step;
+    if (in == tpi) {
+      in = 0;
+      off += wrap;
+    }
+  }
+};
+
+template <bool IS_BF16, bool OUT_F32, bool TWO, bool M32 = false, bool VIEW = false, bool A_KM = false,
+          bool B_KN = false>
 __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(NtArgs p) {
+  static_assert(!VIEW || (TWO && !M32), "view kernels use the 2-phase 16x16x32 schedule");
+  static_assert(VIEW || (!A_KM && !B_KN), "k-major operands need the view kernel");
   // M32 (32x32x16 MFMA) lost the A/B with 4 phases per K-tile (only 2 independent accumulators per
   // phase); variant ":p3" re-tests it with the 2-phase schedule (4 independent accumulators).
   constexpr int BM = 256, BN = 256, BK = 64;
@@ -216,19 +255,38 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(NtArgs p) {
   const int lrow = lane >> 3;
   const uint16_t* ga[2][2];
   const uint16_t* gb[2][2];
+  // K-contiguous operand: piece (h, i) -> tile rows h*128 + (i*8 + wid)*8 + (lane >> 3), 16-B chunk (lane & 7) ^ swz.
+  // k-major operand:      piece (h, i) -> k rows (i*8 + wid)*4 + (lane >> 4) of the K-tile, and the 16-B chunk of
+  //                       the half-tile's 128 rows that lands in slot (lane & 15): 32-B unit ((lane & 15) >> 1) ^ h(k).
+  auto src_ptr = [&](const uint16_t* base, const OpView& v, bool kmajor, int64_t first, int64_t limit, int64_t ld,
+                     int h, int i) -> const uint16_t* {
+    if (kmajor) {
+      const int krow = (i * 8 + wid) * 4 + (lane >> 4);
+      const int s16 = lane & 15;
+      const int hsw = (lane >> 4) | (((wid >> 1) & 1) << 2);                 // h(krow): see the kernel header
+      const int chunk = ((((s16 >> 1) ^ hsw)) << 1) | (s16 & 1);
+      int64_t col = first + h * 128 + chunk * 8;
+      if (col + 8 > limit) col = limit - 8;                                  // ragged edge: valid memory, never stored
+      const uint32_t c1 = (uint32_t)col / (uint32_t)v.r0, c0 = (uint32_t)col - c1 * (uint32_t)v.r0;   // rows < 2^31 (host check)
+      return base + (int64_t)c1 * v.sr1 + c0 + (int64_t)krow * v.sk0;
+    }
+    const int trow = (i * 8 + wid) * 8 + lrow;  // row inside the half-tile
+    const int swz = M32 ? ((trow >> 1) & 7) : (trow & 7);
+    const int lchunk = (lane & 7) ^ swz;
+    int64_t row = first + h * 128 + trow;
+    if (row >= limit) row = limit - 1;
+    if constexpr (VIEW) {
+      const uint32_t r1 = (uint32_t)row / (uint32_t)v.r0, r0 = (uint32_t)row - r1 * (uint32_t)v.r0;
+      return base + (int64_t)r1 * v.sr1 + (int64_t)r0 * v.sr0 + lchunk * 8;
+    }
+    return base + row * ld + lchunk * 8;
+  };
 #pragma unroll
   for (int h = 0; h < 2; ++h)
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const int trow = (i * 8 + wid) * 8 + lrow;  // row inside the half-tile
-      const int swz = M32 ? ((trow >> 1) & 7) : (trow & 7);
-      const int lchunk = (lane & 7) ^ swz;
-      int64_t row = m0 + h * 128 + trow;
-      if (row >= p.M) row = p.M - 1;
-      ga[h][i] = A + row * p.lda + lchunk * 8;
-      row = n0 + h * 128 + trow;
-      if (row >= p.N) row = p.N - 1;
-      gb[h][i] = B + row * p.ldb + lchunk * 8;
+      ga[h][i] = src_ptr(A, p.va, A_KM, m0, p.M, p.lda, h, i);
+      gb[h][i] = src_ptr(B, p.vb, B_KN, n0, p.N, p.ldb, h, i);
     }
   const unsigned lds0 = (unsigned)(size_t)TNH_LDS_PTR(smem);
   // which: 0 = A-half0, 1 = A-half1, 2 = B-half0, 3 = B-half1
@@ -270,19 +328,49 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(NtArgs p) {
   uint4 af[KS][FA];     // [k-step][row fragment] of the current A sub-tile
   uint4 bf[2][KS][FB];  // [sub][k-step][row fragment] of both B sub-tiles
 
+  // k-major images: per-lane part of the transpose-read address.  Lane (g = lane >> 4, i = lane & 15)
+  // reads k row 32 ks + 8 g + 4 r + (i >> 2), bytes 8 (i & 3) .. +7 of 32-B unit u ^ h:
+  //   byte = [8 g + (i >> 2)] * 256 + ((u ^ h) << 5) + 8 (i & 3) + ks * 8192 + r * 1024,   h = (i >> 2) | (g & 1) << 2
+  // the row term, the unit term and the in-unit term occupy disjoint bits, so (base | h << 5) ^ (u << 5) is the address.
+  const unsigned tr_lane = (unsigned)((8 * (lane >> 4) + ((lane & 15) >> 2)) * 256 + 8 * (lane & 3)) |
+                           (unsigned)((((lane & 15) >> 2) | (((lane >> 4) & 1) << 2)) << 5);
+  const unsigned tr_a = tr_lane;                                  // A units: sub * 4 + f
+  const unsigned tr_b = tr_lane ^ (unsigned)(((wc & 1) * 4) << 5);  // B units: (wc & 1) * 4 + sub * 2 + f
+  auto tr_read = [&](unsigned lds_byte) -> uint4 {
+    const v4i16 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4i16*)((lds_char*)TNH_LDS_PTR(smem) + lds_byte));
+    const v4i16 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4i16*)((lds_char*)TNH_LDS_PTR(smem) + lds_byte + 1024));
+    const uint2 l2 = *(const uint2*)&lo, h2 = *(const uint2*)&hi;
+    return make_uint4(l2.x, l2.y, h2.x, h2.y);
+  };
   auto read_a = [&](const char* buf_base, int sub) {
-    const char* sa = buf_base + wr * HALF_BYTES + (sub * 64) * 128;
+    if constexpr (A_KM) {
+      const unsigned base = (unsigned)(buf_base - smem) + wr * HALF_BYTES;
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks)
+      for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-      for (int f = 0; f < FA; ++f) af[ks][f] = *(const uint4*)(sa + f * FROWS * 128 + frag_off[ks]);
+        for (int f = 0; f < FA; ++f) af[ks][f] = tr_read(base + (tr_a ^ (unsigned)((sub * 4 + f) << 5)) + ks * 8192);
+    } else {
+      const char* sa = buf_base + wr * HALF_BYTES + (sub * 64) * 128;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int f = 0; f < FA; ++f) af[ks][f] = *(const uint4*)(sa + f * FROWS * 128 + frag_off[ks]);
+    }
   };
   auto read_b = [&](const char* buf_base, int sub) {
-    const char* sb = buf_base + (2 + (wc >> 1)) * HALF_BYTES + ((wc & 1) * 64 + sub * 32) * 128;
+    if constexpr (B_KN) {
+      const unsigned base = (unsigned)(buf_base - smem) + (2 + (wc >> 1)) * HALF_BYTES;
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks)
+      for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-      for (int f = 0; f < FB; ++f) bf[sub][ks][f] = *(const uint4*)(sb + f * FROWS * 128 + frag_off[ks]);
+        for (int f = 0; f < FB; ++f) bf[sub][ks][f] = tr_read(base + (tr_b ^ (unsigned)((sub * 2 + f) << 5)) + ks * 8192);
+    } else {
+      const char* sb = buf_base + (2 + (wc >> 1)) * HALF_BYTES + ((wc & 1) * 64 + sub * 32) * 128;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int f = 0; f < FB; ++f) bf[sub][ks][f] = *(const uint4*)(sb + f * FROWS * 128 + frag_off[ks]);
+    }
   };
   auto mma_quadrant = [&](int sa, int sb) {
     __builtin_amdgcn_s_setprio(1);
@@ -316,15 +404,23 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(NtArgs p) {
   } while (0)
 
   const int nt = (int)(p.K / BK);
+  // element offset of the K-tile each operand stages next: A runs one tile ahead, B two
+  KWalk wa, wb;
+  if constexpr (VIEW) {
+    wa.init(p.va, 1);
+    wb.init(p.vb, 1);
+  }
   // prologue: tile 0 complete, B halves of tile 1
   issue(0, 0, 0);
   issue(0, 1, 0);
   issue(0, 2, 0);
   issue(0, 3, 0);
   if (nt > 1) {
-    issue(1, 2, BK);
-    issue(1, 3, BK);
+    const int64_t kb1 = VIEW ? wb.off : (int64_t)BK;
+    issue(1, 2, kb1);
+    issue(1, 3, kb1);
   }
+  if constexpr (VIEW) wb.advance();
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (wr == 1) __builtin_amdgcn_s_barrier();  // group 1 runs one interval behind group 0
@@ -340,8 +436,10 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(NtArgs p) {
       read_b(cur, 0);
       read_b(cur, 1);
       if (n1) {
-        issue(b ^ 1, 0, (int64_t)(t + 1) * BK);
-        issue(b ^ 1, 1, (int64_t)(t + 1) * BK);
+        const int64_t ka = VIEW ? wa.off : (int64_t)(t + 1) * BK;
+        issue(b ^ 1, 0, ka);
+        issue(b ^ 1, 1, ka);
+        if constexpr (VIEW) wa.advance();
       }
       TNH_SEG_LOAD_END();
       mma_quadrant(0, 0);
@@ -349,8 +447,10 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(NtArgs p) {
       TNH_SEG_MMA_END();
       read_a(cur, 1);
       if (n2) {
-        issue(b, 2, (int64_t)(t + 2) * BK);
-        issue(b, 3, (int64_t)(t + 2) * BK);
+        const int64_t kb = VIEW ? wb.off : (int64_t)(t + 2) * BK;
+        issue(b, 2, kb);
+        issue(b, 3, kb);
+        if constexpr (VIEW) wb.advance();
         asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
       } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -701,6 +801,74 @@ static int launch_pp(bool is_bf16, bool out_f32, bool two, NtArgs p, int64_t bat
 #undef TNH_PP_LAUNCH
     TNH_LAUNCH_CHECK();
   }
+  return TNH_OK;
+}
+
+// ---- view GEMM: operands read in place through two-level strides (tnh_gemm_view) ----------------
+template <bool A_KM, bool B_KN>
+static void launch_pp_view_t(bool is_bf16, bool out_f32, dim3 grid, const NtArgs& q) {
+  const dim3 block(512);
+  if (is_bf16) {
+    if (out_f32) hipLaunchKernelGGL((gemm_nt_pp_kernel<true, true, true, false, true, A_KM, B_KN>), grid, block, 0, stream(), q);
+    else hipLaunchKernelGGL((gemm_nt_pp_kernel<true, false, true, false, true, A_KM, B_KN>), grid, block, 0, stream(), q);
+  } else {
+    if (out_f32) hipLaunchKernelGGL((gemm_nt_pp_kernel<false, true, true, false, true, A_KM, B_KN>), grid, block, 0, stream(), q);
+    else hipLaunchKernelGGL((gemm_nt_pp_kernel<false, false, true, false, true, A_KM, B_KN>), grid, block, 0, stream(), q);
+  }
+}
+
+static bool view_ok(const OpView& v, int64_t rows, int64_t K, const void* base, const char* which) {
+  const bool kcontig = (v.sk0 == 1), kmajor = (v.sr0 == 1 && v.sk0 != 1);
+  if (!kcontig && !kmajor) {
+    set_error("tnh_gemm_view: operand %s has no contiguous direction (sk0 %lld, sr0 %lld)", which, (long long)v.sk0,
+              (long long)v.sr0);
+    return false;
+  }
+  const int64_t k0 = (int64_t)v.tpi * 64;
+  bool ok = v.tpi >= 1 && v.r0 >= 1 && K % k0 == 0 && ((uintptr_t)base % 16) == 0 && v.sr1 % 8 == 0 && v.sk1 % 8 == 0;
+  if (kcontig) ok = ok && v.sr0 % 8 == 0;
+  else ok = ok && v.sk0 % 8 == 0 && v.r0 % 8 == 0 && rows % 8 == 0;
+  if (!ok) set_error("tnh_gemm_view: operand %s breaks the 16-byte / 64-deep alignment rules of the LDS-DMA loaders", which);
+  return ok;
+}
+
+int gemm_bf16_view(int in_dt, int out_dt, int64_t M, int64_t N, int64_t K, const void* A, const OpView& va,
+                   const void* B, const OpView& vb, void* C, int64_t ldc, const char** name) {
+  const bool big = (M >= 256 && N >= 256) && (((M + 255) / 256) * ((N + 255) / 256) >= 192);
+  if (!big || K % 64 != 0 || K < 128 || ldc % 4 != 0 || ((uintptr_t)C % 16) != 0 || M >= (int64_t(1) << 31) ||
+      N >= (int64_t(1) << 31)) {
+    set_error("tnh_gemm_view: shape outside the 256x256 ping-pong kernel's range");
+    return TNH_ERR_UNSUPPORTED;
+  }
+  if (!view_ok(va, M, K, A, "A") || !view_ok(vb, N, K, B, "B")) return TNH_ERR_UNSUPPORTED;
+  NtArgs p;
+  p.va = va;
+  p.vb = vb;
+  if (p.va.r0 > M) p.va.r0 = M;   // single-level rows: keep the 32-bit row split in range
+  if (p.vb.r0 > N) p.vb.r0 = N;
+  p.A = (const uint16_t*)A;
+  p.B = (const uint16_t*)B;
+  p.C = C;
+  p.M = M; p.N = N; p.K = K;
+  p.lda = va.sr0; p.ldb = vb.sr0; p.ldc = ldc;
+  p.sA = p.sB = p.sC = 0;
+  p.raster = g_opt_raster;
+  p.c_vec = 1;
+  p.a_vw = p.b_vw = 8;
+  p.tiles_m = (int)((M + 255) / 256);
+  p.tiles_n = (int)((N + 255) / 256);
+  const int64_t nwg = (int64_t)p.tiles_m * p.tiles_n;
+  TNH_REQUIRE(nwg < (int64_t(1) << 24), "GEMM grid too large");
+  const bool a_km = (va.sk0 != 1), b_kn = (vb.sk0 != 1);
+  const bool is_bf16 = (in_dt == TNH_BF16), out_f32 = (out_dt == TNH_F32);
+  const dim3 grid((unsigned)nwg, 1);
+  if (a_km && b_kn) launch_pp_view_t<true, true>(is_bf16, out_f32, grid, p);
+  else if (a_km) launch_pp_view_t<true, false>(is_bf16, out_f32, grid, p);
+  else if (b_kn) launch_pp_view_t<false, true>(is_bf16, out_f32, grid, p);
+  else launch_pp_view_t<false, false>(is_bf16, out_f32, grid, p);
+  TNH_LAUNCH_CHECK();
+  *name = a_km ? (b_kn ? "bf16_view_tt_256x256x64_pp" : "bf16_view_tn_256x256x64_pp")
+               : (b_kn ? "bf16_view_nn_256x256x64_pp" : "bf16_view_nt_256x256x64_pp");
   return TNH_OK;
 }
 

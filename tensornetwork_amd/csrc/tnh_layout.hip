@@ -141,14 +141,18 @@ __global__ __launch_bounds__(256) void permute_tiled_kernel(T* __restrict__ dst,
 // 64 (a) x 128 (b) tile.  A thread loads 8 a-consecutive elements of two
 // neighbouring b rows (2 x 16 B), transposes the eight 2x2 micro-blocks in
 // registers (v_perm) into dwords that hold (b, b+1) for one a, and stores them
-// to a dword tile T[a][b/2] (row pitch 65 dwords: conflict-free both ways).  The
-// write side reads 4 consecutive dwords and stores 16 B (8 b-consecutive
-// elements): 256-B contiguous runs per output row.
+// to a dword tile T[a][b/2] of 64 x 64 dwords whose 16-byte chunks are XOR-swizzled
+// with (a >> 3) & 7: the ds_write_b32 of a 32-lane half (8 a-chunks q x 4 columns)
+// then lands on 32 different banks, and the write side fetches its 4 consecutive
+// dwords with ONE conflict-free ds_read_b128 (the 16 lanes of a group read the 16
+// chunks of one row, permuted).  Round 1's padded layout (row pitch 65 dwords, four
+// ds_read_b32 per store) measured 50 % LDS bank-conflict cycles (c and c + 8 on one
+// bank).  Stores are 16 B (8 b-consecutive elements): 256-B runs per output row.
 __global__ __launch_bounds__(256) void permute_tiled16_kernel(uint16_t* __restrict__ dst,
                                                               const uint16_t* __restrict__ src,
                                                               TiledParams p) {
-  constexpr int TA = 64, TB = 128, LD = 65;
-  __shared__ uint32_t T[TA * LD];
+  constexpr int TA = 64, TB = 128, LD = 64;
+  __shared__ __attribute__((aligned(16))) uint32_t T[TA * LD];
   for (int64_t blk = blockIdx.x; blk < p.nblocks; blk += gridDim.x) {
   int64_t bid = blk;
   const int64_t ta = bid % p.tiles_a;
@@ -180,8 +184,9 @@ __global__ __launch_bounds__(256) void permute_tiled16_kernel(uint16_t* __restri
         // xs[e] = (a = 8q+2e, a+1) of row 2j ; ys[e] the same of row 2j+1
         const uint32_t lo = (xs[e] & 0xffffu) | (ys[e] << 16);          // a = 8q+2e:   (b=2j, 2j+1)
         const uint32_t hi = (xs[e] >> 16) | (ys[e] & 0xffff0000u);      // a = 8q+2e+1
-        T[(8 * q + 2 * e) * LD + j] = lo;
-        T[(8 * q + 2 * e + 1) * LD + j] = hi;
+        const int col = (((j >> 2) ^ q) << 2) | (j & 3);                 // (a >> 3) & 7 == q for both rows
+        T[(8 * q + 2 * e) * LD + col] = lo;
+        T[(8 * q + 2 * e + 1) * LD + col] = hi;
       }
     }
   }
@@ -191,11 +196,7 @@ __global__ __launch_bounds__(256) void permute_tiled16_kernel(uint16_t* __restri
 #pragma unroll
     for (int h = 0; h < 4; ++h) {
       const int a = (tid >> 4) + 16 * h;
-      uint4 o;
-      o.x = T[a * LD + 4 * c];
-      o.y = T[a * LD + 4 * c + 1];
-      o.z = T[a * LD + 4 * c + 2];
-      o.w = T[a * LD + 4 * c + 3];
+      const uint4 o = *(const uint4*)&T[a * LD + ((c ^ ((a >> 3) & 7)) << 2)];
       *(uint4*)(dst + out_base + (a0 + a) * p.a_out_stride + b0 + 8 * c) = o;
     }
   }

@@ -132,6 +132,13 @@ int tnh_device_info(char* name, int len, int* cus, int64_t* hbm_bytes) {
   return TNH_OK;
 }
 
+int tnh_device_pci_bus_id(char* buf, int len) {
+  TNH_NEED_INIT();
+  TNH_REQUIRE(buf != nullptr && len >= 16, "tnh_device_pci_bus_id: buffer of >= 16 bytes needed");
+  TNH_HIP(hipDeviceGetPCIBusId(buf, len, g_device));
+  return TNH_OK;
+}
+
 int tnh_malloc(void** ptr, size_t nbytes) {
   TNH_NEED_INIT();
   TNH_REQUIRE(ptr != nullptr, "ptr is null");

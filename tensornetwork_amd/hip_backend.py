@@ -66,6 +66,49 @@ def _row_major_strides(shape):
   return strides
 
 
+def _merge_levels(shape, strides, axes):
+  """[(extent, stride)] of `axes` taken in the given order, with memory-adjacent neighbours merged
+  and size-1 axes dropped (they address nothing)."""
+  levels = []
+  for ax in axes:
+    n, st = int(shape[ax]), int(strides[ax])
+    if n == 1:
+      continue
+    if levels and levels[-1][1] == st * n:
+      levels[-1] = (levels[-1][0] * n, st)
+    else:
+      levels.append((n, st))
+  return levels
+
+
+def _operand_view(shape, free_axes, k_axes):
+  """Two-level strided matrix view (tnh_operand_view) of a dense row-major tensor whose rows are
+  `free_axes` (output order) and whose contraction index is `k_axes` (K order), or None when the
+  tensor cannot be read in place: more than two memory runs on either side, no contiguous
+  direction, an inner contraction run that is not a multiple of 64, or misaligned strides."""
+  strides = _row_major_strides(shape)
+  rows = _merge_levels(shape, strides, free_axes)
+  ks = _merge_levels(shape, strides, k_axes)
+  if not ks or len(rows) > 2 or len(ks) > 2:
+    return None
+  if not rows:
+    rows = [(1, 0)]
+  r0, sr0 = rows[-1]
+  sr1 = rows[0][1] if len(rows) == 2 else 0
+  k0, sk0 = ks[-1]
+  sk1 = ks[0][1] if len(ks) == 2 else 0
+  if (sk0 == 1) == (sr0 == 1):
+    return None                      # exactly one contiguous direction
+  if k0 % 64 != 0:
+    return None
+  if sk0 == 1:
+    if sr0 % 8 or sr1 % 8 or sk1 % 8:
+      return None
+  elif sk0 % 8 or sk1 % 8 or sr1 % 8 or r0 % 8:
+    return None
+  return _lib.OperandView(r0, sr0, sr1, k0, sk0, sk1)
+
+
 class HipBackend(BackendBase):
   """TensorNetwork backend running on one MI355X through libtnhip.so.
 
@@ -83,6 +126,13 @@ class HipBackend(BackendBase):
     self.half_output = half_output
     self._device = device
     self._lib = None
+    # bf16 / f16 tensordot: let the GEMM loaders absorb transposes (tnh_gemm_view) instead of K1 permutes.
+    # TNH_ABSORB_TRANSPOSES=0 keeps the permute + NT lowering (A/B and second opinion in the tests).
+    import os  # pylint: disable=import-outside-toplevel
+    self.absorb_transposes = os.environ.get("TNH_ABSORB_TRANSPOSES", "1") != "0"
+    self.inplace_max_bytes = int(os.environ.get("TNH_VIEW_INPLACE_MAX_BYTES", str(1 << 30)))
+    self.permutes_absorbed = 0   # tnh_gemm_view launches
+    self.permute_launches = 0    # K1 launches (transpose)
 
   # the backend is a per-process singleton bound to one device: copies are the object itself
   def __copy__(self):
@@ -194,6 +244,7 @@ class HipBackend(BackendBase):
     if nd > 16:
       raise NotImplementedError("hip backend supports tensors up to rank 16")
     out = DeviceTensor.empty([tensor.shape[p] for p in perm], tensor.code)
+    self.permute_launches += 1
     _lib.check(self.lib.tnh_permute(_vp(out), _vp(tensor), nd, _lib.i64_array(tensor.shape),
                                     _lib.i32_array(perm), tensor.itemsize), "tnh_permute")
     return out
@@ -395,6 +446,16 @@ class HipBackend(BackendBase):
       out_shape = tuple(a.shape[i] for i in free_a) + tuple(b.shape[i] for i in free_b)
       return self._outer(a, b, out_shape), free_a, free_b
 
+    # bf16 / f16, enough 256 x 256 tiles: read BOTH operands in place through two-level strides
+    # (K8 lowering of tensordot2.py:62-88 -- transposes are absorbed by the GEMM loaders, no K1 launch).
+    if code in _HALF and self.absorb_transposes:
+      a_shape0, b_shape0 = a.shape, b.shape
+      got = self._tensordot_in_place(a, b, axes_a, axes_b, free_a, free_b, m, n, k, hint_a, hint_b)
+      if got is not None:
+        out, used_a, used_b = got
+        out_shape = tuple(a_shape0[i] for i in used_a) + tuple(b_shape0[i] for i in used_b)
+        return out.view(out_shape), used_a, used_b
+
     # memory order of the contracted pairs on each side
     order_a = sorted(range(nc), key=lambda i: axes_a[i])
     order_b = sorted(range(nc), key=lambda i: axes_b[i])
@@ -449,6 +510,68 @@ class HipBackend(BackendBase):
       return self._complex_gemm(a, b, trans_a, trans_b, m, n, k).view(out_shape), free_a, free_b
     out = self._gemm(a, b, trans_a, trans_b, m, n, k, lda, ldb)
     return out.view(out_shape), free_a, free_b
+
+  def _tensordot_in_place(self, a, b, axes_a, axes_b, free_a, free_b, m, n, k, hint_a=None, hint_b=None):
+    """One `tnh_gemm_view` launch that reads the operands as they lie in HBM wherever that pays, or None
+    (caller falls back to the classic permute + tnh_gemm lowering; results are bit-identical either way).
+
+    The contraction order K is free as long as both sides agree: a's memory order of the contracted axes
+    and b's are both tried, and the one that leaves the fewest bytes to permute wins.  An operand is read
+    in place when `_operand_view` offers a view -- except a non-trivial one (k-major, i.e. rows contiguous
+    like a [K][N] operand, or two-level strides) of a tensor larger than `inplace_max_bytes`: measured on
+    MI355X (tools/view_probe.py, profiles/r02_lowering_ab.txt) a workgroup streaming a k-major operand
+    touches 64 new pages per K-tile, and beyond ~1-2 GiB that costs more (8192 x 8192 x 262144: -10 % GEMM
+    rate, 65536^3: -4 %) than the one HBM-bound K1 pass that makes it K-contiguous, while below it the
+    absorbed permute is a net win (D = 64 layout L1: 950 -> 1100-1190 TFLOP/s).  Operands that are not read
+    in place are permuted to [free..., contracted...] (free order = the planner's hint when given) and
+    viewed trivially.  Returns (tensor, used_free_a, used_free_b)."""
+    if m < 256 or n < 256 or ((m + 255) // 256) * ((n + 255) // 256) < 192 or k % 64 or k < 128:
+      return None
+    nc = len(axes_a)
+    orders = [sorted(range(nc), key=lambda i: axes_a[i]), sorted(range(nc), key=lambda i: axes_b[i])]
+    if orders[0] == orders[1]:
+      orders = orders[:1]
+
+    def usable(t, free, kax):
+      v = _operand_view(t.shape, free, kax)
+      plain = v is not None and v.sk0 == 1 and v.sr1 == 0 and v.sk1 == 0       # already [rows][K]: the NT form
+      if v is not None and not plain and t.nbytes > self.inplace_max_bytes:
+        return None
+      return v
+
+    best = None
+    for order in orders:
+      ka, kb = [axes_a[i] for i in order], [axes_b[i] for i in order]
+      va, vb = usable(a, free_a, ka), usable(b, free_b, kb)
+      cost = (a.nbytes if va is None else 0) + (b.nbytes if vb is None else 0)
+      if best is None or cost < best[0]:
+        best = (cost, ka, kb, va, vb)
+    _, ka, kb, va, vb = best
+    used_a, used_b = list(free_a), list(free_b)
+    if va is None:
+      if hint_a is not None and sorted(hint_a) == sorted(free_a):
+        used_a = [int(i) for i in hint_a]
+      a = self.transpose(a, used_a + ka)
+      va = _lib.OperandView(m, k, 0, k, 1, 0)
+    if vb is None:
+      if hint_b is not None and sorted(hint_b) == sorted(free_b):
+        used_b = [int(i) for i in hint_b]
+      b = self.transpose(b, used_b + kb)
+      vb = _lib.OperandView(n, k, 0, k, 1, 0)
+    out_code = _lib.F32 if self.half_output == "float32" else a.code
+    out = DeviceTensor.empty((m, n), out_code)
+    events = getattr(self, "gemm_events", None)
+    if events is not None:
+      start = _lib.Event().record()
+    status = self.lib.tnh_gemm_view(a.code, out_code, m, n, k, _vp(a), ctypes.byref(va), _vp(b), ctypes.byref(vb),
+                                    _vp(out), n)
+    if status == _lib.ERR_UNSUPPORTED:
+      return None     # (a forced A/B variant, or an alignment rule: nothing was launched)
+    _lib.check(status, "tnh_gemm_view")
+    if events is not None:
+      events.append((start, _lib.Event().record()))
+    self.permutes_absorbed += 1
+    return out, used_a, used_b
 
   def _complex_gemm(self, a, b, trans_a, trans_b, m, n, k):
     """complex64 / complex128 product on the f32 / f64 matrix cores: the interleaved (re, im)

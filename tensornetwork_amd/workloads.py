@@ -154,6 +154,94 @@ def mera_descend(be, state, isometry, disentangler, contractor):
   return be.multiply(be.addition(out[0], out[1]), 0.5)
 
 
+class _ShapeOnly:
+  """shape-only stand-in used for planning (never touched by a kernel)."""
+
+  def __init__(self, shape):
+    self.shape = tuple(shape)
+    self.dtype = np.dtype(np.float32)
+    self.ndim = len(self.shape)
+
+
+class _PlanBackend:
+  name = "plan"
+
+  def convert_to_tensor(self, t):
+    return t
+
+  def shape_tuple(self, t):
+    return t.shape
+
+  def conj(self, t):
+    return t
+
+
+def mera_sliced_sample(be, chi: int, dtype, reps: int = 2, seed: int = 17):
+  """configs[4] at a bond dimension whose dense network does not fit (chi = 64: rank-6 inputs of 137 GB,
+  chi^7 intermediates): the layer energy is bond-sliced -- one cut on a leg of the hamiltonian and one on a
+  leg of the state give chi^2 independent slices per placement whose largest tensor is chi^5.  Measures the
+  PER-SLICE cost on this GPU: the 12-node topology is rebuilt with the two cut bonds at dimension 1
+  (operands generated directly at their sliced shapes: synthetic data), contracted with the
+  branch(nbranch=2) path of the sliced sizes.  Returns per-placement slice counts, multiply-adds and
+  seconds per slice; the whole layer is n_slices x that (slices are independent, one scalar all-reduce)."""
+  import functools  # pylint: disable=import-outside-toplevel
+  import time  # pylint: disable=import-outside-toplevel
+  from tensornetwork_amd import contractors, pathfinder  # pylint: disable=import-outside-toplevel
+  algo = functools.partial(pathfinder.branch, nbranch=2)
+  out = {}
+  for placement in ("left", "right"):
+    pb = _PlanBackend()
+    ham, rho = _ShapeOnly((chi,) * 6), _ShapeOnly((chi,) * 6)
+    plan_nodes = mera_layer_network(pb, ham, rho, _ShapeOnly((chi,) * 3), _ShapeOnly((chi,) * 4), placement)
+    inputs = [set(n.edges) for n in plan_nodes]
+    sizes = {e: e.dimension for e in network.get_all_edges(plan_nodes)}
+    hnode = [n for n in plan_nodes if n.tensor is ham][0]
+    rnode = [n for n in plan_nodes if n.tensor is rho][0]
+    best = None
+    for eh in hnode.edges:                      # cheapest pair of cuts: one leg of h, one leg of rho
+      for er in rnode.edges:
+        trial = dict(sizes)
+        trial[eh] = 1
+        trial[er] = 1
+        path = algo(inputs, set(), trial)
+        flops, peak = pathfinder.path_cost(inputs, set(), trial, path)
+        if best is None or (flops, peak) < best[0]:
+          best = ((flops, peak), eh, er, path)
+    (flops, peak), eh, er, path = best
+    cut = {id(eh), id(er)}
+    index = {id(n): i for i, n in enumerate(plan_nodes)}
+    real = []
+    for i, n in enumerate(plan_nodes):
+      shape = tuple(1 if id(e) in cut else e.dimension for e in n.edges)
+      scale = float(np.prod(shape)) ** -0.25
+      real.append(network.Node(be.device_random(shape, dtype=dtype, seed=seed * i + 3, normal=True, a=0.0, b=scale),
+                               backend=be))
+    done = set()
+    for n in plan_nodes:
+      for e in n.edges:
+        if id(e) in done or e.is_dangling():
+          continue
+        done.add(id(e))
+        (n1, a1), (n2, a2) = e.ends()
+        network.connect(real[index[id(n1)]][a1], real[index[id(n2)]][a2])
+    best_t = None
+    for _ in range(reps + 1):
+      node_map, _ = network.copy(real)
+      be.synchronize()
+      t0 = time.perf_counter()
+      res = contractors.contract_path(path, [node_map[n] for n in real]).tensor
+      be.synchronize()
+      t = time.perf_counter() - t0
+      best_t = t if best_t is None else min(best_t, t)
+      del res
+    out[placement] = {"n_slices": chi * chi, "macs_per_slice": float(flops), "peak_elems_per_slice": float(peak),
+                      "sec_per_slice": best_t, "tflops": 2.0 * float(flops) / best_t / 1e12}
+    for n in real:
+      n.tensor = None
+      n.edges = []
+  return out
+
+
 def ham_ising():
   """3-site critical-Ising term  X Z X - (X X 1 + 1 X X)/2  (Evenbly & White 2016), as used by
   simple_mera.py:298-309."""

@@ -707,3 +707,90 @@ def test_device_tensor_deepcopy_pickle_repr(hip):
   assert copy.deepcopy(hip) is hip
   assert "[0., 1., 2.]" in repr(t).replace(" ", "").replace(",", ", ").replace(" ", "") or "0." in repr(t)
   assert "data=" not in repr(dev(hip, np.zeros((100,))))
+
+
+# ------------------------------------------------------------------ transpose-absorbing GEMM (tnh_gemm_view)
+def _view_case(hip, dtype, shape_a, shape_b, axes, seed):
+  """tensordot through the in-place view kernel vs the permute + NT lowering: bit-identical (same MFMA
+  sequence, same K order per tile), and both against float64 on the rounded inputs."""
+  rng = np.random.default_rng(seed)
+  a = rng.standard_normal(shape_a).astype(np.float32) / 8
+  b = rng.standard_normal(shape_b).astype(np.float32) / 8
+  if dtype is ta.bfloat16:
+    a, b = orc.round_bf16(a), orc.round_bf16(b)
+    da, db = hip.to_bfloat16(a), hip.to_bfloat16(b)
+  else:
+    a, b = a.astype(np.float16), b.astype(np.float16)
+    da, db = dev(hip, a), dev(hip, b)
+  hip.absorb_transposes = True
+  before = (hip.permutes_absorbed, hip.permute_launches)
+  got = hip.tensordot(da, db, axes)
+  kernel = hip.lib.tnh_gemm_last_kernel().decode()
+  absorbed = hip.permutes_absorbed - before[0]
+  permutes = hip.permute_launches - before[1]
+  hip.absorb_transposes = False
+  try:
+    ref_dev = hip.tensordot(da, db, axes)
+  finally:
+    hip.absorb_transposes = True
+  g, r = np.asarray(got), np.asarray(ref_dev)
+  np.testing.assert_array_equal(g, r)
+  ref = np.tensordot(a.astype(np.float64), b.astype(np.float64), axes)
+  np.testing.assert_allclose(g, ref, rtol=2.0**-8, atol=2e-3)
+  return kernel, absorbed, permutes
+
+
+@pytest.mark.parametrize("dtype", [ta.bfloat16, np.float16])
+def test_gemm_view_absorbs_transposes_bit_exact(hip, dtype):
+  # (shape_a, shape_b, axes, expected kernel): >= 192 tiles of 256 x 256, K a multiple of 64
+  cases = [
+      ((14, 256, 2, 64), (2, 64, 14, 256), ([2, 3], [0, 1]), "bf16_view_nn"),      # config-2 L0: b is [K][N]
+      ((14, 2, 256, 64), (64, 14, 2, 256), ([1, 3], [2, 0]), "bf16_view_nn"),      # config-2 L1: two-level rows AND k
+      ((2, 64, 14, 256), (2, 64, 14, 256), ([0, 1], [0, 1]), "bf16_view_tt"),      # both k-major
+      ((2, 64, 14, 256), (14, 256, 2, 64), ([0, 1], [2, 3]), "bf16_view_tn"),      # a k-major, b K-contiguous
+      ((3584, 192), (3584, 192), ([1], [1]), "bf16_view_nt"),                       # plain NT through the view kernel
+      ((14, 264, 2, 64), (2, 64, 14, 264), ([2, 3], [0, 1]), "bf16_view_nn"),      # ragged M / N edges (3696 = 14.4 tiles)
+      ((2, 64, 15, 248), (2, 64, 15, 248), ([0, 1], [0, 1]), "bf16_view_tt"),      # ragged, k-major clamp on both sides
+      ((4, 64, 3600), (3600, 4, 64), ([0, 1], [1, 2]), "bf16_view_tn"),            # rank 3, 4 K-tiles
+  ]
+  for i, (sa, sb, axes, want) in enumerate(cases):
+    kernel, absorbed, permutes = _view_case(hip, dtype, sa, sb, axes, 40 + i)
+    assert kernel.startswith(want), (sa, sb, axes, kernel)
+    assert absorbed == 1 and permutes == 0, (sa, sb, axes, absorbed, permutes)
+
+
+def test_gemm_view_falls_back_when_it_cannot_read_in_place(hip):
+  # inner contraction run of 96 (not a multiple of 64) -> permute + NT, still correct
+  # -> both operands permuted to [free, contracted], then the same view kernel on the trivial NT views
+  kernel, absorbed, permutes = _view_case(hip, ta.bfloat16, (14, 2, 256, 96), (96, 14, 2, 256), ([1, 3], [2, 0]), 60)
+  assert absorbed == 1 and permutes == 2 and kernel.startswith("bf16_view_nt"), (kernel, absorbed, permutes)
+  # one side readable in place, the other not: exactly one permute
+  kernel, absorbed, permutes = _view_case(hip, ta.bfloat16, (14, 2, 256, 64), (68, 2, 64, 14, 5), ([1, 3], [1, 2]), 62)
+  assert absorbed == 1 and permutes == 1, (kernel, absorbed, permutes)
+  # a k-major operand above the size policy is permuted instead of being streamed in place
+  keep = hip.inplace_max_bytes
+  hip.inplace_max_bytes = 1 << 16
+  try:
+    kernel, absorbed, permutes = _view_case(hip, ta.bfloat16, (14, 256, 2, 64), (2, 64, 14, 256), ([2, 3], [0, 1]), 63)
+  finally:
+    hip.inplace_max_bytes = keep
+  assert absorbed == 1 and permutes == 1 and kernel.startswith("bf16_view_nt"), (kernel, absorbed, permutes)
+  # too few tiles for the 256 x 256 kernel
+  kernel, absorbed, permutes = _view_case(hip, ta.bfloat16, (512, 128), (128, 512), 1, 61)
+  assert absorbed == 0
+
+
+def test_gemm_view_c_abi_rejects_bad_views_without_launching(hip):
+  import ctypes
+  a = hip.to_bfloat16(np.zeros((4096, 128), np.float32))
+  out = ta.DeviceTensor.empty((4096, 4096), _lib.BF16)
+  good = _lib.OperandView(4096, 128, 0, 128, 1, 0)
+  for bad in (_lib.OperandView(4096, 128, 0, 96, 1, 0),       # k0 not a multiple of 64
+              _lib.OperandView(4096, 2, 0, 128, 2, 0),        # no contiguous direction
+              _lib.OperandView(4096, 124, 0, 128, 1, 0)):     # rows not 16-byte aligned
+    st = hip.lib.tnh_gemm_view(_lib.BF16, _lib.BF16, 4096, 4096, 128, ctypes.c_void_p(a.ptr), ctypes.byref(bad),
+                               ctypes.c_void_p(a.ptr), ctypes.byref(good), ctypes.c_void_p(out.ptr), 4096)
+    assert st == _lib.ERR_UNSUPPORTED, st
+  st = hip.lib.tnh_gemm_view(_lib.F32, _lib.F32, 4096, 4096, 128, ctypes.c_void_p(a.ptr), ctypes.byref(good),
+                             ctypes.c_void_p(a.ptr), ctypes.byref(good), ctypes.c_void_p(out.ptr), 4096)
+  assert st == _lib.ERR_INVALID

@@ -494,3 +494,58 @@ def test_node_name_type_checks(be):
     ta.Node(np.eye(2), axis_names=[0, 1], backend=be)
   with pytest.raises(ValueError, match="axis_names is not the same length"):
     ta.Node(np.eye(2), axis_names=["a"], backend=be)
+
+
+def test_operand_view_addressing_reproduces_tensordot():
+  """Host side of the transpose-absorbing lowering (hip_backend._operand_view -> tnh_gemm_view): whenever a
+  view is offered, the two-level address formula of include/tnh.h must enumerate exactly the matrix
+  that transpose + reshape would have materialised (checked by evaluating the formula in NumPy)."""
+  import itertools
+  from tensornetwork_amd.hip_backend import _operand_view
+
+  def matrix_from_view(flat, v, rows, K):
+    r = np.arange(rows)[:, None]
+    k = np.arange(K)[None, :]
+    idx = (r // v.r0) * v.sr1 + (r % v.r0) * v.sr0 + (k // v.k0) * v.sk1 + (k % v.k0) * v.sk0
+    return flat[idx]
+
+  rng = np.random.default_rng(0)
+  offered = 0
+  for shape_a, shape_b, axes in [
+      ((8, 64, 8, 64), (64, 8, 64, 16), ([1, 3], [2, 0])),      # config-2 layout L1: zero permutes
+      ((8, 8, 64, 64), (64, 64, 8, 16), ([2, 3], [0, 1])),      # layout L0: a K-contiguous, b k-major
+      ((64, 64, 8, 8), (64, 64, 16, 8), ([0, 1], [0, 1])),      # both k-major
+      ((8, 128), (16, 128), ([1], [1])),                         # plain NT
+      ((128, 8), (128, 16), ([0], [0])),                         # plain TN
+      ((2, 8, 64, 1, 64), (64, 64, 8, 3), ([2, 4], [0, 1])),    # size-1 axis in between
+      ((8, 64, 8, 64), (64, 8, 64, 16), ([3, 1], [0, 2])),      # same pairs listed in the other order
+  ]:
+    a = rng.standard_normal(shape_a)
+    b = rng.standard_normal(shape_b)
+    axes_a, axes_b = axes
+    free_a = [i for i in range(a.ndim) if i not in axes_a]
+    free_b = [i for i in range(b.ndim) if i not in axes_b]
+    ref = np.tensordot(a, b, axes)
+    nc = len(axes_a)
+    for order in (sorted(range(nc), key=lambda i: axes_a[i]), sorted(range(nc), key=lambda i: axes_b[i])):
+      va = _operand_view(a.shape, free_a, [axes_a[i] for i in order])
+      vb = _operand_view(b.shape, free_b, [axes_b[i] for i in order])
+      if va is None or vb is None:
+        continue
+      offered += 1
+      m = int(np.prod([a.shape[i] for i in free_a]))
+      n = int(np.prod([b.shape[i] for i in free_b]))
+      k = int(np.prod([a.shape[i] for i in axes_a]))
+      am = matrix_from_view(a.reshape(-1), va, m, k)
+      bm = matrix_from_view(b.reshape(-1), vb, n, k)
+      np.testing.assert_allclose((am @ bm.T).reshape(ref.shape), ref, rtol=1e-12, atol=1e-12)
+      assert (va.sk0 == 1) != (va.sr0 == 1) and (vb.sk0 == 1) != (vb.sr0 == 1)
+      break
+    else:
+      raise AssertionError(f"no in-place view offered for {shape_a} x {shape_b} {axes}")
+  assert offered == 7
+  # refused: inner contraction run not a multiple of 64, three memory runs, misaligned strides
+  assert _operand_view((8, 96, 8, 96), [0, 2], [1, 3]) is None
+  assert _operand_view((4, 64, 4, 64, 4, 64), [0, 2, 4], [1, 3, 5]) is None
+  assert _operand_view((8, 64, 8, 68), [0, 1, 2], [3]) is None       # contraction run 68
+  assert _operand_view((64, 12), [1], [0]) is None                   # k-major with 12-element rows (not 16-B chunks)

@@ -20,7 +20,13 @@ of reference tests that exercise the backend under test.
 
 Importing ``tensornetwork_amd`` registers ``"hip"`` in ``backend_factory._BACKENDS``
 (``tensornetwork_amd.hip_backend.register_with_tensornetwork``), which is all a reference
-user has to do.  Nothing from the reference is modified.
+user has to do.  No reference file is modified.
+
+The reference's TEST HELPERS keep per-backend tables (``tests/testing_utils.py:63-84``
+``np_dtype_to_backend`` knows four names; ``linalg/tests/initialization_test.py`` and
+``node_linalg_test.py`` keep a module-level ``dtypes`` dict per backend name).  A maintainer who
+adds a backend adds its row there; this plugin applies exactly that row
+at run time: the hip backend's dtypes ARE NumPy dtypes, so it reuses the ``"numpy"`` rows.
 """
 import os
 
@@ -34,6 +40,28 @@ _NAMES = [b for b in os.environ.get("TNH_REF_BACKENDS", "hip").split(",") if b]
 _KEEP_ALL = os.environ.get("TNH_REF_KEEP_ALL", "0") == "1"
 
 
+def _teach_test_tables_the_new_backend(module):
+  """The per-backend rows a maintainer would add to the reference's test helpers (see module docstring)."""
+  try:
+    from tensornetwork.tests import testing_utils  # pylint: disable=import-outside-toplevel
+  except Exception:  # pylint: disable=broad-except
+    testing_utils = None
+  if testing_utils is not None and not getattr(testing_utils, "_tnh_patched", False):
+    original = testing_utils.np_dtype_to_backend
+
+    def np_dtype_to_backend(backend, dtype):
+      name = getattr(backend_factory.get_backend(backend), "name", None)
+      if name in _NAMES and name != "numpy":
+        return dtype                      # NumPy dtypes, like the "numpy" / "symmetric" row (testing_utils.py:69-70)
+      return original(backend, dtype)
+    testing_utils.np_dtype_to_backend = np_dtype_to_backend
+    testing_utils._tnh_patched = True     # pylint: disable=protected-access
+  tables = getattr(module, "dtypes", None)
+  if isinstance(tables, dict) and "numpy" in tables:
+    for name in _NAMES:
+      tables.setdefault(name, tables["numpy"])
+
+
 def _has_own_backend_parametrize(metafunc):
   for mark in metafunc.definition.iter_markers("parametrize"):
     argnames = mark.args[0]
@@ -45,6 +73,7 @@ def _has_own_backend_parametrize(metafunc):
 
 
 def pytest_generate_tests(metafunc):
+  _teach_test_tables_the_new_backend(metafunc.module)
   if "backend" not in metafunc.fixturenames or _has_own_backend_parametrize(metafunc):
     return
   values, ids = list(_NAMES), list(_NAMES)
