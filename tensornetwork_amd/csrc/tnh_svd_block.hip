@@ -54,9 +54,9 @@ __device__ __forceinline__ void bj_pair(int n, int r, int i, int& a, int& b) {
 // t = 0: II, 1: IJ, 2: JJ.
 __global__ __launch_bounds__(256) void bj_gram_kernel(const float* __restrict__ X, int64_t ldx, int nb,
                                                       int round, int chunks, int cpw,
-                                                      float* __restrict__ Gp) {
+                                                      float* __restrict__ Gp, int pair0) {
   __shared__ float red[4][3][1024];
-  const int pair = blockIdx.x, split = blockIdx.y, S = gridDim.y;
+  const int pair = pair0 + blockIdx.x, split = blockIdx.y, S = gridDim.y;
   int bi, bj;
   bj_pair(nb, round, pair, bi, bj);
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -257,12 +257,12 @@ template <int NT>
 __global__ __launch_bounds__(NT) void bj_eig3_kernel(const float* __restrict__ Gp, int S,
                                                      float* __restrict__ Jout, int* __restrict__ pairflag,
                                                      int* __restrict__ flag, float tol, int max_inner,
-                                                     int cross) {
+                                                     int cross, int sort, int pair0) {
   constexpr int W = 64, NG = NT / 32, TPT = 32 / NG, VPT = 64 / NG;
   __shared__ f32x4 T[2][32 * 32];        // tile (k, l): (G[2k][2l], G[2k][2l+1], G[2k+1][2l], G[2k+1][2l+1])
   __shared__ double Vt[2][W * W];        // V[i][pos], row-major
   __shared__ int rotated;
-  const int pair = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+  const int pair = pair0 + blockIdx.x, tid = threadIdx.x, lane = tid & 63;
   const float* gp = Gp + (int64_t)pair * S * 3072;
   float* T0 = (float*)&T[0][0];
   // cross mode (only pairs with one row in each block are rotated, 32 rounds):
@@ -303,6 +303,7 @@ __global__ __launch_bounds__(NT) void bj_eig3_kernel(const float* __restrict__ G
   }
   const int nrounds = cross ? 32 : W - 1;
   int any = 0, cur = 0;
+  float thmax = 0.f;   // largest |g_pq| / sqrt(g_pp g_qq) met by this workgroup (convergence telemetry, flag[1])
   for (int sweep = 0; sweep < max_inner; ++sweep) {
     for (int r = 0; r < nrounds; ++r) {
       __syncthreads();
@@ -314,7 +315,9 @@ __global__ __launch_bounds__(NT) void bj_eig3_kernel(const float* __restrict__ G
       const f32x4 d = Tc[l * 32 + l];
       const float gpp = d[0], gpq = d[1], gqq = d[3];
       float tf = 0.f;
-      if (fabsf(gpq) > tol * (__builtin_amdgcn_sqrtf(fabsf(gpp)) * __builtin_amdgcn_sqrtf(fabsf(gqq)))) {
+      const float gden = __builtin_amdgcn_sqrtf(fabsf(gpp)) * __builtin_amdgcn_sqrtf(fabsf(gqq));
+      if (g == 0 && gden > 0.f) thmax = fmaxf(thmax, fabsf(gpq) * __builtin_amdgcn_rcpf(gden));
+      if (fabsf(gpq) > tol * gden) {
         const float zeta = (gqq - gpp) * __builtin_amdgcn_rcpf(2.0f * gpq);
         const float den = fabsf(zeta) + __builtin_amdgcn_sqrtf(1.0f + zeta * zeta);
         tf = __builtin_amdgcn_rcpf(den);
@@ -364,7 +367,40 @@ __global__ __launch_bounds__(NT) void bj_eig3_kernel(const float* __restrict__ G
   // whole sweeps = full periods of the permutation: positions are back where they started
   const double* Vf = Vt[cur];
   float* jo = Jout + (int64_t)pair * (W * W);
-  for (int e = tid; e < W * W; e += NT) jo[e] = (float)Vf[(e >> 6) * W + pos_of(e & 63)];
+  // de Rijk ordering (A/B knob TNH_SVD_SORT=1, default off): the rotated rows leave the pair sorted by
+  // decreasing norm, the 32 largest into the lower-numbered block.  Measured on MI355X it does not pay in
+  // this block scheme: 4096^2 Gaussian 17 -> 20 sweeps, 2048^2 with s_i = 2^(-i/32) 37 -> 35.
+  // `rank` lives in the (idle) other T buffer.
+  int* rank = (int*)&T[cur ^ 1][0];
+  float* dg = (float*)(rank + W);
+  if (sort && any) {
+    __syncthreads();
+    if (tid < W) {
+      const int pi = pos_of(tid);
+      dg[tid] = ((const float*)&T[cur][(pi >> 1) * 32 + (pi >> 1)])[(pi & 1) * 3];
+    }
+    __syncthreads();
+    if (tid < W) {
+      const float di = dg[tid];
+      int rk = 0;
+      for (int j = 0; j < W; ++j) {
+        const float dj = dg[j];
+        rk += (dj > di || (dj == di && j < tid)) ? 1 : 0;
+      }
+      rank[tid] = rk;
+    }
+  } else {
+    __syncthreads();
+    if (tid < W) rank[tid] = tid;
+  }
+  __syncthreads();
+  for (int e = tid; e < W * W; e += NT) jo[(e >> 6) * W + rank[e & 63]] = (float)Vf[(e >> 6) * W + pos_of(e & 63)];
+  if (tid < 64) {   // wave 0 holds the g == 0 lanes (tid < 32)
+    float m = thmax;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    if (tid == 0) atomicMax((unsigned int*)(flag + 1), __float_as_uint(m));
+  }
   if (tid == 0) {
     pairflag[pair] = any;
     if (any) *flag = 1;
@@ -377,8 +413,8 @@ __global__ __launch_bounds__(NT) void bj_eig3_kernel(const float* __restrict__ G
 __global__ __launch_bounds__(256) void bj_update_kernel(float* __restrict__ X, int64_t ldx, int nssX,
                                                         float* __restrict__ R, int64_t ldr, int nssR,
                                                         int nb, int round, const float* __restrict__ J,
-                                                        const int* __restrict__ pairflag) {
-  const int pair = blockIdx.x;
+                                                        const int* __restrict__ pairflag, int pair0) {
+  const int pair = pair0 + blockIdx.x;
   if (!pairflag[pair]) return;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int ss = blockIdx.y * 4 + wid;
@@ -568,6 +604,12 @@ size_t svd_block_scratch_bytes(int esz, int64_t P, int64_t Q) {
          + (size_t)pairs * sizeof(int) + 256;   // pair flags
 }
 
+// auxiliary streams of the grouped round schedule (see svd_block_sweeps)
+constexpr int kMaxGroups = 4;
+static hipStream_t g_aux[kMaxGroups - 1] = {nullptr, nullptr, nullptr};
+static hipEvent_t g_join[kMaxGroups - 1] = {nullptr, nullptr, nullptr};
+static hipEvent_t g_fork = nullptr;
+
 // Sweeps until a whole sweep applies no rotation.  X: P x Q (ld Q), R: P x P.
 template <typename T>
 int svd_block_sweeps(T* X, T* R, int64_t P, int64_t Q, char* scratch, int* flag, double tol,
@@ -592,12 +634,45 @@ int svd_block_sweeps(T* X, T* R, int64_t P, int64_t Q, char* scratch, int* flag,
   const int inner = env ? atoi(env) : 1;
   const char* envc = getenv("TNH_SVD_CROSS");
   const int crossv = envc ? atoi(envc) : 1;
+  const char* envso = getenv("TNH_SVD_SORT");
+  const int sortv = envso ? atoi(envso) : 0;      // de Rijk row ordering inside every pair: A/B knob, off (see bj_eig3_kernel)
   const char* envn = getenv("TNH_SVD_EIGNT");
   const int eig_nt = envn ? atoi(envn) : 1024;   // workgroup size of the LDS eigensolver (A/B knob)
+  // Stop rule: a whole sweep that applies no rotation above `tol` (the last sweep only observes).
+  // TNH_SVD_STOP=<theta> (A/B knob, default off) ends after a sweep whose largest normalised off-diagonal
+  // theta = |g_pq| / sqrt(g_pp g_qq) is <= theta, betting on quadratic convergence.  Measured on MI355X
+  // (profiles/r02_svd_convergence.txt): it saves exactly the observing sweep on configs[2] (17 -> 16, same
+  // values) but is UNSAFE in general -- theta is small from the first sweep when all singular values are close
+  // (eigh's shifted matrix A + |A|_F 1: theta ~ 1e-3 at sweep 1, nowhere near converged), so it stays off.
+  // TNH_SVD_TRACE=1 prints theta per sweep.
+  const char* envs = getenv("TNH_SVD_STOP");
+  const float stop_theta = F64 ? 0.f : (envs ? (float)atof(envs) : 0.f);
+  const bool trace = getenv("TNH_SVD_TRACE") != nullptr;
+  const char* envg = getenv("TNH_SVD_GROUPS");
+  int groups = F64 ? 1 : (envg ? atoi(envg) : 1);
+  if (groups < 1) groups = 1;
+  if (groups > kMaxGroups) groups = kMaxGroups;
+  if (groups > pairs) groups = pairs;
+  if (groups > 1) {
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(stream(), &cap);
+    if (cap != hipStreamCaptureStatusNone) groups = 1;     // inside a graph capture: stay on one stream
+  }
+  if (groups > 1) {
+    for (int i = 0; i < groups - 1; ++i) {
+      if (!g_aux[i]) {
+        TNH_HIP(hipStreamCreateWithFlags(&g_aux[i], hipStreamNonBlocking));
+        TNH_HIP(hipEventCreateWithFlags(&g_join[i], hipEventDisableTiming));
+      }
+    }
+    if (!g_fork) TNH_HIP(hipEventCreateWithFlags(&g_fork, hipEventDisableTiming));
+    TNH_HIP(hipEventRecord(g_fork, stream()));      // everything queued so far precedes the first round
+  }
   int sweeps = 0;
   bool converged = false;
   while (!converged && sweeps < max_sweeps) {
-    TNH_HIP(hipMemsetAsync(flag, 0, sizeof(int), stream()));
+    TNH_HIP(hipMemsetAsync(flag, 0, 4 * sizeof(int), stream()));
+    if (groups > 1) TNH_HIP(hipEventRecord(g_fork, stream()));
     for (int r = 0; r < nb - 1; ++r) {
       const dim3 ugrid((unsigned)pairs, (unsigned)((nssX + nssR + 3) / 4));
       if constexpr (F64) {
@@ -608,27 +683,45 @@ int svd_block_sweeps(T* X, T* R, int64_t P, int64_t Q, char* scratch, int* flag,
         hipLaunchKernelGGL(bj_update64_kernel, ugrid, dim3(256), 0, stream(), X, Q, nssX, R, P, nssR, nb, r, J,
                            pairflag);
       } else {
-        hipLaunchKernelGGL(bj_gram_kernel, dim3((unsigned)pairs, (unsigned)S), dim3(256), 0, stream(), X, Q, nb, r,
-                           chunks, cpw, Gp);
-        if (eig_nt == 512)
-          hipLaunchKernelGGL((bj_eig3_kernel<512>), dim3((unsigned)pairs), dim3(512), 0, stream(), Gp, S, J,
-                             pairflag, flag, (float)tol, inner, (crossv && r > 0) ? 1 : 0);
-        else if (eig_nt == 256)
-          hipLaunchKernelGGL((bj_eig3_kernel<256>), dim3((unsigned)pairs), dim3(256), 0, stream(), Gp, S, J,
-                             pairflag, flag, (float)tol, inner, (crossv && r > 0) ? 1 : 0);
-        else
-          hipLaunchKernelGGL((bj_eig3_kernel<1024>), dim3((unsigned)pairs), dim3(1024), 0, stream(), Gp, S, J,
-                             pairflag, flag, (float)tol, inner, (crossv && r > 0) ? 1 : 0);
-        hipLaunchKernelGGL(bj_update_kernel, ugrid, dim3(256), 0, stream(), X, Q, nssX, R, P, nssR, nb, r, J,
-                           pairflag);
+        // A/B knob TNH_SVD_GROUPS=G (default 1 = one stream): the pairs of a round are independent, so the round
+        // can be issued as G groups on G streams to overlap one group's latency-bound LDS eigensolve with the
+        // others' gram / update kernels.  Measured on MI355X (4096^2): G = 1 0.216 s, G = 2 0.243 s, G = 3 0.269 s,
+        // G = 4 0.307 s -- the per-round fork / join events cost more than the overlap returns, so it stays off.
+        for (int gidx = 0; gidx < groups; ++gidx) {
+          const int p0 = (int)((int64_t)pairs * gidx / groups), p1 = (int)((int64_t)pairs * (gidx + 1) / groups);
+          const int np = p1 - p0;
+          if (np <= 0) continue;
+          hipStream_t st = gidx == 0 ? stream() : g_aux[gidx - 1];
+          if (gidx > 0) TNH_HIP(hipStreamWaitEvent(st, g_fork, 0));
+          const dim3 ug((unsigned)np, ugrid.y);
+          hipLaunchKernelGGL(bj_gram_kernel, dim3((unsigned)np, (unsigned)S), dim3(256), 0, st, X, Q, nb, r, chunks, cpw,
+                             Gp, p0);
+          const int cross = (crossv && r > 0) ? 1 : 0;
+          if (eig_nt == 512)
+            hipLaunchKernelGGL((bj_eig3_kernel<512>), dim3((unsigned)np), dim3(512), 0, st, Gp, S, J, pairflag, flag,
+                               (float)tol, inner, cross, sortv, p0);
+          else if (eig_nt == 256)
+            hipLaunchKernelGGL((bj_eig3_kernel<256>), dim3((unsigned)np), dim3(256), 0, st, Gp, S, J, pairflag, flag,
+                               (float)tol, inner, cross, sortv, p0);
+          else
+            hipLaunchKernelGGL((bj_eig3_kernel<1024>), dim3((unsigned)np), dim3(1024), 0, st, Gp, S, J, pairflag, flag,
+                               (float)tol, inner, cross, sortv, p0);
+          hipLaunchKernelGGL(bj_update_kernel, ug, dim3(256), 0, st, X, Q, nssX, R, P, nssR, nb, r, J, pairflag, p0);
+          if (gidx > 0) TNH_HIP(hipEventRecord(g_join[gidx - 1], st));
+        }
+        for (int gidx = 1; gidx < groups; ++gidx) TNH_HIP(hipStreamWaitEvent(stream(), g_join[gidx - 1], 0));
+        if (groups > 1) TNH_HIP(hipEventRecord(g_fork, stream()));
       }
     }
     TNH_LAUNCH_CHECK();
-    int h = 0;
-    TNH_HIP(hipMemcpyAsync(&h, flag, sizeof(int), hipMemcpyDeviceToHost, stream()));
+    int h[4] = {0, 0, 0, 0};
+    TNH_HIP(hipMemcpyAsync(h, flag, 4 * sizeof(int), hipMemcpyDeviceToHost, stream()));
     TNH_HIP(hipStreamSynchronize(stream()));
     ++sweeps;
-    converged = (h == 0);
+    float theta;
+    memcpy(&theta, &h[1], sizeof(float));
+    if (trace) fprintf(stderr, "[tnh svd] sweep %d: rotated %d, max theta %.3e\n", sweeps, h[0], (double)theta);
+    converged = (h[0] == 0) || (!F64 && stop_theta > 0.f && theta <= stop_theta);
   }
   *sweeps_out = sweeps;
   *converged_out = converged;

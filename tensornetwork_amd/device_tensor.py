@@ -107,12 +107,40 @@ _MALLOC_SECONDS_PER_BYTE = 28e-3 / (1 << 30)
 _gc_cost_seconds = 30e-3
 
 
+_GC_POLICY = {"freeze": True, "collect": True}
+
+
+def configure_gc(freeze=None, collect_before_large_alloc=None):
+  """Opt-outs of the backend's interaction with Python's cyclic collector (the policy above).
+
+  freeze=False                      never call ``gc.freeze()`` (and undo an earlier freeze);
+                                    same as ``TNH_GC_FREEZE=0`` in the environment.
+  collect_before_large_alloc=False  never run ``gc.collect()`` from the allocator in front of a
+                                    large request (``TNH_GC_COLLECT=0``); the out-of-memory retry
+                                    still collects once before giving up.
+  With both off the backend leaves the host process' collector alone: the price is that dead
+  Node <-> Edge cycles hold their HBM until the application's own collections run.  Returns the
+  policy in force."""
+  global _GC_FROZEN  # pylint: disable=global-statement
+  import gc  # pylint: disable=import-outside-toplevel
+  if freeze is not None:
+    _GC_POLICY["freeze"] = bool(freeze)
+    if not freeze and _GC_FROZEN:
+      gc.unfreeze()
+      _GC_FROZEN = False
+  if collect_before_large_alloc is not None:
+    _GC_POLICY["collect"] = bool(collect_before_large_alloc)
+  return dict(_GC_POLICY)
+
+
 def freeze_collector_baseline():
   """Called once when the backend initialises (see above)."""
   global _GC_FROZEN  # pylint: disable=global-statement
   import gc  # pylint: disable=import-outside-toplevel
   import os  # pylint: disable=import-outside-toplevel
-  if _GC_FROZEN or os.environ.get("TNH_GC_FREEZE", "1") == "0":
+  if os.environ.get("TNH_GC_COLLECT", "1") == "0":
+    _GC_POLICY["collect"] = False
+  if _GC_FROZEN or os.environ.get("TNH_GC_FREEZE", "1") == "0" or not _GC_POLICY["freeze"]:
     return
   global _gc_cost_seconds  # pylint: disable=global-statement
   gc.collect()
@@ -124,7 +152,7 @@ def freeze_collector_baseline():
 def _worth_collecting(nbytes):
   """Policy above: is a full collection expected to cost less than a hipMalloc of `nbytes`?"""
   global _gc_cost_seconds  # pylint: disable=global-statement
-  if nbytes < _GC_MIN_BYTES:
+  if nbytes < _GC_MIN_BYTES or not _GC_POLICY["collect"]:
     return False
   if nbytes * _MALLOC_SECONDS_PER_BYTE >= _gc_cost_seconds:
     return True

@@ -116,9 +116,13 @@ class HipBackend(BackendBase):
     device: HIP device index for this process (default ``$LOCAL_RANK`` or 0).
     half_output: dtype of bf16/f16 contraction results: ``"same"`` (default,
       what NumPy semantics give) or ``"float32"`` (keep the fp32 accumulator).
+    manage_gc: ``False`` keeps the backend's hands off Python's cyclic collector (no
+      ``gc.freeze()`` at initialisation, no ``gc.collect()`` in front of large allocations);
+      default ``None`` = the policy of ``tensornetwork_amd.configure_gc`` / the environment
+      (``TNH_GC_FREEZE``, ``TNH_GC_COLLECT``).  See DESIGN.md section 3 and INTEGRATION.md.
   """
 
-  def __init__(self, device=None, half_output="same"):
+  def __init__(self, device=None, half_output="same", manage_gc=None):
     super().__init__()
     self.name = "hip"
     if half_output not in ("same", "float32"):
@@ -126,6 +130,8 @@ class HipBackend(BackendBase):
     self.half_output = half_output
     self._device = device
     self._lib = None
+    if manage_gc is not None:
+      device_tensor.configure_gc(freeze=bool(manage_gc), collect_before_large_alloc=bool(manage_gc))
     # bf16 / f16 tensordot: let the GEMM loaders absorb transposes (tnh_gemm_view) instead of K1 permutes.
     # TNH_ABSORB_TRANSPOSES=0 keeps the permute + NT lowering (A/B and second opinion in the tests).
     import os  # pylint: disable=import-outside-toplevel

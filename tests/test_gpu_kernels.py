@@ -794,3 +794,18 @@ def test_gemm_view_c_abi_rejects_bad_views_without_launching(hip):
   st = hip.lib.tnh_gemm_view(_lib.F32, _lib.F32, 4096, 4096, 128, ctypes.c_void_p(a.ptr), ctypes.byref(good),
                              ctypes.c_void_p(a.ptr), ctypes.byref(good), ctypes.c_void_p(out.ptr), 4096)
   assert st == _lib.ERR_INVALID
+
+
+def test_reductions_f32_vector_paths(hip):
+  """16-byte-load fast paths of K3/K4: contiguous rows split over many waves, axis sums with a small
+  power-of-two inner extent, ragged lengths (scalar tails), against float64."""
+  rng = np.random.default_rng(71)
+  for shape, axis in [((3, 70001), 1), ((1, 1 << 22), 1), ((5, 4099, 16), 1), ((64, 1000, 4), 1), ((2, 333, 256), 1),
+                      ((7, 513, 8), (0, 1)), ((4096, 257), None), ((1031, 64, 32), 1)]:
+    x = rng.standard_normal(shape).astype(np.float32)
+    got = np.asarray(hip.sum(dev(hip, x), axis=axis))
+    ref = x.astype(np.float64).sum(axis=axis)
+    scale = np.sqrt(x.size / max(ref.size, 1))
+    np.testing.assert_allclose(got, ref, rtol=1e-5, atol=2e-6 * scale * 10)
+  v = rng.standard_normal(3_000_001).astype(np.float32)
+  assert float(np.asarray(hip.norm(dev(hip, v)))) == pytest.approx(float(np.linalg.norm(v.astype(np.float64))), rel=1e-6)

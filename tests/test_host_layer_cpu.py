@@ -549,3 +549,30 @@ def test_operand_view_addressing_reproduces_tensordot():
   assert _operand_view((4, 64, 4, 64, 4, 64), [0, 2, 4], [1, 3, 5]) is None
   assert _operand_view((8, 64, 8, 68), [0, 1, 2], [3]) is None       # contraction run 68
   assert _operand_view((64, 12), [1], [0]) is None                   # k-major with 12-element rows (not 16-B chunks)
+
+
+def test_gc_policy_opt_out_leaves_the_collector_alone(monkeypatch):
+  """a library must not freeze / run the host's collector without an opt-out that is
+  part of the API.  With configure_gc(False, False) neither gc.freeze nor gc.collect is reached."""
+  import gc
+  from tensornetwork_amd import device_tensor as dt
+  import tensornetwork_amd as ta
+  saved = (dict(dt._GC_POLICY), dt._GC_FROZEN, dt._gc_cost_seconds)
+  calls = []
+  monkeypatch.setattr(gc, "freeze", lambda: calls.append("freeze"))
+  monkeypatch.setattr(gc, "collect", lambda *a: calls.append("collect") or 0)
+  monkeypatch.setattr(gc, "unfreeze", lambda: calls.append("unfreeze"))
+  try:
+    dt._GC_FROZEN = False
+    assert ta.configure_gc(freeze=False, collect_before_large_alloc=False) == {"freeze": False, "collect": False}
+    dt.freeze_collector_baseline()
+    assert not dt._worth_collecting(64 << 30)
+    assert calls == []
+    assert ta.configure_gc(freeze=True, collect_before_large_alloc=True) == {"freeze": True, "collect": True}
+    dt.freeze_collector_baseline()
+    assert calls == ["collect", "freeze"] and dt._GC_FROZEN
+    ta.configure_gc(freeze=False)
+    assert calls[-1] == "unfreeze" and not dt._GC_FROZEN
+  finally:
+    dt._GC_POLICY.update(saved[0])
+    dt._GC_FROZEN, dt._gc_cost_seconds = saved[1], saved[2]
