@@ -772,7 +772,15 @@ def main():
     if verified:
       verified["all_ok"] = bool(all(v.get("ok", False) for v in verified.values() if isinstance(v, dict)))
       result["verified"] = verified
-    print(json.dumps(result))
+    # the JSON line must be the LAST thing on stdout: drain whatever C libraries (RCCL's version banner under
+    # --comm torch) still hold in their stdio buffers first
+    sys.stdout.flush()
+    try:
+      import ctypes  # pylint: disable=import-outside-toplevel
+      ctypes.CDLL(None).fflush(None)
+    except Exception:  # pylint: disable=broad-except
+      pass
+    print(json.dumps(result), flush=True)
   if comm is not None:
     comm.barrier()
     comm.close()

@@ -15,6 +15,7 @@
 // MASTER_ADDR:MASTER_PORT+k); every rank then calls tnh_comm_init.
 #include "tnh_internal.h"
 #include <dlfcn.h>
+#include <unistd.h>
 #include <rccl/rccl.h>
 
 namespace tnh {
@@ -119,7 +120,23 @@ int tnh_comm_init(const void* host_id, int rank, int world) {
   if (rc != TNH_OK) return rc;
   ncclUniqueId id;
   memcpy(&id, host_id, sizeof(id));
-  TNH_NCCL(g_api.CommInitRank(&g_comm, world, id, rank));
+  // RCCL 2.2x printf()s a version banner ("RCCL version : ...", 5 lines) to stdout from its first
+  // communicator, whatever NCCL_DEBUG says.  A host program whose stdout is a protocol (bench.py: ONE JSON
+  // line) must not get library chatter there: stdout is pointed at stderr for the duration of the call.
+  fflush(stdout);
+  const int saved_stdout = dup(STDOUT_FILENO);
+  if (saved_stdout >= 0) dup2(STDERR_FILENO, STDOUT_FILENO);
+  const ncclResult_t init_rc = g_api.CommInitRank(&g_comm, world, id, rank);
+  fflush(stdout);
+  if (saved_stdout >= 0) {
+    dup2(saved_stdout, STDOUT_FILENO);
+    close(saved_stdout);
+  }
+  if (init_rc != ncclSuccess) {
+    g_comm = nullptr;
+    set_error("ncclCommInitRank failed: %s", g_api.GetErrorString(init_rc));
+    return TNH_ERR_HIP;
+  }
   g_rank = rank;
   g_world = world;
   return TNH_OK;

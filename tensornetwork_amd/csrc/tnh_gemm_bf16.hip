@@ -28,6 +28,7 @@ namespace tnh {
 
 int g_opt_raster = 1;  // A/B knobs, set through tnh_gemm_set_variant("name:r<d>:p<d>")
 int g_opt_phases = 2;  // ping-pong kernel: MFMA clusters per K-tile (2 = 32-MFMA clusters, default; 4)
+int g_opt_tail = 1;    // view GEMM: split-K launch for the last, mostly empty wave of tiles (":t0" switches it off)
 static bool g_pp_default = true;  // ping-pong kernel won the A/B on MI355X (profiles/r01_sweep_v2.jsonl)
 
 #define TNH_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
@@ -403,18 +404,28 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(NtArgs p) {
     __builtin_amdgcn_sched_barrier(0);                      \
   } while (0)
 
-  const int nt = (int)(p.K / BK);
+  int nt = (int)(p.K / BK);
   // element offset of the K-tile each operand stages next: A runs one tile ahead, B two
   KWalk wa, wb;
+  int64_t ka0 = 0, kb0 = 0;
   if constexpr (VIEW) {
-    wa.init(p.va, 1);
-    wb.init(p.vb, 1);
+    int first = 0;
+    if (p.kslice_tiles > 0) {            // split-K launch: this workgroup's slice of the contraction
+      first = (int)blockIdx.y * p.kslice_tiles;
+      nt = (nt - first < p.kslice_tiles) ? (nt - first) : p.kslice_tiles;
+    }
+    wa.init(p.va, first);
+    wb.init(p.vb, first);
+    ka0 = wa.off;
+    kb0 = wb.off;
+    wa.advance();
+    wb.advance();
   }
   // prologue: tile 0 complete, B halves of tile 1
-  issue(0, 0, 0);
-  issue(0, 1, 0);
-  issue(0, 2, 0);
-  issue(0, 3, 0);
+  issue(0, 0, ka0);
+  issue(0, 1, ka0);
+  issue(0, 2, kb0);
+  issue(0, 3, kb0);
   if (nt > 1) {
     const int64_t kb1 = VIEW ? wb.off : (int64_t)BK;
     issue(1, 2, kb1);
@@ -861,14 +872,80 @@ int gemm_bf16_view(int in_dt, int out_dt, int64_t M, int64_t N, int64_t K, const
   TNH_REQUIRE(nwg < (int64_t(1) << 24), "GEMM grid too large");
   const bool a_km = (va.sk0 != 1), b_kn = (vb.sk0 != 1);
   const bool is_bf16 = (in_dt == TNH_BF16), out_f32 = (out_dt == TNH_F32);
-  const dim3 grid((unsigned)nwg, 1);
-  if (a_km && b_kn) launch_pp_view_t<true, true>(is_bf16, out_f32, grid, p);
-  else if (a_km) launch_pp_view_t<true, false>(is_bf16, out_f32, grid, p);
-  else if (b_kn) launch_pp_view_t<false, true>(is_bf16, out_f32, grid, p);
-  else launch_pp_view_t<false, false>(is_bf16, out_f32, grid, p);
-  TNH_LAUNCH_CHECK();
+  p.kslice_tiles = 0;
+  auto launch = [&](const NtArgs& q, unsigned gy, bool f32_out) {
+    const dim3 grid((unsigned)((int64_t)q.tiles_m * q.tiles_n), gy);
+    if (a_km && b_kn) launch_pp_view_t<true, true>(is_bf16, f32_out, grid, q);
+    else if (a_km) launch_pp_view_t<true, false>(is_bf16, f32_out, grid, q);
+    else if (b_kn) launch_pp_view_t<false, true>(is_bf16, f32_out, grid, q);
+    else launch_pp_view_t<false, false>(is_bf16, f32_out, grid, q);
+  };
   *name = a_km ? (b_kn ? "bf16_view_tt_256x256x64_pp" : "bf16_view_tn_256x256x64_pp")
                : (b_kn ? "bf16_view_nn_256x256x64_pp" : "bf16_view_nt_256x256x64_pp");
+
+  // ---- tail split.  Every CU runs one 256 x 256 tile at a time, so a launch takes ceil(tiles / CUs) tile times:
+  // 1296 tiles (D = 96: 36 x 36) = 5.06 "waves" pay for 6.  When the last wave is mostly empty, the last tile rows are
+  // cut off and computed by a SPLIT-K launch of the same kernel (blockIdx.y = K-slice, f32 partial slabs, summed in a
+  // fixed order by K4): 35 x 36 tiles in 5 waves + 36 tiles x 7 slices in 1/7 of a tile time.
+  static const bool tail_env = []() { const char* e = getenv("TNH_GEMM_TAIL_SPLIT"); return !(e && e[0] == '0'); }();
+  const bool tail_on = tail_env && g_opt_tail != 0;     // knob ":t0" of tnh_gemm_set_variant (tests, A/B)
+  const int cus = num_cus() > 0 ? num_cus() : 256;
+  const int nkt = (int)(K / 64);
+  const bool rows_single_level = (p.va.sr1 == 0 || p.va.r0 >= M);
+  if (tail_on && nwg > cus && rows_single_level && ldc == N && nkt >= 32) {
+    const double base = (double)((nwg + cus - 1) / cus);
+    double best = base;
+    int best_rt = 0, best_ks = 0, best_s = 0;
+    for (int rt = 1; rt <= 4 && rt < p.tiles_m; ++rt) {
+      const int64_t main_tiles = (int64_t)(p.tiles_m - rt) * p.tiles_n, tail_tiles = (int64_t)rt * p.tiles_n;
+      int s = (int)(cus / tail_tiles);
+      if (s < 2) continue;
+      if (s > 16) s = 16;
+      const int ks = (nkt + s - 1) / s;
+      if (ks < 8) continue;
+      const int s_eff = (nkt + ks - 1) / ks;
+      const double cost = (double)((main_tiles + cus - 1) / cus) +
+                          (double)((tail_tiles * s_eff + cus - 1) / cus) * ks / nkt + 0.10;   // + reduction passes
+      if (cost < best) { best = cost; best_rt = rt; best_ks = ks; best_s = s_eff; }
+    }
+    if (best_rt > 0 && best <= 0.94 * base) {
+      const int64_t m_main = (int64_t)(p.tiles_m - best_rt) * 256, m_tail = M - m_main;
+      void* W = nullptr;
+      int rc = tnh_malloc(&W, (size_t)best_s * m_tail * N * 4);
+      if (rc == TNH_OK) {
+        NtArgs q = p;                     // main part: rows [0, m_main)
+        q.M = m_main;
+        q.tiles_m = p.tiles_m - best_rt;
+        launch(q, 1, out_f32);
+        NtArgs t = p;                     // tail rows, split over K
+        t.A = p.A + (a_km ? m_main : m_main * p.va.sr0);
+        t.M = m_tail;
+        if (t.va.r0 > t.M) t.va.r0 = t.M;
+        t.tiles_m = (int)((m_tail + 255) / 256);
+        t.C = W;
+        t.ldc = N;
+        t.sC = m_tail * N;
+        t.kslice_tiles = best_ks;
+        launch(t, (unsigned)best_s, true);
+        TNH_LAUNCH_CHECK();
+        char* c_tail = (char*)C + (size_t)m_main * N * (out_f32 ? 4 : 2);
+        if (out_f32) {
+          rc = tnh_sum_mid(c_tail, W, 1, best_s, m_tail * N, TNH_F32);
+        } else {
+          void* T32 = nullptr;
+          rc = tnh_malloc(&T32, (size_t)m_tail * N * 4);
+          if (!rc) rc = tnh_sum_mid(T32, W, 1, best_s, m_tail * N, TNH_F32);
+          if (!rc) rc = tnh_cast(c_tail, out_dt, T32, TNH_F32, m_tail * N);
+          if (T32) tnh_free(T32);
+        }
+        tnh_free(W);
+        return rc;
+      }
+      (void)hipGetLastError();            // no room for the partial slabs: plain launch below
+    }
+  }
+  launch(p, 1, out_f32);
+  TNH_LAUNCH_CHECK();
   return TNH_OK;
 }
 

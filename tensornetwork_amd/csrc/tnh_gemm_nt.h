@@ -22,6 +22,8 @@ struct OpView {
 
 struct NtArgs {
   OpView va, vb;   // view kernels only
+  int kslice_tiles;  // view kernels, split-K launches: blockIdx.y owns K-tiles [y * kslice_tiles, ...) and writes
+                     // its partial product to C + y * sC (0: one slice = all of K)
   const uint16_t* A;
   const uint16_t* B;
   void* C;

@@ -66,6 +66,24 @@ def public_dtype(code):
   return bfloat16 if code == _lib.BF16 else _TNH_TO_NP[code]
 
 
+# bool, unsigned and 8 / 16-bit integers have no kernels of their own: they are STORED as int64 in HBM and
+# carry their NumPy dtype as an alias (``DeviceTensor.dtype`` reports it, readback converts to it).
+# Add / subtract / multiply in two's-complement int64 followed by the truncating conversion on readback is
+# exactly NumPy's modular arithmetic in the narrow type (the reference's tests feed every NumPy dtype to
+# every backend, tests/testing_utils.py:12-20).
+_ALIASED_KINDS = "bu"
+
+
+def storage_of(dtype):
+  """(tnh code, alias or None) for a NumPy dtype / bfloat16 tag."""
+  if dtype is bfloat16 or (isinstance(dtype, str) and dtype in ("bfloat16", "bf16")):
+    return _lib.BF16, None
+  key = np.dtype(dtype)
+  if key.kind in _ALIASED_KINDS or (key.kind == "i" and key.itemsize < 4):
+    return _lib.I64, key
+  return tnh_dtype(key), None
+
+
 def f32_to_bf16_bits(x):
   """float32 ndarray -> uint16 bf16 bit patterns, round-to-nearest-even."""
   u = np.ascontiguousarray(x, dtype=np.float32).view(np.uint32)
@@ -207,23 +225,24 @@ def _rebuild_bf16(host):
 
 class DeviceTensor:
   """Dense row-major tensor in HBM."""
-  __slots__ = ("_block", "_offset", "_shape", "_code", "__weakref__")
+  __slots__ = ("_block", "_offset", "_shape", "_code", "_alias", "__weakref__")
   __array_priority__ = 1000  # ndarray (op) DeviceTensor defers to us
 
-  def __init__(self, block, shape, code, offset=0):
+  def __init__(self, block, shape, code, offset=0, alias=None):
     self._block = block
     self._offset = int(offset)
     self._shape = tuple(int(s) for s in shape)
     self._code = int(code)
+    self._alias = alias          # NumPy dtype of a bool / unsigned / narrow-int tensor stored as int64
 
   # -- construction ----------------------------------------------------------
   @classmethod
-  def empty(cls, shape, code):
+  def empty(cls, shape, code, alias=None):
     shape = tuple(int(s) for s in shape)
     if any(s < 0 for s in shape):
       raise ValueError(f"negative dimensions are not allowed: {shape}")
     n = math.prod(shape)
-    return cls(_Block(n * _ITEMSIZE[code]), shape, code)
+    return cls(_Block(n * _ITEMSIZE[code]), shape, code, 0, alias if code == _lib.I64 else None)
 
   @classmethod
   def from_numpy(cls, array, dtype=None):
@@ -237,12 +256,14 @@ class DeviceTensor:
     else:
       if dtype is not None:
         array = array.astype(dtype)
+      alias = None
       if array.dtype == np.bool_ or array.dtype.kind in "u" or (
           array.dtype.kind == "i" and array.dtype.itemsize < 4):
-        array = array.astype(np.int64)
+        alias = array.dtype
+        array = array.astype(np.int64)       # uint64 keeps its bit pattern
       code = tnh_dtype(array.dtype)
       host = np.ascontiguousarray(array)
-    out = cls.empty(array.shape, code)
+    out = cls.empty(array.shape, code, alias if dtype is None or tnh_dtype(dtype) != _lib.BF16 else None)
     if host.size:
       _lib.check(_lib.lib().tnh_h2d(ctypes.c_void_p(out.ptr),
                                     host.ctypes.data_as(ctypes.c_void_p),
@@ -264,7 +285,11 @@ class DeviceTensor:
 
   @property
   def dtype(self):
-    return public_dtype(self._code)
+    return self._alias if self._alias is not None else public_dtype(self._code)
+
+  @property
+  def alias(self):
+    return self._alias
 
   @property
   def code(self):
@@ -289,7 +314,7 @@ class DeviceTensor:
   def view(self, shape):
     """Metadata-only reshape sharing the device block."""
     shape = tuple(int(s) for s in shape)
-    return DeviceTensor(self._block, shape, self._code, self._offset)
+    return DeviceTensor(self._block, shape, self._code, self._offset, self._alias)
 
   # -- host transfer -----------------------------------------------------------
   def numpy(self):
@@ -303,6 +328,8 @@ class DeviceTensor:
                                     ctypes.c_void_p(self.ptr), host.nbytes), "tnh_d2h")
     if self._code == _lib.BF16:
       return bf16_bits_to_f32(host).reshape(self._shape)
+    if self._alias is not None:
+      return host.astype(self._alias)        # truncating conversion = the narrow type's modular arithmetic
     return host
 
   def __array__(self, dtype=None, copy=None):  # pylint: disable=unused-argument
@@ -341,7 +368,7 @@ class DeviceTensor:
     return self.__deepcopy__({})
 
   def __deepcopy__(self, memo):
-    out = DeviceTensor.empty(self._shape, self._code)
+    out = DeviceTensor.empty(self._shape, self._code, self._alias)
     if self.nbytes:
       _lib.check(_lib.lib().tnh_d2d(ctypes.c_void_p(out.ptr), ctypes.c_void_p(self.ptr), self.nbytes), "tnh_d2d")
     memo[id(self)] = out

@@ -17,7 +17,7 @@ from tensornetwork_amd import _lib
 from tensornetwork_amd.abstract import BackendBase, HAVE_TENSORNETWORK
 from tensornetwork_amd import device_tensor
 from tensornetwork_amd.device_tensor import (DeviceTensor, bfloat16, public_dtype,
-                                             tnh_dtype)
+                                             storage_of, tnh_dtype)
 
 _FLOAT_CODES = (_lib.F32, _lib.F64, _lib.BF16, _lib.F16, _lib.C64, _lib.C128)
 _INT_CODES = (_lib.I32, _lib.I64)
@@ -57,6 +57,23 @@ def _promote(c1, c2):
   if hi == _lib.C64 and lo == _lib.F64:
     return _lib.C128
   return hi
+
+
+def _np_dtype(t):
+  return None if t.dtype is bfloat16 else np.dtype(t.dtype)
+
+
+def _int_result(*tensors):
+  """(code, alias) of an integer-valued result of `tensors` under NumPy's promotion rules, or None when
+  an operand is not an integer / bool tensor (the float lattice of _promote applies then)."""
+  if not all(t.code in _INT_CODES for t in tensors):
+    return None
+  return storage_of(np.result_type(*[_np_dtype(t) for t in tensors]))
+
+
+def _sum_alias(t):
+  """NumPy sums unsigned integers in uint64 and bool / signed ones in int64."""
+  return np.dtype(np.uint64) if (t.alias is not None and t.alias.kind == "u") else None
 
 
 def _row_major_strides(shape):
@@ -178,13 +195,15 @@ class HipBackend(BackendBase):
 
   def cast(self, tensor, dtype):
     """Device-side dtype conversion (bf16/f16/f32/f64, real->complex)."""
-    code = dtype if isinstance(dtype, int) else tnh_dtype(dtype)
+    code, alias = (dtype, None) if isinstance(dtype, int) else storage_of(dtype)
     if tensor.code == code:
-      return tensor
+      if tensor.alias == alias:
+        return tensor
+      return DeviceTensor(tensor._block, tensor.shape, code, tensor._offset, alias)   # same bits, other narrow type  # pylint: disable=protected-access
     self._check_num(tensor, "cast")
     if tensor.is_complex and code not in _REAL_OF:
       raise TypeError(f"cannot cast {tensor.dtype} to a real dtype: the imaginary part would be discarded")
-    out = DeviceTensor.empty(tensor.shape, code)
+    out = DeviceTensor.empty(tensor.shape, code, alias)
     _lib.check(self.lib.tnh_cast(_vp(out), code, _vp(tensor), tensor.code, tensor.size), "tnh_cast")
     return out
 
@@ -249,14 +268,14 @@ class HipBackend(BackendBase):
       return tensor
     if nd > 16:
       raise NotImplementedError("hip backend supports tensors up to rank 16")
-    out = DeviceTensor.empty([tensor.shape[p] for p in perm], tensor.code)
+    out = DeviceTensor.empty([tensor.shape[p] for p in perm], tensor.code, tensor.alias)
     self.permute_launches += 1
     _lib.check(self.lib.tnh_permute(_vp(out), _vp(tensor), nd, _lib.i64_array(tensor.shape),
                                     _lib.i32_array(perm), tensor.itemsize), "tnh_permute")
     return out
 
   def _strided_copy(self, tensor, shape, strides, offset):
-    out = DeviceTensor.empty(shape, tensor.code)
+    out = DeviceTensor.empty(shape, tensor.code, tensor.alias)
     _lib.check(self.lib.tnh_strided_copy(_vp(out), _vp(tensor), len(shape), _lib.i64_array(shape),
                                          _lib.i64_array(strides), int(offset), tensor.itemsize),
                "tnh_strided_copy")
@@ -293,7 +312,7 @@ class HipBackend(BackendBase):
   def copy(self, tensor):
     """A new block holding the same data (device to device)."""
     tensor = self._as_tensor(tensor)
-    out = DeviceTensor.empty(tensor.shape, tensor.code)
+    out = DeviceTensor.empty(tensor.shape, tensor.code, tensor.alias)
     if tensor.nbytes:
       _lib.check(self.lib.tnh_d2d(_vp(out), _vp(tensor), tensor.nbytes), "tnh_d2d")
     return out
@@ -318,7 +337,8 @@ class HipBackend(BackendBase):
   def concat_rows(self, tensors):
     """Concatenate along the leading axis (device-to-device block copies)."""
     tensors = [self._as_tensor(t) for t in tensors]
-    out = DeviceTensor.empty((sum(t.shape[0] for t in tensors),) + tuple(tensors[0].shape[1:]), tensors[0].code)
+    out = DeviceTensor.empty((sum(t.shape[0] for t in tensors),) + tuple(tensors[0].shape[1:]), tensors[0].code,
+                             tensors[0].alias)
     row = 0
     for t in tensors:
       self.copy_rows_into(out, t, row)
@@ -365,11 +385,11 @@ class HipBackend(BackendBase):
 
   # -------------------------------------------------------------- contraction
   def _gemm(self, a, b, trans_a, trans_b, m, n, k, lda, ldb, batch=1, stride_a=0, stride_b=0,
-            out_shape=None, out_code=None):
+            out_shape=None, out_code=None, alias=None):
     code = a.code
     if out_code is None:
       out_code = _lib.F32 if (code in _HALF and self.half_output == "float32") else code
-    out = DeviceTensor.empty(out_shape if out_shape is not None else (m, n), out_code)
+    out = DeviceTensor.empty(out_shape if out_shape is not None else (m, n), out_code, alias)
     events = getattr(self, "gemm_events", None)
     if events is not None:  # bench.py: HIP events on the launch stream around the GEMM only
       start = _lib.Event().record()
@@ -438,7 +458,8 @@ class HipBackend(BackendBase):
     a = self._as_tensor(a)
     b = self._as_tensor(b)
     axes_a, axes_b = self._normalize_axes(a, b, axes)
-    code = _promote(a.code, b.code)
+    ires = _int_result(a, b)
+    code, alias = ires if ires is not None else (_promote(a.code, b.code), None)
     a, b = self.cast(a, code), self.cast(b, code)
     self._check_num(a, "tensordot")
 
@@ -450,7 +471,7 @@ class HipBackend(BackendBase):
     nc = len(axes_a)
     if nc == 0:
       out_shape = tuple(a.shape[i] for i in free_a) + tuple(b.shape[i] for i in free_b)
-      return self._outer(a, b, out_shape), free_a, free_b
+      return self._outer(a, b, out_shape, alias), free_a, free_b
 
     # bf16 / f16, enough 256 x 256 tiles: read BOTH operands in place through two-level strides
     # (K8 lowering of tensordot2.py:62-88 -- transposes are absorbed by the GEMM loaders, no K1 launch).
@@ -514,7 +535,7 @@ class HipBackend(BackendBase):
     ldb = k if trans_b else n
     if code in _REAL_OF and 8 * m * n * k >= (1 << 18):
       return self._complex_gemm(a, b, trans_a, trans_b, m, n, k).view(out_shape), free_a, free_b
-    out = self._gemm(a, b, trans_a, trans_b, m, n, k, lda, ldb)
+    out = self._gemm(a, b, trans_a, trans_b, m, n, k, lda, ldb, alias=alias)
     return out.view(out_shape), free_a, free_b
 
   def _tensordot_in_place(self, a, b, axes_a, axes_b, free_a, free_b, m, n, k, hint_a=None, hint_b=None):
@@ -601,9 +622,9 @@ class HipBackend(BackendBase):
       events.append((start, _lib.Event().record()))
     return out
 
-  def _outer(self, a, b, out_shape):
+  def _outer(self, a, b, out_shape, alias=None):
     m, n = a.size, b.size
-    out = DeviceTensor.empty((m, n), a.code)
+    out = DeviceTensor.empty((m, n), a.code, alias)
     _lib.check(self.lib.tnh_binary(_lib.OP_MUL, _vp(out), _vp(a), _vp(b), 2, _lib.i64_array((m, n)),
                                    _lib.i64_array((1, 0)), _lib.i64_array((0, 1)), a.code), "tnh_binary")
     return out.view(out_shape)
@@ -617,7 +638,8 @@ class HipBackend(BackendBase):
     tensor2 = self._as_tensor(tensor2)
     if (tensor1.ndim <= 1) or (tensor2.ndim <= 1):
       raise ValueError("inputs to `matmul` have to be a tensors of order > 1,")
-    code = _promote(tensor1.code, tensor2.code)
+    ires = _int_result(tensor1, tensor2)
+    code, alias = ires if ires is not None else (_promote(tensor1.code, tensor2.code), None)
     a, b = self.cast(tensor1, code), self.cast(tensor2, code)
     self._check_num(a, "matmul")
     m, k = a.shape[-2:]
@@ -639,7 +661,7 @@ class HipBackend(BackendBase):
       stride_a, stride_b = m * k, k * n
     batch = _prod(batch_shape)
     return self._gemm(a, b, False, False, m, n, k, k, n, batch, stride_a, stride_b,
-                      out_shape=tuple(batch_shape) + (m, n))
+                      out_shape=tuple(batch_shape) + (m, n), alias=alias)
 
   def _broadcast_to(self, t, shape):
     if tuple(t.shape) == tuple(shape):
@@ -671,7 +693,7 @@ class HipBackend(BackendBase):
     rest = [i for i in range(nd) if i not in (ax1, ax2)]
     t = self.transpose(tensor, rest + [ax1, ax2])
     outer = _prod(t.shape[:-2])
-    out = DeviceTensor.empty(t.shape[:-2], t.code)
+    out = DeviceTensor.empty(t.shape[:-2], t.code, _sum_alias(t))
     _lib.check(self.lib.tnh_trace_last2(_vp(out), _vp(t), outer, t.shape[-2], t.shape[-1],
                                         int(offset), t.code), "tnh_trace_last2")
     return out
@@ -691,6 +713,8 @@ class HipBackend(BackendBase):
         tuple(tensor.shape[i] for i in kept)
     if not axes:
       return tensor.view(final_shape)
+    if tensor.code == _lib.I32:
+      tensor = self.cast(tensor, _lib.I64)    # np.sum accumulates (and returns) int64 for narrower integers
     contiguous_run = axes == list(range(axes[0], axes[-1] + 1))
     if contiguous_run:
       outer = _prod(tensor.shape[:axes[0]])
@@ -702,7 +726,7 @@ class HipBackend(BackendBase):
       outer = _prod(tensor.shape[i] for i in kept)
       red = _prod(tensor.shape[i] for i in axes)
       inner = 1
-    out = DeviceTensor.empty(final_shape, tensor.code)
+    out = DeviceTensor.empty(final_shape, tensor.code, _sum_alias(tensor))
     _lib.check(self.lib.tnh_sum_mid(_vp(out), _vp(src), outer, red, inner, tensor.code), "tnh_sum_mid")
     return out
 
@@ -724,7 +748,7 @@ class HipBackend(BackendBase):
     if tensor.code in _INT_CODES and op in (_lib.OP_SQRT, _lib.OP_EXP, _lib.OP_LOG, _lib.OP_SIN, _lib.OP_COS):
       tensor = self.cast(tensor, _lib.F64)    # NumPy evaluates these on integers in float64
     to_real = tensor.is_complex and op in (_lib.OP_ABS, _lib.OP_REAL, _lib.OP_IMAG)
-    out = DeviceTensor.empty(tensor.shape, _REAL_OF[tensor.code] if to_real else tensor.code)
+    out = DeviceTensor.empty(tensor.shape, _REAL_OF[tensor.code] if to_real else tensor.code, tensor.alias)
     _lib.check(self.lib.tnh_unary(op, _vp(out), _vp(tensor), tensor.size, tensor.code), "tnh_unary")
     return out
 
@@ -786,14 +810,15 @@ class HipBackend(BackendBase):
       if s.imag != 0.0 and not t.is_complex:
         code = _lib.C128 if t.code == _lib.F64 else _lib.C64
         t = self.cast(t, code)
-      out = DeviceTensor.empty(t.shape, code)
+      out = DeviceTensor.empty(t.shape, code, t.alias)    # tensor (op) python int keeps the tensor's dtype (NumPy)
       _lib.check(self.lib.tnh_binary_scalar(op, _vp(out), _vp(t), s.real, s.imag, 1 if xs else 0,
                                             t.size, code), "tnh_binary_scalar")
       return out
     a, b = self._as_tensor(x), self._as_tensor(y)
-    code = _promote(a.code, b.code)
+    ires = _int_result(a, b)
+    code, alias = ires if ires is not None else (_promote(a.code, b.code), None)
     if op == _lib.OP_DIV and code in _INT_CODES:
-      code = _lib.F64                         # NumPy: int / int is a float64 true division
+      code, alias = _lib.F64, None            # NumPy: int / int is a float64 true division
     a, b = self.cast(a, code), self.cast(b, code)
     self._check_num(a, "arithmetic")
     try:
@@ -810,7 +835,7 @@ class HipBackend(BackendBase):
       dims = (1,) * pad + tuple(t.shape)
       return [0 if dims[d] == 1 and shape[d] != 1 else st[d] for d in range(len(shape))]
 
-    out = DeviceTensor.empty(shape, code)
+    out = DeviceTensor.empty(shape, code, alias)
     _lib.check(self.lib.tnh_binary(op, _vp(out), _vp(a), _vp(b), len(shape), _lib.i64_array(shape),
                                    _lib.i64_array(bstrides(a)), _lib.i64_array(bstrides(b)), code),
                "tnh_binary")
@@ -851,11 +876,9 @@ class HipBackend(BackendBase):
   # ------------------------------------------------------------ initialisation
   def _fill(self, shape, dtype, re, im=0.0):
     dtype = dtype if dtype is not None else np.float64
-    code = tnh_dtype(dtype)
-    if code not in _NUM_CODES:
-      return DeviceTensor.from_numpy(np.full(shape, re, dtype=dtype))
+    code, alias = storage_of(dtype)
     self.lib  # pylint: disable=pointless-statement
-    out = DeviceTensor.empty(shape, code)
+    out = DeviceTensor.empty(shape, code, alias)
     _lib.check(self.lib.tnh_fill(_vp(out), float(re), float(im), out.size, code), "tnh_fill")
     return out
 
@@ -867,10 +890,10 @@ class HipBackend(BackendBase):
 
   def eye(self, N, dtype=None, M=None):
     dtype = dtype if dtype is not None else np.float64
-    code = tnh_dtype(dtype)
+    code, alias = storage_of(dtype)
     self.lib  # pylint: disable=pointless-statement
     cols = int(N) if M is None else int(M)
-    out = DeviceTensor.empty((int(N), cols), code)
+    out = DeviceTensor.empty((int(N), cols), code, alias)
     _lib.check(self.lib.tnh_eye(_vp(out), int(N), cols, code), "tnh_eye")
     return out
 
@@ -918,7 +941,7 @@ class HipBackend(BackendBase):
     tensor = self._as_tensor(tensor)
     n = tensor.size
     side = n + abs(int(k))
-    out = DeviceTensor.empty((side, side), tensor.code)
+    out = DeviceTensor.empty((side, side), tensor.code, tensor.alias)
     _lib.check(self.lib.tnh_memset(_vp(out), 0, out.nbytes), "tnh_memset")
     offset = int(k) if k >= 0 else -int(k) * side
     _lib.check(self.lib.tnh_strided_scatter(_vp(out), _vp(tensor), 1, _lib.i64_array((n,)),

@@ -809,3 +809,79 @@ def test_reductions_f32_vector_paths(hip):
     np.testing.assert_allclose(got, ref, rtol=1e-5, atol=2e-6 * scale * 10)
   v = rng.standard_normal(3_000_001).astype(np.float32)
   assert float(np.asarray(hip.norm(dev(hip, v)))) == pytest.approx(float(np.linalg.norm(v.astype(np.float64))), rel=1e-6)
+
+
+@pytest.mark.parametrize("dtype", [np.bool_, np.uint8, np.uint16, np.uint32, np.uint64, np.int8, np.int16])
+def test_narrow_and_unsigned_dtypes_behave_like_numpy(hip, dtype):
+  """bool / unsigned / 8-16-bit integers are stored as int64 in HBM with their NumPy dtype as an alias:
+  dtype, data movement, modular arithmetic and NumPy's promotion must come out as on the host
+  (the reference's tests feed every NumPy dtype to every backend, tests/testing_utils.py:12-20)."""
+  rng = np.random.default_rng(5)
+  if dtype is np.bool_:
+    x = rng.integers(0, 2, size=(3, 4, 5)).astype(dtype)
+    y = rng.integers(0, 2, size=(5, 4, 2)).astype(dtype)
+  else:
+    info = np.iinfo(dtype)
+    x = rng.integers(info.min, info.max, size=(3, 4, 5), dtype=dtype, endpoint=True)
+    y = rng.integers(info.min, info.max, size=(5, 4, 2), dtype=dtype, endpoint=True)
+  dx, dy = dev(hip, x), dev(hip, y)
+  assert dx.dtype == np.dtype(dtype)
+  np.testing.assert_array_equal(np.asarray(dx), x)
+  for got, ref in ((hip.transpose(dx, (2, 0, 1)), np.transpose(x, (2, 0, 1))), (hip.reshape(dx, (12, 5)), x.reshape(12, 5)),
+                   (hip.slice(dx, (1, 0, 2), (2, 3, 2)), x[1:3, 0:3, 2:4]), (dx[1], x[1]), (hip.conj(dx), x),
+                   (hip.zeros((2, 3), dtype=dtype), np.zeros((2, 3), dtype=dtype)),
+                   (hip.ones((2, 3), dtype=dtype), np.ones((2, 3), dtype=dtype)),
+                   (hip.eye(3, dtype=dtype), np.eye(3, dtype=dtype)), (hip.diagflat(dx[0, 0]), np.diagflat(x[0, 0]))):
+    assert got.dtype == ref.dtype, (got.dtype, ref.dtype)
+    np.testing.assert_array_equal(np.asarray(got), ref)
+  with np.errstate(over="ignore"):
+    refs = [np.tensordot(x, y, [[2, 1], [0, 1]]), np.tensordot(x[0, 0], y[0, 0], 0)]
+    gots = [hip.tensordot(dx, dy, [[2, 1], [0, 1]]), hip.outer_product(dx[0, 0], dy[0, 0])]
+    if dtype is not np.bool_:
+      refs += [x + x, x * x, x - x, x * 3, np.sum(x, axis=1), np.sum(x), np.trace(x[:, :3, :3], axis1=-2, axis2=-1)]
+      gots += [hip.addition(dx, dx), hip.multiply(dx, dx), hip.subtraction(dx, dx), hip.multiply(dx, 3),
+               hip.sum(dx, axis=1), hip.sum(dx), hip.trace(dev(hip, np.ascontiguousarray(x[:, :3, :3])))]
+    if dtype not in (np.bool_, np.uint64):    # uint64 above 2^63 has no exact int64 / float64 image
+      refs += [x + x.astype(np.int32), x * np.float32(1.0) * x.astype(np.float32)]
+      gots += [hip.addition(dx, dev(hip, x.astype(np.int32))),
+               hip.multiply(hip.multiply(dx, 1.0), dev(hip, x.astype(np.float32)))]
+  for got, ref in zip(gots, refs):
+    if ref.dtype.kind == "f":
+      assert got.dtype.kind == "f"
+      np.testing.assert_allclose(np.asarray(got), ref, rtol=1e-6)
+    else:
+      assert got.dtype == ref.dtype, (got.dtype, ref.dtype)
+      np.testing.assert_array_equal(np.asarray(got), ref)
+
+
+def test_gemm_view_tail_split_matches_unsplit(hip):
+  """36 x 36 tiles on 256 CUs = 5.06 waves: the last tile row is computed by a split-K launch of the view
+  kernel (7 K-slices, f32 partial slabs, fixed-order sum).  Same values as the un-split launch up to the
+  rounding of the f32 partial sums, and both right against float64 on sampled entries."""
+  rng = np.random.default_rng(77)
+  m = n = 9216
+  k = 2048
+  a = hip.device_random((m, k), dtype=ta.bfloat16, seed=5, normal=True, b=k ** -0.5)
+  b = hip.device_random((k, n), dtype=ta.bfloat16, seed=6, normal=True, b=1.0)
+  hip.inplace_max_bytes, keep = 1 << 40, hip.inplace_max_bytes
+  try:
+    got = hip.tensordot(a, b, 1)                      # a K-contiguous, b k-major, tail split on
+    assert hip.lib.tnh_gemm_last_kernel().decode().startswith("bf16_view_nn")
+    _lib.check(hip.lib.tnh_gemm_set_variant(b"auto:t0"))
+    try:
+      ref_dev = hip.tensordot(a, b, 1)
+    finally:
+      _lib.check(hip.lib.tnh_gemm_set_variant(b"auto"))
+  finally:
+    hip.inplace_max_bytes = keep
+  rows = np.concatenate([rng.integers(0, m, 24), np.array([0, m - 256, m - 255, m - 1])])   # incl. the split tail rows
+  cols = rng.integers(0, n, 32)
+  g = np.stack([np.asarray(hip.getitem(got, (int(r),)))[cols] for r in rows]).astype(np.float64)
+  u = np.stack([np.asarray(hip.getitem(ref_dev, (int(r),)))[cols] for r in rows]).astype(np.float64)
+  a_rows = np.stack([np.asarray(hip.getitem(a, (int(r),))) for r in rows]).astype(np.float64)
+  b_cols = np.stack([np.asarray(hip.getitem(b, (slice(None), int(c)))) for c in cols]).astype(np.float64)
+  ref = a_rows @ b_cols.T
+  np.testing.assert_allclose(g, ref, rtol=2.0**-8, atol=2.0**-9)
+  np.testing.assert_allclose(u, ref, rtol=2.0**-8, atol=2.0**-9)
+  np.testing.assert_allclose(g, u, rtol=2.0**-7, atol=1e-6)      # at most one bf16 ulp apart (different f32 summation order)
+  assert np.array_equal(g[:24], u[:24]) or np.abs(g[:24] - u[:24]).max() <= 2.0**-7 * np.abs(u[:24]).max()

@@ -5,7 +5,7 @@ set -u
 export TMPDIR=/tmp
 OUT=$PWD/gpurun_out
 mkdir -p $OUT
-BENCH="python $PWD/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-sweep --mera-chi 0 --svd-n 0 --rr-bond 0 ${BENCH_ARGS:-}"
+BENCH="python $PWD/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-sweep --no-extras --no-verify --mera-chi 0 --svd-n 0 --rr-bond 0 ${BENCH_ARGS:-}"
 cd /tmp
 rocprofv3 --kernel-trace --stats -d $OUT/prof_stats -o bench -- $BENCH > $OUT/prof_stats.log 2>&1
 echo "stats rc=$?"
