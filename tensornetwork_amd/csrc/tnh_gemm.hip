@@ -626,6 +626,8 @@ int tnh_gemm_set_variant(const char* full) {
   else if (!strcmp(name, "bf16_ragged_128x128")) g_variant = 7;
   else if (!strcmp(name, "bf16_ragged_64x256")) g_variant = 8;
   else if (!strcmp(name, "bf16_ragged_256x64")) g_variant = 9;
+  else if (!strcmp(name, "bf16_ragged_192x128")) g_variant = 10;
+  else if (!strcmp(name, "bf16_ragged_128x192")) g_variant = 11;
   else {
     set_error("unknown gemm variant '%s'", name);
     return TNH_ERR_INVALID;

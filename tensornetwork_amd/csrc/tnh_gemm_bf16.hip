@@ -939,6 +939,8 @@ int gemm_bf16_view(int in_dt, int out_dt, int64_t M, int64_t N, int64_t K, const
           if (T32) tnh_free(T32);
         }
         tnh_free(W);
+        *name = a_km ? (b_kn ? "bf16_view_tt_256x256x64_pp+tail_splitk" : "bf16_view_tn_256x256x64_pp+tail_splitk")
+                     : (b_kn ? "bf16_view_nn_256x256x64_pp+tail_splitk" : "bf16_view_nt_256x256x64_pp+tail_splitk");
         return rc;
       }
       (void)hipGetLastError();            // no room for the partial slabs: plain launch below

@@ -25,6 +25,7 @@ extern int g_opt_phases;  // A/B knob (tnh_gemm_set_variant ":p<d>"): p1 disable
 #define g_opt_smallk (g_opt_phases != 1)
 #define g_opt_persist (g_opt_phases != 5)   // ":p5" = one block per tile (A/B)
 extern int g_opt_raster;  // ":r2" disables the LDS-staged epilogue (A/B)
+#define g_opt_wide192 (g_opt_raster != 3)   // ":r3" keeps 128 x 128 tiles for short sides of 129 .. 192 (A/B)
 
 // 8 consecutive k of one operand row -> one 16-B register chunk (zero past K).
 // `vw` (elements per aligned load) is wave-uniform.
@@ -307,7 +308,7 @@ static int row_vector_width(const void* base, int64_t ld, int64_t batch_stride, 
 
 // NT product of any shape / alignment on the matrix cores (called by gemm_bf16_fast
 // when the LDS-DMA kernels' alignment rules do not hold).  shape: 0 auto, 1 128x128,
-// 2 64x256, 3 256x64.
+// 2 64x256, 3 256x64, 4 192x128, 5 128x192.
 int gemm_bf16_ragged(int in_dt, int out_dt, int shape, int64_t M, int64_t N, int64_t K, const void* A,
                      int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int64_t batch,
                      int64_t sA, int64_t sB, int64_t sC, const char** name) {
@@ -331,6 +332,12 @@ int gemm_bf16_ragged(int in_dt, int out_dt, int shape, int64_t M, int64_t N, int
       // streaming products: the square tile keeps the most blocks resident (measured:
       // 144 x 3e6 x 144 0.64 ms vs 0.73 ms for 64x256); only a really short side switches
       shape = (M <= 64 && N > 64) ? 2 : ((N <= 64 && M > 64) ? 3 : 1);
+      // a short M of 129 .. 192 (D = 12 / 13: D^2 = 144 / 169) fits ONE 192-row tile: with 128 x 128 tiles the
+      // long operand is streamed through L2 / LDS twice and the second tile row is mostly padding.  Measured on
+      // MI355X (profiles/r02_skinny_ab.txt): 144 x 2985984 x 144 0.758 -> 0.663-0.696 ms; it loses on short grids
+      // (144 x 248832 x 144: 0.055 -> 0.061 ms, one block per CU at 280 registers) and in the transposed
+      // orientation (128 x 192 tiles: 0.649 -> 0.704 ms), so only the long-N case takes it.
+      if (g_opt_wide192 && M > 128 && M <= 192 && N >= (int64_t(1) << 20)) shape = 4;
     } else {
       // least padded work; ties go to the square tile
       auto padded = [&](int64_t bm, int64_t bn) {
@@ -351,6 +358,16 @@ int gemm_bf16_ragged(int in_dt, int out_dt, int shape, int64_t M, int64_t N, int
     *name = smallk ? "bf16_nt_ragged_256x64x64_smallk" : "bf16_nt_ragged_256x64x64";
     return smallk ? launch_ragged<256, 64, 4, 1, true>(is_bf16, out_f32, p, batch)
                   : launch_ragged<256, 64, 4, 1, false>(is_bf16, out_f32, p, batch);
+  }
+  if (shape == 4) {
+    *name = smallk ? "bf16_nt_ragged_192x128x64_smallk" : "bf16_nt_ragged_192x128x64";
+    return smallk ? launch_ragged<192, 128, 2, 2, true>(is_bf16, out_f32, p, batch)
+                  : launch_ragged<192, 128, 2, 2, false>(is_bf16, out_f32, p, batch);
+  }
+  if (shape == 5) {
+    *name = smallk ? "bf16_nt_ragged_128x192x64_smallk" : "bf16_nt_ragged_128x192x64";
+    return smallk ? launch_ragged<128, 192, 2, 2, true>(is_bf16, out_f32, p, batch)
+                  : launch_ragged<128, 192, 2, 2, false>(is_bf16, out_f32, p, batch);
   }
   *name = smallk ? "bf16_nt_ragged_128x128x64_smallk" : "bf16_nt_ragged_128x128x64";
   return smallk ? launch_ragged<128, 128, 2, 2, true>(is_bf16, out_f32, p, batch)

@@ -153,7 +153,7 @@ class HipBackend(BackendBase):
     # TNH_ABSORB_TRANSPOSES=0 keeps the permute + NT lowering (A/B and second opinion in the tests).
     import os  # pylint: disable=import-outside-toplevel
     self.absorb_transposes = os.environ.get("TNH_ABSORB_TRANSPOSES", "1") != "0"
-    self.inplace_max_bytes = int(os.environ.get("TNH_VIEW_INPLACE_MAX_BYTES", str(1 << 30)))
+    self.inplace_max_bytes = int(os.environ.get("TNH_VIEW_INPLACE_MAX_BYTES", str(2 << 30)))
     self.permutes_absorbed = 0   # tnh_gemm_view launches
     self.permute_launches = 0    # K1 launches (transpose)
 
@@ -544,12 +544,8 @@ class HipBackend(BackendBase):
 
     The contraction order K is free as long as both sides agree: a's memory order of the contracted axes
     and b's are both tried, and the one that leaves the fewest bytes to permute wins.  An operand is read
-    in place when `_operand_view` offers a view -- except a non-trivial one (k-major, i.e. rows contiguous
-    like a [K][N] operand, or two-level strides) of a tensor larger than `inplace_max_bytes`: measured on
-    MI355X (tools/view_probe.py, profiles/r02_lowering_ab.txt) a workgroup streaming a k-major operand
-    touches 64 new pages per K-tile, and beyond ~1-2 GiB that costs more (8192 x 8192 x 262144: -10 % GEMM
-    rate, 65536^3: -4 %) than the one HBM-bound K1 pass that makes it K-contiguous, while below it the
-    absorbed permute is a net win (D = 64 layout L1: 950 -> 1100-1190 TFLOP/s).  Operands that are not read
+    in place when `_operand_view` offers a view and the size / intensity gate in `usable` below lets it.
+    Operands that are not read
     in place are permuted to [free..., contracted...] (free order = the planner's hint when given) and
     viewed trivially.  Returns (tensor, used_free_a, used_free_b)."""
     if m < 256 or n < 256 or ((m + 255) // 256) * ((n + 255) // 256) < 192 or k % 64 or k < 128:
@@ -561,9 +557,16 @@ class HipBackend(BackendBase):
 
     def usable(t, free, kax):
       v = _operand_view(t.shape, free, kax)
-      plain = v is not None and v.sk0 == 1 and v.sr1 == 0 and v.sk1 == 0       # already [rows][K]: the NT form
-      if v is not None and not plain and t.nbytes > self.inplace_max_bytes:
-        return None
+      # Gate (measured, profiles/r02_lowering_ab.txt): a view of a tensor above `inplace_max_bytes` is given up for
+      # ONE K1 pass into a K-contiguous copy when it is k-major (a workgroup streaming it touches 64 new pages per
+      # K-tile: -4 ... -10 % GEMM rate), or when it has two-level strides AND the product is so compute-heavy that
+      # the copy is free (> 2e4 flop per operand byte: config-2 L1 at D = 256 runs 5 % slower on the strided `a`
+      # than on its 3.7 ms copy).  Everything else is read in place: the MERA layer at chi = 32 loses 35 % when
+      # its 68 GB intermediates (30 - 1000 flop per byte) are permuted.
+      if v is not None and t.nbytes > self.inplace_max_bytes:
+        plain = v.sk0 == 1 and v.sr1 == 0 and v.sk1 == 0
+        if v.sk0 != 1 or (not plain and 2.0 * m * n * k > 2e4 * t.nbytes):
+          return None
       return v
 
     best = None

@@ -769,7 +769,7 @@ def test_gemm_view_falls_back_when_it_cannot_read_in_place(hip):
   assert absorbed == 1 and permutes == 1, (kernel, absorbed, permutes)
   # a k-major operand above the size policy is permuted instead of being streamed in place
   keep = hip.inplace_max_bytes
-  hip.inplace_max_bytes = 1 << 16
+  hip.inplace_max_bytes = 1 << 16     # b is k-major and 0.9 MB: above this gate -> permuted, then the plain NT view
   try:
     kernel, absorbed, permutes = _view_case(hip, ta.bfloat16, (14, 256, 2, 64), (2, 64, 14, 256), ([2, 3], [0, 1]), 63)
   finally:

@@ -78,7 +78,10 @@ def main():
               (1728, 248832, 12), (248832, 1728, 12), (144, 248832, 144), (248832, 144, 144),
               (4000, 4000, 4000), (12, 20736, 1728), (20736, 12, 1728)]
     for (m, n, k) in shapes:
-      for variant in ("bf16_ragged_128x128:p5", "bf16_ragged_128x128", "auto"):
+      for variant in ("bf16_ragged_128x128", "bf16_ragged_192x128", "bf16_ragged_128x192", "bf16_ragged_256x64", "auto"):
+        if (variant.endswith("192x128") and not 128 < m <= 192) or (variant.endswith("128x192") and not 128 < n <= 192) or \
+           (variant.endswith("256x64") and not m <= 256 < n):
+          continue
         if variant == "generic" and 2.0 * m * n * k > 3e11:
           continue
         rec = gemm_tflops(be, _lib.BF16, _lib.BF16, 0, 1, m, n, k, variant, "uniform", 5)
