@@ -14,6 +14,7 @@
 // so the four transpose combinations are one kernel.  MFMA roofline: 2*M*N*K flop.
 #include <stdlib.h>
 #include <algorithm>
+#include <type_traits>
 #include "tnh_types.h"
 #include "tnh_gemm_nt.h"
 
@@ -147,6 +148,137 @@ __global__ __launch_bounds__(256) void gemm_mfma_f32_kernel(GemmArgs g) {
           float v = alpha * acc[i][j][r];
           if (beta != 0.f) v += beta * load_out_f32(g.C, g.out_dt, idx);
           store_out_f32(g.C, g.out_dt, idx, v);
+        }
+      }
+    }
+}
+
+// f32 fast path (round 2): same 128 x 128 output tile and v_mfma_f32_32x32x2_f32 schedule, but BK = 32, 16-byte
+// global loads along each operand's contiguous direction, two LDS stages and ONE barrier per K-tile (the loads of
+// tile t+1 are in flight during the 64 MFMAs of tile t and land in the other stage after them).  Needs f32 in /
+// out, 16-byte aligned operands and leading dimensions that are multiples of 4; ragged M / N / K are handled by
+// clamping rows and zero-filling the K tail.  Everything else stays on gemm_mfma_f32_kernel above.
+//   KC_A / KC_B: the operand is K-contiguous (A[m][k] / B[n][k]); otherwise row-contiguous (A[k][m] / B[k][n]).
+template <bool KC_A, bool KC_B>
+__global__ __launch_bounds__(256) void gemm_mfma_f32_v2_kernel(GemmArgs g) {
+  constexpr int BM = 128, BN = 128, BK = 32, LD = 132;
+  __shared__ __attribute__((aligned(16))) float As[2][BK][LD];
+  __shared__ __attribute__((aligned(16))) float Bs[2][BK][LD];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wid = tid >> 6;
+  const int wm = wid >> 1, wn = wid & 1;
+  const int64_t m0 = (int64_t)blockIdx.y * BM, n0 = (int64_t)blockIdx.x * BN;
+  const float* A = (const float*)g.A + (int64_t)blockIdx.z * g.sA;
+  const float* B = (const float*)g.B + (int64_t)blockIdx.z * g.sB;
+  const int64_t cbase = (int64_t)blockIdx.z * g.sC;
+  const int64_t lda = KC_A ? g.rsA : g.csA, ldb = KC_B ? g.csB : g.rsB;   // stride of the non-contiguous index
+
+  float4 ra[4], rb[4];
+  // one operand tile = 128 rows x 32 k = 1024 float4, four per thread
+  auto load_op = [&](auto kc, float4 (&r)[4], const float* P, int64_t ld, int64_t row0, int64_t rows, int64_t k0) {
+    constexpr bool KC = decltype(kc)::value;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if constexpr (KC) {
+        int64_t row = row0 + (tid >> 3) + 32 * j;
+        if (row >= rows) row = rows - 1;                  // clamped rows are computed and never stored
+        const int64_t k = k0 + 4 * (tid & 7);
+        const float* p = P + row * ld + k;
+        if (k + 3 < g.K) v = *(const float4*)p;
+        else {
+          if (k < g.K) v.x = p[0];
+          if (k + 1 < g.K) v.y = p[1];
+          if (k + 2 < g.K) v.z = p[2];
+        }
+      } else {
+        const int64_t k = k0 + (tid >> 5) + 8 * j;
+        const int64_t row = row0 + 4 * (tid & 31);
+        if (k < g.K) {
+          const float* p = P + k * ld + row;
+          if (row + 3 < rows) v = *(const float4*)p;
+          else {
+            if (row < rows) v.x = p[0];
+            if (row + 1 < rows) v.y = p[1];
+            if (row + 2 < rows) v.z = p[2];
+          }
+        }
+      }
+      r[j] = v;
+    }
+  };
+  auto store_op = [&](auto kc, const float4 (&r)[4], float (*S)[LD]) {
+    constexpr bool KC = decltype(kc)::value;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if constexpr (KC) {
+        const int row = (tid >> 3) + 32 * j, k = 4 * (tid & 7);
+        S[k][row] = r[j].x;
+        S[k + 1][row] = r[j].y;
+        S[k + 2][row] = r[j].z;
+        S[k + 3][row] = r[j].w;
+      } else {
+        *(float4*)&S[(tid >> 5) + 8 * j][4 * (tid & 31)] = r[j];
+      }
+    }
+  };
+  using KA = std::integral_constant<bool, KC_A>;
+  using KB = std::integral_constant<bool, KC_B>;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int64_t nt = (g.K + BK - 1) / BK;
+  load_op(KA{}, ra, A, lda, m0, g.M, 0);
+  load_op(KB{}, rb, B, ldb, n0, g.N, 0);
+  store_op(KA{}, ra, As[0]);
+  store_op(KB{}, rb, Bs[0]);
+  __syncthreads();
+  const int kl = lane >> 5, il = lane & 31;
+  for (int64_t t = 0; t < nt; ++t) {
+    const int cur = (int)(t & 1);
+    if (t + 1 < nt) {
+      load_op(KA{}, ra, A, lda, m0, g.M, (t + 1) * BK);
+      load_op(KB{}, rb, B, ldb, n0, g.N, (t + 1) * BK);
+    }
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 2) {
+      const float a0 = As[cur][kk + kl][wm * 64 + il];
+      const float a1 = As[cur][kk + kl][wm * 64 + 32 + il];
+      const float b0 = Bs[cur][kk + kl][wn * 64 + il];
+      const float b1 = Bs[cur][kk + kl][wn * 64 + 32 + il];
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+    }
+    if (t + 1 < nt) {
+      store_op(KA{}, ra, As[cur ^ 1]);
+      store_op(KB{}, rb, Bs[cur ^ 1]);
+    }
+    __syncthreads();
+  }
+
+  const float alpha = (float)g.alpha, beta = (float)g.beta;
+  float* C = (float*)g.C;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int64_t n = n0 + wn * 64 + j * 32 + (lane & 31);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (m < g.M && n < g.N) {
+          const int64_t idx = cbase + m * g.ldc + n;
+          float v = alpha * acc[i][j][r];
+          if (beta != 0.f) v += beta * C[idx];
+          C[idx] = v;
         }
       }
     }
@@ -571,6 +703,11 @@ static int launch_split3(uint16_t* dst, const float* src, int64_t rows, int64_t 
   return TNH_OK;
 }
 
+static bool f32_v2_enabled() {
+  static const bool on = []() { const char* e = getenv("TNH_F32_V2"); return !(e && e[0] == '0'); }();
+  return on;
+}
+
 static thread_local const char* g_last_kernel = "none";
 static thread_local bool g_in_splitk = false;   // re-entrancy guard of the split-K path
 static int g_variant = 0;  // 0 auto, 1 generic (mfma), 2 valu, 3 bf16_128, 4 bf16_256, 5 bf16_256pp,
@@ -856,6 +993,27 @@ int tnh_gemm_ex(int in_dtype, int out_dtype, int transA, int transB, int64_t M, 
           return 0;
         },
         g, batch, 64, 64);
+  }
+  if (in_dtype == TNH_F32 && out_dtype == TNH_F32 && g_variant != 1 && f32_v2_enabled()) {
+    // 16-byte loads need: a contiguous direction on each operand (always true for the two storage forms the
+    // dispatcher produces), the other stride a multiple of 4 elements, 16-byte aligned bases and batch strides
+    const bool kc_a = (g.csA == 1), kc_b = (g.rsB == 1);
+    const int64_t lda_ = kc_a ? g.rsA : g.csA, ldb_ = kc_b ? g.csB : g.rsB;
+    const bool ok = (kc_a || g.rsA == 1) && (kc_b || g.csB == 1) && lda_ % 4 == 0 && ldb_ % 4 == 0 &&
+                    ((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0 && strideA % 4 == 0 && strideB % 4 == 0;
+    if (ok) {
+      g_last_kernel = "mfma_f32_128x128x32_v2";
+      return launch_batched(
+          [&](const GemmArgs&, int64_t b0, dim3 grid) -> int {
+            GemmArgs h = shifted(b0);
+            if (kc_a && kc_b) hipLaunchKernelGGL((gemm_mfma_f32_v2_kernel<true, true>), grid, dim3(256), 0, stream(), h);
+            else if (kc_a) hipLaunchKernelGGL((gemm_mfma_f32_v2_kernel<true, false>), grid, dim3(256), 0, stream(), h);
+            else if (kc_b) hipLaunchKernelGGL((gemm_mfma_f32_v2_kernel<false, true>), grid, dim3(256), 0, stream(), h);
+            else hipLaunchKernelGGL((gemm_mfma_f32_v2_kernel<false, false>), grid, dim3(256), 0, stream(), h);
+            return 0;
+          },
+          g, batch, 128, 128);
+    }
   }
   g_last_kernel = "mfma_f32_128x128x16";
   return launch_batched(

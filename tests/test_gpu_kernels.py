@@ -188,14 +188,15 @@ def test_gemm_f32_on_bf16_matrix_cores(hip, ta_, tb_):
       _lib.check(hip.lib.tnh_gemm_set_variant(b"auto"))
     assert out.dtype == np.float32
     err[kernel] = float((np.abs(out - exact) / scale).max())
-  assert set(err) == {"f32_as_3xbf16_nt_256x256x64_pp", "mfma_f32_128x128x16"}, err
+  native = [kname for kname in err if kname.startswith("mfma_f32_128x128")]
+  assert set(err) == {"f32_as_3xbf16_nt_256x256x64_pp", native[0]} and len(native) == 1, err
   assert err["f32_as_3xbf16_nt_256x256x64_pp"] <= 5e-7                      # ~4 eps_f32 of sum |a||b| at K ~ 1100
-  assert err["f32_as_3xbf16_nt_256x256x64_pp"] <= 1.5 * err["mfma_f32_128x128x16"]
+  assert err["f32_as_3xbf16_nt_256x256x64_pp"] <= 1.5 * err[native[0]]
 
 
 def test_gemm_f32_split_only_for_large_products(hip):
   out, ref, kernel, sk = _gemm_case(hip, np.float32, 1024, 1024, 2048, 0, 1)
-  assert kernel == "mfma_f32_128x128x16"                                   # 16 tiles of 256^2: native kernel
+  assert kernel.startswith("mfma_f32_128x128")                             # 16 tiles of 256^2: native kernel
   np.testing.assert_allclose(out, ref, rtol=GEMM_TOL[np.float32] * sk, atol=GEMM_TOL[np.float32] * sk * np.sqrt(2048))
 
 
@@ -294,14 +295,14 @@ def test_gemm_bf16_auto_dispatch_uses_speed_path(hip):
   np.testing.assert_allclose(np.asarray(out), ref, rtol=1.6e-2, atol=1.6e-2 * 16)
 
 
-@pytest.mark.parametrize("dtype,kernel,tol", [(np.complex64, "mfma_f32_128x128x16", 3e-6), (np.complex128, "mfma_f64_64x64x16", 1e-14)])
+@pytest.mark.parametrize("dtype,kernel,tol", [(np.complex64, "mfma_f32_128x128", 3e-6), (np.complex128, "mfma_f64_64x64x16", 1e-14)])
 @pytest.mark.parametrize("ta_,tb_", [(0, 0), (0, 1), (1, 0), (1, 1)])
 def test_gemm_complex_on_matrix_cores(hip, dtype, kernel, tol, ta_, tb_):
   """complex64 / complex128 contraction = one real MFMA GEMM on the interleaved images of A and C
   against the 2x2-block real expansion of B (tnh_complex_expand), every storage layout."""
   for (m, n, k) in [(200, 136, 96), (64, 257, 33), (512, 384, 256)]:
     out, ref, name, sk = _gemm_case(hip, dtype, m, n, k, ta_, tb_, rng=np.random.default_rng(m + n + k))
-    assert name == kernel, name
+    assert name.startswith(kernel), name
     np.testing.assert_allclose(out, ref, rtol=tol * sk * 4, atol=tol * k * 2)
 
 
@@ -860,13 +861,13 @@ def test_gemm_view_tail_split_matches_unsplit(hip):
   rounding of the f32 partial sums, and both right against float64 on sampled entries."""
   rng = np.random.default_rng(77)
   m = n = 9216
-  k = 2048
+  k = 6144
   a = hip.device_random((m, k), dtype=ta.bfloat16, seed=5, normal=True, b=k ** -0.5)
   b = hip.device_random((k, n), dtype=ta.bfloat16, seed=6, normal=True, b=1.0)
   hip.inplace_max_bytes, keep = 1 << 40, hip.inplace_max_bytes
   try:
     got = hip.tensordot(a, b, 1)                      # a K-contiguous, b k-major, tail split on
-    assert hip.lib.tnh_gemm_last_kernel().decode().startswith("bf16_view_nn")
+    assert hip.lib.tnh_gemm_last_kernel().decode() == "bf16_view_nn_256x256x64_pp+tail_splitk"
     _lib.check(hip.lib.tnh_gemm_set_variant(b"auto:t0"))
     try:
       ref_dev = hip.tensordot(a, b, 1)
@@ -885,3 +886,28 @@ def test_gemm_view_tail_split_matches_unsplit(hip):
   np.testing.assert_allclose(u, ref, rtol=2.0**-8, atol=2.0**-9)
   np.testing.assert_allclose(g, u, rtol=2.0**-7, atol=1e-6)      # at most one bf16 ulp apart (different f32 summation order)
   assert np.array_equal(g[:24], u[:24]) or np.abs(g[:24] - u[:24]).max() <= 2.0**-7 * np.abs(u[:24]).max()
+
+
+@pytest.mark.parametrize("ta_,tb_", [(0, 0), (0, 1), (1, 0), (1, 1)])
+@pytest.mark.parametrize("m,n,k", [(256, 384, 512), (132, 200, 100), (4, 8, 36), (1000, 260, 68), (128, 128, 32)])
+def test_gemm_f32_v2_vector_path(hip, ta_, tb_, m, n, k):
+  """f32 fast path (16-byte loads, BK = 32, two LDS stages): all four storage forms, ragged M / N edges and a K
+  tail, against float64; the kernel actually taken is checked."""
+  out, ref, kernel, sk = _gemm_case(hip, np.float32, m, n, k, ta_, tb_, rng=np.random.default_rng(m + n + k + ta_ + 2 * tb_))
+  assert kernel == "mfma_f32_128x128x32_v2", kernel
+  tol = GEMM_TOL[np.float32]
+  np.testing.assert_allclose(out, ref, rtol=tol * sk, atol=tol * sk * np.sqrt(k))
+
+
+def test_gemm_f32_v2_batched_and_unaligned_fallback(hip):
+  rng = np.random.default_rng(91)
+  a = rng.standard_normal((3, 140, 64)).astype(np.float32)
+  b = rng.standard_normal((3, 64, 72)).astype(np.float32)
+  out = np.asarray(hip.matmul(dev(hip, a), dev(hip, b)))
+  assert hip.lib.tnh_gemm_last_kernel().decode() == "mfma_f32_128x128x32_v2"
+  np.testing.assert_allclose(out, np.matmul(a.astype(np.float64), b.astype(np.float64)), rtol=1e-5, atol=1e-4)
+  x = rng.standard_normal((130, 129)).astype(np.float32)          # leading dimension 129: not a multiple of 4
+  y = rng.standard_normal((129, 70)).astype(np.float32)
+  out = np.asarray(hip.tensordot(dev(hip, x), dev(hip, y), 1))
+  assert hip.lib.tnh_gemm_last_kernel().decode() == "mfma_f32_128x128x16"
+  np.testing.assert_allclose(out, x.astype(np.float64) @ y.astype(np.float64), rtol=1e-5, atol=1e-4)
