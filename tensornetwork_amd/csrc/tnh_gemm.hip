@@ -161,9 +161,14 @@ __global__ __launch_bounds__(256) void gemm_mfma_f32_kernel(GemmArgs g) {
 //   KC_A / KC_B: the operand is K-contiguous (A[m][k] / B[n][k]); otherwise row-contiguous (A[k][m] / B[k][n]).
 template <bool KC_A, bool KC_B>
 __global__ __launch_bounds__(256) void gemm_mfma_f32_v2_kernel(GemmArgs g) {
-  constexpr int BM = 128, BN = 128, BK = 32, LD = 132;
-  __shared__ __attribute__((aligned(16))) float As[2][BK][LD];
-  __shared__ __attribute__((aligned(16))) float Bs[2][BK][LD];
+  // LDS image per operand and stage: row-contiguous operands as [k][row] (pitch 132: one ds_write_b128 per
+  // float4), K-contiguous operands as [row][k] (pitch 33: the four scalar stores of a float4 and the MFMA
+  // fragment reads -- 32 rows at one k -- are both conflict-free; the [k][row] image costs 4-way store conflicts:
+  // 98.8 vs 114 TF at 4096^3 before this change)
+  constexpr int BM = 128, BN = 128, BK = 32, LD = 132, LDK = 33;
+  constexpr int IMG = (BK * LD > BM * LDK) ? BK * LD : BM * LDK;
+  __shared__ __attribute__((aligned(16))) float As[2][IMG];
+  __shared__ __attribute__((aligned(16))) float Bs[2][IMG];
   const int tid = threadIdx.x;
   const int lane = tid & 63, wid = tid >> 6;
   const int wm = wid >> 1, wn = wid & 1;
@@ -207,20 +212,25 @@ __global__ __launch_bounds__(256) void gemm_mfma_f32_v2_kernel(GemmArgs g) {
       r[j] = v;
     }
   };
-  auto store_op = [&](auto kc, const float4 (&r)[4], float (*S)[LD]) {
+  auto store_op = [&](auto kc, const float4 (&r)[4], float* S) {
     constexpr bool KC = decltype(kc)::value;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       if constexpr (KC) {
-        const int row = (tid >> 3) + 32 * j, k = 4 * (tid & 7);
-        S[k][row] = r[j].x;
-        S[k + 1][row] = r[j].y;
-        S[k + 2][row] = r[j].z;
-        S[k + 3][row] = r[j].w;
+        float* d = S + ((tid >> 3) + 32 * j) * LDK + 4 * (tid & 7);
+        d[0] = r[j].x;
+        d[1] = r[j].y;
+        d[2] = r[j].z;
+        d[3] = r[j].w;
       } else {
-        *(float4*)&S[(tid >> 5) + 8 * j][4 * (tid & 31)] = r[j];
+        *(float4*)(S + ((tid >> 5) + 8 * j) * LD + 4 * (tid & 31)) = r[j];
       }
     }
+  };
+  // element (row, k) of an operand image
+  auto at = [&](auto kc, const float* S, int row, int k) -> float {
+    constexpr bool KC = decltype(kc)::value;
+    return KC ? S[row * LDK + k] : S[k * LD + row];
   };
   using KA = std::integral_constant<bool, KC_A>;
   using KB = std::integral_constant<bool, KC_B>;
@@ -248,10 +258,10 @@ __global__ __launch_bounds__(256) void gemm_mfma_f32_v2_kernel(GemmArgs g) {
     }
 #pragma unroll
     for (int kk = 0; kk < BK; kk += 2) {
-      const float a0 = As[cur][kk + kl][wm * 64 + il];
-      const float a1 = As[cur][kk + kl][wm * 64 + 32 + il];
-      const float b0 = Bs[cur][kk + kl][wn * 64 + il];
-      const float b1 = Bs[cur][kk + kl][wn * 64 + 32 + il];
+      const float a0 = at(KA{}, As[cur], wm * 64 + il, kk + kl);
+      const float a1 = at(KA{}, As[cur], wm * 64 + 32 + il, kk + kl);
+      const float b0 = at(KB{}, Bs[cur], wn * 64 + il, kk + kl);
+      const float b1 = at(KB{}, Bs[cur], wn * 64 + 32 + il, kk + kl);
       acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
       acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
       acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
@@ -446,6 +456,131 @@ __global__ __launch_bounds__(256) void gemm_mfma_f64_128_kernel(GemmArgs g) {
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  // f64 C/D layout: col = lane & 15, row = (lane >> 4) + 4 * r
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int64_t n = n0 + wn * 64 + j * 16 + (lane & 15);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int64_t m = m0 + wm * 64 + i * 16 + (lane >> 4) + 4 * r;
+        if (m < g.M && n < g.N) {
+          double v = g.alpha * acc[i][j][r];
+          if (g.beta != 0.0) v += g.beta * C[m * g.ldc + n];
+          C[m * g.ldc + n] = v;
+        }
+      }
+    }
+}
+
+// f64 fast path (round 2).  The 128 x 128 x 32 kernel above compiles to 512 registers (32 separate 64-bit load
+// pointers, 512 accumulator <-> VGPR moves, a spill): one wave per SIMD, 42 of 78.6 TFLOP/s with the board at 810 W
+// and the full 2.4 GHz -- kernel-bound, not power-bound (profiles/r02_power_f32_f64.jsonl).  Same structure as the
+// f32 v2 kernel: BK = 16, 16-byte loads along each operand's contiguous direction from ONE base pointer per
+// operand, two LDS stages, one barrier per K-tile; images [k][row] (pitch 144 doubles) for row-contiguous and
+// [row][k] (pitch 17) for K-contiguous operands, both conflict-free for the 16-row x 4-k fragment reads.
+template <bool KC_A, bool KC_B>
+__global__ __launch_bounds__(256, 2) void gemm_mfma_f64_v2_kernel(GemmArgs g) {
+  constexpr int BM = 128, BN = 128, BK = 16, LD = 144, LDK = 17;
+  constexpr int IMG = (BK * LD > BM * LDK) ? BK * LD : BM * LDK;
+  __shared__ __attribute__((aligned(16))) double As[2][IMG];
+  __shared__ __attribute__((aligned(16))) double Bs[2][IMG];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wid = tid >> 6;
+  const int wm = wid >> 1, wn = wid & 1;
+  const int64_t m0 = (int64_t)blockIdx.y * BM, n0 = (int64_t)blockIdx.x * BN;
+  const double* A = (const double*)g.A + (int64_t)blockIdx.z * g.sA;
+  const double* B = (const double*)g.B + (int64_t)blockIdx.z * g.sB;
+  double* C = (double*)g.C + (int64_t)blockIdx.z * g.sC;
+  const int64_t lda = KC_A ? g.rsA : g.csA, ldb = KC_B ? g.csB : g.rsB;
+  typedef double d2 __attribute__((ext_vector_type(2)));
+
+  d2 ra[4], rb[4];
+  // one operand tile = 128 rows x 16 k = 1024 double2, four per thread
+  auto load_op = [&](auto kc, d2 (&r)[4], const double* P, int64_t ld, int64_t row0, int64_t rows, int64_t k0) {
+    constexpr bool KC = decltype(kc)::value;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      d2 v = {0.0, 0.0};
+      if constexpr (KC) {
+        int64_t row = row0 + (tid >> 3) + 32 * j;
+        if (row >= rows) row = rows - 1;
+        const int64_t k = k0 + 2 * (tid & 7);
+        const double* p = P + row * ld + k;
+        if (k + 1 < g.K) v = *(const d2*)p;
+        else if (k < g.K) v[0] = p[0];
+      } else {
+        const int64_t k = k0 + (tid >> 6) + 4 * j;
+        const int64_t row = row0 + 2 * (tid & 63);
+        if (k < g.K) {
+          const double* p = P + k * ld + row;
+          if (row + 1 < rows) v = *(const d2*)p;
+          else if (row < rows) v[0] = p[0];
+        }
+      }
+      r[j] = v;
+    }
+  };
+  auto store_op = [&](auto kc, const d2 (&r)[4], double* S) {
+    constexpr bool KC = decltype(kc)::value;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if constexpr (KC) {
+        double* d = S + ((tid >> 3) + 32 * j) * LDK + 2 * (tid & 7);
+        d[0] = r[j][0];
+        d[1] = r[j][1];
+      } else {
+        *(d2*)(S + ((tid >> 6) + 4 * j) * LD + 2 * (tid & 63)) = r[j];
+      }
+    }
+  };
+  auto at = [&](auto kc, const double* S, int row, int k) -> double {
+    constexpr bool KC = decltype(kc)::value;
+    return KC ? S[row * LDK + k] : S[k * LD + row];
+  };
+  using KA = std::integral_constant<bool, KC_A>;
+  using KB = std::integral_constant<bool, KC_B>;
+
+  f64x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.0;
+
+  const int64_t nt = (g.K + BK - 1) / BK;
+  load_op(KA{}, ra, A, lda, m0, g.M, 0);
+  load_op(KB{}, rb, B, ldb, n0, g.N, 0);
+  store_op(KA{}, ra, As[0]);
+  store_op(KB{}, rb, Bs[0]);
+  __syncthreads();
+  const int kl = lane >> 4, il = lane & 15;
+  for (int64_t t = 0; t < nt; ++t) {
+    const int cur = (int)(t & 1);
+    if (t + 1 < nt) {
+      load_op(KA{}, ra, A, lda, m0, g.M, (t + 1) * BK);
+      load_op(KB{}, rb, B, ldb, n0, g.N, (t + 1) * BK);
+    }
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 4) {
+      double a[4], b[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a[i] = at(KA{}, As[cur], wm * 64 + i * 16 + il, kk + kl);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) b[j] = at(KB{}, Bs[cur], wn * 64 + j * 16 + il, kk + kl);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    if (t + 1 < nt) {
+      store_op(KA{}, ra, As[cur ^ 1]);
+      store_op(KB{}, rb, Bs[cur ^ 1]);
     }
     __syncthreads();
   }
@@ -975,6 +1110,25 @@ int tnh_gemm_ex(int in_dtype, int out_dtype, int transA, int transB, int64_t M, 
   if (in_dtype == TNH_F64 && M >= 128 && N >= 128 && ((M + 127) / 128) * ((N + 127) / 128) * batch >= 128 &&
       g_variant != 1) {
     // enough 128x128 tiles to occupy the chip: the wider tile halves the LDS reads per MFMA
+    {
+      const bool kc_a = (g.csA == 1), kc_b = (g.rsB == 1);
+      const int64_t lda_ = kc_a ? g.rsA : g.csA, ldb_ = kc_b ? g.csB : g.rsB;
+      const bool ok = f32_v2_enabled() && (kc_a || g.rsA == 1) && (kc_b || g.csB == 1) && lda_ % 2 == 0 && ldb_ % 2 == 0 &&
+                      ((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0 && strideA % 2 == 0 && strideB % 2 == 0;
+      if (ok) {
+        g_last_kernel = "mfma_f64_128x128x16_v2";
+        return launch_batched(
+            [&](const GemmArgs&, int64_t b0, dim3 grid) -> int {
+              GemmArgs h = shifted(b0);
+              if (kc_a && kc_b) hipLaunchKernelGGL((gemm_mfma_f64_v2_kernel<true, true>), grid, dim3(256), 0, stream(), h);
+              else if (kc_a) hipLaunchKernelGGL((gemm_mfma_f64_v2_kernel<true, false>), grid, dim3(256), 0, stream(), h);
+              else if (kc_b) hipLaunchKernelGGL((gemm_mfma_f64_v2_kernel<false, true>), grid, dim3(256), 0, stream(), h);
+              else hipLaunchKernelGGL((gemm_mfma_f64_v2_kernel<false, false>), grid, dim3(256), 0, stream(), h);
+              return 0;
+            },
+            g, batch, 128, 128);
+      }
+    }
     g_last_kernel = "mfma_f64_128x128x32";
     return launch_batched(
         [&](const GemmArgs&, int64_t b0, dim3 grid) -> int {

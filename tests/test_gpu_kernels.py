@@ -367,10 +367,10 @@ def test_tensordot_random_axes_property(hip, dtype):
 def test_gemm_f64_128_tile(hip, ta_, tb_):
   """f64 products with >= 128 tiles of 128x128 take the wider MFMA kernel; ragged edges, every layout."""
   out, ref, kernel, sk = _gemm_case(hip, np.float64, 1500, 1400, 203, ta_, tb_, rng=np.random.default_rng(3))
-  assert kernel == "mfma_f64_128x128x32", kernel
+  assert kernel.startswith("mfma_f64_128x128"), kernel    # x32 (odd leading dimension) or x16_v2 (16-byte loads)
   np.testing.assert_allclose(out, ref, rtol=1e-14 * sk, atol=1e-14 * 203)
   out, ref, kernel, sk = _gemm_case(hip, np.complex128, 1400, 800, 160, ta_, tb_, rng=np.random.default_rng(4))
-  assert kernel == "mfma_f64_128x128x32", kernel     # complex128 rides the same kernel (real expansion)
+  assert kernel.startswith("mfma_f64_128x128"), kernel    # complex128 rides the same kernels (real expansion)
   np.testing.assert_allclose(out, ref, rtol=1e-14 * sk * 4, atol=1e-14 * 160 * 2)
 
 
@@ -911,3 +911,14 @@ def test_gemm_f32_v2_batched_and_unaligned_fallback(hip):
   out = np.asarray(hip.tensordot(dev(hip, x), dev(hip, y), 1))
   assert hip.lib.tnh_gemm_last_kernel().decode() == "mfma_f32_128x128x16"
   np.testing.assert_allclose(out, x.astype(np.float64) @ y.astype(np.float64), rtol=1e-5, atol=1e-4)
+
+
+@pytest.mark.parametrize("ta_,tb_", [(0, 0), (0, 1), (1, 0), (1, 1)])
+@pytest.mark.parametrize("m,n,k", [(1536, 1664, 200), (1410, 1538, 66), (2048, 1024, 16)])
+def test_gemm_f64_v2_vector_path(hip, ta_, tb_, m, n, k):
+  """f64 fast path (>= 128 tiles of 128 x 128; 16-byte loads, BK = 16, two LDS stages): all four storage forms,
+  ragged M / N edges and a K tail, against NumPy's float64 product."""
+  out, ref, kernel, sk = _gemm_case(hip, np.float64, m, n, k, ta_, tb_, rng=np.random.default_rng(m + n + k + ta_ + 2 * tb_))
+  assert kernel == "mfma_f64_128x128x16_v2", kernel
+  tol = GEMM_TOL[np.float64]
+  np.testing.assert_allclose(out, ref, rtol=tol * sk * 4, atol=tol * sk * np.sqrt(k) * 4)
