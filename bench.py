@@ -126,6 +126,22 @@ class TorchComm:
     self._dist.destroy_process_group()
 
 
+def make_rccl_comm(tcomm, be, rank, world):
+  """K8 communicator, with a coordinated way out: if ANY rank cannot create it (no librccl, id exchange
+  failed, ncclCommInitRank error) every rank re-executes this script with --comm torch, so the job still
+  reports a number -- and says which communicator produced it (config.communicator)."""
+  try:
+    return tcomm.RcclComm(be, rank=rank, world=world)   # raises on every rank if it fails on any
+  except Exception as exc:  # pylint: disable=broad-except
+    why = f"{type(exc).__name__}: {exc}"
+  if rank == 0:
+    print(f"[bench] RCCL communicator unavailable ({why}); re-running with --comm torch", file=sys.stderr, flush=True)
+  if os.environ.get("TNH_BENCH_NO_REEXEC"):
+    raise RuntimeError("RCCL communicator unavailable and TNH_BENCH_NO_REEXEC is set")
+  os.environ["TNH_BENCH_NO_REEXEC"] = "1"
+  os.execv(sys.executable, [sys.executable] + sys.argv + ["--comm", "torch"])
+
+
 def sync_all(be, comm):
   be.synchronize()
   if comm is not None:
@@ -652,7 +668,7 @@ def main():
   be.lib  # pylint: disable=pointless-statement
   if use_dist and args.comm == "rccl":
     from tensornetwork_amd import comm as tcomm  # pylint: disable=import-outside-toplevel
-    comm = tcomm.RcclComm(be, rank=rank, world=world)
+    comm = make_rccl_comm(tcomm, be, rank, world)
     comm_name = "libtnhip K8 (tnh_allreduce / tnh_allgather over RCCL), TCP rendezvous for the id"
   elif comm is not None:
     comm.bind()

@@ -136,15 +136,41 @@ class RcclComm:
     self._be = backend
     self._lib = backend.lib
     self._rdv = rendezvous if rendezvous is not None else HostRendezvous(self.rank, self.world)
-    ident = None
-    if self.rank == 0:
-      buf = ctypes.create_string_buffer(128)
-      _lib.check(self._lib.tnh_comm_unique_id(buf), "tnh_comm_unique_id")
-      ident = base64.b64encode(buf.raw).decode()
-    ident = self._rdv.broadcast(ident, root=0)
-    raw = ctypes.create_string_buffer(base64.b64decode(ident), 128)
-    _lib.check(self._lib.tnh_comm_init(raw, self.rank, self.world), "tnh_comm_init")
+    try:
+      self._bootstrap()
+    except Exception:
+      if rendezvous is None:
+        self._rdv.close()
+      raise
     self._scalar = None
+
+  def _bootstrap(self):
+    # Lock-step bootstrap: every rank takes part in both exchanges whatever happened locally, so a failure
+    # on one rank (no librccl, ncclCommInitRank error) raises on EVERY rank instead of leaving the others
+    # waiting -- the caller can then agree on a fall-back.
+    ident, err = None, None
+    if self.rank == 0:
+      try:
+        buf = ctypes.create_string_buffer(128)
+        _lib.check(self._lib.tnh_comm_unique_id(buf), "tnh_comm_unique_id")
+        ident = base64.b64encode(buf.raw).decode()
+      except Exception as exc:  # pylint: disable=broad-except
+        err = f"{type(exc).__name__}: {exc}"
+    first = self._rdv.all_gather({"id": ident, "err": err})[0]
+    if first["err"]:
+      raise RuntimeError(f"RCCL id could not be created on rank 0: {first['err']}")
+    err = None
+    try:
+      raw = ctypes.create_string_buffer(base64.b64decode(first["id"]), 128)
+      _lib.check(self._lib.tnh_comm_init(raw, self.rank, self.world), "tnh_comm_init")
+    except Exception as exc:  # pylint: disable=broad-except
+      err = f"{type(exc).__name__}: {exc}"
+    states = self._rdv.all_gather(err)
+    failed = {r: e for r, e in enumerate(states) if e}
+    if failed:
+      if err is None:
+        self._lib.tnh_comm_destroy()
+      raise RuntimeError(f"tnh_comm_init failed on rank(s) {sorted(failed)}: {next(iter(failed.values()))}")
 
   # -- host-side metadata ------------------------------------------------------------------
   def all_gather_counts(self, n):

@@ -218,3 +218,38 @@ def test_host_rendezvous_three_processes(tmp_path):
       rec = json.load(f)
     assert rec["b"] == "id-from-root"
     assert rec["got"] == [{"rank": k, "n": 10 * k} for k in range(3)]
+
+
+def _rccl_bootstrap_worker(rank, world, port, out_path):
+  sys.path.insert(0, os.path.dirname(HERE))
+  from tensornetwork_amd import _lib, comm
+
+  class _NoGpuBackend:      # libtnhip loads on a CPU-only host; tnh_comm_init then fails ("not initialised")
+    lib = _lib.load_library()
+
+  rdv = comm.HostRendezvous(rank, world, addr="127.0.0.1", port=port, timeout=60)
+  try:
+    comm.RcclComm(_NoGpuBackend(), rank=rank, world=world, rendezvous=rdv)
+    outcome = "created"
+  except RuntimeError as exc:
+    outcome = f"RuntimeError: {exc}"
+  rdv.barrier()             # the rendezvous is still in step on every rank after the failure
+  rdv.close()
+  with open(out_path + f".{rank}.txt", "w") as f:
+    f.write(outcome)
+
+
+def test_rccl_bootstrap_failure_raises_on_every_rank(tmp_path):
+  """No GPU here, so the communicator cannot come up: every rank must get the error (none may be left
+  waiting in an exchange) -- bench.py relies on that to fall back to --comm torch in step."""
+  import torch.multiprocessing as mp
+  with socket.socket() as s:
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+  out_path = str(tmp_path / "boot")
+  mp.spawn(_rccl_bootstrap_worker, args=(2, port, out_path), nprocs=2, join=True)
+  for r in range(2):
+    with open(out_path + f".{r}.txt") as f:
+      outcome = f.read()
+    assert outcome.startswith("RuntimeError"), outcome
+    assert "rank" in outcome
