@@ -900,6 +900,7 @@ int tnh_gemm_set_variant(const char* full) {
   else if (!strcmp(name, "bf16_ragged_256x64")) g_variant = 9;
   else if (!strcmp(name, "bf16_ragged_192x128")) g_variant = 10;
   else if (!strcmp(name, "bf16_ragged_128x192")) g_variant = 11;
+  else if (!strcmp(name, "bf16_stream")) g_variant = 12;
   else {
     set_error("unknown gemm variant '%s'", name);
     return TNH_ERR_INVALID;

@@ -960,6 +960,11 @@ int gemm_bf16_ragged(int in_dt, int out_dt, int shape, int64_t M, int64_t N, int
                      int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int64_t batch,
                      int64_t sA, int64_t sB, int64_t sC, const char** name);
 
+// small x very long products (tnh_gemm_stream.hip)
+bool gemm_bf16_stream_wanted(int out_dt, int64_t M, int64_t N, int64_t K, int64_t batch);
+int gemm_bf16_stream(int in_dt, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* B,
+                     int64_t ldb, void* C, int64_t ldc, const char** name);
+
 int gemm_bf16_fast(int in_dt, int out_dt, int variant, int transA, int transB, int64_t M, int64_t N,
                    int64_t K, const void* A, int64_t lda, const void* B, int64_t ldb, void* C,
                    int64_t ldc, int64_t batch, int64_t sA, int64_t sB, int64_t sC, const char** name) {
@@ -967,9 +972,23 @@ int gemm_bf16_fast(int in_dt, int out_dt, int variant, int transA, int transB, i
     set_error("bf16 matrix-core path needs the NT layout (both operands K-contiguous)");
     return TNH_ERR_UNSUPPORTED;
   }
-  const bool dma_ok = K % 64 == 0 && lda % 8 == 0 && ldb % 8 == 0 && ldc % 4 == 0 &&
-                      ((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0 && ((uintptr_t)C % 16) == 0 &&
-                      sA % 8 == 0 && sB % 8 == 0 && sC % 4 == 0 && M >= 16 && N >= 16;
+  if (variant == 12) {   // "bf16_stream" forced (tests, A/B)
+    if (batch != 1 || out_dt == TNH_F32 || K > 192 || (M > 192 && N > 192)) {
+      set_error("bf16_stream needs batch 1, half output, K <= 192 and one side <= 192");
+      return TNH_ERR_UNSUPPORTED;
+    }
+    return gemm_bf16_stream(in_dt, M, N, K, A, lda, B, ldb, C, ldc, name);
+  }
+  if (variant == 0 && gemm_bf16_stream_wanted(out_dt, M, N, K, batch)) {
+    const int rc = gemm_bf16_stream(in_dt, M, N, K, A, lda, B, ldb, C, ldc, name);
+    if (rc != TNH_ERR_UNSUPPORTED) return rc;   // odd alignment: the tile kernels below
+  }
+  bool dma_ok = K % 64 == 0 && lda % 8 == 0 && ldb % 8 == 0 && ldc % 4 == 0 &&
+                ((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0 && ((uintptr_t)C % 16) == 0 &&
+                sA % 8 == 0 && sB % 8 == 0 && sC % 4 == 0 && M >= 16 && N >= 16;
+  // a short side of <= 64 against a very long one, K <= 192: the 64 x 256 / 256 x 64 small-K tile kernel streams it
+  // better than 128 x 128 LDS-DMA tiles that are half padding (64 x 4e6 x 64: 0.20 vs 0.29 ms)
+  if (variant == 0 && K <= 192 && (M < N ? M : N) <= 64 && (M < N ? N : M) >= (int64_t(1) << 16)) dma_ok = false;
   if (variant >= 6 || !dma_ok) {
     if (variant >= 3 && variant <= 5) {
       set_error("LDS-DMA bf16 kernels need K%%64==0 and 16-B aligned rows");

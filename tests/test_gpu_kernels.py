@@ -255,6 +255,60 @@ def test_gemm_bf16_ragged_auto_dispatch_and_batch(hip):
   np.testing.assert_allclose(np.asarray(c), np.einsum("bmk,bnk->bmn", A, B), rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize("dtype", [ta.bfloat16, np.float16])
+def test_gemm_stream_small_times_long(hip, dtype):
+  """Small x very long NT products take the streaming kernel (small operand resident in LDS, long operand
+  prefetched through registers) in both orientations; same MFMA sequence as the ragged tile kernel, so the
+  two agree bit for bit.  Ragged long side (remainder through the tile kernel), K tails (8, 16, 56, 104 ->
+  zero-filled k-steps); shapes that break the 16-byte rules (K = 7, K = 100 with N odd) take the tile kernels."""
+  for (m, n, k) in [(144, 70000, 144), (70000, 144, 144), (16, 65536, 8), (192, 66008, 192), (66001, 192, 192),
+                    (72, 65544, 104), (65543, 80, 16), (144, 65600, 56), (65600, 32, 8), (65600, 33, 7), (50, 65543, 100),
+                    (100, 66001, 64), (176, 65536, 128)]:
+    rng = np.random.default_rng(m + n + k)
+    out, ref, kernel, _ = _gemm_case(hip, dtype, m, n, k, 0, 1, rng=rng)
+    # 16-byte rules (K % 8, ldc = n % 8) and the size gate (short side 65 .. 192, K >= 16); the rest: tile kernels
+    streamed = (k % 8 == 0 and n % 8 == 0 and k >= 16 and 64 < min(m, n) <= 192)
+    assert kernel.startswith("bf16_nt_stream") == streamed, (kernel, m, n, k)
+    rng = np.random.default_rng(m + n + k)
+    tiled, _, kernel2, _ = _gemm_case(hip, dtype, m, n, k, 0, 1, variant="bf16_ragged_128x128", rng=rng)
+    assert kernel2.startswith("bf16_nt_ragged"), kernel2
+    np.testing.assert_array_equal(out, tiled, err_msg=f"{kernel} vs {kernel2} {m}x{n}x{k}")
+    tol = GEMM_TOL[dtype]
+    np.testing.assert_allclose(out, ref, rtol=tol, atol=tol * np.sqrt(k), err_msg=f"{kernel} {m}x{n}x{k}")
+
+
+def test_gemm_stream_padded_ldc_and_forced_variant(hip):
+  """C rows padded (ldc > N) in both orientations: the padding stays untouched; the forced variant refuses
+  shapes outside its range."""
+  import ctypes
+  rng = np.random.default_rng(21)
+  for (m, n, k, ldc) in [(70000, 104, 40, 112), (100, 70001, 40, 70008)]:
+    A = orc.round_bf16(rng.standard_normal((m, k)))
+    B = orc.round_bf16(rng.standard_normal((n, k)))
+    c = hip.to_bfloat16(np.full((m, ldc), 7.0, dtype=np.float32))
+    _lib.check(hip.lib.tnh_gemm(_lib.BF16, _lib.BF16, 0, 1, m, n, k, ctypes.c_void_p(hip.to_bfloat16(A).ptr), k,
+                                ctypes.c_void_p(hip.to_bfloat16(B).ptr), k, ctypes.c_void_p(c.ptr), ldc, 1, 0, 0, 0))
+    assert hip.lib.tnh_gemm_last_kernel().decode().startswith("bf16_nt_stream")
+    got = np.asarray(c)
+    np.testing.assert_allclose(got[:, :n], A @ B.T, rtol=1.6e-2, atol=1.6e-2 * 7)
+    np.testing.assert_array_equal(got[:, n:], 7.0)
+  _lib.check(hip.lib.tnh_gemm_set_variant(b"bf16_stream"))
+  try:
+    a = hip.to_bfloat16(rng.standard_normal((300, 64)))
+    b = hip.to_bfloat16(rng.standard_normal((400, 64)))
+    c = hip.to_bfloat16(np.zeros((300, 400), dtype=np.float32))
+    st = hip.lib.tnh_gemm(_lib.BF16, _lib.BF16, 0, 1, 300, 400, 64, ctypes.c_void_p(a.ptr), 64, ctypes.c_void_p(b.ptr), 64,
+                          ctypes.c_void_p(c.ptr), 400, 1, 0, 0, 0)
+    assert st == _lib.ERR_UNSUPPORTED, st          # both sides > 192
+    a = hip.to_bfloat16(rng.standard_normal((100, 64)))
+    out = hip.tensordot(a, b, [[1], [1]])          # forced on a short product: still correct
+    assert hip.lib.tnh_gemm_last_kernel().decode().startswith("bf16_nt_stream")
+    np.testing.assert_allclose(np.asarray(out), np.asarray(a).astype(np.float64) @ np.asarray(b).astype(np.float64).T,
+                               rtol=1.6e-2, atol=1.6e-2 * 8)
+  finally:
+    _lib.check(hip.lib.tnh_gemm_set_variant(b"auto"))
+
+
 def test_gemm_bf16_ragged_padded_ldc(hip):
   """C rows padded to ldc > N (N % 8 != 0, ldc % 8 == 0): LDS-staged epilogue with a partial last chunk;
   the padding columns must stay untouched."""

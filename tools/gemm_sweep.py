@@ -68,11 +68,24 @@ def main():
   ap.add_argument("--gemm-only", action="store_true")
   ap.add_argument("--skinny", action="store_true",
                   help="ragged / skinny NT shapes of the D=12 sliced network: generic vs ragged matrix-core kernel")
+  ap.add_argument("--stream", action="store_true",
+                  help="small x very long NT products: streaming kernel (auto) vs the ragged tile kernels")
   ap.add_argument("--variants", default="bf16_128,bf16_256,bf16_256pp")
   args = ap.parse_args()
   global VARIANTS
   VARIANTS = args.variants.split(',')
   be = ta.get_hip_backend()
+  if args.stream:
+    shapes = [(144, 2985984, 144), (2985984, 144, 144), (144, 248832, 144), (248832, 144, 144), (64, 4000000, 64),
+              (192, 2000000, 192), (2000000, 192, 192), (128, 2985984, 128), (2985984, 128, 128), (80, 3000000, 80),
+              (96, 3000000, 96), (112, 3000000, 112), (3000000, 96, 96), (160, 2000000, 160), (176, 2000000, 64),
+              (144, 2985984, 16), (144, 2985984, 64), (144, 2985984, 192), (169, 4826816, 168)]
+    for (m, n, k) in shapes:
+      for variant in ("bf16_ragged", "auto"):
+        rec = gemm_tflops(be, _lib.BF16, _lib.BF16, 0, 1, m, n, k, variant, "uniform", 5)
+        rec["gbps"] = 2.0 * (m * k + n * k + m * n) / rec["ms"] / 1e6
+        print(json.dumps(rec), flush=True)
+    return
   if args.skinny:
     shapes = [(144, 2985984, 144), (2985984, 144, 144), (144, 248832, 1728), (248832, 144, 1728),
               (1728, 248832, 12), (248832, 1728, 12), (144, 248832, 144), (248832, 144, 144),
