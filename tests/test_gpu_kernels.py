@@ -47,6 +47,10 @@ def test_permute_all_perms_rank4(hip, dtype):
     # full 64 x 128 tiles with 16-byte aligned rows: the 2-byte vector kernel (permute_tiled16)
     ((128, 256), (1, 0)), ((64, 128), (1, 0)), ((256, 4, 128), (2, 1, 0)), ((3, 64, 2, 128), (0, 3, 2, 1)),
     ((128, 3, 64), (2, 1, 0)),  # odd batch stride -> falls back to the scalar tiled kernel
+    # brick kernel, 16-byte vectors on both sides (runs of 144 / 1728 elements), on one side only, and not at all
+    ((12, 12, 12, 12, 1, 12, 12, 12), (0, 3, 4, 5, 1, 6, 7, 2)), ((12,) * 6, (2, 1, 3, 4, 5, 0)),
+    ((12,) * 6, (0, 1, 3, 5, 4, 2)), ((8,) * 7, (0, 4, 5, 1, 2, 6, 3)), ((6, 10, 12, 8, 12), (0, 3, 4, 1, 2)),
+    ((5, 9, 12, 7, 12), (0, 3, 4, 1, 2)), ((16, 24, 8, 40), (2, 0, 3, 1)), ((10, 12, 14, 16), (3, 1, 0, 2)),
 ])
 @pytest.mark.parametrize("dtype", [np.float32, np.uint16, np.complex128])
 def test_permute_tiled_and_gather_paths(hip, shape, perm, dtype):
