@@ -224,6 +224,8 @@ struct BrickParams {
   int sdim[TNH_MAX_RANK];       // brick dims, source-fastest first
   int ddim[TNH_MAX_RANK];       // brick dims, destination-fastest first
   int jstr[TNH_MAX_RANK];       // destination-order stride (inside the brick) of sdim[q]
+  int sext[TNH_MAX_RANK];       // ext[sdim[q]]
+  uint32_t smagic[TNH_MAX_RANK];  // ceil(2^32 / sext[q]) (exact quotients for indices < V <= 2^15)
   int V, runA, runB;            // brick volume; contiguous run length in source / destination
   uint32_t magicA, magicB;      // ceil(2^32 / run)
   int pr_shift;                 // log2 of the padding period in bytes, < 0: no padding
@@ -250,19 +252,8 @@ __global__ __launch_bounds__(256) void permute_brick_kernel(T* __restrict__ dst,
   const int nrunA = V / p.runA, nrunB = V / p.runB;
   int64_t* offS = (int64_t*)smem;                 // [nrunA]
   int64_t* offD = offS + nrunA;                   // [nrunB]
-  uint16_t* posD = (uint16_t*)(smem + (((size_t)(nrunA + nrunB) * 8 + 15) & ~size_t(15)));     // [V], 16-B aligned
-  T* data = (T*)((unsigned char*)posD + (((size_t)V * 2 + 15) & ~size_t(15)));
+  T* data = (T*)(smem + (((size_t)(nrunA + nrunB) * 8 + 15) & ~size_t(15)));
   const int tid = threadIdx.x;
-  for (int i = tid; i < V; i += 256) {
-    int rem = i, j = 0;
-    for (int q = 0; q < p.nb; ++q) {
-      const int e = (int)p.ext[p.sdim[q]];
-      const int c = rem % e;
-      rem /= e;
-      j += c * p.jstr[q];
-    }
-    posD[i] = (uint16_t)brick_pad<T>(j, p.pr_shift);
-  }
   for (int k = tid; k < nrunA; k += 256) {
     int rem = k * p.runA;
     int64_t off = 0;
@@ -286,6 +277,23 @@ __global__ __launch_bounds__(256) void permute_brick_kernel(T* __restrict__ dst,
     offD[k] = off;
   }
   __syncthreads();
+  // Destination-order position (inside the brick) of source-order element i, and its coordinate along the
+  // source-fastest brick dim: a few multiply-highs per VECTOR; the elements of a vector advance by jstr[0] and
+  // re-decode only when they wrap along that (fused, so long) dim.  Round 1 read every element's position from a
+  // V-entry LDS table: one more LDS read per element and as much LDS as the payload.  (A per-run table plus a
+  // carry chain inside the run was tried and is slower: the predicated carries cost more VALU than the decode.)
+  const int e0 = p.sext[0], j0 = p.jstr[0];
+  auto decode = [&](int i, int& c0) -> int {
+    int rem = i, j = 0;
+    for (int q = 0; q < p.nb; ++q) {
+      const int quo = (int)(((uint64_t)(uint32_t)rem * p.smagic[q]) >> 32);
+      const int c = rem - quo * p.sext[q];
+      if (q == 0) c0 = c;
+      j += c * p.jstr[q];
+      rem = quo;
+    }
+    return j;
+  };
   for (int64_t brick = blockIdx.x; brick < p.nbricks; brick += gridDim.x) {
     int64_t rem = brick, bs = 0, bd = 0;
     for (int d = p.nd - 1; d >= 0; --d) {
@@ -298,42 +306,31 @@ __global__ __launch_bounds__(256) void permute_brick_kernel(T* __restrict__ dst,
       const int run = (int)(((uint64_t)(uint32_t)i * p.magicA) >> 32);
       const int w = i - run * p.runA;
       const T* g = src + bs + offS[run] + w;
+      T v[RG];
       if constexpr (RG > 1 && RG * sizeof(T) == 16) {
-        const uint4 v = *(const uint4*)g;
-        if constexpr (sizeof(T) == 2) {
-          const uint4 pos = *(const uint4*)(posD + i);       // 8 positions
-          const uint32_t vw[4] = {v.x, v.y, v.z, v.w}, pw[4] = {pos.x, pos.y, pos.z, pos.w};
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            data[pw[e] & 0xffffu] = (T)(vw[e] & 0xffffu);
-            data[pw[e] >> 16] = (T)(vw[e] >> 16);
-          }
-        } else {
-          const uint2 pos = *(const uint2*)(posD + i);       // 4 positions
-          data[pos.x & 0xffffu] = (T)v.x;
-          data[pos.x >> 16] = (T)v.y;
-          data[pos.y & 0xffffu] = (T)v.z;
-          data[pos.y >> 16] = (T)v.w;
-        }
+        *(uint4*)v = *(const uint4*)g;
       } else if constexpr (RG > 1 && RG * sizeof(T) == 8) {
-        const uint2 v = *(const uint2*)g;
-        if constexpr (sizeof(T) == 2) {
-          const uint2 pos = *(const uint2*)(posD + i);       // 4 positions
-          data[pos.x & 0xffffu] = (T)(v.x & 0xffffu);
-          data[pos.x >> 16] = (T)(v.x >> 16);
-          data[pos.y & 0xffffu] = (T)(v.y & 0xffffu);
-          data[pos.y >> 16] = (T)(v.y >> 16);
-        } else {
-          const uint32_t pos = *(const uint32_t*)(posD + i);  // 2 positions
-          data[pos & 0xffffu] = (T)v.x;
-          data[pos >> 16] = (T)v.y;
-        }
+        *(uint2*)v = *(const uint2*)g;
       } else if constexpr (RG == 2) {
-        const uint32_t v = *(const uint32_t*)g;
-        data[posD[i]] = (T)(v & 0xffffu);
-        data[posD[i + 1]] = (T)(v >> 16);
+        *(uint32_t*)v = *(const uint32_t*)g;
       } else {
-        data[posD[i]] = *g;
+        v[0] = *g;
+      }
+      int c0;
+      int j = decode(i, c0);
+      if (c0 + RG <= e0) {                          // the whole vector lies along the source-fastest dim (the usual case)
+#pragma unroll
+        for (int e = 0; e < RG; ++e) data[brick_pad<T>(j + e * j0, p.pr_shift)] = v[e];
+      } else {
+#pragma unroll
+        for (int e = 0; e < RG; ++e) {
+          data[brick_pad<T>(j, p.pr_shift)] = v[e];
+          if (e + 1 < RG) {
+            ++c0;
+            j += j0;
+            if (c0 == e0) j = decode(i + e + 1, c0);   // wrapped: next index of the slower dims
+          }
+        }
       }
     }
     __syncthreads();
@@ -365,14 +362,19 @@ template <typename T>
 static int try_brick(void* dst, const void* src, int r, const int64_t* oshape, const int64_t* istride,
                      const int64_t* ostride, int64_t total) {
   constexpr int ISZ = (int)sizeof(T);
-  const int maxV = 16384 / ISZ;                      // 16 KiB of payload per brick
+  // payload per brick: 32 KiB; round 1: 16 KiB (the position table doubled the LDS)
+  static const int max_kb = []() { const char* e = getenv("TNH_BRICK_MAXKB"); return e ? atoi(e) : 32; }();
+  const int maxV = (max_kb * 1024 / ISZ) < 32768 ? (max_kb * 1024 / ISZ) : 32768;
   // (source run, destination run) targets in elements, best first; the first plan whose brick
   // fits in maxV wins (long source runs matter most: 256-element runs measured 3.7 TB/s vs 2.8)
-  static const int cand2[][2] = {{256, 128}, {128, 128}, {64, 128}, {64, 64}, {32, 64}, {32, 32}};
-  static const int cand4[][2] = {{128, 64}, {64, 64}, {32, 64}, {32, 32}, {16, 32}};
-  static const int cand8[][2] = {{64, 32}, {32, 32}, {16, 32}, {16, 16}};
+  // round 2 (computed positions, vector accesses, bricks up to 32 KiB): 512-element runs on both sides first --
+  // tools/brick_target_probe.sh: 12^8 (0,3,7,8,4,2,5,6,1) 0.58 -> 0.43 ms, 8^9 0.197 -> 0.134 ms; 1024 x 1024 is slower
+  // again (41 KiB bricks, one or two workgroups per CU)
+  static const int cand2[][2] = {{512, 512}, {512, 256}, {256, 256}, {256, 128}, {128, 128}, {64, 128}, {64, 64}, {32, 64}, {32, 32}};
+  static const int cand4[][2] = {{256, 256}, {256, 128}, {128, 64}, {64, 64}, {32, 64}, {32, 32}, {16, 32}};
+  static const int cand8[][2] = {{128, 128}, {64, 32}, {32, 32}, {16, 32}, {16, 16}};
   const int (*cand)[2] = ISZ == 2 ? cand2 : (ISZ == 4 ? cand4 : cand8);
-  int ncand = ISZ == 2 ? 6 : (ISZ == 4 ? 5 : 4);
+  int ncand = ISZ == 2 ? 9 : (ISZ == 4 ? 7 : 5);
   int envc[1][2];
   if (getenv("TNH_BRICK_TA") && getenv("TNH_BRICK_TB")) {   // tuning knobs (tools/permute_one.py)
     envc[0][0] = atoi(getenv("TNH_BRICK_TA"));
@@ -442,21 +444,28 @@ static int try_brick(void* dst, const void* src, int r, const int64_t* oshape, c
     dstr_of[p.ddim[q]] = acc;
     acc *= (int)p.ext[p.ddim[q]];
   }
-  for (int q = 0; q < p.nb; ++q) p.jstr[q] = dstr_of[p.sdim[q]];
+  for (int q = 0; q < p.nb; ++q) {
+    p.jstr[q] = dstr_of[p.sdim[q]];
+    p.sext[q] = (int)p.ext[p.sdim[q]];
+    p.smagic[q] = (uint32_t)((((uint64_t)1 << 32) + p.sext[q] - 1) / p.sext[q]);
+  }
   // contiguous runs: leading brick dims while they are whole and adjacent in memory
-  auto run_len = [&](const int* dims, const int64_t* str) -> int {
+  auto run_len = [&](const int* dims, const int64_t* str, int max_dims, int* ndims) -> int {
     int64_t run = 1, expect = 1;
-    for (int q = 0; q < p.nb; ++q) {
+    int n = 0;
+    for (int q = 0; q < p.nb && n < max_dims; ++q) {
       const int d = dims[q];
       if (str[d] != expect) break;
       run *= p.ext[d];
+      ++n;
       if (p.ext[d] != oshape[d]) break;   // a partial dim ends the run
       expect = str[d] * oshape[d];
     }
+    if (ndims) *ndims = n;
     return (int)run;
   };
-  p.runA = run_len(p.sdim, p.istr);
-  p.runB = run_len(p.ddim, p.ostr);
+  p.runA = run_len(p.sdim, p.istr, TNH_MAX_RANK, nullptr);
+  p.runB = run_len(p.ddim, p.ostr, TNH_MAX_RANK, nullptr);
   if (p.runA < 1 || p.runB < 1 || p.V % p.runA || p.V % p.runB) return TNH_ERR_UNSUPPORTED;
   p.magicA = (uint32_t)((((uint64_t)1 << 32) + p.runA - 1) / p.runA);
   p.magicB = (uint32_t)((((uint64_t)1 << 32) + p.runB - 1) / p.runB);
@@ -470,9 +479,9 @@ static int try_brick(void* dst, const void* src, int r, const int64_t* oshape, c
     p.pr_shift = sh;
   }
   const size_t padV = (size_t)p.V + (p.pr_shift < 0 ? 0 : (((size_t)p.V * ISZ) >> p.pr_shift) * (ISZ == 2 ? 2 : 1)) + 8;
-  const size_t tables = (((size_t)(p.V / p.runA + p.V / p.runB) * 8 + 15) & ~size_t(15)) + (((size_t)p.V * 2 + 15) & ~size_t(15));
+  const size_t tables = (((size_t)(p.V / p.runA + p.V / p.runB) * 8 + 15) & ~size_t(15));
   const size_t smem = tables + padV * ISZ;
-  if (smem > 60 * 1024) return TNH_ERR_UNSUPPORTED;
+  if (smem > 64 * 1024) return TNH_ERR_UNSUPPORTED;
   int64_t grid = (int64_t)num_cus() * 16;
   if (const char* e = getenv("TNH_BRICK_GRID")) grid = (int64_t)num_cus() * atoi(e);
   if (grid > p.nbricks) grid = p.nbricks;
