@@ -240,12 +240,15 @@ __global__ __launch_bounds__(256) void bj_eig_kernel(const TG* __restrict__ Gp, 
 
 // Position-space variant (default).  Pair k always sits at positions (2k, 2k+1);
 // after every round the rows/columns move by the fixed circle-method permutation
-// bj_next_pos (period 63, so whole sweeps end where they started).  A 2x2 tile is
-// one float4 in LDS (one ds_read_b128), results are scattered to destinations that
-// are fixed per thread for the whole kernel (precomputed), and V (f64, pairs of
-// columns as one 16-byte item) moves the same way.  Per round and thread:
-// 1 + TPT + VPT 16-byte reads, 4 TPT + 2 VPT scattered writes, 2 TPT shuffles,
-// one barrier.
+// bj_next_pos (period 63, so whole sweeps end where they started).  G and V live in
+// LDS as component planes (see the kernel), results are scattered to destinations that
+// are fixed per thread for the whole kernel (precomputed).  Per round and thread:
+// 4 TPT + 2 VPT reads, 4 TPT + 2 VPT conflict-free scattered writes, the pair's rotation
+// from a 32-entry LDS table that wave 0 fills for the NEXT round while the others move V.
+// Measured with wall_clock64 inside the kernel (TNH_SVD_TRACE=1) at 4096^2: prologue
+// 2.2 us (was 12.4: dword loads of the S partial tiles), 32 rounds 22.6 us -- a
+// barrier / LDS-latency chain of ~0.7 us per round that neither 8 vs 16 waves, nor the
+// broadcast, nor taking V off wave 0 changes.
 __device__ __forceinline__ int bj_next_pos(int p) {
   if (p == 0) return 0;
   const int k = p >> 1;
@@ -253,18 +256,27 @@ __device__ __forceinline__ int bj_next_pos(int p) {
   return k >= 1 ? 2 * (k - 1) + 1 : 2;
 }
 
-template <int NT>
+template <int NT, bool BCAST>
 __global__ __launch_bounds__(NT) void bj_eig3_kernel(const float* __restrict__ Gp, int S,
                                                      float* __restrict__ Jout, int* __restrict__ pairflag,
                                                      int* __restrict__ flag, float tol, int max_inner,
                                                      int cross, int sort, int pair0) {
   constexpr int W = 64, NG = NT / 32, TPT = 32 / NG, VPT = 64 / NG;
-  __shared__ f32x4 T[2][32 * 32];        // tile (k, l): (G[2k][2l], G[2k][2l+1], G[2k+1][2l], G[2k+1][2l+1])
-  __shared__ double Vt[2][W * W];        // V[i][pos], row-major
+  // Component planes (round 2).  Element (p, q) of G lives in plane (p & 1) * 2 + (q & 1) at [(p >> 1) * 32 + (q >> 1)],
+  // V[i][pos] in plane (pos & 1) at [i * 32 + (pos >> 1)].  The scattered writes of a round move every element
+  // to the position its row / column takes next: consecutive lanes write consecutive words of ONE plane (no bank
+  // conflict).  Round 1 kept a 2 x 2 tile as one float4 and V row-major: one ds_read_b128 per tile, but the writes
+  // of a wave then sat 16 bytes apart -- 4-way bank conflicts on all eight scattered writes of a round, which
+  // (not the arithmetic, not the barrier) is what the 1.2 us per inner round were.
+  __shared__ float T[2][4 * 1024];
+  __shared__ double Vt[2][2 * W * 32];
   __shared__ int rotated;
+  __shared__ float2 cs32[2][32];         // BCAST: (c, s) of the 32 pairs of a round (by round parity), f32 for the tiles ...
+  __shared__ double2 cs64[2][32];        // ... and f64 (c^2 + s^2 = 1 to f64 accuracy) for V
   const int pair = pair0 + blockIdx.x, tid = threadIdx.x, lane = tid & 63;
   const float* gp = Gp + (int64_t)pair * S * 3072;
-  float* T0 = (float*)&T[0][0];
+  float* T0 = &T[0][0];
+  const long long ts0 = wall_clock64();
   // cross mode (only pairs with one row in each block are rotated, 32 rounds):
   // position 2k = row k of block I, position 2k+1 = a row of block J; the J side
   // shifts by one slot per round.  full mode: position == index, 63 rounds.
@@ -273,19 +285,44 @@ __global__ __launch_bounds__(NT) void bj_eig3_kernel(const float* __restrict__ G
     if (!cross) return bj_next_pos(p);
     return (p & 1) ? 2 * (((p >> 1) + 1) & 31) + 1 : p;
   };
-  for (int e = tid; e < W * W; e += NT) {
-    const int i = e >> 6, j = e & 63;
-    int t, idx;
-    if (i < 32 && j < 32) { t = 0; idx = i * 32 + j; }
-    else if (i < 32) { t = 1; idx = i * 32 + (j - 32); }
-    else if (j < 32) { t = 1; idx = j * 32 + (i - 32); }
-    else { t = 2; idx = (i - 32) * 32 + (j - 32); }
-    double acc = 0.0;
-    for (int s = 0; s < S; ++s) acc += (double)gp[(int64_t)s * 3072 + t * 1024 + idx];
-    const int pi = pos_of(i), pj = pos_of(j);
-    T0[((pi >> 1) * 32 + (pj >> 1)) * 4 + (pi & 1) * 2 + (pj & 1)] = (float)acc;
-    Vt[0][i * W + pj] = (i == j) ? 1.0 : 0.0;
+  // G = sum of the S partial tiles (f64, fixed order: deterministic), read as 16-byte rows of the II / IJ / JJ
+  // tiles (768 float4 groups, 8 loads each at 4096^2) -- the lower-left block of G is the mirror of IJ and is
+  // written from the same registers.  Round 1 read dword by dword, 32 dependent round trips per thread; measured
+  // with wall_clock64 the prologue was 12 of the kernel's 37 us.
+  for (int q = tid; q < 768; q += NT) {
+    const int t = q >> 8, row = (q & 255) >> 3, c4 = (q & 7) * 4;
+    const float* src = gp + t * 1024 + row * 32 + c4;
+    f32x4 part[16];
+#pragma unroll
+    for (int sI = 0; sI < 8; ++sI) part[sI] = *(const f32x4*)(src + (sI < S ? sI : S - 1) * 3072);
+    if (S > 8) {
+#pragma unroll
+      for (int sI = 8; sI < 16; ++sI) part[sI] = *(const f32x4*)(src + (sI < S ? sI : S - 1) * 3072);
+    }
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int sI = 0; sI < 16; ++sI) {
+      if (sI < S) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc[u] += (double)part[sI][u];
+      }
+    }
+    const int i = (t == 2 ? 32 : 0) + row;
+    const int pi = pos_of(i);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int j = (t == 0 ? 0 : 32) + c4 + u;
+      const int pj = pos_of(j);
+      const float v = (float)acc[u];
+      T0[((pi & 1) * 2 + (pj & 1)) * 1024 + (pi >> 1) * 32 + (pj >> 1)] = v;
+      if (t == 1) T0[((pj & 1) * 2 + (pi & 1)) * 1024 + (pj >> 1) * 32 + (pi >> 1)] = v;   // G[j][i]
+    }
   }
+  for (int e = tid; e < W * W; e += NT) {
+    const int i = e >> 6, pj = pos_of(e & 63);
+    Vt[0][(pj & 1) * 2048 + i * 32 + (pj >> 1)] = (i == (e & 63)) ? 1.0 : 0.0;
+  }
+  const long long tsA = wall_clock64();
   if (tid == 0) rotated = 0;
   const int l = tid & 31, g = tid >> 5;
   const int src_half = lane & 32;
@@ -296,63 +333,112 @@ __global__ __launch_bounds__(NT) void bj_eig3_kernel(const float* __restrict__ G
   for (int jj = 0; jj < TPT; ++jj) {
     const int k = g + NG * jj;
     const int nr0 = next_pos(2 * k), nr1 = next_pos(2 * k + 1);
-    dst[jj][0] = ((nr0 >> 1) * 32 + (nc0 >> 1)) * 4 + (nr0 & 1) * 2 + (nc0 & 1);
-    dst[jj][1] = ((nr0 >> 1) * 32 + (nc1 >> 1)) * 4 + (nr0 & 1) * 2 + (nc1 & 1);
-    dst[jj][2] = ((nr1 >> 1) * 32 + (nc0 >> 1)) * 4 + (nr1 & 1) * 2 + (nc0 & 1);
-    dst[jj][3] = ((nr1 >> 1) * 32 + (nc1 >> 1)) * 4 + (nr1 & 1) * 2 + (nc1 & 1);
+    dst[jj][0] = ((nr0 & 1) * 2 + (nc0 & 1)) * 1024 + (nr0 >> 1) * 32 + (nc0 >> 1);
+    dst[jj][1] = ((nr0 & 1) * 2 + (nc1 & 1)) * 1024 + (nr0 >> 1) * 32 + (nc1 >> 1);
+    dst[jj][2] = ((nr1 & 1) * 2 + (nc0 & 1)) * 1024 + (nr1 >> 1) * 32 + (nc0 >> 1);
+    dst[jj][3] = ((nr1 & 1) * 2 + (nc1 & 1)) * 1024 + (nr1 >> 1) * 32 + (nc1 >> 1);
   }
   const int nrounds = cross ? 32 : W - 1;
+  __syncthreads();
+  const long long ts1 = wall_clock64();
   int any = 0, cur = 0;
-  float thmax = 0.f;   // largest |g_pq| / sqrt(g_pp g_qq) met by this workgroup (convergence telemetry, flag[1])
+  float thmax2 = 0.f;  // largest g_pq^2 / (g_pp g_qq) met by this workgroup (convergence telemetry, flag[1] = its root)
+  // Rotation of pair l from its diagonal elements (c, s in f32 for the tiles, in f64 with c^2 + s^2 = 1 to f64
+  // accuracy for V).  Threshold and telemetry on squares: no square roots outside the rotation itself.
+  auto rotation = [&](const float* Tb, float& c32, float& s32, double& c64, double& s64, bool leader) {
+    const float gpp = Tb[l * 33], gpq = Tb[1024 + l * 33], gqq = Tb[3072 + l * 33];
+    float tf = 0.f;
+    const float dd = fabsf(gpp) * fabsf(gqq), qq = gpq * gpq;
+    if (leader && dd > 0.f) thmax2 = fmaxf(thmax2, qq * __builtin_amdgcn_rcpf(dd));
+    if (qq > tol * tol * dd) {
+      const float zeta = (gqq - gpp) * __builtin_amdgcn_rcpf(2.0f * gpq);
+      const float den = fabsf(zeta) + __builtin_amdgcn_sqrtf(1.0f + zeta * zeta);
+      tf = __builtin_amdgcn_rcpf(den);
+      tf = (zeta >= 0.f) ? tf : -tf;
+      if (!(fabsf(tf) <= 1.0f)) tf = 0.f;  // inf / nan guard
+      if (leader && tf != 0.f) rotated = 1;
+    }
+    c32 = __builtin_amdgcn_rsqf(1.0f + tf * tf);
+    s32 = c32 * tf;
+    const double t = (double)tf, x = 1.0 + t * t;
+    double y = (double)c32;          // 1 ulp of f32; one Newton step: c^2 + s^2 = 1 to 2^-46
+    y = y * (1.5 - 0.5 * x * y * y);
+    c64 = y;
+    s64 = y * t;
+  };
   for (int sweep = 0; sweep < max_inner; ++sweep) {
+    if constexpr (BCAST) {
+      // rotations of round 0 (later rounds: computed by wave 0 while the other waves update V, see below)
+      __syncthreads();
+      if (tid < 32) {
+        float c32, s32;
+        double c64, s64;
+        rotation(T[cur], c32, s32, c64, s64, true);
+        cs32[0][l] = make_float2(c32, s32);
+        cs64[0][l] = make_double2(c64, s64);
+      }
+    }
     for (int r = 0; r < nrounds; ++r) {
       __syncthreads();
-      const f32x4* Tc = T[cur];
-      float* Tn = (float*)T[cur ^ 1];
+      const float* Tc = T[cur];
+      float* Tn = T[cur ^ 1];
       const double* Vc = Vt[cur];
       double* Vn = Vt[cur ^ 1];
-      // rotation of pair l from its diagonal tile: f32 chain first (feeds the tiles)
-      const f32x4 d = Tc[l * 32 + l];
-      const float gpp = d[0], gpq = d[1], gqq = d[3];
-      float tf = 0.f;
-      const float gden = __builtin_amdgcn_sqrtf(fabsf(gpp)) * __builtin_amdgcn_sqrtf(fabsf(gqq));
-      if (g == 0 && gden > 0.f) thmax = fmaxf(thmax, fabsf(gpq) * __builtin_amdgcn_rcpf(gden));
-      if (fabsf(gpq) > tol * gden) {
-        const float zeta = (gqq - gpp) * __builtin_amdgcn_rcpf(2.0f * gpq);
-        const float den = fabsf(zeta) + __builtin_amdgcn_sqrtf(1.0f + zeta * zeta);
-        tf = __builtin_amdgcn_rcpf(den);
-        tf = (zeta >= 0.f) ? tf : -tf;
-        if (!(fabsf(tf) <= 1.0f)) tf = 0.f;  // inf / nan guard
-        if (g == 0 && tf != 0.f) rotated = 1;
+      float clf, slf;
+      double cl, sl;
+      if constexpr (BCAST) {
+        // ONE rotation per pair, broadcast through LDS (double-buffered by round parity).  Round 1 had every
+        // thread derive its own copy and fetch its row partner's by shuffle.
+        const float2 m = cs32[r & 1][l];
+        clf = m.x;
+        slf = m.y;
+      } else {
+        rotation(Tc, clf, slf, cl, sl, g == 0);
       }
-      const float clf = __builtin_amdgcn_rsqf(1.0f + tf * tf), slf = clf * tf;
 #pragma unroll
       for (int jj = 0; jj < TPT; ++jj) {
         const int k = g + NG * jj;
-        const float ck = __shfl(clf, k | src_half, 64), sk = __shfl(slf, k | src_half, 64);
-        const f32x4 t = Tc[k * 32 + l];
-        const float u00 = ck * t[0] - sk * t[2], u01 = ck * t[1] - sk * t[3];
-        const float u10 = sk * t[0] + ck * t[2], u11 = sk * t[1] + ck * t[3];
+        float ck, sk;
+        if constexpr (BCAST) {
+          const float2 mk = cs32[r & 1][k];
+          ck = mk.x;
+          sk = mk.y;
+        } else {
+          ck = __shfl(clf, k | src_half, 64);
+          sk = __shfl(slf, k | src_half, 64);
+        }
+        const float t0 = Tc[k * 32 + l], t1 = Tc[1024 + k * 32 + l], t2 = Tc[2048 + k * 32 + l], t3 = Tc[3072 + k * 32 + l];
+        const float u00 = ck * t0 - sk * t2, u01 = ck * t1 - sk * t3;
+        const float u10 = sk * t0 + ck * t2, u11 = sk * t1 + ck * t3;
         float v00 = clf * u00 - slf * u01, v01 = slf * u00 + clf * u01;
         float v10 = clf * u10 - slf * u11, v11 = slf * u10 + clf * u11;
-        if (k == l && tf != 0.f) v01 = v10 = 0.f;  // the annihilated element
+        if (k == l && slf != 0.f) v01 = v10 = 0.f;  // the annihilated element
         Tn[dst[jj][0]] = v00;
         Tn[dst[jj][1]] = v01;
         Tn[dst[jj][2]] = v10;
         Tn[dst[jj][3]] = v11;
       }
-      // (c, s) in f64 from t for V: c^2 + s^2 = 1 to f64 accuracy
-      const double t = (double)tf, x = 1.0 + t * t;
-      double y = (double)clf;
-      y = y * (1.5 - 0.5 * x * y * y);
-      y = y * (1.5 - 0.5 * x * y * y);
-      const double cl = y, sl = y * t;
+      if constexpr (BCAST) {
+        const double2 m64 = cs64[r & 1][l];
+        cl = m64.x;
+        sl = m64.y;
+        __syncthreads();            // the next tiles are complete
+        // wave 0 derives the NEXT round's rotations from them while everybody (wave 0 last) moves V: the
+        // dependent chain of reciprocal / square-root steps hides behind the f64 work of the other 15 waves
+        if (tid < 32 && r + 1 < nrounds) {
+          float c32, s32;
+          double c64, s64;
+          rotation(Tn, c32, s32, c64, s64, true);
+          cs32[(r + 1) & 1][l] = make_float2(c32, s32);
+          cs64[(r + 1) & 1][l] = make_double2(c64, s64);
+        }
+      }
 #pragma unroll
       for (int jj = 0; jj < VPT; ++jj) {
         const int i = g + NG * jj;
-        const double vp = Vc[i * W + 2 * l], vq = Vc[i * W + 2 * l + 1];
-        Vn[i * W + nc0] = cl * vp - sl * vq;
-        Vn[i * W + nc1] = sl * vp + cl * vq;
+        const double vp = Vc[i * 32 + l], vq = Vc[2048 + i * 32 + l];
+        Vn[(nc0 & 1) * 2048 + i * 32 + (nc0 >> 1)] = cl * vp - sl * vq;
+        Vn[(nc1 & 1) * 2048 + i * 32 + (nc1 >> 1)] = sl * vp + cl * vq;
       }
       cur ^= 1;
     }
@@ -364,6 +450,7 @@ __global__ __launch_bounds__(NT) void bj_eig3_kernel(const float* __restrict__ G
     if (tid == 0) rotated = 0;
   }
   __syncthreads();
+  const long long ts2 = wall_clock64();
   // whole sweeps = full periods of the permutation: positions are back where they started
   const double* Vf = Vt[cur];
   float* jo = Jout + (int64_t)pair * (W * W);
@@ -377,7 +464,7 @@ __global__ __launch_bounds__(NT) void bj_eig3_kernel(const float* __restrict__ G
     __syncthreads();
     if (tid < W) {
       const int pi = pos_of(tid);
-      dg[tid] = ((const float*)&T[cur][(pi >> 1) * 32 + (pi >> 1)])[(pi & 1) * 3];
+      dg[tid] = T[cur][(pi & 1) * 3 * 1024 + (pi >> 1) * 33];
     }
     __syncthreads();
     if (tid < W) {
@@ -394,9 +481,12 @@ __global__ __launch_bounds__(NT) void bj_eig3_kernel(const float* __restrict__ G
     if (tid < W) rank[tid] = tid;
   }
   __syncthreads();
-  for (int e = tid; e < W * W; e += NT) jo[(e >> 6) * W + rank[e & 63]] = (float)Vf[(e >> 6) * W + pos_of(e & 63)];
+  for (int e = tid; e < W * W; e += NT) {
+    const int pp = pos_of(e & 63);
+    jo[(e >> 6) * W + rank[e & 63]] = (float)Vf[(pp & 1) * 2048 + (e >> 6) * 32 + (pp >> 1)];
+  }
   if (tid < 64) {   // wave 0 holds the g == 0 lanes (tid < 32)
-    float m = thmax;
+    float m = __builtin_amdgcn_sqrtf(thmax2);
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
     if (tid == 0) atomicMax((unsigned int*)(flag + 1), __float_as_uint(m));
@@ -404,6 +494,10 @@ __global__ __launch_bounds__(NT) void bj_eig3_kernel(const float* __restrict__ G
   if (tid == 0) {
     pairflag[pair] = any;
     if (any) *flag = 1;
+    if (pair == 0) {   // timing probe (TNH_SVD_TRACE): 10 ns ticks of prologue / rounds / epilogue of pair 0
+      flag[2] = (int)(ts1 - ts0) | ((int)(tsA - ts0) << 16);
+      flag[3] = (int)(ts2 - ts1);
+    }
   }
 }
 
@@ -638,6 +732,8 @@ int svd_block_sweeps(T* X, T* R, int64_t P, int64_t Q, char* scratch, int* flag,
   const int sortv = envso ? atoi(envso) : 0;      // de Rijk row ordering inside every pair: A/B knob, off (see bj_eig3_kernel)
   const char* envn = getenv("TNH_SVD_EIGNT");
   const int eig_nt = envn ? atoi(envn) : 1024;   // workgroup size of the LDS eigensolver (A/B knob)
+  const char* envb = getenv("TNH_SVD_BCAST");
+  const bool bcast = !(envb && envb[0] == '0');   // rotations computed once per pair and broadcast through LDS (A/B knob)
   // Stop rule: a whole sweep that applies no rotation above `tol` (the last sweep only observes).
   // TNH_SVD_STOP=<theta> (A/B knob, default off) ends after a sweep whose largest normalised off-diagonal
   // theta = |g_pq| / sqrt(g_pp g_qq) is <= theta, betting on quadratic convergence.  Measured on MI355X
@@ -697,15 +793,13 @@ int svd_block_sweeps(T* X, T* R, int64_t P, int64_t Q, char* scratch, int* flag,
           hipLaunchKernelGGL(bj_gram_kernel, dim3((unsigned)np, (unsigned)S), dim3(256), 0, st, X, Q, nb, r, chunks, cpw,
                              Gp, p0);
           const int cross = (crossv && r > 0) ? 1 : 0;
-          if (eig_nt == 512)
-            hipLaunchKernelGGL((bj_eig3_kernel<512>), dim3((unsigned)np), dim3(512), 0, st, Gp, S, J, pairflag, flag,
-                               (float)tol, inner, cross, sortv, p0);
-          else if (eig_nt == 256)
-            hipLaunchKernelGGL((bj_eig3_kernel<256>), dim3((unsigned)np), dim3(256), 0, st, Gp, S, J, pairflag, flag,
-                               (float)tol, inner, cross, sortv, p0);
-          else
-            hipLaunchKernelGGL((bj_eig3_kernel<1024>), dim3((unsigned)np), dim3(1024), 0, st, Gp, S, J, pairflag, flag,
-                               (float)tol, inner, cross, sortv, p0);
+#define TNH_EIG3(NT_, B_)                                                                                        \
+  hipLaunchKernelGGL((bj_eig3_kernel<NT_, B_>), dim3((unsigned)np), dim3(NT_), 0, st, Gp, S, J, pairflag, flag, \
+                     (float)tol, inner, cross, sortv, p0)
+          if (eig_nt == 512) { if (bcast) TNH_EIG3(512, true); else TNH_EIG3(512, false); }
+          else if (eig_nt == 256) { if (bcast) TNH_EIG3(256, true); else TNH_EIG3(256, false); }
+          else { if (bcast) TNH_EIG3(1024, true); else TNH_EIG3(1024, false); }
+#undef TNH_EIG3
           hipLaunchKernelGGL(bj_update_kernel, ug, dim3(256), 0, st, X, Q, nssX, R, P, nssR, nb, r, J, pairflag, p0);
           if (gidx > 0) TNH_HIP(hipEventRecord(g_join[gidx - 1], st));
         }
@@ -720,7 +814,9 @@ int svd_block_sweeps(T* X, T* R, int64_t P, int64_t Q, char* scratch, int* flag,
     ++sweeps;
     float theta;
     memcpy(&theta, &h[1], sizeof(float));
-    if (trace) fprintf(stderr, "[tnh svd] sweep %d: rotated %d, max theta %.3e\n", sweeps, h[0], (double)theta);
+    if (trace)
+      fprintf(stderr, "[tnh svd] sweep %d: rotated %d, max theta %.3e; last eig of pair 0: prologue %.2f us, rounds %.2f us, (of the prologue: loads + sums %.2f us)\n",
+              sweeps, h[0], (double)theta, (h[2] & 0xffff) * 0.01, h[3] * 0.01, ((unsigned)h[2] >> 16) * 0.01);
     converged = (h[0] == 0) || (!F64 && stop_theta > 0.f && theta <= stop_theta);
   }
   *sweeps_out = sweeps;
