@@ -31,6 +31,9 @@ namespace tnh {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// phase stamps (10 ns ticks of wall_clock64) of workgroup (0, 0) of the last gram / update launch, printed by TNH_SVD_TRACE=1
+__device__ int g_bj_phase[8];
+
 // Circle-method pairing of `n` (even) players: pair `i` of round `r` (a < b).
 __device__ __forceinline__ void bj_pair(int n, int r, int i, int& a, int& b) {
   const int q = n - 1;
@@ -56,6 +59,7 @@ __global__ __launch_bounds__(256) void bj_gram_kernel(const float* __restrict__ 
                                                       int round, int chunks, int cpw,
                                                       float* __restrict__ Gp, int pair0) {
   __shared__ float red[4][3][1024];
+  const long long ts0 = wall_clock64();
   const int pair = pair0 + blockIdx.x, split = blockIdx.y, S = gridDim.y;
   int bi, bj;
   bj_pair(nb, round, pair, bi, bj);
@@ -68,9 +72,11 @@ __global__ __launch_bounds__(256) void bj_gram_kernel(const float* __restrict__ 
   f32x16 aII, aIJ, aJJ;
 #pragma unroll
   for (int r = 0; r < 16; ++r) aII[r] = aIJ[r] = aJJ[r] = 0.f;
-  // register ring of PF chunks in flight: the next loads are issued before the
-  // 12 MFMAs (768 cycles) that consume the current chunk
-  constexpr int PF = 4;
+  // register ring of PF chunks in flight: the next loads are issued before the 12 MFMAs that consume the current
+  // chunk.  Round 2: PF 4 -> 16.  wall_clock64 stamps (TNH_SVD_TRACE=1) showed 16.5 us in this loop for 5.1 us of
+  // MFMA issue: four chunks cover 1.3 us of work, the loads come back from Infinity Cache / remote L2 in ~2 us, so
+  // every chunk stalled.  16 chunks (the whole range of a wave at 4096 columns) are 128 VGPRs.
+  constexpr int PF = 16;
   f32x4 ra[PF], rb[PF];
 #pragma unroll
   for (int i = 0; i < PF; ++i)
@@ -96,6 +102,7 @@ __global__ __launch_bounds__(256) void bj_gram_kernel(const float* __restrict__ 
       }
     }
   }
+  const long long ts1 = wall_clock64();
   // C/D layout: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
@@ -110,6 +117,10 @@ __global__ __launch_bounds__(256) void bj_gram_kernel(const float* __restrict__ 
   const float* r0 = &red[0][0][0];
   for (int e = tid; e < 3072; e += 256)
     out[e] = (r0[e] + r0[3072 + e]) + (r0[2 * 3072 + e] + r0[3 * 3072 + e]);
+  if (tid == 0 && blockIdx.x == 0 && blockIdx.y == 0) {
+    g_bj_phase[0] = (int)(ts1 - ts0);
+    g_bj_phase[1] = (int)(wall_clock64() - ts1);
+  }
 }
 
 // ----------------------------------------------------------------------- eig
@@ -508,9 +519,19 @@ __global__ __launch_bounds__(256) void bj_update_kernel(float* __restrict__ X, i
                                                         float* __restrict__ R, int64_t ldr, int nssR,
                                                         int nb, int round, const float* __restrict__ J,
                                                         const int* __restrict__ pairflag, int pair0) {
+  const long long ts0 = wall_clock64();
   const int pair = pair0 + blockIdx.x;
   if (!pairflag[pair]) return;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  // J (64 x 64) once per workgroup through LDS with 16-byte loads.  Round 1: every wave fetched its 64 fragment
+  // values as dword loads -- 64 load instructions whose issue alone held the first MFMA back by ~6 us (stamps).
+  __shared__ float Js[64 * 64];
+  {
+    const f32x4* jsrc = (const f32x4*)(J + (int64_t)pair * 4096);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) ((f32x4*)Js)[tid + 256 * q] = jsrc[tid + 256 * q];
+  }
+  __syncthreads();
   const int ss = blockIdx.y * 4 + wid;
   if (ss >= nssX + nssR) return;
   int bi, bj;
@@ -520,19 +541,19 @@ __global__ __launch_bounds__(256) void bj_update_kernel(float* __restrict__ X, i
   if (ss < nssX) { base = X + (int64_t)ss * 128; ld = ldx; }
   else { base = R + (int64_t)(ss - nssX) * 128; ld = ldr; }
   const int i = lane & 31, kk = lane >> 5;
-  const float* Jp = J + (int64_t)pair * 4096;
   auto grow = [&](int row) -> int64_t { return row < 32 ? (int64_t)bi * 32 + row : (int64_t)bj * 32 + (row - 32); };
 
-  float jf[2][32];
-#pragma unroll
-  for (int ks = 0; ks < 32; ++ks) {
-    jf[0][ks] = Jp[(2 * ks + kk) * 64 + i];
-    jf[1][ks] = Jp[(2 * ks + kk) * 64 + 32 + i];
-  }
   f32x4 bv[32];
 #pragma unroll
   for (int ks = 0; ks < 32; ++ks) bv[ks] = *(const f32x4*)(base + grow(2 * ks + kk) * ld + 4 * i);
+  float jf[2][32];
+#pragma unroll
+  for (int ks = 0; ks < 32; ++ks) {
+    jf[0][ks] = Js[(2 * ks + kk) * 64 + i];
+    jf[1][ks] = Js[(2 * ks + kk) * 64 + 32 + i];
+  }
 
+  long long ts1 = 0;
 #pragma unroll
   for (int it = 0; it < 2; ++it) {
     f32x16 acc[4];
@@ -541,10 +562,12 @@ __global__ __launch_bounds__(256) void bj_update_kernel(float* __restrict__ X, i
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[s][r] = 0.f;
 #pragma unroll
-    for (int ks = 0; ks < 32; ++ks)
+    for (int ks = 0; ks < 32; ++ks) {
 #pragma unroll
       for (int s = 0; s < 4; ++s)
         acc[s] = __builtin_amdgcn_mfma_f32_32x32x2f32(jf[it][ks], bv[ks][s], acc[s], 0, 0, 0);
+      if (it == 0 && ks == 31) ts1 = wall_clock64();
+    }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = 32 * it + (r & 3) + 8 * (r >> 2) + 4 * kk;
@@ -552,6 +575,10 @@ __global__ __launch_bounds__(256) void bj_update_kernel(float* __restrict__ X, i
       o[0] = acc[0][r]; o[1] = acc[1][r]; o[2] = acc[2][r]; o[3] = acc[3][r];
       *(f32x4*)(base + grow(row) * ld + 4 * i) = o;
     }
+  }
+  if (tid == 0 && blockIdx.x == 0 && blockIdx.y == 0) {
+    g_bj_phase[2] = (int)(ts1 - ts0);
+    g_bj_phase[3] = (int)(wall_clock64() - ts1);
   }
 }
 
@@ -814,6 +841,12 @@ int svd_block_sweeps(T* X, T* R, int64_t P, int64_t Q, char* scratch, int* flag,
     ++sweeps;
     float theta;
     memcpy(&theta, &h[1], sizeof(float));
+    if (trace) {
+      int ph[8] = {0};
+      (void)hipMemcpyFromSymbol(ph, HIP_SYMBOL(g_bj_phase), sizeof(ph));
+      fprintf(stderr, "[tnh svd] gram wg(0,0): loads + MFMA %.2f us, reduce + store %.2f us; update wg(0,0): loads + first half %.2f us, rest %.2f us\n",
+              ph[0] * 0.01, ph[1] * 0.01, ph[2] * 0.01, ph[3] * 0.01);
+    }
     if (trace)
       fprintf(stderr, "[tnh svd] sweep %d: rotated %d, max theta %.3e; last eig of pair 0: prologue %.2f us, rounds %.2f us, (of the prologue: loads + sums %.2f us)\n",
               sweeps, h[0], (double)theta, (h[2] & 0xffff) * 0.01, h[3] * 0.01, ((unsigned)h[2] >> 16) * 0.01);
