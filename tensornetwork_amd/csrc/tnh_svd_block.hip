@@ -51,18 +51,45 @@ __device__ __forceinline__ void bj_pair(int n, int r, int i, int& a, int& b) {
   }
 }
 
+// Pairing schedules.  sched 0: the circle method over all nb blocks (pair index i of round r).
+// sched 1 / 2 / 3: the TWO-GROUP schedule (round 2).  The blocks are split into halves H1 = [0, nb/2), H2 = [nb/2, nb)
+// and quarters H1a, H1b, H2a, H2b; a sweep is three phases
+//   1: circle method inside H1 (group 0) and inside H2 (group 1)               nb/2 - 1 rounds
+//   2: H1a x H2a (group 0) and H1b x H2b (group 1), cyclic shifts               nb/4 rounds
+//   3: H1a x H2b (group 0) and H1b x H2a (group 1), cyclic shifts               nb/4 rounds
+// -- every block pair once per sweep, nb - 1 rounds, like the circle method -- and inside a phase the two groups
+// never touch the same block, so each runs its gram -> eig -> update chain on its own stream with NO
+// synchronisation between rounds: one group's latency-bound LDS eigensolve overlaps the other's bandwidth-bound
+// gram / update.  `i` is the global pair index in [0, nb/2): group = i / (nb/4).
+__device__ __forceinline__ void bj_pair_sched(int nb, int sched, int r, int i, int& a, int& b) {
+  if (sched == 0) {
+    bj_pair(nb, r, i, a, b);
+    return;
+  }
+  const int q = nb >> 2, grp = i / q, k = i - grp * q;
+  if (sched == 1) {
+    bj_pair(nb >> 1, r, k, a, b);
+    a += grp * (nb >> 1);
+    b += grp * (nb >> 1);
+  } else {
+    a = grp * q + k;
+    const int other = (sched == 2) ? grp : 1 - grp;
+    b = (nb >> 1) + other * q + (k + r) % q;
+  }
+}
+
 // ---------------------------------------------------------------------- gram
 // grid (pairs, splits), 256 threads.  Wave w of split s covers the 8-column
 // chunks [(4 s + w) cpw, +cpw).  Gp[((pair*S + s)*3 + t)*1024 + row*32 + col],
 // t = 0: II, 1: IJ, 2: JJ.
 __global__ __launch_bounds__(256) void bj_gram_kernel(const float* __restrict__ X, int64_t ldx, int nb,
                                                       int round, int chunks, int cpw,
-                                                      float* __restrict__ Gp, int pair0) {
+                                                      float* __restrict__ Gp, int pair0, int sched) {
   __shared__ float red[4][3][1024];
   const long long ts0 = wall_clock64();
   const int pair = pair0 + blockIdx.x, split = blockIdx.y, S = gridDim.y;
   int bi, bj;
-  bj_pair(nb, round, pair, bi, bj);
+  bj_pair_sched(nb, sched, round, pair, bi, bj);
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const float* xi = X + ((int64_t)bi * 32 + (lane & 31)) * ldx + 4 * (lane >> 5);
   const float* xj = X + ((int64_t)bj * 32 + (lane & 31)) * ldx + 4 * (lane >> 5);
@@ -518,7 +545,7 @@ __global__ __launch_bounds__(NT) void bj_eig3_kernel(const float* __restrict__ G
 __global__ __launch_bounds__(256) void bj_update_kernel(float* __restrict__ X, int64_t ldx, int nssX,
                                                         float* __restrict__ R, int64_t ldr, int nssR,
                                                         int nb, int round, const float* __restrict__ J,
-                                                        const int* __restrict__ pairflag, int pair0) {
+                                                        const int* __restrict__ pairflag, int pair0, int sched) {
   const long long ts0 = wall_clock64();
   const int pair = pair0 + blockIdx.x;
   if (!pairflag[pair]) return;
@@ -535,7 +562,7 @@ __global__ __launch_bounds__(256) void bj_update_kernel(float* __restrict__ X, i
   const int ss = blockIdx.y * 4 + wid;
   if (ss >= nssX + nssR) return;
   int bi, bj;
-  bj_pair(nb, round, pair, bi, bj);
+  bj_pair_sched(nb, sched, round, pair, bi, bj);
   float* base;
   int64_t ld;
   if (ss < nssX) { base = X + (int64_t)ss * 128; ld = ldx; }
@@ -726,10 +753,8 @@ size_t svd_block_scratch_bytes(int esz, int64_t P, int64_t Q) {
 }
 
 // auxiliary streams of the grouped round schedule (see svd_block_sweeps)
-constexpr int kMaxGroups = 4;
-static hipStream_t g_aux[kMaxGroups - 1] = {nullptr, nullptr, nullptr};
-static hipEvent_t g_join[kMaxGroups - 1] = {nullptr, nullptr, nullptr};
-static hipEvent_t g_fork = nullptr;
+static hipStream_t g_aux = nullptr;                 // second stream of the two-group schedule
+static hipEvent_t g_ev[2] = {nullptr, nullptr};
 
 // Sweeps until a whole sweep applies no rotation.  X: P x Q (ld Q), R: P x P.
 template <typename T>
@@ -742,7 +767,9 @@ int svd_block_sweeps(T* X, T* R, int64_t P, int64_t Q, char* scratch, int* flag,
   int* pairflag = (int*)(J + (size_t)pairs * 4096);
   const int chunks = (int)(Q / 8);
   // splits: enough workgroups to fill the chip, each wave with >= 4 chunks of work
-  int S = (2 * num_cus() + pairs - 1) / pairs;
+  // (TNH_SVD_SPLITS: A/B knob; the two-group schedule launches half the pairs at a time)
+  const char* envsp = getenv("TNH_SVD_SPLITS");
+  int S = envsp ? atoi(envsp) : (2 * num_cus() + pairs - 1) / pairs;
   if (S > 16) S = 16;
   while (S > 1 && chunks / (4 * S) < 4) --S;
   if (S < 1) S = 1;
@@ -771,68 +798,79 @@ int svd_block_sweeps(T* X, T* R, int64_t P, int64_t Q, char* scratch, int* flag,
   const char* envs = getenv("TNH_SVD_STOP");
   const float stop_theta = F64 ? 0.f : (envs ? (float)atof(envs) : 0.f);
   const bool trace = getenv("TNH_SVD_TRACE") != nullptr;
-  const char* envg = getenv("TNH_SVD_GROUPS");
-  int groups = F64 ? 1 : (envg ? atoi(envg) : 1);
-  if (groups < 1) groups = 1;
-  if (groups > kMaxGroups) groups = kMaxGroups;
-  if (groups > pairs) groups = pairs;
-  if (groups > 1) {
+  // Two-group schedule (bj_pair_sched): default on for the f32 path when the block count allows it and no graph
+  // capture is open.  TNH_SVD_SCHED=0 goes back to the circle method on one stream.  (Round 2 also tried the SAME
+  // circle round cut into G groups on G streams with a fork / join per round, TNH_SVD_GROUPS: G = 2 / 3 / 4 ->
+  // 0.243 / 0.269 / 0.307 s against 0.216 -- the per-round events cost more than the overlap returned.  The schedule
+  // below needs a cross-stream event only at the three phase boundaries of a sweep.)
+  const char* envg = getenv("TNH_SVD_SCHED");
+  bool two = !F64 && !(envg && envg[0] == '0') && nb % 4 == 0 && nb >= 8;
+  if (two) {
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     (void)hipStreamIsCapturing(stream(), &cap);
-    if (cap != hipStreamCaptureStatusNone) groups = 1;     // inside a graph capture: stay on one stream
+    if (cap != hipStreamCaptureStatusNone) two = false;     // inside a graph capture: stay on one stream
   }
-  if (groups > 1) {
-    for (int i = 0; i < groups - 1; ++i) {
-      if (!g_aux[i]) {
-        TNH_HIP(hipStreamCreateWithFlags(&g_aux[i], hipStreamNonBlocking));
-        TNH_HIP(hipEventCreateWithFlags(&g_join[i], hipEventDisableTiming));
-      }
+  if (two) {
+    if (!g_aux) {
+      TNH_HIP(hipStreamCreateWithFlags(&g_aux, hipStreamNonBlocking));
+      TNH_HIP(hipEventCreateWithFlags(&g_ev[0], hipEventDisableTiming));
+      TNH_HIP(hipEventCreateWithFlags(&g_ev[1], hipEventDisableTiming));
     }
-    if (!g_fork) TNH_HIP(hipEventCreateWithFlags(&g_fork, hipEventDisableTiming));
-    TNH_HIP(hipEventRecord(g_fork, stream()));      // everything queued so far precedes the first round
   }
+  // both streams have seen everything the other one queued so far
+  auto cross_sync = [&]() -> int {
+    TNH_HIP(hipEventRecord(g_ev[0], stream()));
+    TNH_HIP(hipEventRecord(g_ev[1], g_aux));
+    TNH_HIP(hipStreamWaitEvent(g_aux, g_ev[0], 0));
+    TNH_HIP(hipStreamWaitEvent(stream(), g_ev[1], 0));
+    return TNH_OK;
+  };
+  // one round of `np` pairs starting at global pair index p0 on stream st
+  auto f32_round = [&](hipStream_t st, int sched, int r, int p0, int np, int cross) {
+    if constexpr (!F64) {
+      const dim3 ug((unsigned)np, (unsigned)((nssX + nssR + 3) / 4));
+      hipLaunchKernelGGL(bj_gram_kernel, dim3((unsigned)np, (unsigned)S), dim3(256), 0, st, X, Q, nb, r, chunks, cpw, Gp,
+                         p0, sched);
+#define TNH_EIG3(NT_, B_)                                                                                        \
+  hipLaunchKernelGGL((bj_eig3_kernel<NT_, B_>), dim3((unsigned)np), dim3(NT_), 0, st, Gp, S, J, pairflag, flag, \
+                     (float)tol, inner, cross, sortv, p0)
+      if (eig_nt == 512) { if (bcast) TNH_EIG3(512, true); else TNH_EIG3(512, false); }
+      else if (eig_nt == 256) { if (bcast) TNH_EIG3(256, true); else TNH_EIG3(256, false); }
+      else { if (bcast) TNH_EIG3(1024, true); else TNH_EIG3(1024, false); }
+#undef TNH_EIG3
+      hipLaunchKernelGGL(bj_update_kernel, ug, dim3(256), 0, st, X, Q, nssX, R, P, nssR, nb, r, J, pairflag, p0, sched);
+    }
+  };
   int sweeps = 0;
   bool converged = false;
   while (!converged && sweeps < max_sweeps) {
     TNH_HIP(hipMemsetAsync(flag, 0, 4 * sizeof(int), stream()));
-    if (groups > 1) TNH_HIP(hipEventRecord(g_fork, stream()));
-    for (int r = 0; r < nb - 1; ++r) {
-      const dim3 ugrid((unsigned)pairs, (unsigned)((nssX + nssR + 3) / 4));
-      if constexpr (F64) {
+    if constexpr (F64) {
+      for (int r = 0; r < nb - 1; ++r) {
+        const dim3 ugrid((unsigned)pairs, (unsigned)((nssX + nssR + 3) / 4));
         hipLaunchKernelGGL(bj_gram64_kernel, dim3((unsigned)pairs, (unsigned)S), dim3(256), 0, stream(), X, Q, nb, r,
                            chunks, cpw, Gp);
         hipLaunchKernelGGL((bj_eig_kernel<double, 16>), dim3((unsigned)pairs), dim3(256), 0, stream(), Gp, S, J,
                            pairflag, flag, tol, inner, 0);
         hipLaunchKernelGGL(bj_update64_kernel, ugrid, dim3(256), 0, stream(), X, Q, nssX, R, P, nssR, nb, r, J,
                            pairflag);
-      } else {
-        // A/B knob TNH_SVD_GROUPS=G (default 1 = one stream): the pairs of a round are independent, so the round
-        // can be issued as G groups on G streams to overlap one group's latency-bound LDS eigensolve with the
-        // others' gram / update kernels.  Measured on MI355X (4096^2): G = 1 0.216 s, G = 2 0.243 s, G = 3 0.269 s,
-        // G = 4 0.307 s -- the per-round fork / join events cost more than the overlap returns, so it stays off.
-        for (int gidx = 0; gidx < groups; ++gidx) {
-          const int p0 = (int)((int64_t)pairs * gidx / groups), p1 = (int)((int64_t)pairs * (gidx + 1) / groups);
-          const int np = p1 - p0;
-          if (np <= 0) continue;
-          hipStream_t st = gidx == 0 ? stream() : g_aux[gidx - 1];
-          if (gidx > 0) TNH_HIP(hipStreamWaitEvent(st, g_fork, 0));
-          const dim3 ug((unsigned)np, ugrid.y);
-          hipLaunchKernelGGL(bj_gram_kernel, dim3((unsigned)np, (unsigned)S), dim3(256), 0, st, X, Q, nb, r, chunks, cpw,
-                             Gp, p0);
-          const int cross = (crossv && r > 0) ? 1 : 0;
-#define TNH_EIG3(NT_, B_)                                                                                        \
-  hipLaunchKernelGGL((bj_eig3_kernel<NT_, B_>), dim3((unsigned)np), dim3(NT_), 0, st, Gp, S, J, pairflag, flag, \
-                     (float)tol, inner, cross, sortv, p0)
-          if (eig_nt == 512) { if (bcast) TNH_EIG3(512, true); else TNH_EIG3(512, false); }
-          else if (eig_nt == 256) { if (bcast) TNH_EIG3(256, true); else TNH_EIG3(256, false); }
-          else { if (bcast) TNH_EIG3(1024, true); else TNH_EIG3(1024, false); }
-#undef TNH_EIG3
-          hipLaunchKernelGGL(bj_update_kernel, ug, dim3(256), 0, st, X, Q, nssX, R, P, nssR, nb, r, J, pairflag, p0);
-          if (gidx > 0) TNH_HIP(hipEventRecord(g_join[gidx - 1], st));
-        }
-        for (int gidx = 1; gidx < groups; ++gidx) TNH_HIP(hipStreamWaitEvent(stream(), g_join[gidx - 1], 0));
-        if (groups > 1) TNH_HIP(hipEventRecord(g_fork, stream()));
       }
+    } else if (two) {
+      const int half = pairs / 2;   // pairs per group
+      int rc = cross_sync();
+      if (rc) return rc;
+      for (int phase = 1; phase <= 3; ++phase) {
+        const int rounds = (phase == 1) ? nb / 2 - 1 : nb / 4;
+        for (int r = 0; r < rounds; ++r) {
+          const int cross = (crossv && !(phase == 1 && r == 0)) ? 1 : 0;   // the first round also rotates inside the blocks
+          f32_round(stream(), phase, r, 0, half, cross);
+          f32_round(g_aux, phase, r, half, half, cross);
+        }
+        rc = cross_sync();
+        if (rc) return rc;
+      }
+    } else {
+      for (int r = 0; r < nb - 1; ++r) f32_round(stream(), 0, r, 0, pairs, (crossv && r > 0) ? 1 : 0);
     }
     TNH_LAUNCH_CHECK();
     int h[4] = {0, 0, 0, 0};
