@@ -51,30 +51,26 @@ __device__ __forceinline__ void bj_pair(int n, int r, int i, int& a, int& b) {
   }
 }
 
-// Pairing schedules.  sched 0: the circle method over all nb blocks (pair index i of round r).
-// sched 1 / 2 / 3: the TWO-GROUP schedule (round 2).  The blocks are split into halves H1 = [0, nb/2), H2 = [nb/2, nb)
-// and quarters H1a, H1b, H2a, H2b; a sweep is three phases
-//   1: circle method inside H1 (group 0) and inside H2 (group 1)               nb/2 - 1 rounds
-//   2: H1a x H2a (group 0) and H1b x H2b (group 1), cyclic shifts               nb/4 rounds
-//   3: H1a x H2b (group 0) and H1b x H2a (group 1), cyclic shifts               nb/4 rounds
-// -- every block pair once per sweep, nb - 1 rounds, like the circle method -- and inside a phase the two groups
-// never touch the same block, so each runs its gram -> eig -> update chain on its own stream with NO
-// synchronisation between rounds: one group's latency-bound LDS eigensolve overlaps the other's bandwidth-bound
-// gram / update.  `i` is the global pair index in [0, nb/2): group = i / (nb/4).
-__device__ __forceinline__ void bj_pair_sched(int nb, int sched, int r, int i, int& a, int& b) {
-  if (sched == 0) {
-    bj_pair(nb, r, i, a, b);
-    return;
-  }
-  const int q = nb >> 2, grp = i / q, k = i - grp * q;
-  if (sched == 1) {
-    bj_pair(nb >> 1, r, k, a, b);
-    a += grp * (nb >> 1);
-    b += grp * (nb >> 1);
+// Pairing of one GROUP of blocks in round r (k = pair index inside the group):
+//   shift == 0: circle method over the q blocks [abase, abase + q)                    (q / 2 pairs, q - 1 rounds)
+//   shift == 1: blocks [abase, abase + q) against [bbase, bbase + q), cyclic shifts   (q pairs, q rounds)
+// The GROUPED schedule (round 2, svd_block_sweeps) cuts the blocks into G = 2 or 4 parts and a sweep into phases in
+// which the G groups never touch the same block -- first the circle method inside every part, then, for every
+// matching of the parts, half-part x half-part products in two sub-phases -- every block pair once per sweep in
+// nb - 1 rounds, like the plain circle method.  Inside a phase each group runs its gram -> eig -> update chain on
+// its own stream with NO synchronisation between rounds: one group's latency-bound LDS eigensolve overlaps the
+// others' gram / update.
+struct BjGroup {
+  int shift, abase, bbase, q;
+};
+__device__ __forceinline__ void bj_pair_group(const BjGroup& g, int r, int k, int& a, int& b) {
+  if (g.shift == 0) {
+    bj_pair(g.q, r, k, a, b);
+    a += g.abase;
+    b += g.abase;
   } else {
-    a = grp * q + k;
-    const int other = (sched == 2) ? grp : 1 - grp;
-    b = (nb >> 1) + other * q + (k + r) % q;
+    a = g.abase + k;
+    b = g.bbase + (k + r) % g.q;
   }
 }
 
@@ -84,12 +80,12 @@ __device__ __forceinline__ void bj_pair_sched(int nb, int sched, int r, int i, i
 // t = 0: II, 1: IJ, 2: JJ.
 __global__ __launch_bounds__(256) void bj_gram_kernel(const float* __restrict__ X, int64_t ldx, int nb,
                                                       int round, int chunks, int cpw,
-                                                      float* __restrict__ Gp, int pair0, int sched) {
+                                                      float* __restrict__ Gp, int pair0, BjGroup grp) {
   __shared__ float red[4][3][1024];
   const long long ts0 = wall_clock64();
   const int pair = pair0 + blockIdx.x, split = blockIdx.y, S = gridDim.y;
   int bi, bj;
-  bj_pair_sched(nb, sched, round, pair, bi, bj);
+  bj_pair_group(grp, round, (int)blockIdx.x, bi, bj);
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const float* xi = X + ((int64_t)bi * 32 + (lane & 31)) * ldx + 4 * (lane >> 5);
   const float* xj = X + ((int64_t)bj * 32 + (lane & 31)) * ldx + 4 * (lane >> 5);
@@ -545,7 +541,7 @@ __global__ __launch_bounds__(NT) void bj_eig3_kernel(const float* __restrict__ G
 __global__ __launch_bounds__(256) void bj_update_kernel(float* __restrict__ X, int64_t ldx, int nssX,
                                                         float* __restrict__ R, int64_t ldr, int nssR,
                                                         int nb, int round, const float* __restrict__ J,
-                                                        const int* __restrict__ pairflag, int pair0, int sched) {
+                                                        const int* __restrict__ pairflag, int pair0, BjGroup grp) {
   const long long ts0 = wall_clock64();
   const int pair = pair0 + blockIdx.x;
   if (!pairflag[pair]) return;
@@ -562,7 +558,7 @@ __global__ __launch_bounds__(256) void bj_update_kernel(float* __restrict__ X, i
   const int ss = blockIdx.y * 4 + wid;
   if (ss >= nssX + nssR) return;
   int bi, bj;
-  bj_pair_sched(nb, sched, round, pair, bi, bj);
+  bj_pair_group(grp, round, (int)blockIdx.x, bi, bj);
   float* base;
   int64_t ld;
   if (ss < nssX) { base = X + (int64_t)ss * 128; ld = ldx; }
@@ -753,8 +749,8 @@ size_t svd_block_scratch_bytes(int esz, int64_t P, int64_t Q) {
 }
 
 // auxiliary streams of the grouped round schedule (see svd_block_sweeps)
-static hipStream_t g_aux = nullptr;                 // second stream of the two-group schedule
-static hipEvent_t g_ev[2] = {nullptr, nullptr};
+static hipStream_t g_aux[3] = {nullptr, nullptr, nullptr};     // streams of groups 1 .. 3 of the grouped schedule
+static hipEvent_t g_ev[4] = {nullptr, nullptr, nullptr, nullptr};
 
 // Sweeps until a whole sweep applies no rotation.  X: P x Q (ld Q), R: P x P.
 template <typename T>
@@ -798,39 +794,47 @@ int svd_block_sweeps(T* X, T* R, int64_t P, int64_t Q, char* scratch, int* flag,
   const char* envs = getenv("TNH_SVD_STOP");
   const float stop_theta = F64 ? 0.f : (envs ? (float)atof(envs) : 0.f);
   const bool trace = getenv("TNH_SVD_TRACE") != nullptr;
-  // Two-group schedule (bj_pair_sched): default on for the f32 path when the block count allows it and no graph
-  // capture is open.  TNH_SVD_SCHED=0 goes back to the circle method on one stream.  (Round 2 also tried the SAME
-  // circle round cut into G groups on G streams with a fork / join per round, TNH_SVD_GROUPS: G = 2 / 3 / 4 ->
-  // 0.243 / 0.269 / 0.307 s against 0.216 -- the per-round events cost more than the overlap returned.  The schedule
-  // below needs a cross-stream event only at the three phase boundaries of a sweep.)
-  const char* envg = getenv("TNH_SVD_SCHED");
-  bool two = !F64 && !(envg && envg[0] == '0') && nb % 4 == 0 && nb >= 8;
-  if (two) {
-    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-    (void)hipStreamIsCapturing(stream(), &cap);
-    if (cap != hipStreamCaptureStatusNone) two = false;     // inside a graph capture: stay on one stream
-  }
-  if (two) {
-    if (!g_aux) {
-      TNH_HIP(hipStreamCreateWithFlags(&g_aux, hipStreamNonBlocking));
-      TNH_HIP(hipEventCreateWithFlags(&g_ev[0], hipEventDisableTiming));
-      TNH_HIP(hipEventCreateWithFlags(&g_ev[1], hipEventDisableTiming));
+  // Grouped schedule (see BjGroup): default for the f32 path, G = 2 when nb % 4 == 0, else the plain circle method on
+  // one stream; never inside a graph capture.  TNH_SVD_SCHED=1 / 2 / 4 forces the group count.  Measured on MI355X
+  // (4096^2 / 2048^2 / 1024^2 / 512^2): G = 1 0.165 / 0.051 / 0.021 / 0.0093 s, G = 2 0.147 / 0.049 / 0.022 / 0.0095 s,
+  // G = 4 0.139 (15 instead of 16 sweeps; the same 9.2 ms per sweep as G = 2) / 0.055 / 0.025 / 0.0126 s: the overlap
+  // is exhausted with two chains, more streams only add launches.  (Round 2 also tried the SAME circle round cut into G groups on G streams with a fork /
+  // join per round, TNH_SVD_GROUPS: G = 2 / 3 / 4 -> 0.243 / 0.269 / 0.307 s against 0.216 -- the per-round events
+  // cost more than the overlap returned.  This schedule needs cross-stream events only at the phase boundaries.)
+  int G = 1;
+  if (!F64) {
+    if (nb % 4 == 0 && nb >= 8) G = 2;
+    if (const char* envg = getenv("TNH_SVD_SCHED")) {
+      const int want = atoi(envg);
+      if (want == 1 || (want == 2 && nb % 4 == 0 && nb >= 8) || (want == 4 && nb % 8 == 0 && nb >= 16)) G = want;
     }
   }
-  // both streams have seen everything the other one queued so far
+  if (G > 1) {
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(stream(), &cap);
+    if (cap != hipStreamCaptureStatusNone) G = 1;     // inside a graph capture: stay on one stream
+  }
+  if (G > 1) {
+    for (int i = 0; i < G - 1; ++i)
+      if (!g_aux[i]) TNH_HIP(hipStreamCreateWithFlags(&g_aux[i], hipStreamNonBlocking));
+    for (int i = 0; i < G; ++i)
+      if (!g_ev[i]) TNH_HIP(hipEventCreateWithFlags(&g_ev[i], hipEventDisableTiming));
+  }
+  auto gstream = [&](int g) { return g == 0 ? stream() : g_aux[g - 1]; };
+  // every stream has seen everything the others queued so far
   auto cross_sync = [&]() -> int {
-    TNH_HIP(hipEventRecord(g_ev[0], stream()));
-    TNH_HIP(hipEventRecord(g_ev[1], g_aux));
-    TNH_HIP(hipStreamWaitEvent(g_aux, g_ev[0], 0));
-    TNH_HIP(hipStreamWaitEvent(stream(), g_ev[1], 0));
+    for (int g = 0; g < G; ++g) TNH_HIP(hipEventRecord(g_ev[g], gstream(g)));
+    for (int g = 0; g < G; ++g)
+      for (int o = 0; o < G; ++o)
+        if (o != g) TNH_HIP(hipStreamWaitEvent(gstream(g), g_ev[o], 0));
     return TNH_OK;
   };
-  // one round of `np` pairs starting at global pair index p0 on stream st
-  auto f32_round = [&](hipStream_t st, int sched, int r, int p0, int np, int cross) {
+  // one round of a group: `np` pairs whose Gram / J slots start at global pair index p0, on stream st
+  auto f32_round = [&](hipStream_t st, const BjGroup& grp, int r, int p0, int np, int cross) {
     if constexpr (!F64) {
       const dim3 ug((unsigned)np, (unsigned)((nssX + nssR + 3) / 4));
       hipLaunchKernelGGL(bj_gram_kernel, dim3((unsigned)np, (unsigned)S), dim3(256), 0, st, X, Q, nb, r, chunks, cpw, Gp,
-                         p0, sched);
+                         p0, grp);
 #define TNH_EIG3(NT_, B_)                                                                                        \
   hipLaunchKernelGGL((bj_eig3_kernel<NT_, B_>), dim3((unsigned)np), dim3(NT_), 0, st, Gp, S, J, pairflag, flag, \
                      (float)tol, inner, cross, sortv, p0)
@@ -838,9 +842,34 @@ int svd_block_sweeps(T* X, T* R, int64_t P, int64_t Q, char* scratch, int* flag,
       else if (eig_nt == 256) { if (bcast) TNH_EIG3(256, true); else TNH_EIG3(256, false); }
       else { if (bcast) TNH_EIG3(1024, true); else TNH_EIG3(1024, false); }
 #undef TNH_EIG3
-      hipLaunchKernelGGL(bj_update_kernel, ug, dim3(256), 0, st, X, Q, nssX, R, P, nssR, nb, r, J, pairflag, p0, sched);
+      hipLaunchKernelGGL(bj_update_kernel, ug, dim3(256), 0, st, X, Q, nssX, R, P, nssR, nb, r, J, pairflag, p0, grp);
     }
   };
+  // phases of the grouped schedule: groups[phase][g], rounds[phase]
+  struct Phase { int rounds; BjGroup g[4]; };
+  Phase phases[7];
+  int nphases = 0;
+  if (G > 1) {
+    const int part = nb / G, hq = part / 2;      // blocks per part, per half part
+    Phase& p0 = phases[nphases++];
+    p0.rounds = part - 1;
+    for (int g = 0; g < G; ++g) p0.g[g] = BjGroup{0, g * part, 0, part};
+    // matchings of the parts: G = 2: (0,1); G = 4: (0,1)(2,3), (0,2)(1,3), (0,3)(1,2)
+    const int match2[1][1][2] = {{{0, 1}}};
+    const int match4[3][2][2] = {{{0, 1}, {2, 3}}, {{0, 2}, {1, 3}}, {{0, 3}, {1, 2}}};
+    const int nmatch = (G == 2) ? 1 : 3;
+    for (int m = 0; m < nmatch; ++m)
+      for (int t = 0; t < 2; ++t) {
+        Phase& ph = phases[nphases++];
+        ph.rounds = hq;
+        for (int mi = 0; mi < G / 2; ++mi) {
+          const int x = (G == 2) ? match2[0][mi][0] : match4[m][mi][0];
+          const int y = (G == 2) ? match2[0][mi][1] : match4[m][mi][1];
+          for (int u = 0; u < 2; ++u) ph.g[2 * mi + u] = BjGroup{1, x * part + u * hq, y * part + (u ^ t) * hq, hq};
+        }
+      }
+  }
+  const BjGroup whole{0, 0, 0, nb};
   int sweeps = 0;
   bool converged = false;
   while (!converged && sweeps < max_sweeps) {
@@ -855,22 +884,20 @@ int svd_block_sweeps(T* X, T* R, int64_t P, int64_t Q, char* scratch, int* flag,
         hipLaunchKernelGGL(bj_update64_kernel, ugrid, dim3(256), 0, stream(), X, Q, nssX, R, P, nssR, nb, r, J,
                            pairflag);
       }
-    } else if (two) {
-      const int half = pairs / 2;   // pairs per group
+    } else if (G > 1) {
+      const int np = pairs / G;   // pairs per group (part / 2 in the first phase, hq in the others)
       int rc = cross_sync();
       if (rc) return rc;
-      for (int phase = 1; phase <= 3; ++phase) {
-        const int rounds = (phase == 1) ? nb / 2 - 1 : nb / 4;
-        for (int r = 0; r < rounds; ++r) {
-          const int cross = (crossv && !(phase == 1 && r == 0)) ? 1 : 0;   // the first round also rotates inside the blocks
-          f32_round(stream(), phase, r, 0, half, cross);
-          f32_round(g_aux, phase, r, half, half, cross);
+      for (int ph = 0; ph < nphases; ++ph) {
+        for (int r = 0; r < phases[ph].rounds; ++r) {
+          const int cross = (crossv && !(ph == 0 && r == 0)) ? 1 : 0;   // the first round also rotates inside the blocks
+          for (int g = 0; g < G; ++g) f32_round(gstream(g), phases[ph].g[g], r, g * np, np, cross);
         }
         rc = cross_sync();
         if (rc) return rc;
       }
     } else {
-      for (int r = 0; r < nb - 1; ++r) f32_round(stream(), 0, r, 0, pairs, (crossv && r > 0) ? 1 : 0);
+      for (int r = 0; r < nb - 1; ++r) f32_round(stream(), whole, r, 0, pairs, (crossv && r > 0) ? 1 : 0);
     }
     TNH_LAUNCH_CHECK();
     int h[4] = {0, 0, 0, 0};

@@ -6,6 +6,6 @@ R=$PWD; OUT=$PWD/gpurun_out; mkdir -p $OUT
 echo "== tests"
 timeout 900 python -m pytest tests/test_gpu_linalg.py -m gpu -q --timeout 600 > $OUT/pytest_svd.log 2>&1; echo "rc=$?"; tail -3 $OUT/pytest_svd.log
 echo "== A/B"
-for sc in 1 0; do
+for sc in 4 2 1; do
   echo "sched=$sc: $(TNH_SVD_SCHED=$sc timeout 300 python tools/svd_probe.py --check 1 --sizes 4096,2048,1024,512 --reps 2 2>&1 | tail -5 | tr '\n' ' ')"
 done
