@@ -293,6 +293,12 @@ int tnh_svd_factor_topk(int dtype, int64_t m, int64_t n, const void* A, void* S,
 int tnh_svd_vectors_topk(int dtype, int64_t m, int64_t n, const void* A,
                          void* work, const void* S, int64_t k, void* U, void* Vh);
 
+/* The block pairs (32-row blocks a < b ... or a in one part, b in another) of ONE sweep of the block Jacobi
+ * in launch order, for `nb` blocks and `groups` = 1 (circle method), 2 or 4 (grouped schedule: the groups of a
+ * round never share a block, tnh_svd_block.hip).  pairs_out: [nb - 1][nb / 2][2] int32; host only (no GPU needed):
+ * what the tests check -- every block pair exactly once per sweep, every block once per round. */
+int tnh_svd_block_schedule(int nb, int groups, int32_t* pairs_out, int* rounds_out);
+
 /* ---- K9: thin Householder QR --------------------------------------------------
  * A (m x n, row-major, f32 / f64) = Q (m x k) R (k x n), k = min(m, n); blocked
  * Householder (LAPACK geqrf + orgqr: same reflector sign convention, so R matches

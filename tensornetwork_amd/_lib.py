@@ -108,6 +108,7 @@ SIGNATURES = {
                         c_void_p, c_int64, c_void_p, POINTER(c_int)]),
     "tnh_svd_factor_topk": (c_int, [c_int, c_int64, c_int64, c_void_p, c_void_p, c_void_p, POINTER(c_int),
                                     POINTER(c_int)]),
+    "tnh_svd_block_schedule": (c_int, [c_int, c_int, c_void_p, POINTER(c_int)]),
     "tnh_svd_vectors_topk": (c_int, [c_int, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_void_p,
                                      c_void_p]),
     "tnh_qr_work_bytes": (c_int, [c_int, c_int64, c_int64, POINTER(c_size_t)]),

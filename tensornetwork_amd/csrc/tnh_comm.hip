@@ -150,7 +150,7 @@ int tnh_comm_info(int* rank, int* world) {
 
 int tnh_comm_destroy(void) {
   if (g_comm) {
-    if (stream()) hipStreamSynchronize(stream());
+    if (stream()) (void)hipStreamSynchronize(stream());
     ncclResult_t r = g_api.CommDestroy(g_comm);
     g_comm = nullptr;
     g_rank = 0;

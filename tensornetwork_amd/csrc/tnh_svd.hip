@@ -35,6 +35,7 @@ struct SvdLayout {
 template <typename T>
 int svd_block_pad_copy(T* Xp, int64_t P, int64_t Q, const T* A, int64_t m, int64_t n, bool trans);
 size_t svd_block_scratch_bytes(int esz, int64_t P, int64_t Q);
+int svd_block_schedule_pairs(int nb, int groups, int32_t* out, int* rounds_out);
 template <typename T>
 int svd_block_sweeps(T* X, T* R, int64_t P, int64_t Q, char* scratch, int* flag, double tol,
                      int max_sweeps, int* sweeps_out, bool* converged_out);
@@ -694,6 +695,14 @@ int tnh_svd_vectors(int dtype, int64_t m, int64_t n, void* work, int64_t k, void
   if (dtype == TNH_C128) return svd_vectors_cplx<cf64, double>(L, dtype, m, n, (char*)work, k, U, Vh);
   if (dtype == TNH_F32) return svd_vectors_t<float>(L, m, n, (char*)work, k, U, Vh);
   return svd_vectors_t<double>(L, m, n, (char*)work, k, U, Vh);
+}
+
+int tnh_svd_block_schedule(int nb, int groups, int32_t* pairs_out, int* rounds_out) {
+  TNH_REQUIRE(pairs_out && rounds_out, "tnh_svd_block_schedule: null output");
+  TNH_REQUIRE(nb >= 2 && nb % 2 == 0, "tnh_svd_block_schedule: nb must be even (got %d)", nb);
+  TNH_REQUIRE(groups == 1 || ((groups == 2 || groups == 4) && nb % (2 * groups) == 0 && nb >= 4 * groups),
+              "tnh_svd_block_schedule: %d groups need nb %% %d == 0", groups, 2 * groups);
+  return tnh::svd_block_schedule_pairs(nb, groups, pairs_out, rounds_out);
 }
 
 int tnh_svd_factor_topk(int dtype, int64_t m, int64_t n, const void* A, void* S, void* work, int* sweeps_out,

@@ -35,7 +35,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 __device__ int g_bj_phase[8];
 
 // Circle-method pairing of `n` (even) players: pair `i` of round `r` (a < b).
-__device__ __forceinline__ void bj_pair(int n, int r, int i, int& a, int& b) {
+__host__ __device__ __forceinline__ void bj_pair(int n, int r, int i, int& a, int& b) {
   const int q = n - 1;
   if (i == 0) {
     a = q;
@@ -63,7 +63,7 @@ __device__ __forceinline__ void bj_pair(int n, int r, int i, int& a, int& b) {
 struct BjGroup {
   int shift, abase, bbase, q;
 };
-__device__ __forceinline__ void bj_pair_group(const BjGroup& g, int r, int k, int& a, int& b) {
+__host__ __device__ __forceinline__ void bj_pair_group(const BjGroup& g, int r, int k, int& a, int& b) {
   if (g.shift == 0) {
     bj_pair(g.q, r, k, a, b);
     a += g.abase;
@@ -72,6 +72,34 @@ __device__ __forceinline__ void bj_pair_group(const BjGroup& g, int r, int k, in
     a = g.abase + k;
     b = g.bbase + (k + r) % g.q;
   }
+}
+
+// Phases of the grouped schedule for G = 2 or 4 groups (nb % (2 G) == 0): returns the phase count (3 or 7).
+struct BjPhase {
+  int rounds;
+  BjGroup g[4];
+};
+static int bj_build_schedule(int nb, int G, BjPhase* phases) {
+  int nphases = 0;
+  const int part = nb / G, hq = part / 2;      // blocks per part, per half part
+  BjPhase& p0 = phases[nphases++];
+  p0.rounds = part - 1;
+  for (int g = 0; g < G; ++g) p0.g[g] = BjGroup{0, g * part, 0, part};
+  // matchings of the parts: G = 2: (0,1); G = 4: (0,1)(2,3), (0,2)(1,3), (0,3)(1,2)
+  const int match2[1][1][2] = {{{0, 1}}};
+  const int match4[3][2][2] = {{{0, 1}, {2, 3}}, {{0, 2}, {1, 3}}, {{0, 3}, {1, 2}}};
+  const int nmatch = (G == 2) ? 1 : 3;
+  for (int m = 0; m < nmatch; ++m)
+    for (int t = 0; t < 2; ++t) {
+      BjPhase& ph = phases[nphases++];
+      ph.rounds = hq;
+      for (int mi = 0; mi < G / 2; ++mi) {
+        const int x = (G == 2) ? match2[0][mi][0] : match4[m][mi][0];
+        const int y = (G == 2) ? match2[0][mi][1] : match4[m][mi][1];
+        for (int u = 0; u < 2; ++u) ph.g[2 * mi + u] = BjGroup{1, x * part + u * hq, y * part + (u ^ t) * hq, hq};
+      }
+    }
+  return nphases;
 }
 
 // ---------------------------------------------------------------------- gram
@@ -845,30 +873,8 @@ int svd_block_sweeps(T* X, T* R, int64_t P, int64_t Q, char* scratch, int* flag,
       hipLaunchKernelGGL(bj_update_kernel, ug, dim3(256), 0, st, X, Q, nssX, R, P, nssR, nb, r, J, pairflag, p0, grp);
     }
   };
-  // phases of the grouped schedule: groups[phase][g], rounds[phase]
-  struct Phase { int rounds; BjGroup g[4]; };
-  Phase phases[7];
-  int nphases = 0;
-  if (G > 1) {
-    const int part = nb / G, hq = part / 2;      // blocks per part, per half part
-    Phase& p0 = phases[nphases++];
-    p0.rounds = part - 1;
-    for (int g = 0; g < G; ++g) p0.g[g] = BjGroup{0, g * part, 0, part};
-    // matchings of the parts: G = 2: (0,1); G = 4: (0,1)(2,3), (0,2)(1,3), (0,3)(1,2)
-    const int match2[1][1][2] = {{{0, 1}}};
-    const int match4[3][2][2] = {{{0, 1}, {2, 3}}, {{0, 2}, {1, 3}}, {{0, 3}, {1, 2}}};
-    const int nmatch = (G == 2) ? 1 : 3;
-    for (int m = 0; m < nmatch; ++m)
-      for (int t = 0; t < 2; ++t) {
-        Phase& ph = phases[nphases++];
-        ph.rounds = hq;
-        for (int mi = 0; mi < G / 2; ++mi) {
-          const int x = (G == 2) ? match2[0][mi][0] : match4[m][mi][0];
-          const int y = (G == 2) ? match2[0][mi][1] : match4[m][mi][1];
-          for (int u = 0; u < 2; ++u) ph.g[2 * mi + u] = BjGroup{1, x * part + u * hq, y * part + (u ^ t) * hq, hq};
-        }
-      }
-  }
+  BjPhase phases[7];
+  const int nphases = (G > 1) ? bj_build_schedule(nb, G, phases) : 0;
   const BjGroup whole{0, 0, 0, nb};
   int sweeps = 0;
   bool converged = false;
@@ -923,5 +929,35 @@ int svd_block_sweeps(T* X, T* R, int64_t P, int64_t Q, char* scratch, int* flag,
 }
 template int svd_block_sweeps<float>(float*, float*, int64_t, int64_t, char*, int*, double, int, int*, bool*);
 template int svd_block_sweeps<double>(double*, double*, int64_t, int64_t, char*, int*, double, int, int*, bool*);
+
+// The block pairs of one sweep in launch order (host only; tests): out[(round * nb/2 + pair) * 2 + {0, 1}].
+int svd_block_schedule_pairs(int nb, int groups, int32_t* out, int* rounds_out) {
+  int round = 0;
+  const int pairs = nb / 2;
+  if (groups <= 1) {
+    for (int r = 0; r < nb - 1; ++r, ++round)
+      for (int i = 0; i < pairs; ++i) {
+        int a, b;
+        bj_pair(nb, r, i, a, b);
+        out[((int64_t)round * pairs + i) * 2] = a;
+        out[((int64_t)round * pairs + i) * 2 + 1] = b;
+      }
+  } else {
+    BjPhase phases[7];
+    const int nphases = bj_build_schedule(nb, groups, phases);
+    const int np = pairs / groups;
+    for (int ph = 0; ph < nphases; ++ph)
+      for (int r = 0; r < phases[ph].rounds; ++r, ++round)
+        for (int g = 0; g < groups; ++g)
+          for (int k = 0; k < np; ++k) {
+            int a, b;
+            bj_pair_group(phases[ph].g[g], r, k, a, b);
+            out[((int64_t)round * pairs + g * np + k) * 2] = a;
+            out[((int64_t)round * pairs + g * np + k) * 2 + 1] = b;
+          }
+  }
+  *rounds_out = round;
+  return TNH_OK;
+}
 
 }  // namespace tnh

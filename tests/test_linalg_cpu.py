@@ -84,3 +84,38 @@ def test_three_way_bf16_split_arithmetic():
   assert np.max(np.abs(six - exact)[ok] / np.abs(exact)[ok]) < 2.0**-24     # dropped terms: mid*lo, lo*mid, lo*lo
   three = f(mid, yh) + f(hi, ym) + f(hi, yh)
   assert np.max(np.abs(three - exact)[ok] / np.abs(exact)[ok]) > 2.0**-18    # why six products and not three
+
+
+@pytest.mark.parametrize("nb", [8, 16, 24, 128])
+@pytest.mark.parametrize("groups", [1, 2, 4])
+def test_svd_block_schedule_covers_every_pair_once(nb, groups):
+  """The sweep schedules of the block Jacobi (circle method; grouped schedule on 2 / 4 streams,
+  tnh_svd_block.hip): nb - 1 rounds, every block exactly once per round, every block pair exactly once per
+  sweep, and the groups of a round never share a block (they run unsynchronised on different streams)."""
+  import ctypes
+  from tensornetwork_amd import _lib
+  lib = _lib.load_library()
+  if groups > 1 and (nb % (2 * groups) != 0 or nb < 4 * groups):
+    out = np.zeros(((nb - 1), nb // 2, 2), dtype=np.int32)
+    rounds = ctypes.c_int(0)
+    assert lib.tnh_svd_block_schedule(nb, groups, out.ctypes.data_as(ctypes.c_void_p), ctypes.byref(rounds)) != 0
+    return
+  out = np.full(((nb - 1), nb // 2, 2), -1, dtype=np.int32)
+  rounds = ctypes.c_int(0)
+  _lib.check(lib.tnh_svd_block_schedule(nb, groups, out.ctypes.data_as(ctypes.c_void_p), ctypes.byref(rounds)),
+             "tnh_svd_block_schedule")
+  assert rounds.value == nb - 1
+  seen = set()
+  per_group = (nb // 2) // groups
+  for r in range(nb - 1):
+    blocks = out[r].reshape(-1)
+    assert sorted(blocks.tolist()) == list(range(nb)), (r, blocks)
+    for g in range(groups):
+      mine = set(out[r, g * per_group:(g + 1) * per_group].reshape(-1).tolist())
+      rest = set(np.delete(out[r], np.s_[g * per_group:(g + 1) * per_group], axis=0).reshape(-1).tolist())
+      assert not (mine & rest)
+    for a, b in out[r]:
+      key = (min(a, b), max(a, b))
+      assert a != b and key not in seen, (r, key)
+      seen.add(key)
+  assert len(seen) == nb * (nb - 1) // 2
