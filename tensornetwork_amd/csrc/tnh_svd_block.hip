@@ -106,6 +106,11 @@ static int bj_build_schedule(int nb, int G, BjPhase* phases) {
 // grid (pairs, splits), 256 threads.  Wave w of split s covers the 8-column
 // chunks [(4 s + w) cpw, +cpw).  Gp[((pair*S + s)*3 + t)*1024 + row*32 + col],
 // t = 0: II, 1: IJ, 2: JJ.
+// DIAG (A/B knob TNH_SVD_GRAMDIAG=1, default off): only the IJ tile goes through the MFMA; II and JJ are taken as
+// diag(row norms^2), i.e. the rows inside a block are treated as orthogonal during the cross rounds (the Gram
+// kernel sits on the f32 MFMA roofline: 1.6 Gflop per round = 10.2 us of its 17 us).  Measured at 4096^2: 9.15 ->
+// 8.34 ms per sweep, but 17 sweeps instead of 16: 0.146 -> 0.142 s, same accuracy -- not worth a convergence risk.
+template <bool DIAG>
 __global__ __launch_bounds__(256) void bj_gram_kernel(const float* __restrict__ X, int64_t ldx, int nb,
                                                       int round, int chunks, int cpw,
                                                       float* __restrict__ Gp, int pair0, BjGroup grp) {
@@ -128,6 +133,7 @@ __global__ __launch_bounds__(256) void bj_gram_kernel(const float* __restrict__ 
   // MFMA issue: four chunks cover 1.3 us of work, the loads come back from Infinity Cache / remote L2 in ~2 us, so
   // every chunk stalled.  16 chunks (the whole range of a wave at 4096 columns) are 128 VGPRs.
   constexpr int PF = 16;
+  float nI = 0.f, nJ = 0.f;
   f32x4 ra[PF], rb[PF];
 #pragma unroll
   for (int i = 0; i < PF; ++i)
@@ -146,9 +152,14 @@ __global__ __launch_bounds__(256) void bj_gram_kernel(const float* __restrict__ 
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          aII = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], a[e], aII, 0, 0, 0);
+          if constexpr (DIAG) {
+            nI += a[e] * a[e];
+            nJ += b[e] * b[e];
+          } else {
+            aII = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], a[e], aII, 0, 0, 0);
+            aJJ = __builtin_amdgcn_mfma_f32_32x32x2f32(b[e], b[e], aJJ, 0, 0, 0);
+          }
           aIJ = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], b[e], aIJ, 0, 0, 0);
-          aJJ = __builtin_amdgcn_mfma_f32_32x32x2f32(b[e], b[e], aJJ, 0, 0, 0);
         }
       }
     }
@@ -159,9 +170,15 @@ __global__ __launch_bounds__(256) void bj_gram_kernel(const float* __restrict__ 
   for (int r = 0; r < 16; ++r) {
     const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
     const int idx = row * 32 + (lane & 31);
-    red[wid][0][idx] = aII[r];
+    if constexpr (DIAG) {
+      const float fI = nI + __shfl_xor(nI, 32, 64), fJ = nJ + __shfl_xor(nJ, 32, 64);   // both column halves of the row
+      red[wid][0][idx] = (row == (lane & 31)) ? fI : 0.f;
+      red[wid][2][idx] = (row == (lane & 31)) ? fJ : 0.f;
+    } else {
+      red[wid][0][idx] = aII[r];
+      red[wid][2][idx] = aJJ[r];
+    }
     red[wid][1][idx] = aIJ[r];
-    red[wid][2][idx] = aJJ[r];
   }
   __syncthreads();
   float* out = Gp + ((int64_t)pair * S + split) * 3072;
@@ -810,6 +827,8 @@ int svd_block_sweeps(T* X, T* R, int64_t P, int64_t Q, char* scratch, int* flag,
   const int sortv = envso ? atoi(envso) : 0;      // de Rijk row ordering inside every pair: A/B knob, off (see bj_eig3_kernel)
   const char* envn = getenv("TNH_SVD_EIGNT");
   const int eig_nt = envn ? atoi(envn) : 1024;   // workgroup size of the LDS eigensolver (A/B knob)
+  const char* envgd = getenv("TNH_SVD_GRAMDIAG");
+  const bool gramdiag = envgd && envgd[0] == '1';
   const char* envb = getenv("TNH_SVD_BCAST");
   const bool bcast = !(envb && envb[0] == '0');   // rotations computed once per pair and broadcast through LDS (A/B knob)
   // Stop rule: a whole sweep that applies no rotation above `tol` (the last sweep only observes).
@@ -861,8 +880,12 @@ int svd_block_sweeps(T* X, T* R, int64_t P, int64_t Q, char* scratch, int* flag,
   auto f32_round = [&](hipStream_t st, const BjGroup& grp, int r, int p0, int np, int cross) {
     if constexpr (!F64) {
       const dim3 ug((unsigned)np, (unsigned)((nssX + nssR + 3) / 4));
-      hipLaunchKernelGGL(bj_gram_kernel, dim3((unsigned)np, (unsigned)S), dim3(256), 0, st, X, Q, nb, r, chunks, cpw, Gp,
-                         p0, grp);
+      if (gramdiag && cross)
+        hipLaunchKernelGGL(bj_gram_kernel<true>, dim3((unsigned)np, (unsigned)S), dim3(256), 0, st, X, Q, nb, r, chunks,
+                           cpw, Gp, p0, grp);
+      else
+        hipLaunchKernelGGL(bj_gram_kernel<false>, dim3((unsigned)np, (unsigned)S), dim3(256), 0, st, X, Q, nb, r, chunks,
+                           cpw, Gp, p0, grp);
 #define TNH_EIG3(NT_, B_)                                                                                        \
   hipLaunchKernelGGL((bj_eig3_kernel<NT_, B_>), dim3((unsigned)np), dim3(NT_), 0, st, Gp, S, J, pairflag, flag, \
                      (float)tol, inner, cross, sortv, p0)
