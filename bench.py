@@ -53,6 +53,7 @@ if ROOT not in sys.path:
   sys.path.insert(0, ROOT)
 
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense, /opt/skills/guides/MI355X_MICROARCH.md:42
+F32_MFMA_PEAK_TFLOPS = 157.3  # dense f32 matrix peak, same table
 HBM_PEAK_GBPS = 8000.0          # spec, MI355X_MICROARCH.md:35 (about 6.3 TB/s achievable)
 MAX_CLOCK_MHZ = 2400.0
 
@@ -267,9 +268,17 @@ def svd_bench(ta, be, n, k, keep_outputs=False):
   be.synchronize()
   t = time.perf_counter() - t0
   nbytes = 4 * (n * n + n * k + n + k * n)  # read A, write u_k, all s, vh_k
+  # matrix-pipe work of the block Jacobi (tnh_svd_block.hip; top-k mode, rotations not accumulated): per sweep
+  # nb - 1 rounds of nb / 2 block pairs (32-row blocks of the padded P x Q working matrix), per pair three
+  # 32 x 32 x Q Gram tiles and the 64 x 64 x Q update
+  P = Q = -(-n // 128) * 128
+  nb = P // 32
+  mfma_flops = be.last_svd_sweeps * (nb - 1) * (nb // 2) * (3 * 2 * 32 * 32 * Q + 2 * 64 * 64 * Q)
   rec = {"n": n, "k": k, "seconds": t, "gbps": nbytes / t / 1e9, "sweeps": be.last_svd_sweeps,
          "algorithmic_bytes": nbytes, "trunc_len": int(trun.shape[0]),
          "hbm_roofline_frac": nbytes / t / 1e9 / HBM_PEAK_GBPS,
+         "mfma_flops": float(mfma_flops), "mfma_tflops": mfma_flops / t / 1e12,
+         "frac_of_f32_mfma_peak": mfma_flops / t / 1e12 / F32_MFMA_PEAK_TFLOPS,
          "workload": f"split_node of a {shape} f32 node as {n}x{n}, max_singular_values={k} (second call; "
                      "first call warms the allocator)",
          "note": "block one-sided Jacobi: MFMA gram/update + LDS eigensolver per block pair; bound by "
