@@ -226,8 +226,17 @@ __global__ __launch_bounds__(256) void qr_col_kernel(T* __restrict__ P, int64_t 
   // 1. reduce the partial dots of column c: 8 row lanes x 32 columns, each lane sums every 8th
   //    workgroup's partial, then the lanes are combined (fixed order: deterministic)
   {
+    // all partials of this lane requested before the first add (nwg <= QR_MAX_WG = 256: <= 32 per lane; clamped
+    // index, no branch around a load): a load / add loop with a runtime bound takes one L2 round trip per partial
+    double pv[QR_MAX_WG / 8];
+#pragma unroll
+    for (int q = 0; q < QR_MAX_WG / 8; ++q) {
+      const int g = ty + 8 * q;
+      pv[q] = part_in[(int64_t)(g < nwg ? g : nwg - 1) * 32 + tx];
+    }
     double s = 0.0;
-    for (int g = ty; g < nwg; g += 8) s += part_in[(int64_t)g * 32 + tx];
+#pragma unroll
+    for (int q = 0; q < QR_MAX_WG / 8; ++q) s += (ty + 8 * q < nwg) ? pv[q] : 0.0;
     colred[ty][tx] = s;
     __syncthreads();
     if (tid < 32) {
