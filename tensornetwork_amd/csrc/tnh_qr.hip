@@ -328,7 +328,17 @@ __global__ __launch_bounds__(1024) void qr_tmat_kernel(const double* __restrict_
   __shared__ double T_s[32][33];
   const int tid = threadIdx.x, tx = tid & 31, ty = tid >> 5;
   double s = 0.0;
-  for (int g = 0; g < nwg; ++g) s += s_part[((int64_t)g * 32 + ty) * 32 + tx];
+  // 16 partials in flight at a time (clamped index, no branch around a load; same summation order)
+  for (int g0 = 0; g0 < nwg; g0 += 16) {
+    double pv[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int g = g0 + q;
+      pv[q] = s_part[((int64_t)(g < nwg ? g : nwg - 1) * 32 + ty) * 32 + tx];
+    }
+#pragma unroll
+    for (int q = 0; q < 16; ++q) s += (g0 + q < nwg) ? pv[q] : 0.0;
+  }
   S_s[ty][tx] = s;     // S[k = ty][tx]
   T_s[ty][tx] = 0.0;
   __syncthreads();

@@ -228,8 +228,13 @@ __global__ __launch_bounds__(256) void bj_eig_kernel(const TG* __restrict__ Gp, 
   for (int e = tid; e < W * W; e += 256) {
     const int i = e >> 6, j = e & 63;
     const int idx = bj_partial_index<TG, TILE>(i, j);
+    // all S <= 16 partials requested before the first add (clamped index, no branch around a load)
+    TG pv[16];
+#pragma unroll
+    for (int s = 0; s < 16; ++s) pv[s] = gp[(int64_t)(s < S ? s : S - 1) * PSZ + idx];
     double acc = 0.0;
-    for (int s = 0; s < S; ++s) acc += (double)gp[(int64_t)s * PSZ + idx];
+#pragma unroll
+    for (int s = 0; s < 16; ++s) acc += (s < S) ? (double)pv[s] : 0.0;
     G[i * LD + j] = acc;
     V[i * LD + j] = (i == j) ? 1.0 : 0.0;
   }
