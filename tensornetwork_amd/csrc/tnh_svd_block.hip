@@ -340,11 +340,15 @@ __device__ __forceinline__ int bj_next_pos(int p) {
   return k >= 1 ? 2 * (k - 1) + 1 : 2;
 }
 
-template <int NT, bool BCAST>
-__global__ __launch_bounds__(NT) void bj_eig3_kernel(const float* __restrict__ Gp, int S,
-                                                     float* __restrict__ Jout, int* __restrict__ pairflag,
-                                                     int* __restrict__ flag, float tol, int max_inner,
+// TT = scalar of G's planes and of the rotation that feeds them: float (f32 path) or double (f64 path: same
+// kernel since round 2 -- the f64 path used the index-space bj_eig_kernel above, 134 us per launch = 79 % of an
+// f64 SVD; V is f64 in both).
+template <int NT, bool BCAST, typename TT>
+__global__ __launch_bounds__(NT) void bj_eig3_kernel(const TT* __restrict__ Gp, int S,
+                                                     TT* __restrict__ Jout, int* __restrict__ pairflag,
+                                                     int* __restrict__ flag, TT tol, int max_inner,
                                                      int cross, int sort, int pair0) {
+  constexpr bool F64 = sizeof(TT) == 8;
   constexpr int W = 64, NG = NT / 32, TPT = 32 / NG, VPT = 64 / NG;
   // Component planes (round 2).  Element (p, q) of G lives in plane (p & 1) * 2 + (q & 1) at [(p >> 1) * 32 + (q >> 1)],
   // V[i][pos] in plane (pos & 1) at [i * 32 + (pos >> 1)].  The scattered writes of a round move every element
@@ -352,14 +356,14 @@ __global__ __launch_bounds__(NT) void bj_eig3_kernel(const float* __restrict__ G
   // conflict).  Round 1 kept a 2 x 2 tile as one float4 and V row-major: one ds_read_b128 per tile, but the writes
   // of a wave then sat 16 bytes apart -- 4-way bank conflicts on all eight scattered writes of a round, which
   // (not the arithmetic, not the barrier) is what the 1.2 us per inner round were.
-  __shared__ float T[2][4 * 1024];
+  __shared__ TT T[2][4 * 1024];
   __shared__ double Vt[2][2 * W * 32];
   __shared__ int rotated;
-  __shared__ float2 cs32[2][32];         // BCAST: (c, s) of the 32 pairs of a round (by round parity), f32 for the tiles ...
+  __shared__ TT cs32[2][32][2];         // BCAST: (c, s) of the 32 pairs of a round (by round parity), f32 for the tiles ...
   __shared__ double2 cs64[2][32];        // ... and f64 (c^2 + s^2 = 1 to f64 accuracy) for V
   const int pair = pair0 + blockIdx.x, tid = threadIdx.x, lane = tid & 63;
-  const float* gp = Gp + (int64_t)pair * S * 3072;
-  float* T0 = &T[0][0];
+  const TT* gp = Gp + (int64_t)pair * S * (F64 ? 2560 : 3072);
+  TT* T0 = &T[0][0];
   const long long ts0 = wall_clock64();
   // cross mode (only pairs with one row in each block are rotated, 32 rounds):
   // position 2k = row k of block I, position 2k+1 = a row of block J; the J side
@@ -373,9 +377,10 @@ __global__ __launch_bounds__(NT) void bj_eig3_kernel(const float* __restrict__ G
   // tiles (768 float4 groups, 8 loads each at 4096^2) -- the lower-left block of G is the mirror of IJ and is
   // written from the same registers.  Round 1 read dword by dword, 32 dependent round trips per thread; measured
   // with wall_clock64 the prologue was 12 of the kernel's 37 us.
+  if constexpr (!F64) {
   for (int q = tid; q < 768; q += NT) {
     const int t = q >> 8, row = (q & 255) >> 3, c4 = (q & 7) * 4;
-    const float* src = gp + t * 1024 + row * 32 + c4;
+    const float* src = (const float*)gp + t * 1024 + row * 32 + c4;
     f32x4 part[16];
 #pragma unroll
     for (int sI = 0; sI < 8; ++sI) part[sI] = *(const f32x4*)(src + (sI < S ? sI : S - 1) * 3072);
@@ -397,9 +402,24 @@ __global__ __launch_bounds__(NT) void bj_eig3_kernel(const float* __restrict__ G
     for (int u = 0; u < 4; ++u) {
       const int j = (t == 0 ? 0 : 32) + c4 + u;
       const int pj = pos_of(j);
-      const float v = (float)acc[u];
+      const TT v = (TT)acc[u];
       T0[((pi & 1) * 2 + (pj & 1)) * 1024 + (pi >> 1) * 32 + (pj >> 1)] = v;
       if (t == 1) T0[((pj & 1) * 2 + (pi & 1)) * 1024 + (pj >> 1) * 32 + (pi >> 1)] = v;   // G[j][i]
+    }
+  }
+  } else {
+    // f64 partials: the 10 upper 16 x 16 tiles of the f64 gram kernel; all S <= 16 partials of an element in flight
+    for (int e = tid; e < W * W; e += NT) {
+      const int i = e >> 6, j = e & 63;
+      const int idx = bj_partial_index<double, 16>(i, j);
+      double pv[16];
+#pragma unroll
+      for (int sI = 0; sI < 16; ++sI) pv[sI] = (double)gp[(int64_t)(sI < S ? sI : S - 1) * 2560 + idx];
+      double acc = 0.0;
+#pragma unroll
+      for (int sI = 0; sI < 16; ++sI) acc += (sI < S) ? pv[sI] : 0.0;
+      const int pi = pos_of(i), pj = pos_of(j);
+      T0[((pi & 1) * 2 + (pj & 1)) * 1024 + (pi >> 1) * 32 + (pj >> 1)] = (TT)acc;
     }
   }
   for (int e = tid; e < W * W; e += NT) {
@@ -429,74 +449,89 @@ __global__ __launch_bounds__(NT) void bj_eig3_kernel(const float* __restrict__ G
   float thmax2 = 0.f;  // largest g_pq^2 / (g_pp g_qq) met by this workgroup (convergence telemetry, flag[1] = its root)
   // Rotation of pair l from its diagonal elements (c, s in f32 for the tiles, in f64 with c^2 + s^2 = 1 to f64
   // accuracy for V).  Threshold and telemetry on squares: no square roots outside the rotation itself.
-  auto rotation = [&](const float* Tb, float& c32, float& s32, double& c64, double& s64, bool leader) {
-    const float gpp = Tb[l * 33], gpq = Tb[1024 + l * 33], gqq = Tb[3072 + l * 33];
-    float tf = 0.f;
-    const float dd = fabsf(gpp) * fabsf(gqq), qq = gpq * gpq;
-    if (leader && dd > 0.f) thmax2 = fmaxf(thmax2, qq * __builtin_amdgcn_rcpf(dd));
-    if (qq > tol * tol * dd) {
-      const float zeta = (gqq - gpp) * __builtin_amdgcn_rcpf(2.0f * gpq);
-      const float den = fabsf(zeta) + __builtin_amdgcn_sqrtf(1.0f + zeta * zeta);
-      tf = __builtin_amdgcn_rcpf(den);
-      tf = (zeta >= 0.f) ? tf : -tf;
-      if (!(fabsf(tf) <= 1.0f)) tf = 0.f;  // inf / nan guard
-      if (leader && tf != 0.f) rotated = 1;
+  auto rotation = [&](const TT* Tb, TT& c32, TT& s32, double& c64, double& s64, bool leader) {
+    const TT gpp = Tb[l * 33], gpq = Tb[1024 + l * 33], gqq = Tb[3072 + l * 33];
+    if constexpr (F64) {
+      double t = 0.0;
+      const double dd = fabs(gpp) * fabs(gqq), qq = gpq * gpq;
+      if (leader && dd > 0.0) thmax2 = fmaxf(thmax2, (float)(qq / dd));
+      if (qq > tol * tol * dd) {
+        const double zeta = (gqq - gpp) / (2.0 * gpq);
+        t = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+        if (!(fabs(t) <= 1.0)) t = 0.0;  // inf / nan guard
+        if (leader && t != 0.0) rotated = 1;
+      }
+      c64 = 1.0 / sqrt(1.0 + t * t);
+      s64 = c64 * t;
+      c32 = c64;
+      s32 = s64;
+    } else {
+      float tf = 0.f;
+      const float dd = fabsf(gpp) * fabsf(gqq), qq = gpq * gpq;
+      if (leader && dd > 0.f) thmax2 = fmaxf(thmax2, qq * __builtin_amdgcn_rcpf(dd));
+      if (qq > tol * tol * dd) {
+        const float zeta = (gqq - gpp) * __builtin_amdgcn_rcpf(2.0f * gpq);
+        const float den = fabsf(zeta) + __builtin_amdgcn_sqrtf(1.0f + zeta * zeta);
+        tf = __builtin_amdgcn_rcpf(den);
+        tf = (zeta >= 0.f) ? tf : -tf;
+        if (!(fabsf(tf) <= 1.0f)) tf = 0.f;  // inf / nan guard
+        if (leader && tf != 0.f) rotated = 1;
+      }
+      c32 = __builtin_amdgcn_rsqf(1.0f + tf * tf);
+      s32 = c32 * tf;
+      const double t = (double)tf, x = 1.0 + t * t;
+      double y = (double)c32;          // 1 ulp of f32; one Newton step: c^2 + s^2 = 1 to 2^-46
+      y = y * (1.5 - 0.5 * x * y * y);
+      c64 = y;
+      s64 = y * t;
     }
-    c32 = __builtin_amdgcn_rsqf(1.0f + tf * tf);
-    s32 = c32 * tf;
-    const double t = (double)tf, x = 1.0 + t * t;
-    double y = (double)c32;          // 1 ulp of f32; one Newton step: c^2 + s^2 = 1 to 2^-46
-    y = y * (1.5 - 0.5 * x * y * y);
-    c64 = y;
-    s64 = y * t;
   };
   for (int sweep = 0; sweep < max_inner; ++sweep) {
     if constexpr (BCAST) {
       // rotations of round 0 (later rounds: computed by wave 0 while the other waves update V, see below)
       __syncthreads();
       if (tid < 32) {
-        float c32, s32;
+        TT c32, s32;
         double c64, s64;
         rotation(T[cur], c32, s32, c64, s64, true);
-        cs32[0][l] = make_float2(c32, s32);
+        cs32[0][l][0] = c32;
+        cs32[0][l][1] = s32;
         cs64[0][l] = make_double2(c64, s64);
       }
     }
     for (int r = 0; r < nrounds; ++r) {
       __syncthreads();
-      const float* Tc = T[cur];
-      float* Tn = T[cur ^ 1];
+      const TT* Tc = T[cur];
+      TT* Tn = T[cur ^ 1];
       const double* Vc = Vt[cur];
       double* Vn = Vt[cur ^ 1];
-      float clf, slf;
+      TT clf, slf;
       double cl, sl;
       if constexpr (BCAST) {
         // ONE rotation per pair, broadcast through LDS (double-buffered by round parity).  Round 1 had every
         // thread derive its own copy and fetch its row partner's by shuffle.
-        const float2 m = cs32[r & 1][l];
-        clf = m.x;
-        slf = m.y;
+        clf = cs32[r & 1][l][0];
+        slf = cs32[r & 1][l][1];
       } else {
         rotation(Tc, clf, slf, cl, sl, g == 0);
       }
 #pragma unroll
       for (int jj = 0; jj < TPT; ++jj) {
         const int k = g + NG * jj;
-        float ck, sk;
+        TT ck, sk;
         if constexpr (BCAST) {
-          const float2 mk = cs32[r & 1][k];
-          ck = mk.x;
-          sk = mk.y;
+          ck = cs32[r & 1][k][0];
+          sk = cs32[r & 1][k][1];
         } else {
           ck = __shfl(clf, k | src_half, 64);
           sk = __shfl(slf, k | src_half, 64);
         }
-        const float t0 = Tc[k * 32 + l], t1 = Tc[1024 + k * 32 + l], t2 = Tc[2048 + k * 32 + l], t3 = Tc[3072 + k * 32 + l];
-        const float u00 = ck * t0 - sk * t2, u01 = ck * t1 - sk * t3;
-        const float u10 = sk * t0 + ck * t2, u11 = sk * t1 + ck * t3;
-        float v00 = clf * u00 - slf * u01, v01 = slf * u00 + clf * u01;
-        float v10 = clf * u10 - slf * u11, v11 = slf * u10 + clf * u11;
-        if (k == l && slf != 0.f) v01 = v10 = 0.f;  // the annihilated element
+        const TT t0 = Tc[k * 32 + l], t1 = Tc[1024 + k * 32 + l], t2 = Tc[2048 + k * 32 + l], t3 = Tc[3072 + k * 32 + l];
+        const TT u00 = ck * t0 - sk * t2, u01 = ck * t1 - sk * t3;
+        const TT u10 = sk * t0 + ck * t2, u11 = sk * t1 + ck * t3;
+        TT v00 = clf * u00 - slf * u01, v01 = slf * u00 + clf * u01;
+        TT v10 = clf * u10 - slf * u11, v11 = slf * u10 + clf * u11;
+        if (k == l && slf != (TT)0) v01 = v10 = (TT)0;  // the annihilated element
         Tn[dst[jj][0]] = v00;
         Tn[dst[jj][1]] = v01;
         Tn[dst[jj][2]] = v10;
@@ -510,10 +545,11 @@ __global__ __launch_bounds__(NT) void bj_eig3_kernel(const float* __restrict__ G
         // wave 0 derives the NEXT round's rotations from them while everybody (wave 0 last) moves V: the
         // dependent chain of reciprocal / square-root steps hides behind the f64 work of the other 15 waves
         if (tid < 32 && r + 1 < nrounds) {
-          float c32, s32;
+          TT c32, s32;
           double c64, s64;
           rotation(Tn, c32, s32, c64, s64, true);
-          cs32[(r + 1) & 1][l] = make_float2(c32, s32);
+          cs32[(r + 1) & 1][l][0] = c32;
+          cs32[(r + 1) & 1][l][1] = s32;
           cs64[(r + 1) & 1][l] = make_double2(c64, s64);
         }
       }
@@ -537,7 +573,7 @@ __global__ __launch_bounds__(NT) void bj_eig3_kernel(const float* __restrict__ G
   const long long ts2 = wall_clock64();
   // whole sweeps = full periods of the permutation: positions are back where they started
   const double* Vf = Vt[cur];
-  float* jo = Jout + (int64_t)pair * (W * W);
+  TT* jo = Jout + (int64_t)pair * (W * W);
   // de Rijk ordering (A/B knob TNH_SVD_SORT=1, default off): the rotated rows leave the pair sorted by
   // decreasing norm, the 32 largest into the lower-numbered block.  Measured on MI355X it does not pay in
   // this block scheme: 4096^2 Gaussian 17 -> 20 sweeps, 2048^2 with s_i = 2^(-i/32) 37 -> 35.
@@ -548,7 +584,7 @@ __global__ __launch_bounds__(NT) void bj_eig3_kernel(const float* __restrict__ G
     __syncthreads();
     if (tid < W) {
       const int pi = pos_of(tid);
-      dg[tid] = T[cur][(pi & 1) * 3 * 1024 + (pi >> 1) * 33];
+      dg[tid] = (float)T[cur][(pi & 1) * 3 * 1024 + (pi >> 1) * 33];
     }
     __syncthreads();
     if (tid < W) {
@@ -567,7 +603,7 @@ __global__ __launch_bounds__(NT) void bj_eig3_kernel(const float* __restrict__ G
   __syncthreads();
   for (int e = tid; e < W * W; e += NT) {
     const int pp = pos_of(e & 63);
-    jo[(e >> 6) * W + rank[e & 63]] = (float)Vf[(pp & 1) * 2048 + (e >> 6) * 32 + (pp >> 1)];
+    jo[(e >> 6) * W + rank[e & 63]] = (TT)Vf[(pp & 1) * 2048 + (e >> 6) * 32 + (pp >> 1)];
   }
   if (tid < 64) {   // wave 0 holds the g == 0 lanes (tid < 32)
     float m = __builtin_amdgcn_sqrtf(thmax2);
@@ -832,6 +868,8 @@ int svd_block_sweeps(T* X, T* R, int64_t P, int64_t Q, char* scratch, int* flag,
   const int sortv = envso ? atoi(envso) : 0;      // de Rijk row ordering inside every pair: A/B knob, off (see bj_eig3_kernel)
   const char* envn = getenv("TNH_SVD_EIGNT");
   const int eig_nt = envn ? atoi(envn) : 1024;   // workgroup size of the LDS eigensolver (A/B knob)
+  const char* enve64 = getenv("TNH_SVD_EIG64");
+  const bool eig64_new = !(enve64 && enve64[0] == '0');   // f64 path on the position-space eigensolver (A/B knob)
   const char* envgd = getenv("TNH_SVD_GRAMDIAG");
   const bool gramdiag = envgd && envgd[0] == '1';
   const char* envb = getenv("TNH_SVD_BCAST");
@@ -891,8 +929,8 @@ int svd_block_sweeps(T* X, T* R, int64_t P, int64_t Q, char* scratch, int* flag,
       else
         hipLaunchKernelGGL(bj_gram_kernel<false>, dim3((unsigned)np, (unsigned)S), dim3(256), 0, st, X, Q, nb, r, chunks,
                            cpw, Gp, p0, grp);
-#define TNH_EIG3(NT_, B_)                                                                                        \
-  hipLaunchKernelGGL((bj_eig3_kernel<NT_, B_>), dim3((unsigned)np), dim3(NT_), 0, st, Gp, S, J, pairflag, flag, \
+#define TNH_EIG3(NT_, B_)                                                                                               \
+  hipLaunchKernelGGL((bj_eig3_kernel<NT_, B_, float>), dim3((unsigned)np), dim3(NT_), 0, st, Gp, S, J, pairflag, flag, \
                      (float)tol, inner, cross, sortv, p0)
       if (eig_nt == 512) { if (bcast) TNH_EIG3(512, true); else TNH_EIG3(512, false); }
       else if (eig_nt == 256) { if (bcast) TNH_EIG3(256, true); else TNH_EIG3(256, false); }
@@ -913,8 +951,12 @@ int svd_block_sweeps(T* X, T* R, int64_t P, int64_t Q, char* scratch, int* flag,
         const dim3 ugrid((unsigned)pairs, (unsigned)((nssX + nssR + 3) / 4));
         hipLaunchKernelGGL(bj_gram64_kernel, dim3((unsigned)pairs, (unsigned)S), dim3(256), 0, stream(), X, Q, nb, r,
                            chunks, cpw, Gp);
-        hipLaunchKernelGGL((bj_eig_kernel<double, 16>), dim3((unsigned)pairs), dim3(256), 0, stream(), Gp, S, J,
-                           pairflag, flag, tol, inner, 0);
+        if (eig64_new)
+          hipLaunchKernelGGL((bj_eig3_kernel<1024, true, double>), dim3((unsigned)pairs), dim3(1024), 0, stream(), Gp, S, J,
+                             pairflag, flag, tol, inner, (crossv && r > 0) ? 1 : 0, 0, 0);
+        else
+          hipLaunchKernelGGL((bj_eig_kernel<double, 16>), dim3((unsigned)pairs), dim3(256), 0, stream(), Gp, S, J,
+                             pairflag, flag, tol, inner, 0);
         hipLaunchKernelGGL(bj_update64_kernel, ugrid, dim3(256), 0, stream(), X, Q, nssX, R, P, nssR, nb, r, J,
                            pairflag);
       }
