@@ -699,11 +699,11 @@ typedef double f64x2 __attribute__((ext_vector_type(2)));
 
 __global__ __launch_bounds__(256) void bj_gram64_kernel(const double* __restrict__ X, int64_t ldx, int nb,
                                                         int round, int chunks, int cpw,
-                                                        double* __restrict__ Gp) {
+                                                        double* __restrict__ Gp, int pair0, BjGroup grp) {
   __shared__ double red[4][10 * 256];
-  const int pair = blockIdx.x, split = blockIdx.y, S = gridDim.y;
+  const int pair = pair0 + blockIdx.x, split = blockIdx.y, S = gridDim.y;
   int bi, bj;
-  bj_pair(nb, round, pair, bi, bj);
+  bj_pair_group(grp, round, (int)blockIdx.x, bi, bj);
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const double* xr[4];
 #pragma unroll
@@ -749,14 +749,14 @@ __global__ __launch_bounds__(256) void bj_gram64_kernel(const double* __restrict
 __global__ __launch_bounds__(256) void bj_update64_kernel(double* __restrict__ X, int64_t ldx, int nssX,
                                                           double* __restrict__ R, int64_t ldr, int nssR,
                                                           int nb, int round, const double* __restrict__ J,
-                                                          const int* __restrict__ pairflag) {
-  const int pair = blockIdx.x;
+                                                          const int* __restrict__ pairflag, int pair0, BjGroup grp) {
+  const int pair = pair0 + blockIdx.x;
   if (!pairflag[pair]) return;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int ss = blockIdx.y * 4 + wid;
   if (ss >= nssX + nssR) return;
   int bi, bj;
-  bj_pair(nb, round, pair, bi, bj);
+  bj_pair_group(grp, round, (int)blockIdx.x, bi, bj);
   double* base;
   int64_t ld;
   if (ss < nssX) { base = X + (int64_t)ss * 32; ld = ldx; }
@@ -884,21 +884,23 @@ int svd_block_sweeps(T* X, T* R, int64_t P, int64_t Q, char* scratch, int* flag,
   const char* envs = getenv("TNH_SVD_STOP");
   const float stop_theta = F64 ? 0.f : (envs ? (float)atof(envs) : 0.f);
   const bool trace = getenv("TNH_SVD_TRACE") != nullptr;
-  // Grouped schedule (see BjGroup): default for the f32 path, G = 2 when nb % 4 == 0, else the plain circle method on
-  // one stream; never inside a graph capture.  TNH_SVD_SCHED=1 / 2 / 4 forces the group count.  Measured on MI355X
+  // Grouped schedule (see BjGroup): G = 2 when nb % 4 == 0 and nb >= 64 (f32 and f64), else the plain circle method
+  // on one stream; never inside a graph capture.  TNH_SVD_SCHED=1 / 2 / 4 forces the group count.  Measured on MI355X
   // (4096^2 / 2048^2 / 1024^2 / 512^2): G = 1 0.165 / 0.051 / 0.021 / 0.0093 s, G = 2 0.147 / 0.049 / 0.022 / 0.0095 s,
   // G = 4 0.139 (15 instead of 16 sweeps; the same 9.2 ms per sweep as G = 2) / 0.055 / 0.025 / 0.0126 s: the overlap
   // is exhausted with two chains, more streams only add launches.  (Round 2 also tried the SAME circle round cut into G groups on G streams with a fork /
   // join per round, TNH_SVD_GROUPS: G = 2 / 3 / 4 -> 0.243 / 0.269 / 0.307 s against 0.216 -- the per-round events
   // cost more than the overlap returned.  This schedule needs cross-stream events only at the phase boundaries.)
   int G = 1;
-  if (!F64) {
-    if (nb % 4 == 0 && nb >= 8) G = 2;
+  {
+    // two chains pay from 2048 rows on (f32 1024^2: 0.0206 s on one stream, 0.0216 s on two; f64 512^2: 0.0150 / 0.0174)
+    if (nb % 4 == 0 && nb >= 64) G = 2;
     if (const char* envg = getenv("TNH_SVD_SCHED")) {
       const int want = atoi(envg);
       if (want == 1 || (want == 2 && nb % 4 == 0 && nb >= 8) || (want == 4 && nb % 8 == 0 && nb >= 16)) G = want;
     }
   }
+  if (F64 && !eig64_new) G = 1;
   if (G > 1) {
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     (void)hipStreamIsCapturing(stream(), &cap);
@@ -921,6 +923,18 @@ int svd_block_sweeps(T* X, T* R, int64_t P, int64_t Q, char* scratch, int* flag,
   };
   // one round of a group: `np` pairs whose Gram / J slots start at global pair index p0, on stream st
   auto f32_round = [&](hipStream_t st, const BjGroup& grp, int r, int p0, int np, int cross) {
+    if constexpr (F64) {
+      const dim3 ug((unsigned)np, (unsigned)((nssX + nssR + 3) / 4));
+      hipLaunchKernelGGL(bj_gram64_kernel, dim3((unsigned)np, (unsigned)S), dim3(256), 0, st, X, Q, nb, r, chunks, cpw, Gp,
+                         p0, grp);
+      if (eig64_new)
+        hipLaunchKernelGGL((bj_eig3_kernel<1024, true, double>), dim3((unsigned)np), dim3(1024), 0, st, Gp, S, J, pairflag,
+                           flag, tol, inner, cross, 0, p0);
+      else   // (round-1 eigensolver: A/B only; it has no pair offset, so it runs ungrouped -- see below)
+        hipLaunchKernelGGL((bj_eig_kernel<double, 16>), dim3((unsigned)np), dim3(256), 0, st, Gp, S, J, pairflag, flag,
+                           tol, inner, 0);
+      hipLaunchKernelGGL(bj_update64_kernel, ug, dim3(256), 0, st, X, Q, nssX, R, P, nssR, nb, r, J, pairflag, p0, grp);
+    }
     if constexpr (!F64) {
       const dim3 ug((unsigned)np, (unsigned)((nssX + nssR + 3) / 4));
       if (gramdiag && cross)
@@ -946,21 +960,7 @@ int svd_block_sweeps(T* X, T* R, int64_t P, int64_t Q, char* scratch, int* flag,
   bool converged = false;
   while (!converged && sweeps < max_sweeps) {
     TNH_HIP(hipMemsetAsync(flag, 0, 4 * sizeof(int), stream()));
-    if constexpr (F64) {
-      for (int r = 0; r < nb - 1; ++r) {
-        const dim3 ugrid((unsigned)pairs, (unsigned)((nssX + nssR + 3) / 4));
-        hipLaunchKernelGGL(bj_gram64_kernel, dim3((unsigned)pairs, (unsigned)S), dim3(256), 0, stream(), X, Q, nb, r,
-                           chunks, cpw, Gp);
-        if (eig64_new)
-          hipLaunchKernelGGL((bj_eig3_kernel<1024, true, double>), dim3((unsigned)pairs), dim3(1024), 0, stream(), Gp, S, J,
-                             pairflag, flag, tol, inner, (crossv && r > 0) ? 1 : 0, 0, 0);
-        else
-          hipLaunchKernelGGL((bj_eig_kernel<double, 16>), dim3((unsigned)pairs), dim3(256), 0, stream(), Gp, S, J,
-                             pairflag, flag, tol, inner, 0);
-        hipLaunchKernelGGL(bj_update64_kernel, ugrid, dim3(256), 0, stream(), X, Q, nssX, R, P, nssR, nb, r, J,
-                           pairflag);
-      }
-    } else if (G > 1) {
+    if (G > 1) {
       const int np = pairs / G;   // pairs per group (part / 2 in the first phase, hq in the others)
       int rc = cross_sync();
       if (rc) return rc;
