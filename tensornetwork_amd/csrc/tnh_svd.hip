@@ -201,7 +201,9 @@ static int svd_factor_block(const SvdLayout& L, int dtype, int64_t m, int64_t n,
   }
   const double eps = (sizeof(T) == 4) ? 5.9604644775390625e-08 : 1.1102230246251565e-16;
   const double tol = eps * sqrt((double)L.q);
-  const int max_sweeps = 40;
+  // graded inputs (singular values over many decades: every DMRG split) need far more sweeps than Gaussian ones
+  // (f64 2^-i, n = 256: 36); 40 was not enough for f64 DMRG at D = 256
+  const int max_sweeps = 120;
   int sweeps = 0;
   bool converged = false;
   rc = svd_block_sweeps<T>(X, R, P, Q, work + L.off_scratch, flag, tol, max_sweeps, &sweeps, &converged);

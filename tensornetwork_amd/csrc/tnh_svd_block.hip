@@ -446,16 +446,17 @@ __global__ __launch_bounds__(NT) void bj_eig3_kernel(const TT* __restrict__ Gp, 
   __syncthreads();
   const long long ts1 = wall_clock64();
   int any = 0, cur = 0;
-  float thmax2 = 0.f;  // largest g_pq^2 / (g_pp g_qq) met by this workgroup (convergence telemetry, flag[1] = its root)
+  float thmax = 0.f;   // largest |g_pq| / sqrt(g_pp g_qq) met by this workgroup (convergence telemetry, flag[1])
   // Rotation of pair l from its diagonal elements (c, s in f32 for the tiles, in f64 with c^2 + s^2 = 1 to f64
-  // accuracy for V).  Threshold and telemetry on squares: no square roots outside the rotation itself.
+  // accuracy for V).  (An absolute floor on the row norms -- skip pairs with a row below eps |A|_F -- was tried for
+  // graded inputs: it converges in fewer sweeps but leaves the near-null vectors non-orthogonal; not kept.)
   auto rotation = [&](const TT* Tb, TT& c32, TT& s32, double& c64, double& s64, bool leader) {
     const TT gpp = Tb[l * 33], gpq = Tb[1024 + l * 33], gqq = Tb[3072 + l * 33];
     if constexpr (F64) {
       double t = 0.0;
-      const double dd = fabs(gpp) * fabs(gqq), qq = gpq * gpq;
-      if (leader && dd > 0.0) thmax2 = fmaxf(thmax2, (float)(qq / dd));
-      if (qq > tol * tol * dd) {
+      const double gden = sqrt(fabs(gpp)) * sqrt(fabs(gqq));   // (not sqrt(gpp gqq): the product underflows on graded inputs)
+      if (leader && gden > 0.0) thmax = fmaxf(thmax, (float)(fabs(gpq) / gden));
+      if (fabs(gpq) > tol * gden) {
         const double zeta = (gqq - gpp) / (2.0 * gpq);
         t = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
         if (!(fabs(t) <= 1.0)) t = 0.0;  // inf / nan guard
@@ -467,9 +468,12 @@ __global__ __launch_bounds__(NT) void bj_eig3_kernel(const TT* __restrict__ Gp, 
       s32 = s64;
     } else {
       float tf = 0.f;
-      const float dd = fabsf(gpp) * fabsf(gqq), qq = gpq * gpq;
-      if (leader && dd > 0.f) thmax2 = fmaxf(thmax2, qq * __builtin_amdgcn_rcpf(dd));
-      if (qq > tol * tol * dd) {
+      // |g_pq| against tol sqrt(g_pp) sqrt(g_qq) with the two roots taken separately: g_pp g_qq and g_pq^2 underflow
+      // in f32 as soon as two rows are below 1e-10 of the largest (every graded / rank-deficient input), and a test
+      // on the squares then reads "already orthogonal" for rows that are not (caught by tools/svd_graded_probe.py)
+      const float gden = __builtin_amdgcn_sqrtf(fabsf(gpp)) * __builtin_amdgcn_sqrtf(fabsf(gqq));
+      if (leader && gden > 0.f) thmax = fmaxf(thmax, fabsf(gpq) * __builtin_amdgcn_rcpf(gden));
+      if (fabsf(gpq) > tol * gden) {
         const float zeta = (gqq - gpp) * __builtin_amdgcn_rcpf(2.0f * gpq);
         const float den = fabsf(zeta) + __builtin_amdgcn_sqrtf(1.0f + zeta * zeta);
         tf = __builtin_amdgcn_rcpf(den);
@@ -606,7 +610,7 @@ __global__ __launch_bounds__(NT) void bj_eig3_kernel(const TT* __restrict__ Gp, 
     jo[(e >> 6) * W + rank[e & 63]] = (TT)Vf[(pp & 1) * 2048 + (e >> 6) * 32 + (pp >> 1)];
   }
   if (tid < 64) {   // wave 0 holds the g == 0 lanes (tid < 32)
-    float m = __builtin_amdgcn_sqrtf(thmax2);
+    float m = thmax;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
     if (tid == 0) atomicMax((unsigned int*)(flag + 1), __float_as_uint(m));

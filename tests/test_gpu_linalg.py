@@ -314,3 +314,35 @@ def test_tensor_and_functional_api_on_device(hip):
   suite's checker (tests/cases.py:check_tensor_api) with HipBackend."""
   import cases
   cases.check_tensor_api(hip, 1e-9)
+
+
+@pytest.mark.parametrize("dtype,stol,otol", [(np.float32, 2e-6, 2e-5), (np.float64, 1e-12, 1e-11)])
+@pytest.mark.parametrize("n,kind", [(256, "graded2"), (256, "rank40"), (384, "dmrg_like"), (256, "zero_rows")])
+def test_svd_graded_and_rank_deficient_block_path(hip, dtype, stol, otol, n, kind):
+  """Block Jacobi on inputs whose singular values span many decades or vanish (what every DMRG split
+  hands to svd): all singular values to eps * s_1 against LAPACK, U and Vh orthonormal INCLUDING the
+  near-null vectors, reconstruction to eps.  Regression: a rotation test on squared Gram entries underflowed
+  in f32 (rows below 1e-10 of the largest read "already orthogonal"), and 40 sweeps were not enough for f64."""
+  rng = np.random.default_rng(5)
+  u, _ = np.linalg.qr(rng.standard_normal((n, n)))
+  v, _ = np.linalg.qr(rng.standard_normal((n, n)))
+  if kind == "graded2":
+    s = 2.0 ** -np.arange(n)
+  elif kind == "rank40":
+    s = np.concatenate([np.linspace(1, 0.1, 40), np.zeros(n - 40)])
+  elif kind == "zero_rows":
+    s = np.concatenate([np.ones(n // 2), np.zeros(n - n // 2)])
+  else:
+    s = np.exp(-np.arange(n) / 6.0)
+  a = (u * s) @ v.T
+  if kind == "zero_rows":
+    a[::3] = 0.0
+  a = a.astype(dtype)
+  uu, ss, vv, _ = hip.svd(hip.convert_to_tensor(a), 1)
+  a64 = a.astype(np.float64)
+  s_ref = np.linalg.svd(a64, compute_uv=False)
+  uh, sh, vh = (np.asarray(t).astype(np.float64) for t in (uu, ss, vv))
+  assert np.abs(sh - s_ref).max() <= stol * s_ref[0]
+  assert np.abs(uh.T @ uh - np.eye(n)).max() <= otol
+  assert np.abs(vh @ vh.T - np.eye(n)).max() <= otol
+  assert np.abs((uh * sh) @ vh - a64).max() <= 10 * stol * s_ref[0]
