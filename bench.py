@@ -93,6 +93,8 @@ class TorchComm:
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29511")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if os.environ["MASTER_ADDR"].startswith("127.") or os.environ["MASTER_ADDR"] in ("localhost", "::1"):
+      os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")   # see tensornetwork_amd.comm.single_node_rccl_env
     torch.cuda.set_device(local)
     dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
     self._torch, self._dist = torch, dist

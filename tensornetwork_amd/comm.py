@@ -120,6 +120,16 @@ class HostRendezvous:
       self._sock = None
 
 
+def single_node_rccl_env():
+  """One node, rendezvous on loopback: pin RCCL's bootstrap sockets to `lo` unless the user chose an interface.
+  Measured on the MI355X box (tools/rccl_two_ranks_one_gpu.py): with RCCL's own interface choice two ranks never
+  get out of `ncclCommInitRank` (no error, no return within 150 s -- the sandbox has no routable interface);
+  with NCCL_SOCKET_IFNAME=lo the same call answers in seconds."""
+  addr = os.environ.get("MASTER_ADDR", "127.0.0.1")
+  if addr.startswith("127.") or addr in ("localhost", "::1"):
+    os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
+
+
 def env_rank_world():
   return (int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")),
           int(os.environ.get("LOCAL_RANK", "0")))
@@ -135,6 +145,7 @@ class RcclComm:
     self.world = int(env_world if world is None else world)
     self._be = backend
     self._lib = backend.lib
+    single_node_rccl_env()
     self._rdv = rendezvous if rendezvous is not None else HostRendezvous(self.rank, self.world)
     try:
       self._bootstrap()

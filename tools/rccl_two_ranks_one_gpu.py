@@ -21,13 +21,13 @@ except RuntimeError as exc:
   print("rank", rank, "RuntimeError:", str(exc)[:160], flush=True)
 ''' % ROOT
 env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29611", WORLD_SIZE="2", TNHIP_DEVICE="0",
-           HSA_ENABLE_IPC_MODE_LEGACY="0")
+           HSA_ENABLE_IPC_MODE_LEGACY="0")   # (NCCL_SOCKET_IFNAME: left to RcclComm -- tensornetwork_amd.comm.single_node_rccl_env)
 procs = [subprocess.Popen([sys.executable, "-c", CHILD], env=dict(env, RANK=str(r))) for r in range(2)]
 t0 = time.time()
 codes = []
 for p in procs:
   try:
-    codes.append(p.wait(timeout=150 - (time.time() - t0)))
+    codes.append(p.wait(timeout=float(os.environ.get("PROBE_TIMEOUT", "150")) - (time.time() - t0)))
   except subprocess.TimeoutExpired:
     p.kill(); codes.append("timeout")
 print("exit codes", codes, "seconds", round(time.time() - t0, 1))
