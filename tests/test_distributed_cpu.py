@@ -253,3 +253,20 @@ def test_rccl_bootstrap_failure_raises_on_every_rank(tmp_path):
       outcome = f.read()
     assert outcome.startswith("RuntimeError"), outcome
     assert "rank" in outcome
+
+
+def test_single_node_rccl_env_pins_loopback(monkeypatch):
+  """One node (MASTER_ADDR on loopback): RCCL's bootstrap sockets are pinned to `lo` unless the user chose an
+  interface; a routable MASTER_ADDR is left alone."""
+  from tensornetwork_amd import comm
+  monkeypatch.delenv("NCCL_SOCKET_IFNAME", raising=False)
+  monkeypatch.setenv("MASTER_ADDR", "127.0.0.1")
+  comm.single_node_rccl_env()
+  assert os.environ["NCCL_SOCKET_IFNAME"] == "lo"
+  monkeypatch.setenv("NCCL_SOCKET_IFNAME", "eth7")
+  comm.single_node_rccl_env()
+  assert os.environ["NCCL_SOCKET_IFNAME"] == "eth7"
+  monkeypatch.delenv("NCCL_SOCKET_IFNAME")
+  monkeypatch.setenv("MASTER_ADDR", "10.1.2.3")
+  comm.single_node_rccl_env()
+  assert "NCCL_SOCKET_IFNAME" not in os.environ
