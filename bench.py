@@ -673,6 +673,10 @@ def main():
   local = int(os.environ.get("LOCAL_RANK", "0"))
   use_dist = world > 1 or bool(os.environ.get("TNH_BENCH_FORCE_DIST"))
   if use_dist:
+    # before any HIP runtime comes up in this process: the host driver only supports dmabuf IPC
+    # (RCCL / cross-process device memory fail with hipIpcGetMemHandle otherwise); already exported on the boxes
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+  if use_dist:
     assert world == args.gpus or os.environ.get("TNH_BENCH_FORCE_DIST"), (world, args.gpus)
   comm, comm_name = None, "none"
   if use_dist and args.comm == "torch":
