@@ -270,3 +270,38 @@ def test_single_node_rccl_env_pins_loopback(monkeypatch):
   monkeypatch.setenv("MASTER_ADDR", "10.1.2.3")
   comm.single_node_rccl_env()
   assert "NCCL_SOCKET_IFNAME" not in os.environ
+
+
+def _bench_fallback_worker(rank, world, port, out_path):
+  root = os.path.dirname(HERE)
+  sys.path.insert(0, root)
+  os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), TNH_BENCH_NO_REEXEC="1", TNH_COMM_PORT_OFFSET="0")
+  import importlib
+  from tensornetwork_amd import _lib, comm
+  importlib.reload(comm)      # pick up TNH_COMM_PORT_OFFSET
+  import bench
+
+  class _NoGpuBackend:
+    lib = _lib.load_library()
+
+  try:
+    bench.make_rccl_comm(comm, _NoGpuBackend(), rank, world)
+    outcome = "created"
+  except RuntimeError as exc:
+    outcome = f"RuntimeError: {exc}"
+  with open(out_path + f".{rank}.txt", "w") as f:
+    f.write(outcome)
+
+
+def test_bench_rccl_fallback_is_taken_in_step(tmp_path):
+  """bench.make_rccl_comm: when the K8 communicator cannot come up (no GPU here) EVERY rank reaches the fall-back
+  branch (here: the 'no re-exec' guard instead of the execv into --comm torch), none hangs in an exchange."""
+  import torch.multiprocessing as mp
+  with socket.socket() as s:
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+  out_path = str(tmp_path / "fb")
+  mp.spawn(_bench_fallback_worker, args=(2, port, out_path), nprocs=2, join=True)
+  for r in range(2):
+    with open(out_path + f".{r}.txt") as f:
+      assert "TNH_BENCH_NO_REEXEC" in f.read()
