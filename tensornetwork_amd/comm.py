@@ -153,7 +153,6 @@ class RcclComm:
       if rendezvous is None:
         self._rdv.close()
       raise
-    self._scalar = None
 
   def _bootstrap(self):
     # Lock-step bootstrap: every rank takes part in both exchanges whatever happened locally, so a failure

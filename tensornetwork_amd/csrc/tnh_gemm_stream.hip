@@ -17,8 +17,9 @@
 //   * the output tile is re-assembled in LDS and leaves as 16-byte stores of whole row segments
 //     (SWAP: the tile is one contiguous block of C when ldc == Ms).
 // Two workgroups of 256 threads fit a CU (LDS: small image + one BN-row image), so one tile's stores
-// overlap the other's loads.  Any K (zero-filled to a multiple of 32), any row alignment (widest aligned
-// vector per operand, like the ragged kernel), ragged Ms / Nl.
+// overlap the other's loads.  K % 8 == 0 (zero-filled to a multiple of 32 in LDS) and 16-byte aligned rows on
+// all three matrices (host-checked: anything else keeps the tile kernels), any Ms <= 192, ragged Nl (the
+// remainder of < BN long rows goes to the tile kernel).
 //
 // Roofline: HBM.  Algorithmic bytes 2 * (Nl * K + Ms * K + Ms * Nl).
 #include "tnh_gemm_nt.h"
