@@ -54,6 +54,7 @@ if ROOT not in sys.path:
 
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense, /opt/skills/guides/MI355X_MICROARCH.md:42
 F32_MFMA_PEAK_TFLOPS = 157.3  # dense f32 matrix peak, same table
+F64_MFMA_PEAK_TFLOPS = 78.6   # f64 matrix peak (spec)
 HBM_PEAK_GBPS = 8000.0          # spec, MI355X_MICROARCH.md:35 (about 6.3 TB/s achievable)
 MAX_CLOCK_MHZ = 2400.0
 
@@ -78,7 +79,71 @@ def parse_args():
                  help="N > 1: collectives through libtnhip's K8 entry points (default) or torch.distributed")
   p.add_argument("--fill", default="normal", choices=["normal", "zeros"],
                  help="operand fill (zeros shows the DVFS-inflated number; never the headline)")
+  p.add_argument("--dry-run", action="store_true",
+                 help="launcher / rendezvous check only: every rank joins the host rendezvous, rank 0 prints a JSON "
+                      "line with n_gpus; no GPU is touched (CPU test of the --gpus N self-launch)")
   return p.parse_args()
+
+
+# --------------------------------------------------------------------------- launcher
+def visible_gpus():
+  """Devices the HIP runtime shows this process (0 when there is none or the library cannot ask)."""
+  import ctypes  # pylint: disable=import-outside-toplevel
+  try:
+    from tensornetwork_amd import _lib  # pylint: disable=import-outside-toplevel
+    n = ctypes.c_int(0)
+    if _lib.load_library().tnh_device_count(ctypes.byref(n)) != 0:
+      return 0
+    return int(n.value)
+  except Exception:  # pylint: disable=broad-except
+    return 0
+
+
+def self_launch(args):
+  """`python bench.py --gpus N` with N > 1 and no launcher environment: be the launcher.
+
+  One rank per GPU, torchrun's environment contract (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT on
+  loopback), rank 0's stdout is this process' stdout (the ONE JSON line), the other ranks' stdout goes to stderr.
+  Fewer visible devices than ranks is an error, never a silent single-GPU run.  Returns the exit code."""
+  import socket  # pylint: disable=import-outside-toplevel
+  import subprocess  # pylint: disable=import-outside-toplevel
+  n = args.gpus
+  if not args.dry_run:
+    have = visible_gpus()
+    if have < n:
+      print(f"[bench] --gpus {n} asked for {n} ranks (one per GPU) but this process sees {have} device(s); "
+            "refusing to report a smaller job under that flag", file=sys.stderr, flush=True)
+      return 2
+  with socket.socket() as sock:
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+  procs = []
+  for r in range(n):
+    env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+               MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get(
+                   "HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                  stdout=None if r == 0 else sys.stderr))
+  codes = [p.wait() for p in procs]
+  bad = {r: c for r, c in enumerate(codes) if c != 0}
+  if bad:
+    print(f"[bench] rank exit codes {bad}", file=sys.stderr, flush=True)
+    return 1
+  return 0
+
+
+def dry_run(args, rank, world):
+  """Rendezvous only (no GPU): proves that N ranks were started, found each other and agree on the world size."""
+  from tensornetwork_amd import comm as tcomm  # pylint: disable=import-outside-toplevel
+  rdv = tcomm.HostRendezvous(rank, world, timeout=120)
+  seen = rdv.all_gather({"rank": rank, "pid": os.getpid(), "local": int(os.environ.get("LOCAL_RANK", "0"))})
+  rdv.barrier()
+  rdv.close()
+  if rank == 0:
+    print(json.dumps({"metric": "contracted-elements/sec (TFLOP/s) + SVD GB/s, bond-dim sweep, 1/2/4/8 MI355X",
+                      "dry_run": True, "value": None, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                      "ranks_seen": sorted(x["rank"] for x in seen),
+                      "distinct_processes": len({x["pid"] for x in seen})}), flush=True)
 
 
 # --------------------------------------------------------------------------- communicators
@@ -478,8 +543,21 @@ def dtype_sweep(ta, be, D=64):
     A = be.device_random((D,) * 4, dtype=dt, seed=21, normal=True, b=1.0 / D)
     B = be.device_random((D,) * 4, dtype=dt, seed=22, normal=True, b=1.0 / D)
     t, _ = timed_steps(be, lambda: be.tensordot(A, B, [[2, 3], [0, 1]]), 5)   # pylint: disable=cell-var-from-loop
-    rows.append({"dtype": name, "D": D, "gemm": [D * D] * 3, "ms": t * 1e3, "tflops": mult * D**6 / t / 1e12,
-                 "kernel": be.lib.tnh_gemm_last_kernel().decode()})
+    kernel = be.lib.tnh_gemm_last_kernel().decode()
+    row = {"dtype": name, "D": D, "gemm": [D * D] * 3, "ms": t * 1e3, "tflops": mult * D**6 / t / 1e12,
+           "kernel": kernel}
+    # which pipe did the work, and what fraction of ITS peak is that
+    if name == "f64" or name == "complex128":
+      row["roofline"] = {"bound": "mfma f64", "peak": F64_MFMA_PEAK_TFLOPS, "frac": row["tflops"] / F64_MFMA_PEAK_TFLOPS}
+    elif "bf16" in kernel or "pp" in kernel:
+      # f32 (and complex64 through the real expansion) on the bf16 cores: six bf16 products per f32 product
+      bf16_tf = 6.0 * row["tflops"]
+      row["roofline"] = {"bound": "mfma bf16 (3 x bf16 split: 6 bf16 flop per f32 flop)", "bf16_tflops": bf16_tf,
+                         "peak": BF16_MFMA_PEAK_TFLOPS, "frac": bf16_tf / BF16_MFMA_PEAK_TFLOPS,
+                         "note": "f32-equivalent TFLOP/s may exceed the 157 TF f32-MFMA peak; the bound is the bf16 pipe"}
+    else:
+      row["roofline"] = {"bound": "mfma f32", "peak": F32_MFMA_PEAK_TFLOPS, "frac": row["tflops"] / F32_MFMA_PEAK_TFLOPS}
+    rows.append(row)
     del A, B
   return rows
 
@@ -668,16 +746,28 @@ def fenced(result, key, fn):
 
 def main():
   args = parse_args()
+  if args.gpus < 1:
+    sys.exit("--gpus must be >= 1")
+  if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+    sys.exit(self_launch(args))       # no launcher around us: start the N ranks ourselves
   rank = int(os.environ.get("RANK", "0"))
   world = int(os.environ.get("WORLD_SIZE", "1"))
   local = int(os.environ.get("LOCAL_RANK", "0"))
+  if world != args.gpus and not os.environ.get("TNH_BENCH_FORCE_DIST"):
+    # a launcher that started a different number of ranks than --gpus says: never report under the wrong n_gpus
+    sys.exit(f"[bench] --gpus {args.gpus} but WORLD_SIZE={world}: the launcher and the flag disagree")
+  if args.dry_run:
+    dry_run(args, rank, world)
+    return
   use_dist = world > 1 or bool(os.environ.get("TNH_BENCH_FORCE_DIST"))
   if use_dist:
     # before any HIP runtime comes up in this process: the host driver only supports dmabuf IPC
     # (RCCL / cross-process device memory fail with hipIpcGetMemHandle otherwise); already exported on the boxes
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-  if use_dist:
-    assert world == args.gpus or os.environ.get("TNH_BENCH_FORCE_DIST"), (world, args.gpus)
+  if not use_dist or os.environ.get("TNH_BENCH_FORCE_DIST") or world == 1:
+    pass
+  elif visible_gpus() <= local:
+    sys.exit(f"[bench] rank {rank}: LOCAL_RANK {local} has no device (visible: {visible_gpus()})")
   comm, comm_name = None, "none"
   if use_dist and args.comm == "torch":
     comm = TorchComm(rank, world, local)      # torch's HIP runtime first (see TorchComm)
@@ -686,6 +776,7 @@ def main():
   import tensornetwork_amd as ta  # pylint: disable=import-outside-toplevel
   from tensornetwork_amd import _lib, telemetry  # pylint: disable=import-outside-toplevel
 
+  ta.configure_gc(freeze=True)      # this process is ours: opt in to the frozen-baseline collector policy
   be = ta.get_hip_backend()
   be.lib  # pylint: disable=pointless-statement
   if use_dist and args.comm == "rccl":

@@ -322,11 +322,16 @@ int tnh_qr(int dtype, int64_t m, int64_t n, const void* A, void* Q, void* R,
  * Bootstrap: rank 0 calls tnh_comm_unique_id, ships the TNH_COMM_ID_BYTES bytes to
  * the other ranks over a host channel, then every rank calls tnh_comm_init. */
 #define TNH_COMM_ID_BYTES 128
+/* 0 when this rank can enter tnh_comm_init (librccl loads, a device is bound, no communicator yet): the ranks
+ * exchange this BEFORE the collective ncclCommInitRank, so that one rank's local failure is seen by all. */
+int tnh_comm_available(void);
 int tnh_comm_unique_id(void* host_id);
 int tnh_comm_init(const void* host_id, int rank, int world);
 /* *world = 0 when no communicator exists. */
 int tnh_comm_info(int* rank, int* world);
 int tnh_comm_destroy(void);
+/* Error path: drops the communicator with ncclCommAbort (never waits for peers that may not exist). */
+int tnh_comm_abort(void);
 /* In place; op: 0 sum, 1 max, 2 min (complex dtypes: sum only, on (re, im) separately). */
 int tnh_allreduce(void* buf, int64_t count, int dtype, int op);
 int tnh_allreduce_sum(void* buf, int64_t count, int dtype);

@@ -113,6 +113,8 @@ SIGNATURES = {
                                      c_void_p]),
     "tnh_qr_work_bytes": (c_int, [c_int, c_int64, c_int64, POINTER(c_size_t)]),
     "tnh_qr": (c_int, [c_int, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "tnh_comm_available": (c_int, []),
+    "tnh_comm_abort": (c_int, []),
     "tnh_comm_unique_id": (c_int, [c_void_p]),
     "tnh_comm_init": (c_int, [c_void_p, c_int, c_int]),
     "tnh_comm_info": (c_int, [POINTER(c_int), POINTER(c_int)]),

@@ -155,9 +155,19 @@ class RcclComm:
       raise
 
   def _bootstrap(self):
-    # Lock-step bootstrap: every rank takes part in both exchanges whatever happened locally, so a failure
-    # on one rank (no librccl, ncclCommInitRank error) raises on EVERY rank instead of leaving the others
-    # waiting -- the caller can then agree on a fall-back.
+    # Lock-step bootstrap: every rank takes part in every exchange whatever happened locally, so a failure
+    # on one rank raises on EVERY rank instead of leaving the others waiting -- the caller can then agree on
+    # a fall-back.  ncclCommInitRank is itself collective, so anything that can fail LOCALLY (librccl does
+    # not load, no device bound, a stale communicator) is checked and exchanged first (tnh_comm_available):
+    # the ranks enter the collective only when all of them can.
+    pre = None
+    try:
+      _lib.check(self._lib.tnh_comm_available(), "tnh_comm_available")
+    except Exception as exc:  # pylint: disable=broad-except
+      pre = f"{type(exc).__name__}: {exc}"
+    unable = {r: e for r, e in enumerate(self._rdv.all_gather(pre)) if e}
+    if unable:
+      raise RuntimeError(f"RCCL is not usable on rank(s) {sorted(unable)}: {next(iter(unable.values()))}")
     ident, err = None, None
     if self.rank == 0:
       try:
@@ -179,7 +189,7 @@ class RcclComm:
     failed = {r: e for r, e in enumerate(states) if e}
     if failed:
       if err is None:
-        self._lib.tnh_comm_destroy()
+        self._lib.tnh_comm_abort()      # never ncclCommDestroy here: it may wait for peers that never joined
       raise RuntimeError(f"tnh_comm_init failed on rank(s) {sorted(failed)}: {next(iter(failed.values()))}")
 
   # -- host-side metadata ------------------------------------------------------------------

@@ -26,6 +26,7 @@ struct RcclApi {
   ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
   ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;   // optional
   ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
@@ -59,6 +60,7 @@ int load_rccl() {
                   load_sym(g_api.CommDestroy, "ncclCommDestroy") && load_sym(g_api.AllReduce, "ncclAllReduce") &&
                   load_sym(g_api.AllGather, "ncclAllGather") && load_sym(g_api.Broadcast, "ncclBroadcast") &&
                   load_sym(g_api.GetErrorString, "ncclGetErrorString");
+  load_sym(g_api.CommAbort, "ncclCommAbort");
   if (!ok) {
     set_error("librccl is missing a required symbol (%s)", dlerror());
     dlclose(g_api.handle);
@@ -99,6 +101,19 @@ bool reduce_type(int dt, ncclDataType_t* t, int* mult) {
 using namespace tnh;
 
 extern "C" {
+
+int tnh_comm_available(void) {
+  // Pre-flight for the lock-step bootstrap (comm.py): everything ncclCommInitRank needs locally, checked
+  // WITHOUT entering a collective -- a rank that would fail before ncclCommInitRank must say so while the
+  // others can still listen, otherwise they block inside it for good.
+  TNH_NEED_INIT();
+  int rc = load_rccl();
+  if (rc != TNH_OK) return rc;
+  int dev = -1;
+  TNH_HIP(hipGetDevice(&dev));
+  TNH_REQUIRE(g_comm == nullptr, "tnh_comm_available: a communicator already exists (tnh_comm_destroy first)");
+  return TNH_OK;
+}
 
 int tnh_comm_unique_id(void* host_id) {
   TNH_REQUIRE(host_id != nullptr, "tnh_comm_unique_id: null buffer");
@@ -148,6 +163,21 @@ int tnh_comm_info(int* rank, int* world) {
   return TNH_OK;
 }
 
+int tnh_comm_abort(void) {
+  // error path: peers may never have joined, so nothing here may wait for them
+  if (g_comm) {
+    ncclResult_t r = g_api.CommAbort ? g_api.CommAbort(g_comm) : ncclSuccess;
+    g_comm = nullptr;
+    g_rank = 0;
+    g_world = 1;
+    if (r != ncclSuccess) {
+      set_error("ncclCommAbort failed: %s", g_api.GetErrorString(r));
+      return TNH_ERR_HIP;
+    }
+  }
+  return TNH_OK;
+}
+
 int tnh_comm_destroy(void) {
   if (g_comm) {
     if (stream()) (void)hipStreamSynchronize(stream());
@@ -186,7 +216,7 @@ int tnh_allgather(void* dst, const void* src, int64_t nbytes) {
   TNH_REQUIRE(g_comm != nullptr, "tnh_allgather: no communicator (tnh_comm_init)");
   TNH_REQUIRE(nbytes >= 0 && (nbytes == 0 || (dst && src)), "tnh_allgather: bad arguments");
   if (nbytes == 0) return TNH_OK;
-  // 16-byte words where the block allows it: fewer, wider elements for RCCL's copy kernels
+  // 8-byte words where the block allows it: fewer, wider elements for RCCL's copy kernels
   if (nbytes % 8 == 0)
     TNH_NCCL(g_api.AllGather(src, dst, (size_t)(nbytes / 8), ncclInt64, g_comm, stream()));
   else

@@ -117,22 +117,24 @@ def round_to_bf16(x):
 # duration is measured every time and compared with 28 ms/GiB x the request (an application that keeps
 # 400k live objects of its own pays 8 ms per pass -- fine in front of an 8 GiB request, not in front of
 # a 64 MiB one); a skipped opportunity decays the estimate so that it is re-measured eventually.
-# TNH_GC_FREEZE=0 leaves the collector untouched (the first estimate is then 30 ms, i.e. requests
-# of about 1 GiB and more).
+# gc.freeze() changes the host process' heap for good, so it is OPT-IN (round 3): the application asks for it
+# -- `configure_gc(freeze=True)`, `HipBackend(manage_gc=True)` or TNH_GC_FREEZE=1; bench.py does -- and
+# `import tensornetwork_amd` alone never calls it.  Without it the first pass-cost estimate is 30 ms, i.e. the
+# allocator collects in front of requests of about 1 GiB and more and measures from there.
 _GC_FROZEN = False
 _GC_MIN_BYTES = 64 << 20
 _MALLOC_SECONDS_PER_BYTE = 28e-3 / (1 << 30)
 _gc_cost_seconds = 30e-3
 
 
-_GC_POLICY = {"freeze": True, "collect": True}
+_GC_POLICY = {"freeze": False, "collect": True}
 
 
 def configure_gc(freeze=None, collect_before_large_alloc=None):
-  """Opt-outs of the backend's interaction with Python's cyclic collector (the policy above).
+  """The backend's interaction with Python's cyclic collector (the policy above).
 
-  freeze=False                      never call ``gc.freeze()`` (and undo an earlier freeze);
-                                    same as ``TNH_GC_FREEZE=0`` in the environment.
+  freeze=True                       OPT IN to ``gc.freeze()`` at backend initialisation (default off; also
+                                    ``TNH_GC_FREEZE=1``); False undoes an earlier freeze.
   collect_before_large_alloc=False  never run ``gc.collect()`` from the allocator in front of a
                                     large request (``TNH_GC_COLLECT=0``); the out-of-memory retry
                                     still collects once before giving up.
@@ -158,7 +160,9 @@ def freeze_collector_baseline():
   import os  # pylint: disable=import-outside-toplevel
   if os.environ.get("TNH_GC_COLLECT", "1") == "0":
     _GC_POLICY["collect"] = False
-  if _GC_FROZEN or os.environ.get("TNH_GC_FREEZE", "1") == "0" or not _GC_POLICY["freeze"]:
+  env = os.environ.get("TNH_GC_FREEZE")
+  want = _GC_POLICY["freeze"] if env is None else env != "0"
+  if _GC_FROZEN or not want:
     return
   global _gc_cost_seconds  # pylint: disable=global-statement
   gc.collect()

@@ -231,18 +231,18 @@ def contract_sliced(nodes: Sequence[network.Node], cut_edges: Sequence[network.E
     use_graph = hasattr(be, "capture") and len(cut_edges) > 0 and len(mine) >= 4
   if use_graph and mine:
     try:
-      total = _contract_slices_graph(be, nodes, cut_edges, mine, path, output_edge_order)
-      return _finish(be, comm, total, nodes)
+      total, narrow = _contract_slices_graph(be, nodes, cut_edges, mine, path, output_edge_order)
+      return _finish(be, comm, total, narrow)
     except MemoryError:
       pass   # not enough HBM for the captured sequence's fixed blocks: run the slices eagerly
 
-  total = None
+  total, narrow = None, None
   for idx in mine:
     node_map, edge_map = network.copy(nodes)
     for e, i in zip(cut_edges, idx):
       network.slice_edge(edge_map[e], i, 1)
     order = [edge_map[e] for e in output_edge_order] if output_edge_order is not None else None
-    part = _widen(be, contractors.contract_path(path, [node_map[n] for n in nodes], order).tensor)
+    part, narrow = _widen(be, contractors.contract_path(path, [node_map[n] for n in nodes], order).tensor)
     total = part if total is None else be.addition(total, part)
     for n in node_map.values():     # this slice's copies are ours: drop their tensors now (Node <-> Edge
       n.tensor = None               # cycles would otherwise keep the HBM until the cyclic GC runs)
@@ -253,9 +253,9 @@ def contract_sliced(nodes: Sequence[network.Node], cut_edges: Sequence[network.E
     for e in cut_edges:
       network.slice_edge(edge_map[e], 0, 1)
     order = [edge_map[e] for e in output_edge_order] if output_edge_order is not None else None
-    part = contractors.contract_path(path, [node_map[n] for n in nodes], order).tensor
-    total = be.multiply(_widen(be, part), 0.0)
-  return _finish(be, comm, total, nodes)
+    part, narrow = _widen(be, contractors.contract_path(path, [node_map[n] for n in nodes], order).tensor)
+    total = be.multiply(part, 0.0)
+  return _finish(be, comm, total, narrow)
 
 
 def _is_half(tensor):
@@ -264,19 +264,21 @@ def _is_half(tensor):
 
 def _widen(be, tensor):
   """Slice partials of a bf16 / f16 network are ADDED in fp32: hundreds of slices summed in an
-  8-bit mantissa would lose the small ones (the per-slice GEMMs already accumulate in fp32)."""
+  8-bit mantissa would lose the small ones (the per-slice GEMMs already accumulate in fp32).
+  Returns (tensor to accumulate, the half dtype it was widened from or None)."""
   if _is_half(tensor) and hasattr(be, "cast"):
-    return be.cast(tensor, np.float32)
-  return tensor
+    return be.cast(tensor, np.float32), tensor.dtype
+  return tensor, None
 
 
-def _finish(be, comm, total, nodes):
-  """ONE all-reduce of the (fp32-accumulated) partial sums, then a single rounding back to the
-  network's dtype."""
+def _finish(be, comm, total, narrow):
+  """ONE all-reduce of the (fp32-accumulated) partial sums, then a single rounding back to the dtype the
+  per-slice contraction itself produced (`narrow`; None = nothing was widened, e.g. an f32 / f64 network, a
+  backend with half_output="float32", or a mixed network whose result is already wide) -- the sliced result
+  has the dtype of the unsliced contraction of the same network."""
   out = comm.all_reduce_sum(be, total)
-  want = nodes[0].tensor.dtype if nodes else None
-  if want is not None and _is_half(nodes[0].tensor) and not _is_half(out) and hasattr(be, "cast"):
-    out = be.cast(out, want)
+  if narrow is not None and not _is_half(out):
+    out = be.cast(out, narrow)
   return out
 
 
@@ -303,19 +305,19 @@ def _contract_slices_graph(be, nodes, cut_edges, slices, path, output_edge_order
 
   graph = be.capture(run, *staged)
   try:
-    total = None
+    total, narrow = None, None
     for idx in slices:
       for k, wins in windows.items():
         starts = [0] * nodes[k].tensor.ndim
         for ax, c in wins:
           starts[ax] = idx[c]
         be.slice_into(staged[k], nodes[k].tensor, starts)
-      part = _widen(be, graph.launch())
+      part, narrow = _widen(be, graph.launch())
       total = be.multiply(part, 1.0) if total is None else be.addition(total, part)
   finally:
     be.synchronize()
     graph.close()
-  return total
+  return total, narrow
 
 
 def slicing_report(nodes: Sequence[network.Node], cut_edges: Sequence[network.Edge],

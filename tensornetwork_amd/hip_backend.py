@@ -133,10 +133,12 @@ class HipBackend(BackendBase):
     device: HIP device index for this process (default ``$LOCAL_RANK`` or 0).
     half_output: dtype of bf16/f16 contraction results: ``"same"`` (default,
       what NumPy semantics give) or ``"float32"`` (keep the fp32 accumulator).
-    manage_gc: ``False`` keeps the backend's hands off Python's cyclic collector (no
-      ``gc.freeze()`` at initialisation, no ``gc.collect()`` in front of large allocations);
-      default ``None`` = the policy of ``tensornetwork_amd.configure_gc`` / the environment
-      (``TNH_GC_FREEZE``, ``TNH_GC_COLLECT``).  See DESIGN.md section 3 and INTEGRATION.md.
+    manage_gc: ``True`` opts in to ``gc.freeze()`` at initialisation (cheap full collections in front of
+      large allocations); ``False`` keeps the backend's hands off Python's cyclic collector altogether (no
+      freeze, no ``gc.collect()`` in front of large allocations); default ``None`` = the policy of
+      ``tensornetwork_amd.configure_gc`` / the environment (``TNH_GC_FREEZE``, ``TNH_GC_COLLECT``): no
+      freeze, collect only where a measured pass is cheaper than the hipMalloc it avoids.  See DESIGN.md
+      section 3 and INTEGRATION.md.
   """
 
   def __init__(self, device=None, half_output="same", manage_gc=None):

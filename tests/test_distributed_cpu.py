@@ -305,3 +305,106 @@ def test_bench_rccl_fallback_is_taken_in_step(tmp_path):
   for r in range(2):
     with open(out_path + f".{r}.txt") as f:
       assert "TNH_BENCH_NO_REEXEC" in f.read()
+
+
+def test_sliced_result_dtype_follows_the_per_slice_result():
+  """the final cast used to follow nodes[0]'s dtype.  The rule now: round back only what was widened
+  -- a half per-slice result -- so half_output="float32" backends and mixed networks keep their wide result."""
+
+  class _T:
+    def __init__(self, dtype):
+      self.dtype = dtype
+
+  class _Be:
+    def cast(self, t, dtype):
+      return _T(np.dtype(dtype) if not isinstance(dtype, str) else dtype)
+
+  class _Comm:
+    def all_reduce_sum(self, backend, tensor):
+      return tensor
+
+  be = _Be()
+  wide, narrow = distributed._widen(be, _T("bfloat16"))
+  assert str(wide.dtype) == "float32" and narrow == "bfloat16"
+  assert distributed._finish(be, _Comm(), wide, narrow).dtype == "bfloat16"
+  # per-slice result already fp32 (half_output="float32", or a mixed network): nothing is narrowed afterwards
+  wide, narrow = distributed._widen(be, _T(np.dtype(np.float32)))
+  assert narrow is None
+  assert distributed._finish(be, _Comm(), wide, narrow).dtype == np.float32
+
+
+def _asym_bootstrap_worker(rank, world, port, out_path):
+  sys.path.insert(0, os.path.dirname(HERE))
+  from tensornetwork_amd import comm
+
+  class _Lib:
+    """rank 1 cannot load RCCL; rank 0 could -- and would block inside the collective init for good"""
+    def __init__(self, rank):
+      self.rank, self.entered_init = rank, False
+    def tnh_comm_available(self):
+      return -3 if self.rank == 1 else 0
+    def tnh_last_error(self):
+      return b"cannot load librccl (mock)"
+    def tnh_comm_unique_id(self, buf):
+      return 0
+    def tnh_comm_init(self, raw, rank, world):
+      self.entered_init = True
+      return 0
+    def tnh_comm_abort(self):
+      return 0
+
+  class _Be:
+    pass
+  be = _Be()
+  be.lib = _Lib(rank)
+  rdv = comm.HostRendezvous(rank, world, addr="127.0.0.1", port=port, timeout=60)
+  try:
+    comm.RcclComm(be, rank=rank, world=world, rendezvous=rdv)
+    outcome = "created"
+  except RuntimeError as exc:
+    outcome = f"RuntimeError: {exc}"
+  rdv.barrier()
+  rdv.close()
+  with open(out_path + f".{rank}.txt", "w") as f:
+    f.write(f"{outcome}|entered_init={be.lib.entered_init}")
+
+
+def test_rccl_bootstrap_asymmetric_failure_never_enters_the_collective(tmp_path):
+  """one rank failing BEFORE ncclCommInitRank used to leave the healthy ranks inside it.  The
+  pre-flight exchange (tnh_comm_available) makes every rank raise without any of them entering the init."""
+  import torch.multiprocessing as mp
+  with socket.socket() as s:
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+  out_path = str(tmp_path / "asym")
+  mp.spawn(_asym_bootstrap_worker, args=(2, port, out_path), nprocs=2, join=True)
+  for r in range(2):
+    with open(out_path + f".{r}.txt") as f:
+      outcome = f.read()
+    assert outcome.startswith("RuntimeError") and "rank(s) [1]" in outcome, outcome
+    assert outcome.endswith("entered_init=False"), outcome
+
+
+def test_bench_gpus_n_launches_n_ranks_or_fails_loudly():
+  """`python bench.py --gpus 2` without a launcher used to benchmark ONE GPU and print
+  n_gpus: 1.  Now it starts the ranks itself (dry run: rendezvous only) and refuses when devices are missing."""
+  import json
+  import subprocess
+  root = os.path.dirname(HERE)
+  env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+  dry = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run"], env=env,
+                       capture_output=True, text=True, timeout=300)
+  assert dry.returncode == 0, dry.stderr
+  rec = json.loads(dry.stdout.strip().splitlines()[-1])
+  assert rec["n_gpus"] == 2 and rec["ranks_seen"] == [0, 1] and rec["distinct_processes"] == 2
+  # no GPU on this host: the real run must exit non-zero with a message, not fall back to one device
+  env["HIP_VISIBLE_DEVICES"] = ""
+  real = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=env,
+                        capture_output=True, text=True, timeout=300)
+  assert real.returncode != 0 and "n_gpus" not in real.stdout
+  assert "--gpus 2" in real.stderr
+  # a launcher that disagrees with the flag is an error as well
+  env2 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+  odd = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run"], env=env2,
+                       capture_output=True, text=True, timeout=300)
+  assert odd.returncode != 0 and "n_gpus" not in odd.stdout

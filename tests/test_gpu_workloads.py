@@ -391,6 +391,24 @@ def test_sliced_bf16_network_accumulates_partials_in_fp32(hip):
     assert abs(got - ref) <= 2.0 ** -6 * abs(ref) + 1e-4, (got, ref, use_graph)
 
 
+def test_sliced_network_keeps_fp32_when_the_backend_contracts_half_into_fp32():
+  """with HipBackend(half_output="float32") the per-slice results are fp32 by contract; the sliced sum
+  must come back fp32 like the unsliced contraction of the same network (it used to be narrowed to bf16)."""
+  from tensornetwork_amd import distributed, workloads as wl
+  from tensornetwork_amd.hip_backend import HipBackend
+  be = HipBackend(half_output="float32")
+  rng = np.random.default_rng(9)
+  D, n = 6, 16
+  tensors = [orc.round_bf16((rng.standard_normal((D, D, D)) * D ** -0.75)).astype(np.float32) for _ in range(n)]
+  nodes = wl.random_regular_network(be, n=n, D=D, tensors=[be.to_bfloat16(t) for t in tensors])
+  ref = contractors.greedy(wl.random_regular_network(be, n=n, D=D, tensors=[be.to_bfloat16(t) for t in tensors])).tensor
+  cuts = distributed.choose_cut_edges(nodes, min_slices=30)
+  for use_graph in (False, True):
+    out = distributed.contract_sliced(nodes, cuts, use_graph=use_graph)
+    assert out.dtype == ref.dtype == np.float32, (out.dtype, ref.dtype)
+    assert abs(float(np.asarray(out)) - float(np.asarray(ref))) <= 2.0 ** -6 * abs(float(np.asarray(ref))) + 1e-4
+
+
 def test_json_network_from_reference_into_hbm(hip):
   """A network serialised by the reference (NumPy backend, mixed f64 / f32 / complex128 tensors) is
   loaded straight into HBM, contracted on the GPU and written back in the same wire format."""

@@ -562,8 +562,13 @@ def test_gc_policy_opt_out_leaves_the_collector_alone(monkeypatch):
   monkeypatch.setattr(gc, "freeze", lambda: calls.append("freeze"))
   monkeypatch.setattr(gc, "collect", lambda *a: calls.append("collect") or 0)
   monkeypatch.setattr(gc, "unfreeze", lambda: calls.append("unfreeze"))
+  monkeypatch.delenv("TNH_GC_FREEZE", raising=False)
   try:
     dt._GC_FROZEN = False
+    # round 3: freezing the host's heap is opt-in -- the default policy never reaches gc.freeze()
+    dt._GC_POLICY.update({"freeze": False, "collect": True})
+    dt.freeze_collector_baseline()
+    assert calls == [] and not dt._GC_FROZEN
     assert ta.configure_gc(freeze=False, collect_before_large_alloc=False) == {"freeze": False, "collect": False}
     dt.freeze_collector_baseline()
     assert not dt._worth_collecting(64 << 30)
