@@ -293,6 +293,28 @@ int tnh_svd_factor_topk(int dtype, int64_t m, int64_t n, const void* A, void* S,
 int tnh_svd_vectors_topk(int dtype, int64_t m, int64_t n, const void* A,
                          void* work, const void* S, int64_t k, void* U, void* Vh);
 
+/* ---- K7b: band + spectrum-slicing SVD for large f32 matrices (round 3) ----------------------------------
+ * Same contract as tnh_svd_factor / tnh_svd_vectors (A = U diag(S) Vh, ALL min(m, n) values returned, S
+ * descending; replaces np.linalg.svd behind decompositions.py:36) for row-major f32 A with m >= n,
+ * n >= 256, n % 16 == 0 -- a wide matrix is passed transposed by the caller.  Instead of Jacobi sweeps:
+ * (1) two-sided blocked Householder reduction to an upper band of 16 super-diagonals (panels factored by
+ * Cholesky-QR + Householder reconstruction, rank-16 streaming updates), (2) all singular values by spectrum
+ * slicing on T = B^T B in f64 (Sturm counts from the un-pivoted LDL^T, 16-lane groups), (3) the k leading
+ * vectors by inverse iteration on the band and back-transformation.  The work a call does is independent of
+ * the spectrum.
+ *   kcap   : largest k the work buffer is sized for (the caller's max_singular_values).
+ *   status : host int (may be NULL = no read-back); non-zero bits mean the result must NOT be used and the
+ *            caller re-runs tnh_svd_factor: 1 rank-deficient panel, 2 (unused), 4 clustered kept values,
+ *            8 band residual, 16 a kept value below 1e-6 of the largest.
+ * tnh_svd_band_layout returns byte offsets of {Af, Vl, Vr, Tl, Tr, Dblk, Eblk, Bd, Tb, lo, hi, X} inside the
+ * (256-byte aligned) work buffer: the stage-by-stage GPU tests read them back. */
+int tnh_svd_band_supported(int dtype, int64_t m, int64_t n, int64_t k);
+int tnh_svd_band_work_bytes(int64_t m, int64_t n, int64_t kcap, size_t* nbytes);
+int tnh_svd_band_layout(int64_t m, int64_t n, int64_t kcap, int64_t* offsets, int count);
+int tnh_svd_band_factor(int64_t m, int64_t n, const void* A, void* S, void* work, int64_t kcap, int* status_out);
+int tnh_svd_band_vectors(int64_t m, int64_t n, void* work, int64_t kcap, int64_t k, void* U, void* Vh,
+                         int* status_out);
+
 /* The block pairs (32-row blocks a < b ... or a in one part, b in another) of ONE sweep of the block Jacobi
  * in launch order, for `nb` blocks and `groups` = 1 (circle method), 2 or 4 (grouped schedule: the groups of a
  * round never share a block, tnh_svd_block.hip).  pairs_out: [nb - 1][nb / 2][2] int32; host only (no GPU needed):

@@ -994,6 +994,17 @@ class HipBackend(BackendBase):
     mat = self.cast(tensor, work_code).view((m, n))
     r = min(m, n)
 
+    if work_code == _lib.F32 and getattr(self, "svd_band", True):
+      done = self._svd_band(mat, m, n, max_singular_values, max_truncation_error, relative)
+      if done is not None:
+        u, s, vh, s_rest = done
+        keep = s.shape[0]
+        if orig_code != work_code:
+          u, vh = self.cast(u, orig_code), self.cast(vh, orig_code)
+        if orig_code != real_code:
+          s, s_rest = self.cast(s, orig_code), self.cast(s_rest, orig_code)
+        return u.view(tuple(left_dims) + (keep,)), s, vh.view((keep,) + tuple(right_dims)), s_rest
+
     nbytes = ctypes.c_size_t(0)
     _lib.check(self.lib.tnh_svd_work_bytes(work_code, m, n, ctypes.byref(nbytes)), "tnh_svd_work_bytes")
     work = DeviceTensor.empty((max(nbytes.value, 8) // 8 + 1,), _lib.F64)
@@ -1065,6 +1076,68 @@ class HipBackend(BackendBase):
     u = u.view(tuple(left_dims) + (keep,))
     vh = vh.view((keep,) + tuple(right_dims))
     return u, s, vh, s_rest
+
+  # smallest min(m, n) the band path takes (below it the block Jacobi is as fast or faster)
+  svd_band_min = 1024
+  last_svd_path = None
+  last_svd_band_status = 0
+
+  def _svd_band(self, mat, m, n, max_singular_values, max_truncation_error, relative):
+    """K7b (tnh_svd_band_*): band reduction + spectrum slicing + inverse iteration, f32, min(m, n) >= 1024,
+    truncated calls that keep at most half of the spectrum and at most 1024 vectors.  Returns
+    (u (m, k), s (k,), vh (k, n), s_rest) or None when the call is outside the path's range or the device
+    reports that the result must not be used (rank-deficient panel, clustered kept values, a kept value below
+    1e-6 s_1): the caller then runs the Jacobi path -- same truncation rule (decompositions.py:38-57) here."""
+    r = min(m, n)
+    self.last_svd_path = "jacobi"
+    if r < self.svd_band_min or r % 16 or max_singular_values is None:
+      return None
+    kmax = int(max_singular_values)
+    if kmax <= 0 or 2 * kmax > r or kmax > 1024:
+      return None
+    kcap = (kmax + 3) // 4 * 4
+    wide = m < n
+    mm, nn = (n, m) if wide else (m, n)
+    if not self.lib.tnh_svd_band_supported(_lib.F32, mm, nn, kcap):
+      return None
+    a = self.transpose(mat, (1, 0)) if wide else mat
+    nbytes = ctypes.c_size_t(0)
+    _lib.check(self.lib.tnh_svd_band_work_bytes(mm, nn, kcap, ctypes.byref(nbytes)), "tnh_svd_band_work_bytes")
+    work = DeviceTensor.empty((nbytes.value // 8 + 1,), _lib.F64)
+    s_all = DeviceTensor.empty((r,), _lib.F32)
+    status = ctypes.c_int(0)
+    need_host = max_truncation_error is not None
+    _lib.check(self.lib.tnh_svd_band_factor(mm, nn, _vp(a), _vp(s_all), _vp(work), kcap,
+                                            ctypes.byref(status) if need_host else None), "tnh_svd_band_factor")
+    keep = kmax
+    if need_host:
+      if status.value:
+        self.last_svd_band_status = status.value
+        return None
+      s_host = s_all.numpy().astype(np.float64)
+      trunc_errs = np.sqrt(np.cumsum(np.square(s_host[::-1])))
+      abs_err = max_truncation_error * (s_host[0] if r else 0.0) if relative else max_truncation_error
+      keep = int(min(kmax, int(np.count_nonzero(trunc_errs > abs_err)), r))
+    if keep <= 0:
+      return None
+    kk = (keep + 3) // 4 * 4          # the back-transformation moves float4 columns; extra vectors are dropped
+    uu = DeviceTensor.empty((mm, kk), _lib.F32)
+    vvh = DeviceTensor.empty((kk, nn), _lib.F32)
+    _lib.check(self.lib.tnh_svd_band_vectors(mm, nn, _vp(work), kcap, kk, _vp(uu), _vp(vvh), ctypes.byref(status)),
+               "tnh_svd_band_vectors")
+    self.last_svd_band_status = status.value
+    if status.value:
+      return None
+    if kk != keep:
+      uu = self.getitem(uu, (slice(None), slice(0, keep)))
+      vvh = self.getitem(vvh, slice(0, keep))
+    if wide:      # A^T = U' S V'h  ->  A = V'h^T S U'^T
+      u, vh = self.transpose(vvh, (1, 0)), self.transpose(uu, (1, 0))
+    else:
+      u, vh = uu, vvh
+    self.last_svd_path = "band"
+    self.last_svd_sweeps = 0
+    return u, self.getitem(s_all, slice(0, keep)), vh, self.getitem(s_all, slice(keep, r))
 
   def _qr_matrix(self, mat):
     """Thin Householder QR of a device matrix (f32 / f64) -> (q (m, k), r (k, n))."""

@@ -1,0 +1,178 @@
+"""K7b (tnh_svd_band_*): band reduction + spectrum slicing + inverse iteration, on the MI355X.
+
+Oracle: np.linalg.svd in float64 of the same float32 input (what decompositions.py:36 calls), plus the
+stage-by-stage NumPy statement of the algorithm in tools/svd_band_model.py.  Tolerances (f32 path):
+|s - s_ref| <= 1e-5 s_0 for ALL values (s_rest included), orthonormality 1e-4, reconstruction within
+1e-4 s_0 of the best rank-k approximation error."""
+import ctypes
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import tensornetwork_amd as ta
+from tensornetwork_amd import _lib
+from tensornetwork_amd.device_tensor import DeviceTensor
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+
+def gaussian(m, n, seed):
+  return np.random.default_rng(seed).standard_normal((m, n)).astype(np.float32)
+
+
+def graded(m, n, seed, rate=32.0):
+  """decompositions_test.py:55-66 construction: prescribed spectrum between Haar factors."""
+  rng = np.random.default_rng(seed)
+  r = min(m, n)
+  qu, _ = np.linalg.qr(rng.standard_normal((m, r)))
+  qv, _ = np.linalg.qr(rng.standard_normal((n, r)))
+  return ((qu * 2.0 ** (-np.arange(r) / rate)) @ qv.T).astype(np.float32)
+
+
+def check_svd(a, u, s, vh, s_rest, k, tag=""):
+  a64 = a.astype(np.float64)
+  ur, sr, vr = np.linalg.svd(a64, full_matrices=False)
+  s0 = sr[0]
+  s_all = np.concatenate([np.asarray(s, dtype=np.float64), np.asarray(s_rest, dtype=np.float64)])
+  assert s_all.shape == sr.shape
+  assert np.max(np.abs(s_all - sr)) <= 1e-5 * s0, (tag, np.max(np.abs(s_all - sr)) / s0)
+  u64, v64 = np.asarray(u, dtype=np.float64), np.asarray(vh, dtype=np.float64)
+  assert u64.shape == (a.shape[0], k) and v64.shape == (k, a.shape[1])
+  assert np.max(np.abs(u64.T @ u64 - np.eye(k))) <= 1e-4, (tag, "U", np.max(np.abs(u64.T @ u64 - np.eye(k))))
+  assert np.max(np.abs(v64 @ v64.T - np.eye(k))) <= 1e-4, (tag, "V", np.max(np.abs(v64 @ v64.T - np.eye(k))))
+  rec = np.linalg.norm(a64 - (u64 * s_all[:k]) @ v64)
+  best = np.sqrt(np.sum(sr[k:] ** 2))
+  assert rec <= best + 1e-4 * s0 * np.sqrt(k), (tag, rec, best)
+  # every kept triplet is a singular triplet of A:  |A v - s u| small
+  resid = np.max(np.linalg.norm(a64 @ v64.T - u64 * s_all[:k], axis=0))
+  assert resid <= 2e-5 * s0, (tag, resid / s0)
+
+
+@pytest.mark.parametrize("kind,m,n,k", [("gauss", 1024, 1024, 64), ("graded", 1024, 1024, 64),
+                                        ("gauss", 2048, 1024, 128), ("gauss", 1024, 2048, 100),
+                                        ("graded", 1536, 1280, 62)])
+def test_band_svd_matches_lapack(hip, kind, m, n, k):
+  a = (gaussian if kind == "gauss" else graded)(m, n, seed=m + n + k)
+  u, s, vh, s_rest = hip.svd(hip.convert_to_tensor(a), 1, max_singular_values=k)
+  assert hip.last_svd_path == "band", (hip.last_svd_path, hip.last_svd_band_status)
+  check_svd(a, u, s, vh, s_rest, k, f"{kind} {m}x{n} k={k}")
+
+
+def test_band_svd_truncation_error_rule(hip):
+  """decompositions.py:38-57 with max_truncation_error on the band path: keep = min(max_sv, #values whose tail
+  norm exceeds the error)."""
+  a = graded(1024, 1024, seed=5, rate=8.0)
+  sr = np.linalg.svd(a.astype(np.float64), compute_uv=False)
+  err = 1e-3
+  trunc = np.sqrt(np.cumsum(sr[::-1] ** 2))
+  want = int(min(200, np.count_nonzero(trunc > err * sr[0])))
+  u, s, vh, s_rest = hip.svd(hip.convert_to_tensor(a), 1, max_singular_values=200, max_truncation_error=err,
+                             relative=True)
+  assert hip.last_svd_path == "band"
+  assert s.shape[0] == want and s_rest.shape[0] == 1024 - want
+  check_svd(a, u, s, vh, s_rest, want, "trunc-error rule")
+
+
+def test_band_svd_falls_back_loudly_where_it_cannot_be_accurate(hip):
+  """Rank-deficient input (panel Gram singular) and exactly repeated kept values: the device reports it and the
+  backend re-runs the Jacobi path -- the result is still right, and the path taken is recorded."""
+  rng = np.random.default_rng(3)
+  low = (rng.standard_normal((1024, 8)) @ rng.standard_normal((8, 1024))).astype(np.float32)
+  u, s, vh, s_rest = hip.svd(hip.convert_to_tensor(low), 1, max_singular_values=16)
+  assert hip.last_svd_path == "jacobi" and hip.last_svd_band_status != 0
+  sr = np.linalg.svd(low.astype(np.float64), compute_uv=False)
+  np.testing.assert_allclose(np.concatenate([np.asarray(s), np.asarray(s_rest)]), sr, atol=1e-5 * sr[0])
+  # identical singular values: the kept vectors are only defined as a subspace
+  q, _ = np.linalg.qr(rng.standard_normal((1024, 1024)))
+  spec = np.concatenate([np.full(32, 2.0), np.linspace(1.0, 0.1, 1024 - 32)])
+  q2, _ = np.linalg.qr(rng.standard_normal((1024, 1024)))
+  deg = ((q * spec) @ q2.T).astype(np.float32)
+  u, s, vh, s_rest = hip.svd(hip.convert_to_tensor(deg), 1, max_singular_values=32)
+  check_svd(deg, u, s, vh, s_rest, 32, "degenerate")
+
+
+def test_band_stage_outputs_match_the_numpy_model(hip):
+  """Stage by stage against tools/svd_band_model.py on one 512 x 512 input: the band has the singular values of A
+  (orthogonal stage 1), T = B^T B, brackets contain LAPACK's values."""
+  import svd_band_model as model
+  n, kcap = 512, 32
+  a = gaussian(n, n, seed=11)
+  lib = hip.lib
+  nbytes = ctypes.c_size_t(0)
+  _lib.check(lib.tnh_svd_band_work_bytes(n, n, kcap, ctypes.byref(nbytes)))
+  work = DeviceTensor.empty((nbytes.value // 8 + 1,), _lib.F64)
+  s_all = DeviceTensor.empty((n,), _lib.F32)
+  da = hip.convert_to_tensor(a)
+  status = ctypes.c_int(-1)
+  _lib.check(lib.tnh_svd_band_factor(n, n, ctypes.c_void_p(da.ptr), ctypes.c_void_p(s_all.ptr),
+                                     ctypes.c_void_p(work.ptr), kcap, ctypes.byref(status)), "tnh_svd_band_factor")
+  assert status.value == 0
+  offs = (ctypes.c_int64 * 12)()
+  _lib.check(lib.tnh_svd_band_layout(n, n, kcap, offs, 12))
+  names = ["Af", "Vl", "Vr", "Tl", "Tr", "Dblk", "Eblk", "Bd", "Tb", "lo", "hi", "X"]
+  off = dict(zip(names, [int(x) for x in offs]))
+  base = (work.ptr + 255) & ~255
+
+  def fetch(name, count, dtype):
+    out = np.empty(count, dtype=dtype)
+    _lib.check(lib.tnh_d2h(out.ctypes.data_as(ctypes.c_void_p), ctypes.c_void_p(base + off[name]), out.nbytes))
+    return out
+
+  bd = fetch("Bd", n * 17, np.float64).reshape(n, 17)
+  tb = fetch("Tb", n * 17, np.float64).reshape(n, 17)
+  sr = np.linalg.svd(a.astype(np.float64), compute_uv=False)
+  sb = np.linalg.svd(model.band_dense(bd), compute_uv=False)
+  assert np.max(np.abs(sb - sr)) <= 3e-6 * sr[0]          # stage 1 is an orthogonal equivalence (f32 rounding)
+  np.testing.assert_allclose(tb, model.gram_band(bd), rtol=1e-13, atol=1e-13 * sr[0] ** 2)
+  lo = fetch("lo", n, np.float64)
+  hi = fetch("hi", n, np.float64)
+  sb_asc = sb[::-1]
+  assert np.all(lo <= sb_asc + 1e-9 * sr[0]) and np.all(sb_asc <= hi + 1e-9 * sr[0])
+  assert np.max(hi - lo) <= 2e-6 * sr[0]
+  np.testing.assert_allclose(np.asarray(s_all), sr, atol=5e-6 * sr[0])
+  # the model's own stage 1 (same formulas on the host) gives a band with the same singular values
+  af, _, _, ok = model.to_band(a)
+  assert ok
+  sm = np.linalg.svd(model.band_dense(model.band_of(af)), compute_uv=False)
+  assert np.max(np.abs(sm - sb)) <= 3e-6 * sr[0]
+
+
+def test_band_dpp_broadcasts_equal_shuffles(hip, monkeypatch):
+  """The LDL^T kernels move pivots with DPP row_newbcast; TNH_SVDB_DPP=0 builds the same kernels on __shfl.
+  Same arithmetic in the same order: bit-identical singular values and vectors."""
+  a = gaussian(1024, 1024, seed=21)
+  d = hip.convert_to_tensor(a)
+  monkeypatch.setenv("TNH_SVDB_DPP", "1")
+  u1, s1, v1, r1 = hip.svd(d, 1, max_singular_values=32)
+  assert hip.last_svd_path == "band"
+  monkeypatch.setenv("TNH_SVDB_DPP", "0")
+  u2, s2, v2, r2 = hip.svd(d, 1, max_singular_values=32)
+  assert hip.last_svd_path == "band"
+  for x, y in ((u1, u2), (s1, s2), (v1, v2), (r1, r2)):
+    np.testing.assert_array_equal(np.asarray(x), np.asarray(y))
+
+
+def test_split_node_4096_config(hip):
+  """BASELINE configs[2] through the Node API: (16,)*6 node split 3|3, keep 256; prescribed spectrum
+  s_i = 2^(-i/32) (decompositions_test.py:55-66) in the mixed edge order of split_node_test.py:36-47."""
+  rng = np.random.default_rng(0)
+  n = 4096
+  qu, _ = np.linalg.qr(rng.standard_normal((n, n)))
+  qv, _ = np.linalg.qr(rng.standard_normal((n, n)))
+  mat = ((qu * 2.0 ** (-np.arange(n) / 32.0)) @ qv.T).astype(np.float32)
+  # node axes (a0 a1 a2 b0 b1 b2); hand split_node the mixed order left = [a2, a0, a1], right = [b1, b2, b0]
+  node = ta.Node(hip.convert_to_tensor(mat.reshape((16,) * 6)), backend=hip)
+  left = [node[2], node[0], node[1]]
+  right = [node[4], node[5], node[3]]
+  l, r, _ = ta.split_node(node, left, right, max_singular_values=256)
+  assert hip.last_svd_path == "band", hip.last_svd_band_status
+  full = np.tensordot(np.asarray(l.tensor, dtype=np.float64), np.asarray(r.tensor, dtype=np.float64), [[3], [0]])
+  # l axes: a2 a0 a1 | bond ; r axes: bond | b1 b2 b0  ->  back to (a0 a1 a2 b0 b1 b2)
+  full = full.transpose(1, 2, 0, 5, 3, 4).reshape(n, n)
+  sr = np.linalg.svd(mat.astype(np.float64), compute_uv=False)
+  best = np.sqrt(np.sum(sr[256:] ** 2))
+  assert np.linalg.norm(full - mat) <= best + 2e-3 * sr[0]

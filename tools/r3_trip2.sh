@@ -1,0 +1,16 @@
+#!/bin/bash
+# round 3, trip 2: band SVD after the backward-solve / flag fixes and the factor kernel rewrite
+set -u
+O=gpurun_out/r3t2
+mkdir -p $O
+export TMPDIR=/tmp
+timeout 900 python -m pytest tests/test_gpu_svd_band.py -q --timeout 600 > $O/pytest_band.log 2>&1; echo "pytest rc=$?" | tee $O/trip.log
+tail -60 $O/pytest_band.log
+for args in "1024 64 gauss" "4096 256 gauss" "4096 256 graded"; do
+  timeout 300 python tools/svd_band_probe.py $args >> $O/probe.jsonl 2>> $O/probe.err; echo "probe $args rc=$?" | tee -a $O/trip.log
+done
+cat $O/probe.jsonl; tail -5 $O/probe.err
+cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/prof -o band4096 -- python $GRAFT_REPO_ROOT/tools/svd_band_probe.py 4096 256 gauss --no-check > $GRAFT_REPO_ROOT/$O/prof.log 2>&1; echo "rocprof rc=$?" | tee -a $GRAFT_REPO_ROOT/$O/trip.log
+cd $GRAFT_REPO_ROOT
+f=$(find $O/prof -name "*kernel_stats.csv" | head -1)
+[ -n "$f" ] && head -30 "$f"
