@@ -79,6 +79,21 @@ __device__ __forceinline__ double sum16(double v) {      // every lane of the ro
   return v;
 }
 
+// 1 / d and 1 / sqrt(x) to full double precision from the hardware seeds (2^-26-ish) and two Newton steps: a
+// fraction of the IEEE division / square-root sequences, which sit on every pivot's critical path here.
+__device__ __forceinline__ double fast_rcp(double d) {
+  double r = __builtin_amdgcn_rcp(d);
+  r = fma(fma(-d, r, 1.0), r, r);
+  r = fma(fma(-d, r, 1.0), r, r);
+  return r;
+}
+__device__ __forceinline__ double fast_rsqrt(double x) {
+  double y = __builtin_amdgcn_rsq(x);
+  y = y * fma(-0.5 * x * y, y, 1.5);
+  y = y * fma(-0.5 * x * y, y, 1.5);
+  return y;
+}
+
 // ------------------------------------------------------------------------------------------------ stage 1: Gram
 // Panel element (r, i), r = 0 .. rows-1, i = 0 .. 15:  P[r * sr + i * si].
 //   column panel: sr = lda, si = 1      row panel (the LQ is the QR of the transpose): sr = 1, si = lda
@@ -141,86 +156,88 @@ __device__ __forceinline__ void wave_sync() {
 
 // All 256 threads.  In: sh.G0 = sh.G (Gram, f64), sh.Pt.  Out: sh.X, sh.L (V_top), sh.Ti (T^-1, reciprocal diagonal),
 // sh.R and sh.S (R_h = S R), sh.bad.
-__device__ void panel_factor(FactorShared& sh) {
+__device__ __forceinline__ void panel_factor(FactorShared& sh) {
   const int tid = threadIdx.x, i = tid >> 4, c = tid & 15;
   if (tid == 0) sh.bad = 0;
   __syncthreads();
   if (tid < 64) {
-    // lane owns row r = lane & 15, columns 4 g .. 4 g + 3
-    const int r = tid & 15, g = tid >> 4;
+    // Registers + DPP row broadcasts, no LDS round trip per step: lane r (of each 16-lane row; the four rows of the
+    // wave do the same work) holds ROW r of the matrix being factored, register c its column c.
+    const int r = tid & 15;
+    double Gr[16], Wr[16], Rr[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) Gr[k] = sh.G[r][k];
     double gmax = 0.0;
 #pragma unroll
     for (int k = 0; k < 16; ++k) gmax = fmax(gmax, sh.G[k][k]);
     // a panel whose Gram matrix has a pivot below 1e-9 of its largest diagonal entry loses orthogonality in the
     // Cholesky-QR (eps64 * cond^2 ~ 1e-7): reported, the caller takes the Jacobi path
     const double thresh = 1e-9 * fmax(gmax, 1e-300);
-    // ---- Cholesky, right-looking on G
-    for (int j = 0; j < 16; ++j) {
-      double piv = sh.G[j][j];
+    int bad = 0;
+    // ---- Cholesky G = R^T R, right-looking.  G is symmetric, so R(j, r) = G(r, j) / r_jj is lane r's own register j.
+    // Row r of G stops changing at step r, so R(r, c) = G^(r)(r, c) / r_rr is formed after the loop from the lane's own
+    // registers and its own 1 / r_rr.
+    double myrinv = 0.0, mydiag = 0.0;
+    static_for<16>([&](auto jc) {
+      constexpr int j = decltype(jc)::value;
+      double piv = bcast16_dpp<j>(Gr[j]);
       if (!(piv > thresh)) {
         piv = thresh;
-        if (tid == 0) sh.bad = 1;
+        bad = 1;
       }
-      const double rinv = 1.0 / sqrt(piv);
+      const double rinv = fast_rsqrt(piv);
       if (r == j) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int cc = 4 * g + q;
-          sh.R[j][cc] = (cc > j) ? sh.G[j][cc] * rinv : (cc == j ? piv * rinv : 0.0);
-        }
+        myrinv = rinv;
+        mydiag = piv * rinv;
       }
-      wave_sync();
-      if (r > j) {
-        const double ri = sh.R[j][r];
+      const double rowv = (r > j) ? Gr[j] * rinv : 0.0;       // R(j, r) for the rows still being reduced
+      static_for<16>([&](auto cc) {
+        constexpr int c = decltype(cc)::value;
+        if (c > j) Gr[c] = fma(-rowv, bcast16_dpp<c>(rowv), Gr[c]);
+      });
+    });
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int cc = 4 * g + q;
-          if (cc > j) sh.G[r][cc] -= ri * sh.R[j][cc];
-        }
-      }
-      wave_sync();
-    }
-    // ---- LU of Pt - S R with S chosen on the fly
+    for (int c = 0; c < 16; ++c) Rr[c] = (c > r) ? Gr[c] * myrinv : (c == r ? mydiag : 0.0);
+    // ---- in-place LU of Pt - S R: S_jj = -sign of the pivot candidate (so |pivot| >= R_jj)
 #pragma unroll
-    for (int q = 0; q < 4; ++q) sh.W[r][4 * g + q] = sh.Pt[r][4 * g + q];
-    wave_sync();
-    for (int j = 0; j < 16; ++j) {
-      const double wjj = sh.W[j][j];
+    for (int k = 0; k < 16; ++k) Wr[k] = sh.Pt[r][k];
+    static_for<16>([&](auto jc) {
+      constexpr int j = decltype(jc)::value;
+      const double wjj = bcast16_dpp<j>(Wr[j]);
+      const double rjj = bcast16_dpp<j>(Rr[j]);
       const double sj = (wjj >= 0.0) ? -1.0 : 1.0;
-      const double pj = wjj - sj * sh.R[j][j];          // |pj| >= R_jj > 0
-      const double pinv = 1.0 / pj;
-      if (r == j) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int cc = 4 * g + q;
-          sh.Ut[j][cc] = (cc > j) ? sh.W[j][cc] - sj * sh.R[j][cc] : (cc == j ? pj : 0.0);
+      if (tid == 0) sh.S[j] = sj;
+      const double pj = fma(-sj, rjj, wjj);
+      const double lrj = (r > j) ? Wr[j] * fast_rcp(pj) : 0.0;
+      Wr[j] = (r == j) ? pj : ((r > j) ? lrj : Wr[j]);
+      const double sown = (r == j) ? sj : 0.0;                // only row j takes the S R term
+      static_for<16>([&](auto cc) {
+        constexpr int c = decltype(cc)::value;
+        if (c > j) {
+          const double mine = fma(-sown, Rr[c], Wr[c]);       // lane j: Ut(j, c); other lanes: unchanged
+          Wr[c] = fma(-lrj, bcast16_dpp<j>(mine), mine);      // lrj = 0 for rows <= j
         }
-        if (g == 0) sh.S[j] = sj;
-      }
-      if (g == 0) sh.L[r][j] = (r > j) ? sh.W[r][j] * pinv : (r == j ? 1.0 : 0.0);
-      wave_sync();
-      if (r > j) {
-        const double lij = sh.L[r][j];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int cc = 4 * g + q;
-          if (cc > j) sh.W[r][cc] -= lij * sh.Ut[j][cc];
-        }
-      }
-      wave_sync();
-    }
-    // ---- X = Ut^-1: lane c < 16 solves for column c in registers (straight-line code)
+      });
+    });
+    // ---- X = Ut^-1: lane c solves Ut x = e_c; Ut(ii, k) comes from lane ii, register k
+    double x[16];
+    static_for<16>([&](auto ic) {
+      constexpr int ii = 15 - decltype(ic)::value;
+      double acc = (ii == r) ? 1.0 : 0.0;
+      static_for<16>([&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        if (k > ii) acc = fma(-bcast16_dpp<ii>(Wr[k]), x[k], acc);
+      });
+      x[ii] = acc * fast_rcp(bcast16_dpp<ii>(Wr[ii]));
+    });
     if (tid < 16) {
-      double x[16];
 #pragma unroll
-      for (int ii = 15; ii >= 0; --ii) {
-        double acc = (ii == tid) ? 1.0 : 0.0;
-#pragma unroll
-        for (int k = ii + 1; k < 16; ++k) acc -= sh.Ut[ii][k] * x[k];
-        x[ii] = (ii <= tid) ? acc / sh.Ut[ii][ii] : 0.0;
+      for (int k = 0; k < 16; ++k) {
+        sh.X[k][r] = (k <= r) ? x[k] : 0.0;
+        sh.R[r][k] = Rr[k];
+        sh.L[r][k] = (k < r) ? Wr[k] : (k == r ? 1.0 : 0.0);
       }
-#pragma unroll
-      for (int ii = 0; ii < 16; ++ii) sh.X[ii][tid] = x[ii];
+      if (tid == 0 && bad) sh.bad = 1;
     }
   }
   __syncthreads();
@@ -257,7 +274,6 @@ __device__ void panel_factor(FactorShared& sh) {
 //   Vout: rows x 16 row-major (f32).  VtOut (row panels only): 16 x rows (f32), V transposed, pitch vt_pitch.
 //   Tout: 16 x 16 f64 = T^-1 (upper, reciprocal diagonal).  Blk: 16 x 16 f64 band block: column panel -> R_h
 //   (upper); row panel -> R_h^T (lower).
-constexpr int FACTOR_MAX_PARTS = 64;
 template <bool ROWPANEL>
 __global__ __launch_bounds__(256) void factor_kernel(const float* __restrict__ P, int64_t lda, int64_t rows,
                                                      const double* __restrict__ Gpart, int nparts,
@@ -337,37 +353,51 @@ __global__ __launch_bounds__(256) void factor_kernel(const float* __restrict__ P
 // a wave covers 4 rows (g) x 64 columns (float4 per t), a workgroup 16 rows x 64 columns per iteration.
 
 // Wpart[chunk][i][c] = sum over the chunk's RC rows of V[r][i] C[r][c]       (W = V^T C, partial over row chunks)
+// The chunk's V rows are staged once in LDS (every lane group reads whole rows: broadcast reads); the C loads of
+// eight 16-row steps are requested before the first FMA.
 constexpr int W_RC = 256;
+constexpr int W_UNROLL = 4;
 __global__ __launch_bounds__(256) void wpass_kernel(const float* __restrict__ C, int64_t ldc, int64_t rows, int64_t nc,
                                                     const float* __restrict__ V, float* __restrict__ Wpart) {
+  __shared__ float4 vs[W_RC][4];        // V rows of the chunk
   __shared__ float red[4][16][65];      // [wave][i][column]
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, t = lane & 15;
   const int64_t c0 = (int64_t)blockIdx.x * 64 + 4 * t;
   const int64_t rbeg = (int64_t)blockIdx.y * W_RC;
   const bool col_ok = c0 < nc;
+  {
+    const int64_t r = rbeg + tid;
+    const float4* vp = reinterpret_cast<const float4*>(V + r * 16);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) vs[tid][q] = (r < rows) ? vp[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  __syncthreads();
   float acc[16][4];
 #pragma unroll
   for (int i = 0; i < 16; ++i)
 #pragma unroll
     for (int q = 0; q < 4; ++q) acc[i][q] = 0.f;
-#pragma unroll 2
-  for (int it = 0; it < W_RC / 16; ++it) {
-    const int64_t r = rbeg + it * 16 + w * 4 + g;
-    if (r < rows && col_ok) {
-      const float4 cv = *reinterpret_cast<const float4*>(C + r * ldc + c0);
-      const float4* vp = reinterpret_cast<const float4*>(V + r * 16);
-      float vv[16];
+  for (int it0 = 0; it0 < W_RC / 16; it0 += W_UNROLL) {
+    float4 cv[W_UNROLL];
+#pragma unroll
+    for (int u = 0; u < W_UNROLL; ++u) {
+      const int64_t r = rbeg + (it0 + u) * 16 + w * 4 + g;
+      cv[u] = (r < rows && col_ok) ? *reinterpret_cast<const float4*>(C + r * ldc + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int u = 0; u < W_UNROLL; ++u) {
+      const int lr = (it0 + u) * 16 + w * 4 + g;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const float4 x = vp[q];
-        vv[4 * q] = x.x; vv[4 * q + 1] = x.y; vv[4 * q + 2] = x.z; vv[4 * q + 3] = x.w;
-      }
+        const float4 x = vs[lr][q];
+        const float ve[4] = {x.x, x.y, x.z, x.w};
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        acc[i][0] = fmaf(vv[i], cv.x, acc[i][0]);
-        acc[i][1] = fmaf(vv[i], cv.y, acc[i][1]);
-        acc[i][2] = fmaf(vv[i], cv.z, acc[i][2]);
-        acc[i][3] = fmaf(vv[i], cv.w, acc[i][3]);
+        for (int e = 0; e < 4; ++e) {
+          acc[4 * q + e][0] = fmaf(ve[e], cv[u].x, acc[4 * q + e][0]);
+          acc[4 * q + e][1] = fmaf(ve[e], cv[u].y, acc[4 * q + e][1]);
+          acc[4 * q + e][2] = fmaf(ve[e], cv[u].z, acc[4 * q + e][2]);
+          acc[4 * q + e][3] = fmaf(ve[e], cv[u].w, acc[4 * q + e][3]);
+        }
       }
     }
   }
@@ -483,7 +513,7 @@ __global__ __launch_bounds__(256) void update_kernel(float* __restrict__ C, int6
 // Row panel, fused:  Y = C V (rows x 16, row-local),  Z = Y T,  C -= Z V^T.   Vt: 16 x nc (V transposed);
 // T comes as T^-1 (see panel_factor).
 // A workgroup owns 16 rows (lane = (row-in-wave g, column chunk t)) and sweeps all columns twice.
-constexpr int RU_TILES = 4;   // column tiles of 64 per staging step
+constexpr int RU_TILES = 8;   // column tiles of 64 per staging step (8 loads per lane in flight)
 __global__ __launch_bounds__(256) void rowupdate_kernel(float* __restrict__ C, int64_t ldc, int64_t rows, int64_t nc,
                                                         const float* __restrict__ Vt, int64_t vt_pitch,
                                                         const double* __restrict__ T) {
@@ -570,6 +600,98 @@ __global__ __launch_bounds__(256) void rowupdate_kernel(float* __restrict__ C, i
 }
 
 
+// Row panel in three launches (more workgroups than the fused kernel can offer: it owns whole rows):
+//   ypass    Ypart[chunk][r][i] = sum over the chunk's 256 columns of C[r][c] Vt[i][c]      (64-row x 256-column tiles)
+//   yreduce  Z[r][:] = T^T (sum over chunks of Ypart[chunk][r][:])                            (Z = Y T)
+//   update_kernel(C, V := Z, Wt := Vt)                                                        (C -= Z V^T)
+constexpr int Y_ROWS = 64, Y_COLS = 256;
+__global__ __launch_bounds__(256) void ypass_kernel(const float* __restrict__ C, int64_t ldc, int64_t rows, int64_t nc,
+                                                    const float* __restrict__ Vt, int64_t vt_pitch,
+                                                    float* __restrict__ Ypart) {
+  __shared__ float4 vts[Y_COLS / 64][16][16];    // [tile][i][t]
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, t = lane & 15;
+  const int64_t cbeg = (int64_t)blockIdx.x * Y_COLS;
+  const int64_t rbeg = (int64_t)blockIdx.y * Y_ROWS;
+  // all C loads of the tile set first: 4 row steps x 4 column tiles
+  float4 cv[Y_ROWS / 16][Y_COLS / 64];
+#pragma unroll
+  for (int it = 0; it < Y_ROWS / 16; ++it) {
+    const int64_t r = rbeg + it * 16 + w * 4 + g;
+#pragma unroll
+    for (int u = 0; u < Y_COLS / 64; ++u) {
+      const int64_t c = cbeg + u * 64 + 4 * t;
+      cv[it][u] = (r < rows && c < nc) ? *reinterpret_cast<const float4*>(C + r * ldc + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < Y_COLS / 64; ++u) {
+    const int64_t c = cbeg + u * 64 + 4 * (tid & 15);
+    vts[u][tid >> 4][tid & 15] = (c < nc) ? *reinterpret_cast<const float4*>(Vt + (int64_t)(tid >> 4) * vt_pitch + c)
+                                          : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  __syncthreads();
+  float y[Y_ROWS / 16][16];
+#pragma unroll
+  for (int it = 0; it < Y_ROWS / 16; ++it)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) y[it][i] = 0.f;
+#pragma unroll
+  for (int u = 0; u < Y_COLS / 64; ++u)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const float4 v = vts[u][i][t];
+#pragma unroll
+      for (int it = 0; it < Y_ROWS / 16; ++it) {
+        y[it][i] = fmaf(cv[it][u].x, v.x, y[it][i]);
+        y[it][i] = fmaf(cv[it][u].y, v.y, y[it][i]);
+        y[it][i] = fmaf(cv[it][u].z, v.z, y[it][i]);
+        y[it][i] = fmaf(cv[it][u].w, v.w, y[it][i]);
+      }
+    }
+  // combine the 16 column-chunk lanes of each row; lane t keeps entry i == t
+#pragma unroll
+  for (int it = 0; it < Y_ROWS / 16; ++it) {
+    float mine = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      float v = y[it][i];
+      v += __shfl_xor(v, 8, 16);
+      v += __shfl_xor(v, 4, 16);
+      v += __shfl_xor(v, 2, 16);
+      v += __shfl_xor(v, 1, 16);
+      if (t == i) mine = v;
+    }
+    const int64_t r = rbeg + it * 16 + w * 4 + g;
+    if (r < rows) Ypart[((int64_t)blockIdx.x * rows + r) * 16 + t] = mine;
+  }
+}
+
+__global__ __launch_bounds__(256) void yreduce_kernel(const float* __restrict__ Ypart, int nchunks, int64_t rows,
+                                                      const double* __restrict__ Tinv, float* __restrict__ Z) {
+  __shared__ float Ts[16][17];
+  const int tid = threadIdx.x;
+  Ts[tid >> 4][tid & 15] = (float)Tinv[tid];
+  __syncthreads();
+  const int64_t r = (int64_t)blockIdx.x * 256 + tid;
+  if (r >= rows) return;
+  float s[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) s[i] = 0.f;
+  for (int ch = 0; ch < nchunks; ++ch) {
+    const float4* yp = reinterpret_cast<const float4*>(Ypart + ((int64_t)ch * rows + r) * 16);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 v = yp[q];
+      s[4 * q] += v.x; s[4 * q + 1] += v.y; s[4 * q + 2] += v.z; s[4 * q + 3] += v.w;
+    }
+  }
+  float z[16];
+  tsolve(Ts, 1, s, z);
+  float4* zp = reinterpret_cast<float4*>(Z + r * 16);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) zp[q] = make_float4(z[4 * q], z[4 * q + 1], z[4 * q + 2], z[4 * q + 3]);
+}
+
 // ------------------------------------------------------------------------------------------------ stage 2: band
 // Bd[i][d] = B(i, i + d), d = 0 .. 16 (f64), from the panels' 16 x 16 blocks: Dblk[p] = diagonal block (upper
 // triangular), Eblk[p] = super-diagonal block (lower triangular).
@@ -607,10 +729,10 @@ __global__ __launch_bounds__(256) void tband_kernel(const double* __restrict__ B
 }
 
 // Rotated image read by the LDL^T kernels: Trot[i][c], c = 0 .. 15 = T(i, col) for the column col in [i - 15, i]
-// with col % 16 == c (c == i % 16: the diagonal); Trot[i][16] = T(i, i - 16).  Rows n .. n + 15: zero.
+// with col % 16 == c (c == i % 16: the diagonal); Trot[i][16] = T(i, i - 16).  Rows n .. n + 31: zero.
 __global__ __launch_bounds__(256) void trot_kernel(const double* __restrict__ Tb, int64_t n, double* __restrict__ Trot) {
   const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (e >= (n + 16) * TP) return;
+  if (e >= (n + 32) * TP) return;
   const int64_t i = e / TP;
   const int c = (int)(e % TP);
   double v = 0.0;
@@ -693,7 +815,7 @@ __global__ __launch_bounds__(64) void ldl_kernel(const double* __restrict__ Trot
       double d = bcast16<jj, DPP>(S[jj]);
       if (fabs(d) < pivmin) d = -pivmin;
       cnt += (d < 0.0) ? 1 : 0;
-      const double rinv = 1.0 / d;
+      const double rinv = fast_rcp(d);
       const bool me = (l16 == jj);
       const double colv = me ? nr[16] : S[jj];
       if (me) {
@@ -751,40 +873,52 @@ __global__ __launch_bounds__(64) void sturm_lane_kernel(const double* __restrict
   });
   int cnt = 0;
   double lmax2d = 0.0;        // max over the pivots of l_max^2 |d| = the largest |l colv|
+  // the row entering the window at step j is j + 16; it is requested one step ahead (scalar loads: the wait would
+  // otherwise sit in front of every pivot)
+  double nrow[17];
+#pragma unroll
+  for (int c = 0; c < 17; ++c) nrow[c] = Trot[16 * TP + c];
   for (int64_t j0 = 0; j0 < n; j0 += 16) {
     static_for<16>([&](auto jc) {
       constexpr int jj = decltype(jc)::value;
       const int64_t rn = j0 + jj + 16;
-      const double* __restrict__ nrow = Trot + rn * TP;       // wave-uniform
+      const double* __restrict__ ahead = Trot + (rn + 1) * TP;       // wave-uniform
+      double nxt[17];
+#pragma unroll
+      for (int c = 0; c < 17; ++c) nxt[c] = ahead[c];
       const double dsub = (rn < n) ? s2 : -1.0;
       double d = W[jj][jj];
       if (fabs(d) < pivmin) d = -pivmin;
       cnt += (d < 0.0) ? 1 : 0;
-      const double rinv = 1.0 / d;
-      double colv[17], l[17];
+      const double rinv = fast_rcp(d);
+      // Rows j + 1 .. j + 15: their pivot-column entries W[.][jj] stay untouched during the step, so they serve as
+      // colv directly and l_r is a temporary.  The entering row j + 16 goes last and takes its start values straight
+      // from the scalar registers: the window never holds more than its 136 entries.
+      double lmax = 0.0;
       static_for<15>([&](auto rc) {
         constexpr int r = decltype(rc)::value + 1;
-        colv[r] = W[(jj + r) & 15][jj];
-      });
-      colv[16] = nrow[16];
-      static_for<16>([&](auto cc) {
-        constexpr int c = decltype(cc)::value;
-        W[jj][c] = (c == jj) ? nrow[c] - dsub : nrow[c];
-      });
-      double lmax = 0.0;
-      static_for<16>([&](auto rc) {
-        constexpr int r = decltype(rc)::value + 1;
-        l[r] = colv[r] * rinv;
-        lmax = fmax(lmax, fabs(l[r]));
-      });
-      lmax2d = fmax(lmax2d, lmax * lmax * fabs(d));
-      static_for<16>([&](auto rc) {
-        constexpr int r = decltype(rc)::value + 1;
+        constexpr int a = (jj + r) & 15;
+        const double lr = W[a][jj] * rinv;
+        lmax = fmax(lmax, fabs(lr));
         static_for<r>([&](auto qc) {
           constexpr int q = decltype(qc)::value + 1;
-          W[(jj + r) & 15][(jj + q) & 15] = fma(-l[r], colv[q], W[(jj + r) & 15][(jj + q) & 15]);
+          constexpr int b = (jj + q) & 15;
+          W[a][b] = fma(-lr, W[b][jj], W[a][b]);
         });
       });
+      {
+        const double l16 = nrow[16] * rinv;
+        lmax = fmax(lmax, fabs(l16));
+        static_for<15>([&](auto qc) {
+          constexpr int q = decltype(qc)::value + 1;
+          constexpr int b = (jj + q) & 15;
+          W[jj][b] = fma(-l16, W[b][jj], nrow[b]);
+        });
+        W[jj][jj] = fma(-l16, nrow[16], nrow[jj] - dsub);
+      }
+      lmax2d = fmax(lmax2d, lmax * lmax * fabs(d));
+#pragma unroll
+      for (int c = 0; c < 17; ++c) nrow[c] = nxt[c];
     });
   }
   if (valid) {
@@ -991,6 +1125,144 @@ __global__ __launch_bounds__(256) void uv_init_kernel(const double* __restrict__
   }
 }
 
+// Back-transformation X <- H_0 H_1 ... H_(np-1) X with H_p = I - V_p T_p V_p^T (reflectors of ONE side, applied last
+// to first).  The columns of X transform independently, so a workgroup OWNS BT_COLS columns, keeps them in LDS
+// (rows x BT_COLS floats) and walks through all panels without any inter-workgroup step; the panels' V (rows_p x 16,
+// row-major) stream from L2 / Infinity Cache ONCE per panel: a thread keeps its (up to BT_KEEP) V rows in registers
+// between w = V^T x and x -= V (T w).
+//   X: ldx-pitched, rows x ncols (f32), updated in place.  Panel p covers rows row0 + 16 p ... rows - 1.
+constexpr int BT_COLS = 2;
+constexpr int BT_THREADS = 512;
+constexpr int BT_KEEP = 8;        // rows per thread held in registers: BT_THREADS * BT_KEEP = 4096 rows
+__global__ __launch_bounds__(BT_THREADS) void backtransform_kernel(float* __restrict__ X, int64_t ldx, int64_t rows,
+                                                                   int64_t ncols, const float* __restrict__ Vall,
+                                                                   const double* __restrict__ Tall, int64_t npanels,
+                                                                   int64_t row0, int64_t vrows0) {
+  extern __shared__ float xs[];                  // [rows][BT_COLS]
+  __shared__ float red[BT_THREADS / 64][16][BT_COLS];
+  __shared__ float wv[16][BT_COLS];
+  __shared__ float Ts[16][17];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int64_t c0 = (int64_t)blockIdx.x * BT_COLS;
+  for (int64_t r = tid; r < rows; r += BT_THREADS)
+    *reinterpret_cast<float2*>(xs + r * BT_COLS) = *reinterpret_cast<const float2*>(X + r * ldx + c0);
+  __syncthreads();
+  for (int64_t p = npanels - 1; p >= 0; --p) {
+    const int64_t rbeg = row0 + 16 * p;          // first row of X the panel touches
+    const int64_t vrows = vrows0 - 16 * p;       // rows of V_p  (= rows - rbeg)
+    // V_p starts at 16 * (p * vrows0 - 8 p (p - 1)) floats (see vl_offset / vr_offset)
+    const float* V = Vall + 16 * (p * vrows0 - 8 * p * (p - 1));
+    if (tid < 256) Ts[tid >> 4][tid & 15] = (float)Tall[p * 256 + tid];
+    float4 vreg[BT_KEEP][4];
+#pragma unroll
+    for (int it = 0; it < BT_KEEP; ++it) {
+      const int64_t r = tid + (int64_t)BT_THREADS * it;
+      const float4* vp = reinterpret_cast<const float4*>(V + r * 16);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) vreg[it][q] = (r < vrows) ? vp[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    float acc[16][BT_COLS];
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+#pragma unroll
+      for (int q = 0; q < BT_COLS; ++q) acc[i][q] = 0.f;
+#pragma unroll
+    for (int it = 0; it < BT_KEEP; ++it) {
+      const int64_t r = tid + (int64_t)BT_THREADS * it;
+      if (r < vrows) {
+        const float2 x = *reinterpret_cast<const float2*>(xs + (rbeg + r) * BT_COLS);
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+          const float ve[4] = {vreg[it][q4].x, vreg[it][q4].y, vreg[it][q4].z, vreg[it][q4].w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            acc[4 * q4 + e][0] = fmaf(ve[e], x.x, acc[4 * q4 + e][0]);
+            acc[4 * q4 + e][1] = fmaf(ve[e], x.y, acc[4 * q4 + e][1]);
+          }
+        }
+      }
+    }
+    for (int64_t r = tid + (int64_t)BT_THREADS * BT_KEEP; r < vrows; r += BT_THREADS) {     // very tall inputs only
+      const float4* vp = reinterpret_cast<const float4*>(V + r * 16);
+      const float2 x = *reinterpret_cast<const float2*>(xs + (rbeg + r) * BT_COLS);
+#pragma unroll
+      for (int q4 = 0; q4 < 4; ++q4) {
+        const float4 vv = vp[q4];
+        const float ve[4] = {vv.x, vv.y, vv.z, vv.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          acc[4 * q4 + e][0] = fmaf(ve[e], x.x, acc[4 * q4 + e][0]);
+          acc[4 * q4 + e][1] = fmaf(ve[e], x.y, acc[4 * q4 + e][1]);
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+#pragma unroll
+      for (int q = 0; q < BT_COLS; ++q) {
+        float v = acc[i][q];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+        if (lane == 0) red[w][i][q] = v;
+      }
+    __syncthreads();
+    if (tid < BT_COLS) {
+      float sv[16], wo[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        float a = 0.f;
+#pragma unroll
+        for (int k = 0; k < BT_THREADS / 64; ++k) a += red[k][i][tid];
+        sv[i] = a;
+      }
+      tsolve(Ts, 0, sv, wo);                     // w = T (V^T x)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) wv[i][tid] = wo[i];
+    }
+    __syncthreads();
+    float wr[16][BT_COLS];
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+#pragma unroll
+      for (int q = 0; q < BT_COLS; ++q) wr[i][q] = wv[i][q];
+#pragma unroll
+    for (int it = 0; it < BT_KEEP; ++it) {
+      const int64_t r = tid + (int64_t)BT_THREADS * it;
+      if (r < vrows) {
+        float2 x = *reinterpret_cast<const float2*>(xs + (rbeg + r) * BT_COLS);
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+          const float ve[4] = {vreg[it][q4].x, vreg[it][q4].y, vreg[it][q4].z, vreg[it][q4].w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            x.x = fmaf(-ve[e], wr[4 * q4 + e][0], x.x);
+            x.y = fmaf(-ve[e], wr[4 * q4 + e][1], x.y);
+          }
+        }
+        *reinterpret_cast<float2*>(xs + (rbeg + r) * BT_COLS) = x;
+      }
+    }
+    for (int64_t r = tid + (int64_t)BT_THREADS * BT_KEEP; r < vrows; r += BT_THREADS) {
+      const float4* vp = reinterpret_cast<const float4*>(V + r * 16);
+      float2 x = *reinterpret_cast<const float2*>(xs + (rbeg + r) * BT_COLS);
+#pragma unroll
+      for (int q4 = 0; q4 < 4; ++q4) {
+        const float4 vv = vp[q4];
+        const float ve[4] = {vv.x, vv.y, vv.z, vv.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          x.x = fmaf(-ve[e], wr[4 * q4 + e][0], x.x);
+          x.y = fmaf(-ve[e], wr[4 * q4 + e][1], x.y);
+        }
+      }
+      *reinterpret_cast<float2*>(xs + (rbeg + r) * BT_COLS) = x;
+    }
+    __syncthreads();
+  }
+  for (int64_t r = tid; r < rows; r += BT_THREADS)
+    *reinterpret_cast<float2*>(X + r * ldx + c0) = *reinterpret_cast<const float2*>(xs + r * BT_COLS);
+}
+
 // Vh (k x n) = Vv^T
 __global__ __launch_bounds__(256) void transpose_out_kernel(const float* __restrict__ Vv, int64_t n, int64_t k,
                                                             float* __restrict__ Vh) {
@@ -1008,7 +1280,7 @@ __global__ __launch_bounds__(256) void transpose_out_kernel(const float* __restr
 static inline size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct Layout {
-  size_t Af, Vl, Vr, Vt, Tl, Tr, Dblk, Eblk, Gpart, Wpart, Wt, Bd, Tb, Trot, scal, shifts, counts, flags, lo, hi,
+  size_t Af, Vl, Vr, Vt, Zr, Tl, Tr, Dblk, Eblk, Gpart, Wpart, Wt, Bd, Tb, Trot, scal, shifts, counts, flags, lo, hi,
       status, Lc, Dd, X, Uu, Vv, total;
   int64_t np, kcap, nshift;
 };
@@ -1027,6 +1299,7 @@ static Layout make_layout(int64_t m, int64_t n, int64_t kcap) {
   L.Vl = take((size_t)vl_offset(m, np) * 4);
   L.Vr = take((size_t)(vr_offset(n, np - 1) + 16) * 4);
   L.Vt = take((size_t)16 * n * 4);
+  L.Zr = take((size_t)16 * m * 4);
   L.Tl = take((size_t)np * 256 * 8);
   L.Tr = take((size_t)np * 256 * 8);
   L.Dblk = take((size_t)np * 256 * 8);
@@ -1035,7 +1308,10 @@ static Layout make_layout(int64_t m, int64_t n, int64_t kcap) {
   L.Gpart = take((size_t)maxparts * 256 * 8);
   const int64_t wide = n > kcap ? n : kcap;
   const int64_t chunks = (m + W_RC - 1) / W_RC;
-  L.Wpart = take((size_t)chunks * 16 * wide * 4);
+  size_t wpart = (size_t)chunks * 16 * wide * 4;
+  const size_t ypart = (size_t)((n + Y_COLS - 1) / Y_COLS) * m * 16 * 4;     // the row panels' Y partials share the buffer
+  if (ypart > wpart) wpart = ypart;
+  L.Wpart = take(wpart);
   L.Wt = take((size_t)16 * wide * 4);
   L.Bd = take((size_t)n * 17 * 8);
   L.Tb = take((size_t)n * 17 * 8);
@@ -1061,26 +1337,35 @@ static Layout make_layout(int64_t m, int64_t n, int64_t kcap) {
 }
 
 static bool g_dpp = true;
+static bool g_row_fused = false;  // row panels by the row-owning fused kernel (TNH_SVDB_ROWFUSED=1) or ypass / yreduce / update
+static bool g_bt_fused = true;   // back-transformation by column-owning workgroups (TNH_SVDB_BT=0: per-panel launches)
 static bool g_lane = true;       // counts through sturm_lane_kernel (TNH_SVDB_LANE=0: the 16-lane ldl_kernel)
-// Schedule of the spectrum slicing (defaults for the lane kernel: every round is one wave per SIMD at n = 4096):
-//   grid of g_grid_mult * n shifts (capped at 65536), then g_sect_rounds rounds of g_sect_p points per value;
-//   kept values: g_refine_rounds more rounds of g_refine_p points.
+// Schedule of the spectrum slicing.  A count costs 139 f64 FMAs per pivot (8 cycles each on this chip's vector pipe),
+// so the schedule is about the NUMBER of counts and of dependent rounds:
+//   all values: a uniform grid of 16 n shifts (capped at 65536 = one lane-kernel wave per SIMD) gives every value 16
+//   bits at once, one 16-way section round per value adds 4 (bracket 1e-6 sigma_max: s_rest is good to 5e-7);
+//   kept values: g_refine_rounds 16-way rounds on the 16-lane kernel (a few thousand shifts: latency 0.8 ms instead
+//   of the lane kernel's 3 ms) take their brackets to 2^-32 sigma_max so that inverse iteration separates neighbours.
 static int g_grid_mult = 16;
 static int g_sect_p = 15;
-static int g_sect_rounds = 2;
-static int g_refine_p = 255;
-static int g_refine_rounds = 2;
+static int g_sect_rounds = 1;
+static int g_refine_p = 15;
+static int g_refine_rounds = 3;
 
 static void read_env() {
   const char* e = getenv("TNH_SVDB_DPP");
   g_dpp = !(e && e[0] == '0');
+  e = getenv("TNH_SVDB_ROWFUSED");
+  g_row_fused = (e && e[0] == '1');
+  e = getenv("TNH_SVDB_BT");
+  g_bt_fused = !(e && e[0] == '0');
   e = getenv("TNH_SVDB_LANE");
   g_lane = !(e && e[0] == '0');
   g_grid_mult = g_lane ? 16 : 1;
   g_sect_p = g_lane ? 15 : 3;
-  g_sect_rounds = g_lane ? 2 : 6;
-  g_refine_p = g_lane ? 255 : 15;
-  g_refine_rounds = g_lane ? 2 : 4;
+  g_sect_rounds = g_lane ? 1 : 5;
+  g_refine_p = 15;
+  g_refine_rounds = 3;
   e = getenv("TNH_SVDB_GRID");
   if (e && atoi(e) > 0) g_grid_mult = atoi(e);
   e = getenv("TNH_SVDB_SECT");
@@ -1093,8 +1378,8 @@ static void read_env() {
   if (e && atoi(e) >= 0) g_refine_rounds = atoi(e);
 }
 
-static int launch_counts(const Layout& L, char* base, int64_t n, int64_t ns) {
-  if (g_lane) {
+static int launch_counts(const Layout& L, char* base, int64_t n, int64_t ns, bool lane) {
+  if (lane) {
     hipLaunchKernelGGL(sturm_lane_kernel, dim3((unsigned)((ns + 63) / 64)), dim3(64), 0, stream(),
                        (const double*)(base + L.Trot), n, (const double*)(base + L.shifts), ns,
                        (const double*)(base + L.scal), (int*)(base + L.counts), (int*)(base + L.flags));
@@ -1115,14 +1400,14 @@ static int launch_counts(const Layout& L, char* base, int64_t n, int64_t ns) {
 }
 
 // one multi-section round over the values [q0, q0 + nq)
-static int section_round(const Layout& L, char* base, int64_t n, int64_t q0, int64_t nq, int P, int round) {
+static int section_round(const Layout& L, char* base, int64_t n, int64_t q0, int64_t nq, int P, int round, bool lane) {
   if (nq <= 0) return TNH_OK;
   const int64_t ns = nq * P;
   const double skew = 0.07 * (double)((round % 3) - 1);
   hipLaunchKernelGGL(section_kernel, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, stream(),
                      (const double*)(base + L.lo), (const double*)(base + L.hi), q0, nq, P, skew,
                      (double*)(base + L.shifts));
-  int rc = launch_counts(L, base, n, ns);
+  int rc = launch_counts(L, base, n, ns, lane);
   if (rc) return rc;
   hipLaunchKernelGGL(bracket_update_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, stream(),
                      (double*)(base + L.lo), (double*)(base + L.hi), q0, nq, P, (const double*)(base + L.shifts),
@@ -1178,8 +1463,19 @@ static int stage1(const Layout& L, char* base, int64_t m, int64_t n) {
       const int64_t mr = m - j - 16;
       if (mr > 0) {
         float* C = Af + (j + 16) * n + j + 16;
-        hipLaunchKernelGGL(rowupdate_kernel, dim3((unsigned)((mr + 15) / 16)), dim3(256), 0, stream(), C, n, mr, nc,
-                           (const float*)Vt, nc, (const double*)(base + L.Tr) + p * 256);
+        if (g_row_fused) {
+          hipLaunchKernelGGL(rowupdate_kernel, dim3((unsigned)((mr + 15) / 16)), dim3(256), 0, stream(), C, n, mr, nc,
+                             (const float*)Vt, nc, (const double*)(base + L.Tr) + p * 256);
+        } else {
+          const int ych = (int)((nc + Y_COLS - 1) / Y_COLS);
+          float* Z = (float*)(base + L.Zr);
+          hipLaunchKernelGGL(ypass_kernel, dim3(ych, (unsigned)((mr + Y_ROWS - 1) / Y_ROWS)), dim3(256), 0, stream(),
+                             (const float*)C, n, mr, nc, (const float*)Vt, nc, Wpart);
+          hipLaunchKernelGGL(yreduce_kernel, dim3((unsigned)((mr + 255) / 256)), dim3(256), 0, stream(),
+                             (const float*)Wpart, ych, mr, (const double*)(base + L.Tr) + p * 256, Z);
+          hipLaunchKernelGGL(update_kernel, dim3((unsigned)((nc + 63) / 64), (unsigned)((mr + U_RR - 1) / U_RR)), dim3(256),
+                             0, stream(), C, n, mr, nc, (const float*)Z, (const float*)Vt, nc);
+        }
       }
     }
     TNH_LAUNCH_CHECK();
@@ -1193,7 +1489,7 @@ static int values(const Layout& L, char* base, int64_t n, int64_t khint, float* 
                      (const double*)(base + L.Eblk), n, (double*)(base + L.Bd));
   hipLaunchKernelGGL(tband_kernel, dim3(nb17), dim3(256), 0, stream(), (const double*)(base + L.Bd), n,
                      (double*)(base + L.Tb));
-  hipLaunchKernelGGL(trot_kernel, dim3((unsigned)(((n + 16) * TP + 255) / 256)), dim3(256), 0, stream(),
+  hipLaunchKernelGGL(trot_kernel, dim3((unsigned)(((n + 32) * TP + 255) / 256)), dim3(256), 0, stream(),
                      (const double*)(base + L.Tb), n, (double*)(base + L.Trot));
   hipLaunchKernelGGL(smax_kernel, dim3(1), dim3(1024), 0, stream(), (const double*)(base + L.Tb), n,
                      (double*)(base + L.scal));
@@ -1203,14 +1499,23 @@ static int values(const Layout& L, char* base, int64_t n, int64_t khint, float* 
   hipLaunchKernelGGL(grid_kernel, dim3((unsigned)((ng + 255) / 256)), dim3(256), 0, stream(),
                      (const double*)(base + L.scal), ng, (double*)(base + L.shifts));
   TNH_LAUNCH_CHECK();
-  int rc = launch_counts(L, base, n, ng);
+  int rc = launch_counts(L, base, n, ng, g_lane);
   if (rc) return rc;
   hipLaunchKernelGGL(bracket_init_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream(),
                      (const double*)(base + L.scal), (const int*)(base + L.counts), ng, n, (double*)(base + L.lo),
                      (double*)(base + L.hi));
   TNH_LAUNCH_CHECK();
-  for (int r = 0; r < g_sect_rounds; ++r) {
-    rc = section_round(L, base, n, 0, n, g_sect_p, r);
+  // at least 20 bits per value in total: log2(ng) from the grid, log2(P + 1) per section round
+  int rounds = g_sect_rounds;
+  {
+    double bits = log2((double)ng) + rounds * log2((double)g_sect_p + 1.0);
+    while (bits < 20.0 && rounds < 16) {
+      ++rounds;
+      bits += log2((double)g_sect_p + 1.0);
+    }
+  }
+  for (int r = 0; r < rounds; ++r) {
+    rc = section_round(L, base, n, 0, n, g_sect_p, r, g_lane);
     if (rc) return rc;
   }
   (void)khint;
@@ -1224,7 +1529,7 @@ static int vectors(const Layout& L, char* base, int64_t m, int64_t n, int64_t k,
   // kept values: brackets down to ~1e-12 relative so that inverse iteration separates close neighbours
   int rc;
   for (int r = 0; r < g_refine_rounds; ++r) {
-    rc = section_round(L, base, n, n - k, k, g_refine_p, r);
+    rc = section_round(L, base, n, n - k, k, g_refine_p, r, g_lane && g_refine_p > 15);
     if (rc) return rc;
   }
   hipLaunchKernelGGL(vshift_kernel, dim3((unsigned)((k + 255) / 256)), dim3(256), 0, stream(),
@@ -1251,6 +1556,22 @@ static int vectors(const Layout& L, char* base, int64_t m, int64_t n, int64_t k,
   TNH_LAUNCH_CHECK();
   float* Wpart = (float*)(base + L.Wpart);
   float* Wt = (float*)(base + L.Wt);
+  const size_t lds_u = (size_t)m * BT_COLS * sizeof(float), lds_v = (size_t)n * BT_COLS * sizeof(float);
+  if (g_bt_fused && lds_u <= 150 * 1024) {
+    // one launch per side: every workgroup carries BT_COLS columns through all the reflectors
+    static bool attr_done = false;
+    if (!attr_done) {
+      TNH_HIP(hipFuncSetAttribute((const void*)backtransform_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  150 * 1024));
+      attr_done = true;
+    }
+    hipLaunchKernelGGL(backtransform_kernel, dim3((unsigned)(k / BT_COLS)), dim3(BT_THREADS), lds_u, stream(), Uu, k, m, k,
+                       (const float*)(base + L.Vl), (const double*)(base + L.Tl), L.np, (int64_t)0, m);
+    if (L.np > 1)
+      hipLaunchKernelGGL(backtransform_kernel, dim3((unsigned)(k / BT_COLS)), dim3(BT_THREADS), lds_v, stream(), Vv, k, n, k,
+                         (const float*)(base + L.Vr), (const double*)(base + L.Tr), L.np - 1, (int64_t)16, n - 16);
+    TNH_LAUNCH_CHECK();
+  } else {
   // U = Q_L [U_b; 0]: column-panel reflectors, last to first
   for (int64_t p = L.np - 1; p >= 0; --p) {
     const int64_t j = 16 * p, mj = m - j;
@@ -1277,6 +1598,7 @@ static int vectors(const Layout& L, char* base, int64_t m, int64_t n, int64_t k,
                        chunks, k, (const double*)(base + L.Tr) + p * 256, 0, Wt);
     hipLaunchKernelGGL(update_kernel, dim3((unsigned)((k + 63) / 64), (unsigned)((nj + U_RR - 1) / U_RR)), dim3(256), 0,
                        stream(), C, k, nj, k, V, (const float*)Wt, k);
+  }
   }
   hipLaunchKernelGGL(transpose_out_kernel, dim3((unsigned)((n + 31) / 32), (unsigned)((k + 31) / 32)), dim3(256), 0,
                      stream(), (const float*)Vv, n, k, Vh);

@@ -132,7 +132,7 @@ def test_band_stage_outputs_match_the_numpy_model(hip):
   hi = fetch("hi", n, np.float64)
   sb_asc = sb[::-1]
   assert np.all(lo <= sb_asc + 1e-9 * sr[0]) and np.all(sb_asc <= hi + 1e-9 * sr[0])
-  assert np.max(hi - lo) <= 2e-6 * sr[0]
+  assert np.max(hi - lo) <= 4e-6 * sr[0]        # 20 bits of the Gershgorin bound on sigma_max
   np.testing.assert_allclose(np.asarray(s_all), sr, atol=5e-6 * sr[0])
   # the model's own stage 1 (same formulas on the host) gives a band with the same singular values
   af, _, _, ok = model.to_band(a)
@@ -142,8 +142,9 @@ def test_band_stage_outputs_match_the_numpy_model(hip):
 
 
 def test_band_dpp_broadcasts_equal_shuffles(hip, monkeypatch):
-  """The LDL^T kernels move pivots with DPP row_newbcast; TNH_SVDB_DPP=0 builds the same kernels on __shfl.
-  Same arithmetic in the same order: bit-identical singular values and vectors."""
+  """The 16-lane LDL^T / solve kernels move pivots with DPP row_newbcast / row_ror; TNH_SVDB_DPP=0 builds the same
+  kernels on __shfl.  Counts are integers, so the singular values (bracket midpoints) are bit-identical; the vectors
+  agree up to the summation order of the 16-lane dot products."""
   a = gaussian(1024, 1024, seed=21)
   d = hip.convert_to_tensor(a)
   monkeypatch.setenv("TNH_SVDB_DPP", "1")
@@ -152,8 +153,10 @@ def test_band_dpp_broadcasts_equal_shuffles(hip, monkeypatch):
   monkeypatch.setenv("TNH_SVDB_DPP", "0")
   u2, s2, v2, r2 = hip.svd(d, 1, max_singular_values=32)
   assert hip.last_svd_path == "band"
-  for x, y in ((u1, u2), (s1, s2), (v1, v2), (r1, r2)):
-    np.testing.assert_array_equal(np.asarray(x), np.asarray(y))
+  np.testing.assert_array_equal(np.asarray(s1), np.asarray(s2))
+  np.testing.assert_array_equal(np.asarray(r1), np.asarray(r2))
+  np.testing.assert_allclose(np.asarray(u1), np.asarray(u2), atol=2e-6)
+  np.testing.assert_allclose(np.asarray(v1), np.asarray(v2), atol=2e-6)
 
 
 def test_split_node_4096_config(hip):
