@@ -268,18 +268,20 @@ __device__ __forceinline__ void panel_factor(FactorShared& sh) {
   __syncthreads();
 }
 
-// Every workgroup repeats the 16 x 16 factorisation (same inputs, same result) and then forms V for its own 256
-// panel rows below the top block; workgroup 0 also writes the panel's small outputs.
-//   P: panel origin (see gram_kernel); rows: panel rows (incl. the top 16).
-//   Vout: rows x 16 row-major (f32).  VtOut (row panels only): 16 x rows (f32), V transposed, pitch vt_pitch.
-//   Tout: 16 x 16 f64 = T^-1 (upper, reciprocal diagonal).  Blk: 16 x 16 f64 band block: column panel -> R_h
-//   (upper); row panel -> R_h^T (lower).
+// ONE workgroup per panel: the 16 x 16 algebra and the panel's small outputs.
+//   P: panel origin (see gram_kernel).  Xout: 16 x 16 f64 (V_below = P_below X).
+//   Vout: rows 0 .. 15 of the panel's V (rows x 16 row-major, f32) = V_top;  VtOut (row panels): the same, transposed.
+//   Tout: 16 x 16 f64 = T^-1 (upper, reciprocal diagonal).  Blk: band block: column panel -> R_h (upper triangular);
+//   row panel -> R_h^T (lower).
+// (Round-3 measurement: the first version repeated this factorisation in every V-forming workgroup; with more than 8
+// workgroups the launch took 40-60 us instead of 12.)
 template <bool ROWPANEL>
-__global__ __launch_bounds__(256) void factor_kernel(const float* __restrict__ P, int64_t lda, int64_t rows,
+__global__ __launch_bounds__(256) void factor_kernel(const float* __restrict__ P, int64_t lda,
                                                      const double* __restrict__ Gpart, int nparts,
-                                                     float* __restrict__ Vout, float* __restrict__ VtOut,
-                                                     int64_t vt_pitch, double* __restrict__ Tout,
-                                                     double* __restrict__ Blk, int* __restrict__ status) {
+                                                     double* __restrict__ Xout, float* __restrict__ Vout,
+                                                     float* __restrict__ VtOut, int64_t vt_pitch,
+                                                     double* __restrict__ Tout, double* __restrict__ Blk,
+                                                     int* __restrict__ status) {
   __shared__ FactorShared sh;
   const int tid = threadIdx.x, i = tid >> 4, c = tid & 15;
   {
@@ -299,7 +301,27 @@ __global__ __launch_bounds__(256) void factor_kernel(const float* __restrict__ P
     sh.G0[i][c] = g;
     sh.Pt[i][c] = (double)(ROWPANEL ? P[(int64_t)c * lda + i] : P[(int64_t)i * lda + c]);
   }
-  // the panel rows this thread turns into V rows: requested before the factorisation, consumed after it
+  __syncthreads();
+  panel_factor(sh);
+  Xout[tid] = sh.X[i][c];
+  Tout[tid] = sh.Ti[i][c];
+  const double rh = (c >= i) ? sh.S[i] * sh.R[i][c] : 0.0;     // R_h = S R, upper
+  if (!ROWPANEL) Blk[tid] = rh;
+  else Blk[c * 16 + i] = rh;                                    // transposed: lower triangular
+  const float vt = (float)((i >= c) ? sh.L[i][c] : 0.0);        // V_top, unit lower
+  Vout[(int64_t)i * 16 + c] = vt;
+  if (ROWPANEL) VtOut[(int64_t)c * vt_pitch + i] = vt;
+  if (tid == 0 && sh.bad) atomicOr(status, (int)ST_PANEL);
+}
+
+// V rows below the top block: V[r][:] = P[r][:] X (f64 accumulate), r = 16 .. rows - 1, 256 rows per workgroup.
+template <bool ROWPANEL>
+__global__ __launch_bounds__(256) void formv_kernel(const float* __restrict__ P, int64_t lda, int64_t rows,
+                                                    const double* __restrict__ X, float* __restrict__ Vout,
+                                                    float* __restrict__ VtOut, int64_t vt_pitch) {
+  __shared__ double xs[16][17];
+  const int tid = threadIdx.x;
+  xs[tid >> 4][tid & 15] = X[tid];
   const int64_t r = 16 + (int64_t)blockIdx.x * 256 + tid;
   float p[16];
 #pragma unroll
@@ -318,24 +340,13 @@ __global__ __launch_bounds__(256) void factor_kernel(const float* __restrict__ P
     }
   }
   __syncthreads();
-  panel_factor(sh);
-  if (blockIdx.x == 0) {
-    Tout[tid] = sh.Ti[i][c];
-    const double rh = (c >= i) ? sh.S[i] * sh.R[i][c] : 0.0;     // R_h = S R, upper
-    if (!ROWPANEL) Blk[tid] = rh;
-    else Blk[c * 16 + i] = rh;                                    // transposed: lower triangular
-    const float vt = (float)((i >= c) ? sh.L[i][c] : 0.0);        // V_top, unit lower
-    Vout[(int64_t)i * 16 + c] = vt;
-    if (ROWPANEL) VtOut[(int64_t)c * vt_pitch + i] = vt;
-    if (tid == 0 && sh.bad) atomicOr(status, (int)ST_PANEL);
-  }
   if (r < rows) {
     float v[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
       double acc = 0.0;
 #pragma unroll
-      for (int l = 0; l < 16; ++l) acc += (double)p[l] * sh.X[l][k];
+      for (int l = 0; l < 16; ++l) acc += (double)p[l] * xs[l][k];
       v[k] = (float)acc;
     }
     float4* dst = reinterpret_cast<float4*>(Vout + r * 16);
@@ -451,46 +462,67 @@ __device__ __forceinline__ void tsolve(const TS (*Ti)[17], int trans, const floa
   }
 }
 
-// Wt[:, c] = T^T (trans = 1: H^T C) or T (trans = 0: H C) times the sum over chunks of Wpart[chunk][:, c]
+// Wt[:, c] = T^T (trans = 1: H^T C) or T (trans = 0: H C) times the sum over chunks of Wpart[chunk][:, c].
+// 64 columns per workgroup; the four waves take the chunks ch % 4 (their loads are in flight together), wave 0
+// finishes.  Fixed summation order: deterministic.
 __global__ __launch_bounds__(256) void wreduce_kernel(const float* __restrict__ Wpart, int nchunks, int64_t nc,
                                                       const double* __restrict__ Tinv, int trans, float* __restrict__ Wt) {
   __shared__ float Ts[16][17];
-  const int tid = threadIdx.x;
+  __shared__ float part[4][16][65];
+  const int tid = threadIdx.x, cg = tid >> 6, cl = tid & 63;
   Ts[tid >> 4][tid & 15] = (float)Tinv[tid];
-  __syncthreads();
-  const int64_t c = (int64_t)blockIdx.x * 256 + tid;
-  if (c >= nc) return;
+  const int64_t c = (int64_t)blockIdx.x * 64 + cl;
   float s[16];
 #pragma unroll
   for (int l = 0; l < 16; ++l) s[l] = 0.f;
-  for (int ch = 0; ch < nchunks; ++ch) {
+  if (c < nc) {
+    for (int ch = cg; ch < nchunks; ch += 4) {
 #pragma unroll
-    for (int l = 0; l < 16; ++l) s[l] += Wpart[((int64_t)ch * 16 + l) * nc + c];
+      for (int l = 0; l < 16; ++l) s[l] += Wpart[((int64_t)ch * 16 + l) * nc + c];
+    }
   }
-  float w[16];
-  tsolve(Ts, trans, s, w);
 #pragma unroll
-  for (int i = 0; i < 16; ++i) Wt[(int64_t)i * nc + c] = w[i];
+  for (int l = 0; l < 16; ++l) part[cg][l][cl] = s[l];
+  __syncthreads();
+  if (cg == 0 && c < nc) {
+#pragma unroll
+    for (int l = 0; l < 16; ++l) s[l] = (part[0][l][cl] + part[1][l][cl]) + (part[2][l][cl] + part[3][l][cl]);
+    float w[16];
+    tsolve(Ts, trans, s, w);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) Wt[(int64_t)i * nc + c] = w[i];
+  }
 }
 
 // C[r][c] -= sum_i V[r][i] Wt[i][c]          (tiles of U_RR rows x 64 columns)
+// GRAM = 1: the workgroups of the first column tile also write the partial Gram matrices (over their 128 rows) of the
+//           first 16 columns of the UPDATED C -- the next column panel -- to Gpart[blockIdx.y]   (gridDim.y partials);
+// GRAM = 2: the workgroups of the first row tile write the partial Gram matrices (over their 64 columns) of the first
+//           16 rows of the updated C -- the next row panel -- to Gpart[blockIdx.x]                (gridDim.x partials).
+// Either saves the separate pass of gram_kernel over the panel and its launch.
 constexpr int U_RR = 128;
+template <int GRAM>
 __global__ __launch_bounds__(256) void update_kernel(float* __restrict__ C, int64_t ldc, int64_t rows, int64_t nc,
                                                      const float* __restrict__ V, const float* __restrict__ Wt,
-                                                     int64_t wt_pitch) {
+                                                     int64_t wt_pitch, double* __restrict__ Gpart) {
+  __shared__ float tile[(GRAM == 1) ? U_RR : 16][(GRAM == 1) ? 17 : 65];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, t = lane & 15;
   const int64_t c0 = (int64_t)blockIdx.x * 64 + 4 * t;
-  if (c0 >= nc) return;
+  const bool col_ok = c0 < nc;
+  const bool gram_wg = (GRAM == 1) ? (blockIdx.x == 0) : ((GRAM == 2) ? (blockIdx.y == 0) : false);
   float4 wt[16];
 #pragma unroll
-  for (int i = 0; i < 16; ++i) wt[i] = *reinterpret_cast<const float4*>(Wt + (int64_t)i * wt_pitch + c0);
+  for (int i = 0; i < 16; ++i)
+    wt[i] = col_ok ? *reinterpret_cast<const float4*>(Wt + (int64_t)i * wt_pitch + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
   const int64_t rbeg = (int64_t)blockIdx.y * U_RR;
 #pragma unroll 2
   for (int it = 0; it < U_RR / 16; ++it) {
-    const int64_t r = rbeg + it * 16 + w * 4 + g;
-    if (r < rows) {
+    const int lr = it * 16 + w * 4 + g;
+    const int64_t r = rbeg + lr;
+    float4 cv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r < rows && col_ok) {
       float4* cp = reinterpret_cast<float4*>(C + r * ldc + c0);
-      float4 cv = *cp;
+      cv = *cp;
       const float4* vp = reinterpret_cast<const float4*>(V + r * 16);
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
@@ -506,6 +538,26 @@ __global__ __launch_bounds__(256) void update_kernel(float* __restrict__ C, int6
         }
       }
       *cp = cv;
+    }
+    if (GRAM == 1 && gram_wg && t < 4) {
+      tile[lr][4 * t] = cv.x; tile[lr][4 * t + 1] = cv.y; tile[lr][4 * t + 2] = cv.z; tile[lr][4 * t + 3] = cv.w;
+    }
+    if (GRAM == 2 && gram_wg && it == 0) {
+      tile[lr][4 * t] = cv.x; tile[lr][4 * t + 1] = cv.y; tile[lr][4 * t + 2] = cv.z; tile[lr][4 * t + 3] = cv.w;
+    }
+  }
+  if (GRAM != 0 && gram_wg) {       // uniform per workgroup
+    __syncthreads();
+    const int i = tid >> 4, c = tid & 15;
+    double acc = 0.0;
+    if (GRAM == 1) {
+#pragma unroll 8
+      for (int rr = 0; rr < U_RR; ++rr) acc += (double)tile[rr][i] * (double)tile[rr][c];
+      Gpart[(int64_t)blockIdx.y * 256 + tid] = acc;
+    } else {
+#pragma unroll 8
+      for (int cc = 0; cc < 64; ++cc) acc += (double)tile[i][cc] * (double)tile[c][cc];
+      Gpart[(int64_t)blockIdx.x * 256 + tid] = acc;
     }
   }
 }
@@ -669,27 +721,35 @@ __global__ __launch_bounds__(256) void ypass_kernel(const float* __restrict__ C,
 __global__ __launch_bounds__(256) void yreduce_kernel(const float* __restrict__ Ypart, int nchunks, int64_t rows,
                                                       const double* __restrict__ Tinv, float* __restrict__ Z) {
   __shared__ float Ts[16][17];
-  const int tid = threadIdx.x;
+  __shared__ float part[4][64][17];
+  const int tid = threadIdx.x, cg = tid >> 6, rl = tid & 63;
   Ts[tid >> 4][tid & 15] = (float)Tinv[tid];
-  __syncthreads();
-  const int64_t r = (int64_t)blockIdx.x * 256 + tid;
-  if (r >= rows) return;
+  const int64_t r = (int64_t)blockIdx.x * 64 + rl;
   float s[16];
 #pragma unroll
   for (int i = 0; i < 16; ++i) s[i] = 0.f;
-  for (int ch = 0; ch < nchunks; ++ch) {
-    const float4* yp = reinterpret_cast<const float4*>(Ypart + ((int64_t)ch * rows + r) * 16);
+  if (r < rows) {
+    for (int ch = cg; ch < nchunks; ch += 4) {
+      const float4* yp = reinterpret_cast<const float4*>(Ypart + ((int64_t)ch * rows + r) * 16);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const float4 v = yp[q];
-      s[4 * q] += v.x; s[4 * q + 1] += v.y; s[4 * q + 2] += v.z; s[4 * q + 3] += v.w;
+      for (int q = 0; q < 4; ++q) {
+        const float4 v = yp[q];
+        s[4 * q] += v.x; s[4 * q + 1] += v.y; s[4 * q + 2] += v.z; s[4 * q + 3] += v.w;
+      }
     }
   }
-  float z[16];
-  tsolve(Ts, 1, s, z);
-  float4* zp = reinterpret_cast<float4*>(Z + r * 16);
 #pragma unroll
-  for (int q = 0; q < 4; ++q) zp[q] = make_float4(z[4 * q], z[4 * q + 1], z[4 * q + 2], z[4 * q + 3]);
+  for (int i = 0; i < 16; ++i) part[cg][rl][i] = s[i];
+  __syncthreads();
+  if (cg == 0 && r < rows) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s[i] = (part[0][rl][i] + part[1][rl][i]) + (part[2][rl][i] + part[3][rl][i]);
+    float z[16];
+    tsolve(Ts, 1, s, z);
+    float4* zp = reinterpret_cast<float4*>(Z + r * 16);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) zp[q] = make_float4(z[4 * q], z[4 * q + 1], z[4 * q + 2], z[4 * q + 3]);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------ stage 2: band
@@ -1280,7 +1340,7 @@ __global__ __launch_bounds__(256) void transpose_out_kernel(const float* __restr
 static inline size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct Layout {
-  size_t Af, Vl, Vr, Vt, Zr, Tl, Tr, Dblk, Eblk, Gpart, Wpart, Wt, Bd, Tb, Trot, scal, shifts, counts, flags, lo, hi,
+  size_t Af, Vl, Vr, Vt, Zr, Tl, Tr, Dblk, Eblk, Gpart, Gpart2, Xbuf, Wpart, Wt, Bd, Tb, Trot, scal, shifts, counts, flags, lo, hi,
       status, Lc, Dd, X, Uu, Vv, total;
   int64_t np, kcap, nshift;
 };
@@ -1304,8 +1364,10 @@ static Layout make_layout(int64_t m, int64_t n, int64_t kcap) {
   L.Tr = take((size_t)np * 256 * 8);
   L.Dblk = take((size_t)np * 256 * 8);
   L.Eblk = take((size_t)np * 256 * 8);
-  const int64_t maxparts = (m + 255) / 256 + 1;
+  const int64_t maxparts = (m + 127) / 128 + 1;      // gram_kernel: 256 rows per part; update_kernel<1>: 128
   L.Gpart = take((size_t)maxparts * 256 * 8);
+  L.Gpart2 = take((size_t)((n + 63) / 64 + 1) * 256 * 8);      // update_kernel<2>: one part per 64 columns
+  L.Xbuf = take(256 * 8);
   const int64_t wide = n > kcap ? n : kcap;
   const int64_t chunks = (m + W_RC - 1) / W_RC;
   size_t wpart = (size_t)chunks * 16 * wide * 4;
@@ -1418,63 +1480,72 @@ static int section_round(const Layout& L, char* base, int64_t n, int64_t q0, int
 
 static int stage1(const Layout& L, char* base, int64_t m, int64_t n) {
   float* Af = (float*)(base + L.Af);
-  double* Gpart = (double*)(base + L.Gpart);
+  double* Gc = (double*)(base + L.Gpart);                 // partial Grams of the next column panel
+  double* Gr = (double*)(base + L.Gpart2);                // ... of the next row panel
+  double* Xb = (double*)(base + L.Xbuf);
   float* Wpart = (float*)(base + L.Wpart);
   float* Wt = (float*)(base + L.Wt);
   float* Vt = (float*)(base + L.Vt);
   int* status = (int*)(base + L.status);
   const int64_t np = L.np;
+  int parts_c = (int)((m + 255) / 256), parts_r = 0;
+  hipLaunchKernelGGL((gram_kernel<false>), dim3(parts_c), dim3(256), 0, stream(), (const float*)Af, n, m, Gc);
   for (int64_t p = 0; p < np; ++p) {
     const int64_t j = 16 * p;
+    const int64_t mj = m - j, nc = n - j - 16, mr = m - j - 16;
     // ---- column panel: rows j .., columns j .. j + 15
     {
-      const int64_t mj = m - j;
       const float* P = Af + j * n + j;
       float* V = (float*)(base + L.Vl) + vl_offset(m, p);
-      const int parts = (int)((mj + 255) / 256);
-      hipLaunchKernelGGL((gram_kernel<false>), dim3(parts), dim3(256), 0, stream(), P, n, mj, Gpart);
-      const int fb = (int)((mj - 16 + 255) / 256);
-      hipLaunchKernelGGL((factor_kernel<false>), dim3(fb > 0 ? fb : 1), dim3(256), 0, stream(), P, n, mj,
-                         (const double*)Gpart, parts, V, (float*)nullptr, (int64_t)0, (double*)(base + L.Tl) + p * 256,
-                         (double*)(base + L.Dblk) + p * 256, status);
-      const int64_t nc = n - j - 16;
+      double* Tp = (double*)(base + L.Tl) + p * 256;
+      hipLaunchKernelGGL((factor_kernel<false>), dim3(1), dim3(256), 0, stream(), P, n, (const double*)Gc, parts_c, Xb, V,
+                         (float*)nullptr, (int64_t)0, Tp, (double*)(base + L.Dblk) + p * 256, status);
+      if (mj > 16)
+        hipLaunchKernelGGL((formv_kernel<false>), dim3((unsigned)((mj - 16 + 255) / 256)), dim3(256), 0, stream(), P, n, mj,
+                           (const double*)Xb, V, (float*)nullptr, (int64_t)0);
       if (nc > 0) {
         float* C = Af + j * n + j + 16;
         const int chunks = (int)((mj + W_RC - 1) / W_RC);
         hipLaunchKernelGGL(wpass_kernel, dim3((unsigned)((nc + 63) / 64), chunks), dim3(256), 0, stream(),
                            (const float*)C, n, mj, nc, (const float*)V, Wpart);
-        hipLaunchKernelGGL(wreduce_kernel, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, stream(),
-                           (const float*)Wpart, chunks, nc, (const double*)(base + L.Tl) + p * 256, 1, Wt);
-        hipLaunchKernelGGL(update_kernel, dim3((unsigned)((nc + 63) / 64), (unsigned)((mj + U_RR - 1) / U_RR)), dim3(256),
-                           0, stream(), C, n, mj, nc, (const float*)V, (const float*)Wt, nc);
+        hipLaunchKernelGGL(wreduce_kernel, dim3((unsigned)((nc + 63) / 64)), dim3(256), 0, stream(), (const float*)Wpart,
+                           chunks, nc, (const double*)Tp, 1, Wt);
+        // the update also leaves the partial Grams of the row panel (first 16 rows of the updated block)
+        const dim3 grid((unsigned)((nc + 63) / 64), (unsigned)((mj + U_RR - 1) / U_RR));
+        hipLaunchKernelGGL((update_kernel<2>), grid, dim3(256), 0, stream(), C, n, mj, nc, (const float*)V,
+                           (const float*)Wt, nc, Gr);
+        parts_r = (int)grid.x;
       }
     }
     // ---- row panel: rows j .. j + 15, columns j + 16 ..
-    const int64_t nc = n - j - 16;
     if (nc > 0) {
       const float* P = Af + j * n + j + 16;
       float* V = (float*)(base + L.Vr) + vr_offset(n, p);
-      const int parts = (int)((nc + 255) / 256);
-      hipLaunchKernelGGL((gram_kernel<true>), dim3(parts), dim3(256), 0, stream(), P, n, nc, Gpart);
-      const int fb = (int)((nc - 16 + 255) / 256);
-      hipLaunchKernelGGL((factor_kernel<true>), dim3(fb > 0 ? fb : 1), dim3(256), 0, stream(), P, n, nc,
-                         (const double*)Gpart, parts, V, Vt, nc, (double*)(base + L.Tr) + p * 256,
-                         (double*)(base + L.Eblk) + p * 256, status);
-      const int64_t mr = m - j - 16;
+      double* Tp = (double*)(base + L.Tr) + p * 256;
+      hipLaunchKernelGGL((factor_kernel<true>), dim3(1), dim3(256), 0, stream(), P, n, (const double*)Gr, parts_r, Xb, V, Vt,
+                         nc, Tp, (double*)(base + L.Eblk) + p * 256, status);
+      if (nc > 16)
+        hipLaunchKernelGGL((formv_kernel<true>), dim3((unsigned)((nc - 16 + 255) / 256)), dim3(256), 0, stream(), P, n, nc,
+                           (const double*)Xb, V, Vt, nc);
       if (mr > 0) {
         float* C = Af + (j + 16) * n + j + 16;
         if (g_row_fused) {
           hipLaunchKernelGGL(rowupdate_kernel, dim3((unsigned)((mr + 15) / 16)), dim3(256), 0, stream(), C, n, mr, nc,
-                             (const float*)Vt, nc, (const double*)(base + L.Tr) + p * 256);
+                             (const float*)Vt, nc, (const double*)Tp);
+          parts_c = (int)((mr + 255) / 256);
+          hipLaunchKernelGGL((gram_kernel<false>), dim3(parts_c), dim3(256), 0, stream(), (const float*)C, n, mr, Gc);
         } else {
           const int ych = (int)((nc + Y_COLS - 1) / Y_COLS);
           float* Z = (float*)(base + L.Zr);
           hipLaunchKernelGGL(ypass_kernel, dim3(ych, (unsigned)((mr + Y_ROWS - 1) / Y_ROWS)), dim3(256), 0, stream(),
                              (const float*)C, n, mr, nc, (const float*)Vt, nc, Wpart);
-          hipLaunchKernelGGL(yreduce_kernel, dim3((unsigned)((mr + 255) / 256)), dim3(256), 0, stream(),
-                             (const float*)Wpart, ych, mr, (const double*)(base + L.Tr) + p * 256, Z);
-          hipLaunchKernelGGL(update_kernel, dim3((unsigned)((nc + 63) / 64), (unsigned)((mr + U_RR - 1) / U_RR)), dim3(256),
-                             0, stream(), C, n, mr, nc, (const float*)Z, (const float*)Vt, nc);
+          hipLaunchKernelGGL(yreduce_kernel, dim3((unsigned)((mr + 63) / 64)), dim3(256), 0, stream(),
+                             (const float*)Wpart, ych, mr, (const double*)Tp, Z);
+          // ... and this update the partial Grams of the next column panel (first 16 columns of the updated block)
+          const dim3 grid((unsigned)((nc + 63) / 64), (unsigned)((mr + U_RR - 1) / U_RR));
+          hipLaunchKernelGGL((update_kernel<1>), grid, dim3(256), 0, stream(), C, n, mr, nc, (const float*)Z,
+                             (const float*)Vt, nc, Gc);
+          parts_c = (int)grid.y;
         }
       }
     }
@@ -1580,10 +1651,10 @@ static int vectors(const Layout& L, char* base, int64_t m, int64_t n, int64_t k,
     const int chunks = (int)((mj + W_RC - 1) / W_RC);
     hipLaunchKernelGGL(wpass_kernel, dim3((unsigned)((k + 63) / 64), chunks), dim3(256), 0, stream(), (const float*)C, k,
                        mj, k, V, Wpart);
-    hipLaunchKernelGGL(wreduce_kernel, dim3((unsigned)((k + 255) / 256)), dim3(256), 0, stream(), (const float*)Wpart,
+    hipLaunchKernelGGL(wreduce_kernel, dim3((unsigned)((k + 63) / 64)), dim3(256), 0, stream(), (const float*)Wpart,
                        chunks, k, (const double*)(base + L.Tl) + p * 256, 0, Wt);
-    hipLaunchKernelGGL(update_kernel, dim3((unsigned)((k + 63) / 64), (unsigned)((mj + U_RR - 1) / U_RR)), dim3(256), 0,
-                       stream(), C, k, mj, k, V, (const float*)Wt, k);
+    hipLaunchKernelGGL((update_kernel<0>), dim3((unsigned)((k + 63) / 64), (unsigned)((mj + U_RR - 1) / U_RR)), dim3(256), 0,
+                       stream(), C, k, mj, k, V, (const float*)Wt, k, (double*)nullptr);
   }
   TNH_LAUNCH_CHECK();
   // V = Q_R V_b: row-panel reflectors, last to first
@@ -1594,10 +1665,10 @@ static int vectors(const Layout& L, char* base, int64_t m, int64_t n, int64_t k,
     const int chunks = (int)((nj + W_RC - 1) / W_RC);
     hipLaunchKernelGGL(wpass_kernel, dim3((unsigned)((k + 63) / 64), chunks), dim3(256), 0, stream(), (const float*)C, k,
                        nj, k, V, Wpart);
-    hipLaunchKernelGGL(wreduce_kernel, dim3((unsigned)((k + 255) / 256)), dim3(256), 0, stream(), (const float*)Wpart,
+    hipLaunchKernelGGL(wreduce_kernel, dim3((unsigned)((k + 63) / 64)), dim3(256), 0, stream(), (const float*)Wpart,
                        chunks, k, (const double*)(base + L.Tr) + p * 256, 0, Wt);
-    hipLaunchKernelGGL(update_kernel, dim3((unsigned)((k + 63) / 64), (unsigned)((nj + U_RR - 1) / U_RR)), dim3(256), 0,
-                       stream(), C, k, nj, k, V, (const float*)Wt, k);
+    hipLaunchKernelGGL((update_kernel<0>), dim3((unsigned)((k + 63) / 64), (unsigned)((nj + U_RR - 1) / U_RR)), dim3(256), 0,
+                       stream(), C, k, nj, k, V, (const float*)Wt, k, (double*)nullptr);
   }
   }
   hipLaunchKernelGGL(transpose_out_kernel, dim3((unsigned)((n + 31) / 32), (unsigned)((k + 31) / 32)), dim3(256), 0,
