@@ -25,7 +25,9 @@ Extra objects on the same line:
   cpu_baseline   -- the NumPy oracle (port of the reference's tensordot) timed on this box's host cores on a
                     bounded sample (same layout, smaller D).
   svd            -- split_node truncated SVD (configs[2]: (16,)*6 node -> 4096 x 4096, keep 256) in the metric's
-                    GB/s, with the oracle's LAPACK SVD timed on a bounded sample beside it.
+                    GB/s; `sweep` holds SURVEY 8d's full case list: Gaussian and s_i = 2^(-i/32) inputs, natural and
+                    mixed edge order, n = 512 .. 4096, each checked against LAPACK (verified.svd); the oracle's
+                    LAPACK SVD timed on a bounded sample beside it.
   bond_sweep     -- the metric's bond-dimension sweep: contract_between of two rank-4 bf16 nodes at
                     D = 32 .. 256 in the favourable (L0) and the permute-needing (L1) layout, plus the
                     north-star "D = 512" row A(64,128,512,512) . B(512,512,128,64) (GEMM 8192 x 8192 x 262144),
@@ -319,54 +321,55 @@ def cpu_baseline(layout):
 
 
 # --------------------------------------------------------------------------- configs[2]
-def svd_bench(ta, be, n, k, keep_outputs=False):
-  """configs[2]: split_node of a rank-6 fp32 node reshaped n x n, keep k."""
-  side = round(n ** (1.0 / 3.0))
-  if side**3 != n:
-    shape, left_axes, right_axes = (n, n), [0], [1]
+_SVD_DIMS = {512: (8, 8, 8), 1024: (8, 8, 16), 2048: (8, 16, 16), 4096: (16, 16, 16)}
+
+
+def svd_case_matrix(be, n, kind, seed):
+  """The n x n f32 matrix of one configs[2] case, made in HBM.  'gauss': N(0, 1) entries; 'graded': prescribed
+  spectrum s_i = 2^(-i/32) between two orthogonal factors (the construction of decompositions_test.py:55-66, with
+  the factors taken from the device QR of Gaussian matrices instead of a host SVD)."""
+  if kind == "gauss":
+    return be.device_random((n, n), dtype=np.float32, seed=seed, normal=True)
+  qu, _ = be.qr(be.device_random((n, n), dtype=np.float32, seed=seed + 1, normal=True), 1)
+  qv, _ = be.qr(be.device_random((n, n), dtype=np.float32, seed=seed + 2, normal=True), 1)
+  spec = be.convert_to_tensor((2.0 ** (-np.arange(n) / 32.0)).astype(np.float32))
+  return be.tensordot(be.broadcast_right_multiplication(qu, spec), qv, [[1], [1]])
+
+
+def svd_case(ta, be, mat, n, k, order):
+  """split_node of the rank-6 node whose (left | right) matricisation is `mat`; order 'natural': node axes
+  (l0 l1 l2 r0 r1 r2), left edges [0, 1, 2]; 'mixed' (split_node_test.py:36-47): node axes (l0 r0 l1 r1 l2 r2),
+  left edges [0, 2, 4], right edges [1, 3, 5] -- split_node has to permute before it can reshape."""
+  d = _SVD_DIMS.get(n)
+  if d is None:
+    x, left_axes, right_axes = mat, [0], [1]
+  elif order == "natural":
+    x, left_axes, right_axes = be.reshape(mat, d + d), [0, 1, 2], [3, 4, 5]
   else:
-    shape, left_axes, right_axes = (side,) * 6, [0, 1, 2], [3, 4, 5]
-  x = be.device_random(shape, dtype=np.float32, seed=3, normal=True)
-  node = ta.Node(x, backend=be)
-  be.synchronize()
-  t0 = time.perf_counter()
-  left, right, trun = ta.split_node(node, [node[i] for i in left_axes], [node[i] for i in right_axes],
-                                    max_singular_values=k)
-  be.synchronize()
-  t = time.perf_counter() - t0
+    x, left_axes, right_axes = be.transpose(be.reshape(mat, d + d), (0, 3, 1, 4, 2, 5)), [0, 2, 4], [1, 3, 5]
+  best, out = float("inf"), None
+  for rep in range(2):          # the first call warms the allocator; the second is the number
+    node = ta.Node(x, backend=be)
+    be.synchronize()
+    t0 = time.perf_counter()
+    left, right, trun = ta.split_node(node, [node[i] for i in left_axes], [node[i] for i in right_axes],
+                                      max_singular_values=k)
+    be.synchronize()
+    t = time.perf_counter() - t0
+    if rep == 1:
+      best, out = t, (left.tensor, right.tensor, trun)
   nbytes = 4 * (n * n + n * k + n + k * n)  # SURVEY 8d: read A, write u_k, all s, vh_k
-  # matrix-pipe work of the block Jacobi (tnh_svd_block.hip; top-k mode, rotations not accumulated): per sweep
-  # nb - 1 rounds of nb / 2 block pairs (32-row blocks of the padded P x Q working matrix), per pair three
-  # 32 x 32 x Q Gram tiles and the 64 x 64 x Q update
-  P = Q = -(-n // 128) * 128
-  nb = P // 32
-  mfma_flops = be.last_svd_sweeps * (nb - 1) * (nb // 2) * (3 * 2 * 32 * 32 * Q + 2 * 64 * 64 * Q)
-  rec = {"n": n, "k": k, "seconds": t, "gbps": nbytes / t / 1e9, "sweeps": be.last_svd_sweeps,
-         "algorithmic_bytes": nbytes, "trunc_len": int(trun.shape[0]),
-         "hbm_roofline_frac": nbytes / t / 1e9 / HBM_PEAK_GBPS,
-         "mfma_flops": float(mfma_flops), "mfma_tflops": mfma_flops / t / 1e12,
-         "frac_of_f32_mfma_peak": mfma_flops / t / 1e12 / F32_MFMA_PEAK_TFLOPS,
-         "workload": f"split_node of a {shape} f32 node as {n}x{n}, max_singular_values={k} (second call; "
-                     "first call warms the allocator)",
-         "note": "block one-sided Jacobi: MFMA gram/update + LDS eigensolver per block pair; bound by "
-                 "MFMA flops and LDS latency over the sweeps, not by the algorithmic-bytes HBM figure "
-                 "(see DESIGN.md)"}
-  if keep_outputs:
-    return rec, (x, left.tensor, right.tensor, trun)
-  return rec
+  rec = {"n": n, "k": k, "order": order, "seconds": best, "gbps": nbytes / best / 1e9,
+         "hbm_roofline_frac": nbytes / best / 1e9 / HBM_PEAK_GBPS, "algorithmic_bytes": nbytes,
+         "path": getattr(be, "last_svd_path", None), "sweeps": be.last_svd_sweeps}
+  return rec, out
 
 
-def verify_svd(be, n, k, outputs):
-  """configs[2] at full size against LAPACK (SURVEY 8c tolerances): split_node returns left = u sqrt(s),
-  right = sqrt(s) vh (network_operations.py:219-226) and the discarded values.  Checked: the discarded
-  values against np.linalg.svd's (all n - k of them), the kept ones through the column norms of `left`
-  (= sqrt(s_i)), orthogonality of the kept vectors, and the reconstruction error against the best
-  rank-k error sqrt(sum s_rest^2)."""
-  x, left, right, trun = outputs
-  t0 = time.perf_counter()
-  a = host64(x).reshape(n, n)
-  s_ref = np.linalg.svd(a, compute_uv=False)
-  t_lapack = time.perf_counter() - t0
+def check_svd_case(mat_host, s_ref, n, k, outputs):
+  """One case against LAPACK (SURVEY 8c tolerances): split_node returns left = u sqrt(s), right = sqrt(s) vh
+  (network_operations.py:219-226) and the discarded values.  Checked: ALL n singular values (kept ones through the
+  column norms of `left`), orthonormality of the kept vectors, reconstruction against the best rank-k error."""
+  left, right, trun = outputs
   lw = host64(left).reshape(n, k)          # u sqrt(s)
   rw = host64(right).reshape(k, n)         # sqrt(s) vh
   s_rest = host64(trun).reshape(-1)
@@ -377,15 +380,63 @@ def verify_svd(be, n, k, outputs):
   vh = rw / np.sqrt(s_kept)[:, None]
   orth_u = float(np.max(np.abs(u.T @ u - np.eye(k))))
   orth_v = float(np.max(np.abs(vh @ vh.T - np.eye(k))))
-  recon = float(np.linalg.norm(a - lw @ rw))
+  recon = float(np.linalg.norm(mat_host - lw @ rw))
   best = float(np.sqrt(np.sum(s_ref[k:] ** 2)))
-  norm_a = float(np.linalg.norm(a))
-  rec_excess = (recon - best) / norm_a
+  rec_excess = (recon - best) / float(np.linalg.norm(mat_host))
   ok = s_err <= 1e-5 and orth_u <= 1e-4 and orth_v <= 1e-4 and abs(rec_excess) <= 1e-4 and len(s_rest) == n - k
-  return {"n": n, "k": k, "s_max_err_over_s0": s_err, "s_rest_len": int(len(s_rest)), "orth_u": orth_u, "orth_vh": orth_v,
-          "recon_minus_best_over_normA": rec_excess, "lapack_values_only_seconds": t_lapack,
-          "tol": "|s - s_lapack| <= 1e-5 s0 (all n values), orthonormality <= 1e-4, (||A - L R||_F - best rank-k) <= 1e-4 ||A||_F",
-          "ok": bool(ok)}
+  return {"s_max_err_over_s0": s_err, "s_rest_len": int(len(s_rest)), "orth_u": orth_u, "orth_vh": orth_v,
+          "recon_minus_best_over_normA": rec_excess, "ok": bool(ok)}
+
+
+def svd_sweep(ta, be, n_max, verify):
+  """configs[2] in full: inputs (i) Gaussian and (ii) s_i = 2^(-i/32), natural and mixed edge order,
+  n in {512, 1024, 2048, 4096} up to n_max, keep n / 16; each case timed (second call) in seconds and the metric's
+  GB/s, and checked against np.linalg.svd of the same matrix.  Returns (headline record = Gaussian, natural, n_max;
+  all rows; the verified object)."""
+  rows, checks = [], {}
+  headline = None
+  t_lapack = 0.0
+  for n in [x for x in (512, 1024, 2048, 4096) if x <= n_max] or [n_max]:
+    k = max(n // 16, 1)
+    for kind in ("gauss", "graded"):
+      mat = svd_case_matrix(be, n, kind, seed=3 + n)
+      s_ref = mat_host = None
+      if verify:
+        mat_host = host64(mat).reshape(n, n)
+        t0 = time.perf_counter()
+        s_ref = np.linalg.svd(mat_host, compute_uv=False)
+        t_lapack += time.perf_counter() - t0
+      for order in ("natural", "mixed"):
+        rec, out = svd_case(ta, be, mat, n, k, order)
+        rec["input"] = kind
+        if verify:
+          chk = check_svd_case(mat_host, s_ref, n, k, out)
+          rec["check"] = chk
+          checks[f"{kind}_{order}_{n}"] = chk["ok"]
+        rows.append(rec)
+        if kind == "gauss" and order == "natural":
+          headline = dict(rec)
+        del out
+      del mat
+    be.lib.tnh_trim()
+  headline = dict(headline or rows[-1])
+  headline["workload"] = (f"split_node of a rank-6 f32 node as {headline['n']}x{headline['n']}, "
+                          f"max_singular_values={headline['k']} (Gaussian, natural order; second call)")
+  headline["note"] = ("min(m, n) >= 1024: band reduction (Cholesky-QR panels, rank-16 streaming updates) + spectrum "
+                      "slicing on T = B^T B in f64 + inverse iteration + back-transformation (tnh_svd_band.hip); "
+                      "smaller: block one-sided Jacobi.  Bound by dependent small kernels and f64 VALU, not by the "
+                      "algorithmic-bytes HBM figure (DESIGN.md section 6)")
+  verified = None
+  if verify:
+    worst = max(rows, key=lambda r: r["check"]["s_max_err_over_s0"])
+    verified = {"cases": checks, "n_cases": len(checks), "worst_s_err_over_s0": worst["check"]["s_max_err_over_s0"],
+                "worst_orth": max(max(r["check"]["orth_u"], r["check"]["orth_vh"]) for r in rows),
+                "worst_recon_minus_best_over_normA": max(abs(r["check"]["recon_minus_best_over_normA"]) for r in rows),
+                "lapack_values_only_seconds": t_lapack,
+                "tol": "|s - s_lapack| <= 1e-5 s0 (all n values), orthonormality <= 1e-4, "
+                       "(||A - L R||_F - best rank-k) <= 1e-4 ||A||_F",
+                "ok": bool(all(checks.values()))}
+  return headline, rows, verified
 
 
 def svd_cpu_baseline(n_full):
@@ -881,15 +932,11 @@ def main():
       _lib.check(be.lib.tnh_trim())
     if single and args.svd_n > 0:
       try:
-        k = max(args.svd_n // 16, 1)
-        svd_bench(ta, be, args.svd_n, k)  # warm-up
-        result["svd"], outputs = svd_bench(ta, be, args.svd_n, k, keep_outputs=True)
-        if not args.no_verify:
-          try:
-            verified["svd"] = verify_svd(be, args.svd_n, k, outputs)
-          except Exception as exc:  # pylint: disable=broad-except
-            verified["svd"] = {"error": f"{type(exc).__name__}: {exc}"}
-        del outputs
+        head, rows, chk = svd_sweep(ta, be, args.svd_n, not args.no_verify)
+        result["svd"] = head
+        result["svd"]["sweep"] = rows
+        if chk is not None:
+          verified["svd"] = chk
         if not args.no_cpu_baseline:
           result["svd"]["cpu_baseline"] = svd_cpu_baseline(args.svd_n)
       except Exception as exc:  # pylint: disable=broad-except

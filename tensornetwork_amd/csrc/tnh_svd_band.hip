@@ -79,6 +79,31 @@ __device__ __forceinline__ double sum16(double v) {      // every lane of the ro
   return v;
 }
 
+// f32 reductions without the LDS crossbar (ds_bpermute needs a wait per step):
+//   rowsum16: sum over the 16 lanes of a DPP row, every lane gets it (row_ror 8 / 4 / 2 / 1);
+//   rowsx4:   sum over the four rows of the wave, lane % 16 kept (gfx950 v_permlane16_swap / v_permlane32_swap: with
+//             both operands the same register the two results are the two halves exchanged, so their sum is the
+//             pair sum in every lane).
+template <int ROT>
+__device__ __forceinline__ float ror16f(float v) {
+  return __uint_as_float((unsigned)__builtin_amdgcn_mov_dpp((int)__float_as_uint(v), 0x120 + ROT, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float rowsum16(float v) {
+  v += ror16f<8>(v);
+  v += ror16f<4>(v);
+  v += ror16f<2>(v);
+  v += ror16f<1>(v);
+  return v;
+}
+__device__ __forceinline__ float rowsx4(float v) {
+  const unsigned u = __float_as_uint(v);
+  auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  const float s = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+  const unsigned t = __float_as_uint(s);
+  auto b = __builtin_amdgcn_permlane32_swap(t, t, false, false);
+  return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+
 // 1 / d and 1 / sqrt(x) to full double precision from the hardware seeds (2^-26-ish) and two Newton steps: a
 // fraction of the IEEE division / square-root sequences, which sit on every pivot's critical path here.
 __device__ __forceinline__ double fast_rcp(double d) {
@@ -417,9 +442,7 @@ __global__ __launch_bounds__(256) void wpass_kernel(const float* __restrict__ C,
   for (int i = 0; i < 16; ++i)
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      float v = acc[i][q];
-      v += __shfl_xor(v, 16, 64);
-      v += __shfl_xor(v, 32, 64);
+      const float v = rowsx4(acc[i][q]);
       if (g == 0) red[w][i][4 * t + q] = v;
     }
   __syncthreads();
@@ -608,14 +631,7 @@ __global__ __launch_bounds__(256) void rowupdate_kernel(float* __restrict__ C, i
   }
   // combine the 16 column-chunk lanes of each row
 #pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    float v = y[i];
-    v += __shfl_xor(v, 8, 16);
-    v += __shfl_xor(v, 4, 16);
-    v += __shfl_xor(v, 2, 16);
-    v += __shfl_xor(v, 1, 16);
-    y[i] = v;
-  }
+  for (int i = 0; i < 16; ++i) y[i] = rowsum16(y[i]);
   float z[16];
   tsolve(Ts, 1, y, z);        // Z = Y T: row-wise z = T^T y
   // ---- sweep 2: C[r][c] -= sum_i z[i] Vt[i][c]
@@ -656,7 +672,7 @@ __global__ __launch_bounds__(256) void rowupdate_kernel(float* __restrict__ C, i
 //   ypass    Ypart[chunk][r][i] = sum over the chunk's 256 columns of C[r][c] Vt[i][c]      (64-row x 256-column tiles)
 //   yreduce  Z[r][:] = T^T (sum over chunks of Ypart[chunk][r][:])                            (Z = Y T)
 //   update_kernel(C, V := Z, Wt := Vt)                                                        (C -= Z V^T)
-constexpr int Y_ROWS = 64, Y_COLS = 256;
+constexpr int Y_ROWS = 64, Y_COLS = 128;
 __global__ __launch_bounds__(256) void ypass_kernel(const float* __restrict__ C, int64_t ldc, int64_t rows, int64_t nc,
                                                     const float* __restrict__ Vt, int64_t vt_pitch,
                                                     float* __restrict__ Ypart) {
@@ -706,11 +722,7 @@ __global__ __launch_bounds__(256) void ypass_kernel(const float* __restrict__ C,
     float mine = 0.f;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-      float v = y[it][i];
-      v += __shfl_xor(v, 8, 16);
-      v += __shfl_xor(v, 4, 16);
-      v += __shfl_xor(v, 2, 16);
-      v += __shfl_xor(v, 1, 16);
+      const float v = rowsum16(y[it][i]);
       if (t == i) mine = v;
     }
     const int64_t r = rbeg + it * 16 + w * 4 + g;
@@ -1194,10 +1206,22 @@ __global__ __launch_bounds__(256) void uv_init_kernel(const double* __restrict__
 constexpr int BT_COLS = 2;
 constexpr int BT_THREADS = 512;
 constexpr int BT_KEEP = 8;        // rows per thread held in registers: BT_THREADS * BT_KEEP = 4096 rows
-__global__ __launch_bounds__(BT_THREADS) void backtransform_kernel(float* __restrict__ X, int64_t ldx, int64_t rows,
-                                                                   int64_t ncols, const float* __restrict__ Vall,
-                                                                   const double* __restrict__ Tall, int64_t npanels,
-                                                                   int64_t row0, int64_t vrows0) {
+struct BtSide {
+  float* X;
+  int64_t ldx, rows;
+  const float* Vall;
+  const double* Tall;
+  int64_t npanels, row0, vrows0;
+};
+struct BtArgs {
+  BtSide side[2];          // blockIdx.y: 0 = U (column-panel reflectors), 1 = V (row-panel reflectors)
+};
+__global__ __launch_bounds__(BT_THREADS) void backtransform_kernel(BtArgs args) {
+  const BtSide sd = args.side[blockIdx.y];
+  float* __restrict__ X = sd.X;
+  const int64_t ldx = sd.ldx, rows = sd.rows, npanels = sd.npanels, row0 = sd.row0, vrows0 = sd.vrows0;
+  const float* __restrict__ Vall = sd.Vall;
+  const double* __restrict__ Tall = sd.Tall;
   extern __shared__ float xs[];                  // [rows][BT_COLS]
   __shared__ float red[BT_THREADS / 64][16][BT_COLS];
   __shared__ float wv[16][BT_COLS];
@@ -1260,9 +1284,7 @@ __global__ __launch_bounds__(BT_THREADS) void backtransform_kernel(float* __rest
     for (int i = 0; i < 16; ++i)
 #pragma unroll
       for (int q = 0; q < BT_COLS; ++q) {
-        float v = acc[i][q];
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+        const float v = rowsx4(rowsum16(acc[i][q]));
         if (lane == 0) red[w][i][q] = v;
       }
     __syncthreads();
@@ -1636,12 +1658,17 @@ static int vectors(const Layout& L, char* base, int64_t m, int64_t n, int64_t k,
                                   150 * 1024));
       attr_done = true;
     }
-    hipLaunchKernelGGL(backtransform_kernel, dim3((unsigned)(k / BT_COLS)), dim3(BT_THREADS), lds_u, stream(), Uu, k, m, k,
-                       (const float*)(base + L.Vl), (const double*)(base + L.Tl), L.np, (int64_t)0, m);
-    if (L.np > 1)
-      hipLaunchKernelGGL(backtransform_kernel, dim3((unsigned)(k / BT_COLS)), dim3(BT_THREADS), lds_v, stream(), Vv, k, n, k,
-                         (const float*)(base + L.Vr), (const double*)(base + L.Tr), L.np - 1, (int64_t)16, n - 16);
+    // the two sides are independent: ONE launch, blockIdx.y picks the side (k / 2 workgroups each: together they
+    // fill the chip)
+    BtArgs a;
+    a.side[0] = BtSide{Uu, k, m, (const float*)(base + L.Vl), (const double*)(base + L.Tl), L.np, (int64_t)0, m};
+    a.side[1] = BtSide{Vv, k, n, (const float*)(base + L.Vr), (const double*)(base + L.Tr), L.np - 1, (int64_t)16, n - 16};
+    hipLaunchKernelGGL(backtransform_kernel, dim3((unsigned)(k / BT_COLS), 2), dim3(BT_THREADS), lds_u > lds_v ? lds_u : lds_v,
+                       stream(), a);
+    hipLaunchKernelGGL(transpose_out_kernel, dim3((unsigned)((n + 31) / 32), (unsigned)((k + 31) / 32)), dim3(256), 0,
+                       stream(), (const float*)Vv, n, k, Vh);
     TNH_LAUNCH_CHECK();
+    return TNH_OK;
   } else {
   // U = Q_L [U_b; 0]: column-panel reflectors, last to first
   for (int64_t p = L.np - 1; p >= 0; --p) {
