@@ -441,6 +441,10 @@ def test_large_blocks_of_dead_nodes_return_to_the_pool(hip):
     _lib.check(hip.lib.tnh_mem_stats(ctypes.byref(in_use), ctypes.byref(cached), ctypes.byref(peak)))
     return in_use.value + cached.value
 
+  from tensornetwork_amd import device_tensor as dt
+  saved = dict(dt._GC_POLICY)
+  ta.configure_gc(freeze=True)     # round 3: the frozen-baseline policy is opt-in (bench.py opts in the same way)
+  dt.freeze_collector_baseline()
   gc.collect()
   gc.disable()                     # only the allocator's own collection may run
   try:
@@ -454,5 +458,6 @@ def test_large_blocks_of_dead_nodes_return_to_the_pool(hip):
     has = ctypes.c_int(-1)
     _lib.check(hip.lib.tnh_pool_has(1 << 40, ctypes.byref(has)))
     assert has.value == 0
+    ta.configure_gc(freeze=saved["freeze"], collect_before_large_alloc=saved["collect"])
   finally:
     gc.enable()
