@@ -539,7 +539,12 @@ int tnh_qr_work_bytes(int dtype, int64_t m, int64_t n, size_t* nbytes) {
   TNH_REQUIRE(nbytes != nullptr, "null nbytes");
   TNH_REQUIRE(dtype == TNH_F32 || dtype == TNH_F64, "tnh_qr supports f32 / f64 (got dtype %d)", dtype);
   TNH_REQUIRE(m >= 0 && n >= 0, "negative extent");
-  *nbytes = qr_layout(nullptr, dtype_size(dtype), m, n).total + 256;
+  size_t need = qr_layout(nullptr, dtype_size(dtype), m, n).total + 256;
+  if (qr_panel16_supported(dtype, m, n)) {
+    const size_t fast = qr_panel16_work_bytes(m, n);
+    if (fast > need) need = fast;
+  }
+  *nbytes = need;
   return TNH_OK;
 }
 
@@ -553,6 +558,14 @@ int tnh_qr(int dtype, int64_t m, int64_t n, const void* A, void* Q, void* R, voi
   TNH_REQUIRE(m >= 0 && n >= 0, "negative extent");
   if (m == 0 || n == 0) return TNH_OK;
   TNH_REQUIRE(A && Q && R && work, "null pointer");
+  if (qr_panel16_supported(dtype, m, n)) {
+    // 16-wide Cholesky-QR panels (one small kernel per panel instead of a launch per column); a numerically
+    // rank-deficient panel is reported and the matrix goes through the column-by-column path below
+    int st = 0;
+    const int rc = qr_panel16(m, n, (const float*)A, (float*)Q, (float*)R, work, &st);
+    if (rc != TNH_OK) return rc;
+    if (st == 0) return TNH_OK;
+  }
   char* base = (char*)(((uintptr_t)work + 255) & ~(uintptr_t)255);
   if (dtype == TNH_F32) return qr_run<float>(dtype, m, n, (const float*)A, (float*)Q, (float*)R, base);
   return qr_run<double>(dtype, m, n, (const double*)A, (double*)Q, (double*)R, base);

@@ -181,7 +181,10 @@ __device__ __forceinline__ void wave_sync() {
 
 // All 256 threads.  In: sh.G0 = sh.G (Gram, f64), sh.Pt.  Out: sh.X, sh.L (V_top), sh.Ti (T^-1, reciprocal diagonal),
 // sh.R and sh.S (R_h = S R), sh.bad.
-__device__ __forceinline__ void panel_factor(FactorShared& sh) {
+// degenerate: the panel has exactly 16 rows, so its last column has nothing below the diagonal.  LAPACK's larfg
+// then returns tau = 0 (H = I, the entry keeps its sign); here: S_15 = +sign, reciprocal diagonal of T^-1 = 0
+// (so that T w has a zero last component), and R matches np.linalg.qr also in its last diagonal entry.
+__device__ __forceinline__ void panel_factor(FactorShared& sh, bool degenerate) {
   const int tid = threadIdx.x, i = tid >> 4, c = tid & 15;
   if (tid == 0) sh.bad = 0;
   __syncthreads();
@@ -230,9 +233,10 @@ __device__ __forceinline__ void panel_factor(FactorShared& sh) {
       constexpr int j = decltype(jc)::value;
       const double wjj = bcast16_dpp<j>(Wr[j]);
       const double rjj = bcast16_dpp<j>(Rr[j]);
-      const double sj = (wjj >= 0.0) ? -1.0 : 1.0;
+      const bool noop = degenerate && j == 15;
+      const double sj = ((wjj >= 0.0) != noop) ? -1.0 : 1.0;
       if (tid == 0) sh.S[j] = sj;
-      const double pj = fma(-sj, rjj, wjj);
+      const double pj = noop ? 1.0 : fma(-sj, rjj, wjj);
       const double lrj = (r > j) ? Wr[j] * fast_rcp(pj) : 0.0;
       Wr[j] = (r == j) ? pj : ((r > j) ? lrj : Wr[j]);
       const double sown = (r == j) ? sj : 0.0;                // only row j takes the S R term
@@ -288,7 +292,7 @@ __device__ __forceinline__ void panel_factor(FactorShared& sh) {
     double z = 0.0;
 #pragma unroll
     for (int k = 0; k < 16; ++k) z += sh.X[k][i] * sh.ZX[k][c];
-    sh.Ti[i][c] = (c > i) ? z : (c == i ? 2.0 / z : 0.0);       // diagonal: 1 / (N_ii / 2)
+    sh.Ti[i][c] = (c > i) ? z : (c == i ? ((degenerate && i == 15) ? 0.0 : 2.0 / z) : 0.0);   // diagonal: 1 / (N_ii / 2)
   }
   __syncthreads();
 }
@@ -301,7 +305,7 @@ __device__ __forceinline__ void panel_factor(FactorShared& sh) {
 // (Round-3 measurement: the first version repeated this factorisation in every V-forming workgroup; with more than 8
 // workgroups the launch took 40-60 us instead of 12.)
 template <bool ROWPANEL>
-__global__ __launch_bounds__(256) void factor_kernel(const float* __restrict__ P, int64_t lda,
+__global__ __launch_bounds__(256) void factor_kernel(const float* __restrict__ P, int64_t lda, int64_t rows,
                                                      const double* __restrict__ Gpart, int nparts,
                                                      double* __restrict__ Xout, float* __restrict__ Vout,
                                                      float* __restrict__ VtOut, int64_t vt_pitch,
@@ -327,7 +331,7 @@ __global__ __launch_bounds__(256) void factor_kernel(const float* __restrict__ P
     sh.Pt[i][c] = (double)(ROWPANEL ? P[(int64_t)c * lda + i] : P[(int64_t)i * lda + c]);
   }
   __syncthreads();
-  panel_factor(sh);
+  panel_factor(sh, rows == 16);
   Xout[tid] = sh.X[i][c];
   Tout[tid] = sh.Ti[i][c];
   const double rh = (c >= i) ? sh.S[i] * sh.R[i][c] : 0.0;     // R_h = S R, upper
@@ -522,12 +526,13 @@ __global__ __launch_bounds__(256) void wreduce_kernel(const float* __restrict__ 
 //           first 16 columns of the UPDATED C -- the next column panel -- to Gpart[blockIdx.y]   (gridDim.y partials);
 // GRAM = 2: the workgroups of the first row tile write the partial Gram matrices (over their 64 columns) of the first
 //           16 rows of the updated C -- the next row panel -- to Gpart[blockIdx.x]                (gridDim.x partials).
+//           (rows below gram_row0 only: the QR keeps its R rows at the top of the block);
 // Either saves the separate pass of gram_kernel over the panel and its launch.
 constexpr int U_RR = 128;
 template <int GRAM>
 __global__ __launch_bounds__(256) void update_kernel(float* __restrict__ C, int64_t ldc, int64_t rows, int64_t nc,
                                                      const float* __restrict__ V, const float* __restrict__ Wt,
-                                                     int64_t wt_pitch, double* __restrict__ Gpart) {
+                                                     int64_t wt_pitch, double* __restrict__ Gpart, int64_t gram_row0) {
   __shared__ float tile[(GRAM == 1) ? U_RR : 16][(GRAM == 1) ? 17 : 65];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, t = lane & 15;
   const int64_t c0 = (int64_t)blockIdx.x * 64 + 4 * t;
@@ -562,8 +567,10 @@ __global__ __launch_bounds__(256) void update_kernel(float* __restrict__ C, int6
       }
       *cp = cv;
     }
-    if (GRAM == 1 && gram_wg && t < 4) {
-      tile[lr][4 * t] = cv.x; tile[lr][4 * t + 1] = cv.y; tile[lr][4 * t + 2] = cv.z; tile[lr][4 * t + 3] = cv.w;
+    if (GRAM == 1 && gram_wg && t < 4) {      // rows above gram_row0 belong to R, not to the next panel (QR)
+      const bool in = r >= gram_row0;
+      tile[lr][4 * t] = in ? cv.x : 0.f; tile[lr][4 * t + 1] = in ? cv.y : 0.f;
+      tile[lr][4 * t + 2] = in ? cv.z : 0.f; tile[lr][4 * t + 3] = in ? cv.w : 0.f;
     }
     if (GRAM == 2 && gram_wg && it == 0) {
       tile[lr][4 * t] = cv.x; tile[lr][4 * t + 1] = cv.y; tile[lr][4 * t + 2] = cv.z; tile[lr][4 * t + 3] = cv.w;
@@ -1212,6 +1219,7 @@ struct BtSide {
   const float* Vall;
   const double* Tall;
   int64_t npanels, row0, vrows0;
+  int identity;            // X is [I; 0] on entry (forming Q): column c is untouched by the panels beyond c / 16
 };
 struct BtArgs {
   BtSide side[2];          // blockIdx.y: 0 = U (column-panel reflectors), 1 = V (row-panel reflectors)
@@ -1231,7 +1239,9 @@ __global__ __launch_bounds__(BT_THREADS) void backtransform_kernel(BtArgs args) 
   for (int64_t r = tid; r < rows; r += BT_THREADS)
     *reinterpret_cast<float2*>(xs + r * BT_COLS) = *reinterpret_cast<const float2*>(X + r * ldx + c0);
   __syncthreads();
-  for (int64_t p = npanels - 1; p >= 0; --p) {
+  int64_t pfirst = npanels - 1;
+  if (sd.identity && (c0 + BT_COLS - 1) / 16 < pfirst) pfirst = (c0 + BT_COLS - 1) / 16;
+  for (int64_t p = pfirst; p >= 0; --p) {        // npanels = 0 (n = 16 on the V side): nothing to do
     const int64_t rbeg = row0 + 16 * p;          // first row of X the panel touches
     const int64_t vrows = vrows0 - 16 * p;       // rows of V_p  (= rows - rbeg)
     // V_p starts at 16 * (p * vrows0 - 8 p (p - 1)) floats (see vl_offset / vr_offset)
@@ -1520,7 +1530,7 @@ static int stage1(const Layout& L, char* base, int64_t m, int64_t n) {
       const float* P = Af + j * n + j;
       float* V = (float*)(base + L.Vl) + vl_offset(m, p);
       double* Tp = (double*)(base + L.Tl) + p * 256;
-      hipLaunchKernelGGL((factor_kernel<false>), dim3(1), dim3(256), 0, stream(), P, n, (const double*)Gc, parts_c, Xb, V,
+      hipLaunchKernelGGL((factor_kernel<false>), dim3(1), dim3(256), 0, stream(), P, n, mj, (const double*)Gc, parts_c, Xb, V,
                          (float*)nullptr, (int64_t)0, Tp, (double*)(base + L.Dblk) + p * 256, status);
       if (mj > 16)
         hipLaunchKernelGGL((formv_kernel<false>), dim3((unsigned)((mj - 16 + 255) / 256)), dim3(256), 0, stream(), P, n, mj,
@@ -1535,7 +1545,7 @@ static int stage1(const Layout& L, char* base, int64_t m, int64_t n) {
         // the update also leaves the partial Grams of the row panel (first 16 rows of the updated block)
         const dim3 grid((unsigned)((nc + 63) / 64), (unsigned)((mj + U_RR - 1) / U_RR));
         hipLaunchKernelGGL((update_kernel<2>), grid, dim3(256), 0, stream(), C, n, mj, nc, (const float*)V,
-                           (const float*)Wt, nc, Gr);
+                           (const float*)Wt, nc, Gr, (int64_t)0);
         parts_r = (int)grid.x;
       }
     }
@@ -1544,7 +1554,7 @@ static int stage1(const Layout& L, char* base, int64_t m, int64_t n) {
       const float* P = Af + j * n + j + 16;
       float* V = (float*)(base + L.Vr) + vr_offset(n, p);
       double* Tp = (double*)(base + L.Tr) + p * 256;
-      hipLaunchKernelGGL((factor_kernel<true>), dim3(1), dim3(256), 0, stream(), P, n, (const double*)Gr, parts_r, Xb, V, Vt,
+      hipLaunchKernelGGL((factor_kernel<true>), dim3(1), dim3(256), 0, stream(), P, n, nc, (const double*)Gr, parts_r, Xb, V, Vt,
                          nc, Tp, (double*)(base + L.Eblk) + p * 256, status);
       if (nc > 16)
         hipLaunchKernelGGL((formv_kernel<true>), dim3((unsigned)((nc - 16 + 255) / 256)), dim3(256), 0, stream(), P, n, nc,
@@ -1566,7 +1576,7 @@ static int stage1(const Layout& L, char* base, int64_t m, int64_t n) {
           // ... and this update the partial Grams of the next column panel (first 16 columns of the updated block)
           const dim3 grid((unsigned)((nc + 63) / 64), (unsigned)((mr + U_RR - 1) / U_RR));
           hipLaunchKernelGGL((update_kernel<1>), grid, dim3(256), 0, stream(), C, n, mr, nc, (const float*)Z,
-                             (const float*)Vt, nc, Gc);
+                             (const float*)Vt, nc, Gc, (int64_t)0);
           parts_c = (int)grid.y;
         }
       }
@@ -1661,8 +1671,8 @@ static int vectors(const Layout& L, char* base, int64_t m, int64_t n, int64_t k,
     // the two sides are independent: ONE launch, blockIdx.y picks the side (k / 2 workgroups each: together they
     // fill the chip)
     BtArgs a;
-    a.side[0] = BtSide{Uu, k, m, (const float*)(base + L.Vl), (const double*)(base + L.Tl), L.np, (int64_t)0, m};
-    a.side[1] = BtSide{Vv, k, n, (const float*)(base + L.Vr), (const double*)(base + L.Tr), L.np - 1, (int64_t)16, n - 16};
+    a.side[0] = BtSide{Uu, k, m, (const float*)(base + L.Vl), (const double*)(base + L.Tl), L.np, (int64_t)0, m, 0};
+    a.side[1] = BtSide{Vv, k, n, (const float*)(base + L.Vr), (const double*)(base + L.Tr), L.np - 1, (int64_t)16, n - 16, 0};
     hipLaunchKernelGGL(backtransform_kernel, dim3((unsigned)(k / BT_COLS), 2), dim3(BT_THREADS), lds_u > lds_v ? lds_u : lds_v,
                        stream(), a);
     hipLaunchKernelGGL(transpose_out_kernel, dim3((unsigned)((n + 31) / 32), (unsigned)((k + 31) / 32)), dim3(256), 0,
@@ -1681,7 +1691,7 @@ static int vectors(const Layout& L, char* base, int64_t m, int64_t n, int64_t k,
     hipLaunchKernelGGL(wreduce_kernel, dim3((unsigned)((k + 63) / 64)), dim3(256), 0, stream(), (const float*)Wpart,
                        chunks, k, (const double*)(base + L.Tl) + p * 256, 0, Wt);
     hipLaunchKernelGGL((update_kernel<0>), dim3((unsigned)((k + 63) / 64), (unsigned)((mj + U_RR - 1) / U_RR)), dim3(256), 0,
-                       stream(), C, k, mj, k, V, (const float*)Wt, k, (double*)nullptr);
+                       stream(), C, k, mj, k, V, (const float*)Wt, k, (double*)nullptr, (int64_t)0);
   }
   TNH_LAUNCH_CHECK();
   // V = Q_R V_b: row-panel reflectors, last to first
@@ -1695,7 +1705,7 @@ static int vectors(const Layout& L, char* base, int64_t m, int64_t n, int64_t k,
     hipLaunchKernelGGL(wreduce_kernel, dim3((unsigned)((k + 63) / 64)), dim3(256), 0, stream(), (const float*)Wpart,
                        chunks, k, (const double*)(base + L.Tr) + p * 256, 0, Wt);
     hipLaunchKernelGGL((update_kernel<0>), dim3((unsigned)((k + 63) / 64), (unsigned)((nj + U_RR - 1) / U_RR)), dim3(256), 0,
-                       stream(), C, k, nj, k, V, (const float*)Wt, k, (double*)nullptr);
+                       stream(), C, k, nj, k, V, (const float*)Wt, k, (double*)nullptr, (int64_t)0);
   }
   }
   hipLaunchKernelGGL(transpose_out_kernel, dim3((unsigned)((n + 31) / 32), (unsigned)((k + 31) / 32)), dim3(256), 0,
@@ -1704,7 +1714,117 @@ static int vectors(const Layout& L, char* base, int64_t m, int64_t n, int64_t k,
   return TNH_OK;
 }
 
+// ------------------------------------------------------------------------------------------------ QR on the panels
+// Thin Householder QR of an f32 matrix with m >= n, n % 16 == 0 (K9 fast path, round 3): the column-panel half of
+// stage 1 -- Gram partials, one-workgroup factor, V rows, rank-16 update -- and Q = H_0 ... H_(np-1) [I; 0] by the
+// column-owning back-transformation.  Same reflector sign rule as LAPACK's geqrf (S_jj = -sign of the pivot
+// candidate), so R matches np.linalg.qr.  16 launches per 16 columns instead of K9's ~30 per column.
+__global__ __launch_bounds__(256) void qr_out_kernel(const float* __restrict__ Af, const double* __restrict__ Dblk,
+                                                     int64_t m, int64_t n, float* __restrict__ R,
+                                                     float* __restrict__ Q) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e < n * n) {                       // R (n x n): diagonal blocks from the factor kernel, the rest from Af
+    const int64_t i = e / n, c = e % n;
+    const int64_t p = i / 16;
+    float v = 0.f;
+    if (c >= 16 * (p + 1)) v = Af[i * n + c];
+    else if (c >= i) v = (float)Dblk[p * 256 + (i - 16 * p) * 16 + (c - 16 * p)];
+    R[e] = v;
+  }
+  if (e < m * n) Q[e] = (e / n == e % n) ? 1.f : 0.f;       // thin identity, transformed afterwards
+}
+
+static int qr_f32(int64_t m, int64_t n, const float* A, float* Q, float* R, char* base, int* status_host) {
+  const Layout L = make_layout(m, n, 4);
+  float* Af = (float*)(base + L.Af);
+  double* Gc = (double*)(base + L.Gpart);
+  double* Xb = (double*)(base + L.Xbuf);
+  float* Wpart = (float*)(base + L.Wpart);
+  float* Wt = (float*)(base + L.Wt);
+  int* status = (int*)(base + L.status);
+  TNH_HIP(hipMemcpyAsync(Af, A, (size_t)m * n * 4, hipMemcpyDeviceToDevice, stream()));
+  TNH_HIP(hipMemsetAsync(status, 0, 64, stream()));
+  const int64_t np = L.np;
+  int parts = (int)((m + 255) / 256);
+  hipLaunchKernelGGL((gram_kernel<false>), dim3(parts), dim3(256), 0, stream(), (const float*)Af, n, m, Gc);
+  for (int64_t p = 0; p < np; ++p) {
+    const int64_t j = 16 * p, mj = m - j, nc = n - j - 16;
+    const float* P = Af + j * n + j;
+    float* V = (float*)(base + L.Vl) + vl_offset(m, p);
+    double* Tp = (double*)(base + L.Tl) + p * 256;
+    hipLaunchKernelGGL((factor_kernel<false>), dim3(1), dim3(256), 0, stream(), P, n, mj, (const double*)Gc, parts, Xb, V,
+                       (float*)nullptr, (int64_t)0, Tp, (double*)(base + L.Dblk) + p * 256, status);
+    if (mj > 16)
+      hipLaunchKernelGGL((formv_kernel<false>), dim3((unsigned)((mj - 16 + 255) / 256)), dim3(256), 0, stream(), P, n, mj,
+                         (const double*)Xb, V, (float*)nullptr, (int64_t)0);
+    if (nc > 0) {
+      float* C = Af + j * n + j + 16;
+      const int chunks = (int)((mj + W_RC - 1) / W_RC);
+      hipLaunchKernelGGL(wpass_kernel, dim3((unsigned)((nc + 63) / 64), chunks), dim3(256), 0, stream(), (const float*)C,
+                         n, mj, nc, (const float*)V, Wpart);
+      hipLaunchKernelGGL(wreduce_kernel, dim3((unsigned)((nc + 63) / 64)), dim3(256), 0, stream(), (const float*)Wpart,
+                         chunks, nc, (const double*)Tp, 1, Wt);
+      // the update leaves the partial Grams of the next panel: first 16 columns of the block, rows 16 .. (the first
+      // 16 rows are R)
+      const dim3 grid((unsigned)((nc + 63) / 64), (unsigned)((mj + U_RR - 1) / U_RR));
+      hipLaunchKernelGGL((update_kernel<1>), grid, dim3(256), 0, stream(), C, n, mj, nc, (const float*)V,
+                         (const float*)Wt, nc, Gc, (int64_t)16);
+      parts = (int)grid.y;
+    }
+    TNH_LAUNCH_CHECK();
+  }
+  const int64_t ne = m * n;
+  hipLaunchKernelGGL(qr_out_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, stream(), (const float*)Af,
+                     (const double*)(base + L.Dblk), m, n, R, Q);
+  TNH_LAUNCH_CHECK();
+  // ---- Q = H_0 ... H_(np-1) [I; 0]
+  const size_t lds = (size_t)m * BT_COLS * sizeof(float);
+  if (lds <= 150 * 1024) {
+    static bool attr_done = false;
+    if (!attr_done) {
+      TNH_HIP(hipFuncSetAttribute((const void*)backtransform_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  150 * 1024));
+      attr_done = true;
+    }
+    BtArgs a;
+    a.side[0] = BtSide{Q, n, m, (const float*)(base + L.Vl), (const double*)(base + L.Tl), np, (int64_t)0, m, 1};
+    a.side[1] = a.side[0];
+    hipLaunchKernelGGL(backtransform_kernel, dim3((unsigned)(n / BT_COLS), 1), dim3(BT_THREADS), lds, stream(), a);
+  } else {
+    // very tall inputs: the columns do not fit in LDS -- per panel W = V^T Q, W <- T W, Q -= V W (last panel first)
+    for (int64_t p = np - 1; p >= 0; --p) {
+      const int64_t j = 16 * p, mj = m - j;
+      const float* V = (const float*)(base + L.Vl) + vl_offset(m, p);
+      float* C = Q + j * n + j;               // columns before j are untouched by panel p (identity start)
+      const int64_t kc = n - j;
+      const int chunks = (int)((mj + W_RC - 1) / W_RC);
+      hipLaunchKernelGGL(wpass_kernel, dim3((unsigned)((kc + 63) / 64), chunks), dim3(256), 0, stream(), (const float*)C,
+                         n, mj, kc, V, Wpart);
+      hipLaunchKernelGGL(wreduce_kernel, dim3((unsigned)((kc + 63) / 64)), dim3(256), 0, stream(), (const float*)Wpart,
+                         chunks, kc, (const double*)(base + L.Tl) + p * 256, 0, Wt);
+      hipLaunchKernelGGL((update_kernel<0>), dim3((unsigned)((kc + 63) / 64), (unsigned)((mj + U_RR - 1) / U_RR)),
+                         dim3(256), 0, stream(), C, n, mj, kc, V, (const float*)Wt, kc, (double*)nullptr, (int64_t)0);
+    }
+  }
+  TNH_LAUNCH_CHECK();
+  TNH_HIP(hipMemcpyAsync(status_host, status, sizeof(int), hipMemcpyDeviceToHost, stream()));
+  TNH_HIP(hipStreamSynchronize(stream()));
+  return TNH_OK;
+}
+
 }  // namespace svdb
+
+// entry points for tnh_qr.hip
+bool qr_panel16_supported(int dtype, int64_t m, int64_t n) {
+  const char* e = getenv("TNH_QR_PANEL16");
+  if (e && e[0] == '0') return false;
+  return dtype == TNH_F32 && m >= n && n >= 64 && (n % 16) == 0;
+}
+size_t qr_panel16_work_bytes(int64_t m, int64_t n) { return svdb::make_layout(m, n, 4).total + 256; }
+int qr_panel16(int64_t m, int64_t n, const float* A, float* Q, float* R, void* work, int* status_host) {
+  char* base = (char*)(((uintptr_t)work + 255) & ~(uintptr_t)255);
+  return svdb::qr_f32(m, n, A, Q, R, base, status_host);
+}
 }  // namespace tnh
 
 using namespace tnh;

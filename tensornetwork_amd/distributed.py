@@ -199,7 +199,7 @@ def choose_cut_edges(nodes: Sequence[network.Node], min_slices: int,
 def contract_sliced(nodes: Sequence[network.Node], cut_edges: Sequence[network.Edge],
                     comm=None, algorithm: Callable = pathfinder.greedy,
                     output_edge_order: Optional[Sequence[network.Edge]] = None,
-                    use_graph: Optional[bool] = None):
+                    use_graph: Optional[bool] = None, partials_out: Optional[list] = None):
   """Contract `nodes` by summing over all index values of `cut_edges`.
 
   Returns the backend tensor of the full contraction (identical on every rank).
@@ -208,7 +208,10 @@ def contract_sliced(nodes: Sequence[network.Node], cut_edges: Sequence[network.E
   `use_graph` (default: automatically, when the backend offers ``capture`` and this rank
   has >= 4 slices): every slice runs the same launch sequence on tensors of the same
   shape, so the path is captured ONCE into a hipGraph over fixed input blocks; per
-  slice only the sliced inputs are refreshed in place and the graph is replayed."""
+  slice only the sliced inputs are refreshed in place and the graph is replayed.
+
+  `partials_out` (a list; verification runs only): every slice's partial result is appended to it as a host
+  float64 array before it is added (one blocking read per slice; forces the eager path)."""
   comm = comm or LocalComm()
   nodes = list(nodes)
   cut_edges = list(cut_edges)
@@ -227,6 +230,8 @@ def contract_sliced(nodes: Sequence[network.Node], cut_edges: Sequence[network.E
   path = algorithm(inputs, output, sliced_sizes)
 
   mine = all_slices[comm.rank::comm.world]
+  if partials_out is not None:
+    use_graph = False
   if use_graph is None:
     use_graph = hasattr(be, "capture") and len(cut_edges) > 0 and len(mine) >= 4
   if use_graph and mine:
@@ -243,6 +248,8 @@ def contract_sliced(nodes: Sequence[network.Node], cut_edges: Sequence[network.E
       network.slice_edge(edge_map[e], i, 1)
     order = [edge_map[e] for e in output_edge_order] if output_edge_order is not None else None
     part, narrow = _widen(be, contractors.contract_path(path, [node_map[n] for n in nodes], order).tensor)
+    if partials_out is not None:
+      partials_out.append(np.asarray(part, dtype=np.float64).copy())
     total = part if total is None else be.addition(total, part)
     for n in node_map.values():     # this slice's copies are ours: drop their tensors now (Node <-> Edge
       n.tensor = None               # cycles would otherwise keep the HBM until the cyclic GC runs)

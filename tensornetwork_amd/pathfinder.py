@@ -389,6 +389,20 @@ def path_cost(inputs, output, size_dict, path) -> Tuple[int, int]:
   return flops, peak
 
 
+def path_depth(path, num_inputs: int) -> int:
+  """Depth of the contraction tree of a linear path: the largest number of pairwise contractions between an input
+  and the result.  Every intermediate of a bf16 / f16 contraction is rounded once, so a product term meets at most
+  `depth` roundings -- the a-priori error bound ((1 + 2^-9)^depth - 1) * sum |terms| used by bench.py's checks."""
+  depth = [0] * num_inputs
+  for pair in path:
+    if len(pair) == 1:
+      continue
+    i, j = sorted(pair)
+    d = max(depth[i], depth[j]) + 1
+    depth = [x for t, x in enumerate(depth) if t not in (i, j)] + [d]
+  return max(depth) if depth else 0
+
+
 # ----------------------------------------------------------------- ncon-style networks
 def _ncon_sets(tensors, labels):
   """ncon label lists -> (index sets, output set, sizes); a label that repeats on one tensor is a partial

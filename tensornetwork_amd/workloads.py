@@ -176,6 +176,54 @@ class _PlanBackend:
     return t
 
 
+def _mera_slice_plan(chi: int, placement: str):
+  """Host-only plan of ONE bond-sliced placement of the MERA layer at bond dimension chi: the 12-node topology with
+  shape-only tensors, the cheapest pair of cuts (one leg of the hamiltonian, one leg of the state) under
+  branch(nbranch=2), the path on the sliced sizes and its cost."""
+  import functools  # pylint: disable=import-outside-toplevel
+  from tensornetwork_amd import pathfinder  # pylint: disable=import-outside-toplevel
+  algo = functools.partial(pathfinder.branch, nbranch=2)
+  pb = _PlanBackend()
+  ham, rho = _ShapeOnly((chi,) * 6), _ShapeOnly((chi,) * 6)
+  plan_nodes = mera_layer_network(pb, ham, rho, _ShapeOnly((chi,) * 3), _ShapeOnly((chi,) * 4), placement)
+  inputs = [set(n.edges) for n in plan_nodes]
+  sizes = {e: e.dimension for e in network.get_all_edges(plan_nodes)}
+  hnode = [n for n in plan_nodes if n.tensor is ham][0]
+  rnode = [n for n in plan_nodes if n.tensor is rho][0]
+  best = None
+  for eh in hnode.edges:                      # cheapest pair of cuts: one leg of h, one leg of rho
+    for er in rnode.edges:
+      trial = dict(sizes)
+      trial[eh] = 1
+      trial[er] = 1
+      path = algo(inputs, set(), trial)
+      flops, peak = pathfinder.path_cost(inputs, set(), trial, path)
+      if best is None or (flops, peak) < best[0]:
+        best = ((flops, peak), eh, er, path)
+  (flops, peak), eh, er, path = best
+  return {"nodes": plan_nodes, "hnode": hnode, "rnode": rnode, "cut": {id(eh), id(er)}, "path": path,
+          "flops": float(flops), "peak": float(peak), "depth": pathfinder.path_depth(path, len(plan_nodes))}
+
+
+def _mera_slice_network(be, plan, tensor_of):
+  """Real nodes of one slice: node i of the plan gets tensor_of(i, node, sliced_shape)."""
+  plan_nodes, cut = plan["nodes"], plan["cut"]
+  index = {id(n): i for i, n in enumerate(plan_nodes)}
+  real = []
+  for i, n in enumerate(plan_nodes):
+    shape = tuple(1 if id(e) in cut else e.dimension for e in n.edges)
+    real.append(network.Node(tensor_of(i, n, shape), backend=be))
+  done = set()
+  for n in plan_nodes:
+    for e in n.edges:
+      if id(e) in done or e.is_dangling():
+        continue
+      done.add(id(e))
+      (n1, a1), (n2, a2) = e.ends()
+      network.connect(real[index[id(n1)]][a1], real[index[id(n2)]][a2])
+  return real
+
+
 def mera_sliced_sample(be, chi: int, dtype, reps: int = 2, seed: int = 17):
   """configs[4] at a bond dimension whose dense network does not fit (chi = 64: rank-6 inputs of 137 GB,
   chi^7 intermediates): the layer energy is bond-sliced -- one cut on a leg of the hamiltonian and one on a
@@ -184,61 +232,76 @@ def mera_sliced_sample(be, chi: int, dtype, reps: int = 2, seed: int = 17):
   (operands generated directly at their sliced shapes: synthetic data), contracted with the
   branch(nbranch=2) path of the sliced sizes.  Returns per-placement slice counts, multiply-adds and
   seconds per slice; the whole layer is n_slices x that (slices are independent, one scalar all-reduce)."""
-  import functools  # pylint: disable=import-outside-toplevel
   import time  # pylint: disable=import-outside-toplevel
-  from tensornetwork_amd import contractors, pathfinder  # pylint: disable=import-outside-toplevel
-  algo = functools.partial(pathfinder.branch, nbranch=2)
+  from tensornetwork_amd import contractors  # pylint: disable=import-outside-toplevel
   out = {}
   for placement in ("left", "right"):
-    pb = _PlanBackend()
-    ham, rho = _ShapeOnly((chi,) * 6), _ShapeOnly((chi,) * 6)
-    plan_nodes = mera_layer_network(pb, ham, rho, _ShapeOnly((chi,) * 3), _ShapeOnly((chi,) * 4), placement)
-    inputs = [set(n.edges) for n in plan_nodes]
-    sizes = {e: e.dimension for e in network.get_all_edges(plan_nodes)}
-    hnode = [n for n in plan_nodes if n.tensor is ham][0]
-    rnode = [n for n in plan_nodes if n.tensor is rho][0]
-    best = None
-    for eh in hnode.edges:                      # cheapest pair of cuts: one leg of h, one leg of rho
-      for er in rnode.edges:
-        trial = dict(sizes)
-        trial[eh] = 1
-        trial[er] = 1
-        path = algo(inputs, set(), trial)
-        flops, peak = pathfinder.path_cost(inputs, set(), trial, path)
-        if best is None or (flops, peak) < best[0]:
-          best = ((flops, peak), eh, er, path)
-    (flops, peak), eh, er, path = best
-    cut = {id(eh), id(er)}
-    index = {id(n): i for i, n in enumerate(plan_nodes)}
-    real = []
-    for i, n in enumerate(plan_nodes):
-      shape = tuple(1 if id(e) in cut else e.dimension for e in n.edges)
+    plan = _mera_slice_plan(chi, placement)
+
+    def tensor_of(i, node, shape):
       scale = float(np.prod(shape)) ** -0.25
-      real.append(network.Node(be.device_random(shape, dtype=dtype, seed=seed * i + 3, normal=True, a=0.0, b=scale),
-                               backend=be))
-    done = set()
-    for n in plan_nodes:
-      for e in n.edges:
-        if id(e) in done or e.is_dangling():
-          continue
-        done.add(id(e))
-        (n1, a1), (n2, a2) = e.ends()
-        network.connect(real[index[id(n1)]][a1], real[index[id(n2)]][a2])
+      return be.device_random(shape, dtype=dtype, seed=seed * i + 3, normal=True, a=0.0, b=scale)
+
+    real = _mera_slice_network(be, plan, tensor_of)
     best_t = None
     for _ in range(reps + 1):
       node_map, _ = network.copy(real)
       be.synchronize()
       t0 = time.perf_counter()
-      res = contractors.contract_path(path, [node_map[n] for n in real]).tensor
+      res = contractors.contract_path(plan["path"], [node_map[n] for n in real]).tensor
       be.synchronize()
       t = time.perf_counter() - t0
       best_t = t if best_t is None else min(best_t, t)
       del res
-    out[placement] = {"n_slices": chi * chi, "macs_per_slice": float(flops), "peak_elems_per_slice": float(peak),
-                      "sec_per_slice": best_t, "tflops": 2.0 * float(flops) / best_t / 1e12}
+    out[placement] = {"n_slices": chi * chi, "macs_per_slice": plan["flops"], "peak_elems_per_slice": plan["peak"],
+                      "sec_per_slice": best_t, "tflops": 2.0 * plan["flops"] / best_t / 1e12}
     for n in real:
       n.tensor = None
       n.edges = []
+  return out
+
+
+def mera_slice_values(be, chi: int, slices, half_dtype, seed: int = 40):
+  """Real slices of ONE chi-consistent binary-MERA layer network, each contracted three ways.
+
+  The layer's hamiltonian and state (rank 6, 137 GB each at chi = 64) are DEFINED slice-wise along their cut legs:
+  h[.., i, ..] = R(seed_h + i), rho[.., j, ..] = R(seed_r + j) with R a counter-based generator of the sliced shape
+  -- so slice (i, j) of the network is exactly what `slice_edge(cut_h, i); slice_edge(cut_rho, j)` would leave of the
+  full tensors, without ever materialising them; isometry and disentangler are the same full tensors in every
+  slice.  For each placement and each (i, j): the slice's partial energy in `half_dtype` and in f32 on the same
+  (half-rounded) values.  Returns {placement: {"depth": d, "rows": [{"slice": (i, j), "half": .., "f32": ..}]}}."""
+  from tensornetwork_amd import contractors  # pylint: disable=import-outside-toplevel
+  out = {}
+  for placement in ("left", "right"):
+    plan = _mera_slice_plan(chi, placement)
+    rows = []
+    for (i, j) in slices:
+      def tensor_of(k, node, shape, i=i, j=j):
+        scale = float(np.prod(shape)) ** -0.25
+        if node is plan["hnode"]:
+          sd = seed + 1000 + i
+        elif node is plan["rnode"]:
+          sd = seed + 5000 + j
+        else:
+          sd = seed + 7 * k        # isometries / disentanglers: slice-independent
+        return be.device_random(shape, dtype=half_dtype, seed=sd, normal=True, a=0.0, b=scale)
+
+      real = _mera_slice_network(be, plan, tensor_of)
+      vals = {}
+      for name in ("half", "f32"):
+        node_map, _ = network.copy(real)
+        nodes = [node_map[n] for n in real]
+        if name != "half":
+          for nd in nodes:
+            nd.tensor = be.cast(nd.tensor, np.float32)
+        res = contractors.contract_path(plan["path"], nodes).tensor
+        vals[name] = float(np.asarray(res, dtype=np.float64).reshape(-1)[0])
+        del res, nodes, node_map
+      rows.append({"slice": [int(i), int(j)], **vals})
+      for n in real:
+        n.tensor = None
+        n.edges = []
+    out[placement] = {"depth": plan["depth"], "rows": rows}
   return out
 
 

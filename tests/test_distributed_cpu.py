@@ -39,6 +39,17 @@ def test_sliced_equals_unsliced_single_process():
   np.testing.assert_allclose(out, ref, rtol=1e-10)
 
 
+def test_sliced_partials_are_returned_on_request():
+  """bench.py's bf16-vs-f32 checks compare slice partials, not only their sum: partials_out collects them."""
+  be = OracleBackend()
+  nodes = regular_network(be)
+  cuts = distributed.choose_cut_edges(nodes, min_slices=9)
+  parts = []
+  out = distributed.contract_sliced(nodes, cuts, partials_out=parts)
+  assert len(parts) == int(distributed.slicing_report(nodes, cuts)["n_slices"])
+  np.testing.assert_allclose(np.sum([p.reshape(-1)[0] for p in parts]), np.asarray(out).reshape(-1)[0], rtol=1e-12)
+
+
 def test_sliced_with_open_edges():
   be = OracleBackend()
   rng = np.random.default_rng(0)

@@ -198,6 +198,40 @@ def test_gemm_f32_on_bf16_matrix_cores(hip, ta_, tb_):
   assert err["f32_as_3xbf16_nt_256x256x64_pp"] <= 1.5 * err[native[0]]
 
 
+def test_gemm_f32_split_guard_matches_numpy_on_inf_and_tiny_inputs(hip):
+  """the 3 x bf16 split cannot carry inf (inf - inf -> NaN rows), values beyond the bf16 range
+  or near-subnormal values.  Its split kernels flag such operands and a predicated launch of the f32 MFMA kernel
+  recomputes the product: the result is NumPy's (+-inf where NumPy has +-inf, no stray NaN, tiny values kept)."""
+  m, n, k = 3584, 3840, 1024
+  rng = np.random.default_rng(5)
+  a = rng.standard_normal((m, k)).astype(np.float32)
+  b = rng.standard_normal((k, n)).astype(np.float32)
+  with np.errstate(all="ignore"):
+    for case in ("inf", "big", "tiny", "clean"):
+      aa, bb = a.copy(), b.copy()
+      if case == "inf":
+        aa[7, 11] = np.inf
+        bb[3, 5] = -np.inf
+      elif case == "big":
+        aa[9, 1] = 3.40e38            # finite in f32, beyond the largest bf16
+        bb[1, :] = 0.0
+        bb[1, 4] = 0.5
+      elif case == "tiny":
+        aa *= np.float32(1e-36)       # products ~1e-36: the lo parts of the split would be subnormal
+      out = np.asarray(hip.tensordot(dev(hip, aa), dev(hip, bb), [[1], [0]]))
+      assert hip.lib.tnh_gemm_last_kernel().decode() == "f32_as_3xbf16_nt_256x256x64_pp"
+      ref = aa.astype(np.float64) @ bb.astype(np.float64)
+      ref32 = ref.astype(np.float32)
+      # same non-finite pattern as NumPy's float32 product
+      np.testing.assert_array_equal(np.isnan(out), np.isnan(aa @ bb), err_msg=case)
+      np.testing.assert_array_equal(np.isposinf(out), np.isposinf(aa @ bb), err_msg=case)
+      np.testing.assert_array_equal(np.isneginf(out), np.isneginf(aa @ bb), err_msg=case)
+      fin = np.isfinite(ref32) & np.isfinite(out)
+      scale = np.abs(aa.astype(np.float64)) @ np.abs(bb.astype(np.float64))
+      scale[~np.isfinite(scale)] = np.inf
+      assert np.all(np.abs(out[fin] - ref[fin]) <= 2e-6 * scale[fin] + 1e-44), case
+
+
 def test_gemm_f32_split_only_for_large_products(hip):
   out, ref, kernel, sk = _gemm_case(hip, np.float32, 1024, 1024, 2048, 0, 1)
   assert kernel.startswith("mfma_f32_128x128")                             # 16 tiles of 256^2: native kernel

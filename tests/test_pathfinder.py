@@ -100,3 +100,12 @@ def test_disconnected_network_uses_outer_products():
   for alg in ("greedy", "optimal", "branch"):
     path = getattr(pf, alg)(inputs, set(), sizes)
     assert len(path) == 3
+
+
+def test_path_depth_of_chain_and_balanced_tree():
+  """path_depth = roundings a product term can meet: a left-to-right chain of 5 tensors has depth 4, a balanced
+  tree of 4 tensors depth 2 (bench.py's a-priori bound for bf16 contractions uses it)."""
+  from tensornetwork_amd import pathfinder
+  assert pathfinder.path_depth([(0, 1), (0, 3), (0, 2), (0, 1)], 5) == 4      # result always appended, then reused
+  assert pathfinder.path_depth([(0, 1), (0, 1), (0, 1)], 4) == 2             # (a b) (c d) then the two results
+  assert pathfinder.path_depth([], 1) == 0
