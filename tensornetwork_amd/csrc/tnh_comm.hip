@@ -16,7 +16,19 @@
 #include "tnh_internal.h"
 #include <dlfcn.h>
 #include <unistd.h>
+#if __has_include(<rccl/rccl.h>)
 #include <rccl/rccl.h>
+#else
+// A ROCm install without the RCCL development headers still builds the single-GPU library: the handful of types
+// the dlopen'ed entry points need are declared here (ABI of rccl.h 2.x), and load_rccl() reports UNSUPPORTED at run
+// time when librccl itself is missing.
+typedef struct ncclComm* ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+typedef enum { ncclSuccess = 0 } ncclResult_t;
+typedef enum { ncclInt8 = 0, ncclInt32 = 2, ncclInt64 = 4, ncclFloat16 = 6, ncclFloat32 = 7, ncclFloat64 = 8,
+               ncclBfloat16 = 9 } ncclDataType_t;
+typedef enum { ncclSum = 0, ncclProd = 1, ncclMax = 2, ncclMin = 3 } ncclRedOp_t;
+#endif
 
 namespace tnh {
 namespace {

@@ -897,7 +897,7 @@ int tnh_gemm_set_variant(const char* full) {
   // "<variant>[:r<digit>][:p<digit>]" -- the suffixes set A/B knobs of the bf16 speed path
   char name[64];
   snprintf(name, sizeof(name), "%s", full);
-  tnh::g_opt_raster = 1;
+  tnh::g_opt_raster = -1;
   tnh::g_opt_phases = 2;
   tnh::g_opt_tail = 1;
   g_f32_split = -1;   // back to the environment's choice unless ":s<d>" follows

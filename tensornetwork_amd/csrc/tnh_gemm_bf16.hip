@@ -26,7 +26,17 @@
 
 namespace tnh {
 
-int g_opt_raster = 1;  // A/B knobs, set through tnh_gemm_set_variant("name:r<d>:p<d>")
+int g_opt_raster = -1;  // A/B knobs, set through tnh_gemm_set_variant("name:r<d>:p<d>"); -1 = by shape (pick_raster)
+
+// Tile order of the 256 x 256 kernels.  Raster 1 (16 x 16 super-tiles shared by the 8 XCDs) wins wherever there are
+// many tiles (65536^3: 1477 vs 1464 TF, 36864^3: 1545 vs 1482); a grid of at most four resident waves of tiles with
+// a very long K prefers the per-XCD M-grouped order (8192 x 8192 x 262144, the D = 512 row: 1530 vs 1505 TF;
+// profiles/r03_raster_ab.txt)
+static int pick_raster(int64_t M, int64_t N, int64_t K) {
+  if (g_opt_raster >= 0) return g_opt_raster;
+  const int64_t tiles = ((M + 255) / 256) * ((N + 255) / 256);
+  return (tiles <= 1024 && K >= 65536) ? 0 : 1;      // 8192 x 8192 x 65536: 1527 vs 1487 (profiles/r03_gemm_pj_per_flop.md)
+}
 int g_opt_phases = 2;  // ping-pong kernel: MFMA clusters per K-tile (2 = 32-MFMA clusters, default; 4)
 int g_opt_tail = 1;    // view GEMM: split-K launch for the last, mostly empty wave of tiles (":t0" switches it off)
 static bool g_pp_default = true;  // ping-pong kernel won the A/B on MI355X (profiles/r01_sweep_v2.jsonl)
@@ -863,7 +873,7 @@ int gemm_bf16_view(int in_dt, int out_dt, int64_t M, int64_t N, int64_t K, const
   p.M = M; p.N = N; p.K = K;
   p.lda = va.sr0; p.ldb = vb.sr0; p.ldc = ldc;
   p.sA = p.sB = p.sC = 0;
-  p.raster = g_opt_raster;
+  p.raster = pick_raster(M, N, K);
   p.c_vec = 1;
   p.a_vw = p.b_vw = 8;
   p.tiles_m = (int)((M + 255) / 256);
@@ -1005,7 +1015,7 @@ int gemm_bf16_fast(int in_dt, int out_dt, int variant, int transA, int transB, i
   p.M = M; p.N = N; p.K = K;
   p.lda = lda; p.ldb = ldb; p.ldc = ldc;
   p.sA = sA; p.sB = sB; p.sC = sC;
-  p.raster = g_opt_raster;
+  p.raster = pick_raster(M, N, K);
   p.c_vec = 1;
   p.a_vw = p.b_vw = 8;
   const bool is_bf16 = (in_dt == TNH_BF16), out_f32 = (out_dt == TNH_F32);

@@ -211,13 +211,19 @@ bool gemm_bf16_stream_wanted(int out_dt, int64_t M, int64_t N, int64_t K, int64_
 
 template <int BN, bool SWAP>
 static int launch_stream(bool is_bf16, const StreamArgs& p, size_t lds_bytes) {
+  // the attribute is per KERNEL: the bf16 and f16 instantiations have the same function-pointer type, so a flag
+  // inside the generic lambda below would be shared between them -- both are set here, once
+  static const int attr_rc = []() -> int {
+    for (const void* k : {reinterpret_cast<const void*>(gemm_nt_stream_kernel<BN, true, SWAP>),
+                          reinterpret_cast<const void*>(gemm_nt_stream_kernel<BN, false, SWAP>)})
+      if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return 1;
+    return 0;
+  }();
+  if (attr_rc) {
+    set_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed for the streaming GEMM");
+    return TNH_ERR_HIP;
+  }
   auto go = [&](auto kernel) -> int {
-    static bool attr_done = false;
-    if (!attr_done) {
-      TNH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  160 * 1024));
-      attr_done = true;
-    }
     int per_cu = 0;
     TNH_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, lds_bytes));
     if (per_cu < 1) per_cu = 1;

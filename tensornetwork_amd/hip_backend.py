@@ -1077,13 +1077,14 @@ class HipBackend(BackendBase):
     vh = vh.view((keep,) + tuple(right_dims))
     return u, s, vh, s_rest
 
-  # smallest min(m, n) the band path takes (below it the block Jacobi is as fast or faster)
-  svd_band_min = 1024
+  # smallest min(m, n) the band path takes: measured 512^2 keep 32: band 3.9 ms (Gaussian and graded), block Jacobi
+  # 9.5 / 17.8 ms; 768^2: 5.9 vs 14.6 ms (profiles/r03_svd_small_n.txt)
+  svd_band_min = 512
   last_svd_path = None
   last_svd_band_status = 0
 
   def _svd_band(self, mat, m, n, max_singular_values, max_truncation_error, relative):
-    """K7b (tnh_svd_band_*): band reduction + spectrum slicing + inverse iteration, f32, min(m, n) >= 1024,
+    """K7b (tnh_svd_band_*): band reduction + spectrum slicing + inverse iteration, f32, min(m, n) >= 512,
     truncated calls that keep at most half of the spectrum and at most 1024 vectors.  Returns
     (u (m, k), s (k,), vh (k, n), s_rest) or None when the call is outside the path's range or the device
     reports that the result must not be used (rank-deficient panel, clustered kept values, a kept value below

@@ -109,6 +109,7 @@ def run_arm(be, tel, m, n, k, fill, seconds, variant):
          "kernel": be.lib.tnh_gemm_last_kernel().decode()}
   rec.update(smp.summary())
   clock = rec["sclk_mean_mhz"]
+  rec["pj_per_flop"] = (rec["power_mean_w"] / tf) if rec.get("power_mean_w") else None      # W / (TFLOP/s) = pJ / flop
   rec["mfma_frac_of_2p5pf"] = tf / 2500.0
   rec["mfma_frac_at_clock"] = (tf / (2500.0 * clock / 2400.0)) if clock else None
   del A, B, C
