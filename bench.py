@@ -536,8 +536,15 @@ def timed_steps(be, fn, reps, batches=3):
   """Mean seconds per call over `reps` back-to-back calls, best of `batches` batches (secondary rows only: a
   batch of ten 0.1 ms contractions is 1 ms long, one host hiccup in it reads as a 6x slower kernel -- seen
   once on the D = 64 row; the headline is timed over exactly K steps, never best-of)."""
-  fn()
-  be.synchronize()
+  # warm-up for at least 50 ms: the first milliseconds after an idle period (tnh_trim, a host-side check) run at a low
+  # shader clock -- round-3 run: the first layout of D = 32 / 64 read 3-4x slow while the second one was normal
+  t_w = time.perf_counter()
+  while True:
+    out = fn()
+    del out
+    be.synchronize()
+    if time.perf_counter() - t_w >= 0.05:
+      break
   p0 = be.permute_launches
   best = float("inf")
   for _ in range(batches):

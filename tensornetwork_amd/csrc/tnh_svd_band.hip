@@ -1155,6 +1155,62 @@ __global__ __launch_bounds__(64) void solve_kernel(const double* __restrict__ Lc
     for (int64_t i = l16; i < n; i += 16) x[i] *= scale;
 }
 
+// Kept values that the f32 input cannot tell apart (closer than ctol * sigma_max: exact multiplets of symmetric
+// states, the doubled spectrum of a complex matrix's real embedding) share one invariant subspace; inverse iteration
+// from different start vectors returns independent but not orthogonal vectors of it.  Modified Gram-Schmidt inside
+// each such run (vectors are sorted by value, so a cluster is a contiguous range) makes them an orthonormal basis of
+// that subspace -- all the SVD defines there.  One workgroup walks the k vectors in order; a vector without close
+// predecessors costs one comparison.  A vector that collapses (norm < 1e-3 after the projections: the iteration
+// returned a dependent vector) raises ST_CLUSTER and the caller takes the Jacobi path.
+__global__ __launch_bounds__(1024) void cluster_mgs_kernel(double* __restrict__ X, const double* __restrict__ shifts,
+                                                           const double* __restrict__ scal, int64_t n, int64_t k,
+                                                           double ctol, int* __restrict__ status) {
+  __shared__ double red[16];
+  __shared__ double bc;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const double tol = ctol * scal[0];
+  auto block_sum = [&](double v) -> double {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    __syncthreads();
+    if (lane == 0) red[wid] = v;
+    __syncthreads();
+    if (tid == 0) {
+      double s = 0.0;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) s += red[i];
+      bc = s;
+    }
+    __syncthreads();
+    return bc;
+  };
+  for (int64_t v = 1; v < k; ++v) {
+    int64_t first = v;
+    while (first > 0 && shifts[first - 1] - shifts[v] <= tol) --first;       // uniform: every thread agrees
+    if (first == v) continue;
+    double* xv = X + v * n;
+    for (int pass = 0; pass < 2; ++pass)            // "twice is enough"
+      for (int64_t u = first; u < v; ++u) {
+        const double* xu = X + u * n;
+        double d = 0.0;
+        for (int64_t i = tid; i < n; i += 1024) d = fma(xu[i], xv[i], d);
+        d = block_sum(d);
+        for (int64_t i = tid; i < n; i += 1024) xv[i] = fma(-d, xu[i], xv[i]);
+        __syncthreads();
+      }
+    double nn = 0.0;
+    for (int64_t i = tid; i < n; i += 1024) nn = fma(xv[i], xv[i], nn);
+    nn = block_sum(nn);
+    if (!(nn > 1e-6)) {
+      if (tid == 0) atomicOr(status, (int)ST_CLUSTER);
+      nn = 1.0;
+    }
+    const double sc = 1.0 / sqrt(nn);
+    for (int64_t i = tid; i < n; i += 1024) xv[i] *= sc;
+    __syncthreads();
+  }
+}
+
 // Checks on the band (status bits) and the start of the back-transformation:
 //   Vv[i][v] = x_v[i]  (n x k, f32),   Uu[i][v] = (B x_v)[i] / s_v  (rows < n; rows n .. m-1 zero)
 // One workgroup per vector.
@@ -1431,6 +1487,7 @@ static Layout make_layout(int64_t m, int64_t n, int64_t kcap) {
 }
 
 static bool g_dpp = true;
+static double g_cluster_tol = 4e-7;  // kept values closer than this (relative to sigma_max: a few eps_f32) are one cluster (TNH_SVDB_CTOL)
 static bool g_row_fused = false;  // row panels by the row-owning fused kernel (TNH_SVDB_ROWFUSED=1) or ypass / yreduce / update
 static bool g_bt_fused = true;   // back-transformation by column-owning workgroups (TNH_SVDB_BT=0: per-panel launches)
 static bool g_lane = true;       // counts through sturm_lane_kernel (TNH_SVDB_LANE=0: the 16-lane ldl_kernel)
@@ -1449,6 +1506,8 @@ static int g_refine_rounds = 3;
 static void read_env() {
   const char* e = getenv("TNH_SVDB_DPP");
   g_dpp = !(e && e[0] == '0');
+  e = getenv("TNH_SVDB_CTOL");
+  if (e && atof(e) >= 0.0) g_cluster_tol = atof(e);
   e = getenv("TNH_SVDB_ROWFUSED");
   g_row_fused = (e && e[0] == '1');
   e = getenv("TNH_SVDB_BT");
@@ -1651,6 +1710,9 @@ static int vectors(const Layout& L, char* base, int64_t m, int64_t n, int64_t k,
     hipLaunchKernelGGL((solve_kernel<false>), dim3(blocks), dim3(64), 0, stream(), (const double*)(base + L.Lc),
                        (const double*)(base + L.Dd), n, k, 3, (double*)(base + L.X));
   }
+  hipLaunchKernelGGL(cluster_mgs_kernel, dim3(1), dim3(1024), 0, stream(), (double*)(base + L.X),
+                     (const double*)(base + L.shifts), (const double*)(base + L.scal), n, k, g_cluster_tol,
+                     (int*)(base + L.status));
   float* Uu = U;                           // m x k, transformed in place
   float* Vv = (float*)(base + L.Vv);       // n x k
   hipLaunchKernelGGL(uv_init_kernel, dim3((unsigned)k), dim3(256), 0, stream(), (const double*)(base + L.Bd),

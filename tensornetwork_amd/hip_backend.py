@@ -1005,6 +1005,14 @@ class HipBackend(BackendBase):
           s, s_rest = self.cast(s, orig_code), self.cast(s_rest, orig_code)
         return u.view(tuple(left_dims) + (keep,)), s, vh.view((keep,) + tuple(right_dims)), s_rest
 
+    if work_code == _lib.C64 and getattr(self, "svd_band", True):
+      done = self._svd_complex_band(mat, m, n, max_singular_values, max_truncation_error, relative)
+      if done is not None:
+        u, s, vh, s_rest = done
+        keep = s.shape[0]
+        s, s_rest = self.cast(s, orig_code), self.cast(s_rest, orig_code)      # decompositions.py:58-62
+        return u.view(tuple(left_dims) + (keep,)), s, vh.view((keep,) + tuple(right_dims)), s_rest
+
     nbytes = ctypes.c_size_t(0)
     _lib.check(self.lib.tnh_svd_work_bytes(work_code, m, n, ctypes.byref(nbytes)), "tnh_svd_work_bytes")
     work = DeviceTensor.empty((max(nbytes.value, 8) // 8 + 1,), _lib.F64)
@@ -1139,6 +1147,88 @@ class HipBackend(BackendBase):
     self.last_svd_path = "band"
     self.last_svd_sweeps = 0
     return u, self.getitem(s_all, slice(0, keep)), vh, self.getitem(s_all, slice(keep, r))
+
+  def _svd_complex_band(self, mat, m, n, max_singular_values, max_truncation_error, relative):
+    """complex64 truncated SVD of a large matrix through the REAL band path.
+
+    E = phi(conj(A)) (2m x 2n, f32; phi(z) = [[re, im], [-im, re]], tnh_complex_expand) acts on interleaved
+    (re, im) column vectors like A does on complex ones, so A = U S V^H  <=>  E = phi-form(U) (S x I_2) phi-form(V)^T:
+    every singular value of A appears twice in E, and a real singular pair (x, y) of E is the complex pair
+    (x[0::2] + i x[1::2],  y[0::2] + i y[1::2]) of A.  The band path returns an orthonormal basis of each doubled
+    (or larger) value's subspace (cluster Gram-Schmidt); 2k real vectors hold k complex directions plus their
+    multiples by i, from which k independent complex ones are picked and orthonormalised with the small (2k x 2k)
+    complex Gram matrix on the host -- the same combination is applied to the right vectors, so A V = U S holds
+    without a division.  Returns None outside the band path's range (the unitary-rotation Jacobi kernel then runs)."""
+    r = min(m, n)
+    if 2 * r < self.svd_band_min or max_singular_values is None:
+      return None
+    kmax = int(max_singular_values)
+    if kmax <= 0 or 2 * kmax > r or 2 * kmax > 1024:
+      return None
+    emb = DeviceTensor.empty((2 * m, 2 * n), _lib.F32)
+    _lib.check(self.lib.tnh_complex_expand(_vp(emb), _vp(mat), m, n, n, 1, 1, _lib.C64), "tnh_complex_expand")
+    done = self._svd_band(emb, 2 * m, 2 * n, 2 * kmax, None, False)
+    if done is None:
+      return None
+    ur, sr, vrh, sr_rest = done                              # (2m, 2k), (2k,), (2k, 2n), (2r - 2k,)
+    s_all = np.concatenate([np.asarray(sr, dtype=np.float64), np.asarray(sr_rest, dtype=np.float64)])
+    s_c = 0.5 * (s_all[0::2] + s_all[1::2])                  # r complex singular values
+    keep = kmax
+    if max_truncation_error is not None:
+      trunc_errs = np.sqrt(np.cumsum(np.square(s_c[::-1])))
+      abs_err = max_truncation_error * (s_c[0] if r else 0.0) if relative else max_truncation_error
+      keep = int(min(kmax, int(np.count_nonzero(trunc_errs > abs_err)), r))
+    if keep <= 0:
+      return None
+    k2 = 2 * keep
+
+    def as_complex(x, rows, cols, ld):
+      # complex[i, j] = x[2 i, j] + i x[2 i + 1, j]: one strided gather into interleaved (re, im)
+      out = DeviceTensor.empty((rows, cols), _lib.C64)
+      _lib.check(self.lib.tnh_strided_copy(_vp(out), _vp(x), 3, _lib.i64_array((rows, cols, 2)),
+                                           _lib.i64_array((2 * ld, 1, ld)), 0, 4), "tnh_strided_copy")
+      return out
+
+    zu = as_complex(ur, m, k2, 2 * kmax)                     # candidates for U: m x 2k (first 2 keep columns)
+    vr = self.transpose(vrh, (1, 0))                         # (2n, 2k)
+    zv = as_complex(vr, n, k2, 2 * kmax)
+    # k independent complex directions among the 2k candidates, from the (2k x 2k) Gram matrix on the host.  Distinct
+    # complex singular values: the two real vectors of a pair span ONE complex line, so the even-numbered candidates
+    # are independent and a Cholesky factor orthonormalises them; otherwise (larger clusters) greedy Gram-Schmidt.
+    g = np.asarray(self._tensordot_impl(self.conj(zu), zu, [[0], [0]], None, None)[0]).astype(np.complex128)
+    coef = np.zeros((k2, keep), dtype=np.complex128)
+    basis = None
+    try:
+      ge = g[0::2, 0::2]
+      if np.linalg.eigvalsh(ge)[0] > 0.25:
+        linv = np.linalg.inv(np.linalg.cholesky(ge))            # G_ee = L L^H; columns of Z_e L^-H are orthonormal
+        coef[0::2, :] = linv.conj().T
+        basis = True
+    except np.linalg.LinAlgError:
+      basis = None
+    if basis is None:
+      basis = []                                               # coefficient vectors c with (Zu c) orthonormal
+      for j in range(k2):
+        c = np.zeros(k2, dtype=np.complex128)
+        c[j] = 1.0
+        for b in basis:
+          c = c - b * (b.conj() @ g @ c)
+        nrm2 = float(np.real(c.conj() @ g @ c))
+        if nrm2 > 0.25:
+          basis.append(c / np.sqrt(nrm2))
+          if len(basis) == keep:
+            break
+      if len(basis) < keep:
+        return None
+      coef[:, :] = np.stack(basis, axis=1)
+    cdev = self.convert_to_tensor(coef.astype(np.complex64))
+    u = self._tensordot_impl(zu, cdev, [[1], [0]], None, None)[0]               # m x keep
+    v = self._tensordot_impl(zv, cdev, [[1], [0]], None, None)[0]               # n x keep
+    vh = self.conj(self.transpose(v, (1, 0)))
+    s_dev = self.convert_to_tensor(s_c[:keep].astype(np.float32))
+    s_rest = self.convert_to_tensor(s_c[keep:].astype(np.float32))
+    self.last_svd_path = "band (complex via the real embedding)"
+    return u, s_dev, vh, s_rest
 
   def _qr_matrix(self, mat):
     """Thin Householder QR of a device matrix (f32 / f64) -> (q (m, k), r (k, n))."""

@@ -92,7 +92,16 @@ def test_band_svd_falls_back_loudly_where_it_cannot_be_accurate(hip):
   q2, _ = np.linalg.qr(rng.standard_normal((1024, 1024)))
   deg = ((q * spec) @ q2.T).astype(np.float32)
   u, s, vh, s_rest = hip.svd(hip.convert_to_tensor(deg), 1, max_singular_values=32)
+  # round 3: runs of kept values that f32 cannot tell apart are orthonormalised inside the band path (cluster
+  # Gram-Schmidt on the inverse-iteration vectors): no fall-back needed
+  assert hip.last_svd_path == "band", hip.last_svd_band_status
   check_svd(deg, u, s, vh, s_rest, 32, "degenerate")
+  # pairs (the spectrum of a complex matrix's real embedding looks like this), cut in the middle of nothing
+  spec2 = np.repeat(np.linspace(3.0, 0.05, 512), 2)
+  pairs = ((q * spec2) @ q2.T).astype(np.float32)
+  u, s, vh, s_rest = hip.svd(hip.convert_to_tensor(pairs), 1, max_singular_values=64)
+  assert hip.last_svd_path == "band", hip.last_svd_band_status
+  check_svd(pairs, u, s, vh, s_rest, 64, "pairs")
 
 
 def test_band_stage_outputs_match_the_numpy_model(hip):
@@ -179,3 +188,26 @@ def test_split_node_4096_config(hip):
   sr = np.linalg.svd(mat.astype(np.float64), compute_uv=False)
   best = np.sqrt(np.sum(sr[256:] ** 2))
   assert np.linalg.norm(full - mat) <= best + 2e-3 * sr[0]
+
+
+def test_complex64_svd_through_the_real_embedding(hip):
+  """complex64 split through the band path: the real embedding doubles every singular value, the
+  band path returns orthonormal bases of the doubled subspaces, k complex directions are extracted on the way out
+  (split_node_test.py:63-73 is the small-matrix version of this call)."""
+  rng = np.random.default_rng(12)
+  m, n, k = 1024, 768, 48
+  a = (rng.standard_normal((m, n)) + 1j * rng.standard_normal((m, n))).astype(np.complex64)
+  u, s, vh, s_rest = hip.svd(hip.convert_to_tensor(a), 1, max_singular_values=k)
+  assert "complex via the real embedding" in hip.last_svd_path, (hip.last_svd_path, hip.last_svd_band_status)
+  assert u.dtype == np.complex64 and s.dtype == np.complex64 and s_rest.shape == (n - k,)
+  a128 = a.astype(np.complex128)
+  sr = np.linalg.svd(a128, compute_uv=False)
+  s_all = np.concatenate([np.asarray(s).real, np.asarray(s_rest).real]).astype(np.float64)
+  assert np.max(np.abs(np.asarray(s).imag)) == 0.0
+  assert np.max(np.abs(s_all - sr)) <= 1e-5 * sr[0]
+  uu, vv = np.asarray(u).astype(np.complex128), np.asarray(vh).astype(np.complex128)
+  assert np.max(np.abs(uu.conj().T @ uu - np.eye(k))) <= 1e-4
+  assert np.max(np.abs(vv @ vv.conj().T - np.eye(k))) <= 1e-4
+  assert np.max(np.linalg.norm(a128 @ vv.conj().T - uu * s_all[:k], axis=0)) <= 2e-5 * sr[0]
+  rec = np.linalg.norm(a128 - (uu * s_all[:k]) @ vv)
+  assert rec <= np.sqrt(np.sum(sr[k:] ** 2)) + 1e-4 * sr[0] * np.sqrt(k)
