@@ -93,8 +93,25 @@ __global__ __launch_bounds__(256) void reduce_rows_f32v_kernel(float* __restrict
   int64_t r1 = r0 + chunk;
   if (r1 > R) r1 = R;
   const float* p = in + row * row_stride;
-  float a0 = 0.f, a1 = 0.f;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
   int64_t r = r0 + 4 * lane;
+  for (; r + 771 < r1; r += 1024) {                  // four float4 per lane per iteration (64 B in flight per lane)
+    const float4 x = *(const float4*)(p + r), y = *(const float4*)(p + r + 256);
+    const float4 z = *(const float4*)(p + r + 512), w = *(const float4*)(p + r + 768);
+    if (square) {
+      a0 += x.x * x.x + x.y * x.y + x.z * x.z + x.w * x.w;
+      a1 += y.x * y.x + y.y * y.y + y.z * y.z + y.w * y.w;
+      a2 += z.x * z.x + z.y * z.y + z.z * z.z + z.w * z.w;
+      a3 += w.x * w.x + w.y * w.y + w.z * w.z + w.w * w.w;
+    } else {
+      a0 += (x.x + x.y) + (x.z + x.w);
+      a1 += (y.x + y.y) + (y.z + y.w);
+      a2 += (z.x + z.y) + (z.z + z.w);
+      a3 += (w.x + w.y) + (w.z + w.w);
+    }
+  }
+  a0 += a2;
+  a1 += a3;
   for (; r + 259 < r1; r += 512) {                   // two float4 per lane per iteration
     const float4 x = *(const float4*)(p + r), y = *(const float4*)(p + r + 256);
     if (square) {
