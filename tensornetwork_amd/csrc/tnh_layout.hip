@@ -81,6 +81,7 @@ struct TiledParams {
   int64_t tiles_a, tiles_b;
   int64_t nblocks;
   int nbatch;
+  int order = 1;           // permute_tiled16: consecutive workgroups along b (1 = a fastest)
   int64_t bshape[TNH_MAX_RANK];
   int64_t bin[TNH_MAX_RANK];
   int64_t bout[TNH_MAX_RANK];
@@ -98,10 +99,21 @@ __global__ __launch_bounds__(256) void permute_tiled_kernel(T* __restrict__ dst,
   // grid-stride over tiles: gridDim.x * blockDim.x must stay below 2^32 on this runtime
   for (int64_t blk = blockIdx.x; blk < p.nblocks; blk += gridDim.x) {
   int64_t bid = blk;
-  const int64_t ta = bid % p.tiles_a;
-  bid /= p.tiles_a;
-  const int64_t tb = bid % p.tiles_b;
-  bid /= p.tiles_b;
+  int64_t ta, tb;          // p.order consecutive workgroups along b (see permute_tiled16_kernel)
+  if (p.order > 1) {
+    const int64_t tl = bid % p.order;
+    bid /= p.order;
+    ta = bid % p.tiles_a;
+    bid /= p.tiles_a;
+    const int64_t groups = p.tiles_b / p.order;
+    tb = (bid % groups) * p.order + tl;
+    bid /= groups;
+  } else {
+    ta = bid % p.tiles_a;
+    bid /= p.tiles_a;
+    tb = bid % p.tiles_b;
+    bid /= p.tiles_b;
+  }
   int64_t in_base = 0, out_base = 0;
 #pragma unroll 1
   for (int d = p.nbatch - 1; d >= 0; --d) {
@@ -148,17 +160,36 @@ __global__ __launch_bounds__(256) void permute_tiled_kernel(T* __restrict__ dst,
 // chunks of one row, permuted).  Round 1's padded layout (row pitch 65 dwords, four
 // ds_read_b32 per store) measured 50 % LDS bank-conflict cycles (c and c + 8 on one
 // bank).  Stores are 16 B (8 b-consecutive elements): 256-B runs per output row.
+template <int NA>
 __global__ __launch_bounds__(256) void permute_tiled16_kernel(uint16_t* __restrict__ dst,
                                                               const uint16_t* __restrict__ src,
                                                               TiledParams p) {
+  // NA = 2 (round-3 experiment, not dispatched): two neighbouring a-tiles per workgroup = 256-byte source runs and
+  // eight loads per thread in flight.  Measured: no change (4.24 vs 4.22 TB/s) -- what helps is the ORDER of the
+  // tiles (p.order below), i.e. the write side.
   constexpr int TA = 64, TB = 128, LD = 64;
-  __shared__ __attribute__((aligned(16))) uint32_t T[TA * LD];
-  for (int64_t blk = blockIdx.x; blk < p.nblocks; blk += gridDim.x) {
+  __shared__ __attribute__((aligned(16))) uint32_t T[NA][TA * LD];
+  const int64_t tiles_a = p.tiles_a / NA;          // NA == 2 only with an even tile count
+  const int64_t nblocks = p.nblocks / NA;
+  for (int64_t blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
   int64_t bid = blk;
-  const int64_t ta = bid % p.tiles_a;
-  bid /= p.tiles_a;
-  const int64_t tb = bid % p.tiles_b;
-  bid /= p.tiles_b;
+  // tile order: p.order consecutive workgroups take neighbouring b-tiles (their 256-byte output runs are adjacent in
+  // every output row: longer DRAM bursts on the write side), then a runs, then the remaining b-tiles
+  int64_t ta, tb;
+  if (p.order > 1) {
+    const int64_t tl = bid % p.order;
+    bid /= p.order;
+    ta = bid % tiles_a;
+    bid /= tiles_a;
+    const int64_t groups = p.tiles_b / p.order;
+    tb = (bid % groups) * p.order + tl;
+    bid /= groups;
+  } else {
+    ta = bid % tiles_a;
+    bid /= tiles_a;
+    tb = bid % p.tiles_b;
+    bid /= p.tiles_b;
+  }
   int64_t in_base = 0, out_base = 0;
 #pragma unroll 1
   for (int d = p.nbatch - 1; d >= 0; --d) {
@@ -169,36 +200,48 @@ __global__ __launch_bounds__(256) void permute_tiled16_kernel(uint16_t* __restri
     bid = q;
   }
   const int tid = threadIdx.x;
-  const int64_t a0 = ta * TA, b0 = tb * TB;
+  const int64_t a0 = ta * (TA * NA), b0 = tb * TB;
   {
     const int q = tid & 7;  // a chunk: a = 8 q .. 8 q + 7
+    uint4 xv[NA][2], yv[NA][2];
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int j = (tid >> 3) + 32 * h;  // b pair: rows 2 j, 2 j + 1
-      const uint16_t* s0 = src + in_base + (b0 + 2 * j) * p.b_in_stride + a0 + 8 * q;
-      const uint4 x = *(const uint4*)s0;
-      const uint4 y = *(const uint4*)(s0 + p.b_in_stride);
-      const uint32_t xs[4] = {x.x, x.y, x.z, x.w}, ys[4] = {y.x, y.y, y.z, y.w};
+    for (int t = 0; t < NA; ++t)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        // xs[e] = (a = 8q+2e, a+1) of row 2j ; ys[e] the same of row 2j+1
-        const uint32_t lo = (xs[e] & 0xffffu) | (ys[e] << 16);          // a = 8q+2e:   (b=2j, 2j+1)
-        const uint32_t hi = (xs[e] >> 16) | (ys[e] & 0xffff0000u);      // a = 8q+2e+1
-        const int col = (((j >> 2) ^ q) << 2) | (j & 3);                 // (a >> 3) & 7 == q for both rows
-        T[(8 * q + 2 * e) * LD + col] = lo;
-        T[(8 * q + 2 * e + 1) * LD + col] = hi;
+      for (int h = 0; h < 2; ++h) {
+        const int j = (tid >> 3) + 32 * h;  // b pair: rows 2 j, 2 j + 1
+        const uint16_t* s0 = src + in_base + (b0 + 2 * j) * p.b_in_stride + a0 + t * TA + 8 * q;
+        xv[t][h] = *(const uint4*)s0;
+        yv[t][h] = *(const uint4*)(s0 + p.b_in_stride);
       }
-    }
+#pragma unroll
+    for (int t = 0; t < NA; ++t)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int j = (tid >> 3) + 32 * h;
+        const uint4 x = xv[t][h], y = yv[t][h];
+        const uint32_t xs[4] = {x.x, x.y, x.z, x.w}, ys[4] = {y.x, y.y, y.z, y.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          // xs[e] = (a = 8q+2e, a+1) of row 2j ; ys[e] the same of row 2j+1
+          const uint32_t lo = (xs[e] & 0xffffu) | (ys[e] << 16);          // a = 8q+2e:   (b=2j, 2j+1)
+          const uint32_t hi = (xs[e] >> 16) | (ys[e] & 0xffff0000u);      // a = 8q+2e+1
+          const int col = (((j >> 2) ^ q) << 2) | (j & 3);                 // (a >> 3) & 7 == q for both rows
+          T[t][(8 * q + 2 * e) * LD + col] = lo;
+          T[t][(8 * q + 2 * e + 1) * LD + col] = hi;
+        }
+      }
   }
   __syncthreads();
   {
     const int c = tid & 15;  // 16-byte chunk along b: dwords 4 c .. 4 c + 3
 #pragma unroll
-    for (int h = 0; h < 4; ++h) {
-      const int a = (tid >> 4) + 16 * h;
-      const uint4 o = *(const uint4*)&T[a * LD + ((c ^ ((a >> 3) & 7)) << 2)];
-      *(uint4*)(dst + out_base + (a0 + a) * p.a_out_stride + b0 + 8 * c) = o;
-    }
+    for (int t = 0; t < NA; ++t)
+#pragma unroll
+      for (int h = 0; h < 4; ++h) {
+        const int a = (tid >> 4) + 16 * h;
+        const uint4 o = *(const uint4*)&T[t][a * LD + ((c ^ ((a >> 3) & 7)) << 2)];
+        *(uint4*)(dst + out_base + (a0 + t * TA + a) * p.a_out_stride + b0 + 8 * c) = o;
+      }
   }
   __syncthreads();
   }
@@ -586,6 +629,13 @@ static int dispatch_gather(void* dst, const void* src, const GatherParams& p, in
 template <typename T, int TILE>
 static int launch_tiled(void* dst, const void* src, TiledParams p, int64_t nblocks) {
   p.nblocks = nblocks;
+  {
+    const char* eo = getenv("TNH_PERMUTE_ORDER_T");      // default 1 until measured per element size
+    int order = eo ? atoi(eo) : 1;
+    if (order < 1) order = 1;
+    while (order > 1 && p.tiles_b % order != 0) order >>= 1;
+    p.order = order;
+  }
   const int64_t grid = nblocks < (int64_t(1) << 22) ? nblocks : (int64_t(1) << 22);
   hipLaunchKernelGGL((permute_tiled_kernel<T, TILE>), dim3((unsigned)grid), dim3(256), 0, stream(),
                      (T*)dst, (const T*)src, p);
@@ -791,8 +841,18 @@ int tnh_permute(void* dst, const void* src, int rank, const int64_t* shape, cons
       }
       if (ok && !getenv("TNH_PERMUTE_NO16")) {
         f.nblocks = nblocks;
+        {
+          // consecutive workgroups take neighbouring b-tiles in groups of up to 16 (measured on the [K][N] -> [N][K]
+          // permute of a (128,)^4 bf16 tensor: 4.08 TB/s a-fastest, 4.22 / 4.27 / 4.36 / 4.75 / 4.58 / 4.28 with groups
+          // of 2 / 4 / 8 / 16 / 32 / 64); TNH_PERMUTE_ORDER overrides
+          const char* eo = getenv("TNH_PERMUTE_ORDER");
+          int order = eo ? atoi(eo) : 16;
+          if (order < 1) order = 1;
+          while (order > 1 && f.tiles_b % order != 0) order >>= 1;
+          f.order = order;
+        }
         const int64_t grid = nblocks < (int64_t(1) << 22) ? nblocks : (int64_t(1) << 22);
-        hipLaunchKernelGGL(permute_tiled16_kernel, dim3((unsigned)grid), dim3(256), 0, stream(),
+        hipLaunchKernelGGL(permute_tiled16_kernel<1>, dim3((unsigned)grid), dim3(256), 0, stream(),
                            (uint16_t*)dst, (const uint16_t*)src, f);
         TNH_LAUNCH_CHECK();
         return TNH_OK;

@@ -930,6 +930,7 @@ __global__ __launch_bounds__(64) void ldl_kernel(const double* __restrict__ Trot
 // are wave-uniform (scalar loads).  136 f64 FMAs per pivot for 64 shifts, against 16 x 16 FMAs + 34 DPP moves for 4
 // shifts in ldl_kernel -- but a wave needs n * ~700 cycles whatever the number of shifts, so this kernel is for
 // rounds with tens of thousands of shifts (the grid and the multi-section rounds), ldl_kernel for the factor.
+template <bool FLAGS>      // FLAGS = false: the uniform grid round (bracket_init only reads the counts)
 __global__ __launch_bounds__(64) void sturm_lane_kernel(const double* __restrict__ Trot, int64_t n,
                                                         const double* __restrict__ shifts, int64_t ns,
                                                         const double* __restrict__ scal, int* __restrict__ counts,
@@ -978,7 +979,7 @@ __global__ __launch_bounds__(64) void sturm_lane_kernel(const double* __restrict
         constexpr int r = decltype(rc)::value + 1;
         constexpr int a = (jj + r) & 15;
         const double lr = W[a][jj] * rinv;
-        lmax = fmax(lmax, fabs(lr));
+        if (FLAGS) lmax = fmax(lmax, fabs(lr));
         static_for<r>([&](auto qc) {
           constexpr int q = decltype(qc)::value + 1;
           constexpr int b = (jj + q) & 15;
@@ -987,7 +988,7 @@ __global__ __launch_bounds__(64) void sturm_lane_kernel(const double* __restrict
       });
       {
         const double l16 = nrow[16] * rinv;
-        lmax = fmax(lmax, fabs(l16));
+        if (FLAGS) lmax = fmax(lmax, fabs(l16));
         static_for<15>([&](auto qc) {
           constexpr int q = decltype(qc)::value + 1;
           constexpr int b = (jj + q) & 15;
@@ -995,14 +996,14 @@ __global__ __launch_bounds__(64) void sturm_lane_kernel(const double* __restrict
         });
         W[jj][jj] = fma(-l16, nrow[16], nrow[jj] - dsub);
       }
-      lmax2d = fmax(lmax2d, lmax * lmax * fabs(d));
+      if (FLAGS) lmax2d = fmax(lmax2d, lmax * lmax * fabs(d));
 #pragma unroll
       for (int c = 0; c < 17; ++c) nrow[c] = nxt[c];
     });
   }
   if (valid) {
     counts[sidx] = cnt;
-    flags[sidx] = (lmax2d > flagbound) ? 1 : 0;
+    flags[sidx] = (FLAGS && lmax2d > flagbound) ? 1 : 0;
   }
 }
 
@@ -1531,11 +1532,16 @@ static void read_env() {
   if (e && atoi(e) >= 0) g_refine_rounds = atoi(e);
 }
 
-static int launch_counts(const Layout& L, char* base, int64_t n, int64_t ns, bool lane) {
+static int launch_counts(const Layout& L, char* base, int64_t n, int64_t ns, bool lane, bool need_flags = true) {
   if (lane) {
-    hipLaunchKernelGGL(sturm_lane_kernel, dim3((unsigned)((ns + 63) / 64)), dim3(64), 0, stream(),
-                       (const double*)(base + L.Trot), n, (const double*)(base + L.shifts), ns,
-                       (const double*)(base + L.scal), (int*)(base + L.counts), (int*)(base + L.flags));
+    if (need_flags)
+      hipLaunchKernelGGL(sturm_lane_kernel<true>, dim3((unsigned)((ns + 63) / 64)), dim3(64), 0, stream(),
+                         (const double*)(base + L.Trot), n, (const double*)(base + L.shifts), ns,
+                         (const double*)(base + L.scal), (int*)(base + L.counts), (int*)(base + L.flags));
+    else
+      hipLaunchKernelGGL(sturm_lane_kernel<false>, dim3((unsigned)((ns + 63) / 64)), dim3(64), 0, stream(),
+                         (const double*)(base + L.Trot), n, (const double*)(base + L.shifts), ns,
+                         (const double*)(base + L.scal), (int*)(base + L.counts), (int*)(base + L.flags));
     TNH_LAUNCH_CHECK();
     return TNH_OK;
   }
@@ -1661,7 +1667,7 @@ static int values(const Layout& L, char* base, int64_t n, int64_t khint, float* 
   hipLaunchKernelGGL(grid_kernel, dim3((unsigned)((ng + 255) / 256)), dim3(256), 0, stream(),
                      (const double*)(base + L.scal), ng, (double*)(base + L.shifts));
   TNH_LAUNCH_CHECK();
-  int rc = launch_counts(L, base, n, ng, g_lane);
+  int rc = launch_counts(L, base, n, ng, g_lane, false);
   if (rc) return rc;
   hipLaunchKernelGGL(bracket_init_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream(),
                      (const double*)(base + L.scal), (const int*)(base + L.counts), ng, n, (double*)(base + L.lo),
