@@ -74,6 +74,42 @@ __global__ __launch_bounds__(256) void gather_kernel(T* __restrict__ dst,
   }
 }
 
+// Row-preserving permute whose rows are shorter than a 128-B line: the lines of the source are
+// shared by g = 128 / row_bytes rows that sit far apart in the output, so a linear walk of the
+// output touches every source line from g different workgroups (different XCDs, i.e. different
+// L2s) and the kernel reads g x the bytes (4.2 TB/s algorithmic = 6.4 TB/s of traffic on the
+// (16,)^6 f32 case of configs[2]).  Here the walk is over (outer..., line-mate, row): the g rows
+// of one source line are taken by neighbouring lanes of one wave, and because the dim just
+// outside the line-mate is the output's next-fastest, the same wave also fills whole output
+// lines.  Both sides are strided, so each element carries two offsets.
+struct Gather2Params {
+  int rank;
+  uint32_t total;
+  uint32_t shape[TNH_MAX_RANK + 1];
+  uint32_t sstride[TNH_MAX_RANK + 1];
+  uint32_t dstride[TNH_MAX_RANK + 1];
+  uint32_t magic[TNH_MAX_RANK + 1];
+  uint32_t shift[TNH_MAX_RANK + 1];
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void gather2_kernel(T* __restrict__ dst, const T* __restrict__ src,
+                                                      Gather2Params p) {
+  const uint32_t step = gridDim.x * blockDim.x;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < p.total; i += step) {
+    uint32_t rem = i, so = 0, dof = 0;
+#pragma unroll 1
+    for (int d = p.rank - 1; d >= 0; --d) {
+      const uint32_t q = fastdiv(rem, p.magic[d], p.shift[d]);
+      const uint32_t c = rem - q * p.shape[d];
+      so += c * p.sstride[d];
+      dof += c * p.dstride[d];
+      rem = q;
+    }
+    dst[dof] = src[so];
+  }
+}
+
 struct TiledParams {
   int64_t Na, Nb;          // a: fastest dim of src, b: fastest dim of dst
   int64_t a_out_stride;    // stride of a in dst
@@ -787,6 +823,56 @@ int tnh_permute(void* dst, const void* src, int rank, const int64_t* shape, cons
       p.shape[d] = (d == r - 1) ? row : oshape[d];
       p.stride[d] = istride[d];
       p.total *= p.shape[d];
+    }
+    // rows shorter than a line: walk line-mates together (see gather2_kernel)
+    static const int linemate = [] { const char* e = getenv("TNH_PERMUTE_LINEMATE"); return e ? atoi(e) : 1; }();
+    const int64_t row_bytes = row * wide;
+    if (linemate && wide == 16 && row >= 2 && row_bytes < 128 && 128 % row_bytes == 0 && r >= 3 && r <= TNH_MAX_RANK &&
+        p.total < (int64_t(1) << 31)) {
+      int ds = -1;  // the source dim whose stride is one row: its neighbours share lines
+      for (int d = 0; d < r - 1; ++d)
+        if (istride[d] == row) ds = d;
+      int64_t g = 128 / row_bytes;
+      while (ds >= 0 && g > 1 && oshape[ds] % g != 0) g /= 2;
+      if (ds >= 0 && g > 1 && oshape[ds] / g >= 1) {
+        Gather2Params q;
+        int64_t ost[TNH_MAX_RANK];
+        {
+          int64_t acc = 1;
+          for (int d = r - 1; d >= 0; --d) {
+            ost[d] = acc;
+            acc *= p.shape[d];
+          }
+        }
+        int n = 0;
+        bool ok = true;
+        auto push = [&](int64_t sz, int64_t ss, int64_t dd) {
+          if (sz == 1) return;
+          if (ss * (sz - 1) >= (int64_t(1) << 31) || dd * (sz - 1) >= (int64_t(1) << 31)) ok = false;
+          q.shape[n] = (uint32_t)sz;
+          q.sstride[n] = (uint32_t)ss;
+          q.dstride[n] = (uint32_t)dd;
+          fastdiv_gen((uint32_t)sz, &q.magic[n], &q.shift[n]);
+          ++n;
+        };
+        for (int d = 0; d < r - 1; ++d) {
+          if (d == ds) push(oshape[d] / g, istride[d] * g, ost[d] * g);
+          else push(oshape[d], istride[d], ost[d]);
+        }
+        push(g, istride[ds], ost[ds]);
+        push(row, 1, 1);
+        if (ok) {
+          q.rank = n;
+          q.total = (uint32_t)p.total;
+          int64_t blocks = (p.total + 255) / 256;
+          const int64_t cap = (int64_t)num_cus() * 16;
+          if (blocks > cap) blocks = cap;
+          hipLaunchKernelGGL((gather2_kernel<uint4>), dim3((unsigned)blocks), dim3(256), 0, stream(), (uint4*)dst,
+                             (const uint4*)src, q);
+          TNH_LAUNCH_CHECK();
+          return TNH_OK;
+        }
+      }
     }
     return dispatch_gather<false>(dst, src, p, wide);
   }

@@ -51,6 +51,10 @@ def test_permute_all_perms_rank4(hip, dtype):
     ((12, 12, 12, 12, 1, 12, 12, 12), (0, 3, 4, 5, 1, 6, 7, 2)), ((12,) * 6, (2, 1, 3, 4, 5, 0)),
     ((12,) * 6, (0, 1, 3, 5, 4, 2)), ((8,) * 7, (0, 4, 5, 1, 2, 6, 3)), ((6, 10, 12, 8, 12), (0, 3, 4, 1, 2)),
     ((5, 9, 12, 7, 12), (0, 3, 4, 1, 2)), ((16, 24, 8, 40), (2, 0, 3, 1)), ((10, 12, 14, 16), (3, 1, 0, 2)),
+    # rows shorter than a 128-B line with the innermost dim preserved: the line-mate walk (gather2_kernel) with
+    # g = 2, 4, 8 rows per line, a mate dim that g does not divide (g halves), and an odd one (plain gather)
+    ((6, 16, 10, 16), (1, 0, 2, 3)), ((6, 12, 7, 8), (2, 0, 1, 3)), ((5, 8, 9, 4), (2, 1, 0, 3)),
+    ((3, 6, 5, 8), (1, 0, 2, 3)), ((3, 7, 5, 8), (2, 0, 1, 3)), ((4, 4, 4, 4, 4, 16), (3, 1, 4, 0, 2, 5)),
 ])
 @pytest.mark.parametrize("dtype", [np.float32, np.uint16, np.complex128])
 def test_permute_tiled_and_gather_paths(hip, shape, perm, dtype):
