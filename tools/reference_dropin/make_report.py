@@ -10,7 +10,7 @@ CAUSES = [
     (r"File\(\) takes no arguments|h5py", "HDF5 save/load: `h5py` is not in the image (inert stub); identical failure on backend=\"numpy\" here"),
     (r"np\.int64\(|Regex pattern did not match", "error text embeds `repr(np.int64)`: NumPy 2 prints `np.int64(3)`; identical failure on backend=\"numpy\" here"),
     (r"Invalid backend|Unexpected backend|KeyError: 'hip'", "the reference's TEST HELPERS (`testing_utils.py`, module-level dtype tables) hard-code the four backend names; not reachable without editing the reference"),
-    (r"stub has no attribute|jax is not installed|tensorflow is not installed", "needs jax / tensorflow (not installed)"),
+    (r"stub has no attribute|jax is not installed|tensorflow is not installed|module 'jax\.numpy' has no attribute", "needs jax / tensorflow (not installed)"),
     (r"dtype\('int64'\) == dtype\('bool'\)|uint|1\.84467441e\+19|dtype\('int64'\) == dtype", "bool / unsigned / 8-16-bit integer tensors are stored widened to int64 in HBM (documented in DESIGN.md section 9; outside the hot path)"),
 ]
 

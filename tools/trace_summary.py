@@ -45,7 +45,7 @@ def main():
   for k, v in sorted(gaps.items(), key=lambda kv: -sum(kv[1])):
     print(f"  {k:30s} n={len(v):5d} mean={sum(v) / len(v) / 1e3:7.2f} total={sum(v) / 1e6:7.2f} ms")
   # per-panel samples: walk stage 1 by gram_kernel<false> occurrences
-  idx = [i for i, r in enumerate(seg) if short(r["Kernel_Name"]).startswith("gram_kernel<false>")]
+  idx = [i for i, r in enumerate(seg) if short(r["Kernel_Name"]).startswith("factor_kernel<false>")]
   for p in (0, 1, 16, 64, 128, 192, 240):
     if p >= len(idx):
       continue
