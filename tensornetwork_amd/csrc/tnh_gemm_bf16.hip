@@ -39,6 +39,16 @@ static int pick_raster(int64_t M, int64_t N, int64_t K) {
 }
 int g_opt_phases = 2;  // ping-pong kernel: MFMA clusters per K-tile (2 = 32-MFMA clusters, default; 4)
 int g_opt_tail = 1;    // view GEMM: split-K launch for the last, mostly empty wave of tiles (":t0" switches it off)
+int g_opt_persist = -1;  // ping-pong kernels: one workgroup per CU looping over tiles (":g0" / ":g1"; -1: when tiles > CUs)
+
+// grid.x of a ping-pong launch over `tiles` output tiles
+static unsigned pp_grid_x(int64_t tiles, unsigned grid_y) {
+  const int cus = num_cus() > 0 ? num_cus() : 256;
+  static const int env = []() { const char* e = getenv("TNH_GEMM_PERSIST"); return e ? atoi(e) : -1; }();
+  const int mode = g_opt_persist >= 0 ? g_opt_persist : env;
+  const bool on = (mode != 0) && grid_y == 1 && tiles > cus;
+  return on ? (unsigned)cus : (unsigned)tiles;
+}
 static bool g_pp_default = true;  // ping-pong kernel won the A/B on MI355X (profiles/r01_sweep_v2.jsonl)
 
 #define TNH_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
@@ -255,9 +265,13 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(NtArgs p) {
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wid >> 2, wc = wid & 3;
 
-  int tm, tn;
-  tile_of_block(blockIdx.x, p.tiles_m, p.tiles_n, p.raster, tm, tn);
-  const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
+  // Persistent over tiles: workgroup b computes tiles b, b + gridDim.x, ... (gridDim.x = tiles: one each, as before;
+  // gridDim.x = CUs: the loads of the next tile's first K-tiles are issued BEFORE the epilogue of the current one,
+  // and the workgroup hand-over on the CU -- which can hold only one of these 128-KiB-LDS workgroups -- is gone).
+  // The hardware deals consecutive workgroup ids round-robin to the XCDs, so tile t still runs on XCD t & 7 and
+  // the rasters of tile_of_block keep their meaning.
+  const int ntiles = p.tiles_m * p.tiles_n;
+  int64_t m0 = 0, n0 = 0;
   const uint16_t* A = p.A + (int64_t)blockIdx.y * p.sA;
   const uint16_t* B = p.B + (int64_t)blockIdx.y * p.sB;
 
@@ -292,13 +306,19 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(NtArgs p) {
     }
     return base + row * ld + lchunk * 8;
   };
+  auto setup_tile = [&](int t) {
+    int tm, tn;
+    tile_of_block(t, p.tiles_m, p.tiles_n, p.raster, tm, tn);
+    m0 = (int64_t)tm * BM;
+    n0 = (int64_t)tn * BN;
 #pragma unroll
-  for (int h = 0; h < 2; ++h)
+    for (int h = 0; h < 2; ++h)
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      ga[h][i] = src_ptr(A, p.va, A_KM, m0, p.M, p.lda, h, i);
-      gb[h][i] = src_ptr(B, p.vb, B_KN, n0, p.N, p.ldb, h, i);
-    }
+      for (int i = 0; i < 2; ++i) {
+        ga[h][i] = src_ptr(A, p.va, A_KM, m0, p.M, p.lda, h, i);
+        gb[h][i] = src_ptr(B, p.vb, B_KN, n0, p.N, p.ldb, h, i);
+      }
+  };
   const unsigned lds0 = (unsigned)(size_t)TNH_LDS_PTR(smem);
   // which: 0 = A-half0, 1 = A-half1, 2 = B-half0, 3 = B-half1
   auto issue = [&](int buf, int which, int64_t k0) {
@@ -322,6 +342,7 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(NtArgs p) {
 
   f32x4 acc[M32 ? 1 : 8][M32 ? 1 : 4];
   f32x16 acc32[M32 ? 4 : 1][M32 ? 2 : 1];
+  auto zero_acc = [&]() {
   if constexpr (M32) {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -335,6 +356,7 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(NtArgs p) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
+  };
 
   uint4 af[KS][FA];     // [k-step][row fragment] of the current A sub-tile
   uint4 bf[2][KS][FB];  // [sub][k-step][row fragment] of both B sub-tiles
@@ -415,34 +437,43 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(NtArgs p) {
   } while (0)
 
   int nt = (int)(p.K / BK);
+  int kfirst = 0;
+  if constexpr (VIEW) {
+    if (p.kslice_tiles > 0) {            // split-K launch: this workgroup's slice of the contraction
+      kfirst = (int)blockIdx.y * p.kslice_tiles;
+      nt = (nt - kfirst < p.kslice_tiles) ? (nt - kfirst) : p.kslice_tiles;
+    }
+  }
   // element offset of the K-tile each operand stages next: A runs one tile ahead, B two
   KWalk wa, wb;
-  int64_t ka0 = 0, kb0 = 0;
-  if constexpr (VIEW) {
-    int first = 0;
-    if (p.kslice_tiles > 0) {            // split-K launch: this workgroup's slice of the contraction
-      first = (int)blockIdx.y * p.kslice_tiles;
-      nt = (nt - first < p.kslice_tiles) ? (nt - first) : p.kslice_tiles;
+  // prologue of an output tile (its LDS-DMA source pointers set by setup_tile): K-tile 0 complete, B halves of K-tile 1
+  auto start_tile = [&]() {
+    int64_t ka0 = 0, kb0 = 0;
+    if constexpr (VIEW) {
+      wa.init(p.va, kfirst);
+      wb.init(p.vb, kfirst);
+      ka0 = wa.off;
+      kb0 = wb.off;
+      wa.advance();
+      wb.advance();
     }
-    wa.init(p.va, first);
-    wb.init(p.vb, first);
-    ka0 = wa.off;
-    kb0 = wb.off;
-    wa.advance();
-    wb.advance();
-  }
-  // prologue: tile 0 complete, B halves of tile 1
-  issue(0, 0, ka0);
-  issue(0, 1, ka0);
-  issue(0, 2, kb0);
-  issue(0, 3, kb0);
-  if (nt > 1) {
-    const int64_t kb1 = VIEW ? wb.off : (int64_t)BK;
-    issue(1, 2, kb1);
-    issue(1, 3, kb1);
-  }
-  if constexpr (VIEW) wb.advance();
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    issue(0, 0, ka0);
+    issue(0, 1, ka0);
+    issue(0, 2, kb0);
+    issue(0, 3, kb0);
+    if (nt > 1) {
+      const int64_t kb1 = VIEW ? wb.off : (int64_t)BK;
+      issue(1, 2, kb1);
+      issue(1, 3, kb1);
+    }
+    if constexpr (VIEW) wb.advance();
+  };
+  setup_tile((int)blockIdx.x);
+  start_tile();
+
+  for (int tile = (int)blockIdx.x;;) {
+  zero_acc();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this tile's prologue loads (and the previous tile's stores)
   __syncthreads();
   if (wr == 1) __builtin_amdgcn_s_barrier();  // group 1 runs one interval behind group 0
   __builtin_amdgcn_sched_barrier(0);
@@ -513,9 +544,18 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(NtArgs p) {
     TNH_SEG_MMA_END();
   }
   if (wr == 0) __builtin_amdgcn_s_barrier();  // pairs with group 1's last barrier
-#undef TNH_SEG_LOAD_END
-#undef TNH_SEG_MMA_END
+  __builtin_amdgcn_sched_barrier(0);
 
+  // every wave is past its last LDS read of this tile: start the next tile's loads, then store this one
+  const int64_t em0 = m0, en0 = n0;
+  const int next = tile + (int)gridDim.x;
+  const bool more = next < ntiles;
+  if (more) {
+    setup_tile(next);
+    start_tile();
+  }
+  {
+  const int64_t m0 = em0, n0 = en0;
   char* Cb = (char*)p.C + (int64_t)blockIdx.y * p.sC * (OUT_F32 ? 4 : 2);
   if constexpr (!M32) {
     store_wave_tile<IS_BF16, OUT_F32, 8, 4>(acc, p, Cb, m0, n0, BM, BN, wr * 128, wc * 64, lane);
@@ -555,6 +595,12 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(NtArgs p) {
         }
     }
   }
+  }
+  if (!more) break;
+  tile = next;
+  }
+#undef TNH_SEG_LOAD_END
+#undef TNH_SEG_MMA_END
 }
 
 
@@ -805,7 +851,7 @@ static int launch_pp(bool is_bf16, bool out_f32, bool two, NtArgs p, int64_t bat
     q.A = p.A + b0 * p.sA;
     q.B = p.B + b0 * p.sB;
     q.C = (char*)p.C + b0 * p.sC * esz_out;
-    const dim3 grid((unsigned)nwg, (unsigned)nb), block(512);
+    const dim3 grid(pp_grid_x(nwg, (unsigned)nb), (unsigned)nb), block(512);
 #define TNH_PP_LAUNCH(B16, O32)                                                                               \
   do {                                                                                                       \
     if (m32) hipLaunchKernelGGL((gemm_nt_pp_kernel<B16, O32, true, true>), grid, block, 0, stream(), q);      \
@@ -884,7 +930,7 @@ int gemm_bf16_view(int in_dt, int out_dt, int64_t M, int64_t N, int64_t K, const
   const bool is_bf16 = (in_dt == TNH_BF16), out_f32 = (out_dt == TNH_F32);
   p.kslice_tiles = 0;
   auto launch = [&](const NtArgs& q, unsigned gy, bool f32_out) {
-    const dim3 grid((unsigned)((int64_t)q.tiles_m * q.tiles_n), gy);
+    const dim3 grid(pp_grid_x((int64_t)q.tiles_m * q.tiles_n, gy), gy);
     if (a_km && b_kn) launch_pp_view_t<true, true>(is_bf16, f32_out, grid, q);
     else if (a_km) launch_pp_view_t<true, false>(is_bf16, f32_out, grid, q);
     else if (b_kn) launch_pp_view_t<false, true>(is_bf16, f32_out, grid, q);

@@ -98,6 +98,29 @@ __device__ __forceinline__ void store_wave_tile(const f32x4 (&acc)[FM][FN], cons
                                                 int64_t m0, int64_t n0, int BM, int BN, int wave_m,
                                                 int wave_n, int lane) {
   const bool full = (m0 + BM <= p.M) && (n0 + BN <= p.N);
+  if constexpr (!OUT_F32 && FN % 2 == 0) {
+    // Half output, full tile, 16-B aligned rows: 16-B stores.  A lane holds 4 consecutive n (8 B) of one m per
+    // fragment and the lane 16 further on the next 4; v_permlane16_swap on the fragment pair (j, j + 1) hands
+    // lane rows 0 / 2 the columns 0-7 / 8-15 of fragment j and rows 1 / 3 those of fragment j + 1.  Per store
+    // instruction 16 rows x 64 B instead of 16 rows x 32 B, and half as many instructions: the epilogue of a
+    // 256 x 256 tile was 7-9 us of the CU's time with the 8-B stores (32768^2 x 1024: 1.05 -> see DESIGN K2).
+    if (p.c_vec && full && (p.ldc & 7) == 0 && (((uintptr_t)Cb) & 15) == 0) {
+      const int r = lane >> 4;
+#pragma unroll
+      for (int i = 0; i < FM; ++i) {
+        const int64_t m = m0 + wave_m + i * 16 + (lane & 15);
+#pragma unroll
+        for (int j = 0; j < FN; j += 2) {
+          const f32x4 va = acc[i][j], vb = acc[i][j + 1];
+          const auto sx = __builtin_amdgcn_permlane16_swap(pack2<IS_BF16>(va[0], va[1]), pack2<IS_BF16>(vb[0], vb[1]), false, false);
+          const auto sy = __builtin_amdgcn_permlane16_swap(pack2<IS_BF16>(va[2], va[3]), pack2<IS_BF16>(vb[2], vb[3]), false, false);
+          const int64_t n = n0 + wave_n + (j + (r & 1)) * 16 + (r >> 1) * 8;
+          *(uint4*)(Cb + (m * p.ldc + n) * 2) = make_uint4(sx[0], sy[0], sx[1], sy[1]);
+        }
+      }
+      return;
+    }
+  }
 #pragma unroll
   for (int i = 0; i < FM; ++i) {
     const int64_t m = m0 + wave_m + i * 16 + (lane & 15);

@@ -1018,3 +1018,30 @@ def test_gemm_f64_v2_vector_path(hip, ta_, tb_, m, n, k):
   assert kernel == "mfma_f64_128x128x16_v2", kernel
   tol = GEMM_TOL[np.float64]
   np.testing.assert_allclose(out, ref, rtol=tol * sk * 4, atol=tol * sk * np.sqrt(k) * 4)
+
+
+@pytest.mark.parametrize("m,n,k,kn", [(4352, 4352, 192, False), (8192, 8192, 128, False), (4400, 5000, 320, False),
+                                      (4352, 4608, 256, True), (8192, 4096, 64 * 5, True)])
+def test_gemm_persistent_tiles_match_one_workgroup_per_tile(hip, m, n, k, kn):
+  """More output tiles than CUs: one workgroup per CU loops over its tiles, the loads of the next tile issued in
+  front of the epilogue of the current one (gemm_nt_pp_kernel).  Same MFMA sequence per tile, so the results are
+  bit-identical to the one-workgroup-per-tile launch (knob ":g0"), for the NT form (ragged edges included) and
+  for the in-place view kernels; and right against float64 on sampled rows."""
+  rng = np.random.default_rng(m + n + k)
+  a = hip.device_random((m, k), dtype=ta.bfloat16, seed=15, normal=True, b=k ** -0.5)
+  b = hip.device_random((k, n) if kn else (n, k), dtype=ta.bfloat16, seed=16, normal=True, b=1.0)
+  axes = 1 if kn else [[1], [1]]
+  got = hip.tensordot(a, b, axes)
+  name = hip.lib.tnh_gemm_last_kernel().decode()
+  assert "256x256x64_pp" in name, name
+  _lib.check(hip.lib.tnh_gemm_set_variant(b"auto:g0"))
+  try:
+    ref_dev = hip.tensordot(a, b, axes)
+  finally:
+    _lib.check(hip.lib.tnh_gemm_set_variant(b"auto"))
+  g, u = np.asarray(got), np.asarray(ref_dev)
+  np.testing.assert_array_equal(g, u)
+  rows = np.concatenate([rng.integers(0, m, 12), np.array([0, m - 1])])
+  an, bn = np.asarray(a).astype(np.float64), np.asarray(b).astype(np.float64)
+  ref = an[rows] @ (bn if kn else bn.T)
+  np.testing.assert_allclose(g[rows], ref, rtol=2.0**-7, atol=2.0**-8)
