@@ -920,7 +920,7 @@ int gemm_bf16_view(int in_dt, int out_dt, int64_t M, int64_t N, int64_t K, const
   p.lda = va.sr0; p.ldb = vb.sr0; p.ldc = ldc;
   p.sA = p.sB = p.sC = 0;
   p.raster = pick_raster(M, N, K);
-  p.c_vec = 1;
+  p.c_vec = ((int64_t)M * N * 2 >= (int64_t(64) << 20)) ? 3 : 1;
   p.a_vw = p.b_vw = 8;
   p.tiles_m = (int)((M + 255) / 256);
   p.tiles_n = (int)((N + 255) / 256);
@@ -1062,7 +1062,7 @@ int gemm_bf16_fast(int in_dt, int out_dt, int variant, int transA, int transB, i
   p.lda = lda; p.ldb = ldb; p.ldc = ldc;
   p.sA = sA; p.sB = sB; p.sC = sC;
   p.raster = pick_raster(M, N, K);
-  p.c_vec = 1;
+  p.c_vec = ((int64_t)M * N * 2 >= (int64_t(64) << 20)) ? 3 : 1;
   p.a_vw = p.b_vw = 8;
   const bool is_bf16 = (in_dt == TNH_BF16), out_f32 = (out_dt == TNH_F32);
   // 256x256 tiles once there are enough of them to fill the 256 CUs.

@@ -32,6 +32,8 @@ struct NtArgs {
   int64_t sA, sB, sC;
   int tiles_m, tiles_n;
   int c_vec;   // 1: C rows are 8-B (half out) / 16-B (f32 out) aligned at every n % 4 == 0 -> vector stores;
+               // 3 (ping-pong kernels, half out): the same with non-temporal 16-B stores (C of 64 MiB and more: it is
+               //   not read again before it has left the L2; +1 % at 32768^2 x 1024..4096);
                // 2 (ragged kernel, half out): also 16-B aligned at every n % 8 == 0 -> LDS-staged row stores
   int a_vw, b_vw;  // ragged kernel only: widest aligned load (elements: 8, 4, 2, 1) on rows of A / B
   int raster;  // 1 (default): 16x16 super-tiles shared by the 8 XCDs (3x less HBM traffic, +2%); 0: per-XCD ranges, M-grouped
@@ -115,7 +117,10 @@ __device__ __forceinline__ void store_wave_tile(const f32x4 (&acc)[FM][FN], cons
           const auto sx = __builtin_amdgcn_permlane16_swap(pack2<IS_BF16>(va[0], va[1]), pack2<IS_BF16>(vb[0], vb[1]), false, false);
           const auto sy = __builtin_amdgcn_permlane16_swap(pack2<IS_BF16>(va[2], va[3]), pack2<IS_BF16>(vb[2], vb[3]), false, false);
           const int64_t n = n0 + wave_n + (j + (r & 1)) * 16 + (r >> 1) * 8;
-          *(uint4*)(Cb + (m * p.ldc + n) * 2) = make_uint4(sx[0], sy[0], sx[1], sy[1]);
+          typedef unsigned v4u __attribute__((ext_vector_type(4)));
+          const v4u o = {sx[0], sy[0], sx[1], sy[1]};
+          if (p.c_vec == 3) __builtin_nontemporal_store(o, (v4u*)(Cb + (m * p.ldc + n) * 2));   // large C: streaming
+          else *(v4u*)(Cb + (m * p.ldc + n) * 2) = o;
         }
       }
       return;
