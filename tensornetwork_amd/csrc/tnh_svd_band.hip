@@ -397,56 +397,15 @@ __global__ __launch_bounds__(256) void formv_kernel(const float* __restrict__ P,
 // eight 16-row steps are requested before the first FMA.
 constexpr int W_RC = 256;
 constexpr int W_UNROLL = 4;
-// FORMV: the V rows below the top block are formed here, V[r][:] = P[r][:] X (what formv_kernel does: same sums, same
-// order), by every workgroup for its own chunk; the workgroups of the first column tile also write them to V.  Saves
-// the formv launch of every panel (4.5-5 us of a ~40 us chain); P = the panel, 16 columns to the left of C.
-template <bool FORMV>
 __global__ __launch_bounds__(256) void wpass_kernel(const float* __restrict__ C, int64_t ldc, int64_t rows, int64_t nc,
-                                                    float* __restrict__ V, float* __restrict__ Wpart,
-                                                    const float* __restrict__ P, const double* __restrict__ X) {
+                                                    const float* __restrict__ V, float* __restrict__ Wpart) {
   __shared__ float4 vs[W_RC][4];        // V rows of the chunk
   __shared__ float red[4][16][65];      // [wave][i][column]
-  __shared__ double xs[FORMV ? 16 : 1][17];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, t = lane & 15;
   const int64_t c0 = (int64_t)blockIdx.x * 64 + 4 * t;
   const int64_t rbeg = (int64_t)blockIdx.y * W_RC;
   const bool col_ok = c0 < nc;
-  if constexpr (FORMV) {
-    xs[tid >> 4][tid & 15] = X[tid];
-    const int64_t r = rbeg + tid;
-    float p[16];
-#pragma unroll
-    for (int l = 0; l < 16; ++l) p[l] = 0.f;
-    if (r < rows) {
-      const float4* src = reinterpret_cast<const float4*>((r < 16) ? (const float*)(V + r * 16) : (P + r * ldc));
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const float4 x = src[q];
-        p[4 * q] = x.x; p[4 * q + 1] = x.y; p[4 * q + 2] = x.z; p[4 * q + 3] = x.w;
-      }
-    }
-    __syncthreads();
-    float v[16];
-    if (r >= 16 && r < rows) {
-#pragma unroll
-      for (int k = 0; k < 16; ++k) {
-        double acc = 0.0;
-#pragma unroll
-        for (int l = 0; l < 16; ++l) acc += (double)p[l] * xs[l][k];
-        v[k] = (float)acc;
-      }
-      if (blockIdx.x == 0) {
-        float4* dst = reinterpret_cast<float4*>(V + r * 16);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) dst[q] = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
-      }
-    } else {
-#pragma unroll
-      for (int k = 0; k < 16; ++k) v[k] = p[k];      // top block rows come from the factor kernel; rows past the end: 0
-    }
-#pragma unroll
-    for (int q = 0; q < 4; ++q) vs[tid][q] = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
-  } else {
+  {
     const int64_t r = rbeg + tid;
     const float4* vp = reinterpret_cast<const float4*>(V + r * 16);
 #pragma unroll
@@ -721,16 +680,10 @@ __global__ __launch_bounds__(256) void rowupdate_kernel(float* __restrict__ C, i
 //   yreduce  Z[r][:] = T^T (sum over chunks of Ypart[chunk][r][:])                            (Z = Y T)
 //   update_kernel(C, V := Z, Wt := Vt)                                                        (C -= Z V^T)
 constexpr int Y_ROWS = 64, Y_COLS = 128;
-// FORMV: the columns of V^T past the top block are formed here, Vt[:, c] = X^T P[:, c] (formv_kernel's sums), by every
-// workgroup for its own 128 columns -- two threads per column, eight entries each; the workgroups of the first row
-// tile also write them to Vt and to V (row-major, for the back-transformation).  P = the row panel, 16 rows above C.
-template <bool FORMV>
 __global__ __launch_bounds__(256) void ypass_kernel(const float* __restrict__ C, int64_t ldc, int64_t rows, int64_t nc,
-                                                    float* __restrict__ Vt, int64_t vt_pitch,
-                                                    float* __restrict__ Ypart, const float* __restrict__ P,
-                                                    const double* __restrict__ X, float* __restrict__ Vout) {
+                                                    const float* __restrict__ Vt, int64_t vt_pitch,
+                                                    float* __restrict__ Ypart) {
   __shared__ float4 vts[Y_COLS / 64][16][16];    // [tile][i][t]
-  __shared__ double xs[FORMV ? 16 : 1][17];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, t = lane & 15;
   const int64_t cbeg = (int64_t)blockIdx.x * Y_COLS;
   const int64_t rbeg = (int64_t)blockIdx.y * Y_ROWS;
@@ -745,47 +698,11 @@ __global__ __launch_bounds__(256) void ypass_kernel(const float* __restrict__ C,
       cv[it][u] = (r < rows && c < nc) ? *reinterpret_cast<const float4*>(C + r * ldc + c) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   }
-  if constexpr (FORMV) {
-    static_assert(Y_COLS == 128, "two threads per column");
-    xs[tid >> 4][tid & 15] = X[tid];
-    const int cl = tid & 127, half = tid >> 7;
-    const int64_t c = cbeg + cl;
-    float p[16];
 #pragma unroll
-    for (int l = 0; l < 16; ++l) p[l] = (c >= 16 && c < nc) ? P[(int64_t)l * ldc + c] : 0.f;
-    __syncthreads();
-    float v[8];
-    if (c >= 16 && c < nc) {
-#pragma unroll
-      for (int kk = 0; kk < 8; ++kk) {
-        const int k = 8 * half + kk;
-        double acc = 0.0;
-#pragma unroll
-        for (int l = 0; l < 16; ++l) acc += (double)p[l] * xs[l][k];
-        v[kk] = (float)acc;
-      }
-      if (blockIdx.y == 0) {
-#pragma unroll
-        for (int kk = 0; kk < 8; ++kk) Vt[(int64_t)(8 * half + kk) * vt_pitch + c] = v[kk];
-        float4* dst = reinterpret_cast<float4*>(Vout + c * 16 + 8 * half);
-        dst[0] = make_float4(v[0], v[1], v[2], v[3]);
-        dst[1] = make_float4(v[4], v[5], v[6], v[7]);
-      }
-    } else {
-#pragma unroll
-      for (int kk = 0; kk < 8; ++kk)       // top block columns come from the factor kernel; columns past the end: 0
-        v[kk] = (c < nc) ? Vt[(int64_t)(8 * half + kk) * vt_pitch + c] : 0.f;
-    }
-    float* vf = reinterpret_cast<float*>(&vts[0][0][0]);      // [tile][i][64 columns]
-#pragma unroll
-    for (int kk = 0; kk < 8; ++kk) vf[((cl >> 6) * 16 + 8 * half + kk) * 64 + (cl & 63)] = v[kk];
-  } else {
-#pragma unroll
-    for (int u = 0; u < Y_COLS / 64; ++u) {
-      const int64_t c = cbeg + u * 64 + 4 * (tid & 15);
-      vts[u][tid >> 4][tid & 15] = (c < nc) ? *reinterpret_cast<const float4*>(Vt + (int64_t)(tid >> 4) * vt_pitch + c)
-                                            : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
+  for (int u = 0; u < Y_COLS / 64; ++u) {
+    const int64_t c = cbeg + u * 64 + 4 * (tid & 15);
+    vts[u][tid >> 4][tid & 15] = (c < nc) ? *reinterpret_cast<const float4*>(Vt + (int64_t)(tid >> 4) * vt_pitch + c)
+                                          : make_float4(0.f, 0.f, 0.f, 0.f);
   }
   __syncthreads();
   float y[Y_ROWS / 16][16];
@@ -1572,7 +1489,6 @@ static Layout make_layout(int64_t m, int64_t n, int64_t kcap) {
 
 static bool g_dpp = true;
 static double g_cluster_tol = 4e-7;  // kept values closer than this (relative to sigma_max: a few eps_f32) are one cluster (TNH_SVDB_CTOL)
-static bool g_formv_fused = true;  // V rows formed inside the W / Y passes (TNH_SVDB_FORMV=0: the separate formv launches)
 static bool g_row_fused = false;  // row panels by the row-owning fused kernel (TNH_SVDB_ROWFUSED=1) or ypass / yreduce / update
 static bool g_bt_fused = true;   // back-transformation by column-owning workgroups (TNH_SVDB_BT=0: per-panel launches)
 static bool g_lane = true;       // counts through sturm_lane_kernel (TNH_SVDB_LANE=0: the 16-lane ldl_kernel)
@@ -1595,8 +1511,6 @@ static void read_env() {
   if (e && atof(e) >= 0.0) g_cluster_tol = atof(e);
   e = getenv("TNH_SVDB_ROWFUSED");
   g_row_fused = (e && e[0] == '1');
-  e = getenv("TNH_SVDB_FORMV");
-  g_formv_fused = !(e && e[0] == '0');
   e = getenv("TNH_SVDB_BT");
   g_bt_fused = !(e && e[0] == '0');
   e = getenv("TNH_SVDB_LANE");
@@ -1683,18 +1597,14 @@ static int stage1(const Layout& L, char* base, int64_t m, int64_t n) {
       double* Tp = (double*)(base + L.Tl) + p * 256;
       hipLaunchKernelGGL((factor_kernel<false>), dim3(1), dim3(256), 0, stream(), P, n, mj, (const double*)Gc, parts_c, Xb, V,
                          (float*)nullptr, (int64_t)0, Tp, (double*)(base + L.Dblk) + p * 256, status);
-      if (mj > 16 && (nc <= 0 || !g_formv_fused))      // otherwise the W pass forms the V rows itself
+      if (mj > 16)
         hipLaunchKernelGGL((formv_kernel<false>), dim3((unsigned)((mj - 16 + 255) / 256)), dim3(256), 0, stream(), P, n, mj,
                            (const double*)Xb, V, (float*)nullptr, (int64_t)0);
       if (nc > 0) {
         float* C = Af + j * n + j + 16;
         const int chunks = (int)((mj + W_RC - 1) / W_RC);
-        if (g_formv_fused)
-          hipLaunchKernelGGL((wpass_kernel<true>), dim3((unsigned)((nc + 63) / 64), chunks), dim3(256), 0, stream(),
-                             (const float*)C, n, mj, nc, V, Wpart, P, (const double*)Xb);
-        else
-          hipLaunchKernelGGL((wpass_kernel<false>), dim3((unsigned)((nc + 63) / 64), chunks), dim3(256), 0, stream(),
-                             (const float*)C, n, mj, nc, V, Wpart, (const float*)nullptr, (const double*)nullptr);
+        hipLaunchKernelGGL(wpass_kernel, dim3((unsigned)((nc + 63) / 64), chunks), dim3(256), 0, stream(),
+                           (const float*)C, n, mj, nc, (const float*)V, Wpart);
         hipLaunchKernelGGL(wreduce_kernel, dim3((unsigned)((nc + 63) / 64)), dim3(256), 0, stream(), (const float*)Wpart,
                            chunks, nc, (const double*)Tp, 1, Wt);
         // the update also leaves the partial Grams of the row panel (first 16 rows of the updated block)
@@ -1711,8 +1621,7 @@ static int stage1(const Layout& L, char* base, int64_t m, int64_t n) {
       double* Tp = (double*)(base + L.Tr) + p * 256;
       hipLaunchKernelGGL((factor_kernel<true>), dim3(1), dim3(256), 0, stream(), P, n, nc, (const double*)Gr, parts_r, Xb, V, Vt,
                          nc, Tp, (double*)(base + L.Eblk) + p * 256, status);
-      const bool y_forms_v = g_formv_fused && !g_row_fused && mr > 0;
-      if (nc > 16 && !y_forms_v)
+      if (nc > 16)
         hipLaunchKernelGGL((formv_kernel<true>), dim3((unsigned)((nc - 16 + 255) / 256)), dim3(256), 0, stream(), P, n, nc,
                            (const double*)Xb, V, Vt, nc);
       if (mr > 0) {
@@ -1725,13 +1634,8 @@ static int stage1(const Layout& L, char* base, int64_t m, int64_t n) {
         } else {
           const int ych = (int)((nc + Y_COLS - 1) / Y_COLS);
           float* Z = (float*)(base + L.Zr);
-          if (y_forms_v)
-            hipLaunchKernelGGL((ypass_kernel<true>), dim3(ych, (unsigned)((mr + Y_ROWS - 1) / Y_ROWS)), dim3(256), 0, stream(),
-                               (const float*)C, n, mr, nc, Vt, nc, Wpart, P, (const double*)Xb, V);
-          else
-            hipLaunchKernelGGL((ypass_kernel<false>), dim3(ych, (unsigned)((mr + Y_ROWS - 1) / Y_ROWS)), dim3(256), 0, stream(),
-                               (const float*)C, n, mr, nc, Vt, nc, Wpart, (const float*)nullptr, (const double*)nullptr,
-                               (float*)nullptr);
+          hipLaunchKernelGGL(ypass_kernel, dim3(ych, (unsigned)((mr + Y_ROWS - 1) / Y_ROWS)), dim3(256), 0, stream(),
+                             (const float*)C, n, mr, nc, (const float*)Vt, nc, Wpart);
           hipLaunchKernelGGL(yreduce_kernel, dim3((unsigned)((mr + 63) / 64)), dim3(256), 0, stream(),
                              (const float*)Wpart, ych, mr, (const double*)Tp, Z);
           // ... and this update the partial Grams of the next column panel (first 16 columns of the updated block)
@@ -1850,8 +1754,8 @@ static int vectors(const Layout& L, char* base, int64_t m, int64_t n, int64_t k,
     const float* V = (const float*)(base + L.Vl) + vl_offset(m, p);
     float* C = Uu + j * k;
     const int chunks = (int)((mj + W_RC - 1) / W_RC);
-    hipLaunchKernelGGL((wpass_kernel<false>), dim3((unsigned)((k + 63) / 64), chunks), dim3(256), 0, stream(), (const float*)C, k,
-                       mj, k, (float*)V, Wpart, (const float*)nullptr, (const double*)nullptr);
+    hipLaunchKernelGGL(wpass_kernel, dim3((unsigned)((k + 63) / 64), chunks), dim3(256), 0, stream(), (const float*)C, k,
+                       mj, k, V, Wpart);
     hipLaunchKernelGGL(wreduce_kernel, dim3((unsigned)((k + 63) / 64)), dim3(256), 0, stream(), (const float*)Wpart,
                        chunks, k, (const double*)(base + L.Tl) + p * 256, 0, Wt);
     hipLaunchKernelGGL((update_kernel<0>), dim3((unsigned)((k + 63) / 64), (unsigned)((mj + U_RR - 1) / U_RR)), dim3(256), 0,
@@ -1864,8 +1768,8 @@ static int vectors(const Layout& L, char* base, int64_t m, int64_t n, int64_t k,
     const float* V = (const float*)(base + L.Vr) + vr_offset(n, p);
     float* C = Vv + j * k;
     const int chunks = (int)((nj + W_RC - 1) / W_RC);
-    hipLaunchKernelGGL((wpass_kernel<false>), dim3((unsigned)((k + 63) / 64), chunks), dim3(256), 0, stream(), (const float*)C, k,
-                       nj, k, (float*)V, Wpart, (const float*)nullptr, (const double*)nullptr);
+    hipLaunchKernelGGL(wpass_kernel, dim3((unsigned)((k + 63) / 64), chunks), dim3(256), 0, stream(), (const float*)C, k,
+                       nj, k, V, Wpart);
     hipLaunchKernelGGL(wreduce_kernel, dim3((unsigned)((k + 63) / 64)), dim3(256), 0, stream(), (const float*)Wpart,
                        chunks, k, (const double*)(base + L.Tr) + p * 256, 0, Wt);
     hipLaunchKernelGGL((update_kernel<0>), dim3((unsigned)((k + 63) / 64), (unsigned)((nj + U_RR - 1) / U_RR)), dim3(256), 0,
@@ -1918,18 +1822,14 @@ static int qr_f32(int64_t m, int64_t n, const float* A, float* Q, float* R, char
     double* Tp = (double*)(base + L.Tl) + p * 256;
     hipLaunchKernelGGL((factor_kernel<false>), dim3(1), dim3(256), 0, stream(), P, n, mj, (const double*)Gc, parts, Xb, V,
                        (float*)nullptr, (int64_t)0, Tp, (double*)(base + L.Dblk) + p * 256, status);
-    if (mj > 16 && (nc <= 0 || !g_formv_fused))
+    if (mj > 16)
       hipLaunchKernelGGL((formv_kernel<false>), dim3((unsigned)((mj - 16 + 255) / 256)), dim3(256), 0, stream(), P, n, mj,
                          (const double*)Xb, V, (float*)nullptr, (int64_t)0);
     if (nc > 0) {
       float* C = Af + j * n + j + 16;
       const int chunks = (int)((mj + W_RC - 1) / W_RC);
-      if (g_formv_fused)
-        hipLaunchKernelGGL((wpass_kernel<true>), dim3((unsigned)((nc + 63) / 64), chunks), dim3(256), 0, stream(),
-                           (const float*)C, n, mj, nc, V, Wpart, P, (const double*)Xb);
-      else
-        hipLaunchKernelGGL((wpass_kernel<false>), dim3((unsigned)((nc + 63) / 64), chunks), dim3(256), 0, stream(),
-                           (const float*)C, n, mj, nc, V, Wpart, (const float*)nullptr, (const double*)nullptr);
+      hipLaunchKernelGGL(wpass_kernel, dim3((unsigned)((nc + 63) / 64), chunks), dim3(256), 0, stream(), (const float*)C,
+                         n, mj, nc, (const float*)V, Wpart);
       hipLaunchKernelGGL(wreduce_kernel, dim3((unsigned)((nc + 63) / 64)), dim3(256), 0, stream(), (const float*)Wpart,
                          chunks, nc, (const double*)Tp, 1, Wt);
       // the update leaves the partial Grams of the next panel: first 16 columns of the block, rows 16 .. (the first
@@ -1966,8 +1866,8 @@ static int qr_f32(int64_t m, int64_t n, const float* A, float* Q, float* R, char
       float* C = Q + j * n + j;               // columns before j are untouched by panel p (identity start)
       const int64_t kc = n - j;
       const int chunks = (int)((mj + W_RC - 1) / W_RC);
-      hipLaunchKernelGGL((wpass_kernel<false>), dim3((unsigned)((kc + 63) / 64), chunks), dim3(256), 0, stream(), (const float*)C,
-                         n, mj, kc, (float*)V, Wpart, (const float*)nullptr, (const double*)nullptr);
+      hipLaunchKernelGGL(wpass_kernel, dim3((unsigned)((kc + 63) / 64), chunks), dim3(256), 0, stream(), (const float*)C,
+                         n, mj, kc, V, Wpart);
       hipLaunchKernelGGL(wreduce_kernel, dim3((unsigned)((kc + 63) / 64)), dim3(256), 0, stream(), (const float*)Wpart,
                          chunks, kc, (const double*)(base + L.Tl) + p * 256, 0, Wt);
       hipLaunchKernelGGL((update_kernel<0>), dim3((unsigned)((kc + 63) / 64), (unsigned)((mj + U_RR - 1) / U_RR)),
