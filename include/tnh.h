@@ -165,7 +165,8 @@ int tnh_complex_expand(void* dst, const void* src, int64_t K, int64_t N,
  * data; generalised here to operands whose free / contracted axes each form up to two memory runs,
  * e.g. a[i0, k1, i2, k3]).  Element (r, k) of an operand lives at
  *     (r / r0) * sr1 + (r % r0) * sr0  +  (k / k0) * sk1 + (k % k0) * sk0      (elements)
- * with exactly one of sk0 / sr0 equal to 1 ("K-contiguous" or "k-major"), k0 % 64 == 0 and
+ * with exactly one of sk0 / sr0 equal to 1 ("K-contiguous" or "k-major"), k0 % 32 == 0 (a 64-deep
+ * K-tile may take its two halves from two runs: bond dimensions 32, 96, 160 ...), K % 64 == 0 and
  * K % k0 == 0; strides multiples of 8 elements, bases 16-byte aligned.  C is row-major M x N (ldc).
  * Returns TNH_ERR_UNSUPPORTED (nothing launched) when the shape is outside the 256 x 256 tile
  * kernel's range or an alignment rule fails: the caller then materialises a permuted copy and

@@ -959,11 +959,11 @@ int tnh_gemm_view(int in_dtype, int out_dtype, int64_t M, int64_t N, int64_t K, 
   TNH_REQUIRE(M > 0 && N > 0 && K > 0 && A && B && C && va && vb, "tnh_gemm_view: bad arguments");
   TNH_REQUIRE(ldc >= N, "ldc (%lld) < N (%lld)", (long long)ldc, (long long)N);
   auto conv = [](const tnh_operand_view* v, int64_t K, OpView* o) -> bool {
-    if (v->k0 <= 0 || v->r0 <= 0 || v->k0 % 64 != 0 || K % v->k0 != 0) return false;
+    if (v->k0 <= 0 || v->r0 <= 0 || v->k0 % 32 != 0 || K % v->k0 != 0) return false;
     o->r0 = v->r0; o->sr0 = v->sr0; o->sr1 = v->sr1;
     o->sk0 = v->sk0; o->sk1 = v->sk1;
-    o->tpi = (int)(v->k0 / 64);
-    return v->k0 / 64 < (int64_t(1) << 30);
+    o->tpi = (int)(v->k0 / 32);
+    return v->k0 / 32 < (int64_t(1) << 30);
   };
   if (g_variant != 0) {   // a kernel forced through tnh_gemm_set_variant (tests, A/B): the caller's fallback path runs it
     set_error("tnh_gemm_view: a GEMM variant is forced");
@@ -971,7 +971,7 @@ int tnh_gemm_view(int in_dtype, int out_dtype, int64_t M, int64_t N, int64_t K, 
   }
   OpView a, b;
   if (!conv(va, K, &a) || !conv(vb, K, &b)) {
-    set_error("tnh_gemm_view: the inner contraction run of an operand is not a multiple of 64 that divides K");
+    set_error("tnh_gemm_view: the inner contraction run of an operand is not a multiple of 32 that divides K");
     return TNH_ERR_UNSUPPORTED;
   }
   const char* name = nullptr;

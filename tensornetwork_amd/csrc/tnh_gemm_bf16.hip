@@ -223,24 +223,34 @@ typedef short v4i16 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) v4i16 lds_v4i16;
 typedef __attribute__((address_space(3))) char lds_char;
 
-// walks the element offset of consecutive K-tiles of one operand (wave-uniform, SALU only)
+// walks the element offsets of consecutive HALF K-tiles (32 contraction indices) of one operand (wave-uniform, SALU
+// only): the inner contraction run of a view is a multiple of 32, so a 64-deep K-tile may take its two halves from
+// two different runs (D = 96: runs of 96 = 3 halves; chi = 32: every half its own run).
 struct KWalk {
   int64_t off, step, wrap;
-  int in, tpi;
+  int in, hpr;
   __device__ __forceinline__ void init(const OpView& v, int tile) {
-    tpi = v.tpi;
-    step = 64 * v.sk0;
+    hpr = v.tpi;
+    step = 32 * v.sk0;
     wrap = v.sk1 - (int64_t)v.tpi * step;
-    in = tile % v.tpi;
-    off = (int64_t)(tile / v.tpi) * v.sk1 + (int64_t)in * step;
+    const int half = 2 * tile;
+    in = half % v.tpi;
+    off = (int64_t)(half / v.tpi) * v.sk1 + (int64_t)in * step;
   }
-  __device__ __forceinline__ void advance() {
+  __device__ __forceinline__ void advance_half() {
     ++in;
     off += step;
-    if (in == tpi) {
+    if (in == hpr) {
       in = 0;
       off += wrap;
     }
+  }
+  // offsets of the two halves of the next K-tile
+  __device__ __forceinline__ void next(int64_t& h0, int64_t& h1) {
+    h0 = off;
+    advance_half();
+    h1 = off;
+    advance_half();
   }
 };
 
@@ -293,7 +303,7 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(NtArgs p) {
       int64_t col = first + h * 128 + chunk * 8;
       if (col + 8 > limit) col = limit - 8;                                  // ragged edge: valid memory, never stored
       const uint32_t c1 = (uint32_t)col / (uint32_t)v.r0, c0 = (uint32_t)col - c1 * (uint32_t)v.r0;   // rows < 2^31 (host check)
-      return base + (int64_t)c1 * v.sr1 + c0 + (int64_t)krow * v.sk0;
+      return base + (int64_t)c1 * v.sr1 + c0 + (int64_t)(krow & 31) * v.sk0;      // piece i = half i of the K-tile
     }
     const int trow = (i * 8 + wid) * 8 + lrow;  // row inside the half-tile
     const int swz = M32 ? ((trow >> 1) & 7) : (trow & 7);
@@ -302,7 +312,7 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(NtArgs p) {
     if (row >= limit) row = limit - 1;
     if constexpr (VIEW) {
       const uint32_t r1 = (uint32_t)row / (uint32_t)v.r0, r0 = (uint32_t)row - r1 * (uint32_t)v.r0;
-      return base + (int64_t)r1 * v.sr1 + (int64_t)r0 * v.sr0 + lchunk * 8;
+      return base + (int64_t)r1 * v.sr1 + (int64_t)r0 * v.sr0 + (lchunk & 3) * 8;   // chunks 4-7: second half
     }
     return base + row * ld + lchunk * 8;
   };
@@ -315,18 +325,26 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(NtArgs p) {
     for (int h = 0; h < 2; ++h)
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        ga[h][i] = src_ptr(A, p.va, A_KM, m0, p.M, p.lda, h, i);
+        ga[h][i] = src_ptr(A, p.va, A_KM, m0 + p.m_off, p.M + p.m_off, p.lda, h, i);
         gb[h][i] = src_ptr(B, p.vb, B_KN, n0, p.N, p.ldb, h, i);
       }
   };
   const unsigned lds0 = (unsigned)(size_t)TNH_LDS_PTR(smem);
-  // which: 0 = A-half0, 1 = A-half1, 2 = B-half0, 3 = B-half1
-  auto issue = [&](int buf, int which, int64_t k0) {
+  // which: 0 = A-half0, 1 = A-half1, 2 = B-half0, 3 = B-half1 (halves of the tile's ROWS).  k0 / k1: element offsets of
+  // the two 32-deep halves of the K-tile (plain NT kernels: k1 unused, the pointers carry the full chunk offset).
+  // A K-contiguous row keeps chunks 0-3 of its 128-B LDS row in the first half and 4-7 in the second (the chunk a
+  // lane fetches is (lane & 7) ^ swizzle(row), the swizzle being lane >> 3 for every piece); a k-major piece i is
+  // half i.
+  const bool hi_half = ((((lane & 7) ^ (lane >> 3)) >> 2) & 1) != 0;
+  auto issue = [&](int buf, int which, int64_t k0, int64_t k1) {
     const unsigned base = lds0 + buf * BUF_BYTES + which * HALF_BYTES;
+    const bool kmajor = (which < 2) ? A_KM : B_KN;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const uint16_t* g = (which < 2) ? ga[which & 1][i] : gb[which & 1][i];
-      glds16(g + k0, __builtin_amdgcn_readfirstlane(base + (i * 8 + wid) * 1024));
+      int64_t k = k0;
+      if constexpr (VIEW) k = kmajor ? (i == 0 ? k0 : k1) : (hi_half ? k1 : k0);
+      glds16(g + k, __builtin_amdgcn_readfirstlane(base + (i * 8 + wid) * 1024));
     }
   };
 
@@ -448,25 +466,26 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(NtArgs p) {
   KWalk wa, wb;
   // prologue of an output tile (its LDS-DMA source pointers set by setup_tile): K-tile 0 complete, B halves of K-tile 1
   auto start_tile = [&]() {
-    int64_t ka0 = 0, kb0 = 0;
+    int64_t ka0 = 0, ka1 = 0, kb0 = 0, kb1 = 0;
     if constexpr (VIEW) {
       wa.init(p.va, kfirst);
       wb.init(p.vb, kfirst);
-      ka0 = wa.off;
-      kb0 = wb.off;
-      wa.advance();
-      wb.advance();
+      wa.next(ka0, ka1);
+      wb.next(kb0, kb1);
     }
-    issue(0, 0, ka0);
-    issue(0, 1, ka0);
-    issue(0, 2, kb0);
-    issue(0, 3, kb0);
+    issue(0, 0, ka0, ka1);
+    issue(0, 1, ka0, ka1);
+    issue(0, 2, kb0, kb1);
+    issue(0, 3, kb0, kb1);
     if (nt > 1) {
-      const int64_t kb1 = VIEW ? wb.off : (int64_t)BK;
-      issue(1, 2, kb1);
-      issue(1, 3, kb1);
+      int64_t kc0 = (int64_t)BK, kc1 = 0;
+      if constexpr (VIEW) wb.next(kc0, kc1);
+      issue(1, 2, kc0, kc1);
+      issue(1, 3, kc0, kc1);
+    } else if constexpr (VIEW) {
+      int64_t d0, d1;
+      wb.next(d0, d1);
     }
-    if constexpr (VIEW) wb.advance();
   };
   setup_tile((int)blockIdx.x);
   start_tile();
@@ -488,10 +507,10 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(NtArgs p) {
       read_b(cur, 0);
       read_b(cur, 1);
       if (n1) {
-        const int64_t ka = VIEW ? wa.off : (int64_t)(t + 1) * BK;
-        issue(b ^ 1, 0, ka);
-        issue(b ^ 1, 1, ka);
-        if constexpr (VIEW) wa.advance();
+        int64_t ka = (int64_t)(t + 1) * BK, ka1 = 0;
+        if constexpr (VIEW) wa.next(ka, ka1);
+        issue(b ^ 1, 0, ka, ka1);
+        issue(b ^ 1, 1, ka, ka1);
       }
       TNH_SEG_LOAD_END();
       mma_quadrant(0, 0);
@@ -499,10 +518,10 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(NtArgs p) {
       TNH_SEG_MMA_END();
       read_a(cur, 1);
       if (n2) {
-        const int64_t kb = VIEW ? wb.off : (int64_t)(t + 2) * BK;
-        issue(b, 2, kb);
-        issue(b, 3, kb);
-        if constexpr (VIEW) wb.advance();
+        int64_t kb = (int64_t)(t + 2) * BK, kb1 = 0;
+        if constexpr (VIEW) wb.next(kb, kb1);
+        issue(b, 2, kb, kb1);
+        issue(b, 3, kb, kb1);
         asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
       } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -516,25 +535,25 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(NtArgs p) {
     // ---- phase 0
     read_a(cur, 0);
     read_b(cur, 0);
-    if (n1) issue(b ^ 1, 0, (int64_t)(t + 1) * BK);
+    if (n1) issue(b ^ 1, 0, (int64_t)(t + 1) * BK, 0);
     TNH_SEG_LOAD_END();
     mma_quadrant(0, 0);
     TNH_SEG_MMA_END();
     // ---- phase 1
     read_b(cur, 1);
-    if (n1) issue(b ^ 1, 1, (int64_t)(t + 1) * BK);
+    if (n1) issue(b ^ 1, 1, (int64_t)(t + 1) * BK, 0);
     TNH_SEG_LOAD_END();
     mma_quadrant(0, 1);
     TNH_SEG_MMA_END();
     // ---- phase 2
     read_a(cur, 1);
-    if (n2) issue(b, 2, (int64_t)(t + 2) * BK);
+    if (n2) issue(b, 2, (int64_t)(t + 2) * BK, 0);
     TNH_SEG_LOAD_END();
     mma_quadrant(1, 1);
     TNH_SEG_MMA_END();
     // ---- phase 3
     if (n2) {
-      issue(b, 3, (int64_t)(t + 2) * BK);
+      issue(b, 3, (int64_t)(t + 2) * BK, 0);
       asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // tile t+1 landed; B halves of t+2 in flight
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -851,6 +870,7 @@ static int launch_pp(bool is_bf16, bool out_f32, bool two, NtArgs p, int64_t bat
     q.A = p.A + b0 * p.sA;
     q.B = p.B + b0 * p.sB;
     q.C = (char*)p.C + b0 * p.sC * esz_out;
+    q.m_off = 0;
     const dim3 grid(pp_grid_x(nwg, (unsigned)nb), (unsigned)nb), block(512);
 #define TNH_PP_LAUNCH(B16, O32)                                                                               \
   do {                                                                                                       \
@@ -891,7 +911,7 @@ static bool view_ok(const OpView& v, int64_t rows, int64_t K, const void* base, 
               (long long)v.sr0);
     return false;
   }
-  const int64_t k0 = (int64_t)v.tpi * 64;
+  const int64_t k0 = (int64_t)v.tpi * 32;
   bool ok = v.tpi >= 1 && v.r0 >= 1 && K % k0 == 0 && ((uintptr_t)base % 16) == 0 && v.sr1 % 8 == 0 && v.sk1 % 8 == 0;
   if (kcontig) ok = ok && v.sr0 % 8 == 0;
   else ok = ok && v.sk0 % 8 == 0 && v.r0 % 8 == 0 && rows % 8 == 0;
@@ -929,6 +949,7 @@ int gemm_bf16_view(int in_dt, int out_dt, int64_t M, int64_t N, int64_t K, const
   const bool a_km = (va.sk0 != 1), b_kn = (vb.sk0 != 1);
   const bool is_bf16 = (in_dt == TNH_BF16), out_f32 = (out_dt == TNH_F32);
   p.kslice_tiles = 0;
+  p.m_off = 0;
   auto launch = [&](const NtArgs& q, unsigned gy, bool f32_out) {
     const dim3 grid(pp_grid_x((int64_t)q.tiles_m * q.tiles_n, gy), gy);
     if (a_km && b_kn) launch_pp_view_t<true, true>(is_bf16, f32_out, grid, q);
@@ -947,10 +968,9 @@ int gemm_bf16_view(int in_dt, int out_dt, int64_t M, int64_t N, int64_t K, const
   const bool tail_on = tail_env && g_opt_tail != 0;     // knob ":t0" of tnh_gemm_set_variant (tests, A/B)
   const int cus = num_cus() > 0 ? num_cus() : 256;
   const int nkt = (int)(K / 64);
-  const bool rows_single_level = (p.va.sr1 == 0 || p.va.r0 >= M);
   // (measured, tools/tail_probe.py: 9216^3 +5.6 %, 9216 x 9216 x 2048 -3.7 % -- the partial-slab reduction does not
   // shrink with K -- hence only for K >= 6144)
-  if (tail_on && nwg > cus && rows_single_level && ldc == N && nkt >= 96) {
+  if (tail_on && nwg > cus && ldc == N && nkt >= 96) {
     const double base = (double)((nwg + cus - 1) / cus);
     double best = base;
     int best_rt = 0, best_ks = 0, best_s = 0;
@@ -975,10 +995,9 @@ int gemm_bf16_view(int in_dt, int out_dt, int64_t M, int64_t N, int64_t K, const
         q.M = m_main;
         q.tiles_m = p.tiles_m - best_rt;
         launch(q, 1, out_f32);
-        NtArgs t = p;                     // tail rows, split over K
-        t.A = p.A + (a_km ? m_main : m_main * p.va.sr0);
+        NtArgs t = p;                     // tail rows [m_main, M) of A (two-level rows included: the row index
+        t.m_off = m_main;                 // keeps its origin), split over K
         t.M = m_tail;
-        if (t.va.r0 > t.M) t.va.r0 = t.M;
         t.tiles_m = (int)((m_tail + 255) / 256);
         t.C = W;
         t.ldc = N;

@@ -11,17 +11,18 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 // One operand of a "view" GEMM (tnh_gemm_view): a rank-<=4 tensor read in place as a matrix whose
 // row index and contraction index are each split over up to two memory levels (elements):
-//   row r = r1 * r0 + r0'  ->  r1 * sr1 + r0' * sr0        k = k1 * (64 * tpi) + k0'  ->  k1 * sk1 + k0' * sk0
+//   row r = r1 * r0 + r0'  ->  r1 * sr1 + r0' * sr0        k = k1 * (32 * tpi) + k0'  ->  k1 * sk1 + k0' * sk0
 // with exactly one of sk0 / sr0 equal to 1: "K-contiguous" (the NT form generalised) or "k-major"
-// (rows contiguous: what a [K][N] operand is).  A K-tile of 64 never straddles a k1 boundary.
+// (rows contiguous: what a [K][N] operand is).  A half K-tile (32 indices) never straddles a k1 boundary.
 struct OpView {
   int64_t r0, sr0, sr1;
   int64_t sk0, sk1;
-  int tpi;   // K-tiles per inner contraction run (k0 / 64)
+  int tpi;   // half K-tiles (32 contraction indices) per inner contraction run (k0 / 32)
 };
 
 struct NtArgs {
   OpView va, vb;   // view kernels only
+  int64_t m_off;     // ping-pong kernels: row index of A's first row (tail launches of a two-level-row view), else 0
   int kslice_tiles;  // view kernels, split-K launches: blockIdx.y owns K-tiles [y * kslice_tiles, ...) and writes
                      // its partial product to C + y * sC (0: one slice = all of K)
   const uint16_t* A;

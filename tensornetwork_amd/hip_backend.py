@@ -102,7 +102,7 @@ def _operand_view(shape, free_axes, k_axes):
   """Two-level strided matrix view (tnh_operand_view) of a dense row-major tensor whose rows are
   `free_axes` (output order) and whose contraction index is `k_axes` (K order), or None when the
   tensor cannot be read in place: more than two memory runs on either side, no contiguous
-  direction, an inner contraction run that is not a multiple of 64, or misaligned strides."""
+  direction, an inner contraction run that is not a multiple of 32, or misaligned strides."""
   strides = _row_major_strides(shape)
   rows = _merge_levels(shape, strides, free_axes)
   ks = _merge_levels(shape, strides, k_axes)
@@ -116,7 +116,7 @@ def _operand_view(shape, free_axes, k_axes):
   sk1 = ks[0][1] if len(ks) == 2 else 0
   if (sk0 == 1) == (sr0 == 1):
     return None                      # exactly one contiguous direction
-  if k0 % 64 != 0:
+  if k0 % 32 != 0:
     return None
   if sk0 == 1:
     if sr0 % 8 or sr1 % 8 or sk1 % 8:
@@ -557,8 +557,17 @@ class HipBackend(BackendBase):
     if orders[0] == orders[1]:
       orders = orders[:1]
 
-    def usable(t, free, kax):
+    out_bytes = m * n * a.itemsize
+
+    def usable(t, free, kax, hint):
       v = _operand_view(t.shape, free, kax)
+      # The planner asked for another order of this operand's free axes (it lays the RESULT out for the contractions
+      # that follow) and the operand is small against the result: pay its K1 pass now rather than a pass over the
+      # result later (MERA chi = 32: with the runs-of-32 views every small operand became readable in place, and the
+      # 68 GB intermediate then needed a 137 GB permute in front of the next product).
+      if v is not None and hint is not None and sorted(hint) == sorted(free) and \
+          [int(i) for i in hint] != list(free) and 8 * t.nbytes <= out_bytes:
+        return None
       # Gate (measured, profiles/r02_lowering_ab.txt): a view of a tensor above `inplace_max_bytes` is given up for
       # ONE K1 pass into a K-contiguous copy when it is k-major (a workgroup streaming it touches 64 new pages per
       # K-tile: -4 ... -10 % GEMM rate), or when it has two-level strides AND the product is so compute-heavy that
@@ -574,7 +583,7 @@ class HipBackend(BackendBase):
     best = None
     for order in orders:
       ka, kb = [axes_a[i] for i in order], [axes_b[i] for i in order]
-      va, vb = usable(a, free_a, ka), usable(b, free_b, kb)
+      va, vb = usable(a, free_a, ka, hint_a), usable(b, free_b, kb, hint_b)
       cost = (a.nbytes if va is None else 0) + (b.nbytes if vb is None else 0)
       if best is None or cost < best[0]:
         best = (cost, ka, kb, va, vb)

@@ -849,6 +849,11 @@ def test_gemm_view_absorbs_transposes_bit_exact(hip, dtype):
       ((14, 264, 2, 64), (2, 64, 14, 264), ([2, 3], [0, 1]), "bf16_view_nn"),      # ragged M / N edges (3696 = 14.4 tiles)
       ((2, 64, 15, 248), (2, 64, 15, 248), ([0, 1], [0, 1]), "bf16_view_tt"),      # ragged, k-major clamp on both sides
       ((4, 64, 3600), (3600, 4, 64), ([0, 1], [1, 2]), "bf16_view_tn"),            # rank 3, 4 K-tiles
+      # inner contraction runs that are multiples of 32 but not of 64: a K-tile takes its halves from two runs
+      ((14, 2, 256, 96), (96, 14, 2, 256), ([1, 3], [2, 0]), "bf16_view_nn"),      # D = 96 flavour of config-2 L1
+      ((64, 32, 56, 32), (32, 32, 60, 64), ([1, 3], [0, 1]), "bf16_view_nn"),      # chi = 32: every half its own run
+      ((4, 15, 32, 248), (4, 15, 32, 248), ([0, 2], [0, 2]), "bf16_view_tt"),      # both k-major, runs of 32, ragged
+      ((12, 2, 304, 160), (160, 12, 2, 304), ([1, 3], [2, 0]), "bf16_view_nn"),    # runs of 160 = 5 halves, ragged
   ]
   for i, (sa, sb, axes, want) in enumerate(cases):
     kernel, absorbed, permutes = _view_case(hip, dtype, sa, sb, axes, 40 + i)
@@ -857,9 +862,9 @@ def test_gemm_view_absorbs_transposes_bit_exact(hip, dtype):
 
 
 def test_gemm_view_falls_back_when_it_cannot_read_in_place(hip):
-  # inner contraction run of 96 (not a multiple of 64) -> permute + NT, still correct
+  # inner contraction run of 48 (not a multiple of 32) -> permute + NT, still correct
   # -> both operands permuted to [free, contracted], then the same view kernel on the trivial NT views
-  kernel, absorbed, permutes = _view_case(hip, ta.bfloat16, (14, 2, 256, 96), (96, 14, 2, 256), ([1, 3], [2, 0]), 60)
+  kernel, absorbed, permutes = _view_case(hip, ta.bfloat16, (14, 4, 256, 48), (48, 14, 4, 256), ([1, 3], [2, 0]), 60)
   assert absorbed == 1 and permutes == 2 and kernel.startswith("bf16_view_nt"), (kernel, absorbed, permutes)
   # one side readable in place, the other not: exactly one permute
   kernel, absorbed, permutes = _view_case(hip, ta.bfloat16, (14, 2, 256, 64), (68, 2, 64, 14, 5), ([1, 3], [1, 2]), 62)
@@ -882,7 +887,8 @@ def test_gemm_view_c_abi_rejects_bad_views_without_launching(hip):
   a = hip.to_bfloat16(np.zeros((4096, 128), np.float32))
   out = ta.DeviceTensor.empty((4096, 4096), _lib.BF16)
   good = _lib.OperandView(4096, 128, 0, 128, 1, 0)
-  for bad in (_lib.OperandView(4096, 128, 0, 96, 1, 0),       # k0 not a multiple of 64
+  for bad in (_lib.OperandView(4096, 128, 0, 96, 1, 0),       # k0 does not divide K
+              _lib.OperandView(4096, 128, 0, 16, 1, 128 * 4096),   # k0 not a multiple of 32
               _lib.OperandView(4096, 2, 0, 128, 2, 0),        # no contiguous direction
               _lib.OperandView(4096, 124, 0, 128, 1, 0)):     # rows not 16-byte aligned
     st = hip.lib.tnh_gemm_view(_lib.BF16, _lib.BF16, 4096, 4096, 128, ctypes.c_void_p(a.ptr), ctypes.byref(bad),
@@ -1045,3 +1051,31 @@ def test_gemm_persistent_tiles_match_one_workgroup_per_tile(hip, m, n, k, kn):
   an, bn = np.asarray(a).astype(np.float64), np.asarray(b).astype(np.float64)
   ref = an[rows] @ (bn if kn else bn.T)
   np.testing.assert_allclose(g[rows], ref, rtol=2.0**-7, atol=2.0**-8)
+
+
+def test_gemm_view_tail_split_with_two_level_rows_and_runs_of_96(hip):
+  """config-2 layout L1 at D = 96: a[i0, k1, i2, k3] . b[k3, j1, k1, j3] -- both operands in place (inner contraction
+  runs of 96 = three half K-tiles, two-level rows), 36 x 36 tiles, and the last tile row of the two-level-row operand
+  goes through the split-K tail launch (row offset instead of a pointer offset).  Against the un-split launch and
+  float64 on sampled entries."""
+  rng = np.random.default_rng(78)
+  D = 96
+  a = hip.device_random((D,) * 4, dtype=ta.bfloat16, seed=25, normal=True, b=1.0 / D)
+  b = hip.device_random((D,) * 4, dtype=ta.bfloat16, seed=26, normal=True, b=1.0)
+  before = hip.permute_launches
+  got = hip.tensordot(a, b, [[1, 3], [2, 0]])
+  assert hip.lib.tnh_gemm_last_kernel().decode() == "bf16_view_nn_256x256x64_pp+tail_splitk"
+  assert hip.permute_launches == before
+  _lib.check(hip.lib.tnh_gemm_set_variant(b"auto:t0"))
+  try:
+    ref_dev = hip.tensordot(a, b, [[1, 3], [2, 0]])
+  finally:
+    _lib.check(hip.lib.tnh_gemm_set_variant(b"auto"))
+  an, bn = np.asarray(a).astype(np.float64), np.asarray(b).astype(np.float64)
+  i0 = np.concatenate([rng.integers(0, D, 6), np.array([0, D - 3, D - 2, D - 1])])     # incl. the split tail rows
+  g = np.asarray(got)[i0][:, -8:]
+  u = np.asarray(ref_dev)[i0][:, -8:]
+  ref = np.einsum("xkil,ljkm->xijm", an[i0][:, :, -8:, :], bn)
+  np.testing.assert_allclose(g, ref, rtol=2.0**-8, atol=2.0**-9)
+  np.testing.assert_allclose(u, ref, rtol=2.0**-8, atol=2.0**-9)
+  np.testing.assert_allclose(g, u, rtol=2.0**-7, atol=1e-6)

@@ -519,6 +519,8 @@ def test_operand_view_addressing_reproduces_tensordot():
       ((128, 8), (128, 16), ([0], [0])),                         # plain TN
       ((2, 8, 64, 1, 64), (64, 64, 8, 3), ([2, 4], [0, 1])),    # size-1 axis in between
       ((8, 64, 8, 64), (64, 8, 64, 16), ([3, 1], [0, 2])),      # same pairs listed in the other order
+      ((8, 96, 8, 96), (96, 8, 96, 16), ([1, 3], [2, 0])),      # D = 96: runs of 96 = three half K-tiles
+      ((8, 32, 8, 32), (32, 32, 8, 16), ([1, 3], [0, 1])),      # chi = 32: runs of 32
   ]:
     a = rng.standard_normal(shape_a)
     b = rng.standard_normal(shape_b)
@@ -543,9 +545,9 @@ def test_operand_view_addressing_reproduces_tensordot():
       break
     else:
       raise AssertionError(f"no in-place view offered for {shape_a} x {shape_b} {axes}")
-  assert offered == 7
-  # refused: inner contraction run not a multiple of 64, three memory runs, misaligned strides
-  assert _operand_view((8, 96, 8, 96), [0, 2], [1, 3]) is None
+  assert offered == 9
+  # refused: inner contraction run not a multiple of 32, three memory runs, misaligned strides
+  assert _operand_view((8, 48, 8, 48), [0, 2], [1, 3]) is None
   assert _operand_view((4, 64, 4, 64, 4, 64), [0, 2, 4], [1, 3, 5]) is None
   assert _operand_view((8, 64, 8, 68), [0, 1, 2], [3]) is None       # contraction run 68
   assert _operand_view((64, 12), [1], [0]) is None                   # k-major with 12-element rows (not 16-B chunks)
