@@ -258,6 +258,13 @@ int tnh_random(void* dst, int64_t n, int dtype, uint64_t seed, int normal,
 int tnh_cast(void* dst, int dst_dtype, const void* src, int src_dtype,
              int64_t n);
 
+/* dst_i = canonical value of the int64 src_i in a narrower integer type: mode 0 the low `bits` (8, 16, 32, 64)
+ * zero-extended, mode 1 sign-extended, mode 2 (src_i != 0).  The host layer stores bool / unsigned / 8-16-bit
+ * integer tensors (which the reference's tests feed to every backend, tests/testing_utils.py:12-20) widened to
+ * int64; +, -, * are exact modulo 2^bits without this, everything else (conversion to float, sums, division, abs,
+ * sign) normalises first. */
+int tnh_wrap_int(void* dst, const void* src, int64_t n, int bits, int mode);
+
 /* ------------------------------------------------------------------ K7 SVD */
 /* Thin SVD of the row-major m x n matrix A (dtype F32 or F64):
  *   A = U diag(S) Vh,  r = min(m, n), S descending, ALL r values returned.

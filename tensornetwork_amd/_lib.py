@@ -98,6 +98,7 @@ SIGNATURES = {
     "tnh_random": (c_int, [c_void_p, c_int64, c_int, ctypes.c_uint64, c_int, c_double, c_double]),
     "tnh_eye": (c_int, [c_void_p, c_int64, c_int64, c_int]),
     "tnh_cast": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int64]),
+    "tnh_wrap_int": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int]),
     "tnh_svd_work_bytes": (c_int, [c_int, c_int64, c_int64,
                                    POINTER(c_size_t)]),
     "tnh_svd_factor": (c_int, [c_int, c_int64, c_int64, c_void_p, c_void_p,

@@ -462,6 +462,24 @@ static int cast_from(void* dst, int dst_dtype, const void* src, int64_t n) {
 
 using namespace tnh;
 
+namespace tnh {
+// int64 storage of a narrow / unsigned / bool tensor brought back to the canonical value of its NumPy dtype:
+// mode 0: the low `bits` zero-extended, 1: sign-extended, 2: x != 0.
+__global__ __launch_bounds__(256) void wrap_int_kernel(int64_t* __restrict__ dst, const int64_t* __restrict__ src, int64_t n,
+                                                       int bits, int mode) {
+  const int64_t step = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += step) {
+    const int64_t x = src[i];
+    int64_t y;
+    if (mode == 2) y = (x != 0) ? 1 : 0;
+    else if (bits == 64) y = x;
+    else if (mode == 0) y = (int64_t)((uint64_t)x & (((uint64_t)1 << bits) - 1));
+    else y = (int64_t)((uint64_t)x << (64 - bits)) >> (64 - bits);
+    dst[i] = y;
+  }
+}
+}  // namespace tnh
+
 extern "C" {
 
 int tnh_unary(int op, void* dst, const void* src, int64_t n, int dtype) {
@@ -666,6 +684,20 @@ int tnh_random(void* dst, int64_t n, int dtype, uint64_t seed, int normal, doubl
   const unsigned g = grid_for(n);
   TNH_DISPATCH_FLOAT(dtype, hipLaunchKernelGGL((random_kernel<DT>), dim3(g), dim3(256), 0, stream(),
                                                (typename Tr<DT>::S*)dst, n, seed, normal, a, b));
+  TNH_LAUNCH_CHECK();
+  return TNH_OK;
+}
+
+int tnh_wrap_int(void* dst, const void* src, int64_t n, int bits, int mode) {
+  TNH_NEED_INIT();
+  TNH_REQUIRE(n >= 0, "negative size");
+  TNH_REQUIRE(mode >= 0 && mode <= 2, "tnh_wrap_int: mode %d", mode);
+  TNH_REQUIRE(mode == 2 || bits == 8 || bits == 16 || bits == 32 || bits == 64, "tnh_wrap_int: %d bits", bits);
+  if (n == 0) return TNH_OK;
+  TNH_REQUIRE(dst && src, "null pointer");
+  const int64_t blocks = (n + 255) / 256;
+  hipLaunchKernelGGL(tnh::wrap_int_kernel, dim3((unsigned)(blocks < 65536 * 16 ? blocks : 65536 * 16)), dim3(256), 0,
+                     tnh::stream(), (int64_t*)dst, (const int64_t*)src, n, bits, mode);
   TNH_LAUNCH_CHECK();
   return TNH_OK;
 }

@@ -252,7 +252,8 @@ class DeviceTensor:
   def from_numpy(cls, array, dtype=None):
     """H2D copy. ``dtype=bfloat16`` rounds a real array to bf16 on the host."""
     array = np.asarray(array)
-    if dtype is not None and tnh_dtype(dtype) == _lib.BF16:
+    to_bf16 = dtype is not None and storage_of(dtype)[0] == _lib.BF16
+    if to_bf16:
       if array.dtype.kind not in "fiu":
         raise TypeError(f"cannot convert {array.dtype} to bfloat16")
       host = f32_to_bf16_bits(array.astype(np.float32))
@@ -267,7 +268,7 @@ class DeviceTensor:
         array = array.astype(np.int64)       # uint64 keeps its bit pattern
       code = tnh_dtype(array.dtype)
       host = np.ascontiguousarray(array)
-    out = cls.empty(array.shape, code, alias if dtype is None or tnh_dtype(dtype) != _lib.BF16 else None)
+    out = cls.empty(array.shape, code, None if to_bf16 else alias)
     if host.size:
       _lib.check(_lib.lib().tnh_h2d(ctypes.c_void_p(out.ptr),
                                     host.ctypes.data_as(ctypes.c_void_p),

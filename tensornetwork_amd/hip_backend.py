@@ -195,14 +195,38 @@ class HipBackend(BackendBase):
       return x
     return self.convert_to_tensor(x)
 
+  def _canonical(self, tensor, alias=None):
+    """A bool / unsigned / narrow-integer tensor is stored widened to int64 and stays exact under +, -, * only
+    modulo 2^bits; everything else -- conversion to another dtype, sums, division, abs, sign -- must see the value
+    NumPy holds in the narrow type: wrapped (zero- or sign-extended low bits), bool as 0 / 1 (tnh_wrap_int)."""
+    alias = tensor.alias if alias is None else alias
+    if alias is None or tensor.code != _lib.I64 or not tensor.size:
+      return tensor
+    mode = 2 if alias.kind == "b" else (0 if alias.kind == "u" else 1)
+    if mode != 2 and alias.itemsize == 8:
+      return tensor
+    out = DeviceTensor.empty(tensor.shape, _lib.I64, tensor.alias)
+    _lib.check(self.lib.tnh_wrap_int(_vp(out), _vp(tensor), tensor.size, 8 * alias.itemsize, mode), "tnh_wrap_int")
+    return out
+
   def cast(self, tensor, dtype):
     """Device-side dtype conversion (bf16/f16/f32/f64, real->complex)."""
     code, alias = (dtype, None) if isinstance(dtype, int) else storage_of(dtype)
     if tensor.code == code:
       if tensor.alias == alias:
         return tensor
-      return DeviceTensor(tensor._block, tensor.shape, code, tensor._offset, alias)   # same bits, other narrow type  # pylint: disable=protected-access
+      # another narrow type on the same int64 storage: the source's canonical value, then (to bool) != 0
+      t = self._canonical(tensor)
+      t = DeviceTensor(t._block, t.shape, code, t._offset, alias)   # pylint: disable=protected-access
+      return self._canonical(t) if alias is not None and alias.kind == "b" else t
     self._check_num(tensor, "cast")
+    tensor = self._canonical(tensor)
+    if alias is not None and alias.kind == "b" and tensor.code not in _INT_CODES:
+      # float -> bool is (x != 0), not a truncation (0.5 is True): sign(x)^2 is exactly 0 or 1
+      if tensor.is_complex:
+        tensor = self._unary(_lib.OP_ABS, tensor)
+      sgn = self._unary(_lib.OP_SIGN, tensor)
+      tensor = self._binary(_lib.OP_MUL, sgn, sgn)
     if tensor.is_complex and code not in _REAL_OF:
       raise TypeError(f"cannot cast {tensor.dtype} to a real dtype: the imaginary part would be discarded")
     out = DeviceTensor.empty(tensor.shape, code, alias)
@@ -705,7 +729,7 @@ class HipBackend(BackendBase):
     if ax1 == ax2:
       raise ValueError("axis1 and axis2 cannot be the same")
     rest = [i for i in range(nd) if i not in (ax1, ax2)]
-    t = self.transpose(tensor, rest + [ax1, ax2])
+    t = self.transpose(self._canonical(tensor), rest + [ax1, ax2])
     outer = _prod(t.shape[:-2])
     out = DeviceTensor.empty(t.shape[:-2], t.code, _sum_alias(t))
     _lib.check(self.lib.tnh_trace_last2(_vp(out), _vp(t), outer, t.shape[-2], t.shape[-1],
@@ -727,6 +751,7 @@ class HipBackend(BackendBase):
         tuple(tensor.shape[i] for i in kept)
     if not axes:
       return tensor.view(final_shape)
+    tensor = self._canonical(tensor)
     if tensor.code == _lib.I32:
       tensor = self.cast(tensor, _lib.I64)    # np.sum accumulates (and returns) int64 for narrower integers
     contiguous_run = axes == list(range(axes[0], axes[-1] + 1))
@@ -761,6 +786,8 @@ class HipBackend(BackendBase):
     self._check_num(tensor, "elementwise math")
     if tensor.code in _INT_CODES and op in (_lib.OP_SQRT, _lib.OP_EXP, _lib.OP_LOG, _lib.OP_SIN, _lib.OP_COS):
       tensor = self.cast(tensor, _lib.F64)    # NumPy evaluates these on integers in float64
+    if op in (_lib.OP_ABS, _lib.OP_SIGN):
+      tensor = self._canonical(tensor)
     to_real = tensor.is_complex and op in (_lib.OP_ABS, _lib.OP_REAL, _lib.OP_IMAG)
     out = DeviceTensor.empty(tensor.shape, _REAL_OF[tensor.code] if to_real else tensor.code, tensor.alias)
     _lib.check(self.lib.tnh_unary(op, _vp(out), _vp(tensor), tensor.size, tensor.code), "tnh_unary")

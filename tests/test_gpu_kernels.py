@@ -1079,3 +1079,41 @@ def test_gemm_view_tail_split_with_two_level_rows_and_runs_of_96(hip):
   np.testing.assert_allclose(g, ref, rtol=2.0**-8, atol=2.0**-9)
   np.testing.assert_allclose(u, ref, rtol=2.0**-8, atol=2.0**-9)
   np.testing.assert_allclose(g, u, rtol=2.0**-7, atol=1e-6)
+
+
+def test_narrow_integer_storage_is_normalised_where_arithmetic_is_not_modular(hip):
+  """The int64 storage of a narrow / unsigned / bool tensor may hold an unwrapped value after +, -, * (exact modulo
+  2^bits); conversions, sums, traces, division, abs and sign must see NumPy's value (tnh_wrap_int)."""
+  a = np.array([200, 100, 255, 7], dtype=np.uint8)
+  b = np.array([100, 200, 3, 250], dtype=np.uint8)
+  da, db = dev(hip, a), dev(hip, b)
+  s = hip.addition(da, db)                                   # stored 300, 300, 258, 257
+  with np.errstate(over="ignore"):
+    ref = a + b
+    np.testing.assert_array_equal(np.asarray(s), ref)
+    np.testing.assert_array_equal(np.asarray(hip.cast(s, np.float32)), ref.astype(np.float32))
+    np.testing.assert_array_equal(np.asarray(hip.cast(s, np.int64)), ref.astype(np.int64))
+    np.testing.assert_array_equal(np.asarray(hip.cast(s, np.int8)), ref.astype(np.int8))
+    assert int(np.asarray(hip.sum(s))) == int(np.sum(ref))
+    np.testing.assert_allclose(np.asarray(hip.divide(s, db)), ref / b)
+    np.testing.assert_allclose(np.asarray(hip.multiply(s, 0.5)), ref * 0.5)
+    np.testing.assert_allclose(np.asarray(hip.sqrt(s)), np.sqrt(ref.astype(np.float64)), rtol=1e-12)   # (NumPy itself answers in float16)
+    m = hip.multiply(dev(hip, np.full((3, 3), 16, np.uint8)), dev(hip, np.full((3, 3), 17, np.uint8)))   # 272 -> 16
+    assert int(np.asarray(hip.trace(m))) == 48
+    i8 = hip.multiply(dev(hip, np.array([100, -100, 3], np.int8)), dev(hip, np.array([2, 2, -50], np.int8)))
+    r8 = np.array([100, -100, 3], np.int8) * np.array([2, 2, -50], np.int8)        # -56, 56, 106
+    np.testing.assert_array_equal(np.asarray(hip.abs(i8)), np.abs(r8))
+    np.testing.assert_array_equal(np.asarray(hip.sign(i8)), np.sign(r8))
+    np.testing.assert_array_equal(np.asarray(hip.cast(i8, np.float64)), r8.astype(np.float64))
+  t = dev(hip, np.array([True, True, False]))
+  tt = hip.addition(t, t)                                    # bool + bool is a logical or
+  np.testing.assert_array_equal(np.asarray(tt), np.array([True, True, False]))
+  assert int(np.asarray(hip.sum(tt))) == 2
+  np.testing.assert_array_equal(np.asarray(hip.cast(dev(hip, np.array([0.5, 0.0, -2.0, 1.0])), np.bool_)),
+                                np.array([True, False, True, True]))
+  np.testing.assert_array_equal(np.asarray(hip.cast(dev(hip, np.array([2, 0, -1], np.int64)), np.bool_)),
+                                np.array([True, False, True]))
+  from tensornetwork_amd.device_tensor import DeviceTensor
+  u = DeviceTensor.from_numpy(np.array([1, 2, 300]), dtype=np.uint8)
+  assert u.dtype == np.uint8
+  np.testing.assert_array_equal(np.asarray(u), np.array([1, 2, 300]).astype(np.uint8))
