@@ -576,6 +576,8 @@ class HipBackend(BackendBase):
     viewed trivially.  Returns (tensor, used_free_a, used_free_b)."""
     if m < 256 or n < 256 or ((m + 255) // 256) * ((n + 255) // 256) < 192 or k % 64 or k < 128:
       return None
+    if a.ptr % 16 or b.ptr % 16:
+      return None     # (a sliced view at an odd offset: tnh_gemm_view would refuse it AFTER the permutes below were paid)
     nc = len(axes_a)
     orders = [sorted(range(nc), key=lambda i: axes_a[i]), sorted(range(nc), key=lambda i: axes_b[i])]
     if orders[0] == orders[1]:
