@@ -26,7 +26,7 @@ CASES = [
 be = ta.get_hip_backend()
 for shape, perm in CASES:
   x = be.device_random(shape, dtype=ta.bfloat16, seed=1, normal=True)
-  y = be.transpose(x, perm); be.synchronize()
+  y = be.transpose(x, perm); y = be.transpose(x, perm); be.synchronize()   # both output blocks of the loop come from the pool
   s = _lib.Event().record()
   for _ in range(5): y = be.transpose(x, perm)
   e = _lib.Event().record(); e.synchronize()
