@@ -101,12 +101,56 @@ __device__ __forceinline__ void store_wave_tile(const f32x4 (&acc)[FM][FN], cons
                                                 int64_t m0, int64_t n0, int BM, int BN, int wave_m,
                                                 int wave_n, int lane) {
   const bool full = (m0 + BM <= p.M) && (n0 + BN <= p.N);
-  if constexpr (!OUT_F32 && FN % 2 == 0) {
-    // Half output, full tile, 16-B aligned rows: 16-B stores.  A lane holds 4 consecutive n (8 B) of one m per
-    // fragment and the lane 16 further on the next 4; v_permlane16_swap on the fragment pair (j, j + 1) hands
-    // lane rows 0 / 2 the columns 0-7 / 8-15 of fragment j and rows 1 / 3 those of fragment j + 1.  Per store
-    // instruction 16 rows x 64 B instead of 16 rows x 32 B, and half as many instructions: the epilogue of a
-    // 256 x 256 tile was 7-9 us of the CU's time with the 8-B stores (32768^2 x 1024: 1.05 -> see DESIGN K2).
+  if constexpr (!OUT_F32 && FN % 4 == 0) {
+    // Half output, full tile, 16-B aligned rows: 16-B stores that cover whole 128-B lines.  A lane holds 4 consecutive
+    // n (8 B) of one m per fragment and the lane 16 further on the next 4.  Step 1, v_permlane16_swap on the fragment
+    // pairs (j, j + 1): lane rows 0 / 2 get columns 0-7 / 8-15 of fragment j, rows 1 / 3 those of fragment j + 1 --
+    // 16 B per lane, 64 B per m.  Step 2, a rotation by 8 inside the 16-lane rows between the pairs (j, j + 1) and
+    // (j + 2, j + 3): lanes 0-7 keep the first 32 columns, lanes 8-15 the second 32, of m = lane & 7 (first store)
+    // and 8 + (lane & 7) (second store) -- 8 rows x 128 B per store instruction.  The 8-byte stores this replaces
+    // (16 rows x 32 B each) kept the CU's address path busy for 7.3 us per 256 x 256 tile, the 64-B-per-row form for
+    // 3.9 us (profiles/r03_gemm_epilogue.md).
+    if (p.c_vec && full && (p.ldc & 7) == 0 && (((uintptr_t)Cb) & 15) == 0) {
+      typedef unsigned v4u __attribute__((ext_vector_type(4)));
+      const int r = lane >> 4, c = lane & 15;
+      const bool lo = c < 8;
+      auto ror8 = [](unsigned x) -> unsigned { return (unsigned)__builtin_amdgcn_mov_dpp((int)x, 0x128, 0xf, 0xf, true); };
+#pragma unroll
+      for (int i = 0; i < FM; ++i) {
+#pragma unroll
+        for (int j = 0; j < FN; j += 4) {
+          v4u v[2];
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const f32x4 va = acc[i][j + 2 * h], vb = acc[i][j + 2 * h + 1];
+            const auto sx = __builtin_amdgcn_permlane16_swap(pack2<IS_BF16>(va[0], va[1]), pack2<IS_BF16>(vb[0], vb[1]), false, false);
+            const auto sy = __builtin_amdgcn_permlane16_swap(pack2<IS_BF16>(va[2], va[3]), pack2<IS_BF16>(vb[2], vb[3]), false, false);
+            v[h] = v4u{sx[0], sy[0], sx[1], sy[1]};
+          }
+          v4u w0, w1;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const unsigned a8 = ror8(v[0][e]), b8 = ror8(v[1][e]);
+            w0[e] = lo ? v[0][e] : b8;
+            w1[e] = lo ? a8 : v[1][e];
+          }
+          const int64_t n = n0 + wave_n + j * 16 + 32 * (c >> 3) + 16 * (r & 1) + 8 * (r >> 1);
+          const int64_t m = m0 + wave_m + i * 16 + (c & 7);
+          char* q0 = Cb + (m * p.ldc + n) * 2;
+          char* q1 = q0 + 8 * p.ldc * 2;
+          if (p.c_vec == 3) {      // large C: streaming stores
+            __builtin_nontemporal_store(w0, (v4u*)q0);
+            __builtin_nontemporal_store(w1, (v4u*)q1);
+          } else {
+            *(v4u*)q0 = w0;
+            *(v4u*)q1 = w1;
+          }
+        }
+      }
+      return;
+    }
+  } else if constexpr (!OUT_F32 && FN % 2 == 0) {
+    // two fragments per wave row only: step 1 alone (16 rows x 64 B per store)
     if (p.c_vec && full && (p.ldc & 7) == 0 && (((uintptr_t)Cb) & 15) == 0) {
       const int r = lane >> 4;
 #pragma unroll
@@ -118,10 +162,7 @@ __device__ __forceinline__ void store_wave_tile(const f32x4 (&acc)[FM][FN], cons
           const auto sx = __builtin_amdgcn_permlane16_swap(pack2<IS_BF16>(va[0], va[1]), pack2<IS_BF16>(vb[0], vb[1]), false, false);
           const auto sy = __builtin_amdgcn_permlane16_swap(pack2<IS_BF16>(va[2], va[3]), pack2<IS_BF16>(vb[2], vb[3]), false, false);
           const int64_t n = n0 + wave_n + (j + (r & 1)) * 16 + (r >> 1) * 8;
-          typedef unsigned v4u __attribute__((ext_vector_type(4)));
-          const v4u o = {sx[0], sy[0], sx[1], sy[1]};
-          if (p.c_vec == 3) __builtin_nontemporal_store(o, (v4u*)(Cb + (m * p.ldc + n) * 2));   // large C: streaming
-          else *(v4u*)(Cb + (m * p.ldc + n) * 2) = o;
+          *(uint4*)(Cb + (m * p.ldc + n) * 2) = make_uint4(sx[0], sy[0], sx[1], sy[1]);
         }
       }
       return;
