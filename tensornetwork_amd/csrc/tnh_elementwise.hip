@@ -424,9 +424,9 @@ __global__ __launch_bounds__(256) void cast_kernel(typename Tr<DST>::S* __restri
   }
 }
 
-static inline unsigned grid_for(int64_t n) {
+static inline unsigned grid_for(int64_t n, int64_t bytes_per_item = 4) {
   int64_t blocks = (n + 255) / 256;
-  const int64_t cap = (int64_t)num_cus() * 16;
+  const int64_t cap = (int64_t)num_cus() * stream_wgs_per_cu(n * bytes_per_item);
   if (blocks > cap) blocks = cap;
   if (blocks < 1) blocks = 1;
   return (unsigned)blocks;

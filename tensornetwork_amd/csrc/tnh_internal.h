@@ -15,6 +15,7 @@ void set_error(const char* fmt, ...);
 hipStream_t stream();       // process stream (nullptr before tnh_init)
 bool initialised();
 int num_cus();
+int stream_wgs_per_cu(int64_t bytes);   // grid-stride streaming kernels: workgroups per CU for a buffer of this size
 
 #define TNH_HIP(call)                                                        \
   do {                                                                       \

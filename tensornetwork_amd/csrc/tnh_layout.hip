@@ -626,7 +626,7 @@ template <typename T, bool SCATTER>
 static int launch_gather(void* dst, const void* src, const GatherParams& p) {
   if (p.total == 0) return TNH_OK;
   int64_t blocks = (p.total + 255) / 256;
-  const int64_t cap = (int64_t)num_cus() * 16;
+  const int64_t cap = (int64_t)num_cus() * stream_wgs_per_cu(p.total * (int64_t)sizeof(T));
   if (blocks > cap) blocks = cap;
   // 32-bit index math when every offset fits (the common case).
   bool small = p.total < (int64_t(1) << 31);
@@ -865,7 +865,7 @@ int tnh_permute(void* dst, const void* src, int rank, const int64_t* shape, cons
           q.rank = n;
           q.total = (uint32_t)p.total;
           int64_t blocks = (p.total + 255) / 256;
-          const int64_t cap = (int64_t)num_cus() * 16;
+          const int64_t cap = (int64_t)num_cus() * stream_wgs_per_cu(p.total * 16);
           if (blocks > cap) blocks = cap;
           hipLaunchKernelGGL((gather2_kernel<uint4>), dim3((unsigned)blocks), dim3(256), 0, stream(), (uint4*)dst,
                              (const uint4*)src, q);
@@ -937,7 +937,11 @@ int tnh_permute(void* dst, const void* src, int rank, const int64_t* shape, cons
           while (order > 1 && f.tiles_b % order != 0) order >>= 1;
           f.order = order;
         }
-        const int64_t grid = nblocks < (int64_t(1) << 22) ? nblocks : (int64_t(1) << 22);
+        int64_t grid = nblocks < (int64_t(1) << 22) ? nblocks : (int64_t(1) << 22);
+        if (const char* eg = getenv("TNH_PERMUTE_TILED_WGS")) {      // A/B: persistent grid of this many workgroups per CU
+          const int64_t cap = (int64_t)num_cus() * atoi(eg);
+          if (cap > 0 && grid > cap) grid = cap;
+        }
         hipLaunchKernelGGL(permute_tiled16_kernel<1>, dim3((unsigned)grid), dim3(256), 0, stream(),
                            (uint16_t*)dst, (const uint16_t*)src, f);
         TNH_LAUNCH_CHECK();

@@ -25,6 +25,15 @@ void set_error(const char* fmt, ...) {
 hipStream_t stream() { return g_stream; }
 bool initialised() { return g_device >= 0; }
 int num_cus() { return g_cus; }
+// Workgroups per CU of the grid-stride streaming kernels (permutes, elementwise, reductions) on buffers beyond the
+// 256 MB Infinity Cache.  Measured (tools/bw_probe, 1 GiB): a plain read reaches 6.37 TB/s with 4 workgroups of
+// 256 threads per CU and 5.4-5.6 with 8-32; a plain copy 5.55 TB/s against 4.6-4.8 -- the narrower the front that
+// sweeps through memory, the fewer DRAM pages are open at a time.  TNH_STREAM_WGS overrides (A/B).
+int stream_wgs_per_cu(int64_t bytes) {
+  static const int env = []() { const char* e = getenv("TNH_STREAM_WGS"); return e ? atoi(e) : 0; }();
+  if (env > 0) return env;
+  return bytes >= (int64_t(256) << 20) ? 4 : 16;
+}
 
 // ---------------------------------------------------------------- block pool
 // Blocks are rounded to 512 B (small) or 2 MiB (>= 1 MiB) and recycled through
