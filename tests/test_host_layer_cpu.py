@@ -1,6 +1,8 @@
 """The host layers (ncon / network / contractors) driven by the CPU oracle backend
 must reproduce the reference's outputs on the golden cases.  The very same
 drivers (tests/cases.py) run on the hip backend in the GPU suite."""
+import os
+
 import numpy as np
 import pytest
 
@@ -583,3 +585,24 @@ def test_gc_policy_opt_out_leaves_the_collector_alone(monkeypatch):
   finally:
     dt._GC_POLICY.update(saved[0])
     dt._GC_FROZEN, dt._gc_cost_seconds = saved[1], saved[2]
+
+
+def test_mera_layer_lowering_keeps_the_big_intermediate_in_place():
+  """Host dry run of the binary-MERA layer at chi = 32 (tools/mera_trace.py: the real lowering code on shape-only
+  tensors): every contraction of both placements is ONE in-place view GEMM, the 68 GB intermediate is never permuted
+  -- the planner's layout hints win over an available view when the operand is small against the result -- and the
+  K1 passes that remain move 4.3 GB tensors only."""
+  import re
+  import subprocess
+  import sys
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  out = subprocess.run([sys.executable, os.path.join(root, "tools", "mera_trace.py"), "--chi", "32"], capture_output=True,
+                       text=True, timeout=300, check=True).stdout
+  assert "trace stopped" not in out, out
+  gemms = re.findall(r"view GEMM M=(\d+) N=(\d+) K=(\d+)", out)
+  assert len(gemms) == 12, out                                   # six contractions per placement, none on the fallback
+  moved = [float(x) for x in re.findall(r"permute .* ([0-9.]+) GB moved", out)]
+  assert moved and max(moved) < 10.0 and sum(moved) < 30.0, moved
+  # the two large products of a placement: 2^20 x 2^15 x 2^10 and 2^10 x 2^15 x 2^20
+  big = sorted((int(m), int(n), int(k)) for m, n, k in gemms if int(m) * int(n) * int(k) >= 2**45)
+  assert big == [(1024, 32768, 1048576)] * 2 + [(1048576, 32768, 1024)] * 2, big
