@@ -1,0 +1,169 @@
+"""HipBackend's HOST logic with real numbers on the CPU: the contraction lowering (transpose + reshape + GEMM,
+abstract_backend.py:27-38; spec backends/tensorflow/tensordot2.py:22-250), the in-place view lowering with the
+planner's layout hints, and the layout planning of network.contract_between / contractors.contract_path -- driven
+through tests/emu_tnh.py, a NumPy emulation of the C-ABI entry points those paths call (test infrastructure; the
+kernels themselves are checked by the `-m gpu` suite against the same references)."""
+import itertools
+
+import numpy as np
+import pytest
+
+import tensornetwork_amd as ta
+from tensornetwork_amd import contractors, workloads
+from oracle import numpy_oracle as orc
+from oracle.numpy_oracle import OracleBackend
+
+from emu_tnh import emulated_backend
+
+
+def _dev(be, x, bf16=False):
+  return be.to_bfloat16(x) if bf16 else be.convert_to_tensor(x)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64, "bf16", np.int64])
+def test_tensordot_lowering_random_axes(dtype):
+  """tensordot2_test.py:163-207 restated for the lowering: random ranks, dims, axes subsets and scalar `axes` --
+  every layout branch (contracted axes leading / trailing / in the middle, both K orders) against np.tensordot."""
+  rng = np.random.default_rng(11)
+  bf16 = dtype == "bf16"
+  with emulated_backend() as be:
+    for trial in range(80):
+      ra, rb = rng.integers(1, 5), rng.integers(1, 5)
+      nc = int(rng.integers(0, min(ra, rb) + 1))
+      dims_c = [int(rng.integers(1, 7)) for _ in range(nc)]
+      axes_a = list(rng.permutation(ra)[:nc])
+      axes_b = list(rng.permutation(rb)[:nc])
+      sa = [int(rng.integers(1, 7)) for _ in range(ra)]
+      sb = [int(rng.integers(1, 7)) for _ in range(rb)]
+      for i, (x, y) in enumerate(zip(axes_a, axes_b)):
+        sa[x] = sb[y] = dims_c[i]
+      if dtype is np.int64:
+        a = rng.integers(-9, 9, size=sa).astype(np.int64)
+        b = rng.integers(-9, 9, size=sb).astype(np.int64)
+      else:
+        a = rng.standard_normal(sa).astype(np.float32 if bf16 else dtype)
+        b = rng.standard_normal(sb).astype(np.float32 if bf16 else dtype)
+        if bf16:
+          a, b = orc.round_bf16(a), orc.round_bf16(b)
+      axes = [[int(x) for x in axes_a], [int(y) for y in axes_b]]
+      if nc and trial % 7 == 0 and axes_a == list(range(ra - nc, ra)) and axes_b == list(range(nc)):
+        axes = nc                                     # the scalar form
+      got = np.asarray(be.tensordot(_dev(be, a, bf16), _dev(be, b, bf16), axes))
+      ref = np.tensordot(a.astype(np.float64), b.astype(np.float64), axes)
+      assert got.shape == ref.shape, (sa, sb, axes)
+      if dtype is np.int64:
+        np.testing.assert_array_equal(got, ref.astype(np.int64))
+      else:
+        tol = 2.0**-7 if bf16 else (1e-5 if dtype is np.float32 else 1e-12)
+        np.testing.assert_allclose(got, ref, rtol=tol, atol=tol * 8 * max(1, int(np.prod(dims_c))) ** 0.5)
+
+
+_VIEW_CASES = [
+    # (shape_a, shape_b, axes, kernel, K1 launches): the cases of tests/test_gpu_kernels.py::test_gemm_view_*
+    ((14, 256, 2, 64), (2, 64, 14, 256), ([2, 3], [0, 1]), "emu_view_nn", 0),      # config-2 L0: b is [K][N]
+    ((14, 2, 256, 64), (64, 14, 2, 256), ([1, 3], [2, 0]), "emu_view_nn", 0),      # config-2 L1: two-level rows and k
+    ((2, 64, 14, 256), (2, 64, 14, 256), ([0, 1], [0, 1]), "emu_view_tt", 0),      # both k-major
+    ((2, 64, 14, 256), (14, 256, 2, 64), ([0, 1], [2, 3]), "emu_view_tn", 0),
+    ((3584, 192), (3584, 192), ([1], [1]), "emu_view_nt", 0),
+    ((14, 2, 256, 96), (96, 14, 2, 256), ([1, 3], [2, 0]), "emu_view_nn", 0),      # runs of 96: half K-tiles
+    ((64, 32, 56, 32), (32, 32, 60, 64), ([1, 3], [0, 1]), "emu_view_nn", 0),      # runs of 32
+    ((14, 4, 256, 48), (48, 14, 4, 256), ([1, 3], [2, 0]), "emu_view_nt", 2),      # runs of 48: both permuted
+    ((14, 2, 256, 64), (68, 2, 64, 14, 5), ([1, 3], [1, 2]), "emu_view_n", 1),     # one side readable in place
+]
+
+
+@pytest.mark.parametrize("sa,sb,axes,kernel,permutes", _VIEW_CASES)
+def test_in_place_view_lowering_matches_numpy(sa, sb, axes, kernel, permutes):
+  """bf16 products with >= 192 tiles of 256 x 256: which operands are read in place, which are permuted, and the
+  values -- the view the host hands to tnh_gemm_view must address exactly the matrix transpose + reshape would have
+  built (include/tnh.h: tnh_operand_view)."""
+  rng = np.random.default_rng(sum(sa) + sum(sb))
+  a = orc.round_bf16(rng.standard_normal(sa).astype(np.float32))
+  b = orc.round_bf16(rng.standard_normal(sb).astype(np.float32))
+  with emulated_backend() as be:
+    da, db = be.to_bfloat16(a), be.to_bfloat16(b)
+    before = be.permute_launches
+    got = np.asarray(be.tensordot(da, db, axes))
+    assert be.lib.tnh_gemm_last_kernel().decode().startswith(kernel)
+    assert be.permute_launches - before == permutes
+    be.absorb_transposes = False            # the classic lowering: permute + NT GEMM
+    ref_classic = np.asarray(be.tensordot(da, db, axes))
+  ref = np.tensordot(a.astype(np.float64), b.astype(np.float64), axes)
+  k = int(np.prod([sa[i] for i in axes[0]]))
+  np.testing.assert_allclose(got, ref, rtol=2.0**-7, atol=2.0**-8 * k**0.5)
+  np.testing.assert_allclose(ref_classic, ref, rtol=2.0**-7, atol=2.0**-8 * k**0.5)
+
+
+def test_planner_hints_decide_the_free_axis_order_and_small_operands_follow_them():
+  """tensordot_planned: an operand that is permuted anyway takes the planner's free-axis order; an operand that could
+  be read in place still follows the hint when it is small against the result; a large one keeps
+  its natural order.  The returned orders describe the result's axes exactly."""
+  rng = np.random.default_rng(5)
+  a = orc.round_bf16(rng.standard_normal((16, 64, 16, 256)).astype(np.float32))     # free (0, 2), contracted (1, 3)
+  b = orc.round_bf16(rng.standard_normal((64, 256, 4096)).astype(np.float32))       # contracted (0, 1), free (2,)
+  with emulated_backend() as be:
+    da, db = be.to_bfloat16(a), be.to_bfloat16(b)
+    out, used_a, used_b = be.tensordot_planned(da, db, [[1, 3], [0, 1]], [2, 0], [2])
+    got = np.asarray(out)
+    # a (8 MB) is small against the 2 GB-equivalent ... here: 256 x 4096 result of 2 MB -> a is NOT small: natural order
+    assert list(used_b) == [2]
+    ref = np.tensordot(a.astype(np.float64), b.astype(np.float64), [[1, 3], [0, 1]])          # axes (a0, a2, b2)
+    perm = [[0, 2].index(i) for i in used_a] + [2]
+    np.testing.assert_allclose(got, np.transpose(ref, perm), rtol=2.0**-7, atol=2.0**-8 * 128)
+    # a small operand against a large result: (64, 8, 64) . (64, 64, 8192): m = 8 x ... below the view kernel's range,
+    # so use a shape inside it: a = (512, 64, 4), free (0, 2) hinted as (2, 0)
+    a2 = orc.round_bf16(rng.standard_normal((512, 64, 4)).astype(np.float32))
+    b2 = orc.round_bf16(rng.standard_normal((64, 32768)).astype(np.float32))
+    d2a, d2b = be.to_bfloat16(a2), be.to_bfloat16(b2)
+    before = be.permute_launches
+    out2, used2a, used2b = be.tensordot_planned(d2a, d2b, [[1], [0]], [2, 0], [1])
+    assert [int(i) for i in used2a] == [2, 0] and be.permute_launches - before >= 1      # 8 x a.nbytes <= result bytes
+    ref2 = np.transpose(np.tensordot(a2.astype(np.float64), b2.astype(np.float64), [[1], [0]]), (1, 0, 2))
+    np.testing.assert_allclose(np.asarray(out2), ref2, rtol=2.0**-7, atol=2.0**-8 * 8)
+    # the same operand without a hint is read in place: no K1 launch for it
+    before = be.permute_launches
+    _, used3a, _ = be.tensordot_planned(d2a, d2b, [[1], [0]], None, None)
+    assert [int(i) for i in used3a] == [0, 2]
+
+
+@pytest.mark.parametrize("contractor", [contractors.greedy, contractors.auto])
+def test_planned_contraction_paths_reproduce_the_oracle_backend(contractor):
+  """contractors.contract_path turns on layout planning for a backend that offers tensordot_planned (edge -> step
+  times, operand order swaps, latest-first free axes: network.contract_between): the result of a closed network must
+  not depend on it.  20-node 3-regular network and the 16-site MPS overlap against the oracle backend."""
+  ob = OracleBackend()
+  ref = float(np.asarray(contractor(workloads.random_regular_network(ob, n=20, D=3, seed=4, dtype=np.float64)).tensor))
+  with emulated_backend() as be:
+    got = float(np.asarray(contractor(workloads.random_regular_network(be, n=20, D=3, seed=4, dtype=np.float64)).tensor))
+  assert abs(got - ref) <= 1e-10 * max(1.0, abs(ref))
+  kets = workloads.mps_tensors(8, 2, 6, seed=3, dtype=np.float64)
+  ref = float(np.asarray(contractor(workloads.mps_overlap_network(ob, kets)).tensor))
+  with emulated_backend() as be:
+    got = float(np.asarray(contractor(workloads.mps_overlap_network(be, kets)).tensor))
+  assert abs(got - ref) <= 1e-10 * max(1.0, abs(ref))
+
+
+def test_mera_layer_energy_through_the_planned_lowering():
+  """Binary-MERA layer energy (simple_mera.py:53-112) at chi = 4, both placements, contractors.branch -- the path the
+  chi = 32 / 64 bench legs take -- on the emulated backend against the oracle backend."""
+  ham, rho, iso, dis = workloads.mera_random_tensors(4, seed=9, dtype=np.float64)
+  branch = lambda nodes: contractors.branch(nodes, nbranch=2)
+  ob = OracleBackend()
+  ref = float(np.asarray(workloads.mera_energy(ob, ham, rho, iso, dis, branch)))
+  with emulated_backend() as be:
+    got = float(np.asarray(workloads.mera_energy(be, *(be.convert_to_tensor(t) for t in (ham, rho, iso, dis)), branch)))
+  assert abs(got - ref) <= 1e-10 * max(1.0, abs(ref))
+
+
+def test_every_free_axis_order_a_hint_can_ask_for():
+  """All 6 orders of three free axes on each side: the result carries them in the order the call reports."""
+  rng = np.random.default_rng(8)
+  a = rng.standard_normal((3, 4, 5, 6)).astype(np.float64)       # contracted axis 2
+  b = rng.standard_normal((5, 2, 3, 4)).astype(np.float64)       # contracted axis 0
+  ref = np.tensordot(a, b, [[2], [0]])                            # (a0, a1, a3, b1, b2, b3)
+  with emulated_backend() as be:
+    da, db = be.convert_to_tensor(a), be.convert_to_tensor(b)
+    for ha, hb in itertools.product(itertools.permutations([0, 1, 3]), itertools.permutations([1, 2, 3])):
+      out, ua, ub = be.tensordot_planned(da, db, [[2], [0]], list(ha), list(hb))
+      perm = [[0, 1, 3].index(i) for i in ua] + [3 + [1, 2, 3].index(i) for i in ub]
+      np.testing.assert_allclose(np.asarray(out), np.transpose(ref, perm), rtol=1e-12, atol=1e-12)
