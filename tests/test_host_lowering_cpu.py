@@ -60,15 +60,15 @@ def test_tensordot_lowering_random_axes(dtype):
 
 _VIEW_CASES = [
     # (shape_a, shape_b, axes, kernel, K1 launches): the cases of tests/test_gpu_kernels.py::test_gemm_view_*
-    ((14, 256, 2, 64), (2, 64, 14, 256), ([2, 3], [0, 1]), "emu_view_nn", 0),      # config-2 L0: b is [K][N]
-    ((14, 2, 256, 64), (64, 14, 2, 256), ([1, 3], [2, 0]), "emu_view_nn", 0),      # config-2 L1: two-level rows and k
-    ((2, 64, 14, 256), (2, 64, 14, 256), ([0, 1], [0, 1]), "emu_view_tt", 0),      # both k-major
-    ((2, 64, 14, 256), (14, 256, 2, 64), ([0, 1], [2, 3]), "emu_view_tn", 0),
-    ((3584, 192), (3584, 192), ([1], [1]), "emu_view_nt", 0),
-    ((14, 2, 256, 96), (96, 14, 2, 256), ([1, 3], [2, 0]), "emu_view_nn", 0),      # runs of 96: half K-tiles
-    ((64, 32, 56, 32), (32, 32, 60, 64), ([1, 3], [0, 1]), "emu_view_nn", 0),      # runs of 32
-    ((14, 4, 256, 48), (48, 14, 4, 256), ([1, 3], [2, 0]), "emu_view_nt", 2),      # runs of 48: both permuted
-    ((14, 2, 256, 64), (68, 2, 64, 14, 5), ([1, 3], [1, 2]), "emu_view_n", 1),     # one side readable in place
+    ((14, 256, 2, 64), (2, 64, 14, 256), ([2, 3], [0, 1]), "bf16_view_nn", 0),      # config-2 L0: b is [K][N]
+    ((14, 2, 256, 64), (64, 14, 2, 256), ([1, 3], [2, 0]), "bf16_view_nn", 0),      # config-2 L1: two-level rows and k
+    ((2, 64, 14, 256), (2, 64, 14, 256), ([0, 1], [0, 1]), "bf16_view_tt", 0),      # both k-major
+    ((2, 64, 14, 256), (14, 256, 2, 64), ([0, 1], [2, 3]), "bf16_view_tn", 0),
+    ((3584, 192), (3584, 192), ([1], [1]), "bf16_view_nt", 0),
+    ((14, 2, 256, 96), (96, 14, 2, 256), ([1, 3], [2, 0]), "bf16_view_nn", 0),      # runs of 96: half K-tiles
+    ((64, 32, 56, 32), (32, 32, 60, 64), ([1, 3], [0, 1]), "bf16_view_nn", 0),      # runs of 32
+    ((14, 4, 256, 48), (48, 14, 4, 256), ([1, 3], [2, 0]), "bf16_view_nt", 2),      # runs of 48: both permuted
+    ((14, 2, 256, 64), (68, 2, 64, 14, 5), ([1, 3], [1, 2]), "bf16_view_n", 1),     # one side readable in place
 ]
 
 
@@ -167,3 +167,139 @@ def test_every_free_axis_order_a_hint_can_ask_for():
       out, ua, ub = be.tensordot_planned(da, db, [[2], [0]], list(ha), list(hb))
       perm = [[0, 1, 3].index(i) for i in ua] + [3 + [1, 2, 3].index(i) for i in ub]
       np.testing.assert_allclose(np.asarray(out), np.transpose(ref, perm), rtol=1e-12, atol=1e-12)
+
+
+# ---- the golden workload drivers of the GPU suite (tests/cases.py; outputs generated by the reference itself,
+# tests/golden/make_golden.py) on the emulated backend: every HipBackend method they reach runs its host logic here
+import cases as C  # noqa: E402  pylint: disable=wrong-import-position
+
+
+def test_golden_ncon_and_contract_between_on_the_emulated_backend(golden):
+  with emulated_backend() as be:
+    for case in golden.cases["ncon"]:
+      C.assert_close(C.run_ncon(be, golden, case), golden[case["out"]])
+    for case in golden.cases["contract_between"]:
+      C.assert_close(C.run_contract_between(be, golden, case), golden[case["out"]])
+
+
+def test_golden_contractors_and_misc_ops_on_the_emulated_backend(golden):
+  with emulated_backend() as be:
+    for case in golden.cases["contractors"]:
+      C.assert_close(C.run_contractor(be, golden, case), golden[case["out"]])
+    for case in golden.cases["misc"]:
+      for name, val in C.run_misc(be, golden, case).items():
+        C.assert_close(val, golden[case[name]])
+      x, v = be.convert_to_tensor(golden[case["x"]]), be.convert_to_tensor(golden[case["v"]])
+      C.assert_close(be.norm(x), golden[case["norm"]])
+      C.assert_close(be.sqrt(be.abs(x)), golden[case["sqrtabs"]])
+      C.assert_close(be.subtraction(x, v), golden[case["sub"]])
+
+
+def test_graph_surgery_and_tensor_api_on_the_emulated_backend():
+  with emulated_backend() as be:
+    C.check_graph_surgery(be, 1e-5)
+    C.check_tensor_api(be, 1e-5)
+
+
+def test_golden_split_node_and_linalg_drivers_on_the_emulated_backend(golden, golden_linalg):
+  """split_node in every truncation mode (decompositions.py:38-57 is applied on the HOST), QR / RQ with the phase
+  fix of decompositions.py:91-94, eigh / inv / expm built on the SVD and GEMM entry points -- LAPACK stands in for the
+  kernels behind the emulated C ABI, the host code is the product's."""
+  with emulated_backend() as be:
+    for case in golden.cases["split_node"]:
+      left, right, trun, recon = C.run_split(be, golden, case)
+      assert list(left.shape) == case["left_shape"] and list(right.shape) == case["right_shape"], case["x"]
+      x = golden[case["x"]]
+      scale = float(np.max(np.abs(x))) * np.sqrt(x.size) + 1e-30
+      C.assert_close(trun, golden[case["trun"]], scale=scale)
+      C.assert_close(recon, golden[case["recon"]], scale=scale)
+    for case in golden_linalg.cases["qr"]:
+      x = golden_linalg[case["x"]]
+      m = np.asarray(x).reshape(int(np.prod(x.shape[:case["pivot"]])), -1)
+      full_rank = np.linalg.matrix_rank(m) == min(m.shape) or not np.any(m)
+      C.check_qr_case(be, golden_linalg, case, tight=bool(full_rank))
+    for case in golden_linalg.cases["split_qr"]:
+      C.check_split_qr_case(be, golden_linalg, case)
+    for case in golden_linalg.cases["linalg"]:
+      C.check_linalg_case(be, golden_linalg, case)
+
+
+@pytest.mark.parametrize("tag", C.MPS_GOLDEN_TAGS)
+def test_mps_measurements_on_the_emulated_backend(tag):
+  """FiniteMPS measurements (base_mps.py:322-479) against the reference's recorded numbers, host code on the
+  emulated C ABI."""
+  with emulated_backend() as be:
+    C.check_mps_golden_case(be, C.load_mps_golden(), tag, 1e-10)
+
+
+def test_complex_golden_drivers_on_the_emulated_backend(golden_complex):
+  """complex64 / complex128 svd (all truncation modes), eigh / inv / expm vs the reference's outputs."""
+  with emulated_backend() as be:
+    for case in golden_complex.cases["svd"]:
+      C.check_svd_case(be, golden_complex, case)
+    for case in golden_complex.cases["linalg"]:
+      C.check_linalg_case(be, golden_complex, case)
+
+
+@pytest.mark.parametrize("tag", C.INFINITE_MPS_GOLDEN_TAGS)
+def test_infinite_mps_on_the_emulated_backend(tag):
+  """InfiniteMPS.canonicalize: Krylov-Schur eigs on 'device' vectors, eigh, masks + index_update, truncated svd, inv."""
+  with emulated_backend() as be:
+    C.check_infinite_mps_golden_case(be, C.load_mps_golden(), tag, 1e-11)
+
+
+# ---- selected tests of the `-m gpu` suite, unchanged, with the emulated backend in place of the `hip` fixture: the
+# ones whose subject is HOST behaviour (error paths, Krylov recurrences, DMRG sweeps, dtype aliases, the Tensor API)
+def _expand(fn):
+  """All parameter sets of a test function's stacked @pytest.mark.parametrize marks."""
+  sets = [{}]
+  for mark in getattr(fn, "pytestmark", []):
+    if mark.name != "parametrize":
+      continue
+    names, values = mark.args[0], mark.args[1]
+    names = [n.strip() for n in names.split(",")] if isinstance(names, str) else list(names)
+    new = []
+    for base in sets:
+      for v in values:
+        v = v.values if hasattr(v, "values") else v
+        vs = (v,) if len(names) == 1 and not (isinstance(v, tuple) and len(names) > 1) else tuple(v)
+        new.append({**base, **dict(zip(names, vs))})
+    sets = new
+  return sets
+
+
+def _gpu_suite_selection():
+  import test_gpu_kernels as TK  # pylint: disable=import-outside-toplevel
+  import test_gpu_linalg as TL   # pylint: disable=import-outside-toplevel
+  import test_gpu_mps as TM      # pylint: disable=import-outside-toplevel
+  import test_gpu_workloads as TW  # pylint: disable=import-outside-toplevel
+  return [TL.test_linalg_errors, TL.test_eigsh_lanczos_device_vectors, TL.test_eigsh_and_gmres_device_vectors,
+          TL.test_eigs_device_vectors, TL.test_eigsh_complex_hermitian_and_pivot, TL.test_compare_and_index_update,
+          TL.test_tensor_and_functional_api_on_device, TL.test_complex_split_node_golden, TL.test_complex_qr_rq_golden,
+          TM.test_mps_canonical_form_on_device, TM.test_dmrg_ground_energy_vs_exact_f64, TM.test_dmrg_f32_chain_of_12,
+          TM.test_free_fermion_2d_one_site_dmrg_on_device,
+          TW.test_config1_readme_ncon, TW.test_split_node_config3_small, TW.test_greedy_mps_chain_and_regular_graph,
+          TW.test_json_network_from_reference_into_hbm,
+          TK.test_gemm_view_absorbs_transposes_bit_exact, TK.test_gemm_view_falls_back_when_it_cannot_read_in_place,
+          TK.test_tensordot_random_axes_property, TK.test_misc_golden,
+          TK.test_narrow_and_unsigned_dtypes_behave_like_numpy,
+          TK.test_narrow_integer_storage_is_normalised_where_arithmetic_is_not_modular]
+
+
+def _selection_ids():
+  try:
+    return [f.__module__.replace("test_gpu_", "") + "::" + f.__name__ for f in _gpu_suite_selection()]
+  except Exception:  # pylint: disable=broad-except
+    return []
+
+
+@pytest.mark.parametrize("index", range(len(_selection_ids())), ids=_selection_ids())
+def test_gpu_suite_host_level_tests_on_the_emulated_backend(index, golden, golden_linalg, golden_complex):
+  import inspect
+  fn = _gpu_suite_selection()[index]
+  fixtures = {"golden": golden, "golden_linalg": golden_linalg, "golden_complex": golden_complex}
+  wanted = inspect.signature(fn).parameters
+  for params in _expand(fn):
+    with emulated_backend() as be:
+      kwargs = {"hip": be, **{k: v for k, v in fixtures.items() if k in wanted}, **params}
+      fn(**{k: v for k, v in kwargs.items() if k in wanted})
