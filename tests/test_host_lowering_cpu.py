@@ -303,3 +303,18 @@ def test_gpu_suite_host_level_tests_on_the_emulated_backend(index, golden, golde
     with emulated_backend() as be:
       kwargs = {"hip": be, **{k: v for k, v in fixtures.items() if k in wanted}, **params}
       fn(**{k: v for k, v in kwargs.items() if k in wanted})
+
+
+def test_bench_svd_leg_runs_on_the_emulated_backend():
+  """bench.py's split_node timing leg (svd_case / check_svd_case) end to end on a small matrix: the record it writes
+  into the JSON line and the LAPACK check it applies."""
+  import bench  # pylint: disable=import-outside-toplevel
+  rng = np.random.default_rng(2)
+  n, k = 64, 8
+  mat_host = rng.standard_normal((n, n)).astype(np.float32)
+  s_ref = np.linalg.svd(mat_host.astype(np.float64), compute_uv=False)
+  with emulated_backend() as be:
+    rec, outputs = bench.svd_case(ta, be, be.convert_to_tensor(mat_host), n, k, "natural")
+    check = bench.check_svd_case(mat_host.astype(np.float64), s_ref, n, k, outputs)
+  assert rec["n"] == n and rec["k"] == k and len(rec["samples_ms"]) == 3 and rec["seconds"] * 1e3 == min(rec["samples_ms"])
+  assert check["ok"], check
