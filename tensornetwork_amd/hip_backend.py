@@ -732,6 +732,8 @@ class HipBackend(BackendBase):
       raise ValueError("axis1 and axis2 cannot be the same")
     rest = [i for i in range(nd) if i not in (ax1, ax2)]
     t = self.transpose(self._canonical(tensor), rest + [ax1, ax2])
+    if t.code == _lib.I32:
+      t = self.cast(t, _lib.I64)              # np.trace accumulates (and returns) int64 for narrower integers, like np.sum
     outer = _prod(t.shape[:-2])
     out = DeviceTensor.empty(t.shape[:-2], t.code, _sum_alias(t))
     _lib.check(self.lib.tnh_trace_last2(_vp(out), _vp(t), outer, t.shape[-2], t.shape[-1],
@@ -801,6 +803,8 @@ class HipBackend(BackendBase):
   def conj(self, tensor):
     tensor = self._as_tensor(tensor)
     if not tensor.is_complex:
+      if tensor.alias is not None and tensor.alias.kind == "b":
+        return self.cast(tensor, np.int8)     # np.conj has no bool loop: NumPy answers in int8
       return tensor
     return self._unary(_lib.OP_CONJ, tensor)
 
@@ -846,14 +850,21 @@ class HipBackend(BackendBase):
       sv = x if xs else y
       s = complex(sv)
       self._check_num(t, "arithmetic")
-      if t.code in _INT_CODES and (op == _lib.OP_DIV or not isinstance(sv, (numbers.Integral, np.integer))
-                                   or isinstance(sv, (bool, np.bool_))):
-        t = self.cast(t, _lib.F64)            # int (op) float -> float64; true division is float64 (NumPy)
+      if t.code == _lib.BF16:
+        if s.imag != 0.0:
+          t = self.cast(t, _lib.C64)          # no NumPy dtype to ask: bf16 stays bf16, a complex scalar makes complex64
+      else:
+        # NumPy's promotion (NEP 50): a Python scalar is weakly typed -- it keeps the tensor's dtype unless its KIND
+        # is higher (bool < int < float < complex), then the default dtype of that kind at the tensor's precision
+        # (bool (op) 3 -> int64, int32 (op) True -> int32, int (op) 2.5 -> float64, float32 (op) 1j -> complex64);
+        # a NumPy scalar is strongly typed.  np.result_type implements both.
+        res = np.result_type(np.dtype(t.dtype), sv)
+        if op == _lib.OP_DIV and res.kind in "iub":
+          res = np.dtype(np.float64)          # true division of integers is float64
+        if res != np.dtype(t.dtype):
+          t = self.cast(t, res)
       code = t.code
-      if s.imag != 0.0 and not t.is_complex:
-        code = _lib.C128 if t.code == _lib.F64 else _lib.C64
-        t = self.cast(t, code)
-      out = DeviceTensor.empty(t.shape, code, t.alias)    # tensor (op) python int keeps the tensor's dtype (NumPy)
+      out = DeviceTensor.empty(t.shape, code, t.alias)
       _lib.check(self.lib.tnh_binary_scalar(op, _vp(out), _vp(t), s.real, s.imag, 1 if xs else 0,
                                             t.size, code), "tnh_binary_scalar")
       return out

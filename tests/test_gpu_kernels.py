@@ -931,7 +931,7 @@ def test_narrow_and_unsigned_dtypes_behave_like_numpy(hip, dtype):
   assert dx.dtype == np.dtype(dtype)
   np.testing.assert_array_equal(np.asarray(dx), x)
   for got, ref in ((hip.transpose(dx, (2, 0, 1)), np.transpose(x, (2, 0, 1))), (hip.reshape(dx, (12, 5)), x.reshape(12, 5)),
-                   (hip.slice(dx, (1, 0, 2), (2, 3, 2)), x[1:3, 0:3, 2:4]), (dx[1], x[1]), (hip.conj(dx), x),
+                   (hip.slice(dx, (1, 0, 2), (2, 3, 2)), x[1:3, 0:3, 2:4]), (dx[1], x[1]), (hip.conj(dx), np.conj(x)),
                    (hip.zeros((2, 3), dtype=dtype), np.zeros((2, 3), dtype=dtype)),
                    (hip.ones((2, 3), dtype=dtype), np.ones((2, 3), dtype=dtype)),
                    (hip.eye(3, dtype=dtype), np.eye(3, dtype=dtype)), (hip.diagflat(dx[0, 0]), np.diagflat(x[0, 0]))):
