@@ -1457,6 +1457,10 @@ class HipBackend(BackendBase):
     is a real scalar or a tensor of the same shape.  Backs DeviceTensor's comparison operators."""
     ops = {"<": 0, "<=": 1, ">": 2, ">=": 3, "==": 4, "!=": 5}
     tensor = self._as_tensor(tensor)
+    if tensor.code in _INT_CODES:
+      # integers (and the narrow / unsigned / bool aliases, at their NumPy value) are compared as float64: exact up to
+      # 2^53, which covers every integer a tensor network's bookkeeping produces
+      tensor = self.cast(tensor, _lib.F64)
     if tensor.code not in (_lib.F32, _lib.F64, _lib.BF16, _lib.F16):
       raise NotImplementedError(f"comparison is not implemented for dtype {tensor.dtype} on the hip backend")
     out = DeviceTensor.empty(tensor.shape, _lib.I32)

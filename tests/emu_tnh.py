@@ -228,7 +228,8 @@ class EmuLib:
 
     x, y = operand(a, sa), operand(b, sb)
     with np.errstate(all="ignore"):
-      out = {_lib.OP_ADD: np.add, _lib.OP_SUB: np.subtract, _lib.OP_MUL: np.multiply, _lib.OP_DIV: np.divide}[op](x, y)
+      out = {_lib.OP_ADD: np.add, _lib.OP_SUB: np.subtract, _lib.OP_MUL: np.multiply, _lib.OP_DIV: np.divide,
+             _lib.OP_POW: np.power}[op](x, y)
     self._flat(dst, n, _NP[code])[:] = self._from_f(out, code).reshape(-1)
     return _lib.OK
 

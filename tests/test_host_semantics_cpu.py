@@ -116,3 +116,103 @@ def test_backend_methods_follow_numpy_dtype_and_value_semantics():
             except Exception as e:
               fails.append((name + " scalar exc", dt, sc))
   assert not fails, fails[:20]
+
+
+def test_methods_and_error_paths_match_the_numpy_backend():
+  """Values, result dtypes and exception TYPES of the backend's methods against the oracle backend (the restatement
+  of numpy_backend.py) -- batched matmul and its rank check (numpy_backend.py:609-612), the broadcast multiplications
+  and their ValueErrors (560-575), diagonal / diagflat / trace with offsets and axes (847-888, 684-707), sums,
+  slices, reshapes, transposes, elementwise math, eye / ones / zeros, index_update (548-552), tensordot axis errors."""
+  from oracle.numpy_oracle import OracleBackend  # pylint: disable=import-outside-toplevel
+  rng = np.random.default_rng(1)
+  ob = OracleBackend()
+  fails = []
+
+  def close(got, ref, what):
+    got, ref = np.asarray(got), np.asarray(ref)
+    ok = got.shape == ref.shape and got.dtype == ref.dtype
+    if ok:
+      tol = 1e-4 if ref.dtype in (np.float32, np.complex64) else 1e-10
+      ok = np.allclose(got, ref, rtol=tol, atol=tol, equal_nan=True) if ref.dtype.kind in "fc" else np.array_equal(got, ref)
+    if not ok:
+      fails.append((what, str(got.dtype), str(ref.dtype), got.shape, ref.shape))
+
+  with emulated_backend() as be_hip:
+    def both(what, fn, ref_fn=None):
+      """fn(backend, convert) on the oracle (or ref_fn on NumPy) and on the emulated backend: same values, or the same
+      exception type."""
+      try:
+        r, rexc = (ref_fn() if ref_fn is not None else fn(ob, lambda x: x)), None
+      except Exception as e:  # pylint: disable=broad-except
+        r, rexc = None, e
+      try:
+        g, gexc = fn(be_hip, be_hip.convert_to_tensor), None
+      except Exception as e:  # pylint: disable=broad-except
+        g, gexc = None, e
+      if rexc is not None or gexc is not None:
+        if type(rexc) is not type(gexc):
+          fails.append((what, "exceptions differ", repr(rexc)[:80], repr(gexc)[:80]))
+        return
+      if isinstance(r, (tuple, list)):
+        for i, (a, b) in enumerate(zip(g, r)):
+          close(a, b, f"{what}[{i}]")
+      else:
+        close(g, r, what)
+
+    with np.errstate(all="ignore"):
+      for dt in (np.float32, np.float64, np.complex64, np.int64, np.int32):
+        x = (rng.standard_normal((2, 3, 4, 5)) * 3).astype(dt)
+        m = (rng.standard_normal((4, 4)) * 3).astype(dt)
+        v = (rng.standard_normal((5,)) * 3).astype(dt)
+        w = (rng.standard_normal((2,)) * 3).astype(dt)
+        xt = np.swapaxes(x, -1, -2).copy()
+        both(f"matmul batch {dt}", lambda be, c: be.matmul(c(x), c(xt)))
+        both(f"matmul rank1 {dt}", lambda be, c: be.matmul(c(v), c(v)))
+        both(f"matmul mismatch {dt}", lambda be, c: be.matmul(c(x), c(x)))
+        both(f"brm {dt}", lambda be, c: be.broadcast_right_multiplication(c(x), c(v)))
+        both(f"blm {dt}", lambda be, c: be.broadcast_left_multiplication(c(w), c(x)))
+        both(f"brm bad {dt}", lambda be, c: be.broadcast_right_multiplication(c(x), c(m)))
+        both(f"blm bad {dt}", lambda be, c: be.broadcast_left_multiplication(c(m), c(x)))
+        both(f"outer {dt}", lambda be, c: be.outer_product(c(v), c(m)))
+        for off in (-1, 0, 1, 7):
+          both(f"diagonal {dt} {off}", lambda be, c: be.diagonal(c(x), offset=off))
+          both(f"diagonal axes {dt} {off}", lambda be, c: be.diagonal(c(x), offset=off, axis1=0, axis2=2))
+          both(f"trace {dt} {off}", lambda be, c: be.trace(c(x), offset=off))
+          both(f"diagflat {dt} {off}", lambda be, c: be.diagflat(c(v), k=off))
+        both(f"diagonal same axes {dt}", lambda be, c: be.diagonal(c(x), axis1=1, axis2=1))
+        both(f"diagonal rank1 {dt}", lambda be, c: be.diagonal(c(v)))
+        both(f"trace rank1 {dt}", lambda be, c: be.trace(c(v)))
+        both(f"diagflat rank2 {dt}", lambda be, c: be.diagflat(c(m)))
+        both(f"sum tuple neg {dt}", lambda be, c: be.sum(c(x), axis=(-1, 0)))
+        both(f"slice bad {dt}", lambda be, c: be.slice(c(x), (0, 0), (1, 1)))
+        both(f"slice too big {dt}", lambda be, c: be.slice(c(x), (0, 0, 0, 3), (1, 1, 1, 9)))
+        both(f"reshape -1 {dt}", lambda be, c: be.reshape(c(x), (-1, 5)))
+        both(f"reshape bad {dt}", lambda be, c: be.reshape(c(x), (7, 7)))
+        both(f"transpose none {dt}", lambda be, c: be.transpose(c(x)))
+        both(f"transpose bad {dt}", lambda be, c: be.transpose(c(x), (0, 1)))
+        both(f"power {dt}", lambda be, c: be.power(c(np.abs(m) + 1), c(np.ones_like(m) * 2)),
+             ref_fn=lambda: np.power(np.abs(m) + 1, np.ones_like(m) * 2))
+        both(f"power scalar {dt}", lambda be, c: be.power(c(np.abs(m) + 1), 2), ref_fn=lambda: np.power(np.abs(m) + 1, 2))
+        both(f"divide tensors {dt}", lambda be, c: be.divide(c(x), c(np.abs(v) + 1)))
+        both(f"shape_tensor {dt}", lambda be, c: be.shape_tensor(c(x)))
+        both(f"shape_tuple {dt}", lambda be, c: be.shape_tuple(c(x)))
+        both(f"shape_prod {dt}", lambda be, c: be.shape_prod(c(x)))
+        both(f"sqrt {dt}", lambda be, c: be.sqrt(c(np.abs(m))))
+        both(f"exp {dt}", lambda be, c: be.exp(c(m / 4)))
+        both(f"log {dt}", lambda be, c: be.log(c(np.abs(m) + 1)))
+        both(f"sin cos {dt}", lambda be, c: (be.sin(c(m)), be.cos(c(m))))
+        both(f"norm {dt}", lambda be, c: be.norm(c(x)))
+        both(f"eye {dt}", lambda be, c: be.eye(3, dtype=dt, M=5))
+        both(f"ones zeros {dt}", lambda be, c: (be.ones((2, 3), dtype=dt), be.zeros((2, 3), dtype=dt)))
+        both(f"sign {dt}", lambda be, c: be.sign(c(m)))
+        both(f"tensordot bad axes {dt}", lambda be, c: be.tensordot(c(x), c(x), [[0], [1]]))
+        x2 = np.moveaxis(x, (0, 1), (2, 3)).copy()
+        both(f"tensordot int axes {dt}", lambda be, c: be.tensordot(c(x), c(x2), 2))
+        if np.dtype(dt).kind == "f":
+          both(f"index_update {dt}", lambda be, c: be.index_update(c(m), c(m) > 0, 7))
+          both(f"expm {dt}", lambda be, c: be.expm(c(m / 8)))
+          both(f"inv {dt}", lambda be, c: be.inv(c(m + 5 * np.eye(4, dtype=dt))))
+        if np.dtype(dt).kind == "i":      # integer comparisons: int32 0 / 1 mask (the device form of a bool array)
+          mask = np.asarray(be_hip.convert_to_tensor(m) > 0)
+          np.testing.assert_array_equal(mask != 0, m > 0)
+  assert not fails, fails[:20]
