@@ -11,9 +11,16 @@ from oracle.numpy_oracle import OracleBackend
 import cases as C
 
 
-@pytest.fixture(scope="module")
-def be():
-  return OracleBackend()
+@pytest.fixture(scope="module", params=["oracle", "hip-emulated"])
+def be(request):
+  """The host layers under both backends: the oracle (NumPy restatement of the reference's backend) and HipBackend on
+  the emulated C ABI (tests/emu_tnh.py) -- the second runs the product's own backend code, planning hooks included."""
+  if request.param == "oracle":
+    yield OracleBackend()
+    return
+  from emu_tnh import emulated_backend  # pylint: disable=import-outside-toplevel
+  with emulated_backend() as hip:
+    yield hip
 
 
 def test_ncon_cases(be, golden):
