@@ -42,6 +42,8 @@ class EmuLib:
     self._blocks = {}
     self.calls = []            # (entry point, summary) in call order: tests assert on what was launched
     self._last_kernel = b"emu"
+    self._recording = None
+    self._pinned = []
 
   # ---- memory (tnh.h: tnh_malloc / tnh_free / tnh_pool_has / tnh_h2d / tnh_d2h / tnh_d2d / tnh_memset / tnh_sync)
   def tnh_malloc(self, pref, nbytes):
@@ -53,7 +55,9 @@ class EmuLib:
     return _lib.OK
 
   def tnh_free(self, p):
-    self._blocks.pop(_addr(p), None)
+    buf = self._blocks.pop(_addr(p), None)
+    if self._recording is not None and buf is not None:
+      self._pinned.append(buf)       # tnh.h: every block a captured sequence touched stays pinned to the graph
     return _lib.OK
 
   def tnh_pool_has(self, nbytes, has_ref):  # pylint: disable=unused-argument
@@ -400,6 +404,51 @@ class EmuLib:
     self._flat(q_out, m * k, _NP[code])[:] = q.astype(_NP[code]).reshape(-1)
     self._flat(r_out, k * n, _NP[code])[:] = r.astype(_NP[code]).reshape(-1)
     return _lib.OK
+
+
+  # ---- hipGraph capture (tnh.h: every tnh_* kernel call between begin / end is recorded instead of executed;
+  #      tnh_graph_launch replays the sequence).  Recording happens in __getattribute__ below.
+  _NOT_CAPTURED = ("tnh_malloc", "tnh_free", "tnh_pool_has", "tnh_last_error", "tnh_gemm_last_kernel", "tnh_graph_begin",
+                   "tnh_graph_end", "tnh_graph_launch", "tnh_graph_destroy", "tnh_gemm_set_variant", "tnh_svd_work_bytes",
+                   "tnh_qr_work_bytes", "tnh_svd_band_supported")
+
+  def tnh_graph_begin(self):
+    self._recording = []
+    self._pinned = []
+    return _lib.OK
+
+  def tnh_graph_end(self, handle_ref):
+    self._graphs = getattr(self, "_graphs", {})
+    key = len(self._graphs) + 1
+    self._graphs[key] = self._recording
+    self._graph_pins = getattr(self, "_graph_pins", {})
+    self._graph_pins[key] = self._pinned
+    self._recording = None
+    handle_ref._obj.value = key      # pylint: disable=protected-access
+    return _lib.OK
+
+  def tnh_graph_launch(self, handle):
+    for fn, args in self._graphs[_addr(handle)]:
+      status = fn(*args)
+      if status != _lib.OK:
+        return status
+    return _lib.OK
+
+  def tnh_graph_destroy(self, handle):
+    getattr(self, "_graphs", {}).pop(_addr(handle), None)
+    getattr(self, "_graph_pins", {}).pop(_addr(handle), None)
+    return _lib.OK
+
+  def __getattribute__(self, name):
+    attr = object.__getattribute__(self, name)
+    if name.startswith("tnh_") and name not in EmuLib._NOT_CAPTURED:
+      rec = object.__getattribute__(self, "__dict__").get("_recording")
+      if rec is not None:
+        def record(*args):
+          rec.append((attr, args))
+          return _lib.OK
+        return record
+    return attr
 
 
 class EmulatedHipBackend(hip_backend.HipBackend):

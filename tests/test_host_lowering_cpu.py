@@ -273,7 +273,13 @@ def _gpu_suite_selection():
   import test_gpu_linalg as TL   # pylint: disable=import-outside-toplevel
   import test_gpu_mps as TM      # pylint: disable=import-outside-toplevel
   import test_gpu_workloads as TW  # pylint: disable=import-outside-toplevel
-  return [TL.test_linalg_errors, TL.test_eigsh_lanczos_device_vectors, TL.test_eigsh_and_gmres_device_vectors,
+  import test_gpu_graph as TG      # pylint: disable=import-outside-toplevel
+  return [TG.test_graph_surgery_reference_cases_on_device, TG.test_switch_backend_host_network_into_hbm,
+          TW.test_config2_bf16_contract_between_full_check, TW.test_config2_bf16_D64_sampled_entries,
+          TW.test_tensordot_linearity_and_identity_large, TW.test_regular_network_sliced_on_gpu, TW.test_mera_layer_on_gpu,
+          TW.test_hipgraph_capture_replay, TW.test_sliced_contraction_graph_equals_eager,
+          TW.test_sliced_bf16_network_accumulates_partials_in_fp32,
+          TL.test_linalg_errors, TL.test_eigsh_lanczos_device_vectors, TL.test_eigsh_and_gmres_device_vectors,
           TL.test_eigs_device_vectors, TL.test_eigsh_complex_hermitian_and_pivot, TL.test_compare_and_index_update,
           TL.test_tensor_and_functional_api_on_device, TL.test_complex_split_node_golden, TL.test_complex_qr_rq_golden,
           TM.test_mps_canonical_form_on_device, TM.test_dmrg_ground_energy_vs_exact_f64, TM.test_dmrg_f32_chain_of_12,

@@ -7,9 +7,15 @@ from tensornetwork_amd import contractors, distributed, workloads as wl
 from oracle.numpy_oracle import OracleBackend
 
 
-@pytest.fixture(scope="module")
-def be():
-  return OracleBackend()
+@pytest.fixture(scope="module", params=["oracle", "hip-emulated"])
+def be(request):
+  """Both backends: the oracle, and HipBackend on the emulated C ABI (tests/emu_tnh.py: the product's backend code)."""
+  if request.param == "oracle":
+    yield OracleBackend()
+    return
+  from emu_tnh import emulated_backend  # pylint: disable=import-outside-toplevel
+  with emulated_backend() as hip:
+    yield hip
 
 
 def test_wavelet_mera_energy_kat(be):
