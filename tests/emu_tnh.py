@@ -406,11 +406,51 @@ class EmuLib:
     return _lib.OK
 
 
+  # ---- runtime odds and ends bench.py touches (tnh.h: tnh_random, tnh_trim, tnh_event_*, tnh_device_pci_bus_id)
+  def tnh_random(self, dst, n, code, seed, normal, a, b):
+    rng = np.random.default_rng(int(seed))
+    x = rng.normal(a, b, int(n)) if normal else rng.uniform(a, b, int(n))
+    if code in (_lib.C64, _lib.C128):
+      x = x + 1j * (rng.normal(a, b, int(n)) if normal else rng.uniform(a, b, int(n)))
+    self._flat(dst, int(n), _NP[code])[:] = self._from_f(x, code)
+    return _lib.OK
+
+  def tnh_trim(self):
+    return _lib.OK
+
+  def tnh_device_pci_bus_id(self, buf, n):  # pylint: disable=unused-argument
+    return _lib.ERR_UNSUPPORTED
+
+  def tnh_event_create(self, ev_ref):
+    import time  # pylint: disable=import-outside-toplevel
+    self._events = getattr(self, "_events", {})
+    key = len(self._events) + 1
+    self._events[key] = time.perf_counter()
+    ev_ref._obj.value = key        # pylint: disable=protected-access
+    return _lib.OK
+
+  def tnh_event_record(self, ev):
+    import time  # pylint: disable=import-outside-toplevel
+    self._events[_addr(ev)] = time.perf_counter()
+    return _lib.OK
+
+  def tnh_event_sync(self, ev):  # pylint: disable=unused-argument
+    return _lib.OK
+
+  def tnh_event_elapsed_ms(self, start, stop, ms_ref):
+    ms_ref._obj.value = max((self._events[_addr(stop)] - self._events[_addr(start)]) * 1e3, 1e-6)   # pylint: disable=protected-access
+    return _lib.OK
+
+  def tnh_event_destroy(self, ev):
+    getattr(self, "_events", {}).pop(_addr(ev), None)
+    return _lib.OK
+
   # ---- hipGraph capture (tnh.h: every tnh_* kernel call between begin / end is recorded instead of executed;
   #      tnh_graph_launch replays the sequence).  Recording happens in __getattribute__ below.
   _NOT_CAPTURED = ("tnh_malloc", "tnh_free", "tnh_pool_has", "tnh_last_error", "tnh_gemm_last_kernel", "tnh_graph_begin",
                    "tnh_graph_end", "tnh_graph_launch", "tnh_graph_destroy", "tnh_gemm_set_variant", "tnh_svd_work_bytes",
-                   "tnh_qr_work_bytes", "tnh_svd_band_supported")
+                   "tnh_qr_work_bytes", "tnh_svd_band_supported", "tnh_trim", "tnh_event_create", "tnh_event_destroy",
+                   "tnh_device_pci_bus_id")
 
   def tnh_graph_begin(self):
     self._recording = []

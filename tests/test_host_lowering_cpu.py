@@ -324,3 +324,32 @@ def test_bench_svd_leg_runs_on_the_emulated_backend():
     check = bench.check_svd_case(mat_host.astype(np.float64), s_ref, n, k, outputs)
   assert rec["n"] == n and rec["k"] == k and len(rec["samples_ms"]) == 3 and rec["seconds"] * 1e3 == min(rec["samples_ms"])
   assert check["ok"], check
+
+
+def test_bench_main_assembles_its_json_line_on_the_emulated_backend(monkeypatch, capsys):
+  """bench.py end to end (headline leg with its value check, the sliced 64-node network, the MERA layer, roofline
+  and verified objects) at toy sizes on the emulated backend: the control flow and the JSON contract of the line the
+  driver parses -- the numbers themselves mean nothing here."""
+  import json  # pylint: disable=import-outside-toplevel
+  import sys  # pylint: disable=import-outside-toplevel
+  import bench  # pylint: disable=import-outside-toplevel
+  with emulated_backend() as be:
+    monkeypatch.setattr(ta, "get_hip_backend", lambda: be)
+    monkeypatch.setattr(ta, "configure_gc", lambda **kwargs: None)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--bond", "16", "--steps", "2", "--warmup", "1", "--svd-n", "0",
+                                      "--rr-bond", "2", "--rr-min-slices", "4", "--mera-chi", "4", "--no-sweep",
+                                      "--no-extras", "--no-cpu-baseline"])
+    for var in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+      monkeypatch.delenv(var, raising=False)
+    bench.main()
+  line = capsys.readouterr().out.strip().splitlines()[-1]
+  rec = json.loads(line)
+  for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "verified", "sliced_network", "mera"):
+    assert key in rec, key
+  assert rec["n_gpus"] == 1 and rec["steps"] == 2 and rec["warmup"] == 1 and rec["dtype"] == "bf16"
+  assert rec["higher_is_better"] is True and rec["vs_baseline"] is None and "workload" in rec["config"]
+  assert set(rec["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
+  assert rec["verified"]["headline_D16_L0"]["ok"] is True and rec["verified"]["mera_chi4_bf16_vs_f32"]["ok"] is True
+  assert "sliced_network_bf16_vs_f32" in rec["verified"] and "all_ok" in rec["verified"]   # (the statistical model
+  # behind the sliced check needs more than the 4 partials of a D = 2 toy network to hold: only its presence is asserted)
