@@ -229,15 +229,20 @@ def _rebuild_bf16(host):
 
 class DeviceTensor:
   """Dense row-major tensor in HBM."""
-  __slots__ = ("_block", "_offset", "_shape", "_code", "_alias", "__weakref__")
+  __slots__ = ("_block", "_offset", "_shape", "_code", "_alias", "_pad", "__weakref__")
   __array_priority__ = 1000  # ndarray (op) DeviceTensor defers to us
 
-  def __init__(self, block, shape, code, offset=0, alias=None):
+  def __init__(self, block, shape, code, offset=0, alias=None, pad=None):
     self._block = block
     self._offset = int(offset)
     self._shape = tuple(int(s) for s in shape)
     self._code = int(code)
     self._alias = alias          # NumPy dtype of a bool / unsigned / narrow-int tensor stored as int64
+    # (split, pitch) of a ROW-PADDED contraction result (HipBackend.pad_results, off by default): axes [split:] are
+    # dense row-major (one "row"), consecutive rows -- the row-major index over axes [:split] -- lie `pitch` elements
+    # apart, pitch > row length.  Only the in-place contraction lowering reads such a tensor as it lies (its operand
+    # views carry arbitrary strides); every other backend entry point takes the dense copy first (HipBackend._dense).
+    self._pad = pad
 
   # -- construction ----------------------------------------------------------
   @classmethod
@@ -316,14 +321,56 @@ class DeviceTensor:
   def is_complex(self):
     return self._code in (_lib.C64, _lib.C128)
 
+  @property
+  def pad(self):
+    return self._pad
+
+  @property
+  def strides(self):
+    """Element strides of the axes (row-major; rows `pitch` apart for a row-padded result)."""
+    st = [1] * len(self._shape)
+    for d in range(len(self._shape) - 2, -1, -1):
+      st[d] = st[d + 1] * self._shape[d + 1]
+    if self._pad is not None:
+      split, pitch = self._pad
+      row = math.prod(self._shape[split:])
+      for d in range(split):
+        st[d] = st[d] // row * pitch
+    return st
+
   def view(self, shape):
     """Metadata-only reshape sharing the device block."""
     shape = tuple(int(s) for s in shape)
-    return DeviceTensor(self._block, shape, self._code, self._offset, self._alias)
+    if self._pad is None:
+      return DeviceTensor(self._block, shape, self._code, self._offset, self._alias)
+    # row-padded: the new shape has to keep the row boundary
+    split, pitch = self._pad
+    rows = math.prod(self._shape[:split])
+    acc, new_split = 1, None
+    for i in range(len(shape) + 1):
+      if acc == rows and math.prod(shape[i:]) == math.prod(self._shape[split:]):
+        new_split = i
+        break
+      if i < len(shape):
+        acc *= shape[i]
+    if new_split is None or math.prod(shape) != self.size:
+      raise ValueError(f"a row-padded tensor of shape {self._shape} (rows = axes [:{split}]) cannot be viewed as {shape}")
+    return DeviceTensor(self._block, shape, self._code, self._offset, self._alias, (new_split, pitch))
 
   # -- host transfer -----------------------------------------------------------
   def numpy(self):
     """Blocking D2H copy. bfloat16 tensors come back as float32."""
+    if self._pad is not None:            # whole rows incl. their padding come over, the padding is cut on the host
+      split, pitch = self._pad
+      rows, row = math.prod(self._shape[:split]), math.prod(self._shape[split:])
+      raw = np.empty((rows, pitch), dtype=np.uint16 if self._code == _lib.BF16 else _TNH_TO_NP[self._code])
+      if raw.size:
+        _lib.check(_lib.lib().tnh_d2h(raw.ctypes.data_as(ctypes.c_void_p), ctypes.c_void_p(self.ptr),
+                                      ((rows - 1) * pitch + row) * raw.itemsize), "tnh_d2h")
+      host = np.ascontiguousarray(raw[:, :row]).reshape(self._shape)
+      if self._code == _lib.BF16:
+        return bf16_bits_to_f32(host).reshape(self._shape)
+      return host.astype(self._alias) if self._alias is not None else host
     if self._code == _lib.BF16:
       host = np.empty(self._shape, dtype=np.uint16)
     else:
@@ -373,6 +420,10 @@ class DeviceTensor:
     return self.__deepcopy__({})
 
   def __deepcopy__(self, memo):
+    if self._pad is not None:            # the dense copy IS a copy
+      out = self._backend()._dense(self)  # pylint: disable=protected-access
+      memo[id(self)] = out
+      return out
     out = DeviceTensor.empty(self._shape, self._code, self._alias)
     if self.nbytes:
       _lib.check(_lib.lib().tnh_d2d(ctypes.c_void_p(out.ptr), ctypes.c_void_p(self.ptr), self.nbytes), "tnh_d2d")

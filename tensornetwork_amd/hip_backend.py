@@ -98,12 +98,13 @@ def _merge_levels(shape, strides, axes):
   return levels
 
 
-def _operand_view(shape, free_axes, k_axes):
+def _operand_view(shape, free_axes, k_axes, strides=None):
   """Two-level strided matrix view (tnh_operand_view) of a dense row-major tensor whose rows are
   `free_axes` (output order) and whose contraction index is `k_axes` (K order), or None when the
   tensor cannot be read in place: more than two memory runs on either side, no contiguous
   direction, an inner contraction run that is not a multiple of 32, or misaligned strides."""
-  strides = _row_major_strides(shape)
+  if strides is None:
+    strides = _row_major_strides(shape)          # (a row-padded contraction result passes its own)
   rows = _merge_levels(shape, strides, free_axes)
   ks = _merge_levels(shape, strides, k_axes)
   if not ks or len(rows) > 2 or len(ks) > 2:
@@ -155,6 +156,8 @@ class HipBackend(BackendBase):
     # TNH_ABSORB_TRANSPOSES=0 keeps the permute + NT lowering (A/B and second opinion in the tests).
     import os  # pylint: disable=import-outside-toplevel
     self.absorb_transposes = os.environ.get("TNH_ABSORB_TRANSPOSES", "1") != "0"
+    self.pad_results = os.environ.get("TNH_PAD_RESULTS", "0") == "1"       # see _result_pitch
+    self.pad_min_bytes = int(os.environ.get("TNH_PAD_MIN_BYTES", str(2 << 30)))
     self.inplace_max_bytes = int(os.environ.get("TNH_VIEW_INPLACE_MAX_BYTES", str(2 << 30)))
     self.permutes_absorbed = 0   # tnh_gemm_view launches
     self.permute_launches = 0    # K1 launches (transpose)
@@ -192,8 +195,34 @@ class HipBackend(BackendBase):
 
   def _as_tensor(self, x):
     if isinstance(x, DeviceTensor):
-      return x
+      return self._dense(x)
     return self.convert_to_tensor(x)
+
+  def _dense(self, tensor):
+    """The dense row-major copy of a row-padded contraction result (DeviceTensor.pad; only produced when
+    `pad_results` is on), any other tensor as it is.  Every entry point except the in-place contraction lowering
+    works on dense tensors."""
+    if tensor.pad is None:
+      return tensor
+    split, pitch = tensor.pad
+    rows, row = _prod(tensor.shape[:split]), _prod(tensor.shape[split:])
+    out = DeviceTensor.empty(tensor.shape, tensor.code, tensor.alias)
+    if tensor.size:
+      _lib.check(self.lib.tnh_strided_copy(_vp(out), _vp(tensor), 2, _lib.i64_array((rows, row)),
+                                           _lib.i64_array((pitch, 1)), 0, tensor.itemsize), "tnh_strided_copy")
+    return out
+
+  def _result_pitch(self, m, n, itemsize):
+    """Row pitch (elements) of an m x n contraction result: n, or n + 64 when `pad_results` is on and the rows are
+    a power of two of 4 KiB or more in a result of `pad_min_bytes` or more.  Why: a later contraction that re-views
+    such a result with rows of 1 MiB or more finds ALL its rows at the same offset modulo the pitch -- the same few
+    HBM channels -- and runs at 850 TFLOP/s whatever the data (profiles/r03_gemm_epilogue.md section 5: 1.05-1.65
+    PFLOP/s with 128 bytes of padding per row).  Off by default until it has been measured on the workload it is for
+    (the chi = 32 MERA layer): TNH_PAD_RESULTS=1 or `be.pad_results = True`."""
+    row_bytes = n * itemsize
+    if not self.pad_results or row_bytes < 4096 or row_bytes & (row_bytes - 1) or m * row_bytes < self.pad_min_bytes:
+      return n
+    return n + 64
 
   def _canonical(self, tensor, alias=None):
     """A bool / unsigned / narrow-integer tensor is stored widened to int64 and stays exact under +, -, * only
@@ -220,7 +249,7 @@ class HipBackend(BackendBase):
       t = DeviceTensor(t._block, t.shape, code, t._offset, alias)   # pylint: disable=protected-access
       return self._canonical(t) if alias is not None and alias.kind == "b" else t
     self._check_num(tensor, "cast")
-    tensor = self._canonical(tensor)
+    tensor = self._canonical(self._dense(tensor))
     if alias is not None and alias.kind == "b" and tensor.code not in _INT_CODES:
       # float -> bool is (x != 0), not a truncation (0.5 is True): sign(x)^2 is exactly 0 or 1
       if tensor.is_complex:
@@ -382,6 +411,7 @@ class HipBackend(BackendBase):
 
   def getitem(self, tensor, key):
     """Basic (int / slice / Ellipsis) indexing, materialised by one gather."""
+    tensor = self._dense(tensor)
     if not isinstance(key, tuple):
       key = (key,)
     if any(k is Ellipsis for k in key):
@@ -481,8 +511,8 @@ class HipBackend(BackendBase):
     brings it to [free, contracted] form.  For bf16/f16 both operands are
     brought to the K-contiguous form the 16x16x32 MFMA kernels consume.
     """
-    a = self._as_tensor(a)
-    b = self._as_tensor(b)
+    a = a if isinstance(a, DeviceTensor) else self.convert_to_tensor(a)     # (row-padded results stay as they lie
+    b = b if isinstance(b, DeviceTensor) else self.convert_to_tensor(b)     #  until the in-place lowering has looked)
     axes_a, axes_b = self._normalize_axes(a, b, axes)
     ires = _int_result(a, b)
     code, alias = ires if ires is not None else (_promote(a.code, b.code), None)
@@ -497,7 +527,7 @@ class HipBackend(BackendBase):
     nc = len(axes_a)
     if nc == 0:
       out_shape = tuple(a.shape[i] for i in free_a) + tuple(b.shape[i] for i in free_b)
-      return self._outer(a, b, out_shape, alias), free_a, free_b
+      return self._outer(self._dense(a), self._dense(b), out_shape, alias), free_a, free_b
 
     # bf16 / f16, enough 256 x 256 tiles: read BOTH operands in place through two-level strides
     # (K8 lowering of tensordot2.py:62-88 -- transposes are absorbed by the GEMM loaders, no K1 launch).
@@ -508,6 +538,7 @@ class HipBackend(BackendBase):
         out, used_a, used_b = got
         out_shape = tuple(a_shape0[i] for i in used_a) + tuple(b_shape0[i] for i in used_b)
         return out.view(out_shape), used_a, used_b
+    a, b = self._dense(a), self._dense(b)
 
     # memory order of the contracted pairs on each side
     order_a = sorted(range(nc), key=lambda i: axes_a[i])
@@ -586,7 +617,7 @@ class HipBackend(BackendBase):
     out_bytes = m * n * a.itemsize
 
     def usable(t, free, kax, hint):
-      v = _operand_view(t.shape, free, kax)
+      v = _operand_view(t.shape, free, kax, t.strides if t.pad is not None else None)
       # The planner asked for another order of this operand's free axes (it lays the RESULT out for the contractions
       # that follow) and the operand is small against the result: pay its K1 pass now rather than a pass over the
       # result later (MERA chi = 32: with the runs-of-32 views every small operand became readable in place, and the
@@ -626,12 +657,17 @@ class HipBackend(BackendBase):
       b = self.transpose(b, used_b + kb)
       vb = _lib.OperandView(n, k, 0, k, 1, 0)
     out_code = _lib.F32 if self.half_output == "float32" else a.code
-    out = DeviceTensor.empty((m, n), out_code)
+    ldc = self._result_pitch(m, n, 4 if out_code == _lib.F32 else 2)
+    if ldc == n:
+      out = DeviceTensor.empty((m, n), out_code)
+    else:
+      block = DeviceTensor.empty((m * ldc,), out_code)
+      out = DeviceTensor(block._block, (m, n), out_code, 0, None, (1, ldc))   # pylint: disable=protected-access
     events = getattr(self, "gemm_events", None)
     if events is not None:
       start = _lib.Event().record()
     status = self.lib.tnh_gemm_view(a.code, out_code, m, n, k, _vp(a), ctypes.byref(va), _vp(b), ctypes.byref(vb),
-                                    _vp(out), n)
+                                    _vp(out), ldc)
     if status == _lib.ERR_UNSUPPORTED:
       return None     # (a forced A/B variant, or an alignment rule: nothing was launched)
     _lib.check(status, "tnh_gemm_view")

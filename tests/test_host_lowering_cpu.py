@@ -353,3 +353,78 @@ def test_bench_main_assembles_its_json_line_on_the_emulated_backend(monkeypatch,
   assert rec["verified"]["headline_D16_L0"]["ok"] is True and rec["verified"]["mera_chi4_bf16_vs_f32"]["ok"] is True
   assert "sliced_network_bf16_vs_f32" in rec["verified"] and "all_ok" in rec["verified"]   # (the statistical model
   # behind the sliced check needs more than the 4 partials of a D = 2 toy network to hold: only its presence is asserted)
+
+
+def test_row_padded_contraction_results_are_read_in_place_or_made_dense():
+  """`pad_results` (off by default): a large contraction result whose rows are a power of two gets 128 bytes of
+  padding per row (profiles/r03_gemm_epilogue.md section 5: power-of-two pitches alias the HBM channels of the
+  contraction that re-views the result).  The next in-place contraction reads it as it lies -- its operand view
+  carries the pitch -- and everything else sees the dense copy."""
+  rng = np.random.default_rng(12)
+  a = orc.round_bf16(rng.standard_normal((13, 256, 128)).astype(np.float32) / 8)      # (r1, r2, k)
+  b = orc.round_bf16(rng.standard_normal((128, 4096)).astype(np.float32) / 8)         # (k, c): rows of 8 KiB
+  w = orc.round_bf16(rng.standard_normal((256, 4096, 16)).astype(np.float32) / 32)    # contracts (r2, c) of the result
+  ref1 = np.tensordot(a.astype(np.float64), b.astype(np.float64), [[2], [0]])         # (13, 256, 4096)
+  with emulated_backend() as be:
+    be.pad_results, be.pad_min_bytes = True, 1 << 20
+    c1 = be.tensordot(be.to_bfloat16(a), be.to_bfloat16(b), [[2], [0]])
+    assert c1.pad == (2, 4096 + 64) and c1.shape == (13, 256, 4096)
+    assert c1.strides == [256 * 4160, 4160, 1]
+    np.testing.assert_allclose(np.asarray(c1), ref1, rtol=2.0**-7, atol=2.0**-8 * 12)
+    c1h = orc.round_bf16(np.asarray(c1))
+    # a small product over (r2, c) of the result: outside the view kernel's range -> the dense copy, classic lowering
+    c2 = be.tensordot(be.to_bfloat16(w), c1, [[0, 1], [1, 2]])                           # (16, 13)
+    ref2 = np.tensordot(w.astype(np.float64), c1h.astype(np.float64), [[0, 1], [1, 2]])
+    np.testing.assert_allclose(np.asarray(c2), ref2, rtol=2.0**-6, atol=2.0**-7 * 1024)
+    # a product inside the view kernel's range reads the padded result in place: c1 (13 x 256 rows at the PITCH) . v
+    v = orc.round_bf16(rng.standard_normal((4096, 4096)).astype(np.float32) / 64)
+    vd = be.to_bfloat16(v)
+    n_before = len(be.lib.calls)
+    before = be.permute_launches
+    c3 = be.tensordot(c1, vd, [[2], [0]])                                                # m = 3328, n = 4096, K = 4096
+    call = [c for c in be.lib.calls[n_before:] if c[0] == "view_gemm"]
+    assert len(call) == 1 and call[0][4] == (1, 0, 0) and be.permute_launches == before, (call, be.lib.calls[n_before:])
+    ref3 = np.tensordot(c1h.astype(np.float64), v.astype(np.float64), [[2], [0]])
+    assert c3.pad == (2, 4160)                                                           # 3328 x 4096 again: padded
+    np.testing.assert_allclose(np.asarray(c3), ref3, rtol=2.0**-6, atol=2.0**-7 * 64)
+    # dense consumers
+    np.testing.assert_allclose(np.asarray(be.sum(c1, axis=(0, 1))), c1h.astype(np.float64).sum(axis=(0, 1)), rtol=2e-2, atol=0.5)
+    np.testing.assert_array_equal(np.asarray(be.transpose(c1, (2, 0, 1))), np.transpose(c1h, (2, 0, 1)))
+    np.testing.assert_array_equal(np.asarray(c1[3, 5:9]), c1h[3, 5:9])
+    np.testing.assert_array_equal(np.asarray(be.reshape(c1, (13 * 256, 4096))), c1h.reshape(13 * 256, 4096))
+    import copy  # pylint: disable=import-outside-toplevel
+    d = copy.deepcopy(c1)
+    assert d.pad is None
+    np.testing.assert_array_equal(np.asarray(d), c1h)
+    with pytest.raises(ValueError):
+      c1.view((13 * 256 * 2, 2048))                 # does not keep the row boundary
+    assert c1.view((13 * 256, 4096)).pad == (1, 4160) and c1.view((13, 16, 16, 4096)).pad == (3, 4160)
+    # off by default
+    be.pad_results = False
+    assert be.tensordot(be.to_bfloat16(a), be.to_bfloat16(b), [[2], [0]]).pad is None
+
+
+def test_row_padded_operand_with_the_pitch_in_its_contraction_index():
+  """The shape of the MERA layer's second large product: the padded result (R, r2, c) is contracted over (r2, c) --
+  the contraction index has two levels and the OUTER one strides by the pitch -- against a dense K-contiguous
+  operand.  One view GEMM, no permute, values as NumPy's."""
+  from tensornetwork_amd.device_tensor import DeviceTensor  # pylint: disable=import-outside-toplevel
+  from tensornetwork_amd import _lib  # pylint: disable=import-outside-toplevel
+  rng = np.random.default_rng(13)
+  R, r2, c, pitch, m = 1024, 4, 4096, 4096 + 64, 12288          # 48 x 4 tiles of 256 x 256, K = 16384
+  t = rng.integers(-4, 5, size=(R, r2, c)).astype(np.float32) / 8           # small dyadic values: exact in bf16
+  a = rng.integers(-4, 5, size=(m, r2, c), dtype=np.int8).astype(np.float32) / 8
+  with emulated_backend() as be:
+    padded_host = np.zeros((R * r2, pitch), dtype=np.float32)
+    padded_host[:, :c] = t.reshape(R * r2, c)
+    block = be.to_bfloat16(padded_host)
+    tp = DeviceTensor(block._block, (R, r2, c), _lib.BF16, 0, None, (2, pitch))   # pylint: disable=protected-access
+    np.testing.assert_array_equal(np.asarray(tp), t)
+    before, n_before = be.permute_launches, len(be.lib.calls)
+    out = be.tensordot(be.to_bfloat16(a), tp, [[1, 2], [1, 2]])                    # (m, R)
+    calls = [x for x in be.lib.calls[n_before:] if x[0] == "view_gemm"]
+    assert be.permute_launches == before and len(calls) == 1
+    assert calls[0][5] == (1, 0, pitch), calls                                      # b: sk0 = 1, one row level, sk1 = pitch
+    got = np.asarray(out)
+  ref = a.reshape(m, -1) @ t.reshape(R, -1).T                                       # f32, exact for these values up to 2^24
+  np.testing.assert_allclose(got, ref, rtol=2.0**-7, atol=2.0**-7)
