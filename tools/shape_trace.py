@@ -11,7 +11,7 @@ LOG = []
 
 class FakeTensor(device_tensor.DeviceTensor):
   def __init__(self, shape, code, alias=None):
-    self._shape = tuple(int(s) for s in shape); self._code = code; self._block = None; self._offset = 0; self._alias = None
+    self._shape = tuple(int(s) for s in shape); self._code = code; self._block = None; self._offset = 0; self._alias = None; self._pad = None
   @classmethod
   def empty(cls, shape, code, alias=None):
     return cls(shape, code)
