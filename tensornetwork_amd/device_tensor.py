@@ -338,11 +338,19 @@ class DeviceTensor:
         st[d] = st[d] // row * pitch
     return st
 
+  def _clone(self, shape, pad=None):
+    """Another view of the same block (the host dry-run tools subclass this)."""
+    return DeviceTensor(self._block, shape, self._code, self._offset, self._alias, pad)
+
+  def as_rows(self, rows, cols, pitch):
+    """This flat block seen as `rows` rows of `cols` elements lying `pitch` elements apart (a row-padded result)."""
+    return self._clone((rows, cols), (1, int(pitch)))
+
   def view(self, shape):
     """Metadata-only reshape sharing the device block."""
     shape = tuple(int(s) for s in shape)
     if self._pad is None:
-      return DeviceTensor(self._block, shape, self._code, self._offset, self._alias)
+      return self._clone(shape)
     # row-padded: the new shape has to keep the row boundary
     split, pitch = self._pad
     rows = math.prod(self._shape[:split])
@@ -355,7 +363,7 @@ class DeviceTensor:
         acc *= shape[i]
     if new_split is None or math.prod(shape) != self.size:
       raise ValueError(f"a row-padded tensor of shape {self._shape} (rows = axes [:{split}]) cannot be viewed as {shape}")
-    return DeviceTensor(self._block, shape, self._code, self._offset, self._alias, (new_split, pitch))
+    return self._clone(shape, (new_split, pitch))
 
   # -- host transfer -----------------------------------------------------------
   def numpy(self):

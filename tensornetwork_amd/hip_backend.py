@@ -214,13 +214,13 @@ class HipBackend(BackendBase):
 
   def _result_pitch(self, m, n, itemsize):
     """Row pitch (elements) of an m x n contraction result: n, or n + 64 when `pad_results` is on and the rows are
-    a power of two of 4 KiB or more in a result of `pad_min_bytes` or more.  Why: a later contraction that re-views
+    a power of two of 2 KiB or more in a result of `pad_min_bytes` or more.  Why: a later contraction that re-views
     such a result with rows of 1 MiB or more finds ALL its rows at the same offset modulo the pitch -- the same few
     HBM channels -- and runs at 850 TFLOP/s whatever the data (profiles/r03_gemm_epilogue.md section 5: 1.05-1.65
     PFLOP/s with 128 bytes of padding per row).  Off by default until it has been measured on the workload it is for
     (the chi = 32 MERA layer): TNH_PAD_RESULTS=1 or `be.pad_results = True`."""
     row_bytes = n * itemsize
-    if not self.pad_results or row_bytes < 4096 or row_bytes & (row_bytes - 1) or m * row_bytes < self.pad_min_bytes:
+    if not self.pad_results or row_bytes < 2048 or row_bytes & (row_bytes - 1) or m * row_bytes < self.pad_min_bytes:
       return n
     return n + 64
 
@@ -661,8 +661,7 @@ class HipBackend(BackendBase):
     if ldc == n:
       out = DeviceTensor.empty((m, n), out_code)
     else:
-      block = DeviceTensor.empty((m * ldc,), out_code)
-      out = DeviceTensor(block._block, (m, n), out_code, 0, None, (1, ldc))   # pylint: disable=protected-access
+      out = DeviceTensor.empty((m * ldc,), out_code).as_rows(m, n, ldc)
     events = getattr(self, "gemm_events", None)
     if events is not None:
       start = _lib.Event().record()

@@ -16,8 +16,10 @@ class FakeTensor(device_tensor.DeviceTensor):
   @classmethod
   def empty(cls, shape, code, alias=None):
     return cls(shape, code)
-  def view(self, shape):
-    return FakeTensor(shape, self._code)
+  def _clone(self, shape, pad=None):
+    t = FakeTensor(shape, self._code)
+    t._pad = pad
+    return t
   @property
   def ptr(self):
     return 0
@@ -50,6 +52,11 @@ class TraceBackend(hip_backend.HipBackend):
             alias=None):
     LOG.append(("gemm", int(trans_a), int(trans_b), m, n, k, batch))
     return FakeTensor(out_shape if out_shape is not None else (m, n), a.code)
+  def _dense(self, tensor):
+    if tensor.pad is None:
+      return tensor
+    LOG.append(("permute", tensor.shape, "dense copy of a padded result", tensor.size * 2))
+    return FakeTensor(tensor.shape, tensor.code)
   def _outer(self, a, b, out_shape, alias=None):
     return FakeTensor(out_shape, a.code)
   def _strided_copy(self, tensor, shape, strides, offset):
@@ -64,8 +71,10 @@ class TraceBackend(hip_backend.HipBackend):
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--chi", type=int, default=32)
+ap.add_argument("--pad", action="store_true", help="row-padded results on (HipBackend.pad_results)")
 a = ap.parse_args()
 be = TraceBackend()
+be.pad_results = a.pad
 chi = a.chi
 ham = FakeTensor((chi,) * 6, _lib.BF16)
 state = FakeTensor((chi,) * 6, _lib.BF16)

@@ -15,8 +15,10 @@ class FakeTensor(device_tensor.DeviceTensor):
   @classmethod
   def empty(cls, shape, code, alias=None):
     return cls(shape, code)
-  def view(self, shape):
-    return FakeTensor(shape, self._code)
+  def _clone(self, shape, pad=None):
+    t = FakeTensor(shape, self._code)
+    t._pad = pad
+    return t
   @property
   def ptr(self):
     return 0
