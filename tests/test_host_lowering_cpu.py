@@ -287,7 +287,11 @@ def _gpu_suite_selection():
           TW.test_config1_readme_ncon, TW.test_split_node_config3_small, TW.test_greedy_mps_chain_and_regular_graph,
           TW.test_json_network_from_reference_into_hbm,
           TK.test_gemm_view_absorbs_transposes_bit_exact, TK.test_gemm_view_falls_back_when_it_cannot_read_in_place,
-          TK.test_tensordot_random_axes_property, TK.test_misc_golden,
+          TK.test_tensordot_random_axes_property, TK.test_misc_golden, TK.test_tensordot_golden,
+          TK.test_tensordot_errors_and_empty, TK.test_elementwise_math, TK.test_init_functions, TK.test_casts,
+          TK.test_integer_tensordot_matmul_sum_trace_exact, TK.test_integer_arithmetic_follows_numpy_promotion,
+          TK.test_cast_refuses_to_drop_an_imaginary_part, TK.test_device_tensor_deepcopy_pickle_repr,
+          TK.test_slice_diagonal_diagflat_bit_exact, TK.test_permute_golden_bit_exact, TK.test_permute_all_perms_rank4,
           TK.test_narrow_and_unsigned_dtypes_behave_like_numpy,
           TK.test_narrow_integer_storage_is_normalised_where_arithmetic_is_not_modular]
 
