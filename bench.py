@@ -865,6 +865,115 @@ def partials_check(p_half, p_f32, n_roundings, half_bits=9, margin=3.0):
           "ok": bool(rms_rel <= margin * model)}
 
 
+COMPACT_LINE_LIMIT = 4096     # the driver's parser reads the LAST stdout line out of an 8 KB tail
+
+
+def _num(x, digits=4):
+  """a float rounded to `digits` significant digits (the detail file keeps full precision)"""
+  if isinstance(x, bool) or not isinstance(x, (int, float)):
+    return x
+  if isinstance(x, int) or x != x or x in (float("inf"), float("-inf")):
+    return x
+  return float(f"{x:.{digits}g}")
+
+
+def _pick(d, keys, digits=4):
+  if not isinstance(d, dict):
+    return None
+  if "error" in d:
+    return {"error": str(d["error"])[:120]}
+  return {k: _num(d[k], digits) for k in keys if k in d and d[k] is not None}
+
+
+def compact_line(result, detail_name):
+  """The ONE line the driver parses: every contract key, `roofline`, `cpu_baseline`, and a few numbers of each
+  secondary leg -- everything else lives in the detail file.  Kept under COMPACT_LINE_LIMIT bytes
+  (tests/test_host_lowering_cpu.py checks the length on the emulated backend)."""
+  line = {k: result.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step",
+                                     "higher_is_better", "scaling", "vs_baseline", "dtype", "data")}
+  line["value"], line["ms_per_step"] = _num(line["value"], 6), _num(line["ms_per_step"], 6)
+  cfg = dict(result.get("config") or {})
+  cfg["comm"] = str(cfg.get("comm", "none"))[:48]
+  line["config"] = cfg
+  roof = result.get("roofline") or {}
+  line["roofline"] = {k: _num(roof.get(k), 5) for k in (
+      "bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "algorithmic_bytes", "kernel",
+      "kernel_ms", "launches", "observed_clock_mhz", "board_power_w", "frac_at_observed_clock") if k in roof}
+  cpu = result.get("cpu_baseline")
+  if isinstance(cpu, dict):
+    line["cpu_baseline"] = {k: _num(cpu.get(k)) for k in ("value", "unit", "cores", "kind") if k in cpu}
+    if "error" in cpu:
+      line["cpu_baseline"]["error"] = str(cpu["error"])[:120]
+    if "sample" in cpu:
+      line["cpu_baseline"]["sample"] = str(cpu["sample"])[:160]
+  ver = result.get("verified")
+  if isinstance(ver, dict):
+    checks = {k: v for k, v in ver.items() if isinstance(v, dict)}
+    line["verified"] = {"all_ok": ver.get("all_ok"), "checks": len(checks),
+                        "failed": sorted(k for k, v in checks.items() if not v.get("ok", False))[:8]}
+  sweep = result.get("bond_sweep")
+  if isinstance(sweep, list):
+    # "D<bond><layout>": [TFLOP/s, K1 permute launches per contraction]
+    line["bond_sweep"] = {
+        f"D{r.get('D')}" + (str(r.get("layout"))[:2] if str(r.get("layout", ""))[:2] in ("L0", "L1") else "row"):
+            [_num(r.get("tflops")), r.get("permute_launches")] for r in sweep if isinstance(r, dict)}
+  elif isinstance(sweep, dict):
+    line["bond_sweep"] = _pick(sweep, ())
+  svd = result.get("svd")
+  if isinstance(svd, dict):
+    line["svd"] = _pick(svd, ("n", "k", "seconds", "gbps", "hbm_roofline_frac", "path"))
+    if isinstance(line["svd"], dict) and "error" not in line["svd"]:
+      rows = {}
+      for r in svd.get("sweep") or []:
+        if isinstance(r, dict) and r.get("input") in (None, "gauss") and r.get("order") in (None, "natural"):
+          rows[f"{r.get('dtype', 'f32')}_{r.get('n')}" + (f"_{r['mode']}" if r.get("mode") else "")] = _num(r.get("seconds"))
+      line["svd"]["seconds_by_case"] = rows
+      if isinstance(svd.get("bound"), dict):
+        line["svd"]["bound"] = _pick(svd["bound"], ("launches", "launch_floor_s", "update_bytes", "update_floor_s"))
+      if isinstance(svd.get("cpu_baseline"), dict):
+        line["svd"]["cpu_gbps"] = _num(svd["cpu_baseline"].get("value"))
+  line["sliced_network"] = _pick(result.get("sliced_network"),
+                                 ("n_slices", "n_gpus", "seconds", "tflops", "allreduce_seconds", "scaling", "collective",
+                                  "permute_time_frac"))
+  line["mera"] = _pick(result.get("mera"), ("chi", "seconds", "tflops", "permute_launches"))
+  line["mera_chi64"] = _pick(result.get("mera_chi64"),
+                             ("measured_seconds", "measured_slices", "measured_tflops", "layer_seconds_1gpu_extrapolated",
+                              "layer_seconds_8gpu_extrapolated", "tflops_1gpu"))
+  chain = result.get("mps_chain")
+  if isinstance(chain, list):
+    line["mps_chain_ms"] = {f"d{r.get('d')}": [_num(r.get("gpu_eager_ms")), _num(r.get("gpu_graph_replay_ms"))]
+                            for r in chain if isinstance(r, dict)}
+  line = {k: v for k, v in line.items() if v is not None or k == "vs_baseline"}
+  line["detail"] = detail_name
+  text = json.dumps(line, separators=(",", ":"))
+  for drop in ("mps_chain_ms", "mera_chi64", "bond_sweep", "mera", "sliced_network", "svd"):
+    if len(text) < COMPACT_LINE_LIMIT:
+      break
+    line.pop(drop, None)              # never reached at the bench's own sizes; the contract keys always fit
+    text = json.dumps(line, separators=(",", ":"))
+  return text
+
+
+def emit(result, args):
+  """Write the full record to the detail file(s) and print the compact line LAST on stdout."""
+  detail_name = "bench_detail.json" if args.gpus == 1 else f"bench_detail_n{args.gpus}.json"
+  targets = [os.path.join(ROOT, detail_name)]
+  scratch = os.path.join(ROOT, "gpurun_out")
+  try:
+    os.makedirs(scratch, exist_ok=True)
+    targets.append(os.path.join(scratch, detail_name))      # travels back from the GPU box with the call
+  except OSError:
+    pass
+  blob = json.dumps(result)
+  for path in targets:
+    try:
+      with open(path, "w") as f:
+        f.write(blob + "\n")
+    except OSError as exc:
+      print(f"[bench] could not write {path}: {exc}", file=sys.stderr)
+  print(compact_line(result, detail_name), flush=True)
+
+
 def fenced(result, key, fn):
   """every secondary leg is fenced: whatever happens in one of them, the headline line is printed"""
   try:
@@ -1038,7 +1147,7 @@ def main():
       ctypes.CDLL(None).fflush(None)
     except Exception:  # pylint: disable=broad-except
       pass
-    print(json.dumps(result), flush=True)
+    emit(result, args)
   if comm is not None:
     comm.barrier()
     comm.close()

@@ -330,7 +330,7 @@ def test_bench_svd_leg_runs_on_the_emulated_backend():
   assert check["ok"], check
 
 
-def test_bench_main_assembles_its_json_line_on_the_emulated_backend(monkeypatch, capsys):
+def test_bench_main_assembles_its_json_line_on_the_emulated_backend(monkeypatch, capsys, tmp_path):
   """bench.py end to end (headline leg with its value check, the sliced 64-node network, the MERA layer, roofline
   and verified objects) at toy sizes on the emulated backend: the control flow and the JSON contract of the line the
   driver parses -- the numbers themselves mean nothing here."""
@@ -345,18 +345,53 @@ def test_bench_main_assembles_its_json_line_on_the_emulated_backend(monkeypatch,
                                       "--no-extras", "--no-cpu-baseline"])
     for var in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
       monkeypatch.delenv(var, raising=False)
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))       # the detail file goes next to the (relocated) bench
     bench.main()
-  line = capsys.readouterr().out.strip().splitlines()[-1]
-  rec = json.loads(line)
+  out = capsys.readouterr().out.strip().splitlines()
+  line = out[-1]
+  assert len(out) == 1 and len(line.encode()) < 4096, len(line)      # the driver reads the LAST line of an 8 KB tail
+  head = json.loads(line)
   for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-              "vs_baseline", "dtype", "data", "config", "roofline", "verified", "sliced_network", "mera"):
-    assert key in rec, key
-  assert rec["n_gpus"] == 1 and rec["steps"] == 2 and rec["warmup"] == 1 and rec["dtype"] == "bf16"
-  assert rec["higher_is_better"] is True and rec["vs_baseline"] is None and "workload" in rec["config"]
-  assert set(rec["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
+              "vs_baseline", "dtype", "data", "config", "roofline", "verified", "sliced_network", "mera", "detail"):
+    assert key in head, key
+  assert head["n_gpus"] == 1 and head["steps"] == 2 and head["warmup"] == 1 and head["dtype"] == "bf16"
+  assert head["higher_is_better"] is True and head["vs_baseline"] is None and "workload" in head["config"]
+  assert set(head["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
+  assert set(head["verified"]) == {"all_ok", "checks", "failed"}
+  # everything else is in the detail file, written next to bench.py and into gpurun_out/ (which travels back)
+  for path in (tmp_path / head["detail"], tmp_path / "gpurun_out" / head["detail"]):
+    rec = json.loads(path.read_text())
+    assert rec["value"] == pytest.approx(head["value"], rel=1e-5) and rec["roofline"]["kernel"] == head["roofline"]["kernel"]
   assert rec["verified"]["headline_D16_L0"]["ok"] is True and rec["verified"]["mera_chi4_bf16_vs_f32"]["ok"] is True
   assert "sliced_network_bf16_vs_f32" in rec["verified"] and "all_ok" in rec["verified"]   # (the statistical model
   # behind the sliced check needs more than the 4 partials of a D = 2 toy network to hold: only its presence is asserted)
+
+
+def test_bench_compact_line_of_a_full_size_record_stays_under_the_parser_limit():
+  """the driver could not parse a 21 KB line.  The compact line of a REAL full-size record (round 3's
+  builder-side run, every leg present) must stay under 4 KB, parse, and carry the contract keys + roofline +
+  cpu_baseline; a record in which every secondary leg failed must too."""
+  import json  # pylint: disable=import-outside-toplevel
+  import os  # pylint: disable=import-outside-toplevel
+  import bench  # pylint: disable=import-outside-toplevel
+  path = os.path.join(os.path.dirname(__file__), "..", "profiles", "r03_bench_final.json")
+  full = json.loads(open(path).read().strip().splitlines()[-1])
+  assert len(json.dumps(full)) > 16000
+  text = bench.compact_line(full, "bench_detail.json")
+  assert len(text.encode()) < bench.COMPACT_LINE_LIMIT and "\n" not in text
+  head = json.loads(text)
+  for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+    assert key in head, key
+  assert set(head["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
+  assert set(head["cpu_baseline"]) >= {"value", "unit", "cores", "kind", "sample"}
+  assert head["verified"] == {"all_ok": True, "checks": 10, "failed": []}
+  assert head["bond_sweep"]["D512row"][1] == 1.0 and head["svd"]["seconds"] == pytest.approx(0.04169, rel=1e-3)
+  broken = dict(full)
+  for key in ("sliced_network", "bond_sweep", "mera", "mera_chi64", "svd", "cpu_baseline"):
+    broken[key] = {"error": "RuntimeError: " + "x" * 4000}
+  text = bench.compact_line(broken, "bench_detail.json")
+  assert len(text.encode()) < bench.COMPACT_LINE_LIMIT and json.loads(text)["svd"]["error"].startswith("RuntimeError")
 
 
 def test_row_padded_contraction_results_are_read_in_place_or_made_dense():
