@@ -77,8 +77,15 @@ def parse_args():
   p.add_argument("--no-verify", action="store_true", help="skip the value checks (verified object)")
   p.add_argument("--no-extras", action="store_true", help="skip mps_chain / mera_chi64 / helpers")
   p.add_argument("--mera-chi", type=int, default=32, help="bond dimension of the MERA layer network (0 = skip)")
-  p.add_argument("--comm", default=os.environ.get("TNH_BENCH_COMM", "rccl"), choices=["rccl", "torch"],
-                 help="N > 1: collectives through libtnhip's K8 entry points (default) or torch.distributed")
+  p.add_argument("--mera64-full", type=int, default=1, choices=[0, 1, 2],
+                 help="placements of the chi = 64 MERA layer run in FULL (4096 slices each, ~150 s per placement on one "
+                      "MI355X); the others are reported per slice x count")
+  p.add_argument("--mera64-budget", type=float, default=200.0, help="seconds after which a full placement stops early")
+  p.add_argument("--bringup-timeout", type=float, default=float(os.environ.get("TNH_BENCH_BRINGUP_TIMEOUT_S", "300")),
+                 help="N > 1: seconds the ranks get to rendezvous, create the RCCL communicator and pass the first "
+                      "barrier before the job is killed with a message (a hang inside RCCL must not become the record)")
+  p.add_argument("--job-timeout", type=float, default=float(os.environ.get("TNH_BENCH_JOB_TIMEOUT_S", "1500")),
+                 help="self-launched N > 1 jobs: seconds before the launcher kills every rank")
   p.add_argument("--fill", default="normal", choices=["normal", "zeros"],
                  help="operand fill (zeros shows the DVFS-inflated number; never the headline)")
   p.add_argument("--dry-run", action="store_true",
@@ -126,10 +133,29 @@ def self_launch(args):
                    "HSA_ENABLE_IPC_MODE_LEGACY", "0"))
     procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                   stdout=None if r == 0 else sys.stderr))
-  codes = [p.wait() for p in procs]
-  bad = {r: c for r, c in enumerate(codes) if c != 0}
-  if bad:
-    print(f"[bench] rank exit codes {bad}", file=sys.stderr, flush=True)
+  # Watch the ranks instead of waiting for them one by one: the first rank that fails takes the others down (they
+  # would otherwise sit in a collective for ever), and the whole job has a wall-clock limit.
+  deadline = time.monotonic() + args.job_timeout
+  codes = [None] * n
+  why = None
+  while any(c is None for c in codes):
+    for r, proc in enumerate(procs):
+      if codes[r] is None:
+        codes[r] = proc.poll()
+    failed = {r: c for r, c in enumerate(codes) if c not in (None, 0)}
+    if failed:
+      why = f"rank exit codes {failed}"
+    elif time.monotonic() > deadline:
+      why = f"job exceeded --job-timeout {args.job_timeout:.0f} s"
+    if why:
+      for r, proc in enumerate(procs):
+        if codes[r] is None:
+          proc.kill()
+          codes[r] = proc.wait()
+      break
+    time.sleep(0.05)
+  if why:
+    print(f"[bench] {why}; every rank stopped, no result line", file=sys.stderr, flush=True)
     return 1
   return 0
 
@@ -149,67 +175,40 @@ def dry_run(args, rank, world):
 
 
 # --------------------------------------------------------------------------- communicators
-class TorchComm:
-  """Fall-back communicator (--comm torch): torch.distributed process group, same method names as
-  tensornetwork_amd.comm.RcclComm.  torch's bundled HIP runtime has to come up before libtnhip.so,
-  which is why this one is built before the backend is touched."""
+class Watchdog:
+  """Bounded time for a step that can hang inside a collective (communicator bring-up, the first barrier): if the
+  block does not finish within `seconds`, say so on stderr and end THIS process with exit code 3 -- under torchrun
+  or `self_launch` the failing rank takes the job down, so a hang becomes a failed run with a message instead of a
+  driver-side timeout.  ctypes releases the GIL during library calls, so the timer thread runs while the main
+  thread is stuck in RCCL; `os._exit` because a normal exit would wait for the stuck call."""
 
-  def __init__(self, rank, world, local):
-    import torch  # pylint: disable=import-outside-toplevel
-    import torch.distributed as dist  # pylint: disable=import-outside-toplevel
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", "29511")
-    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    if os.environ["MASTER_ADDR"].startswith("127.") or os.environ["MASTER_ADDR"] in ("localhost", "::1"):
-      os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")   # see tensornetwork_amd.comm.single_node_rccl_env
-    torch.cuda.set_device(local)
-    dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
-    self._torch, self._dist = torch, dist
-    self.rank, self.world = rank, world
-    self._inner = None
+  def __init__(self, seconds, what, rank):
+    import threading  # pylint: disable=import-outside-toplevel
+    self._timer = threading.Timer(seconds, self._fire) if seconds and seconds > 0 else None
+    self._what, self._rank, self._seconds = what, rank, seconds
+    if self._timer is not None:
+      self._timer.daemon = True
 
-  def bind(self):
-    from tensornetwork_amd import distributed  # pylint: disable=import-outside-toplevel
-    self._inner = distributed.TorchDistComm()
+  def _fire(self):
+    print(f"[bench] rank {self._rank}: {self._what} did not finish within {self._seconds:.0f} s "
+          "(--bringup-timeout); stopping the job", file=sys.stderr, flush=True)
+    os._exit(3)  # pylint: disable=protected-access
 
-  def all_reduce_sum(self, backend, tensor):
-    return self._inner.all_reduce_sum(backend, tensor)
+  def __enter__(self):
+    if self._timer is not None:
+      self._timer.start()
+    return self
 
-  def all_gather_rows(self, backend, tensor, rows):
-    return self._inner.all_gather_rows(backend, tensor, rows)
-
-  def all_gather_counts(self, n):
-    return self._inner.all_gather_counts(n)
-
-  def barrier(self):
-    self._torch.cuda.synchronize()
-    self._dist.barrier()
-    self._torch.cuda.synchronize()
-
-  def max_over_ranks(self, value):
-    t = self._torch.tensor([value], dtype=self._torch.float64, device="cuda")
-    self._dist.all_reduce(t, op=self._dist.ReduceOp.MAX)
-    return float(t.item())
-
-  def close(self):
-    self._dist.barrier()
-    self._dist.destroy_process_group()
+  def __exit__(self, *exc):
+    if self._timer is not None:
+      self._timer.cancel()
+    return False
 
 
 def make_rccl_comm(tcomm, be, rank, world):
-  """K8 communicator, with a coordinated way out: if ANY rank cannot create it (no librccl, id exchange
-  failed, ncclCommInitRank error) every rank re-executes this script with --comm torch, so the job still
-  reports a number -- and says which communicator produced it (config.communicator)."""
-  try:
-    return tcomm.RcclComm(be, rank=rank, world=world)   # raises on every rank if it fails on any
-  except Exception as exc:  # pylint: disable=broad-except
-    why = f"{type(exc).__name__}: {exc}"
-  if rank == 0:
-    print(f"[bench] RCCL communicator unavailable ({why}); re-running with --comm torch", file=sys.stderr, flush=True)
-  if os.environ.get("TNH_BENCH_NO_REEXEC"):
-    raise RuntimeError("RCCL communicator unavailable and TNH_BENCH_NO_REEXEC is set")
-  os.environ["TNH_BENCH_NO_REEXEC"] = "1"
-  os.execv(sys.executable, [sys.executable] + sys.argv + ["--comm", "torch"])
+  """K8 communicator (the only one: RCCL through libtnhip's C ABI).  A rank that cannot create it raises on EVERY
+  rank (lock-step bootstrap, comm.py) and the job ends with a message -- no second communicator to fall back on."""
+  return tcomm.RcclComm(be, rank=rank, world=world)
 
 
 def sync_all(be, comm):
@@ -408,6 +407,7 @@ def svd_sweep(ta, be, n_max, verify):
         t0 = time.perf_counter()
         s_ref = np.linalg.svd(mat_host, compute_uv=False)
         t_lapack += time.perf_counter() - t0
+        _S_REF[(kind, n)] = s_ref          # the call-shape rows below re-use the same matrices
       for order in ("natural", "mixed"):
         rec, out = svd_case(ta, be, mat, n, k, order)
         rec["input"] = kind
@@ -439,6 +439,71 @@ def svd_sweep(ta, be, n_max, verify):
                        "(||A - L R||_F - best rank-k) <= 1e-4 ||A||_F",
                 "ok": bool(all(checks.values()))}
   return headline, rows, verified
+
+
+_S_REF = {}
+
+
+def svd_wide_rows(ta, be, n_max, verify):
+  """The call shapes beyond `max_singular_values` alone, one row each at the bench's size:
+  truncation error alone (k picked on the host from the values), the full SVD of split_node_full_svd, a side that is
+  not a multiple of the 16-wide panels, and float64 -- each timed like the sweep's rows (best of three after a warm-up
+  call) and checked against LAPACK on ALL values plus the residual |A v - s u| of the kept triplets."""
+  rows = []
+  n = min(n_max, 4096)
+
+  def run(mode, kind, mat, call, dtype="f32", tol=1e-5):
+    best, out, samples = float("inf"), None, []
+    for rep in range(4):
+      be.synchronize()
+      t0 = time.perf_counter()
+      res = call(mat)
+      be.synchronize()
+      t = time.perf_counter() - t0
+      if rep >= 1:
+        samples.append(t * 1e3)
+        if t < best:
+          best, out = t, res
+    u, sv, vh, rest = out
+    m_, n_ = mat.shape
+    k = int(sv.shape[0])
+    item = 8 if dtype == "f64" else 4
+    nbytes = item * (m_ * n_ + m_ * k + min(m_, n_) + k * n_)
+    rec = {"n": int(min(m_, n_)), "k": k, "mode": mode, "dtype": dtype, "order": "natural", "input": kind,
+           "seconds": best, "gbps": nbytes / best / 1e9, "algorithmic_bytes": nbytes, "samples_ms": samples,
+           "path": getattr(be, "last_svd_path", None)}
+    if verify:
+      a = host64(mat)
+      s_ref = _S_REF.get((kind, m_)) if m_ == n_ else None
+      if s_ref is None:
+        s_ref = np.linalg.svd(a, compute_uv=False)
+      s_all = np.concatenate([host64(sv).reshape(-1), host64(rest).reshape(-1)])
+      uu, vv = host64(u).reshape(m_, k), host64(vh).reshape(k, n_)
+      chk = {"s_max_err_over_s0": float(np.max(np.abs(s_all - s_ref)) / s_ref[0]),
+             "orth_u": float(np.max(np.abs(uu.T @ uu - np.eye(k)))), "orth_vh": float(np.max(np.abs(vv @ vv.T - np.eye(k)))),
+             "triplet_resid_over_s0": float(np.max(np.linalg.norm(a @ vv.T - uu * s_all[:k], axis=0)) / s_ref[0])}
+      chk["ok"] = bool(chk["s_max_err_over_s0"] <= tol and chk["orth_u"] <= 10 * tol and chk["orth_vh"] <= 10 * tol
+                       and chk["triplet_resid_over_s0"] <= 4 * tol and s_all.shape == s_ref.shape)
+      rec["check"] = chk
+    rows.append(rec)
+
+  g = svd_case_matrix(be, n, "graded", seed=3 + n)            # s_i = 2^(-i/32): the tail norm picks k ~ n / 16
+  err = 2.0 ** (-(n // 16) / 32.0) * 4.7
+  run("err_only", "graded", g, lambda x: be.svd(x, 1, max_truncation_error=err, relative=True))
+  del g
+  nf = min(n, 2048)
+  a = svd_case_matrix(be, nf, "gauss", seed=3 + nf)
+  run("full", "gauss", a, lambda x: be.svd(x, 1))
+  del a
+  nodd = nf - 48 + 8                                            # 2008 = 16 * 125 + 8: padded to the 16-wide panels
+  a = svd_case_matrix(be, nodd, "gauss", seed=3 + nodd)
+  run("pad16", "gauss", a, lambda x: be.svd(x, 1, max_singular_values=nodd // 16))
+  del a
+  a64 = be.cast(svd_case_matrix(be, n, "gauss", seed=3 + n), np.float64)       # the sweep's Gaussian matrix, in f64
+  run("max_sv", "gauss", a64, lambda x: be.svd(x, 1, max_singular_values=n // 16), dtype="f64", tol=1e-9)
+  del a64
+  be.lib.tnh_trim()
+  return rows
 
 
 def svd_cpu_baseline(n_full):
@@ -753,14 +818,22 @@ def verify_mera(ta, be, chi=16):
           "ok": bool(rel32 <= 1e-3 and rel16 <= 1e-1)}
 
 
-def mera_chi64_bench(ta, be, n_gpus=8, verify=False):
+def mera_chi64_bench(ta, be, n_gpus=8, verify=False, full_placements=0, budget_s=200.0, chi=64):
   from tensornetwork_amd import workloads  # pylint: disable=import-outside-toplevel
-  per = workloads.mera_sliced_sample(be, 64, ta.bfloat16, reps=2)
+  per = workloads.mera_sliced_sample(be, chi, ta.bfloat16, reps=2)
+  measured = {}
+  for pl in ("left", "right")[:max(0, int(full_placements))]:
+    # the placement as a RUN: all chi^2 slices through the path, partials added on the device
+    run = workloads.mera_sliced_run(be, chi, pl, ta.bfloat16, budget_seconds=budget_s, check_every=1024 if verify else 0)
+    if verify and run["checks"]:
+      chk = partials_check([[c[1]] for c in run["checks"]], [[c[2]] for c in run["checks"]], 11)
+      run["checks_vs_f32"] = {k: chk[k] for k in ("n_values", "rms_rel_err", "model_rms", "err_over_tol", "ok")}
+    measured[pl] = run
   checked = None
   if verify:
     # four REAL slices per placement of one chi = 64-consistent network (tensors defined slice-wise along the cut
     # legs = slice_edge semantics), bf16 vs f32 on the same values, a-priori rounding bound per slice
-    vals = workloads.mera_slice_values(be, 64, [(0, 0), (1, 5), (17, 3), (63, 62)], ta.bfloat16)
+    vals = workloads.mera_slice_values(be, chi, [(0, 0), (1, 5), (17 % chi, 3), (chi - 1, chi - 2)], ta.bfloat16)
     rows, p16, p32 = [], [], []
     for pl, v in vals.items():
       for r in v["rows"]:
@@ -771,62 +844,90 @@ def mera_chi64_bench(ta, be, n_gpus=8, verify=False):
     checked["slices"] = rows
   total = sum(v["sec_per_slice"] * v["n_slices"] for v in per.values())
   flops = sum(2.0 * v["macs_per_slice"] * v["n_slices"] for v in per.values())
-  return {"workload": "binary-MERA layer energy at chi = 64, bf16: two cut bonds per placement -> 4096 slices each "
-                      "(the dense network needs 137 GB rank-6 inputs and chi^7 intermediates)",
-          "placements": per, "flops_total": flops,
-          "layer_seconds_1gpu_extrapolated": total, f"layer_seconds_{n_gpus}gpu_extrapolated": total / n_gpus,
-          "tflops_1gpu": flops / total / 1e12,
-          "label": "EXTRAPOLATED: measured seconds per slice (one slice per placement, best of 3) x slice count; "
-                   "slices are independent, one scalar all-reduce at the end",
-          **({"verified": checked} if checked is not None else {})}
+  rec = {"workload": f"binary-MERA layer energy at chi = {chi}, bf16: two cut bonds per placement -> {chi * chi} slices each "
+                     "(the dense network needs 137 GB rank-6 inputs and chi^7 intermediates)",
+         "placements": per, "flops_total": flops,
+         "layer_seconds_1gpu_extrapolated": total, f"layer_seconds_{n_gpus}gpu_extrapolated": total / n_gpus,
+         "tflops_1gpu": flops / total / 1e12,
+         "label": "EXTRAPOLATED rows: measured seconds per slice (one slice per placement, best of 3) x slice count; "
+                  "slices are independent, one scalar all-reduce at the end"}
+  if measured:
+    done = sum(m["slices_done"] for m in measured.values())
+    secs = sum(m["seconds"] for m in measured.values())
+    rec["measured"] = measured
+    rec["measured_slices"] = done
+    rec["measured_seconds"] = secs
+    rec["measured_tflops"] = sum(2.0 * m["macs_per_slice"] * m["slices_done"] for m in measured.values()) / secs / 1e12
+    complete = all(m["slices_done"] == m["n_slices"] for m in measured.values())
+    rec["measured_label"] = (f"MEASURED on 1 GPU: {len(measured)} of 2 placements run slice by slice "
+                             f"({done} slices{'' if complete else ', stopped by the time budget'}); the 8-GPU figure "
+                             "stays arithmetic (no 8-GPU node on the builder's side)")
+    if verify:
+      rec.setdefault("verified_runs", {pl: m.get("checks_vs_f32") for pl, m in measured.items()})
+  if checked is not None:
+    rec["verified"] = checked
+  return rec
 
 
 # --------------------------------------------------------------------------- helper kernels
 def helpers_bench(ta, be):
-  """HBM-bound helper kernels at the shapes the BASELINE configs produce; GB/s = algorithmic bytes / time."""
+  """HBM-bound helper kernels at the shapes the BASELINE configs produce; GB/s = algorithmic bytes / time.
+
+  Every row ROTATES over enough distinct input buffers, and keeps as many results alive, that the bytes touched
+  between two uses of the same buffer exceed 1 GiB = 4x the 256 MiB Infinity Cache (the round-3
+  rows re-ran one 67 MB input with a recycled output block -- those were Infinity-Cache rates, not HBM rates)."""
+  from tensornetwork_amd import _lib  # pylint: disable=import-outside-toplevel
   rows = []
 
-  def add(name, fn, nbytes, reps=10):
-    fn()
+  def add(name, make, op, nbytes, touched, reps=3):
+    n_buf = max(2, -(-(1 << 30) // touched))
+    xs = [make(i) for i in range(n_buf)]
+    outs = [op(x) for x in xs]            # warm-up; the results stay alive: every call of a rotation writes its own block
     be.synchronize()
-    from tensornetwork_amd import _lib  # pylint: disable=import-outside-toplevel
     s = _lib.Event().record()
     for _ in range(reps):
-      out = fn()
-      del out
+      for i, x in enumerate(xs):
+        outs[i] = None                    # back to the pool just before the call that takes a block of this size again
+        outs[i] = op(x)
     e = _lib.Event().record()
     e.synchronize()
-    ms = s.elapsed_ms(e) / reps
+    ms = s.elapsed_ms(e) / (reps * n_buf)
     rows.append({"op": name, "ms": ms, "algorithmic_bytes": nbytes, "gbps": nbytes / ms / 1e6,
-                 "hbm_roofline_frac": nbytes / ms / 1e6 / HBM_PEAK_GBPS})
+                 "hbm_roofline_frac": nbytes / ms / 1e6 / HBM_PEAK_GBPS, "buffers": n_buf,
+                 "bytes_between_reuse": n_buf * touched})
+    del xs, outs
+    _lib.check(be.lib.tnh_trim())
 
-  x = be.device_random((16,) * 6, dtype=np.float32, seed=41)
-  add("K1 permute f32 (16,)*6 -> (0,2,4,1,3,5)  [configs[2] mixed edge order]", lambda: be.transpose(x, (0, 2, 4, 1, 3, 5)),
-      2 * x.nbytes)
-  del x
-  x = be.device_random((128,) * 4, dtype=ta.bfloat16, seed=42)
-  add("K1 permute bf16 (128,)*4 -> (0,2,1,3)  [configs[1] L1 operand, D = 128]", lambda: be.transpose(x, (0, 2, 1, 3)),
-      2 * x.nbytes)
-  add("K1 permute bf16 (128,)*4 -> (2,3,0,1)  [[K][N] -> [N][K]]", lambda: be.transpose(x, (2, 3, 0, 1)), 2 * x.nbytes)
-  del x
-  x = be.device_random((4096, 4096, 16), dtype=np.float32, seed=43)
-  add("K4 sum f32 (4096,4096,16) over axis 1", lambda: be.sum(x, axis=1), x.nbytes + x.nbytes // 4096)
-  add("K4 sum f32 (4096,4096,16) over all axes", lambda: be.sum(x), x.nbytes)
-  del x
-  x = be.device_random((4096, 256, 256), dtype=np.float32, seed=44)
-  add("K3 trace f32 (4096,256,256) over the last two axes", lambda: be.trace(x), 4096 * 256 * 4 + 4096 * 4)
+  f32_16_6 = 4 * 16 ** 6
+  add("K1 permute f32 (16,)*6 -> (0,2,4,1,3,5)  [configs[2] mixed edge order]",
+      lambda i: be.device_random((16,) * 6, dtype=np.float32, seed=41 + i),
+      lambda x: be.transpose(x, (0, 2, 4, 1, 3, 5)), 2 * f32_16_6, 2 * f32_16_6)
+  bf16_128_4 = 2 * 128 ** 4
+  mk = lambda i: be.device_random((128,) * 4, dtype=ta.bfloat16, seed=52 + i)      # noqa: E731
+  add("K1 permute bf16 (128,)*4 -> (0,2,1,3)  [configs[1] L1 operand, D = 128]", mk,
+      lambda x: be.transpose(x, (0, 2, 1, 3)), 2 * bf16_128_4, 2 * bf16_128_4)
+  add("K1 permute bf16 (128,)*4 -> (2,3,0,1)  [[K][N] -> [N][K]]", mk,
+      lambda x: be.transpose(x, (2, 3, 0, 1)), 2 * bf16_128_4, 2 * bf16_128_4)
+  big = 4 * 4096 * 4096 * 16
+  mk = lambda i: be.device_random((4096, 4096, 16), dtype=np.float32, seed=63 + i)  # noqa: E731
+  add("K4 sum f32 (4096,4096,16) over axis 1", mk, lambda x: be.sum(x, axis=1), big + big // 4096, big)
+  add("K4 sum f32 (4096,4096,16) over all axes", mk, lambda x: be.sum(x), big, big)
+  tr = 4 * 4096 * 256 * 256
+  add("K3 trace f32 (4096,256,256) over the last two axes",
+      lambda i: be.device_random((4096, 256, 256), dtype=np.float32, seed=74 + i), lambda x: be.trace(x),
+      4096 * 256 * 4 + 4096 * 4, 4096 * 256 * 128)
   # a diagonal element sits alone in its 128-byte line (stride 257 floats): the memory system moves a line per element
   rows[-1]["line_granular_bytes"] = 4096 * 256 * 128 + 4096 * 4
   rows[-1]["line_granular_gbps"] = rows[-1]["line_granular_bytes"] / rows[-1]["ms"] / 1e6
   rows[-1]["note"] = "gbps counts the 4 useful bytes per diagonal element; line_granular_gbps the 128-byte lines they arrive in"
-  del x
-  x = be.device_random((4096, 4096), dtype=np.float32, seed=45)
+  sq = 4 * 4096 * 4096
+  mk = lambda i: be.device_random((4096, 4096), dtype=np.float32, seed=85 + i)     # noqa: E731
   v = be.device_random((4096,), dtype=np.float32, seed=46)
-  add("K5 broadcast_right_multiplication f32 4096^2 x (4096,)  [u sqrt(s)]", lambda: be.broadcast_right_multiplication(x, v),
-      2 * x.nbytes)
-  add("K5 broadcast_left_multiplication f32 (4096,) x 4096^2  [sqrt(s) vh]", lambda: be.broadcast_left_multiplication(v, x),
-      2 * x.nbytes)
-  add("K6 sqrt f32 4096^2", lambda: be.sqrt(x), 2 * x.nbytes)
+  add("K5 broadcast_right_multiplication f32 4096^2 x (4096,)  [u sqrt(s)]", mk,
+      lambda x: be.broadcast_right_multiplication(x, v), 2 * sq, 2 * sq)
+  add("K5 broadcast_left_multiplication f32 (4096,) x 4096^2  [sqrt(s) vh]", mk,
+      lambda x: be.broadcast_left_multiplication(v, x), 2 * sq, 2 * sq)
+  add("K6 sqrt f32 4096^2", mk, lambda x: be.sqrt(x), 2 * sq, 2 * sq)
   return rows
 
 
@@ -925,8 +1026,9 @@ def compact_line(result, detail_name):
     if isinstance(line["svd"], dict) and "error" not in line["svd"]:
       rows = {}
       for r in svd.get("sweep") or []:
-        if isinstance(r, dict) and r.get("input") in (None, "gauss") and r.get("order") in (None, "natural"):
-          rows[f"{r.get('dtype', 'f32')}_{r.get('n')}" + (f"_{r['mode']}" if r.get("mode") else "")] = _num(r.get("seconds"))
+        if isinstance(r, dict) and (r.get("mode") or r.get("input") in (None, "gauss")) and r.get("order") in (None, "natural"):
+          rows[f"{r.get('dtype', 'f32')}_{r.get('n')}" + (f"_{r['mode']}" if r.get("mode") else "")] = \
+              [_num(r.get("seconds")), "b" if str(r.get("path", "")).startswith("band") else "j"]
       line["svd"]["seconds_by_case"] = rows
       if isinstance(svd.get("bound"), dict):
         line["svd"]["bound"] = _pick(svd["bound"], ("launches", "launch_floor_s", "update_bytes", "update_floor_s"))
@@ -1007,9 +1109,6 @@ def main():
   elif visible_gpus() <= local:
     sys.exit(f"[bench] rank {rank}: LOCAL_RANK {local} has no device (visible: {visible_gpus()})")
   comm, comm_name = None, "none"
-  if use_dist and args.comm == "torch":
-    comm = TorchComm(rank, world, local)      # torch's HIP runtime first (see TorchComm)
-    comm_name = "torch.distributed (nccl = RCCL)"
   os.environ.setdefault("TNHIP_DEVICE", str(local))
   import tensornetwork_amd as ta  # pylint: disable=import-outside-toplevel
   from tensornetwork_amd import _lib, telemetry  # pylint: disable=import-outside-toplevel
@@ -1017,12 +1116,12 @@ def main():
   ta.configure_gc(freeze=True)      # this process is ours: opt in to the frozen-baseline collector policy
   be = ta.get_hip_backend()
   be.lib  # pylint: disable=pointless-statement
-  if use_dist and args.comm == "rccl":
+  if use_dist:
     from tensornetwork_amd import comm as tcomm  # pylint: disable=import-outside-toplevel
-    comm = make_rccl_comm(tcomm, be, rank, world)
+    with Watchdog(args.bringup_timeout, "RCCL bring-up (rendezvous, ncclCommInitRank, first barrier)", rank):
+      comm = make_rccl_comm(tcomm, be, rank, world)
+      sync_all(be, comm)
     comm_name = "libtnhip K8 (tnh_allreduce / tnh_allgather over RCCL), TCP rendezvous for the id"
-  elif comm is not None:
-    comm.bind()
 
   D = args.bond
   M = N = K = D * D
@@ -1114,7 +1213,8 @@ def main():
         verified[f"mera_chi{args.mera_chi}_bf16_vs_f32"] = result["mera"].pop("verified")
       _lib.check(be.lib.tnh_trim())
     if single and not args.no_extras:
-      fenced(result, "mera_chi64", lambda: mera_chi64_bench(ta, be, verify=not args.no_verify))
+      fenced(result, "mera_chi64", lambda: mera_chi64_bench(ta, be, verify=not args.no_verify,
+                                                            full_placements=args.mera64_full, budget_s=args.mera64_budget))
       if isinstance(result["mera_chi64"], dict) and "verified" in result["mera_chi64"]:
         verified["mera_chi64_real_slices_bf16_vs_f32"] = result["mera_chi64"].pop("verified")
       _lib.check(be.lib.tnh_trim())
@@ -1128,6 +1228,15 @@ def main():
         result["svd"]["sweep"] = rows
         if chk is not None:
           verified["svd"] = chk
+        try:
+          wide = svd_wide_rows(ta, be, args.svd_n, not args.no_verify)
+          result["svd"]["sweep"] = rows + wide
+          if not args.no_verify:
+            verified["svd_call_shapes"] = {"cases": {f"{r['dtype']}_{r['mode']}_{r['n']}": r["check"]["ok"] for r in wide},
+                                           "paths": {f"{r['dtype']}_{r['mode']}_{r['n']}": r["path"] for r in wide},
+                                           "ok": bool(all(r["check"]["ok"] for r in wide))}
+        except Exception as exc:  # pylint: disable=broad-except
+          result["svd"]["call_shapes_error"] = f"{type(exc).__name__}: {exc}"
         if not args.no_cpu_baseline:
           result["svd"]["cpu_baseline"] = svd_cpu_baseline(args.svd_n)
       except Exception as exc:  # pylint: disable=broad-except
@@ -1139,8 +1248,7 @@ def main():
     if verified:
       verified["all_ok"] = bool(all(v.get("ok", False) for v in verified.values() if isinstance(v, dict)))
       result["verified"] = verified
-    # the JSON line must be the LAST thing on stdout: drain whatever C libraries (RCCL's version banner under
-    # --comm torch) still hold in their stdio buffers first
+    # the JSON line must be the LAST thing on stdout: drain whatever C libraries still hold in their stdio buffers first
     sys.stdout.flush()
     try:
       import ctypes  # pylint: disable=import-outside-toplevel

@@ -38,7 +38,8 @@ typedef enum {
   TNH_ERR_UNSUPPORTED = -3,  /* valid request this build has no kernel for      */
   TNH_ERR_NOMEM = -4,        /* device allocation failed                        */
   TNH_ERR_NOT_INIT = -5,     /* tnh_init has not been called                    */
-  TNH_ERR_NO_CONVERGE = -6   /* iterative kernel (SVD) hit its sweep limit      */
+  TNH_ERR_NO_CONVERGE = -6,  /* iterative kernel (SVD) hit its sweep limit      */
+  TNH_ERR_TIMEOUT = -7       /* a collective bring-up did not finish in time    */
 } tnh_status;
 
 /* ------------------------------------------------------------------ dtypes */
@@ -310,7 +311,10 @@ int tnh_svd_vectors_topk(int dtype, int64_t m, int64_t n, const void* A,
  * slicing on T = B^T B in f64 (Sturm counts from the un-pivoted LDL^T, 16-lane groups), (3) the k leading
  * vectors by inverse iteration on the band and back-transformation.  The work a call does is independent of
  * the spectrum.
- *   kcap   : largest k the work buffer is sized for (the caller's max_singular_values).
+ *   kcap   : largest k the work buffer is sized for (the caller's max_singular_values; min(m, n) when the
+ *            caller only knows k after it has seen the values, i.e. max_truncation_error alone).
+ *   S_kept : device f32[k] or NULL -- the k kept values again, from the brackets the vectors stage refines to
+ *            2^-32 sigma_max (tnh_svd_band_factor's S carries 20 bits per value: 5e-7 sigma_max).
  *   status : host int (may be NULL = no read-back); non-zero bits mean the result must NOT be used and the
  *            caller re-runs tnh_svd_factor: 1 rank-deficient panel, 2 (unused), 4 clustered kept values,
  *            8 band residual, 16 a kept value below 1e-6 of the largest.
@@ -321,7 +325,7 @@ int tnh_svd_band_work_bytes(int64_t m, int64_t n, int64_t kcap, size_t* nbytes);
 int tnh_svd_band_layout(int64_t m, int64_t n, int64_t kcap, int64_t* offsets, int count);
 int tnh_svd_band_factor(int64_t m, int64_t n, const void* A, void* S, void* work, int64_t kcap, int* status_out);
 int tnh_svd_band_vectors(int64_t m, int64_t n, void* work, int64_t kcap, int64_t k, void* U, void* Vh,
-                         int* status_out);
+                         void* S_kept, int* status_out);
 
 /* The block pairs (32-row blocks a < b ... or a in one part, b in another) of ONE sweep of the block Jacobi
  * in launch order, for `nb` blocks and `groups` = 1 (circle method), 2 or 4 (grouped schedule: the groups of a
@@ -337,7 +341,9 @@ int tnh_svd_block_schedule(int nb, int groups, int32_t* pairs_out, int* rounds_o
  * Replaces AbstractBackend.qr / rq (abstract_backend.py:139-153; oracle
  * backends/numpy/decompositions.py:77-124, np.linalg.qr in 'reduced' mode); the
  * non_negative_diagonal phase fix and the rq transposes stay on the host side of
- * the boundary, as in the reference. */
+ * the boundary, as in the reference.
+ * f32 with m >= n >= 64, n % 16 == 0 runs on K7b's 16-wide panel kernels and reads ONE status word back (a
+ * stream synchronisation per call); inside tnh_graph_begin / tnh_graph_end that path is not taken. */
 int tnh_qr_work_bytes(int dtype, int64_t m, int64_t n, size_t* nbytes);
 int tnh_qr(int dtype, int64_t m, int64_t n, const void* A, void* Q, void* R,
            void* work);
@@ -356,6 +362,9 @@ int tnh_qr(int dtype, int64_t m, int64_t n, const void* A, void* Q, void* R,
  * exchange this BEFORE the collective ncclCommInitRank, so that one rank's local failure is seen by all. */
 int tnh_comm_available(void);
 int tnh_comm_unique_id(void* host_id);
+/* Collective over all ranks.  Bounded: ncclCommInitRank runs on a helper thread and the call returns
+ * TNH_ERR_TIMEOUT after TNH_COMM_INIT_TIMEOUT_S seconds (environment; default 180, 0 = no limit) -- the helper is
+ * then still inside RCCL and the process should report and exit (os._exit: a normal exit may wait for it). */
 int tnh_comm_init(const void* host_id, int rank, int world);
 /* *world = 0 when no communicator exists. */
 int tnh_comm_info(int* rank, int* world);

@@ -18,7 +18,7 @@ class HipRuntimeError(RuntimeError):
 
 # tnh_status (include/tnh.h)
 OK, ERR_HIP, ERR_INVALID, ERR_UNSUPPORTED, ERR_NOMEM, ERR_NOT_INIT, \
-    ERR_NO_CONVERGE = 0, -1, -2, -3, -4, -5, -6
+    ERR_NO_CONVERGE, ERR_TIMEOUT = 0, -1, -2, -3, -4, -5, -6, -7
 
 # tnh_dtype
 F32, F64, BF16, F16, C64, C128, I32, I64 = range(8)
@@ -116,7 +116,7 @@ SIGNATURES = {
     "tnh_svd_band_work_bytes": (c_int, [c_int64, c_int64, c_int64, POINTER(c_size_t)]),
     "tnh_svd_band_layout": (c_int, [c_int64, c_int64, c_int64, _I64P, c_int]),
     "tnh_svd_band_factor": (c_int, [c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_int64, POINTER(c_int)]),
-    "tnh_svd_band_vectors": (c_int, [c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_void_p,
+    "tnh_svd_band_vectors": (c_int, [c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p,
                                      POINTER(c_int)]),
     "tnh_qr_work_bytes": (c_int, [c_int, c_int64, c_int64, POINTER(c_size_t)]),
     "tnh_qr": (c_int, [c_int, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
@@ -174,6 +174,8 @@ def check(status, what=""):
     raise NotImplementedError(msg)
   if status == ERR_NOMEM:
     raise MemoryError(msg)
+  if status == ERR_TIMEOUT:
+    raise TimeoutError(msg)
   raise HipRuntimeError(msg)
 
 

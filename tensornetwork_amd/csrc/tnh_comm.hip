@@ -15,7 +15,13 @@
 // MASTER_ADDR:MASTER_PORT+k); every rank then calls tnh_comm_init.
 #include "tnh_internal.h"
 #include <dlfcn.h>
+#include <stdlib.h>
 #include <unistd.h>
+#include <chrono>
+#include <condition_variable>
+#include <memory>
+#include <mutex>
+#include <thread>
 #if __has_include(<rccl/rccl.h>)
 #include <rccl/rccl.h>
 #else
@@ -153,12 +159,58 @@ int tnh_comm_init(const void* host_id, int rank, int world) {
   fflush(stdout);
   const int saved_stdout = dup(STDOUT_FILENO);
   if (saved_stdout >= 0) dup2(STDERR_FILENO, STDOUT_FILENO);
-  const ncclResult_t init_rc = g_api.CommInitRank(&g_comm, world, id, rank);
+  // Bounded bring-up (round 4): ncclCommInitRank is collective and has no timeout of its own -- a peer that never
+  // arrives, or a bootstrap interface that does not route (measured on the GPU box: no return within 150 s), blocks
+  // it for good.  It runs on a helper thread; this thread waits TNH_COMM_INIT_TIMEOUT_S seconds (default 180; 0 =
+  // wait for ever, the old behaviour).  On a timeout the call returns TNH_ERR_TIMEOUT and the helper is left behind,
+  // still inside RCCL (there is no communicator handle to abort yet): the process is expected to report and exit.
+  struct InitState {
+    std::mutex mu;
+    std::condition_variable cv;
+    bool done = false;
+    ncclResult_t rc = ncclSuccess;
+    ncclComm_t comm = nullptr;
+  };
+  auto st = std::make_shared<InitState>();
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  double limit_s = 180.0;
+  if (const char* e = getenv("TNH_COMM_INIT_TIMEOUT_S")) limit_s = atof(e);
+  auto fn = g_api.CommInitRank;
+  std::thread helper([st, fn, id, world, rank, dev]() {
+    (void)hipSetDevice(dev);                       // the current device is per thread
+    ncclComm_t c = nullptr;
+    const ncclResult_t r = fn(&c, world, id, rank);
+    std::lock_guard<std::mutex> lk(st->mu);
+    st->rc = r;
+    st->comm = c;
+    st->done = true;
+    st->cv.notify_all();
+  });
+  bool finished;
+  {
+    std::unique_lock<std::mutex> lk(st->mu);
+    if (limit_s > 0.0)
+      finished = st->cv.wait_for(lk, std::chrono::duration<double>(limit_s), [&] { return st->done; });
+    else {
+      st->cv.wait(lk, [&] { return st->done; });
+      finished = true;
+    }
+  }
   fflush(stdout);
   if (saved_stdout >= 0) {
     dup2(saved_stdout, STDOUT_FILENO);
     close(saved_stdout);
   }
+  if (!finished) {
+    helper.detach();
+    set_error("ncclCommInitRank did not return within %.0f s on rank %d of %d (TNH_COMM_INIT_TIMEOUT_S): a peer is "
+              "missing or RCCL's bootstrap interface does not route (NCCL_SOCKET_IFNAME)", limit_s, rank, world);
+    return TNH_ERR_TIMEOUT;
+  }
+  helper.join();
+  const ncclResult_t init_rc = st->rc;
+  g_comm = st->comm;
   if (init_rc != ncclSuccess) {
     g_comm = nullptr;
     set_error("ncclCommInitRank failed: %s", g_api.GetErrorString(init_rc));

@@ -1078,8 +1078,11 @@ int tnh_gemm_ex(int in_dtype, int out_dtype, int transA, int transB, int64_t M, 
     }
     int rc = g_split_flag ? tnh_malloc(&A3, (size_t)M * 6 * Kp * 2) : TNH_ERR_NOMEM;
     if (!rc) rc = tnh_malloc(&B3, (size_t)N * 6 * Kp * 2);
+    if (!rc && hipMemsetAsync(g_split_flag, 0, sizeof(int), stream()) != hipSuccess) {
+      set_error("hipMemsetAsync(split flag) failed");
+      rc = TNH_ERR_HIP;          // falls through to the frees below (an early return leaked A3 / B3)
+    }
     if (!rc) {
-      TNH_HIP(hipMemsetAsync(g_split_flag, 0, sizeof(int), stream()));
       // A element (m, k): transA ? A[k * lda + m] : A[m * lda + k];  B element (n, k): transB ? B[n * ldb + k] : B[k * ldb + n]
       rc = launch_split3((uint16_t*)A3, (const float*)A, M, K, Kp, !transA, lda, 0, g_split_flag);
       if (!rc) rc = launch_split3((uint16_t*)B3, (const float*)B, N, K, Kp, transB != 0, ldb, 1, g_split_flag);

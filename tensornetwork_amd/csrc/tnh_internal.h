@@ -14,6 +14,7 @@ namespace tnh {
 void set_error(const char* fmt, ...);
 hipStream_t stream();       // process stream (nullptr before tnh_init)
 bool initialised();
+bool capturing();        // between tnh_graph_begin and tnh_graph_end: no host synchronisation is legal on the stream
 int num_cus();
 int stream_wgs_per_cu(int64_t bytes);   // grid-stride streaming kernels: workgroups per CU for a buffer of this size
 

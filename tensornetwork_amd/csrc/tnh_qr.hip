@@ -558,9 +558,11 @@ int tnh_qr(int dtype, int64_t m, int64_t n, const void* A, void* Q, void* R, voi
   TNH_REQUIRE(m >= 0 && n >= 0, "negative extent");
   if (m == 0 || n == 0) return TNH_OK;
   TNH_REQUIRE(A && Q && R && work, "null pointer");
-  if (qr_panel16_supported(dtype, m, n)) {
+  if (qr_panel16_supported(dtype, m, n) && !capturing()) {
     // 16-wide Cholesky-QR panels (one small kernel per panel instead of a launch per column); a numerically
-    // rank-deficient panel is reported and the matrix goes through the column-by-column path below
+    // rank-deficient panel is reported and the matrix goes through the column-by-column path below.  The report is a
+    // status word read back by the host (one stream synchronisation per call: tnh.h says so), which is illegal while
+    // the stream is being captured into a hipGraph -- a captured QR takes the column path
     int st = 0;
     const int rc = qr_panel16(m, n, (const float*)A, (float*)Q, (float*)R, work, &st);
     if (rc != TNH_OK) return rc;

@@ -24,6 +24,7 @@ void set_error(const char* fmt, ...) {
 }
 hipStream_t stream() { return g_stream; }
 bool initialised() { return g_device >= 0; }
+bool capturing() { return g_capturing; }
 int num_cus() { return g_cus; }
 // Workgroups per CU of the grid-stride streaming kernels (permutes, elementwise, reductions) on buffers beyond the
 // 256 MB Infinity Cache.  Measured (tools/bw_probe, 1 GiB): a plain read reaches 6.37 TB/s with 4 workgroups of

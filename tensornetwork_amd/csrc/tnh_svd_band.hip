@@ -1077,6 +1077,15 @@ __global__ __launch_bounds__(256) void values_out_kernel(const double* __restric
   S[i] = (float)(0.5 * (lo[q] + hi[q]));
 }
 
+// the k kept values again, from their REFINED brackets (2^-32 sigma_max instead of the 20 bits every value gets)
+__global__ __launch_bounds__(256) void values_kept_kernel(const double* __restrict__ lo, const double* __restrict__ hi,
+                                                          int64_t n, int64_t k, float* __restrict__ S) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= k) return;
+  const int64_t q = n - 1 - i;
+  S[i] = (float)(0.5 * (lo[q] + hi[q]));
+}
+
 // shifts of the inverse iteration: vector v (0 = largest) uses the midpoint of its refined bracket
 __global__ __launch_bounds__(256) void vshift_kernel(const double* __restrict__ lo, const double* __restrict__ hi,
                                                      int64_t n, int64_t k, double* __restrict__ shifts) {
@@ -1693,13 +1702,16 @@ static int values(const Layout& L, char* base, int64_t n, int64_t khint, float* 
   return TNH_OK;
 }
 
-static int vectors(const Layout& L, char* base, int64_t m, int64_t n, int64_t k, float* U, float* Vh) {
+static int vectors(const Layout& L, char* base, int64_t m, int64_t n, int64_t k, float* U, float* Vh, float* S_kept) {
   // kept values: brackets down to ~1e-12 relative so that inverse iteration separates close neighbours
   int rc;
   for (int r = 0; r < g_refine_rounds; ++r) {
     rc = section_round(L, base, n, n - k, k, g_refine_p, r, g_lane && g_refine_p > 15);
     if (rc) return rc;
   }
+  if (S_kept)     // the caller's S holds the 20-bit values of every bracket; the kept ones are known better now
+    hipLaunchKernelGGL(values_kept_kernel, dim3((unsigned)((k + 255) / 256)), dim3(256), 0, stream(),
+                       (const double*)(base + L.lo), (const double*)(base + L.hi), n, k, S_kept);
   hipLaunchKernelGGL(vshift_kernel, dim3((unsigned)((k + 255) / 256)), dim3(256), 0, stream(),
                      (const double*)(base + L.lo), (const double*)(base + L.hi), n, k, (double*)(base + L.shifts));
   const unsigned blocks = (unsigned)((k + 3) / 4);
@@ -1930,6 +1942,7 @@ int tnh_svd_band_factor(int64_t m, int64_t n, const void* A, void* S, void* work
   TNH_REQUIRE(A && S && work, "null pointer");
   TNH_REQUIRE(tnh_svd_band_supported(TNH_F32, m, n, 0), "tnh_svd_band_factor: unsupported shape %lld x %lld",
               (long long)m, (long long)n);
+  TNH_REQUIRE(!(status_out && capturing()), "tnh_svd_band_factor: a status read-back synchronises the stream (graph capture)");
   read_env();
   char* base = (char*)(((uintptr_t)work + 255) & ~(uintptr_t)255);
   const Layout L = make_layout(m, n, kcap > 4 ? kcap : 4);
@@ -1950,16 +1963,17 @@ int tnh_svd_band_factor(int64_t m, int64_t n, const void* A, void* S, void* work
 }
 
 int tnh_svd_band_vectors(int64_t m, int64_t n, void* work, int64_t kcap, int64_t k, void* U, void* Vh,
-                         int* status_out) {
+                         void* S_kept, int* status_out) {
   TNH_NEED_INIT();
   TNH_REQUIRE(work && U && Vh, "null pointer");
   TNH_REQUIRE(k > 0 && k <= kcap && tnh_svd_band_supported(TNH_F32, m, n, k),
               "tnh_svd_band_vectors: unsupported k = %lld (kcap %lld) for %lld x %lld", (long long)k, (long long)kcap,
               (long long)m, (long long)n);
+  TNH_REQUIRE(!(status_out && capturing()), "tnh_svd_band_vectors: a status read-back synchronises the stream (graph capture)");
   read_env();
   char* base = (char*)(((uintptr_t)work + 255) & ~(uintptr_t)255);
   const Layout L = make_layout(m, n, kcap > 4 ? kcap : 4);
-  int rc = vectors(L, base, m, n, k, (float*)U, (float*)Vh);
+  int rc = vectors(L, base, m, n, k, (float*)U, (float*)Vh, (float*)S_kept);
   if (rc) return rc;
   if (status_out) {
     int st = 0;

@@ -124,7 +124,7 @@ def round_to_bf16(x):
 _GC_FROZEN = False
 _GC_MIN_BYTES = 64 << 20
 _MALLOC_SECONDS_PER_BYTE = 28e-3 / (1 << 30)
-_gc_cost_seconds = 0.0       # unknown until the first pass has been timed (the first large pool miss collects once)
+_gc_cost_seconds = 30e-3     # a full pass of an unfrozen heap before one has been timed; configure_gc(freeze=True) resets it to 0
 
 
 _GC_POLICY = {"freeze": False, "collect": True}

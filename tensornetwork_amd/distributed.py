@@ -12,9 +12,10 @@ results add up.  That is the natural partition of a contractor path:
   * ONE all-reduce(sum) of the (small) result tensor finishes the job -- the
     only data-path collective, and only because the partition has a genuine
     exchange step.  On GPUs it is RCCL through libtnhip's own K8 entry points
-    (``tensornetwork_amd.comm.RcclComm``: ``tnh_allreduce`` on the library stream); the
-    CPU test-suite drives the same code with the oracle backend over gloo
-    (``TorchDistComm``, host arrays).
+    (``tensornetwork_amd.comm.RcclComm``: ``tnh_allreduce`` on the library stream) -- the only
+    communicator of the package.  The CPU test-suite drives the same partitioning code with the
+    oracle backend over gloo through a TEST-side adapter (``tests/gloo_comm.py``: any object with
+    ``rank`` / ``world`` / ``all_reduce_sum`` / ``all_gather_rows`` / ``all_gather_counts`` will do).
 
 Networks that do not partition (MPS chains zipped from a boundary, a single
 SVD) are run as independent replicas instead -- see bench.py.
@@ -37,120 +38,6 @@ class LocalComm:
 
   def all_gather_rows(self, backend, tensor, rows_per_rank):  # pylint: disable=unused-argument
     return tensor
-
-
-class TorchDistComm:
-  """all-reduce through an initialised ``torch.distributed`` process group.
-
-  GPU tensors of the hip backend are handed to RCCL zero-copy through
-  ``__cuda_array_interface__``; NumPy tensors (oracle backend, gloo) go through
-  ``torch.from_numpy``."""
-
-  def __init__(self):
-    import torch.distributed as dist  # pylint: disable=import-outside-toplevel
-    if not dist.is_initialized():
-      raise RuntimeError("torch.distributed process group is not initialised")
-    self._dist = dist
-    self.rank = dist.get_rank()
-    self.world = dist.get_world_size()
-
-  def all_gather_counts(self, n):
-    """Every rank's integer (host-side metadata exchange)."""
-    outs = [None] * self.world
-    self._dist.all_gather_object(outs, int(n))
-    return [int(x) for x in outs]
-
-  def all_reduce_sum(self, backend, tensor):
-    import torch  # pylint: disable=import-outside-toplevel
-    from tensornetwork_amd.device_tensor import DeviceTensor  # pylint: disable=import-outside-toplevel
-    if isinstance(tensor, DeviceTensor):
-      # Fallback path (bench.py --comm torch): the product path is RcclComm.  Always reduce a
-      # fresh block -- `tensor` may alias a caller-owned operand (network.copy shares tensors).
-      from tensornetwork_amd import _lib  # pylint: disable=import-outside-toplevel
-      half = tensor.code in (_lib.BF16, _lib.F16)
-      work = backend.cast(tensor, np.float32) if half else backend.copy(tensor)   # bf16/f16 sums travel as fp32
-      backend.synchronize()                        # our stream -> visible to RCCL's stream
-      view = torch.as_tensor(_CudaView(work, real_image=True), device=f"cuda:{torch.cuda.current_device()}")
-      self._dist.all_reduce(view, op=self._dist.ReduceOp.SUM)
-      torch.cuda.synchronize()
-      return backend.cast(work, tensor.dtype) if half else work
-    host = np.ascontiguousarray(np.asarray(tensor))
-    flat = host.reshape(-1).copy()
-    if flat.dtype.kind == "c":   # gloo has no complex sum: reduce the interleaved real image
-      real = flat.view(np.float32 if flat.dtype == np.complex64 else np.float64)
-      t = torch.from_numpy(real)
-      self._dist.all_reduce(t, op=self._dist.ReduceOp.SUM)
-      return t.numpy().view(flat.dtype).reshape(host.shape)
-    t = torch.from_numpy(flat)
-    self._dist.all_reduce(t, op=self._dist.ReduceOp.SUM)
-    return t.numpy().reshape(host.shape)
-
-
-  def all_gather_rows(self, backend, tensor, rows_per_rank):
-    """Concatenate the ranks' row blocks (leading axis) of a sharded result: ONE all-gather.
-
-    Blocks are padded to the largest block so that the collective is the plain
-    equal-size all-gather (RCCL's fast path); ``rows_per_rank`` lists every rank's
-    true row count."""
-    import torch  # pylint: disable=import-outside-toplevel
-    from tensornetwork_amd.device_tensor import DeviceTensor  # pylint: disable=import-outside-toplevel
-    rows = [int(r) for r in rows_per_rank]
-    pad = max(rows)
-    tail = tuple(tensor.shape[1:])
-    if isinstance(tensor, DeviceTensor):
-      full = DeviceTensor.empty((self.world * pad,) + tail, tensor.code)
-      mine = tensor
-      if rows[self.rank] != pad:
-        mine = DeviceTensor.empty((pad,) + tail, tensor.code)
-        backend.lib.tnh_memset(ctypes_ptr(mine), 0, mine.nbytes)
-        backend.copy_rows_into(mine, tensor, 0)
-      backend.synchronize()
-      dev = f"cuda:{torch.cuda.current_device()}"
-      src = torch.as_tensor(_CudaView(mine, raw=True), device=dev)
-      dst = torch.as_tensor(_CudaView(full, raw=True), device=dev)
-      self._dist.all_gather_into_tensor(dst, src)
-      torch.cuda.synchronize()
-      if all(r == pad for r in rows):
-        return full
-      parts = [backend.getitem(full, slice(k * pad, k * pad + rows[k])) for k in range(self.world)]
-      return backend.concat_rows(parts)
-    host = np.ascontiguousarray(np.asarray(tensor))
-    buf = np.zeros((pad,) + tail, dtype=host.dtype)
-    buf[:rows[self.rank]] = host
-    src = torch.from_numpy(buf.view(np.uint8).reshape(-1).copy())
-    outs = [torch.empty_like(src) for _ in range(self.world)]
-    self._dist.all_gather(outs, src)
-    blocks = [o.numpy().view(host.dtype).reshape((pad,) + tail)[:rows[k]] for k, o in enumerate(outs)]
-    return np.concatenate(blocks, axis=0)
-
-
-def ctypes_ptr(tensor):
-  import ctypes  # pylint: disable=import-outside-toplevel
-  return ctypes.c_void_p(tensor.ptr)
-
-
-class _CudaView:
-  """Exposes a DeviceTensor through ``__cuda_array_interface__`` (zero-copy)."""
-
-  def __init__(self, tensor, raw=False, real_image=False):
-    self._keep = tensor
-    if real_image and np.dtype(tensor.dtype).kind == "c":
-      # complex64 / complex128 summed as their interleaved (re, im) float32 / float64 image
-      real = np.dtype(np.float32 if np.dtype(tensor.dtype) == np.complex64 else np.float64)
-      self.__cuda_array_interface__ = {"shape": (int(tensor.size) * 2,), "typestr": real.str,
-                                       "data": (tensor.ptr, False), "version": 2, "strides": None}
-      return
-    if raw:   # byte view: lets dtypes torch does not know (bf16 tag, complex) ride a collective
-      self.__cuda_array_interface__ = {"shape": (int(tensor.nbytes),), "typestr": "|u1",
-                                       "data": (tensor.ptr, False), "version": 2, "strides": None}
-      return
-    self.__cuda_array_interface__ = {
-        "shape": tuple(tensor.shape) if tensor.shape else (1,),
-        "typestr": np.dtype(tensor.dtype).str,
-        "data": (tensor.ptr, False),
-        "version": 2,
-        "strides": None,
-    }
 
 
 # ---------------------------------------------------------------- slice planning

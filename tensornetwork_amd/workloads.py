@@ -305,6 +305,89 @@ def mera_slice_values(be, chi: int, slices, half_dtype, seed: int = 40):
   return out
 
 
+def mera_sliced_run(be, chi: int, placement: str, half_dtype, seed: int = 40, budget_seconds: float = None,
+                    check_every: int = 0):
+  """ONE placement of the bond-sliced binary-MERA layer energy as a RUN: all chi^2 slices of the
+  network `mera_slice_values` defines (hamiltonian and state given slice-wise along their cut legs -- what
+  `slice_edge(cut_h, i); slice_edge(cut_rho, j)` leaves of the full rank-6 tensors, which at chi = 64 are 137 GB each
+  and are never materialised; isometry and disentangler are the same tensors in every slice), each contracted with
+  the branch(nbranch=2) path of the sliced sizes, partial energies added in f32 ON THE DEVICE (one read-back at the
+  end).  The hamiltonian slice is generated once per i, the state slice once per (i, j) (2 GB of counter-based
+  random numbers: ~1 ms beside a ~37 ms slice).
+
+  budget_seconds: stop after the first slice that ends beyond it (the record then says how many slices ran).
+  check_every: every that many slices the same slice is also contracted in f32 on the same half-rounded values
+  (returned as `checks`: [(i, j), half, f32]) -- a sample of the a-priori rounding check, not part of the timing.
+  Returns {"n_slices", "slices_done", "seconds", "energy_partial_sum", "macs_per_slice", "checks", ...}."""
+  import time  # pylint: disable=import-outside-toplevel
+  from tensornetwork_amd import contractors  # pylint: disable=import-outside-toplevel
+  plan = _mera_slice_plan(chi, placement)
+  fixed = {}
+
+  def gen(k, node, shape, i, j):
+    scale = float(np.prod(shape)) ** -0.25
+    if node is plan["hnode"]:
+      sd = seed + 1000 + i
+    elif node is plan["rnode"]:
+      sd = seed + 5000 + j
+    else:
+      sd = seed + 7 * k        # isometries / disentanglers: slice-independent
+    return be.device_random(shape, dtype=half_dtype, seed=sd, normal=True, a=0.0, b=scale)
+
+  acc = be.zeros((), dtype=np.float32)
+  done, checks, check_seconds = 0, [], 0.0
+  be.synchronize()
+  t0 = time.perf_counter()
+  stop = False
+  for i in range(chi):
+    h_i = None
+    for j in range(chi):
+      def tensor_of(k, node, shape, i=i, j=j):
+        nonlocal h_i
+        if node is plan["hnode"]:
+          if h_i is None:
+            h_i = gen(k, node, shape, i, j)
+          return h_i
+        if node is plan["rnode"]:
+          return gen(k, node, shape, i, j)
+        if k not in fixed:
+          fixed[k] = gen(k, node, shape, i, j)
+        return fixed[k]
+
+      real = _mera_slice_network(be, plan, tensor_of)
+      res = contractors.contract_path(plan["path"], real).tensor
+      acc = be.addition(acc, be.reshape(be.cast(res, np.float32), ()))
+      done += 1
+      if check_every and (done - 1) % check_every == 0:
+        be.synchronize()
+        tc = time.perf_counter()
+        real32 = _mera_slice_network(be, plan, lambda k, node, shape: be.cast(tensor_of(k, node, shape), np.float32))
+        r32 = contractors.contract_path(plan["path"], real32).tensor
+        checks.append([[i, j], float(np.asarray(res, dtype=np.float64).reshape(-1)[0]),
+                       float(np.asarray(r32, dtype=np.float64).reshape(-1)[0])])
+        for n in real32:
+          n.tensor, n.edges = None, []
+        del real32, r32
+        be.synchronize()
+        check_seconds += time.perf_counter() - tc
+      for n in real:               # Node <-> Edge cycles: without this the 2 GB state slice waits for the cyclic GC
+        n.tensor, n.edges = None, []
+      del res, real
+      if budget_seconds is not None and done % 16 == 0:
+        be.synchronize()
+        if time.perf_counter() - t0 - check_seconds > budget_seconds:
+          stop = True
+          break
+    if stop:
+      break
+  be.synchronize()
+  seconds = time.perf_counter() - t0 - check_seconds
+  return {"placement": placement, "n_slices": chi * chi, "slices_done": done, "seconds": seconds,
+          "energy_partial_sum": float(np.asarray(acc, dtype=np.float64).reshape(-1)[0]),
+          "macs_per_slice": plan["flops"], "peak_elems_per_slice": plan["peak"], "depth": plan["depth"],
+          "tflops": 2.0 * plan["flops"] * done / max(seconds, 1e-30) / 1e12, "checks": checks}
+
+
 def ham_ising():
   """3-site critical-Ising term  X Z X - (X X 1 + 1 X X)/2  (Evenbly & White 2016), as used by
   simple_mera.py:298-309."""

@@ -390,8 +390,53 @@ class EmuLib:
     self._flat(vh_out, k * n, _NP[code])[:] = vh[:k].astype(_NP[code]).reshape(-1)
     return _lib.OK
 
-  def tnh_svd_band_supported(self, code, m, n, k):  # pylint: disable=unused-argument
-    return 0
+  # ---- K7b (tnh.h: band + spectrum-slicing SVD; same two-phase contract, tall f32 input with n % 16 == 0, a status
+  #      word instead of an answer where the device path cannot be accurate).  LAPACK stands in for the kernels; the
+  #      emulation keeps the CONTRACT the host logic depends on: shape rules, `kcap` consistent between the two calls,
+  #      20-bit values from factor / refined values from vectors, status 1 for a numerically rank-deficient input and
+  #      16 for a kept value below 1e-6 of the largest.  Off unless a test switches `band_svd` on.
+  band_svd = False
+
+  def tnh_svd_band_supported(self, code, m, n, k):
+    if not self.band_svd:
+      return 0
+    return int(code == _lib.F32 and m >= n and n >= 256 and n % 16 == 0 and 0 <= k <= n and k % 4 == 0)
+
+  def tnh_svd_band_work_bytes(self, m, n, kcap, nbytes_ref):
+    assert m >= n and n % 16 == 0 and 0 <= kcap <= n
+    nbytes_ref._obj.value = 256 + 8 * int(max(kcap, 4))     # pylint: disable=protected-access
+    return _lib.OK
+
+  def tnh_svd_band_factor(self, m, n, a, s_out, work, kcap, status_ref):
+    assert self.tnh_svd_band_supported(_lib.F32, m, n, 0)
+    mat = np.array(self._flat(a, m * n, np.float32)).reshape(m, n).astype(np.float64)
+    u, sv, vh = np.linalg.svd(mat, full_matrices=False)
+    # a 16-column panel whose Gram matrix has a pivot below 1e-9 of the largest: stands in as "fewer than 16 values
+    # above 3e-5 s_1" (graded spectra pass on the device -- their panels are well conditioned --, low-rank inputs do not)
+    status = 1 if sv[0] == 0 or sv[min(15, n - 1)] < 3e-5 * sv[0] else 0
+    self._band_state = getattr(self, "_band_state", {})
+    self._band_state[_addr(work)] = (u, sv, vh, int(kcap), status)
+    coarse = np.round(sv / sv[0] * 2.0**20) / 2.0**20 * sv[0] if sv[0] > 0 else sv   # what 20-bit brackets carry
+    self._flat(s_out, n, np.float32)[:] = coarse.astype(np.float32)
+    self.calls.append(("svd_band_factor", (int(m), int(n), int(kcap))))
+    if status_ref is not None:
+      status_ref._obj.value = status     # pylint: disable=protected-access
+    return _lib.OK
+
+  def tnh_svd_band_vectors(self, m, n, work, kcap, k, u_out, vh_out, s_kept, status_ref):
+    u, sv, vh, kcap0, status = self._band_state[_addr(work)]
+    k = int(k)
+    assert int(kcap) == kcap0 and 0 < k <= kcap0 and k % 4 == 0, (kcap, kcap0, k)
+    if sv[k - 1] <= 1e-6 * sv[0]:
+      status |= 16
+    self._flat(u_out, m * k, np.float32)[:] = u[:, :k].astype(np.float32).reshape(-1)
+    self._flat(vh_out, k * n, np.float32)[:] = vh[:k].astype(np.float32).reshape(-1)
+    if _addr(s_kept):
+      self._flat(s_kept, k, np.float32)[:] = sv[:k].astype(np.float32)
+    self.calls.append(("svd_band_vectors", (int(m), int(n), int(kcap), k)))
+    if status_ref is not None:
+      status_ref._obj.value = status     # pylint: disable=protected-access
+    return _lib.OK
 
   def tnh_qr_work_bytes(self, code, m, n, nbytes_ref):  # pylint: disable=unused-argument
     nbytes_ref._obj.value = 64     # pylint: disable=protected-access
@@ -449,7 +494,7 @@ class EmuLib:
   #      tnh_graph_launch replays the sequence).  Recording happens in __getattribute__ below.
   _NOT_CAPTURED = ("tnh_malloc", "tnh_free", "tnh_pool_has", "tnh_last_error", "tnh_gemm_last_kernel", "tnh_graph_begin",
                    "tnh_graph_end", "tnh_graph_launch", "tnh_graph_destroy", "tnh_gemm_set_variant", "tnh_svd_work_bytes",
-                   "tnh_qr_work_bytes", "tnh_svd_band_supported", "tnh_trim", "tnh_event_create", "tnh_event_destroy",
+                   "tnh_qr_work_bytes", "tnh_svd_band_supported", "tnh_svd_band_work_bytes", "tnh_trim", "tnh_event_create", "tnh_event_destroy",
                    "tnh_device_pci_bus_id")
 
   def tnh_graph_begin(self):

@@ -11,6 +11,11 @@ import tensornetwork_amd as ta
 from tensornetwork_amd import contractors, distributed, network
 from oracle.numpy_oracle import OracleBackend
 
+HERE_ = os.path.dirname(os.path.abspath(__file__))
+if HERE_ not in sys.path:
+  sys.path.insert(0, HERE_)
+from gloo_comm import GlooComm  # noqa: E402  pylint: disable=wrong-import-position
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
@@ -75,7 +80,7 @@ def _worker(rank, world, port, out_path):
   be = OracleBackend()
   nodes = regular_network(be)
   cuts = distributed.choose_cut_edges(nodes, min_slices=9)
-  comm = distributed.TorchDistComm()
+  comm = GlooComm()
   out = distributed.contract_sliced(nodes, cuts, comm=comm)
   np.save(out_path + f".{rank}.npy", np.asarray(out))
   dist.barrier()
@@ -93,7 +98,7 @@ def _worker_sharded(rank, world, port, out_path):
   rng = np.random.default_rng(3)
   a = rng.standard_normal((7, 4, 5, 6))          # 7 rows over 2 ranks: uneven blocks (4 + 3)
   b = rng.standard_normal((6, 5, 3, 2))
-  comm = distributed.TorchDistComm()
+  comm = GlooComm()
   full, bounds = distributed.tensordot_sharded(be, a, b, [[3, 2], [0, 1]], comm=comm)
   part, pb = distributed.tensordot_sharded(be, a, b, [[3, 2], [0, 1]], comm=comm, gather=False)
   lo, hi = distributed.shard_rows(7, world)[rank]
@@ -162,7 +167,7 @@ def _worker_complex(rank, world, port, out_path):
   for n in nodes:   # genuinely complex entries: a dropped imaginary part changes the result
     n.tensor = n.tensor + 1j * rng.standard_normal(n.tensor.shape)
   cuts = distributed.choose_cut_edges(nodes, min_slices=9)
-  out = distributed.contract_sliced(nodes, cuts, comm=distributed.TorchDistComm())
+  out = distributed.contract_sliced(nodes, cuts, comm=GlooComm())
   np.save(out_path + f".{rank}.npy", np.asarray(out))
   dist.barrier()
   dist.destroy_process_group()
@@ -283,10 +288,10 @@ def test_single_node_rccl_env_pins_loopback(monkeypatch):
   assert "NCCL_SOCKET_IFNAME" not in os.environ
 
 
-def _bench_fallback_worker(rank, world, port, out_path):
+def _bench_comm_worker(rank, world, port, out_path):
   root = os.path.dirname(HERE)
   sys.path.insert(0, root)
-  os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), TNH_BENCH_NO_REEXEC="1", TNH_COMM_PORT_OFFSET="0")
+  os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), TNH_COMM_PORT_OFFSET="0")
   import importlib
   from tensornetwork_amd import _lib, comm
   importlib.reload(comm)      # pick up TNH_COMM_PORT_OFFSET
@@ -304,18 +309,59 @@ def _bench_fallback_worker(rank, world, port, out_path):
     f.write(outcome)
 
 
-def test_bench_rccl_fallback_is_taken_in_step(tmp_path):
-  """bench.make_rccl_comm: when the K8 communicator cannot come up (no GPU here) EVERY rank reaches the fall-back
-  branch (here: the 'no re-exec' guard instead of the execv into --comm torch), none hangs in an exchange."""
+def test_bench_has_one_communicator_and_its_failure_raises_on_every_rank(tmp_path):
+  """bench.make_rccl_comm: when the K8 communicator cannot come up (no GPU here) EVERY rank gets the exception in
+  step (none hangs in an exchange) -- and there is no second communicator to fall back on (VERDICT r3 weak 9:
+  the torch.distributed route is gone from bench.py and from the package)."""
   import torch.multiprocessing as mp
   with socket.socket() as s:
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
   out_path = str(tmp_path / "fb")
-  mp.spawn(_bench_fallback_worker, args=(2, port, out_path), nprocs=2, join=True)
+  mp.spawn(_bench_comm_worker, args=(2, port, out_path), nprocs=2, join=True)
   for r in range(2):
     with open(out_path + f".{r}.txt") as f:
-      assert "TNH_BENCH_NO_REEXEC" in f.read()
+      assert f.read().startswith("RuntimeError: RCCL is not usable on rank(s) [0, 1]")
+  root = os.path.dirname(HERE)
+  for rel in ("bench.py", "tensornetwork_amd/distributed.py", "tensornetwork_amd/comm.py"):
+    src = open(os.path.join(root, rel)).read()
+    assert "import torch" not in src and "torch.distributed" not in src.replace("torch.distributed.run", ""), rel
+
+
+def test_bench_watchdog_turns_a_hang_into_exit_code_3(tmp_path):
+  """a step that hangs inside a collective must end the rank with a message, not the record with a
+  driver-side timeout.  The watchdog fires while the main thread is blocked (here: in a sleep), and stays quiet when
+  the block finishes in time."""
+  import subprocess
+  root = os.path.dirname(HERE)
+  code = ("import sys, time; sys.path.insert(0, %r); import bench\n"
+          "with bench.Watchdog(30, 'fast step', 0):\n  pass\n"
+          "with bench.Watchdog(0.5, 'RCCL bring-up', 5):\n  time.sleep(60)\n"
+          "print('not reached')\n" % root)
+  t0 = __import__("time").monotonic()
+  res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+  assert res.returncode == 3 and __import__("time").monotonic() - t0 < 30
+  assert "rank 5: RCCL bring-up did not finish within" in res.stderr and "not reached" not in res.stdout
+
+
+def test_self_launch_stops_every_rank_when_one_fails_or_the_job_times_out(tmp_path, monkeypatch):
+  """bench.self_launch watches its ranks: one failing rank takes the others down (they would wait in a collective
+  for ever), and the job as a whole has a wall-clock limit.  Ranks here: a stand-in script instead of bench.py."""
+  import argparse
+  import bench
+  script = tmp_path / "rank.py"
+  script.write_text("import os, sys, time\n"
+                    "mode = os.environ['FAKE_MODE']\n"
+                    "if mode == 'fail' and os.environ['RANK'] == '1':\n  sys.exit(7)\n"
+                    "time.sleep(120)\n")
+  monkeypatch.setattr(bench, "__file__", str(script))
+  monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "3"])
+  for mode, timeout in (("fail", 100.0), ("hang", 1.0)):
+    monkeypatch.setenv("FAKE_MODE", mode)
+    args = argparse.Namespace(gpus=3, dry_run=True, job_timeout=timeout)
+    t0 = __import__("time").monotonic()
+    assert bench.self_launch(args) == 1
+    assert __import__("time").monotonic() - t0 < 30, mode
 
 
 def test_sliced_result_dtype_follows_the_per_slice_result():
@@ -419,3 +465,58 @@ def test_bench_gpus_n_launches_n_ranks_or_fails_loudly():
   odd = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run"], env=env2,
                        capture_output=True, text=True, timeout=300)
   assert odd.returncode != 0 and "n_gpus" not in odd.stdout
+
+
+def _worker_rr64(rank, world, port, out_path):
+  os.environ["MASTER_ADDR"] = "127.0.0.1"
+  os.environ["MASTER_PORT"] = str(port)
+  sys.path.insert(0, os.path.dirname(HERE))
+  sys.path.insert(0, HERE)
+  import torch
+  import torch.distributed as dist
+  torch.set_num_threads(1)
+  dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+  from tensornetwork_amd import workloads
+  be = OracleBackend()
+  nodes = workloads.random_regular_network(be, n=64, D=4, seed=6, dtype=np.float64)
+  cuts = distributed.choose_cut_edges(nodes, min_slices=64)
+  rep = distributed.slicing_report(nodes, cuts)
+  mine = []
+  out = distributed.contract_sliced(nodes, cuts, comm=GlooComm(), partials_out=mine)
+  np.savez(out_path + f".{rank}.npz", out=np.asarray(out), n_mine=len(mine), n_slices=int(rep["n_slices"]))
+  dist.barrier()
+  dist.destroy_process_group()
+
+
+def test_eight_rank_rehearsal_of_the_north_star_network(tmp_path):
+  """the first 8-rank run must not be the first time the 8-rank logic executes.  The bench's own
+  workload -- the 64-node random 3-regular network of SURVEY 8d (graph seed 6), here at D = 4 on the oracle backend
+  over gloo -- on 8 ranks: the launcher starts 8 ranks that find each other (`--gpus 8 --dry-run`), every rank gets
+  its share of the slices (round-robin, within one of each other), and the 8-rank all-reduced value equals the
+  1-rank value."""
+  import json
+  import subprocess
+  import torch.multiprocessing as mp
+  root = os.path.dirname(HERE)
+  env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+  dry = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--dry-run"], env=env,
+                       capture_output=True, text=True, timeout=600)
+  assert dry.returncode == 0, dry.stderr
+  rec = json.loads(dry.stdout.strip().splitlines()[-1])
+  assert rec["n_gpus"] == 8 and rec["ranks_seen"] == list(range(8)) and rec["distinct_processes"] == 8
+  with socket.socket() as s:
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+  out_path = str(tmp_path / "rr")
+  mp.spawn(_worker_rr64, args=(8, port, out_path), nprocs=8, join=True)
+  from tensornetwork_amd import workloads
+  be = OracleBackend()
+  nodes = workloads.random_regular_network(be, n=64, D=4, seed=6, dtype=np.float64)
+  cuts = distributed.choose_cut_edges(nodes, min_slices=64)
+  ref = np.asarray(distributed.contract_sliced(nodes, cuts))
+  got = [np.load(out_path + f".{r}.npz") for r in range(8)]
+  n_slices = int(got[0]["n_slices"])
+  assert n_slices >= 64 and sum(int(g["n_mine"]) for g in got) == n_slices
+  assert max(int(g["n_mine"]) for g in got) - min(int(g["n_mine"]) for g in got) <= 1
+  for g in got:
+    np.testing.assert_allclose(g["out"], ref, rtol=1e-9)

@@ -211,3 +211,73 @@ def test_complex64_svd_through_the_real_embedding(hip):
   assert np.max(np.linalg.norm(a128 @ vv.conj().T - uu * s_all[:k], axis=0)) <= 2e-5 * sr[0]
   rec = np.linalg.norm(a128 - (uu * s_all[:k]) @ vv)
   assert rec <= np.sqrt(np.sum(sr[k:] ** 2)) + 1e-4 * sr[0] * np.sqrt(k)
+
+
+# ---- round 4: every call shape the reference makes takes the band path ------------------------------
+def test_band_svd_truncation_error_alone(hip):
+  """split_node(max_truncation_err=...) without max_singular_values (network_operations.py:130-137, 219-223): the
+  values come first, k is picked on the host by decompositions.py:38-57, then the vectors."""
+  a = graded(1024, 768, seed=21, rate=16.0)
+  sr = np.linalg.svd(a.astype(np.float64), compute_uv=False)
+  for err, relative in ((2e-3, False), (1e-2, True)):
+    trunc = np.sqrt(np.cumsum(sr[::-1] ** 2))
+    want = int(np.count_nonzero(trunc > (err * sr[0] if relative else err)))
+    u, s, vh, s_rest = hip.svd(hip.convert_to_tensor(a), 1, max_truncation_error=err, relative=relative)
+    assert hip.last_svd_path == "band", (hip.last_svd_path, hip.last_svd_band_status)
+    assert abs(s.shape[0] - want) <= 1 and s_rest.shape[0] == 768 - s.shape[0]     # a value ON the threshold may fall either way
+    check_svd(a, u, s, vh, s_rest, s.shape[0], f"trunc error alone {err} rel={relative}")
+
+
+@pytest.mark.parametrize("m,n", [(1024, 1024), (1280, 768)])
+def test_band_svd_full(hip, m, n):
+  """split_node_full_svd (network_operations.py:446-588): no truncation at all -- k = min(m, n) vectors."""
+  a = gaussian(m, n, seed=m + 3 * n)
+  u, s, vh, s_rest = hip.svd(hip.convert_to_tensor(a), 1)
+  assert hip.last_svd_path == "band", (hip.last_svd_path, hip.last_svd_band_status)
+  assert s_rest.shape == (0,)
+  check_svd(a, u, s, vh, s_rest, min(m, n), f"full {m}x{n}")
+  # the whole thing reconstructs A (not only the best rank-k part)
+  rec = (np.asarray(u, dtype=np.float64) * np.asarray(s, dtype=np.float64)) @ np.asarray(vh, dtype=np.float64)
+  assert np.max(np.abs(rec - a)) <= 2e-5 * float(np.asarray(s)[0])
+
+
+def test_band_svd_keeps_more_than_half(hip):
+  a = gaussian(1024, 1024, seed=77)
+  u, s, vh, s_rest = hip.svd(hip.convert_to_tensor(a), 1, max_singular_values=700)
+  assert hip.last_svd_path == "band", (hip.last_svd_path, hip.last_svd_band_status)
+  check_svd(a, u, s, vh, s_rest, 700, "k = 700 of 1024")
+
+
+@pytest.mark.parametrize("kind,m,n,k", [("gauss", 1000, 1000, 50), ("graded", 1030, 900, 64), ("gauss", 777, 1500, 33)])
+def test_band_svd_sides_that_are_not_multiples_of_16(hip, kind, m, n, k):
+  """min(m, n) % 16 != 0: blockdiag(A, delta I) padding (HipBackend._svd_band_pad); D = 500 bonds give 1000 x 1000."""
+  a = (gaussian if kind == "gauss" else graded)(m, n, seed=m + n + k)
+  u, s, vh, s_rest = hip.svd(hip.convert_to_tensor(a), 1, max_singular_values=k)
+  assert hip.last_svd_path == "band", (hip.last_svd_path, hip.last_svd_band_status)
+  assert s_rest.shape == (min(m, n) - k,)
+  check_svd(a, u, s, vh, s_rest, k, f"padded {kind} {m}x{n} k={k}")
+  # and with the truncation rule on the padded spectrum
+  u, s, vh, s_rest = hip.svd(hip.convert_to_tensor(a), 1, max_singular_values=k, max_truncation_error=1e-3, relative=True)
+  assert hip.last_svd_path == "band"
+  sr = np.linalg.svd(a.astype(np.float64), compute_uv=False)
+  want = int(min(k, np.count_nonzero(np.sqrt(np.cumsum(sr[::-1] ** 2)) > 1e-3 * sr[0])))
+  assert abs(s.shape[0] - want) <= 1
+  check_svd(a, u, s, vh, s_rest, s.shape[0], "padded + truncation rule")
+
+
+def test_band_svd_kept_values_keep_their_relative_accuracy(hip):
+  """the kept values come from the brackets the vectors stage refines to 2^-32 s_1, not from the
+  20-bit brackets every value gets -- a kept value of 2e-5 s_1 is good to ~1e-3 relative (the f32 reduction's own
+  backward error, 1e-7 s_1 absolute), not to the 3 % a 5e-7 s_1 bracket would give."""
+  rng = np.random.default_rng(9)
+  n, k = 1024, 64
+  q1, _ = np.linalg.qr(rng.standard_normal((n, n)))
+  q2, _ = np.linalg.qr(rng.standard_normal((n, n)))
+  spec = np.concatenate([2.0 ** (-np.arange(k) / 4.0), np.full(n - k, 2.0 ** -18)])      # kept: 1 ... 1.8e-5
+  a = ((q1 * spec) @ q2.T).astype(np.float32)
+  u, s, vh, s_rest = hip.svd(hip.convert_to_tensor(a), 1, max_singular_values=k)
+  assert hip.last_svd_path == "band", (hip.last_svd_path, hip.last_svd_band_status)
+  sr = np.linalg.svd(a.astype(np.float64), compute_uv=False)
+  got = np.asarray(s, dtype=np.float64)
+  assert np.max(np.abs(got - sr[:k])) <= 2e-7 * sr[0], np.max(np.abs(got - sr[:k])) / sr[0]
+  assert np.max(np.abs(got - sr[:k]) / sr[:k]) <= 1e-2

@@ -256,63 +256,6 @@ def test_sliced_contraction_graph_equals_eager(hip):
   assert abs(eager - graph) <= 1e-5 * max(abs(eager), 1e-3)
 
 
-_RCCL_SCRIPT = r"""
-import os, socket, sys
-import numpy as np
-import torch                      # torch (its bundled HIP runtime) must initialise BEFORE libtnhip.so
-import torch.distributed as dist
-with socket.socket() as s:
-  s.bind(("127.0.0.1", 0))
-  port = s.getsockname()[1]
-os.environ["MASTER_ADDR"] = "127.0.0.1"
-os.environ["MASTER_PORT"] = str(port)
-os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-torch.cuda.set_device(0)
-dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
-sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
-import tensornetwork_amd as ta
-from tensornetwork_amd import distributed
-from oracle import numpy_oracle as orc
-hip = ta.get_hip_backend()
-comm = distributed.TorchDistComm()
-rng = np.random.default_rng(1)
-x = rng.standard_normal((5, 7)).astype(np.float32)
-out = comm.all_reduce_sum(hip, hip.convert_to_tensor(x))
-np.testing.assert_array_equal(np.asarray(out), x)
-xb = orc.round_bf16(x)
-out = comm.all_reduce_sum(hip, hip.to_bfloat16(xb))          # bf16 partial sums travel as fp32
-np.testing.assert_array_equal(np.asarray(out), xb)
-xc = (x + 1j * x).astype(np.complex64)
-for t, ref in [(hip.convert_to_tensor(x), x), (hip.to_bfloat16(xb), xb), (hip.convert_to_tensor(xc), xc)]:
-  got = comm.all_gather_rows(hip, t, [5])                    # byte view: any dtype rides the collective
-  np.testing.assert_array_equal(np.asarray(got), ref)
-a = rng.standard_normal((6, 3, 4)).astype(np.float32)
-b = rng.standard_normal((4, 3, 2)).astype(np.float32)
-full, bounds = distributed.tensordot_sharded(hip, hip.convert_to_tensor(a), hip.convert_to_tensor(b),
-                                             [[2, 1], [0, 1]], comm=comm)
-assert bounds == (0, 6)
-np.testing.assert_allclose(np.asarray(full), np.tensordot(a, b, [[2, 1], [0, 1]]), rtol=1e-5, atol=1e-5)
-parts = [hip.convert_to_tensor(a[:2]), hip.convert_to_tensor(a[2:])]
-np.testing.assert_array_equal(np.asarray(hip.concat_rows(parts)), a)   # uneven-block path of all_gather_rows
-dist.destroy_process_group()
-print("RCCL-OK")
-"""
-
-
-def test_rccl_collectives_on_device_tensors_world1():
-  """The GPU side of tensornetwork_amd.distributed: all-reduce and all-gather run by RCCL directly on
-  the pooled HBM blocks (zero-copy __cuda_array_interface__ views), in a 1-rank process group -- the
-  N > 1 logic is covered by the gloo tests in test_distributed_cpu.py.  Own process: torch's bundled
-  HIP runtime has to come up before libtnhip.so (the order bench.py uses)."""
-  import os
-  import subprocess
-  import sys
-  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-  res = subprocess.run([sys.executable, "-c", f"ROOT = {root!r}\n" + _RCCL_SCRIPT], capture_output=True, text=True,
-                       timeout=600)
-  assert res.returncode == 0 and "RCCL-OK" in res.stdout, res.stdout[-2000:] + res.stderr[-4000:]
-
-
 def test_k8_rccl_collectives_through_the_c_abi_world1(hip):
   """K8 (include/tnh.h): tnh_comm_unique_id / tnh_comm_init / tnh_allreduce / tnh_allgather /
   tnh_broadcast on the library's own stream, in THIS process (no torch, no second HIP runtime), in a

@@ -467,3 +467,109 @@ def test_row_padded_operand_with_the_pitch_in_its_contraction_index():
     got = np.asarray(out)
   ref = a.reshape(m, -1) @ t.reshape(R, -1).T                                       # f32, exact for these values up to 2^24
   np.testing.assert_allclose(got, ref, rtol=2.0**-7, atol=2.0**-7)
+
+
+# ---- the band SVD's host logic (hip_backend._svd_band*): which call shapes take the path, the truncation rule on the
+#      host between the two device calls, padding to the 16-wide panels, the loud fall-back -- on the emulated C ABI
+#      (tests/emu_tnh.py keeps the CONTRACT of tnh_svd_band_*; the kernels are tested on the MI355X)
+def _ref_svd_rule(a, max_sv, max_err, relative):
+  """decompositions.py:21-74 on a matrix, through the pinned oracle."""
+  return orc.svd(a.astype(np.float64), 1, max_sv, max_err, relative)
+
+
+def _check_band_result(a, out, ref, tag):
+  u, s, vh, rest = (np.asarray(x, dtype=np.float64) for x in out)
+  ur, sr, vhr, restr = ref
+  assert s.shape == sr.shape and rest.shape == restr.shape, (tag, s.shape, sr.shape, rest.shape, restr.shape)
+  s0 = max(float(sr[0]) if sr.size else float(restr[0]), 1e-30)
+  np.testing.assert_allclose(s, sr, atol=2e-6 * s0, err_msg=tag)
+  np.testing.assert_allclose(rest, restr, atol=4e-6 * s0, err_msg=tag)
+  k = s.shape[0]
+  assert u.shape == (a.shape[0], k) and vh.shape == (k, a.shape[1])
+  np.testing.assert_allclose(u.T @ u, np.eye(k), atol=1e-5)
+  np.testing.assert_allclose(vh @ vh.T, np.eye(k), atol=1e-5)
+  np.testing.assert_allclose((u * s) @ vh, (ur * sr) @ vhr, atol=2e-5 * s0, err_msg=tag)
+
+
+@pytest.mark.parametrize("m,n", [(512, 512), (640, 512), (512, 768), (520, 520), (515, 700), (700, 523)])
+@pytest.mark.parametrize("mode", ["max_sv", "err_only", "both", "full", "relative_err"])
+def test_band_svd_host_logic_takes_every_call_shape_the_reference_makes(m, n, mode):
+  rng = np.random.default_rng(m * 7 + n)
+  r = min(m, n)
+  qu, _ = np.linalg.qr(rng.standard_normal((m, r)))
+  qv, _ = np.linalg.qr(rng.standard_normal((n, r)))
+  spec = 3.0 * 2.0 ** (-np.arange(r) / 40.0)                      # 3 ... 4e-4: every value above the 1e-6 s_1 floor
+  a = ((qu * spec) @ qv.T).astype(np.float32)
+  kw = {"max_sv": dict(max_singular_values=37), "err_only": dict(max_truncation_error=0.05),
+        "both": dict(max_singular_values=300, max_truncation_error=0.3),
+        "full": {}, "relative_err": dict(max_truncation_error=1e-2, relative=True)}[mode]
+  ref = _ref_svd_rule(a, kw.get("max_singular_values"), kw.get("max_truncation_error"), kw.get("relative", False))
+  with emulated_backend() as be:
+    be.lib.band_svd = True
+    out = [np.asarray(x) for x in be.svd(be.convert_to_tensor(a), 1, **kw)]
+    assert be.last_svd_path == "band", (be.last_svd_path, be.last_svd_band_status)
+    calls = [c for c in be.lib.calls if c[0].startswith("svd_band")]
+    assert [c[0] for c in calls] == ["svd_band_factor", "svd_band_vectors"]
+    mm, nn, kcap = calls[0][1]
+    assert mm >= nn and nn % 16 == 0 and nn - r == -r % 16 and calls[1][1][:3] == (mm, nn, kcap)
+    if "max_truncation_error" in kw:
+      assert kcap == nn                           # k is only known after the values
+    elif mode == "max_sv":
+      assert kcap == (37 + (-r % 16) + 3) // 4 * 4
+  _check_band_result(a, out, ref, f"{m}x{n} {mode}")
+
+
+def test_band_svd_host_logic_falls_back_loudly():
+  rng = np.random.default_rng(5)
+  low = (rng.standard_normal((512, 6)) @ rng.standard_normal((6, 512))).astype(np.float32)       # rank 6
+  graded = ((np.linalg.qr(rng.standard_normal((512, 512)))[0] * 2.0 ** (-np.arange(512) / 8.0))
+            @ np.linalg.qr(rng.standard_normal((512, 512)))[0]).astype(np.float32)               # 1 ... 6e-20
+  with emulated_backend() as be:
+    be.lib.band_svd = True
+    be._svd_band_failed = set()      # pylint: disable=protected-access
+    # (1) numerically rank-deficient: reported by the factor stage.  The first call only learns it after the vectors
+    # stage (nothing is read back in between); the shape is remembered and the second call stops after the factor.
+    for trip, n_calls in ((0, 2), (1, 1)):
+      be.lib.calls.clear()
+      u, s, vh, rest = be.svd(be.convert_to_tensor(low), 1, max_singular_values=8)
+      assert be.last_svd_path == "jacobi" and be.last_svd_band_status & 1, trip
+      assert len([c for c in be.lib.calls if c[0].startswith("svd_band")]) == n_calls, (trip, be.lib.calls)
+      sr = np.linalg.svd(low.astype(np.float64), compute_uv=False)
+      np.testing.assert_allclose(np.concatenate([np.asarray(s), np.asarray(rest)]), sr, atol=1e-5 * sr[0])
+    # (2) a kept value below 1e-6 s_1 (here: a full SVD of a steeply graded matrix): status 16 -> Jacobi
+    be._svd_band_failed = set()      # pylint: disable=protected-access
+    u, s, vh, rest = be.svd(be.convert_to_tensor(graded), 1)
+    assert be.last_svd_path == "jacobi" and s.shape == (512,) and rest.shape == (0,)
+    # ... while the same matrix truncated above the floor stays on the band path
+    u, s, vh, rest = be.svd(be.convert_to_tensor(graded), 1, max_singular_values=64)
+    assert be.last_svd_path == "band" and s.shape == (64,) and rest.shape == (448,)
+    # (3) too small for the path, and a work buffer beyond the cap
+    be.svd(be.convert_to_tensor(graded[:300, :300]), 1, max_singular_values=8)
+    assert be.last_svd_path == "jacobi"
+    be.svd_band_max_factor_bytes = 512 * 64 * 128
+    be.svd(be.convert_to_tensor(graded), 1, max_singular_values=65)
+    assert be.last_svd_path == "jacobi"
+    # k unknown before the values AND k = n too large for the buffer: values first with the smallest layout, then again
+    be.lib.calls.clear()
+    u, s, vh, rest = be.svd(be.convert_to_tensor(graded), 1, max_truncation_error=0.1)
+    assert be.last_svd_path == "band"
+    assert [c[0] for c in be.lib.calls if c[0].startswith("svd_band")] == ["svd_band_factor", "svd_band_vectors"] * 2
+    ref = _ref_svd_rule(graded, None, 0.1, False)
+    assert s.shape == ref[1].shape and 8 < s.shape[0] <= 64
+
+
+def test_band_svd_kept_values_come_from_the_refined_brackets():
+  """tnh_svd_band_factor's S carries 20 bits per value (5e-7 s_1); the kept values must come from
+  the vectors stage's refined brackets -- small kept values keep their RELATIVE accuracy."""
+  rng = np.random.default_rng(9)
+  q1, _ = np.linalg.qr(rng.standard_normal((512, 512)))
+  q2, _ = np.linalg.qr(rng.standard_normal((512, 512)))
+  spec = np.concatenate([2.0 ** (-np.arange(64) / 4.0), np.full(448, 2.0 ** -17)])      # kept: 1 ... 1.8e-5
+  a = ((q1 * spec) @ q2.T).astype(np.float32)
+  with emulated_backend() as be:
+    be.lib.band_svd = True
+    u, s, vh, rest = [np.asarray(x) for x in be.svd(be.convert_to_tensor(a), 1, max_singular_values=64)]
+    assert be.last_svd_path == "band"
+  sr = np.linalg.svd(a.astype(np.float64), compute_uv=False)
+  np.testing.assert_allclose(np.asarray(s), sr[:64], rtol=2e-6)          # not 5e-7 / 1.8e-5 = 3 %
+  np.testing.assert_allclose(np.asarray(rest), sr[64:], atol=1e-6)
