@@ -1208,9 +1208,9 @@ class HipBackend(BackendBase):
     wide = m < n
     mm, nn = (n, m) if wide else (m, n)
     a = self.transpose(mat, (1, 0)) if wide else mat
-    pad, delta = -r % 16, None
+    pad, delta, mix = -r % 16, None, None
     if pad:
-      a, delta = self._svd_band_pad(a, mm, nn, pad)
+      a, delta, *mix = self._svd_band_pad(a, mm, nn, pad)
       if a is None:
         return None
     pick = None
@@ -1233,8 +1233,11 @@ class HipBackend(BackendBase):
       nxt = float(np.asarray(self.getitem(s, slice(pad, pad + 1)))[0])
       if np.any(np.abs(head - delta) > 1e-5 * delta) or not nxt < delta * (1.0 - 1e-3):
         return None
-      uu = self.getitem(uu, (slice(0, mm), slice(pad, pad + keep)))
-      vvh = self.getitem(vvh, (slice(pad, pad + keep), slice(0, nn)))
+      uu = self.getitem(uu, (slice(None), slice(pad, pad + keep)))
+      vvh = self.getitem(vvh, slice(pad, pad + keep))
+      uu, vvh = self._svd_band_unpad(uu, vvh, *mix)
+      uu = self.getitem(uu, slice(0, mm))
+      vvh = self.getitem(vvh, (slice(None), slice(0, nn)))
       s = self.getitem(s, slice(pad, pad + keep))
     if wide:      # A^T = U' S V'h  ->  A = V'h^T S U'^T
       u, vh = self.transpose(vvh, (1, 0)), self.transpose(uu, (1, 0))
@@ -1298,14 +1301,20 @@ class HipBackend(BackendBase):
     return uu, s_kept, vvh, self.getitem(s_all, slice(keep, nn))
 
   def _svd_band_pad(self, a, mm, nn, pad):
-    """nn not a multiple of the 16-wide panels: the band path runs on A' = blockdiag(A, delta I_pad), pad < 16, with
-    delta = 2 x a power-iteration estimate of s_1 (an estimate from below, so delta > s_1 unless it is off by more
-    than a factor two -- the caller checks that on the returned values).  A' has the singular triplets of A
-    (zero-extended) plus `pad` triplets (delta, e_i, e_i) that lead the spectrum: the call asks for `pad` more
-    vectors and drops the first `pad`.  Zero padding alone would not do: a zero column makes the last panel's Gram
-    matrix singular, which the Cholesky-QR reports instead of processing.  Costs one extra pass over A, sixteen
-    matrix-vector products, and a factor <= 2 in the absolute accuracy of the values (the brackets are relative to
-    the largest value, now delta).  Returns (A', delta) or (None, None)."""
+    """nn not a multiple of the 16-wide panels: the band path runs on
+        A'' = H_z blockdiag(A, delta I_pad) H_w,    H_x = I - 2 x x^T  (x a dense random unit vector),
+    pad < 16, delta = 2 x a power-iteration estimate of s_1 (an estimate from below, so delta > s_1 unless it is off
+    by more than a factor two -- the caller checks that on the returned values).  A'' has the singular values of A
+    plus `pad` values delta that lead the spectrum, and singular vectors H_z [u; 0], H_w [v; 0]: the call asks for
+    `pad` more vectors, drops the first `pad` and undoes the two reflections (`_svd_band_unpad`).
+    Why not zero padding: a zero column makes the last panel's Gram matrix singular, which the Cholesky-QR reports
+    instead of processing.  Why the reflections: in the bare blockdiag form the reflectors of the delta columns are
+    exact row swaps that leave whole ZERO rows in the next row panel (measured on the MI355X in round 4: status 25;
+    reproduced in tools/svd_band_model.py) -- one dense reflection per side removes every exact zero, and the panels'
+    Gram pivots stay where an unpadded matrix has them (model: 1e-3 ... 7e-7 of the largest, threshold 1e-9).
+    Costs three extra passes over A, sixteen + two matrix-vector products, and a factor <= 2 in the absolute accuracy
+    of the values (the brackets are relative to the largest value, now delta).
+    Returns (A'', delta, z, w) or (None, None, None, None)."""
     x = self.device_random((nn,), np.float32, seed=12345)
     for _ in range(8):
       y = self._tensordot_impl(a, x, [[1], [0]], None, None)[0]
@@ -1313,7 +1322,7 @@ class HipBackend(BackendBase):
       x = self._binary(_lib.OP_DIV, x, self.norm(x))
     est = float(np.asarray(self.norm(self._tensordot_impl(a, x, [[1], [0]], None, None)[0])))
     if not np.isfinite(est) or est <= 0.0:
-      return None, None
+      return None, None, None, None
     delta = float(np.float32(2.0 * est))
     big = DeviceTensor.empty((mm + pad, nn + pad), _lib.F32)
     _lib.check(self.lib.tnh_memset(_vp(big), 0, big.nbytes), "tnh_memset")
@@ -1323,7 +1332,23 @@ class HipBackend(BackendBase):
     _lib.check(self.lib.tnh_strided_scatter(_vp(big), _vp(dvec), 1, _lib.i64_array((pad,)),
                                             _lib.i64_array((nn + pad + 1,)), mm * (nn + pad) + nn, 4),
                "tnh_strided_scatter")
-    return big, delta
+    z = self.device_random((mm + pad,), np.float32, seed=23456)
+    z = self._binary(_lib.OP_DIV, z, self.norm(z))
+    w = self.device_random((nn + pad,), np.float32, seed=34567)
+    w = self._binary(_lib.OP_DIV, w, self.norm(w))
+    q = self._tensordot_impl(z, big, [[0], [0]], None, None)[0]                    # z^T A'
+    big = self._binary(_lib.OP_SUB, big, self.outer_product(self._binary(_lib.OP_MUL, z, 2.0), q))
+    p = self._tensordot_impl(big, w, [[1], [0]], None, None)[0]                    # (H_z A') w
+    big = self._binary(_lib.OP_SUB, big, self.outer_product(self._binary(_lib.OP_MUL, p, 2.0), w))
+    return big, delta, z, w
+
+  def _svd_band_unpad(self, uu, vvh, z, w):
+    """U' = H_z U'', V'^T = V''^T H_w for the vectors of the padded, reflected matrix (`_svd_band_pad`)."""
+    c = self._tensordot_impl(z, uu, [[0], [0]], None, None)[0]                     # (k,)
+    uu = self._binary(_lib.OP_SUB, uu, self.outer_product(self._binary(_lib.OP_MUL, z, 2.0), c))
+    d = self._tensordot_impl(vvh, w, [[1], [0]], None, None)[0]                    # (k,)
+    vvh = self._binary(_lib.OP_SUB, vvh, self.outer_product(self._binary(_lib.OP_MUL, d, 2.0), w))
+    return uu, vvh
 
   def _svd_complex_band(self, mat, m, n, max_singular_values, max_truncation_error, relative):
     """complex64 truncated SVD of a large matrix through the REAL band path.

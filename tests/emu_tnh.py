@@ -35,6 +35,35 @@ def _ints(arr, n):
   return [int(arr[i]) for i in range(n)]
 
 
+def _panels_full_rank(mat, threshold=1e-9):
+  import os  # pylint: disable=import-outside-toplevel
+  import sys  # pylint: disable=import-outside-toplevel
+  tools = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools")
+  if tools not in sys.path:
+    sys.path.insert(0, tools)
+  import svd_band_model as model  # pylint: disable=import-outside-toplevel
+  worst = [1.0]
+  inner = model.panel_factor
+
+  def watched(gram, ptop):
+    g = np.asarray(gram, dtype=np.float64).copy()
+    gmax = max(float(np.max(np.diag(g))), 1e-300)
+    for j in range(g.shape[0]):                 # un-pivoted Cholesky pivots, as the factor kernel forms them
+      d = g[j, j]
+      worst[0] = min(worst[0], d / gmax)
+      if not d > threshold * gmax:
+        break
+      g[j + 1:, j + 1:] -= np.outer(g[j + 1:, j], g[j, j + 1:]) / d
+    return inner(gram, ptop)
+
+  model.panel_factor = watched
+  try:
+    model.to_band(np.asarray(mat, dtype=np.float32))
+  finally:
+    model.panel_factor = inner
+  return worst[0] > threshold
+
+
 class EmuLib:
   """The subset of include/tnh.h the contraction lowering uses, on host memory."""
 
@@ -411,9 +440,11 @@ class EmuLib:
     assert self.tnh_svd_band_supported(_lib.F32, m, n, 0)
     mat = np.array(self._flat(a, m * n, np.float32)).reshape(m, n).astype(np.float64)
     u, sv, vh = np.linalg.svd(mat, full_matrices=False)
-    # a 16-column panel whose Gram matrix has a pivot below 1e-9 of the largest: stands in as "fewer than 16 values
-    # above 3e-5 s_1" (graded spectra pass on the device -- their panels are well conditioned --, low-rank inputs do not)
-    status = 1 if sv[0] == 0 or sv[min(15, n - 1)] < 3e-5 * sv[0] else 0
+    # ST_PANEL: a 16-wide panel whose Gram matrix has a Cholesky pivot below 1e-9 of its largest diagonal entry --
+    # decided by running stage 1 of the NumPy model of the algorithm (tools/svd_band_model.py: the same panels, the
+    # same order) on the input, so that inputs with structurally rank-deficient panels (zero-padded or block-diagonal
+    # matrices, low rank) fail here as they do on the MI355X
+    status = 1 if sv[0] == 0 or not _panels_full_rank(mat) else 0
     self._band_state = getattr(self, "_band_state", {})
     self._band_state[_addr(work)] = (u, sv, vh, int(kcap), status)
     coarse = np.round(sv / sv[0] * 2.0**20) / 2.0**20 * sv[0] if sv[0] > 0 else sv   # what 20-bit brackets carry

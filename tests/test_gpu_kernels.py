@@ -1117,3 +1117,43 @@ def test_narrow_integer_storage_is_normalised_where_arithmetic_is_not_modular(hi
   u = DeviceTensor.from_numpy(np.array([1, 2, 300]), dtype=np.uint8)
   assert u.dtype == np.uint8
   np.testing.assert_array_equal(np.asarray(u), np.array([1, 2, 300]).astype(np.uint8))
+
+
+def test_row_padded_results_on_the_device(hip):
+  """`pad_results` (off by default; measured in round 4 on the MERA chi = 32 layer: 0.2917 s with it, 0.2841 s
+  without -- no gain, so it stays off) on the MI355X: a large contraction result whose rows are a power of two is
+  written at a padded pitch (tnh_gemm_view's ldc), the next in-place contraction reads it through its strides (row
+  index AND contraction index carrying the pitch), everything else sees the dense copy.  Values against NumPy on the
+  same bf16-rounded operands."""
+  from oracle import numpy_oracle as orc
+  rng = np.random.default_rng(12)
+  a = orc.round_bf16(rng.standard_normal((13, 256, 128)).astype(np.float32) / 8)      # (r1, r2, k)
+  b = orc.round_bf16(rng.standard_normal((128, 4096)).astype(np.float32) / 8)         # (k, c): rows of 8 KiB
+  v = orc.round_bf16(rng.standard_normal((4096, 4096)).astype(np.float32) / 64)
+  w = orc.round_bf16(rng.standard_normal((12288, 4, 4096)).astype(np.float32) / 64)   # contracts (r2-part, c)
+  saved = (hip.pad_results, hip.pad_min_bytes)
+  try:
+    hip.pad_results, hip.pad_min_bytes = True, 1 << 20
+    c1 = hip.tensordot(hip.to_bfloat16(a), hip.to_bfloat16(b), [[2], [0]])             # (13, 256, 4096), padded rows
+    assert c1.pad == (2, 4096 + 64) and c1.shape == (13, 256, 4096)
+    ref1 = np.tensordot(a.astype(np.float64), b.astype(np.float64), [[2], [0]])
+    np.testing.assert_allclose(np.asarray(c1), ref1, rtol=2.0**-7, atol=2.0**-8 * 12)
+    c1h = orc.round_bf16(np.asarray(c1)).astype(np.float64)
+    before = hip.permute_launches
+    c3 = hip.tensordot(c1, hip.to_bfloat16(v), [[2], [0]])                             # rows at the pitch, K contiguous
+    assert hip.permute_launches == before and hip.lib.tnh_gemm_last_kernel().decode().startswith("bf16_view")
+    np.testing.assert_allclose(np.asarray(c3), np.tensordot(c1h, v.astype(np.float64), [[2], [0]]), rtol=2.0**-6,
+                               atol=2.0**-7 * 64)
+    # the pitch inside the contraction index: (13 x 64) x (4 x 4096) against a dense K-contiguous operand
+    c1v = c1.view((13 * 64, 4, 4096))
+    before = hip.permute_launches
+    c4 = hip.tensordot(hip.to_bfloat16(w), c1v, [[1, 2], [1, 2]])                      # (12288, 832)
+    assert hip.permute_launches == before
+    ref4 = np.tensordot(w.astype(np.float64), c1h.reshape(13 * 64, 4, 4096), [[1, 2], [1, 2]])
+    np.testing.assert_allclose(np.asarray(c4), ref4, rtol=2.0**-6, atol=2.0**-7 * 128)
+    # dense consumers
+    np.testing.assert_array_equal(np.asarray(hip.transpose(c1, (2, 0, 1))), np.transpose(orc.round_bf16(np.asarray(c1)), (2, 0, 1)))
+    np.testing.assert_array_equal(np.asarray(hip.reshape(c1, (13 * 256, 4096))), orc.round_bf16(np.asarray(c1)).reshape(13 * 256, 4096))
+    assert hip.reshape(c1, (13 * 256, 4096)).pad == (1, 4160)                          # reshape keeps the padding (ADVICE r3)
+  finally:
+    hip.pad_results, hip.pad_min_bytes = saved
