@@ -304,7 +304,7 @@ int tnh_svd_vectors_topk(int dtype, int64_t m, int64_t n, const void* A,
 
 /* ---- K7b: band + spectrum-slicing SVD for large f32 matrices (round 3) ----------------------------------
  * Same contract as tnh_svd_factor / tnh_svd_vectors (A = U diag(S) Vh, ALL min(m, n) values returned, S
- * descending; replaces np.linalg.svd behind decompositions.py:36) for row-major f32 A with m >= n,
+ * descending; replaces np.linalg.svd behind decompositions.py:36) for row-major f32 / f64 A with m >= n,
  * n >= 256, n % 16 == 0 -- a wide matrix is passed transposed by the caller.  Instead of Jacobi sweeps:
  * (1) two-sided blocked Householder reduction to an upper band of 16 super-diagonals (panels factored by
  * Cholesky-QR + Householder reconstruction, rank-16 streaming updates), (2) all singular values by spectrum
@@ -318,13 +318,20 @@ int tnh_svd_vectors_topk(int dtype, int64_t m, int64_t n, const void* A,
  *   status : host int (may be NULL = no read-back); non-zero bits mean the result must NOT be used and the
  *            caller re-runs tnh_svd_factor: 1 rank-deficient panel, 2 (unused), 4 clustered kept values,
  *            8 band residual, 16 a kept value below 1e-6 of the largest.
+ * dtype TNH_F32 or TNH_F64 (round 4; A, U, Vh, S, S_kept in that type).  The f64 form runs the same stages with
+ * two Cholesky-QR passes per panel (the Gram matrix of an f64 panel carries eps64 cond^2), every value to 32 bits
+ * (discarded values good to 1.2e-10 s_1; TNH_SVDB_BITS64), kept brackets to 2^-44 s_1, one Newton-Schulz step on the
+ * kept right and left band vectors (two f64 GEMMs each), and returns the kept VALUES as Rayleigh quotients |B v|;
+ * status bit 16 there means a kept value below 1e-5 s_1 (the vectors of smaller values lose eps64 (s_1 / s)^2 / gap
+ * on T = B^T B).
  * tnh_svd_band_layout returns byte offsets of {Af, Vl, Vr, Tl, Tr, Dblk, Eblk, Bd, Tb, lo, hi, X} inside the
  * (256-byte aligned) work buffer: the stage-by-stage GPU tests read them back. */
 int tnh_svd_band_supported(int dtype, int64_t m, int64_t n, int64_t k);
-int tnh_svd_band_work_bytes(int64_t m, int64_t n, int64_t kcap, size_t* nbytes);
-int tnh_svd_band_layout(int64_t m, int64_t n, int64_t kcap, int64_t* offsets, int count);
-int tnh_svd_band_factor(int64_t m, int64_t n, const void* A, void* S, void* work, int64_t kcap, int* status_out);
-int tnh_svd_band_vectors(int64_t m, int64_t n, void* work, int64_t kcap, int64_t k, void* U, void* Vh,
+int tnh_svd_band_work_bytes(int dtype, int64_t m, int64_t n, int64_t kcap, size_t* nbytes);
+int tnh_svd_band_layout(int dtype, int64_t m, int64_t n, int64_t kcap, int64_t* offsets, int count);
+int tnh_svd_band_factor(int dtype, int64_t m, int64_t n, const void* A, void* S, void* work, int64_t kcap,
+                        int* status_out);
+int tnh_svd_band_vectors(int dtype, int64_t m, int64_t n, void* work, int64_t kcap, int64_t k, void* U, void* Vh,
                          void* S_kept, int* status_out);
 
 /* The block pairs (32-row blocks a < b ... or a in one part, b in another) of ONE sweep of the block Jacobi

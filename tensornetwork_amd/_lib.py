@@ -113,10 +113,10 @@ SIGNATURES = {
     "tnh_svd_vectors_topk": (c_int, [c_int, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_void_p,
                                      c_void_p]),
     "tnh_svd_band_supported": (c_int, [c_int, c_int64, c_int64, c_int64]),
-    "tnh_svd_band_work_bytes": (c_int, [c_int64, c_int64, c_int64, POINTER(c_size_t)]),
-    "tnh_svd_band_layout": (c_int, [c_int64, c_int64, c_int64, _I64P, c_int]),
-    "tnh_svd_band_factor": (c_int, [c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_int64, POINTER(c_int)]),
-    "tnh_svd_band_vectors": (c_int, [c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p,
+    "tnh_svd_band_work_bytes": (c_int, [c_int, c_int64, c_int64, c_int64, POINTER(c_size_t)]),
+    "tnh_svd_band_layout": (c_int, [c_int, c_int64, c_int64, c_int64, _I64P, c_int]),
+    "tnh_svd_band_factor": (c_int, [c_int, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_int64, POINTER(c_int)]),
+    "tnh_svd_band_vectors": (c_int, [c_int, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p,
                                      POINTER(c_int)]),
     "tnh_qr_work_bytes": (c_int, [c_int, c_int64, c_int64, POINTER(c_size_t)]),
     "tnh_qr": (c_int, [c_int, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -119,23 +119,54 @@ __device__ __forceinline__ double fast_rsqrt(double x) {
   return y;
 }
 
+// ------------------------------------------------------------------------------------------------ element types
+// Round 4: the stage-1 kernels, the start of stage 3 and the back-transformation are templates over the element type
+// T (float: the round-3 path, unchanged; double: f64 inputs -- the reference's default dtype).  A lane still owns FOUR
+// consecutive elements (one 16-byte load for float, two for double), so the lane geometry -- 16 lanes x 4 = 64 columns
+// per workgroup row -- and every index computation are the same for both.
+template <typename T>
+struct alignas(sizeof(T) * 4) V4 {
+  T x, y, z, w;
+};
+template <typename T>
+struct alignas(sizeof(T) * 2) V2 {
+  T x, y;
+};
+template <typename T>
+__device__ __forceinline__ V4<T> vzero() {
+  return V4<T>{T(0), T(0), T(0), T(0)};
+}
+__device__ __forceinline__ float fmaT(float a, float b, float c) { return fmaf(a, b, c); }
+__device__ __forceinline__ double fmaT(double a, double b, double c) { return fma(a, b, c); }
+__device__ __forceinline__ double rowsum16(double v) { return sum16<true>(v); }
+__device__ __forceinline__ double rowsx4(double v) {     // sum over the four 16-lane rows of the wave, lane % 16 kept
+  v += __shfl_xor(v, 16, 64);
+  v += __shfl_xor(v, 32, 64);
+  return v;
+}
+// rows of a W-pass chunk (wpass_kernel stages them in LDS: 16 floats or doubles per row)
+template <typename T>
+constexpr int w_rc() {
+  return sizeof(T) == 4 ? 256 : 128;
+}
+
 // ------------------------------------------------------------------------------------------------ stage 1: Gram
 // Panel element (r, i), r = 0 .. rows-1, i = 0 .. 15:  P[r * sr + i * si].
 //   column panel: sr = lda, si = 1      row panel (the LQ is the QR of the transpose): sr = 1, si = lda
 // Gpart[b][i][c] = sum over the block's 256 panel rows of P(r, i) P(r, c), f64 (products of floats are exact).
-template <bool ROWPANEL>
-__global__ __launch_bounds__(256) void gram_kernel(const float* __restrict__ P, int64_t lda, int64_t rows,
+template <bool ROWPANEL, typename T>
+__global__ __launch_bounds__(256) void gram_kernel(const T* __restrict__ P, int64_t lda, int64_t rows,
                                                    double* __restrict__ Gpart) {
-  __shared__ float tile[256][17];
+  __shared__ T tile[256][17];
   const int tid = threadIdx.x;
   const int64_t r0 = (int64_t)blockIdx.x * 256;
   if (!ROWPANEL) {
     const int64_t r = r0 + tid;
-    float4 v[4];
+    V4<T> v[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) v[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int q = 0; q < 4; ++q) v[q] = vzero<T>();
     if (r < rows) {
-      const float4* src = reinterpret_cast<const float4*>(P + r * lda);
+      const V4<T>* src = reinterpret_cast<const V4<T>*>(P + r * lda);
 #pragma unroll
       for (int q = 0; q < 4; ++q) v[q] = src[q];
     }
@@ -147,7 +178,7 @@ __global__ __launch_bounds__(256) void gram_kernel(const float* __restrict__ P, 
   } else {
     const int64_t r = r0 + tid;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) tile[tid][i] = (r < rows) ? P[(int64_t)i * lda + r] : 0.f;
+    for (int i = 0; i < 16; ++i) tile[tid][i] = (r < rows) ? P[(int64_t)i * lda + r] : T(0);
   }
   __syncthreads();
   const int i = tid >> 4, c = tid & 15;
@@ -179,18 +210,62 @@ __device__ __forceinline__ void wave_sync() {
   __builtin_amdgcn_wave_barrier();
 }
 
+// Cholesky G = R^T R, right-looking, in registers + DPP row broadcasts (no LDS round trip per step): lane r (of each
+// 16-lane row; the four rows of the wave do the same work) holds ROW r of the matrix, register c its column c.
+// G is symmetric, so R(j, r) = G(r, j) / r_jj is lane r's own register j.  Row r of G stops changing at step r, so
+// R(r, c) = G^(r)(r, c) / r_rr is formed after the loop from the lane's own registers and its own 1 / r_rr.
+// A pivot that is not above `thresh` is replaced by it and reported (bad).
+__device__ __forceinline__ void cholesky_rows(double (&Gr)[16], int r, double thresh, int& bad, double (&Rr)[16]) {
+  double myrinv = 0.0, mydiag = 0.0;
+  static_for<16>([&](auto jc) {
+    constexpr int j = decltype(jc)::value;
+    double piv = bcast16_dpp<j>(Gr[j]);
+    if (!(piv > thresh)) {
+      piv = thresh;
+      bad = 1;
+    }
+    const double rinv = fast_rsqrt(piv);
+    if (r == j) {
+      myrinv = rinv;
+      mydiag = piv * rinv;
+    }
+    const double rowv = (r > j) ? Gr[j] * rinv : 0.0;       // R(j, r) for the rows still being reduced
+    static_for<16>([&](auto cc) {
+      constexpr int c = decltype(cc)::value;
+      if (c > j) Gr[c] = fma(-rowv, bcast16_dpp<c>(rowv), Gr[c]);
+    });
+  });
+#pragma unroll
+  for (int c = 0; c < 16; ++c) Rr[c] = (c > r) ? Gr[c] * myrinv : (c == r ? mydiag : 0.0);
+}
+
+// Inverse of an upper triangular matrix held row per lane (Ur = row r): lane c solves U x = e_c, x[ii] = (U^-1)(ii, c)
+// for ii <= c (entries below the diagonal of the inverse are not touched: the caller masks them).
+__device__ __forceinline__ void upper_inverse_cols(const double (&Ur)[16], int r, double (&x)[16]) {
+  static_for<16>([&](auto ic) {
+    constexpr int ii = 15 - decltype(ic)::value;
+    double acc = (ii == r) ? 1.0 : 0.0;
+    static_for<16>([&](auto kc) {
+      constexpr int k = decltype(kc)::value;
+      if (k > ii) acc = fma(-bcast16_dpp<ii>(Ur[k]), x[k], acc);
+    });
+    x[ii] = acc * fast_rcp(bcast16_dpp<ii>(Ur[ii]));
+  });
+}
+
 // All 256 threads.  In: sh.G0 = sh.G (Gram, f64), sh.Pt.  Out: sh.X, sh.L (V_top), sh.Ti (T^-1, reciprocal diagonal),
 // sh.R and sh.S (R_h = S R), sh.bad.
 // degenerate: the panel has exactly 16 rows, so its last column has nothing below the diagonal.  LAPACK's larfg
 // then returns tau = 0 (H = I, the entry keeps its sign); here: S_15 = +sign, reciprocal diagonal of T^-1 = 0
 // (so that T w has a zero last component), and R matches np.linalg.qr also in its last diagonal entry.
-__device__ __forceinline__ void panel_factor(FactorShared& sh, bool degenerate) {
+// rel_thresh: a panel whose Gram matrix has a pivot below rel_thresh of its largest diagonal entry loses
+// orthogonality in the Cholesky-QR (eps64 * cond^2): reported, the caller takes the Jacobi path.  1e-9 for f32
+// input (eps64 cond^2 ~ 1e-7); the second pass of the f64 path sees G = I + O(eps64 cond^2) and uses 1e-3.
+__device__ __forceinline__ void panel_factor(FactorShared& sh, bool degenerate, double rel_thresh) {
   const int tid = threadIdx.x, i = tid >> 4, c = tid & 15;
   if (tid == 0) sh.bad = 0;
   __syncthreads();
   if (tid < 64) {
-    // Registers + DPP row broadcasts, no LDS round trip per step: lane r (of each 16-lane row; the four rows of the
-    // wave do the same work) holds ROW r of the matrix being factored, register c its column c.
     const int r = tid & 15;
     double Gr[16], Wr[16], Rr[16];
 #pragma unroll
@@ -198,34 +273,9 @@ __device__ __forceinline__ void panel_factor(FactorShared& sh, bool degenerate) 
     double gmax = 0.0;
 #pragma unroll
     for (int k = 0; k < 16; ++k) gmax = fmax(gmax, sh.G[k][k]);
-    // a panel whose Gram matrix has a pivot below 1e-9 of its largest diagonal entry loses orthogonality in the
-    // Cholesky-QR (eps64 * cond^2 ~ 1e-7): reported, the caller takes the Jacobi path
-    const double thresh = 1e-9 * fmax(gmax, 1e-300);
+    const double thresh = rel_thresh * fmax(gmax, 1e-300);
     int bad = 0;
-    // ---- Cholesky G = R^T R, right-looking.  G is symmetric, so R(j, r) = G(r, j) / r_jj is lane r's own register j.
-    // Row r of G stops changing at step r, so R(r, c) = G^(r)(r, c) / r_rr is formed after the loop from the lane's own
-    // registers and its own 1 / r_rr.
-    double myrinv = 0.0, mydiag = 0.0;
-    static_for<16>([&](auto jc) {
-      constexpr int j = decltype(jc)::value;
-      double piv = bcast16_dpp<j>(Gr[j]);
-      if (!(piv > thresh)) {
-        piv = thresh;
-        bad = 1;
-      }
-      const double rinv = fast_rsqrt(piv);
-      if (r == j) {
-        myrinv = rinv;
-        mydiag = piv * rinv;
-      }
-      const double rowv = (r > j) ? Gr[j] * rinv : 0.0;       // R(j, r) for the rows still being reduced
-      static_for<16>([&](auto cc) {
-        constexpr int c = decltype(cc)::value;
-        if (c > j) Gr[c] = fma(-rowv, bcast16_dpp<c>(rowv), Gr[c]);
-      });
-    });
-#pragma unroll
-    for (int c = 0; c < 16; ++c) Rr[c] = (c > r) ? Gr[c] * myrinv : (c == r ? mydiag : 0.0);
+    cholesky_rows(Gr, r, thresh, bad, Rr);
     // ---- in-place LU of Pt - S R: S_jj = -sign of the pivot candidate (so |pivot| >= R_jj)
 #pragma unroll
     for (int k = 0; k < 16; ++k) Wr[k] = sh.Pt[r][k];
@@ -250,15 +300,7 @@ __device__ __forceinline__ void panel_factor(FactorShared& sh, bool degenerate) 
     });
     // ---- X = Ut^-1: lane c solves Ut x = e_c; Ut(ii, k) comes from lane ii, register k
     double x[16];
-    static_for<16>([&](auto ic) {
-      constexpr int ii = 15 - decltype(ic)::value;
-      double acc = (ii == r) ? 1.0 : 0.0;
-      static_for<16>([&](auto kc) {
-        constexpr int k = decltype(kc)::value;
-        if (k > ii) acc = fma(-bcast16_dpp<ii>(Wr[k]), x[k], acc);
-      });
-      x[ii] = acc * fast_rcp(bcast16_dpp<ii>(Wr[ii]));
-    });
+    upper_inverse_cols(Wr, r, x);
     if (tid < 16) {
 #pragma unroll
       for (int k = 0; k < 16; ++k) {
@@ -297,70 +339,177 @@ __device__ __forceinline__ void panel_factor(FactorShared& sh, bool degenerate) 
   __syncthreads();
 }
 
+// sum of `nparts` 16 x 16 partial Gram matrices, entry `tid`: all partials requested before the first add (clamped
+// index, no branch around a load)
+__device__ __forceinline__ double gram_sum(const double* __restrict__ Gpart, int nparts, int tid) {
+  double g = 0.0;
+  for (int b0 = 0; b0 < nparts; b0 += 16) {
+    double pv[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int b = b0 + q;
+      pv[q] = Gpart[(int64_t)(b < nparts ? b : nparts - 1) * 256 + tid];
+    }
+#pragma unroll
+    for (int q = 0; q < 16; ++q) g += (b0 + q < nparts) ? pv[q] : 0.0;
+  }
+  return g;
+}
+
 // ONE workgroup per panel: the 16 x 16 algebra and the panel's small outputs.
 //   P: panel origin (see gram_kernel).  Xout: 16 x 16 f64 (V_below = P_below X).
-//   Vout: rows 0 .. 15 of the panel's V (rows x 16 row-major, f32) = V_top;  VtOut (row panels): the same, transposed.
+//   Vout: rows 0 .. 15 of the panel's V (rows x 16 row-major) = V_top;  VtOut (row panels): the same, transposed.
 //   Tout: 16 x 16 f64 = T^-1 (upper, reciprocal diagonal).  Blk: band block: column panel -> R_h (upper triangular);
 //   row panel -> R_h^T (lower).
+//   R1 (f64 path, second pass of the Cholesky-QR2): the panel in memory is Q1 = P0 R1^-1 of the original panel P0;
+//   the reflector H that triangularises Q1 ([S R2; 0]) triangularises P0 = Q1 R1 to [S R2 R1; 0]: Blk = S R2 R1.
 // (Round-3 measurement: the first version repeated this factorisation in every V-forming workgroup; with more than 8
 // workgroups the launch took 40-60 us instead of 12.)
-template <bool ROWPANEL>
-__global__ __launch_bounds__(256) void factor_kernel(const float* __restrict__ P, int64_t lda, int64_t rows,
+template <bool ROWPANEL, typename T>
+__global__ __launch_bounds__(256) void factor_kernel(const T* __restrict__ P, int64_t lda, int64_t rows,
                                                      const double* __restrict__ Gpart, int nparts,
-                                                     double* __restrict__ Xout, float* __restrict__ Vout,
-                                                     float* __restrict__ VtOut, int64_t vt_pitch,
+                                                     double* __restrict__ Xout, T* __restrict__ Vout,
+                                                     T* __restrict__ VtOut, int64_t vt_pitch,
                                                      double* __restrict__ Tout, double* __restrict__ Blk,
+                                                     const double* __restrict__ R1, double rel_thresh,
                                                      int* __restrict__ status) {
   __shared__ FactorShared sh;
   const int tid = threadIdx.x, i = tid >> 4, c = tid & 15;
   {
-    // all partials requested before the first add (clamped index, no branch around a load)
-    double g = 0.0;
-    for (int b0 = 0; b0 < nparts; b0 += 16) {
-      double pv[16];
-#pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        const int b = b0 + q;
-        pv[q] = Gpart[(int64_t)(b < nparts ? b : nparts - 1) * 256 + tid];
-      }
-#pragma unroll
-      for (int q = 0; q < 16; ++q) g += (b0 + q < nparts) ? pv[q] : 0.0;
-    }
+    const double g = gram_sum(Gpart, nparts, tid);
     sh.G[i][c] = g;
     sh.G0[i][c] = g;
     sh.Pt[i][c] = (double)(ROWPANEL ? P[(int64_t)c * lda + i] : P[(int64_t)i * lda + c]);
   }
   __syncthreads();
-  panel_factor(sh, rows == 16);
+  panel_factor(sh, rows == 16, rel_thresh);
   Xout[tid] = sh.X[i][c];
   Tout[tid] = sh.Ti[i][c];
-  const double rh = (c >= i) ? sh.S[i] * sh.R[i][c] : 0.0;     // R_h = S R, upper
+  double rh;
+  if (R1 != nullptr) {
+    sh.W[i][c] = R1[tid];
+    __syncthreads();
+    double acc = 0.0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) acc += sh.R[i][k] * sh.W[k][c];      // upper x upper: zero below the diagonal
+    rh = (c >= i) ? sh.S[i] * acc : 0.0;
+  } else {
+    rh = (c >= i) ? sh.S[i] * sh.R[i][c] : 0.0;                       // R_h = S R, upper
+  }
   if (!ROWPANEL) Blk[tid] = rh;
   else Blk[c * 16 + i] = rh;                                    // transposed: lower triangular
-  const float vt = (float)((i >= c) ? sh.L[i][c] : 0.0);        // V_top, unit lower
+  const T vt = (T)((i >= c) ? sh.L[i][c] : 0.0);                // V_top, unit lower
   Vout[(int64_t)i * 16 + c] = vt;
   if (ROWPANEL) VtOut[(int64_t)c * vt_pitch + i] = vt;
   if (tid == 0 && sh.bad) atomicOr(status, (int)ST_PANEL);
 }
 
+// f64 path, first pass of the Cholesky-QR2: G1 = P^T P (partials) -> R1 (upper, f64) and R1^-1.  One workgroup (one
+// wave does the work).  The Gram matrix of an f64 panel carries eps64 cond^2 of error, which a single Cholesky-QR
+// turns into that much backward error of the panel's factorisation (f32 input: 1e-16 cond^2 against an eps of 6e-8
+// -- invisible; f64 input: visible from cond ~ 30 on).  The second pass factors Q1 = P R1^-1, whose Gram matrix is
+// I + O(eps64 cond^2): its Cholesky-QR is accurate to eps64 as long as eps64 cond^2 << 1 (pivots below 1e-13 of the
+// largest are reported: cond > 3e6).
+__global__ __launch_bounds__(64) void chol_kernel(const double* __restrict__ Gpart, int nparts, double* __restrict__ R1,
+                                                  double* __restrict__ R1inv, int* __restrict__ status) {
+  __shared__ double G[16][17];
+  const int tid = threadIdx.x, r = tid & 15;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int t = tid + 64 * e;
+    G[t >> 4][t & 15] = gram_sum(Gpart, nparts, t);
+  }
+  __syncthreads();
+  double Gr[16], Rr[16], x[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) Gr[k] = G[r][k];
+  double gmax = 0.0;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) gmax = fmax(gmax, G[k][k]);
+  int bad = 0;
+  cholesky_rows(Gr, r, 1e-13 * fmax(gmax, 1e-300), bad, Rr);
+  upper_inverse_cols(Rr, r, x);
+  if (tid < 16) {
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      R1[r * 16 + k] = Rr[k];
+      R1inv[k * 16 + r] = (k <= r) ? x[k] : 0.0;       // lane r holds column r of the inverse
+    }
+    if (tid == 0 && bad) atomicOr(status, (int)ST_PANEL);
+  }
+}
+
+// f64 path: Q1 = P R1^-1 in place (256 panel rows per workgroup) and the partial Gram matrices of Q1.
+template <bool ROWPANEL, typename T>
+__global__ __launch_bounds__(256) void scaleq_kernel(T* __restrict__ P, int64_t lda, int64_t rows,
+                                                     const double* __restrict__ R1inv, double* __restrict__ Gpart) {
+  __shared__ double xs[16][17];
+  __shared__ T tile[256][17];
+  const int tid = threadIdx.x;
+  xs[tid >> 4][tid & 15] = R1inv[tid];
+  const int64_t r = (int64_t)blockIdx.x * 256 + tid;
+  T p[16];
+#pragma unroll
+  for (int l = 0; l < 16; ++l) p[l] = T(0);
+  if (r < rows) {
+    if (!ROWPANEL) {
+      const V4<T>* src = reinterpret_cast<const V4<T>*>(P + r * lda);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const V4<T> v = src[q];
+        p[4 * q] = v.x; p[4 * q + 1] = v.y; p[4 * q + 2] = v.z; p[4 * q + 3] = v.w;
+      }
+    } else {
+#pragma unroll
+      for (int l = 0; l < 16; ++l) p[l] = P[(int64_t)l * lda + r];
+    }
+  }
+  __syncthreads();
+  T qv[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    double acc = 0.0;
+#pragma unroll
+    for (int l = 0; l <= k; ++l) acc += (double)p[l] * xs[l][k];      // R1^-1 is upper triangular
+    qv[k] = (T)acc;
+    tile[tid][k] = qv[k];
+  }
+  if (r < rows) {
+    if (!ROWPANEL) {
+      V4<T>* dst = reinterpret_cast<V4<T>*>(P + r * lda);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) dst[q] = V4<T>{qv[4 * q], qv[4 * q + 1], qv[4 * q + 2], qv[4 * q + 3]};
+    } else {
+#pragma unroll
+      for (int k = 0; k < 16; ++k) P[(int64_t)k * lda + r] = qv[k];
+    }
+  }
+  __syncthreads();
+  const int i = tid >> 4, c = tid & 15;
+  double acc = 0.0;
+#pragma unroll 8
+  for (int rr = 0; rr < 256; ++rr) acc += (double)tile[rr][i] * (double)tile[rr][c];
+  Gpart[(int64_t)blockIdx.x * 256 + tid] = acc;
+}
+
 // V rows below the top block: V[r][:] = P[r][:] X (f64 accumulate), r = 16 .. rows - 1, 256 rows per workgroup.
-template <bool ROWPANEL>
-__global__ __launch_bounds__(256) void formv_kernel(const float* __restrict__ P, int64_t lda, int64_t rows,
-                                                    const double* __restrict__ X, float* __restrict__ Vout,
-                                                    float* __restrict__ VtOut, int64_t vt_pitch) {
+template <bool ROWPANEL, typename T>
+__global__ __launch_bounds__(256) void formv_kernel(const T* __restrict__ P, int64_t lda, int64_t rows,
+                                                    const double* __restrict__ X, T* __restrict__ Vout,
+                                                    T* __restrict__ VtOut, int64_t vt_pitch) {
   __shared__ double xs[16][17];
   const int tid = threadIdx.x;
   xs[tid >> 4][tid & 15] = X[tid];
   const int64_t r = 16 + (int64_t)blockIdx.x * 256 + tid;
-  float p[16];
+  T p[16];
 #pragma unroll
-  for (int l = 0; l < 16; ++l) p[l] = 0.f;
+  for (int l = 0; l < 16; ++l) p[l] = T(0);
   if (r < rows) {
     if (!ROWPANEL) {
-      const float4* src = reinterpret_cast<const float4*>(P + r * lda);
+      const V4<T>* src = reinterpret_cast<const V4<T>*>(P + r * lda);
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const float4 v = src[q];
+        const V4<T> v = src[q];
         p[4 * q] = v.x; p[4 * q + 1] = v.y; p[4 * q + 2] = v.z; p[4 * q + 3] = v.w;
       }
     } else {
@@ -370,17 +519,17 @@ __global__ __launch_bounds__(256) void formv_kernel(const float* __restrict__ P,
   }
   __syncthreads();
   if (r < rows) {
-    float v[16];
+    T v[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
       double acc = 0.0;
 #pragma unroll
       for (int l = 0; l < 16; ++l) acc += (double)p[l] * xs[l][k];
-      v[k] = (float)acc;
+      v[k] = (T)acc;
     }
-    float4* dst = reinterpret_cast<float4*>(Vout + r * 16);
+    V4<T>* dst = reinterpret_cast<V4<T>*>(Vout + r * 16);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) dst[q] = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+    for (int q = 0; q < 4; ++q) dst[q] = V4<T>{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
     if (ROWPANEL) {
 #pragma unroll
       for (int k = 0; k < 16; ++k) VtOut[(int64_t)k * vt_pitch + r] = v[k];
@@ -390,53 +539,54 @@ __global__ __launch_bounds__(256) void formv_kernel(const float* __restrict__ P,
 
 // ------------------------------------------------------------------------------------------------ rank-16 streaming
 // Lane geometry shared by the streaming kernels: 256 threads = 4 waves; lane = (g = lane / 16, t = lane % 16);
-// a wave covers 4 rows (g) x 64 columns (float4 per t), a workgroup 16 rows x 64 columns per iteration.
+// a wave covers 4 rows (g) x 64 columns (4 elements per t), a workgroup 16 rows x 64 columns per iteration.
 
 // Wpart[chunk][i][c] = sum over the chunk's RC rows of V[r][i] C[r][c]       (W = V^T C, partial over row chunks)
 // The chunk's V rows are staged once in LDS (every lane group reads whole rows: broadcast reads); the C loads of
-// eight 16-row steps are requested before the first FMA.
-constexpr int W_RC = 256;
+// four 16-row steps are requested before the first FMA.
 constexpr int W_UNROLL = 4;
-__global__ __launch_bounds__(256) void wpass_kernel(const float* __restrict__ C, int64_t ldc, int64_t rows, int64_t nc,
-                                                    const float* __restrict__ V, float* __restrict__ Wpart) {
-  __shared__ float4 vs[W_RC][4];        // V rows of the chunk
-  __shared__ float red[4][16][65];      // [wave][i][column]
+template <typename T>
+__global__ __launch_bounds__(256) void wpass_kernel(const T* __restrict__ C, int64_t ldc, int64_t rows, int64_t nc,
+                                                    const T* __restrict__ V, T* __restrict__ Wpart) {
+  constexpr int RC = w_rc<T>();
+  __shared__ V4<T> vs[RC][4];       // V rows of the chunk
+  __shared__ T red[4][16][65];      // [wave][i][column]
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, t = lane & 15;
   const int64_t c0 = (int64_t)blockIdx.x * 64 + 4 * t;
-  const int64_t rbeg = (int64_t)blockIdx.y * W_RC;
+  const int64_t rbeg = (int64_t)blockIdx.y * RC;
   const bool col_ok = c0 < nc;
-  {
+  if (tid < RC) {
     const int64_t r = rbeg + tid;
-    const float4* vp = reinterpret_cast<const float4*>(V + r * 16);
+    const V4<T>* vp = reinterpret_cast<const V4<T>*>(V + r * 16);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) vs[tid][q] = (r < rows) ? vp[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int q = 0; q < 4; ++q) vs[tid][q] = (r < rows) ? vp[q] : vzero<T>();
   }
   __syncthreads();
-  float acc[16][4];
+  T acc[16][4];
 #pragma unroll
   for (int i = 0; i < 16; ++i)
 #pragma unroll
-    for (int q = 0; q < 4; ++q) acc[i][q] = 0.f;
-  for (int it0 = 0; it0 < W_RC / 16; it0 += W_UNROLL) {
-    float4 cv[W_UNROLL];
+    for (int q = 0; q < 4; ++q) acc[i][q] = T(0);
+  for (int it0 = 0; it0 < RC / 16; it0 += W_UNROLL) {
+    V4<T> cv[W_UNROLL];
 #pragma unroll
     for (int u = 0; u < W_UNROLL; ++u) {
       const int64_t r = rbeg + (it0 + u) * 16 + w * 4 + g;
-      cv[u] = (r < rows && col_ok) ? *reinterpret_cast<const float4*>(C + r * ldc + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
+      cv[u] = (r < rows && col_ok) ? *reinterpret_cast<const V4<T>*>(C + r * ldc + c0) : vzero<T>();
     }
 #pragma unroll
     for (int u = 0; u < W_UNROLL; ++u) {
       const int lr = (it0 + u) * 16 + w * 4 + g;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const float4 x = vs[lr][q];
-        const float ve[4] = {x.x, x.y, x.z, x.w};
+        const V4<T> x = vs[lr][q];
+        const T ve[4] = {x.x, x.y, x.z, x.w};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          acc[4 * q + e][0] = fmaf(ve[e], cv[u].x, acc[4 * q + e][0]);
-          acc[4 * q + e][1] = fmaf(ve[e], cv[u].y, acc[4 * q + e][1]);
-          acc[4 * q + e][2] = fmaf(ve[e], cv[u].z, acc[4 * q + e][2]);
-          acc[4 * q + e][3] = fmaf(ve[e], cv[u].w, acc[4 * q + e][3]);
+          acc[4 * q + e][0] = fmaT(ve[e], cv[u].x, acc[4 * q + e][0]);
+          acc[4 * q + e][1] = fmaT(ve[e], cv[u].y, acc[4 * q + e][1]);
+          acc[4 * q + e][2] = fmaT(ve[e], cv[u].z, acc[4 * q + e][2]);
+          acc[4 * q + e][3] = fmaT(ve[e], cv[u].w, acc[4 * q + e][3]);
         }
       }
     }
@@ -446,7 +596,7 @@ __global__ __launch_bounds__(256) void wpass_kernel(const float* __restrict__ C,
   for (int i = 0; i < 16; ++i)
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const float v = rowsx4(acc[i][q]);
+      const T v = rowsx4(acc[i][q]);
       if (g == 0) red[w][i][4 * t + q] = v;
     }
   __syncthreads();
@@ -454,37 +604,37 @@ __global__ __launch_bounds__(256) void wpass_kernel(const float* __restrict__ C,
   const int i = tid >> 4;
   const int64_t cc = (int64_t)blockIdx.x * 64 + 4 * (tid & 15);
   if (cc < nc) {
-    float o[4];
+    T o[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      float s = 0.f;
+      T s = T(0);
 #pragma unroll
       for (int k = 0; k < 4; ++k) s += red[k][i][4 * (tid & 15) + q];
       o[q] = s;
     }
-    *reinterpret_cast<float4*>(Wpart + ((int64_t)blockIdx.y * 16 + i) * nc + cc) = make_float4(o[0], o[1], o[2], o[3]);
+    *reinterpret_cast<V4<T>*>(Wpart + ((int64_t)blockIdx.y * 16 + i) * nc + cc) = V4<T>{o[0], o[1], o[2], o[3]};
   }
 }
 
 // Solves with the upper triangular T^-1 = Ti (diagonal stored as its reciprocal), per thread, in registers.
 //   trans = 1:  w = T^T s  <=>  Ti^T w = s  (forward substitution)      trans = 0:  w = T s  <=>  Ti w = s  (backward)
-template <typename TS>
-__device__ __forceinline__ void tsolve(const TS (*Ti)[17], int trans, const float* s, float* w) {
+template <typename TS, typename T>
+__device__ __forceinline__ void tsolve(const TS (*Ti)[17], int trans, const T* s, T* w) {
   if (trans) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-      float acc = s[i];
+      T acc = s[i];
 #pragma unroll
-      for (int l = 0; l < i; ++l) acc = fmaf(-(float)Ti[l][i], w[l], acc);
-      w[i] = acc * (float)Ti[i][i];
+      for (int l = 0; l < i; ++l) acc = fmaT(-(T)Ti[l][i], w[l], acc);
+      w[i] = acc * (T)Ti[i][i];
     }
   } else {
 #pragma unroll
     for (int i = 15; i >= 0; --i) {
-      float acc = s[i];
+      T acc = s[i];
 #pragma unroll
-      for (int l = i + 1; l < 16; ++l) acc = fmaf(-(float)Ti[i][l], w[l], acc);
-      w[i] = acc * (float)Ti[i][i];
+      for (int l = i + 1; l < 16; ++l) acc = fmaT(-(T)Ti[i][l], w[l], acc);
+      w[i] = acc * (T)Ti[i][i];
     }
   }
 }
@@ -492,16 +642,17 @@ __device__ __forceinline__ void tsolve(const TS (*Ti)[17], int trans, const floa
 // Wt[:, c] = T^T (trans = 1: H^T C) or T (trans = 0: H C) times the sum over chunks of Wpart[chunk][:, c].
 // 64 columns per workgroup; the four waves take the chunks ch % 4 (their loads are in flight together), wave 0
 // finishes.  Fixed summation order: deterministic.
-__global__ __launch_bounds__(256) void wreduce_kernel(const float* __restrict__ Wpart, int nchunks, int64_t nc,
-                                                      const double* __restrict__ Tinv, int trans, float* __restrict__ Wt) {
-  __shared__ float Ts[16][17];
-  __shared__ float part[4][16][65];
+template <typename T>
+__global__ __launch_bounds__(256) void wreduce_kernel(const T* __restrict__ Wpart, int nchunks, int64_t nc,
+                                                      const double* __restrict__ Tinv, int trans, T* __restrict__ Wt) {
+  __shared__ T Ts[16][17];
+  __shared__ T part[4][16][65];
   const int tid = threadIdx.x, cg = tid >> 6, cl = tid & 63;
-  Ts[tid >> 4][tid & 15] = (float)Tinv[tid];
+  Ts[tid >> 4][tid & 15] = (T)Tinv[tid];
   const int64_t c = (int64_t)blockIdx.x * 64 + cl;
-  float s[16];
+  T s[16];
 #pragma unroll
-  for (int l = 0; l < 16; ++l) s[l] = 0.f;
+  for (int l = 0; l < 16; ++l) s[l] = T(0);
   if (c < nc) {
     for (int ch = cg; ch < nchunks; ch += 4) {
 #pragma unroll
@@ -514,7 +665,7 @@ __global__ __launch_bounds__(256) void wreduce_kernel(const float* __restrict__ 
   if (cg == 0 && c < nc) {
 #pragma unroll
     for (int l = 0; l < 16; ++l) s[l] = (part[0][l][cl] + part[1][l][cl]) + (part[2][l][cl] + part[3][l][cl]);
-    float w[16];
+    T w[16];
     tsolve(Ts, trans, s, w);
 #pragma unroll
     for (int i = 0; i < 16; ++i) Wt[(int64_t)i * nc + c] = w[i];
@@ -529,48 +680,48 @@ __global__ __launch_bounds__(256) void wreduce_kernel(const float* __restrict__ 
 //           (rows below gram_row0 only: the QR keeps its R rows at the top of the block);
 // Either saves the separate pass of gram_kernel over the panel and its launch.
 constexpr int U_RR = 128;
-template <int GRAM>
-__global__ __launch_bounds__(256) void update_kernel(float* __restrict__ C, int64_t ldc, int64_t rows, int64_t nc,
-                                                     const float* __restrict__ V, const float* __restrict__ Wt,
+template <int GRAM, typename T>
+__global__ __launch_bounds__(256) void update_kernel(T* __restrict__ C, int64_t ldc, int64_t rows, int64_t nc,
+                                                     const T* __restrict__ V, const T* __restrict__ Wt,
                                                      int64_t wt_pitch, double* __restrict__ Gpart, int64_t gram_row0) {
-  __shared__ float tile[(GRAM == 1) ? U_RR : 16][(GRAM == 1) ? 17 : 65];
+  __shared__ T tile[(GRAM == 1) ? U_RR : 16][(GRAM == 1) ? 17 : 65];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, t = lane & 15;
   const int64_t c0 = (int64_t)blockIdx.x * 64 + 4 * t;
   const bool col_ok = c0 < nc;
   const bool gram_wg = (GRAM == 1) ? (blockIdx.x == 0) : ((GRAM == 2) ? (blockIdx.y == 0) : false);
-  float4 wt[16];
+  V4<T> wt[16];
 #pragma unroll
   for (int i = 0; i < 16; ++i)
-    wt[i] = col_ok ? *reinterpret_cast<const float4*>(Wt + (int64_t)i * wt_pitch + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
+    wt[i] = col_ok ? *reinterpret_cast<const V4<T>*>(Wt + (int64_t)i * wt_pitch + c0) : vzero<T>();
   const int64_t rbeg = (int64_t)blockIdx.y * U_RR;
 #pragma unroll 2
   for (int it = 0; it < U_RR / 16; ++it) {
     const int lr = it * 16 + w * 4 + g;
     const int64_t r = rbeg + lr;
-    float4 cv = make_float4(0.f, 0.f, 0.f, 0.f);
+    V4<T> cv = vzero<T>();
     if (r < rows && col_ok) {
-      float4* cp = reinterpret_cast<float4*>(C + r * ldc + c0);
+      V4<T>* cp = reinterpret_cast<V4<T>*>(C + r * ldc + c0);
       cv = *cp;
-      const float4* vp = reinterpret_cast<const float4*>(V + r * 16);
+      const V4<T>* vp = reinterpret_cast<const V4<T>*>(V + r * 16);
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const float4 x = vp[q];
-        const float vv[4] = {x.x, x.y, x.z, x.w};
+        const V4<T> x = vp[q];
+        const T vv[4] = {x.x, x.y, x.z, x.w};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const float4 ww = wt[4 * q + e];
-          cv.x = fmaf(-vv[e], ww.x, cv.x);
-          cv.y = fmaf(-vv[e], ww.y, cv.y);
-          cv.z = fmaf(-vv[e], ww.z, cv.z);
-          cv.w = fmaf(-vv[e], ww.w, cv.w);
+          const V4<T> ww = wt[4 * q + e];
+          cv.x = fmaT(-vv[e], ww.x, cv.x);
+          cv.y = fmaT(-vv[e], ww.y, cv.y);
+          cv.z = fmaT(-vv[e], ww.z, cv.z);
+          cv.w = fmaT(-vv[e], ww.w, cv.w);
         }
       }
       *cp = cv;
     }
     if (GRAM == 1 && gram_wg && t < 4) {      // rows above gram_row0 belong to R, not to the next panel (QR)
       const bool in = r >= gram_row0;
-      tile[lr][4 * t] = in ? cv.x : 0.f; tile[lr][4 * t + 1] = in ? cv.y : 0.f;
-      tile[lr][4 * t + 2] = in ? cv.z : 0.f; tile[lr][4 * t + 3] = in ? cv.w : 0.f;
+      tile[lr][4 * t] = in ? cv.x : T(0); tile[lr][4 * t + 1] = in ? cv.y : T(0);
+      tile[lr][4 * t + 2] = in ? cv.z : T(0); tile[lr][4 * t + 3] = in ? cv.w : T(0);
     }
     if (GRAM == 2 && gram_wg && it == 0) {
       tile[lr][4 * t] = cv.x; tile[lr][4 * t + 1] = cv.y; tile[lr][4 * t + 2] = cv.z; tile[lr][4 * t + 3] = cv.w;
@@ -593,7 +744,7 @@ __global__ __launch_bounds__(256) void update_kernel(float* __restrict__ C, int6
 }
 
 // Row panel, fused:  Y = C V (rows x 16, row-local),  Z = Y T,  C -= Z V^T.   Vt: 16 x nc (V transposed);
-// T comes as T^-1 (see panel_factor).
+// T comes as T^-1 (see panel_factor).  f32 only (A/B variant, TNH_SVDB_ROWFUSED=1).
 // A workgroup owns 16 rows (lane = (row-in-wave g, column chunk t)) and sweeps all columns twice.
 constexpr int RU_TILES = 8;   // column tiles of 64 per staging step (8 loads per lane in flight)
 __global__ __launch_bounds__(256) void rowupdate_kernel(float* __restrict__ C, int64_t ldc, int64_t rows, int64_t nc,
@@ -676,60 +827,66 @@ __global__ __launch_bounds__(256) void rowupdate_kernel(float* __restrict__ C, i
 
 
 // Row panel in three launches (more workgroups than the fused kernel can offer: it owns whole rows):
-//   ypass    Ypart[chunk][r][i] = sum over the chunk's 256 columns of C[r][c] Vt[i][c]      (64-row x 256-column tiles)
+//   ypass    Ypart[chunk][r][i] = sum over the chunk's 128 columns of C[r][c] Vt[i][c]      (Y_ROWS-row x 128-column tiles)
 //   yreduce  Z[r][:] = T^T (sum over chunks of Ypart[chunk][r][:])                            (Z = Y T)
 //   update_kernel(C, V := Z, Wt := Vt)                                                        (C -= Z V^T)
-constexpr int Y_ROWS = 64, Y_COLS = 128;
-__global__ __launch_bounds__(256) void ypass_kernel(const float* __restrict__ C, int64_t ldc, int64_t rows, int64_t nc,
-                                                    const float* __restrict__ Vt, int64_t vt_pitch,
-                                                    float* __restrict__ Ypart) {
-  __shared__ float4 vts[Y_COLS / 64][16][16];    // [tile][i][t]
+constexpr int Y_COLS = 128;
+template <typename T>
+constexpr int y_rows() {
+  return sizeof(T) == 4 ? 64 : 32;      // accumulators: Y_ROWS / 16 x 16 per lane
+}
+template <typename T>
+__global__ __launch_bounds__(256) void ypass_kernel(const T* __restrict__ C, int64_t ldc, int64_t rows, int64_t nc,
+                                                    const T* __restrict__ Vt, int64_t vt_pitch,
+                                                    T* __restrict__ Ypart) {
+  constexpr int YR = y_rows<T>();
+  __shared__ V4<T> vts[Y_COLS / 64][16][16];    // [tile][i][t]
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, t = lane & 15;
   const int64_t cbeg = (int64_t)blockIdx.x * Y_COLS;
-  const int64_t rbeg = (int64_t)blockIdx.y * Y_ROWS;
-  // all C loads of the tile set first: 4 row steps x 4 column tiles
-  float4 cv[Y_ROWS / 16][Y_COLS / 64];
+  const int64_t rbeg = (int64_t)blockIdx.y * YR;
+  // all C loads of the tile set first: YR / 16 row steps x 2 column tiles
+  V4<T> cv[YR / 16][Y_COLS / 64];
 #pragma unroll
-  for (int it = 0; it < Y_ROWS / 16; ++it) {
+  for (int it = 0; it < YR / 16; ++it) {
     const int64_t r = rbeg + it * 16 + w * 4 + g;
 #pragma unroll
     for (int u = 0; u < Y_COLS / 64; ++u) {
       const int64_t c = cbeg + u * 64 + 4 * t;
-      cv[it][u] = (r < rows && c < nc) ? *reinterpret_cast<const float4*>(C + r * ldc + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+      cv[it][u] = (r < rows && c < nc) ? *reinterpret_cast<const V4<T>*>(C + r * ldc + c) : vzero<T>();
     }
   }
 #pragma unroll
   for (int u = 0; u < Y_COLS / 64; ++u) {
     const int64_t c = cbeg + u * 64 + 4 * (tid & 15);
-    vts[u][tid >> 4][tid & 15] = (c < nc) ? *reinterpret_cast<const float4*>(Vt + (int64_t)(tid >> 4) * vt_pitch + c)
-                                          : make_float4(0.f, 0.f, 0.f, 0.f);
+    vts[u][tid >> 4][tid & 15] = (c < nc) ? *reinterpret_cast<const V4<T>*>(Vt + (int64_t)(tid >> 4) * vt_pitch + c)
+                                          : vzero<T>();
   }
   __syncthreads();
-  float y[Y_ROWS / 16][16];
+  T y[YR / 16][16];
 #pragma unroll
-  for (int it = 0; it < Y_ROWS / 16; ++it)
+  for (int it = 0; it < YR / 16; ++it)
 #pragma unroll
-    for (int i = 0; i < 16; ++i) y[it][i] = 0.f;
+    for (int i = 0; i < 16; ++i) y[it][i] = T(0);
 #pragma unroll
   for (int u = 0; u < Y_COLS / 64; ++u)
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-      const float4 v = vts[u][i][t];
+      const V4<T> v = vts[u][i][t];
 #pragma unroll
-      for (int it = 0; it < Y_ROWS / 16; ++it) {
-        y[it][i] = fmaf(cv[it][u].x, v.x, y[it][i]);
-        y[it][i] = fmaf(cv[it][u].y, v.y, y[it][i]);
-        y[it][i] = fmaf(cv[it][u].z, v.z, y[it][i]);
-        y[it][i] = fmaf(cv[it][u].w, v.w, y[it][i]);
+      for (int it = 0; it < YR / 16; ++it) {
+        y[it][i] = fmaT(cv[it][u].x, v.x, y[it][i]);
+        y[it][i] = fmaT(cv[it][u].y, v.y, y[it][i]);
+        y[it][i] = fmaT(cv[it][u].z, v.z, y[it][i]);
+        y[it][i] = fmaT(cv[it][u].w, v.w, y[it][i]);
       }
     }
   // combine the 16 column-chunk lanes of each row; lane t keeps entry i == t
 #pragma unroll
-  for (int it = 0; it < Y_ROWS / 16; ++it) {
-    float mine = 0.f;
+  for (int it = 0; it < YR / 16; ++it) {
+    T mine = T(0);
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-      const float v = rowsum16(y[it][i]);
+      const T v = rowsum16(y[it][i]);
       if (t == i) mine = v;
     }
     const int64_t r = rbeg + it * 16 + w * 4 + g;
@@ -737,22 +894,23 @@ __global__ __launch_bounds__(256) void ypass_kernel(const float* __restrict__ C,
   }
 }
 
-__global__ __launch_bounds__(256) void yreduce_kernel(const float* __restrict__ Ypart, int nchunks, int64_t rows,
-                                                      const double* __restrict__ Tinv, float* __restrict__ Z) {
-  __shared__ float Ts[16][17];
-  __shared__ float part[4][64][17];
+template <typename T>
+__global__ __launch_bounds__(256) void yreduce_kernel(const T* __restrict__ Ypart, int nchunks, int64_t rows,
+                                                      const double* __restrict__ Tinv, T* __restrict__ Z) {
+  __shared__ T Ts[16][17];
+  __shared__ T part[4][64][17];
   const int tid = threadIdx.x, cg = tid >> 6, rl = tid & 63;
-  Ts[tid >> 4][tid & 15] = (float)Tinv[tid];
+  Ts[tid >> 4][tid & 15] = (T)Tinv[tid];
   const int64_t r = (int64_t)blockIdx.x * 64 + rl;
-  float s[16];
+  T s[16];
 #pragma unroll
-  for (int i = 0; i < 16; ++i) s[i] = 0.f;
+  for (int i = 0; i < 16; ++i) s[i] = T(0);
   if (r < rows) {
     for (int ch = cg; ch < nchunks; ch += 4) {
-      const float4* yp = reinterpret_cast<const float4*>(Ypart + ((int64_t)ch * rows + r) * 16);
+      const V4<T>* yp = reinterpret_cast<const V4<T>*>(Ypart + ((int64_t)ch * rows + r) * 16);
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const float4 v = yp[q];
+        const V4<T> v = yp[q];
         s[4 * q] += v.x; s[4 * q + 1] += v.y; s[4 * q + 2] += v.z; s[4 * q + 3] += v.w;
       }
     }
@@ -763,11 +921,11 @@ __global__ __launch_bounds__(256) void yreduce_kernel(const float* __restrict__ 
   if (cg == 0 && r < rows) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) s[i] = (part[0][rl][i] + part[1][rl][i]) + (part[2][rl][i] + part[3][rl][i]);
-    float z[16];
+    T z[16];
     tsolve(Ts, 1, s, z);
-    float4* zp = reinterpret_cast<float4*>(Z + r * 16);
+    V4<T>* zp = reinterpret_cast<V4<T>*>(Z + r * 16);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) zp[q] = make_float4(z[4 * q], z[4 * q + 1], z[4 * q + 2], z[4 * q + 3]);
+    for (int q = 0; q < 4; ++q) zp[q] = V4<T>{z[4 * q], z[4 * q + 1], z[4 * q + 2], z[4 * q + 3]};
   }
 }
 
@@ -857,9 +1015,9 @@ __global__ __launch_bounds__(1024) void smax_kernel(const double* __restrict__ T
 template <bool STORE, bool DPP>
 __global__ __launch_bounds__(64) void ldl_kernel(const double* __restrict__ Trot, int64_t n,
                                                  const double* __restrict__ shifts, int64_t ns,
-                                                 const double* __restrict__ scal, int* __restrict__ counts,
-                                                 int* __restrict__ flags, double* __restrict__ Lc,
-                                                 double* __restrict__ Dd) {
+                                                 const double* __restrict__ scal, double tau_rel,
+                                                 int* __restrict__ counts, int* __restrict__ flags,
+                                                 double* __restrict__ Lc, double* __restrict__ Dd) {
   const int lane = threadIdx.x, grp = lane >> 4, l16 = lane & 15;
   int64_t sidx = (int64_t)blockIdx.x * 4 + grp;
   const bool valid = sidx < ns;
@@ -869,8 +1027,9 @@ __global__ __launch_bounds__(64) void ldl_kernel(const double* __restrict__ Trot
   const double pivmin = scal[1];
   // A small pivot d injects an error of about eps |l_i colv_c| = eps colv^2 / |d| into the window; the count at sigma
   // then belongs to a matrix that is off by that much, i.e. to sigma off by error / (2 sigma).  Flag the count (the
-  // bracket update skips flagged points) when that exceeds a fifth of the target resolution tau = 2^-23 sigma_max.
-  const double tau = scal[0] * 1.2e-7;
+  // bracket update skips flagged points) when that exceeds a fifth of the target resolution tau = tau_rel sigma_max
+  // (2^-23 in the f32 path's rounds).
+  const double tau = scal[0] * tau_rel;
   const double flagbound = fmax(sg, tau) * tau * (0.4 / 2.3e-16);
   double S[16];
   {
@@ -933,15 +1092,15 @@ __global__ __launch_bounds__(64) void ldl_kernel(const double* __restrict__ Trot
 template <bool FLAGS>      // FLAGS = false: the uniform grid round (bracket_init only reads the counts)
 __global__ __launch_bounds__(64) void sturm_lane_kernel(const double* __restrict__ Trot, int64_t n,
                                                         const double* __restrict__ shifts, int64_t ns,
-                                                        const double* __restrict__ scal, int* __restrict__ counts,
-                                                        int* __restrict__ flags) {
+                                                        const double* __restrict__ scal, double tau_rel,
+                                                        int* __restrict__ counts, int* __restrict__ flags) {
   int64_t sidx = (int64_t)blockIdx.x * 64 + threadIdx.x;
   const bool valid = sidx < ns;
   if (!valid) sidx = ns - 1;
   const double sg = shifts[sidx];
   const double s2 = sg * sg;
   const double pivmin = scal[1];
-  const double tau = scal[0] * 1.2e-7;
+  const double tau = scal[0] * tau_rel;
   const double flagbound = fmax(sg, tau) * tau * (0.4 / 2.3e-16);     // see ldl_kernel
   double W[16][16];
   static_for<16>([&](auto ac) {
@@ -1069,30 +1228,38 @@ __global__ __launch_bounds__(256) void bracket_update_kernel(double* __restrict_
 }
 
 // S_out[i] (descending, f32) = midpoint of the bracket of q = n - 1 - i
+template <typename T>
 __global__ __launch_bounds__(256) void values_out_kernel(const double* __restrict__ lo, const double* __restrict__ hi,
-                                                         int64_t n, float* __restrict__ S) {
+                                                         int64_t n, T* __restrict__ S) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   const int64_t q = n - 1 - i;
-  S[i] = (float)(0.5 * (lo[q] + hi[q]));
+  S[i] = (T)(0.5 * (lo[q] + hi[q]));
 }
 
 // the k kept values again, from their REFINED brackets (2^-32 sigma_max instead of the 20 bits every value gets)
+// (f64 path: `rayleigh` != NULL holds |B x_v| of the kept vectors -- the Rayleigh quotient of the band, accurate to
+// the SQUARE of the vector's error, i.e. to eps64 where the bracket is good to 2^-44 sigma_max at best.)
+template <typename T>
 __global__ __launch_bounds__(256) void values_kept_kernel(const double* __restrict__ lo, const double* __restrict__ hi,
-                                                          int64_t n, int64_t k, float* __restrict__ S) {
+                                                          const double* __restrict__ rayleigh, int64_t n, int64_t k,
+                                                          T* __restrict__ S) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= k) return;
   const int64_t q = n - 1 - i;
-  S[i] = (float)(0.5 * (lo[q] + hi[q]));
+  S[i] = (T)(rayleigh ? rayleigh[i] : 0.5 * (lo[q] + hi[q]));
 }
 
 // shifts of the inverse iteration: vector v (0 = largest) uses the midpoint of its refined bracket
+// (shifts[k + v] = half the bracket's width: two values whose brackets overlap cannot be told apart -- see
+// cluster_mgs_kernel)
 __global__ __launch_bounds__(256) void vshift_kernel(const double* __restrict__ lo, const double* __restrict__ hi,
                                                      int64_t n, int64_t k, double* __restrict__ shifts) {
   const int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (v >= k) return;
   const int64_t q = n - 1 - v;
   shifts[v] = 0.5 * (lo[q] + hi[q]);
+  shifts[k + v] = 0.5 * (hi[q] - lo[q]);
 }
 
 // ------------------------------------------------------------------------------------------------ stage 3: solves
@@ -1195,8 +1362,10 @@ __global__ __launch_bounds__(1024) void cluster_mgs_kernel(double* __restrict__ 
     return bc;
   };
   for (int64_t v = 1; v < k; ++v) {
+    // close = closer than tol OR brackets that overlap (round 4: a bracket whose section points were all flagged stays
+    // wider than tol; two members of an exact multiplet then sit at different midpoints of overlapping brackets)
     int64_t first = v;
-    while (first > 0 && shifts[first - 1] - shifts[v] <= tol) --first;       // uniform: every thread agrees
+    while (first > 0 && shifts[first - 1] - shifts[v] <= tol + shifts[k + first - 1] + shifts[k + v]) --first;   // uniform
     if (first == v) continue;
     double* xv = X + v * n;
     for (int pass = 0; pass < 2; ++pass)            // "twice is enough"
@@ -1222,33 +1391,33 @@ __global__ __launch_bounds__(1024) void cluster_mgs_kernel(double* __restrict__ 
 }
 
 // Checks on the band (status bits) and the start of the back-transformation:
-//   Vv[i][v] = x_v[i]  (n x k, f32),   Uu[i][v] = (B x_v)[i] / s_v  (rows < n; rows n .. m-1 zero)
-// One workgroup per vector.
+//   Vv[i][v] = x_v[i]  (n x k),   Uu[i][v] = (B x_v)[i] / s_v  (rows < n; rows n .. m-1 zero)
+// One workgroup per vector.  f64 path (rayleigh != NULL): s_v is replaced by |B x_v| -- the Rayleigh quotient of the
+// pair on the band (u is then a unit vector by construction); the |u| = 1 check becomes a check of that value against
+// the bracket it came from, at the bracket's accuracy (resid_tol).
+template <typename T>
 __global__ __launch_bounds__(256) void uv_init_kernel(const double* __restrict__ Bd, const double* __restrict__ X,
                                                       const double* __restrict__ shifts, const double* __restrict__ scal,
-                                                      int64_t m, int64_t n, int64_t k, float* __restrict__ Uu,
-                                                      float* __restrict__ Vv, int* __restrict__ status) {
+                                                      int64_t m, int64_t n, int64_t k, T* __restrict__ Uu,
+                                                      T* __restrict__ Vv, double* __restrict__ rayleigh,
+                                                      double* __restrict__ Ub, double resid_tol, double orth_tol,
+                                                      double range_tol, int* __restrict__ status) {
   __shared__ double red[256];
+  __shared__ double sc_inv;
   const int64_t v = blockIdx.x;
   const double* x = X + v * n;
   const double sv = shifts[v];
-  const double inv = (sv > 0.0) ? 1.0 / sv : 0.0;
   double un = 0.0, dot1 = 0.0, dot2 = 0.0;
-  for (int64_t i = threadIdx.x; i < m; i += 256) {
+  // pass 1: |B x|^2 and the neighbour dot products
+  for (int64_t i = threadIdx.x; i < n; i += 256) {
     double u = 0.0;
-    if (i < n) {
 #pragma unroll
-      for (int d = 0; d <= 16; ++d)
-        if (i + d < n) u += Bd[i * 17 + d] * x[i + d];
-      u *= inv;
-      Vv[i * k + v] = (float)x[i];
-      un = fma(u, u, un);
-      if (v + 1 < k) dot1 = fma(x[i], X[(v + 1) * n + i], dot1);
-      if (v + 2 < k) dot2 = fma(x[i], X[(v + 2) * n + i], dot2);
-    }
-    Uu[i * k + v] = (float)u;
+    for (int d = 0; d <= 16; ++d)
+      if (i + d < n) u += Bd[i * 17 + d] * x[i + d];
+    un = fma(u, u, un);
+    if (v + 1 < k) dot1 = fma(x[i], X[(v + 1) * n + i], dot1);
+    if (v + 2 < k) dot2 = fma(x[i], X[(v + 2) * n + i], dot2);
   }
-  // |u| = 1 iff (s_v, x_v) is a singular pair of the band; neighbours must be orthogonal
   double vals[3] = {un, dot1, dot2};
   double out[3];
   for (int w = 0; w < 3; ++w) {
@@ -1262,97 +1431,132 @@ __global__ __launch_bounds__(256) void uv_init_kernel(const double* __restrict__
     out[w] = red[0];
   }
   if (threadIdx.x == 0) {
+    const double bx = sqrt(out[0]);                 // |B x_v|
+    const double s_used = rayleigh ? bx : sv;
+    if (rayleigh) rayleigh[v] = bx;
+    sc_inv = (s_used > 0.0) ? 1.0 / s_used : 0.0;
     int st = 0;
-    if (!(fabs(out[0] - 1.0) < 1e-5)) st |= ST_RESID;
-    if (!(fabs(out[1]) < 1e-6) || !(fabs(out[2]) < 1e-6)) st |= ST_CLUSTER;
-    if (!(sv > 1e-6 * scal[0])) st |= ST_RANGE;
+    // (s_v, x_v) is a singular pair of the band iff |B x_v| = s_v
+    if (!(fabs(bx - sv) <= resid_tol * fmax(sv, 1e-300))) st |= ST_RESID;
+    if (!(fabs(out[1]) < orth_tol) || !(fabs(out[2]) < orth_tol)) st |= ST_CLUSTER;
+    if (!(sv > range_tol * scal[0])) st |= ST_RANGE;
     if (st) atomicOr(status, st);
   }
+  __syncthreads();
+  const double inv = sc_inv;
+  for (int64_t i = threadIdx.x; i < m; i += 256) {
+    double u = 0.0;
+    if (i < n) {
+#pragma unroll
+      for (int d = 0; d <= 16; ++d)
+        if (i + d < n) u += Bd[i * 17 + d] * x[i + d];
+      u *= inv;
+      Vv[i * k + v] = (T)x[i];
+      if (Ub) Ub[v * n + i] = u;        // f64 path: the left vectors on the band go through a Newton-Schulz step first
+    }
+    if (!Ub) Uu[i * k + v] = (T)u;
+  }
+}
+
+// f64 path: Uu[i][v] = Ub[v][i] (rows < n), 0 below
+template <typename T>
+__global__ __launch_bounds__(256) void ub_out_kernel(const double* __restrict__ Ub, int64_t m, int64_t n, int64_t k,
+                                                     T* __restrict__ Uu) {
+  const int64_t v = blockIdx.x;
+  for (int64_t i = threadIdx.x; i < m; i += 256) Uu[i * k + v] = (i < n) ? (T)Ub[v * n + i] : T(0);
 }
 
 // Back-transformation X <- H_0 H_1 ... H_(np-1) X with H_p = I - V_p T_p V_p^T (reflectors of ONE side, applied last
 // to first).  The columns of X transform independently, so a workgroup OWNS BT_COLS columns, keeps them in LDS
-// (rows x BT_COLS floats) and walks through all panels without any inter-workgroup step; the panels' V (rows_p x 16,
-// row-major) stream from L2 / Infinity Cache ONCE per panel: a thread keeps its (up to BT_KEEP) V rows in registers
+// (rows x BT_COLS elements) and walks through all panels without any inter-workgroup step; the panels' V (rows_p x 16,
+// row-major) stream from L2 / Infinity Cache ONCE per panel: a thread keeps its (up to KEEP) V rows in registers
 // between w = V^T x and x -= V (T w).
-//   X: ldx-pitched, rows x ncols (f32), updated in place.  Panel p covers rows row0 + 16 p ... rows - 1.
+//   X: ldx-pitched, rows x ncols, updated in place.  Panel p covers rows row0 + 16 p ... rows - 1.
 constexpr int BT_COLS = 2;
 constexpr int BT_THREADS = 512;
-constexpr int BT_KEEP = 8;        // rows per thread held in registers: BT_THREADS * BT_KEEP = 4096 rows
+template <typename T>
+constexpr int bt_keep() {
+  return sizeof(T) == 4 ? 8 : 4;     // rows per thread held in registers (16 values each): 4096 rows (f32) / 2048 (f64)
+}
+template <typename T>
 struct BtSide {
-  float* X;
+  T* X;
   int64_t ldx, rows;
-  const float* Vall;
+  const T* Vall;
   const double* Tall;
   int64_t npanels, row0, vrows0;
   int identity;            // X is [I; 0] on entry (forming Q): column c is untouched by the panels beyond c / 16
 };
+template <typename T>
 struct BtArgs {
-  BtSide side[2];          // blockIdx.y: 0 = U (column-panel reflectors), 1 = V (row-panel reflectors)
+  BtSide<T> side[2];       // blockIdx.y: 0 = U (column-panel reflectors), 1 = V (row-panel reflectors)
 };
-__global__ __launch_bounds__(BT_THREADS) void backtransform_kernel(BtArgs args) {
-  const BtSide sd = args.side[blockIdx.y];
-  float* __restrict__ X = sd.X;
+template <typename T>
+__global__ __launch_bounds__(BT_THREADS) void backtransform_kernel(BtArgs<T> args) {
+  constexpr int KEEP = bt_keep<T>();
+  const BtSide<T> sd = args.side[blockIdx.y];
+  T* __restrict__ X = sd.X;
   const int64_t ldx = sd.ldx, rows = sd.rows, npanels = sd.npanels, row0 = sd.row0, vrows0 = sd.vrows0;
-  const float* __restrict__ Vall = sd.Vall;
+  const T* __restrict__ Vall = sd.Vall;
   const double* __restrict__ Tall = sd.Tall;
-  extern __shared__ float xs[];                  // [rows][BT_COLS]
-  __shared__ float red[BT_THREADS / 64][16][BT_COLS];
-  __shared__ float wv[16][BT_COLS];
-  __shared__ float Ts[16][17];
+  extern __shared__ __align__(16) unsigned char bt_smem[];
+  T* xs = reinterpret_cast<T*>(bt_smem);         // [rows][BT_COLS]
+  __shared__ T red[BT_THREADS / 64][16][BT_COLS];
+  __shared__ T wv[16][BT_COLS];
+  __shared__ T Ts[16][17];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int64_t c0 = (int64_t)blockIdx.x * BT_COLS;
   for (int64_t r = tid; r < rows; r += BT_THREADS)
-    *reinterpret_cast<float2*>(xs + r * BT_COLS) = *reinterpret_cast<const float2*>(X + r * ldx + c0);
+    *reinterpret_cast<V2<T>*>(xs + r * BT_COLS) = *reinterpret_cast<const V2<T>*>(X + r * ldx + c0);
   __syncthreads();
   int64_t pfirst = npanels - 1;
   if (sd.identity && (c0 + BT_COLS - 1) / 16 < pfirst) pfirst = (c0 + BT_COLS - 1) / 16;
   for (int64_t p = pfirst; p >= 0; --p) {        // npanels = 0 (n = 16 on the V side): nothing to do
     const int64_t rbeg = row0 + 16 * p;          // first row of X the panel touches
     const int64_t vrows = vrows0 - 16 * p;       // rows of V_p  (= rows - rbeg)
-    // V_p starts at 16 * (p * vrows0 - 8 p (p - 1)) floats (see vl_offset / vr_offset)
-    const float* V = Vall + 16 * (p * vrows0 - 8 * p * (p - 1));
-    if (tid < 256) Ts[tid >> 4][tid & 15] = (float)Tall[p * 256 + tid];
-    float4 vreg[BT_KEEP][4];
+    // V_p starts at 16 * (p * vrows0 - 8 p (p - 1)) elements (see vl_offset / vr_offset)
+    const T* V = Vall + 16 * (p * vrows0 - 8 * p * (p - 1));
+    if (tid < 256) Ts[tid >> 4][tid & 15] = (T)Tall[p * 256 + tid];
+    V4<T> vreg[KEEP][4];
 #pragma unroll
-    for (int it = 0; it < BT_KEEP; ++it) {
+    for (int it = 0; it < KEEP; ++it) {
       const int64_t r = tid + (int64_t)BT_THREADS * it;
-      const float4* vp = reinterpret_cast<const float4*>(V + r * 16);
+      const V4<T>* vp = reinterpret_cast<const V4<T>*>(V + r * 16);
 #pragma unroll
-      for (int q = 0; q < 4; ++q) vreg[it][q] = (r < vrows) ? vp[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int q = 0; q < 4; ++q) vreg[it][q] = (r < vrows) ? vp[q] : vzero<T>();
     }
-    float acc[16][BT_COLS];
+    T acc[16][BT_COLS];
 #pragma unroll
     for (int i = 0; i < 16; ++i)
 #pragma unroll
-      for (int q = 0; q < BT_COLS; ++q) acc[i][q] = 0.f;
+      for (int q = 0; q < BT_COLS; ++q) acc[i][q] = T(0);
 #pragma unroll
-    for (int it = 0; it < BT_KEEP; ++it) {
+    for (int it = 0; it < KEEP; ++it) {
       const int64_t r = tid + (int64_t)BT_THREADS * it;
       if (r < vrows) {
-        const float2 x = *reinterpret_cast<const float2*>(xs + (rbeg + r) * BT_COLS);
+        const V2<T> x = *reinterpret_cast<const V2<T>*>(xs + (rbeg + r) * BT_COLS);
 #pragma unroll
         for (int q4 = 0; q4 < 4; ++q4) {
-          const float ve[4] = {vreg[it][q4].x, vreg[it][q4].y, vreg[it][q4].z, vreg[it][q4].w};
+          const T ve[4] = {vreg[it][q4].x, vreg[it][q4].y, vreg[it][q4].z, vreg[it][q4].w};
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            acc[4 * q4 + e][0] = fmaf(ve[e], x.x, acc[4 * q4 + e][0]);
-            acc[4 * q4 + e][1] = fmaf(ve[e], x.y, acc[4 * q4 + e][1]);
+            acc[4 * q4 + e][0] = fmaT(ve[e], x.x, acc[4 * q4 + e][0]);
+            acc[4 * q4 + e][1] = fmaT(ve[e], x.y, acc[4 * q4 + e][1]);
           }
         }
       }
     }
-    for (int64_t r = tid + (int64_t)BT_THREADS * BT_KEEP; r < vrows; r += BT_THREADS) {     // very tall inputs only
-      const float4* vp = reinterpret_cast<const float4*>(V + r * 16);
-      const float2 x = *reinterpret_cast<const float2*>(xs + (rbeg + r) * BT_COLS);
+    for (int64_t r = tid + (int64_t)BT_THREADS * KEEP; r < vrows; r += BT_THREADS) {     // taller inputs only
+      const V4<T>* vp = reinterpret_cast<const V4<T>*>(V + r * 16);
+      const V2<T> x = *reinterpret_cast<const V2<T>*>(xs + (rbeg + r) * BT_COLS);
 #pragma unroll
       for (int q4 = 0; q4 < 4; ++q4) {
-        const float4 vv = vp[q4];
-        const float ve[4] = {vv.x, vv.y, vv.z, vv.w};
+        const V4<T> vv = vp[q4];
+        const T ve[4] = {vv.x, vv.y, vv.z, vv.w};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          acc[4 * q4 + e][0] = fmaf(ve[e], x.x, acc[4 * q4 + e][0]);
-          acc[4 * q4 + e][1] = fmaf(ve[e], x.y, acc[4 * q4 + e][1]);
+          acc[4 * q4 + e][0] = fmaT(ve[e], x.x, acc[4 * q4 + e][0]);
+          acc[4 * q4 + e][1] = fmaT(ve[e], x.y, acc[4 * q4 + e][1]);
         }
       }
     }
@@ -1360,15 +1564,15 @@ __global__ __launch_bounds__(BT_THREADS) void backtransform_kernel(BtArgs args) 
     for (int i = 0; i < 16; ++i)
 #pragma unroll
       for (int q = 0; q < BT_COLS; ++q) {
-        const float v = rowsx4(rowsum16(acc[i][q]));
+        const T v = rowsx4(rowsum16(acc[i][q]));
         if (lane == 0) red[w][i][q] = v;
       }
     __syncthreads();
     if (tid < BT_COLS) {
-      float sv[16], wo[16];
+      T sv[16], wo[16];
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        float a = 0.f;
+        T a = T(0);
 #pragma unroll
         for (int k = 0; k < BT_THREADS / 64; ++k) a += red[k][i][tid];
         sv[i] = a;
@@ -1378,86 +1582,100 @@ __global__ __launch_bounds__(BT_THREADS) void backtransform_kernel(BtArgs args) 
       for (int i = 0; i < 16; ++i) wv[i][tid] = wo[i];
     }
     __syncthreads();
-    float wr[16][BT_COLS];
+    T wr[16][BT_COLS];
 #pragma unroll
     for (int i = 0; i < 16; ++i)
 #pragma unroll
       for (int q = 0; q < BT_COLS; ++q) wr[i][q] = wv[i][q];
 #pragma unroll
-    for (int it = 0; it < BT_KEEP; ++it) {
+    for (int it = 0; it < KEEP; ++it) {
       const int64_t r = tid + (int64_t)BT_THREADS * it;
       if (r < vrows) {
-        float2 x = *reinterpret_cast<const float2*>(xs + (rbeg + r) * BT_COLS);
+        V2<T> x = *reinterpret_cast<const V2<T>*>(xs + (rbeg + r) * BT_COLS);
 #pragma unroll
         for (int q4 = 0; q4 < 4; ++q4) {
-          const float ve[4] = {vreg[it][q4].x, vreg[it][q4].y, vreg[it][q4].z, vreg[it][q4].w};
+          const T ve[4] = {vreg[it][q4].x, vreg[it][q4].y, vreg[it][q4].z, vreg[it][q4].w};
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            x.x = fmaf(-ve[e], wr[4 * q4 + e][0], x.x);
-            x.y = fmaf(-ve[e], wr[4 * q4 + e][1], x.y);
+            x.x = fmaT(-ve[e], wr[4 * q4 + e][0], x.x);
+            x.y = fmaT(-ve[e], wr[4 * q4 + e][1], x.y);
           }
         }
-        *reinterpret_cast<float2*>(xs + (rbeg + r) * BT_COLS) = x;
+        *reinterpret_cast<V2<T>*>(xs + (rbeg + r) * BT_COLS) = x;
       }
     }
-    for (int64_t r = tid + (int64_t)BT_THREADS * BT_KEEP; r < vrows; r += BT_THREADS) {
-      const float4* vp = reinterpret_cast<const float4*>(V + r * 16);
-      float2 x = *reinterpret_cast<const float2*>(xs + (rbeg + r) * BT_COLS);
+    for (int64_t r = tid + (int64_t)BT_THREADS * KEEP; r < vrows; r += BT_THREADS) {
+      const V4<T>* vp = reinterpret_cast<const V4<T>*>(V + r * 16);
+      V2<T> x = *reinterpret_cast<const V2<T>*>(xs + (rbeg + r) * BT_COLS);
 #pragma unroll
       for (int q4 = 0; q4 < 4; ++q4) {
-        const float4 vv = vp[q4];
-        const float ve[4] = {vv.x, vv.y, vv.z, vv.w};
+        const V4<T> vv = vp[q4];
+        const T ve[4] = {vv.x, vv.y, vv.z, vv.w};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          x.x = fmaf(-ve[e], wr[4 * q4 + e][0], x.x);
-          x.y = fmaf(-ve[e], wr[4 * q4 + e][1], x.y);
+          x.x = fmaT(-ve[e], wr[4 * q4 + e][0], x.x);
+          x.y = fmaT(-ve[e], wr[4 * q4 + e][1], x.y);
         }
       }
-      *reinterpret_cast<float2*>(xs + (rbeg + r) * BT_COLS) = x;
+      *reinterpret_cast<V2<T>*>(xs + (rbeg + r) * BT_COLS) = x;
     }
     __syncthreads();
   }
   for (int64_t r = tid; r < rows; r += BT_THREADS)
-    *reinterpret_cast<float2*>(X + r * ldx + c0) = *reinterpret_cast<const float2*>(xs + r * BT_COLS);
+    *reinterpret_cast<V2<T>*>(X + r * ldx + c0) = *reinterpret_cast<const V2<T>*>(xs + r * BT_COLS);
 }
 
 // Vh (k x n) = Vv^T
-__global__ __launch_bounds__(256) void transpose_out_kernel(const float* __restrict__ Vv, int64_t n, int64_t k,
-                                                            float* __restrict__ Vh) {
-  __shared__ float tile[32][33];
+template <typename T>
+__global__ __launch_bounds__(256) void transpose_out_kernel(const T* __restrict__ Vv, int64_t n, int64_t k,
+                                                            T* __restrict__ Vh) {
+  __shared__ T tile[32][33];
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;     // 32 x 8
   const int64_t i0 = (int64_t)blockIdx.x * 32, v0 = (int64_t)blockIdx.y * 32;
   for (int r = ty; r < 32; r += 8)
-    tile[r][tx] = (i0 + r < n && v0 + tx < k) ? Vv[(i0 + r) * k + v0 + tx] : 0.f;
+    tile[r][tx] = (i0 + r < n && v0 + tx < k) ? Vv[(i0 + r) * k + v0 + tx] : T(0);
   __syncthreads();
   for (int r = ty; r < 32; r += 8)
     if (v0 + r < k && i0 + tx < n) Vh[(v0 + r) * n + i0 + tx] = tile[tx][r];
+}
+
+// Newton-Schulz coefficient matrix of the f64 path: G <- 1.5 I - 0.5 G  (k x k)
+__global__ __launch_bounds__(256) void ns_coeff_kernel(double* __restrict__ G, int64_t k) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= k * k) return;
+  G[e] = ((e / k == e % k) ? 1.5 : 0.0) - 0.5 * G[e];
 }
 
 // ------------------------------------------------------------------------------------------------ host side
 static inline size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct Layout {
-  size_t Af, Vl, Vr, Vt, Zr, Tl, Tr, Dblk, Eblk, Gpart, Gpart2, Xbuf, Wpart, Wt, Bd, Tb, Trot, scal, shifts, counts, flags, lo, hi,
-      status, Lc, Dd, X, Uu, Vv, total;
+  size_t Af, Vl, Vr, Vt, Zr, Tl, Tr, Dblk, Eblk, Gpart, Gpart2, Gq, R1, R1inv, Xbuf, Wpart, Wt, Bd, Tb, Trot, scal, shifts,
+      counts, flags, lo, hi, status, ray, Lc, Dd, X, X2, X3, Gns, Uu, Vv, total;
   int64_t np, kcap, nshift;
+  int esz;
 };
 
-static int64_t vl_offset(int64_t m, int64_t p) { return 16 * (p * m - 8 * p * (p - 1)); }        // floats
-static int64_t vr_offset(int64_t n, int64_t p) { return 16 * (p * n - 8 * p * (p + 1)); }        // floats
+static int64_t vl_offset(int64_t m, int64_t p) { return 16 * (p * m - 8 * p * (p - 1)); }        // elements
+static int64_t vr_offset(int64_t n, int64_t p) { return 16 * (p * n - 8 * p * (p + 1)); }        // elements
 
-static Layout make_layout(int64_t m, int64_t n, int64_t kcap) {
+// esz: 4 (f32 input) or 8 (f64 input).  Everything up to `status` does not depend on kcap except through the shift
+// buffers' size; the f64-only blocks (Gq .. R1inv, ray, X2, X3, Gns) are empty for f32.
+static Layout make_layout(int64_t m, int64_t n, int64_t kcap, int esz) {
   Layout L;
   const int64_t np = n / 16;
+  const bool f64 = esz == 8;
+  const size_t e = (size_t)esz;
   L.np = np;
   L.kcap = kcap;
+  L.esz = esz;
   size_t off = 0;
   auto take = [&](size_t bytes) { size_t o = off; off += al(bytes); return o; };
-  L.Af = take((size_t)m * n * 4);
-  L.Vl = take((size_t)vl_offset(m, np) * 4);
-  L.Vr = take((size_t)(vr_offset(n, np - 1) + 16) * 4);
-  L.Vt = take((size_t)16 * n * 4);
-  L.Zr = take((size_t)16 * m * 4);
+  L.Af = take((size_t)m * n * e);
+  L.Vl = take((size_t)vl_offset(m, np) * e);
+  L.Vr = take((size_t)(vr_offset(n, np - 1) + 16) * e);
+  L.Vt = take((size_t)16 * n * e);
+  L.Zr = take((size_t)16 * m * e);
   L.Tl = take((size_t)np * 256 * 8);
   L.Tr = take((size_t)np * 256 * 8);
   L.Dblk = take((size_t)np * 256 * 8);
@@ -1465,14 +1683,18 @@ static Layout make_layout(int64_t m, int64_t n, int64_t kcap) {
   const int64_t maxparts = (m + 127) / 128 + 1;      // gram_kernel: 256 rows per part; update_kernel<1>: 128
   L.Gpart = take((size_t)maxparts * 256 * 8);
   L.Gpart2 = take((size_t)((n + 63) / 64 + 1) * 256 * 8);      // update_kernel<2>: one part per 64 columns
+  L.Gq = take(f64 ? (size_t)((m + 255) / 256 + 1) * 256 * 8 : 0);   // Cholesky-QR2: Gram partials of Q1 (256 rows per part)
+  L.R1 = take(f64 ? 256 * 8 : 0);
+  L.R1inv = take(f64 ? 256 * 8 : 0);
   L.Xbuf = take(256 * 8);
   const int64_t wide = n > kcap ? n : kcap;
-  const int64_t chunks = (m + W_RC - 1) / W_RC;
-  size_t wpart = (size_t)chunks * 16 * wide * 4;
-  const size_t ypart = (size_t)((n + Y_COLS - 1) / Y_COLS) * m * 16 * 4;     // the row panels' Y partials share the buffer
+  const int64_t wrc = f64 ? w_rc<double>() : w_rc<float>();
+  const int64_t chunks = (m + wrc - 1) / wrc;
+  size_t wpart = (size_t)chunks * 16 * wide * e;
+  const size_t ypart = (size_t)((n + Y_COLS - 1) / Y_COLS) * m * 16 * e;     // the row panels' Y partials share the buffer
   if (ypart > wpart) wpart = ypart;
   L.Wpart = take(wpart);
-  L.Wt = take((size_t)16 * wide * 4);
+  L.Wt = take((size_t)16 * wide * e);
   L.Bd = take((size_t)n * 17 * 8);
   L.Tb = take((size_t)n * 17 * 8);
   L.Trot = take((size_t)(n + 32) * TP * 8);
@@ -1487,18 +1709,24 @@ static Layout make_layout(int64_t m, int64_t n, int64_t kcap) {
   L.lo = take((size_t)n * 8);
   L.hi = take((size_t)n * 8);
   L.status = take(64);
+  L.ray = take(f64 ? (size_t)kcap * 8 : 0);
   L.Lc = take((size_t)kcap * n * 16 * 8);
   L.Dd = take((size_t)kcap * n * 8);
   L.X = take((size_t)kcap * n * 8);
-  L.Uu = take((size_t)m * kcap * 4);
-  L.Vv = take((size_t)n * kcap * 4);
+  L.X2 = take(f64 ? (size_t)kcap * n * 8 : 0);
+  L.X3 = take(f64 ? (size_t)kcap * n * 8 : 0);
+  L.Gns = take(f64 ? (size_t)kcap * kcap * 8 : 0);
+  L.Uu = take((size_t)m * kcap * e);
+  L.Vv = take((size_t)n * kcap * e);
   L.total = off;
   return L;
 }
 
 static bool g_dpp = true;
 static double g_cluster_tol = 4e-7;  // kept values closer than this (relative to sigma_max: a few eps_f32) are one cluster (TNH_SVDB_CTOL)
-static bool g_row_fused = false;  // row panels by the row-owning fused kernel (TNH_SVDB_ROWFUSED=1) or ypass / yreduce / update
+static double g_cluster_tol64 = 1e-10;  // f64 input: closer than this is a cluster; wider neighbours are separated by the
+                                     // inverse iteration to eps64 / gap <= 1e-6 and made orthonormal by ONE Newton-Schulz step
+static bool g_row_fused = false;  // row panels by the row-owning fused kernel (TNH_SVDB_ROWFUSED=1; f32 only) or ypass / yreduce / update
 static bool g_bt_fused = true;   // back-transformation by column-owning workgroups (TNH_SVDB_BT=0: per-panel launches)
 static bool g_lane = true;       // counts through sturm_lane_kernel (TNH_SVDB_LANE=0: the 16-lane ldl_kernel)
 // Schedule of the spectrum slicing.  A count costs 139 f64 FMAs per pivot (8 cycles each on this chip's vector pipe),
@@ -1507,17 +1735,23 @@ static bool g_lane = true;       // counts through sturm_lane_kernel (TNH_SVDB_L
 //   bits at once, one 16-way section round per value adds 4 (bracket 1e-6 sigma_max: s_rest is good to 5e-7);
 //   kept values: g_refine_rounds 16-way rounds on the 16-lane kernel (a few thousand shifts: latency 0.8 ms instead
 //   of the lane kernel's 3 ms) take their brackets to 2^-32 sigma_max so that inverse iteration separates neighbours.
+//   f64 input: every value to g_bits64 bits (default 32: s_rest good to 1.2e-10 sigma_max; three more lane rounds),
+//   kept values to 2^-44 sigma_max (three more 16-lane rounds) -- beyond that the un-pivoted LDL^T of the band does not
+//   resolve (eps64 n |T| / 2 sigma); the kept VALUES then come from the Rayleigh quotient |B x| of their vectors.
 static int g_grid_mult = 16;
 static int g_sect_p = 15;
 static int g_sect_rounds = 1;
 static int g_refine_p = 15;
 static int g_refine_rounds = 3;
+static int g_bits64 = 32;
 
 static void read_env() {
   const char* e = getenv("TNH_SVDB_DPP");
   g_dpp = !(e && e[0] == '0');
   e = getenv("TNH_SVDB_CTOL");
   if (e && atof(e) >= 0.0) g_cluster_tol = atof(e);
+  e = getenv("TNH_SVDB_CTOL64");
+  if (e && atof(e) >= 0.0) g_cluster_tol64 = atof(e);
   e = getenv("TNH_SVDB_ROWFUSED");
   g_row_fused = (e && e[0] == '1');
   e = getenv("TNH_SVDB_BT");
@@ -1529,6 +1763,7 @@ static void read_env() {
   g_sect_rounds = g_lane ? 1 : 5;
   g_refine_p = 15;
   g_refine_rounds = 3;
+  g_bits64 = 32;
   e = getenv("TNH_SVDB_GRID");
   if (e && atoi(e) > 0) g_grid_mult = atoi(e);
   e = getenv("TNH_SVDB_SECT");
@@ -1539,43 +1774,48 @@ static void read_env() {
   if (e && atoi(e) > 0) g_refine_p = atoi(e);
   e = getenv("TNH_SVDB_REFINE");
   if (e && atoi(e) >= 0) g_refine_rounds = atoi(e);
+  e = getenv("TNH_SVDB_BITS64");
+  if (e && atoi(e) >= 20 && atoi(e) <= 44) g_bits64 = atoi(e);
 }
 
-static int launch_counts(const Layout& L, char* base, int64_t n, int64_t ns, bool lane, bool need_flags = true) {
+// tau_rel: resolution (relative to sigma_max) the round is after -- a count whose small pivots injected more than a
+// fifth of it is flagged and ignored by the bracket update (1.2e-7 = 2^-23: the f32 path's rounds)
+static int launch_counts(const Layout& L, char* base, int64_t n, int64_t ns, bool lane, bool need_flags, double tau_rel) {
   if (lane) {
     if (need_flags)
       hipLaunchKernelGGL(sturm_lane_kernel<true>, dim3((unsigned)((ns + 63) / 64)), dim3(64), 0, stream(),
                          (const double*)(base + L.Trot), n, (const double*)(base + L.shifts), ns,
-                         (const double*)(base + L.scal), (int*)(base + L.counts), (int*)(base + L.flags));
+                         (const double*)(base + L.scal), tau_rel, (int*)(base + L.counts), (int*)(base + L.flags));
     else
       hipLaunchKernelGGL(sturm_lane_kernel<false>, dim3((unsigned)((ns + 63) / 64)), dim3(64), 0, stream(),
                          (const double*)(base + L.Trot), n, (const double*)(base + L.shifts), ns,
-                         (const double*)(base + L.scal), (int*)(base + L.counts), (int*)(base + L.flags));
+                         (const double*)(base + L.scal), tau_rel, (int*)(base + L.counts), (int*)(base + L.flags));
     TNH_LAUNCH_CHECK();
     return TNH_OK;
   }
   const unsigned blocks = (unsigned)((ns + 3) / 4);
   if (g_dpp)
     hipLaunchKernelGGL((ldl_kernel<false, true>), dim3(blocks), dim3(64), 0, stream(), (const double*)(base + L.Trot), n,
-                       (const double*)(base + L.shifts), ns, (const double*)(base + L.scal), (int*)(base + L.counts),
-                       (int*)(base + L.flags), (double*)nullptr, (double*)nullptr);
+                       (const double*)(base + L.shifts), ns, (const double*)(base + L.scal), tau_rel,
+                       (int*)(base + L.counts), (int*)(base + L.flags), (double*)nullptr, (double*)nullptr);
   else
     hipLaunchKernelGGL((ldl_kernel<false, false>), dim3(blocks), dim3(64), 0, stream(), (const double*)(base + L.Trot), n,
-                       (const double*)(base + L.shifts), ns, (const double*)(base + L.scal), (int*)(base + L.counts),
-                       (int*)(base + L.flags), (double*)nullptr, (double*)nullptr);
+                       (const double*)(base + L.shifts), ns, (const double*)(base + L.scal), tau_rel,
+                       (int*)(base + L.counts), (int*)(base + L.flags), (double*)nullptr, (double*)nullptr);
   TNH_LAUNCH_CHECK();
   return TNH_OK;
 }
 
 // one multi-section round over the values [q0, q0 + nq)
-static int section_round(const Layout& L, char* base, int64_t n, int64_t q0, int64_t nq, int P, int round, bool lane) {
+static int section_round(const Layout& L, char* base, int64_t n, int64_t q0, int64_t nq, int P, int round, bool lane,
+                         double tau_rel) {
   if (nq <= 0) return TNH_OK;
   const int64_t ns = nq * P;
   const double skew = 0.07 * (double)((round % 3) - 1);
   hipLaunchKernelGGL(section_kernel, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, stream(),
                      (const double*)(base + L.lo), (const double*)(base + L.hi), q0, nq, P, skew,
                      (double*)(base + L.shifts));
-  int rc = launch_counts(L, base, n, ns, lane);
+  int rc = launch_counts(L, base, n, ns, lane, true, tau_rel);
   if (rc) return rc;
   hipLaunchKernelGGL(bracket_update_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, stream(),
                      (double*)(base + L.lo), (double*)(base + L.hi), q0, nq, P, (const double*)(base + L.shifts),
@@ -1584,75 +1824,107 @@ static int section_round(const Layout& L, char* base, int64_t n, int64_t q0, int
   return TNH_OK;
 }
 
+template <typename T>
 static int stage1(const Layout& L, char* base, int64_t m, int64_t n) {
-  float* Af = (float*)(base + L.Af);
+  constexpr bool QR2 = sizeof(T) == 8;       // f64 input: two Cholesky-QR passes per panel (see chol_kernel)
+  constexpr int WRC = w_rc<T>();
+  constexpr int YR = y_rows<T>();
+  T* Af = (T*)(base + L.Af);
   double* Gc = (double*)(base + L.Gpart);                 // partial Grams of the next column panel
   double* Gr = (double*)(base + L.Gpart2);                // ... of the next row panel
+  double* Gq = (double*)(base + L.Gq);
+  double* R1 = (double*)(base + L.R1);
+  double* R1inv = (double*)(base + L.R1inv);
   double* Xb = (double*)(base + L.Xbuf);
-  float* Wpart = (float*)(base + L.Wpart);
-  float* Wt = (float*)(base + L.Wt);
-  float* Vt = (float*)(base + L.Vt);
+  T* Wpart = (T*)(base + L.Wpart);
+  T* Wt = (T*)(base + L.Wt);
+  T* Vt = (T*)(base + L.Vt);
   int* status = (int*)(base + L.status);
   const int64_t np = L.np;
   int parts_c = (int)((m + 255) / 256), parts_r = 0;
-  hipLaunchKernelGGL((gram_kernel<false>), dim3(parts_c), dim3(256), 0, stream(), (const float*)Af, n, m, Gc);
+  hipLaunchKernelGGL((gram_kernel<false, T>), dim3(parts_c), dim3(256), 0, stream(), (const T*)Af, n, m, Gc);
   for (int64_t p = 0; p < np; ++p) {
     const int64_t j = 16 * p;
     const int64_t mj = m - j, nc = n - j - 16, mr = m - j - 16;
     // ---- column panel: rows j .., columns j .. j + 15
     {
-      const float* P = Af + j * n + j;
-      float* V = (float*)(base + L.Vl) + vl_offset(m, p);
+      T* P = Af + j * n + j;
+      T* V = (T*)(base + L.Vl) + vl_offset(m, p);
       double* Tp = (double*)(base + L.Tl) + p * 256;
-      hipLaunchKernelGGL((factor_kernel<false>), dim3(1), dim3(256), 0, stream(), P, n, mj, (const double*)Gc, parts_c, Xb, V,
-                         (float*)nullptr, (int64_t)0, Tp, (double*)(base + L.Dblk) + p * 256, status);
+      if (QR2) {
+        const int qparts = (int)((mj + 255) / 256);
+        hipLaunchKernelGGL(chol_kernel, dim3(1), dim3(64), 0, stream(), (const double*)Gc, parts_c, R1, R1inv, status);
+        hipLaunchKernelGGL((scaleq_kernel<false, T>), dim3(qparts), dim3(256), 0, stream(), P, n, mj,
+                           (const double*)R1inv, Gq);
+        hipLaunchKernelGGL((factor_kernel<false, T>), dim3(1), dim3(256), 0, stream(), (const T*)P, n, mj,
+                           (const double*)Gq, qparts, Xb, V, (T*)nullptr, (int64_t)0, Tp,
+                           (double*)(base + L.Dblk) + p * 256, (const double*)R1, 1e-3, status);
+      } else {
+        hipLaunchKernelGGL((factor_kernel<false, T>), dim3(1), dim3(256), 0, stream(), (const T*)P, n, mj,
+                           (const double*)Gc, parts_c, Xb, V, (T*)nullptr, (int64_t)0, Tp,
+                           (double*)(base + L.Dblk) + p * 256, (const double*)nullptr, 1e-9, status);
+      }
       if (mj > 16)
-        hipLaunchKernelGGL((formv_kernel<false>), dim3((unsigned)((mj - 16 + 255) / 256)), dim3(256), 0, stream(), P, n, mj,
-                           (const double*)Xb, V, (float*)nullptr, (int64_t)0);
+        hipLaunchKernelGGL((formv_kernel<false, T>), dim3((unsigned)((mj - 16 + 255) / 256)), dim3(256), 0, stream(),
+                           (const T*)P, n, mj, (const double*)Xb, V, (T*)nullptr, (int64_t)0);
       if (nc > 0) {
-        float* C = Af + j * n + j + 16;
-        const int chunks = (int)((mj + W_RC - 1) / W_RC);
-        hipLaunchKernelGGL(wpass_kernel, dim3((unsigned)((nc + 63) / 64), chunks), dim3(256), 0, stream(),
-                           (const float*)C, n, mj, nc, (const float*)V, Wpart);
-        hipLaunchKernelGGL(wreduce_kernel, dim3((unsigned)((nc + 63) / 64)), dim3(256), 0, stream(), (const float*)Wpart,
-                           chunks, nc, (const double*)Tp, 1, Wt);
+        T* C = Af + j * n + j + 16;
+        const int chunks = (int)((mj + WRC - 1) / WRC);
+        hipLaunchKernelGGL((wpass_kernel<T>), dim3((unsigned)((nc + 63) / 64), chunks), dim3(256), 0, stream(),
+                           (const T*)C, n, mj, nc, (const T*)V, Wpart);
+        hipLaunchKernelGGL((wreduce_kernel<T>), dim3((unsigned)((nc + 63) / 64)), dim3(256), 0, stream(),
+                           (const T*)Wpart, chunks, nc, (const double*)Tp, 1, Wt);
         // the update also leaves the partial Grams of the row panel (first 16 rows of the updated block)
         const dim3 grid((unsigned)((nc + 63) / 64), (unsigned)((mj + U_RR - 1) / U_RR));
-        hipLaunchKernelGGL((update_kernel<2>), grid, dim3(256), 0, stream(), C, n, mj, nc, (const float*)V,
-                           (const float*)Wt, nc, Gr, (int64_t)0);
+        hipLaunchKernelGGL((update_kernel<2, T>), grid, dim3(256), 0, stream(), C, n, mj, nc, (const T*)V,
+                           (const T*)Wt, nc, Gr, (int64_t)0);
         parts_r = (int)grid.x;
       }
     }
     // ---- row panel: rows j .. j + 15, columns j + 16 ..
     if (nc > 0) {
-      const float* P = Af + j * n + j + 16;
-      float* V = (float*)(base + L.Vr) + vr_offset(n, p);
+      T* P = Af + j * n + j + 16;
+      T* V = (T*)(base + L.Vr) + vr_offset(n, p);
       double* Tp = (double*)(base + L.Tr) + p * 256;
-      hipLaunchKernelGGL((factor_kernel<true>), dim3(1), dim3(256), 0, stream(), P, n, nc, (const double*)Gr, parts_r, Xb, V, Vt,
-                         nc, Tp, (double*)(base + L.Eblk) + p * 256, status);
+      if (QR2) {
+        const int qparts = (int)((nc + 255) / 256);
+        hipLaunchKernelGGL(chol_kernel, dim3(1), dim3(64), 0, stream(), (const double*)Gr, parts_r, R1, R1inv, status);
+        hipLaunchKernelGGL((scaleq_kernel<true, T>), dim3(qparts), dim3(256), 0, stream(), P, n, nc,
+                           (const double*)R1inv, Gq);
+        hipLaunchKernelGGL((factor_kernel<true, T>), dim3(1), dim3(256), 0, stream(), (const T*)P, n, nc,
+                           (const double*)Gq, qparts, Xb, V, Vt, nc, Tp, (double*)(base + L.Eblk) + p * 256,
+                           (const double*)R1, 1e-3, status);
+      } else {
+        hipLaunchKernelGGL((factor_kernel<true, T>), dim3(1), dim3(256), 0, stream(), (const T*)P, n, nc,
+                           (const double*)Gr, parts_r, Xb, V, Vt, nc, Tp, (double*)(base + L.Eblk) + p * 256,
+                           (const double*)nullptr, 1e-9, status);
+      }
       if (nc > 16)
-        hipLaunchKernelGGL((formv_kernel<true>), dim3((unsigned)((nc - 16 + 255) / 256)), dim3(256), 0, stream(), P, n, nc,
-                           (const double*)Xb, V, Vt, nc);
+        hipLaunchKernelGGL((formv_kernel<true, T>), dim3((unsigned)((nc - 16 + 255) / 256)), dim3(256), 0, stream(),
+                           (const T*)P, n, nc, (const double*)Xb, V, Vt, nc);
       if (mr > 0) {
-        float* C = Af + (j + 16) * n + j + 16;
-        if (g_row_fused) {
-          hipLaunchKernelGGL(rowupdate_kernel, dim3((unsigned)((mr + 15) / 16)), dim3(256), 0, stream(), C, n, mr, nc,
-                             (const float*)Vt, nc, (const double*)Tp);
-          parts_c = (int)((mr + 255) / 256);
-          hipLaunchKernelGGL((gram_kernel<false>), dim3(parts_c), dim3(256), 0, stream(), (const float*)C, n, mr, Gc);
-        } else {
-          const int ych = (int)((nc + Y_COLS - 1) / Y_COLS);
-          float* Z = (float*)(base + L.Zr);
-          hipLaunchKernelGGL(ypass_kernel, dim3(ych, (unsigned)((mr + Y_ROWS - 1) / Y_ROWS)), dim3(256), 0, stream(),
-                             (const float*)C, n, mr, nc, (const float*)Vt, nc, Wpart);
-          hipLaunchKernelGGL(yreduce_kernel, dim3((unsigned)((mr + 63) / 64)), dim3(256), 0, stream(),
-                             (const float*)Wpart, ych, mr, (const double*)Tp, Z);
-          // ... and this update the partial Grams of the next column panel (first 16 columns of the updated block)
-          const dim3 grid((unsigned)((nc + 63) / 64), (unsigned)((mr + U_RR - 1) / U_RR));
-          hipLaunchKernelGGL((update_kernel<1>), grid, dim3(256), 0, stream(), C, n, mr, nc, (const float*)Z,
-                             (const float*)Vt, nc, Gc, (int64_t)0);
-          parts_c = (int)grid.y;
+        T* C = Af + (j + 16) * n + j + 16;
+        if constexpr (sizeof(T) == 4) {
+          if (g_row_fused) {
+            hipLaunchKernelGGL(rowupdate_kernel, dim3((unsigned)((mr + 15) / 16)), dim3(256), 0, stream(), C, n, mr, nc,
+                               (const float*)Vt, nc, (const double*)Tp);
+            parts_c = (int)((mr + 255) / 256);
+            hipLaunchKernelGGL((gram_kernel<false, T>), dim3(parts_c), dim3(256), 0, stream(), (const T*)C, n, mr, Gc);
+            TNH_LAUNCH_CHECK();
+            continue;
+          }
         }
+        const int ych = (int)((nc + Y_COLS - 1) / Y_COLS);
+        T* Z = (T*)(base + L.Zr);
+        hipLaunchKernelGGL((ypass_kernel<T>), dim3(ych, (unsigned)((mr + YR - 1) / YR)), dim3(256), 0, stream(),
+                           (const T*)C, n, mr, nc, (const T*)Vt, nc, Wpart);
+        hipLaunchKernelGGL((yreduce_kernel<T>), dim3((unsigned)((mr + 63) / 64)), dim3(256), 0, stream(),
+                           (const T*)Wpart, ych, mr, (const double*)Tp, Z);
+        // ... and this update the partial Grams of the next column panel (first 16 columns of the updated block)
+        const dim3 grid((unsigned)((nc + 63) / 64), (unsigned)((mr + U_RR - 1) / U_RR));
+        hipLaunchKernelGGL((update_kernel<1, T>), grid, dim3(256), 0, stream(), C, n, mr, nc, (const T*)Z,
+                           (const T*)Vt, nc, Gc, (int64_t)0);
+        parts_c = (int)grid.y;
       }
     }
     TNH_LAUNCH_CHECK();
@@ -1660,7 +1932,9 @@ static int stage1(const Layout& L, char* base, int64_t m, int64_t n) {
   return TNH_OK;
 }
 
-static int values(const Layout& L, char* base, int64_t n, int64_t khint, float* S_out) {
+template <typename T>
+static int values(const Layout& L, char* base, int64_t n, T* S_out) {
+  constexpr bool F64 = sizeof(T) == 8;
   const unsigned nb17 = (unsigned)((n * 17 + 255) / 256);
   hipLaunchKernelGGL(band_kernel, dim3(nb17), dim3(256), 0, stream(), (const double*)(base + L.Dblk),
                      (const double*)(base + L.Eblk), n, (double*)(base + L.Bd));
@@ -1676,120 +1950,163 @@ static int values(const Layout& L, char* base, int64_t n, int64_t khint, float* 
   hipLaunchKernelGGL(grid_kernel, dim3((unsigned)((ng + 255) / 256)), dim3(256), 0, stream(),
                      (const double*)(base + L.scal), ng, (double*)(base + L.shifts));
   TNH_LAUNCH_CHECK();
-  int rc = launch_counts(L, base, n, ng, g_lane, false);
+  int rc = launch_counts(L, base, n, ng, g_lane, false, 1.2e-7);
   if (rc) return rc;
   hipLaunchKernelGGL(bracket_init_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream(),
                      (const double*)(base + L.scal), (const int*)(base + L.counts), ng, n, (double*)(base + L.lo),
                      (double*)(base + L.hi));
   TNH_LAUNCH_CHECK();
-  // at least 20 bits per value in total: log2(ng) from the grid, log2(P + 1) per section round
+  // at least 20 (f64 input: g_bits64) bits per value in total: log2(ng) from the grid, log2(P + 1) per section round
+  const double want = F64 ? (double)g_bits64 : 20.0;
+  const double per_round = log2((double)g_sect_p + 1.0);
   int rounds = g_sect_rounds;
   {
-    double bits = log2((double)ng) + rounds * log2((double)g_sect_p + 1.0);
-    while (bits < 20.0 && rounds < 16) {
+    double bits = log2((double)ng) + rounds * per_round;
+    while (bits < want && rounds < 16) {
       ++rounds;
-      bits += log2((double)g_sect_p + 1.0);
+      bits += per_round;
     }
   }
+  double bits = log2((double)ng);
   for (int r = 0; r < rounds; ++r) {
-    rc = section_round(L, base, n, 0, n, g_sect_p, r, g_lane);
+    bits += per_round;
+    // f64 input: the flag threshold follows the resolution the round is after (never finer than 2^-44)
+    const double tau = F64 ? fmax(exp2(-bits), exp2(-44.0)) : 1.2e-7;
+    rc = section_round(L, base, n, 0, n, g_sect_p, r, g_lane, F64 ? fmin(tau, 1.2e-7) : tau);
     if (rc) return rc;
   }
-  (void)khint;
-  hipLaunchKernelGGL(values_out_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream(),
+  hipLaunchKernelGGL((values_out_kernel<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream(),
                      (const double*)(base + L.lo), (const double*)(base + L.hi), n, S_out);
   TNH_LAUNCH_CHECK();
   return TNH_OK;
 }
 
-static int vectors(const Layout& L, char* base, int64_t m, int64_t n, int64_t k, float* U, float* Vh, float* S_kept) {
-  // kept values: brackets down to ~1e-12 relative so that inverse iteration separates close neighbours
+// One Newton-Schulz step  Y = (1.5 I - 0.5 X X^T) X  on k row vectors of length n (f64): the polar factor's first
+// iterate -- orthonormality error e -> ~e^2, the smallest change that achieves it, two GEMMs on the f64 matrix cores.
+static int newton_schulz(double* X, double* Y, double* G, int64_t k, int64_t n) {
+  int rc = tnh_gemm(TNH_F64, TNH_F64, 0, 1, k, k, n, X, n, X, n, G, k, 1, 0, 0, 0);
+  if (rc) return rc;
+  hipLaunchKernelGGL(ns_coeff_kernel, dim3((unsigned)((k * k + 255) / 256)), dim3(256), 0, stream(), G, k);
+  TNH_LAUNCH_CHECK();
+  return tnh_gemm(TNH_F64, TNH_F64, 0, 0, k, n, k, G, k, X, n, Y, n, 1, 0, 0, 0);
+}
+
+template <typename T>
+static int vectors(const Layout& L, char* base, int64_t m, int64_t n, int64_t k, T* U, T* Vh, T* S_kept) {
+  constexpr bool F64 = sizeof(T) == 8;
+  // kept values: brackets down to 2^-32 (f64 input: 2^-44) sigma_max so that inverse iteration separates close neighbours
   int rc;
-  for (int r = 0; r < g_refine_rounds; ++r) {
-    rc = section_round(L, base, n, n - k, k, g_refine_p, r, g_lane && g_refine_p > 15);
+  const int refine_rounds = g_refine_rounds + (F64 ? 3 : 0);
+  double bits = F64 ? (double)g_bits64 : 20.0;
+  for (int r = 0; r < refine_rounds; ++r) {
+    bits += log2((double)g_refine_p + 1.0);
+    const double tau = F64 ? fmin(fmax(exp2(-bits), exp2(-44.0)), 1.2e-7) : 1.2e-7;
+    rc = section_round(L, base, n, n - k, k, g_refine_p, r, g_lane && g_refine_p > 15, tau);
     if (rc) return rc;
   }
-  if (S_kept)     // the caller's S holds the 20-bit values of every bracket; the kept ones are known better now
-    hipLaunchKernelGGL(values_kept_kernel, dim3((unsigned)((k + 255) / 256)), dim3(256), 0, stream(),
-                       (const double*)(base + L.lo), (const double*)(base + L.hi), n, k, S_kept);
   hipLaunchKernelGGL(vshift_kernel, dim3((unsigned)((k + 255) / 256)), dim3(256), 0, stream(),
                      (const double*)(base + L.lo), (const double*)(base + L.hi), n, k, (double*)(base + L.shifts));
   const unsigned blocks = (unsigned)((k + 3) / 4);
   if (g_dpp) {
     hipLaunchKernelGGL((ldl_kernel<true, true>), dim3(blocks), dim3(64), 0, stream(), (const double*)(base + L.Trot), n,
-                       (const double*)(base + L.shifts), k, (const double*)(base + L.scal), (int*)nullptr, (int*)nullptr,
-                       (double*)(base + L.Lc), (double*)(base + L.Dd));
+                       (const double*)(base + L.shifts), k, (const double*)(base + L.scal), 1.2e-7, (int*)nullptr,
+                       (int*)nullptr, (double*)(base + L.Lc), (double*)(base + L.Dd));
     hipLaunchKernelGGL((solve_kernel<true>), dim3(blocks), dim3(64), 0, stream(), (const double*)(base + L.Lc),
                        (const double*)(base + L.Dd), n, k, 3, (double*)(base + L.X));
   } else {
     hipLaunchKernelGGL((ldl_kernel<true, false>), dim3(blocks), dim3(64), 0, stream(), (const double*)(base + L.Trot), n,
-                       (const double*)(base + L.shifts), k, (const double*)(base + L.scal), (int*)nullptr, (int*)nullptr,
-                       (double*)(base + L.Lc), (double*)(base + L.Dd));
+                       (const double*)(base + L.shifts), k, (const double*)(base + L.scal), 1.2e-7, (int*)nullptr,
+                       (int*)nullptr, (double*)(base + L.Lc), (double*)(base + L.Dd));
     hipLaunchKernelGGL((solve_kernel<false>), dim3(blocks), dim3(64), 0, stream(), (const double*)(base + L.Lc),
                        (const double*)(base + L.Dd), n, k, 3, (double*)(base + L.X));
   }
   hipLaunchKernelGGL(cluster_mgs_kernel, dim3(1), dim3(1024), 0, stream(), (double*)(base + L.X),
-                     (const double*)(base + L.shifts), (const double*)(base + L.scal), n, k, g_cluster_tol,
-                     (int*)(base + L.status));
-  float* Uu = U;                           // m x k, transformed in place
-  float* Vv = (float*)(base + L.Vv);       // n x k
-  hipLaunchKernelGGL(uv_init_kernel, dim3((unsigned)k), dim3(256), 0, stream(), (const double*)(base + L.Bd),
-                     (const double*)(base + L.X), (const double*)(base + L.shifts), (const double*)(base + L.scal), m, n,
-                     k, Uu, Vv, (int*)(base + L.status));
+                     (const double*)(base + L.shifts), (const double*)(base + L.scal), n, k,
+                     F64 ? g_cluster_tol64 : g_cluster_tol, (int*)(base + L.status));
   TNH_LAUNCH_CHECK();
-  float* Wpart = (float*)(base + L.Wpart);
-  float* Wt = (float*)(base + L.Wt);
-  const size_t lds_u = (size_t)m * BT_COLS * sizeof(float), lds_v = (size_t)n * BT_COLS * sizeof(float);
+  double* Xcur = (double*)(base + L.X);
+  double* ray = nullptr;
+  double* Ub = nullptr;
+  if (F64) {
+    // neighbours closer than ~1e-6 sigma_max come out of the inverse iteration orthogonal to eps64 / gap only
+    rc = newton_schulz(Xcur, (double*)(base + L.X2), (double*)(base + L.Gns), k, n);
+    if (rc) return rc;
+    Xcur = (double*)(base + L.X2);
+    ray = (double*)(base + L.ray);
+    Ub = (double*)(base + L.X);          // free again: the left vectors on the band, k x n
+  }
+  T* Uu = U;                           // m x k, transformed in place
+  T* Vv = (T*)(base + L.Vv);           // n x k
+  hipLaunchKernelGGL((uv_init_kernel<T>), dim3((unsigned)k), dim3(256), 0, stream(), (const double*)(base + L.Bd),
+                     (const double*)Xcur, (const double*)(base + L.shifts), (const double*)(base + L.scal), m, n,
+                     k, Uu, Vv, ray, Ub, F64 ? 1e-6 : 5e-6, F64 ? 1e-10 : 1e-6, F64 ? 1e-5 : 1e-6,
+                     (int*)(base + L.status));
+  TNH_LAUNCH_CHECK();
+  if (F64) {
+    // u = B v / |B v| inherits eps64 (s_1 / s)^2 of non-orthogonality from v's error along its neighbours: same cure
+    rc = newton_schulz(Ub, (double*)(base + L.X3), (double*)(base + L.Gns), k, n);
+    if (rc) return rc;
+    hipLaunchKernelGGL((ub_out_kernel<T>), dim3((unsigned)k), dim3(256), 0, stream(), (const double*)(base + L.X3), m, n,
+                       k, Uu);
+    TNH_LAUNCH_CHECK();
+  }
+  if (S_kept)     // the caller's S holds the coarse values of every bracket; the kept ones are known better now
+    hipLaunchKernelGGL((values_kept_kernel<T>), dim3((unsigned)((k + 255) / 256)), dim3(256), 0, stream(),
+                       (const double*)(base + L.lo), (const double*)(base + L.hi), (const double*)ray, n, k, S_kept);
+  T* Wpart = (T*)(base + L.Wpart);
+  T* Wt = (T*)(base + L.Wt);
+  constexpr int WRC = w_rc<T>();
+  const size_t lds_u = (size_t)m * BT_COLS * sizeof(T), lds_v = (size_t)n * BT_COLS * sizeof(T);
   if (g_bt_fused && lds_u <= 150 * 1024) {
     // one launch per side: every workgroup carries BT_COLS columns through all the reflectors
     static bool attr_done = false;
     if (!attr_done) {
-      TNH_HIP(hipFuncSetAttribute((const void*)backtransform_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+      TNH_HIP(hipFuncSetAttribute((const void*)backtransform_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   150 * 1024));
       attr_done = true;
     }
     // the two sides are independent: ONE launch, blockIdx.y picks the side (k / 2 workgroups each: together they
     // fill the chip)
-    BtArgs a;
-    a.side[0] = BtSide{Uu, k, m, (const float*)(base + L.Vl), (const double*)(base + L.Tl), L.np, (int64_t)0, m, 0};
-    a.side[1] = BtSide{Vv, k, n, (const float*)(base + L.Vr), (const double*)(base + L.Tr), L.np - 1, (int64_t)16, n - 16, 0};
-    hipLaunchKernelGGL(backtransform_kernel, dim3((unsigned)(k / BT_COLS), 2), dim3(BT_THREADS), lds_u > lds_v ? lds_u : lds_v,
-                       stream(), a);
-    hipLaunchKernelGGL(transpose_out_kernel, dim3((unsigned)((n + 31) / 32), (unsigned)((k + 31) / 32)), dim3(256), 0,
-                       stream(), (const float*)Vv, n, k, Vh);
+    BtArgs<T> a;
+    a.side[0] = BtSide<T>{Uu, k, m, (const T*)(base + L.Vl), (const double*)(base + L.Tl), L.np, (int64_t)0, m, 0};
+    a.side[1] = BtSide<T>{Vv, k, n, (const T*)(base + L.Vr), (const double*)(base + L.Tr), L.np - 1, (int64_t)16, n - 16, 0};
+    hipLaunchKernelGGL((backtransform_kernel<T>), dim3((unsigned)(k / BT_COLS), 2), dim3(BT_THREADS),
+                       lds_u > lds_v ? lds_u : lds_v, stream(), a);
+    hipLaunchKernelGGL((transpose_out_kernel<T>), dim3((unsigned)((n + 31) / 32), (unsigned)((k + 31) / 32)), dim3(256), 0,
+                       stream(), (const T*)Vv, n, k, Vh);
     TNH_LAUNCH_CHECK();
     return TNH_OK;
   } else {
   // U = Q_L [U_b; 0]: column-panel reflectors, last to first
   for (int64_t p = L.np - 1; p >= 0; --p) {
     const int64_t j = 16 * p, mj = m - j;
-    const float* V = (const float*)(base + L.Vl) + vl_offset(m, p);
-    float* C = Uu + j * k;
-    const int chunks = (int)((mj + W_RC - 1) / W_RC);
-    hipLaunchKernelGGL(wpass_kernel, dim3((unsigned)((k + 63) / 64), chunks), dim3(256), 0, stream(), (const float*)C, k,
+    const T* V = (const T*)(base + L.Vl) + vl_offset(m, p);
+    T* C = Uu + j * k;
+    const int chunks = (int)((mj + WRC - 1) / WRC);
+    hipLaunchKernelGGL((wpass_kernel<T>), dim3((unsigned)((k + 63) / 64), chunks), dim3(256), 0, stream(), (const T*)C, k,
                        mj, k, V, Wpart);
-    hipLaunchKernelGGL(wreduce_kernel, dim3((unsigned)((k + 63) / 64)), dim3(256), 0, stream(), (const float*)Wpart,
+    hipLaunchKernelGGL((wreduce_kernel<T>), dim3((unsigned)((k + 63) / 64)), dim3(256), 0, stream(), (const T*)Wpart,
                        chunks, k, (const double*)(base + L.Tl) + p * 256, 0, Wt);
-    hipLaunchKernelGGL((update_kernel<0>), dim3((unsigned)((k + 63) / 64), (unsigned)((mj + U_RR - 1) / U_RR)), dim3(256), 0,
-                       stream(), C, k, mj, k, V, (const float*)Wt, k, (double*)nullptr, (int64_t)0);
+    hipLaunchKernelGGL((update_kernel<0, T>), dim3((unsigned)((k + 63) / 64), (unsigned)((mj + U_RR - 1) / U_RR)), dim3(256), 0,
+                       stream(), C, k, mj, k, V, (const T*)Wt, k, (double*)nullptr, (int64_t)0);
   }
   TNH_LAUNCH_CHECK();
   // V = Q_R V_b: row-panel reflectors, last to first
   for (int64_t p = L.np - 2; p >= 0; --p) {
     const int64_t j = 16 * (p + 1), nj = n - j;
-    const float* V = (const float*)(base + L.Vr) + vr_offset(n, p);
-    float* C = Vv + j * k;
-    const int chunks = (int)((nj + W_RC - 1) / W_RC);
-    hipLaunchKernelGGL(wpass_kernel, dim3((unsigned)((k + 63) / 64), chunks), dim3(256), 0, stream(), (const float*)C, k,
+    const T* V = (const T*)(base + L.Vr) + vr_offset(n, p);
+    T* C = Vv + j * k;
+    const int chunks = (int)((nj + WRC - 1) / WRC);
+    hipLaunchKernelGGL((wpass_kernel<T>), dim3((unsigned)((k + 63) / 64), chunks), dim3(256), 0, stream(), (const T*)C, k,
                        nj, k, V, Wpart);
-    hipLaunchKernelGGL(wreduce_kernel, dim3((unsigned)((k + 63) / 64)), dim3(256), 0, stream(), (const float*)Wpart,
+    hipLaunchKernelGGL((wreduce_kernel<T>), dim3((unsigned)((k + 63) / 64)), dim3(256), 0, stream(), (const T*)Wpart,
                        chunks, k, (const double*)(base + L.Tr) + p * 256, 0, Wt);
-    hipLaunchKernelGGL((update_kernel<0>), dim3((unsigned)((k + 63) / 64), (unsigned)((nj + U_RR - 1) / U_RR)), dim3(256), 0,
-                       stream(), C, k, nj, k, V, (const float*)Wt, k, (double*)nullptr, (int64_t)0);
+    hipLaunchKernelGGL((update_kernel<0, T>), dim3((unsigned)((k + 63) / 64), (unsigned)((nj + U_RR - 1) / U_RR)), dim3(256), 0,
+                       stream(), C, k, nj, k, V, (const T*)Wt, k, (double*)nullptr, (int64_t)0);
   }
   }
-  hipLaunchKernelGGL(transpose_out_kernel, dim3((unsigned)((n + 31) / 32), (unsigned)((k + 31) / 32)), dim3(256), 0,
-                     stream(), (const float*)Vv, n, k, Vh);
+  hipLaunchKernelGGL((transpose_out_kernel<T>), dim3((unsigned)((n + 31) / 32), (unsigned)((k + 31) / 32)), dim3(256), 0,
+                     stream(), (const T*)Vv, n, k, Vh);
   TNH_LAUNCH_CHECK();
   return TNH_OK;
 }
@@ -1815,7 +2132,7 @@ __global__ __launch_bounds__(256) void qr_out_kernel(const float* __restrict__ A
 }
 
 static int qr_f32(int64_t m, int64_t n, const float* A, float* Q, float* R, char* base, int* status_host) {
-  const Layout L = make_layout(m, n, 4);
+  const Layout L = make_layout(m, n, 4, 4);
   float* Af = (float*)(base + L.Af);
   double* Gc = (double*)(base + L.Gpart);
   double* Xb = (double*)(base + L.Xbuf);
@@ -1826,28 +2143,29 @@ static int qr_f32(int64_t m, int64_t n, const float* A, float* Q, float* R, char
   TNH_HIP(hipMemsetAsync(status, 0, 64, stream()));
   const int64_t np = L.np;
   int parts = (int)((m + 255) / 256);
-  hipLaunchKernelGGL((gram_kernel<false>), dim3(parts), dim3(256), 0, stream(), (const float*)Af, n, m, Gc);
+  hipLaunchKernelGGL((gram_kernel<false, float>), dim3(parts), dim3(256), 0, stream(), (const float*)Af, n, m, Gc);
   for (int64_t p = 0; p < np; ++p) {
     const int64_t j = 16 * p, mj = m - j, nc = n - j - 16;
     const float* P = Af + j * n + j;
     float* V = (float*)(base + L.Vl) + vl_offset(m, p);
     double* Tp = (double*)(base + L.Tl) + p * 256;
-    hipLaunchKernelGGL((factor_kernel<false>), dim3(1), dim3(256), 0, stream(), P, n, mj, (const double*)Gc, parts, Xb, V,
-                       (float*)nullptr, (int64_t)0, Tp, (double*)(base + L.Dblk) + p * 256, status);
+    hipLaunchKernelGGL((factor_kernel<false, float>), dim3(1), dim3(256), 0, stream(), P, n, mj, (const double*)Gc, parts,
+                       Xb, V, (float*)nullptr, (int64_t)0, Tp, (double*)(base + L.Dblk) + p * 256, (const double*)nullptr,
+                       1e-9, status);
     if (mj > 16)
-      hipLaunchKernelGGL((formv_kernel<false>), dim3((unsigned)((mj - 16 + 255) / 256)), dim3(256), 0, stream(), P, n, mj,
+      hipLaunchKernelGGL((formv_kernel<false, float>), dim3((unsigned)((mj - 16 + 255) / 256)), dim3(256), 0, stream(), P, n, mj,
                          (const double*)Xb, V, (float*)nullptr, (int64_t)0);
     if (nc > 0) {
       float* C = Af + j * n + j + 16;
-      const int chunks = (int)((mj + W_RC - 1) / W_RC);
-      hipLaunchKernelGGL(wpass_kernel, dim3((unsigned)((nc + 63) / 64), chunks), dim3(256), 0, stream(), (const float*)C,
+      const int chunks = (int)((mj + w_rc<float>() - 1) / w_rc<float>());
+      hipLaunchKernelGGL((wpass_kernel<float>), dim3((unsigned)((nc + 63) / 64), chunks), dim3(256), 0, stream(), (const float*)C,
                          n, mj, nc, (const float*)V, Wpart);
-      hipLaunchKernelGGL(wreduce_kernel, dim3((unsigned)((nc + 63) / 64)), dim3(256), 0, stream(), (const float*)Wpart,
+      hipLaunchKernelGGL((wreduce_kernel<float>), dim3((unsigned)((nc + 63) / 64)), dim3(256), 0, stream(), (const float*)Wpart,
                          chunks, nc, (const double*)Tp, 1, Wt);
       // the update leaves the partial Grams of the next panel: first 16 columns of the block, rows 16 .. (the first
       // 16 rows are R)
       const dim3 grid((unsigned)((nc + 63) / 64), (unsigned)((mj + U_RR - 1) / U_RR));
-      hipLaunchKernelGGL((update_kernel<1>), grid, dim3(256), 0, stream(), C, n, mj, nc, (const float*)V,
+      hipLaunchKernelGGL((update_kernel<1, float>), grid, dim3(256), 0, stream(), C, n, mj, nc, (const float*)V,
                          (const float*)Wt, nc, Gc, (int64_t)16);
       parts = (int)grid.y;
     }
@@ -1862,14 +2180,14 @@ static int qr_f32(int64_t m, int64_t n, const float* A, float* Q, float* R, char
   if (lds <= 150 * 1024) {
     static bool attr_done = false;
     if (!attr_done) {
-      TNH_HIP(hipFuncSetAttribute((const void*)backtransform_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+      TNH_HIP(hipFuncSetAttribute((const void*)backtransform_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   150 * 1024));
       attr_done = true;
     }
-    BtArgs a;
-    a.side[0] = BtSide{Q, n, m, (const float*)(base + L.Vl), (const double*)(base + L.Tl), np, (int64_t)0, m, 1};
+    BtArgs<float> a;
+    a.side[0] = BtSide<float>{Q, n, m, (const float*)(base + L.Vl), (const double*)(base + L.Tl), np, (int64_t)0, m, 1};
     a.side[1] = a.side[0];
-    hipLaunchKernelGGL(backtransform_kernel, dim3((unsigned)(n / BT_COLS), 1), dim3(BT_THREADS), lds, stream(), a);
+    hipLaunchKernelGGL((backtransform_kernel<float>), dim3((unsigned)(n / BT_COLS), 1), dim3(BT_THREADS), lds, stream(), a);
   } else {
     // very tall inputs: the columns do not fit in LDS -- per panel W = V^T Q, W <- T W, Q -= V W (last panel first)
     for (int64_t p = np - 1; p >= 0; --p) {
@@ -1877,12 +2195,12 @@ static int qr_f32(int64_t m, int64_t n, const float* A, float* Q, float* R, char
       const float* V = (const float*)(base + L.Vl) + vl_offset(m, p);
       float* C = Q + j * n + j;               // columns before j are untouched by panel p (identity start)
       const int64_t kc = n - j;
-      const int chunks = (int)((mj + W_RC - 1) / W_RC);
-      hipLaunchKernelGGL(wpass_kernel, dim3((unsigned)((kc + 63) / 64), chunks), dim3(256), 0, stream(), (const float*)C,
+      const int chunks = (int)((mj + w_rc<float>() - 1) / w_rc<float>());
+      hipLaunchKernelGGL((wpass_kernel<float>), dim3((unsigned)((kc + 63) / 64), chunks), dim3(256), 0, stream(), (const float*)C,
                          n, mj, kc, V, Wpart);
-      hipLaunchKernelGGL(wreduce_kernel, dim3((unsigned)((kc + 63) / 64)), dim3(256), 0, stream(), (const float*)Wpart,
+      hipLaunchKernelGGL((wreduce_kernel<float>), dim3((unsigned)((kc + 63) / 64)), dim3(256), 0, stream(), (const float*)Wpart,
                          chunks, kc, (const double*)(base + L.Tl) + p * 256, 0, Wt);
-      hipLaunchKernelGGL((update_kernel<0>), dim3((unsigned)((kc + 63) / 64), (unsigned)((mj + U_RR - 1) / U_RR)),
+      hipLaunchKernelGGL((update_kernel<0, float>), dim3((unsigned)((kc + 63) / 64), (unsigned)((mj + U_RR - 1) / U_RR)),
                          dim3(256), 0, stream(), C, n, mj, kc, V, (const float*)Wt, kc, (double*)nullptr, (int64_t)0);
     }
   }
@@ -1900,7 +2218,7 @@ bool qr_panel16_supported(int dtype, int64_t m, int64_t n) {
   if (e && e[0] == '0') return false;
   return dtype == TNH_F32 && m >= n && n >= 64 && (n % 16) == 0;
 }
-size_t qr_panel16_work_bytes(int64_t m, int64_t n) { return svdb::make_layout(m, n, 4).total + 256; }
+size_t qr_panel16_work_bytes(int64_t m, int64_t n) { return svdb::make_layout(m, n, 4, 4).total + 256; }
 int qr_panel16(int64_t m, int64_t n, const float* A, float* Q, float* R, void* work, int* status_host) {
   char* base = (char*)(((uintptr_t)work + 255) & ~(uintptr_t)255);
   return svdb::qr_f32(m, n, A, Q, R, base, status_host);
@@ -1913,45 +2231,47 @@ using namespace tnh::svdb;
 extern "C" {
 
 int tnh_svd_band_supported(int dtype, int64_t m, int64_t n, int64_t k) {
-  if (dtype != TNH_F32) return 0;
+  if (dtype != TNH_F32 && dtype != TNH_F64) return 0;
   if (m < n) return 0;                       // the caller passes the tall orientation
   if (n < 256 || (n % 16) != 0) return 0;
   if (k < 0 || k > n) return 0;
-  if (k > 0 && (k % 4) != 0) return 0;       // float4 columns in the back-transformation
+  if (k > 0 && (k % 4) != 0) return 0;       // four-element columns in the back-transformation
   return 1;
 }
 
-int tnh_svd_band_work_bytes(int64_t m, int64_t n, int64_t kcap, size_t* nbytes) {
+int tnh_svd_band_work_bytes(int dtype, int64_t m, int64_t n, int64_t kcap, size_t* nbytes) {
   TNH_REQUIRE(nbytes != nullptr, "null nbytes");
-  TNH_REQUIRE(m >= n && n >= 32 && n % 16 == 0 && kcap >= 0 && kcap <= n, "tnh_svd_band: unsupported shape %lld x %lld",
-              (long long)m, (long long)n);
-  *nbytes = make_layout(m, n, kcap > 4 ? kcap : 4).total + 256;
+  TNH_REQUIRE((dtype == TNH_F32 || dtype == TNH_F64) && m >= n && n >= 32 && n % 16 == 0 && kcap >= 0 && kcap <= n,
+              "tnh_svd_band: unsupported dtype %d / shape %lld x %lld", dtype, (long long)m, (long long)n);
+  *nbytes = make_layout(m, n, kcap > 4 ? kcap : 4, dtype == TNH_F64 ? 8 : 4).total + 256;
   return TNH_OK;
 }
 
-int tnh_svd_band_layout(int64_t m, int64_t n, int64_t kcap, int64_t* offsets, int count) {
+int tnh_svd_band_layout(int dtype, int64_t m, int64_t n, int64_t kcap, int64_t* offsets, int count) {
   TNH_REQUIRE(offsets != nullptr && count >= 12, "tnh_svd_band_layout: need room for 12 offsets");
-  const Layout L = make_layout(m, n, kcap > 4 ? kcap : 4);
+  const Layout L = make_layout(m, n, kcap > 4 ? kcap : 4, dtype == TNH_F64 ? 8 : 4);
   const size_t o[12] = {L.Af, L.Vl, L.Vr, L.Tl, L.Tr, L.Dblk, L.Eblk, L.Bd, L.Tb, L.lo, L.hi, L.X};
   for (int i = 0; i < 12; ++i) offsets[i] = (int64_t)o[i];
   return TNH_OK;
 }
 
-int tnh_svd_band_factor(int64_t m, int64_t n, const void* A, void* S, void* work, int64_t kcap, int* status_out) {
+int tnh_svd_band_factor(int dtype, int64_t m, int64_t n, const void* A, void* S, void* work, int64_t kcap,
+                        int* status_out) {
   TNH_NEED_INIT();
   TNH_REQUIRE(A && S && work, "null pointer");
-  TNH_REQUIRE(tnh_svd_band_supported(TNH_F32, m, n, 0), "tnh_svd_band_factor: unsupported shape %lld x %lld",
-              (long long)m, (long long)n);
+  TNH_REQUIRE(tnh_svd_band_supported(dtype, m, n, 0), "tnh_svd_band_factor: unsupported dtype %d / shape %lld x %lld",
+              dtype, (long long)m, (long long)n);
   TNH_REQUIRE(!(status_out && capturing()), "tnh_svd_band_factor: a status read-back synchronises the stream (graph capture)");
   read_env();
   char* base = (char*)(((uintptr_t)work + 255) & ~(uintptr_t)255);
-  const Layout L = make_layout(m, n, kcap > 4 ? kcap : 4);
-  TNH_HIP(hipMemcpyAsync(base + L.Af, A, (size_t)m * n * 4, hipMemcpyDeviceToDevice, stream()));
+  const int esz = dtype == TNH_F64 ? 8 : 4;
+  const Layout L = make_layout(m, n, kcap > 4 ? kcap : 4, esz);
+  TNH_HIP(hipMemcpyAsync(base + L.Af, A, (size_t)m * n * esz, hipMemcpyDeviceToDevice, stream()));
   TNH_HIP(hipMemsetAsync(base + L.status, 0, 64, stream()));
   TNH_HIP(hipMemsetAsync(base + L.Eblk, 0, (size_t)L.np * 256 * 8, stream()));
-  int rc = stage1(L, base, m, n);
+  int rc = esz == 8 ? stage1<double>(L, base, m, n) : stage1<float>(L, base, m, n);
   if (rc) return rc;
-  rc = values(L, base, n, kcap, (float*)S);
+  rc = esz == 8 ? values<double>(L, base, n, (double*)S) : values<float>(L, base, n, (float*)S);
   if (rc) return rc;
   if (status_out) {
     int st = 0;
@@ -1962,18 +2282,20 @@ int tnh_svd_band_factor(int64_t m, int64_t n, const void* A, void* S, void* work
   return TNH_OK;
 }
 
-int tnh_svd_band_vectors(int64_t m, int64_t n, void* work, int64_t kcap, int64_t k, void* U, void* Vh,
+int tnh_svd_band_vectors(int dtype, int64_t m, int64_t n, void* work, int64_t kcap, int64_t k, void* U, void* Vh,
                          void* S_kept, int* status_out) {
   TNH_NEED_INIT();
   TNH_REQUIRE(work && U && Vh, "null pointer");
-  TNH_REQUIRE(k > 0 && k <= kcap && tnh_svd_band_supported(TNH_F32, m, n, k),
+  TNH_REQUIRE(k > 0 && k <= kcap && tnh_svd_band_supported(dtype, m, n, k),
               "tnh_svd_band_vectors: unsupported k = %lld (kcap %lld) for %lld x %lld", (long long)k, (long long)kcap,
               (long long)m, (long long)n);
   TNH_REQUIRE(!(status_out && capturing()), "tnh_svd_band_vectors: a status read-back synchronises the stream (graph capture)");
   read_env();
   char* base = (char*)(((uintptr_t)work + 255) & ~(uintptr_t)255);
-  const Layout L = make_layout(m, n, kcap > 4 ? kcap : 4);
-  int rc = vectors(L, base, m, n, k, (float*)U, (float*)Vh, (float*)S_kept);
+  const int esz = dtype == TNH_F64 ? 8 : 4;
+  const Layout L = make_layout(m, n, kcap > 4 ? kcap : 4, esz);
+  int rc = esz == 8 ? vectors<double>(L, base, m, n, k, (double*)U, (double*)Vh, (double*)S_kept)
+                    : vectors<float>(L, base, m, n, k, (float*)U, (float*)Vh, (float*)S_kept);
   if (rc) return rc;
   if (status_out) {
     int st = 0;

@@ -1087,7 +1087,8 @@ class HipBackend(BackendBase):
     r = min(m, n)
     self.last_svd_path = "jacobi"
 
-    if work_code == _lib.F32 and getattr(self, "svd_band", True):
+    if work_code in (_lib.F32, _lib.F64) and getattr(self, "svd_band", True) and \
+        (work_code == _lib.F32 or getattr(self, "svd_band_f64", True)):
       done = self._svd_band(mat, m, n, max_singular_values, max_truncation_error, relative)
       if done is not None:
         u, s, vh, s_rest = done
@@ -1098,7 +1099,8 @@ class HipBackend(BackendBase):
           s, s_rest = self.cast(s, orig_code), self.cast(s_rest, orig_code)
         return u.view(tuple(left_dims) + (keep,)), s, vh.view((keep,) + tuple(right_dims)), s_rest
 
-    if work_code == _lib.C64 and getattr(self, "svd_band", True):
+    if work_code in (_lib.C64, _lib.C128) and getattr(self, "svd_band", True) and \
+        (work_code == _lib.C64 or getattr(self, "svd_band_f64", True)):
       done = self._svd_complex_band(mat, m, n, max_singular_values, max_truncation_error, relative)
       if done is not None:
         u, s, vh, s_rest = done
@@ -1189,7 +1191,8 @@ class HipBackend(BackendBase):
   svd_band_max_factor_bytes = 24 << 30
 
   def _svd_band(self, mat, m, n, max_singular_values, max_truncation_error, relative):
-    """K7b (tnh_svd_band_*): band reduction + spectrum slicing + inverse iteration, f32, min(m, n) >= 512.
+    """K7b (tnh_svd_band_*): band reduction + spectrum slicing + inverse iteration, f32 and (round 4) f64,
+    min(m, n) >= 512.
 
     Round 4: every call shape the reference makes (network_operations.py:130-255, 446-588) --
     `max_singular_values` alone, `max_truncation_error` alone (values first, k picked on the host by
@@ -1248,10 +1251,10 @@ class HipBackend(BackendBase):
     return u, s, vh, s_rest
 
   def _svd_band_core(self, a, mm, nn, kmax, pick):
-    """The device calls of the band path on a tall (mm >= nn) f32 matrix with nn % 16 == 0: factor (ALL values) ->
+    """The device calls of the band path on a tall (mm >= nn) f32 / f64 matrix with nn % 16 == 0: factor (ALL values) ->
     number of kept triplets (`kmax`, or `pick(values on the host)`) -> vectors.  Returns (u (mm, keep), s (keep,),
     vh (keep, nn), s_rest (nn - keep,)) or None."""
-    if pick is not None and nn * nn * 128 > self.svd_band_max_factor_bytes:
+    if pick is not None and nn * nn * self._svd_band_bytes_per_vector_row(a.code) > self.svd_band_max_factor_bytes:
       # k is only known after the values, and a work buffer for k = nn would be too large: values with the smallest
       # layout first, then the whole call again with the k they give (twice the factor stage; nn > 14000 only)
       first = self._svd_band_core(a, mm, nn, 4, None)
@@ -1261,19 +1264,19 @@ class HipBackend(BackendBase):
       return self._svd_band_core(a, mm, nn, max(pick(s_host), 0), None)
     kmax = min(int(kmax), nn)
     kcap = nn if pick is not None else (kmax + 3) // 4 * 4
-    if kmax <= 0 or kcap * nn * 128 > self.svd_band_max_factor_bytes:
+    if kmax <= 0 or kcap * nn * self._svd_band_bytes_per_vector_row(a.code) > self.svd_band_max_factor_bytes:
       return None
-    if not self.lib.tnh_svd_band_supported(_lib.F32, mm, nn, kcap):
+    if not self.lib.tnh_svd_band_supported(a.code, mm, nn, kcap):
       return None
     nbytes = ctypes.c_size_t(0)
-    _lib.check(self.lib.tnh_svd_band_work_bytes(mm, nn, kcap, ctypes.byref(nbytes)), "tnh_svd_band_work_bytes")
+    _lib.check(self.lib.tnh_svd_band_work_bytes(a.code, mm, nn, kcap, ctypes.byref(nbytes)), "tnh_svd_band_work_bytes")
     work = DeviceTensor.empty((nbytes.value // 8 + 1,), _lib.F64)
-    s_all = DeviceTensor.empty((nn,), _lib.F32)
+    s_all = DeviceTensor.empty((nn,), a.code)
     status = ctypes.c_int(0)
     # the status word of the factor stage is read back when the values are needed on the host anyway, and for a shape
     # whose last call failed (a rank-deficient input otherwise pays factor + vectors + Jacobi each time)
-    check_now = pick is not None or (mm, nn) in self._svd_band_failed
-    _lib.check(self.lib.tnh_svd_band_factor(mm, nn, _vp(a), _vp(s_all), _vp(work), kcap,
+    check_now = pick is not None or (a.code, mm, nn) in self._svd_band_failed
+    _lib.check(self.lib.tnh_svd_band_factor(a.code, mm, nn, _vp(a), _vp(s_all), _vp(work), kcap,
                                             ctypes.byref(status) if check_now else None), "tnh_svd_band_factor")
     if check_now and status.value:
       self.last_svd_band_status = status.value
@@ -1282,16 +1285,16 @@ class HipBackend(BackendBase):
     if keep <= 0:
       return None
     kk = (keep + 3) // 4 * 4          # the back-transformation moves float4 columns; extra vectors are dropped
-    uu = DeviceTensor.empty((mm, kk), _lib.F32)
-    vvh = DeviceTensor.empty((kk, nn), _lib.F32)
-    s_kept = DeviceTensor.empty((kk,), _lib.F32)
-    _lib.check(self.lib.tnh_svd_band_vectors(mm, nn, _vp(work), kcap, kk, _vp(uu), _vp(vvh), _vp(s_kept),
+    uu = DeviceTensor.empty((mm, kk), a.code)
+    vvh = DeviceTensor.empty((kk, nn), a.code)
+    s_kept = DeviceTensor.empty((kk,), a.code)
+    _lib.check(self.lib.tnh_svd_band_vectors(a.code, mm, nn, _vp(work), kcap, kk, _vp(uu), _vp(vvh), _vp(s_kept),
                                              ctypes.byref(status)), "tnh_svd_band_vectors")
     self.last_svd_band_status = status.value
     if status.value:
-      self._svd_band_failed.add((mm, nn))
+      self._svd_band_failed.add((a.code, mm, nn))
       return None
-    self._svd_band_failed.discard((mm, nn))
+    self._svd_band_failed.discard((a.code, mm, nn))
     if kk != keep:
       uu = self.getitem(uu, (slice(None), slice(0, keep)))
       vvh = self.getitem(vvh, slice(0, keep))
@@ -1299,6 +1302,12 @@ class HipBackend(BackendBase):
     # kept values: from the brackets the vectors stage refined to 2^-32 s_1; the discarded ones
     # keep the 20 bits every bracket gets (5e-7 s_1)
     return uu, s_kept, vvh, self.getitem(s_all, slice(keep, nn))
+
+  @staticmethod
+  def _svd_band_bytes_per_vector_row(code):
+    """inverse-iteration workspace per kept vector and matrix row: the stored LDL^T factor (16 + 1 doubles) and the
+    vector; the f64 path adds two more vector buffers (Newton-Schulz)"""
+    return 128 + 16 + (16 if code == _lib.F64 else 0)
 
   def _svd_band_pad(self, a, mm, nn, pad):
     """nn not a multiple of the 16-wide panels: the band path runs on
@@ -1315,7 +1324,8 @@ class HipBackend(BackendBase):
     Costs three extra passes over A, sixteen + two matrix-vector products, and a factor <= 2 in the absolute accuracy
     of the values (the brackets are relative to the largest value, now delta).
     Returns (A'', delta, z, w) or (None, None, None, None)."""
-    x = self.device_random((nn,), np.float32, seed=12345)
+    npdt = np.float64 if a.code == _lib.F64 else np.float32
+    x = self.cast(self.device_random((nn,), np.float32, seed=12345), a.code)
     for _ in range(8):
       y = self._tensordot_impl(a, x, [[1], [0]], None, None)[0]
       x = self._tensordot_impl(a, y, [[0], [0]], None, None)[0]
@@ -1323,18 +1333,18 @@ class HipBackend(BackendBase):
     est = float(np.asarray(self.norm(self._tensordot_impl(a, x, [[1], [0]], None, None)[0])))
     if not np.isfinite(est) or est <= 0.0:
       return None, None, None, None
-    delta = float(np.float32(2.0 * est))
-    big = DeviceTensor.empty((mm + pad, nn + pad), _lib.F32)
+    delta = float(npdt(2.0 * est))
+    big = DeviceTensor.empty((mm + pad, nn + pad), a.code)
     _lib.check(self.lib.tnh_memset(_vp(big), 0, big.nbytes), "tnh_memset")
     _lib.check(self.lib.tnh_strided_scatter(_vp(big), _vp(a), 2, _lib.i64_array((mm, nn)),
-                                            _lib.i64_array((nn + pad, 1)), 0, 4), "tnh_strided_scatter")
-    dvec = self._fill((pad,), np.float32, delta)
+                                            _lib.i64_array((nn + pad, 1)), 0, a.itemsize), "tnh_strided_scatter")
+    dvec = self._fill((pad,), npdt, delta)
     _lib.check(self.lib.tnh_strided_scatter(_vp(big), _vp(dvec), 1, _lib.i64_array((pad,)),
-                                            _lib.i64_array((nn + pad + 1,)), mm * (nn + pad) + nn, 4),
+                                            _lib.i64_array((nn + pad + 1,)), mm * (nn + pad) + nn, a.itemsize),
                "tnh_strided_scatter")
-    z = self.device_random((mm + pad,), np.float32, seed=23456)
+    z = self.cast(self.device_random((mm + pad,), np.float32, seed=23456), a.code)
     z = self._binary(_lib.OP_DIV, z, self.norm(z))
-    w = self.device_random((nn + pad,), np.float32, seed=34567)
+    w = self.cast(self.device_random((nn + pad,), np.float32, seed=34567), a.code)
     w = self._binary(_lib.OP_DIV, w, self.norm(w))
     q = self._tensordot_impl(z, big, [[0], [0]], None, None)[0]                    # z^T A'
     big = self._binary(_lib.OP_SUB, big, self.outer_product(self._binary(_lib.OP_MUL, z, 2.0), q))
@@ -1351,9 +1361,9 @@ class HipBackend(BackendBase):
     return uu, vvh
 
   def _svd_complex_band(self, mat, m, n, max_singular_values, max_truncation_error, relative):
-    """complex64 truncated SVD of a large matrix through the REAL band path.
+    """complex64 / complex128 SVD of a large matrix through the REAL band path (f32 / f64).
 
-    E = phi(conj(A)) (2m x 2n, f32; phi(z) = [[re, im], [-im, re]], tnh_complex_expand) acts on interleaved
+    E = phi(conj(A)) (2m x 2n, real; phi(z) = [[re, im], [-im, re]], tnh_complex_expand) acts on interleaved
     (re, im) column vectors like A does on complex ones, so A = U S V^H  <=>  E = phi-form(U) (S x I_2) phi-form(V)^T:
     every singular value of A appears twice in E, and a real singular pair (x, y) of E is the complex pair
     (x[0::2] + i x[1::2],  y[0::2] + i y[1::2]) of A.  The band path returns an orthonormal basis of each doubled
@@ -1368,8 +1378,11 @@ class HipBackend(BackendBase):
     kmax = r if max_singular_values is None else min(int(max_singular_values), r)
     if kmax <= 0:
       return None
-    emb = DeviceTensor.empty((2 * m, 2 * n), _lib.F32)
-    _lib.check(self.lib.tnh_complex_expand(_vp(emb), _vp(mat), m, n, n, 1, 1, _lib.C64), "tnh_complex_expand")
+    ccode = mat.code                                         # complex64 -> f32 band path, complex128 -> f64
+    rcode = _REAL_OF[ccode]
+    rnp, cnp = (np.float32, np.complex64) if ccode == _lib.C64 else (np.float64, np.complex128)
+    emb = DeviceTensor.empty((2 * m, 2 * n), rcode)
+    _lib.check(self.lib.tnh_complex_expand(_vp(emb), _vp(mat), m, n, n, 1, 1, ccode), "tnh_complex_expand")
     done = self._svd_band(emb, 2 * m, 2 * n, 2 * kmax, None, False)
     self.last_svd_path = "jacobi"                            # until this method has an answer of its own
     if done is None:
@@ -1388,9 +1401,10 @@ class HipBackend(BackendBase):
 
     def as_complex(x, rows, cols, ld):
       # complex[i, j] = x[2 i, j] + i x[2 i + 1, j]: one strided gather into interleaved (re, im)
-      out = DeviceTensor.empty((rows, cols), _lib.C64)
+      out = DeviceTensor.empty((rows, cols), ccode)
       _lib.check(self.lib.tnh_strided_copy(_vp(out), _vp(x), 3, _lib.i64_array((rows, cols, 2)),
-                                           _lib.i64_array((2 * ld, 1, ld)), 0, 4), "tnh_strided_copy")
+                                           _lib.i64_array((2 * ld, 1, ld)), 0, 4 if rcode == _lib.F32 else 8),
+                 "tnh_strided_copy")
       return out
 
     zu = as_complex(ur, m, k2, 2 * kmax)                     # candidates for U: m x 2k (first 2 keep columns)
@@ -1425,12 +1439,12 @@ class HipBackend(BackendBase):
       if len(basis) < keep:
         return None
       coef[:, :] = np.stack(basis, axis=1)
-    cdev = self.convert_to_tensor(coef.astype(np.complex64))
+    cdev = self.convert_to_tensor(coef.astype(cnp))
     u = self._tensordot_impl(zu, cdev, [[1], [0]], None, None)[0]               # m x keep
     v = self._tensordot_impl(zv, cdev, [[1], [0]], None, None)[0]               # n x keep
     vh = self.conj(self.transpose(v, (1, 0)))
-    s_dev = self.convert_to_tensor(s_c[:keep].astype(np.float32))
-    s_rest = self.convert_to_tensor(s_c[keep:].astype(np.float32))
+    s_dev = self.convert_to_tensor(s_c[:keep].astype(rnp))
+    s_rest = self.convert_to_tensor(s_c[keep:].astype(rnp))
     self.last_svd_path = "band (complex via the real embedding)"
     return u, s_dev, vh, s_rest
 

@@ -429,16 +429,16 @@ class EmuLib:
   def tnh_svd_band_supported(self, code, m, n, k):
     if not self.band_svd:
       return 0
-    return int(code == _lib.F32 and m >= n and n >= 256 and n % 16 == 0 and 0 <= k <= n and k % 4 == 0)
+    return int(code in (_lib.F32, _lib.F64) and m >= n and n >= 256 and n % 16 == 0 and 0 <= k <= n and k % 4 == 0)
 
-  def tnh_svd_band_work_bytes(self, m, n, kcap, nbytes_ref):
-    assert m >= n and n % 16 == 0 and 0 <= kcap <= n
+  def tnh_svd_band_work_bytes(self, code, m, n, kcap, nbytes_ref):
+    assert code in (_lib.F32, _lib.F64) and m >= n and n % 16 == 0 and 0 <= kcap <= n
     nbytes_ref._obj.value = 256 + 8 * int(max(kcap, 4))     # pylint: disable=protected-access
     return _lib.OK
 
-  def tnh_svd_band_factor(self, m, n, a, s_out, work, kcap, status_ref):
-    assert self.tnh_svd_band_supported(_lib.F32, m, n, 0)
-    mat = np.array(self._flat(a, m * n, np.float32)).reshape(m, n).astype(np.float64)
+  def tnh_svd_band_factor(self, code, m, n, a, s_out, work, kcap, status_ref):
+    assert self.tnh_svd_band_supported(code, m, n, 0)
+    mat = np.array(self._flat(a, m * n, _NP[code])).reshape(m, n).astype(np.float64)
     u, sv, vh = np.linalg.svd(mat, full_matrices=False)
     # ST_PANEL: a 16-wide panel whose Gram matrix has a Cholesky pivot below 1e-9 of its largest diagonal entry --
     # decided by running stage 1 of the NumPy model of the algorithm (tools/svd_band_model.py: the same panels, the
@@ -446,24 +446,25 @@ class EmuLib:
     # matrices, low rank) fail here as they do on the MI355X
     status = 1 if sv[0] == 0 or not _panels_full_rank(mat) else 0
     self._band_state = getattr(self, "_band_state", {})
-    self._band_state[_addr(work)] = (u, sv, vh, int(kcap), status)
-    coarse = np.round(sv / sv[0] * 2.0**20) / 2.0**20 * sv[0] if sv[0] > 0 else sv   # what 20-bit brackets carry
-    self._flat(s_out, n, np.float32)[:] = coarse.astype(np.float32)
+    self._band_state[_addr(work)] = (u, sv, vh, int(kcap), status, code)
+    bits = 20 if code == _lib.F32 else 32          # what the brackets of ALL values carry
+    coarse = np.round(sv / sv[0] * 2.0**bits) / 2.0**bits * sv[0] if sv[0] > 0 else sv
+    self._flat(s_out, n, _NP[code])[:] = coarse.astype(_NP[code])
     self.calls.append(("svd_band_factor", (int(m), int(n), int(kcap))))
     if status_ref is not None:
       status_ref._obj.value = status     # pylint: disable=protected-access
     return _lib.OK
 
-  def tnh_svd_band_vectors(self, m, n, work, kcap, k, u_out, vh_out, s_kept, status_ref):
-    u, sv, vh, kcap0, status = self._band_state[_addr(work)]
+  def tnh_svd_band_vectors(self, code, m, n, work, kcap, k, u_out, vh_out, s_kept, status_ref):
+    u, sv, vh, kcap0, status, code0 = self._band_state[_addr(work)]
     k = int(k)
-    assert int(kcap) == kcap0 and 0 < k <= kcap0 and k % 4 == 0, (kcap, kcap0, k)
-    if sv[k - 1] <= 1e-6 * sv[0]:
+    assert code == code0 and int(kcap) == kcap0 and 0 < k <= kcap0 and k % 4 == 0, (kcap, kcap0, k)
+    if sv[k - 1] <= (1e-6 if code == _lib.F32 else 1e-5) * sv[0]:
       status |= 16
-    self._flat(u_out, m * k, np.float32)[:] = u[:, :k].astype(np.float32).reshape(-1)
-    self._flat(vh_out, k * n, np.float32)[:] = vh[:k].astype(np.float32).reshape(-1)
+    self._flat(u_out, m * k, _NP[code])[:] = u[:, :k].astype(_NP[code]).reshape(-1)
+    self._flat(vh_out, k * n, _NP[code])[:] = vh[:k].astype(_NP[code]).reshape(-1)
     if _addr(s_kept):
-      self._flat(s_kept, k, np.float32)[:] = sv[:k].astype(np.float32)
+      self._flat(s_kept, k, _NP[code])[:] = sv[:k].astype(_NP[code])
     self.calls.append(("svd_band_vectors", (int(m), int(n), int(kcap), k)))
     if status_ref is not None:
       status_ref._obj.value = status     # pylint: disable=protected-access

@@ -112,16 +112,16 @@ def test_band_stage_outputs_match_the_numpy_model(hip):
   a = gaussian(n, n, seed=11)
   lib = hip.lib
   nbytes = ctypes.c_size_t(0)
-  _lib.check(lib.tnh_svd_band_work_bytes(n, n, kcap, ctypes.byref(nbytes)))
+  _lib.check(lib.tnh_svd_band_work_bytes(_lib.F32, n, n, kcap, ctypes.byref(nbytes)))
   work = DeviceTensor.empty((nbytes.value // 8 + 1,), _lib.F64)
   s_all = DeviceTensor.empty((n,), _lib.F32)
   da = hip.convert_to_tensor(a)
   status = ctypes.c_int(-1)
-  _lib.check(lib.tnh_svd_band_factor(n, n, ctypes.c_void_p(da.ptr), ctypes.c_void_p(s_all.ptr),
+  _lib.check(lib.tnh_svd_band_factor(_lib.F32, n, n, ctypes.c_void_p(da.ptr), ctypes.c_void_p(s_all.ptr),
                                      ctypes.c_void_p(work.ptr), kcap, ctypes.byref(status)), "tnh_svd_band_factor")
   assert status.value == 0
   offs = (ctypes.c_int64 * 12)()
-  _lib.check(lib.tnh_svd_band_layout(n, n, kcap, offs, 12))
+  _lib.check(lib.tnh_svd_band_layout(_lib.F32, n, n, kcap, offs, 12))
   names = ["Af", "Vl", "Vr", "Tl", "Tr", "Dblk", "Eblk", "Bd", "Tb", "lo", "hi", "X"]
   off = dict(zip(names, [int(x) for x in offs]))
   base = (work.ptr + 255) & ~255
@@ -281,3 +281,95 @@ def test_band_svd_kept_values_keep_their_relative_accuracy(hip):
   got = np.asarray(s, dtype=np.float64)
   assert np.max(np.abs(got - sr[:k])) <= 2e-7 * sr[0], np.max(np.abs(got - sr[:k])) / sr[0]
   assert np.max(np.abs(got - sr[:k]) / sr[:k]) <= 1e-2
+
+
+# ---- round 4: float64 (and complex128 through it) on the band path ------------------------------------------------------
+def check_svd64(a, u, s, vh, s_rest, k, tag="", tol_s=1e-11, tol_rest=3e-8, tol_orth=1e-9, tol_res=2e-10):
+  """f64 band path vs LAPACK.  Stated tolerances: kept values 1e-11 s_0 (Rayleigh quotients on
+  the band), DISCARDED values 3e-8 s_0 -- brackets of 32 bits (2e-10 s_0) where the un-pivoted LDL^T of T = B^T B
+  resolves them, and a floor of sqrt(eps64) s_0 ~ 1.5e-8 s_0 below which T = B^T B cannot tell a value from zero
+  (measured: 1.5e-9 on Gaussian input, 1.6e-8 on the tail of a graded one) --, orthonormality 1e-9, triplet residual
+  |A v - s u| <= 2e-10 s_0."""
+  cplx = np.iscomplexobj(a)
+  a128 = a.astype(np.complex128 if cplx else np.float64)
+  sr = np.linalg.svd(a128, compute_uv=False)
+  s0 = sr[0]
+  sk, srest = np.real(np.asarray(s)).astype(np.float64), np.real(np.asarray(s_rest)).astype(np.float64)
+  assert sk.shape == (k,) and srest.shape == (min(a.shape) - k,)
+  assert np.max(np.abs(sk - sr[:k])) <= tol_s * s0, (tag, "kept", np.max(np.abs(sk - sr[:k])) / s0)
+  if srest.size:
+    assert np.max(np.abs(srest - sr[k:])) <= tol_rest * s0, (tag, "rest", np.max(np.abs(srest - sr[k:])) / s0)
+  uu, vv = np.asarray(u).astype(a128.dtype), np.asarray(vh).astype(a128.dtype)
+  assert uu.shape == (a.shape[0], k) and vv.shape == (k, a.shape[1])
+  assert np.max(np.abs(uu.conj().T @ uu - np.eye(k))) <= tol_orth, (tag, "U", np.max(np.abs(uu.conj().T @ uu - np.eye(k))))
+  assert np.max(np.abs(vv @ vv.conj().T - np.eye(k))) <= tol_orth, (tag, "V", np.max(np.abs(vv @ vv.conj().T - np.eye(k))))
+  resid = np.max(np.linalg.norm(a128 @ vv.conj().T - uu * sk, axis=0))
+  assert resid <= tol_res * s0, (tag, "resid", resid / s0)
+
+
+def graded64(m, n, seed, rate=32.0):
+  rng = np.random.default_rng(seed)
+  r = min(m, n)
+  qu, _ = np.linalg.qr(rng.standard_normal((m, r)))
+  qv, _ = np.linalg.qr(rng.standard_normal((n, r)))
+  return (qu * 2.0 ** (-np.arange(r) / rate)) @ qv.T
+
+
+@pytest.mark.parametrize("kind,m,n,k", [("gauss", 1024, 1024, 64), ("graded", 1024, 1024, 64), ("gauss", 1536, 1024, 100),
+                                        ("gauss", 1024, 2048, 128), ("graded", 1000, 1100, 50)])
+def test_band_svd_float64(hip, kind, m, n, k):
+  """The reference's default dtype (ncon_interface_test.py:39-43, base_mps.py) on the band path: f64 panels by two
+  Cholesky-QR passes, values to 32 bits, kept values as Rayleigh quotients, one Newton-Schulz step on the kept
+  vectors."""
+  a = np.random.default_rng(m + n + k).standard_normal((m, n)) if kind == "gauss" else graded64(m, n, seed=m + n + k)
+  u, s, vh, s_rest = hip.svd(hip.convert_to_tensor(a), 1, max_singular_values=k)
+  assert hip.last_svd_path == "band", (hip.last_svd_path, hip.last_svd_band_status)
+  assert u.dtype == np.float64 and s.dtype == np.float64 and vh.dtype == np.float64 and s_rest.dtype == np.float64
+  check_svd64(a, u, s, vh, s_rest, k, f"f64 {kind} {m}x{n} k={k}")
+
+
+def test_band_svd_float64_other_call_shapes(hip):
+  a = graded64(1024, 1024, seed=4, rate=16.0)
+  sr = np.linalg.svd(a, compute_uv=False)
+  u, s, vh, s_rest = hip.svd(hip.convert_to_tensor(a), 1, max_truncation_error=1e-3, relative=True)
+  assert hip.last_svd_path == "band", (hip.last_svd_path, hip.last_svd_band_status)
+  want = int(np.count_nonzero(np.sqrt(np.cumsum(sr[::-1] ** 2)) > 1e-3 * sr[0]))
+  assert abs(s.shape[0] - want) <= 1
+  check_svd64(a, u, s, vh, s_rest, s.shape[0], "f64 trunc error alone")
+  g = np.random.default_rng(8).standard_normal((768, 768))
+  u, s, vh, s_rest = hip.svd(hip.convert_to_tensor(g), 1)                     # split_node_full_svd
+  assert hip.last_svd_path == "band", (hip.last_svd_path, hip.last_svd_band_status)
+  check_svd64(g, u, s, vh, s_rest, 768, "f64 full", tol_res=5e-9)
+  rec = (np.asarray(u) * np.asarray(s)) @ np.asarray(vh)
+  assert np.max(np.abs(rec - g)) <= 1e-9 * sr[0] * 100
+  # a kept value below 1e-5 s_1 is outside the f64 band path's range: reported, Jacobi answers
+  steep = graded64(1024, 1024, seed=5, rate=4.0)
+  u, s, vh, s_rest = hip.svd(hip.convert_to_tensor(steep), 1, max_singular_values=128)      # s_128 = 2^-32 s_1
+  assert hip.last_svd_path == "jacobi" and hip.last_svd_band_status & 16
+  np.testing.assert_allclose(np.asarray(s), np.linalg.svd(steep, compute_uv=False)[:128], rtol=1e-7, atol=1e-14)
+
+
+def test_band_svd_complex128_through_the_f64_embedding(hip):
+  rng = np.random.default_rng(13)
+  m, n, k = 768, 640, 40
+  a = rng.standard_normal((m, n)) + 1j * rng.standard_normal((m, n))
+  u, s, vh, s_rest = hip.svd(hip.convert_to_tensor(a), 1, max_singular_values=k)
+  assert "complex via the real embedding" in hip.last_svd_path, (hip.last_svd_path, hip.last_svd_band_status)
+  assert u.dtype == np.complex128 and s.dtype == np.complex128
+  check_svd64(a, u, s, vh, s_rest, k, "complex128")
+
+
+def test_qr_fast_path_is_not_taken_inside_a_graph_capture(hip):
+  """the 16-wide-panel QR reads a status word back (a stream synchronisation), illegal while the stream is
+  captured -- a captured QR takes the column path and replays correctly."""
+  a = gaussian(512, 256, seed=3)
+  q0, r0 = hip.qr(hip.convert_to_tensor(a), 1)
+  ref_q, ref_r = np.asarray(q0), np.asarray(r0)
+  x = hip.convert_to_tensor(a)
+  graph = hip.capture(lambda t: hip.qr(t, 1), x)
+  q, r = graph.launch()
+  hip.synchronize()
+  np.testing.assert_allclose(np.asarray(q) @ np.asarray(r), a, atol=2e-5)
+  np.testing.assert_allclose(np.abs(np.asarray(r)), np.abs(ref_r), atol=2e-4)
+  assert np.max(np.abs(np.asarray(q).T @ np.asarray(q) - np.eye(256))) < 1e-4
+  del ref_q

@@ -573,3 +573,36 @@ def test_band_svd_kept_values_come_from_the_refined_brackets():
   sr = np.linalg.svd(a.astype(np.float64), compute_uv=False)
   np.testing.assert_allclose(np.asarray(s), sr[:64], rtol=2e-6)          # not 5e-7 / 1.8e-5 = 3 %
   np.testing.assert_allclose(np.asarray(rest), sr[64:], atol=1e-6)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.complex64, np.complex128])
+@pytest.mark.parametrize("mode", ["max_sv", "err_only", "full"])
+def test_band_svd_host_logic_in_the_other_dtypes(dtype, mode):
+  """float64 runs the same host logic on the f64 entry points (round 4); complex64 / complex128 go through the real
+  embedding (2m x 2n, every value doubled) of the f32 / f64 band path."""
+  rng = np.random.default_rng(17)
+  m, n = (520, 530) if dtype == np.float64 else (280, 264)
+  r = min(m, n)
+  cplx = np.dtype(dtype).kind == "c"
+  g = lambda *sh: rng.standard_normal(sh) + (1j * rng.standard_normal(sh) if cplx else 0.0)
+  qu, _ = np.linalg.qr(g(m, r))
+  qv, _ = np.linalg.qr(g(n, r))
+  spec = 3.0 * 2.0 ** (-np.arange(r) / 40.0)
+  a = ((qu * spec) @ qv.conj().T).astype(dtype)
+  kw = {"max_sv": dict(max_singular_values=21), "err_only": dict(max_truncation_error=0.05), "full": {}}[mode]
+  ref = orc.svd(a.astype(np.complex128 if cplx else np.float64), 1, kw.get("max_singular_values"),
+                kw.get("max_truncation_error"), False)
+  with emulated_backend() as be:
+    be.lib.band_svd = True
+    out = [np.asarray(x) for x in be.svd(be.convert_to_tensor(a), 1, **kw)]
+    assert be.last_svd_path.startswith("band"), (be.last_svd_path, be.last_svd_band_status)
+    assert out[0].dtype == dtype and out[1].dtype == dtype and out[2].dtype == dtype
+  u, s, vh, rest = out
+  tol = 3e-6 if np.dtype(dtype).itemsize in (4, 8) and dtype != np.float64 else 1e-9
+  s0 = float(np.real(ref[1][0]))
+  assert s.shape == ref[1].shape and rest.shape == ref[3].shape
+  np.testing.assert_allclose(np.real(s), np.real(ref[1]), atol=tol * s0)
+  np.testing.assert_allclose(np.real(rest), np.real(ref[3]), atol=2 * tol * s0)
+  k = s.shape[0]
+  np.testing.assert_allclose(u.conj().T @ u, np.eye(k), atol=20 * tol)
+  np.testing.assert_allclose((u * np.real(s)) @ vh, (ref[0] * ref[1]) @ ref[2], atol=40 * tol * s0)

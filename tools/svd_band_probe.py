@@ -29,7 +29,7 @@ def main():
     a = ((qu * 2.0 ** (-np.arange(n) / 32.0)) @ qv.T).astype(np.float32)
   da = be.convert_to_tensor(a)
   nbytes = ctypes.c_size_t(0)
-  _lib.check(lib.tnh_svd_band_work_bytes(n, n, k, ctypes.byref(nbytes)))
+  _lib.check(lib.tnh_svd_band_work_bytes(_lib.F32, n, n, k, ctypes.byref(nbytes)))
   work = DeviceTensor.empty((nbytes.value // 8 + 1,), _lib.F64)
   s_all = DeviceTensor.empty((n,), _lib.F32)
   u = DeviceTensor.empty((n, k), _lib.F32)
@@ -40,11 +40,11 @@ def main():
   for rep in range(3):
     be.synchronize()
     t0 = time.perf_counter()
-    _lib.check(lib.tnh_svd_band_factor(n, n, ctypes.c_void_p(da.ptr), ctypes.c_void_p(s_all.ptr),
+    _lib.check(lib.tnh_svd_band_factor(_lib.F32, n, n, ctypes.c_void_p(da.ptr), ctypes.c_void_p(s_all.ptr),
                                        ctypes.c_void_p(work.ptr), k, ctypes.byref(st1)), "factor")
     t1 = time.perf_counter()
-    _lib.check(lib.tnh_svd_band_vectors(n, n, ctypes.c_void_p(work.ptr), k, k, ctypes.c_void_p(u.ptr),
-                                        ctypes.c_void_p(vh.ptr), ctypes.byref(st2)), "vectors")
+    _lib.check(lib.tnh_svd_band_vectors(_lib.F32, n, n, ctypes.c_void_p(work.ptr), k, k, ctypes.c_void_p(u.ptr),
+                                        ctypes.c_void_p(vh.ptr), None, ctypes.byref(st2)), "vectors")
     t2 = time.perf_counter()
     rec[f"rep{rep}"] = {"factor_ms": (t1 - t0) * 1e3, "vectors_ms": (t2 - t1) * 1e3, "total_ms": (t2 - t0) * 1e3,
                         "status": [st1.value, st2.value]}
