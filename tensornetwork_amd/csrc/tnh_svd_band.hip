@@ -1253,13 +1253,30 @@ __global__ __launch_bounds__(256) void values_kept_kernel(const double* __restri
 // shifts of the inverse iteration: vector v (0 = largest) uses the midpoint of its refined bracket
 // (shifts[k + v] = half the bracket's width: two values whose brackets overlap cannot be told apart -- see
 // cluster_mgs_kernel)
+// push_rel > 0 (f64 path): a value with a neighbour it cannot be told apart from (closer than push_rel sigma_max, or
+// overlapping brackets) is shifted UP by push_rel sigma_max.  Why: the f64 brackets are refined to the resolution of
+// the LDL^T itself (2^-44), where rounding has split an exact multiplet into copies ~1e-13 sigma_max apart; a shift
+// that happens to sit 1000x closer to one copy makes EVERY start vector converge to that copy's vector (measured on
+// the real embedding of a complex128 matrix: collapsed pairs, status 12).  From push_rel away all copies are
+// amplified alike and different starts give independent vectors of the eigenspace, which cluster_mgs_kernel
+// orthonormalises; the neighbours outside the multiplet are >> push_rel away, so convergence is unaffected.
 __global__ __launch_bounds__(256) void vshift_kernel(const double* __restrict__ lo, const double* __restrict__ hi,
-                                                     int64_t n, int64_t k, double* __restrict__ shifts) {
+                                                     const double* __restrict__ scal, int64_t n, int64_t k,
+                                                     double push_rel, double* __restrict__ shifts) {
   const int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (v >= k) return;
   const int64_t q = n - 1 - v;
-  shifts[v] = 0.5 * (lo[q] + hi[q]);
-  shifts[k + v] = 0.5 * (hi[q] - lo[q]);
+  const double mid = 0.5 * (lo[q] + hi[q]), hw = 0.5 * (hi[q] - lo[q]);
+  double sh = mid;
+  if (push_rel > 0.0) {
+    const double tol = push_rel * scal[0];
+    bool close = false;
+    if (q + 1 < n) close = close || (0.5 * (lo[q + 1] + hi[q + 1]) - mid <= tol + hw + 0.5 * (hi[q + 1] - lo[q + 1]));
+    if (q >= 1) close = close || (mid - 0.5 * (lo[q - 1] + hi[q - 1]) <= tol + hw + 0.5 * (hi[q - 1] - lo[q - 1]));
+    if (close) sh = mid + tol;
+  }
+  shifts[v] = sh;
+  shifts[k + v] = hw;
 }
 
 // ------------------------------------------------------------------------------------------------ stage 3: solves
@@ -1366,6 +1383,8 @@ __global__ __launch_bounds__(1024) void cluster_mgs_kernel(double* __restrict__ 
     // wider than tol; two members of an exact multiplet then sit at different midpoints of overlapping brackets)
     int64_t first = v;
     while (first > 0 && shifts[first - 1] - shifts[v] <= tol + shifts[k + first - 1] + shifts[k + v]) --first;   // uniform
+    // (f64 path: every member of such a run was pushed up by the same tol in vshift_kernel, the ends of a chain may
+    // differ by it -- the comparison above is on the pushed values, a chain's neighbours still differ by <= tol + widths)
     if (first == v) continue;
     double* xv = X + v * n;
     for (int pass = 0; pass < 2; ++pass)            // "twice is enough"
@@ -1744,6 +1763,7 @@ static int g_sect_rounds = 1;
 static int g_refine_p = 15;
 static int g_refine_rounds = 3;
 static int g_bits64 = 32;
+static bool g_ns64 = true;      // f64 input: Newton-Schulz step on the kept band vectors (TNH_SVDB_NS=0: off, diagnostics)
 
 static void read_env() {
   const char* e = getenv("TNH_SVDB_DPP");
@@ -1774,6 +1794,8 @@ static void read_env() {
   if (e && atoi(e) > 0) g_refine_p = atoi(e);
   e = getenv("TNH_SVDB_REFINE");
   if (e && atoi(e) >= 0) g_refine_rounds = atoi(e);
+  e = getenv("TNH_SVDB_NS");
+  g_ns64 = !(e && e[0] == '0');
   e = getenv("TNH_SVDB_BITS64");
   if (e && atoi(e) >= 20 && atoi(e) <= 44) g_bits64 = atoi(e);
 }
@@ -2005,7 +2027,8 @@ static int vectors(const Layout& L, char* base, int64_t m, int64_t n, int64_t k,
     if (rc) return rc;
   }
   hipLaunchKernelGGL(vshift_kernel, dim3((unsigned)((k + 255) / 256)), dim3(256), 0, stream(),
-                     (const double*)(base + L.lo), (const double*)(base + L.hi), n, k, (double*)(base + L.shifts));
+                     (const double*)(base + L.lo), (const double*)(base + L.hi), (const double*)(base + L.scal), n, k,
+                     F64 ? g_cluster_tol64 : 0.0, (double*)(base + L.shifts));
   const unsigned blocks = (unsigned)((k + 3) / 4);
   if (g_dpp) {
     hipLaunchKernelGGL((ldl_kernel<true, true>), dim3(blocks), dim3(64), 0, stream(), (const double*)(base + L.Trot), n,
@@ -2025,14 +2048,13 @@ static int vectors(const Layout& L, char* base, int64_t m, int64_t n, int64_t k,
                      F64 ? g_cluster_tol64 : g_cluster_tol, (int*)(base + L.status));
   TNH_LAUNCH_CHECK();
   double* Xcur = (double*)(base + L.X);
-  double* ray = nullptr;
+  double* ray = F64 ? (double*)(base + L.ray) : nullptr;
   double* Ub = nullptr;
-  if (F64) {
+  if (F64 && g_ns64) {
     // neighbours closer than ~1e-6 sigma_max come out of the inverse iteration orthogonal to eps64 / gap only
     rc = newton_schulz(Xcur, (double*)(base + L.X2), (double*)(base + L.Gns), k, n);
     if (rc) return rc;
     Xcur = (double*)(base + L.X2);
-    ray = (double*)(base + L.ray);
     Ub = (double*)(base + L.X);          // free again: the left vectors on the band, k x n
   }
   T* Uu = U;                           // m x k, transformed in place
@@ -2042,7 +2064,7 @@ static int vectors(const Layout& L, char* base, int64_t m, int64_t n, int64_t k,
                      k, Uu, Vv, ray, Ub, F64 ? 1e-6 : 5e-6, F64 ? 1e-10 : 1e-6, F64 ? 1e-5 : 1e-6,
                      (int*)(base + L.status));
   TNH_LAUNCH_CHECK();
-  if (F64) {
+  if (F64 && g_ns64) {
     // u = B v / |B v| inherits eps64 (s_1 / s)^2 of non-orthogonality from v's error along its neighbours: same cure
     rc = newton_schulz(Ub, (double*)(base + L.X3), (double*)(base + L.Gns), k, n);
     if (rc) return rc;
@@ -2250,8 +2272,9 @@ int tnh_svd_band_work_bytes(int dtype, int64_t m, int64_t n, int64_t kcap, size_
 int tnh_svd_band_layout(int dtype, int64_t m, int64_t n, int64_t kcap, int64_t* offsets, int count) {
   TNH_REQUIRE(offsets != nullptr && count >= 12, "tnh_svd_band_layout: need room for 12 offsets");
   const Layout L = make_layout(m, n, kcap > 4 ? kcap : 4, dtype == TNH_F64 ? 8 : 4);
-  const size_t o[12] = {L.Af, L.Vl, L.Vr, L.Tl, L.Tr, L.Dblk, L.Eblk, L.Bd, L.Tb, L.lo, L.hi, L.X};
-  for (int i = 0; i < 12; ++i) offsets[i] = (int64_t)o[i];
+  const size_t o[16] = {L.Af, L.Vl, L.Vr, L.Tl, L.Tr, L.Dblk, L.Eblk, L.Bd, L.Tb, L.lo, L.hi, L.X, L.shifts, L.status, L.X2,
+                        L.Gns};
+  for (int i = 0; i < count && i < 16; ++i) offsets[i] = (int64_t)o[i];
   return TNH_OK;
 }
 
