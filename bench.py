@@ -389,6 +389,36 @@ def check_svd_case(mat_host, s_ref, n, k, outputs):
           "recon_minus_best_over_normA": rec_excess, "ok": bool(ok)}
 
 
+def svd_bound(m, n, k, itemsize=4):
+  """What bounds the band SVD (tnh_svd_band.hip) of an m x n matrix keeping k triplets -- NOT the metric's
+  algorithmic bytes (75.5 MB at 4096^2: 9 us of HBM time).  Counted from the algorithm:
+    launches       dependent kernel launches: 10 per 16-wide panel pair of stage 1 (f64 input: 14, two Cholesky-QR
+                   passes), ~40 for the spectrum slicing, ~12 for the vectors;  floor = 4.5 us each back to back;
+    update_bytes   the rank-16 streaming updates read the trailing block once for W = V^T C and read + write it for
+                   C -= V W, for the column and for the row panel: 6 x itemsize x sum_p (m - 16 p)(n - 16 p);
+                   floor at the 6.3 TB/s a copy reaches on this part;
+    sturm_fma      f64 FMAs of the Sturm counts: 139 per pivot, n pivots per shift, 65536 + 15 n shifts for all values
+                   (f64 input: three more rounds) + 3 x 15 k for the kept ones; this chip issues one 64-lane v_fma_f64
+                   per SIMD every 8 cycles: floor = FMAs / 64 x 8 cycles / (1024 SIMDs x 2.4 GHz).
+  The three floors add up (the stages are dependent): that sum is the `floor_s` the measured time is compared with."""
+  npanels = n // 16
+  f64 = itemsize == 8
+  launches = (14 if f64 else 10) * npanels + 40 + (12 if f64 else 0) + 12
+  tail = sum((m - 16 * p) * (n - 16 * p) for p in range(npanels))
+  update_bytes = 6.0 * itemsize * tail
+  rounds_all = 1 + (3 if f64 else 0)
+  shifts = 65536 + rounds_all * 15 * n + (6 if f64 else 3) * 15 * k
+  sturm_fma = 139.0 * n * shifts
+  launch_floor = launches * 4.5e-6
+  update_floor = update_bytes / 6.3e12
+  sturm_floor = sturm_fma / 64.0 * 8.0 / (1024 * 2.4e9)
+  return {"launches": launches, "launch_floor_s": launch_floor, "update_bytes": update_bytes,
+          "update_floor_s": update_floor, "sturm_f64_fma": sturm_fma, "sturm_floor_s": sturm_floor,
+          "floor_s": launch_floor + update_floor + sturm_floor,
+          "note": "dependent-launch floor + rank-16 update traffic at copy rate + f64 Sturm counts at the vector pipe's "
+                  "issue rate; the metric's algorithmic bytes would take microseconds"}
+
+
 def svd_sweep(ta, be, n_max, verify):
   """configs[2] in full: inputs (i) Gaussian and (ii) s_i = 2^(-i/32), natural and mixed edge order,
   n in {512, 1024, 2048, 4096} up to n_max, keep n / 16; each case timed (second call) in seconds and the metric's
@@ -424,6 +454,8 @@ def svd_sweep(ta, be, n_max, verify):
   headline = dict(headline or rows[-1])
   headline["workload"] = (f"split_node of a rank-6 f32 node as {headline['n']}x{headline['n']}, "
                           f"max_singular_values={headline['k']} (Gaussian, natural order; second call)")
+  headline["bound"] = svd_bound(headline["n"], headline["n"], headline["k"])
+  headline["frac_of_floor"] = headline["bound"]["floor_s"] / headline["seconds"]
   headline["note"] = ("min(m, n) >= 1024: band reduction (Cholesky-QR panels, rank-16 streaming updates) + spectrum "
                       "slicing on T = B^T B in f64 + inverse iteration + back-transformation (tnh_svd_band.hip); "
                       "smaller: block one-sided Jacobi.  Bound by dependent small kernels and f64 VALU, not by the "
@@ -1031,7 +1063,7 @@ def compact_line(result, detail_name):
               [_num(r.get("seconds")), "b" if str(r.get("path", "")).startswith("band") else "j"]
       line["svd"]["seconds_by_case"] = rows
       if isinstance(svd.get("bound"), dict):
-        line["svd"]["bound"] = _pick(svd["bound"], ("launches", "launch_floor_s", "update_bytes", "update_floor_s"))
+        line["svd"]["bound"] = _pick(svd["bound"], ("launches", "launch_floor_s", "update_floor_s", "sturm_floor_s", "floor_s"))
       if isinstance(svd.get("cpu_baseline"), dict):
         line["svd"]["cpu_gbps"] = _num(svd["cpu_baseline"].get("value"))
   line["sliced_network"] = _pick(result.get("sliced_network"),

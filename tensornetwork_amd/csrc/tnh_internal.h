@@ -100,8 +100,8 @@ __device__ __forceinline__ T wave_sum(T v) {
 // K9 fast path (f32, m >= n, n % 16 == 0): 16-wide panels factored by the band SVD's panel kernels (tnh_svd_band.hip).
 // *status_host != 0: a panel was numerically rank-deficient, the caller must use the column-by-column path.
 bool qr_panel16_supported(int dtype, int64_t m, int64_t n);
-size_t qr_panel16_work_bytes(int64_t m, int64_t n);
-int qr_panel16(int64_t m, int64_t n, const float* A, float* Q, float* R, void* work, int* status_host);
+size_t qr_panel16_work_bytes(int dtype, int64_t m, int64_t n);
+int qr_panel16(int dtype, int64_t m, int64_t n, const void* A, void* Q, void* R, void* work, int* status_host);
 
 struct DimVec {
   int64_t v[TNH_MAX_RANK];

@@ -541,7 +541,7 @@ int tnh_qr_work_bytes(int dtype, int64_t m, int64_t n, size_t* nbytes) {
   TNH_REQUIRE(m >= 0 && n >= 0, "negative extent");
   size_t need = qr_layout(nullptr, dtype_size(dtype), m, n).total + 256;
   if (qr_panel16_supported(dtype, m, n)) {
-    const size_t fast = qr_panel16_work_bytes(m, n);
+    const size_t fast = qr_panel16_work_bytes(dtype, m, n);
     if (fast > need) need = fast;
   }
   *nbytes = need;
@@ -564,7 +564,7 @@ int tnh_qr(int dtype, int64_t m, int64_t n, const void* A, void* Q, void* R, voi
     // status word read back by the host (one stream synchronisation per call: tnh.h says so), which is illegal while
     // the stream is being captured into a hipGraph -- a captured QR takes the column path
     int st = 0;
-    const int rc = qr_panel16(m, n, (const float*)A, (float*)Q, (float*)R, work, &st);
+    const int rc = qr_panel16(dtype, m, n, A, Q, R, work, &st);
     if (rc != TNH_OK) return rc;
     if (st == 0) return TNH_OK;
   }

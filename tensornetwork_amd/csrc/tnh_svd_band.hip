@@ -2138,92 +2138,108 @@ static int vectors(const Layout& L, char* base, int64_t m, int64_t n, int64_t k,
 // stage 1 -- Gram partials, one-workgroup factor, V rows, rank-16 update -- and Q = H_0 ... H_(np-1) [I; 0] by the
 // column-owning back-transformation.  Same reflector sign rule as LAPACK's geqrf (S_jj = -sign of the pivot
 // candidate), so R matches np.linalg.qr.  16 launches per 16 columns instead of K9's ~30 per column.
-__global__ __launch_bounds__(256) void qr_out_kernel(const float* __restrict__ Af, const double* __restrict__ Dblk,
-                                                     int64_t m, int64_t n, float* __restrict__ R,
-                                                     float* __restrict__ Q) {
+template <typename T>
+__global__ __launch_bounds__(256) void qr_out_kernel(const T* __restrict__ Af, const double* __restrict__ Dblk,
+                                                     int64_t m, int64_t n, T* __restrict__ R, T* __restrict__ Q) {
   const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (e < n * n) {                       // R (n x n): diagonal blocks from the factor kernel, the rest from Af
     const int64_t i = e / n, c = e % n;
     const int64_t p = i / 16;
-    float v = 0.f;
+    T v = T(0);
     if (c >= 16 * (p + 1)) v = Af[i * n + c];
-    else if (c >= i) v = (float)Dblk[p * 256 + (i - 16 * p) * 16 + (c - 16 * p)];
+    else if (c >= i) v = (T)Dblk[p * 256 + (i - 16 * p) * 16 + (c - 16 * p)];
     R[e] = v;
   }
-  if (e < m * n) Q[e] = (e / n == e % n) ? 1.f : 0.f;       // thin identity, transformed afterwards
+  if (e < m * n) Q[e] = (e / n == e % n) ? T(1) : T(0);       // thin identity, transformed afterwards
 }
 
-static int qr_f32(int64_t m, int64_t n, const float* A, float* Q, float* R, char* base, int* status_host) {
-  const Layout L = make_layout(m, n, 4, 4);
-  float* Af = (float*)(base + L.Af);
+// T = float (round 3) or double (round 4: two Cholesky-QR passes per panel, as in the f64 band reduction)
+template <typename T>
+static int qr_panels(int64_t m, int64_t n, const T* A, T* Q, T* R, char* base, int* status_host) {
+  constexpr bool QR2 = sizeof(T) == 8;
+  constexpr int WRC = w_rc<T>();
+  const Layout L = make_layout(m, n, 4, (int)sizeof(T));
+  T* Af = (T*)(base + L.Af);
   double* Gc = (double*)(base + L.Gpart);
+  double* Gq = (double*)(base + L.Gq);
+  double* R1 = (double*)(base + L.R1);
+  double* R1inv = (double*)(base + L.R1inv);
   double* Xb = (double*)(base + L.Xbuf);
-  float* Wpart = (float*)(base + L.Wpart);
-  float* Wt = (float*)(base + L.Wt);
+  T* Wpart = (T*)(base + L.Wpart);
+  T* Wt = (T*)(base + L.Wt);
   int* status = (int*)(base + L.status);
-  TNH_HIP(hipMemcpyAsync(Af, A, (size_t)m * n * 4, hipMemcpyDeviceToDevice, stream()));
+  TNH_HIP(hipMemcpyAsync(Af, A, (size_t)m * n * sizeof(T), hipMemcpyDeviceToDevice, stream()));
   TNH_HIP(hipMemsetAsync(status, 0, 64, stream()));
   const int64_t np = L.np;
   int parts = (int)((m + 255) / 256);
-  hipLaunchKernelGGL((gram_kernel<false, float>), dim3(parts), dim3(256), 0, stream(), (const float*)Af, n, m, Gc);
+  hipLaunchKernelGGL((gram_kernel<false, T>), dim3(parts), dim3(256), 0, stream(), (const T*)Af, n, m, Gc);
   for (int64_t p = 0; p < np; ++p) {
     const int64_t j = 16 * p, mj = m - j, nc = n - j - 16;
-    const float* P = Af + j * n + j;
-    float* V = (float*)(base + L.Vl) + vl_offset(m, p);
+    T* P = Af + j * n + j;
+    T* V = (T*)(base + L.Vl) + vl_offset(m, p);
     double* Tp = (double*)(base + L.Tl) + p * 256;
-    hipLaunchKernelGGL((factor_kernel<false, float>), dim3(1), dim3(256), 0, stream(), P, n, mj, (const double*)Gc, parts,
-                       Xb, V, (float*)nullptr, (int64_t)0, Tp, (double*)(base + L.Dblk) + p * 256, (const double*)nullptr,
-                       1e-9, status);
+    if (QR2) {
+      const int qparts = (int)((mj + 255) / 256);
+      hipLaunchKernelGGL(chol_kernel, dim3(1), dim3(64), 0, stream(), (const double*)Gc, parts, R1, R1inv, status);
+      hipLaunchKernelGGL((scaleq_kernel<false, T>), dim3(qparts), dim3(256), 0, stream(), P, n, mj, (const double*)R1inv, Gq);
+      hipLaunchKernelGGL((factor_kernel<false, T>), dim3(1), dim3(256), 0, stream(), (const T*)P, n, mj, (const double*)Gq,
+                         qparts, Xb, V, (T*)nullptr, (int64_t)0, Tp, (double*)(base + L.Dblk) + p * 256,
+                         (const double*)R1, 1e-3, status);
+    } else {
+      hipLaunchKernelGGL((factor_kernel<false, T>), dim3(1), dim3(256), 0, stream(), (const T*)P, n, mj, (const double*)Gc,
+                         parts, Xb, V, (T*)nullptr, (int64_t)0, Tp, (double*)(base + L.Dblk) + p * 256,
+                         (const double*)nullptr, 1e-9, status);
+    }
     if (mj > 16)
-      hipLaunchKernelGGL((formv_kernel<false, float>), dim3((unsigned)((mj - 16 + 255) / 256)), dim3(256), 0, stream(), P, n, mj,
-                         (const double*)Xb, V, (float*)nullptr, (int64_t)0);
+      hipLaunchKernelGGL((formv_kernel<false, T>), dim3((unsigned)((mj - 16 + 255) / 256)), dim3(256), 0, stream(),
+                         (const T*)P, n, mj, (const double*)Xb, V, (T*)nullptr, (int64_t)0);
     if (nc > 0) {
-      float* C = Af + j * n + j + 16;
-      const int chunks = (int)((mj + w_rc<float>() - 1) / w_rc<float>());
-      hipLaunchKernelGGL((wpass_kernel<float>), dim3((unsigned)((nc + 63) / 64), chunks), dim3(256), 0, stream(), (const float*)C,
-                         n, mj, nc, (const float*)V, Wpart);
-      hipLaunchKernelGGL((wreduce_kernel<float>), dim3((unsigned)((nc + 63) / 64)), dim3(256), 0, stream(), (const float*)Wpart,
+      T* C = Af + j * n + j + 16;
+      const int chunks = (int)((mj + WRC - 1) / WRC);
+      hipLaunchKernelGGL((wpass_kernel<T>), dim3((unsigned)((nc + 63) / 64), chunks), dim3(256), 0, stream(), (const T*)C,
+                         n, mj, nc, (const T*)V, Wpart);
+      hipLaunchKernelGGL((wreduce_kernel<T>), dim3((unsigned)((nc + 63) / 64)), dim3(256), 0, stream(), (const T*)Wpart,
                          chunks, nc, (const double*)Tp, 1, Wt);
       // the update leaves the partial Grams of the next panel: first 16 columns of the block, rows 16 .. (the first
       // 16 rows are R)
       const dim3 grid((unsigned)((nc + 63) / 64), (unsigned)((mj + U_RR - 1) / U_RR));
-      hipLaunchKernelGGL((update_kernel<1, float>), grid, dim3(256), 0, stream(), C, n, mj, nc, (const float*)V,
-                         (const float*)Wt, nc, Gc, (int64_t)16);
+      hipLaunchKernelGGL((update_kernel<1, T>), grid, dim3(256), 0, stream(), C, n, mj, nc, (const T*)V,
+                         (const T*)Wt, nc, Gc, (int64_t)16);
       parts = (int)grid.y;
     }
     TNH_LAUNCH_CHECK();
   }
   const int64_t ne = m * n;
-  hipLaunchKernelGGL(qr_out_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, stream(), (const float*)Af,
+  hipLaunchKernelGGL((qr_out_kernel<T>), dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, stream(), (const T*)Af,
                      (const double*)(base + L.Dblk), m, n, R, Q);
   TNH_LAUNCH_CHECK();
   // ---- Q = H_0 ... H_(np-1) [I; 0]
-  const size_t lds = (size_t)m * BT_COLS * sizeof(float);
+  const size_t lds = (size_t)m * BT_COLS * sizeof(T);
   if (lds <= 150 * 1024) {
     static bool attr_done = false;
     if (!attr_done) {
-      TNH_HIP(hipFuncSetAttribute((const void*)backtransform_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize,
+      TNH_HIP(hipFuncSetAttribute((const void*)backtransform_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   150 * 1024));
       attr_done = true;
     }
-    BtArgs<float> a;
-    a.side[0] = BtSide<float>{Q, n, m, (const float*)(base + L.Vl), (const double*)(base + L.Tl), np, (int64_t)0, m, 1};
+    BtArgs<T> a;
+    a.side[0] = BtSide<T>{Q, n, m, (const T*)(base + L.Vl), (const double*)(base + L.Tl), np, (int64_t)0, m, 1};
     a.side[1] = a.side[0];
-    hipLaunchKernelGGL((backtransform_kernel<float>), dim3((unsigned)(n / BT_COLS), 1), dim3(BT_THREADS), lds, stream(), a);
+    hipLaunchKernelGGL((backtransform_kernel<T>), dim3((unsigned)(n / BT_COLS), 1), dim3(BT_THREADS), lds, stream(), a);
   } else {
     // very tall inputs: the columns do not fit in LDS -- per panel W = V^T Q, W <- T W, Q -= V W (last panel first)
     for (int64_t p = np - 1; p >= 0; --p) {
       const int64_t j = 16 * p, mj = m - j;
-      const float* V = (const float*)(base + L.Vl) + vl_offset(m, p);
-      float* C = Q + j * n + j;               // columns before j are untouched by panel p (identity start)
+      const T* V = (const T*)(base + L.Vl) + vl_offset(m, p);
+      T* C = Q + j * n + j;               // columns before j are untouched by panel p (identity start)
       const int64_t kc = n - j;
-      const int chunks = (int)((mj + w_rc<float>() - 1) / w_rc<float>());
-      hipLaunchKernelGGL((wpass_kernel<float>), dim3((unsigned)((kc + 63) / 64), chunks), dim3(256), 0, stream(), (const float*)C,
+      const int chunks = (int)((mj + WRC - 1) / WRC);
+      hipLaunchKernelGGL((wpass_kernel<T>), dim3((unsigned)((kc + 63) / 64), chunks), dim3(256), 0, stream(), (const T*)C,
                          n, mj, kc, V, Wpart);
-      hipLaunchKernelGGL((wreduce_kernel<float>), dim3((unsigned)((kc + 63) / 64)), dim3(256), 0, stream(), (const float*)Wpart,
+      hipLaunchKernelGGL((wreduce_kernel<T>), dim3((unsigned)((kc + 63) / 64)), dim3(256), 0, stream(), (const T*)Wpart,
                          chunks, kc, (const double*)(base + L.Tl) + p * 256, 0, Wt);
-      hipLaunchKernelGGL((update_kernel<0, float>), dim3((unsigned)((kc + 63) / 64), (unsigned)((mj + U_RR - 1) / U_RR)),
-                         dim3(256), 0, stream(), C, n, mj, kc, V, (const float*)Wt, kc, (double*)nullptr, (int64_t)0);
+      hipLaunchKernelGGL((update_kernel<0, T>), dim3((unsigned)((kc + 63) / 64), (unsigned)((mj + U_RR - 1) / U_RR)),
+                         dim3(256), 0, stream(), C, n, mj, kc, V, (const T*)Wt, kc, (double*)nullptr, (int64_t)0);
     }
   }
   TNH_LAUNCH_CHECK();
@@ -2238,12 +2254,16 @@ static int qr_f32(int64_t m, int64_t n, const float* A, float* Q, float* R, char
 bool qr_panel16_supported(int dtype, int64_t m, int64_t n) {
   const char* e = getenv("TNH_QR_PANEL16");
   if (e && e[0] == '0') return false;
-  return dtype == TNH_F32 && m >= n && n >= 64 && (n % 16) == 0;
+  return (dtype == TNH_F32 || dtype == TNH_F64) && m >= n && n >= 64 && (n % 16) == 0;
 }
-size_t qr_panel16_work_bytes(int64_t m, int64_t n) { return svdb::make_layout(m, n, 4, 4).total + 256; }
-int qr_panel16(int64_t m, int64_t n, const float* A, float* Q, float* R, void* work, int* status_host) {
+size_t qr_panel16_work_bytes(int dtype, int64_t m, int64_t n) {
+  return svdb::make_layout(m, n, 4, dtype == TNH_F64 ? 8 : 4).total + 256;
+}
+int qr_panel16(int dtype, int64_t m, int64_t n, const void* A, void* Q, void* R, void* work, int* status_host) {
   char* base = (char*)(((uintptr_t)work + 255) & ~(uintptr_t)255);
-  return svdb::qr_f32(m, n, A, Q, R, base, status_host);
+  if (dtype == TNH_F64)
+    return svdb::qr_panels<double>(m, n, (const double*)A, (double*)Q, (double*)R, base, status_host);
+  return svdb::qr_panels<float>(m, n, (const float*)A, (float*)Q, (float*)R, base, status_host);
 }
 }  // namespace tnh
 
