@@ -1388,13 +1388,24 @@ class HipBackend(BackendBase):
     if done is None:
       return None
     ur, sr, vrh, sr_rest = done                              # (2m, 2k), (2k,), (2k, 2n), (2r - 2k,)
-    s_all = np.concatenate([np.asarray(sr, dtype=np.float64), np.asarray(sr_rest, dtype=np.float64)])
-    s_c = 0.5 * (s_all[0::2] + s_all[1::2])                  # r complex singular values
+
+    def pair_mean(x):                                        # every complex value appears twice: mean of each pair
+      if x.shape[0] == 0:
+        return x
+      return self._binary(_lib.OP_MUL, self._binary(_lib.OP_ADD, self.getitem(x, slice(0, None, 2)),
+                                                    self.getitem(x, slice(1, None, 2))), 0.5)
+
     keep = kmax
+    s_kept_dev, s_rest_dev = pair_mean(sr), pair_mean(sr_rest)        # (kmax,), (r - kmax,): on the device
     if max_truncation_error is not None:
+      # the truncation rule needs the values on the host (decompositions.py:38-57), as on every path
+      s_c = np.concatenate([np.asarray(s_kept_dev, dtype=np.float64), np.asarray(s_rest_dev, dtype=np.float64)])
       trunc_errs = np.sqrt(np.cumsum(np.square(s_c[::-1])))
       abs_err = max_truncation_error * (s_c[0] if r else 0.0) if relative else max_truncation_error
       keep = int(min(kmax, int(np.count_nonzero(trunc_errs > abs_err)), r))
+      if keep != kmax:
+        s_all_dev = self.convert_to_tensor(s_c.astype(rnp))
+        s_kept_dev, s_rest_dev = self.getitem(s_all_dev, slice(0, keep)), self.getitem(s_all_dev, slice(keep, r))
     if keep <= 0:
       return None
     k2 = 2 * keep
@@ -1410,27 +1421,31 @@ class HipBackend(BackendBase):
     zu = as_complex(ur, m, k2, 2 * kmax)                     # candidates for U: m x 2k (first 2 keep columns)
     vr = self.transpose(vrh, (1, 0))                         # (2n, 2k)
     zv = as_complex(vr, n, k2, 2 * kmax)
-    # k independent complex directions among the 2k candidates, from the (2k x 2k) Gram matrix on the host.  Distinct
-    # complex singular values: the two real vectors of a pair span ONE complex line, so the even-numbered candidates
-    # are independent and a Cholesky factor orthonormalises them; otherwise (larger clusters) greedy Gram-Schmidt.
-    g = np.asarray(self._tensordot_impl(self.conj(zu), zu, [[0], [0]], None, None)[0]).astype(np.complex128)
-    coef = np.zeros((k2, keep), dtype=np.complex128)
-    basis = None
-    try:
-      ge = g[0::2, 0::2]
-      if np.linalg.eigvalsh(ge)[0] > 0.25:
-        linv = np.linalg.inv(np.linalg.cholesky(ge))            # G_ee = L L^H; columns of Z_e L^-H are orthonormal
-        coef[0::2, :] = linv.conj().T
-        basis = True
-    except np.linalg.LinAlgError:
-      basis = None
-    if basis is None:
+    # k independent complex directions among the 2k candidates.  The two real vectors of a pair span ONE complex
+    # line and different pairs are orthogonal, so the even-numbered candidates Z_e are orthonormal up to the real
+    # path's own error; one Newton-Schulz step  Z_e (1.5 I - 0.5 Z_e^H Z_e)  on the DEVICE polishes them (round 4: no
+    # host LAPACK in this path any more), and the same coefficients go onto the right vectors, so that A V = U S holds
+    # without a division.  The one read-back is the check at the end: |Z_e^H Z_e - I| -- large only when a complex
+    # value is itself degenerate (real clusters of four and more, where the even candidates can be dependent).
+    even = (slice(None), slice(0, k2, 2))
+    zue, zve = self.getitem(zu, even), self.getitem(zv, even)
+    eye = self.eye(keep, dtype=cnp)
+    gram = self._tensordot_impl(self.conj(zue), zue, [[0], [0]], None, None)[0]           # keep x keep
+    dev = float(np.asarray(self.norm(self._binary(_lib.OP_SUB, gram, eye))).real)
+    if np.isfinite(dev) and dev < 0.1:
+      coef_dev = self._binary(_lib.OP_SUB, self._binary(_lib.OP_MUL, eye, 1.5), self._binary(_lib.OP_MUL, gram, 0.5))
+      u = self._tensordot_impl(zue, coef_dev, [[1], [0]], None, None)[0]                  # m x keep
+      v = self._tensordot_impl(zve, coef_dev, [[1], [0]], None, None)[0]                  # n x keep
+    else:
+      # degenerate complex values: greedy Gram-Schmidt over all 2k candidates on the (2k x 2k) Gram matrix (host
+      # arithmetic on a small matrix; the rare path)
+      g = np.asarray(self._tensordot_impl(self.conj(zu), zu, [[0], [0]], None, None)[0]).astype(np.complex128)
       basis = []                                               # coefficient vectors c with (Zu c) orthonormal
       for j in range(k2):
         c = np.zeros(k2, dtype=np.complex128)
         c[j] = 1.0
-        for b in basis:
-          c = c - b * (b.conj() @ g @ c)
+        for bvec in basis:
+          c = c - bvec * (bvec.conj() @ g @ c)
         nrm2 = float(np.real(c.conj() @ g @ c))
         if nrm2 > 0.25:
           basis.append(c / np.sqrt(nrm2))
@@ -1438,13 +1453,11 @@ class HipBackend(BackendBase):
             break
       if len(basis) < keep:
         return None
-      coef[:, :] = np.stack(basis, axis=1)
-    cdev = self.convert_to_tensor(coef.astype(cnp))
-    u = self._tensordot_impl(zu, cdev, [[1], [0]], None, None)[0]               # m x keep
-    v = self._tensordot_impl(zv, cdev, [[1], [0]], None, None)[0]               # n x keep
+      cdev = self.convert_to_tensor(np.stack(basis, axis=1).astype(cnp))
+      u = self._tensordot_impl(zu, cdev, [[1], [0]], None, None)[0]               # m x keep
+      v = self._tensordot_impl(zv, cdev, [[1], [0]], None, None)[0]               # n x keep
     vh = self.conj(self.transpose(v, (1, 0)))
-    s_dev = self.convert_to_tensor(s_c[:keep].astype(rnp))
-    s_rest = self.convert_to_tensor(s_c[keep:].astype(rnp))
+    s_dev, s_rest = s_kept_dev, s_rest_dev
     self.last_svd_path = "band (complex via the real embedding)"
     return u, s_dev, vh, s_rest
 

@@ -1,7 +1,8 @@
 """A few band SVD calls for rocprofv3 --kernel-trace --stats (f32 and f64, 4096^2 keep 256)."""
 import sys
 import numpy as np
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import tensornetwork_amd as ta
 be = ta.get_hip_backend()
 which = sys.argv[1] if len(sys.argv) > 1 else "f32"
