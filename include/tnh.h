@@ -319,8 +319,8 @@ int tnh_svd_vectors_topk(int dtype, int64_t m, int64_t n, const void* A,
  *            caller re-runs tnh_svd_factor: 1 rank-deficient panel, 2 (unused), 4 clustered kept values,
  *            8 band residual, 16 a kept value below 1e-6 of the largest.
  * dtype TNH_F32 or TNH_F64 (round 4; A, U, Vh, S, S_kept in that type).  The f64 form runs the same stages with
- * two Cholesky-QR passes per panel (the Gram matrix of an f64 panel carries eps64 cond^2), every value to 32 bits
- * (discarded values good to 1.2e-10 s_1; TNH_SVDB_BITS64), kept brackets to 2^-44 s_1, one Newton-Schulz step on the
+ * two Cholesky-QR passes per panel (the Gram matrix of an f64 panel carries eps64 cond^2), every value to 28 bits
+ * (discarded values good to 2e-9 s_1 where T = B^T B resolves them; TNH_SVDB_BITS64), kept brackets to 2^-44 s_1, one Newton-Schulz step on the
  * kept right and left band vectors (two f64 GEMMs each), and returns the kept VALUES as Rayleigh quotients |B v|;
  * status bit 16 there means a kept value below 1e-5 s_1 (the vectors of smaller values lose eps64 (s_1 / s)^2 / gap
  * on T = B^T B).

@@ -410,16 +410,13 @@ __global__ __launch_bounds__(256) void factor_kernel(const T* __restrict__ P, in
 // -- invisible; f64 input: visible from cond ~ 30 on).  The second pass factors Q1 = P R1^-1, whose Gram matrix is
 // I + O(eps64 cond^2): its Cholesky-QR is accurate to eps64 as long as eps64 cond^2 << 1 (pivots below 1e-13 of the
 // largest are reported: cond > 3e6).
-__global__ __launch_bounds__(64) void chol_kernel(const double* __restrict__ Gpart, int nparts, double* __restrict__ R1,
-                                                  double* __restrict__ R1inv, int* __restrict__ status) {
+__global__ __launch_bounds__(256) void chol_kernel(const double* __restrict__ Gpart, int nparts, double* __restrict__ R1,
+                                                   double* __restrict__ R1inv, int* __restrict__ status) {
   __shared__ double G[16][17];
   const int tid = threadIdx.x, r = tid & 15;
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const int t = tid + 64 * e;
-    G[t >> 4][t & 15] = gram_sum(Gpart, nparts, t);
-  }
+  G[tid >> 4][tid & 15] = gram_sum(Gpart, nparts, tid);      // one entry per thread: all partials in flight at once
   __syncthreads();
+  if (tid >= 64) return;
   double Gr[16], Rr[16], x[16];
 #pragma unroll
   for (int k = 0; k < 16; ++k) Gr[k] = G[r][k];
@@ -544,11 +541,15 @@ __global__ __launch_bounds__(256) void formv_kernel(const T* __restrict__ P, int
 // Wpart[chunk][i][c] = sum over the chunk's RC rows of V[r][i] C[r][c]       (W = V^T C, partial over row chunks)
 // The chunk's V rows are staged once in LDS (every lane group reads whole rows: broadcast reads); the C loads of
 // four 16-row steps are requested before the first FMA.
-constexpr int W_UNROLL = 4;
+template <typename T>
+constexpr int w_unroll() {
+  return sizeof(T) == 4 ? 4 : 2;      // C rows requested ahead per lane (f64: 64 accumulator + 8 load doubles per step of two)
+}
 template <typename T>
 __global__ __launch_bounds__(256) void wpass_kernel(const T* __restrict__ C, int64_t ldc, int64_t rows, int64_t nc,
                                                     const T* __restrict__ V, T* __restrict__ Wpart) {
   constexpr int RC = w_rc<T>();
+  constexpr int W_UNROLL = w_unroll<T>();
   __shared__ V4<T> vs[RC][4];       // V rows of the chunk
   __shared__ T red[4][16][65];      // [wave][i][column]
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, t = lane & 15;
@@ -1754,7 +1755,7 @@ static bool g_lane = true;       // counts through sturm_lane_kernel (TNH_SVDB_L
 //   bits at once, one 16-way section round per value adds 4 (bracket 1e-6 sigma_max: s_rest is good to 5e-7);
 //   kept values: g_refine_rounds 16-way rounds on the 16-lane kernel (a few thousand shifts: latency 0.8 ms instead
 //   of the lane kernel's 3 ms) take their brackets to 2^-32 sigma_max so that inverse iteration separates neighbours.
-//   f64 input: every value to g_bits64 bits (default 32: s_rest good to 1.2e-10 sigma_max; three more lane rounds),
+//   f64 input: every value to g_bits64 bits (default 28: s_rest good to 2e-9 sigma_max; two more lane rounds),
 //   kept values to 2^-44 sigma_max (three more 16-lane rounds) -- beyond that the un-pivoted LDL^T of the band does not
 //   resolve (eps64 n |T| / 2 sigma); the kept VALUES then come from the Rayleigh quotient |B x| of their vectors.
 static int g_grid_mult = 16;
@@ -1762,7 +1763,7 @@ static int g_sect_p = 15;
 static int g_sect_rounds = 1;
 static int g_refine_p = 15;
 static int g_refine_rounds = 3;
-static int g_bits64 = 32;
+static int g_bits64 = 28;
 static bool g_ns64 = true;      // f64 input: Newton-Schulz step on the kept band vectors (TNH_SVDB_NS=0: off, diagnostics)
 
 static void read_env() {
@@ -1783,7 +1784,7 @@ static void read_env() {
   g_sect_rounds = g_lane ? 1 : 5;
   g_refine_p = 15;
   g_refine_rounds = 3;
-  g_bits64 = 32;
+  g_bits64 = 28;
   e = getenv("TNH_SVDB_GRID");
   if (e && atoi(e) > 0) g_grid_mult = atoi(e);
   e = getenv("TNH_SVDB_SECT");
@@ -1875,7 +1876,7 @@ static int stage1(const Layout& L, char* base, int64_t m, int64_t n) {
       double* Tp = (double*)(base + L.Tl) + p * 256;
       if (QR2) {
         const int qparts = (int)((mj + 255) / 256);
-        hipLaunchKernelGGL(chol_kernel, dim3(1), dim3(64), 0, stream(), (const double*)Gc, parts_c, R1, R1inv, status);
+        hipLaunchKernelGGL(chol_kernel, dim3(1), dim3(256), 0, stream(), (const double*)Gc, parts_c, R1, R1inv, status);
         hipLaunchKernelGGL((scaleq_kernel<false, T>), dim3(qparts), dim3(256), 0, stream(), P, n, mj,
                            (const double*)R1inv, Gq);
         hipLaunchKernelGGL((factor_kernel<false, T>), dim3(1), dim3(256), 0, stream(), (const T*)P, n, mj,
@@ -1910,7 +1911,7 @@ static int stage1(const Layout& L, char* base, int64_t m, int64_t n) {
       double* Tp = (double*)(base + L.Tr) + p * 256;
       if (QR2) {
         const int qparts = (int)((nc + 255) / 256);
-        hipLaunchKernelGGL(chol_kernel, dim3(1), dim3(64), 0, stream(), (const double*)Gr, parts_r, R1, R1inv, status);
+        hipLaunchKernelGGL(chol_kernel, dim3(1), dim3(256), 0, stream(), (const double*)Gr, parts_r, R1, R1inv, status);
         hipLaunchKernelGGL((scaleq_kernel<true, T>), dim3(qparts), dim3(256), 0, stream(), P, n, nc,
                            (const double*)R1inv, Gq);
         hipLaunchKernelGGL((factor_kernel<true, T>), dim3(1), dim3(256), 0, stream(), (const T*)P, n, nc,
@@ -2180,7 +2181,7 @@ static int qr_panels(int64_t m, int64_t n, const T* A, T* Q, T* R, char* base, i
     double* Tp = (double*)(base + L.Tl) + p * 256;
     if (QR2) {
       const int qparts = (int)((mj + 255) / 256);
-      hipLaunchKernelGGL(chol_kernel, dim3(1), dim3(64), 0, stream(), (const double*)Gc, parts, R1, R1inv, status);
+      hipLaunchKernelGGL(chol_kernel, dim3(1), dim3(256), 0, stream(), (const double*)Gc, parts, R1, R1inv, status);
       hipLaunchKernelGGL((scaleq_kernel<false, T>), dim3(qparts), dim3(256), 0, stream(), P, n, mj, (const double*)R1inv, Gq);
       hipLaunchKernelGGL((factor_kernel<false, T>), dim3(1), dim3(256), 0, stream(), (const T*)P, n, mj, (const double*)Gq,
                          qparts, Xb, V, (T*)nullptr, (int64_t)0, Tp, (double*)(base + L.Dblk) + p * 256,

@@ -286,7 +286,7 @@ def test_band_svd_kept_values_keep_their_relative_accuracy(hip):
 # ---- round 4: float64 (and complex128 through it) on the band path ------------------------------------------------------
 def check_svd64(a, u, s, vh, s_rest, k, tag="", tol_s=1e-11, tol_rest=3e-8, tol_orth=1e-9, tol_res=2e-10):
   """f64 band path vs LAPACK.  Stated tolerances: kept values 1e-11 s_0 (Rayleigh quotients on
-  the band), DISCARDED values 3e-8 s_0 -- brackets of 32 bits (2e-10 s_0) where the un-pivoted LDL^T of T = B^T B
+  the band), DISCARDED values 3e-8 s_0 -- brackets of 28 bits (2e-9 s_0) where the un-pivoted LDL^T of T = B^T B
   resolves them, and a floor of sqrt(eps64) s_0 ~ 1.5e-8 s_0 below which T = B^T B cannot tell a value from zero
   (measured: 1.5e-9 on Gaussian input, 1.6e-8 on the tail of a graded one) --, orthonormality 1e-9, triplet residual
   |A v - s u| <= 2e-10 s_0."""
@@ -319,7 +319,7 @@ def graded64(m, n, seed, rate=32.0):
                                         ("gauss", 1024, 2048, 128), ("graded", 1000, 1100, 50)])
 def test_band_svd_float64(hip, kind, m, n, k):
   """The reference's default dtype (ncon_interface_test.py:39-43, base_mps.py) on the band path: f64 panels by two
-  Cholesky-QR passes, values to 32 bits, kept values as Rayleigh quotients, one Newton-Schulz step on the kept
+  Cholesky-QR passes, values to 28 bits, kept values as Rayleigh quotients, one Newton-Schulz step on the kept
   vectors."""
   a = np.random.default_rng(m + n + k).standard_normal((m, n)) if kind == "gauss" else graded64(m, n, seed=m + n + k)
   u, s, vh, s_rest = hip.svd(hip.convert_to_tensor(a), 1, max_singular_values=k)
