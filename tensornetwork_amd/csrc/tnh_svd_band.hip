@@ -1261,13 +1261,19 @@ __global__ __launch_bounds__(256) void values_kept_kernel(const double* __restri
 // the real embedding of a complex128 matrix: collapsed pairs, status 12).  From push_rel away all copies are
 // amplified alike and different starts give independent vectors of the eigenspace, which cluster_mgs_kernel
 // orthonormalises; the neighbours outside the multiplet are >> push_rel away, so convergence is unaffected.
+// The smallest kept value is also checked against the path's range here (range_rel sigma_max): a call that keeps
+// values below it is going to be refused by uv_init_kernel anyway, and knowing it BEFORE the vector stages lets
+// cluster_mgs_kernel step aside -- numerically low-rank inputs (two-site DMRG splits) put hundreds of such values into
+// one "cluster", whose serial Gram-Schmidt took 250 ms per refused call (measured, round 4).
 __global__ __launch_bounds__(256) void vshift_kernel(const double* __restrict__ lo, const double* __restrict__ hi,
                                                      const double* __restrict__ scal, int64_t n, int64_t k,
-                                                     double push_rel, double* __restrict__ shifts) {
+                                                     double push_rel, double range_rel, double* __restrict__ shifts,
+                                                     int* __restrict__ status) {
   const int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (v >= k) return;
   const int64_t q = n - 1 - v;
   const double mid = 0.5 * (lo[q] + hi[q]), hw = 0.5 * (hi[q] - lo[q]);
+  if (v == k - 1 && !(mid > range_rel * scal[0])) atomicOr(status, (int)ST_RANGE);
   double sh = mid;
   if (push_rel > 0.0) {
     const double tol = push_rel * scal[0];
@@ -1364,6 +1370,7 @@ __global__ __launch_bounds__(1024) void cluster_mgs_kernel(double* __restrict__ 
   __shared__ double bc;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const double tol = ctol * scal[0];
+  if (*status != 0) return;        // the call is already refused (range / panel): nothing here will be used
   auto block_sum = [&](double v) -> double {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
@@ -1387,6 +1394,10 @@ __global__ __launch_bounds__(1024) void cluster_mgs_kernel(double* __restrict__ 
     // (f64 path: every member of such a run was pushed up by the same tol in vshift_kernel, the ends of a chain may
     // differ by it -- the comparison above is on the pushed values, a chain's neighbours still differ by <= tol + widths)
     if (first == v) continue;
+    if (v - first >= 256) {           // a run this long is a numerically rank-deficient block, not a multiplet: refuse
+      if (tid == 0) atomicOr(status, (int)ST_CLUSTER);      // (the serial Gram-Schmidt is quadratic in the run's length)
+      return;
+    }
     double* xv = X + v * n;
     for (int pass = 0; pass < 2; ++pass)            // "twice is enough"
       for (int64_t u = first; u < v; ++u) {
@@ -2029,7 +2040,7 @@ static int vectors(const Layout& L, char* base, int64_t m, int64_t n, int64_t k,
   }
   hipLaunchKernelGGL(vshift_kernel, dim3((unsigned)((k + 255) / 256)), dim3(256), 0, stream(),
                      (const double*)(base + L.lo), (const double*)(base + L.hi), (const double*)(base + L.scal), n, k,
-                     F64 ? g_cluster_tol64 : 0.0, (double*)(base + L.shifts));
+                     F64 ? g_cluster_tol64 : 0.0, F64 ? 1e-5 : 1e-6, (double*)(base + L.shifts), (int*)(base + L.status));
   const unsigned blocks = (unsigned)((k + 3) / 4);
   if (g_dpp) {
     hipLaunchKernelGGL((ldl_kernel<true, true>), dim3(blocks), dim3(64), 0, stream(), (const double*)(base + L.Trot), n,

@@ -161,6 +161,8 @@ class HipBackend(BackendBase):
     self.inplace_max_bytes = int(os.environ.get("TNH_VIEW_INPLACE_MAX_BYTES", str(2 << 30)))
     self.permutes_absorbed = 0   # tnh_gemm_view launches
     self.permute_launches = 0    # K1 launches (transpose)
+    self._svd_band_failed = set()      # per backend object (the class attributes below only say what they are)
+    self._svd_band_backoff = {}
 
   # the backend is a per-process singleton bound to one device: copies are the object itself
   def __copy__(self):
@@ -1186,6 +1188,7 @@ class HipBackend(BackendBase):
   last_svd_path = None
   last_svd_band_status = 0
   _svd_band_failed = set()      # tall shapes whose last band call reported a status: read it early next time
+  _svd_band_backoff = {}        # (dtype, mm, nn) -> (consecutive reports, calls still to skip)
 
   # largest inverse-iteration workspace (the stored LDL^T factors: k * min(m, n) * 128 bytes) the band path asks for
   svd_band_max_factor_bytes = 24 << 30
@@ -1263,6 +1266,15 @@ class HipBackend(BackendBase):
       s_host = np.concatenate([np.asarray(first[1], dtype=np.float64), np.asarray(first[3], dtype=np.float64)])
       return self._svd_band_core(a, mm, nn, max(pick(s_host), 0), None)
     kmax = min(int(kmax), nn)
+    # Back-off for shapes on which the path keeps reporting (round 4, measured on two-site DMRG: the splits in the
+    # middle of the chain keep values below 1e-6 s_1, every one of them paid the band stages AND the Jacobi path:
+    # 1.0 -> 1.8 s per sweep).  From the second consecutive report on (f = 2, 3, ...) a shape skips the band path
+    # min(2^f, 64) times, then tries again; one success clears it.
+    key = (a.code, mm, nn)
+    fails, skip = self._svd_band_backoff.get(key, (0, 0))
+    if skip > 0:
+      self._svd_band_backoff[key] = (fails, skip - 1)
+      return None
     kcap = nn if pick is not None else (kmax + 3) // 4 * 4
     if kmax <= 0 or kcap * nn * self._svd_band_bytes_per_vector_row(a.code) > self.svd_band_max_factor_bytes:
       return None
@@ -1280,6 +1292,7 @@ class HipBackend(BackendBase):
                                             ctypes.byref(status) if check_now else None), "tnh_svd_band_factor")
     if check_now and status.value:
       self.last_svd_band_status = status.value
+      self._svd_band_backoff[key] = (fails + 1, 0 if fails == 0 else min(2 ** (fails + 1), 64))
       return None
     keep = kmax if pick is None else int(min(pick(s_all.numpy().astype(np.float64)), nn))
     if keep <= 0:
@@ -1293,8 +1306,10 @@ class HipBackend(BackendBase):
     self.last_svd_band_status = status.value
     if status.value:
       self._svd_band_failed.add((a.code, mm, nn))
+      self._svd_band_backoff[key] = (fails + 1, 0 if fails == 0 else min(2 ** (fails + 1), 64))
       return None
     self._svd_band_failed.discard((a.code, mm, nn))
+    self._svd_band_backoff.pop(key, None)
     if kk != keep:
       uu = self.getitem(uu, (slice(None), slice(0, keep)))
       vvh = self.getitem(vvh, slice(0, keep))

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 import tensornetwork_amd as ta
-from tensornetwork_amd import contractors, workloads
+from tensornetwork_amd import _lib, contractors, workloads
 from oracle import numpy_oracle as orc
 from oracle.numpy_oracle import OracleBackend
 
@@ -536,11 +536,23 @@ def test_band_svd_host_logic_falls_back_loudly():
       assert len([c for c in be.lib.calls if c[0].startswith("svd_band")]) == n_calls, (trip, be.lib.calls)
       sr = np.linalg.svd(low.astype(np.float64), compute_uv=False)
       np.testing.assert_allclose(np.concatenate([np.asarray(s), np.asarray(rest)]), sr, atol=1e-5 * sr[0])
+    # a shape that keeps reporting backs off: after 2 reports the next min(2^2, 64) = 4 calls skip the band path
+    # altogether (two-site DMRG splits keep values below the floor on every call), then it is tried again
+    assert be._svd_band_backoff[(_lib.F32, 512, 512)] == (2, 4)      # pylint: disable=protected-access
+    for _ in range(4):
+      be.lib.calls.clear()
+      be.svd(be.convert_to_tensor(low), 1, max_singular_values=8)
+      assert be.last_svd_path == "jacobi" and not [c for c in be.lib.calls if c[0].startswith("svd_band")]
+    be.lib.calls.clear()
+    be.svd(be.convert_to_tensor(low), 1, max_singular_values=8)
+    assert len([c for c in be.lib.calls if c[0].startswith("svd_band")]) == 1      # tried again (and reported again)
     # (2) a kept value below 1e-6 s_1 (here: a full SVD of a steeply graded matrix): status 16 -> Jacobi
     be._svd_band_failed = set()      # pylint: disable=protected-access
+    be._svd_band_backoff = {}        # pylint: disable=protected-access
     u, s, vh, rest = be.svd(be.convert_to_tensor(graded), 1)
     assert be.last_svd_path == "jacobi" and s.shape == (512,) and rest.shape == (0,)
     # ... while the same matrix truncated above the floor stays on the band path
+    be._svd_band_backoff = {}        # pylint: disable=protected-access
     u, s, vh, rest = be.svd(be.convert_to_tensor(graded), 1, max_singular_values=64)
     assert be.last_svd_path == "band" and s.shape == (64,) and rest.shape == (448,)
     # (3) too small for the path, and a work buffer beyond the cap
