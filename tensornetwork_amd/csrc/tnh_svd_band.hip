@@ -543,17 +543,29 @@ __global__ __launch_bounds__(256) void formv_kernel(const T* __restrict__ P, int
 // four 16-row steps are requested before the first FMA.
 template <typename T>
 constexpr int w_unroll() {
-  return sizeof(T) == 4 ? 4 : 2;      // C rows requested ahead per lane (f64: 64 accumulator + 8 load doubles per step of two)
+  return 4;      // C rows requested ahead per lane
 }
+// columns per lane of the W pass: one 16-byte load per row (4 floats, 2 doubles) -- with 4 doubles per lane the 64
+// accumulators alone are 128 registers and the kernel ran at one wave per SIMD (38 us against 12 for float)
+template <typename T>
+constexpr int w_cpl() {
+  return 16 / (int)sizeof(T);
+}
+template <typename T, int N>
+struct alignas(sizeof(T) * N) VN {
+  T e[N];
+};
 template <typename T>
 __global__ __launch_bounds__(256) void wpass_kernel(const T* __restrict__ C, int64_t ldc, int64_t rows, int64_t nc,
                                                     const T* __restrict__ V, T* __restrict__ Wpart) {
   constexpr int RC = w_rc<T>();
   constexpr int W_UNROLL = w_unroll<T>();
+  constexpr int CPL = w_cpl<T>();
+  constexpr int TILE = 16 * CPL;    // columns per workgroup
   __shared__ V4<T> vs[RC][4];       // V rows of the chunk
-  __shared__ T red[4][16][65];      // [wave][i][column]
+  __shared__ T red[4][16][TILE + 1];      // [wave][i][column]
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, t = lane & 15;
-  const int64_t c0 = (int64_t)blockIdx.x * 64 + 4 * t;
+  const int64_t c0 = (int64_t)blockIdx.x * TILE + CPL * t;
   const int64_t rbeg = (int64_t)blockIdx.y * RC;
   const bool col_ok = c0 < nc;
   if (tid < RC) {
@@ -563,17 +575,22 @@ __global__ __launch_bounds__(256) void wpass_kernel(const T* __restrict__ C, int
     for (int q = 0; q < 4; ++q) vs[tid][q] = (r < rows) ? vp[q] : vzero<T>();
   }
   __syncthreads();
-  T acc[16][4];
+  T acc[16][CPL];
 #pragma unroll
   for (int i = 0; i < 16; ++i)
 #pragma unroll
-    for (int q = 0; q < 4; ++q) acc[i][q] = T(0);
-  for (int it0 = 0; it0 < RC / 16; it0 += W_UNROLL) {
-    V4<T> cv[W_UNROLL];
+    for (int q = 0; q < CPL; ++q) acc[i][q] = T(0);
+  auto step = [&](int it0) {
+    VN<T, CPL> cv[W_UNROLL];
 #pragma unroll
     for (int u = 0; u < W_UNROLL; ++u) {
       const int64_t r = rbeg + (it0 + u) * 16 + w * 4 + g;
-      cv[u] = (r < rows && col_ok) ? *reinterpret_cast<const V4<T>*>(C + r * ldc + c0) : vzero<T>();
+      if (r < rows && col_ok) {
+        cv[u] = *reinterpret_cast<const VN<T, CPL>*>(C + r * ldc + c0);
+      } else {
+#pragma unroll
+        for (int q = 0; q < CPL; ++q) cv[u].e[q] = T(0);
+      }
     }
 #pragma unroll
     for (int u = 0; u < W_UNROLL; ++u) {
@@ -583,37 +600,40 @@ __global__ __launch_bounds__(256) void wpass_kernel(const T* __restrict__ C, int
         const V4<T> x = vs[lr][q];
         const T ve[4] = {x.x, x.y, x.z, x.w};
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          acc[4 * q + e][0] = fmaT(ve[e], cv[u].x, acc[4 * q + e][0]);
-          acc[4 * q + e][1] = fmaT(ve[e], cv[u].y, acc[4 * q + e][1]);
-          acc[4 * q + e][2] = fmaT(ve[e], cv[u].z, acc[4 * q + e][2]);
-          acc[4 * q + e][3] = fmaT(ve[e], cv[u].w, acc[4 * q + e][3]);
-        }
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int c = 0; c < CPL; ++c) acc[4 * q + e][c] = fmaT(ve[e], cv[u].e[c], acc[4 * q + e][c]);
       }
     }
+  };
+  if constexpr (sizeof(T) == 4) {
+    for (int it0 = 0; it0 < RC / 16; it0 += W_UNROLL) step(it0);        // (the compiler's own unrolling: 132 registers)
+  } else {
+#pragma unroll 1                                                        // f64: unrolled, the body hoists every LDS read
+    for (int it0 = 0; it0 < RC / 16; it0 += W_UNROLL) step(it0);        // of the chunk (256 + 44 registers); rolled: 110
   }
   // rows of one wave: the four lane groups g hold the same columns
 #pragma unroll
   for (int i = 0; i < 16; ++i)
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < CPL; ++q) {
       const T v = rowsx4(acc[i][q]);
-      if (g == 0) red[w][i][4 * t + q] = v;
+      if (g == 0) red[w][i][CPL * t + q] = v;
     }
   __syncthreads();
-  // 16 x 64 outputs, 4 per thread: fixed summation order over the waves
+  // 16 x TILE outputs, CPL per thread: fixed summation order over the waves
   const int i = tid >> 4;
-  const int64_t cc = (int64_t)blockIdx.x * 64 + 4 * (tid & 15);
+  const int64_t cc = (int64_t)blockIdx.x * TILE + CPL * (tid & 15);
   if (cc < nc) {
-    T o[4];
+    VN<T, CPL> o;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      T s = T(0);
+    for (int q = 0; q < CPL; ++q) {
+      T sacc = T(0);
 #pragma unroll
-      for (int k = 0; k < 4; ++k) s += red[k][i][4 * (tid & 15) + q];
-      o[q] = s;
+      for (int k = 0; k < 4; ++k) sacc += red[k][i][CPL * (tid & 15) + q];
+      o.e[q] = sacc;
     }
-    *reinterpret_cast<V4<T>*>(Wpart + ((int64_t)blockIdx.y * 16 + i) * nc + cc) = V4<T>{o[0], o[1], o[2], o[3]};
+    *reinterpret_cast<VN<T, CPL>*>(Wpart + ((int64_t)blockIdx.y * 16 + i) * nc + cc) = o;
   }
 }
 
@@ -834,7 +854,7 @@ __global__ __launch_bounds__(256) void rowupdate_kernel(float* __restrict__ C, i
 constexpr int Y_COLS = 128;
 template <typename T>
 constexpr int y_rows() {
-  return sizeof(T) == 4 ? 64 : 32;      // accumulators: Y_ROWS / 16 x 16 per lane
+  return sizeof(T) == 4 ? 64 : 16;      // accumulators: Y_ROWS / 16 x 16 per lane (f64: 32 rows needed 256 + 86 registers)
 }
 template <typename T>
 __global__ __launch_bounds__(256) void ypass_kernel(const T* __restrict__ C, int64_t ldc, int64_t rows, int64_t nc,
@@ -1904,7 +1924,7 @@ static int stage1(const Layout& L, char* base, int64_t m, int64_t n) {
       if (nc > 0) {
         T* C = Af + j * n + j + 16;
         const int chunks = (int)((mj + WRC - 1) / WRC);
-        hipLaunchKernelGGL((wpass_kernel<T>), dim3((unsigned)((nc + 63) / 64), chunks), dim3(256), 0, stream(),
+        hipLaunchKernelGGL((wpass_kernel<T>), dim3((unsigned)((nc + 16 * w_cpl<T>() - 1) / (16 * w_cpl<T>())), chunks), dim3(256), 0, stream(),
                            (const T*)C, n, mj, nc, (const T*)V, Wpart);
         hipLaunchKernelGGL((wreduce_kernel<T>), dim3((unsigned)((nc + 63) / 64)), dim3(256), 0, stream(),
                            (const T*)Wpart, chunks, nc, (const double*)Tp, 1, Wt);
@@ -2117,7 +2137,7 @@ static int vectors(const Layout& L, char* base, int64_t m, int64_t n, int64_t k,
     const T* V = (const T*)(base + L.Vl) + vl_offset(m, p);
     T* C = Uu + j * k;
     const int chunks = (int)((mj + WRC - 1) / WRC);
-    hipLaunchKernelGGL((wpass_kernel<T>), dim3((unsigned)((k + 63) / 64), chunks), dim3(256), 0, stream(), (const T*)C, k,
+    hipLaunchKernelGGL((wpass_kernel<T>), dim3((unsigned)((k + 16 * w_cpl<T>() - 1) / (16 * w_cpl<T>())), chunks), dim3(256), 0, stream(), (const T*)C, k,
                        mj, k, V, Wpart);
     hipLaunchKernelGGL((wreduce_kernel<T>), dim3((unsigned)((k + 63) / 64)), dim3(256), 0, stream(), (const T*)Wpart,
                        chunks, k, (const double*)(base + L.Tl) + p * 256, 0, Wt);
@@ -2131,7 +2151,7 @@ static int vectors(const Layout& L, char* base, int64_t m, int64_t n, int64_t k,
     const T* V = (const T*)(base + L.Vr) + vr_offset(n, p);
     T* C = Vv + j * k;
     const int chunks = (int)((nj + WRC - 1) / WRC);
-    hipLaunchKernelGGL((wpass_kernel<T>), dim3((unsigned)((k + 63) / 64), chunks), dim3(256), 0, stream(), (const T*)C, k,
+    hipLaunchKernelGGL((wpass_kernel<T>), dim3((unsigned)((k + 16 * w_cpl<T>() - 1) / (16 * w_cpl<T>())), chunks), dim3(256), 0, stream(), (const T*)C, k,
                        nj, k, V, Wpart);
     hipLaunchKernelGGL((wreduce_kernel<T>), dim3((unsigned)((k + 63) / 64)), dim3(256), 0, stream(), (const T*)Wpart,
                        chunks, k, (const double*)(base + L.Tr) + p * 256, 0, Wt);
@@ -2208,7 +2228,7 @@ static int qr_panels(int64_t m, int64_t n, const T* A, T* Q, T* R, char* base, i
     if (nc > 0) {
       T* C = Af + j * n + j + 16;
       const int chunks = (int)((mj + WRC - 1) / WRC);
-      hipLaunchKernelGGL((wpass_kernel<T>), dim3((unsigned)((nc + 63) / 64), chunks), dim3(256), 0, stream(), (const T*)C,
+      hipLaunchKernelGGL((wpass_kernel<T>), dim3((unsigned)((nc + 16 * w_cpl<T>() - 1) / (16 * w_cpl<T>())), chunks), dim3(256), 0, stream(), (const T*)C,
                          n, mj, nc, (const T*)V, Wpart);
       hipLaunchKernelGGL((wreduce_kernel<T>), dim3((unsigned)((nc + 63) / 64)), dim3(256), 0, stream(), (const T*)Wpart,
                          chunks, nc, (const double*)Tp, 1, Wt);
@@ -2246,7 +2266,7 @@ static int qr_panels(int64_t m, int64_t n, const T* A, T* Q, T* R, char* base, i
       T* C = Q + j * n + j;               // columns before j are untouched by panel p (identity start)
       const int64_t kc = n - j;
       const int chunks = (int)((mj + WRC - 1) / WRC);
-      hipLaunchKernelGGL((wpass_kernel<T>), dim3((unsigned)((kc + 63) / 64), chunks), dim3(256), 0, stream(), (const T*)C,
+      hipLaunchKernelGGL((wpass_kernel<T>), dim3((unsigned)((kc + 16 * w_cpl<T>() - 1) / (16 * w_cpl<T>())), chunks), dim3(256), 0, stream(), (const T*)C,
                          n, mj, kc, V, Wpart);
       hipLaunchKernelGGL((wreduce_kernel<T>), dim3((unsigned)((kc + 63) / 64)), dim3(256), 0, stream(), (const T*)Wpart,
                          chunks, kc, (const double*)(base + L.Tl) + p * 256, 0, Wt);

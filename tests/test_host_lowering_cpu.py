@@ -618,3 +618,39 @@ def test_band_svd_host_logic_in_the_other_dtypes(dtype, mode):
   k = s.shape[0]
   np.testing.assert_allclose(u.conj().T @ u, np.eye(k), atol=20 * tol)
   np.testing.assert_allclose((u * np.real(s)) @ vh, (ref[0] * ref[1]) @ ref[2], atol=40 * tol * s0)
+
+
+def test_band_svd_host_logic_random_call_shapes():
+  """A seeded sweep over shapes (tall / wide, padded or not), dtypes and truncation arguments: the band path's host
+  logic against the pinned oracle's rule (decompositions.py:21-74) -- shapes of all four outputs and the values."""
+  rng = np.random.default_rng(2024)
+  with emulated_backend() as be:
+    be.lib.band_svd = True
+    for trial in range(14):
+      m, n = (int(x) for x in rng.integers(512, 640, size=2))
+      if trial % 3 == 0:
+        m += int(rng.integers(100, 400))
+      dtype = [np.float32, np.float64][trial % 2]
+      r = min(m, n)
+      spec = 2.0 * 2.0 ** (-np.arange(r) / float(rng.integers(30, 60)))
+      qu, _ = np.linalg.qr(rng.standard_normal((m, r)))
+      qv, _ = np.linalg.qr(rng.standard_normal((n, r)))
+      a = ((qu * spec) @ qv.T).astype(dtype)
+      kw = {}
+      if trial % 4 != 3:
+        kw["max_singular_values"] = int(rng.integers(1, r + 40))           # may exceed min(m, n)
+      if trial % 2 == 1 or trial % 4 == 3:
+        kw["max_truncation_error"] = float(10.0 ** rng.uniform(-3, -0.5))
+        kw["relative"] = bool(trial % 3 == 1)
+      ref = orc.svd(a.astype(np.float64), 1, kw.get("max_singular_values"), kw.get("max_truncation_error"),
+                    kw.get("relative", False))
+      be._svd_band_backoff = {}      # pylint: disable=protected-access
+      u, s, vh, rest = [np.asarray(x) for x in be.svd(be.convert_to_tensor(a), 1, **kw)]
+      tag = (trial, m, n, np.dtype(dtype).name, kw, be.last_svd_path, be.last_svd_band_status)
+      assert be.last_svd_path == "band" or ref[1].shape[0] == 0, tag
+      assert s.shape == ref[1].shape and rest.shape == ref[3].shape and u.shape == ref[0].shape and vh.shape == ref[2].shape, tag
+      tol = 4e-6 if dtype == np.float32 else 1e-8
+      np.testing.assert_allclose(s, ref[1], atol=tol * spec[0], err_msg=str(tag))
+      np.testing.assert_allclose(rest, ref[3], atol=2 * tol * spec[0], err_msg=str(tag))
+      if s.shape[0]:
+        np.testing.assert_allclose((u * s) @ vh, (ref[0] * ref[1]) @ ref[2], atol=40 * tol * spec[0], err_msg=str(tag))
