@@ -14,14 +14,13 @@ python tools/traffic_json.py $OUT $OUT/bench_detail.json $O/traffic.json > /dev/
 cat $O/traffic.json | head -20
 rm -f $OUT/prof_stats/*kernel_trace.csv $OUT/prof_stats/*/*kernel_trace.csv
 timeout 1200 python -m pytest tests -m gpu -q --timeout 900 > $O/pytest_gpu.txt 2>&1; echo "pytest rc=$?"; tail -3 $O/pytest_gpu.txt
-timeout 1500 python bench.py --gpus 1 --steps 20 --warmup 5 --mera64-full ${MERA64:-2} --mera64-budget 400 > $O/bench.out 2> $O/bench.err; echo "bench rc=$?"; tail -3 $O/bench.err
+timeout 1500 python bench.py --gpus 1 --steps 20 --warmup 5 --mera64-full ${MERA64:-1} --mera64-budget 400 > $O/bench.out 2> $O/bench.err; echo "bench rc=$?"; tail -3 $O/bench.err
 cp $OUT/bench_detail.json $O/bench_detail.json; tail -c 4000 $O/bench.out; echo
 for dt in f32 f64; do
   (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/prof_svd_$dt -o svd -- python $OUT/../tools/svd_stats_run.py $dt > $O/svd_$dt.log 2>&1; echo "svd $dt prof rc=$?")
-  f=$(find $OUT/prof_svd_$dt -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/svd_${dt}_kernel_stats.csv
   find $OUT/prof_svd_$dt -name "*kernel_trace.csv" -delete
 done
-head -25 $O/svd_f32_kernel_stats.csv; head -25 $O/svd_f64_kernel_stats.csv
+python tools/svd_stats_summary.py $OUT $O
 python - <<'PY'
 import json
 r = json.loads(open("gpurun_out/r4final/bench_detail.json").read())
