@@ -1026,10 +1026,19 @@ int tnh_gemm_ex(int in_dtype, int out_dtype, int transA, int transB, int64_t M, 
   // strided-batched GEMM into f32 / f64 partials, summed by the K4 reduction (fixed order).
   const bool cplx_in = (in_dtype == TNH_C64 || in_dtype == TNH_C128);
   const bool int_in = (in_dtype == TNH_I32 || in_dtype == TNH_I64);   // exact integer products: VALU kernel only
-  if (plain && !cplx_in && !int_in && batch == 1 && ldc == N && K >= 4096 && g_variant == 0 && !g_in_splitk) {
+  // Round 4, the mid-K regime for f32 / f64: a 128 x 128 tile of an f32 product keeps ONE CU busy for K x 0.054 us
+  // (f64: K x 0.11 us) -- the 16-site MPS overlap of configs[3] is 29 products of (512 ... 1024)^3 / 2 that ran 45 us
+  // each on 16-32 of the 256 CUs (rocprofv3: 86 % of the chain's 1.5 ms).  From K = 512 on, with at most
+  // CUs / 8 tiles of at least 64 x 64 outputs, K is cut into slices of >= 128 so that the chip is filled twice over.
+  const bool wide_in = (in_dtype == TNH_F32 || in_dtype == TNH_F64);
+  const int64_t kmin = wide_in ? 512 : 4096;
+  if (plain && !cplx_in && !int_in && batch == 1 && ldc == N && K >= kmin && g_variant == 0 && !g_in_splitk) {
     const int64_t tiles = ((M + 127) / 128) * ((N + 127) / 128);
-    int64_t splits = std::min<int64_t>({K / 1024, (2 * (int64_t)num_cus()) / tiles, 256});
-    if (tiles * 4 <= (int64_t)num_cus() && splits >= 2) {
+    const bool mid = K < 4096;
+    int64_t splits = mid ? std::min<int64_t>({K / 128, (2 * (int64_t)num_cus()) / tiles, 32})
+                         : std::min<int64_t>({K / 1024, (2 * (int64_t)num_cus()) / tiles, 256});
+    const bool few = mid ? (tiles * 8 <= (int64_t)num_cus() && M >= 64 && N >= 64) : (tiles * 4 <= (int64_t)num_cus());
+    if (few && splits >= 2) {
       int64_t kc = (K + splits - 1) / splits;
       kc = (kc + 63) / 64 * 64;                       // keeps the bf16 kernels' K % 64 rule for full slices
       const int64_t full = K / kc, rem = K - full * kc;

@@ -398,7 +398,9 @@ def test_gemm_complex_on_matrix_cores(hip, dtype, kernel, tol, ta_, tb_):
   against the 2x2-block real expansion of B (tnh_complex_expand), every storage layout."""
   for (m, n, k) in [(200, 136, 96), (64, 257, 33), (512, 384, 256)]:
     out, ref, name, sk = _gemm_case(hip, dtype, m, n, k, ta_, tb_, rng=np.random.default_rng(m + n + k))
-    assert name.startswith(kernel), name
+    # (the 2 k = 512-deep real product of the last shape is in the mid-K split-K regime of round 4: same kernels,
+    # K slices, partials summed in a fixed order)
+    assert name.startswith(kernel) or (name == "splitk" and 2 * k >= 512), name
     np.testing.assert_allclose(out, ref, rtol=tol * sk * 4, atol=tol * k * 2)
 
 
@@ -479,6 +481,22 @@ def test_gemm_split_k_small_output(hip, dtype):
     out, ref, kernel, sk = _gemm_case(hip, dtype, m, n, k, ta_, tb_, rng=rng)
     assert kernel == "splitk", (kernel, m, n, k)
     tol = {np.float32: 2e-6, np.float64: 1e-14, ta.bfloat16: 1.6e-2, np.float16: 2e-3}[dtype]
+    np.testing.assert_allclose(out, ref, rtol=tol * 4, atol=tol * np.sqrt(k) * 4, err_msg=f"{m}x{n}x{k}")
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_gemm_split_k_mid_size_f32_f64(hip, dtype):
+  """Round 4: f32 / f64 products with few tiles and K of a few hundred to a few thousand (MPS transfer-matrix steps:
+  (512 ... 1024)^3 / 2) are split over K too -- one 128 x 128 f32 tile keeps a CU busy for K x 0.054 us; below the
+  thresholds (small K, tiny outputs, many tiles) nothing changes.  Every layout, ragged K."""
+  rng = np.random.default_rng(11)
+  kmin = 512
+  for (m, n, k, ta_, tb_, want) in [(512, 512, 1024, 0, 0, True), (1024, 512, 1000, 0, 1, True), (512, 1024, kmin, 1, 0, True),
+                                    (200, 300, 2500, 1, 1, True), (512, 512, kmin - 64, 0, 0, False),
+                                    (32, 512, 2048, 0, 0, False), (2048, 2048, 1024, 0, 1, False)]:
+    out, ref, kernel, sk = _gemm_case(hip, dtype, m, n, k, ta_, tb_, rng=rng)
+    assert (kernel == "splitk") == want, (kernel, m, n, k)
+    tol = 2e-6 if dtype == np.float32 else 1e-14
     np.testing.assert_allclose(out, ref, rtol=tol * 4, atol=tol * np.sqrt(k) * 4, err_msg=f"{m}x{n}x{k}")
 
 
@@ -991,7 +1009,7 @@ def test_gemm_view_tail_split_matches_unsplit(hip):
 
 
 @pytest.mark.parametrize("ta_,tb_", [(0, 0), (0, 1), (1, 0), (1, 1)])
-@pytest.mark.parametrize("m,n,k", [(256, 384, 512), (132, 200, 100), (4, 8, 36), (1000, 260, 68), (128, 128, 32)])
+@pytest.mark.parametrize("m,n,k", [(256, 384, 480), (132, 200, 100), (4, 8, 36), (1000, 260, 68), (128, 128, 32)])
 def test_gemm_f32_v2_vector_path(hip, ta_, tb_, m, n, k):
   """f32 fast path (16-byte loads, BK = 32, two LDS stages): all four storage forms, ragged M / N edges and a K
   tail, against float64; the kernel actually taken is checked."""
