@@ -81,10 +81,10 @@ def parse_args():
                  help="placements of the chi = 64 MERA layer run in FULL (4096 slices each, ~150 s per placement on one "
                       "MI355X); the others are reported per slice x count")
   p.add_argument("--mera64-budget", type=float, default=200.0, help="seconds after which a full placement stops early")
-  p.add_argument("--bringup-timeout", type=float, default=float(os.environ.get("TNH_BENCH_BRINGUP_TIMEOUT_S", "300")),
+  p.add_argument("--bringup-timeout", type=float, default=float(os.environ.get("TNH_BENCH_BRINGUP_TIMEOUT_S", "900")),
                  help="N > 1: seconds the ranks get to rendezvous, create the RCCL communicator and pass the first "
                       "barrier before the job is killed with a message (a hang inside RCCL must not become the record)")
-  p.add_argument("--job-timeout", type=float, default=float(os.environ.get("TNH_BENCH_JOB_TIMEOUT_S", "1500")),
+  p.add_argument("--job-timeout", type=float, default=float(os.environ.get("TNH_BENCH_JOB_TIMEOUT_S", "2700")),
                  help="self-launched N > 1 jobs: seconds before the launcher kills every rank")
   p.add_argument("--fill", default="normal", choices=["normal", "zeros"],
                  help="operand fill (zeros shows the DVFS-inflated number; never the headline)")

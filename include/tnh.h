@@ -370,7 +370,7 @@ int tnh_qr(int dtype, int64_t m, int64_t n, const void* A, void* Q, void* R,
 int tnh_comm_available(void);
 int tnh_comm_unique_id(void* host_id);
 /* Collective over all ranks.  Bounded: ncclCommInitRank runs on a helper thread and the call returns
- * TNH_ERR_TIMEOUT after TNH_COMM_INIT_TIMEOUT_S seconds (environment; default 180, 0 = no limit) -- the helper is
+ * TNH_ERR_TIMEOUT after TNH_COMM_INIT_TIMEOUT_S seconds (environment; default 600, 0 = no limit) -- the helper is
  * then still inside RCCL and the process should report and exit (os._exit: a normal exit may wait for it). */
 int tnh_comm_init(const void* host_id, int rank, int world);
 /* *world = 0 when no communicator exists. */

@@ -49,7 +49,7 @@ def _recv_msg(sock):
 class HostRendezvous:
   """TCP star for small host-side exchanges between the ranks of one job."""
 
-  def __init__(self, rank, world, addr=None, port=None, timeout=300.0):
+  def __init__(self, rank, world, addr=None, port=None, timeout=900.0):
     self.rank, self.world = int(rank), int(world)
     self._peers = []
     self._sock = None

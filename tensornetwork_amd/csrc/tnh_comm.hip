@@ -161,7 +161,8 @@ int tnh_comm_init(const void* host_id, int rank, int world) {
   if (saved_stdout >= 0) dup2(STDERR_FILENO, STDOUT_FILENO);
   // Bounded bring-up (round 4): ncclCommInitRank is collective and has no timeout of its own -- a peer that never
   // arrives, or a bootstrap interface that does not route (measured on the GPU box: no return within 150 s), blocks
-  // it for good.  It runs on a helper thread; this thread waits TNH_COMM_INIT_TIMEOUT_S seconds (default 180; 0 =
+  // it for good.  It runs on a helper thread; this thread waits TNH_COMM_INIT_TIMEOUT_S seconds (default 600 -- on a
+  // fresh box the first touch of librccl.so alone was measured at minutes, page by page from the image; 0 =
   // wait for ever, the old behaviour).  On a timeout the call returns TNH_ERR_TIMEOUT and the helper is left behind,
   // still inside RCCL (there is no communicator handle to abort yet): the process is expected to report and exit.
   struct InitState {
@@ -174,7 +175,7 @@ int tnh_comm_init(const void* host_id, int rank, int world) {
   auto st = std::make_shared<InitState>();
   int dev = 0;
   (void)hipGetDevice(&dev);
-  double limit_s = 180.0;
+  double limit_s = 600.0;
   if (const char* e = getenv("TNH_COMM_INIT_TIMEOUT_S")) limit_s = atof(e);
   auto fn = g_api.CommInitRank;
   std::thread helper([st, fn, id, world, rank, dev]() {
