@@ -1235,9 +1235,8 @@ class HipBackend(BackendBase):
       return None
     if pad:
       # the `pad` leading triplets are (delta, e_i, e_i); anything else means the s_1 estimate was off by more than 2
-      head = np.asarray(self.getitem(s, slice(0, pad)), dtype=np.float64)
-      nxt = float(np.asarray(self.getitem(s, slice(pad, pad + 1)))[0])
-      if np.any(np.abs(head - delta) > 1e-5 * delta) or not nxt < delta * (1.0 - 1e-3):
+      lead = np.asarray(self.getitem(s, slice(0, pad + 1)), dtype=np.float64)       # one read-back: the check below
+      if np.any(np.abs(lead[:pad] - delta) > 1e-5 * delta) or not lead[pad] < delta * (1.0 - 1e-3):
         return None
       uu = self.getitem(uu, (slice(None), slice(pad, pad + keep)))
       vvh = self.getitem(vvh, slice(pad, pad + keep))
