@@ -1,4 +1,7 @@
-"""Headline benchmark: one JSON line per run (contract described in the task brief).
+"""Headline benchmark: ONE compact JSON line (the last line of stdout, < 4 KB: every contract key, `roofline`,
+`cpu_baseline`, `verified` {all_ok, checks, failed}, one or two numbers per secondary leg) + the full record in
+`bench_detail.json` next to this file and under gpurun_out/ (round 4: the one 21 KB line of round 3 did not fit the
+driver's 8 KB tail).  The objects described below are those of the FULL record.
 
 Workload at N=1 (BASELINE.json configs[1]): ``contract_between`` of two rank-4
 bf16 nodes with two shared bonds of dimension D=256 (layout L0: a[2]^b[0],
@@ -26,8 +29,11 @@ Extra objects on the same line:
                     bounded sample (same layout, smaller D).
   svd            -- split_node truncated SVD (configs[2]: (16,)*6 node -> 4096 x 4096, keep 256) in the metric's
                     GB/s; `sweep` holds SURVEY 8d's full case list: Gaussian and s_i = 2^(-i/32) inputs, natural and
-                    mixed edge order, n = 512 .. 4096, each checked against LAPACK (verified.svd); the oracle's
-                    LAPACK SVD timed on a bounded sample beside it.
+                    mixed edge order, n = 512 .. 4096, each checked against LAPACK (verified.svd), plus one row per
+                    call shape of round 4 (truncation error alone, full SVD, a side that is not a multiple of 16,
+                    float64: verified.svd_call_shapes); `bound` = what really bounds the band SVD (dependent
+                    launches, rank-16 update traffic, f64 Sturm counts); the oracle's LAPACK SVD timed on a bounded
+                    sample beside it.
   bond_sweep     -- the metric's bond-dimension sweep: contract_between of two rank-4 bf16 nodes at
                     D = 32 .. 256 in the favourable (L0) and the permute-needing (L1) layout, plus the
                     north-star "D = 512" row A(64,128,512,512) . B(512,512,128,64) (GEMM 8192 x 8192 x 262144),
@@ -36,7 +42,8 @@ Extra objects on the same line:
   mps_chain      -- configs[3]: <psi|psi> of a 16-site MPS, bulk D = 512, contractors.greedy (d = 2 and d = 4;
                     eager and hipGraph replay) with the NumPy oracle backend's time beside it.
   mera           -- configs[4] shape on one GPU: binary-MERA layer energy at chi = 32 (68.7 GB intermediate).
-  mera_chi64     -- configs[4] at chi = 64: measured per-slice cost x slice count (labelled extrapolated).
+  mera_chi64     -- configs[4] at chi = 64: `--mera64-full` placements (default 1 of 2) run slice by slice (4096
+                    slices, ~165 s: `measured_*`), the rest as per-slice cost x slice count (labelled extrapolated).
   helpers        -- HBM-bound helper kernels (K1 permute, K3/K4 reductions, K5 scaling) in GB/s vs 8 TB/s.
   sliced_network -- the north-star scaling network (64-node random 3-regular graph, bond D, bf16):
                     bond-sliced greedy contraction, slices dealt over the N ranks, ONE all-reduce of
