@@ -179,6 +179,43 @@ typedef struct {
 int tnh_gemm_view(int in_dtype, int out_dtype, int64_t M, int64_t N, int64_t K, const void* A,
                   const tnh_operand_view* va, const void* B, const tnh_operand_view* vb, void* C,
                   int64_t ldc);
+/* bf16 / f16 contraction of a SMALL operand with a very long tensor that is read where it lies -- the "gather"
+ * lowering of tensordot for a many-axis intermediate whose contracted axes sit anywhere among its free ones
+ * (what ncon / the greedy contractor produce when a small tensor takes one or two bonds off a big intermediate:
+ * ncon_interface.py:336-343, 483-489 -> tensordot, numpy_backend.py:35-37):
+ *     C[Ms, Nl] = S[Ms, K] * L[Nl, K]^T   (small_first != 0)        C[Nl, Ms] = L[Nl, K] * S[Ms, K]^T   (small_first == 0)
+ * Row n of L is the n-th index tuple of the long tensor's free axes (row-major, natural axis order), column k the
+ * k-th tuple of its contracted axes (row-major, memory order); S is row-major with rows lds apart, K-contiguous,
+ * its K index in that same order.  The descriptor splits the long tensor into tiles -- a tile is a box holding
+ * every contracted index and BN = 48 or 64 consecutive free tuples:
+ *   box digits   d = 0 .. nd-1 in memory order (stride ascending; digit 0 is the innermost axis: stride 1,
+ *                extent a multiple of 4): ext[d] indices of the digit lie inside one box, stride[d] elements apart;
+ *                mult[d] is the digit's weight in the tile-row index (free digit) or in k (bit d of k_mask set);
+ *   tile digits  the tile number, innermost first: text[d] values, box origins tstride[d] elements apart.
+ * Strides other than digit 0's are multiples of 4 elements, L is 8-byte aligned, S and C 16-byte; K % 8 == 0,
+ * 8 <= K <= 192, Ms <= 192 (Ms % 8 == 0 when small_first == 0), ldc % 8 == 0.  l_elems = elements of the long
+ * tensor (bounds check).  Returns TNH_ERR_UNSUPPORTED, nothing launched, when a rule fails (or TNH_GEMM_GATHER=0):
+ * the caller permutes and calls tnh_gemm; results are bit-identical to that path (same MFMA sequence). */
+#define TNH_GATHER_MAX_DIGITS 8
+#define TNH_GATHER_MAX_TILE_DIGITS 6
+typedef struct {
+  int32_t nd;
+  int32_t ext[TNH_GATHER_MAX_DIGITS];
+  int32_t stride[TNH_GATHER_MAX_DIGITS];
+  int32_t mult[TNH_GATHER_MAX_DIGITS];
+  int32_t k_mask;
+  int32_t nt;
+  int32_t text[TNH_GATHER_MAX_TILE_DIGITS];
+  int64_t tstride[TNH_GATHER_MAX_TILE_DIGITS];
+} tnh_gather_desc;
+int tnh_gemm_gather(int dtype, int64_t Ms, int64_t K, int64_t Nl, const void* S, int64_t lds, const void* L,
+                    int64_t l_elems, const tnh_gather_desc* desc, void* C, int64_t ldc, int small_first);
+/* Host-only (needs neither tnh_init nor a device): validates a descriptor as tnh_gemm_gather does and writes the
+ * first `nchunks` 8-byte chunks of a box in the order the kernel's threads take them (element offset in the box,
+ * tile row, k of the chunk's first element; the other three follow along k when digit 0 is contracted, along the
+ * rows otherwise) and the origins of the first `ntiles` boxes.  Returns BN (> 0) or a negative tnh_status. */
+int tnh_gemm_gather_plan(const tnh_gather_desc* desc, int64_t K, int64_t Nl, int64_t l_elems, int32_t* chunk_off,
+                         int32_t* chunk_row, int32_t* chunk_k, int64_t nchunks, int64_t* tile_base, int64_t ntiles);
 const char* tnh_gemm_last_kernel(void);
 /* Force a variant ("auto", "generic", "valu", "bf16_128", "bf16_256", "bf16_256pp", "bf16_ragged*"),
  * optionally followed by A/B knobs ":r<d>" (tile raster), ":p<d>" (bf16 pipeline variant; 6 = the

@@ -34,6 +34,15 @@ class OperandView(ctypes.Structure):
               ("k0", c_int64), ("sk0", c_int64), ("sk1", c_int64)]
 
 
+GATHER_MAX_DIGITS, GATHER_MAX_TILE_DIGITS = 8, 6
+
+class GatherDesc(ctypes.Structure):
+  """tnh_gather_desc (include/tnh.h): tile plan of the long operand of tnh_gemm_gather."""
+  _fields_ = [("nd", c_int32), ("ext", c_int32 * GATHER_MAX_DIGITS), ("stride", c_int32 * GATHER_MAX_DIGITS),
+              ("mult", c_int32 * GATHER_MAX_DIGITS), ("k_mask", c_int32), ("nt", c_int32),
+              ("text", c_int32 * GATHER_MAX_TILE_DIGITS), ("tstride", c_int64 * GATHER_MAX_TILE_DIGITS)]
+
+
 _I64P = POINTER(c_int64)
 _I32P = POINTER(c_int32)
 
@@ -77,6 +86,10 @@ SIGNATURES = {
     "tnh_gemm_ex": (c_int, [c_int, c_int, c_int, c_int, c_int64, c_int64, c_int64,
                             c_void_p, c_int64, c_void_p, c_int64, c_void_p,
                             c_int64, c_int64, c_int64, c_int64, c_int64, c_double, c_double]),
+    "tnh_gemm_gather": (c_int, [c_int, c_int64, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_int64,
+                                POINTER(GatherDesc), c_void_p, c_int64, c_int]),
+    "tnh_gemm_gather_plan": (c_int, [POINTER(GatherDesc), c_int64, c_int64, c_int64, _I32P, _I32P, _I32P, c_int64,
+                                     _I64P, c_int64]),
     "tnh_gemm_view": (c_int, [c_int, c_int, c_int64, c_int64, c_int64, c_void_p, POINTER(OperandView),
                               c_void_p, POINTER(OperandView), c_void_p, c_int64]),
     "tnh_complex_expand": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_int, c_int]),

@@ -41,6 +41,13 @@ int gemm_bf16_fast(int in_dt, int out_dt, int variant, int transA, int transB, i
 int gemm_bf16_view(int in_dt, int out_dt, int64_t M, int64_t N, int64_t K, const void* A, const OpView& va,
                    const void* B, const OpView& vb, void* C, int64_t ldc, const char** name);
 
+// provided by tnh_gemm_gather.hip
+int gemm_gather(int dtype, int64_t Ms, int64_t K, int64_t Nl, const void* S, int64_t lds, const void* L,
+                int64_t l_elems, const tnh_gather_desc* desc, void* C, int64_t ldc, int small_first,
+                const char** name);
+int gemm_gather_plan(const tnh_gather_desc* desc, int64_t K, int64_t Nl, int64_t l_elems, int32_t* chunk_off,
+                     int32_t* chunk_row, int32_t* chunk_k, int64_t nchunks, int64_t* tile_base, int64_t ntiles);
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 
@@ -978,6 +985,28 @@ int tnh_gemm_view(int in_dtype, int out_dtype, int64_t M, int64_t N, int64_t K, 
   int rc = gemm_bf16_view(in_dtype, out_dtype, M, N, K, A, a, B, b, C, ldc, &name);
   if (rc == TNH_OK) g_last_kernel = name;
   return rc;
+}
+
+int tnh_gemm_gather(int dtype, int64_t Ms, int64_t K, int64_t Nl, const void* S, int64_t lds, const void* L,
+                    int64_t l_elems, const tnh_gather_desc* desc, void* C, int64_t ldc, int small_first) {
+  TNH_NEED_INIT();
+  TNH_REQUIRE(desc != nullptr && S != nullptr && L != nullptr && C != nullptr, "tnh_gemm_gather: null argument");
+  TNH_REQUIRE(dtype == TNH_BF16 || dtype == TNH_F16, "tnh_gemm_gather: bf16 / f16 only");
+  if (g_variant != 0) {   // a kernel forced through tnh_gemm_set_variant (tests, A/B): the caller's fallback path runs it
+    set_error("tnh_gemm_gather: a GEMM variant is forced");
+    return TNH_ERR_UNSUPPORTED;
+  }
+  const char* name = nullptr;
+  const int rc = gemm_gather(dtype, Ms, K, Nl, S, lds, L, l_elems, desc, C, ldc, small_first, &name);
+  if (rc == TNH_OK) g_last_kernel = name;
+  return rc;
+}
+
+int tnh_gemm_gather_plan(const tnh_gather_desc* desc, int64_t K, int64_t Nl, int64_t l_elems, int32_t* chunk_off,
+                         int32_t* chunk_row, int32_t* chunk_k, int64_t nchunks, int64_t* tile_base, int64_t ntiles) {
+  TNH_REQUIRE(desc != nullptr && (nchunks == 0 || (chunk_off && chunk_row && chunk_k)) && (ntiles == 0 || tile_base),
+              "tnh_gemm_gather_plan: null argument");
+  return gemm_gather_plan(desc, K, Nl, l_elems, chunk_off, chunk_row, chunk_k, nchunks, tile_base, ntiles);
 }
 
 int tnh_gemm(int in_dtype, int out_dtype, int transA, int transB, int64_t M, int64_t N, int64_t K,

@@ -127,6 +127,85 @@ def _operand_view(shape, free_axes, k_axes, strides=None):
   return _lib.OperandView(r0, sr0, sr1, k0, sk0, sk1)
 
 
+def _gather_descriptor(shape, k_axes):
+  """Tile plan (tnh_gather_desc, include/tnh.h) for reading a dense row-major tensor in place as the long operand
+  of tnh_gemm_gather: rows = the free axes in natural order, K = `k_axes` in memory order.  Returns
+  (descriptor, BN, long_rows) or None when no box of 64 / 48 free tuples x all contracted indices
+  exists whose pieces are 8-byte aligned (the caller then permutes, as before).
+
+  Digits are the tensor's axes innermost first, with size-1 axes dropped and memory-adjacent axes of the same
+  role merged.  A box takes the contracted digits in full, the free digits below the split digit in full, and
+  T indices of the split digit (T divides its extent); the tile number runs over the rest of the split digit
+  and the free digits above it."""
+  strides = _row_major_strides(shape)
+  kset = set(int(x) for x in k_axes)
+  digits = []                                   # [extent, stride, contracted?], innermost first
+  for ax in range(len(shape) - 1, -1, -1):
+    n = int(shape[ax])
+    if n == 1:
+      continue
+    is_k = ax in kset
+    if digits and digits[-1][2] == is_k:
+      digits[-1][0] *= n                        # dense row-major: neighbours of one role are one run
+    else:
+      digits.append([n, int(strides[ax]), is_k])
+  free = [i for i, d in enumerate(digits) if not d[2]]
+  if not free or len(free) == len(digits) or digits[0][0] % 4:
+    return None
+  # the split digit: whole free digits while they fit, then T of the next one
+  below, split, t_split, bn = 1, None, 0, 0
+  for i in free:
+    ext = digits[i][0]
+    for target in (64, 48):
+      if target % below == 0 and ext % (target // below) == 0:
+        split, t_split, bn = i, target // below, target
+        break
+    if split is not None:
+      break
+    if below * ext >= 48:
+      return None
+    below *= ext
+  if split is None:
+    return None
+  if split == 0 and t_split % 4:
+    return None
+  if sum((d[0] - 1) * d[1] for d in digits) >= 1 << 31:
+    return None                                 # (the descriptor holds 32-bit box offsets)
+  desc = _lib.GatherDesc()
+  nd, w_row, w_k = 0, 1, 1
+  for i, (ext, stride, is_k) in enumerate(digits):
+    if not is_k and i > split:
+      continue
+    if nd == _lib.GATHER_MAX_DIGITS:
+      return None
+    inside = t_split if i == split else ext
+    desc.ext[nd], desc.stride[nd] = inside, stride
+    if is_k:
+      desc.mult[nd] = w_k
+      desc.k_mask |= 1 << nd
+      w_k *= ext
+    else:
+      desc.mult[nd] = w_row
+      w_row *= inside
+    nd += 1
+  desc.nd = nd
+  nt, rows = 0, bn
+  for i in free:
+    if i < split:
+      continue
+    ext, stride = digits[i][0], digits[i][1]
+    count, step = (ext // t_split, stride * t_split) if i == split else (ext, stride)
+    rows *= count
+    if count == 1:
+      continue
+    if nt == _lib.GATHER_MAX_TILE_DIGITS:
+      return None
+    desc.text[nt], desc.tstride[nt] = count, step
+    nt += 1
+  desc.nt = nt
+  return desc, bn, rows
+
+
 class HipBackend(BackendBase):
   """TensorNetwork backend running on one MI355X through libtnhip.so.
 
@@ -159,6 +238,11 @@ class HipBackend(BackendBase):
     self.pad_results = os.environ.get("TNH_PAD_RESULTS", "0") == "1"       # see _result_pitch
     self.pad_min_bytes = int(os.environ.get("TNH_PAD_MIN_BYTES", str(2 << 30)))
     self.inplace_max_bytes = int(os.environ.get("TNH_VIEW_INPLACE_MAX_BYTES", str(2 << 30)))
+    # bf16 / f16 tensordot of a small tensor with a many-axis intermediate: the streaming GEMM gathers the
+    # intermediate where it lies (tnh_gemm_gather) instead of K1-permuting it first.  TNH_GATHER_GEMM=0/1.
+    self.gather_gemm = os.environ.get("TNH_GATHER_GEMM", "0") == "1"
+    self.gather_min_rows = 1 << 16
+    self.gather_launches = 0     # tnh_gemm_gather launches
     self.permutes_absorbed = 0   # tnh_gemm_view launches
     self.permute_launches = 0    # K1 launches (transpose)
     self._svd_band_failed = set()      # per backend object (the class attributes below only say what they are)
@@ -541,6 +625,12 @@ class HipBackend(BackendBase):
 
     # bf16 / f16, enough 256 x 256 tiles: read BOTH operands in place through two-level strides
     # (K8 lowering of tensordot2.py:62-88 -- transposes are absorbed by the GEMM loaders, no K1 launch).
+    if code in _HALF and self.gather_gemm and self.half_output == "same":
+      got = self._tensordot_gather(a, b, axes_a, axes_b, free_a, free_b, m, n, k, hint_a, hint_b)
+      if got is not None:
+        out, used_a, used_b = got
+        out_shape = tuple(a.shape[i] for i in used_a) + tuple(b.shape[i] for i in used_b)
+        return out.view(out_shape), used_a, used_b
     if code in _HALF and self.absorb_transposes:
       a_shape0, b_shape0 = a.shape, b.shape
       got = self._tensordot_in_place(a, b, axes_a, axes_b, free_a, free_b, m, n, k, hint_a, hint_b)
@@ -604,6 +694,56 @@ class HipBackend(BackendBase):
       return self._complex_gemm(a, b, trans_a, trans_b, m, n, k).view(out_shape), free_a, free_b
     out = self._gemm(a, b, trans_a, trans_b, m, n, k, lda, ldb, alias=alias)
     return out.view(out_shape), free_a, free_b
+
+  def _tensordot_gather(self, a, b, axes_a, axes_b, free_a, free_b, m, n, k, hint_a=None, hint_b=None):
+    """One `tnh_gemm_gather` launch for a SMALL operand (65 ... 192 free tuples, K <= 192) against a long
+    many-axis tensor whose contracted axes are not trailing, or None (the caller's permute + GEMM lowering
+    runs; results are bit-identical either way).  The long tensor is read where it lies, so its free axes
+    come out in natural order whatever the planner hinted -- the NEXT contraction gathers it again instead
+    of finding it laid out; only the small operand is permuted (to [free, contracted in the long tensor's
+    memory order]).  Returns (tensor, used_free_a, used_free_b)."""
+    small_first = m <= n
+    ms, nl = (m, n) if small_first else (n, m)
+    if not (64 < ms <= 192 and 16 <= k <= 192 and k % 8 == 0 and nl >= self.gather_min_rows):
+      return None
+    if not small_first and ms % 8:
+      return None
+    small, long_ = (a, b) if small_first else (b, a)
+    axes_s, axes_l = (axes_a, axes_b) if small_first else (axes_b, axes_a)
+    free_s, free_l = (free_a, free_b) if small_first else (free_b, free_a)
+    hint_s = hint_a if small_first else hint_b
+    if long_.pad is not None or long_.ptr % 8:
+      return None
+    nc = len(axes_l)
+    if sorted(axes_l) == list(range(long_.ndim - nc, long_.ndim)):
+      return None       # contracted axes trailing: the streaming kernel reads it as it is
+    plan = _gather_descriptor(long_.shape, axes_l)
+    if plan is None:
+      return None
+    desc, _, rows = plan
+    if rows != nl:
+      return None
+    order = sorted(range(nc), key=lambda i: axes_l[i])       # the long tensor's memory order of the contracted pairs
+    used_s = list(free_s)
+    if hint_s is not None and sorted(hint_s) == sorted(free_s):
+      used_s = [int(i) for i in hint_s]
+    small = self.transpose(self._dense(small), used_s + [axes_s[i] for i in order])
+    if small.ptr % 16:
+      return None
+    out = DeviceTensor.empty((ms, nl) if small_first else (nl, ms), long_.code)
+    events = getattr(self, "gemm_events", None)
+    if events is not None:
+      start = _lib.Event().record()
+    status = self.lib.tnh_gemm_gather(long_.code, ms, k, nl, _vp(small), k, _vp(long_), long_.size,
+                                      ctypes.byref(desc), _vp(out), nl if small_first else ms, 1 if small_first else 0)
+    if status == _lib.ERR_UNSUPPORTED:
+      return None     # (a forced A/B variant, TNH_GEMM_GATHER=0, or an alignment rule: nothing was launched)
+    _lib.check(status, "tnh_gemm_gather")
+    if events is not None:
+      events.append((start, _lib.Event().record()))
+    self.gather_launches += 1
+    used_l = sorted(free_l)
+    return (out, used_s, used_l) if small_first else (out, used_l, used_s)
 
   def _tensordot_in_place(self, a, b, axes_a, axes_b, free_a, free_b, m, n, k, hint_a=None, hint_b=None):
     """One `tnh_gemm_view` launch that reads the operands as they lie in HBM wherever that pays, or None

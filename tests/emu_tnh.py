@@ -247,6 +247,70 @@ class EmuLib:
     self.calls.append(("view_gemm", int(m), int(n), int(k), (va.sk0, va.sr1, va.sk1), (vb.sk0, vb.sr1, vb.sk1)))
     return _lib.OK
 
+  # ---- K2 gather (tnh.h: tnh_gather_desc -- a tile is a box of the long tensor: all contracted indices x BN free
+  #      tuples; box digits in memory order with their weight in the tile row / in k, tile digits innermost first)
+  @staticmethod
+  def _gather_index(desc, k, nl, l_elems):
+    """(element index of L[n, k] in the long tensor, BN), or None where the library refuses the descriptor"""
+    nd, nt = int(desc.nd), int(desc.nt)
+    if not 1 <= nd <= _lib.GATHER_MAX_DIGITS or not 0 <= nt <= _lib.GATHER_MAX_TILE_DIGITS:
+      return None
+    ext, stride, mult = list(desc.ext[:nd]), list(desc.stride[:nd]), list(desc.mult[:nd])
+    is_k = [(desc.k_mask >> d) & 1 for d in range(nd)]
+    if stride[0] != 1 or mult[0] != 1 or ext[0] % 4 or any(st % 4 for st in stride[1:]) or min(ext + stride + mult) < 1:
+      return None
+    bn = int(np.prod([e for e, f in zip(ext, is_k) if not f], dtype=np.int64))
+    if bn not in (48, 64) or int(np.prod([e for e, f in zip(ext, is_k) if f], dtype=np.int64)) != k:
+      return None
+    grids = np.meshgrid(*[np.arange(e, dtype=np.int64) for e in ext], indexing="ij")
+    zero = np.zeros(grids[0].shape, dtype=np.int64)
+    off = (zero + sum(g * st for g, st in zip(grids, stride))).reshape(-1)
+    row = (zero + sum(g * w for g, w, f in zip(grids, mult, is_k) if not f)).reshape(-1)
+    col = (zero + sum(g * w for g, w, f in zip(grids, mult, is_k) if f)).reshape(-1)
+    if row.max() >= bn or col.max() >= k or len(set(zip(row.tolist(), col.tolist()))) != row.size:
+      return None                       # the image is not covered exactly once
+    box = np.zeros((bn, k), dtype=np.int64)
+    box[row, col] = off
+    text, tstride = list(desc.text[:nt]), list(desc.tstride[:nt])
+    tiles = int(np.prod(text, dtype=np.int64)) if nt else 1
+    if tiles * bn != nl or any(t < 1 for t in text) or any(st < 0 or st % 4 for st in tstride):
+      return None
+    base = np.zeros(tiles, dtype=np.int64)
+    t = np.arange(tiles, dtype=np.int64)
+    for e, st in zip(text, tstride):
+      base += (t % e) * st
+      t //= e
+    idx = (base[:, None, None] + box[None, :, :]).reshape(nl, k)
+    if int(idx.max()) >= l_elems:
+      return None
+    return idx, bn
+
+  def tnh_gemm_gather(self, code, ms, k, nl, s, lds, l, l_elems, desc, c, ldc, small_first):
+    desc = desc._obj                    # pylint: disable=protected-access
+    if code not in (_lib.BF16, _lib.F16):
+      return _lib.ERR_INVALID
+    swap = not small_first
+    if not (1 <= ms <= 192 and 8 <= k <= 192 and k % 8 == 0 and nl >= 48 and lds % 8 == 0 and ldc % 8 == 0 and
+            lds >= k and _addr(s) % 16 == 0 and _addr(l) % 8 == 0 and _addr(c) % 16 == 0 and
+            (not swap or ms % 8 == 0) and ldc >= (ms if swap else nl)):
+      return _lib.ERR_UNSUPPORTED
+    got = self._gather_index(desc, int(k), int(nl), int(l_elems))
+    if got is None:
+      return _lib.ERR_UNSUPPORTED
+    idx, bn = got
+    flat = self._flat(l, int(l_elems), _NP[code])
+    lm = np.ascontiguousarray(self._to_f(flat[idx], code).astype(np.float32))
+    sm = np.ascontiguousarray(self._matrix(s, code, ms, k, lds, 0, 0).astype(np.float32))
+    # the arithmetic form of tnh_gemm above: contiguous (M x K) times contiguous (N x K) transposed
+    prod = np.matmul(lm, sm.T) if swap else np.matmul(sm, lm.T)
+    rows, cols = prod.shape
+    cflat = self._flat(c, (rows - 1) * ldc + cols, _NP[code])
+    cm = np.lib.stride_tricks.as_strided(cflat, shape=(rows, cols), strides=(ldc * cflat.itemsize, cflat.itemsize))
+    cm[:, :] = self._from_f(prod, code)
+    self._last_kernel = ("bf16_gather_%dxS" % bn if swap else "bf16_gather_Sx%d" % bn).encode()
+    self.calls.append(("gather_gemm", int(ms), int(nl), int(k), int(bn), bool(desc.k_mask & 1), bool(small_first)))
+    return _lib.OK
+
   # ---- K6 (tnh.h: dst = a (op) b with broadcasting expressed as element strides) -- used by outer_product
   def tnh_binary(self, op, dst, a, b, rank, shape, a_strides, b_strides, code):
     shape, sa, sb = _ints(shape, rank), _ints(a_strides, rank), _ints(b_strides, rank)

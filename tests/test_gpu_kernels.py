@@ -1175,3 +1175,144 @@ def test_row_padded_results_on_the_device(hip):
     assert hip.reshape(c1, (13 * 256, 4096)).pad == (1, 4160)                          # reshape keeps the padding
   finally:
     hip.pad_results, hip.pad_min_bytes = saved
+
+
+# ---------------------------------------------------------------- K2 gather: the long operand read where it lies
+# (shape_small, shape_long, axes_small, axes_long, small_first, kernel, same K order as the classic lowering)
+_GATHER_CASES = [
+    ((12, 12, 12, 12), (12,) * 7, [1, 3], [3, 6], True, "bf16_gather_Sx48", True),            # D = 12: runs of 12 along k
+    ((12, 12, 12, 12), (12, 12, 12, 12, 12, 1, 12, 12), [1, 3], [2, 7], True, "bf16_gather_Sx64", True),
+    ((12, 12, 12, 12), (12,) * 7, [1, 3], [1, 5], True, "bf16_gather_Sx48", True),            # innermost axis free
+    ((12, 12, 12, 12), (12,) * 7, [1, 3], [0, 1], True, "bf16_gather_Sx64", True),            # k-major long operand
+    ((12, 12, 12, 12), (12,) * 7, [1, 3], [3, 6], False, "bf16_gather_48xS", True),           # long operand first
+    ((12, 12, 12, 12), (12,) * 7, [1, 3], [0, 1], False, "bf16_gather_64xS", True),
+    ((16, 8, 8, 8), (8,) * 8, [1, 3], [3, 7], True, "bf16_gather_Sx64", True),                # K = 64, Ms = 128
+    ((16, 12, 12, 16), (12, 12, 12, 16, 12, 12), [1, 3], [1, 3], True, "bf16_gather_Sx48", True),   # K = Ms = 192
+    ((10, 8, 8, 5), (8, 16, 5, 16, 16, 16), [1, 3], [0, 2], True, "bf16_gather_Sx64", True),  # Ms = 80, K = 40
+    ((10, 5, 8, 8), (64, 5, 16, 16, 8), [1, 3], [1, 4], True, "bf16_gather_Sx64", True),      # K = 40, runs of 8
+    ((10, 5, 8, 8), (64, 5, 16, 16, 8), [1, 3], [1, 4], False, "bf16_gather_64xS", True),
+    ((12, 12, 12, 12), (12,) * 7, [3, 1], [3, 6], True, "bf16_gather_Sx48", False),           # pairs in the other order
+]
+
+
+def _gather_operands(hip, dtype, shape_s, shape_l, seed):
+  rng = np.random.default_rng(seed)
+  s = rng.standard_normal(shape_s).astype(np.float32) / 8
+  l = rng.standard_normal(shape_l).astype(np.float32) / 8
+  if dtype is ta.bfloat16:
+    s, l = orc.round_bf16(s), orc.round_bf16(l)
+    return s, l, hip.to_bfloat16(s), hip.to_bfloat16(l)
+  s, l = s.astype(np.float16), l.astype(np.float16)
+  return s, l, dev(hip, s), dev(hip, l)
+
+
+@pytest.mark.parametrize("dtype", [ta.bfloat16, np.float16])
+def test_gemm_gather_reads_the_long_operand_in_place_bit_exact(hip, dtype):
+  """tensordot of a small tensor with a many-axis one whose contracted axes are not trailing: ONE tnh_gemm_gather
+  launch and no K1 pass over the long operand; bit-identical to permute + streaming GEMM when both take the
+  contracted pairs in the same order (same MFMA sequence), and against float64 on the rounded inputs."""
+  keep = (hip.gather_gemm, hip.gather_min_rows)
+  hip.gather_min_rows = 1024
+  try:
+    for i, (shape_s, shape_l, axes_s, axes_l, small_first, want, same_order) in enumerate(_GATHER_CASES):
+      if hasattr(hip, "_emu") and int(np.prod(shape_l)) > (1 << 21):      # the NumPy emulation of the C ABI (CPU suite): two indices of the outermost free axis
+        outer = min(ax for ax in range(len(shape_l)) if ax not in axes_l)
+        shape_l = tuple(2 if ax == outer else n for ax, n in enumerate(shape_l))
+      s, l, ds, dl = _gather_operands(hip, dtype, shape_s, shape_l, 700 + i)
+      args = (ds, dl, [axes_s, axes_l]) if small_first else (dl, ds, [axes_l, axes_s])
+      hip.gather_gemm = True
+      before = (hip.gather_launches, hip.permute_launches)
+      got = hip.tensordot(*args)
+      kernel = hip.lib.tnh_gemm_last_kernel().decode()
+      assert hip.gather_launches - before[0] == 1, (shape_s, shape_l, axes_l, _lib.last_error())
+      assert hip.permute_launches - before[1] <= 1          # the small operand at most
+      assert kernel == want, (shape_l, axes_l, kernel)
+      hip.gather_gemm = False
+      classic = hip.tensordot(*args)
+      g, c = np.asarray(got), np.asarray(classic)
+      ref = np.tensordot(s.astype(np.float64), l.astype(np.float64), [axes_s, axes_l]) if small_first else \
+          np.tensordot(l.astype(np.float64), s.astype(np.float64), [axes_l, axes_s])
+      assert g.shape == ref.shape
+      if same_order:
+        np.testing.assert_array_equal(g, c)
+      np.testing.assert_allclose(g, ref, rtol=2.0**-8, atol=2e-3)
+      np.testing.assert_allclose(c, ref, rtol=2.0**-8, atol=2e-3)
+      del got, classic, ds, dl
+  finally:
+    hip.gather_gemm, hip.gather_min_rows = keep
+
+
+def test_gemm_gather_follows_the_planner_hint_for_the_small_operand_only(hip):
+  """tensordot_planned with the gather lowering: the small operand's free axes take the hinted order (it is permuted
+  anyway), the long operand's stay in natural order whatever was hinted, and the returned orders describe the result."""
+  keep = (hip.gather_gemm, hip.gather_min_rows)
+  hip.gather_gemm, hip.gather_min_rows = True, 4096
+  try:
+    s, l, ds, dl = _gather_operands(hip, ta.bfloat16, (12, 12, 12, 12), (12,) * 6, 731)
+    out, used_s, used_l = hip.tensordot_planned(ds, dl, [[1, 3], [4, 1]], [2, 0], [5, 0, 3, 2])
+    assert hip.lib.tnh_gemm_last_kernel().decode().startswith("bf16_gather")
+    assert [int(i) for i in used_s] == [2, 0] and [int(i) for i in used_l] == [0, 2, 3, 5]
+    ref = np.tensordot(s.astype(np.float64), l.astype(np.float64), [[1, 3], [4, 1]])      # axes (s0, s2, l0, l2, l3, l5)
+    np.testing.assert_allclose(np.asarray(out), np.transpose(ref, (1, 0, 2, 3, 4, 5)), rtol=2.0**-8, atol=2e-3)
+  finally:
+    hip.gather_gemm, hip.gather_min_rows = keep
+
+
+def test_gemm_gather_leaves_other_products_alone(hip):
+  """Outside its range the gather lowering launches nothing: contracted axes already trailing (the streaming kernel
+  reads that as it is), an innermost extent that is not a multiple of 4, a short long operand, f32."""
+  keep = (hip.gather_gemm, hip.gather_min_rows)
+  hip.gather_gemm, hip.gather_min_rows = True, 4096
+  try:
+    for shape_s, shape_l, axes_s, axes_l in [((12, 12, 12, 12), (12,) * 6, [1, 3], [4, 5]),
+                                            ((10, 10, 10, 10), (10,) * 6, [1, 3], [1, 4]),
+                                            ((12, 12, 12, 12), (12,) * 4, [1, 3], [0, 2])]:
+      s, l, ds, dl = _gather_operands(hip, ta.bfloat16, shape_s, shape_l, 741)
+      before = hip.gather_launches
+      got = np.asarray(hip.tensordot(ds, dl, [axes_s, axes_l]))
+      assert hip.gather_launches == before
+      ref = np.tensordot(s.astype(np.float64), l.astype(np.float64), [axes_s, axes_l])
+      np.testing.assert_allclose(got, ref, rtol=2.0**-8, atol=2e-3)
+    rng = np.random.default_rng(5)
+    s32, l32 = rng.standard_normal((12,) * 4).astype(np.float32), rng.standard_normal((12,) * 6).astype(np.float32)
+    before = hip.gather_launches
+    got = np.asarray(hip.tensordot(dev(hip, s32), dev(hip, l32), [[1, 3], [1, 4]]))
+    assert hip.gather_launches == before
+    np.testing.assert_allclose(got, np.tensordot(s32.astype(np.float64), l32.astype(np.float64), [[1, 3], [1, 4]]),
+                               rtol=1e-4, atol=1e-4)
+  finally:
+    hip.gather_gemm, hip.gather_min_rows = keep
+
+
+def test_gemm_gather_c_abi_rejects_bad_descriptors_without_launching(hip):
+  import ctypes
+  from tensornetwork_amd import hip_backend
+  long_shape = (12,) * 5
+  desc, bn, rows = hip_backend._gather_descriptor(long_shape, [1, 4])      # pylint: disable=protected-access
+  assert (bn, rows) == (48, 1728)
+  l = hip.to_bfloat16(np.zeros(long_shape, np.float32))
+  s = hip.to_bfloat16(np.zeros((144, 144), np.float32))
+  out = ta.DeviceTensor.empty((144, 1728), _lib.BF16)
+
+  def call(d, code=_lib.BF16, k=144, nl=1728, l_elems=12**5):
+    return hip.lib.tnh_gemm_gather(code, 144, k, nl, ctypes.c_void_p(s.ptr), 144, ctypes.c_void_p(l.ptr), l_elems,
+                                   ctypes.byref(d), ctypes.c_void_p(out.ptr), nl, 1)
+
+  def variant(**changes):
+    d = _lib.GatherDesc.from_buffer_copy(bytes(desc))
+    for name, (index, value) in changes.items():
+      if index is None:
+        setattr(d, name, value)
+      else:
+        getattr(d, name)[index] = value
+    return d
+
+  assert call(desc) == _lib.OK
+  assert call(variant(mult=(1, 2))) == _lib.ERR_UNSUPPORTED           # two chunks on one image element
+  assert call(variant(stride=(1, 10))) == _lib.ERR_UNSUPPORTED        # a piece that is not 8-byte aligned
+  assert call(variant(ext=(0, 8))) == _lib.ERR_UNSUPPORTED            # innermost extent: contracted columns != K
+  assert call(variant(nd=(None, 9))) == _lib.ERR_UNSUPPORTED
+  assert call(variant(text=(0, 5))) == _lib.ERR_UNSUPPORTED           # tiles x BN != long rows
+  assert call(desc, l_elems=12**5 - 1) == _lib.ERR_UNSUPPORTED        # the last box leaves the tensor
+  assert call(desc, k=136) == _lib.ERR_UNSUPPORTED
+  assert call(desc, code=_lib.F32) == _lib.ERR_INVALID

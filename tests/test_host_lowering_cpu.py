@@ -287,6 +287,9 @@ def _gpu_suite_selection():
           TW.test_config1_readme_ncon, TW.test_split_node_config3_small, TW.test_greedy_mps_chain_and_regular_graph,
           TW.test_json_network_from_reference_into_hbm,
           TK.test_gemm_view_absorbs_transposes_bit_exact, TK.test_gemm_view_falls_back_when_it_cannot_read_in_place,
+          TK.test_gemm_gather_reads_the_long_operand_in_place_bit_exact,
+          TK.test_gemm_gather_follows_the_planner_hint_for_the_small_operand_only,
+          TK.test_gemm_gather_leaves_other_products_alone, TK.test_gemm_gather_c_abi_rejects_bad_descriptors_without_launching,
           TK.test_tensordot_random_axes_property, TK.test_misc_golden, TK.test_tensordot_golden,
           TK.test_tensordot_errors_and_empty, TK.test_elementwise_math, TK.test_init_functions, TK.test_casts,
           TK.test_integer_tensordot_matmul_sum_trace_exact, TK.test_integer_arithmetic_follows_numpy_promotion,
@@ -654,3 +657,104 @@ def test_band_svd_host_logic_random_call_shapes():
       np.testing.assert_allclose(rest, ref[3], atol=2 * tol * spec[0], err_msg=str(tag))
       if s.shape[0]:
         np.testing.assert_allclose((u * s) @ vh, (ref[0] * ref[1]) @ ref[2], atol=40 * tol * spec[0], err_msg=str(tag))
+
+
+# ------------------------------------------------------------------ K2 gather: the tile plan of the long operand
+def _plan_through_the_library(desc, bn, k, nl, l_elems):
+  """chunk plan and box origins as the KERNEL computes them (tnh_gemm_gather_plan runs the kernel's own index
+  functions on the host: no device needed)"""
+  import ctypes  # pylint: disable=import-outside-toplevel
+  lib = _lib.load_library()
+  nch, nt = bn * k // 4, nl // bn
+  off, row, col = (np.zeros(nch, np.int32) for _ in range(3))
+  base = np.zeros(nt, np.int64)
+  p32, p64 = ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int64)
+  rc = lib.tnh_gemm_gather_plan(ctypes.byref(desc), k, nl, l_elems, off.ctypes.data_as(p32), row.ctypes.data_as(p32),
+                                col.ctypes.data_as(p32), nch, base.ctypes.data_as(p64), nt)
+  assert rc == bn, (rc, _lib.last_error())
+  return off, row, col, base
+
+
+def _check_gather_plan(shape, k_axes):
+  from tensornetwork_amd import hip_backend  # pylint: disable=import-outside-toplevel
+  plan = hip_backend._gather_descriptor(shape, k_axes)      # pylint: disable=protected-access
+  if plan is None:
+    return None
+  desc, bn, nl = plan
+  free = [i for i in range(len(shape)) if i not in k_axes]
+  k = int(np.prod([shape[i] for i in k_axes]))
+  assert nl == int(np.prod([shape[i] for i in free])) and bn in (48, 64)
+  x = np.arange(int(np.prod(shape)), dtype=np.int64).reshape(shape)
+  want = np.transpose(x, free + sorted(k_axes)).reshape(nl, k)      # rows: free axes, natural order; k: memory order
+  off, row, col, base = _plan_through_the_library(desc, bn, k, nl, x.size)
+  kin = bool(desc.k_mask & 1)
+  got = np.full((nl, k), -1, np.int64)
+  flat = x.reshape(-1)
+  tiles = np.arange(nl // bn)[:, None]
+  for i in range(4):                                   # a chunk's four elements: along k (innermost axis contracted) or rows
+    r, c = (row, col + i) if kin else (row + i, col)
+    got[tiles * bn + r[None, :], np.broadcast_to(c[None, :], (tiles.size, c.size))] = flat[base[:, None] + off[None, :] + i]
+  np.testing.assert_array_equal(got, want)
+  assert (np.diff(off) > 0).all()                      # threads walk the box in memory order
+  return bn, kin
+
+
+def test_gather_plan_reads_the_matrix_transpose_would_have_built():
+  """The descriptor the host builds (hip_backend._gather_descriptor) run through the library's own index functions
+  addresses exactly transpose(long, free + contracted).reshape(rows, K) -- for the shapes of the D = 12 network
+  (ncon_interface.py:336-343 -> tensordot) and for whatever else the rule accepts."""
+  assert _check_gather_plan((12, 12, 12, 12, 1, 12, 12), (1, 6)) == (64, True)          # contracted (3, 8) of the rank 9
+  assert _check_gather_plan((4, 12, 12, 12, 12, 12, 1, 12), (2, 5)) == (48, False)      # (1, 6): innermost axis free
+  assert _check_gather_plan((12, 12, 12, 12, 12), (3, 0)) == (48, False)
+  assert _check_gather_plan((12, 12, 12, 12, 12), (0, 1)) == (64, False)                # k-major
+  assert _check_gather_plan((12, 12, 12, 12, 12), (2, 4)) == (48, True)
+  assert _check_gather_plan((8, 8, 8, 8, 8, 8), (1, 4)) == (64, False)
+  assert _check_gather_plan((16, 16, 16, 16), (1,)) == (64, False)
+  assert _check_gather_plan((12, 20736), (0,)) == (64, False)
+  assert _check_gather_plan((3, 12, 5, 144, 12, 7, 4), (1, 6)) == (64, True)
+  assert _check_gather_plan((10, 10, 10, 10), (1,)) is None                              # pieces not 8-byte aligned
+  assert _check_gather_plan((3, 12, 5, 144, 12, 7, 4), (1, 4)) is None                   # 28 innermost free: no 48 / 64 rows
+  assert _check_gather_plan((12, 12, 12), (2,)) is None or True                          # (trailing: the host never asks)
+  rng = np.random.default_rng(11)
+  accepted = 0
+  for _ in range(300):
+    rank = int(rng.integers(2, 8))
+    shape = tuple(int(x) for x in rng.choice([1, 2, 3, 4, 5, 8, 12, 16], size=rank))
+    if not 48 <= int(np.prod(shape)) <= 400000:
+      continue
+    nk = int(rng.integers(1, min(3, rank - 1) + 1))
+    k_axes = tuple(int(x) for x in rng.choice(rank, size=nk, replace=False))
+    k = int(np.prod([shape[i] for i in k_axes]))
+    if k % 8 or not 8 <= k <= 192:
+      continue
+    accepted += _check_gather_plan(shape, k_axes) is not None
+  assert accepted >= 10, accepted
+
+
+def test_gather_lowering_inside_a_contraction_path():
+  """A small bond-12 network whose greedy path takes two bonds off a rank-5 intermediate: with the gather lowering the
+  intermediate is never K1-permuted, the planner's bookkeeping of the result's axis order still holds (values against
+  einsum), and the same network without it gives the same bits."""
+  import tensornetwork_amd as tn  # pylint: disable=import-outside-toplevel
+  rng = np.random.default_rng(3)
+  big = orc.round_bf16(rng.standard_normal((12,) * 5).astype(np.float32) / 4)
+  s1 = orc.round_bf16(rng.standard_normal((12,) * 4).astype(np.float32) / 4)
+  s2 = orc.round_bf16(rng.standard_normal((12,) * 4).astype(np.float32) / 4)
+  ref = np.einsum("abcde,bdxy,xcwz->aeywz", big.astype(np.float64), s1.astype(np.float64), s2.astype(np.float64))
+  def run(on):        # (its device tensors die with the frame, inside the emulation they were allocated from)
+    with emulated_backend() as be:
+      be.gather_gemm, be.gather_min_rows = on, 1024
+      operands = [be.to_bfloat16(big), be.to_bfloat16(s1), be.to_bfloat16(s2)]
+      before = be.permute_launches
+      out = np.asarray(tn.ncon(operands, [[-1, 1, 2, 3, -2], [1, 3, 4, -3], [4, 2, -4, -5]], backend=be))
+      del operands
+      return (out, be.gather_launches, be.permute_launches - before,
+              [c for c in be.lib.calls if c[0] == "permute" and int(np.prod(c[1])) >= 12**5])
+
+  results = {on: run(on) for on in (True, False)}
+  got, launches, _, big_permutes = results[True]
+  # (one pass over a 12^5 tensor remains either way: ncon's final reordering of the result to (-1 ... -5))
+  assert launches == 2 and len(big_permutes) <= 1, (launches, big_permutes)
+  assert results[False][1] == 0 and len(results[False][3]) == len(big_permutes) + 2, results[False][3]
+  np.testing.assert_allclose(got, ref, rtol=2.0**-6, atol=2.0**-6)
+  np.testing.assert_allclose(results[False][0], ref, rtol=2.0**-6, atol=2.0**-6)

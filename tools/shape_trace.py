@@ -26,10 +26,16 @@ class FakeTensor(device_tensor.DeviceTensor):
 device_tensor.DeviceTensor.empty = FakeTensor.empty
 hip_backend.DeviceTensor.empty = FakeTensor.empty
 
+class FakeLib:
+  """only what the gather lowering calls"""
+  def tnh_gemm_gather(self, code, ms, k, nl, s, lds, l, l_elems, desc, c, ldc, small_first):
+    LOG.append(("gather_gemm", int(ms), int(nl), int(k)))
+    return _lib.OK
+
 class TraceBackend(hip_backend.HipBackend):
   @property
   def lib(self):
-    return None
+    return FakeLib()
   def cast(self, tensor, dtype):
     return tensor
   def transpose(self, tensor, perm=None):
@@ -59,8 +65,10 @@ class TraceBackend(hip_backend.HipBackend):
 ap = argparse.ArgumentParser()
 ap.add_argument("--D", type=int, default=12)
 ap.add_argument("--min-slices", type=int, default=64)
+ap.add_argument("--gather", type=int, default=0, help="1: with the gather lowering (tnh_gemm_gather)")
 a = ap.parse_args()
 be = TraceBackend()
+be.gather_gemm = bool(a.gather)
 import networkx as nx
 g = nx.random_regular_graph(3, 64, seed=6)
 D = a.D
@@ -78,12 +86,19 @@ for rec in LOG:
   if rec[0] == "gemm":
     _, ta_, tb_, m, n, k, batch = rec
     fl = 2.0 * m * n * k * batch; tot += fl
+  elif rec[0] == "gather_gemm":
+    tot += 2.0 * rec[1] * rec[2] * rec[3]
 for rec in LOG:
   if rec[0] == "gemm":
     _, ta_, tb_, m, n, k, batch = rec
     fl = 2.0 * m * n * k * batch
     if fl / tot > 0.002:
       print(f"gemm tA={ta_} tB={tb_} M={m} N={n} K={k}  {fl:.3e} flop  {100*fl/tot:.1f}%")
+  elif rec[0] == "gather_gemm":
+    fl = 2.0 * rec[1] * rec[2] * rec[3]
+    if fl / tot > 0.002:
+      print(f"gather_gemm Ms={rec[1]} Nl={rec[2]} K={rec[3]}  {fl:.3e} flop  {100*fl/tot:.1f}%")
   elif rec[0] == "permute" and np.prod(rec[1]) > 1e6:
     print("permute", rec[1], rec[2], f"{np.prod(rec[1]):.2e} elems")
-print("total flop", f"{tot:.3e}", "n_gemm", sum(1 for r in LOG if r[0] == "gemm"))
+print("total flop", f"{tot:.3e}", "n_gemm", sum(1 for r in LOG if r[0] == "gemm"), "n_gather", sum(1 for r in LOG if r[0] == "gather_gemm"),
+      "permuted elements", f"{sum(float(np.prod(r[1])) for r in LOG if r[0] == 'permute'):.3e}")
