@@ -27,26 +27,77 @@
 //
 // Roofline: HBM.  Algorithmic bytes 2 * (Nl * K + Ms * K + Ms * Nl).
 #include "tnh_gemm_nt.h"
+#include <mutex>
 
 namespace tnh {
 
 // ---- descriptor arithmetic shared by the kernel, the host-side validation and tnh_gemm_gather_plan
-__host__ __device__ __forceinline__ void gather_chunk(const tnh_gather_desc& g, unsigned e, int& off, int& row,
-                                                      int& kcol) {
-  off = 0;
-  row = 0;
-  kcol = 0;
+// Chunk e of a box (8 bytes: four elements of the innermost digit), e counted in memory order: e written in the
+// mixed radix of the box digits gives the digit indices, hence the element offset in the box and the image position.
+// A thread owns chunks tid, tid + 256, tid + 512, ...: tid is decoded with one division per digit, the step of
+// 256 is added digit by digit with carries afterwards (the divisions of a direct decode of every chunk were ~10 us
+// of prologue per launch: profiles/r04_gather_gemm.md).  Chunks past the end of the box repeat the last one.
+template <int NB>
+__host__ __device__ __forceinline__ void gather_thread_chunks(const tnh_gather_desc& g, int tid, int total,
+                                                              int (&off)[NB], int (&row)[NB], int (&kcol)[NB]) {
+  unsigned radix[TNH_GATHER_MAX_DIGITS], digit[TNH_GATHER_MAX_DIGITS], step[TNH_GATHER_MAX_DIGITS];
+  {
+    unsigned e = (unsigned)tid, inc = 256u;
+#pragma unroll
+    for (int d = 0; d < TNH_GATHER_MAX_DIGITS; ++d) {
+      // digits the box does not have count modulo 1 (always 0, carries fall through); the top digit is unbounded
+      radix[d] = 1u;
+      digit[d] = 0u;
+      step[d] = 0u;
+      if (d < g.nd) {
+        const unsigned ext = d == 0 ? (unsigned)g.ext[0] >> 2 : (unsigned)g.ext[d];
+        radix[d] = ext;
+        const unsigned qe = e / ext, qi = inc / ext;
+        digit[d] = e - qe * ext;
+        step[d] = inc - qi * ext;
+        e = qe;
+        inc = qi;
+      }
+    }
+  }
+  int last_off = 0, last_row = 0, last_k = 0;     // chunk total - 1: every digit at its maximum
 #pragma unroll
   for (int d = 0; d < TNH_GATHER_MAX_DIGITS; ++d) {
     if (d < g.nd) {
-      const unsigned ext = d == 0 ? (unsigned)g.ext[0] >> 2 : (unsigned)g.ext[d];
-      const unsigned q = e / ext;
-      unsigned r = e - q * ext;
-      if (d == 0) r <<= 2;
-      off += (int)r * g.stride[d];
-      if ((g.k_mask >> d) & 1) kcol += (int)r * g.mult[d];
-      else row += (int)r * g.mult[d];
-      e = q;
+      const int top = d == 0 ? g.ext[0] - 4 : g.ext[d] - 1;
+      last_off += top * g.stride[d];
+      if ((g.k_mask >> d) & 1) last_k += top * g.mult[d];
+      else last_row += top * g.mult[d];
+    }
+  }
+#pragma unroll
+  for (int it = 0; it < NB; ++it) {
+    if (it * 256 + tid >= total) {
+      off[it] = last_off;
+      row[it] = last_row;
+      kcol[it] = last_k;
+    } else {
+      int o = 0, r = 0, k = 0;
+#pragma unroll
+      for (int d = 0; d < TNH_GATHER_MAX_DIGITS; ++d) {
+        if (d < g.nd) {
+          const int idx = d == 0 ? (int)(digit[0] << 2) : (int)digit[d];
+          o += idx * g.stride[d];
+          if ((g.k_mask >> d) & 1) k += idx * g.mult[d];
+          else r += idx * g.mult[d];
+        }
+      }
+      off[it] = o;
+      row[it] = r;
+      kcol[it] = k;
+    }
+    unsigned carry = 0;                            // next chunk of this thread: + 256 in the mixed radix
+#pragma unroll
+    for (int d = 0; d < TNH_GATHER_MAX_DIGITS; ++d) {
+      unsigned v = digit[d] + step[d] + carry;
+      carry = v >= radix[d] ? 1u : 0u;
+      if (carry) v -= radix[d];
+      digit[d] = v;
     }
   }
 }
@@ -110,25 +161,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   // ---- this thread's chunks of a box: (offset in the box, image position) is the same for every tile
   int loff[NB], lsm[NB];
   {
-    const int total = BN * (K >> 2);
+    int crow[NB], ccol[NB];
+    gather_thread_chunks<NB>(p.g, tid, BN * (K >> 2), loff, crow, ccol);
 #pragma unroll
-    for (int it = 0; it < NB; ++it) {
-      int e = it * 256 + tid;
-      if (e >= total) e = total - 1;              // duplicates of the last chunk: same address, same data
-      int off, row, kcol;
-      gather_chunk(p.g, (unsigned)e, off, row, kcol);
-      loff[it] = off;
-      lsm[it] = row * PA + kcol * 2;
-    }
+    for (int it = 0; it < NB; ++it) lsm[it] = crow[it] * PA + ccol[it] * 2;
   }
-  uint2 rl[NB];
-  auto load_long = [&](int tile) {
+  // Two tiles of prefetch in registers (the streaming kernel keeps one): a box is 14 - 18 KB, and one box per
+  // workgroup in flight is 7 - 9 MB over the chip -- less than HBM latency x rate (measured: 48-row boxes at
+  // 2.6 TB/s with one, see profiles/r04_gather_gemm.md).
+  uint2 rl0[NB], rl1[NB];
+  auto load_long = [&](int tile, uint2 (&rl)[NB]) {
     const uint16_t* base = p.L + gather_tile_base(p.g, tile);
 #pragma unroll
     for (int it = 0; it < NB; ++it) rl[it] = *(const uint2*)(base + loff[it]);
   };
   const int padch = cpr - kch;                     // 16-B chunks of zero k-padding per image row (0 ... 3)
-  auto store_long = [&]() {
+  auto store_long = [&](const uint2 (&rl)[NB]) {
 #pragma unroll
     for (int it = 0; it < NB; ++it) {
       if constexpr (KIN) {
@@ -172,15 +220,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
   const int frag_row = lane & 15, frag_chk = lane >> 4;
   const int last = p.ntiles - 1;
-  int tile = blockIdx.x;                       // the host launches at most ntiles workgroups
-  load_long(tile);
-  store_long();
+  const int step = (int)gridDim.x;             // the host launches at most ntiles workgroups
 
-  for (; tile <= last; tile += (int)gridDim.x) {
+  // One tile: `hold` has the NEXT tile's box (requested one body earlier), `fill` takes the one after it.  The image
+  // of the next tile is written at the END of the body, right after this tile's stores were issued: there the wait
+  // for `hold` has one predecessor path with static counts (the loads into `fill`, then NST stores: all younger).
+  auto body = [&](int tile, uint2 (&hold)[NB], uint2 (&fill)[NB]) {
     __syncthreads();                            // long image (and, first time, the small image) complete
     {
-      const int next = tile + (int)gridDim.x;
-      load_long(next <= last ? next : last);   // in flight during the MFMA work and the epilogue
+      const int far = tile + 2 * step;
+      load_long(far <= last ? far : last, fill);   // in flight during this tile and the next
     }
 
     f32x4 acc[MAX_MI][FN];
@@ -239,7 +288,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       }
     }
     __syncthreads();                            // staging consumed: R takes the next long image
-    store_long();
+    store_long(hold);
+  };
+
+  int tile = blockIdx.x;
+  load_long(tile, rl0);
+  store_long(rl0);
+  load_long(tile + step <= last ? tile + step : last, rl0);
+  for (;;) {
+    body(tile, rl0, rl1);
+    tile += step;
+    if (tile > last) break;
+    body(tile, rl1, rl0);
+    tile += step;
+    if (tile > last) break;
   }
 }
 
@@ -279,20 +341,56 @@ static int gather_validate(const tnh_gather_desc& g, int64_t K, int64_t Nl, int6
   const bool kin = g.k_mask & 1;
   unsigned char seen[64 * 48];
   memset(seen, 0, sizeof(seen));
-  for (int e = 0; e < total; ++e) {
-    int off, row, kcol;
-    gather_chunk(g, (unsigned)e, off, row, kcol);
-    if (off < 0 || off > span || row < 0 || kcol < 0) { *why = "chunk out of the box"; return 0; }
-    for (int i = 0; i < 4; ++i) {
-      const int r = kin ? row : row + i, c = kin ? kcol + i : kcol;
-      if (r >= rows || c >= K) { *why = "chunk leaves the image"; return 0; }
-      unsigned char& cell = seen[r * 48 + (c >> 2)];
-      const unsigned char bit = (unsigned char)(1u << (c & 3));
-      if (cell & bit) { *why = "two chunks write one image element"; return 0; }
-      cell |= bit;
+  for (int tid = 0; tid < 256; ++tid) {
+    int coff[12], crow[12], ccol[12];
+    gather_thread_chunks<12>(g, tid, total, coff, crow, ccol);      // the kernel's own decode, thread by thread
+    for (int it = 0; it < 12 && it * 256 + tid < total; ++it) {
+      const int off = coff[it], row = crow[it], kcol = ccol[it];
+      if (off < 0 || off > span || row < 0 || kcol < 0) { *why = "chunk out of the box"; return 0; }
+      for (int i = 0; i < 4; ++i) {
+        const int r = kin ? row : row + i, c = kin ? kcol + i : kcol;
+        if (r >= rows || c >= K) { *why = "chunk leaves the image"; return 0; }
+        unsigned char& cell = seen[r * 48 + (c >> 2)];
+        const unsigned char bit = (unsigned char)(1u << (c & 3));
+        if (cell & bit) { *why = "two chunks write one image element"; return 0; }
+        cell |= bit;
+      }
     }
   }
   return (int)rows;
+}
+
+// The check costs ~0.1 ms of host time and a contraction path asks for the same few descriptors slice after slice:
+// the last 32 accepted (descriptor, K, Nl, elements) are remembered.
+static int gather_validate_cached(const tnh_gather_desc& g, int64_t K, int64_t Nl, int64_t l_elems, const char** why) {
+  struct Entry {
+    tnh_gather_desc g;
+    int64_t K, Nl, l_elems;
+    int bn;
+  };
+  static std::mutex mu;
+  static Entry seen[32];
+  static int count = 0, next = 0;
+  *why = nullptr;
+  {
+    std::lock_guard<std::mutex> lock(mu);
+    for (int i = 0; i < count; ++i)
+      if (seen[i].K == K && seen[i].Nl == Nl && seen[i].l_elems == l_elems && !memcmp(&seen[i].g, &g, sizeof(g)))
+        return seen[i].bn;
+  }
+  const int bn = gather_validate(g, K, Nl, l_elems, why);
+  if (bn) {
+    std::lock_guard<std::mutex> lock(mu);
+    Entry& e = seen[next];
+    e.g = g;
+    e.K = K;
+    e.Nl = Nl;
+    e.l_elems = l_elems;
+    e.bn = bn;
+    next = (next + 1) % 32;
+    if (count < 32) ++count;
+  }
+  return bn;
 }
 
 static bool gather_enabled() {
@@ -345,7 +443,7 @@ int gemm_gather(int dtype, int64_t Ms, int64_t K, int64_t Nl, const void* S, int
                         lds % 8 == 0 && ldc % 8 == 0 && lds >= K && ((uintptr_t)S % 16) == 0 &&
                         ((uintptr_t)L % 8) == 0 && ((uintptr_t)C % 16) == 0 && (!swap || Ms % 8 == 0) &&
                         ldc >= (swap ? Ms : Nl);
-  if (shape_ok) bn = gather_validate(*desc, K, Nl, l_elems, &why);
+  if (shape_ok) bn = gather_validate_cached(*desc, K, Nl, l_elems, &why);
   if (shape_ok && bn && (swap ? (int64_t)bn * ldc : Ms * ldc) >= (int64_t(1) << 30)) {
     bn = 0;
     why = "32-bit offsets inside one output tile";
@@ -393,12 +491,16 @@ int gemm_gather_plan(const tnh_gather_desc* desc, int64_t K, int64_t Nl, int64_t
   const int64_t total = (int64_t)bn * (K >> 2);
   TNH_REQUIRE(nchunks >= 0 && nchunks <= total && ntiles >= 0 && ntiles <= Nl / bn,
               "tnh_gemm_gather_plan: more chunks / tiles asked than there are");
-  for (int64_t e = 0; e < nchunks; ++e) {
-    int off, row, kcol;
-    gather_chunk(*desc, (unsigned)e, off, row, kcol);
-    chunk_off[e] = off;
-    chunk_row[e] = row;
-    chunk_k[e] = kcol;
+  for (int tid = 0; tid < 256; ++tid) {
+    int coff[12], crow[12], ccol[12];
+    gather_thread_chunks<12>(*desc, tid, (int)total, coff, crow, ccol);
+    for (int it = 0; it < 12; ++it) {
+      const int64_t e = (int64_t)it * 256 + tid;
+      if (e >= nchunks) break;
+      chunk_off[e] = coff[it];
+      chunk_row[e] = crow[it];
+      chunk_k[e] = ccol[it];
+    }
   }
   for (int64_t t = 0; t < ntiles; ++t) tile_base[t] = gather_tile_base(*desc, (int)t);
   return bn;

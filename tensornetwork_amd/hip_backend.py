@@ -206,6 +206,17 @@ def _gather_descriptor(shape, k_axes):
   return desc, bn, rows
 
 
+def _gather_piece_bytes(desc, itemsize=2):
+  """bytes of the contiguous pieces of memory a box is made of (its leading digits while each starts where the
+  one before ends)"""
+  run = 1
+  for d in range(desc.nd):
+    if desc.stride[d] != run:
+      break
+    run *= desc.ext[d]
+  return run * itemsize
+
+
 class HipBackend(BackendBase):
   """TensorNetwork backend running on one MI355X through libtnhip.so.
 
@@ -242,6 +253,7 @@ class HipBackend(BackendBase):
     # intermediate where it lies (tnh_gemm_gather) instead of K1-permuting it first.  TNH_GATHER_GEMM=0/1.
     self.gather_gemm = os.environ.get("TNH_GATHER_GEMM", "0") == "1"
     self.gather_min_rows = 1 << 16
+    self.gather_min_piece_bytes = int(os.environ.get("TNH_GATHER_MIN_PIECE", "0"))
     self.gather_launches = 0     # tnh_gemm_gather launches
     self.permutes_absorbed = 0   # tnh_gemm_view launches
     self.permute_launches = 0    # K1 launches (transpose)
@@ -584,7 +596,7 @@ class HipBackend(BackendBase):
   def tensordot(self, a, b, axes):
     return self._tensordot_impl(a, b, axes, None, None)[0]
 
-  def tensordot_planned(self, a, b, axes, free_order_a=None, free_order_b=None):
+  def tensordot_planned(self, a, b, axes, free_order_a=None, free_order_b=None, allow_swap=False):
     """``tensordot`` whose result may carry the free axes of an operand in a caller-chosen order
     -- but only where that is FREE: an operand that needs a K1 permute anyway (its contracted axes
     are neither leading nor trailing) is permuted straight into ``free_order_x + contracted``;
@@ -592,10 +604,16 @@ class HipBackend(BackendBase):
     with the free axes of ``a`` / ``b`` in result order.  The contractors use it to lay a big
     intermediate out for the NEXT contractions while they pay for the current permute
     (tensornetwork_amd.contractors.contract_path): permutes are HBM-bound, skipping one saves
-    2 x bytes of traffic."""
-    return self._tensordot_impl(a, b, axes, free_order_a, free_order_b)
+    2 x bytes of traffic.
 
-  def _tensordot_impl(self, a, b, axes, hint_a, hint_b):
+    ``allow_swap=True`` (callers for whom the axis order of the result is bookkeeping) returns a fourth value
+    ``swapped``: when true the result carries ``b``'s free axes FIRST, then ``a``'s -- the gather lowering writes
+    [long operand's axes..., small operand's axes] whichever operand the long one is, because that output tile is
+    one contiguous block of memory."""
+    out = self._tensordot_impl(a, b, axes, free_order_a, free_order_b, allow_swap)
+    return out if allow_swap else out[:3]
+
+  def _tensordot_impl(self, a, b, axes, hint_a, hint_b, allow_swap=False):
     """c[free_a..., free_b...] = sum_axes a*b (abstract_backend.py:27-38).
 
     Lowered as transpose + reshape + ONE GEMM (the reference's own spec for this
@@ -621,23 +639,23 @@ class HipBackend(BackendBase):
     nc = len(axes_a)
     if nc == 0:
       out_shape = tuple(a.shape[i] for i in free_a) + tuple(b.shape[i] for i in free_b)
-      return self._outer(self._dense(a), self._dense(b), out_shape, alias), free_a, free_b
+      return self._outer(self._dense(a), self._dense(b), out_shape, alias), free_a, free_b, False
 
     # bf16 / f16, enough 256 x 256 tiles: read BOTH operands in place through two-level strides
     # (K8 lowering of tensordot2.py:62-88 -- transposes are absorbed by the GEMM loaders, no K1 launch).
     if code in _HALF and self.gather_gemm and self.half_output == "same":
-      got = self._tensordot_gather(a, b, axes_a, axes_b, free_a, free_b, m, n, k, hint_a, hint_b)
+      got = self._tensordot_gather(a, b, axes_a, axes_b, free_a, free_b, m, n, k, hint_a, hint_b, allow_swap)
       if got is not None:
-        out, used_a, used_b = got
-        out_shape = tuple(a.shape[i] for i in used_a) + tuple(b.shape[i] for i in used_b)
-        return out.view(out_shape), used_a, used_b
+        out, used_a, used_b, swapped = got
+        shape_a, shape_b = tuple(a.shape[i] for i in used_a), tuple(b.shape[i] for i in used_b)
+        return out.view(shape_b + shape_a if swapped else shape_a + shape_b), used_a, used_b, swapped
     if code in _HALF and self.absorb_transposes:
       a_shape0, b_shape0 = a.shape, b.shape
       got = self._tensordot_in_place(a, b, axes_a, axes_b, free_a, free_b, m, n, k, hint_a, hint_b)
       if got is not None:
         out, used_a, used_b = got
         out_shape = tuple(a_shape0[i] for i in used_a) + tuple(b_shape0[i] for i in used_b)
-        return out.view(out_shape), used_a, used_b
+        return out.view(out_shape), used_a, used_b, False
     a, b = self._dense(a), self._dense(b)
 
     # memory order of the contracted pairs on each side
@@ -691,22 +709,27 @@ class HipBackend(BackendBase):
     lda = m if trans_a else k
     ldb = k if trans_b else n
     if code in _REAL_OF and 8 * m * n * k >= (1 << 18):
-      return self._complex_gemm(a, b, trans_a, trans_b, m, n, k).view(out_shape), free_a, free_b
+      return self._complex_gemm(a, b, trans_a, trans_b, m, n, k).view(out_shape), free_a, free_b, False
     out = self._gemm(a, b, trans_a, trans_b, m, n, k, lda, ldb, alias=alias)
-    return out.view(out_shape), free_a, free_b
+    return out.view(out_shape), free_a, free_b, False
 
-  def _tensordot_gather(self, a, b, axes_a, axes_b, free_a, free_b, m, n, k, hint_a=None, hint_b=None):
+  def _tensordot_gather(self, a, b, axes_a, axes_b, free_a, free_b, m, n, k, hint_a=None, hint_b=None,
+                        allow_swap=False):
     """One `tnh_gemm_gather` launch for a SMALL operand (65 ... 192 free tuples, K <= 192) against a long
     many-axis tensor whose contracted axes are not trailing, or None (the caller's permute + GEMM lowering
     runs; results are bit-identical either way).  The long tensor is read where it lies, so its free axes
     come out in natural order whatever the planner hinted -- the NEXT contraction gathers it again instead
     of finding it laid out; only the small operand is permuted (to [free, contracted in the long tensor's
-    memory order]).  Returns (tensor, used_free_a, used_free_b)."""
+    memory order]).  With `allow_swap` the result is [long operand's axes..., small operand's axes] whichever
+    operand the long one is: an output tile is then one contiguous block of 14 - 18 KB instead of Ms row
+    segments of 96 / 128 bytes (measured: profiles/r04_gather_gemm.md).
+    Returns (tensor, used_free_a, used_free_b, swapped)."""
     small_first = m <= n
     ms, nl = (m, n) if small_first else (n, m)
     if not (64 < ms <= 192 and 16 <= k <= 192 and k % 8 == 0 and nl >= self.gather_min_rows):
       return None
-    if not small_first and ms % 8:
+    long_rows_first = not small_first or (allow_swap and ms % 8 == 0)     # C[Nl, Ms]: the kernel's "swap" form
+    if long_rows_first and ms % 8:
       return None
     small, long_ = (a, b) if small_first else (b, a)
     axes_s, axes_l = (axes_a, axes_b) if small_first else (axes_b, axes_a)
@@ -721,7 +744,7 @@ class HipBackend(BackendBase):
     if plan is None:
       return None
     desc, _, rows = plan
-    if rows != nl:
+    if rows != nl or _gather_piece_bytes(desc, long_.itemsize) < self.gather_min_piece_bytes:
       return None
     order = sorted(range(nc), key=lambda i: axes_l[i])       # the long tensor's memory order of the contracted pairs
     used_s = list(free_s)
@@ -730,12 +753,13 @@ class HipBackend(BackendBase):
     small = self.transpose(self._dense(small), used_s + [axes_s[i] for i in order])
     if small.ptr % 16:
       return None
-    out = DeviceTensor.empty((ms, nl) if small_first else (nl, ms), long_.code)
+    out = DeviceTensor.empty((nl, ms) if long_rows_first else (ms, nl), long_.code)
     events = getattr(self, "gemm_events", None)
     if events is not None:
       start = _lib.Event().record()
     status = self.lib.tnh_gemm_gather(long_.code, ms, k, nl, _vp(small), k, _vp(long_), long_.size,
-                                      ctypes.byref(desc), _vp(out), nl if small_first else ms, 1 if small_first else 0)
+                                      ctypes.byref(desc), _vp(out), ms if long_rows_first else nl,
+                                      0 if long_rows_first else 1)
     if status == _lib.ERR_UNSUPPORTED:
       return None     # (a forced A/B variant, TNH_GEMM_GATHER=0, or an alignment rule: nothing was launched)
     _lib.check(status, "tnh_gemm_gather")
@@ -743,7 +767,9 @@ class HipBackend(BackendBase):
       events.append((start, _lib.Event().record()))
     self.gather_launches += 1
     used_l = sorted(free_l)
-    return (out, used_s, used_l) if small_first else (out, used_l, used_s)
+    if small_first:
+      return out, used_s, used_l, long_rows_first       # (swapped: b's axes, the long operand's, come first)
+    return out, used_l, used_s, False
 
   def _tensordot_in_place(self, a, b, axes_a, axes_b, free_a, free_b, m, n, k, hint_a=None, hint_b=None):
     """One `tnh_gemm_view` launch that reads the operands as they lie in HBM wherever that pays, or None

@@ -188,9 +188,9 @@ class _Engine:
         ax1 = [l1.index(l) for l in closing]
         ax2 = [l2.index(l) for l in closing]
         order = sorted(range(len(ax1)), key=lambda n: ax1[n])
-        result, u1, u2 = be.tensordot_planned(t1, t2, (tuple(ax1[n] for n in order), tuple(ax2[n] for n in order)),
-                                              o1, o2)
-        new_labels = [l1[n] for n in u1] + [l2[n] for n in u2]
+        result, u1, u2, swapped = be.tensordot_planned(t1, t2, (tuple(ax1[n] for n in order), tuple(ax2[n] for n in order)),
+                                                       o1, o2, allow_swap=True)
+        new_labels = [l2[n] for n in u2] + [l1[n] for n in u1] if swapped else [l1[n] for n in u1] + [l2[n] for n in u2]
         self.ops.append((result, new_labels))
         return closing
       if closing:

@@ -603,9 +603,13 @@ def contract_between(node1: Node, node2: Node, name: Optional[str] = None,
         node1, node2, axes1, axes2, order1, order2 = node2, node1, axes2, axes1, order2, order1
         pairs = sorted(zip(axes1, axes2))
         axes1, axes2 = [p[0] for p in pairs], [p[1] for p in pairs]
-      t, used1, used2 = be.tensordot_planned(node1.tensor, node2.tensor, [axes1, axes2], order1, order2)
+      # (the axis order of the result is bookkeeping here: the backend may put node2's axes first)
+      t, used1, used2, swapped = be.tensordot_planned(node1.tensor, node2.tensor, [axes1, axes2], order1, order2,
+                                                      allow_swap=True)
       out = Node(t, name=name, backend=be)
       sources = [(node1, i) for i in used1] + [(node2, i) for i in used2]
+      if swapped:
+        sources = sources[len(used1):] + sources[:len(used1)]
     else:
       t = be.tensordot(node1.tensor, node2.tensor, [axes1, axes2])
       out = Node(t, name=name, backend=be)

@@ -29,7 +29,9 @@ hip_backend.DeviceTensor.empty = FakeTensor.empty
 class FakeLib:
   """only what the gather lowering calls"""
   def tnh_gemm_gather(self, code, ms, k, nl, s, lds, l, l_elems, desc, c, ldc, small_first):
-    LOG.append(("gather_gemm", int(ms), int(nl), int(k)))
+    d = desc._obj
+    LOG.append(("gather_gemm", int(ms), int(nl), int(k), hip_backend._gather_piece_bytes(d), bool(d.k_mask & 1),
+                int(np.prod([d.ext[i] for i in range(d.nd) if not (d.k_mask >> i) & 1]))))
     return _lib.OK
 
 class TraceBackend(hip_backend.HipBackend):
@@ -97,7 +99,8 @@ for rec in LOG:
   elif rec[0] == "gather_gemm":
     fl = 2.0 * rec[1] * rec[2] * rec[3]
     if fl / tot > 0.002:
-      print(f"gather_gemm Ms={rec[1]} Nl={rec[2]} K={rec[3]}  {fl:.3e} flop  {100*fl/tot:.1f}%")
+      print(f"gather_gemm Ms={rec[1]} Nl={rec[2]} K={rec[3]}  {fl:.3e} flop  {100*fl/tot:.1f}%  pieces of {rec[4]} B, "
+            f"innermost axis {'contracted' if rec[5] else 'free'}, BN {rec[6]}")
   elif rec[0] == "permute" and np.prod(rec[1]) > 1e6:
     print("permute", rec[1], rec[2], f"{np.prod(rec[1]):.2e} elems")
 print("total flop", f"{tot:.3e}", "n_gemm", sum(1 for r in LOG if r[0] == "gemm"), "n_gather", sum(1 for r in LOG if r[0] == "gather_gemm"),
