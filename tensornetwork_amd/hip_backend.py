@@ -250,10 +250,14 @@ class HipBackend(BackendBase):
     self.pad_min_bytes = int(os.environ.get("TNH_PAD_MIN_BYTES", str(2 << 30)))
     self.inplace_max_bytes = int(os.environ.get("TNH_VIEW_INPLACE_MAX_BYTES", str(2 << 30)))
     # bf16 / f16 tensordot of a small tensor with a many-axis intermediate: the streaming GEMM gathers the
-    # intermediate where it lies (tnh_gemm_gather) instead of K1-permuting it first.  TNH_GATHER_GEMM=0/1.
-    self.gather_gemm = os.environ.get("TNH_GATHER_GEMM", "0") == "1"
+    # intermediate where it lies (tnh_gemm_gather) instead of K1-permuting it first (TNH_GATHER_GEMM=0: off).
+    # Measured per product (profiles/r04_gather_gemm.md): 1.4 - 2.4 x faster than permute + streaming GEMM for
+    # every placement of the contracted axes.  Inside a PLANNED path (contractors, ncon) a box made of pieces
+    # shorter than `gather_min_piece_bytes` keeps the classic lowering: there the K1 pass also lays the operand
+    # out for the contractions that follow (one permute serves two products of the D = 12 network).
+    self.gather_gemm = os.environ.get("TNH_GATHER_GEMM", "1") != "0"
     self.gather_min_rows = 1 << 16
-    self.gather_min_piece_bytes = int(os.environ.get("TNH_GATHER_MIN_PIECE", "0"))
+    self.gather_min_piece_bytes = int(os.environ.get("TNH_GATHER_MIN_PIECE", "256"))
     self.gather_launches = 0     # tnh_gemm_gather launches
     self.permutes_absorbed = 0   # tnh_gemm_view launches
     self.permute_launches = 0    # K1 launches (transpose)
@@ -744,7 +748,8 @@ class HipBackend(BackendBase):
     if plan is None:
       return None
     desc, _, rows = plan
-    if rows != nl or _gather_piece_bytes(desc, long_.itemsize) < self.gather_min_piece_bytes:
+    planned = allow_swap or hint_a is not None or hint_b is not None
+    if rows != nl or (planned and _gather_piece_bytes(desc, long_.itemsize) < self.gather_min_piece_bytes):
       return None
     order = sorted(range(nc), key=lambda i: axes_l[i])       # the long tensor's memory order of the contracted pairs
     used_s = list(free_s)

@@ -67,7 +67,7 @@ class TraceBackend(hip_backend.HipBackend):
 ap = argparse.ArgumentParser()
 ap.add_argument("--D", type=int, default=12)
 ap.add_argument("--min-slices", type=int, default=64)
-ap.add_argument("--gather", type=int, default=0, help="1: with the gather lowering (tnh_gemm_gather)")
+ap.add_argument("--gather", type=int, default=1, help="0: without the gather lowering (tnh_gemm_gather)")
 a = ap.parse_args()
 be = TraceBackend()
 be.gather_gemm = bool(a.gather)
