@@ -989,6 +989,84 @@ def load_traffic(kernel_name, M, N, K):
   return None, None
 
 
+GATHER_CASES = {     # contracted axes of the rank-8 long tensor (bond D): where they sit decides what a box looks like
+    "k37_innermost_contracted_free_run_1728": [3, 7],
+    "k47_innermost_contracted_free_run_144": [4, 7],
+    "k16_innermost_free_contracted_right_above": [1, 6],
+    "k15_two_innermost_free": [1, 5],
+    "k01_k_major": [0, 1],
+}
+
+
+def gather_gemm_bench(ta, be, verify, D=12, rank=8, reps=5, cases=None):
+  """A D x D x D x D tensor takes two bonds off a rank-8 intermediate (D = 12: 430 M elements, the 144 x 2 985 984
+  x 144 products of the north-star network): `tnh_gemm_gather` reading the intermediate where it lies against the
+  classic lowering (K1 permute + streaming GEMM), both operand orders, whole-call microseconds (host side included).
+  Results are compared on the device: same MFMA sequence per element, so the difference must be exactly zero."""
+  from tensornetwork_amd import hip_backend  # pylint: disable=import-outside-toplevel
+  long_shape = (D,) * rank
+  small = be.device_random((D, D, D, D), dtype=ta.bfloat16, seed=1, normal=True, a=0.0, b=0.1)
+  long_ = be.device_random(long_shape, dtype=ta.bfloat16, seed=2, normal=True, a=0.0, b=0.1)
+  nbytes = 2 * (D**rank + D * D * D**(rank - 2) + D**4)     # read the long operand and the small one, write the result
+  keep = (be.gather_gemm, be.gather_min_rows)
+  be.gather_min_rows = min(be.gather_min_rows, D**(rank - 2))
+
+  def timed(fn):
+    out = fn()
+    del out
+    be.synchronize()
+    best = float("inf")
+    for _ in range(3):
+      t0 = time.perf_counter()
+      for _ in range(reps):
+        out = fn()
+        del out
+      be.synchronize()
+      best = min(best, (time.perf_counter() - t0) / reps)
+    return best
+
+  rows, all_exact = [], True
+  try:
+    for name, axes_l in (cases or GATHER_CASES).items():
+      plan = hip_backend._gather_descriptor(long_shape, axes_l)      # pylint: disable=protected-access
+      row = {"case": name, "contracted_axes": axes_l,
+             "box": None if plan is None else {"rows": plan[1], "piece_bytes": hip_backend._gather_piece_bytes(plan[0]),  # pylint: disable=protected-access
+                                               "innermost_axis_contracted": bool(plan[0].k_mask & 1)}}
+      for orient in ("small_first", "long_first"):
+        call = (small, long_, [[1, 3], axes_l]) if orient == "small_first" else (long_, small, [axes_l, [1, 3]])
+        rec = {}
+        for mode in ("classic", "gather"):
+          be.gather_gemm = mode == "gather"
+          g0, p0 = be.gather_launches, be.permute_launches
+          t = timed(lambda: be.tensordot(*call))      # pylint: disable=cell-var-from-loop
+          n_calls = 3 * reps + 1
+          rec[mode + "_us"] = t * 1e6
+          rec[mode + "_TBps"] = nbytes / t / 1e12
+          rec[mode + "_launches"] = {"gather": (be.gather_launches - g0) // n_calls, "permute": (be.permute_launches - p0) // n_calls}
+          rec[mode + "_kernel"] = be.lib.tnh_gemm_last_kernel().decode()
+        rec["speedup"] = rec["classic_us"] / rec["gather_us"]
+        if verify:
+          be.gather_gemm = True
+          got = be.tensordot(*call)
+          be.gather_gemm = False
+          ref = be.tensordot(*call)
+          rec["max_abs_difference"] = float(np.asarray(be.norm(be.subtraction(got, ref))).reshape(-1)[0])
+          del got, ref
+          trailing = sorted(axes_l) == list(range(rank - len(axes_l), rank))     # the streaming kernel's own case
+          all_exact = all_exact and rec["max_abs_difference"] == 0.0 and \
+              rec["gather_launches"]["gather"] == (0 if trailing or plan is None else 1)
+        row[orient] = rec
+      rows.append(row)
+  finally:
+    be.gather_gemm, be.gather_min_rows = keep
+  out = {"workload": f"bf16 ({D},)*4 x ({D},)*{rank}, two bonds contracted, rows = contracted axes of the long tensor",
+         "algorithmic_bytes": nbytes, "timing": f"whole tensordot call, mean of {reps}, best of 3", "rows": rows}
+  if verify:
+    out["verified"] = {"tol": "gather result - classic result == 0 (2-norm of the difference on the device), one gather launch",
+                       "ok": bool(all_exact)}
+  return out
+
+
 def partials_check(p_half, p_f32, n_roundings, half_bits=9, margin=3.0):
   """bf16 (half_bits = 9: unit round-off u = 2^-9) slice partials against the same slices in f32, judged by an
   A-PRIORI error model instead of a tolerance picked after the fact:
@@ -1089,10 +1167,16 @@ def compact_line(result, detail_name):
   if isinstance(chain, list):
     line["mps_chain_ms"] = {f"d{r.get('d')}": [_num(r.get("gpu_eager_ms")), _num(r.get("gpu_graph_replay_ms"))]
                             for r in chain if isinstance(r, dict)}
+  gather = result.get("gather_gemm")
+  if isinstance(gather, dict) and isinstance(gather.get("rows"), list):
+    # case -> [classic us, gather us] with the small operand first, then with the long operand first
+    line["gather_gemm_us"] = {str(r.get("case", "?")).split("_")[0]:
+                              [_num(r.get(o, {}).get(m + "_us"), 3) for o in ("small_first", "long_first") for m in ("classic", "gather")]
+                              for r in gather["rows"] if isinstance(r, dict)}
   line = {k: v for k, v in line.items() if v is not None or k == "vs_baseline"}
   line["detail"] = detail_name
   text = json.dumps(line, separators=(",", ":"))
-  for drop in ("mps_chain_ms", "mera_chi64", "bond_sweep", "mera", "sliced_network", "svd"):
+  for drop in ("gather_gemm_us", "mps_chain_ms", "mera_chi64", "bond_sweep", "mera", "sliced_network", "svd"):
     if len(text) < COMPACT_LINE_LIMIT:
       break
     line.pop(drop, None)              # never reached at the bench's own sizes; the contract keys always fit
@@ -1264,6 +1348,10 @@ def main():
       _lib.check(be.lib.tnh_trim())
       fenced(result, "mps_chain", lambda: mps_chain_bench(ta, be, not args.no_cpu_baseline))
       fenced(result, "helpers", lambda: helpers_bench(ta, be))
+      _lib.check(be.lib.tnh_trim())
+      fenced(result, "gather_gemm", lambda: gather_gemm_bench(ta, be, not args.no_verify))
+      if isinstance(result["gather_gemm"], dict) and "verified" in result["gather_gemm"]:
+        verified["gather_gemm_equals_permute_plus_gemm"] = result["gather_gemm"].pop("verified")
       _lib.check(be.lib.tnh_trim())
     if single and args.svd_n > 0:
       try:

@@ -758,3 +758,23 @@ def test_gather_lowering_inside_a_contraction_path():
   assert results[False][1] == 0 and len(results[False][3]) >= len(big_permutes) + 2, results[False][3]
   np.testing.assert_allclose(got, ref, rtol=2.0**-6, atol=2.0**-6)
   np.testing.assert_allclose(results[False][0], ref, rtol=2.0**-6, atol=2.0**-6)
+
+
+def test_bench_gather_leg_runs_on_the_emulated_backend():
+  """bench.py's gather_gemm leg end to end at a reduced rank: the rows it writes, the device-side equality check and the
+  entry of the compact line."""
+  import json  # pylint: disable=import-outside-toplevel
+  import bench  # pylint: disable=import-outside-toplevel
+  with emulated_backend() as be:
+    rec = bench.gather_gemm_bench(ta, be, True, D=12, rank=6, reps=1,
+                                  cases={"k15_x": [1, 5], "k03_y": [0, 3], "k45_trailing": [4, 5]})
+  assert rec["verified"]["ok"], rec
+  by_case = {r["case"]: r for r in rec["rows"]}
+  assert by_case["k15_x"]["box"] == {"rows": 64, "piece_bytes": 1536, "innermost_axis_contracted": True}
+  assert by_case["k15_x"]["small_first"]["gather_kernel"] == "bf16_gather_Sx64"
+  assert by_case["k15_x"]["long_first"]["gather_kernel"] == "bf16_gather_64xS"
+  assert by_case["k15_x"]["small_first"]["classic_launches"] == {"gather": 0, "permute": 2}
+  assert by_case["k15_x"]["small_first"]["gather_launches"] == {"gather": 1, "permute": 1}
+  assert by_case["k45_trailing"]["small_first"]["gather_launches"]["gather"] == 0
+  line = json.loads(bench.compact_line({"metric": "m", "value": 1.0, "gather_gemm": rec}, "bench_detail.json"))
+  assert set(line["gather_gemm_us"]) == {"k15", "k03", "k45"} and len(line["gather_gemm_us"]["k15"]) == 4
