@@ -194,7 +194,7 @@ int tnh_gemm_view(int in_dtype, int out_dtype, int64_t M, int64_t N, int64_t K, 
  *   tile digits  the tile number, innermost first: text[d] values, box origins tstride[d] elements apart.
  * Strides other than digit 0's are multiples of 4 elements, L is 8-byte aligned, S and C 16-byte; K % 8 == 0,
  * 8 <= K <= 192, Ms <= 192 (Ms % 8 == 0 when small_first == 0), ldc % 8 == 0.  l_elems = elements of the long
- * tensor (bounds check).  Returns TNH_ERR_UNSUPPORTED, nothing launched, when a rule fails (or TNH_GEMM_GATHER=0):
+ * tensor (bounds check).  Returns TNH_ERR_UNSUPPORTED, nothing launched, when a rule fails (or TNH_GATHER_GEMM=0):
  * the caller permutes and calls tnh_gemm; results are bit-identical to that path (same MFMA sequence). */
 #define TNH_GATHER_MAX_DIGITS 8
 #define TNH_GATHER_MAX_TILE_DIGITS 6

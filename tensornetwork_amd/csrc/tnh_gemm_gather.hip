@@ -394,7 +394,7 @@ static int gather_validate_cached(const tnh_gather_desc& g, int64_t K, int64_t N
 }
 
 static bool gather_enabled() {
-  static const bool on = []() { const char* e = getenv("TNH_GEMM_GATHER"); return !(e && e[0] == '0'); }();
+  static const bool on = []() { const char* e = getenv("TNH_GATHER_GEMM"); return !(e && e[0] == '0'); }();
   return on;
 }
 
@@ -450,7 +450,7 @@ int gemm_gather(int dtype, int64_t Ms, int64_t K, int64_t Nl, const void* S, int
   }
   if (!bn) {
     set_error("tnh_gemm_gather: outside the gather kernel's range (%s)",
-              why ? why : "shape / alignment / TNH_GEMM_GATHER=0");
+              why ? why : "shape / alignment / TNH_GATHER_GEMM=0");
     return TNH_ERR_UNSUPPORTED;
   }
   GatherArgs p;

@@ -766,7 +766,7 @@ class HipBackend(BackendBase):
                                       ctypes.byref(desc), _vp(out), ms if long_rows_first else nl,
                                       0 if long_rows_first else 1)
     if status == _lib.ERR_UNSUPPORTED:
-      return None     # (a forced A/B variant, TNH_GEMM_GATHER=0, or an alignment rule: nothing was launched)
+      return None     # (a forced A/B variant, TNH_GATHER_GEMM=0, or an alignment rule: nothing was launched)
     _lib.check(status, "tnh_gemm_gather")
     if events is not None:
       events.append((start, _lib.Event().record()))

@@ -1258,6 +1258,37 @@ def test_gemm_gather_follows_the_planner_hint_for_the_small_operand_only(hip):
     hip.gather_gemm, hip.gather_min_rows = keep
 
 
+def test_gemm_gather_may_put_the_long_operands_axes_first(hip):
+  """tensordot_planned(..., allow_swap=True): callers for whom the result's axis order is bookkeeping get
+  [long operand's axes..., small operand's axes] (the contiguous output tile) and are told so; without the flag the
+  order is tensordot's own.  Same values either way."""
+  keep = (hip.gather_gemm, hip.gather_min_rows)
+  hip.gather_gemm, hip.gather_min_rows = True, 1024
+  try:
+    s, l, ds, dl = _gather_operands(hip, ta.bfloat16, (12, 12, 12, 12), (12,) * 6, 733)
+    axes = [[1, 3], [2, 5]]
+    ref = np.tensordot(s.astype(np.float64), l.astype(np.float64), axes)             # axes (s0, s2, l0, l1, l3, l4)
+    out, used_s, used_l, swapped = hip.tensordot_planned(ds, dl, axes, None, None, allow_swap=True)
+    assert swapped and hip.lib.tnh_gemm_last_kernel().decode() == "bf16_gather_48xS"
+    assert [int(i) for i in used_s] == [0, 2] and [int(i) for i in used_l] == [0, 1, 3, 4]
+    got = np.asarray(out)
+    assert got.shape == (12,) * 6
+    np.testing.assert_allclose(got, np.transpose(ref, (2, 3, 4, 5, 0, 1)), rtol=2.0**-8, atol=2e-3)
+    plain, _, _, swapped = hip.tensordot_planned(ds, dl, axes, None, None, allow_swap=False) + (False,)
+    np.testing.assert_array_equal(np.transpose(np.asarray(plain), (2, 3, 4, 5, 0, 1)), got)
+    # the long operand first: nothing to swap
+    out, used_l, used_s, swapped = hip.tensordot_planned(dl, ds, [axes[1], axes[0]], None, None, allow_swap=True)
+    assert not swapped and hip.lib.tnh_gemm_last_kernel().decode() == "bf16_gather_48xS"
+    np.testing.assert_array_equal(np.asarray(out), got)
+    # a product outside the gather lowering is never swapped
+    out, _, _, swapped = hip.tensordot_planned(ds, dl, [[1, 3], [4, 5]], None, None, allow_swap=True)
+    assert not swapped
+    np.testing.assert_allclose(np.asarray(out), np.tensordot(s.astype(np.float64), l.astype(np.float64), [[1, 3], [4, 5]]),
+                               rtol=2.0**-8, atol=2e-3)
+  finally:
+    hip.gather_gemm, hip.gather_min_rows = keep
+
+
 def test_gemm_gather_leaves_other_products_alone(hip):
   """Outside its range the gather lowering launches nothing: contracted axes already trailing (the streaming kernel
   reads that as it is), an innermost extent that is not a multiple of 4, a short long operand, f32."""
