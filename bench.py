@@ -995,6 +995,8 @@ GATHER_CASES = {     # contracted axes of the rank-8 long tensor (bond D): where
     "k16_innermost_free_contracted_right_above": [1, 6],
     "k15_two_innermost_free": [1, 5],
     "k01_k_major": [0, 1],
+    # 1728 contracted indices (the 144 x 248 832 x 1728 product of a slice): the K-loop kernel, 12 steps of 144
+    "k167_k_loop_1728": ([1, 3, 4], [1, 6, 7]),
 }
 
 
@@ -1005,11 +1007,11 @@ def gather_gemm_bench(ta, be, verify, D=12, rank=8, reps=5, cases=None):
   Results are compared on the device: same MFMA sequence per element, so the difference must be exactly zero."""
   from tensornetwork_amd import hip_backend  # pylint: disable=import-outside-toplevel
   long_shape = (D,) * rank
-  small = be.device_random((D, D, D, D), dtype=ta.bfloat16, seed=1, normal=True, a=0.0, b=0.1)
+  small4 = be.device_random((D, D, D, D), dtype=ta.bfloat16, seed=1, normal=True, a=0.0, b=0.1)
+  small5 = None                                             # (made when a case contracts three axes)
   long_ = be.device_random(long_shape, dtype=ta.bfloat16, seed=2, normal=True, a=0.0, b=0.1)
-  nbytes = 2 * (D**rank + D * D * D**(rank - 2) + D**4)     # read the long operand and the small one, write the result
   keep = (be.gather_gemm, be.gather_min_rows)
-  be.gather_min_rows = min(be.gather_min_rows, D**(rank - 2))
+  be.gather_min_rows = min(be.gather_min_rows, D**(rank - 3))
 
   def timed(fn):
     out = fn()
@@ -1027,13 +1029,19 @@ def gather_gemm_bench(ta, be, verify, D=12, rank=8, reps=5, cases=None):
 
   rows, all_exact = [], True
   try:
-    for name, axes_l in (cases or GATHER_CASES).items():
+    for name, spec in (cases or GATHER_CASES).items():
+      axes_s, axes_l = spec if isinstance(spec, tuple) else ([1, 3], spec)
+      if len(axes_s) == 3 and small5 is None:
+        small5 = be.device_random((D,) * 5, dtype=ta.bfloat16, seed=3, normal=True, a=0.0, b=0.1)
+      small = small5 if len(axes_s) == 3 else small4
+      # read the long operand and the small one, write the result
+      nbytes = 2 * (D**rank + D * D * D**(rank - len(axes_l)) + small.size)
       plan = hip_backend._gather_descriptor(long_shape, axes_l)      # pylint: disable=protected-access
-      row = {"case": name, "contracted_axes": axes_l,
+      row = {"case": name, "contracted_axes": axes_l, "algorithmic_bytes": nbytes,
              "box": None if plan is None else {"rows": plan[1], "piece_bytes": hip_backend._gather_piece_bytes(plan[0]),  # pylint: disable=protected-access
                                                "innermost_axis_contracted": bool(plan[0].k_mask & 1)}}
       for orient in ("small_first", "long_first"):
-        call = (small, long_, [[1, 3], axes_l]) if orient == "small_first" else (long_, small, [axes_l, [1, 3]])
+        call = (small, long_, [axes_s, axes_l]) if orient == "small_first" else (long_, small, [axes_l, axes_s])
         rec = {}
         for mode in ("classic", "gather"):
           be.gather_gemm = mode == "gather"
@@ -1051,19 +1059,23 @@ def gather_gemm_bench(ta, be, verify, D=12, rank=8, reps=5, cases=None):
           be.gather_gemm = False
           ref = be.tensordot(*call)
           rec["max_abs_difference"] = float(np.asarray(be.norm(be.subtraction(got, ref))).reshape(-1)[0])
+          looped = plan is not None and plan[0].kl_ext > 1
+          if looped:      # another grouping of the fp32 partial sums than the tile kernels': equal to round-off, not bit for bit
+            rec["rel_difference"] = rec["max_abs_difference"] / max(float(np.asarray(be.norm(ref)).reshape(-1)[0]), 1e-30)
           del got, ref
           trailing = sorted(axes_l) == list(range(rank - len(axes_l), rank))     # the streaming kernel's own case
-          all_exact = all_exact and rec["max_abs_difference"] == 0.0 and \
-              rec["gather_launches"]["gather"] == (0 if trailing or plan is None else 1)
+          same = rec["rel_difference"] <= 2.0**-9 if looped else rec["max_abs_difference"] == 0.0
+          all_exact = all_exact and same and rec["gather_launches"]["gather"] == (0 if trailing or plan is None else 1)
         row[orient] = rec
       rows.append(row)
   finally:
     be.gather_gemm, be.gather_min_rows = keep
-  out = {"workload": f"bf16 ({D},)*4 x ({D},)*{rank}, two bonds contracted, rows = contracted axes of the long tensor",
-         "algorithmic_bytes": nbytes, "timing": f"whole tensordot call, mean of {reps}, best of 3", "rows": rows}
+  out = {"workload": f"bf16 ({D},)*4 x ({D},)*{rank}, two bonds contracted (k_loop row: ({D},)*5, three), rows = contracted "
+                     "axes of the long tensor",
+         "timing": f"whole tensordot call, mean of {reps}, best of 3", "rows": rows}
   if verify:
-    out["verified"] = {"tol": "gather result - classic result == 0 (2-norm of the difference on the device), one gather launch",
-                       "ok": bool(all_exact)}
+    out["verified"] = {"tol": "gather result - classic result == 0 (2-norm of the difference on the device; K loop: relative "
+                              "2-norm <= 2^-9), one gather launch", "ok": bool(all_exact)}
   return out
 
 

@@ -194,7 +194,11 @@ int tnh_gemm_view(int in_dtype, int out_dtype, int64_t M, int64_t N, int64_t K, 
  *   tile digits  the tile number, innermost first: text[d] values, box origins tstride[d] elements apart.
  * Strides other than digit 0's are multiples of 4 elements, L is 8-byte aligned, S and C 16-byte; K % 8 == 0,
  * 8 <= K <= 192, Ms <= 192 (Ms % 8 == 0 when small_first == 0), ldc % 8 == 0.  l_elems = elements of the long
- * tensor (bounds check).  Returns TNH_ERR_UNSUPPORTED, nothing launched, when a rule fails (or TNH_GATHER_GEMM=0):
+ * tensor (bounds check).
+ * K loop (kl_ext > 1): K = kl_ext * Kbox; the box holds the Kbox = K / kl_ext innermost contracted indices (the rules
+ * above apply to Kbox) and the outermost contracted digit is walked step by step, kl_stride elements per step, the
+ * accumulators staying in registers: a product like 144 x 248 832 x 1728 reads its long operand in place, once.
+ * The slice S[:, step * Kbox ...] of the small operand is re-staged per step (Ms * Kbox / 8 <= 2816).  Returns TNH_ERR_UNSUPPORTED, nothing launched, when a rule fails (or TNH_GATHER_GEMM=0):
  * the caller permutes and calls tnh_gemm; results are bit-identical to that path (same MFMA sequence). */
 #define TNH_GATHER_MAX_DIGITS 8
 #define TNH_GATHER_MAX_TILE_DIGITS 6
@@ -207,6 +211,8 @@ typedef struct {
   int32_t nt;
   int32_t text[TNH_GATHER_MAX_TILE_DIGITS];
   int64_t tstride[TNH_GATHER_MAX_TILE_DIGITS];
+  int32_t kl_ext;      /* K loop: the outermost contracted digit taken step by step (1: all of K is inside the box) */
+  int64_t kl_stride;   /* elements between two steps */
 } tnh_gather_desc;
 int tnh_gemm_gather(int dtype, int64_t Ms, int64_t K, int64_t Nl, const void* S, int64_t lds, const void* L,
                     int64_t l_elems, const tnh_gather_desc* desc, void* C, int64_t ldc, int small_first);

@@ -40,7 +40,8 @@ class GatherDesc(ctypes.Structure):
   """tnh_gather_desc (include/tnh.h): tile plan of the long operand of tnh_gemm_gather."""
   _fields_ = [("nd", c_int32), ("ext", c_int32 * GATHER_MAX_DIGITS), ("stride", c_int32 * GATHER_MAX_DIGITS),
               ("mult", c_int32 * GATHER_MAX_DIGITS), ("k_mask", c_int32), ("nt", c_int32),
-              ("text", c_int32 * GATHER_MAX_TILE_DIGITS), ("tstride", c_int64 * GATHER_MAX_TILE_DIGITS)]
+              ("text", c_int32 * GATHER_MAX_TILE_DIGITS), ("tstride", c_int64 * GATHER_MAX_TILE_DIGITS),
+              ("kl_ext", c_int32), ("kl_stride", c_int64)]
 
 
 _I64P = POINTER(c_int64)

@@ -117,6 +117,15 @@ __host__ __device__ __forceinline__ int64_t gather_tile_base(const tnh_gather_de
   return base;
 }
 
+// Zero, but not to the optimiser: added to an address computation inside a loop body it keeps that computation IN the
+// body (hoisted out, the per-thread addresses of the K-loop kernel's small slice and epilogue cost ~50 registers and
+// pushed the slice's prefetch registers into scratch).
+__device__ __forceinline__ int opaque_zero() {
+  int z = 0;
+  asm volatile("" : "+s"(z));
+  return z;
+}
+
 struct GatherArgs {
   tnh_gather_desc g;
   const uint16_t* S;   // small operand, [Ms][K] rows lds apart
@@ -305,6 +314,201 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   }
 }
 
+// The same product with a K LOOP (kl_ext > 1): K = kl_ext * Kbox with only the Kbox innermost contracted indices inside
+// a box; the outermost contracted digit is walked step by step (p.g.kl_stride elements per step) with the accumulators
+// staying in registers, and the Ms x Kbox slice of the small operand that belongs to the step is re-staged into LDS
+// (it comes from L2: Ms x K x 2 bytes in all, read once per tile).  Steps of all tiles of a workgroup form ONE sequence
+// through which the boxes are prefetched two deep and the small slices one deep; the epilogue runs after a tile's last
+// step.  D = 12: 144 x 248 832 x 1728 against contracted axes (1, 7, 8) of a rank-9 tensor = 12 steps of 144.
+template <int BN, bool IS_BF16, bool SWAP, bool KIN>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_gather_kloop_kernel(GatherArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int FN = BN / 16;
+  constexpr int MAX_MI = 3;
+  constexpr int NB = (BN * 48 + 255) / 256;
+  constexpr int NST = (192 * BN / 8 + 255) / 256;
+  constexpr int NS = 11;                            // 16-B chunks of a small slice per thread (host: Ms * Kbox / 8 <= 2816)
+  static_assert(BN == 48 || BN == 64, "tile rows");
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int K = p.K, Ms = p.Ms;                    // K: indices inside a box (Kbox)
+  const int Kp = (K + 31) & ~31, cpr = Kp >> 3, kch = K >> 3, ksteps = Kp >> 5;
+  const int PA = Kp * 2 + 16;
+  const int msf = (Ms + 15) >> 4;
+  const int msp = msf * 16;
+  char* sS = smem;
+  char* sR = smem + msp * PA;
+  const int EP = (SWAP ? msp : BN) * 2 + 16;
+  const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
+  const int klx = p.g.kl_ext;
+  const int64_t kls = p.g.kl_stride;
+
+  // ---- small image: zero rows / zero k padding once; the slices overwrite the Ms x Kbox part only
+  for (int idx = tid; idx < msp * cpr; idx += 256) {
+    const int row = idx / cpr, c = idx - row * cpr;
+    *(uint4*)(sS + row * PA + c * 16) = zero4;
+  }
+  int spos[NS];                                    // (row << 8) | chunk of this thread's pieces of a slice
+  {
+    const int total = Ms * kch;
+#pragma unroll
+    for (int it = 0; it < NS; ++it) {
+      int idx = it * 256 + tid;
+      if (idx >= total) idx = total - 1;
+      const int row = idx / kch;
+      spos[it] = (row << 8) | (idx - row * kch);
+    }
+  }
+  typedef unsigned v4u __attribute__((ext_vector_type(4)));
+  v4u sreg[NS];
+  auto load_small = [&](int kl) {
+    const uint16_t* base = p.S + (int64_t)kl * K;
+    const int z = opaque_zero();
+#pragma unroll
+    for (int it = 0; it < NS; ++it) {
+      const int pos = spos[it] + z;
+      sreg[it] = *(const v4u*)(base + (pos >> 8) * (int)p.lds + (pos & 255) * 8);
+    }
+  };
+  auto store_small = [&]() {
+    const int z = opaque_zero();
+#pragma unroll
+    for (int it = 0; it < NS; ++it) {
+      const int pos = spos[it] + z;
+      *(v4u*)(sS + (pos >> 8) * PA + (pos & 255) * 16) = sreg[it];
+    }
+  };
+
+  int loff[NB], lsm[NB];
+  {
+    int crow[NB], ccol[NB];
+    gather_thread_chunks<NB>(p.g, tid, BN * (K >> 2), loff, crow, ccol);
+#pragma unroll
+    for (int it = 0; it < NB; ++it) lsm[it] = crow[it] * PA + ccol[it] * 2;
+  }
+  uint2 rl[NB];                                    // ONE box of prefetch here (registers: the small slice needs 44)
+  auto load_long = [&](int tile, int kl) {
+    const uint16_t* base = p.L + gather_tile_base(p.g, tile) + (int64_t)kl * kls;
+#pragma unroll
+    for (int it = 0; it < NB; ++it) rl[it] = *(const uint2*)(base + loff[it]);
+  };
+  const int padch = cpr - kch;
+  auto store_long = [&]() {
+#pragma unroll
+    for (int it = 0; it < NB; ++it) {
+      if constexpr (KIN) {
+        *(uint2*)(sR + lsm[it]) = rl[it];
+      } else {
+        char* q = sR + lsm[it];
+        *(uint16_t*)(q) = (uint16_t)(rl[it].x & 0xffffu);
+        *(uint16_t*)(q + PA) = (uint16_t)(rl[it].x >> 16);
+        *(uint16_t*)(q + 2 * PA) = (uint16_t)(rl[it].y & 0xffffu);
+        *(uint16_t*)(q + 3 * PA) = (uint16_t)(rl[it].y >> 16);
+      }
+    }
+    for (int idx = tid; idx < BN * padch; idx += 256) {
+      const int row = idx / padch, c = idx - row * padch;
+      *(uint4*)(sR + row * PA + (kch + c) * 16) = zero4;
+    }
+  };
+
+  const int frag_row = lane & 15, frag_chk = lane >> 4;
+  const int last = p.ntiles - 1;
+  const int step = (int)gridDim.x;
+  // the step after (tile, kl) in this workgroup's sequence; past the end it stays on the last step (a harmless re-read)
+  auto advance = [&](int& tile, int& kl) {
+    if (kl + 1 < klx) {
+      ++kl;
+    } else if (tile + step <= last) {
+      tile += step;
+      kl = 0;
+    }
+  };
+
+  f32x4 acc[MAX_MI][FN];
+#pragma unroll
+  for (int i = 0; i < MAX_MI; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  auto body = [&](int tile, int kl) {
+    __syncthreads();                            // both images complete
+    {
+      int t1 = tile, k1 = kl;
+      advance(t1, k1);
+      load_long(t1, k1);                        // the next step's box and its slice of the small operand: in flight
+      load_small(k1);                           // during the MFMA work (and the epilogue) of this one
+    }
+    for (int ks = 0; ks < ksteps; ++ks) {
+      const int koff = (ks * 4 + frag_chk) * 16;
+      uint4 lf[FN];
+#pragma unroll
+      for (int j = 0; j < FN; ++j) lf[j] = *(const uint4*)(sR + (j * 16 + frag_row) * PA + koff);
+#pragma unroll
+      for (int i = 0; i < MAX_MI; ++i) {
+        const int mi = wid + 4 * i;
+        if (mi < msf) {
+          const uint4 sf = *(const uint4*)(sS + (mi * 16 + frag_row) * PA + koff);
+#pragma unroll
+          for (int j = 0; j < FN; ++j) {
+            if constexpr (SWAP) acc[i][j] = mma16<IS_BF16>(sf, lf[j], acc[i][j]);
+            else acc[i][j] = mma16<IS_BF16>(lf[j], sf, acc[i][j]);
+          }
+        }
+      }
+    }
+    __syncthreads();                            // images consumed
+    if (kl == klx - 1) {                        // (uniform) the tile's last step: results out, accumulators cleared
+#pragma unroll
+      for (int i = 0; i < MAX_MI; ++i) {
+        const int mi = wid + 4 * i;
+        if (mi < msf) {
+#pragma unroll
+          for (int j = 0; j < FN; ++j) {
+            uint2 o;
+            o.x = pack2<IS_BF16>(acc[i][j][0], acc[i][j][1]);
+            o.y = pack2<IS_BF16>(acc[i][j][2], acc[i][j][3]);
+            if constexpr (SWAP) *(uint2*)(sR + (j * 16 + frag_row) * EP + (mi * 16 + frag_chk * 4) * 2) = o;
+            else *(uint2*)(sR + (mi * 16 + frag_row) * EP + (j * 16 + frag_chk * 4) * 2) = o;
+            acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+          }
+        }
+      }
+      __syncthreads();
+      {
+        uint16_t* cbase = p.C + (SWAP ? (int64_t)tile * BN * p.ldc : (int64_t)tile * BN);
+        const int total = SWAP ? BN * (Ms >> 3) : Ms * (BN / 8);
+        const int z = opaque_zero();
+#pragma unroll
+        for (int it = 0; it < NST; ++it) {
+          int idx = it * 256 + tid + z;
+          if (idx >= total) idx = total - 1;
+          const int per_row = SWAP ? (Ms >> 3) : BN / 8;
+          const int row = idx / per_row, ch = idx - row * per_row;
+          const uint4 v = *(const uint4*)(sR + row * EP + ch * 16);
+          *(uint4*)(cbase + (int64_t)row * p.ldc + ch * 8) = v;
+        }
+      }
+      __syncthreads();                          // staging consumed
+    }
+    store_long();
+    store_small();
+  };
+
+  int tile = blockIdx.x, kl = 0;
+  load_long(tile, 0);
+  load_small(0);
+  __syncthreads();                              // the zero fill of the small image is complete
+  store_long();
+  store_small();
+  for (;;) {
+    body(tile, kl);
+    if (kl == klx - 1 && tile + step > last) break;
+    advance(tile, kl);
+  }
+}
+
 // ---- host side
 // Everything the kernel relies on, checked by brute force over the <= 3072 chunks of a box (rows and columns of the
 // image are hit exactly once, offsets stay inside the tensor).  Returns the tile height BN (48 / 64) or 0.
@@ -335,7 +539,11 @@ static int gather_validate(const tnh_gather_desc& g, int64_t K, int64_t Nl, int6
     if (tiles >= (int64_t(1) << 30)) { *why = "too many tiles"; return 0; }
   }
   if (tiles * rows != Nl) { *why = "tiles x BN != long rows"; return 0; }
-  if (tspan + span + 1 > l_elems) { *why = "the last box leaves the tensor"; return 0; }
+  if (g.kl_ext < 1 || g.kl_ext > 4096 || (g.kl_ext > 1 && (g.kl_stride < 4 || g.kl_stride % 4))) {
+    *why = "K loop";
+    return 0;
+  }
+  if (tspan + span + (int64_t)(g.kl_ext - 1) * g.kl_stride + 1 > l_elems) { *why = "the last box leaves the tensor"; return 0; }
   // the image is covered exactly once
   const int total = (int)(rows * (K >> 2));
   const bool kin = g.k_mask & 1;
@@ -402,7 +610,9 @@ template <int BN, bool SWAP, bool KIN>
 static int launch_gather(bool is_bf16, const GatherArgs& p, size_t lds_bytes) {
   static const int attr_rc = []() -> int {
     for (const void* k : {reinterpret_cast<const void*>(gemm_gather_kernel<BN, true, SWAP, KIN>),
-                          reinterpret_cast<const void*>(gemm_gather_kernel<BN, false, SWAP, KIN>)})
+                          reinterpret_cast<const void*>(gemm_gather_kernel<BN, false, SWAP, KIN>),
+                          reinterpret_cast<const void*>(gemm_gather_kloop_kernel<BN, true, SWAP, KIN>),
+                          reinterpret_cast<const void*>(gemm_gather_kloop_kernel<BN, false, SWAP, KIN>)})
       if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return 1;
     return 0;
   }();
@@ -419,7 +629,9 @@ static int launch_gather(bool is_bf16, const GatherArgs& p, size_t lds_bytes) {
     hipLaunchKernelGGL(kernel, dim3((unsigned)gx), dim3(256), lds_bytes, stream(), p);
     return TNH_OK;
   };
-  const int rc = is_bf16 ? go(gemm_gather_kernel<BN, true, SWAP, KIN>) : go(gemm_gather_kernel<BN, false, SWAP, KIN>);
+  int rc;
+  if (p.g.kl_ext > 1) rc = is_bf16 ? go(gemm_gather_kloop_kernel<BN, true, SWAP, KIN>) : go(gemm_gather_kloop_kernel<BN, false, SWAP, KIN>);
+  else rc = is_bf16 ? go(gemm_gather_kernel<BN, true, SWAP, KIN>) : go(gemm_gather_kernel<BN, false, SWAP, KIN>);
   if (rc) return rc;
   TNH_LAUNCH_CHECK();
   return TNH_OK;
@@ -439,11 +651,14 @@ int gemm_gather(int dtype, int64_t Ms, int64_t K, int64_t Nl, const void* S, int
   const bool swap = !small_first;
   const char* why = nullptr;
   int bn = 0;
-  const bool shape_ok = gather_enabled() && Ms >= 1 && Ms <= 192 && K >= 8 && K <= 192 && K % 8 == 0 && Nl >= 48 &&
+  const int64_t steps = desc->kl_ext >= 1 ? desc->kl_ext : 0;       // K = steps * Kbox (steps == 1: no K loop)
+  const int64_t Kbox = steps && K % steps == 0 ? K / steps : 0;
+  const bool shape_ok = gather_enabled() && Ms >= 1 && Ms <= 192 && Kbox >= 8 && Kbox <= 192 && Kbox % 8 == 0 && Nl >= 48 &&
                         lds % 8 == 0 && ldc % 8 == 0 && lds >= K && ((uintptr_t)S % 16) == 0 &&
                         ((uintptr_t)L % 8) == 0 && ((uintptr_t)C % 16) == 0 && (!swap || Ms % 8 == 0) &&
-                        ldc >= (swap ? Ms : Nl);
-  if (shape_ok) bn = gather_validate_cached(*desc, K, Nl, l_elems, &why);
+                        ldc >= (swap ? Ms : Nl) && Ms * lds < (int64_t(1) << 30) &&
+                        (steps == 1 || Ms * (Kbox / 8) <= 11 * 256);
+  if (shape_ok) bn = gather_validate_cached(*desc, Kbox, Nl, l_elems, &why);
   if (shape_ok && bn && (swap ? (int64_t)bn * ldc : Ms * ldc) >= (int64_t(1) << 30)) {
     bn = 0;
     why = "32-bit offsets inside one output tile";
@@ -461,9 +676,9 @@ int gemm_gather(int dtype, int64_t Ms, int64_t K, int64_t Nl, const void* S, int
   p.lds = lds;
   p.ldc = ldc;
   p.Ms = (int)Ms;
-  p.K = (int)K;
+  p.K = (int)Kbox;
   p.ntiles = (int)(Nl / bn);
-  const int Kp = (int)((K + 31) & ~31), PA = Kp * 2 + 16;
+  const int Kp = (int)((Kbox + 31) & ~31), PA = Kp * 2 + 16;
   const int msp = (p.Ms + 15) / 16 * 16;
   const size_t image = (size_t)bn * PA;
   const size_t staging = swap ? (size_t)bn * (msp * 2 + 16) : (size_t)msp * (bn * 2 + 16);
@@ -471,10 +686,10 @@ int gemm_gather(int dtype, int64_t Ms, int64_t K, int64_t Nl, const void* S, int
   const bool kin = desc->k_mask & 1;
   const bool is_bf16 = dtype == TNH_BF16;
   if (bn == 48) {
-    *name = swap ? "bf16_gather_48xS" : "bf16_gather_Sx48";
+    *name = steps > 1 ? (swap ? "bf16_gather_kloop_48xS" : "bf16_gather_kloop_Sx48") : (swap ? "bf16_gather_48xS" : "bf16_gather_Sx48");
     return launch_gather_bn<48>(swap, kin, is_bf16, p, lds_bytes);
   }
-  *name = swap ? "bf16_gather_64xS" : "bf16_gather_Sx64";
+  *name = steps > 1 ? (swap ? "bf16_gather_kloop_64xS" : "bf16_gather_kloop_Sx64") : (swap ? "bf16_gather_64xS" : "bf16_gather_Sx64");
   return launch_gather_bn<64>(swap, kin, is_bf16, p, lds_bytes);
 }
 
@@ -483,12 +698,14 @@ int gemm_gather(int dtype, int64_t Ms, int64_t K, int64_t Nl, const void* S, int
 int gemm_gather_plan(const tnh_gather_desc* desc, int64_t K, int64_t Nl, int64_t l_elems, int32_t* chunk_off,
                      int32_t* chunk_row, int32_t* chunk_k, int64_t nchunks, int64_t* tile_base, int64_t ntiles) {
   const char* why = nullptr;
-  const int bn = gather_validate(*desc, K, Nl, l_elems, &why);
+  const int64_t steps = desc->kl_ext >= 1 ? desc->kl_ext : 0;
+  const int64_t Kbox = steps && K % steps == 0 ? K / steps : 0;      // the plan is that of ONE step of the K loop
+  const int bn = Kbox >= 4 && Kbox % 4 == 0 ? gather_validate(*desc, Kbox, Nl, l_elems, &why) : 0;
   if (!bn) {
     set_error("tnh_gemm_gather_plan: %s", why ? why : "invalid descriptor");
     return TNH_ERR_UNSUPPORTED;
   }
-  const int64_t total = (int64_t)bn * (K >> 2);
+  const int64_t total = (int64_t)bn * (Kbox >> 2);
   TNH_REQUIRE(nchunks >= 0 && nchunks <= total && ntiles >= 0 && ntiles <= Nl / bn,
               "tnh_gemm_gather_plan: more chunks / tiles asked than there are");
   for (int tid = 0; tid < 256; ++tid) {

@@ -127,11 +127,13 @@ def _operand_view(shape, free_axes, k_axes, strides=None):
   return _lib.OperandView(r0, sr0, sr1, k0, sk0, sk1)
 
 
-def _gather_descriptor(shape, k_axes):
+def _gather_descriptor(shape, k_axes, max_box_k=192):
   """Tile plan (tnh_gather_desc, include/tnh.h) for reading a dense row-major tensor in place as the long operand
   of tnh_gemm_gather: rows = the free axes in natural order, K = `k_axes` in memory order.  Returns
   (descriptor, BN, long_rows) or None when no box of 64 / 48 free tuples x all contracted indices
-  exists whose pieces are 8-byte aligned (the caller then permutes, as before).
+  exists whose pieces are 8-byte aligned (the caller then permutes, as before).  More than `max_box_k`
+  contracted indices: the box takes the innermost contracted digits that fit and the ONE remaining
+  (outermost) contracted digit becomes the K loop (descriptor.kl_ext steps); anything else is None.
 
   Digits are the tensor's axes innermost first, with size-1 axes dropped and memory-adjacent axes of the same
   role merged.  A box takes the contracted digits in full, the free digits below the split digit in full, and
@@ -152,6 +154,25 @@ def _gather_descriptor(shape, k_axes):
   free = [i for i, d in enumerate(digits) if not d[2]]
   if not free or len(free) == len(digits) or digits[0][0] % 4:
     return None
+  # K loop: contracted digits beyond max_box_k indices (innermost first) -- exactly one may be left over
+  kl_ext, kl_stride, box_k = 1, 0, 1
+  looped = None
+  for i, d in enumerate(digits):
+    if not d[2]:
+      continue
+    if looped is not None:
+      return None                               # two contracted digits outside the box
+    if box_k * d[0] <= max_box_k:
+      box_k *= d[0]
+    else:
+      looped, kl_ext, kl_stride = i, d[0], d[1]
+  if looped is not None:
+    if box_k % 8 or box_k < 8 or looped == 0:
+      return None
+    digits = [d for i, d in enumerate(digits) if i != looped]
+    # (removing the digit may leave two free digits as neighbours in the list: they are NOT merged -- their strides
+    #  differ by the looped digit's extent -- which the box / tile logic below does not need)
+    free = [i for i, d in enumerate(digits) if not d[2]]
   # the split digit: whole free digits while they fit, then T of the next one
   below, split, t_split, bn = 1, None, 0, 0
   for i in free:
@@ -169,7 +190,7 @@ def _gather_descriptor(shape, k_axes):
     return None
   if split == 0 and t_split % 4:
     return None
-  if sum((d[0] - 1) * d[1] for d in digits) >= 1 << 31:
+  if sum((d[0] - 1) * d[1] for d in digits) >= 1 << 31 or kl_ext > 4096 or (kl_ext > 1 and kl_stride % 4):
     return None                                 # (the descriptor holds 32-bit box offsets)
   desc = _lib.GatherDesc()
   nd, w_row, w_k = 0, 1, 1
@@ -203,6 +224,7 @@ def _gather_descriptor(shape, k_axes):
     desc.text[nt], desc.tstride[nt] = count, step
     nt += 1
   desc.nt = nt
+  desc.kl_ext, desc.kl_stride = kl_ext, kl_stride
   return desc, bn, rows
 
 
@@ -719,9 +741,10 @@ class HipBackend(BackendBase):
 
   def _tensordot_gather(self, a, b, axes_a, axes_b, free_a, free_b, m, n, k, hint_a=None, hint_b=None,
                         allow_swap=False):
-    """One `tnh_gemm_gather` launch for a SMALL operand (65 ... 192 free tuples, K <= 192) against a long
-    many-axis tensor whose contracted axes are not trailing, or None (the caller's permute + GEMM lowering
-    runs; results are bit-identical either way).  The long tensor is read where it lies, so its free axes
+    """One `tnh_gemm_gather` launch for a SMALL operand (65 ... 192 free tuples) against a long many-axis
+    tensor whose contracted axes are not trailing, or None (the caller's permute + GEMM lowering runs;
+    results are bit-identical either way for K <= 192; beyond that the kernel walks the outermost contracted
+    axis step by step -- same products, another grouping of the fp32 sums than the tile kernels').  The long tensor is read where it lies, so its free axes
     come out in natural order whatever the planner hinted -- the NEXT contraction gathers it again instead
     of finding it laid out; only the small operand is permuted (to [free, contracted in the long tensor's
     memory order]).  With `allow_swap` the result is [long operand's axes..., small operand's axes] whichever
@@ -730,7 +753,7 @@ class HipBackend(BackendBase):
     Returns (tensor, used_free_a, used_free_b, swapped)."""
     small_first = m <= n
     ms, nl = (m, n) if small_first else (n, m)
-    if not (64 < ms <= 192 and 16 <= k <= 192 and k % 8 == 0 and nl >= self.gather_min_rows):
+    if not (64 < ms <= 192 and 16 <= k <= 192 * 4096 and k % 8 == 0 and nl >= self.gather_min_rows):
       return None
     long_rows_first = not small_first or (allow_swap and ms % 8 == 0)     # C[Nl, Ms]: the kernel's "swap" form
     if long_rows_first and ms % 8:
@@ -748,6 +771,8 @@ class HipBackend(BackendBase):
     if plan is None:
       return None
     desc, _, rows = plan
+    if desc.kl_ext > 1 and ms * (k // desc.kl_ext // 8) > 11 * 256:
+      return None       # (the K-loop kernel re-stages an Ms x K / steps slice of the small operand per step)
     planned = allow_swap or hint_a is not None or hint_b is not None
     if rows != nl or (planned and _gather_piece_bytes(desc, long_.itemsize) < self.gather_min_piece_bytes):
       return None

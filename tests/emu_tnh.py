@@ -281,6 +281,11 @@ class EmuLib:
       base += (t % e) * st
       t //= e
     idx = (base[:, None, None] + box[None, :, :]).reshape(nl, k)
+    steps = int(desc.kl_ext)
+    if steps < 1 or (steps > 1 and (desc.kl_stride < 4 or desc.kl_stride % 4)):
+      return None
+    if steps > 1:                       # K loop: the outermost contracted digit, step by step (k = step * Kbox + k_box)
+      idx = np.concatenate([idx + kl * int(desc.kl_stride) for kl in range(steps)], axis=1)
     if int(idx.max()) >= l_elems:
       return None
     return idx, bn
@@ -290,11 +295,13 @@ class EmuLib:
     if code not in (_lib.BF16, _lib.F16):
       return _lib.ERR_INVALID
     swap = not small_first
-    if not (1 <= ms <= 192 and 8 <= k <= 192 and k % 8 == 0 and nl >= 48 and lds % 8 == 0 and ldc % 8 == 0 and
+    steps = int(desc.kl_ext)
+    kbox = k // steps if steps >= 1 and k % steps == 0 else 0
+    if not (1 <= ms <= 192 and 8 <= kbox <= 192 and kbox % 8 == 0 and nl >= 48 and lds % 8 == 0 and ldc % 8 == 0 and
             lds >= k and _addr(s) % 16 == 0 and _addr(l) % 8 == 0 and _addr(c) % 16 == 0 and
-            (not swap or ms % 8 == 0) and ldc >= (ms if swap else nl)):
+            (not swap or ms % 8 == 0) and ldc >= (ms if swap else nl) and (steps == 1 or ms * (kbox // 8) <= 11 * 256)):
       return _lib.ERR_UNSUPPORTED
-    got = self._gather_index(desc, int(k), int(nl), int(l_elems))
+    got = self._gather_index(desc, int(kbox), int(nl), int(l_elems))
     if got is None:
       return _lib.ERR_UNSUPPORTED
     idx, bn = got
@@ -307,7 +314,8 @@ class EmuLib:
     cflat = self._flat(c, (rows - 1) * ldc + cols, _NP[code])
     cm = np.lib.stride_tricks.as_strided(cflat, shape=(rows, cols), strides=(ldc * cflat.itemsize, cflat.itemsize))
     cm[:, :] = self._from_f(prod, code)
-    self._last_kernel = ("bf16_gather_%dxS" % bn if swap else "bf16_gather_Sx%d" % bn).encode()
+    loop = "kloop_" if steps > 1 else ""
+    self._last_kernel = (f"bf16_gather_{loop}{bn}xS" if swap else f"bf16_gather_{loop}Sx{bn}").encode()
     self.calls.append(("gather_gemm", int(ms), int(nl), int(k), int(bn), bool(desc.k_mask & 1), bool(small_first)))
     return _lib.OK
 

@@ -1289,6 +1289,55 @@ def test_gemm_gather_may_put_the_long_operands_axes_first(hip):
     hip.gather_gemm, hip.gather_min_rows = keep
 
 
+# (shape_small, shape_long, axes_small, axes_long, small_first, kernel): more than 192 contracted indices
+_GATHER_KLOOP_CASES = [
+    ((12, 12, 12, 12, 12), (12,) * 7, [1, 3, 4], [1, 5, 6], True, "bf16_gather_kloop_Sx64"),     # 144 x 248 832 x 1728
+    ((12, 12, 12, 12, 12), (12,) * 7, [1, 3, 4], [1, 5, 6], False, "bf16_gather_kloop_64xS"),
+    ((12, 12, 12, 12, 12), (12,) * 7, [1, 3, 4], [0, 4, 5], True, "bf16_gather_kloop_Sx48"),     # innermost axis free
+    ((12, 12, 12, 12, 12), (12,) * 7, [1, 3, 4], [0, 4, 5], False, "bf16_gather_kloop_48xS"),
+    ((16, 6, 8, 64), (6, 16, 8, 64, 16, 4), [1, 3], [0, 3], True, "bf16_gather_kloop_Sx64"),      # Ms = 128, 6 steps of 64
+    ((10, 8, 8, 40), (8, 64, 16, 40), [1, 3], [0, 3], True, "bf16_gather_kloop_Sx64"),            # Ms = 80, 8 steps of 40
+    ((10, 8, 8, 40), (8, 64, 16, 40), [1, 3], [0, 3], False, "bf16_gather_kloop_64xS"),
+]
+
+
+@pytest.mark.parametrize("dtype", [ta.bfloat16, np.float16])
+def test_gemm_gather_k_loop(hip, dtype):
+  """More than 192 contracted indices: the box takes the innermost contracted digits, the outermost one is walked step by
+  step with the accumulators in registers -- the long operand is still read in place, once.  Against float64 on the
+  rounded inputs and against the classic lowering (permute + tile kernels: same products, another grouping of the
+  fp32 partial sums, so equal to fp32 round-off, not bit for bit)."""
+  keep = (hip.gather_gemm, hip.gather_min_rows)
+  hip.gather_min_rows = 1024
+  try:
+    for i, (shape_s, shape_l, axes_s, axes_l, small_first, want) in enumerate(_GATHER_KLOOP_CASES):
+      if hasattr(hip, "_emu") and int(np.prod(shape_l)) > (1 << 21):      # the NumPy emulation of the C ABI (CPU suite)
+        outer = min(ax for ax in range(len(shape_l)) if ax not in axes_l)
+        shape_l = tuple(2 if ax == outer else n for ax, n in enumerate(shape_l))
+      s, l, ds, dl = _gather_operands(hip, dtype, shape_s, shape_l, 760 + i)
+      args = (ds, dl, [axes_s, axes_l]) if small_first else (dl, ds, [axes_l, axes_s])
+      hip.gather_gemm = True
+      before = (hip.gather_launches, hip.permute_launches)
+      got = hip.tensordot(*args)
+      kernel = hip.lib.tnh_gemm_last_kernel().decode()
+      assert hip.gather_launches - before[0] == 1, (shape_s, shape_l, axes_l, _lib.last_error())
+      assert hip.permute_launches - before[1] <= 1 and kernel == want, (shape_l, axes_l, kernel)
+      hip.gather_gemm = False
+      classic = hip.tensordot(*args)
+      g, c = np.asarray(got), np.asarray(classic)
+      ref = np.tensordot(s.astype(np.float64), l.astype(np.float64), [axes_s, axes_l]) if small_first else \
+          np.tensordot(l.astype(np.float64), s.astype(np.float64), [axes_l, axes_s])
+      k = int(np.prod([shape_s[a] for a in axes_s]))
+      half_ulp = 2.0**-9 if dtype is ta.bfloat16 else 2.0**-12
+      tol = dict(rtol=2 * half_ulp, atol=2 * half_ulp * np.abs(ref).max() + 1e-6 * k**0.5)
+      np.testing.assert_allclose(g, ref, **tol)
+      np.testing.assert_allclose(c, ref, **tol)
+      assert np.mean(g == c) > 0.9          # the two fp32 sums round to the same half-precision value almost everywhere
+      del got, classic, ds, dl
+  finally:
+    hip.gather_gemm, hip.gather_min_rows = keep
+
+
 def test_gemm_gather_leaves_other_products_alone(hip):
   """Outside its range the gather lowering launches nothing: contracted axes already trailing (the streaming kernel
   reads that as it is), an innermost extent that is not a multiple of 4, a short long operand, f32."""

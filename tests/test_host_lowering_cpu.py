@@ -289,7 +289,7 @@ def _gpu_suite_selection():
           TK.test_gemm_view_absorbs_transposes_bit_exact, TK.test_gemm_view_falls_back_when_it_cannot_read_in_place,
           TK.test_gemm_gather_reads_the_long_operand_in_place_bit_exact,
           TK.test_gemm_gather_follows_the_planner_hint_for_the_small_operand_only,
-          TK.test_gemm_gather_may_put_the_long_operands_axes_first,
+          TK.test_gemm_gather_may_put_the_long_operands_axes_first, TK.test_gemm_gather_k_loop,
           TK.test_gemm_gather_leaves_other_products_alone, TK.test_gemm_gather_c_abi_rejects_bad_descriptors_without_launching,
           TK.test_tensordot_random_axes_property, TK.test_misc_golden, TK.test_tensordot_golden,
           TK.test_tensordot_errors_and_empty, TK.test_elementwise_math, TK.test_init_functions, TK.test_casts,
@@ -661,7 +661,7 @@ def test_band_svd_host_logic_random_call_shapes():
 
 
 # ------------------------------------------------------------------ K2 gather: the tile plan of the long operand
-def _plan_through_the_library(desc, bn, k, nl, l_elems):
+def _plan_through_the_library(desc, bn, k, nl, l_elems, k_total=None):
   """chunk plan and box origins as the KERNEL computes them (tnh_gemm_gather_plan runs the kernel's own index
   functions on the host: no device needed)"""
   import ctypes  # pylint: disable=import-outside-toplevel
@@ -670,7 +670,7 @@ def _plan_through_the_library(desc, bn, k, nl, l_elems):
   off, row, col = (np.zeros(nch, np.int32) for _ in range(3))
   base = np.zeros(nt, np.int64)
   p32, p64 = ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int64)
-  rc = lib.tnh_gemm_gather_plan(ctypes.byref(desc), k, nl, l_elems, off.ctypes.data_as(p32), row.ctypes.data_as(p32),
+  rc = lib.tnh_gemm_gather_plan(ctypes.byref(desc), k_total or k, nl, l_elems, off.ctypes.data_as(p32), row.ctypes.data_as(p32),
                                 col.ctypes.data_as(p32), nch, base.ctypes.data_as(p64), nt)
   assert rc == bn, (rc, _lib.last_error())
   return off, row, col, base
@@ -684,20 +684,24 @@ def _check_gather_plan(shape, k_axes):
   desc, bn, nl = plan
   free = [i for i in range(len(shape)) if i not in k_axes]
   k = int(np.prod([shape[i] for i in k_axes]))
-  assert nl == int(np.prod([shape[i] for i in free])) and bn in (48, 64)
+  steps = int(desc.kl_ext)                             # K loop: k = step * kbox + (index inside the box)
+  kbox = k // steps
+  assert nl == int(np.prod([shape[i] for i in free])) and bn in (48, 64) and steps * kbox == k
   x = np.arange(int(np.prod(shape)), dtype=np.int64).reshape(shape)
   want = np.transpose(x, free + sorted(k_axes)).reshape(nl, k)      # rows: free axes, natural order; k: memory order
-  off, row, col, base = _plan_through_the_library(desc, bn, k, nl, x.size)
+  off, row, col, base = _plan_through_the_library(desc, bn, kbox, nl, x.size, k)
   kin = bool(desc.k_mask & 1)
   got = np.full((nl, k), -1, np.int64)
   flat = x.reshape(-1)
   tiles = np.arange(nl // bn)[:, None]
-  for i in range(4):                                   # a chunk's four elements: along k (innermost axis contracted) or rows
-    r, c = (row, col + i) if kin else (row + i, col)
-    got[tiles * bn + r[None, :], np.broadcast_to(c[None, :], (tiles.size, c.size))] = flat[base[:, None] + off[None, :] + i]
+  for kl in range(steps):
+    for i in range(4):                                 # a chunk's four elements: along k (innermost axis contracted) or rows
+      r, c = (row, col + i) if kin else (row + i, col)
+      got[tiles * bn + r[None, :], np.broadcast_to(kl * kbox + c[None, :], (tiles.size, c.size))] = \
+          flat[base[:, None] + kl * int(desc.kl_stride) + off[None, :] + i]
   np.testing.assert_array_equal(got, want)
   assert (np.diff(off) > 0).all()                      # threads walk the box in memory order
-  return bn, kin
+  return (bn, kin) if steps == 1 else (bn, kin, steps)
 
 
 def test_gather_plan_reads_the_matrix_transpose_would_have_built():
@@ -716,6 +720,13 @@ def test_gather_plan_reads_the_matrix_transpose_would_have_built():
   assert _check_gather_plan((10, 10, 10, 10), (1,)) is None                              # pieces not 8-byte aligned
   assert _check_gather_plan((3, 12, 5, 144, 12, 7, 4), (1, 4)) is None                   # 28 innermost free: no 48 / 64 rows
   assert _check_gather_plan((12, 12, 12), (2,)) is None or True                          # (trailing: the host never asks)
+  # more than 192 contracted indices: the innermost contracted digits in the box, the outermost one walked step by step
+  assert _check_gather_plan((12,) * 7, (1, 5, 6)) == (64, True, 12)                      # 144 x 248 832 x 1728 of the D = 12 network
+  assert _check_gather_plan((12,) * 6, (1, 4, 5)) == (48, True, 12)
+  assert _check_gather_plan((12,) * 6, (0, 3, 4)) == (48, False, 12)                     # innermost axis free
+  assert _check_gather_plan((4, 16, 8, 16, 16), (0, 1, 3)) == (64, False, 64)            # (0, 1) are one digit: 64 steps
+  assert _check_gather_plan((6, 16, 8, 64, 4), (0, 3)) == (64, False, 6)
+  assert _check_gather_plan((16, 4, 16, 4, 16, 16), (0, 2, 4)) is None                   # two contracted digits outside the box
   rng = np.random.default_rng(11)
   accepted = 0
   for _ in range(300):
@@ -726,7 +737,7 @@ def test_gather_plan_reads_the_matrix_transpose_would_have_built():
     nk = int(rng.integers(1, min(3, rank - 1) + 1))
     k_axes = tuple(int(x) for x in rng.choice(rank, size=nk, replace=False))
     k = int(np.prod([shape[i] for i in k_axes]))
-    if k % 8 or not 8 <= k <= 192:
+    if k % 8 or not 8 <= k <= 2048:
       continue
     accepted += _check_gather_plan(shape, k_axes) is not None
   assert accepted >= 10, accepted
@@ -768,7 +779,8 @@ def test_bench_gather_leg_runs_on_the_emulated_backend():
   import bench  # pylint: disable=import-outside-toplevel
   with emulated_backend() as be:
     rec = bench.gather_gemm_bench(ta, be, True, D=12, rank=6, reps=1,
-                                  cases={"k15_x": [1, 5], "k03_y": [0, 3], "k45_trailing": [4, 5]})
+                                  cases={"k15_x": [1, 5], "k03_y": [0, 3], "k45_trailing": [4, 5],
+                                         "k145_loop": ([1, 3, 4], [1, 4, 5])})
   assert rec["verified"]["ok"], rec
   by_case = {r["case"]: r for r in rec["rows"]}
   assert by_case["k15_x"]["box"] == {"rows": 64, "piece_bytes": 1536, "innermost_axis_contracted": True}
@@ -778,4 +790,6 @@ def test_bench_gather_leg_runs_on_the_emulated_backend():
   assert by_case["k15_x"]["small_first"]["gather_launches"] == {"gather": 1, "permute": 1}
   assert by_case["k45_trailing"]["small_first"]["gather_launches"]["gather"] == 0
   line = json.loads(bench.compact_line({"metric": "m", "value": 1.0, "gather_gemm": rec}, "bench_detail.json"))
-  assert set(line["gather_gemm_us"]) == {"k15", "k03", "k45"} and len(line["gather_gemm_us"]["k15"]) == 4
+  assert by_case["k145_loop"]["small_first"]["gather_kernel"] == "bf16_gather_kloop_Sx48"
+  assert by_case["k145_loop"]["small_first"]["rel_difference"] <= 2.0**-9
+  assert set(line["gather_gemm_us"]) == {"k15", "k03", "k45", "k145"} and len(line["gather_gemm_us"]["k15"]) == 4
