@@ -8,6 +8,7 @@ arithmetic (``shape_*``), argument validation and the SVD truncation rule stay
 on the host, exactly as in the reference.
 """
 import ctypes
+import functools
 import io
 import numbers
 
@@ -128,6 +129,12 @@ def _operand_view(shape, free_axes, k_axes, strides=None):
 
 
 def _gather_descriptor(shape, k_axes, max_box_k=192):
+  """see _gather_descriptor_cached: the same few (shape, axes) come back slice after slice"""
+  return _gather_descriptor_cached(tuple(int(n) for n in shape), tuple(int(x) for x in k_axes), int(max_box_k))
+
+
+@functools.lru_cache(maxsize=512)
+def _gather_descriptor_cached(shape, k_axes, max_box_k):
   """Tile plan (tnh_gather_desc, include/tnh.h) for reading a dense row-major tensor in place as the long operand
   of tnh_gemm_gather: rows = the free axes in natural order, K = `k_axes` in memory order.  Returns
   (descriptor, BN, long_rows) or None when no box of 64 / 48 free tuples x all contracted indices
