@@ -974,7 +974,9 @@ int gemm_bf16_view(int in_dt, int out_dt, int64_t M, int64_t N, int64_t K, const
     const double base = (double)((nwg + cus - 1) / cus);
     double best = base;
     int best_rt = 0, best_ks = 0, best_s = 0;
-    for (int rt = 1; rt <= 4 && rt < p.tiles_m; ++rt) {
+    // (up to 32 tile rows: 81 x 7 tiles -- the 20736 x 1728 x 20736 product of the D = 12 network -- are 2.2 waves, and
+    //  cutting 8 rows leaves 511 tiles = 2 waves + 56 tiles x 4 K-slices: 3 tile times -> 2.35)
+    for (int rt = 1; rt <= 32 && rt < p.tiles_m; ++rt) {
       const int64_t main_tiles = (int64_t)(p.tiles_m - rt) * p.tiles_n, tail_tiles = (int64_t)rt * p.tiles_n;
       int s = (int)(cus / tail_tiles);
       if (s < 2) continue;

@@ -1071,6 +1071,34 @@ def test_gemm_persistent_tiles_match_one_workgroup_per_tile(hip, m, n, k, kn):
   np.testing.assert_allclose(g[rows], ref, rtol=2.0**-7, atol=2.0**-8)
 
 
+def test_gemm_view_tail_split_cuts_as_many_tile_rows_as_it_takes(hip):
+  """81 x 7 tiles (the 20736 x 1728 x 20736 product of the D = 12 network) = 2.2 waves on 256 CUs: eight tile rows are
+  cut off so that the main part is exactly two waves, and computed by a 4-slice split-K launch.  Same values as the
+  un-split launch up to the rounding of the f32 partial sums; both right against float64 on sampled entries."""
+  rng = np.random.default_rng(78)
+  m, n, k = 20736, 1728, 20736
+  a = hip.device_random((m, k), dtype=ta.bfloat16, seed=7, normal=True, b=k ** -0.5)
+  b = hip.device_random((n, k), dtype=ta.bfloat16, seed=8, normal=True, b=1.0)
+  got = hip.tensordot(a, b, [[1], [1]])
+  assert hip.lib.tnh_gemm_last_kernel().decode() == "bf16_view_nt_256x256x64_pp+tail_splitk"
+  _lib.check(hip.lib.tnh_gemm_set_variant(b"auto:t0"))
+  try:
+    ref_dev = hip.tensordot(a, b, [[1], [1]])
+    assert hip.lib.tnh_gemm_last_kernel().decode() == "bf16_view_nt_256x256x64_pp"
+  finally:
+    _lib.check(hip.lib.tnh_gemm_set_variant(b"auto"))
+  rows = np.concatenate([rng.integers(0, m, 16), np.array([0, m - 2048 - 1, m - 2048, m - 1025, m - 1])])   # main / cut rows
+  cols = rng.integers(0, n, 32)
+  g = np.stack([np.asarray(hip.getitem(got, (int(r),)))[cols] for r in rows]).astype(np.float64)
+  u = np.stack([np.asarray(hip.getitem(ref_dev, (int(r),)))[cols] for r in rows]).astype(np.float64)
+  a_rows = np.stack([np.asarray(hip.getitem(a, (int(r),))) for r in rows]).astype(np.float64)
+  b_rows = np.stack([np.asarray(hip.getitem(b, (int(c),))) for c in cols]).astype(np.float64)
+  ref = a_rows @ b_rows.T
+  np.testing.assert_allclose(g, ref, rtol=2.0**-8, atol=2.0**-9)
+  np.testing.assert_allclose(u, ref, rtol=2.0**-8, atol=2.0**-9)
+  np.testing.assert_allclose(g, u, rtol=2.0**-7, atol=1e-6)      # at most one bf16 ulp apart (different f32 summation order)
+
+
 def test_gemm_view_tail_split_with_two_level_rows_and_runs_of_96(hip):
   """config-2 layout L1 at D = 96: a[i0, k1, i2, k3] . b[k3, j1, k1, j3] -- both operands in place (inner contraction
   runs of 96 = three half K-tiles, two-level rows), 36 x 36 tiles, and the last tile row of the two-level-row operand
