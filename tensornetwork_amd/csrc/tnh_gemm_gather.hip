@@ -387,14 +387,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
     for (int it = 0; it < NB; ++it) lsm[it] = crow[it] * PA + ccol[it] * 2;
   }
-  uint2 rl[NB];                                    // ONE box of prefetch here (registers: the small slice needs 44)
-  auto load_long = [&](int tile, int kl) {
+  // Boxes of register prefetch: two at 48 rows, one at 64 (the small slice needs 44 registers; 229 of 256 are taken
+  // at 64 rows with one).  With one, a step sees most of a load latency: 4.3 us per step against 2.7 us per tile of
+  // the single-box kernel (profiles/r04_gather_gemm.md).
+  constexpr int DEPTH = BN == 48 ? 2 : 1;
+  uint2 rl0[NB], rl1[DEPTH == 2 ? NB : 1];
+  auto load_long = [&](int tile, int kl, uint2 (&rl)[NB]) {
     const uint16_t* base = p.L + gather_tile_base(p.g, tile) + (int64_t)kl * kls;
 #pragma unroll
     for (int it = 0; it < NB; ++it) rl[it] = *(const uint2*)(base + loff[it]);
   };
   const int padch = cpr - kch;
-  auto store_long = [&]() {
+  auto store_long = [&](const uint2 (&rl)[NB]) {
 #pragma unroll
     for (int it = 0; it < NB; ++it) {
       if constexpr (KIN) {
@@ -432,13 +436,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
     for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  auto body = [&](int tile, int kl) {
+  // One step.  `hold` receives (DEPTH 1) or already has (DEPTH 2) the NEXT step's box; with DEPTH 2 `fill` takes the
+  // one after it.  The next step's slice of the small operand is requested here too.
+  auto body = [&](int tile, int kl, uint2 (&hold)[NB], uint2 (&fill)[NB]) {
     __syncthreads();                            // both images complete
     {
       int t1 = tile, k1 = kl;
       advance(t1, k1);
-      load_long(t1, k1);                        // the next step's box and its slice of the small operand: in flight
-      load_small(k1);                           // during the MFMA work (and the epilogue) of this one
+      if constexpr (DEPTH == 2) {
+        int t2 = t1, k2 = k1;
+        advance(t2, k2);
+        load_long(t2, k2, fill);                // in flight during this step and the next
+      } else {
+        load_long(t1, k1, hold);                // in flight during the MFMA work (and the epilogue) of this step
+      }
+      load_small(k1);
     }
     for (int ks = 0; ks < ksteps; ++ks) {
       const int koff = (ks * 4 + frag_chk) * 16;
@@ -492,20 +504,36 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       }
       __syncthreads();                          // staging consumed
     }
-    store_long();
+    store_long(hold);
     store_small();
   };
 
   int tile = blockIdx.x, kl = 0;
-  load_long(tile, 0);
+  load_long(tile, 0, rl0);
   load_small(0);
   __syncthreads();                              // the zero fill of the small image is complete
-  store_long();
+  store_long(rl0);
   store_small();
-  for (;;) {
-    body(tile, kl);
-    if (kl == klx - 1 && tile + step > last) break;
-    advance(tile, kl);
+  if constexpr (DEPTH == 2) {
+    {
+      int t1 = tile, k1 = kl;
+      advance(t1, k1);
+      load_long(t1, k1, rl0);
+    }
+    for (;;) {
+      body(tile, kl, rl0, rl1);
+      if (kl == klx - 1 && tile + step > last) break;
+      advance(tile, kl);
+      body(tile, kl, rl1, rl0);
+      if (kl == klx - 1 && tile + step > last) break;
+      advance(tile, kl);
+    }
+  } else {
+    for (;;) {
+      body(tile, kl, rl0, rl0);
+      if (kl == klx - 1 && tile + step > last) break;
+      advance(tile, kl);
+    }
   }
 }
 

@@ -1323,6 +1323,8 @@ _GATHER_KLOOP_CASES = [
     ((12, 12, 12, 12, 12), (12,) * 7, [1, 3, 4], [1, 5, 6], False, "bf16_gather_kloop_64xS"),
     ((12, 12, 12, 12, 12), (12,) * 7, [1, 3, 4], [0, 4, 5], True, "bf16_gather_kloop_Sx48"),     # innermost axis free
     ((12, 12, 12, 12, 12), (12,) * 7, [1, 3, 4], [0, 4, 5], False, "bf16_gather_kloop_48xS"),
+    ((12, 12, 12, 12, 12), (12,) * 7, [1, 3, 4], [2, 5, 6], True, "bf16_gather_kloop_Sx48"),     # the slice's own variant:
+    ((12, 12, 12, 12, 12), (12,) * 7, [1, 3, 4], [2, 5, 6], False, "bf16_gather_kloop_48xS"),    # 48 rows, two boxes ahead
     ((16, 6, 8, 64), (6, 16, 8, 64, 16, 4), [1, 3], [0, 3], True, "bf16_gather_kloop_Sx64"),      # Ms = 128, 6 steps of 64
     ((10, 8, 8, 40), (8, 64, 16, 40), [1, 3], [0, 3], True, "bf16_gather_kloop_Sx64"),            # Ms = 80, 8 steps of 40
     ((10, 8, 8, 40), (8, 64, 16, 40), [1, 3], [0, 3], False, "bf16_gather_kloop_64xS"),
