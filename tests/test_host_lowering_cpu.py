@@ -793,3 +793,73 @@ def test_bench_gather_leg_runs_on_the_emulated_backend():
   assert by_case["k145_loop"]["small_first"]["gather_kernel"] == "bf16_gather_kloop_Sx48"
   assert by_case["k145_loop"]["small_first"]["rel_difference"] <= 2.0**-9
   assert set(line["gather_gemm_us"]) == {"k15", "k03", "k45", "k145"} and len(line["gather_gemm_us"]["k15"]) == 4
+
+
+def test_gather_lowering_random_products_match_numpy():
+  """Random small x long products through HipBackend.tensordot / tensordot_planned on the emulated C ABI with the
+  gather lowering on: whatever the placement of the contracted axes, the order of the pairs, the operand order and
+  the K loop, the values are np.tensordot's and the returned axis bookkeeping describes the result."""
+  from tensornetwork_amd import hip_backend  # pylint: disable=import-outside-toplevel
+  rng = np.random.default_rng(2024)
+  gathered = looped = swapped_seen = 0
+  with emulated_backend() as be:
+    be.gather_gemm, be.gather_min_rows = True, 48
+    trial = 0
+    for _ in range(4000):
+      if trial >= 40:
+        break
+      rank = int(rng.integers(3, 7))
+      shape_l = [int(x) for x in rng.choice([4, 8, 12, 16], size=rank)]
+      nk = int(rng.integers(1, min(3, rank - 1) + 1))
+      axes_l = sorted(int(x) for x in rng.choice(rank, size=nk, replace=False))
+      k = int(np.prod([shape_l[a] for a in axes_l]))
+      nl = int(np.prod(shape_l)) // k
+      if k % 8 or k < 16 or k > 1024 or nl < 256 or nl * k > 1500000:      # (nl > ms: the long operand is the long one)
+        continue
+      free_s = [int(x) for x in rng.choice([6, 8, 12, 16], size=2)]
+      ms = int(np.prod(free_s))
+      if not 64 < ms <= 192:
+        continue
+      trial += 1
+      # the small tensor: free axes and the contracted ones (paired with the long tensor's in a random order) interleaved
+      pair_order = [int(x) for x in rng.permutation(nk)]
+      dims = [("f", d) for d in free_s] + [("k", i) for i in pair_order]
+      dims = [dims[i] for i in rng.permutation(len(dims))]
+      shape_s = [d if kind == "f" else shape_l[axes_l[d]] for kind, d in dims]
+      axes_s_of_pair = {d: pos for pos, (kind, d) in enumerate(dims) if kind == "k"}
+      axes_s = [axes_s_of_pair[i] for i in range(nk)]          # axes_s[i] pairs with axes_l[i]
+      s = orc.round_bf16(rng.standard_normal(shape_s).astype(np.float32) / 4)
+      l = orc.round_bf16(rng.standard_normal(shape_l).astype(np.float32) / 4)
+      ds, dl = be.to_bfloat16(s), be.to_bfloat16(l)
+      small_first = bool(rng.integers(0, 2))
+      plan = hip_backend._gather_descriptor(shape_l, axes_l)      # pylint: disable=protected-access
+      trailing = axes_l == list(range(rank - nk, rank))
+      args = (ds, dl, [axes_s, axes_l]) if small_first else (dl, ds, [axes_l, axes_s])
+      ref = np.tensordot(s.astype(np.float64), l.astype(np.float64), [axes_s, axes_l]) if small_first else \
+          np.tensordot(l.astype(np.float64), s.astype(np.float64), [axes_l, axes_s])
+      before = be.gather_launches
+      if trial % 2:
+        out, used_a, used_b, swapped = be.tensordot_planned(*args, None, None, allow_swap=True)
+        got = np.asarray(out)
+        na = len(used_a)
+        free_a = [i for i in range(args[0].ndim) if i not in args[2][0]]
+        free_b = [i for i in range(args[1].ndim) if i not in args[2][1]]
+        perm_a = [free_a.index(int(i)) for i in used_a]
+        perm_b = [len(free_a) + free_b.index(int(i)) for i in used_b]
+        want = np.transpose(ref, perm_b + perm_a if swapped else perm_a + perm_b)
+        swapped_seen += bool(swapped)
+        assert len(used_b) + na == ref.ndim
+      else:
+        got, want = np.asarray(be.tensordot(*args)), ref
+      used = be.gather_launches - before
+      eligible = plan is not None and not trailing and (small_first or ms % 8 == 0) and \
+          (plan[0].kl_ext == 1 or ms * (k // plan[0].kl_ext // 8) <= 11 * 256)
+      # (planned calls keep the permute for boxes of short pieces)
+      if eligible and (trial % 2 == 0 or hip_backend._gather_piece_bytes(plan[0]) >= be.gather_min_piece_bytes):  # pylint: disable=protected-access
+        assert used == 1, (shape_s, shape_l, axes_s, axes_l, small_first)
+      gathered += used
+      looped += used and plan[0].kl_ext > 1
+      assert got.shape == want.shape
+      np.testing.assert_allclose(got, want, rtol=2.0**-7, atol=2.0**-8 * k**0.5)
+      del ds, dl
+  assert gathered >= 8 and looped >= 1 and swapped_seen >= 1, (gathered, looped, swapped_seen)
