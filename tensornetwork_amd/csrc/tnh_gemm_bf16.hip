@@ -1037,6 +1037,12 @@ int gemm_bf16_ragged(int in_dt, int out_dt, int shape, int64_t M, int64_t N, int
                      int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int64_t batch,
                      int64_t sA, int64_t sB, int64_t sC, const char** name);
 
+// K <= 16, large results (tnh_gemm_smallk.hip)
+bool gemm_bf16_smallk_wanted(int out_dt, int64_t M, int64_t N, int64_t K, int64_t batch, const void* A, int64_t lda,
+                             const void* B, int64_t ldb, const void* C, int64_t ldc);
+int gemm_bf16_smallk(int in_dt, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* B, int64_t ldb,
+                     void* C, int64_t ldc, const char** name);
+
 // small x very long products (tnh_gemm_stream.hip)
 bool gemm_bf16_stream_wanted(int out_dt, int64_t M, int64_t N, int64_t K, int64_t batch);
 int gemm_bf16_stream(int in_dt, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* B,
@@ -1060,6 +1066,9 @@ int gemm_bf16_fast(int in_dt, int out_dt, int variant, int transA, int transB, i
     const int rc = gemm_bf16_stream(in_dt, M, N, K, A, lda, B, ldb, C, ldc, name);
     if (rc != TNH_ERR_UNSUPPORTED) return rc;   // odd alignment: the tile kernels below
   }
+  // K <= 16 with a large result: a store stream (tnh_gemm_smallk.hip)
+  if (variant == 0 && gemm_bf16_smallk_wanted(out_dt, M, N, K, batch, A, lda, B, ldb, C, ldc))
+    return gemm_bf16_smallk(in_dt, M, N, K, A, lda, B, ldb, C, ldc, name);
   bool dma_ok = K % 64 == 0 && lda % 8 == 0 && ldb % 8 == 0 && ldc % 4 == 0 &&
                 ((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0 && ((uintptr_t)C % 16) == 0 &&
                 sA % 8 == 0 && sB % 8 == 0 && sC % 4 == 0 && M >= 16 && N >= 16;
