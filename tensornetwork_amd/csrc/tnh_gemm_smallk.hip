@@ -2,7 +2,8 @@
 // bond between two tensors lowers to (D = 12: 1728 x 248 832 x 12, a 860 MB result from 6 MB of operands; the reference
 // reaches it through tensordot, numpy_backend.py:35-37).  Such a product is a pure STORE stream (2 M N bytes against
 // 2 M N K flop, K <= 16), and the tile kernels spend it badly: a 128 x 128 x 64 tile is one mostly-zero K step between
-// a load phase and a 32 KB epilogue, 10 us per tile (1.6 TB/s: profiles/r04_rr64_D12_final_kernel_seq.txt).  Here a
+// a load phase and a 32 KB epilogue, 10 us per tile (1.6 TB/s: profiles/r04_rr64_D12_final_kernel_seq.txt; 484 us for
+// the product above, this kernel: 174 us = 4.9 TB/s, profiles/r04_smallk_check.jsonl).  Here a
 // thread owns 8 consecutive columns: it keeps its 8 rows of B in registers as f32 (8 K values), walks 64 rows of A that
 // the workgroup staged in LDS as f32 (every lane reads the same address: a broadcast), and leaves one 16-byte store per
 // row -- 4 KB contiguous per wave and row.  f32 FMAs in k order; results agree with the matrix-core kernels to the
@@ -79,7 +80,7 @@ __global__ __launch_bounds__(256) void gemm_smallk_kernel(SmallKArgs p) {
 // true when the product is in this kernel's range and large enough to be a store stream
 bool gemm_bf16_smallk_wanted(int out_dt, int64_t M, int64_t N, int64_t K, int64_t batch, const void* A, int64_t lda,
                              const void* B, int64_t ldb, const void* C, int64_t ldc) {
-  static const bool on = []() { const char* e = getenv("TNH_GEMM_SMALLK"); return e ? e[0] != '0' : false; }();
+  static const bool on = []() { const char* e = getenv("TNH_GEMM_SMALLK"); return !(e && e[0] == '0'); }();   // "0": tile kernels
   if (!on || batch != 1 || out_dt == TNH_F32 || K < 4 || K > 16 || K % 4 != 0) return false;
   if (M < 16 || N < 256 || N % 8 != 0 || M * N < (int64_t(1) << 22)) return false;
   return lda % 4 == 0 && ldb % 4 == 0 && ldc % 8 == 0 && lda >= K && ldb >= K && ldc >= N && ((uintptr_t)A % 8) == 0 &&

@@ -1205,6 +1205,39 @@ def test_row_padded_results_on_the_device(hip):
     hip.pad_results, hip.pad_min_bytes = saved
 
 
+# ---------------------------------------------------------------- K2 with K <= 16: a store stream
+@pytest.mark.parametrize("dtype,m,n,k", [(ta.bfloat16, 1000, 20008, 12), (np.float16, 144, 65536, 4),
+                                         (ta.bfloat16, 1728, 24576, 16), (ta.bfloat16, 200, 40000, 8)])
+def test_gemm_small_k_store_stream(hip, dtype, m, n, k):
+  """One small bond contracted between two tensors (K <= 16, a large result): `gemm_smallk_kernel` -- f32 FMAs in k
+  order, so every entry is the correctly rounded half-precision value of the exact product sum (<= 0.5 ulp + the fp32
+  round-off), and within one ulp of the tile kernels' result."""
+  rng = np.random.default_rng(m + k)
+  a = rng.standard_normal((m, k)).astype(np.float32)
+  b = rng.standard_normal((n, k)).astype(np.float32)
+  if dtype is ta.bfloat16:
+    a, b = orc.round_bf16(a), orc.round_bf16(b)
+    da, db = hip.to_bfloat16(a), hip.to_bfloat16(b)
+  else:
+    a, b = a.astype(np.float16), b.astype(np.float16)
+    da, db = dev(hip, a), dev(hip, b)
+  got = np.asarray(hip.tensordot(da, db, [[1], [1]])).astype(np.float64)
+  kernel = hip.lib.tnh_gemm_last_kernel().decode()
+  if not hasattr(hip, "_emu"):
+    assert kernel == "bf16_smallk_64x2048", kernel
+  ref = a.astype(np.float64) @ b.astype(np.float64).T
+  ulp = 2.0**-7 if dtype is ta.bfloat16 else 2.0**-10            # relative spacing at the bottom of a binade
+  assert np.max(np.abs(got - ref) / (np.abs(ref) * ulp + 1e-3 * ulp)) <= 0.52
+  if not hasattr(hip, "_emu"):
+    _lib.check(hip.lib.tnh_gemm_set_variant(b"bf16_ragged"))
+    try:
+      tile = np.asarray(hip.tensordot(da, db, [[1], [1]])).astype(np.float64)
+      assert hip.lib.tnh_gemm_last_kernel().decode().startswith("bf16_nt_ragged")
+    finally:
+      _lib.check(hip.lib.tnh_gemm_set_variant(b"auto"))
+    assert np.max(np.abs(got - tile) / (np.abs(ref) * ulp + 1e-3 * ulp)) <= 1.02
+
+
 # ---------------------------------------------------------------- K2 gather: the long operand read where it lies
 # (shape_small, shape_long, axes_small, axes_long, small_first, kernel, same K order as the classic lowering)
 _GATHER_CASES = [

@@ -290,6 +290,7 @@ def _gpu_suite_selection():
           TK.test_gemm_gather_reads_the_long_operand_in_place_bit_exact,
           TK.test_gemm_gather_follows_the_planner_hint_for_the_small_operand_only,
           TK.test_gemm_gather_may_put_the_long_operands_axes_first, TK.test_gemm_gather_k_loop,
+          TK.test_gemm_small_k_store_stream,
           TK.test_gemm_gather_leaves_other_products_alone, TK.test_gemm_gather_c_abi_rejects_bad_descriptors_without_launching,
           TK.test_tensordot_random_axes_property, TK.test_misc_golden, TK.test_tensordot_golden,
           TK.test_tensordot_errors_and_empty, TK.test_elementwise_math, TK.test_init_functions, TK.test_casts,
