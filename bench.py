@@ -613,12 +613,16 @@ def sliced_network_bench(ta, be, comm, rank, world, D, min_slices, verify):
     t_reduce_max = comm.max_over_ranks(t_reduce)
   else:
     t_compute_max, t_reduce_max = t_compute, t_reduce
-  total_flops = 2.0 * rep["flops_per_slice"] * rep["n_slices"]   # the cost model counts multiply-adds
+  # the cost model counts multiply-adds; the slice-invariant steps of the path run once per rank, not once per slice
+  inv = rep.get("flops_invariant_per_slice", 0.0)
+  total_flops = 2.0 * ((rep["flops_per_slice"] - inv) * rep["n_slices"] + inv * world)
   result = float(np.asarray(out).reshape(-1)[0])
   rec = {"workload": f"64-node random 3-regular network (seed 6), bond D={D}, bf16, {len(cuts)} cut bonds",
          "n_slices": int(rep["n_slices"]), "n_gpus": world, "seconds": t, "scaling": "strong",
          "flops_total": total_flops, "tflops": total_flops / t / 1e12,
          "peak_intermediate_elems": rep["peak_per_slice"],
+         "steps_per_slice": int(rep.get("steps_per_slice", 0)) - int(rep.get("invariant_steps", 0)),
+         "slice_invariant_steps_run_once": int(rep.get("invariant_steps", 0)),
          "slowest_rank_compute_seconds": t_compute_max, "allreduce_seconds": t_reduce_max,
          "collective": "one all-reduce(sum) of the fp32-accumulated scalar (tnh_allreduce, RCCL)" if world > 1 else "none",
          "accumulation": "slice partials added in fp32, rounded to bf16 once", "result": result}

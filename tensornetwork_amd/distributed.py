@@ -83,10 +83,60 @@ def choose_cut_edges(nodes: Sequence[network.Node], min_slices: int,
   return cuts
 
 
+def _variant_steps(n_inputs: int, variant_inputs: Sequence[bool], path):
+  """Walk a linear path symbolically: [(id_a, id_b, id_new, variant)] per pairwise step, ids 0 .. n_inputs - 1 for the
+  inputs and n_inputs + s for the result of step s; a result is variant when one of its operands is."""
+  ids = list(range(n_inputs))
+  variant = list(variant_inputs)
+  steps = []
+  for pair in path:
+    if len(pair) == 1:
+      continue
+    a, b = sorted(pair)
+    ia, ib, new = ids[a], ids[b], n_inputs + len(steps)
+    variant.append(variant[ia] or variant[ib])
+    steps.append((ia, ib, new, variant[new]))
+    ids = [x for k, x in enumerate(ids) if k not in (a, b)] + [new]
+  return steps
+
+
+def _hoist_invariant(nodes, cut_edges, path, output_edge_order):
+  """Every slice contracts the same network with the same path; a pairwise step neither of whose operands
+  depends on a cut bond gives the same tensor in every slice.  Those steps are run ONCE here, on a copy of
+  the network, and the slices contract what is left: the inputs that touch a cut bond, the slice-invariant
+  intermediates, and the remaining steps of the SAME path in the same order (so every slice partial is the
+  tensor it was before).  Returns (nodes, cut_edges, path, output_edge_order, steps hoisted) of the reduced
+  network, or None when there is nothing to hoist."""
+  if any(e.is_trace() for n in nodes for e in n.edges if not e.is_dangling()):
+    return None       # (contract_path folds trace edges first, which renumbers nothing but replaces nodes)
+  touched = {id(nd) for e in cut_edges for nd, _ in e.ends()}
+  steps = _variant_steps(len(nodes), [id(n) in touched for n in nodes], path)
+  hoist = [st for st in steps if not st[3]]
+  if not hoist:
+    return None
+  node_map, edge_map = network.copy(nodes)
+  by_id = {k: node_map[n] for k, n in enumerate(nodes)}
+  # layout planning as contract_path does it, with the times of the WHOLE path: an invariant intermediate is laid
+  # out for the step that consumes it, once, instead of being permuted in every slice
+  edge_time = contractors._edge_times(path, [node_map[n] for n in nodes])      # pylint: disable=protected-access
+  for ia, ib, new, _ in hoist:
+    by_id[new] = network.contract_between(by_id.pop(ia), by_id.pop(ib), allow_outer_product=True, edge_time=edge_time)
+  live = sorted(by_id)                      # what the slices start from
+  cur, rest = list(live), []
+  for ia, ib, new, is_variant in steps:
+    if not is_variant:
+      continue
+    rest.append(tuple(sorted((cur.index(ia), cur.index(ib)))))
+    cur = [x for x in cur if x not in (ia, ib)] + [new]
+  order = [edge_map[e] for e in output_edge_order] if output_edge_order is not None else None
+  return [by_id[k] for k in live], [edge_map[e] for e in cut_edges], rest, order, len(hoist)
+
+
 def contract_sliced(nodes: Sequence[network.Node], cut_edges: Sequence[network.Edge],
                     comm=None, algorithm: Callable = pathfinder.greedy,
                     output_edge_order: Optional[Sequence[network.Edge]] = None,
-                    use_graph: Optional[bool] = None, partials_out: Optional[list] = None):
+                    use_graph: Optional[bool] = None, partials_out: Optional[list] = None,
+                    hoist_invariant: bool = True, stats: Optional[dict] = None):
   """Contract `nodes` by summing over all index values of `cut_edges`.
 
   Returns the backend tensor of the full contraction (identical on every rank).
@@ -98,7 +148,11 @@ def contract_sliced(nodes: Sequence[network.Node], cut_edges: Sequence[network.E
   slice only the sliced inputs are refreshed in place and the graph is replayed.
 
   `partials_out` (a list; verification runs only): every slice's partial result is appended to it as a host
-  float64 array before it is added (one blocking read per slice; forces the eager path)."""
+  float64 array before it is added (one blocking read per slice; forces the eager path).
+
+  `hoist_invariant` (default on): the steps of the path that do not depend on a cut bond are contracted ONCE
+  before the slice loop (`_hoist_invariant`); the slices run the remaining steps of the same path.  `stats`
+  (a dict) receives ``hoisted_steps`` / ``steps_per_slice``."""
   comm = comm or LocalComm()
   nodes = list(nodes)
   cut_edges = list(cut_edges)
@@ -115,6 +169,14 @@ def contract_sliced(nodes: Sequence[network.Node], cut_edges: Sequence[network.E
   for e in cut_edges:
     sliced_sizes[e] = 1
   path = algorithm(inputs, output, sliced_sizes)
+  hoisted = 0
+  if hoist_invariant and cut_edges and len(all_slices) > 1:
+    reduced = _hoist_invariant(nodes, cut_edges, path, output_edge_order)
+    if reduced is not None:
+      nodes, cut_edges, path, output_edge_order, hoisted = reduced
+  if stats is not None:
+    stats["hoisted_steps"] = hoisted
+    stats["steps_per_slice"] = sum(1 for pair in path if len(pair) > 1)
 
   mine = all_slices[comm.rank::comm.world]
   if partials_out is not None:
@@ -227,8 +289,27 @@ def slicing_report(nodes: Sequence[network.Node], cut_edges: Sequence[network.Ed
     sliced[e] = 1
   path1 = algorithm(inputs, output, sliced)
   flops1, peak1 = pathfinder.path_cost(inputs, output, sliced, path1)
+  # the part of a slice that does not depend on the cut bonds (contract_sliced runs it once: _hoist_invariant)
+  nodes = list(nodes)
+  touched = {id(nd) for e in cut_edges for nd, _ in e.ends()}
+  steps = _variant_steps(len(nodes), [id(n) in touched for n in nodes], path1)
+  invariant, remaining = 0, [frozenset(x) for x in inputs]
+  live = list(range(len(nodes)))
+  for ia, ib, new, is_variant in steps:
+    k1, k2 = remaining[live.index(ia)], remaining[live.index(ib)]
+    others = set(output)
+    for x, k in zip(live, remaining):
+      if x not in (ia, ib):
+        others |= k
+    if not is_variant:
+      invariant += pathfinder._size(k1 | k2, sliced)      # pylint: disable=protected-access
+    keep = [(x, k) for x, k in zip(live, remaining) if x not in (ia, ib)]
+    live = [x for x, _ in keep] + [new]
+    remaining = [k for _, k in keep] + [frozenset(d for d in (k1 | k2) if d in others)]
   return {"n_slices": n_slices, "flops_unsliced": float(flops0), "peak_unsliced": float(peak0),
           "flops_per_slice": float(flops1), "peak_per_slice": float(peak1),
+          "flops_invariant_per_slice": float(invariant),
+          "invariant_steps": sum(1 for st in steps if not st[3]), "steps_per_slice": len(steps),
           "overhead": float(flops1) * n_slices / max(float(flops0), 1.0)}
 
 

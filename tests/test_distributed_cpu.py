@@ -520,3 +520,42 @@ def test_eight_rank_rehearsal_of_the_north_star_network(tmp_path):
   assert max(int(g["n_mine"]) for g in got) - min(int(g["n_mine"]) for g in got) <= 1
   for g in got:
     np.testing.assert_allclose(g["out"], ref, rtol=1e-9)
+
+
+def test_slice_invariant_steps_are_contracted_once():
+  """contract_sliced runs the steps of the path that touch no cut bond ONCE, before the slice loop: same result and
+  the same slice partials as without hoisting, fewer pairwise contractions, and slicing_report counts the same steps."""
+  from tensornetwork_amd import network as net_mod  # pylint: disable=import-outside-toplevel
+  nodes = regular_network(OracleBackend(), n=14, D=3, seed=4)
+  cuts = distributed.choose_cut_edges(nodes, min_slices=9)
+  calls = {"n": 0}
+  real = net_mod.contract_between
+
+  def counting(*args, **kwargs):
+    calls["n"] += 1
+    return real(*args, **kwargs)
+
+  results = {}
+  net_mod.contract_between = counting
+  try:
+    for on in (True, False):
+      calls["n"], parts, stats = 0, [], {}
+      out = distributed.contract_sliced(nodes, cuts, hoist_invariant=on, partials_out=parts, stats=stats)
+      results[on] = (np.asarray(out), [np.asarray(p) for p in parts], calls["n"], dict(stats))
+  finally:
+    net_mod.contract_between = real
+  rep = distributed.slicing_report(nodes, cuts)
+  n_slices = int(rep["n_slices"])
+  (out1, parts1, calls1, stats1), (out0, parts0, calls0, stats0) = results[True], results[False]
+  np.testing.assert_allclose(out1, out0, rtol=1e-12, atol=1e-12)
+  assert len(parts1) == len(parts0) == n_slices
+  for a, b in zip(parts1, parts0):
+    np.testing.assert_allclose(a, b, rtol=1e-12, atol=1e-12)
+  assert stats0["hoisted_steps"] == 0 and stats1["hoisted_steps"] == rep["invariant_steps"] > 0
+  assert stats1["steps_per_slice"] == rep["steps_per_slice"] - rep["invariant_steps"]
+  assert calls0 == n_slices * rep["steps_per_slice"]
+  assert calls1 == rep["invariant_steps"] + n_slices * stats1["steps_per_slice"]
+  assert 0 < rep["flops_invariant_per_slice"] < rep["flops_per_slice"]
+  # the unsliced contraction of the same network
+  ref = contractors.greedy(list(network.copy(nodes)[0].values())).tensor
+  np.testing.assert_allclose(out1, np.asarray(ref), rtol=1e-9, atol=1e-9)

@@ -82,7 +82,11 @@ nodes = [nodes[v] for v in sorted(g.nodes)]
 cuts = distributed.choose_cut_edges(nodes, min_slices=a.min_slices)
 class One(distributed.LocalComm):
   rank, world = 0, 10**9
-distributed.contract_sliced(nodes, cuts, comm=One(), use_graph=False)
+STATS = {}
+distributed.contract_sliced(nodes, cuts, comm=One(), use_graph=False, stats=STATS)
+rep = distributed.slicing_report(nodes, cuts)
+print("slice-invariant steps (run once, before the slice loop):", STATS.get("hoisted_steps"), "of", rep["steps_per_slice"],
+      f"= {rep['flops_invariant_per_slice'] / rep['flops_per_slice']:.2e} of a slice's flops; the launches below are those steps + ONE slice")
 tot = 0
 for rec in LOG:
   if rec[0] == "gemm":
