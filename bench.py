@@ -872,7 +872,14 @@ def mera_chi64_bench(ta, be, n_gpus=8, verify=False, full_placements=0, budget_s
   measured = {}
   for pl in ("left", "right")[:max(0, int(full_placements))]:
     # the placement as a RUN: all chi^2 slices through the path, partials added on the device
-    run = workloads.mera_sliced_run(be, chi, pl, ta.bfloat16, budget_seconds=budget_s, check_every=1024 if verify else 0)
+    # (partial contractions that depend on one of the two slice indices only are computed once per value of that index:
+    #  workloads.mera_sliced_run(reuse_partials=True); should that path fail on this box, the slice-by-slice run stands in)
+    try:
+      run = workloads.mera_sliced_run(be, chi, pl, ta.bfloat16, budget_seconds=budget_s, check_every=1024 if verify else 0)
+    except Exception as exc:  # pylint: disable=broad-except
+      run = workloads.mera_sliced_run(be, chi, pl, ta.bfloat16, budget_seconds=budget_s, check_every=1024 if verify else 0,
+                                      reuse_partials=False)
+      run["reuse_partials_error"] = f"{type(exc).__name__}: {exc}"[:300]
     if verify and run["checks"]:
       chk = partials_check([[c[1]] for c in run["checks"]], [[c[2]] for c in run["checks"]], 11)
       run["checks_vs_f32"] = {k: chk[k] for k in ("n_values", "rms_rel_err", "model_rms", "err_over_tol", "ok")}
@@ -905,10 +912,18 @@ def mera_chi64_bench(ta, be, n_gpus=8, verify=False, full_placements=0, budget_s
     rec["measured"] = measured
     rec["measured_slices"] = done
     rec["measured_seconds"] = secs
-    rec["measured_tflops"] = sum(2.0 * m["macs_per_slice"] * m["slices_done"] for m in measured.values()) / secs / 1e12
+    # executed multiply-adds (with partial results reused across slices far fewer than slices x one slice's cost)
+    rec["measured_tflops"] = sum(2.0 * m.get("executed_macs", m["macs_per_slice"] * m["slices_done"])
+                                 for m in measured.values()) / secs / 1e12
+    rec["measured_reuse_partials"] = bool(all(m.get("reuse_partials") for m in measured.values()))
+    alone = sum(per[pl]["sec_per_slice"] * m["slices_done"] for pl, m in measured.items() if pl in per)
+    if alone > 0:
+      rec["measured_speedup_over_slice_by_slice"] = alone / secs       # against (seconds of one slice alone) x slices done
     complete = all(m["slices_done"] == m["n_slices"] for m in measured.values())
-    rec["measured_label"] = (f"MEASURED on 1 GPU: {len(measured)} of 2 placements run slice by slice "
-                             f"({done} slices{'' if complete else ', stopped by the time budget'}); the 8-GPU figure "
+    rec["measured_label"] = (f"MEASURED on 1 GPU: {len(measured)} of 2 placements, every slice contracted "
+                             f"({done} slices{'' if complete else ', stopped by the time budget'}); partial results that "
+                             "depend on one slice index only are reused across slices when measured_reuse_partials is true "
+                             "(the EXTRAPOLATED rows are per-slice seconds x slices, without reuse); the 8-GPU figure "
                              "stays arithmetic (no 8-GPU node on the builder's side)")
     if verify:
       rec.setdefault("verified_runs", {pl: m.get("checks_vs_f32") for pl, m in measured.items()})
@@ -1177,7 +1192,8 @@ def compact_line(result, detail_name):
                                   "permute_time_frac"))
   line["mera"] = _pick(result.get("mera"), ("chi", "seconds", "tflops", "permute_launches"))
   line["mera_chi64"] = _pick(result.get("mera_chi64"),
-                             ("measured_seconds", "measured_slices", "measured_tflops", "layer_seconds_1gpu_extrapolated",
+                             ("measured_seconds", "measured_slices", "measured_tflops", "measured_reuse_partials",
+                              "measured_speedup_over_slice_by_slice", "layer_seconds_1gpu_extrapolated",
                               "layer_seconds_8gpu_extrapolated", "tflops_1gpu"))
   chain = result.get("mps_chain")
   if isinstance(chain, list):

@@ -864,3 +864,46 @@ def test_gather_lowering_random_products_match_numpy():
       np.testing.assert_allclose(got, want, rtol=2.0**-7, atol=2.0**-8 * k**0.5)
       del ds, dl
   assert gathered >= 8 and looped >= 1 and swapped_seen >= 1, (gathered, looped, swapped_seen)
+
+
+@pytest.mark.parametrize("placement", ["left", "right"])
+def test_mera_sliced_run_reuses_partial_contractions(placement):
+  """The bond-sliced MERA layer: the hamiltonian slice depends on i only, the state slice on j only, so most steps of the
+  path depend on one index; computing them once per value of that index gives the same slice results (the f32 check of
+  sampled slices is exact in f32) and the same sum (up to the order of the f32 additions), with the executed
+  multiply-adds counted per stage."""
+  from tensornetwork_amd import workloads  # pylint: disable=import-outside-toplevel
+  chi = 4
+  with emulated_backend() as be:
+    alone = workloads.mera_sliced_run(be, chi, placement, np.float32, reuse_partials=False)
+    staged = workloads.mera_sliced_run(be, chi, placement, np.float32, check_every=3)
+    half_alone = workloads.mera_sliced_run(be, chi, placement, ta.bfloat16, reuse_partials=False)
+    half_staged = workloads.mera_sliced_run(be, chi, placement, ta.bfloat16)
+  assert staged["reuse_partials"] and staged["slices_done"] == alone["slices_done"] == chi * chi
+  assert abs(staged["energy_partial_sum"] - alone["energy_partial_sum"]) <= 1e-5 * max(1.0, abs(alone["energy_partial_sum"]))
+  assert half_staged["energy_partial_sum"] == half_alone["energy_partial_sum"]
+  assert staged["checks"] and all(abs(c[1] - c[2]) <= 1e-6 * max(1.0, abs(c[2])) for c in staged["checks"])
+  macs, runs = staged["macs_by_dependence"], staged["stage_runs"]
+  assert runs == {"none": 1, "i": chi, "j": chi, "ij": chi * chi}
+  assert abs(sum(macs.values()) - staged["macs_per_slice"]) <= 1e-9 * staged["macs_per_slice"]      # the stages ARE the path
+  assert staged["executed_macs"] == macs["none"] + chi * (macs["i"] + macs["j"]) + chi * chi * macs["ij"]
+  assert staged["executed_macs"] < 0.5 * staged["macs_per_slice"] * chi * chi
+  # a time budget stops between slices and says how far it got
+  with emulated_backend() as be:
+    short = workloads.mera_sliced_run(be, 6, placement, np.float32, budget_seconds=0.0)
+  assert 0 < short["slices_done"] < 36 and short["stage_runs"]["ij"] == short["slices_done"]
+
+
+def test_bench_mera_chi64_leg_on_the_emulated_backend():
+  """bench.py's mera_chi64 leg at chi = 4 with both placements run: the record distinguishes the measured run (partial
+  results reused) from the per-slice extrapolation and counts the executed flops."""
+  import bench  # pylint: disable=import-outside-toplevel
+  with emulated_backend() as be:
+    rec = bench.mera_chi64_bench(ta, be, verify=True, full_placements=2, budget_s=60.0, chi=4)
+  assert rec["measured_slices"] == 32 and rec["measured_reuse_partials"] is True
+  assert set(rec["measured"]) == {"left", "right"} and all("reuse_partials_error" not in m for m in rec["measured"].values())
+  # (at chi = 4 a placement's run samples ONE slice partial, too few for the rms model: only its presence is checked)
+  assert rec["verified"]["ok"] and set(rec["verified_runs"]) == {"left", "right"}
+  executed = sum(m["executed_macs"] for m in rec["measured"].values())
+  assert abs(rec["measured_tflops"] - 2.0 * executed / rec["measured_seconds"] / 1e12) <= 1e-9 * rec["measured_tflops"]
+  assert rec["measured_speedup_over_slice_by_slice"] > 0
