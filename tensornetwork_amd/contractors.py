@@ -11,7 +11,7 @@ Works on ``tensornetwork_amd.network.Node`` objects; the search itself is pure
 host code, the pairwise steps are GEMMs on the backend.
 """
 import functools
-from typing import Dict, Callable, Iterable, List, Optional, Sequence, Set, Tuple
+from typing import Any, Dict, Callable, Iterable, List, Optional, Sequence, Set, Tuple
 
 from tensornetwork_amd import network, pathfinder
 
@@ -77,6 +77,38 @@ def _edge_times(path: Sequence[Tuple[int, ...]], nodes: Sequence[network.Node]) 
     groups = [g for i, g in enumerate(groups) if i not in (a, b)] + [merged_nodes]
     owner_edges = [g for i, g in enumerate(owner_edges) if i not in (a, b)] + [merged_edges]
   return times
+
+
+def contract_labelled(be, operands: Dict[int, Tuple[Any, Sequence[Any]]], steps: Sequence[Tuple[int, int, int]],
+                      label_time: Optional[Dict[Any, int]] = None) -> Dict[int, Tuple[Any, List[Any]]]:
+  """Pairwise contractions on operands given as {id: (tensor, axis labels)}: axes that carry the same label are
+  connected, a label that occurs once stays open (its partner lives elsewhere -- another stage of a staged
+  contraction -- or it is a dangling leg).  `steps` = [(id_a, id_b, id_new)] in execution order.  Returns
+  {id: (tensor, axis labels)} of what is left.  Layout planning as in `contract_path`: `label_time` says at which step
+  of the whole path a label is contracted (network.contract_between's `edge_time`)."""
+  nodes = {k: network.Node(t, backend=be) for k, (t, _) in operands.items()}
+  edge_label, first = {}, {}
+  for k, (_, labels) in operands.items():
+    for ax, lab in enumerate(labels):
+      if lab in first:
+        k0, ax0 = first.pop(lab)
+        edge_label[network.connect(nodes[k0][ax0], nodes[k][ax])] = lab
+      else:
+        first[lab] = (k, ax)
+  for lab, (k, ax) in first.items():
+    edge_label[nodes[k][ax]] = lab
+  edge_time = None
+  if label_time is not None:
+    edge_time = {e: label_time[lab] for e, lab in edge_label.items() if lab in label_time}
+  for ia, ib, new in steps:
+    a, b = nodes.pop(ia), nodes.pop(ib)
+    nodes[new] = network.contract_between(a, b, allow_outer_product=True, edge_time=edge_time)
+    for used in (a, b):               # Node <-> Edge cycles: drop the references now (intermediates can be GBs; the
+      used.tensor, used.edges = None, []   # operands' tensors stay alive with whoever passed them in)
+  out = {k: (nd.tensor, [edge_label[e] for e in nd.edges]) for k, nd in nodes.items()}
+  for nd in nodes.values():
+    nd.tensor, nd.edges = None, []
+  return out
 
 
 def contract_path(path: Sequence[Tuple[int, ...]], nodes: Iterable[network.Node],

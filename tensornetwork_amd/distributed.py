@@ -132,11 +132,141 @@ def _hoist_invariant(nodes, cut_edges, path, output_edge_order):
   return [by_id[k] for k in live], [edge_map[e] for e in cut_edges], rest, order, len(hoist)
 
 
+class _StagePlan:
+  """Which steps of a sliced network's path depend on which cut bonds.
+
+  An input depends on the cuts it touches, a step on the union of its operands' cuts.  A step that depends on the
+  cuts S gives the same tensor in all slices that agree on the index values of S: it needs to run once per value
+  tuple of S, not once per slice.  (The D = 12 north-star network with its two cuts: 38 of 63 steps depend on no cut,
+  20 steps -- 99.4 % of a slice's multiply-adds -- on the second cut alone, 5 small ones on the first or on both:
+  12 runs of the expensive part instead of 144.)"""
+
+  def __init__(self, nodes, cut_edges, path):
+    self.n = len(nodes)
+    self.dims = [e.dimension for e in cut_edges]
+    inputs, output, sizes = _index_problem(nodes)
+    sliced = dict(sizes)
+    for e in cut_edges:
+      sliced[e] = 1
+    pos = {id(nd): k for k, nd in enumerate(nodes)}
+    self.windows: Dict[int, List[Tuple[int, int]]] = {}          # input -> [(axis, cut number)]
+    for c, e in enumerate(cut_edges):
+      for nd, ax in e.ends():
+        self.windows.setdefault(pos[id(nd)], []).append((ax, c))
+    dep = [frozenset(c for _, c in self.windows.get(k, [])) for k in range(self.n)]
+    ids = list(range(self.n))
+    remaining = [frozenset(x) for x in inputs]
+    self.steps = []                                              # (id_a, id_b, id_new, cuts it depends on, multiply-adds)
+    for pair in path:
+      if len(pair) == 1:
+        continue
+      a, b = sorted(pair)
+      k1, k2 = remaining[a], remaining[b]
+      others = set(output)
+      for t, k in enumerate(remaining):
+        if t not in (a, b):
+          others |= k
+      new = self.n + len(self.steps)
+      dep.append(dep[ids[a]] | dep[ids[b]])
+      self.steps.append((ids[a], ids[b], new, dep[new], float(pathfinder._size(k1 | k2, sliced))))   # pylint: disable=protected-access
+      ids = [x for t, x in enumerate(ids) if t not in (a, b)] + [new]
+      remaining = [k for t, k in enumerate(remaining) if t not in (a, b)] + [frozenset(d for d in (k1 | k2) if d in others)]
+    self.dep = dep
+    self.final = self.steps[-1][2] if self.steps else 0
+    self.classes = sorted({st[3] for st in self.steps}, key=lambda c: (len(c), sorted(c)))
+    self.class_steps = {c: [(a, b, new) for a, b, new, d, _ in self.steps if d == c] for c in self.classes}
+    self.class_macs = {c: sum(st[4] for st in self.steps if st[3] == c) for c in self.classes}
+    self.class_needs = {}
+    for c, lst in self.class_steps.items():
+      produced = {new for _, _, new in lst}
+      self.class_needs[c] = sorted({x for a, b, _ in lst for x in (a, b)} - produced)
+    self.labels = [[id(e) for e in nd.edges] for nd in nodes]
+    self.label_time = {id(e): t for e, t in contractors._edge_times(path, nodes).items()}     # pylint: disable=protected-access
+    # loop order of the slices: the cut whose steps cost most varies slowest
+    weight = [sum(m for c, m in self.class_macs.items() if k in c) for k in range(len(cut_edges))]
+    self.loop_order = sorted(range(len(cut_edges)), key=lambda k: (-weight[k], k))
+
+  def macs_alone(self) -> float:
+    return sum(st[4] for st in self.steps)
+
+  def macs_with_reuse(self, slices) -> float:
+    """multiply-adds executed for `slices` (index tuples) when every class runs once per distinct value tuple"""
+    total = 0.0
+    for c, macs in self.class_macs.items():
+      total += macs * len({tuple(idx[k] for k in sorted(c)) for idx in slices})
+    return total
+
+  def ordered(self, slices):
+    return sorted(slices, key=lambda idx: tuple(idx[k] for k in self.loop_order))
+
+
+def _contract_slices_staged(be, nodes, plan: _StagePlan, slices, output_edge_order, partials_out, stats):
+  """The slices of one rank with every step run once per distinct value of the cuts it depends on (`_StagePlan`).
+  Results of a class are kept for the value tuple in use (and for all value tuples when the class is cheap to
+  keep: <= 64 results of <= 256 MiB in all), so with the slices in `plan.ordered` order the expensive classes run
+  once per value.  Every slice partial is the tensor the slice-by-slice contraction gives: same steps, same order,
+  same operands."""
+  n = plan.n
+  cache: Dict[frozenset, Dict[tuple, dict]] = {c: {} for c in plan.classes}
+  keep_all: Dict[frozenset, bool] = {}
+  runs = {c: 0 for c in plan.classes}
+  sliced_inputs: Dict[int, Tuple[tuple, object]] = {}
+
+  def input_tensor(k, idx):
+    wins = plan.windows.get(k)
+    if not wins:
+      return nodes[k].tensor
+    key = tuple(idx[c] for _, c in wins)
+    if k in sliced_inputs and sliced_inputs[k][0] == key:
+      return sliced_inputs[k][1]
+    t = nodes[k].tensor
+    shape = list(be.shape_tuple(t))
+    starts = [0] * len(shape)
+    for ax, c in wins:
+      starts[ax], shape[ax] = idx[c], 1
+    sliced_inputs[k] = (key, be.slice(t, tuple(starts), tuple(shape)))
+    return sliced_inputs[k][1]
+
+  def stage(c, idx):
+    key = tuple(idx[k] for k in sorted(c))
+    got = cache[c].get(key)
+    if got is not None:
+      return got
+    operands = {}
+    for x in plan.class_needs[c]:
+      operands[x] = (input_tensor(x, idx), plan.labels[x]) if x < n else stage(plan.dep[x], idx)[x]
+    out = contractors.contract_labelled(be, operands, plan.class_steps[c], plan.label_time)
+    runs[c] += 1
+    if c not in keep_all:
+      count = int(np.prod([plan.dims[k] for k in c])) if c else 1
+      nbytes = sum(int(np.prod(be.shape_tuple(t))) * 4 for t, _ in out.values())
+      keep_all[c] = count <= 64 and count * nbytes <= (256 << 20)
+    if not keep_all[c]:
+      cache[c].clear()
+    cache[c][key] = out
+    return out
+
+  want = [id(e) for e in output_edge_order] if output_edge_order is not None else None
+  total, narrow = None, None
+  for idx in slices:
+    tensor, labels = stage(plan.dep[plan.final], idx)[plan.final]
+    if want is not None and list(labels) != want:
+      tensor = be.transpose(tensor, tuple(labels.index(lab) for lab in want))
+    part, narrow = _widen(be, tensor)
+    if partials_out is not None:
+      partials_out.append(np.asarray(part, dtype=np.float64).copy())
+    total = be.multiply(part, 1.0) if total is None else be.addition(total, part)
+  if stats is not None:
+    stats["stage_runs"] = {",".join(str(k) for k in sorted(c)) or "-": r for c, r in runs.items()}
+    stats["executed_macs"] = sum(plan.class_macs[c] * r for c, r in runs.items())
+  return total, narrow
+
+
 def contract_sliced(nodes: Sequence[network.Node], cut_edges: Sequence[network.Edge],
                     comm=None, algorithm: Callable = pathfinder.greedy,
                     output_edge_order: Optional[Sequence[network.Edge]] = None,
                     use_graph: Optional[bool] = None, partials_out: Optional[list] = None,
-                    hoist_invariant: bool = True, stats: Optional[dict] = None):
+                    hoist_invariant: bool = True, stats: Optional[dict] = None, reuse: Optional[bool] = None):
   """Contract `nodes` by summing over all index values of `cut_edges`.
 
   Returns the backend tensor of the full contraction (identical on every rank).
@@ -150,9 +280,14 @@ def contract_sliced(nodes: Sequence[network.Node], cut_edges: Sequence[network.E
   `partials_out` (a list; verification runs only): every slice's partial result is appended to it as a host
   float64 array before it is added (one blocking read per slice; forces the eager path).
 
-  `hoist_invariant` (default on): the steps of the path that do not depend on a cut bond are contracted ONCE
-  before the slice loop (`_hoist_invariant`); the slices run the remaining steps of the same path.  `stats`
-  (a dict) receives ``hoisted_steps`` / ``steps_per_slice``."""
+  `reuse` (default: automatically, when `use_graph` is left alone and it saves at least a fifth of this rank's
+  multiply-adds): every step runs
+  once per distinct value of the cut bonds it DEPENDS on instead of once per slice (`_StagePlan`,
+  `_contract_slices_staged`); the slices are then dealt to the ranks in contiguous blocks of the order in which the
+  expensive steps change least.  Otherwise (`hoist_invariant`, default on) only the steps that depend on no cut bond
+  are contracted once, before the slice loop (`_hoist_invariant`), and the slices run the remaining steps of the same
+  path eagerly or as a hipGraph.  Every slice partial is the same tensor in all three modes.  `stats` (a dict)
+  receives ``mode`` and the step / multiply-add counts."""
   comm = comm or LocalComm()
   nodes = list(nodes)
   cut_edges = list(cut_edges)
@@ -169,12 +304,35 @@ def contract_sliced(nodes: Sequence[network.Node], cut_edges: Sequence[network.E
   for e in cut_edges:
     sliced_sizes[e] = 1
   path = algorithm(inputs, output, sliced_sizes)
+
+  # ---- staged reuse: steps run once per distinct value of the cuts they depend on
+  if reuse is None and use_graph is not None:
+    reuse = False            # the caller picked the slice-by-slice machinery (eager or hipGraph) explicitly
+  if cut_edges and len(all_slices) > 1 and reuse is not False and \
+      not any(e.is_trace() for n in nodes for e in n.edges if not e.is_dangling()):
+    plan = _StagePlan(nodes, cut_edges, path)
+    ordered = plan.ordered(all_slices)
+    per = -(-len(ordered) // comm.world)                     # contiguous blocks: a rank sees few values of the costly cuts
+    mine = ordered[comm.rank * per:(comm.rank + 1) * per]
+    alone = plan.macs_alone() * max(len(mine), 1)
+    if reuse or (mine and plan.macs_with_reuse(mine) <= 0.8 * alone):
+      if stats is not None:
+        stats.update({"mode": "staged", "hoisted_steps": 0, "steps_per_slice": len(plan.steps),
+                      "macs_alone": plan.macs_alone() * len(mine), "slices": len(mine)})
+      if mine:
+        total, narrow = _contract_slices_staged(be, nodes, plan, mine, output_edge_order, partials_out, stats)
+        return _finish(be, comm, total, narrow)
+      # this rank got no slice: zeros of the result's shape and dtype (one slice's result times zero)
+      part, narrow = _contract_slices_staged(be, nodes, plan, ordered[:1], output_edge_order, None, None)
+      return _finish(be, comm, be.multiply(part, 0.0), narrow)
+
   hoisted = 0
   if hoist_invariant and cut_edges and len(all_slices) > 1:
     reduced = _hoist_invariant(nodes, cut_edges, path, output_edge_order)
     if reduced is not None:
       nodes, cut_edges, path, output_edge_order, hoisted = reduced
   if stats is not None:
+    stats["mode"] = "slice by slice"
     stats["hoisted_steps"] = hoisted
     stats["steps_per_slice"] = sum(1 for pair in path if len(pair) > 1)
 
@@ -277,8 +435,9 @@ def _contract_slices_graph(be, nodes, cut_edges, slices, path, output_edge_order
 
 
 def slicing_report(nodes: Sequence[network.Node], cut_edges: Sequence[network.Edge],
-                   algorithm: Callable = pathfinder.greedy) -> Dict[str, float]:
-  """Cost model of a slicing plan (host only): flops and peak intermediate, sliced vs unsliced."""
+                   algorithm: Callable = pathfinder.greedy, world: int = 1) -> Dict[str, float]:
+  """Cost model of a slicing plan (host only): flops and peak intermediate, sliced vs unsliced; what `world` ranks
+  execute when every step runs once per value of the cuts it depends on (contract_sliced's default mode)."""
   inputs, output, sizes = _index_problem(nodes)
   path0 = algorithm(inputs, output, sizes)
   flops0, peak0 = pathfinder.path_cost(inputs, output, sizes, path0)
@@ -306,9 +465,19 @@ def slicing_report(nodes: Sequence[network.Node], cut_edges: Sequence[network.Ed
     keep = [(x, k) for x, k in zip(live, remaining) if x not in (ia, ib)]
     live = [x for x, _ in keep] + [new]
     remaining = [k for _, k in keep] + [frozenset(d for d in (k1 | k2) if d in others)]
+  reuse = {}
+  if cut_edges and n_slices > 1 and not any(e.is_trace() for n in nodes for e in n.edges if not e.is_dangling()):
+    plan = _StagePlan(nodes, list(cut_edges), path1)
+    ordered = plan.ordered(list(itertools.product(*[range(e.dimension) for e in cut_edges])))
+    per = -(-len(ordered) // max(int(world), 1))
+    blocks = [ordered[r * per:(r + 1) * per] for r in range(max(int(world), 1))]
+    per_rank = [plan.macs_with_reuse(b) for b in blocks]
+    reuse = {"flops_with_reuse_all_ranks": float(sum(per_rank)), "flops_with_reuse_slowest_rank": float(max(per_rank)),
+             "reuse_classes": {",".join(str(k) for k in sorted(c)) or "-": float(m) for c, m in plan.class_macs.items()},
+             "staged_by_default": bool(blocks[0] and per_rank[0] <= 0.8 * plan.macs_alone() * len(blocks[0]))}
   return {"n_slices": n_slices, "flops_unsliced": float(flops0), "peak_unsliced": float(peak0),
           "flops_per_slice": float(flops1), "peak_per_slice": float(peak1),
-          "flops_invariant_per_slice": float(invariant),
+          "flops_invariant_per_slice": float(invariant), **reuse,
           "invariant_steps": sum(1 for st in steps if not st[3]), "steps_per_slice": len(steps),
           "overhead": float(flops1) * n_slices / max(float(flops0), 1.0)}
 

@@ -345,31 +345,9 @@ def _mera_stages(plan):
 
 
 def _run_stage(be, operands, steps, label_time):
-  """Contract `steps` ((id_a, id_b, id_new) in path order) on operands {id: (tensor, axis labels)}: axes with the same
-  label are connected, labels that occur once stay open (their partner lives in another stage).  Returns
-  {id: (tensor, axis labels)} of what is left.  Layout planning as in contractors.contract_path: `label_time` says at
-  which step of the whole path a label is contracted."""
-  nodes = {k: network.Node(t, backend=be) for k, (t, _) in operands.items()}
-  edge_label, first = {}, {}
-  for k, (_, labels) in operands.items():
-    for ax, lab in enumerate(labels):
-      if lab in first:
-        k0, ax0 = first.pop(lab)
-        edge_label[network.connect(nodes[k0][ax0], nodes[k][ax])] = lab
-      else:
-        first[lab] = (k, ax)
-  for lab, (k, ax) in first.items():
-    edge_label[nodes[k][ax]] = lab
-  edge_time = {e: label_time[lab] for e, lab in edge_label.items() if lab in label_time}
-  for ia, ib, new in steps:
-    a, b = nodes.pop(ia), nodes.pop(ib)
-    nodes[new] = network.contract_between(a, b, allow_outer_product=True, edge_time=edge_time)
-    for used in (a, b):               # Node <-> Edge cycles: drop the references now (2 GB intermediates; the
-      used.tensor, used.edges = None, []   # operands' tensors stay alive with whoever passed them in)
-  out = {k: (nd.tensor, [edge_label[e] for e in nd.edges]) for k, nd in nodes.items()}
-  for nd in nodes.values():
-    nd.tensor, nd.edges = None, []
-  return out
+  """contractors.contract_labelled (kept under this name for the MERA stages)"""
+  from tensornetwork_amd import contractors  # pylint: disable=import-outside-toplevel
+  return contractors.contract_labelled(be, operands, steps, label_time)
 
 
 def mera_sliced_run(be, chi: int, placement: str, half_dtype, seed: int = 40, budget_seconds: float = None,

@@ -540,7 +540,7 @@ def test_slice_invariant_steps_are_contracted_once():
   try:
     for on in (True, False):
       calls["n"], parts, stats = 0, [], {}
-      out = distributed.contract_sliced(nodes, cuts, hoist_invariant=on, partials_out=parts, stats=stats)
+      out = distributed.contract_sliced(nodes, cuts, hoist_invariant=on, partials_out=parts, stats=stats, reuse=False)
       results[on] = (np.asarray(out), [np.asarray(p) for p in parts], calls["n"], dict(stats))
   finally:
     net_mod.contract_between = real
@@ -559,3 +559,65 @@ def test_slice_invariant_steps_are_contracted_once():
   # the unsliced contraction of the same network
   ref = contractors.greedy(list(network.copy(nodes)[0].values())).tensor
   np.testing.assert_allclose(out1, np.asarray(ref), rtol=1e-9, atol=1e-9)
+
+
+@pytest.mark.parametrize("seed,n,min_slices", [(4, 14, 9), (6, 12, 27), (9, 16, 4)])
+def test_steps_run_once_per_value_of_the_cuts_they_depend_on(seed, n, min_slices):
+  """Staged reuse (the default when it saves a fifth of the work): a step that depends on the cut bonds S runs once per
+  distinct value tuple of S.  Same result, the same multiset of slice partials as the slice-by-slice run, and exactly
+  the predicted number of stage runs and multiply-adds."""
+  nodes = regular_network(OracleBackend(), n=n, D=3, seed=seed)
+  cuts = distributed.choose_cut_edges(nodes, min_slices=min_slices)
+  parts_s, parts_0, stats_s, stats_0 = [], [], {}, {}
+  out_s = distributed.contract_sliced(nodes, cuts, reuse=True, partials_out=parts_s, stats=stats_s)
+  out_0 = distributed.contract_sliced(nodes, cuts, reuse=False, hoist_invariant=False, partials_out=parts_0, stats=stats_0)
+  np.testing.assert_allclose(np.asarray(out_s), np.asarray(out_0), rtol=1e-10, atol=1e-12)
+  assert stats_s["mode"] == "staged" and stats_0["mode"] == "slice by slice"
+  a = np.sort(np.array([float(np.asarray(p).reshape(-1)[0]) for p in parts_s]))
+  b = np.sort(np.array([float(np.asarray(p).reshape(-1)[0]) for p in parts_0]))
+  np.testing.assert_allclose(a, b, rtol=1e-10, atol=1e-12)
+  # the plan predicts what ran
+  inputs, output, sizes = distributed._index_problem(nodes)      # pylint: disable=protected-access
+  sliced = dict(sizes)
+  for e in cuts:
+    sliced[e] = 1
+  from tensornetwork_amd import pathfinder  # pylint: disable=import-outside-toplevel
+  plan = distributed._StagePlan(nodes, cuts, pathfinder.greedy(inputs, output, sliced))      # pylint: disable=protected-access
+  dims = [e.dimension for e in cuts]
+  for c, runs in stats_s["stage_runs"].items():
+    ks = [int(x) for x in c.split(",")] if c != "-" else []
+    assert runs == int(np.prod([dims[k] for k in ks])) if ks else runs == 1
+  n_slices = int(np.prod(dims))
+  assert stats_s["executed_macs"] == sum(m * int(np.prod([dims[k] for k in c])) for c, m in plan.class_macs.items())
+  assert stats_s["executed_macs"] <= plan.macs_alone() * n_slices
+  assert abs(plan.macs_alone() - distributed.slicing_report(nodes, cuts)["flops_per_slice"]) < 1e-6 * plan.macs_alone()
+
+
+def test_staged_reuse_with_open_edges_and_ranks():
+  """Open legs come out in the requested order in the staged mode too, and contiguous blocks of the reordered slices
+  over the ranks add up to the whole."""
+  be = OracleBackend()
+  rng = np.random.default_rng(3)
+  a = network.Node(rng.standard_normal((3, 4, 5)), backend=be)
+  b = network.Node(rng.standard_normal((4, 5, 6, 2)), backend=be)
+  c = network.Node(rng.standard_normal((2, 6, 7)), backend=be)
+  e1 = network.connect(a[1], b[0])
+  network.connect(a[2], b[1])
+  network.connect(b[2], c[1])
+  e2 = network.connect(b[3], c[0])
+  ref = np.einsum("xab,abcd,dcy->yx", np.asarray(a.tensor), np.asarray(b.tensor), np.asarray(c.tensor))
+  out = distributed.contract_sliced([a, b, c], [e1, e2], output_edge_order=[c[2], a[0]], reuse=True)
+  np.testing.assert_allclose(np.asarray(out), ref, rtol=1e-10)
+
+  class Rank(distributed.LocalComm):
+    def __init__(self, rank, world):
+      self.rank, self.world = rank, world
+
+  total = sum(np.asarray(distributed.contract_sliced([a, b, c], [e1, e2], comm=Rank(r, 3), output_edge_order=[c[2], a[0]],
+                                                     reuse=True)) for r in range(3))
+  np.testing.assert_allclose(total, ref, rtol=1e-10)
+  # more ranks than slices: the idle ranks contribute zeros of the right shape
+  outs = [np.asarray(distributed.contract_sliced([a, b, c], [e2], comm=Rank(r, 3), output_edge_order=[c[2], a[0]], reuse=True))
+          for r in range(3)]
+  assert outs[2].shape == ref.shape and not outs[2].any()
+  np.testing.assert_allclose(sum(outs), ref, rtol=1e-10)

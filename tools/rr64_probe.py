@@ -13,7 +13,7 @@ ap.add_argument("--n", type=int, default=64)
 ap.add_argument("--min-slices", type=int, default=64)
 ap.add_argument("--max-slices", type=int, default=8)
 ap.add_argument("--dtype", default="bf16")
-ap.add_argument("--graph", type=int, default=-1)
+ap.add_argument("--graph", type=int, default=-1, help="-1: contract_sliced's default mode (staged reuse); 0 / 1: slice by slice, eager / hipGraph")
 a = ap.parse_args()
 be = ta.get_hip_backend()
 import networkx as nx
@@ -50,11 +50,16 @@ ug = None if a.graph < 0 else bool(a.graph)
 out = distributed.contract_sliced(nodes, cuts, comm=Sub(world), use_graph=ug)  # warm-up
 be.synchronize()
 t0 = time.perf_counter()
-out = distributed.contract_sliced(nodes, cuts, comm=Sub(world), use_graph=ug)
+stats = {}
+out = distributed.contract_sliced(nodes, cuts, comm=Sub(world), use_graph=ug, stats=stats)
 be.synchronize()
 dt = time.perf_counter() - t0
 done = len(range(0, n_slices, world))
 print(json.dumps({"D": D, "dtype": a.dtype, "graph": a.graph, "n_slices": n_slices, "slices_run": done, "plan_s": t_plan,
                   "sec_per_slice": dt / done, "flops_per_slice": 2.0 * rep["flops_per_slice"],
-                  "tflops": 2.0 * rep["flops_per_slice"] * done / dt / 1e12, "peak_elems": rep["peak_per_slice"],
+                  "mode": stats.get("mode"), "stage_runs": stats.get("stage_runs"),
+                  # executed flops (a step runs once per value of the cuts it depends on in the default mode)
+                  "tflops": 2.0 * stats.get("executed_macs", rep["flops_per_slice"] * done) / dt / 1e12,
+                  "tflops_if_every_slice_ran_alone": 2.0 * rep["flops_per_slice"] * done / dt / 1e12,
+                  "peak_elems": rep["peak_per_slice"],
                   "est_full_1gpu_s": dt / done * n_slices, "partial": float(np.asarray(out).reshape(-1)[0])}))
