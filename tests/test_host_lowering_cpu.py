@@ -907,3 +907,21 @@ def test_bench_mera_chi64_leg_on_the_emulated_backend():
   executed = sum(m["executed_macs"] for m in rec["measured"].values())
   assert abs(rec["measured_tflops"] - 2.0 * executed / rec["measured_seconds"] / 1e12) <= 1e-9 * rec["measured_tflops"]
   assert rec["measured_speedup_over_slice_by_slice"] > 0
+
+
+@pytest.mark.parametrize("D,min_slices,staged", [(3, 8, False), (4, 30, True)])
+def test_bench_sliced_network_leg_on_the_emulated_backend(D, min_slices, staged):
+  """bench.py's sliced-network leg end to end at a small bond dimension: the mode contract_sliced takes, the executed
+  flops beside what stand-alone slices would cost, the f32 check of every slice partial, the compact-line entry."""
+  import json  # pylint: disable=import-outside-toplevel
+  import bench  # pylint: disable=import-outside-toplevel
+  with emulated_backend() as be:
+    rec = bench.sliced_network_bench(ta, be, None, 0, 1, D, min_slices, True)
+  assert rec["verified"]["ok"] and rec["verified"]["n_values"] == rec["n_slices"]
+  assert (rec["mode"] != "slice by slice") == staged
+  assert rec["flops_total"] <= rec["flops_if_every_slice_ran_alone"]
+  if staged:
+    assert rec["speedup_over_slices_alone_at_this_rate"] > 1.25
+  assert abs(rec["tflops"] - rec["flops_total"] / rec["seconds"] / 1e12) <= 1e-9 * rec["tflops"]
+  line = json.loads(bench.compact_line({"metric": "m", "value": 1.0, "sliced_network": rec}, "bench_detail.json"))
+  assert line["sliced_network"]["mode"] == rec["mode"] and line["sliced_network"]["n_slices"] == rec["n_slices"]
