@@ -49,11 +49,18 @@ def _index_problem(nodes: Sequence[network.Node]):
 
 
 def choose_cut_edges(nodes: Sequence[network.Node], min_slices: int,
-                     algorithm: Callable = pathfinder.greedy) -> List[network.Edge]:
+                     algorithm: Callable = pathfinder.greedy, beam: int = 0) -> List[network.Edge]:
   """Pick contracted edges to slice until there are >= min_slices slices.
 
   Greedy rule: cut the edge whose removal (dimension -> 1) gives the cheapest
-  re-searched path; this keeps the redundant work introduced by slicing small."""
+  re-searched path; this keeps the redundant work introduced by slicing small.
+
+  `beam` > 0 (opt-in): a beam search over cut SETS instead -- every level extends the `beam` best
+  partial sets by one of the `beam` best single cuts -- ranked by the multiply-adds `contract_sliced` executes when
+  every step runs once per value of the cuts it depends on (`_StagePlan.macs_with_reuse`), then by the cost of the
+  slices run alone, then by the peak intermediate."""
+  if beam > 0:
+    return _choose_cut_edges_beam(nodes, min_slices, algorithm, beam)
   inputs, output, sizes = _index_problem(nodes)
   sizes = dict(sizes)
   cuts: List[network.Edge] = []
@@ -81,6 +88,49 @@ def choose_cut_edges(nodes: Sequence[network.Node], min_slices: int,
     sizes[e] = 1
     candidates.remove(e)
   return cuts
+
+
+def _choose_cut_edges_beam(nodes, min_slices, algorithm, beam):
+  nodes = list(nodes)
+  inputs, output, sizes = _index_problem(nodes)
+  pos = {id(n): i for i, n in enumerate(nodes)}
+  key_of = lambda e: min((pos[id(nd)], ax) for nd, ax in e.ends())
+  candidates = sorted((e for e in sizes if e not in output and not e.is_trace() and sizes[e] > 1), key=key_of)
+
+  def cost(cuts):
+    trial = dict(sizes)
+    for e in cuts:
+      trial[e] = 1
+    path = algorithm(inputs, output, trial)
+    plan = _StagePlan(nodes, list(cuts), path)
+    flops, peak = pathfinder.path_cost(inputs, output, trial, path)
+    n = int(np.prod([sizes[e] for e in cuts]))
+    every = list(itertools.product(*[range(sizes[e]) for e in cuts]))
+    return (plan.macs_with_reuse(every), flops * n, peak)
+
+  singles = sorted(((cost([e]), key_of(e), e) for e in candidates), key=lambda t: (t[0], t[1]))
+  pool = [t[2] for t in singles[:beam]]
+  partial = [(c, [e]) for c, _, e in singles[:beam]]
+  while partial:
+    done = [p for p in partial if int(np.prod([sizes[e] for e in p[1]])) >= min_slices]
+    if done:
+      return min(done, key=lambda p: (p[0], [key_of(e) for e in p[1]]))[1]
+    grown, seen = [], set()
+    for _, cuts in partial:
+      for e in pool:
+        if e in cuts:
+          continue
+        ident = frozenset(id(x) for x in cuts + [e])
+        if ident in seen:
+          continue
+        seen.add(ident)
+        new = sorted(cuts + [e], key=key_of)
+        grown.append((cost(new), new))
+    if not grown:
+      break
+    grown.sort(key=lambda p: (p[0], [key_of(e) for e in p[1]]))
+    partial = grown[:beam]
+  return choose_cut_edges(nodes, min_slices, algorithm)     # (fewer candidates than levels: the sequential rule)
 
 
 def _variant_steps(n_inputs: int, variant_inputs: Sequence[bool], path):
