@@ -14,4 +14,5 @@ be = ta.get_hip_backend()
 rec = bench.sliced_network_bench(ta, be, None, 0, 1, a.D, 64, True)
 rec["gather_launches"] = be.gather_launches
 rec["permute_launches"] = be.permute_launches
-print(json.dumps({k: rec[k] for k in ("seconds", "tflops", "n_slices", "result", "verified", "gather_launches", "permute_launches")}))
+print(json.dumps({k: rec.get(k) for k in ("seconds", "tflops", "mode", "flops_total", "flops_if_every_slice_ran_alone", "n_slices", "result",
+                                          "verified", "gather_launches", "permute_launches")}))
