@@ -7,8 +7,9 @@ network into ``d_1*...*d_s`` independent networks of identical topology whose
 results add up.  That is the natural partition of a contractor path:
 
   * the pairwise order is searched ONCE on the sliced topology (host),
-  * slices are dealt round-robin to ranks; every rank contracts its slices with
-    the same path on its own GPU and accumulates the partial result locally,
+  * slices are dealt to the ranks (contiguous blocks of the order in which the costly cut bonds vary slowest;
+    round-robin in the slice-by-slice mode); every rank contracts its slices with the same path on its own GPU --
+    each step once per distinct value of the cut bonds it depends on -- and accumulates the partial result locally,
   * ONE all-reduce(sum) of the (small) result tensor finishes the job -- the
     only data-path collective, and only because the partition has a genuine
     exchange step.  On GPUs it is RCCL through libtnhip's own K8 entry points
