@@ -598,11 +598,21 @@ def sliced_network_bench(ta, be, comm, rank, world, D, min_slices, verify):
 
   class _Few(distributed.LocalComm):   # warm-up on half of the slices (allocator, kernels)
     rank, world = 0, max(1, int(rep["n_slices"]) // 2)
-  distributed.contract_sliced(nodes, cuts, comm=_Few())
+  kw, staged_error = {}, None
+  try:
+    distributed.contract_sliced(nodes, cuts, comm=_Few())
+  except Exception as exc:  # pylint: disable=broad-except
+    if world != 1:
+      raise               # (a fallback on one rank only would change the partition under the others)
+    # the default mode (every step once per value of the cuts it depends on) failed on this box: slice by slice
+    staged_error = f"{type(exc).__name__}: {exc}"[:300]
+    kw = {"reuse": False}
+    rep["staged_by_default"] = False
+    distributed.contract_sliced(nodes, cuts, comm=_Few(), **kw)
   sync_all(be, comm)
   timed = _Timed(comm)
   t0 = time.perf_counter()
-  out = distributed.contract_sliced(nodes, cuts, comm=timed)
+  out = distributed.contract_sliced(nodes, cuts, comm=timed, **kw)
   sync_all(be, comm)
   t = time.perf_counter() - t0
   t_compute = timed.t_compute_end - t0
@@ -634,17 +644,19 @@ def sliced_network_bench(ta, be, comm, rank, world, D, min_slices, verify):
          "slowest_rank_compute_seconds": t_compute_max, "allreduce_seconds": t_reduce_max,
          "collective": "one all-reduce(sum) of the fp32-accumulated scalar (tnh_allreduce, RCCL)" if world > 1 else "none",
          "accumulation": "slice partials added in fp32, rounded to bf16 once", "result": result}
+  if staged_error is not None:
+    rec["default_mode_error"] = staged_error
   if verify and world == 1:
     # the same slices in f32 on the same (bf16-valued) tensors, slice partial by slice partial, against the a-priori
     # error model of partials_check (the round-2 tolerance of 5e-2 |ref| on the SUM was written
     # after the number was seen)
     t0 = time.perf_counter()
     p16, p32 = [], []
-    distributed.contract_sliced(nodes, cuts, partials_out=p16)
+    distributed.contract_sliced(nodes, cuts, partials_out=p16, **kw)
     t32 = [be.cast(x, np.float32) for x in tensors]
     nodes32 = workloads.random_regular_network(be, n=n, D=D, seed=6, tensors=t32)
     cuts32 = distributed.choose_cut_edges(nodes32, min_slices=min_slices)
-    ref = float(np.asarray(distributed.contract_sliced(nodes32, cuts32, partials_out=p32), dtype=np.float64).reshape(-1)[0])
+    ref = float(np.asarray(distributed.contract_sliced(nodes32, cuts32, partials_out=p32, **kw), dtype=np.float64).reshape(-1)[0])
     be.synchronize()
     chk = partials_check(p16, p32, n - 1)             # n nodes: n - 1 intermediates per slice
     chk.update({"f32_same_slices": ref, "bf16": result, "rel_err_of_the_sum": abs(result - ref) / max(abs(ref), 1e-30),
