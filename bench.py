@@ -42,12 +42,19 @@ Extra objects on the same line:
   mps_chain      -- configs[3]: <psi|psi> of a 16-site MPS, bulk D = 512, contractors.greedy (d = 2 and d = 4;
                     eager and hipGraph replay) with the NumPy oracle backend's time beside it.
   mera           -- configs[4] shape on one GPU: binary-MERA layer energy at chi = 32 (68.7 GB intermediate).
-  mera_chi64     -- configs[4] at chi = 64: `--mera64-full` placements (default 1 of 2) run slice by slice (4096
-                    slices, ~165 s: `measured_*`), the rest as per-slice cost x slice count (labelled extrapolated).
+  mera_chi64     -- configs[4] at chi = 64: `--mera64-full` placements (default 1 of 2) run in full (all 4096 slices;
+                    partial contractions that depend on one slice index only are computed once per value of that index:
+                    `measured_*` with the EXECUTED flops), the rest as per-slice cost x slice count (labelled
+                    extrapolated: one slice contracted on its own x 4096).
   helpers        -- HBM-bound helper kernels (K1 permute, K3/K4 reductions, K5 scaling) in GB/s vs 8 TB/s.
+  gather_gemm    -- one product of the D = 12 network (a 144 x 144 tensor takes two bonds off a 430 M-element rank-8
+                    intermediate) for five placements of the contracted axes + the K = 1728 product: `tnh_gemm_gather`
+                    against permute + streaming GEMM, both operand orders, device-side equality check.
   sliced_network -- the north-star scaling network (64-node random 3-regular graph, bond D, bf16):
                     bond-sliced greedy contraction, slices dealt over the N ranks, ONE all-reduce of
-                    the scalar (strong scaling: fixed total work); per-rank compute and all-reduce times.
+                    the scalar (strong scaling: fixed total work); per-rank compute and all-reduce times.  Every step
+                    of the path runs once per distinct value of the cut bonds it depends on (`mode`); `tflops` counts
+                    the executed flops, `flops_if_every_slice_ran_alone` is what 144 stand-alone slices would cost.
 """
 import argparse
 import json
