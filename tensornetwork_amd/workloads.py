@@ -488,6 +488,8 @@ def _mera_sliced_run_staged(be, chi, placement, plan, half_dtype, seed, budget_s
   t0 = time.perf_counter()
   once = _run_stage(be, operands("", [], 0, 0), steps[""], lt) if steps[""] else {}
   per_i = [_run_stage(be, operands("i", [once], i, 0), steps["i"], lt) if steps["i"] else {} for i in range(chi)]
+  be.synchronize()
+  seconds_once_per_i = time.perf_counter() - t0
   j_done, stop = 0, False
   for j in range(chi):
     per_j = _run_stage(be, operands("j", [once], 0, j), steps["j"], lt) if steps["j"] else {}
@@ -527,6 +529,8 @@ def _mera_sliced_run_staged(be, chi, placement, plan, half_dtype, seed, budget_s
           "energy_partial_sum": float(np.asarray(acc, dtype=np.float64).reshape(-1)[0]),
           "macs_per_slice": plan["flops"], "peak_elems_per_slice": plan["peak"], "depth": plan["depth"],
           "reuse_partials": True, "executed_macs": executed,
+          "seconds_by_phase": {"steps that depend on no index or on i (once per i)": seconds_once_per_i,
+                               "steps that depend on j (once per j) and on both (every slice)": seconds - seconds_once_per_i},
           "macs_by_dependence": {"none": macs[""], "i": macs["i"], "j": macs["j"], "ij": macs["ij"]},
           "stage_runs": {"none": 1 if steps[""] else 0, "i": chi, "j": j_done, "ij": done},
           "tflops": 2.0 * executed / max(seconds, 1e-30) / 1e12,
