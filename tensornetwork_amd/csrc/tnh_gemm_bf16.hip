@@ -254,10 +254,22 @@ struct KWalk {
   }
 };
 
+// SCHED (round 5, A/B knobs ":p7" / ":p8"):
+//   1  ONE 64-MFMA cluster per K-tile: every fragment of the K-tile (24 ds_read_b128 = 96 registers) is read in one
+//      load segment, two barriers per K-tile instead of four.  A whole LDS buffer is restaged at once, two intervals
+//      ahead: tile t + 2 goes into tile t's buffer during the interval after group 1's last read of it -- group 0
+//      issues its pieces in its load segment of tile t + 1, group 1 at the head of its MFMA cluster of tile t (the
+//      same interval), and each wave waits for its own pieces (vmcnt(0)) at the end of the FOLLOWING interval.
+//   2  M32 with the four independent 32x32 accumulators of a cluster interleaved (k-step outermost): the dependent
+//      MFMA is four issues = 128 cycles behind its producer instead of two = 64 (exactly the instruction's latency).
 template <bool IS_BF16, bool OUT_F32, bool TWO, bool M32 = false, bool VIEW = false, bool A_KM = false,
-          bool B_KN = false>
+          bool B_KN = false, int SCHED = 0>
 __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(NtArgs p) {
   static_assert(!VIEW || (TWO && !M32), "view kernels use the 2-phase 16x16x32 schedule");
+  static_assert(SCHED != 1 || (TWO && !M32), "the one-cluster schedule is a 16x16x32 schedule");
+  static_assert(SCHED != 2 || (TWO && M32 && !VIEW), "the interleaved schedule is the 32x32x16 one");
+  constexpr bool ONE = (SCHED == 1);
+  constexpr int ASUBS = ONE ? 2 : 1;
   static_assert(VIEW || (!A_KM && !B_KN), "k-major operands need the view kernel");
   // M32 (32x32x16 MFMA) lost the A/B with 4 phases per K-tile (only 2 independent accumulators per
   // phase); variant ":p3" re-tests it with the 2-phase schedule (4 independent accumulators).
@@ -376,7 +388,7 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(NtArgs p) {
   }
   };
 
-  uint4 af[KS][FA];     // [k-step][row fragment] of the current A sub-tile
+  uint4 af[ASUBS][KS][FA];   // [sub (one-cluster schedule: both)][k-step][row fragment] of the current A sub-tile
   uint4 bf[2][KS][FB];  // [sub][k-step][row fragment] of both B sub-tiles
 
   // k-major images: per-lane part of the transpose-read address.  Lane (g = lane >> 4, i = lane & 15)
@@ -399,13 +411,13 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(NtArgs p) {
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-        for (int f = 0; f < FA; ++f) af[ks][f] = tr_read(base + (tr_a ^ (unsigned)((sub * 4 + f) << 5)) + ks * 8192);
+        for (int f = 0; f < FA; ++f) af[sub % ASUBS][ks][f] = tr_read(base + (tr_a ^ (unsigned)((sub * 4 + f) << 5)) + ks * 8192);
     } else {
       const char* sa = buf_base + wr * HALF_BYTES + (sub * 64) * 128;
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-        for (int f = 0; f < FA; ++f) af[ks][f] = *(const uint4*)(sa + f * FROWS * 128 + frag_off[ks]);
+        for (int f = 0; f < FA; ++f) af[sub % ASUBS][ks][f] = *(const uint4*)(sa + f * FROWS * 128 + frag_off[ks]);
     }
   };
   auto read_b = [&](const char* buf_base, int sub) {
@@ -432,10 +444,26 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(NtArgs p) {
 #pragma unroll
         for (int j = 0; j < FB; ++j) {
           if constexpr (M32)
-            acc32[sa * 2 + i][sb] = mma32<IS_BF16>(bf[sb][ks][j], af[ks][i], acc32[sa * 2 + i][sb]);
+            acc32[sa * 2 + i][sb] = mma32<IS_BF16>(bf[sb][ks][j], af[sa % ASUBS][ks][i], acc32[sa * 2 + i][sb]);
           else
-            acc[sa * 4 + i][sb * 2 + j] = mma16<IS_BF16>(bf[sb][ks][j], af[ks][i], acc[sa * 4 + i][sb * 2 + j]);
+            acc[sa * 4 + i][sb * 2 + j] = mma16<IS_BF16>(bf[sb][ks][j], af[sa % ASUBS][ks][i], acc[sa * 4 + i][sb * 2 + j]);
         }
+    __builtin_amdgcn_s_setprio(0);
+  };
+  // SCHED 2: both quadrants of A sub-tile `sa` as one cluster, accumulators interleaved
+  auto mma_pair32 = [&](int sa, int sb_first) {
+    __builtin_amdgcn_s_setprio(1);
+    if constexpr (M32) {
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const int sb = sb_first ^ q;
+#pragma unroll
+          for (int i = 0; i < FA; ++i)
+            acc32[sa * 2 + i][sb] = mma32<IS_BF16>(bf[sb][ks][0], af[0][ks][i], acc32[sa * 2 + i][sb]);
+        }
+    }
     __builtin_amdgcn_s_setprio(0);
   };
   // end of a load segment: retire this wave's LDS reads, then meet the other waves
@@ -480,6 +508,12 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(NtArgs p) {
     if (nt > 1) {
       int64_t kc0 = (int64_t)BK, kc1 = 0;
       if constexpr (VIEW) wb.next(kc0, kc1);
+      if constexpr (ONE) {               // both buffers complete: A walks two tiles ahead as well
+        int64_t kd0 = (int64_t)BK, kd1 = 0;
+        if constexpr (VIEW) wa.next(kd0, kd1);
+        issue(1, 0, kd0, kd1);
+        issue(1, 1, kd0, kd1);
+      }
       issue(1, 2, kc0, kc1);
       issue(1, 3, kc0, kc1);
     } else if constexpr (VIEW) {
@@ -501,6 +535,74 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(NtArgs p) {
     const int b = t & 1;
     const char* cur = smem + b * BUF_BYTES;
     const bool n1 = (t + 1 < nt), n2 = (t + 2 < nt);
+    if constexpr (ONE) {
+      // one 64-MFMA cluster per K-tile (see SCHED above).  `stage2`: this wave's 8 pieces of K-tile t + 2 -> buffer b.
+      auto stage2 = [&]() {
+        int64_t ka = (int64_t)(t + 2) * BK, ka1 = 0, kb = ka, kb1 = 0;
+        if constexpr (VIEW) {
+          wa.next(ka, ka1);
+          wb.next(kb, kb1);
+        }
+        issue(b, 0, ka, ka1);
+        issue(b, 1, ka, ka1);
+        issue(b, 2, kb, kb1);
+        issue(b, 3, kb, kb1);
+      };
+      read_a(cur, 0);
+      read_b(cur, 0);
+      read_b(cur, 1);
+      read_a(cur, 1);
+      if (wr == 0) {
+        // group 0: K-tile t + 1 into the buffer K-tile t - 1 left (group 1 read it last one interval ago)
+        if (t >= 1 && n1) {
+          int64_t ka = (int64_t)(t + 1) * BK, ka1 = 0, kb = ka, kb1 = 0;
+          if constexpr (VIEW) {
+            wa.next(ka, ka1);
+            wb.next(kb, kb1);
+          }
+          issue(b ^ 1, 0, ka, ka1);
+          issue(b ^ 1, 1, ka, ka1);
+          issue(b ^ 1, 2, kb, kb1);
+          issue(b ^ 1, 3, kb, kb1);
+        }
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // group 1: its pieces of K-tile t + 1 (issued one interval ago)
+      }
+      TNH_SEG_LOAD_END();
+      if (wr == 1 && n2) stage2();
+      __builtin_amdgcn_sched_barrier(0);
+      mma_quadrant(0, 0);
+      mma_quadrant(0, 1);
+      mma_quadrant(1, 1);
+      mma_quadrant(1, 0);
+      if (wr == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // group 0: its pieces of K-tile t + 1
+      TNH_SEG_MMA_END();
+      continue;
+    }
+    if constexpr (TWO && SCHED == 2) {
+      read_a(cur, 0);
+      read_b(cur, 0);
+      read_b(cur, 1);
+      if (n1) {
+        issue(b ^ 1, 0, (int64_t)(t + 1) * BK, 0);
+        issue(b ^ 1, 1, (int64_t)(t + 1) * BK, 0);
+      }
+      TNH_SEG_LOAD_END();
+      mma_pair32(0, 0);
+      TNH_SEG_MMA_END();
+      read_a(cur, 1);
+      if (n2) {
+        issue(b, 2, (int64_t)(t + 2) * BK, 0);
+        issue(b, 3, (int64_t)(t + 2) * BK, 0);
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      TNH_SEG_LOAD_END();
+      mma_pair32(1, 1);
+      TNH_SEG_MMA_END();
+      continue;
+    }
     if constexpr (TWO) {
       // two phases per K-tile, 32-MFMA clusters: half as many barriers per flop
       read_a(cur, 0);
@@ -874,7 +976,9 @@ static int launch_pp(bool is_bf16, bool out_f32, bool two, NtArgs p, int64_t bat
     const dim3 grid(pp_grid_x(nwg, (unsigned)nb), (unsigned)nb), block(512);
 #define TNH_PP_LAUNCH(B16, O32)                                                                               \
   do {                                                                                                       \
-    if (m32) hipLaunchKernelGGL((gemm_nt_pp_kernel<B16, O32, true, true>), grid, block, 0, stream(), q);      \
+    if (g_opt_phases == 7) hipLaunchKernelGGL((gemm_nt_pp_kernel<B16, O32, true, false, false, false, false, 1>), grid, block, 0, stream(), q); \
+    else if (g_opt_phases == 8) hipLaunchKernelGGL((gemm_nt_pp_kernel<B16, O32, true, true, false, false, false, 2>), grid, block, 0, stream(), q); \
+    else if (m32) hipLaunchKernelGGL((gemm_nt_pp_kernel<B16, O32, true, true>), grid, block, 0, stream(), q);      \
     else if (two) hipLaunchKernelGGL((gemm_nt_pp_kernel<B16, O32, true>), grid, block, 0, stream(), q);      \
     else hipLaunchKernelGGL((gemm_nt_pp_kernel<B16, O32, false>), grid, block, 0, stream(), q);              \
   } while (0)
@@ -895,6 +999,18 @@ static int launch_pp(bool is_bf16, bool out_f32, bool two, NtArgs p, int64_t bat
 template <bool A_KM, bool B_KN>
 static void launch_pp_view_t(bool is_bf16, bool out_f32, dim3 grid, const NtArgs& q) {
   const dim3 block(512);
+  if constexpr (!A_KM && !B_KN) {
+    if (g_opt_phases == 7) {      // A/B knob ":p7": one 64-MFMA cluster per K-tile
+      if (is_bf16) {
+        if (out_f32) hipLaunchKernelGGL((gemm_nt_pp_kernel<true, true, true, false, true, false, false, 1>), grid, block, 0, stream(), q);
+        else hipLaunchKernelGGL((gemm_nt_pp_kernel<true, false, true, false, true, false, false, 1>), grid, block, 0, stream(), q);
+      } else {
+        if (out_f32) hipLaunchKernelGGL((gemm_nt_pp_kernel<false, true, true, false, true, false, false, 1>), grid, block, 0, stream(), q);
+        else hipLaunchKernelGGL((gemm_nt_pp_kernel<false, false, true, false, true, false, false, 1>), grid, block, 0, stream(), q);
+      }
+      return;
+    }
+  }
   if (is_bf16) {
     if (out_f32) hipLaunchKernelGGL((gemm_nt_pp_kernel<true, true, true, false, true, A_KM, B_KN>), grid, block, 0, stream(), q);
     else hipLaunchKernelGGL((gemm_nt_pp_kernel<true, false, true, false, true, A_KM, B_KN>), grid, block, 0, stream(), q);

@@ -50,18 +50,59 @@ def _index_problem(nodes: Sequence[network.Node]):
 
 
 def choose_cut_edges(nodes: Sequence[network.Node], min_slices: int,
-                     algorithm: Callable = pathfinder.greedy, beam: int = 0) -> List[network.Edge]:
+                     algorithm: Callable = pathfinder.greedy, beam: Optional[int] = None,
+                     world: int = 1) -> List[network.Edge]:
   """Pick contracted edges to slice until there are >= min_slices slices.
 
-  Greedy rule: cut the edge whose removal (dimension -> 1) gives the cheapest
-  re-searched path; this keeps the redundant work introduced by slicing small.
+  The cut SET is ranked by what `contract_sliced` then executes (`_StagePlan`): first the multiply-adds of the
+  SLOWEST of `world` ranks under the partition `contract_sliced` uses (`_StagePlan.partition`) -- every step once per
+  distinct value of the cuts it depends on -- then the multiply-adds of all ranks, then the cost of the slices run
+  alone, then the peak intermediate.  Two searches, the better set wins (ties: the sequential one):
 
-  `beam` > 0 (opt-in): a beam search over cut SETS instead -- every level extends the `beam` best
-  partial sets by one of the `beam` best single cuts -- ranked by the multiply-adds `contract_sliced` executes when
-  every step runs once per value of the cuts it depends on (`_StagePlan.macs_with_reuse`), then by the cost of the
-  slices run alone, then by the peak intermediate."""
-  if beam > 0:
-    return _choose_cut_edges_beam(nodes, min_slices, algorithm, beam)
+    * the sequential rule: cut the edge whose removal (dimension -> 1) gives the cheapest re-searched path, repeat;
+    * a beam search over cut sets (`beam` partial sets per level, each extended by one of the `beam` best single
+      cuts).  `beam=None` (default): 24 for networks of at most 512 candidate edges, else off; `beam=0`: the
+      sequential rule alone (rounds 1-4).
+
+  Every rank must call this with the same arguments: the search is deterministic (candidates in the order of their
+  first end's position in `nodes`, strict comparisons)."""
+  nodes = list(nodes)
+  seq = _choose_cut_edges_sequential(nodes, min_slices, algorithm)
+  _, _, sizes = _index_problem(nodes)
+  n_cand = sum(1 for e in sizes if not e.is_dangling() and not e.is_trace() and sizes[e] > 1)
+  if beam is None:
+    beam = 24 if n_cand <= 512 else 0
+  if beam <= 0 or not seq or any(e.is_trace() for n in nodes for e in n.edges if not e.is_dangling()):
+    return seq
+  cost = _cut_cost_fn(nodes, algorithm, max(int(world), 1))
+  found = _choose_cut_edges_beam(nodes, min_slices, beam, cost)
+  if found is None:
+    return seq
+  return found if cost(found) < cost(seq) else seq
+
+
+def _cut_cost_fn(nodes, algorithm, world):
+  """cost(cuts) -> (slowest rank's multiply-adds with reuse, all ranks', slices alone, peak intermediate)"""
+  inputs, output, sizes = _index_problem(nodes)
+  memo = {}
+
+  def cost(cuts):
+    ident = frozenset(id(e) for e in cuts)
+    if ident not in memo:
+      trial = dict(sizes)
+      for e in cuts:
+        trial[e] = 1
+      path = algorithm(inputs, output, trial)
+      plan = _StagePlan(nodes, list(cuts), path)
+      flops, peak = pathfinder.path_cost(inputs, output, trial, path)
+      every = list(itertools.product(*[range(sizes[e]) for e in cuts]))
+      per_rank = [plan.macs_with_reuse(b) for b in plan.partition(every, world) if b]
+      memo[ident] = (max(per_rank), sum(per_rank), float(flops) * len(every), float(peak))
+    return memo[ident]
+  return cost
+
+
+def _choose_cut_edges_sequential(nodes, min_slices, algorithm):
   inputs, output, sizes = _index_problem(nodes)
   sizes = dict(sizes)
   cuts: List[network.Edge] = []
@@ -91,24 +132,11 @@ def choose_cut_edges(nodes: Sequence[network.Node], min_slices: int,
   return cuts
 
 
-def _choose_cut_edges_beam(nodes, min_slices, algorithm, beam):
-  nodes = list(nodes)
+def _choose_cut_edges_beam(nodes, min_slices, beam, cost):
   inputs, output, sizes = _index_problem(nodes)
   pos = {id(n): i for i, n in enumerate(nodes)}
   key_of = lambda e: min((pos[id(nd)], ax) for nd, ax in e.ends())
   candidates = sorted((e for e in sizes if e not in output and not e.is_trace() and sizes[e] > 1), key=key_of)
-
-  def cost(cuts):
-    trial = dict(sizes)
-    for e in cuts:
-      trial[e] = 1
-    path = algorithm(inputs, output, trial)
-    plan = _StagePlan(nodes, list(cuts), path)
-    flops, peak = pathfinder.path_cost(inputs, output, trial, path)
-    n = int(np.prod([sizes[e] for e in cuts]))
-    every = list(itertools.product(*[range(sizes[e]) for e in cuts]))
-    return (plan.macs_with_reuse(every), flops * n, peak)
-
   singles = sorted(((cost([e]), key_of(e), e) for e in candidates), key=lambda t: (t[0], t[1]))
   pool = [t[2] for t in singles[:beam]]
   partial = [(c, [e]) for c, _, e in singles[:beam]]
@@ -131,7 +159,7 @@ def _choose_cut_edges_beam(nodes, min_slices, algorithm, beam):
       break
     grown.sort(key=lambda p: (p[0], [key_of(e) for e in p[1]]))
     partial = grown[:beam]
-  return choose_cut_edges(nodes, min_slices, algorithm)     # (fewer candidates than levels: the sequential rule)
+  return None     # (fewer candidates than levels: the sequential rule stands)
 
 
 def _variant_steps(n_inputs: int, variant_inputs: Sequence[bool], path):
@@ -247,16 +275,71 @@ class _StagePlan:
       total += macs * len({tuple(idx[k] for k in sorted(c)) for idx in slices})
     return total
 
-  def ordered(self, slices):
-    return sorted(slices, key=lambda idx: tuple(idx[k] for k in self.loop_order))
+  def ordered(self, slices, loop_order=None):
+    order = self.loop_order if loop_order is None else loop_order
+    return sorted(slices, key=lambda idx: tuple(idx[k] for k in order))
+
+  def partition(self, slices, world: int):
+    """The slices dealt to `world` ranks: contiguous blocks of the slices sorted with one cut varying slowest,
+    either balanced (sizes differ by at most one) or of ceil(n / world) slices each; of all loop orders (at most 24
+    tried, the weight order first) x the two block rules the one whose SLOWEST rank executes the fewest multiply-adds
+    with reuse, then the fewest in all.  Pure host arithmetic on the plan: every rank computes the same blocks.
+    A rank's block may be empty (fewer slices than ranks)."""
+    slices = list(slices)
+    world = max(int(world), 1)
+    if world == 1:
+      return [self.ordered(slices)]
+    orders = [tuple(self.loop_order)]
+    for perm in itertools.permutations(range(len(self.dims))):
+      if perm not in orders and len(orders) < 24:
+        orders.append(perm)
+    best = None
+    for order in orders:
+      seq = self.ordered(slices, order)
+      base, extra = divmod(len(seq), world)
+      per = -(-len(seq) // world)
+      bounds_balanced, start = [], 0
+      for r in range(world):
+        stop = start + base + (1 if r < extra else 0)
+        bounds_balanced.append((start, stop))
+        start = stop
+      for bounds in (bounds_balanced, [(r * per, (r + 1) * per) for r in range(world)]):
+        blocks = [seq[a:b] for a, b in bounds]
+        loads = [self.macs_with_reuse(b) for b in blocks]
+        key = (max(loads), sum(loads))
+        if best is None or key < best[0]:
+          best = (key, blocks)
+    return best[1]
 
 
-def _contract_slices_staged(be, nodes, plan: _StagePlan, slices, output_edge_order, partials_out, stats):
+def _itemsize(t) -> int:
+  dt = str(getattr(t, "dtype", "float32"))
+  if dt in ("bfloat16", "float16"):
+    return 2
+  try:
+    return int(np.dtype(dt).itemsize)
+  except TypeError:
+    return 4
+
+
+# results of a class are kept for ALL its value tuples when they fit in this many bytes (a 288 GB part: the chi = 64
+# MERA placement keeps 64 partial results of 33 MB each per cut)
+STAGE_CACHE_BYTES = 16 << 30
+
+
+def _contract_slices_staged(be, nodes, plan: _StagePlan, slices, output_edge_order, partials_out, stats,
+                            input_provider=None, cache_bytes=None, on_slice=None):
   """The slices of one rank with every step run once per distinct value of the cuts it depends on (`_StagePlan`).
-  Results of a class are kept for the value tuple in use (and for all value tuples when the class is cheap to
-  keep: <= 64 results of <= 256 MiB in all), so with the slices in `plan.ordered` order the expensive classes run
-  once per value.  Every slice partial is the tensor the slice-by-slice contraction gives: same steps, same order,
-  same operands."""
+  Results of a class are kept for the value tuple in use, and for all value tuples when they fit in `cache_bytes`
+  (default STAGE_CACHE_BYTES, counted with the tensors' real item size); otherwise the class is recomputed when its
+  value tuple comes back (`stats["executed_macs"]` counts what RAN, not the model).  Every slice partial is the tensor
+  the slice-by-slice contraction gives: same steps, same order, same operands.
+
+  `input_provider(k, idx)` (optional): tensor of input k for slice idx WITH its cut legs at extent 1, or None to
+  slice `nodes[k].tensor` here -- for inputs that are defined slice-wise and never materialised (the 137 GB rank-6
+  tensors of the chi = 64 MERA layer).  `on_slice(n_done, idx, tensor)`: called after every slice with its partial
+  (time budgets, sampled checks); returning True stops the loop."""
+  budget = STAGE_CACHE_BYTES if cache_bytes is None else int(cache_bytes)
   n = plan.n
   cache: Dict[frozenset, Dict[tuple, dict]] = {c: {} for c in plan.classes}
   keep_all: Dict[frozenset, bool] = {}
@@ -270,6 +353,11 @@ def _contract_slices_staged(be, nodes, plan: _StagePlan, slices, output_edge_ord
     key = tuple(idx[c] for _, c in wins)
     if k in sliced_inputs and sliced_inputs[k][0] == key:
       return sliced_inputs[k][1]
+    if input_provider is not None:
+      given = input_provider(k, idx)
+      if given is not None:
+        sliced_inputs[k] = (key, given)
+        return given
     t = nodes[k].tensor
     shape = list(be.shape_tuple(t))
     starts = [0] * len(shape)
@@ -290,26 +378,34 @@ def _contract_slices_staged(be, nodes, plan: _StagePlan, slices, output_edge_ord
     runs[c] += 1
     if c not in keep_all:
       count = int(np.prod([plan.dims[k] for k in c])) if c else 1
-      nbytes = sum(int(np.prod(be.shape_tuple(t))) * 4 for t, _ in out.values())
-      keep_all[c] = count <= 64 and count * nbytes <= (256 << 20)
+      nbytes = sum(int(np.prod(be.shape_tuple(t))) * _itemsize(t) for t, _ in out.values())
+      keep_all[c] = count * nbytes <= budget
     if not keep_all[c]:
       cache[c].clear()
     cache[c][key] = out
     return out
 
   want = [id(e) for e in output_edge_order] if output_edge_order is not None else None
-  total, narrow = None, None
+  total, narrow, done = None, None, 0
   for idx in slices:
     tensor, labels = stage(plan.dep[plan.final], idx)[plan.final]
-    if want is not None and list(labels) != want:
-      tensor = be.transpose(tensor, tuple(labels.index(lab) for lab in want))
+    if want is None:
+      want = list(labels)      # no order asked for: the first slice's (the label order a backend returns may depend
+                               # on operand alignment; every later partial is brought to the same one before it is added)
+    if list(labels) != want:
+      tensor = be.transpose(tensor, tuple(list(labels).index(lab) for lab in want))
     part, narrow = _widen(be, tensor)
     if partials_out is not None:
       partials_out.append(np.asarray(part, dtype=np.float64).copy())
     total = be.multiply(part, 1.0) if total is None else be.addition(total, part)
+    done += 1
+    if on_slice is not None and on_slice(done, idx, tensor):
+      break
   if stats is not None:
     stats["stage_runs"] = {",".join(str(k) for k in sorted(c)) or "-": r for c, r in runs.items()}
     stats["executed_macs"] = sum(plan.class_macs[c] * r for c, r in runs.items())
+    stats["slices_done"] = done
+    stats["classes_kept_for_all_values"] = {",".join(str(k) for k in sorted(c)) or "-": bool(v) for c, v in keep_all.items()}
   return total, narrow
 
 
@@ -362,22 +458,26 @@ def contract_sliced(nodes: Sequence[network.Node], cut_edges: Sequence[network.E
   if cut_edges and len(all_slices) > 1 and reuse is not False and \
       not any(e.is_trace() for n in nodes for e in n.edges if not e.is_dangling()):
     plan = _StagePlan(nodes, cut_edges, path)
-    ordered = plan.ordered(all_slices)
-    per = -(-len(ordered) // comm.world)                     # contiguous blocks: a rank sees few values of the costly cuts
-    mine = ordered[comm.rank * per:(comm.rank + 1) * per]
-    alone = plan.macs_alone() * max(len(mine), 1)
-    if reuse or (mine and plan.macs_with_reuse(mine) <= 0.8 * alone):
+    blocks = plan.partition(all_slices, comm.world)          # the same on every rank (host arithmetic on the plan)
+    mine = blocks[comm.rank]
+    # The MODE is decided from all ranks' blocks, never from this rank's own: a rank that chose differently would
+    # take a different share of the slices (some summed twice, others never -- ADVICE r4).
+    with_reuse = max(plan.macs_with_reuse(b) for b in blocks)
+    alone = plan.macs_alone() * max(len(b) for b in blocks)
+    if reuse or with_reuse <= 0.8 * alone:
       if stats is not None:
         stats.update({"mode": "staged", "hoisted_steps": 0, "steps_per_slice": len(plan.steps),
-                      "macs_alone": plan.macs_alone() * len(mine), "slices": len(mine)})
+                      "macs_alone": plan.macs_alone() * len(mine), "slices": len(mine),
+                      "model_macs_with_reuse": plan.macs_with_reuse(mine), "executed_macs": 0.0})
       if mine:
         total, narrow = _contract_slices_staged(be, nodes, plan, mine, output_edge_order, partials_out, stats)
         return _finish(be, comm, total, narrow)
       # this rank got no slice: zeros of the result's shape and dtype (one slice's result times zero)
-      part, narrow = _contract_slices_staged(be, nodes, plan, ordered[:1], output_edge_order, None, None)
+      part, narrow = _contract_slices_staged(be, nodes, plan, plan.ordered(all_slices)[:1], output_edge_order, None, None)
       return _finish(be, comm, be.multiply(part, 0.0), narrow)
 
   hoisted = 0
+  nodes_before_hoist, cuts_before_hoist = nodes, cut_edges
   if hoist_invariant and cut_edges and len(all_slices) > 1:
     reduced = _hoist_invariant(nodes, cut_edges, path, output_edge_order)
     if reduced is not None:
@@ -388,6 +488,15 @@ def contract_sliced(nodes: Sequence[network.Node], cut_edges: Sequence[network.E
     stats["steps_per_slice"] = sum(1 for pair in path if len(pair) > 1)
 
   mine = all_slices[comm.rank::comm.world]
+  if stats is not None:
+    inputs_r, output_r, sizes_r = _index_problem(nodes)
+    for e in cut_edges:
+      sizes_r[e] = 1
+    per_slice = float(pathfinder.path_cost(inputs_r, output_r, sizes_r, path)[0])
+    inv = 0.0
+    if hoisted:
+      inv = float(slicing_report(nodes_before_hoist, cuts_before_hoist, algorithm)["flops_invariant_per_slice"])
+    stats.update({"slices": len(mine), "executed_macs": per_slice * max(len(mine), 1) + inv})
   if partials_out is not None:
     use_graph = False
   if use_graph is None:
@@ -519,13 +628,12 @@ def slicing_report(nodes: Sequence[network.Node], cut_edges: Sequence[network.Ed
   reuse = {}
   if cut_edges and n_slices > 1 and not any(e.is_trace() for n in nodes for e in n.edges if not e.is_dangling()):
     plan = _StagePlan(nodes, list(cut_edges), path1)
-    ordered = plan.ordered(list(itertools.product(*[range(e.dimension) for e in cut_edges])))
-    per = -(-len(ordered) // max(int(world), 1))
-    blocks = [ordered[r * per:(r + 1) * per] for r in range(max(int(world), 1))]
+    blocks = plan.partition(list(itertools.product(*[range(e.dimension) for e in cut_edges])), max(int(world), 1))
     per_rank = [plan.macs_with_reuse(b) for b in blocks]
     reuse = {"flops_with_reuse_all_ranks": float(sum(per_rank)), "flops_with_reuse_slowest_rank": float(max(per_rank)),
+             "slices_per_rank": [len(b) for b in blocks],
              "reuse_classes": {",".join(str(k) for k in sorted(c)) or "-": float(m) for c, m in plan.class_macs.items()},
-             "staged_by_default": bool(blocks[0] and per_rank[0] <= 0.8 * plan.macs_alone() * len(blocks[0]))}
+             "staged_by_default": bool(max(per_rank) <= 0.8 * plan.macs_alone() * max(len(b) for b in blocks))}
   return {"n_slices": n_slices, "flops_unsliced": float(flops0), "peak_unsliced": float(peak0),
           "flops_per_slice": float(flops1), "peak_per_slice": float(peak1),
           "flops_invariant_per_slice": float(invariant), **reuse,

@@ -639,9 +639,11 @@ def test_cut_selection_by_beam_search_is_never_worse_in_executed_work():
       plan = distributed._StagePlan(nodes, list(cuts), pathfinder.greedy(inputs, output, sliced))      # pylint: disable=protected-access
       return plan.macs_with_reuse(list(itertools.product(*[range(e.dimension) for e in cuts])))
 
-    seq = distributed.choose_cut_edges(nodes, min_slices=9)
+    seq = distributed.choose_cut_edges(nodes, min_slices=9, beam=0)     # the sequential rule alone (rounds 1-4)
     beam = distributed.choose_cut_edges(nodes, min_slices=9, beam=8)
+    default = distributed.choose_cut_edges(nodes, min_slices=9)         # round 5: beam 24, the better of the two
     assert int(np.prod([e.dimension for e in beam])) >= 9
     assert executed(beam) <= executed(seq)
+    assert executed(default) <= executed(beam)
     np.testing.assert_allclose(np.asarray(distributed.contract_sliced(nodes, beam)), np.asarray(distributed.contract_sliced(nodes, seq)),
                                rtol=1e-9, atol=1e-12)
