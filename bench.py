@@ -83,8 +83,13 @@ def parse_args():
   p.add_argument("--bond", type=int, default=256, help="bond dimension D of the rank-4 nodes")
   p.add_argument("--layout", default="L0", choices=["L0", "L1"])
   p.add_argument("--svd-n", type=int, default=4096, help="side of the split_node matrix (0 = skip)")
-  p.add_argument("--rr-bond", type=int, default=12,
-                 help="bond dimension of the 64-node random-regular network (0 = skip)")
+  p.add_argument("--rr-bond", type=int, default=16,
+                 help="bond dimension of the 64-node random-regular network (0 = skip).  16 (round 5; rounds 1-4: 12): "
+                      "the 16 values of the costly cut bond divide evenly among 2 / 4 / 8 ranks (12 values on 8 ranks "
+                      "cap the speed-up at 6.0x before any overhead) and one contraction is 1.3e15 flop, so per-rank "
+                      "fixed costs no longer show")
+  p.add_argument("--rr-bond-small", type=int, default=12,
+                 help="second, smaller instance of the same network, one GPU only (the rounds 1-4 row; 0 = skip)")
   p.add_argument("--rr-min-slices", type=int, default=64)
   p.add_argument("--no-cpu-baseline", action="store_true")
   p.add_argument("--no-sweep", action="store_true", help="skip the bond-dimension sweep rows")
@@ -94,7 +99,7 @@ def parse_args():
   p.add_argument("--mera64-full", type=int, default=1, choices=[0, 1, 2],
                  help="placements of the chi = 64 MERA layer run in FULL (4096 slices each, ~150 s per placement on one "
                       "MI355X); the others are reported per slice x count")
-  p.add_argument("--mera64-budget", type=float, default=200.0, help="seconds after which a full placement stops early")
+  p.add_argument("--mera64-budget", type=float, default=150.0, help="seconds after which a full placement stops early")
   p.add_argument("--bringup-timeout", type=float, default=float(os.environ.get("TNH_BENCH_BRINGUP_TIMEOUT_S", "900")),
                  help="N > 1: seconds the ranks get to rendezvous, create the RCCL communicator and pass the first "
                       "barrier before the job is killed with a message (a hang inside RCCL must not become the record)")
@@ -587,8 +592,9 @@ def sliced_network_bench(ta, be, comm, rank, world, D, min_slices, verify):
   n = 64
   tensors = workloads.random_regular_device_tensors(be, n, D, ta.bfloat16, seed=6)
   nodes = workloads.random_regular_network(be, n=n, D=D, seed=6, tensors=tensors)
-  cuts = distributed.choose_cut_edges(nodes, min_slices=min_slices)
+  cuts = distributed.choose_cut_edges(nodes, min_slices=min_slices, world=world)
   rep = distributed.slicing_report(nodes, cuts, world=world)
+  cut_at = [[(nodes.index(nd), ax) for nd, ax in e.ends()] for e in cuts]     # the same cuts on a copy of the network
 
   class _Timed:
     """wraps the communicator: separates this rank's compute time from the all-reduce"""
@@ -618,8 +624,9 @@ def sliced_network_bench(ta, be, comm, rank, world, D, min_slices, verify):
     distributed.contract_sliced(nodes, cuts, comm=_Few(), **kw)
   sync_all(be, comm)
   timed = _Timed(comm)
+  ran = {}
   t0 = time.perf_counter()
-  out = distributed.contract_sliced(nodes, cuts, comm=timed, **kw)
+  out = distributed.contract_sliced(nodes, cuts, comm=timed, stats=ran, **kw)
   sync_all(be, comm)
   t = time.perf_counter() - t0
   t_compute = timed.t_compute_end - t0
@@ -633,17 +640,25 @@ def sliced_network_bench(ta, be, comm, rank, world, D, min_slices, verify):
   # The cost model counts multiply-adds.  EXECUTED work: contract_sliced runs every step once per distinct value of the
   # cut bonds it depends on (D = 12: 99.4 % of a slice's work depends on ONE of the two cuts, i.e. 12 runs, not 144);
   # without that mode the slice-invariant steps still run once per rank, not once per slice.
-  inv = rep.get("flops_invariant_per_slice", 0.0)
+  # WHAT RAN: the mode and the executed multiply-adds come from the timed call's own counters -- every
+  # rank's, summed -- not from the host cost model; the model's figure stays beside it as a cross-check.
   alone_flops = 2.0 * rep["flops_per_slice"] * rep["n_slices"]
-  if rep.get("staged_by_default"):
-    total_flops = 2.0 * rep["flops_with_reuse_all_ranks"]
-  else:
-    total_flops = 2.0 * ((rep["flops_per_slice"] - inv) * rep["n_slices"] + inv * world)
+  executed = float(ran.get("executed_macs", 0.0))
+  if comm is not None:
+    executed = comm.sum_over_ranks(executed)
+  total_flops = 2.0 * executed
+  staged = ran.get("mode") == "staged"
+  model_flops = 2.0 * rep["flops_with_reuse_all_ranks"] if rep.get("staged_by_default") else None
   result = float(np.asarray(out).reshape(-1)[0])
   rec = {"workload": f"64-node random 3-regular network (seed 6), bond D={D}, bf16, {len(cuts)} cut bonds",
          "n_slices": int(rep["n_slices"]), "n_gpus": world, "seconds": t, "scaling": "strong",
-         "mode": "every step once per value of the cuts it depends on" if rep.get("staged_by_default") else "slice by slice",
+         "mode": "every step once per value of the cuts it depends on" if staged else "slice by slice",
          "flops_total": total_flops, "tflops": total_flops / t / 1e12,
+         "flops_total_by_the_host_model": model_flops,
+         "executed_equals_model": (abs(total_flops - model_flops) <= 1e-6 * model_flops) if (staged and model_flops) else None,
+         "slices_per_rank": rep.get("slices_per_rank"),
+         "ideal_speedup_of_this_partition": (distributed.slicing_report(nodes, cuts, world=1)["flops_with_reuse_slowest_rank"]
+                                             / rep["flops_with_reuse_slowest_rank"]) if rep.get("flops_with_reuse_slowest_rank") else None,
          "flops_if_every_slice_ran_alone": alone_flops, "speedup_over_slices_alone_at_this_rate": alone_flops / total_flops,
          "peak_intermediate_elems": rep["peak_per_slice"],
          "steps_per_slice": int(rep.get("steps_per_slice", 0)) - int(rep.get("invariant_steps", 0)),
@@ -662,7 +677,7 @@ def sliced_network_bench(ta, be, comm, rank, world, D, min_slices, verify):
     distributed.contract_sliced(nodes, cuts, partials_out=p16, **kw)
     t32 = [be.cast(x, np.float32) for x in tensors]
     nodes32 = workloads.random_regular_network(be, n=n, D=D, seed=6, tensors=t32)
-    cuts32 = distributed.choose_cut_edges(nodes32, min_slices=min_slices)
+    cuts32 = [nodes32[ends[0][0]][ends[0][1]] for ends in cut_at]      # the same bonds (no second search)
     ref = float(np.asarray(distributed.contract_sliced(nodes32, cuts32, partials_out=p32, **kw), dtype=np.float64).reshape(-1)[0])
     be.synchronize()
     chk = partials_check(p16, p32, n - 1)             # n nodes: n - 1 intermediates per slice
@@ -898,9 +913,10 @@ def mera_chi64_bench(ta, be, n_gpus=8, verify=False, full_placements=0, budget_s
   per = workloads.mera_sliced_sample(be, chi, ta.bfloat16, reps=2)
   measured = {}
   for pl in ("left", "right")[:max(0, int(full_placements))]:
-    # the placement as a RUN: all chi^2 slices through the path, partials added on the device
-    # (partial contractions that depend on one of the two slice indices only are computed once per value of that index:
-    #  workloads.mera_sliced_run(reuse_partials=True); should that path fail on this box, the slice-by-slice run stands in)
+    # the placement as a RUN: all chi^2 slices through distributed._contract_slices_staged (the machinery of
+    # contract_sliced), partials added on the device.  Every step runs once per distinct value of the cuts it depends
+    # on, with BOTH ends of each cut leg sliced (slice_edge): at chi = 64 the class that depends on both cuts is 98 %
+    # of the executed work, and the executed multiply-adds equal the flop-optimal dense cost of the network.
     try:
       run = workloads.mera_sliced_run(be, chi, pl, ta.bfloat16, budget_seconds=budget_s, check_every=1024 if verify else 0)
     except Exception as exc:  # pylint: disable=broad-except
@@ -913,9 +929,9 @@ def mera_chi64_bench(ta, be, n_gpus=8, verify=False, full_placements=0, budget_s
     measured[pl] = run
   checked = None
   if verify:
-    # four REAL slices per placement of one chi = 64-consistent network (tensors defined slice-wise along the cut
-    # legs = slice_edge semantics), bf16 vs f32 on the same values, a-priori rounding bound per slice
-    vals = workloads.mera_slice_values(be, chi, [(0, 0), (1, 5), (17 % chi, 3), (chi - 1, chi - 2)], ta.bfloat16)
+    # four slices per placement of the layer workloads.MeraSlicedLayer defines (slice_edge semantics: both ends of each
+    # cut leg sliced), each contracted alone, bf16 vs f32 on the same values, a-priori rounding bound per slice
+    vals = workloads.mera_slice_values(be, chi, [(0, 0), (1, 5 % chi), (17 % chi, 3 % chi), (chi - 1, chi - 2)], ta.bfloat16)
     rows, p16, p32 = [], [], []
     for pl, v in vals.items():
       for r in v["rows"]:
@@ -947,11 +963,16 @@ def mera_chi64_bench(ta, be, n_gpus=8, verify=False, full_placements=0, budget_s
     if alone > 0:
       rec["measured_speedup_over_slice_by_slice"] = alone / secs       # against (seconds of one slice alone) x slices done
     complete = all(m["slices_done"] == m["n_slices"] for m in measured.values())
+    rec["measured_executed_macs"] = sum(m.get("executed_macs", 0.0) for m in measured.values())
+    rec["measured_macs_if_every_slice_ran_alone"] = sum(m["macs_per_slice"] * m["slices_done"] for m in measured.values())
     rec["measured_label"] = (f"MEASURED on 1 GPU: {len(measured)} of 2 placements, every slice contracted "
-                             f"({done} slices{'' if complete else ', stopped by the time budget'}); partial results that "
-                             "depend on one slice index only are reused across slices when measured_reuse_partials is true "
-                             "(the EXTRAPOLATED rows are per-slice seconds x slices, without reuse); the 8-GPU figure "
-                             "stays arithmetic (no 8-GPU node on the builder's side)")
+                             f"({done} slices{'' if complete else ', stopped by the time budget'}) through "
+                             "distributed._contract_slices_staged; each cut slices BOTH tensors on its leg (slice_edge), "
+                             "a step runs once per distinct value of the cuts it depends on when "
+                             "measured_reuse_partials is true -- a complete placement then executes the flop-optimal "
+                             "DENSE cost of the network (3.72e16 multiply-adds at chi = 64), 41 % of 4096 stand-alone "
+                             "slices (the EXTRAPOLATED rows are per-slice seconds x slices, without reuse); the 8-GPU "
+                             "figure stays arithmetic (no 8-GPU node on the builder's side)")
     if verify:
       rec.setdefault("verified_runs", {pl: m.get("checks_vs_f32") for pl, m in measured.items()})
   if checked is not None:
@@ -1216,11 +1237,12 @@ def compact_line(result, detail_name):
         line["svd"]["cpu_gbps"] = _num(svd["cpu_baseline"].get("value"))
   line["sliced_network"] = _pick(result.get("sliced_network"),
                                  ("n_slices", "n_gpus", "seconds", "tflops", "mode", "allreduce_seconds", "scaling", "collective",
-                                  "permute_time_frac"))
+                                  "permute_time_frac", "ideal_speedup_of_this_partition", "executed_equals_model"))
+  line["sliced_network_small"] = _pick(result.get("sliced_network_small"), ("n_slices", "seconds", "tflops", "mode"))
   line["mera"] = _pick(result.get("mera"), ("chi", "seconds", "tflops", "permute_launches"))
   line["mera_chi64"] = _pick(result.get("mera_chi64"),
                              ("measured_seconds", "measured_slices", "measured_tflops", "measured_reuse_partials",
-                              "measured_speedup_over_slice_by_slice", "layer_seconds_1gpu_extrapolated",
+                              "measured_executed_macs", "measured_speedup_over_slice_by_slice", "layer_seconds_1gpu_extrapolated",
                               "layer_seconds_8gpu_extrapolated", "tflops_1gpu"))
   chain = result.get("mps_chain")
   if isinstance(chain, list):
@@ -1235,7 +1257,7 @@ def compact_line(result, detail_name):
   line = {k: v for k, v in line.items() if v is not None or k == "vs_baseline"}
   line["detail"] = detail_name
   text = json.dumps(line, separators=(",", ":"))
-  for drop in ("gather_gemm_us", "mps_chain_ms", "mera_chi64", "bond_sweep", "mera", "sliced_network", "svd"):
+  for drop in ("gather_gemm_us", "mps_chain_ms", "sliced_network_small", "mera_chi64", "bond_sweep", "mera", "sliced_network", "svd"):
     if len(text) < COMPACT_LINE_LIMIT:
       break
     line.pop(drop, None)              # never reached at the bench's own sizes; the contract keys always fit
@@ -1383,6 +1405,10 @@ def main():
                                                                   not args.no_verify))
     if isinstance(result["sliced_network"], dict) and "verified" in result["sliced_network"]:
       verified["sliced_network_bf16_vs_f32"] = result["sliced_network"].pop("verified")
+    if world == 1 and args.rr_bond_small > 0 and args.rr_bond_small != args.rr_bond:
+      # the rounds 1-4 instance (D = 12: 0.092 s on one GPU in round 4), for continuity
+      fenced(result, "sliced_network_small", lambda: sliced_network_bench(ta, be, comm, rank, world, args.rr_bond_small,
+                                                                          args.rr_min_slices, False))
   if rank == 0:
     single = world == 1
     if single and not args.no_sweep:

@@ -17,6 +17,7 @@
 #include <dlfcn.h>
 #include <stdlib.h>
 #include <unistd.h>
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <memory>
@@ -53,6 +54,7 @@ struct RcclApi {
 
 RcclApi g_api;
 ncclComm_t g_comm = nullptr;
+std::atomic<bool> g_init_abandoned{false};   // a bring-up timed out: its helper thread may still be inside RCCL
 int g_rank = 0, g_world = 1;
 
 template <typename F>
@@ -149,6 +151,11 @@ int tnh_comm_init(const void* host_id, int rank, int world) {
   TNH_REQUIRE(host_id != nullptr && world >= 1 && rank >= 0 && rank < world, "tnh_comm_init: bad rank %d / world %d",
               rank, world);
   TNH_REQUIRE(g_comm == nullptr, "tnh_comm_init: a communicator already exists (tnh_comm_destroy first)");
+  // After a bring-up timeout a helper thread may still sit inside ncclCommInitRank (see below): a second bring-up in
+  // this process would race with it, and a communicator it completes later is never tracked.  The library stays
+  // poisoned for communicators: report and exit is the only way on.
+  TNH_REQUIRE(!g_init_abandoned.load(), "tnh_comm_init: an earlier bring-up timed out in this process and its helper "
+              "thread may still be inside RCCL; no further communicator can be created here (exit the process)");
   int rc = load_rccl();
   if (rc != TNH_OK) return rc;
   ncclUniqueId id;
@@ -169,6 +176,7 @@ int tnh_comm_init(const void* host_id, int rank, int world) {
     std::mutex mu;
     std::condition_variable cv;
     bool done = false;
+    bool abandoned = false;
     ncclResult_t rc = ncclSuccess;
     ncclComm_t comm = nullptr;
   };
@@ -178,15 +186,22 @@ int tnh_comm_init(const void* host_id, int rank, int world) {
   double limit_s = 600.0;
   if (const char* e = getenv("TNH_COMM_INIT_TIMEOUT_S")) limit_s = atof(e);
   auto fn = g_api.CommInitRank;
-  std::thread helper([st, fn, id, world, rank, dev]() {
+  auto abort_fn = g_api.CommAbort;
+  std::thread helper([st, fn, abort_fn, id, world, rank, dev]() {
     (void)hipSetDevice(dev);                       // the current device is per thread
     ncclComm_t c = nullptr;
     const ncclResult_t r = fn(&c, world, id, rank);
-    std::lock_guard<std::mutex> lk(st->mu);
-    st->rc = r;
-    st->comm = c;
-    st->done = true;
-    st->cv.notify_all();
+    bool abandoned;
+    {
+      std::lock_guard<std::mutex> lk(st->mu);
+      st->rc = r;
+      st->comm = c;
+      st->done = true;
+      abandoned = st->abandoned;
+      st->cv.notify_all();
+    }
+    // nobody is waiting any more (the caller returned TNH_ERR_TIMEOUT): the communicator is ours to release
+    if (abandoned && r == ncclSuccess && c != nullptr && abort_fn) (void)abort_fn(c);
   });
   bool finished;
   {
@@ -198,12 +213,20 @@ int tnh_comm_init(const void* host_id, int rank, int world) {
       finished = true;
     }
   }
+  if (!finished) {
+    std::lock_guard<std::mutex> lk(st->mu);
+    if (st->done) finished = true;            // it returned between the wait and here
+    else st->abandoned = true;
+  }
+  // (after a timeout the abandoned helper may still print RCCL's banner to the restored stdout; the caller gets
+  //  TNH_ERR_TIMEOUT and is expected to report on stderr and exit)
   fflush(stdout);
   if (saved_stdout >= 0) {
     dup2(saved_stdout, STDOUT_FILENO);
     close(saved_stdout);
   }
   if (!finished) {
+    g_init_abandoned.store(true);
     helper.detach();
     set_error("ncclCommInitRank did not return within %.0f s on rank %d of %d (TNH_COMM_INIT_TIMEOUT_S): a peer is "
               "missing or RCCL's bootstrap interface does not route (NCCL_SOCKET_IFNAME)", limit_s, rank, world);

@@ -254,21 +254,29 @@ struct KWalk {
   }
 };
 
-// SCHED (round 5, A/B knobs ":p7" / ":p8"):
-//   1  ONE 64-MFMA cluster per K-tile: every fragment of the K-tile (24 ds_read_b128 = 96 registers) is read in one
-//      load segment, two barriers per K-tile instead of four.  A whole LDS buffer is restaged at once, two intervals
-//      ahead: tile t + 2 goes into tile t's buffer during the interval after group 1's last read of it -- group 0
-//      issues its pieces in its load segment of tile t + 1, group 1 at the head of its MFMA cluster of tile t (the
-//      same interval), and each wave waits for its own pieces (vmcnt(0)) at the end of the FOLLOWING interval.
-//   2  M32 with the four independent 32x32 accumulators of a cluster interleaved (k-step outermost): the dependent
-//      MFMA is four issues = 128 cycles behind its producer instead of two = 64 (exactly the instruction's latency).
+// SCHED = 1 (round 5, A/B knob ":p7"): ONE 64-MFMA cluster per K-tile -- every fragment of the K-tile (24 ds_read_b128
+// = 96 registers) is read in one load segment, two barriers per K-tile instead of four.  LDS: A double-buffered
+// (2 x 32 KiB), B triple-buffered (3 x 32 KiB) = 160 KiB, the whole CU.  Group g (waves 4g .. 4g+3) loads what it
+// alone reads of A -- half g, four pieces per wave -- and half g of B, always in its LOAD segment:
+//
+//   load segment of K-tile t (group g, interval 2t + g):  24 fragment reads of tile t;
+//        A-half g of tile t+1 -> A buffer (t+1) & 1   (last read by this group in its load segment of tile t-1)
+//        B-half g of tile t+2 -> B slot (t+2) % 3     (tile t-1's slot, last read by group 1 in interval 2t-1)
+//   RAW  group 1 ends its load segment with vmcnt(8): its B-half 1 of tile t+1 (issued one K-tile ago) has landed
+//        before group 0 reads tile t+1 in the next interval; every wave ends its MFMA cluster with vmcnt(4): its A
+//        pieces of tile t+1 and its older B pieces have landed, only B of tile t+2 stays in flight.
+//   distances: A two intervals (~2 x 1100 cycles), B three to four.
+// (The first form of this schedule -- whole buffers restaged two intervals ahead, group 1 issuing at the head of its
+// MFMA cluster -- lost 8-20 % to the default: profiles/r05_gemm_variants.md.)
 template <bool IS_BF16, bool OUT_F32, bool TWO, bool M32 = false, bool VIEW = false, bool A_KM = false,
           bool B_KN = false, int SCHED = 0>
 __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(NtArgs p) {
   static_assert(!VIEW || (TWO && !M32), "view kernels use the 2-phase 16x16x32 schedule");
-  static_assert(SCHED != 1 || (TWO && !M32), "the one-cluster schedule is a 16x16x32 schedule");
-  static_assert(SCHED != 2 || (TWO && M32 && !VIEW), "the interleaved schedule is the 32x32x16 one");
+  static_assert(SCHED == 0 || (TWO && !M32 && !A_KM && !B_KN), "the round-5 schedules: 16x16x32, K-contiguous operands");
   constexpr bool ONE = (SCHED == 1);
+  // SCHED = 2 (A/B knob ":p8"): the default schedule with the MFMAs of a quadrant in snake order -- every issue
+  // changes exactly one of the two operand registers (fewer operand-bus toggles; same sums, bit-identical)
+  constexpr bool SNAKE = (SCHED == 2);
   constexpr int ASUBS = ONE ? 2 : 1;
   static_assert(VIEW || (!A_KM && !B_KN), "k-major operands need the view kernel");
   // M32 (32x32x16 MFMA) lost the A/B with 4 phases per K-tile (only 2 independent accumulators per
@@ -280,7 +288,7 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(NtArgs p) {
   constexpr int FA = M32 ? 2 : 4;            // row fragments per 64-row A sub-tile
   constexpr int FB = M32 ? 1 : 2;            // row fragments per 32-row B sub-tile
   constexpr int FROWS = M32 ? 32 : 16;
-  __shared__ __attribute__((aligned(1024))) char smem[2 * BUF_BYTES];
+  __shared__ __attribute__((aligned(1024))) char smem[ONE ? 10 * HALF_BYTES : 2 * BUF_BYTES];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -317,7 +325,8 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(NtArgs p) {
       const uint32_t c1 = (uint32_t)col / (uint32_t)v.r0, c0 = (uint32_t)col - c1 * (uint32_t)v.r0;   // rows < 2^31 (host check)
       return base + (int64_t)c1 * v.sr1 + c0 + (int64_t)(krow & 31) * v.sk0;      // piece i = half i of the K-tile
     }
-    const int trow = (i * 8 + wid) * 8 + lrow;  // row inside the half-tile
+    const int trow = ONE ? (i * 4 + wc) * 8 + lrow      // one-cluster schedule: the 4 waves of a group cover a half-tile
+                         : (i * 8 + wid) * 8 + lrow;    // row inside the half-tile
     const int swz = M32 ? ((trow >> 1) & 7) : (trow & 7);
     const int lchunk = (lane & 7) ^ swz;
     int64_t row = first + h * 128 + trow;
@@ -337,8 +346,13 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(NtArgs p) {
     for (int h = 0; h < 2; ++h)
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        ga[h][i] = src_ptr(A, p.va, A_KM, m0 + p.m_off, p.M + p.m_off, p.lda, h, i);
-        gb[h][i] = src_ptr(B, p.vb, B_KN, n0, p.N, p.ldb, h, i);
+        if constexpr (ONE) {     // four pieces of the half this wave's group owns (piece 2 h + i)
+          ga[h][i] = src_ptr(A, p.va, false, m0 + p.m_off, p.M + p.m_off, p.lda, wr, 2 * h + i);
+          gb[h][i] = src_ptr(B, p.vb, false, n0, p.N, p.ldb, wr, 2 * h + i);
+        } else {
+          ga[h][i] = src_ptr(A, p.va, A_KM, m0 + p.m_off, p.M + p.m_off, p.lda, h, i);
+          gb[h][i] = src_ptr(B, p.vb, B_KN, n0, p.N, p.ldb, h, i);
+        }
       }
   };
   const unsigned lds0 = (unsigned)(size_t)TNH_LDS_PTR(smem);
@@ -359,6 +373,19 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(NtArgs p) {
       glds16(g + k, __builtin_amdgcn_readfirstlane(base + (i * 8 + wid) * 1024));
     }
   };
+
+  // one-cluster schedule: this wave's four pieces of its group's half of A (is_a) or B -> LDS half-tile at `base`
+  auto issue_own = [&](unsigned base, bool is_a, int64_t k0, int64_t k1) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const uint16_t* g = is_a ? ga[q >> 1][q & 1] : gb[q >> 1][q & 1];
+      int64_t k = k0;
+      if constexpr (VIEW) k = hi_half ? k1 : k0;
+      glds16(g + k, __builtin_amdgcn_readfirstlane(base + (q * 4 + wc) * 1024));
+    }
+  };
+  const unsigned own_a = lds0 + wr * HALF_BYTES;                    // + (tile & 1) * 2 * HALF_BYTES
+  const unsigned own_b = lds0 + 4 * HALF_BYTES + wr * HALF_BYTES;   // + (tile % 3) * 2 * HALF_BYTES
 
   // fragment read offsets inside a half-tile image (row base is a multiple of FROWS)
   int frag_off[KS];
@@ -445,25 +472,11 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(NtArgs p) {
         for (int j = 0; j < FB; ++j) {
           if constexpr (M32)
             acc32[sa * 2 + i][sb] = mma32<IS_BF16>(bf[sb][ks][j], af[sa % ASUBS][ks][i], acc32[sa * 2 + i][sb]);
-          else
-            acc[sa * 4 + i][sb * 2 + j] = mma16<IS_BF16>(bf[sb][ks][j], af[sa % ASUBS][ks][i], acc[sa * 4 + i][sb * 2 + j]);
+          else {
+            const int jj = (SNAKE && (i & 1)) ? FB - 1 - j : j;
+            acc[sa * 4 + i][sb * 2 + jj] = mma16<IS_BF16>(bf[sb][ks][jj], af[sa % ASUBS][ks][i], acc[sa * 4 + i][sb * 2 + jj]);
+          }
         }
-    __builtin_amdgcn_s_setprio(0);
-  };
-  // SCHED 2: both quadrants of A sub-tile `sa` as one cluster, accumulators interleaved
-  auto mma_pair32 = [&](int sa, int sb_first) {
-    __builtin_amdgcn_s_setprio(1);
-    if constexpr (M32) {
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-          const int sb = sb_first ^ q;
-#pragma unroll
-          for (int i = 0; i < FA; ++i)
-            acc32[sa * 2 + i][sb] = mma32<IS_BF16>(bf[sb][ks][0], af[0][ks][i], acc32[sa * 2 + i][sb]);
-        }
-    }
     __builtin_amdgcn_s_setprio(0);
   };
   // end of a load segment: retire this wave's LDS reads, then meet the other waves
@@ -501,6 +514,25 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(NtArgs p) {
       wa.next(ka0, ka1);
       wb.next(kb0, kb1);
     }
+    if constexpr (ONE) {        // A of K-tiles 0, 1 and B of K-tiles 0, 1, 2 (this group's halves)
+      issue_own(own_a, true, ka0, ka1);
+      issue_own(own_b, false, kb0, kb1);
+      if (nt > 1) {
+        int64_t a0 = (int64_t)BK, a1 = 0, b0 = (int64_t)BK, b1 = 0;
+        if constexpr (VIEW) {
+          wa.next(a0, a1);
+          wb.next(b0, b1);
+        }
+        issue_own(own_a + 2 * HALF_BYTES, true, a0, a1);
+        issue_own(own_b + 2 * HALF_BYTES, false, b0, b1);
+      }
+      if (nt > 2) {
+        int64_t b0 = (int64_t)2 * BK, b1 = 0;
+        if constexpr (VIEW) wb.next(b0, b1);
+        issue_own(own_b + 4 * HALF_BYTES, false, b0, b1);
+      }
+      return;
+    }
     issue(0, 0, ka0, ka1);
     issue(0, 1, ka0, ka1);
     issue(0, 2, kb0, kb1);
@@ -508,12 +540,6 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(NtArgs p) {
     if (nt > 1) {
       int64_t kc0 = (int64_t)BK, kc1 = 0;
       if constexpr (VIEW) wb.next(kc0, kc1);
-      if constexpr (ONE) {               // both buffers complete: A walks two tiles ahead as well
-        int64_t kd0 = (int64_t)BK, kd1 = 0;
-        if constexpr (VIEW) wa.next(kd0, kd1);
-        issue(1, 0, kd0, kd1);
-        issue(1, 1, kd0, kd1);
-      }
       issue(1, 2, kc0, kc1);
       issue(1, 3, kc0, kc1);
     } else if constexpr (VIEW) {
@@ -531,76 +557,44 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(NtArgs p) {
   if (wr == 1) __builtin_amdgcn_s_barrier();  // group 1 runs one interval behind group 0
   __builtin_amdgcn_sched_barrier(0);
 
+  int b3 = 0;      // one-cluster schedule: K-tile % 3 (B slot)
   for (int t = 0; t < nt; ++t) {
     const int b = t & 1;
     const char* cur = smem + b * BUF_BYTES;
     const bool n1 = (t + 1 < nt), n2 = (t + 2 < nt);
     if constexpr (ONE) {
-      // one 64-MFMA cluster per K-tile (see SCHED above).  `stage2`: this wave's 8 pieces of K-tile t + 2 -> buffer b.
-      auto stage2 = [&]() {
-        int64_t ka = (int64_t)(t + 2) * BK, ka1 = 0, kb = ka, kb1 = 0;
-        if constexpr (VIEW) {
-          wa.next(ka, ka1);
-          wb.next(kb, kb1);
-        }
-        issue(b, 0, ka, ka1);
-        issue(b, 1, ka, ka1);
-        issue(b, 2, kb, kb1);
-        issue(b, 3, kb, kb1);
-      };
-      read_a(cur, 0);
-      read_b(cur, 0);
-      read_b(cur, 1);
-      read_a(cur, 1);
-      if (wr == 0) {
-        // group 0: K-tile t + 1 into the buffer K-tile t - 1 left (group 1 read it last one interval ago)
-        if (t >= 1 && n1) {
-          int64_t ka = (int64_t)(t + 1) * BK, ka1 = 0, kb = ka, kb1 = 0;
-          if constexpr (VIEW) {
-            wa.next(ka, ka1);
-            wb.next(kb, kb1);
-          }
-          issue(b ^ 1, 0, ka, ka1);
-          issue(b ^ 1, 1, ka, ka1);
-          issue(b ^ 1, 2, kb, kb1);
-          issue(b ^ 1, 3, kb, kb1);
-        }
-      } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // group 1: its pieces of K-tile t + 1 (issued one interval ago)
+      // one 64-MFMA cluster per K-tile (schedule in the kernel header)
+      const char* curA = smem + (t & 1) * 2 * HALF_BYTES;
+      const char* curB = smem + 2 * HALF_BYTES + b3 * 2 * HALF_BYTES;     // read_b adds (2 + (wc >> 1)) half-tiles
+      read_a(curA, 0);
+      read_b(curB, 0);
+      read_b(curB, 1);
+      read_a(curA, 1);
+      const bool ia = (t >= 1) && n1, ib = (t >= 1) && n2;
+      if (ia) {
+        int64_t ka = (int64_t)(t + 1) * BK, ka1 = 0;
+        if constexpr (VIEW) wa.next(ka, ka1);
+        issue_own(own_a + ((t + 1) & 1) * 2 * HALF_BYTES, true, ka, ka1);
+      }
+      if (ib) {
+        int64_t kb = (int64_t)(t + 2) * BK, kb1 = 0;
+        if constexpr (VIEW) wb.next(kb, kb1);
+        const int slot = (b3 == 0) ? 2 : b3 - 1;       // (t + 2) % 3
+        issue_own(own_b + slot * 2 * HALF_BYTES, false, kb, kb1);
+      }
+      if (wr == 1) {            // group 1's half of B of K-tile t + 1: group 0 reads it in the next interval
+        if (ia && ib) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
       TNH_SEG_LOAD_END();
-      if (wr == 1 && n2) stage2();
-      __builtin_amdgcn_sched_barrier(0);
       mma_quadrant(0, 0);
       mma_quadrant(0, 1);
       mma_quadrant(1, 1);
       mma_quadrant(1, 0);
-      if (wr == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // group 0: its pieces of K-tile t + 1
+      if (ib) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");     // A of K-tile t + 1 (and older pieces) landed
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       TNH_SEG_MMA_END();
-      continue;
-    }
-    if constexpr (TWO && SCHED == 2) {
-      read_a(cur, 0);
-      read_b(cur, 0);
-      read_b(cur, 1);
-      if (n1) {
-        issue(b ^ 1, 0, (int64_t)(t + 1) * BK, 0);
-        issue(b ^ 1, 1, (int64_t)(t + 1) * BK, 0);
-      }
-      TNH_SEG_LOAD_END();
-      mma_pair32(0, 0);
-      TNH_SEG_MMA_END();
-      read_a(cur, 1);
-      if (n2) {
-        issue(b, 2, (int64_t)(t + 2) * BK, 0);
-        issue(b, 3, (int64_t)(t + 2) * BK, 0);
-        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-      } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      }
-      TNH_SEG_LOAD_END();
-      mma_pair32(1, 1);
-      TNH_SEG_MMA_END();
+      b3 = (b3 == 2) ? 0 : b3 + 1;
       continue;
     }
     if constexpr (TWO) {
@@ -977,7 +971,7 @@ static int launch_pp(bool is_bf16, bool out_f32, bool two, NtArgs p, int64_t bat
 #define TNH_PP_LAUNCH(B16, O32)                                                                               \
   do {                                                                                                       \
     if (g_opt_phases == 7) hipLaunchKernelGGL((gemm_nt_pp_kernel<B16, O32, true, false, false, false, false, 1>), grid, block, 0, stream(), q); \
-    else if (g_opt_phases == 8) hipLaunchKernelGGL((gemm_nt_pp_kernel<B16, O32, true, true, false, false, false, 2>), grid, block, 0, stream(), q); \
+    else if (g_opt_phases == 8) hipLaunchKernelGGL((gemm_nt_pp_kernel<B16, O32, true, false, false, false, false, 2>), grid, block, 0, stream(), q); \
     else if (m32) hipLaunchKernelGGL((gemm_nt_pp_kernel<B16, O32, true, true>), grid, block, 0, stream(), q);      \
     else if (two) hipLaunchKernelGGL((gemm_nt_pp_kernel<B16, O32, true>), grid, block, 0, stream(), q);      \
     else hipLaunchKernelGGL((gemm_nt_pp_kernel<B16, O32, false>), grid, block, 0, stream(), q);              \

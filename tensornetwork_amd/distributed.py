@@ -54,10 +54,10 @@ def choose_cut_edges(nodes: Sequence[network.Node], min_slices: int,
                      world: int = 1) -> List[network.Edge]:
   """Pick contracted edges to slice until there are >= min_slices slices.
 
-  The cut SET is ranked by what `contract_sliced` then executes (`_StagePlan`): first the multiply-adds of the
-  SLOWEST of `world` ranks under the partition `contract_sliced` uses (`_StagePlan.partition`) -- every step once per
-  distinct value of the cuts it depends on -- then the multiply-adds of all ranks, then the cost of the slices run
-  alone, then the peak intermediate.  Two searches, the better set wins (ties: the sequential one):
+  The cut SET is ranked by what `contract_sliced` then executes (`_StagePlan`): first the estimated time
+  (`step_seconds`: a flop / byte / launch roofline per pairwise step) of the SLOWEST of `world` ranks under the
+  partition `contract_sliced` uses (`_StagePlan.partition`) -- every step once per distinct value of the cuts it
+  depends on -- then the sum over the ranks, then the multiply-adds, then the peak intermediate.  Two searches, the better set wins (ties: the sequential one):
 
     * the sequential rule: cut the edge whose removal (dimension -> 1) gives the cheapest re-searched path, repeat;
     * a beam search over cut sets (`beam` partial sets per level, each extended by one of the `beam` best single
@@ -82,7 +82,7 @@ def choose_cut_edges(nodes: Sequence[network.Node], min_slices: int,
 
 
 def _cut_cost_fn(nodes, algorithm, world):
-  """cost(cuts) -> (slowest rank's multiply-adds with reuse, all ranks', slices alone, peak intermediate)"""
+  """cost(cuts) -> (slowest rank's estimated seconds with reuse, all ranks', multiply-adds with reuse, peak intermediate)"""
   inputs, output, sizes = _index_problem(nodes)
   memo = {}
 
@@ -96,8 +96,8 @@ def _cut_cost_fn(nodes, algorithm, world):
       plan = _StagePlan(nodes, list(cuts), path)
       flops, peak = pathfinder.path_cost(inputs, output, trial, path)
       every = list(itertools.product(*[range(sizes[e]) for e in cuts]))
-      per_rank = [plan.macs_with_reuse(b) for b in plan.partition(every, world) if b]
-      memo[ident] = (max(per_rank), sum(per_rank), float(flops) * len(every), float(peak))
+      per_rank = [plan.seconds_with_reuse(b) for b in plan.partition(every, world) if b]
+      memo[ident] = (max(per_rank), sum(per_rank), plan.macs_with_reuse(every), float(peak))
     return memo[ident]
   return cost
 
@@ -211,6 +211,21 @@ def _hoist_invariant(nodes, cut_edges, path, output_edge_order):
   return [by_id[k] for k in live], [edge_map[e] for e in cut_edges], rest, order, len(hoist)
 
 
+# Roofline estimate of one pairwise step on an MI355X, used to RANK cut sets and partitions (never reported as a
+# measurement): the larger of the multiply-adds at 600 TFLOP/s and the operand + result bytes (2-byte elements) at
+# 2.5 TB/s, plus 8 us of launches.  Calibrated on the D = 12 64-node network (profiles/r05_rr_scaling_rehearsal.jsonl):
+# the cuts with the FEWEST multiply-adds (1.73e13 against 2.18e13) ran 3.4x SLOWER on the GPU (0.312 s against 0.093 s)
+# because 69 % of their work sits in thin per-slice products that move bytes, not flops; this model ranks the two sets
+# the right way round (0.18 s against 0.11 s), a multiply-add count does not.
+STEP_FLOPS_PER_SECOND = 6.0e14
+STEP_BYTES_PER_SECOND = 2.5e12
+STEP_LAUNCH_SECONDS = 8.0e-6
+
+
+def step_seconds(macs: float, elements_moved: float) -> float:
+  return max(2.0 * macs / STEP_FLOPS_PER_SECOND, 2.0 * elements_moved / STEP_BYTES_PER_SECOND) + STEP_LAUNCH_SECONDS
+
+
 class _StagePlan:
   """Which steps of a sliced network's path depend on which cut bonds.
 
@@ -236,6 +251,7 @@ class _StagePlan:
     ids = list(range(self.n))
     remaining = [frozenset(x) for x in inputs]
     self.steps = []                                              # (id_a, id_b, id_new, cuts it depends on, multiply-adds)
+    self.step_seconds = []                                       # roofline estimate per step (step_seconds)
     for pair in path:
       if len(pair) == 1:
         continue
@@ -247,14 +263,18 @@ class _StagePlan:
           others |= k
       new = self.n + len(self.steps)
       dep.append(dep[ids[a]] | dep[ids[b]])
-      self.steps.append((ids[a], ids[b], new, dep[new], float(pathfinder._size(k1 | k2, sliced))))   # pylint: disable=protected-access
+      kept = frozenset(d for d in (k1 | k2) if d in others)
+      size = lambda ks: float(pathfinder._size(ks, sliced))      # pylint: disable=protected-access
+      self.steps.append((ids[a], ids[b], new, dep[new], size(k1 | k2)))
+      self.step_seconds.append(step_seconds(size(k1 | k2), size(k1) + size(k2) + size(kept)))
       ids = [x for t, x in enumerate(ids) if t not in (a, b)] + [new]
-      remaining = [k for t, k in enumerate(remaining) if t not in (a, b)] + [frozenset(d for d in (k1 | k2) if d in others)]
+      remaining = [k for t, k in enumerate(remaining) if t not in (a, b)] + [kept]
     self.dep = dep
     self.final = self.steps[-1][2] if self.steps else 0
     self.classes = sorted({st[3] for st in self.steps}, key=lambda c: (len(c), sorted(c)))
     self.class_steps = {c: [(a, b, new) for a, b, new, d, _ in self.steps if d == c] for c in self.classes}
     self.class_macs = {c: sum(st[4] for st in self.steps if st[3] == c) for c in self.classes}
+    self.class_seconds = {c: sum(t for st, t in zip(self.steps, self.step_seconds) if st[3] == c) for c in self.classes}
     self.class_needs = {}
     for c, lst in self.class_steps.items():
       produced = {new for _, _, new in lst}
@@ -262,7 +282,7 @@ class _StagePlan:
     self.labels = [[id(e) for e in nd.edges] for nd in nodes]
     self.label_time = {id(e): t for e, t in contractors._edge_times(path, nodes).items()}     # pylint: disable=protected-access
     # loop order of the slices: the cut whose steps cost most varies slowest
-    weight = [sum(m for c, m in self.class_macs.items() if k in c) for k in range(len(cut_edges))]
+    weight = [sum(m for c, m in self.class_seconds.items() if k in c) for k in range(len(cut_edges))]
     self.loop_order = sorted(range(len(cut_edges)), key=lambda k: (-weight[k], k))
 
   def macs_alone(self) -> float:
@@ -275,6 +295,13 @@ class _StagePlan:
       total += macs * len({tuple(idx[k] for k in sorted(c)) for idx in slices})
     return total
 
+  def seconds_with_reuse(self, slices) -> float:
+    """`step_seconds` summed over what runs for `slices`: every class once per distinct value tuple"""
+    total = 0.0
+    for c, sec in self.class_seconds.items():
+      total += sec * len({tuple(idx[k] for k in sorted(c)) for idx in slices})
+    return total
+
   def ordered(self, slices, loop_order=None):
     order = self.loop_order if loop_order is None else loop_order
     return sorted(slices, key=lambda idx: tuple(idx[k] for k in order))
@@ -282,8 +309,8 @@ class _StagePlan:
   def partition(self, slices, world: int):
     """The slices dealt to `world` ranks: contiguous blocks of the slices sorted with one cut varying slowest,
     either balanced (sizes differ by at most one) or of ceil(n / world) slices each; of all loop orders (at most 24
-    tried, the weight order first) x the two block rules the one whose SLOWEST rank executes the fewest multiply-adds
-    with reuse, then the fewest in all.  Pure host arithmetic on the plan: every rank computes the same blocks.
+    tried, the weight order first) x the two block rules the one whose SLOWEST rank has the smallest estimated time
+    (`seconds_with_reuse`), then the smallest sum.  Pure host arithmetic on the plan: every rank computes the same blocks.
     A rank's block may be empty (fewer slices than ranks)."""
     slices = list(slices)
     world = max(int(world), 1)
@@ -305,7 +332,7 @@ class _StagePlan:
         start = stop
       for bounds in (bounds_balanced, [(r * per, (r + 1) * per) for r in range(world)]):
         blocks = [seq[a:b] for a, b in bounds]
-        loads = [self.macs_with_reuse(b) for b in blocks]
+        loads = [self.seconds_with_reuse(b) for b in blocks]
         key = (max(loads), sum(loads))
         if best is None or key < best[0]:
           best = (key, blocks)
@@ -328,7 +355,7 @@ STAGE_CACHE_BYTES = 16 << 30
 
 
 def _contract_slices_staged(be, nodes, plan: _StagePlan, slices, output_edge_order, partials_out, stats,
-                            input_provider=None, cache_bytes=None, on_slice=None):
+                            input_provider=None, cache_bytes=None, on_slice=None, reuse=True):
   """The slices of one rank with every step run once per distinct value of the cuts it depends on (`_StagePlan`).
   Results of a class are kept for the value tuple in use, and for all value tuples when they fit in `cache_bytes`
   (default STAGE_CACHE_BYTES, counted with the tensors' real item size); otherwise the class is recomputed when its
@@ -338,7 +365,8 @@ def _contract_slices_staged(be, nodes, plan: _StagePlan, slices, output_edge_ord
   `input_provider(k, idx)` (optional): tensor of input k for slice idx WITH its cut legs at extent 1, or None to
   slice `nodes[k].tensor` here -- for inputs that are defined slice-wise and never materialised (the 137 GB rank-6
   tensors of the chi = 64 MERA layer).  `on_slice(n_done, idx, tensor)`: called after every slice with its partial
-  (time budgets, sampled checks); returning True stops the loop."""
+  (time budgets, sampled checks); returning True stops the loop.  `reuse=False`: nothing is kept from one slice to
+  the next -- every step runs in every slice (the slice-by-slice baseline on the same machinery)."""
   budget = STAGE_CACHE_BYTES if cache_bytes is None else int(cache_bytes)
   n = plan.n
   cache: Dict[frozenset, Dict[tuple, dict]] = {c: {} for c in plan.classes}
@@ -399,6 +427,10 @@ def _contract_slices_staged(be, nodes, plan: _StagePlan, slices, output_edge_ord
       partials_out.append(np.asarray(part, dtype=np.float64).copy())
     total = be.multiply(part, 1.0) if total is None else be.addition(total, part)
     done += 1
+    if not reuse:
+      for kept in cache.values():
+        kept.clear()
+      sliced_inputs.clear()
     if on_slice is not None and on_slice(done, idx, tensor):
       break
   if stats is not None:
@@ -631,6 +663,7 @@ def slicing_report(nodes: Sequence[network.Node], cut_edges: Sequence[network.Ed
     blocks = plan.partition(list(itertools.product(*[range(e.dimension) for e in cut_edges])), max(int(world), 1))
     per_rank = [plan.macs_with_reuse(b) for b in blocks]
     reuse = {"flops_with_reuse_all_ranks": float(sum(per_rank)), "flops_with_reuse_slowest_rank": float(max(per_rank)),
+             "model_seconds_slowest_rank": float(max(plan.seconds_with_reuse(b) for b in blocks)),
              "slices_per_rank": [len(b) for b in blocks],
              "reuse_classes": {",".join(str(k) for k in sorted(c)) or "-": float(m) for c, m in plan.class_macs.items()},
              "staged_by_default": bool(max(per_rank) <= 0.8 * plan.macs_alone() * max(len(b) for b in blocks))}

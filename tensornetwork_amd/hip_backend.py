@@ -1275,10 +1275,20 @@ class HipBackend(BackendBase):
           relative=False):
     """Truncated SVD (abstract_backend.py:79-137; rule of decompositions.py:21-74).
 
-    The Jacobi factorisation runs on the GPU and returns ALL singular values;
-    the keep/discard decision below restates decompositions.py:38-57 on the
-    host; only the kept vectors are then emitted by the GPU.  complex64 / complex128
-    run the same one-sided Jacobi with unitary plane rotations (2-row kernel).
+    Two device paths, same truncation rule (decompositions.py:38-57, restated on the host on the singular values):
+
+      * band path (K7b, `_svd_band`; f32 / bf16 / f16 / f64 with min(m, n) >= `svd_band_min`, complex64 / complex128
+        through the real embedding): band reduction, spectrum slicing for the values, inverse iteration for the KEPT
+        vectors only, back-transformation.  Every call shape (max_singular_values, max_truncation_error, both, neither).
+      * one-sided block Jacobi (K7; every other shape, and the fall-back): all singular values, then only the kept
+        vectors are emitted.  complex inputs use unitary plane rotations.
+
+    Which one ran is in `last_svd_path` after the call.  The band path reports numerically rank-deficient panels /
+    unconverged vectors through a status word; the call then falls back to Jacobi, and a shape that reports twice in
+    a row skips the band path for min(2^f, 64) calls (`svd_band_policy()` shows the state, `reset_svd_band_policy()`
+    clears it, `svd_band_backoff = False` switches the skipping off; the state lives in this backend object).  Both
+    paths obey the same rule; they differ in the accuracy of the DISCARDED values `s_rest` (band: 20-bit brackets,
+    5e-7 s_1; Jacobi: full precision).
     """
     tensor = self._as_tensor(tensor)
     self._check_float(tensor, "svd")
@@ -1393,6 +1403,18 @@ class HipBackend(BackendBase):
   _svd_band_failed = set()      # tall shapes whose last band call reported a status: read it early next time
   _svd_band_backoff = {}        # (dtype, mm, nn) -> (consecutive reports, calls still to skip)
 
+  svd_band_backoff = True       # skip the band path for shapes that keep reporting (see svd's docstring)
+
+  def svd_band_policy(self):
+    """The band path's back-off state: {(dtype code, rows, cols): {"consecutive_reports", "calls_still_skipped"}} and
+    the shapes whose status word is read early.  Empty = every eligible call tries the band path."""
+    return {"backoff": {k: {"consecutive_reports": f, "calls_still_skipped": sk} for k, (f, sk) in self._svd_band_backoff.items()},
+            "status_read_early_for": sorted(self._svd_band_failed), "enabled": bool(self.svd_band_backoff)}
+
+  def reset_svd_band_policy(self):
+    self._svd_band_failed.clear()
+    self._svd_band_backoff.clear()
+
   # largest inverse-iteration workspace (the stored LDL^T factors: k * min(m, n) * 128 bytes) the band path asks for
   svd_band_max_factor_bytes = 24 << 30
 
@@ -1474,8 +1496,9 @@ class HipBackend(BackendBase):
     # min(2^f, 64) times, then tries again; one success clears it.
     key = (a.code, mm, nn)
     fails, skip = self._svd_band_backoff.get(key, (0, 0))
-    if skip > 0:
+    if skip > 0 and self.svd_band_backoff:
       self._svd_band_backoff[key] = (fails, skip - 1)
+      self.last_svd_path = f"jacobi (band path skipped: {fails} consecutive status reports on this shape, {skip - 1} skips left)"
       return None
     kcap = nn if pick is not None else (kmax + 3) // 4 * 4
     if kmax <= 0 or kcap * nn * self._svd_band_bytes_per_vector_row(a.code) > self.svd_band_max_factor_bytes:
@@ -1495,6 +1518,7 @@ class HipBackend(BackendBase):
     if check_now and status.value:
       self.last_svd_band_status = status.value
       self._svd_band_backoff[key] = (fails + 1, 0 if fails == 0 else min(2 ** (fails + 1), 64))
+      self.last_svd_path = f"jacobi (band path reported status {status.value} in its factor stage)"
       return None
     keep = kmax if pick is None else int(min(pick(s_all.numpy().astype(np.float64)), nn))
     if keep <= 0:
@@ -1509,6 +1533,7 @@ class HipBackend(BackendBase):
     if status.value:
       self._svd_band_failed.add((a.code, mm, nn))
       self._svd_band_backoff[key] = (fails + 1, 0 if fails == 0 else min(2 ** (fails + 1), 64))
+      self.last_svd_path = f"jacobi (band path reported status {status.value} in its vectors stage)"
       return None
     self._svd_band_failed.discard((a.code, mm, nn))
     self._svd_band_backoff.pop(key, None)

@@ -178,11 +178,20 @@ class _PlanBackend:
 
 def _mera_slice_plan(chi: int, placement: str):
   """Host-only plan of ONE bond-sliced placement of the MERA layer at bond dimension chi: the 12-node topology with
-  shape-only tensors, the cheapest pair of cuts (one leg of the hamiltonian, one leg of the state) under
-  branch(nbranch=2), the path on the sliced sizes and its cost."""
+  shape-only tensors, one cut on a leg of the hamiltonian and one on a leg of the state (chi^2 slices), and the path.
+
+  `slice_edge` (reference network_components.py:1636-1682) slices BOTH nodes of an edge: the disentangler / isometry
+  at the other end of each cut leg changes with the slice index just as the hamiltonian / state does, so a step of the
+  path depends on a cut as soon as it has absorbed EITHER end (`distributed._StagePlan` with windows on both ends).
+  What a sliced run executes when every step runs once per distinct value of the cuts it depends on is the cost of
+  the same path on the UNSLICED sizes with the two cut legs kept as batch indices -- so that is what the pathfinder
+  is asked to minimise: output = {cut legs}, full sizes.  Candidates: all 36 (h leg, state leg) pairs under
+  branch(nbranch=2), the four best re-searched with `optimal`; ranked by (executed multiply-adds, peak intermediate
+  of a slice, multiply-adds of one slice alone) among the plans whose peak intermediate is at most chi^5 elements.  At chi = 64 every good choice executes 3.72e16 multiply-adds per
+  placement -- the flop-optimal DENSE cost of the network: reuse recovers the dense cost, it cannot beat it."""
   import functools  # pylint: disable=import-outside-toplevel
-  from tensornetwork_amd import pathfinder  # pylint: disable=import-outside-toplevel
-  algo = functools.partial(pathfinder.branch, nbranch=2)
+  import itertools  # pylint: disable=import-outside-toplevel
+  from tensornetwork_amd import distributed, pathfinder  # pylint: disable=import-outside-toplevel
   pb = _PlanBackend()
   ham, rho = _ShapeOnly((chi,) * 6), _ShapeOnly((chi,) * 6)
   plan_nodes = mera_layer_network(pb, ham, rho, _ShapeOnly((chi,) * 3), _ShapeOnly((chi,) * 4), placement)
@@ -190,349 +199,226 @@ def _mera_slice_plan(chi: int, placement: str):
   sizes = {e: e.dimension for e in network.get_all_edges(plan_nodes)}
   hnode = [n for n in plan_nodes if n.tensor is ham][0]
   rnode = [n for n in plan_nodes if n.tensor is rho][0]
-  best = None
-  for eh in hnode.edges:                      # cheapest pair of cuts: one leg of h, one leg of rho
-    for er in rnode.edges:
-      trial = dict(sizes)
-      trial[eh] = 1
-      trial[er] = 1
-      path = algo(inputs, set(), trial)
-      flops, peak = pathfinder.path_cost(inputs, set(), trial, path)
-      if best is None or (flops, peak) < best[0]:
-        best = ((flops, peak), eh, er, path)
-  (flops, peak), eh, er, path = best
-  return {"nodes": plan_nodes, "hnode": hnode, "rnode": rnode, "cut": {id(eh), id(er)}, "path": path,
-          "flops": float(flops), "peak": float(peak), "depth": pathfinder.path_depth(path, len(plan_nodes))}
+  every = list(itertools.product(range(chi), range(chi)))
+
+  def rate(eh, er, algo):
+    path = algo(inputs, {eh, er}, sizes)
+    trial = dict(sizes)
+    trial[eh] = 1
+    trial[er] = 1
+    flops, peak = pathfinder.path_cost(inputs, set(), trial, path)
+    stage = distributed._StagePlan(plan_nodes, [eh, er], path)      # pylint: disable=protected-access
+    return (stage.macs_with_reuse(every), float(peak), float(flops)), path, stage
+
+  branch2 = functools.partial(pathfinder.branch, nbranch=2)
+  rows = []
+  for a, eh in enumerate(hnode.edges):
+    for b, er in enumerate(rnode.edges):
+      key, path, stage = rate(eh, er, branch2)
+      rows.append((key, (a, b), eh, er, path, stage))
+  # no intermediate larger than the sliced rank-6 inputs themselves (chi^5 elements: 2 GB in bf16 at chi = 64; the
+  # cheapest-by-a-hair plans keep a chi^6 intermediate -- 137 GB)
+  fits = lambda key: key[1] <= float(chi) ** 5
+  order = lambda r: (not fits(r[0]), r[0], r[1])
+  rows.sort(key=order)
+  best = rows[0]
+  for _, (a, b), eh, er, _, _ in rows[:4]:
+    key, path, stage = rate(eh, er, pathfinder.optimal)
+    cand = (key, (a, b), eh, er, path, stage)
+    if order(cand) < order(best):
+      best = cand
+  (executed, peak, flops), _, eh, er, path, stage = best
+  return {"nodes": plan_nodes, "hnode": hnode, "rnode": rnode, "cuts": [eh, er], "cut": {id(eh), id(er)}, "path": path,
+          "stage": stage, "flops": float(flops), "peak": float(peak), "executed_macs_with_reuse": float(executed),
+          "depth": pathfinder.path_depth(path, len(plan_nodes))}
 
 
-def _mera_slice_network(be, plan, tensor_of):
-  """Real nodes of one slice: node i of the plan gets tensor_of(i, node, sliced_shape)."""
-  plan_nodes, cut = plan["nodes"], plan["cut"]
-  index = {id(n): i for i, n in enumerate(plan_nodes)}
-  real = []
-  for i, n in enumerate(plan_nodes):
-    shape = tuple(1 if id(e) in cut else e.dimension for e in n.edges)
-    real.append(network.Node(tensor_of(i, n, shape), backend=be))
-  done = set()
-  for n in plan_nodes:
-    for e in n.edges:
-      if id(e) in done or e.is_dangling():
-        continue
-      done.add(id(e))
-      (n1, a1), (n2, a2) = e.ends()
-      network.connect(real[index[id(n1)]][a1], real[index[id(n2)]][a2])
-  return real
+class _Held:
+  """what `distributed._contract_slices_staged` needs of an input node: its tensor"""
+
+  def __init__(self, tensor):
+    self.tensor = tensor
+
+
+class MeraSlicedLayer:
+  """ONE placement of the binary-MERA layer energy (examples/simple_mera/simple_mera.py:54-112) as the network
+  `slice_edge(cut_h, i, 1); slice_edge(cut_rho, j, 1)` leaves of it, for every (i, j), at a bond dimension whose rank-6
+  tensors cannot be materialised (chi = 64: 137 GB each).
+
+  The layer's tensors are DEFINED, not stored: the hamiltonian slice-wise along its cut leg, h[.., i, ..] = R(seed_h + i)
+  (R a counter-based generator of the sliced shape), the state likewise along its own, rho[.., j, ..] = R(seed_r + j);
+  ONE isometry (chi^3) and ONE disentangler (chi^4) as full tensors shared by all their nodes, as in the reference.
+  Slice (i, j) of the network is then: h's slice i, rho's slice j, the disentangler / isometry at the OTHER end of
+  each cut leg sliced at the same index (slice_edge slices both nodes of the edge), every other node whole.  The
+  slices are contracted by `distributed._contract_slices_staged` -- the machinery `contract_sliced` runs -- with the
+  two rank-6 inputs handed in slice by slice (`input_provider`).  `host_tensors()` materialises the same network on
+  the host for small chi (tests: the slices must add up to the dense energy)."""
+
+  def __init__(self, be, chi: int, placement: str, dtype, seed: int = 40):
+    self.be, self.chi, self.placement, self.dtype, self.seed = be, int(chi), placement, dtype, seed
+    self.plan = _mera_slice_plan(self.chi, placement)
+    self.stage = self.plan["stage"]
+    nodes = self.plan["nodes"]
+    self.hk, self.rk = nodes.index(self.plan["hnode"]), nodes.index(self.plan["rnode"])
+    self.rank = [len(n.edges) for n in nodes]
+    self.scale = {3: float(chi) ** -0.75, 4: float(chi) ** -1.0, 6: float(chi) ** -1.5}      # closed network: variance 1
+    self._full = {}          # rank -> full tensor (isometry, disentangler) by dtype name
+    # axis of the cut leg on the two virtual inputs
+    self.h_axis = [ax for ax, c in self.stage.windows[self.hk] if c == 0][0]
+    self.r_axis = [ax for ax, c in self.stage.windows[self.rk] if c == 1][0]
+
+  # ---- tensors
+  def _virtual(self, k, index, dtype):
+    axis = self.h_axis if k == self.hk else self.r_axis
+    shape = tuple(1 if ax == axis else self.chi for ax in range(6))
+    sd = self.seed + (1000 if k == self.hk else 5000) + int(index)
+    return self.be.device_random(shape, dtype=self.dtype, seed=sd, normal=True, a=0.0, b=self.scale[6]) \
+        if dtype is None else self.be.cast(
+            self.be.device_random(shape, dtype=self.dtype, seed=sd, normal=True, a=0.0, b=self.scale[6]), dtype)
+
+  def _shared(self, rank, dtype):
+    key = (rank, str(dtype))
+    if key not in self._full:
+      t = self.be.device_random((self.chi,) * rank, dtype=self.dtype, seed=self.seed + 7 * rank, normal=True, a=0.0,
+                                b=self.scale[rank])
+      self._full[key] = t if dtype is None else self.be.cast(t, dtype)
+    return self._full[key]
+
+  def holders(self, dtype=None):
+    """inputs as `_contract_slices_staged` wants them: full tensors for the isometry / disentangler nodes, None for the
+    two rank-6 nodes (handed in slice by slice).  dtype: None = the layer's own, else a cast of the same values"""
+    return [_Held(None if k in (self.hk, self.rk) else self._shared(self.rank[k], dtype)) for k in range(len(self.rank))]
+
+  def provider(self, dtype=None):
+    def give(k, idx):
+      if k == self.hk:
+        return self._virtual(k, idx[0], dtype)
+      if k == self.rk:
+        return self._virtual(k, idx[1], dtype)
+      return None          # a real input with a cut leg: sliced from its full tensor by the caller
+    return give
+
+  def host_tensors(self):
+    """(hamiltonian, state, isometry, disentangler) of the SAME layer as host float64 arrays (small chi only)"""
+    if self.chi > 12:
+      raise ValueError("the rank-6 tensors are materialised for tests at small chi only")
+    cat = lambda k, axis: np.concatenate([np.asarray(self._virtual(k, i, None), dtype=np.float64) for i in range(self.chi)],
+                                         axis=axis)
+    return (cat(self.hk, self.h_axis), cat(self.rk, self.r_axis),
+            np.asarray(self._shared(3, None), dtype=np.float64), np.asarray(self._shared(4, None), dtype=np.float64))
+
+  def all_slices(self):
+    import itertools  # pylint: disable=import-outside-toplevel
+    return self.stage.ordered(list(itertools.product(range(self.chi), range(self.chi))))
+
+  # ---- contraction
+  def contract(self, slices, reuse=True, dtype=None, stats=None, on_slice=None, partials_out=None):
+    """sum of the partial energies of `slices` (a device scalar, f32-accumulated); reuse=False: every step in every
+    slice (the slice-by-slice run)"""
+    from tensornetwork_amd import distributed  # pylint: disable=import-outside-toplevel
+    total, _ = distributed._contract_slices_staged(      # pylint: disable=protected-access
+        self.be, self.holders(dtype), self.stage, slices, None, partials_out, stats, input_provider=self.provider(dtype),
+        on_slice=on_slice, reuse=reuse)
+    return total
 
 
 def mera_sliced_sample(be, chi: int, dtype, reps: int = 2, seed: int = 17):
-  """configs[4] at a bond dimension whose dense network does not fit (chi = 64: rank-6 inputs of 137 GB,
-  chi^7 intermediates): the layer energy is bond-sliced -- one cut on a leg of the hamiltonian and one on a
-  leg of the state give chi^2 independent slices per placement whose largest tensor is chi^5.  Measures the
-  PER-SLICE cost on this GPU: the 12-node topology is rebuilt with the two cut bonds at dimension 1
-  (operands generated directly at their sliced shapes: synthetic data), contracted with the
-  branch(nbranch=2) path of the sliced sizes.  Returns per-placement slice counts, multiply-adds and
-  seconds per slice; the whole layer is n_slices x that (slices are independent, one scalar all-reduce)."""
+  """Seconds of ONE slice contracted on its own, per placement (the EXTRAPOLATED rows of the bench: x slice count):
+  slice (0, 0) of `MeraSlicedLayer` -- every step of the path, nothing reused -- best of `reps` after a warm-up."""
   import time  # pylint: disable=import-outside-toplevel
-  from tensornetwork_amd import contractors  # pylint: disable=import-outside-toplevel
   out = {}
   for placement in ("left", "right"):
-    plan = _mera_slice_plan(chi, placement)
-
-    def tensor_of(i, node, shape):
-      scale = float(np.prod(shape)) ** -0.25
-      return be.device_random(shape, dtype=dtype, seed=seed * i + 3, normal=True, a=0.0, b=scale)
-
-    real = _mera_slice_network(be, plan, tensor_of)
+    layer = MeraSlicedLayer(be, chi, placement, dtype, seed=seed)
     best_t = None
     for _ in range(reps + 1):
-      node_map, _ = network.copy(real)
       be.synchronize()
       t0 = time.perf_counter()
-      res = contractors.contract_path(plan["path"], [node_map[n] for n in real]).tensor
+      res = layer.contract([(0, 0)], reuse=False)
       be.synchronize()
       t = time.perf_counter() - t0
       best_t = t if best_t is None else min(best_t, t)
       del res
+    plan = layer.plan
     out[placement] = {"n_slices": chi * chi, "macs_per_slice": plan["flops"], "peak_elems_per_slice": plan["peak"],
                       "sec_per_slice": best_t, "tflops": 2.0 * plan["flops"] / best_t / 1e12}
-    for n in real:
-      n.tensor = None
-      n.edges = []
   return out
 
 
 def mera_slice_values(be, chi: int, slices, half_dtype, seed: int = 40):
-  """Real slices of ONE chi-consistent binary-MERA layer network, each contracted three ways.
-
-  The layer's hamiltonian and state (rank 6, 137 GB each at chi = 64) are DEFINED slice-wise along their cut legs:
-  h[.., i, ..] = R(seed_h + i), rho[.., j, ..] = R(seed_r + j) with R a counter-based generator of the sliced shape
-  -- so slice (i, j) of the network is exactly what `slice_edge(cut_h, i); slice_edge(cut_rho, j)` would leave of the
-  full tensors, without ever materialising them; isometry and disentangler are the same full tensors in every
-  slice.  For each placement and each (i, j): the slice's partial energy in `half_dtype` and in f32 on the same
-  (half-rounded) values.  Returns {placement: {"depth": d, "rows": [{"slice": (i, j), "half": .., "f32": ..}]}}."""
-  from tensornetwork_amd import contractors  # pylint: disable=import-outside-toplevel
+  """Slices (i, j) of the layer `MeraSlicedLayer` defines, each contracted on its own in `half_dtype` and in f32 on
+  the same (half-rounded) values.  Returns {placement: {"depth": d, "rows": [{"slice": (i, j), "half": .., "f32": ..}]}}."""
   out = {}
   for placement in ("left", "right"):
-    plan = _mera_slice_plan(chi, placement)
+    layer = MeraSlicedLayer(be, chi, placement, half_dtype, seed=seed)
     rows = []
     for (i, j) in slices:
-      def tensor_of(k, node, shape, i=i, j=j):
-        scale = float(np.prod(shape)) ** -0.25
-        if node is plan["hnode"]:
-          sd = seed + 1000 + i
-        elif node is plan["rnode"]:
-          sd = seed + 5000 + j
-        else:
-          sd = seed + 7 * k        # isometries / disentanglers: slice-independent
-        return be.device_random(shape, dtype=half_dtype, seed=sd, normal=True, a=0.0, b=scale)
-
-      real = _mera_slice_network(be, plan, tensor_of)
       vals = {}
-      for name in ("half", "f32"):
-        node_map, _ = network.copy(real)
-        nodes = [node_map[n] for n in real]
-        if name != "half":
-          for nd in nodes:
-            nd.tensor = be.cast(nd.tensor, np.float32)
-        res = contractors.contract_path(plan["path"], nodes).tensor
+      for name, dt in (("half", None), ("f32", np.float32)):
+        res = layer.contract([(int(i), int(j))], reuse=False, dtype=dt)
         vals[name] = float(np.asarray(res, dtype=np.float64).reshape(-1)[0])
-        del res, nodes, node_map
+        del res
       rows.append({"slice": [int(i), int(j)], **vals})
-      for n in real:
-        n.tensor = None
-        n.edges = []
-    out[placement] = {"depth": plan["depth"], "rows": rows}
+    out[placement] = {"depth": layer.plan["depth"], "rows": rows}
   return out
-
-
-def _mera_stages(plan):
-  """Which steps of the placement's path depend on which slice index: the hamiltonian slice changes with i only, the
-  state slice with j only, everything else with neither, and a step inherits the union of its operands' dependencies.
-  Returns the steps as (id_a, id_b, id_new, dep) -- ids 0 .. 11 for the inputs, 12 + s for the result of step s, dep a
-  string out of "", "i", "j", "ij" -- with each step's multiply-adds, the axis labels of the inputs (one label per plan
-  edge) and the step at which the path contracts each label (layout planning)."""
-  from tensornetwork_amd import contractors, pathfinder  # pylint: disable=import-outside-toplevel
-  nodes, path, cut = plan["nodes"], plan["path"], plan["cut"]
-  n = len(nodes)
-  sizes = {e: (1 if id(e) in cut else e.dimension) for e in network.get_all_edges(nodes)}
-  deps = [""] * n
-  deps[nodes.index(plan["hnode"])] = "i"
-  deps[nodes.index(plan["rnode"])] = "j"
-  ids = list(range(n))
-  remaining = [frozenset(nd.edges) for nd in nodes]
-  dep_of = list(deps)
-  steps = []
-  for pair in path:
-    if len(pair) == 1:
-      continue
-    a, b = sorted(pair)
-    k1, k2 = remaining[a], remaining[b]
-    others = set()
-    for t, k in enumerate(remaining):
-      if t not in (a, b):
-        others |= k
-    dep = "".join(sorted(set(dep_of[ids[a]]) | set(dep_of[ids[b]])))
-    new = n + len(steps)
-    dep_of.append(dep)
-    steps.append((ids[a], ids[b], new, dep, float(pathfinder._size(k1 | k2, sizes))))      # pylint: disable=protected-access
-    ids = [x for t, x in enumerate(ids) if t not in (a, b)] + [new]
-    remaining = [k for t, k in enumerate(remaining) if t not in (a, b)] + [frozenset(d for d in (k1 | k2) if d in others)]
-  times = contractors._edge_times(path, nodes)      # pylint: disable=protected-access
-  return {"steps": steps, "input_dep": deps, "labels": [[id(e) for e in nd.edges] for nd in nodes],
-          "shapes": [tuple(1 if id(e) in cut else e.dimension for e in nd.edges) for nd in nodes],
-          "label_time": {id(e): t for e, t in times.items()},
-          "macs": {d: sum(st[4] for st in steps if st[3] == d) for d in ("", "i", "j", "ij")}}
-
-
-def _run_stage(be, operands, steps, label_time):
-  """contractors.contract_labelled (kept under this name for the MERA stages)"""
-  from tensornetwork_amd import contractors  # pylint: disable=import-outside-toplevel
-  return contractors.contract_labelled(be, operands, steps, label_time)
 
 
 def mera_sliced_run(be, chi: int, placement: str, half_dtype, seed: int = 40, budget_seconds: float = None,
                     check_every: int = 0, reuse_partials: bool = True):
-  """ONE placement of the bond-sliced binary-MERA layer energy as a RUN: all chi^2 slices of the
-  network `mera_slice_values` defines (hamiltonian and state given slice-wise along their cut legs -- what
-  `slice_edge(cut_h, i); slice_edge(cut_rho, j)` leaves of the full rank-6 tensors, which at chi = 64 are 137 GB each
-  and are never materialised; isometry and disentangler are the same tensors in every slice), each contracted with
-  the branch(nbranch=2) path of the sliced sizes, partial energies added in f32 ON THE DEVICE (one read-back at the
-  end).  The hamiltonian slice is generated once per i, the state slice once per (i, j) (2 GB of counter-based
-  random numbers: ~1 ms beside a ~37 ms slice).
+  """ONE placement of the bond-sliced binary-MERA layer energy as a RUN: all chi^2 slices of `MeraSlicedLayer` (what
+  `slice_edge` on one leg of the hamiltonian and one leg of the state leaves of the layer, BOTH ends of each cut leg
+  sliced) through `distributed._contract_slices_staged`, partial energies added in f32 on the device (one read-back).
 
-  budget_seconds: stop after the first slice that ends beyond it (the record then says how many slices ran).
-  check_every: every that many slices the same slice is also contracted in f32 on the same half-rounded values
-  (returned as `checks`: [(i, j), half, f32]) -- a sample of the a-priori rounding check, not part of the timing.
-  Returns {"n_slices", "slices_done", "seconds", "energy_partial_sum", "macs_per_slice", "checks", ...}.
+  reuse_partials (default): every step runs once per distinct value of the cuts it depends on; the results of a class
+  of steps are kept for all its values when they fit in `distributed.STAGE_CACHE_BYTES` (chi = 64: the steps that
+  depend on ONE cut -- 64 results of 33 MB each -- stay; the class that depends on both is 98 % of the executed
+  multiply-adds and runs in every slice).  False: every step in every slice.  `executed_macs` counts what RAN.
 
-  reuse_partials (default): the hamiltonian slice depends on i only and the state slice on j only, so most steps of
-  the path depend on ONE of the two indices (chi = 64: 40 % of a slice's multiply-adds on i, 59.6 % on j, 0.3 % on
-  both, `_mera_stages`).  Those partial contractions are computed once per i (kept: chi tensors of chi^4 elements)
-  and once per j (one chi^5 tensor at a time), and a slice (i, j) only runs the steps that depend on both -- the same
-  steps on the same values in the same order as the slice-by-slice run, so every slice result is the same tensor.
-  `executed_macs` counts what ran; `macs_per_slice` stays the cost of one slice contracted on its own."""
+  budget_seconds: stop after the first slice that ends beyond it (checked every 16 slices; the record says how many
+  slices ran).  check_every: every that many slices the same slice is also contracted alone in f32 on the same
+  half-rounded values (`checks`: [(i, j), half, f32]) -- a sample of the a-priori rounding check, outside the timing."""
   import time  # pylint: disable=import-outside-toplevel
-  from tensornetwork_amd import contractors  # pylint: disable=import-outside-toplevel
-  plan = _mera_slice_plan(chi, placement)
-  if reuse_partials:
-    return _mera_sliced_run_staged(be, chi, placement, plan, half_dtype, seed, budget_seconds, check_every)
-  fixed = {}
-
-  def gen(k, node, shape, i, j):
-    scale = float(np.prod(shape)) ** -0.25
-    if node is plan["hnode"]:
-      sd = seed + 1000 + i
-    elif node is plan["rnode"]:
-      sd = seed + 5000 + j
-    else:
-      sd = seed + 7 * k        # isometries / disentanglers: slice-independent
-    return be.device_random(shape, dtype=half_dtype, seed=sd, normal=True, a=0.0, b=scale)
-
-  acc = be.zeros((), dtype=np.float32)
-  done, checks, check_seconds = 0, [], 0.0
+  layer = MeraSlicedLayer(be, chi, placement, half_dtype, seed=seed)
+  plan, stage = layer.plan, layer.stage
+  slices = layer.all_slices()
+  checks, clock = [], {"check": 0.0}
   be.synchronize()
   t0 = time.perf_counter()
-  stop = False
-  for i in range(chi):
-    h_i = None
-    for j in range(chi):
-      def tensor_of(k, node, shape, i=i, j=j):
-        nonlocal h_i
-        if node is plan["hnode"]:
-          if h_i is None:
-            h_i = gen(k, node, shape, i, j)
-          return h_i
-        if node is plan["rnode"]:
-          return gen(k, node, shape, i, j)
-        if k not in fixed:
-          fixed[k] = gen(k, node, shape, i, j)
-        return fixed[k]
 
-      real = _mera_slice_network(be, plan, tensor_of)
-      res = contractors.contract_path(plan["path"], real).tensor
-      acc = be.addition(acc, be.reshape(be.cast(res, np.float32), ()))
-      done += 1
-      if check_every and (done - 1) % check_every == 0:
-        be.synchronize()
-        tc = time.perf_counter()
-        real32 = _mera_slice_network(be, plan, lambda k, node, shape: be.cast(tensor_of(k, node, shape), np.float32))
-        r32 = contractors.contract_path(plan["path"], real32).tensor
-        checks.append([[i, j], float(np.asarray(res, dtype=np.float64).reshape(-1)[0]),
-                       float(np.asarray(r32, dtype=np.float64).reshape(-1)[0])])
-        for n in real32:
-          n.tensor, n.edges = None, []
-        del real32, r32
-        be.synchronize()
-        check_seconds += time.perf_counter() - tc
-      for n in real:               # Node <-> Edge cycles: without this the 2 GB state slice waits for the cyclic GC
-        n.tensor, n.edges = None, []
-      del res, real
-      if budget_seconds is not None and done % 16 == 0:
-        be.synchronize()
-        if time.perf_counter() - t0 - check_seconds > budget_seconds:
-          stop = True
-          break
-    if stop:
-      break
+  def on_slice(done, idx, tensor):
+    if check_every and (done - 1) % check_every == 0:
+      be.synchronize()
+      tc = time.perf_counter()
+      r32 = layer.contract([idx], reuse=False, dtype=np.float32)
+      checks.append([[int(idx[0]), int(idx[1])], float(np.asarray(tensor, dtype=np.float64).reshape(-1)[0]),
+                     float(np.asarray(r32, dtype=np.float64).reshape(-1)[0])])
+      be.synchronize()
+      clock["check"] += time.perf_counter() - tc
+    if budget_seconds is not None and done % 16 == 0:
+      be.synchronize()
+      return time.perf_counter() - t0 - clock["check"] > budget_seconds
+    return False
+
+  stats = {}
+  acc = layer.contract(slices, reuse=reuse_partials, stats=stats, on_slice=on_slice)
   be.synchronize()
-  seconds = time.perf_counter() - t0 - check_seconds
+  seconds = time.perf_counter() - t0 - clock["check"]
+  done = int(stats["slices_done"])
+  name = {"-": "none", "0": "i", "1": "j", "0,1": "ij"}
+  macs = {name[",".join(str(k) for k in sorted(c)) or "-"]: m for c, m in stage.class_macs.items()}
+  runs = {name[k]: v for k, v in stats["stage_runs"].items()}
+  for k in ("none", "i", "j", "ij"):
+    macs.setdefault(k, 0.0)
+    runs.setdefault(k, 0)
+  executed = float(stats["executed_macs"])
   return {"placement": placement, "n_slices": chi * chi, "slices_done": done, "seconds": seconds,
           "energy_partial_sum": float(np.asarray(acc, dtype=np.float64).reshape(-1)[0]),
           "macs_per_slice": plan["flops"], "peak_elems_per_slice": plan["peak"], "depth": plan["depth"],
-          "tflops": 2.0 * plan["flops"] * done / max(seconds, 1e-30) / 1e12, "checks": checks}
-
-
-def _mera_sliced_run_staged(be, chi, placement, plan, half_dtype, seed, budget_seconds, check_every):
-  """mera_sliced_run with the partial contractions that depend on one slice index only computed once per value of
-  that index (see there)."""
-  import time  # pylint: disable=import-outside-toplevel
-  from tensornetwork_amd import contractors  # pylint: disable=import-outside-toplevel
-  st = _mera_stages(plan)
-  nodes = plan["nodes"]
-  n_in = len(nodes)
-  hk, rk = nodes.index(plan["hnode"]), nodes.index(plan["rnode"])
-  steps = {d: [(a, b, new) for a, b, new, dep, _ in st["steps"] if dep == d] for d in ("", "i", "j", "ij")}
-  needs = {}
-  for d, lst in steps.items():
-    produced = {new for _, _, new in lst}
-    needs[d] = sorted({x for a, b, _ in lst for x in (a, b)} - produced)
-  final_id = st["steps"][-1][2]
-  fixed = {}
-
-  def gen(k, i, j):
-    shape = st["shapes"][k]
-    scale = float(np.prod(shape)) ** -0.25
-    sd = seed + 1000 + i if k == hk else (seed + 5000 + j if k == rk else seed + 7 * k)
-    return be.device_random(shape, dtype=half_dtype, seed=sd, normal=True, a=0.0, b=scale)
-
-  def input_tensor(k, i, j):
-    if k in (hk, rk):
-      return gen(k, i, j)
-    if k not in fixed:
-      fixed[k] = gen(k, 0, 0)          # isometries / disentanglers: slice-independent
-    return fixed[k]
-
-  def operands(d, pools, i, j):
-    out = {}
-    for k in needs[d]:
-      if k < n_in:
-        out[k] = (input_tensor(k, i, j), st["labels"][k])
-      else:
-        out[k] = next(pool[k] for pool in pools if k in pool)
-    return out
-
-  lt = st["label_time"]
-  acc = be.zeros((), dtype=np.float32)
-  done, checks, check_seconds = 0, [], 0.0
-  be.synchronize()
-  t0 = time.perf_counter()
-  once = _run_stage(be, operands("", [], 0, 0), steps[""], lt) if steps[""] else {}
-  per_i = [_run_stage(be, operands("i", [once], i, 0), steps["i"], lt) if steps["i"] else {} for i in range(chi)]
-  be.synchronize()
-  seconds_once_per_i = time.perf_counter() - t0
-  j_done, stop = 0, False
-  for j in range(chi):
-    per_j = _run_stage(be, operands("j", [once], 0, j), steps["j"], lt) if steps["j"] else {}
-    j_done += 1
-    for i in range(chi):
-      left = _run_stage(be, operands("ij", [per_i[i], per_j, once], i, j), steps["ij"], lt)
-      res = left[final_id][0]
-      acc = be.addition(acc, be.reshape(be.cast(res, np.float32), ()))
-      done += 1
-      if check_every and (done - 1) % check_every == 0:
-        be.synchronize()
-        tc = time.perf_counter()
-        tensors32 = [be.cast(input_tensor(k, i, j), np.float32) for k in range(n_in)]
-        real32 = _mera_slice_network(be, plan, lambda k, node, shape: tensors32[k])      # pylint: disable=cell-var-from-loop
-        r32 = contractors.contract_path(plan["path"], real32).tensor
-        checks.append([[i, j], float(np.asarray(res, dtype=np.float64).reshape(-1)[0]),
-                       float(np.asarray(r32, dtype=np.float64).reshape(-1)[0])])
-        for nd in real32:
-          nd.tensor, nd.edges = None, []
-        del real32, r32, tensors32
-        be.synchronize()
-        check_seconds += time.perf_counter() - tc
-      del res, left
-      if budget_seconds is not None and done % 16 == 0:
-        be.synchronize()
-        if time.perf_counter() - t0 - check_seconds > budget_seconds:
-          stop = True
-          break
-    del per_j
-    if stop:
-      break
-  be.synchronize()
-  seconds = time.perf_counter() - t0 - check_seconds
-  macs = st["macs"]
-  executed = macs[""] + chi * macs["i"] + j_done * macs["j"] + done * macs["ij"]
-  return {"placement": placement, "n_slices": chi * chi, "slices_done": done, "seconds": seconds,
-          "energy_partial_sum": float(np.asarray(acc, dtype=np.float64).reshape(-1)[0]),
-          "macs_per_slice": plan["flops"], "peak_elems_per_slice": plan["peak"], "depth": plan["depth"],
-          "reuse_partials": True, "executed_macs": executed,
-          "seconds_by_phase": {"steps that depend on no index or on i (once per i)": seconds_once_per_i,
-                               "steps that depend on j (once per j) and on both (every slice)": seconds - seconds_once_per_i},
-          "macs_by_dependence": {"none": macs[""], "i": macs["i"], "j": macs["j"], "ij": macs["ij"]},
-          "stage_runs": {"none": 1 if steps[""] else 0, "i": chi, "j": j_done, "ij": done},
+          "reuse_partials": bool(reuse_partials), "executed_macs": executed,
+          "model_macs_with_reuse_all_slices": plan["executed_macs_with_reuse"],
+          "macs_by_dependence": macs, "stage_runs": runs,
+          "classes_kept_for_all_values": stats.get("classes_kept_for_all_values"),
+          "semantics": "slice_edge on both ends of each cut leg (the disentangler / isometry next to a cut leg is sliced "
+                       "with it); hamiltonian and state defined slice-wise, never materialised",
           "tflops": 2.0 * executed / max(seconds, 1e-30) / 1e12,
           "tflops_if_every_slice_ran_alone": 2.0 * plan["flops"] * done / max(seconds, 1e-30) / 1e12, "checks": checks}
 

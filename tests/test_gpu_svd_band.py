@@ -83,7 +83,7 @@ def test_band_svd_falls_back_loudly_where_it_cannot_be_accurate(hip):
   rng = np.random.default_rng(3)
   low = (rng.standard_normal((1024, 8)) @ rng.standard_normal((8, 1024))).astype(np.float32)
   u, s, vh, s_rest = hip.svd(hip.convert_to_tensor(low), 1, max_singular_values=16)
-  assert hip.last_svd_path == "jacobi" and hip.last_svd_band_status != 0
+  assert hip.last_svd_path.startswith("jacobi (band path reported status") and hip.last_svd_band_status != 0
   sr = np.linalg.svd(low.astype(np.float64), compute_uv=False)
   np.testing.assert_allclose(np.concatenate([np.asarray(s), np.asarray(s_rest)]), sr, atol=1e-5 * sr[0])
   # identical singular values: the kept vectors are only defined as a subspace
@@ -345,7 +345,7 @@ def test_band_svd_float64_other_call_shapes(hip):
   # a kept value below 1e-5 s_1 is outside the f64 band path's range: reported, Jacobi answers
   steep = graded64(1024, 1024, seed=5, rate=4.0)
   u, s, vh, s_rest = hip.svd(hip.convert_to_tensor(steep), 1, max_singular_values=128)      # s_128 = 2^-32 s_1
-  assert hip.last_svd_path == "jacobi" and hip.last_svd_band_status & 16
+  assert hip.last_svd_path.startswith("jacobi") and hip.last_svd_band_status & 16
   np.testing.assert_allclose(np.asarray(s), np.linalg.svd(steep, compute_uv=False)[:128], rtol=1e-7, atol=1e-14)
 
 
@@ -373,3 +373,41 @@ def test_qr_fast_path_is_not_taken_inside_a_graph_capture(hip):
   np.testing.assert_allclose(np.abs(np.asarray(r)), np.abs(ref_r), atol=2e-4)
   assert np.max(np.abs(np.asarray(q).T @ np.asarray(q) - np.eye(256))) < 1e-4
   del ref_q
+
+
+def test_band_svd_backoff_is_an_inspectable_resettable_per_backend_policy(hip):
+  """which path a call takes after the band path has reported on a shape is a documented policy of
+  the backend OBJECT: visible (`svd_band_policy`), resettable, switchable, and named in `last_svd_path` -- never a
+  silent function of the process's history.  Both paths obey the same truncation rule."""
+  rng = np.random.default_rng(8)
+  low = (rng.standard_normal((1024, 8)) @ rng.standard_normal((8, 1024))).astype(np.float32)
+  sr = np.linalg.svd(low.astype(np.float64), compute_uv=False)
+  dev = hip.convert_to_tensor(low)
+  hip.reset_svd_band_policy()
+  assert hip.svd_band_policy()["backoff"] == {} and hip.svd_band_policy()["status_read_early_for"] == []
+  paths = []
+  for _ in range(4):
+    _, s, _, _ = hip.svd(dev, 1, max_singular_values=16)
+    paths.append(hip.last_svd_path)
+    np.testing.assert_allclose(np.asarray(s)[:8], sr[:8], rtol=1e-4)
+  # first two calls try the band path and report; from the second consecutive report on the shape is skipped
+  assert paths[0].startswith("jacobi (band path reported status") and paths[1].startswith("jacobi (band path reported status")
+  assert paths[2].startswith("jacobi (band path skipped") and paths[3].startswith("jacobi (band path skipped")
+  state = hip.svd_band_policy()
+  assert len(state["backoff"]) == 1 and list(state["backoff"].values())[0]["consecutive_reports"] == 2
+  # reset: the next call tries the band path again; with the policy switched off it always tries
+  hip.reset_svd_band_policy()
+  hip.svd(dev, 1, max_singular_values=16)
+  assert hip.last_svd_path.startswith("jacobi (band path reported status")
+  hip.svd_band_backoff = False
+  try:
+    for _ in range(3):
+      hip.svd(dev, 1, max_singular_values=16)
+      assert hip.last_svd_path.startswith("jacobi (band path reported status")
+  finally:
+    hip.svd_band_backoff = True
+    hip.reset_svd_band_policy()
+  # a well-conditioned matrix of the same shape is untouched by any of this
+  good = rng.standard_normal((1024, 1024)).astype(np.float32)
+  hip.svd(hip.convert_to_tensor(good), 1, max_singular_values=16)
+  assert hip.last_svd_path == "band"

@@ -404,3 +404,106 @@ def test_large_blocks_of_dead_nodes_return_to_the_pool(hip):
     ta.configure_gc(freeze=saved["freeze"], collect_before_large_alloc=saved["collect"])
   finally:
     gc.enable()
+
+
+# ---- round 5: the scheduling modes of contract_sliced and the sliced MERA layer, on the GPU -------------------------
+@pytest.mark.parametrize("case", ["16 nodes D=4, two cuts", "16 nodes D=3, three cuts", "open legs, bf16"])
+def test_contract_sliced_reuse_equals_slice_by_slice_on_gpu(hip, case):
+  """`contract_sliced(reuse=True)` (every step once per distinct value of the cuts it depends on) against
+  `reuse=False` (every step in every slice): the SAME slice partials one by one -- same steps, same order, same
+  operands, so the f32 partials agree to rounding of the reordered f32 additions only and the bf16 ones exactly --
+  and both against the oracle's greedy contraction of the unsliced network."""
+  from tensornetwork_amd import distributed, workloads as wl
+  rng = np.random.default_rng(11)
+  if case.startswith("open"):
+    # a ring of 6 rank-3 bf16 tensors with the third legs open: the result is a rank-6 tensor
+    raw = [orc.round_bf16(rng.standard_normal((6, 6, 4)) * 6 ** -0.5) for _ in range(6)]
+    def build(be, conv):
+      nodes = [network.Node(conv(t), backend=be) for t in raw]
+      for k in range(6):
+        network.connect(nodes[k][1], nodes[(k + 1) % 6][0])
+      return nodes, [n[2] for n in nodes]
+    nodes, order = build(hip, hip.to_bfloat16)
+    cuts = [nodes[0][1], nodes[3][1]]
+    ref_nodes, ref_order = build(orc.OracleBackend(), lambda t: t.astype(np.float64))
+    ref = np.asarray(contractors.greedy(ref_nodes, output_edge_order=ref_order).tensor)
+    tol, exact = 3e-2, True
+  else:
+    n, D, min_slices = (16, 4, 16) if "D=4" in case else (16, 3, 27)
+    tensors = [(rng.standard_normal((D, D, D)) * D ** -0.75).astype(np.float32) for _ in range(n)]
+    ref = np.asarray(contractors.greedy(wl.random_regular_network(orc.OracleBackend(), n=n, D=D,
+                                                                  tensors=[t.astype(np.float64) for t in tensors])).tensor)
+    nodes = wl.random_regular_network(hip, n=n, D=D, tensors=tensors)
+    cuts = distributed.choose_cut_edges(nodes, min_slices=min_slices)
+    order = None
+    assert len(cuts) == (2 if "two" in case else 3)
+    tol, exact = 2e-4, False
+  p_reuse, p_alone, s_reuse, s_alone = [], [], {}, {}
+  out_r = np.asarray(distributed.contract_sliced(nodes, cuts, output_edge_order=order, reuse=True, partials_out=p_reuse,
+                                                 stats=s_reuse), dtype=np.float64)
+  out_a = np.asarray(distributed.contract_sliced(nodes, cuts, output_edge_order=order, reuse=False, partials_out=p_alone,
+                                                 stats=s_alone), dtype=np.float64)
+  assert s_reuse["mode"] == "staged" and s_alone["mode"] == "slice by slice"
+  assert len(p_reuse) == len(p_alone) == int(np.prod([e.dimension for e in cuts]))
+  # the staged run visits the slices in the order of its loop nest; compare as multisets keyed by value
+  key = lambda arr: tuple(np.round(np.asarray(arr, dtype=np.float64).reshape(-1)[:4], 10))
+  a_sorted, r_sorted = sorted(p_alone, key=key), sorted(p_reuse, key=key)
+  scale = max(float(np.max(np.abs(x))) for x in p_alone) + 1e-30
+  for x, y in zip(a_sorted, r_sorted):
+    if exact:
+      np.testing.assert_array_equal(x, y)
+    else:
+      np.testing.assert_allclose(x, y, rtol=0, atol=2e-6 * scale)
+  assert s_reuse["executed_macs"] <= s_alone["executed_macs"]
+  np.testing.assert_allclose(out_r, out_a, rtol=tol, atol=tol * float(np.max(np.abs(ref))))
+  np.testing.assert_allclose(out_r.reshape(ref.shape), ref, rtol=tol, atol=tol * float(np.max(np.abs(ref))))
+
+
+def test_contract_sliced_default_mode_is_the_same_on_every_rank_on_gpu(hip):
+  """with `reuse=None` every rank must take the same decision, whatever its own block looks like --
+  here 9 slices on 4, 5, 7 and 8 emulated ranks (short and empty last blocks), each rank's share contracted on this
+  GPU and the shares added: the sum is the one-rank result."""
+  from tensornetwork_amd import distributed, workloads as wl
+  rng = np.random.default_rng(3)
+  tensors = [(rng.standard_normal((3, 3, 3)) * 3 ** -0.75).astype(np.float32) for _ in range(12)]
+  nodes = wl.random_regular_network(hip, n=12, D=3, tensors=tensors)
+  cuts = distributed.choose_cut_edges(nodes, min_slices=9)
+  one = float(np.asarray(distributed.contract_sliced(nodes, cuts)))
+
+  class Rank(distributed.LocalComm):
+    def __init__(self, rank, world):
+      self.rank, self.world = rank, world
+
+  for world in (4, 5, 7, 8):
+    modes, total = set(), 0.0
+    for r in range(world):
+      st = {}
+      total += float(np.asarray(distributed.contract_sliced(nodes, cuts, comm=Rank(r, world), stats=st)))
+      modes.add(st["mode"])
+    assert len(modes) == 1, (world, modes)
+    assert abs(total - one) <= 1e-4 * max(abs(one), 1e-3), (world, total, one)
+
+
+@pytest.mark.parametrize("placement", ["left", "right"])
+def test_mera_sliced_layer_on_gpu(hip, placement):
+  """configs[4] semantics at chi = 8: the 64 slices `slice_edge(cut_h, i); slice_edge(cut_rho, j)` leave of ONE layer
+  (both nodes of each cut edge sliced: reference network_components.py:1670-1680), contracted with reuse and slice by
+  slice on the GPU, against the DENSE layer energy of the same (materialised) tensors on the oracle backend."""
+  from tensornetwork_amd import workloads as wl
+  chi = 8
+  layer = wl.MeraSlicedLayer(hip, chi, placement, np.float32)
+  ham, rho, iso, dis = layer.host_tensors()
+  dense = float(np.asarray(contractors.branch(wl.mera_layer_network(orc.OracleBackend(), ham, rho, iso, dis, placement),
+                                              nbranch=2).tensor))
+  staged = wl.mera_sliced_run(hip, chi, placement, np.float32, check_every=16)
+  alone = wl.mera_sliced_run(hip, chi, placement, np.float32, reuse_partials=False)
+  assert staged["slices_done"] == alone["slices_done"] == chi * chi
+  assert abs(staged["energy_partial_sum"] - dense) <= 1e-4 * max(1.0, abs(dense))
+  assert abs(alone["energy_partial_sum"] - dense) <= 1e-4 * max(1.0, abs(dense))
+  assert staged["stage_runs"] == {"none": 1, "i": chi, "j": chi, "ij": chi * chi}
+  assert staged["executed_macs"] == staged["model_macs_with_reuse_all_slices"] < alone["executed_macs"]
+  assert staged["checks"] and all(abs(c[1] - c[2]) <= 1e-5 * max(1.0, abs(c[2])) for c in staged["checks"])
+  # bf16: reuse and slice-by-slice run the same kernels on the same operands
+  h16 = wl.mera_sliced_run(hip, chi, placement, ta.bfloat16)
+  a16 = wl.mera_sliced_run(hip, chi, placement, ta.bfloat16, reuse_partials=False)
+  assert h16["energy_partial_sum"] == a16["energy_partial_sum"]
