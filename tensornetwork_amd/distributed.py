@@ -349,9 +349,28 @@ def _itemsize(t) -> int:
     return 4
 
 
-# results of a class are kept for ALL its value tuples when they fit in this many bytes (a 288 GB part: the chi = 64
-# MERA placement keeps 64 partial results of 33 MB each per cut)
+# Results of a class of steps whose value tuple comes BACK after others have intervened (a class keyed on a cut that
+# is not the slowest of the loop nest) are kept for all its values when they fit the cache budget: 60 % of the HBM that
+# is free when the rank's slice loop starts on a hip backend (the chi = 64 MERA placement keeps 64 results of 2 GB --
+# 137 GB -- for the fast cut; recomputing them instead cost 48 % more executed work: profiles/r05_bench_trip3.json),
+# STAGE_CACHE_BYTES on any other backend.  A class whose value tuples are visited in one contiguous run each keeps
+# the result in use only.
 STAGE_CACHE_BYTES = 16 << 30
+
+
+def _cache_budget(be) -> int:
+  lib = getattr(be, "lib", None)
+  try:
+    import ctypes  # pylint: disable=import-outside-toplevel
+    name = ctypes.create_string_buffer(64)
+    cus, hbm = ctypes.c_int(0), ctypes.c_int64(0)
+    in_use, cached, peak = ctypes.c_int64(0), ctypes.c_int64(0), ctypes.c_int64(0)
+    if lib.tnh_device_info(name, 64, ctypes.byref(cus), ctypes.byref(hbm)) == 0 and \
+        lib.tnh_mem_stats(ctypes.byref(in_use), ctypes.byref(cached), ctypes.byref(peak)) == 0 and hbm.value > 0:
+      return max(int(0.6 * (hbm.value - in_use.value)), STAGE_CACHE_BYTES // 16)
+  except Exception:  # pylint: disable=broad-except
+    pass
+  return STAGE_CACHE_BYTES
 
 
 def _contract_slices_staged(be, nodes, plan: _StagePlan, slices, output_edge_order, partials_out, stats,
@@ -367,7 +386,15 @@ def _contract_slices_staged(be, nodes, plan: _StagePlan, slices, output_edge_ord
   tensors of the chi = 64 MERA layer).  `on_slice(n_done, idx, tensor)`: called after every slice with its partial
   (time budgets, sampled checks); returning True stops the loop.  `reuse=False`: nothing is kept from one slice to
   the next -- every step runs in every slice (the slice-by-slice baseline on the same machinery)."""
-  budget = STAGE_CACHE_BYTES if cache_bytes is None else int(cache_bytes)
+  budget = {"left": _cache_budget(be) if cache_bytes is None else int(cache_bytes)}
+  slices = list(slices)
+  # which classes see a value tuple again after another one intervened (only those need more than the result in use)
+  revisited, distinct = {}, {}
+  for c in plan.classes:
+    keys = [tuple(idx[k] for k in sorted(c)) for idx in slices]
+    runs_of_keys = sum(1 for t in range(len(keys)) if t == 0 or keys[t] != keys[t - 1])
+    distinct[c] = len(set(keys))
+    revisited[c] = runs_of_keys > distinct[c]
   n = plan.n
   cache: Dict[frozenset, Dict[tuple, dict]] = {c: {} for c in plan.classes}
   keep_all: Dict[frozenset, bool] = {}
@@ -405,9 +432,11 @@ def _contract_slices_staged(be, nodes, plan: _StagePlan, slices, output_edge_ord
     out = contractors.contract_labelled(be, operands, plan.class_steps[c], plan.label_time)
     runs[c] += 1
     if c not in keep_all:
-      count = int(np.prod([plan.dims[k] for k in c])) if c else 1
       nbytes = sum(int(np.prod(be.shape_tuple(t))) * _itemsize(t) for t, _ in out.values())
-      keep_all[c] = count * nbytes <= budget
+      need = distinct[c] * nbytes
+      keep_all[c] = bool(reuse and revisited[c] and need <= budget["left"])
+      if keep_all[c]:
+        budget["left"] -= need
     if not keep_all[c]:
       cache[c].clear()
     cache[c][key] = out
@@ -438,6 +467,7 @@ def _contract_slices_staged(be, nodes, plan: _StagePlan, slices, output_edge_ord
     stats["executed_macs"] = sum(plan.class_macs[c] * r for c, r in runs.items())
     stats["slices_done"] = done
     stats["classes_kept_for_all_values"] = {",".join(str(k) for k in sorted(c)) or "-": bool(v) for c, v in keep_all.items()}
+    stats["classes_revisited"] = {",".join(str(k) for k in sorted(c)) or "-": bool(v) for c, v in revisited.items()}
   return total, narrow
 
 

@@ -537,7 +537,7 @@ def test_band_svd_host_logic_falls_back_loudly():
     for trip, n_calls in ((0, 2), (1, 1)):
       be.lib.calls.clear()
       u, s, vh, rest = be.svd(be.convert_to_tensor(low), 1, max_singular_values=8)
-      assert be.last_svd_path == "jacobi" and be.last_svd_band_status & 1, trip
+      assert be.last_svd_path.startswith("jacobi") and be.last_svd_band_status & 1, trip
       assert len([c for c in be.lib.calls if c[0].startswith("svd_band")]) == n_calls, (trip, be.lib.calls)
       sr = np.linalg.svd(low.astype(np.float64), compute_uv=False)
       np.testing.assert_allclose(np.concatenate([np.asarray(s), np.asarray(rest)]), sr, atol=1e-5 * sr[0])
@@ -547,7 +547,7 @@ def test_band_svd_host_logic_falls_back_loudly():
     for _ in range(4):
       be.lib.calls.clear()
       be.svd(be.convert_to_tensor(low), 1, max_singular_values=8)
-      assert be.last_svd_path == "jacobi" and not [c for c in be.lib.calls if c[0].startswith("svd_band")]
+      assert be.last_svd_path.startswith("jacobi") and not [c for c in be.lib.calls if c[0].startswith("svd_band")]
     be.lib.calls.clear()
     be.svd(be.convert_to_tensor(low), 1, max_singular_values=8)
     assert len([c for c in be.lib.calls if c[0].startswith("svd_band")]) == 1      # tried again (and reported again)
@@ -555,7 +555,7 @@ def test_band_svd_host_logic_falls_back_loudly():
     be._svd_band_failed = set()      # pylint: disable=protected-access
     be._svd_band_backoff = {}        # pylint: disable=protected-access
     u, s, vh, rest = be.svd(be.convert_to_tensor(graded), 1)
-    assert be.last_svd_path == "jacobi" and s.shape == (512,) and rest.shape == (0,)
+    assert be.last_svd_path.startswith("jacobi") and s.shape == (512,) and rest.shape == (0,)
     # ... while the same matrix truncated above the floor stays on the band path
     be._svd_band_backoff = {}        # pylint: disable=protected-access
     u, s, vh, rest = be.svd(be.convert_to_tensor(graded), 1, max_singular_values=64)
