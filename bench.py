@@ -313,12 +313,33 @@ def cpu_baseline(layout):
     threads = os.cpu_count() or 1
   axes = [[2, 3], [0, 1]] if layout == "L0" else [[1, 3], [2, 0]]
   rng = np.random.default_rng(2)
+  # The reference itself, when the builder shipped it beside the repo for this call (TN_REFERENCE_DIR, the scratch
+  # copy of tools/reference_dropin/gpurun_with_reference.sh; the driver's box has none): its own contract_between on
+  # its own NumPy backend -> kind "reference".  Otherwise the oracle -> kind "port".
+  tn_ref = None
+  ref_dir = os.environ.get("TN_REFERENCE_DIR")
+  if ref_dir and os.path.isdir(os.path.join(ref_dir, "tensornetwork")):
+    try:
+      # inert stubs for what the image lacks (h5py, graphviz, jax / tensorflow; opt_einsum -> our path finder): the
+      # same ones the golden-fixture generators and the drop-in harness use
+      for stub in ("tests/golden/_stubs", "tools/reference_dropin/_stubs"):
+        sys.path.insert(0, os.path.join(ROOT, stub))
+      sys.path.insert(0, ref_dir)
+      import tensornetwork as tn_ref  # pylint: disable=import-outside-toplevel,import-error
+    except Exception:  # pylint: disable=broad-except
+      tn_ref = None
 
   def run(D):
     A = orc.round_bf16(rng.standard_normal((D,) * 4) / D)
     B = orc.round_bf16(rng.standard_normal((D,) * 4) / D)
     t0 = time.perf_counter()
-    orc.tensordot(A, B, axes)
+    if tn_ref is not None:
+      a, b = tn_ref.Node(A, backend="numpy"), tn_ref.Node(B, backend="numpy")
+      for x, y in zip(*axes):
+        a[x] ^ b[y]  # pylint: disable=pointless-statement
+      tn_ref.contract_between(a, b)
+    else:
+      orc.tensordot(A, B, axes)
     return time.perf_counter() - t0
 
   run(32)  # warm-up (BLAS thread pool)
@@ -331,6 +352,11 @@ def cpu_baseline(layout):
       D = cand
   t = run(D) if D != 64 else t64
   flops = 2.0 * float(D)**6
+  if tn_ref is not None:
+    return {"value": flops / t / 1e12, "unit": "TFLOP/s", "cores": int(threads), "kind": "reference",
+            "sample": f"google/TensorNetwork {getattr(tn_ref, '__version__', '?')} itself (tn.contract_between on its NumPy "
+                      f"backend, shipped beside the repo for this call), layout {layout}, D={D} (GEMM {D*D}^3), fp32 on "
+                      f"bf16-rounded inputs, {t:.2f} s; D=64 probe {flops64 / t64 / 1e12:.3f} TFLOP/s"}
   return {"value": flops / t / 1e12, "unit": "TFLOP/s", "cores": int(threads), "kind": "port",
           "sample": f"oracle tensordot (NumPy restatement of the reference's numpy_backend.tensordot; the reference "
                     f"itself is not installed on this box), layout {layout}, D={D} (GEMM {D*D}^3), fp32 on "

@@ -1674,34 +1674,47 @@ class HipBackend(BackendBase):
     eye = self.eye(keep, dtype=cnp)
     gram = self._tensordot_impl(self.conj(zue), zue, [[0], [0]], None, None)[0]           # keep x keep
     dev = float(np.asarray(self.norm(self._binary(_lib.OP_SUB, gram, eye))).real)
-    if np.isfinite(dev) and dev < 0.1:
+    if np.isfinite(dev) and dev < 0.1 and not self.svd_complex_force_cluster_path:
       coef_dev = self._binary(_lib.OP_SUB, self._binary(_lib.OP_MUL, eye, 1.5), self._binary(_lib.OP_MUL, gram, 0.5))
       u = self._tensordot_impl(zue, coef_dev, [[1], [0]], None, None)[0]                  # m x keep
       v = self._tensordot_impl(zve, coef_dev, [[1], [0]], None, None)[0]                  # n x keep
     else:
-      # degenerate complex values: greedy Gram-Schmidt over all 2k candidates on the (2k x 2k) Gram matrix (host
-      # arithmetic on a small matrix; the rare path)
+      # degenerate complex values (or `svd_complex_force_cluster_path`, which the GPU tests set to cover this branch):
+      # greedy Gram-Schmidt over all 2k candidates on the (2k x 2k) Gram matrix -- host arithmetic on a small matrix
       g = np.asarray(self._tensordot_impl(self.conj(zu), zu, [[0], [0]], None, None)[0]).astype(np.complex128)
-      basis = []                                               # coefficient vectors c with (Zu c) orthonormal
-      for j in range(k2):
-        c = np.zeros(k2, dtype=np.complex128)
-        c[j] = 1.0
-        for bvec in basis:
-          c = c - bvec * (bvec.conj() @ g @ c)
-        nrm2 = float(np.real(c.conj() @ g @ c))
-        if nrm2 > 0.25:
-          basis.append(c / np.sqrt(nrm2))
-          if len(basis) == keep:
-            break
-      if len(basis) < keep:
+      basis = self._independent_directions(g, keep)
+      if basis is None:
         return None
-      cdev = self.convert_to_tensor(np.stack(basis, axis=1).astype(cnp))
+      cdev = self.convert_to_tensor(basis.astype(cnp))
       u = self._tensordot_impl(zu, cdev, [[1], [0]], None, None)[0]               # m x keep
       v = self._tensordot_impl(zv, cdev, [[1], [0]], None, None)[0]               # n x keep
     vh = self.conj(self.transpose(v, (1, 0)))
     s_dev, s_rest = s_kept_dev, s_rest_dev
     self.last_svd_path = "band (complex via the real embedding)"
     return u, s_dev, vh, s_rest
+
+  svd_complex_force_cluster_path = False     # tests: take the degenerate-value branch of _svd_complex_band always
+
+  @staticmethod
+  def _independent_directions(gram, keep):
+    """`keep` coefficient vectors c (columns of the result) such that the combinations Z c of the candidates Z with
+    Gram matrix `gram` = Z^H Z are orthonormal: greedy Gram-Schmidt in the Gram metric over the candidates in their
+    order, a candidate whose remainder has squared norm <= 1/4 is dependent on the earlier ones and skipped.  None
+    when fewer than `keep` independent directions exist."""
+    g = np.asarray(gram, dtype=np.complex128)
+    n = g.shape[0]
+    basis = []
+    for j in range(n):
+      c = np.zeros(n, dtype=np.complex128)
+      c[j] = 1.0
+      for bvec in basis:
+        c = c - bvec * (bvec.conj() @ g @ c)
+      nrm2 = float(np.real(c.conj() @ g @ c))
+      if nrm2 > 0.25:
+        basis.append(c / np.sqrt(nrm2))
+        if len(basis) == keep:
+          return np.stack(basis, axis=1)
+    return None
 
   def _qr_matrix(self, mat):
     """Thin Householder QR of a device matrix (f32 / f64) -> (q (m, k), r (k, n))."""

@@ -411,3 +411,35 @@ def test_band_svd_backoff_is_an_inspectable_resettable_per_backend_policy(hip):
   good = rng.standard_normal((1024, 1024)).astype(np.float32)
   hip.svd(hip.convert_to_tensor(good), 1, max_singular_values=16)
   assert hip.last_svd_path == "band"
+
+
+@pytest.mark.parametrize("dtype", [np.complex64, np.complex128])
+def test_complex_svd_cluster_branch_on_gpu(hip, dtype):
+  """the branch of the complex band path that handles degenerate complex values (greedy
+  Gram-Schmidt over all 2k real-embedding candidates on their Gram matrix) had never run on the GPU.  Forced here
+  on an ordinary matrix -- it must give the same decomposition as the Newton-Schulz branch and as LAPACK."""
+  rng = np.random.default_rng(21)
+  m, n, k = 768, 640, 24
+  a = (rng.standard_normal((m, n)) + 1j * rng.standard_normal((m, n))).astype(dtype)
+  dev = hip.convert_to_tensor(a)
+  u0, s0, vh0, _ = hip.svd(dev, 1, max_singular_values=k)
+  assert "complex via the real embedding" in hip.last_svd_path, (hip.last_svd_path, hip.last_svd_band_status)
+  hip.svd_complex_force_cluster_path = True
+  try:
+    u, s, vh, s_rest = hip.svd(dev, 1, max_singular_values=k)
+    assert "complex via the real embedding" in hip.last_svd_path
+  finally:
+    hip.svd_complex_force_cluster_path = False
+  a128 = a.astype(np.complex128)
+  sr = np.linalg.svd(a128, compute_uv=False)
+  tol = 1e-5 if dtype == np.complex64 else 1e-12
+  s_all = np.concatenate([np.asarray(s).real, np.asarray(s_rest).real]).astype(np.float64)
+  assert np.max(np.abs(s_all[:k] - sr[:k])) <= tol * sr[0]
+  np.testing.assert_array_equal(np.asarray(s), np.asarray(s0))
+  uu, vv = np.asarray(u).astype(np.complex128), np.asarray(vh).astype(np.complex128)
+  assert np.max(np.abs(uu.conj().T @ uu - np.eye(k))) <= 20 * tol
+  assert np.max(np.abs(vv @ vv.conj().T - np.eye(k))) <= 20 * tol
+  assert np.max(np.linalg.norm(a128 @ vv.conj().T - uu * s_all[:k], axis=0)) <= 20 * tol * sr[0]
+  # same subspaces as the Newton-Schulz branch (the vectors themselves differ by phases)
+  p0 = np.asarray(u0).astype(np.complex128)
+  assert np.linalg.norm(uu @ (uu.conj().T @ p0) - p0) <= 100 * tol * np.sqrt(k)

@@ -953,3 +953,50 @@ def test_bench_sliced_network_leg_on_the_emulated_backend(D, min_slices, staged)
   assert abs(rec["tflops"] - rec["flops_total"] / rec["seconds"] / 1e12) <= 1e-9 * rec["tflops"]
   line = json.loads(bench.compact_line({"metric": "m", "value": 1.0, "sliced_network": rec}, "bench_detail.json"))
   assert line["sliced_network"]["mode"] == rec["mode"] and line["sliced_network"]["n_slices"] == rec["n_slices"]
+
+
+def test_independent_directions_of_the_complex_svd_cluster_branch():
+  """`HipBackend._independent_directions` (the host arithmetic of the complex band SVD's degenerate-value branch): from
+  2k candidates that span only k complex directions -- every direction present twice, once rotated by i as in the real
+  embedding -- it picks k coefficient vectors whose combinations are orthonormal; fewer directions than asked: None."""
+  from tensornetwork_amd.hip_backend import HipBackend  # pylint: disable=import-outside-toplevel
+  rng = np.random.default_rng(4)
+  k, m = 6, 40
+  q, _ = np.linalg.qr(rng.standard_normal((m, k)) + 1j * rng.standard_normal((m, k)))
+  z = np.empty((m, 2 * k), dtype=np.complex128)
+  z[:, 0::2], z[:, 1::2] = q, 1j * q                       # the pair of real vectors of one complex line
+  z = z @ np.kron(np.eye(k), np.array([[1.0, 0.3], [0.0, 1.0]]))      # and not even orthogonal inside a pair
+  c = HipBackend._independent_directions(z.conj().T @ z, k)      # pylint: disable=protected-access
+  assert c is not None and c.shape == (2 * k, k)
+  y = z @ c
+  np.testing.assert_allclose(y.conj().T @ y, np.eye(k), atol=1e-12)
+  np.testing.assert_allclose(q @ (q.conj().T @ y), y, atol=1e-12)      # inside the span of the k directions
+  assert HipBackend._independent_directions(z.conj().T @ z, k + 1) is None      # pylint: disable=protected-access
+
+
+@pytest.mark.parametrize("dtype", [np.complex64, np.complex128])
+def test_complex_band_svd_cluster_branch_gives_the_same_decomposition(dtype):
+  """The degenerate-value branch of `_svd_complex_band`, forced on an ordinary matrix (emulated C ABI): same values,
+  orthonormal vectors, A V = U S -- the host logic the GPU test `test_complex_svd_cluster_branch_on_gpu` runs on the
+  device."""
+  rng = np.random.default_rng(23)
+  m, n, k = 300, 280, 12
+  a = (rng.standard_normal((m, n)) + 1j * rng.standard_normal((m, n))).astype(dtype)
+  with emulated_backend() as be:
+    be.lib.band_svd = True
+    dev = be.convert_to_tensor(a)
+    s0 = np.asarray(be.svd(dev, 1, max_singular_values=k)[1])
+    assert be.last_svd_path.startswith("band"), be.last_svd_path
+    be.svd_complex_force_cluster_path = True
+    try:
+      u, s, vh, _ = (np.asarray(x) for x in be.svd(dev, 1, max_singular_values=k))
+      assert be.last_svd_path.startswith("band"), be.last_svd_path
+    finally:
+      be.svd_complex_force_cluster_path = False
+  tol = 1e-5 if dtype == np.complex64 else 1e-11
+  np.testing.assert_array_equal(s, s0)
+  a128 = a.astype(np.complex128)
+  sr = np.linalg.svd(a128, compute_uv=False)
+  np.testing.assert_allclose(np.real(s), sr[:k], atol=tol * sr[0])
+  np.testing.assert_allclose(u.conj().T @ u, np.eye(k), atol=20 * tol)
+  np.testing.assert_allclose(a128 @ vh.conj().T, u * np.real(s), atol=40 * tol * sr[0])
