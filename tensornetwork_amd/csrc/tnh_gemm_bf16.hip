@@ -245,6 +245,23 @@ struct KWalk {
       off += wrap;
     }
   }
+  // KW = 1 (inner contraction runs that are multiples of 64): the same walk in whole K-tiles
+  __device__ __forceinline__ void init_tiles(const OpView& v, int tile) {
+    hpr = v.tpi >> 1;
+    step = 64 * v.sk0;
+    wrap = v.sk1 - (int64_t)hpr * step;
+    in = tile % hpr;
+    off = (int64_t)(tile / hpr) * v.sk1 + (int64_t)in * step;
+  }
+  __device__ __forceinline__ void next_tile(int64_t& h0) {
+    h0 = off;
+    ++in;
+    off += step;
+    if (in == hpr) {
+      in = 0;
+      off += wrap;
+    }
+  }
   // offsets of the two halves of the next K-tile
   __device__ __forceinline__ void next(int64_t& h0, int64_t& h1) {
     h0 = off;
@@ -253,6 +270,37 @@ struct KWalk {
     advance_half();
   }
 };
+
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+
+// ---- helpers of the lean main loop (SCHED = 3) ---------------------------------------------------------------------
+// One 1-KiB LDS-DMA piece in the SADDR form: lane address = 64-bit wave-uniform base (SGPR pair) + 32-bit per-lane
+// byte offset -- no 64-bit VALU add per piece; M0 = LDS destination = wave-uniform base + an immediate, written by
+// ONE scalar add inside the asm block (M0 is not saved / restored: the compiler sets M0 itself right before each of
+// its own uses and nothing in these kernels keeps a value in it).
+template <int IMM>
+__device__ __forceinline__ void glds16s(unsigned voff, const void* sbase, unsigned lds_base) {
+  asm volatile(
+      "s_add_u32 m0, %1, %2\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %0, %3"
+      :
+      : "v"(voff), "s"(lds_base), "n"(IMM), "s"(sbase)
+      : "memory", "scc");       // s_add_u32 writes SCC
+}
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
+// A fragment read the compiler does not track (no s_waitcnt lgkmcnt of its own in front of every MFMA: the load
+// segments end with our lgkmcnt(0) anyway)
+template <int OFF>
+__device__ __forceinline__ void lds_frag(uint4& dst, unsigned addr) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(*(u32x4_t*)&dst) : "v"(addr), "n"(OFF));
+}
 
 // SCHED = 1 (round 5, A/B knob ":p7"): ONE 64-MFMA cluster per K-tile -- every fragment of the K-tile (24 ds_read_b128
 // = 96 registers) is read in one load segment, two barriers per K-tile instead of four.  LDS: A double-buffered
@@ -268,11 +316,31 @@ struct KWalk {
 //   distances: A two intervals (~2 x 1100 cycles), B three to four.
 // (The first form of this schedule -- whole buffers restaged two intervals ahead, group 1 issuing at the head of its
 // MFMA cluster -- lost 8-20 % to the default: profiles/r05_gemm_variants.md.)
+// KW (view kernels with K-contiguous operands; round 5): how the contraction index walks through memory.
+//   0  general: inner runs that are multiples of 32 -- the walk advances in HALF K-tiles and every lane picks the half
+//      its chunk belongs to (62 more instructions per K-tile and wave than the plain NT loop);
+//   1  inner runs that are multiples of 64 on both operands: the walk advances in whole K-tiles, lanes carry their
+//      full chunk offset;
+//   2  one contiguous run on both operands: offset = K-tile x 64, the plain NT loop.  Measured on the headline shape
+//      (65536^3, the same buffers): the general walk 1422-1425 TFLOP/s, the plain loop 1489-1496
+//      (profiles/r05_gemm_headline_plain_vs_view.jsonl) -- which is why the view launcher picks the cheapest walk
+//      the operands allow.  Same MFMA sequence in all three: bit-identical results.
 template <bool IS_BF16, bool OUT_F32, bool TWO, bool M32 = false, bool VIEW = false, bool A_KM = false,
-          bool B_KN = false, int SCHED = 0>
+          bool B_KN = false, int SCHED = 0, int KW = 0>
 __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(NtArgs p) {
+  static_assert(KW == 0 || (VIEW && !A_KM && !B_KN), "the tile-granular K walks are for K-contiguous view operands");
   static_assert(!VIEW || (TWO && !M32), "view kernels use the 2-phase 16x16x32 schedule");
   static_assert(SCHED == 0 || (TWO && !M32 && !A_KM && !B_KN), "the round-5 schedules: 16x16x32, K-contiguous operands");
+  // SCHED = 3: the default two-cluster schedule with a LEAN main loop -- the same fragment reads, LDS-DMA pieces, MFMAs
+  // and barriers, and about 50 fewer bookkeeping instructions per K-tile and wave (205 -> ~150): SADDR-form LDS-DMA
+  // (one 64-bit scalar add per operand and K-tile instead of a 64-bit VALU add per piece; M0 written by one scalar add,
+  // not saved / restored), fragment reads as untracked asm (no compiler lgkmcnt waits between the MFMAs), one s_setprio
+  // pair per cluster, the K loop unrolled by two so that both LDS buffers have static addresses (no per-K-tile VALU).
+  // Why: on this kernel every instruction the load segment issues costs ~0.06 % (the 62 extra instructions of the
+  // general view walk cost 4.3 %: profiles/r05_gemm_headline_plain_vs_view.jsonl).  Needs single-level rows (plain NT,
+  // or a view with KW = 2 whose rows are linear) and row offsets inside a tile below 4 GiB (host check).
+  constexpr bool LEAN = (SCHED == 3);
+  static_assert(!LEAN || !VIEW || KW == 2, "the lean loop takes plain NT operands or contiguous-K views");
   constexpr bool ONE = (SCHED == 1);
   // SCHED = 2 (A/B knob ":p8"): the default schedule with the MFMAs of a quadrant in snake order -- every issue
   // changes exactly one of the two operand registers (fewer operand-bus toggles; same sums, bit-identical)
@@ -333,15 +401,36 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(NtArgs p) {
     if (row >= limit) row = limit - 1;
     if constexpr (VIEW) {
       const uint32_t r1 = (uint32_t)row / (uint32_t)v.r0, r0 = (uint32_t)row - r1 * (uint32_t)v.r0;
-      return base + (int64_t)r1 * v.sr1 + (int64_t)r0 * v.sr0 + (lchunk & 3) * 8;   // chunks 4-7: second half
+      return base + (int64_t)r1 * v.sr1 + (int64_t)r0 * v.sr0 + (KW >= 1 ? lchunk : (lchunk & 3)) * 8;   // KW 0: chunks 4-7 = second half, offset in k1
     }
     return base + row * ld + lchunk * 8;
   };
+  uint32_t oa[2][2], ob[2][2];          // lean loop: byte offset of this lane's piece (h, i) from row 0, k 0 of the tile
+  const uint16_t* abase = nullptr;      // lean loop: wave-uniform address of the tile's first row of A / B
+  const uint16_t* bbase = nullptr;
   auto setup_tile = [&](int t) {
     int tm, tn;
     tile_of_block(t, p.tiles_m, p.tiles_n, p.raster, tm, tn);
     m0 = (int64_t)tm * BM;
     n0 = (int64_t)tn * BN;
+    if constexpr (LEAN) {
+      const int64_t fa = m0 + p.m_off, la = p.M + p.m_off;
+      abase = A + fa * p.lda;
+      bbase = B + n0 * p.ldb;
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int trow = (i * 8 + wid) * 8 + lrow;
+          const int lchunk = (lane & 7) ^ (trow & 7);
+          int64_t ra = fa + h * 128 + trow, rb = n0 + h * 128 + trow;
+          if (ra >= la) ra = la - 1;              // ragged edge: re-read the last row, never stored
+          if (rb >= p.N) rb = p.N - 1;
+          oa[h][i] = (uint32_t)(((ra - fa) * p.lda + lchunk * 8) * 2);
+          ob[h][i] = (uint32_t)(((rb - n0) * p.ldb + lchunk * 8) * 2);
+        }
+      return;
+    }
 #pragma unroll
     for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -369,7 +458,7 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(NtArgs p) {
     for (int i = 0; i < 2; ++i) {
       const uint16_t* g = (which < 2) ? ga[which & 1][i] : gb[which & 1][i];
       int64_t k = k0;
-      if constexpr (VIEW) k = kmajor ? (i == 0 ? k0 : k1) : (hi_half ? k1 : k0);
+      if constexpr (VIEW && KW == 0) k = kmajor ? (i == 0 ? k0 : k1) : (hi_half ? k1 : k0);
       glds16(g + k, __builtin_amdgcn_readfirstlane(base + (i * 8 + wid) * 1024));
     }
   };
@@ -380,12 +469,26 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(NtArgs p) {
     for (int q = 0; q < 4; ++q) {
       const uint16_t* g = is_a ? ga[q >> 1][q & 1] : gb[q >> 1][q & 1];
       int64_t k = k0;
-      if constexpr (VIEW) k = hi_half ? k1 : k0;
+      if constexpr (VIEW && KW == 0) k = hi_half ? k1 : k0;
       glds16(g + k, __builtin_amdgcn_readfirstlane(base + (q * 4 + wc) * 1024));
     }
   };
   const unsigned own_a = lds0 + wr * HALF_BYTES;                    // + (tile & 1) * 2 * HALF_BYTES
   const unsigned own_b = lds0 + 4 * HALF_BYTES + wr * HALF_BYTES;   // + (tile % 3) * 2 * HALF_BYTES
+
+  // lean loop: the 2 pieces of half-tile WHICH (0 = A-half0 .. 3 = B-half1) of the K-tile at element offset k -> buffer
+  const unsigned lean_dst0 = __builtin_amdgcn_readfirstlane(lds0 + wid * 1024);
+  auto issue_lean = [&](auto bufc, auto whichc, int64_t k) {
+    constexpr int BUF = decltype(bufc)::value, WHICH = decltype(whichc)::value;
+    const void* sb = (WHICH < 2) ? (const void*)(abase + k) : (const void*)(bbase + k);
+    if constexpr (WHICH < 2) {
+      glds16s<BUF * BUF_BYTES + WHICH * HALF_BYTES>(oa[WHICH & 1][0], sb, lean_dst0);
+      glds16s<BUF * BUF_BYTES + WHICH * HALF_BYTES + 8 * 1024>(oa[WHICH & 1][1], sb, lean_dst0);
+    } else {
+      glds16s<BUF * BUF_BYTES + WHICH * HALF_BYTES>(ob[WHICH & 1][0], sb, lean_dst0);
+      glds16s<BUF * BUF_BYTES + WHICH * HALF_BYTES + 8 * 1024>(ob[WHICH & 1][1], sb, lean_dst0);
+    }
+  };
 
   // fragment read offsets inside a half-tile image (row base is a multiple of FROWS)
   int frag_off[KS];
@@ -417,6 +520,37 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(NtArgs p) {
 
   uint4 af[ASUBS][KS][FA];   // [sub (one-cluster schedule: both)][k-step][row fragment] of the current A sub-tile
   uint4 bf[2][KS][FB];  // [sub][k-step][row fragment] of both B sub-tiles
+
+  // lean loop: LDS byte addresses of this lane's fragment rows, wave's sub-tile origin included, per k-step; buffer 1
+  // is BUF_BYTES further on (beyond the 16-bit offset field, hence its own registers)
+  unsigned a_rd[2][KS], b_rd[2][KS];
+  if constexpr (LEAN) {
+#pragma unroll
+    for (int bq = 0; bq < 2; ++bq)
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        a_rd[bq][ks] = lds0 + bq * BUF_BYTES + wr * HALF_BYTES + frag_off[ks];
+        b_rd[bq][ks] = lds0 + bq * BUF_BYTES + (2 + (wc >> 1)) * HALF_BYTES + ((wc & 1) * 64) * 128 + frag_off[ks];
+      }
+  }
+  auto lean_read_a = [&](auto bufc, auto subc) {
+    constexpr int BUF = decltype(bufc)::value, SUB = decltype(subc)::value;
+    static_for<0, 2>([&](auto ks) {
+      static_for<0, 4>([&](auto f) {
+        lds_frag<SUB * 64 * 128 + decltype(f)::value * 16 * 128>(af[0][decltype(ks)::value][decltype(f)::value],
+                                                                 a_rd[BUF][decltype(ks)::value]);
+      });
+    });
+  };
+  auto lean_read_b = [&](auto bufc, auto subc) {
+    constexpr int BUF = decltype(bufc)::value, SUB = decltype(subc)::value;
+    static_for<0, 2>([&](auto ks) {
+      static_for<0, 2>([&](auto f) {
+        lds_frag<SUB * 32 * 128 + decltype(f)::value * 16 * 128>(bf[SUB][decltype(ks)::value][decltype(f)::value],
+                                                                 b_rd[BUF][decltype(ks)::value]);
+      });
+    });
+  };
 
   // k-major images: per-lane part of the transpose-read address.  Lane (g = lane >> 4, i = lane & 15)
   // reads k row 32 ks + 8 g + 4 r + (i >> 2), bytes 8 (i & 3) .. +7 of 32-B unit u ^ h:
@@ -479,6 +613,23 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(NtArgs p) {
         }
     __builtin_amdgcn_s_setprio(0);
   };
+  // lean loop: both quadrants of A sub-tile `sa` under ONE s_setprio pair (same MFMA order as two mma_quadrant calls)
+  auto mma_cluster = [&](int sa, int sb_first) {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int sb = sb_first ^ q;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int i = 0; i < FA; ++i)
+#pragma unroll
+          for (int j = 0; j < FB; ++j)
+            if constexpr (!M32)
+              acc[sa * 4 + i][sb * 2 + j] = mma16<IS_BF16>(bf[sb][ks][j], af[0][ks][i], acc[sa * 4 + i][sb * 2 + j]);
+    }
+    __builtin_amdgcn_s_setprio(0);
+  };
   // end of a load segment: retire this wave's LDS reads, then meet the other waves
 #define TNH_SEG_LOAD_END()                                  \
   do {                                                      \
@@ -505,14 +656,44 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(NtArgs p) {
   }
   // element offset of the K-tile each operand stages next: A runs one tile ahead, B two
   KWalk wa, wb;
+  auto walk = [&](KWalk& w, int64_t& h0, int64_t& h1, int kt) {      // element offsets of K-tile kt of this launch's slice
+    if constexpr (KW == 2) {
+      h0 = (int64_t)(kfirst + kt) * BK;
+      h1 = 0;
+    } else if constexpr (KW == 1) {
+      w.next_tile(h0);
+      h1 = 0;
+    } else {
+      w.next(h0, h1);
+    }
+  };
   // prologue of an output tile (its LDS-DMA source pointers set by setup_tile): K-tile 0 complete, B halves of K-tile 1
   auto start_tile = [&]() {
+    if constexpr (LEAN) {       // K-tile 0 complete -> buffer 0, the B halves of K-tile 1 -> buffer 1
+      using I0 = std::integral_constant<int, 0>;
+      using I1 = std::integral_constant<int, 1>;
+      const int64_t k0e = (int64_t)kfirst * BK;
+      issue_lean(I0{}, I0{}, k0e);
+      issue_lean(I0{}, I1{}, k0e);
+      issue_lean(I0{}, std::integral_constant<int, 2>{}, k0e);
+      issue_lean(I0{}, std::integral_constant<int, 3>{}, k0e);
+      if (nt > 1) {
+        issue_lean(I1{}, std::integral_constant<int, 2>{}, k0e + BK);
+        issue_lean(I1{}, std::integral_constant<int, 3>{}, k0e + BK);
+      }
+      return;
+    }
     int64_t ka0 = 0, ka1 = 0, kb0 = 0, kb1 = 0;
     if constexpr (VIEW) {
-      wa.init(p.va, kfirst);
-      wb.init(p.vb, kfirst);
-      wa.next(ka0, ka1);
-      wb.next(kb0, kb1);
+      if constexpr (KW == 1) {
+        wa.init_tiles(p.va, kfirst);
+        wb.init_tiles(p.vb, kfirst);
+      } else if constexpr (KW == 0) {
+        wa.init(p.va, kfirst);
+        wb.init(p.vb, kfirst);
+      }
+      walk(wa, ka0, ka1, 0);
+      walk(wb, kb0, kb1, 0);
     }
     if constexpr (ONE) {        // A of K-tiles 0, 1 and B of K-tiles 0, 1, 2 (this group's halves)
       issue_own(own_a, true, ka0, ka1);
@@ -520,15 +701,15 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(NtArgs p) {
       if (nt > 1) {
         int64_t a0 = (int64_t)BK, a1 = 0, b0 = (int64_t)BK, b1 = 0;
         if constexpr (VIEW) {
-          wa.next(a0, a1);
-          wb.next(b0, b1);
+          walk(wa, a0, a1, 1);
+          walk(wb, b0, b1, 1);
         }
         issue_own(own_a + 2 * HALF_BYTES, true, a0, a1);
         issue_own(own_b + 2 * HALF_BYTES, false, b0, b1);
       }
       if (nt > 2) {
         int64_t b0 = (int64_t)2 * BK, b1 = 0;
-        if constexpr (VIEW) wb.next(b0, b1);
+        if constexpr (VIEW) walk(wb, b0, b1, 2);
         issue_own(own_b + 4 * HALF_BYTES, false, b0, b1);
       }
       return;
@@ -539,12 +720,12 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(NtArgs p) {
     issue(0, 3, kb0, kb1);
     if (nt > 1) {
       int64_t kc0 = (int64_t)BK, kc1 = 0;
-      if constexpr (VIEW) wb.next(kc0, kc1);
+      if constexpr (VIEW) walk(wb, kc0, kc1, 1);
       issue(1, 2, kc0, kc1);
       issue(1, 3, kc0, kc1);
     } else if constexpr (VIEW) {
       int64_t d0, d1;
-      wb.next(d0, d1);
+      walk(wb, d0, d1, 1);
     }
   };
   setup_tile((int)blockIdx.x);
@@ -557,6 +738,42 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(NtArgs p) {
   if (wr == 1) __builtin_amdgcn_s_barrier();  // group 1 runs one interval behind group 0
   __builtin_amdgcn_sched_barrier(0);
 
+  if constexpr (LEAN) {
+    // the two-cluster schedule of the default loop (table in the kernel header), K-tile t in buffer B = t & 1, unrolled by two
+    auto body = [&](auto bufc, int t) {
+      constexpr int B = decltype(bufc)::value;
+      using IB = std::integral_constant<int, B>;
+      using IO = std::integral_constant<int, B ^ 1>;
+      const bool n1 = (t + 1 < nt), n2 = (t + 2 < nt);
+      lean_read_a(IB{}, std::integral_constant<int, 0>{});
+      lean_read_b(IB{}, std::integral_constant<int, 0>{});
+      lean_read_b(IB{}, std::integral_constant<int, 1>{});
+      if (n1) {
+        const int64_t ka = (int64_t)(kfirst + t + 1) * BK;
+        issue_lean(IO{}, std::integral_constant<int, 0>{}, ka);
+        issue_lean(IO{}, std::integral_constant<int, 1>{}, ka);
+      }
+      TNH_SEG_LOAD_END();
+      mma_cluster(0, 0);
+      TNH_SEG_MMA_END();
+      lean_read_a(IB{}, std::integral_constant<int, 1>{});
+      if (n2) {
+        const int64_t kb = (int64_t)(kfirst + t + 2) * BK;
+        issue_lean(IB{}, std::integral_constant<int, 2>{}, kb);
+        issue_lean(IB{}, std::integral_constant<int, 3>{}, kb);
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      TNH_SEG_LOAD_END();
+      mma_cluster(1, 1);
+      TNH_SEG_MMA_END();
+    };
+    for (int t = 0; t < nt; t += 2) {
+      body(std::integral_constant<int, 0>{}, t);
+      if (t + 1 < nt) body(std::integral_constant<int, 1>{}, t + 1);
+    }
+  } else {
   int b3 = 0;      // one-cluster schedule: K-tile % 3 (B slot)
   for (int t = 0; t < nt; ++t) {
     const int b = t & 1;
@@ -573,12 +790,12 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(NtArgs p) {
       const bool ia = (t >= 1) && n1, ib = (t >= 1) && n2;
       if (ia) {
         int64_t ka = (int64_t)(t + 1) * BK, ka1 = 0;
-        if constexpr (VIEW) wa.next(ka, ka1);
+        if constexpr (VIEW) walk(wa, ka, ka1, t + 1);
         issue_own(own_a + ((t + 1) & 1) * 2 * HALF_BYTES, true, ka, ka1);
       }
       if (ib) {
         int64_t kb = (int64_t)(t + 2) * BK, kb1 = 0;
-        if constexpr (VIEW) wb.next(kb, kb1);
+        if constexpr (VIEW) walk(wb, kb, kb1, t + 2);
         const int slot = (b3 == 0) ? 2 : b3 - 1;       // (t + 2) % 3
         issue_own(own_b + slot * 2 * HALF_BYTES, false, kb, kb1);
       }
@@ -604,7 +821,7 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(NtArgs p) {
       read_b(cur, 1);
       if (n1) {
         int64_t ka = (int64_t)(t + 1) * BK, ka1 = 0;
-        if constexpr (VIEW) wa.next(ka, ka1);
+        if constexpr (VIEW) walk(wa, ka, ka1, t + 1);
         issue(b ^ 1, 0, ka, ka1);
         issue(b ^ 1, 1, ka, ka1);
       }
@@ -615,7 +832,7 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(NtArgs p) {
       read_a(cur, 1);
       if (n2) {
         int64_t kb = (int64_t)(t + 2) * BK, kb1 = 0;
-        if constexpr (VIEW) wb.next(kb, kb1);
+        if constexpr (VIEW) walk(wb, kb, kb1, t + 2);
         issue(b, 2, kb, kb1);
         issue(b, 3, kb, kb1);
         asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
@@ -658,6 +875,7 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(NtArgs p) {
     mma_quadrant(1, 0);
     TNH_SEG_MMA_END();
   }
+  }   // (default / one-cluster loops)
   if (wr == 0) __builtin_amdgcn_s_barrier();  // pairs with group 1's last barrier
   __builtin_amdgcn_sched_barrier(0);
 
@@ -755,13 +973,6 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(NtArgs p) {
 // ---------------------------------------------------------------------------
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;   // asm operands must be plain vectors
 
-template <int I, int N, typename F>
-__device__ __forceinline__ void static_for(F&& f) {
-  if constexpr (I < N) {
-    f(std::integral_constant<int, I>{});
-    static_for<I + 1, N>(f);
-  }
-}
 
 template <int OFF>
 __device__ __forceinline__ void lds_read16_asm(u32x4& dst, unsigned addr) {
@@ -954,6 +1165,17 @@ static int launch_nt(bool is_bf16, bool out_f32, NtArgs p, int64_t batch) {
   return TNH_OK;
 }
 
+int g_opt_lean = -1;     // A/B knob ":l<d>": the lean main loop of the ping-pong kernels (-1: on where it applies)
+
+// The lean loop addresses a tile's rows as a 32-bit byte offset from the tile's first row
+static bool lean_wanted(const NtArgs& q) {
+  static const int env = []() { const char* e = getenv("TNH_GEMM_LEAN"); return e ? atoi(e) : -1; }();
+  const int mode = g_opt_lean >= 0 ? g_opt_lean : env;
+  if (mode == 0) return false;
+  const int64_t span_a = 255 * q.lda + 64, span_b = 255 * q.ldb + 64;
+  return span_a > 0 && span_b > 0 && span_a * 2 < (int64_t(1) << 32) && span_b * 2 < (int64_t(1) << 32);
+}
+
 static int launch_pp(bool is_bf16, bool out_f32, bool two, NtArgs p, int64_t batch, bool m32 = false) {
   p.tiles_m = (int)((p.M + 255) / 256);
   p.tiles_n = (int)((p.N + 255) / 256);
@@ -968,9 +1190,11 @@ static int launch_pp(bool is_bf16, bool out_f32, bool two, NtArgs p, int64_t bat
     q.C = (char*)p.C + b0 * p.sC * esz_out;
     q.m_off = 0;
     const dim3 grid(pp_grid_x(nwg, (unsigned)nb), (unsigned)nb), block(512);
+    const bool lean = lean_wanted(q) && two && !m32 && g_opt_phases != 8;
 #define TNH_PP_LAUNCH(B16, O32)                                                                               \
   do {                                                                                                       \
     if (g_opt_phases == 7) hipLaunchKernelGGL((gemm_nt_pp_kernel<B16, O32, true, false, false, false, false, 1>), grid, block, 0, stream(), q); \
+    else if (lean) hipLaunchKernelGGL((gemm_nt_pp_kernel<B16, O32, true, false, false, false, false, 3>), grid, block, 0, stream(), q); \
     else if (g_opt_phases == 8) hipLaunchKernelGGL((gemm_nt_pp_kernel<B16, O32, true, false, false, false, false, 2>), grid, block, 0, stream(), q); \
     else if (m32) hipLaunchKernelGGL((gemm_nt_pp_kernel<B16, O32, true, true>), grid, block, 0, stream(), q);      \
     else if (two) hipLaunchKernelGGL((gemm_nt_pp_kernel<B16, O32, true>), grid, block, 0, stream(), q);      \
@@ -990,10 +1214,31 @@ static int launch_pp(bool is_bf16, bool out_f32, bool two, NtArgs p, int64_t bat
 }
 
 // ---- view GEMM: operands read in place through two-level strides (tnh_gemm_view) ----------------
+int g_opt_kwalk = -1;    // A/B knob ":w<d>": cap on the K-walk form of the view kernel (-1: the cheapest the operands allow)
+
 template <bool A_KM, bool B_KN>
-static void launch_pp_view_t(bool is_bf16, bool out_f32, dim3 grid, const NtArgs& q) {
+static void launch_pp_view_t(bool is_bf16, bool out_f32, dim3 grid, const NtArgs& q, int kw = 0) {
   const dim3 block(512);
   if constexpr (!A_KM && !B_KN) {
+    if (kw >= 1 && g_opt_phases != 7) {      // K-contiguous operands whose contraction runs allow a tile-granular walk
+      // single-level (or linear two-level) rows + one contiguous contraction run: the lean loop
+      const bool lean = kw == 2 && q.va.r0 >= q.M + q.m_off && q.vb.r0 >= q.N && lean_wanted(q);
+#define TNH_VIEW_KW(B16, O32)                                                                                              \
+  do {                                                                                                                     \
+    if (lean) hipLaunchKernelGGL((gemm_nt_pp_kernel<B16, O32, true, false, true, false, false, 3, 2>), grid, block, 0, stream(), q); \
+    else if (kw == 2) hipLaunchKernelGGL((gemm_nt_pp_kernel<B16, O32, true, false, true, false, false, 0, 2>), grid, block, 0, stream(), q); \
+    else hipLaunchKernelGGL((gemm_nt_pp_kernel<B16, O32, true, false, true, false, false, 0, 1>), grid, block, 0, stream(), q);         \
+  } while (0)
+      if (is_bf16) {
+        if (out_f32) TNH_VIEW_KW(true, true);
+        else TNH_VIEW_KW(true, false);
+      } else {
+        if (out_f32) TNH_VIEW_KW(false, true);
+        else TNH_VIEW_KW(false, false);
+      }
+#undef TNH_VIEW_KW
+      return;
+    }
     if (g_opt_phases == 7) {      // A/B knob ":p7": one 64-MFMA cluster per K-tile
       if (is_bf16) {
         if (out_f32) hipLaunchKernelGGL((gemm_nt_pp_kernel<true, true, true, false, true, false, false, 1>), grid, block, 0, stream(), q);
@@ -1060,12 +1305,28 @@ int gemm_bf16_view(int in_dt, int out_dt, int64_t M, int64_t N, int64_t K, const
   const bool is_bf16 = (in_dt == TNH_BF16), out_f32 = (out_dt == TNH_F32);
   p.kslice_tiles = 0;
   p.m_off = 0;
+  // The cheapest K walk both operands allow (kernel header, KW): 2 = one contiguous contraction run each (a run that
+  // continues seamlessly into the next counts), 1 = runs that are multiples of 64, 0 = half-K-tile walk.
+  int kw = 0;
+  if (!a_km && !b_kn) {
+    auto contiguous = [&](OpView& v) {
+      const bool yes = (int64_t)v.tpi * 32 >= K || v.sk1 == (int64_t)v.tpi * 32;
+      if (yes) {                       // normalise to ONE run (tile-granular walks read tpi / sk1)
+        v.tpi = (int)(K / 32);
+        v.sk1 = K;
+      }
+      return yes;
+    };
+    const bool ca = contiguous(p.va), cb = contiguous(p.vb);
+    kw = (ca && cb) ? 2 : ((p.va.tpi % 2 == 0 && p.vb.tpi % 2 == 0) ? 1 : 0);
+    if (g_opt_kwalk >= 0 && kw > g_opt_kwalk) kw = g_opt_kwalk;
+  }
   auto launch = [&](const NtArgs& q, unsigned gy, bool f32_out) {
     const dim3 grid(pp_grid_x((int64_t)q.tiles_m * q.tiles_n, gy), gy);
     if (a_km && b_kn) launch_pp_view_t<true, true>(is_bf16, f32_out, grid, q);
     else if (a_km) launch_pp_view_t<true, false>(is_bf16, f32_out, grid, q);
     else if (b_kn) launch_pp_view_t<false, true>(is_bf16, f32_out, grid, q);
-    else launch_pp_view_t<false, false>(is_bf16, f32_out, grid, q);
+    else launch_pp_view_t<false, false>(is_bf16, f32_out, grid, q, kw);
   };
   *name = a_km ? (b_kn ? "bf16_view_tt_256x256x64_pp" : "bf16_view_tn_256x256x64_pp")
                : (b_kn ? "bf16_view_nn_256x256x64_pp" : "bf16_view_nt_256x256x64_pp");

@@ -1461,3 +1461,69 @@ def test_gemm_gather_c_abi_rejects_bad_descriptors_without_launching(hip):
   assert call(desc, l_elems=12**5 - 1) == _lib.ERR_UNSUPPORTED        # the last box leaves the tensor
   assert call(desc, k=136) == _lib.ERR_UNSUPPORTED
   assert call(desc, code=_lib.F32) == _lib.ERR_INVALID
+
+
+@pytest.mark.parametrize("dtype", [ta.bfloat16, np.float16])
+def test_gemm_view_k_walk_forms_are_bit_identical(hip, dtype):
+  """Round 5: the view kernel walks the contraction index in the cheapest form both operands allow (KW in
+  tnh_gemm_bf16.hip: 2 = one contiguous run, 1 = runs that are multiples of 64, 0 = half K-tiles) -- measured +5 % on
+  the headline shape.  Same MFMA sequence in all of them: for operands that allow form 2 / 1, capping the form with
+  the A/B knob ":w<d>" must give bit-identical results, and all of them the permute + NT result."""
+  rng = np.random.default_rng(31)
+  cases = [
+      # (shape_a, shape_b, axes): K-contiguous on both sides
+      ((3584, 4, 64), (3840, 4, 64), ([1, 2], [1, 2])),              # one contiguous run of 256 each -> form 2
+      ((14, 4, 256, 128), (15, 4, 256, 128), ([1, 3], [1, 3])),      # runs of 128 (two-level K and rows) -> form 1
+      ((14, 4, 256, 96), (15, 4, 256, 96), ([1, 3], [1, 3])),        # runs of 96 = 3 halves -> form 0 only
+  ]
+  for shape_a, shape_b, axes in cases:
+    a = (rng.standard_normal(shape_a) / 8).astype(np.float32)
+    b = (rng.standard_normal(shape_b) / 8).astype(np.float32)
+    if dtype is ta.bfloat16:
+      a, b = orc.round_bf16(a), orc.round_bf16(b)
+      da, db = hip.to_bfloat16(a), hip.to_bfloat16(b)
+    else:
+      a, b = a.astype(np.float16), b.astype(np.float16)
+      da, db = dev(hip, a), dev(hip, b)
+    outs = {}
+    for knob in ("auto", "auto:l0", "auto:w1", "auto:w0"):
+      _lib.check(hip.lib.tnh_gemm_set_variant(knob.encode()))
+      try:
+        before = hip.permute_launches
+        outs[knob] = np.asarray(hip.tensordot(da, db, axes))
+        kernel = hip.lib.tnh_gemm_last_kernel().decode()
+        assert "view_nt" in kernel and hip.permute_launches == before, (knob, kernel)
+      finally:
+        _lib.check(hip.lib.tnh_gemm_set_variant(b"auto"))
+    np.testing.assert_array_equal(outs["auto"], outs["auto:w0"])
+    np.testing.assert_array_equal(outs["auto:l0"], outs["auto:w0"])
+    np.testing.assert_array_equal(outs["auto:w1"], outs["auto:w0"])
+    hip.absorb_transposes = False
+    try:
+      ref_dev = np.asarray(hip.tensordot(da, db, axes))
+    finally:
+      hip.absorb_transposes = True
+    np.testing.assert_array_equal(outs["auto"], ref_dev)
+    ref = np.tensordot(a.astype(np.float64), b.astype(np.float64), axes)
+    np.testing.assert_allclose(outs["auto"], ref, rtol=2.0**-8, atol=2e-3)
+
+
+@pytest.mark.parametrize("dtype", [ta.bfloat16, np.float16])
+@pytest.mark.parametrize("m,n,k", [(1000, 900, 320), (2560, 2816, 64), (4096, 4096, 1088), (3584, 3840, 128)])
+def test_gemm_lean_main_loop_is_bit_identical(hip, dtype, m, n, k):
+  """Round 5: the lean main loop of the ping-pong kernel (SADDR LDS-DMA, untracked fragment reads, K loop unrolled
+  by two: ~150 instead of 205 instructions per K-tile and wave) issues the same fragment reads, LDS-DMA pieces and
+  MFMAs in the same order as the loop it replaces -- bit-identical results with the knob ':l0' (old loop), for ragged
+  M / N edges, odd and even K-tile counts, one K-tile, persistent and one-tile-per-workgroup grids; and against
+  float64."""
+  rng = np.random.default_rng(m + n + k)
+  out = {}
+  for knob in ("bf16_256pp", "bf16_256pp:l0", "bf16_256pp:g0", "bf16_256pp:l0:g0"):
+    o, ref, kernel, _ = _gemm_case(hip, dtype, m, n, k, 0, 1, variant=knob, rng=np.random.default_rng(m + n + k))
+    assert kernel == "bf16_nt_256x256x64_pp"
+    out[knob] = o
+  np.testing.assert_array_equal(out["bf16_256pp"], out["bf16_256pp:l0"])
+  np.testing.assert_array_equal(out["bf16_256pp:g0"], out["bf16_256pp:l0"])
+  np.testing.assert_array_equal(out["bf16_256pp:l0:g0"], out["bf16_256pp:l0"])
+  tol = GEMM_TOL[dtype]
+  np.testing.assert_allclose(out["bf16_256pp"], ref, rtol=tol, atol=tol * np.sqrt(k))

@@ -79,9 +79,14 @@ def headline(be, tel, variants, seconds, d=256):
   va = _lib.OperandView(m, k, 0, k, 1, 0)
   vb = _lib.OperandView(n, k, 0, k, 1, 0)
   for v in variants:
-    _lib.check(be.lib.tnh_gemm_set_variant(v.encode()))
+    plain = v.startswith("plain:")       # the plain NT entry point (tnh_gemm) on the same buffers instead of the view kernel
+    _lib.check(be.lib.tnh_gemm_set_variant((v[6:] if plain else v).encode()))
 
     def call():
+      if plain:
+        _lib.check(be.lib.tnh_gemm(_lib.BF16, _lib.BF16, 0, 1, m, n, k, ctypes.c_void_p(A.ptr), k, ctypes.c_void_p(B.ptr), k,
+                                   ctypes.c_void_p(C.ptr), n, 1, 0, 0, 0))
+        return
       _lib.check(be.lib.tnh_gemm_view(_lib.BF16, _lib.BF16, m, n, k, ctypes.c_void_p(A.ptr), ctypes.byref(va),
                                       ctypes.c_void_p(B.ptr), ctypes.byref(vb), ctypes.c_void_p(C.ptr), n))
     call()
@@ -113,11 +118,13 @@ def main():
   ap.add_argument("--headline", type=int, default=1)
   ap.add_argument("--headline_variants", default="auto,auto:p7,auto")
   ap.add_argument("--reps", type=int, default=1)
+  ap.add_argument("--parity", type=int, default=1)
   a = ap.parse_args()
   be = ta.get_hip_backend()
   tel = Telemetry(be.lib)
   variants = a.variants.split(",")
-  parity(be, variants)
+  if a.parity:
+    parity(be, variants)
   for rep in range(a.reps):
     for shape in a.shapes.split(","):
       m, n, k = (int(x) for x in shape.split("x"))
