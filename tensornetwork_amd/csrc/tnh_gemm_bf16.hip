@@ -294,6 +294,15 @@ __device__ __forceinline__ void glds16s(unsigned voff, const void* sbase, unsign
       : "v"(voff), "s"(lds_base), "n"(IMM), "s"(sbase)
       : "memory", "scc");       // s_add_u32 writes SCC
 }
+// The same piece in two statements, for callers that put another instruction (a fragment read) between them: that
+// instruction is the wait state the M0 write needs before an LDS-DMA reads it, and the s_nop goes away.
+template <int IMM>
+__device__ __forceinline__ void glds_m0(unsigned lds_base) {
+  asm volatile("s_add_u32 m0, %0, %1" : : "s"(lds_base), "n"(IMM) : "scc");
+}
+__device__ __forceinline__ void glds_go(unsigned voff, const void* sbase) {
+  asm volatile("global_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(sbase) : "memory");
+}
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
 // A fragment read the compiler does not track (no s_waitcnt lgkmcnt of its own in front of every MFMA: the load
 // segments end with our lgkmcnt(0) anyway)
@@ -340,7 +349,7 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(NtArgs p) {
   // general view walk cost 4.3 %: profiles/r05_gemm_headline_plain_vs_view.jsonl).  Needs single-level rows (plain NT,
   // or a view with KW = 2 whose rows are linear) and row offsets inside a tile below 4 GiB (host check).
   constexpr bool LEAN = (SCHED == 3);
-  static_assert(!LEAN || !VIEW || KW == 2, "the lean loop takes plain NT operands or contiguous-K views");
+  static_assert(!LEAN || !VIEW || KW >= 1, "the lean loop takes plain NT operands or views with a tile-granular K walk");
   constexpr bool ONE = (SCHED == 1);
   // SCHED = 2 (A/B knob ":p8"): the default schedule with the MFMAs of a quadrant in snake order -- every issue
   // changes exactly one of the two operand registers (fewer operand-bus toggles; same sums, bit-identical)
@@ -414,9 +423,21 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(NtArgs p) {
     m0 = (int64_t)tm * BM;
     n0 = (int64_t)tn * BN;
     if constexpr (LEAN) {
+      // element offset of row r of an operand from the operand's base (two-level rows of a view; r < 2^31: host check)
+      auto row_elems = [&](const OpView& v, int64_t ld, int64_t r) -> int64_t {
+        if constexpr (VIEW) {
+          const uint32_t r1 = (uint32_t)r / (uint32_t)v.r0, r0 = (uint32_t)r - r1 * (uint32_t)v.r0;
+          return (int64_t)r1 * v.sr1 + (int64_t)r0 * v.sr0;
+        }
+        return r * ld;
+      };
       const int64_t fa = m0 + p.m_off, la = p.M + p.m_off;
-      abase = A + fa * p.lda;
-      bbase = B + n0 * p.ldb;
+      const int64_t a0 = p.lean_rel_a ? row_elems(p.va, p.lda, fa) : 0, b0 = p.lean_rel_b ? row_elems(p.vb, p.ldb, n0) : 0;
+      // (the tile's first row is the same for every lane: made scalar here so that the SADDR operand stays in SGPRs)
+      abase = A + (((int64_t)__builtin_amdgcn_readfirstlane((int)(a0 >> 32)) << 32) |
+                   (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)a0));
+      bbase = B + (((int64_t)__builtin_amdgcn_readfirstlane((int)(b0 >> 32)) << 32) |
+                   (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)b0));
 #pragma unroll
       for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -426,8 +447,8 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(NtArgs p) {
           int64_t ra = fa + h * 128 + trow, rb = n0 + h * 128 + trow;
           if (ra >= la) ra = la - 1;              // ragged edge: re-read the last row, never stored
           if (rb >= p.N) rb = p.N - 1;
-          oa[h][i] = (uint32_t)(((ra - fa) * p.lda + lchunk * 8) * 2);
-          ob[h][i] = (uint32_t)(((rb - n0) * p.ldb + lchunk * 8) * 2);
+          oa[h][i] = (uint32_t)((row_elems(p.va, p.lda, ra) - a0 + lchunk * 8) * 2);
+          ob[h][i] = (uint32_t)((row_elems(p.vb, p.ldb, rb) - b0 + lchunk * 8) * 2);
         }
       return;
     }
@@ -489,6 +510,15 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(NtArgs p) {
       glds16s<BUF * BUF_BYTES + WHICH * HALF_BYTES + 8 * 1024>(ob[WHICH & 1][1], sb, lean_dst0);
     }
   };
+  // piece I (0 / 1) of half-tile WHICH in two steps (M0, then the load) for the interleaved main loop
+  auto piece_m0 = [&](auto bufc, auto whichc, auto ic) {
+    constexpr int BUF = decltype(bufc)::value, WHICH = decltype(whichc)::value, I = decltype(ic)::value;
+    glds_m0<BUF * BUF_BYTES + WHICH * HALF_BYTES + I * 8 * 1024>(lean_dst0);
+  };
+  auto piece_go = [&](auto whichc, auto ic, const void* sb) {
+    constexpr int WHICH = decltype(whichc)::value, I = decltype(ic)::value;
+    glds_go((WHICH < 2) ? oa[WHICH & 1][I] : ob[WHICH & 1][I], sb);
+  };
 
   // fragment read offsets inside a half-tile image (row base is a multiple of FROWS)
   int frag_off[KS];
@@ -541,6 +571,11 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(NtArgs p) {
                                                                  a_rd[BUF][decltype(ks)::value]);
       });
     });
+  };
+  // one fragment: Q = 0..7 -> A (sub, ks = Q >> 2, f = Q & 3); used by the interleaved issue below
+  auto lean_read_a1 = [&](auto bufc, auto subc, auto qc) {
+    constexpr int BUF = decltype(bufc)::value, SUB = decltype(subc)::value, Q = decltype(qc)::value;
+    lds_frag<SUB * 64 * 128 + (Q & 3) * 16 * 128>(af[0][Q >> 2][Q & 3], a_rd[BUF][Q >> 2]);
   };
   auto lean_read_b = [&](auto bufc, auto subc) {
     constexpr int BUF = decltype(bufc)::value, SUB = decltype(subc)::value;
@@ -657,7 +692,7 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(NtArgs p) {
   // element offset of the K-tile each operand stages next: A runs one tile ahead, B two
   KWalk wa, wb;
   auto walk = [&](KWalk& w, int64_t& h0, int64_t& h1, int kt) {      // element offsets of K-tile kt of this launch's slice
-    if constexpr (KW == 2) {
+    if constexpr (KW == 2 || !VIEW) {
       h0 = (int64_t)(kfirst + kt) * BK;
       h1 = 0;
     } else if constexpr (KW == 1) {
@@ -672,14 +707,21 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(NtArgs p) {
     if constexpr (LEAN) {       // K-tile 0 complete -> buffer 0, the B halves of K-tile 1 -> buffer 1
       using I0 = std::integral_constant<int, 0>;
       using I1 = std::integral_constant<int, 1>;
-      const int64_t k0e = (int64_t)kfirst * BK;
-      issue_lean(I0{}, I0{}, k0e);
-      issue_lean(I0{}, I1{}, k0e);
-      issue_lean(I0{}, std::integral_constant<int, 2>{}, k0e);
-      issue_lean(I0{}, std::integral_constant<int, 3>{}, k0e);
+      if constexpr (VIEW && KW == 1) {
+        wa.init_tiles(p.va, kfirst);
+        wb.init_tiles(p.vb, kfirst);
+      }
+      int64_t ka = 0, kb = 0, kc = 0, unused = 0;
+      walk(wa, ka, unused, 0);
+      walk(wb, kb, unused, 0);
+      issue_lean(I0{}, I0{}, ka);
+      issue_lean(I0{}, I1{}, ka);
+      issue_lean(I0{}, std::integral_constant<int, 2>{}, kb);
+      issue_lean(I0{}, std::integral_constant<int, 3>{}, kb);
       if (nt > 1) {
-        issue_lean(I1{}, std::integral_constant<int, 2>{}, k0e + BK);
-        issue_lean(I1{}, std::integral_constant<int, 3>{}, k0e + BK);
+        walk(wb, kc, unused, 1);
+        issue_lean(I1{}, std::integral_constant<int, 2>{}, kc);
+        issue_lean(I1{}, std::integral_constant<int, 3>{}, kc);
       }
       return;
     }
@@ -744,31 +786,54 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(NtArgs p) {
       constexpr int B = decltype(bufc)::value;
       using IB = std::integral_constant<int, B>;
       using IO = std::integral_constant<int, B ^ 1>;
+      using C0 = std::integral_constant<int, 0>;
+      using C1 = std::integral_constant<int, 1>;
+      using C2 = std::integral_constant<int, 2>;
+      using C3 = std::integral_constant<int, 3>;
       const bool n1 = (t + 1 < nt), n2 = (t + 2 < nt);
-      lean_read_a(IB{}, std::integral_constant<int, 0>{});
-      lean_read_b(IB{}, std::integral_constant<int, 0>{});
-      lean_read_b(IB{}, std::integral_constant<int, 1>{});
+      int64_t unused = 0;
+      // ---- load segment 1: B sub-tiles 0 / 1 (8 reads), A sub-tile 0 (8 reads); A halves of K-tile t + 1 -> other buffer.
+      // Every LDS-DMA piece is [M0 write] [one fragment read] [load]: the read is the wait state the M0 write needs.
+      lean_read_b(IB{}, C0{});
+      lean_read_b(IB{}, C1{});
       if (n1) {
-        const int64_t ka = (int64_t)(kfirst + t + 1) * BK;
-        issue_lean(IO{}, std::integral_constant<int, 0>{}, ka);
-        issue_lean(IO{}, std::integral_constant<int, 1>{}, ka);
+        int64_t ka = 0;
+        walk(wa, ka, unused, t + 1);
+        const void* sb = (const void*)(abase + ka);
+        piece_m0(IO{}, C0{}, C0{}); lean_read_a1(IB{}, C0{}, C0{}); piece_go(C0{}, C0{}, sb); lean_read_a1(IB{}, C0{}, C1{});
+        piece_m0(IO{}, C0{}, C1{}); lean_read_a1(IB{}, C0{}, C2{}); piece_go(C0{}, C1{}, sb); lean_read_a1(IB{}, C0{}, C3{});
+        piece_m0(IO{}, C1{}, C0{}); lean_read_a1(IB{}, C0{}, std::integral_constant<int, 4>{}); piece_go(C1{}, C0{}, sb);
+        lean_read_a1(IB{}, C0{}, std::integral_constant<int, 5>{});
+        piece_m0(IO{}, C1{}, C1{}); lean_read_a1(IB{}, C0{}, std::integral_constant<int, 6>{}); piece_go(C1{}, C1{}, sb);
+        lean_read_a1(IB{}, C0{}, std::integral_constant<int, 7>{});
+      } else {
+        lean_read_a(IB{}, C0{});
       }
       TNH_SEG_LOAD_END();
       mma_cluster(0, 0);
       TNH_SEG_MMA_END();
-      lean_read_a(IB{}, std::integral_constant<int, 1>{});
+      // ---- load segment 2: A sub-tile 1 (8 reads); B halves of K-tile t + 2 -> this buffer
       if (n2) {
-        const int64_t kb = (int64_t)(kfirst + t + 2) * BK;
-        issue_lean(IB{}, std::integral_constant<int, 2>{}, kb);
-        issue_lean(IB{}, std::integral_constant<int, 3>{}, kb);
+        int64_t kb = 0;
+        walk(wb, kb, unused, t + 2);
+        const void* sb = (const void*)(bbase + kb);
+        piece_m0(IB{}, C2{}, C0{}); lean_read_a1(IB{}, C1{}, C0{}); piece_go(C2{}, C0{}, sb); lean_read_a1(IB{}, C1{}, C1{});
+        piece_m0(IB{}, C2{}, C1{}); lean_read_a1(IB{}, C1{}, C2{}); piece_go(C2{}, C1{}, sb); lean_read_a1(IB{}, C1{}, C3{});
+        piece_m0(IB{}, C3{}, C0{}); lean_read_a1(IB{}, C1{}, std::integral_constant<int, 4>{}); piece_go(C3{}, C0{}, sb);
+        lean_read_a1(IB{}, C1{}, std::integral_constant<int, 5>{});
+        piece_m0(IB{}, C3{}, C1{}); lean_read_a1(IB{}, C1{}, std::integral_constant<int, 6>{}); piece_go(C3{}, C1{}, sb);
+        lean_read_a1(IB{}, C1{}, std::integral_constant<int, 7>{});
         asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
       } else {
+        lean_read_a(IB{}, C1{});
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
       TNH_SEG_LOAD_END();
       mma_cluster(1, 1);
       TNH_SEG_MMA_END();
     };
+    // (peeling the last two K-tiles off to get a condition-free body was tried: four copies of the body made the
+    //  register allocator spill 300 bytes per lane into the loop -- not kept)
     for (int t = 0; t < nt; t += 2) {
       body(std::integral_constant<int, 0>{}, t);
       if (t + 1 < nt) body(std::integral_constant<int, 1>{}, t + 1);
@@ -1176,6 +1241,32 @@ static bool lean_wanted(const NtArgs& q) {
   return span_a > 0 && span_b > 0 && span_a * 2 < (int64_t(1) << 32) && span_b * 2 < (int64_t(1) << 32);
 }
 
+// View operands (K-contiguous): can the lean loop address the rows?  Sets q.lean_rel_a / _b.
+//   1  rows ascend in memory (sr0 > 0 and, with two levels, sr1 >= the extent of an inner run of rows) and any 256
+//      consecutive rows plus a K-tile span < 4 GiB: offsets from the tile's first row;
+//   0  otherwise, if both strides are non-negative and the whole operand spans < 4 GiB: offsets from the operand's base.
+static bool lean_view_rows(NtArgs& q) {
+  static const int env = []() { const char* e = getenv("TNH_GEMM_LEAN"); return e ? atoi(e) : -1; }();
+  const int mode = g_opt_lean >= 0 ? g_opt_lean : env;
+  if (mode == 0) return false;
+  const int64_t lim = int64_t(1) << 31;      // elements (2 bytes each)
+  auto one = [&](const OpView& v, int64_t rows, int& rel) -> bool {
+    if (v.sr0 <= 0) return false;
+    const bool single = v.r0 >= rows;
+    const int64_t inner = (v.r0 - 1) * v.sr0;
+    if (single || v.sr1 > inner) {           // ascending rows
+      const int64_t steps = single ? 0 : (255 / v.r0 + 2);
+      const int64_t span = (single ? 255 * v.sr0 : inner + steps * v.sr1) + 64;
+      if (span < lim) { rel = 1; return true; }
+    }
+    if (!single && v.sr1 < 0) return false;
+    const int64_t whole = (single ? (rows - 1) * v.sr0 : inner + ((rows - 1) / v.r0) * v.sr1) + 64;
+    if (whole < lim) { rel = 0; return true; }
+    return false;
+  };
+  return one(q.va, q.M + q.m_off, q.lean_rel_a) && one(q.vb, q.N, q.lean_rel_b);
+}
+
 static int launch_pp(bool is_bf16, bool out_f32, bool two, NtArgs p, int64_t batch, bool m32 = false) {
   p.tiles_m = (int)((p.M + 255) / 256);
   p.tiles_n = (int)((p.N + 255) / 256);
@@ -1189,6 +1280,7 @@ static int launch_pp(bool is_bf16, bool out_f32, bool two, NtArgs p, int64_t bat
     q.B = p.B + b0 * p.sB;
     q.C = (char*)p.C + b0 * p.sC * esz_out;
     q.m_off = 0;
+    q.lean_rel_a = q.lean_rel_b = 1;
     const dim3 grid(pp_grid_x(nwg, (unsigned)nb), (unsigned)nb), block(512);
     const bool lean = lean_wanted(q) && two && !m32 && g_opt_phases != 8;
 #define TNH_PP_LAUNCH(B16, O32)                                                                               \
@@ -1221,11 +1313,13 @@ static void launch_pp_view_t(bool is_bf16, bool out_f32, dim3 grid, const NtArgs
   const dim3 block(512);
   if constexpr (!A_KM && !B_KN) {
     if (kw >= 1 && g_opt_phases != 7) {      // K-contiguous operands whose contraction runs allow a tile-granular walk
-      // single-level (or linear two-level) rows + one contiguous contraction run: the lean loop
-      const bool lean = kw == 2 && q.va.r0 >= q.M + q.m_off && q.vb.r0 >= q.N && lean_wanted(q);
+      // the lean loop: rows addressable as 32-bit offsets from a wave-uniform base (lean_view_rows)
+      NtArgs ql = q;
+      const bool lean = lean_view_rows(ql);
 #define TNH_VIEW_KW(B16, O32)                                                                                              \
   do {                                                                                                                     \
-    if (lean) hipLaunchKernelGGL((gemm_nt_pp_kernel<B16, O32, true, false, true, false, false, 3, 2>), grid, block, 0, stream(), q); \
+    if (lean && kw == 2) hipLaunchKernelGGL((gemm_nt_pp_kernel<B16, O32, true, false, true, false, false, 3, 2>), grid, block, 0, stream(), ql); \
+    else if (lean) hipLaunchKernelGGL((gemm_nt_pp_kernel<B16, O32, true, false, true, false, false, 3, 1>), grid, block, 0, stream(), ql); \
     else if (kw == 2) hipLaunchKernelGGL((gemm_nt_pp_kernel<B16, O32, true, false, true, false, false, 0, 2>), grid, block, 0, stream(), q); \
     else hipLaunchKernelGGL((gemm_nt_pp_kernel<B16, O32, true, false, true, false, false, 0, 1>), grid, block, 0, stream(), q);         \
   } while (0)

@@ -37,6 +37,8 @@ struct NtArgs {
                //   not read again before it has left the L2; +1 % at 32768^2 x 1024..4096);
                // 2 (ragged kernel, half out): also 16-B aligned at every n % 8 == 0 -> LDS-staged row stores
   int a_vw, b_vw;  // ragged kernel only: widest aligned load (elements: 8, 4, 2, 1) on rows of A / B
+  int lean_rel_a, lean_rel_b;   // lean loop: 1 = a lane's row offsets are taken from the tile's first row (rows ascend in
+                                // memory, a tile spans < 4 GiB), 0 = from the operand's base (the whole operand spans < 4 GiB)
   int raster;  // 1 (default): 16x16 super-tiles shared by the 8 XCDs (3x less HBM traffic, +2%); 0: per-XCD ranges, M-grouped
 };
 
