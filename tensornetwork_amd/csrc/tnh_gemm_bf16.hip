@@ -349,7 +349,9 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(NtArgs p) {
   // general view walk cost 4.3 %: profiles/r05_gemm_headline_plain_vs_view.jsonl).  Needs single-level rows (plain NT,
   // or a view with KW = 2 whose rows are linear) and row offsets inside a tile below 4 GiB (host check).
   constexpr bool LEAN = (SCHED == 3);
-  static_assert(!LEAN || !VIEW || KW >= 1, "the lean loop takes plain NT operands or views with a tile-granular K walk");
+  // (KW = 0 in the lean loop: the full chunk offset sits in the lane offsets as for KW >= 1, and in a K-tile whose halves
+  //  come from two runs the lanes of the second half add the distance between the runs beyond 32 elements -- one v_and
+  //  + four v_add per operand, in those K-tiles only)
   constexpr bool ONE = (SCHED == 1);
   // SCHED = 2 (A/B knob ":p8"): the default schedule with the MFMAs of a quadrant in snake order -- every issue
   // changes exactly one of the two operand registers (fewer operand-bus toggles; same sums, bit-identical)
@@ -414,6 +416,8 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(NtArgs p) {
     }
     return base + row * ld + lchunk * 8;
   };
+  const uint16_t* a_next = nullptr;     // lean loop with a contiguous K: wave-uniform address of the next K-tile A / B stage
+  const uint16_t* b_next = nullptr;
   uint32_t oa[2][2], ob[2][2];          // lean loop: byte offset of this lane's piece (h, i) from row 0, k 0 of the tile
   const uint16_t* abase = nullptr;      // lean loop: wave-uniform address of the tile's first row of A / B
   const uint16_t* bbase = nullptr;
@@ -499,25 +503,23 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(NtArgs p) {
 
   // lean loop: the 2 pieces of half-tile WHICH (0 = A-half0 .. 3 = B-half1) of the K-tile at element offset k -> buffer
   const unsigned lean_dst0 = __builtin_amdgcn_readfirstlane(lds0 + wid * 1024);
-  auto issue_lean = [&](auto bufc, auto whichc, int64_t k) {
-    constexpr int BUF = decltype(bufc)::value, WHICH = decltype(whichc)::value;
-    const void* sb = (WHICH < 2) ? (const void*)(abase + k) : (const void*)(bbase + k);
-    if constexpr (WHICH < 2) {
-      glds16s<BUF * BUF_BYTES + WHICH * HALF_BYTES>(oa[WHICH & 1][0], sb, lean_dst0);
-      glds16s<BUF * BUF_BYTES + WHICH * HALF_BYTES + 8 * 1024>(oa[WHICH & 1][1], sb, lean_dst0);
-    } else {
-      glds16s<BUF * BUF_BYTES + WHICH * HALF_BYTES>(ob[WHICH & 1][0], sb, lean_dst0);
-      glds16s<BUF * BUF_BYTES + WHICH * HALF_BYTES + 8 * 1024>(ob[WHICH & 1][1], sb, lean_dst0);
-    }
-  };
   // piece I (0 / 1) of half-tile WHICH in two steps (M0, then the load) for the interleaved main loop
   auto piece_m0 = [&](auto bufc, auto whichc, auto ic) {
     constexpr int BUF = decltype(bufc)::value, WHICH = decltype(whichc)::value, I = decltype(ic)::value;
     glds_m0<BUF * BUF_BYTES + WHICH * HALF_BYTES + I * 8 * 1024>(lean_dst0);
   };
-  auto piece_go = [&](auto whichc, auto ic, const void* sb) {
-    constexpr int WHICH = decltype(whichc)::value, I = decltype(ic)::value;
-    glds_go((WHICH < 2) ? oa[WHICH & 1][I] : ob[WHICH & 1][I], sb);
+  auto piece_go = [&](uint32_t voff, const void* sb) { glds_go(voff, sb); };
+  const uint32_t himask = hi_half ? 0xffffffffu : 0u;      // lanes whose chunk lies in the second half of a K-tile
+  // prologue form: both pieces of half-tile WHICH of the K-tile whose halves start at element offsets k0 / k1
+  auto stage_lean = [&](auto bufc, auto whichc, int64_t k0, int64_t k1) {
+    constexpr int BUF = decltype(bufc)::value, WHICH = decltype(whichc)::value;
+    uint32_t extra = 0;
+    if constexpr (VIEW && KW == 0) extra = himask & (uint32_t)((k1 - k0 - 32) * 2);
+    const void* sb = (WHICH < 2) ? (const void*)(abase + k0) : (const void*)(bbase + k0);
+    const uint32_t o0 = ((WHICH < 2) ? oa[WHICH & 1][0] : ob[WHICH & 1][0]) + extra;
+    const uint32_t o1 = ((WHICH < 2) ? oa[WHICH & 1][1] : ob[WHICH & 1][1]) + extra;
+    glds16s<BUF * BUF_BYTES + WHICH * HALF_BYTES>(o0, sb, lean_dst0);
+    glds16s<BUF * BUF_BYTES + WHICH * HALF_BYTES + 8 * 1024>(o1, sb, lean_dst0);
   };
 
   // fragment read offsets inside a half-tile image (row base is a multiple of FROWS)
@@ -710,18 +712,25 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(NtArgs p) {
       if constexpr (VIEW && KW == 1) {
         wa.init_tiles(p.va, kfirst);
         wb.init_tiles(p.vb, kfirst);
+      } else if constexpr (VIEW && KW == 0) {
+        wa.init(p.va, kfirst);
+        wb.init(p.vb, kfirst);
       }
-      int64_t ka = 0, kb = 0, kc = 0, unused = 0;
-      walk(wa, ka, unused, 0);
-      walk(wb, kb, unused, 0);
-      issue_lean(I0{}, I0{}, ka);
-      issue_lean(I0{}, I1{}, ka);
-      issue_lean(I0{}, std::integral_constant<int, 2>{}, kb);
-      issue_lean(I0{}, std::integral_constant<int, 3>{}, kb);
+      int64_t ka = 0, ka1 = 0, kb = 0, kb1 = 0, kc = 0, kc1 = 0;
+      walk(wa, ka, ka1, 0);
+      walk(wb, kb, kb1, 0);
+      stage_lean(I0{}, I0{}, ka, ka1);
+      stage_lean(I0{}, I1{}, ka, ka1);
+      stage_lean(I0{}, std::integral_constant<int, 2>{}, kb, kb1);
+      stage_lean(I0{}, std::integral_constant<int, 3>{}, kb, kb1);
       if (nt > 1) {
-        walk(wb, kc, unused, 1);
-        issue_lean(I1{}, std::integral_constant<int, 2>{}, kc);
-        issue_lean(I1{}, std::integral_constant<int, 3>{}, kc);
+        walk(wb, kc, kc1, 1);
+        stage_lean(I1{}, std::integral_constant<int, 2>{}, kc, kc1);
+        stage_lean(I1{}, std::integral_constant<int, 3>{}, kc, kc1);
+      }
+      if constexpr (!VIEW || KW == 2) {       // running stage pointers: A one K-tile ahead, B two
+        a_next = abase + (int64_t)(kfirst + 1) * BK;
+        b_next = bbase + (int64_t)(kfirst + 2) * BK;
       }
       return;
     }
@@ -790,21 +799,35 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(NtArgs p) {
       using C1 = std::integral_constant<int, 1>;
       using C2 = std::integral_constant<int, 2>;
       using C3 = std::integral_constant<int, 3>;
-      const bool n1 = (t + 1 < nt), n2 = (t + 2 < nt);
+      const int left = nt - t;                 // K-tiles from this one on (scalar compares below, no lane masks)
       int64_t unused = 0;
       // ---- load segment 1: B sub-tiles 0 / 1 (8 reads), A sub-tile 0 (8 reads); A halves of K-tile t + 1 -> other buffer.
       // Every LDS-DMA piece is [M0 write] [one fragment read] [load]: the read is the wait state the M0 write needs.
       lean_read_b(IB{}, C0{});
       lean_read_b(IB{}, C1{});
-      if (n1) {
-        int64_t ka = 0;
-        walk(wa, ka, unused, t + 1);
-        const void* sb = (const void*)(abase + ka);
-        piece_m0(IO{}, C0{}, C0{}); lean_read_a1(IB{}, C0{}, C0{}); piece_go(C0{}, C0{}, sb); lean_read_a1(IB{}, C0{}, C1{});
-        piece_m0(IO{}, C0{}, C1{}); lean_read_a1(IB{}, C0{}, C2{}); piece_go(C0{}, C1{}, sb); lean_read_a1(IB{}, C0{}, C3{});
-        piece_m0(IO{}, C1{}, C0{}); lean_read_a1(IB{}, C0{}, std::integral_constant<int, 4>{}); piece_go(C1{}, C0{}, sb);
+      if (left > 1) {
+        const void* sb;
+        uint32_t v0 = oa[0][0], v1 = oa[0][1], v2 = oa[1][0], v3 = oa[1][1];
+        if constexpr (!VIEW || KW == 2) {
+          sb = (const void*)a_next;
+          a_next += BK;
+        } else {
+          int64_t ka = 0, ka1 = 0;
+          walk(wa, ka, ka1, t + 1);
+          sb = (const void*)(abase + ka);
+          if constexpr (KW == 0) {
+            const uint32_t d = (uint32_t)((ka1 - ka - 32) * 2);     // wave-uniform; 0 unless the halves come from two runs
+            if (d != 0) {
+              const uint32_t e = himask & d;
+              v0 += e; v1 += e; v2 += e; v3 += e;
+            }
+          }
+        }
+        piece_m0(IO{}, C0{}, C0{}); lean_read_a1(IB{}, C0{}, C0{}); piece_go(v0, sb); lean_read_a1(IB{}, C0{}, C1{});
+        piece_m0(IO{}, C0{}, C1{}); lean_read_a1(IB{}, C0{}, C2{}); piece_go(v1, sb); lean_read_a1(IB{}, C0{}, C3{});
+        piece_m0(IO{}, C1{}, C0{}); lean_read_a1(IB{}, C0{}, std::integral_constant<int, 4>{}); piece_go(v2, sb);
         lean_read_a1(IB{}, C0{}, std::integral_constant<int, 5>{});
-        piece_m0(IO{}, C1{}, C1{}); lean_read_a1(IB{}, C0{}, std::integral_constant<int, 6>{}); piece_go(C1{}, C1{}, sb);
+        piece_m0(IO{}, C1{}, C1{}); lean_read_a1(IB{}, C0{}, std::integral_constant<int, 6>{}); piece_go(v3, sb);
         lean_read_a1(IB{}, C0{}, std::integral_constant<int, 7>{});
       } else {
         lean_read_a(IB{}, C0{});
@@ -813,15 +836,29 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(NtArgs p) {
       mma_cluster(0, 0);
       TNH_SEG_MMA_END();
       // ---- load segment 2: A sub-tile 1 (8 reads); B halves of K-tile t + 2 -> this buffer
-      if (n2) {
-        int64_t kb = 0;
-        walk(wb, kb, unused, t + 2);
-        const void* sb = (const void*)(bbase + kb);
-        piece_m0(IB{}, C2{}, C0{}); lean_read_a1(IB{}, C1{}, C0{}); piece_go(C2{}, C0{}, sb); lean_read_a1(IB{}, C1{}, C1{});
-        piece_m0(IB{}, C2{}, C1{}); lean_read_a1(IB{}, C1{}, C2{}); piece_go(C2{}, C1{}, sb); lean_read_a1(IB{}, C1{}, C3{});
-        piece_m0(IB{}, C3{}, C0{}); lean_read_a1(IB{}, C1{}, std::integral_constant<int, 4>{}); piece_go(C3{}, C0{}, sb);
+      if (left > 2) {
+        const void* sb;
+        uint32_t v0 = ob[0][0], v1 = ob[0][1], v2 = ob[1][0], v3 = ob[1][1];
+        if constexpr (!VIEW || KW == 2) {
+          sb = (const void*)b_next;
+          b_next += BK;
+        } else {
+          int64_t kb = 0, kb1 = 0;
+          walk(wb, kb, kb1, t + 2);
+          sb = (const void*)(bbase + kb);
+          if constexpr (KW == 0) {
+            const uint32_t d = (uint32_t)((kb1 - kb - 32) * 2);
+            if (d != 0) {
+              const uint32_t e = himask & d;
+              v0 += e; v1 += e; v2 += e; v3 += e;
+            }
+          }
+        }
+        piece_m0(IB{}, C2{}, C0{}); lean_read_a1(IB{}, C1{}, C0{}); piece_go(v0, sb); lean_read_a1(IB{}, C1{}, C1{});
+        piece_m0(IB{}, C2{}, C1{}); lean_read_a1(IB{}, C1{}, C2{}); piece_go(v1, sb); lean_read_a1(IB{}, C1{}, C3{});
+        piece_m0(IB{}, C3{}, C0{}); lean_read_a1(IB{}, C1{}, std::integral_constant<int, 4>{}); piece_go(v2, sb);
         lean_read_a1(IB{}, C1{}, std::integral_constant<int, 5>{});
-        piece_m0(IB{}, C3{}, C1{}); lean_read_a1(IB{}, C1{}, std::integral_constant<int, 6>{}); piece_go(C3{}, C1{}, sb);
+        piece_m0(IB{}, C3{}, C1{}); lean_read_a1(IB{}, C1{}, std::integral_constant<int, 6>{}); piece_go(v3, sb);
         lean_read_a1(IB{}, C1{}, std::integral_constant<int, 7>{});
         asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
       } else {
@@ -1245,22 +1282,25 @@ static bool lean_wanted(const NtArgs& q) {
 //   1  rows ascend in memory (sr0 > 0 and, with two levels, sr1 >= the extent of an inner run of rows) and any 256
 //      consecutive rows plus a K-tile span < 4 GiB: offsets from the tile's first row;
 //   0  otherwise, if both strides are non-negative and the whole operand spans < 4 GiB: offsets from the operand's base.
-static bool lean_view_rows(NtArgs& q) {
+static bool lean_view_rows(NtArgs& q, bool half_walk = false) {
   static const int env = []() { const char* e = getenv("TNH_GEMM_LEAN"); return e ? atoi(e) : -1; }();
   const int mode = g_opt_lean >= 0 ? g_opt_lean : env;
   if (mode == 0) return false;
   const int64_t lim = int64_t(1) << 31;      // elements (2 bytes each)
   auto one = [&](const OpView& v, int64_t rows, int& rel) -> bool {
     if (v.sr0 <= 0) return false;
+    // half-K-tile walk: the lanes of a K-tile's second half add the distance between two contraction runs
+    const int64_t jump = half_walk ? (v.sk1 - (int64_t)v.tpi * 32) : 0;
+    if (jump < 0 || jump >= lim / 2) return false;
     const bool single = v.r0 >= rows;
     const int64_t inner = (v.r0 - 1) * v.sr0;
-    if (single || v.sr1 > inner) {           // ascending rows
+    if (mode != 2 && (single || v.sr1 > inner)) {           // ascending rows (knob ":l2" prefers the operand-base form: tests)
       const int64_t steps = single ? 0 : (255 / v.r0 + 2);
-      const int64_t span = (single ? 255 * v.sr0 : inner + steps * v.sr1) + 64;
+      const int64_t span = (single ? 255 * v.sr0 : inner + steps * v.sr1) + 64 + jump;
       if (span < lim) { rel = 1; return true; }
     }
     if (!single && v.sr1 < 0) return false;
-    const int64_t whole = (single ? (rows - 1) * v.sr0 : inner + ((rows - 1) / v.r0) * v.sr1) + 64;
+    const int64_t whole = (single ? (rows - 1) * v.sr0 : inner + ((rows - 1) / v.r0) * v.sr1) + 64 + jump;
     if (whole < lim) { rel = 0; return true; }
     return false;
   };
@@ -1312,14 +1352,16 @@ template <bool A_KM, bool B_KN>
 static void launch_pp_view_t(bool is_bf16, bool out_f32, dim3 grid, const NtArgs& q, int kw = 0) {
   const dim3 block(512);
   if constexpr (!A_KM && !B_KN) {
-    if (kw >= 1 && g_opt_phases != 7) {      // K-contiguous operands whose contraction runs allow a tile-granular walk
+    if (g_opt_phases != 7) {      // K-contiguous operands: the cheapest K walk they allow, in the lean loop where it applies
       // the lean loop: rows addressable as 32-bit offsets from a wave-uniform base (lean_view_rows)
       NtArgs ql = q;
-      const bool lean = lean_view_rows(ql);
+      const bool lean = lean_view_rows(ql, kw == 0);
 #define TNH_VIEW_KW(B16, O32)                                                                                              \
   do {                                                                                                                     \
     if (lean && kw == 2) hipLaunchKernelGGL((gemm_nt_pp_kernel<B16, O32, true, false, true, false, false, 3, 2>), grid, block, 0, stream(), ql); \
-    else if (lean) hipLaunchKernelGGL((gemm_nt_pp_kernel<B16, O32, true, false, true, false, false, 3, 1>), grid, block, 0, stream(), ql); \
+    else if (lean && kw == 1) hipLaunchKernelGGL((gemm_nt_pp_kernel<B16, O32, true, false, true, false, false, 3, 1>), grid, block, 0, stream(), ql); \
+    else if (lean) hipLaunchKernelGGL((gemm_nt_pp_kernel<B16, O32, true, false, true, false, false, 3, 0>), grid, block, 0, stream(), ql); \
+    else if (kw == 0) hipLaunchKernelGGL((gemm_nt_pp_kernel<B16, O32, true, false, true, false, false, 0, 0>), grid, block, 0, stream(), q); \
     else if (kw == 2) hipLaunchKernelGGL((gemm_nt_pp_kernel<B16, O32, true, false, true, false, false, 0, 2>), grid, block, 0, stream(), q); \
     else hipLaunchKernelGGL((gemm_nt_pp_kernel<B16, O32, true, false, true, false, false, 0, 1>), grid, block, 0, stream(), q);         \
   } while (0)

@@ -1475,6 +1475,8 @@ def test_gemm_view_k_walk_forms_are_bit_identical(hip, dtype):
       ((3584, 4, 64), (3840, 4, 64), ([1, 2], [1, 2])),              # one contiguous run of 256 each -> form 2
       ((14, 4, 256, 128), (15, 4, 256, 128), ([1, 3], [1, 3])),      # runs of 128 (two-level K and rows) -> form 1
       ((14, 4, 256, 96), (15, 4, 256, 96), ([1, 3], [1, 3])),        # runs of 96 = 3 halves -> form 0 only
+      ((14, 12, 256, 32), (15, 12, 256, 32), ([1, 3], [1, 3])),      # runs of 32: every K-tile takes its halves from two runs
+      ((3700, 320), (3600, 320), ([1], [1])),                        # ragged M / N edges, odd K-tile count
   ]
   for shape_a, shape_b, axes in cases:
     a = (rng.standard_normal(shape_a) / 8).astype(np.float32)
@@ -1486,7 +1488,7 @@ def test_gemm_view_k_walk_forms_are_bit_identical(hip, dtype):
       a, b = a.astype(np.float16), b.astype(np.float16)
       da, db = dev(hip, a), dev(hip, b)
     outs = {}
-    for knob in ("auto", "auto:l0", "auto:w1", "auto:w0"):
+    for knob in ("auto", "auto:l0", "auto:l2", "auto:w1", "auto:w0", "auto:w0:l0"):
       _lib.check(hip.lib.tnh_gemm_set_variant(knob.encode()))
       try:
         before = hip.permute_launches
@@ -1495,9 +1497,10 @@ def test_gemm_view_k_walk_forms_are_bit_identical(hip, dtype):
         assert "view_nt" in kernel and hip.permute_launches == before, (knob, kernel)
       finally:
         _lib.check(hip.lib.tnh_gemm_set_variant(b"auto"))
-    np.testing.assert_array_equal(outs["auto"], outs["auto:w0"])
-    np.testing.assert_array_equal(outs["auto:l0"], outs["auto:w0"])
-    np.testing.assert_array_equal(outs["auto:w1"], outs["auto:w0"])
+    # ":l0" = the loop of rounds 1-4, ":l2" = lean loop with lane offsets from the operand's base instead of the tile's
+    # first row, ":w<d>" = cap on the K-walk form
+    for knob in ("auto", "auto:l0", "auto:l2", "auto:w1", "auto:w0"):
+      np.testing.assert_array_equal(outs[knob], outs["auto:w0:l0"])
     hip.absorb_transposes = False
     try:
       ref_dev = np.asarray(hip.tensordot(da, db, axes))
