@@ -339,7 +339,9 @@ template <bool IS_BF16, bool OUT_F32, bool TWO, bool M32 = false, bool VIEW = fa
 __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(NtArgs p) {
   static_assert(KW == 0 || (VIEW && !A_KM && !B_KN), "the tile-granular K walks are for K-contiguous view operands");
   static_assert(!VIEW || (TWO && !M32), "view kernels use the 2-phase 16x16x32 schedule");
-  static_assert(SCHED == 0 || (TWO && !M32 && !A_KM && !B_KN), "the round-5 schedules: 16x16x32, K-contiguous operands");
+  static_assert(SCHED == 0 || (TWO && !M32), "the round-5 schedules are 16x16x32 schedules");
+  static_assert(SCHED == 0 || SCHED == 3 || (!A_KM && !B_KN), "one-cluster / snake: K-contiguous operands");
+  static_assert(!(A_KM || B_KN) || KW == 0, "k-major operands: half-K-tile walk");
   // SCHED = 3: the default two-cluster schedule with a LEAN main loop -- the same fragment reads, LDS-DMA pieces, MFMAs
   // and barriers, and about 50 fewer bookkeeping instructions per K-tile and wave (205 -> ~150): SADDR-form LDS-DMA
   // (one 64-bit scalar add per operand and K-tile instead of a 64-bit VALU add per piece; M0 written by one scalar add,
@@ -435,8 +437,13 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(NtArgs p) {
         }
         return r * ld;
       };
+      auto row_elems_km = [&](const OpView& v, int64_t c) -> int64_t {       // k-major: rows are the contiguous direction
+        const uint32_t c1 = (uint32_t)c / (uint32_t)v.r0, c0 = (uint32_t)c - c1 * (uint32_t)v.r0;
+        return (int64_t)c1 * v.sr1 + c0;
+      };
       const int64_t fa = m0 + p.m_off, la = p.M + p.m_off;
-      const int64_t a0 = p.lean_rel_a ? row_elems(p.va, p.lda, fa) : 0, b0 = p.lean_rel_b ? row_elems(p.vb, p.ldb, n0) : 0;
+      const int64_t a0 = !p.lean_rel_a ? 0 : (A_KM ? row_elems_km(p.va, fa) : row_elems(p.va, p.lda, fa));
+      const int64_t b0 = !p.lean_rel_b ? 0 : (B_KN ? row_elems_km(p.vb, n0) : row_elems(p.vb, p.ldb, n0));
       // (the tile's first row is the same for every lane: made scalar here so that the SADDR operand stays in SGPRs)
       abase = A + (((int64_t)__builtin_amdgcn_readfirstlane((int)(a0 >> 32)) << 32) |
                    (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)a0));
@@ -448,11 +455,30 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(NtArgs p) {
         for (int i = 0; i < 2; ++i) {
           const int trow = (i * 8 + wid) * 8 + lrow;
           const int lchunk = (lane & 7) ^ (trow & 7);
-          int64_t ra = fa + h * 128 + trow, rb = n0 + h * 128 + trow;
-          if (ra >= la) ra = la - 1;              // ragged edge: re-read the last row, never stored
-          if (rb >= p.N) rb = p.N - 1;
-          oa[h][i] = (uint32_t)((row_elems(p.va, p.lda, ra) - a0 + lchunk * 8) * 2);
-          ob[h][i] = (uint32_t)((row_elems(p.vb, p.ldb, rb) - b0 + lchunk * 8) * 2);
+          // k-major operand (stored [k][row], rows contiguous): piece i = k rows (i * 8 + wid) * 4 + (lane >> 4) of the
+          // K-tile (i.e. half i), 16-byte chunk of the half-tile's 128 rows as in src_ptr; its K offset comes per piece
+          const int krow = ((i * 8 + wid) * 4 + (lane >> 4)) & 31;
+          const int s16 = lane & 15;
+          const int hsw = (lane >> 4) | (((wid >> 1) & 1) << 2);
+          const int kchunk = ((((s16 >> 1) ^ hsw)) << 1) | (s16 & 1);
+          if constexpr (A_KM) {
+            int64_t col = fa + h * 128 + kchunk * 8;
+            if (col + 8 > la) col = la - 8;
+            oa[h][i] = (uint32_t)((row_elems_km(p.va, col) - a0 + (int64_t)krow * p.va.sk0) * 2);
+          } else {
+            int64_t ra = fa + h * 128 + trow;
+            if (ra >= la) ra = la - 1;              // ragged edge: re-read the last row, never stored
+            oa[h][i] = (uint32_t)((row_elems(p.va, p.lda, ra) - a0 + lchunk * 8) * 2);
+          }
+          if constexpr (B_KN) {
+            int64_t col = n0 + h * 128 + kchunk * 8;
+            if (col + 8 > p.N) col = p.N - 8;
+            ob[h][i] = (uint32_t)((row_elems_km(p.vb, col) - b0 + (int64_t)krow * p.vb.sk0) * 2);
+          } else {
+            int64_t rb = n0 + h * 128 + trow;
+            if (rb >= p.N) rb = p.N - 1;
+            ob[h][i] = (uint32_t)((row_elems(p.vb, p.ldb, rb) - b0 + lchunk * 8) * 2);
+          }
         }
       return;
     }
@@ -513,13 +539,20 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(NtArgs p) {
   // prologue form: both pieces of half-tile WHICH of the K-tile whose halves start at element offsets k0 / k1
   auto stage_lean = [&](auto bufc, auto whichc, int64_t k0, int64_t k1) {
     constexpr int BUF = decltype(bufc)::value, WHICH = decltype(whichc)::value;
-    uint32_t extra = 0;
-    if constexpr (VIEW && KW == 0) extra = himask & (uint32_t)((k1 - k0 - 32) * 2);
-    const void* sb = (WHICH < 2) ? (const void*)(abase + k0) : (const void*)(bbase + k0);
-    const uint32_t o0 = ((WHICH < 2) ? oa[WHICH & 1][0] : ob[WHICH & 1][0]) + extra;
-    const uint32_t o1 = ((WHICH < 2) ? oa[WHICH & 1][1] : ob[WHICH & 1][1]) + extra;
-    glds16s<BUF * BUF_BYTES + WHICH * HALF_BYTES>(o0, sb, lean_dst0);
-    glds16s<BUF * BUF_BYTES + WHICH * HALF_BYTES + 8 * 1024>(o1, sb, lean_dst0);
+    constexpr bool KMAJOR = (WHICH < 2) ? A_KM : B_KN;
+    const uint16_t* xb = (WHICH < 2) ? abase : bbase;
+    const uint32_t o0 = (WHICH < 2) ? oa[WHICH & 1][0] : ob[WHICH & 1][0];
+    const uint32_t o1 = (WHICH < 2) ? oa[WHICH & 1][1] : ob[WHICH & 1][1];
+    if constexpr (KMAJOR) {       // piece i is half i of the K-tile: its own scalar base
+      glds16s<BUF * BUF_BYTES + WHICH * HALF_BYTES>(o0, (const void*)(xb + k0), lean_dst0);
+      glds16s<BUF * BUF_BYTES + WHICH * HALF_BYTES + 8 * 1024>(o1, (const void*)(xb + k1), lean_dst0);
+    } else {
+      uint32_t extra = 0;
+      if constexpr (VIEW && KW == 0) extra = himask & (uint32_t)((k1 - k0 - 32) * 2);
+      const void* sb = (const void*)(xb + k0);
+      glds16s<BUF * BUF_BYTES + WHICH * HALF_BYTES>(o0 + extra, sb, lean_dst0);
+      glds16s<BUF * BUF_BYTES + WHICH * HALF_BYTES + 8 * 1024>(o1 + extra, sb, lean_dst0);
+    }
   };
 
   // fragment read offsets inside a half-tile image (row base is a multiple of FROWS)
@@ -791,8 +824,46 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(NtArgs p) {
 
   if constexpr (LEAN) {
     // the two-cluster schedule of the default loop (table in the kernel header), K-tile t in buffer B = t & 1, unrolled by two
+    // k-major operand(s): the same schedule, fragment reads through the tracked transposing / plain readers, the pieces
+    // of a k-major operand from two scalar bases (one per half of the K-tile), nothing interleaved
+    auto body_km = [&](auto bufc, int t) {
+      constexpr int B = decltype(bufc)::value;
+      using IB = std::integral_constant<int, B>;
+      using IO = std::integral_constant<int, B ^ 1>;
+      const char* cur = smem + B * BUF_BYTES;
+      const int left = nt - t;
+      read_a(cur, 0);
+      read_b(cur, 0);
+      read_b(cur, 1);
+      if (left > 1) {
+        int64_t k0 = 0, k1 = 0;
+        walk(wa, k0, k1, t + 1);
+        stage_lean(IO{}, std::integral_constant<int, 0>{}, k0, k1);
+        stage_lean(IO{}, std::integral_constant<int, 1>{}, k0, k1);
+      }
+      TNH_SEG_LOAD_END();
+      mma_cluster(0, 0);
+      TNH_SEG_MMA_END();
+      read_a(cur, 1);
+      if (left > 2) {
+        int64_t k0 = 0, k1 = 0;
+        walk(wb, k0, k1, t + 2);
+        stage_lean(IB{}, std::integral_constant<int, 2>{}, k0, k1);
+        stage_lean(IB{}, std::integral_constant<int, 3>{}, k0, k1);
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      TNH_SEG_LOAD_END();
+      mma_cluster(1, 1);
+      TNH_SEG_MMA_END();
+    };
     auto body = [&](auto bufc, int t) {
       constexpr int B = decltype(bufc)::value;
+      if constexpr (A_KM || B_KN) {
+        body_km(bufc, t);
+        return;
+      }
       using IB = std::integral_constant<int, B>;
       using IO = std::integral_constant<int, B ^ 1>;
       using C0 = std::integral_constant<int, 0>;
@@ -1282,15 +1353,16 @@ static bool lean_wanted(const NtArgs& q) {
 //   1  rows ascend in memory (sr0 > 0 and, with two levels, sr1 >= the extent of an inner run of rows) and any 256
 //      consecutive rows plus a K-tile span < 4 GiB: offsets from the tile's first row;
 //   0  otherwise, if both strides are non-negative and the whole operand spans < 4 GiB: offsets from the operand's base.
-static bool lean_view_rows(NtArgs& q, bool half_walk = false) {
+static bool lean_view_rows(NtArgs& q, bool half_walk = false, bool a_km = false, bool b_kn = false) {
   static const int env = []() { const char* e = getenv("TNH_GEMM_LEAN"); return e ? atoi(e) : -1; }();
   const int mode = g_opt_lean >= 0 ? g_opt_lean : env;
   if (mode == 0) return false;
   const int64_t lim = int64_t(1) << 31;      // elements (2 bytes each)
-  auto one = [&](const OpView& v, int64_t rows, int& rel) -> bool {
+  auto one = [&](const OpView& v, int64_t rows, int& rel, bool kmajor) -> bool {
     if (v.sr0 <= 0) return false;
-    // half-K-tile walk: the lanes of a K-tile's second half add the distance between two contraction runs
-    const int64_t jump = half_walk ? (v.sk1 - (int64_t)v.tpi * 32) : 0;
+    // K-contiguous operand, half-K-tile walk: the lanes of a K-tile's second half add the distance between two
+    // contraction runs; k-major operand: a lane's k row inside a half K-tile (each half has its own scalar base)
+    const int64_t jump = kmajor ? 32 * v.sk0 : (half_walk ? (v.sk1 - (int64_t)v.tpi * 32) : 0);
     if (jump < 0 || jump >= lim / 2) return false;
     const bool single = v.r0 >= rows;
     const int64_t inner = (v.r0 - 1) * v.sr0;
@@ -1304,7 +1376,7 @@ static bool lean_view_rows(NtArgs& q, bool half_walk = false) {
     if (whole < lim) { rel = 0; return true; }
     return false;
   };
-  return one(q.va, q.M + q.m_off, q.lean_rel_a) && one(q.vb, q.N, q.lean_rel_b);
+  return one(q.va, q.M + q.m_off, q.lean_rel_a, a_km) && one(q.vb, q.N, q.lean_rel_b, b_kn);
 }
 
 static int launch_pp(bool is_bf16, bool out_f32, bool two, NtArgs p, int64_t batch, bool m32 = false) {
@@ -1382,6 +1454,19 @@ static void launch_pp_view_t(bool is_bf16, bool out_f32, dim3 grid, const NtArgs
       } else {
         if (out_f32) hipLaunchKernelGGL((gemm_nt_pp_kernel<false, true, true, false, true, false, false, 1>), grid, block, 0, stream(), q);
         else hipLaunchKernelGGL((gemm_nt_pp_kernel<false, false, true, false, true, false, false, 1>), grid, block, 0, stream(), q);
+      }
+      return;
+    }
+  }
+  if constexpr (A_KM || B_KN) {
+    NtArgs ql = q;
+    if (g_opt_phases != 7 && lean_view_rows(ql, true, A_KM, B_KN)) {
+      if (is_bf16) {
+        if (out_f32) hipLaunchKernelGGL((gemm_nt_pp_kernel<true, true, true, false, true, A_KM, B_KN, 3, 0>), grid, block, 0, stream(), ql);
+        else hipLaunchKernelGGL((gemm_nt_pp_kernel<true, false, true, false, true, A_KM, B_KN, 3, 0>), grid, block, 0, stream(), ql);
+      } else {
+        if (out_f32) hipLaunchKernelGGL((gemm_nt_pp_kernel<false, true, true, false, true, A_KM, B_KN, 3, 0>), grid, block, 0, stream(), ql);
+        else hipLaunchKernelGGL((gemm_nt_pp_kernel<false, false, true, false, true, A_KM, B_KN, 3, 0>), grid, block, 0, stream(), ql);
       }
       return;
     }

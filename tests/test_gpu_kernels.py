@@ -1477,6 +1477,11 @@ def test_gemm_view_k_walk_forms_are_bit_identical(hip, dtype):
       ((14, 4, 256, 96), (15, 4, 256, 96), ([1, 3], [1, 3])),        # runs of 96 = 3 halves -> form 0 only
       ((14, 12, 256, 32), (15, 12, 256, 32), ([1, 3], [1, 3])),      # runs of 32: every K-tile takes its halves from two runs
       ((3700, 320), (3600, 320), ([1], [1])),                        # ragged M / N edges, odd K-tile count
+      # k-major operands (stored [k][row]): the lean loop stages each half of a K-tile from its own scalar base
+      ((14, 256, 2, 64), (2, 64, 15, 256), ([2, 3], [0, 1])),        # b k-major (config-2 L0)
+      ((2, 64, 14, 256), (15, 256, 2, 64), ([0, 1], [2, 3])),        # a k-major
+      ((2, 96, 14, 256), (2, 96, 15, 256), ([0, 1], [0, 1])),        # both k-major, runs of 96
+      ((4, 32, 15, 248), (4, 32, 15, 248), ([0, 1], [0, 1])),        # both k-major, ragged edges, runs of 32
   ]
   for shape_a, shape_b, axes in cases:
     a = (rng.standard_normal(shape_a) / 8).astype(np.float32)
@@ -1494,7 +1499,7 @@ def test_gemm_view_k_walk_forms_are_bit_identical(hip, dtype):
         before = hip.permute_launches
         outs[knob] = np.asarray(hip.tensordot(da, db, axes))
         kernel = hip.lib.tnh_gemm_last_kernel().decode()
-        assert "view_nt" in kernel and hip.permute_launches == before, (knob, kernel)
+        assert "view_" in kernel and hip.permute_launches == before, (knob, kernel)
       finally:
         _lib.check(hip.lib.tnh_gemm_set_variant(b"auto"))
     # ":l0" = the loop of rounds 1-4, ":l2" = lean loop with lane offsets from the operand's base instead of the tile's
