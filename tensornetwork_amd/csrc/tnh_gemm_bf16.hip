@@ -340,7 +340,7 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(NtArgs p) {
   static_assert(KW == 0 || (VIEW && !A_KM && !B_KN), "the tile-granular K walks are for K-contiguous view operands");
   static_assert(!VIEW || (TWO && !M32), "view kernels use the 2-phase 16x16x32 schedule");
   static_assert(SCHED == 0 || (TWO && !M32), "the round-5 schedules are 16x16x32 schedules");
-  static_assert(SCHED == 0 || SCHED == 3 || (!A_KM && !B_KN), "one-cluster / snake / no-priority: K-contiguous operands");
+  static_assert(SCHED == 0 || SCHED == 3 || (!A_KM && !B_KN), "one-cluster / snake: K-contiguous operands");
   static_assert(!(A_KM || B_KN) || KW == 0, "k-major operands: half-K-tile walk");
   // SCHED = 3: the default two-cluster schedule with a LEAN main loop -- the same fragment reads, LDS-DMA pieces, MFMAs
   // and barriers, and about 50 fewer bookkeeping instructions per K-tile and wave (205 -> ~150): SADDR-form LDS-DMA
@@ -350,8 +350,9 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(NtArgs p) {
   // Why: on this kernel every instruction the load segment issues costs ~0.06 % (the 62 extra instructions of the
   // general view walk cost 4.3 %: profiles/r05_gemm_headline_plain_vs_view.jsonl).  Needs single-level rows (plain NT,
   // or a view with KW = 2 whose rows are linear) and row offsets inside a tile below 4 GiB (host check).
-  constexpr bool LEAN = (SCHED == 3 || SCHED == 4);      // 4 (A/B knob ":l3"): the lean loop without s_setprio around the clusters
-  constexpr bool NOPRIO = (SCHED == 4);
+  constexpr bool LEAN = (SCHED == 3);
+  // (the lean loop without the s_setprio pair around its clusters measured the same to 0.1 %:
+  //  profiles/r05_gemm_setprio_ab.jsonl -- the pair stays)
   // (KW = 0 in the lean loop: the full chunk offset sits in the lane offsets as for KW >= 1, and in a K-tile whose halves
   //  come from two runs the lanes of the second half add the distance between the runs beyond 32 elements -- one v_and
   //  + four v_add per operand, in those K-tiles only)
@@ -686,7 +687,7 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(NtArgs p) {
   };
   // lean loop: both quadrants of A sub-tile `sa` under ONE s_setprio pair (same MFMA order as two mma_quadrant calls)
   auto mma_cluster = [&](int sa, int sb_first) {
-    if constexpr (!NOPRIO) __builtin_amdgcn_s_setprio(1);
+    __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
       const int sb = sb_first ^ q;
@@ -699,7 +700,7 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(NtArgs p) {
             if constexpr (!M32)
               acc[sa * 4 + i][sb * 2 + j] = mma16<IS_BF16>(bf[sb][ks][j], af[0][ks][i], acc[sa * 4 + i][sb * 2 + j]);
     }
-    if constexpr (!NOPRIO) __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_s_setprio(0);
   };
   // end of a load segment: retire this wave's LDS reads, then meet the other waves
 #define TNH_SEG_LOAD_END()                                  \
@@ -1399,7 +1400,6 @@ static int launch_pp(bool is_bf16, bool out_f32, bool two, NtArgs p, int64_t bat
 #define TNH_PP_LAUNCH(B16, O32)                                                                               \
   do {                                                                                                       \
     if (g_opt_phases == 7) hipLaunchKernelGGL((gemm_nt_pp_kernel<B16, O32, true, false, false, false, false, 1>), grid, block, 0, stream(), q); \
-    else if (lean && g_opt_lean == 3) hipLaunchKernelGGL((gemm_nt_pp_kernel<B16, O32, true, false, false, false, false, 4>), grid, block, 0, stream(), q); \
     else if (lean) hipLaunchKernelGGL((gemm_nt_pp_kernel<B16, O32, true, false, false, false, false, 3>), grid, block, 0, stream(), q); \
     else if (g_opt_phases == 8) hipLaunchKernelGGL((gemm_nt_pp_kernel<B16, O32, true, false, false, false, false, 2>), grid, block, 0, stream(), q); \
     else if (m32) hipLaunchKernelGGL((gemm_nt_pp_kernel<B16, O32, true, true>), grid, block, 0, stream(), q);      \
@@ -1432,8 +1432,7 @@ static void launch_pp_view_t(bool is_bf16, bool out_f32, dim3 grid, const NtArgs
       const bool lean = lean_view_rows(ql, kw == 0);
 #define TNH_VIEW_KW(B16, O32)                                                                                              \
   do {                                                                                                                     \
-    if (lean && kw == 2 && g_opt_lean == 3) hipLaunchKernelGGL((gemm_nt_pp_kernel<B16, O32, true, false, true, false, false, 4, 2>), grid, block, 0, stream(), ql); \
-    else if (lean && kw == 2) hipLaunchKernelGGL((gemm_nt_pp_kernel<B16, O32, true, false, true, false, false, 3, 2>), grid, block, 0, stream(), ql); \
+    if (lean && kw == 2) hipLaunchKernelGGL((gemm_nt_pp_kernel<B16, O32, true, false, true, false, false, 3, 2>), grid, block, 0, stream(), ql); \
     else if (lean && kw == 1) hipLaunchKernelGGL((gemm_nt_pp_kernel<B16, O32, true, false, true, false, false, 3, 1>), grid, block, 0, stream(), ql); \
     else if (lean) hipLaunchKernelGGL((gemm_nt_pp_kernel<B16, O32, true, false, true, false, false, 3, 0>), grid, block, 0, stream(), ql); \
     else if (kw == 0) hipLaunchKernelGGL((gemm_nt_pp_kernel<B16, O32, true, false, true, false, false, 0, 0>), grid, block, 0, stream(), q); \
