@@ -846,7 +846,12 @@ class HipBackend(BackendBase):
       # its 68 GB intermediates (30 - 1000 flop per byte) are permuted.
       if v is not None and t.nbytes > self.inplace_max_bytes:
         plain = v.sk0 == 1 and v.sr1 == 0 and v.sk1 == 0
-        if v.sk0 != 1 or (not plain and 2.0 * m * n * k > 2e4 * t.nbytes):
+        # (round 5: a K-contiguous two-level view whose inner contraction run is a multiple of 64 walks K tile by tile in
+        #  the lean loop; measured on config-2 L1 (profiles/r05_l1_gate.jsonl): D = 192 (2.7 GB) in place 1467-1477
+        #  TFLOP/s with ONE K1 launch against 1451 with two; D = 256 (8.6 GB, power-of-two strides) in place 1314-1319
+        #  against 1477 -- so only up to `inplace_strided_max_bytes`)
+        tile_walk = v.sk0 == 1 and v.k0 % 64 == 0 and self.inplace_strided_big and t.nbytes <= self.inplace_strided_max_bytes
+        if v.sk0 != 1 or (not plain and not tile_walk and 2.0 * m * n * k > 2e4 * t.nbytes):
           return None
       return v
 
@@ -1404,6 +1409,10 @@ class HipBackend(BackendBase):
   _svd_band_backoff = {}        # (dtype, mm, nn) -> (consecutive reports, calls still to skip)
 
   svd_band_backoff = True       # skip the band path for shapes that keep reporting (see svd's docstring)
+  inplace_strided_max_bytes = 4 << 30
+  inplace_strided_big = True    # tensordot: read K-contiguous two-level views above inplace_max_bytes in place when their
+                                # contraction runs are multiples of 64 (False: the round 2-4 gate copies them when the
+                                # product is compute-heavy)
 
   def svd_band_policy(self):
     """The band path's back-off state: {(dtype code, rows, cols): {"consecutive_reports", "calls_still_skipped"}} and
