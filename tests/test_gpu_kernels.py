@@ -126,6 +126,24 @@ def _gemm_case(hip, dtype, m, n, k, ta_, tb_, batch=None, variant="auto", rng=No
   return np.asarray(out), ref, kernel, np.sqrt(k)
 
 
+@pytest.fixture(autouse=True)
+def _kernel_tests_read_k_major_operands_in_place(request):
+  """The tests of this file exercise the KERNELS: the in-place k-major readers included.  The backend's default
+  policy (round 5) sends a compute-heavy product with a k-major operand through one K1 pass instead because that is
+  faster (`HipBackend.kmajor_inplace_penalty`, tested in test_k_major_operands_take_the_faster_lowering); it is
+  switched off here and restored afterwards."""
+  if "hip" not in request.fixturenames:
+    yield
+    return
+  be = request.getfixturevalue("hip")
+  keep = be.kmajor_inplace_penalty
+  be.kmajor_inplace_penalty = 0.0
+  try:
+    yield
+  finally:
+    be.kmajor_inplace_penalty = keep
+
+
 GEMM_TOL = {np.float32: 3e-6, np.float64: 1e-14, np.float16: 2e-3, ta.bfloat16: 1.6e-2,
             np.complex64: 3e-6, np.complex128: 1e-14}
 
@@ -1535,3 +1553,29 @@ def test_gemm_lean_main_loop_is_bit_identical(hip, dtype, m, n, k):
   np.testing.assert_array_equal(out["bf16_256pp:l0:g0"], out["bf16_256pp:l0"])
   tol = GEMM_TOL[dtype]
   np.testing.assert_allclose(out["bf16_256pp"], ref, rtol=tol, atol=tol * np.sqrt(k))
+
+
+def test_k_major_operands_take_the_faster_lowering(hip):
+  """Round 5 (profiles/r05_kmajor_gate_small.jsonl): with the lean NT loop, reading a k-major operand in place costs
+  a product ~10 %; the backend takes ONE K1 pass instead wherever that pass is cheaper (D = 96 and up of config-2 L0),
+  and keeps the in-place read for small products (D = 64).  Same values either way (bit-identical kernels)."""
+  hip.kmajor_inplace_penalty = type(hip).kmajor_inplace_penalty      # the default policy (the autouse fixture zeroed it)
+  rng = np.random.default_rng(5)
+  for D, want_permutes, want_kernel in ((64, 0, "bf16_view_nn"), (96, 1, "bf16_view_nt")):
+    a = orc.round_bf16(rng.standard_normal((D,) * 4) / D)
+    b = orc.round_bf16(rng.standard_normal((D,) * 4) / D)
+    da, db = hip.to_bfloat16(a), hip.to_bfloat16(b)
+    before = hip.permute_launches
+    got = np.asarray(hip.tensordot(da, db, [[2, 3], [0, 1]]))
+    kernel = hip.lib.tnh_gemm_last_kernel().decode()
+    assert hip.permute_launches - before == want_permutes and kernel.startswith(want_kernel), (D, kernel)
+    hip.kmajor_inplace_penalty = 0.0
+    try:
+      other = np.asarray(hip.tensordot(da, db, [[2, 3], [0, 1]]))
+      assert hip.lib.tnh_gemm_last_kernel().decode().startswith("bf16_view_nn")
+    finally:
+      hip.kmajor_inplace_penalty = type(hip).kmajor_inplace_penalty
+    np.testing.assert_array_equal(got.reshape(-1)[::97], other.reshape(-1)[::97])
+    if D == 64:
+      ref = np.tensordot(a.astype(np.float64), b.astype(np.float64), [[2, 3], [0, 1]])
+      np.testing.assert_allclose(got, ref, rtol=2.0**-8, atol=2e-3)

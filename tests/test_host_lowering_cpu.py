@@ -1000,3 +1000,19 @@ def test_complex_band_svd_cluster_branch_gives_the_same_decomposition(dtype):
   np.testing.assert_allclose(np.real(s), sr[:k], atol=tol * sr[0])
   np.testing.assert_allclose(u.conj().T @ u, np.eye(k), atol=20 * tol)
   np.testing.assert_allclose(a128 @ vh.conj().T, u * np.real(s), atol=40 * tol * sr[0])
+
+
+def test_k_major_cost_rule_on_the_emulated_backend():
+  """`HipBackend.kmajor_inplace_penalty` (round 5): a k-major operand is read in place only where ONE K1 pass would cost
+  more than a tenth of the product -- config-2 L0 at D = 64 stays in place (view_nn, no permute), D = 96 takes the
+  pass and the plain NT view; with the rule off both are read in place.  Launch bookkeeping on the emulated C ABI."""
+  rng = np.random.default_rng(2)
+  with emulated_backend() as be:
+    for D, rule, want in ((64, 0.10, 0), (96, 0.10, 1), (96, 0.0, 0)):
+      a = be.to_bfloat16(rng.standard_normal((D,) * 4).astype(np.float32) / D)
+      b = be.to_bfloat16(rng.standard_normal((D,) * 4).astype(np.float32) / D)
+      be.kmajor_inplace_penalty = rule
+      before = be.permute_launches
+      out = be.tensordot(a, b, [[2, 3], [0, 1]])
+      assert be.permute_launches - before == want, (D, rule)
+      assert out.shape == (D, D, D, D)
