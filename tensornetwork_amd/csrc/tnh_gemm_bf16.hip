@@ -1364,7 +1364,8 @@ static bool lean_view_rows(NtArgs& q, bool half_walk = false, bool a_km = false,
     if (v.sr0 <= 0) return false;
     // K-contiguous operand, half-K-tile walk: the lanes of a K-tile's second half add the distance between two
     // contraction runs; k-major operand: a lane's k row inside a half K-tile (each half has its own scalar base)
-    const int64_t jump = kmajor ? 32 * v.sk0 : (half_walk ? (v.sk1 - (int64_t)v.tpi * 32) : 0);
+    const bool one_run = (int64_t)v.tpi * 32 >= q.K;          // (sk1 is meaningless then: the walk never wraps)
+    const int64_t jump = kmajor ? 32 * v.sk0 : ((half_walk && !one_run) ? (v.sk1 - (int64_t)v.tpi * 32) : 0);
     if (jump < 0 || jump >= lim / 2) return false;
     const bool single = v.r0 >= rows;
     const int64_t inner = (v.r0 - 1) * v.sr0;

@@ -844,11 +844,12 @@ class HipBackend(BackendBase):
       # the copy is free (> 2e4 flop per operand byte: config-2 L1 at D = 256 runs 5 % slower on the strided `a`
       # than on its 3.7 ms copy).  Everything else is read in place: the MERA layer at chi = 32 loses 35 % when
       # its 68 GB intermediates (30 - 1000 flop per byte) are permuted.
-      # Round 5 (profiles/r05_kmajor_gate_small.jsonl, r05_kmajor_gate.jsonl): with the lean NT loop a k-major operand
-      # read in place costs the product ~10 % at every size measured (D = 96 / 128 L0: 1259 / 1330 TFLOP/s in place,
-      # 1360 / 1474 through ONE K1 pass; D = 192 / 256 / the D = 512 row: 1280 / 1190 / 1320 against 1504 / 1518 /
-      # 1366-1437); only where the pass would cost more than that (D = 64: a 0.1 ms product) does the in-place read
-      # win.  Estimate: 10 % of the product at 1.45 PFLOP/s against 2 x bytes at 5 TB/s + 6 us.
+      # Round 5 (profiles/r05_kmajor_gate_small.jsonl, r05_kmajor_gate.jsonl): with the lean loops a k-major operand
+      # read in place costs the GEMM ~10 % (D = 96 / 128 L0: 1264-1271 / 1336-1356 TFLOP/s in place, 1323-1336 /
+      # 1419-1421 through ONE K1 pass; D = 192 / 256 / the D = 512 row: 1233-1245 / 1176 / 1264-1283 against 1400 /
+      # 1384-1394 / 1353-1360); only where the pass would cost more than that (D = 64: a 0.1 ms product, 1299-1307
+      # against 1201-1203) does the in-place read win.  Estimate: 10 % of the product at 1.45 PFLOP/s against
+      # 2 x bytes at 5 TB/s + 6 us.
       if v is not None and v.sk0 != 1 and self.kmajor_inplace_penalty > 0.0:
         if self.kmajor_inplace_penalty * (2.0 * m * n * k / 1.45e15) > 2.0 * t.nbytes / 5.0e12 + 6.0e-6:
           return None

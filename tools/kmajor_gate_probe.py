@@ -13,6 +13,7 @@ def row(name, step, flops):
   for rep in range(2):
     for gate in (default_gate, 1 << 42):
       be.inplace_max_bytes = gate
+      be.kmajor_inplace_penalty = 0.0        # the size gate alone decides
       t, permutes = bench.timed_steps(be, step, 3, batches=1)
       print(json.dumps({"case": name, "gate_bytes": gate, "rep": rep, "ms": t * 1e3, "tflops": flops / t / 1e12,
                         "permute_launches": permutes, "kernel": be.lib.tnh_gemm_last_kernel().decode()}), flush=True)

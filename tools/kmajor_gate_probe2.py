@@ -11,6 +11,7 @@ for D in (64, 96, 128):
   for rep in range(2):
     for gate in (default_gate, 0):
       be.inplace_max_bytes = gate
+      be.kmajor_inplace_penalty = 0.0        # the size gate alone decides: in place (default gate) or ONE K1 pass (gate 0)
       t, permutes = bench.timed_steps(be, lambda: bench.one_step(ta, be, A, B, "L0"), 10, batches=3)
       print(json.dumps({"case": f"D{D}_L0", "gate_bytes": gate, "rep": rep, "ms": t * 1e3, "tflops": 2.0 * D**6 / t / 1e12,
                         "permute_launches": permutes, "kernel": be.lib.tnh_gemm_last_kernel().decode()}), flush=True)
