@@ -7,7 +7,8 @@ Workload at N=1 (BASELINE.json configs[1]): ``contract_between`` of two rank-4
 bf16 nodes with two shared bonds of dimension D=256 (layout L0: a[2]^b[0],
 a[3]^b[1]) -> one 65536^3 GEMM on the MFMA path, operands generated in HBM.
 A "step" is one such contract_between through the product path
-(Node bookkeeping -> HipBackend.tensordot -> tnh_gemm_view: both operands read in place).
+(Node bookkeeping -> HipBackend.tensordot -> ONE K1 pass over the k-major operand `b` -> tnh_gemm_view: the lean
+ping-pong kernel on two K-contiguous views).
 ``value`` = 2*M*N*K*steps / wall time, TFLOP/s, inputs resident in HBM.
 
 N>1 (one process per GPU; RCCL through libtnhip's own K8 entry points for the barrier, the
@@ -25,8 +26,10 @@ Extra objects on the same line:
                     device operands; configs[2] at 4096^2 vs LAPACK (all 4096 singular values incl. s_rest,
                     orthonormality, reconstruction vs the best rank-k error); the bf16 sliced network vs an f32
                     run of the same tensors; the MERA layer at chi = 16 vs the float64 oracle.
-  cpu_baseline   -- the NumPy oracle (port of the reference's tensordot) timed on this box's host cores on a
-                    bounded sample (same layout, smaller D).
+  cpu_baseline   -- the NumPy oracle (port of the reference's tensordot; `kind: "port"`) timed on this box's host cores
+                    on a bounded sample (same layout, smaller D) -- or, when the builder shipped the reference beside
+                    the repo for the call (TN_REFERENCE_DIR), google/TensorNetwork's own contract_between on its NumPy
+                    backend (`kind: "reference"`).
   svd            -- split_node truncated SVD (configs[2]: (16,)*6 node -> 4096 x 4096, keep 256) in the metric's
                     GB/s; `sweep` holds SURVEY 8d's full case list: Gaussian and s_i = 2^(-i/32) inputs, natural and
                     mixed edge order, n = 512 .. 4096, each checked against LAPACK (verified.svd), plus one row per
@@ -42,19 +45,22 @@ Extra objects on the same line:
   mps_chain      -- configs[3]: <psi|psi> of a 16-site MPS, bulk D = 512, contractors.greedy (d = 2 and d = 4;
                     eager and hipGraph replay) with the NumPy oracle backend's time beside it.
   mera           -- configs[4] shape on one GPU: binary-MERA layer energy at chi = 32 (68.7 GB intermediate).
-  mera_chi64     -- configs[4] at chi = 64: `--mera64-full` placements (default 1 of 2) run in full (all 4096 slices;
-                    partial contractions that depend on one slice index only are computed once per value of that index:
-                    `measured_*` with the EXECUTED flops), the rest as per-slice cost x slice count (labelled
-                    extrapolated: one slice contracted on its own x 4096).
+  mera_chi64     -- configs[4] at chi = 64: `--mera64-full` placements (default 1 of 2) run in full -- all 4096 slices that
+                    `slice_edge` on one leg of the hamiltonian and one leg of the state leaves (BOTH tensors on a cut
+                    leg sliced), through the machinery of contract_sliced; a step runs once per distinct value of the
+                    cuts it depends on: `measured_*` with the EXECUTED flops = the dense-optimal cost of the network
+                    -- the rest as per-slice cost x slice count (labelled extrapolated: one slice alone x 4096).
   helpers        -- HBM-bound helper kernels (K1 permute, K3/K4 reductions, K5 scaling) in GB/s vs 8 TB/s.
   gather_gemm    -- one product of the D = 12 network (a 144 x 144 tensor takes two bonds off a 430 M-element rank-8
                     intermediate) for five placements of the contracted axes + the K = 1728 product: `tnh_gemm_gather`
                     against permute + streaming GEMM, both operand orders, device-side equality check.
-  sliced_network -- the north-star scaling network (64-node random 3-regular graph, bond D, bf16):
-                    bond-sliced greedy contraction, slices dealt over the N ranks, ONE all-reduce of
-                    the scalar (strong scaling: fixed total work); per-rank compute and all-reduce times.  Every step
-                    of the path runs once per distinct value of the cut bonds it depends on (`mode`); `tflops` counts
-                    the executed flops, `flops_if_every_slice_ran_alone` is what 144 stand-alone slices would cost.
+  sliced_network -- the north-star scaling network (64-node random 3-regular graph, bond D = 16 from round 5 on: the 16
+                    values of the costly cut divide evenly among 2 / 4 / 8 ranks; bf16): bond-sliced greedy contraction,
+                    slices dealt over the N ranks (`distributed._StagePlan.partition`), ONE all-reduce of the scalar
+                    (strong scaling: fixed total work); per-rank compute and all-reduce times.  Every step of the path
+                    runs once per distinct value of the cut bonds it depends on (`mode`); `tflops` counts the executed
+                    flops as the run itself counted them (summed over ranks), `flops_if_every_slice_ran_alone` is what
+                    the stand-alone slices would cost.  `sliced_network_small`: the D = 12 instance of rounds 1-4 (N = 1).
 """
 import argparse
 import json
