@@ -307,11 +307,15 @@ class _StagePlan:
     return sorted(slices, key=lambda idx: tuple(idx[k] for k in order))
 
   def partition(self, slices, world: int):
-    """The slices dealt to `world` ranks: contiguous blocks of the slices sorted with one cut varying slowest,
-    either balanced (sizes differ by at most one) or of ceil(n / world) slices each; of all loop orders (at most 24
-    tried, the weight order first) x the two block rules the one whose SLOWEST rank has the smallest estimated time
-    (`seconds_with_reuse`), then the smallest sum.  Pure host arithmetic on the plan: every rank computes the same blocks.
-    A rank's block may be empty (fewer slices than ranks)."""
+    """The slices dealt to `world` ranks.  Candidates: (1) contiguous blocks of the slices sorted with one cut varying
+    slowest, either balanced (sizes differ by at most one) or of ceil(n / world) slices each, for all loop orders (at
+    most 24 tried, the weight order first); (2) when `slices` is the full product of the cuts' ranges, GRIDS: world =
+    w_0 x w_1 x ..., cut k's range split into w_k balanced sub-ranges, one rank per cell (a rank then repeats only
+    d_k / w_k values of every single-cut class and keeps as many results: the chi = 64 MERA placement on 8 ranks as
+    4 x 2 keeps 32 results of 2 GB per rank instead of 64).  Chosen: the candidate whose SLOWEST rank has the smallest
+    estimated time (`seconds_with_reuse`), then the smallest sum, then the earlier candidate (a grid only replaces
+    contiguous blocks when it is strictly better).  Pure host arithmetic on the plan: every rank computes the same
+    blocks.  A rank's block may be empty (fewer slices than ranks)."""
     slices = list(slices)
     world = max(int(world), 1)
     if world == 1:
@@ -336,7 +340,40 @@ class _StagePlan:
         key = (max(loads), sum(loads))
         if best is None or key < best[0]:
           best = (key, blocks)
+    full = len(self.dims) > 1 and len(slices) == int(np.prod(self.dims)) and \
+        set(slices) == set(itertools.product(*[range(d) for d in self.dims]))
+    if full:
+      for grid in self._grids(world):
+        if sum(1 for w in grid if w > 1) < 2:
+          continue                     # one cut split only: the contiguous blocks above
+        ranges = []
+        for d, w in zip(self.dims, grid):
+          base, extra = divmod(d, w)
+          edges = [0]
+          for r in range(w):
+            edges.append(edges[-1] + base + (1 if r < extra else 0))
+          ranges.append([range(edges[r], edges[r + 1]) for r in range(w)])
+        blocks = [self.ordered(list(itertools.product(*cell))) for cell in itertools.product(*ranges)]
+        loads = [self.seconds_with_reuse(b) for b in blocks]
+        key = (max(loads), sum(loads))
+        if key < best[0]:
+          best = (key, blocks)
     return best[1]
+
+  def _grids(self, world: int):
+    """factorisations of `world` over the cuts, factor k at most the cut's dimension"""
+    out = []
+
+    def rec(k, left, acc):
+      if k == len(self.dims):
+        if left == 1:
+          out.append(tuple(acc))
+        return
+      for w in range(1, min(left, self.dims[k]) + 1):
+        if left % w == 0:
+          rec(k + 1, left // w, acc + [w])
+    rec(0, world, [])
+    return out
 
 
 def _itemsize(t) -> int:
@@ -444,31 +481,38 @@ def _contract_slices_staged(be, nodes, plan: _StagePlan, slices, output_edge_ord
 
   want = [id(e) for e in output_edge_order] if output_edge_order is not None else None
   total, narrow, done = None, None, 0
-  for idx in slices:
-    tensor, labels = stage(plan.dep[plan.final], idx)[plan.final]
-    if want is None:
-      want = list(labels)      # no order asked for: the first slice's (the label order a backend returns may depend
-                               # on operand alignment; every later partial is brought to the same one before it is added)
-    if list(labels) != want:
-      tensor = be.transpose(tensor, tuple(list(labels).index(lab) for lab in want))
-    part, narrow = _widen(be, tensor)
-    if partials_out is not None:
-      partials_out.append(np.asarray(part, dtype=np.float64).copy())
-    total = be.multiply(part, 1.0) if total is None else be.addition(total, part)
-    done += 1
-    if not reuse:
-      for kept in cache.values():
-        kept.clear()
-      sliced_inputs.clear()
-    if on_slice is not None and on_slice(done, idx, tensor):
-      break
-  if stats is not None:
-    stats["stage_runs"] = {",".join(str(k) for k in sorted(c)) or "-": r for c, r in runs.items()}
-    stats["executed_macs"] = sum(plan.class_macs[c] * r for c, r in runs.items())
-    stats["slices_done"] = done
-    stats["classes_kept_for_all_values"] = {",".join(str(k) for k in sorted(c)) or "-": bool(v) for c, v in keep_all.items()}
-    stats["classes_revisited"] = {",".join(str(k) for k in sorted(c)) or "-": bool(v) for c, v in revisited.items()}
-  return total, narrow
+  try:
+    for idx in slices:
+      tensor, labels = stage(plan.dep[plan.final], idx)[plan.final]
+      if want is None:
+        want = list(labels)      # no order asked for: the first slice's (the label order a backend returns may depend
+                                 # on operand alignment; every later partial is brought to the same one before it is added)
+      if list(labels) != want:
+        tensor = be.transpose(tensor, tuple(list(labels).index(lab) for lab in want))
+      part, narrow = _widen(be, tensor)
+      if partials_out is not None:
+        partials_out.append(np.asarray(part, dtype=np.float64).copy())
+      total = be.multiply(part, 1.0) if total is None else be.addition(total, part)
+      done += 1
+      if not reuse:
+        for kept in cache.values():
+          kept.clear()
+        sliced_inputs.clear()
+      if on_slice is not None and on_slice(done, idx, tensor):
+        break
+    if stats is not None:
+      stats["stage_runs"] = {",".join(str(k) for k in sorted(c)) or "-": r for c, r in runs.items()}
+      stats["executed_macs"] = sum(plan.class_macs[c] * r for c, r in runs.items())
+      stats["slices_done"] = done
+      stats["classes_kept_for_all_values"] = {",".join(str(k) for k in sorted(c)) or "-": bool(v) for c, v in keep_all.items()}
+      stats["classes_revisited"] = {",".join(str(k) for k in sorted(c)) or "-": bool(v) for c, v in revisited.items()}
+    return total, narrow
+  finally:
+    # `stage` refers to itself (a reference cycle through its closure): without this the kept results -- up to 60 % of
+    # the HBM -- would stay allocated until the cyclic collector runs, and the next call would size its cache on what is left
+    for kept in cache.values():
+      kept.clear()
+    sliced_inputs.clear()
 
 
 def contract_sliced(nodes: Sequence[network.Node], cut_edges: Sequence[network.Edge],

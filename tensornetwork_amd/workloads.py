@@ -369,9 +369,10 @@ def mera_sliced_run(be, chi: int, placement: str, half_dtype, seed: int = 40, bu
   sliced) through `distributed._contract_slices_staged`, partial energies added in f32 on the device (one read-back).
 
   reuse_partials (default): every step runs once per distinct value of the cuts it depends on; the results of a class
-  of steps are kept for all its values when they fit in `distributed.STAGE_CACHE_BYTES` (chi = 64: the steps that
-  depend on ONE cut -- 64 results of 33 MB each -- stay; the class that depends on both is 98 % of the executed
-  multiply-adds and runs in every slice).  False: every step in every slice.  `executed_macs` counts what RAN.
+  of steps whose values come back are kept for all of them when they fit the cache budget (60 % of the free HBM; chi =
+  64: the class that depends on the FAST cut alone -- 64 results of 2 GB -- stays, the slow cut's class changes once per
+  64 slices and keeps the result in use only; the class that depends on both is 98 % of the executed multiply-adds and
+  runs in every slice).  False: every step in every slice.  `executed_macs` counts what RAN.
 
   budget_seconds: stop after the first slice that ends beyond it (checked every 16 slices; the record says how many
   slices ran).  check_every: every that many slices the same slice is also contracted alone in f32 on the same

@@ -703,6 +703,63 @@ def test_partition_minimises_the_slowest_rank_and_is_rank_independent():
     assert max(plan.seconds_with_reuse(b) for b in blocks) <= max(plan.seconds_with_reuse(b) for b in old) * (1 + 1e-12)
 
 
+def test_partition_takes_a_grid_where_two_single_cut_classes_cost_something():
+  """The chi = 64 MERA placement (shapes only): the classes that depend on ONE cut are 1.5 % of the work each way, a rank
+  of 8 that owns 8 values of the slow cut and all 64 of the fast one repeats the fast cut's class 64 times (ideal 7.60x,
+  64 results of 2 GB kept); the 4 x 2 grid repeats 16 + 32 (ideal 7.71x, 32 results kept).  `partition` must find it, keep
+  every slice exactly once, and stay with contiguous blocks where a grid is not strictly better (4 ranks: a tie)."""
+  import itertools  # pylint: disable=import-outside-toplevel
+  from tensornetwork_amd import workloads  # pylint: disable=import-outside-toplevel
+  plan = workloads._mera_slice_plan(64, "left")["stage"]      # pylint: disable=protected-access
+  every = plan.ordered(list(itertools.product(range(64), range(64))))
+  ideal = lambda blocks: plan.macs_with_reuse(every) / max(plan.macs_with_reuse(b) for b in blocks)
+  b8 = plan.partition(every, 8)
+  assert sorted(x for b in b8 for x in b) == sorted(every) and [len(b) for b in b8] == [512] * 8
+  assert sorted({len({i for i, _ in b}) for b in b8}) == [16] and sorted({len({j for _, j in b}) for b in b8}) == [32]
+  assert 7.70 < ideal(b8) < 7.72
+  b4 = plan.partition(every, 4)
+  assert all(len({i for i, _ in b}) == 16 and len({j for _, j in b}) == 64 for b in b4)      # contiguous blocks (tie)
+  # a subset of the slices (not the full product): contiguous blocks only
+  sub = [s for s in every if s[0] < 5]
+  bs = plan.partition(sub, 8)
+  assert sorted(x for b in bs for x in b) == sorted(sub)
+  assert plan._grids(8) == [(1, 8), (2, 4), (4, 2), (8, 1)]      # pylint: disable=protected-access
+
+
+def test_staged_contraction_releases_what_it_kept_when_it_returns():
+  """`stage` in `_contract_slices_staged` is a closure that refers to itself: the results it kept would wait for the
+  cyclic collector (up to 60 % of the HBM; the next call would size its cache on the rest -- seen in the 8-rank
+  rehearsal of the chi = 64 MERA placement, profiles/r05_mera_rank_share_rehearsal.jsonl).  They are dropped
+  explicitly: with the collector switched off, the tensors a call kept are gone when it has returned."""
+  import gc  # pylint: disable=import-outside-toplevel
+  import weakref  # pylint: disable=import-outside-toplevel
+  be = OracleBackend()
+  nodes = regular_network(be, n=10, D=3, seed=4)
+  cuts = distributed.choose_cut_edges(nodes, min_slices=9)
+  seen = []
+  orig = contractors.contract_labelled
+
+  class Arr(np.ndarray):      # ndarray subclass: weak-referenceable
+    pass
+
+  def spy(be_, operands, steps, label_time=None):
+    out = orig(be_, operands, steps, label_time)
+    out = {k: (np.asarray(t).view(Arr), labs) for k, (t, labs) in out.items()}
+    seen.extend(weakref.ref(t) for t, _ in out.values())
+    return out
+  gc.collect()
+  gc.disable()
+  try:
+    contractors.contract_labelled = spy
+    want = distributed.contract_sliced(nodes, cuts, reuse=True)
+    alive = sum(1 for r in seen if r() is not None)
+  finally:
+    contractors.contract_labelled = orig
+    gc.enable()
+  assert seen and alive <= 1, (alive, len(seen))            # at most the tensor the result is a view of
+  np.testing.assert_allclose(np.asarray(want), np.asarray(distributed.contract_sliced(nodes, cuts, reuse=False)), rtol=1e-10)
+
+
 def test_cut_selection_prefers_the_faster_set_not_the_fewest_multiply_adds():
   """Round-5 measurement (profiles/r05_rr_scaling_rehearsal.jsonl): on the D = 12 64-node network the cut pair with
   the fewest executed multiply-adds (1.73e13) ran 3.4x slower on the GPU than the sequential rule's pair (2.18e13):
