@@ -914,6 +914,28 @@ def test_mera_sliced_run_reuses_partial_contractions(placement):
   assert 0 < short["slices_done"] < 36 and short["stage_runs"]["ij"] == short["slices_done"]
 
 
+def test_mera_sliced_layer_on_a_grid_of_ranks():
+  """`_StagePlan.partition` deals the chi^2 slices of a MERA placement to 4 ranks as a 2 x 2 grid (two cut values each
+  way per rank): every rank's share through `_contract_slices_staged` executes exactly what the model says, and the rank
+  partials add up to the energy of all slices (f32: the same slice results, summed in another grouping)."""
+  from tensornetwork_amd import workloads  # pylint: disable=import-outside-toplevel
+  chi = 4
+  with emulated_backend() as be:
+    layer = workloads.MeraSlicedLayer(be, chi, "left", np.float32)
+    every = layer.all_slices()
+    blocks = layer.stage.partition(every, 4)
+    assert [(len({i for i, _ in b}), len({j for _, j in b})) for b in blocks] == [(2, 2)] * 4
+    assert sorted(x for b in blocks for x in b) == sorted(every)
+    whole = float(np.asarray(layer.contract(every), dtype=np.float64).reshape(-1)[0])
+    parts = []
+    for block in blocks:
+      st = {}
+      parts.append(float(np.asarray(layer.contract(block, stats=st), dtype=np.float64).reshape(-1)[0]))
+      assert st["executed_macs"] == layer.stage.macs_with_reuse(block) and st["slices_done"] == 4
+      assert st["stage_runs"] == {"-": 1, "0": 2, "1": 2, "0,1": 4}
+  assert abs(sum(parts) - whole) <= 1e-5 * max(1.0, abs(whole))
+
+
 def test_bench_mera_chi64_leg_on_the_emulated_backend():
   """bench.py's mera_chi64 leg at chi = 4 with both placements run: the record distinguishes the measured run (partial
   results reused) from the per-slice extrapolation and counts the executed flops."""
