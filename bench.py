@@ -1007,6 +1007,23 @@ def mera_chi64_bench(ta, be, n_gpus=8, verify=False, full_placements=0, budget_s
                              "figure stays arithmetic (no 8-GPU node on the builder's side)")
     if verify:
       rec.setdefault("verified_runs", {pl: m.get("checks_vs_f32") for pl, m in measured.items()})
+    # the same placement on n_gpus ranks: host arithmetic on the plan (which slices each rank gets, what it executes) --
+    # a MODEL row; the one-GPU rehearsal of all 8 shares is profiles/r05_mera_rank_share_rehearsal.jsonl (7.63x of 7.71x)
+    try:
+      import itertools  # pylint: disable=import-outside-toplevel
+      pl0 = next(iter(measured))
+      stage = workloads._mera_slice_plan(chi, pl0)["stage"]      # pylint: disable=protected-access
+      every = list(itertools.product(range(chi), range(chi)))
+      blocks = stage.partition(every, n_gpus)
+      ideal = stage.macs_with_reuse(every) / max(stage.macs_with_reuse(b) for b in blocks)
+      if measured[pl0]["slices_done"] == measured[pl0]["n_slices"]:
+        rec["ranks_model"] = {"world": n_gpus, "ideal_speedup_of_the_partition": ideal,
+                              "cut_values_per_rank": [len({i for i, _ in blocks[0]}), len({j for _, j in blocks[0]})],
+                              "seconds_per_placement_at_ideal": measured[pl0]["seconds"] / ideal,
+                              "label": "MODEL (slowest rank's executed multiply-adds); rehearsed on one GPU by "
+                                       "tools/mera_rank_share_rehearsal.py"}
+    except Exception as exc:  # pylint: disable=broad-except
+      rec["ranks_model_error"] = f"{type(exc).__name__}: {exc}"[:200]
   if checked is not None:
     rec["verified"] = checked
   return rec
