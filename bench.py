@@ -1371,6 +1371,14 @@ def main():
   import tensornetwork_amd as ta  # pylint: disable=import-outside-toplevel
   from tensornetwork_amd import _lib, telemetry  # pylint: disable=import-outside-toplevel
 
+  # Everything the legs import goes in BEFORE the freeze: a collector pass walks what was created after it, and
+  # `import networkx` alone (workloads.random_regular_graph's optional dependency) is 21.7k objects = 1.3 ms per pass
+  # on the MI355X box (profiles/r05_alloc_gc_probe.md)
+  from tensornetwork_amd import contractors, distributed, pathfinder, workloads  # pylint: disable=import-outside-toplevel,unused-import
+  try:
+    import networkx  # pylint: disable=import-outside-toplevel,unused-import
+  except ImportError:
+    pass
   ta.configure_gc(freeze=True)      # this process is ours: opt in to the frozen-baseline collector policy
   be = ta.get_hip_backend()
   be.lib  # pylint: disable=pointless-statement
@@ -1448,7 +1456,7 @@ def main():
     except Exception as exc:  # pylint: disable=broad-except
       verified["headline"] = {"error": f"{type(exc).__name__}: {exc}"}
   del out, A, B
-  _lib.check(be.lib.tnh_trim())
+  ta.trim_pool()
   if args.rr_bond > 0:
     fenced(result, "sliced_network", lambda: sliced_network_bench(ta, be, comm, rank, world, args.rr_bond, args.rr_min_slices,
                                                                   not args.no_verify))
@@ -1461,32 +1469,33 @@ def main():
   if rank == 0:
     single = world == 1
     if single and not args.no_sweep:
+      ta.trim_pool()
       try:
         result["bond_sweep"], checks = bond_sweep(ta, be, not args.no_verify)
         verified.update(checks)
       except Exception as exc:  # pylint: disable=broad-except
         result["bond_sweep"] = {"error": f"{type(exc).__name__}: {exc}"}
-      _lib.check(be.lib.tnh_trim())
+      ta.trim_pool()
       fenced(result, "dtype_sweep", lambda: dtype_sweep(ta, be))
-      _lib.check(be.lib.tnh_trim())
+      ta.trim_pool()
     if single and args.mera_chi > 0:
       fenced(result, "mera", lambda: mera_bench(ta, be, args.mera_chi, verify=not args.no_verify))
       if isinstance(result["mera"], dict) and "verified" in result["mera"]:
         verified[f"mera_chi{args.mera_chi}_bf16_vs_f32"] = result["mera"].pop("verified")
-      _lib.check(be.lib.tnh_trim())
+      ta.trim_pool()
     if single and not args.no_extras:
       fenced(result, "mera_chi64", lambda: mera_chi64_bench(ta, be, verify=not args.no_verify,
                                                             full_placements=args.mera64_full, budget_s=args.mera64_budget))
       if isinstance(result["mera_chi64"], dict) and "verified" in result["mera_chi64"]:
         verified["mera_chi64_real_slices_bf16_vs_f32"] = result["mera_chi64"].pop("verified")
-      _lib.check(be.lib.tnh_trim())
+      ta.trim_pool()
       fenced(result, "mps_chain", lambda: mps_chain_bench(ta, be, not args.no_cpu_baseline))
       fenced(result, "helpers", lambda: helpers_bench(ta, be))
-      _lib.check(be.lib.tnh_trim())
+      ta.trim_pool()
       fenced(result, "gather_gemm", lambda: gather_gemm_bench(ta, be, not args.no_verify))
       if isinstance(result["gather_gemm"], dict) and "verified" in result["gather_gemm"]:
         verified["gather_gemm_equals_permute_plus_gemm"] = result["gather_gemm"].pop("verified")
-      _lib.check(be.lib.tnh_trim())
+      ta.trim_pool()
     if single and args.svd_n > 0:
       try:
         head, rows, chk = svd_sweep(ta, be, args.svd_n, not args.no_verify)

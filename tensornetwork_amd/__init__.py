@@ -11,7 +11,8 @@ Compute lives in ``libtnhip.so`` (hand-written HIP kernels, C ABI in
 ``include/tnh.h``); there is no CPU fallback.
 """
 from tensornetwork_amd._lib import HipRuntimeError
-from tensornetwork_amd.device_tensor import DeviceTensor, bfloat16, round_to_bf16, configure_gc
+from tensornetwork_amd.device_tensor import DeviceTensor, bfloat16, round_to_bf16, configure_gc, gc_stats
+from tensornetwork_amd.device_tensor import trim as trim_pool
 from tensornetwork_amd.hip_backend import (HipBackend, get_hip_backend,
                                            register_with_tensornetwork)
 from tensornetwork_amd.ncon import (ncon, einsum, DefaultBackend, set_default_backend,

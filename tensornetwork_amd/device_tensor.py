@@ -121,10 +121,29 @@ def round_to_bf16(x):
 # -- `configure_gc(freeze=True)`, `HipBackend(manage_gc=True)` or TNH_GC_FREEZE=1; bench.py does -- and
 # `import tensornetwork_amd` alone never calls it.  Without it the first pass-cost estimate is 30 ms, i.e. the
 # allocator collects in front of requests of about 1 GiB and more and measures from there.
+# Amortised passes (round 5).  A pass walks every tracked object created since the freeze, and a launch loop is
+# asynchronous only while the host's share of a step stays below the GPU's: measured on the MI355X box
+# (tools/alloc_gc_probe.py, profiles/r05_alloc_gc_probe.md), the D = 96 contraction (1.15 ms of GPU time, one 170 MB
+# result per step) ran at 1364 TFLOP/s in a fresh process and at 1028 after `import networkx` had put 21.7k objects
+# behind the freeze: 1.3 ms per pass, one pass per step, the step host-bound at 1.52 ms.  (gc.collect(1) does not
+# help: the pass of step i promotes the operand nodes of step i, whose edges the result then adopts -- measured
+# 0 hits in 50.)  So a pool miss of at most _SLACK_MAX_REQUEST bytes may skip the pass and let the pool GROW by that
+# block, until _SLACK_PER_SIZE bytes have been granted to requests of that size (_SLACK_TOTAL over all sizes); from
+# then on every miss of that size runs the pass, which now returns ALL the dead blocks of the skipped steps at once:
+# one pass per ~12 steps at 170 MB instead of one per step, for at most 2 GiB of HBM.  Requests above 512 MiB keep
+# one pass per miss (their steps are milliseconds long).
 _GC_FROZEN = False
 _GC_MIN_BYTES = 64 << 20
 _MALLOC_SECONDS_PER_BYTE = 28e-3 / (1 << 30)
 _gc_cost_seconds = 30e-3     # a full pass of an unfrozen heap before one has been timed; configure_gc(freeze=True) resets it to 0
+
+
+_SLACK_PER_SIZE = 2 << 30            # the pool may grow by this much per request size through skipped passes ...
+_SLACK_TOTAL = 8 << 30               # ... and by this much over all sizes
+_SLACK_MAX_REQUEST = 512 << 20       # only requests up to this size may skip
+_slack_granted = {}                  # request size -> bytes granted so far (the blocks stay in the pool's circulation;
+                                     # trim() starts the count again)
+_gc_stats = {"full_passes": 0, "passes_skipped_for_slack": 0}
 
 
 _GC_POLICY = {"freeze": False, "collect": True}
@@ -189,6 +208,39 @@ def _collect_and_time():
   t0 = time.perf_counter()
   gc.collect()
   _gc_cost_seconds = time.perf_counter() - t0
+  _gc_stats["full_passes"] += 1
+
+
+def _grant_slack(lib, nbytes):
+  """Amortised passes (policy above): may this pool miss skip the collector pass and grow the pool instead?"""
+  if nbytes > _SLACK_MAX_REQUEST:
+    return False
+  total = sum(_slack_granted.values())
+  if total:
+    # a trim (tnh_trim called past `trim()` below) returns the granted blocks to the driver: the pool then holds
+    # less than what was granted, and the count starts again
+    in_use, cached = ctypes.c_int64(0), ctypes.c_int64(0)
+    if lib.tnh_mem_stats(ctypes.byref(in_use), ctypes.byref(cached), None) == 0 and \
+        in_use.value + cached.value < total:
+      _slack_granted.clear()
+      total = 0
+  if _slack_granted.get(nbytes, 0) + nbytes > _SLACK_PER_SIZE or total + nbytes > _SLACK_TOTAL:
+    return False
+  _slack_granted[nbytes] = _slack_granted.get(nbytes, 0) + nbytes
+  _gc_stats["passes_skipped_for_slack"] += 1
+  return True
+
+
+def gc_stats():
+  """The allocator's collector passes so far: full passes run, passes skipped for slack, the last pass' seconds,
+  bytes of slack granted."""
+  return dict(_gc_stats, full_pass_seconds=_gc_cost_seconds, slack_granted_bytes=sum(_slack_granted.values()))
+
+
+def trim():
+  """Return the pool's cached blocks to the driver (tnh_trim) and start the slack count again."""
+  _lib.check(_lib.lib().tnh_trim(), "tnh_trim")
+  _slack_granted.clear()
 
 
 class _Block:
@@ -201,7 +253,8 @@ class _Block:
     if int(nbytes) >= _GC_MIN_BYTES:
       has = ctypes.c_int(1)
       lib.tnh_pool_has(int(nbytes), ctypes.byref(has))
-      if not has.value and _worth_collecting(int(nbytes)):
+      if not has.value and _GC_POLICY["collect"] and not _grant_slack(lib, int(nbytes)) and \
+          _worth_collecting(int(nbytes)):
         _collect_and_time()
     status = lib.tnh_malloc(ctypes.byref(p), max(int(nbytes), 1))
     if status == _lib.ERR_NOMEM:
