@@ -622,6 +622,10 @@ static int try_brick(void* dst, const void* src, int r, const int64_t* oshape, c
   return TNH_OK;
 }
 
+#ifndef TNH_BRICK_RAGGED_DEFAULT
+#define TNH_BRICK_RAGGED_DEFAULT true
+#endif
+
 template <typename T, bool SCATTER>
 static int launch_gather(void* dst, const void* src, const GatherParams& p) {
   if (p.total == 0) return TNH_OK;
@@ -893,7 +897,11 @@ int tnh_permute(void* dst, const void* src, int rank, const int64_t* shape, cons
     }
   }
   // (c0) small fastest dims on either side: brick kernel
-  if (ia >= 0 && (oshape[ia] < 64 || oshape[ib] < 64) && itemsize >= 2 && !getenv("TNH_PERMUTE_NOBRICK")) {
+  // (round 5) also for 2-byte tensors whose (a, b) extents the 64 x 128 fast path below cannot tile (D = 96, 160, ...):
+  // the scalar 64 x 64 fallback moved the [K][N] -> [N][K] pass of a (96,)^4 tensor at 1.48 TB/s (measured)
+  static const bool brick_ragged = []() { const char* e = getenv("TNH_BRICK_RAGGED"); return e ? atoi(e) != 0 : TNH_BRICK_RAGGED_DEFAULT; }();
+  const bool ragged16 = brick_ragged && ia >= 0 && itemsize == 2 && (oshape[ia] % 64 != 0 || oshape[ib] % 128 != 0);
+  if (ia >= 0 && (oshape[ia] < 64 || oshape[ib] < 64 || ragged16) && itemsize >= 2 && !getenv("TNH_PERMUTE_NOBRICK")) {
     int rc = TNH_ERR_UNSUPPORTED;
     switch (itemsize) {
       case 2: rc = try_brick<uint16_t>(dst, src, r, oshape, istride, ostride, total); break;

@@ -47,6 +47,10 @@ def test_permute_all_perms_rank4(hip, dtype):
     # full 64 x 128 tiles with 16-byte aligned rows: the 2-byte vector kernel (permute_tiled16)
     ((128, 256), (1, 0)), ((64, 128), (1, 0)), ((256, 4, 128), (2, 1, 0)), ((3, 64, 2, 128), (0, 3, 2, 1)),
     ((128, 3, 64), (2, 1, 0)),  # odd batch stride -> falls back to the scalar tiled kernel
+    # 2-byte tensors whose (a, b) extents are >= 64 but not multiples of 64 / 128 (round 5: brick kernel instead of the
+    # scalar 64 x 64 tiles -- the [K][N] -> [N][K] pass of a (96,)^4 tensor 1.48 -> 4.06 TB/s)
+    ((96, 2, 3, 96), (1, 3, 2, 0)), ((72, 72), (1, 0)), ((100, 3, 100), (2, 1, 0)), ((160, 96), (1, 0)),
+    ((66, 5, 130), (2, 1, 0)),
     # brick kernel, 16-byte vectors on both sides (runs of 144 / 1728 elements), on one side only, and not at all
     ((12, 12, 12, 12, 1, 12, 12, 12), (0, 3, 4, 5, 1, 6, 7, 2)), ((12,) * 6, (2, 1, 3, 4, 5, 0)),
     ((12,) * 6, (0, 1, 3, 5, 4, 2)), ((8,) * 7, (0, 4, 5, 1, 2, 6, 3)), ((6, 10, 12, 8, 12), (0, 3, 4, 1, 2)),
