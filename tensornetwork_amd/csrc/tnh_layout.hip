@@ -900,7 +900,10 @@ int tnh_permute(void* dst, const void* src, int rank, const int64_t* shape, cons
   // (round 5) also for 2-byte tensors whose (a, b) extents the 64 x 128 fast path below cannot tile (D = 96, 160, ...):
   // the scalar 64 x 64 fallback moved the [K][N] -> [N][K] pass of a (96,)^4 tensor at 1.48 TB/s (measured)
   static const bool brick_ragged = []() { const char* e = getenv("TNH_BRICK_RAGGED"); return e ? atoi(e) != 0 : TNH_BRICK_RAGGED_DEFAULT; }();
-  const bool ragged16 = brick_ragged && ia >= 0 && itemsize == 2 && (oshape[ia] % 64 != 0 || oshape[ib] % 128 != 0);
+  // (not for [64][N] -> [N][64] with whole 64 x 64 tiles: their output is one contiguous 8 KB piece per tile and the
+  //  scalar tiles stay ahead, 2.66 against 2.06 TB/s -- profiles/r05_ragged_brick_probe.txt)
+  const bool ragged16 = brick_ragged && ia >= 0 && itemsize == 2 && (oshape[ia] % 64 != 0 || oshape[ib] % 128 != 0) &&
+                        !(oshape[ib] == 64 && ia == r - 2 && oshape[ia] % 64 == 0);
   if (ia >= 0 && (oshape[ia] < 64 || oshape[ib] < 64 || ragged16) && itemsize >= 2 && !getenv("TNH_PERMUTE_NOBRICK")) {
     int rc = TNH_ERR_UNSUPPORTED;
     switch (itemsize) {
