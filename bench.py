@@ -231,9 +231,75 @@ class Watchdog:
 
 
 def make_rccl_comm(tcomm, be, rank, world):
-  """K8 communicator (the only one: RCCL through libtnhip's C ABI).  A rank that cannot create it raises on EVERY
-  rank (lock-step bootstrap, comm.py) and the job ends with a message -- no second communicator to fall back on."""
+  """K8 communicator (RCCL through libtnhip's C ABI).  A rank that cannot create it raises on EVERY rank (lock-step
+  bootstrap, comm.py), so the ranks can agree on what to do next in step (`HostComm` below)."""
   return tcomm.RcclComm(be, rank=rank, world=world)
+
+
+class HostComm:
+  """bench.py only, and only when the K8 communicator cannot be brought up on this node (the exception of
+  `make_rccl_comm`, raised on every rank): the barrier, the max / sum of a scalar over the ranks and the ONE small
+  all-reduce of the sliced network go through `comm.HostRendezvous` (TCP on MASTER_ADDR) instead of RCCL, and the
+  result line says so (`config.comm`).  The headline needs no data-path collective -- N independent contractions
+   -- so its number is the same measurement; a row whose exchange is the thing measured
+  (`sliced_network.allreduce_seconds`) is labelled as a host exchange.  Never used by the package."""
+
+  MAX_ELEMS = 1 << 20           # the result of a sliced contraction is small (a scalar for closed networks)
+
+  def __init__(self, rdv, reason):
+    self._rdv, self.reason = rdv, str(reason)
+    self.rank, self.world = rdv.rank, rdv.world
+
+  def barrier(self):
+    self._rdv.barrier()
+
+  def max_over_ranks(self, value):
+    return max(float(v) for v in self._rdv.all_gather(float(value)))
+
+  def sum_over_ranks(self, value):
+    return float(sum(float(v) for v in self._rdv.all_gather(float(value))))
+
+  def all_gather_counts(self, n):
+    return [int(x) for x in self._rdv.all_gather(int(n))]
+
+  def all_reduce_sum(self, backend, tensor):
+    """Sum over ranks on the host: D2H, gathered as lists, added in float64 in rank order on every rank (so every
+    rank holds the same bits), rounded once to the tensor's dtype, H2D."""
+    from tensornetwork_amd.device_tensor import DeviceTensor, bfloat16  # pylint: disable=import-outside-toplevel
+    host = np.asarray(tensor)
+    if host.size > self.MAX_ELEMS:
+      raise RuntimeError(f"HostComm.all_reduce_sum is for small results (<= {self.MAX_ELEMS} elements), got {host.size}")
+    cplx = np.iscomplexobj(host)
+    flat = host.reshape(-1)
+    mine = [flat.real.astype(np.float64).tolist(), flat.imag.astype(np.float64).tolist() if cplx else None]
+    total_re, total_im = np.zeros(flat.size), np.zeros(flat.size)
+    for re, im in self._rdv.all_gather(mine):
+      total_re += np.asarray(re, dtype=np.float64)
+      if im is not None:
+        total_im += np.asarray(im, dtype=np.float64)
+    total = (total_re + 1j * total_im) if cplx else total_re
+    is_bf16 = getattr(tensor, "dtype", None) is bfloat16 or str(getattr(tensor, "dtype", "")) == "bfloat16"
+    out = total.astype(np.float32 if is_bf16 else host.dtype).reshape(host.shape)
+    if isinstance(tensor, DeviceTensor):
+      return DeviceTensor.from_numpy(out, dtype=bfloat16) if is_bf16 else DeviceTensor.from_numpy(out)
+    return out
+
+  def close(self):
+    self._rdv.close()
+
+
+def bring_up_comm(tcomm, be, rank, world):
+  """(communicator, its name for `config.comm`): RCCL through the C ABI; the host exchange if that raises."""
+  try:
+    comm = make_rccl_comm(tcomm, be, rank, world)
+    return comm, "libtnhip K8 (tnh_allreduce / tnh_allgather over RCCL), TCP rendezvous for the id"
+  except (RuntimeError, TimeoutError) as exc:          # raised on every rank, in step
+    reason = f"{type(exc).__name__}: {exc}"[:240]
+    print(f"[bench] rank {rank}: the RCCL communicator did not come up ({reason}); barrier / scalar reductions go "
+          "through the host rendezvous (TCP) instead -- the headline has no data-path collective", file=sys.stderr, flush=True)
+    base = int(os.environ.get("MASTER_PORT", "29500")) + int(os.environ.get("TNH_COMM_PORT_OFFSET", "23"))
+    rdv = tcomm.HostRendezvous(rank, world, port=base + 1, timeout=120)
+    return HostComm(rdv, reason), f"HOST EXCHANGE (TCP rendezvous): the RCCL communicator did not come up -- {reason}"
 
 
 def sync_all(be, comm):
@@ -696,7 +762,9 @@ def sliced_network_bench(ta, be, comm, rank, world, D, min_slices, verify):
          "steps_per_slice": int(rep.get("steps_per_slice", 0)) - int(rep.get("invariant_steps", 0)),
          "slice_invariant_steps_run_once": int(rep.get("invariant_steps", 0)),
          "slowest_rank_compute_seconds": t_compute_max, "allreduce_seconds": t_reduce_max,
-         "collective": "one all-reduce(sum) of the fp32-accumulated scalar (tnh_allreduce, RCCL)" if world > 1 else "none",
+         "collective": ("none" if world == 1 else "one all-reduce(sum) of the fp32-accumulated scalar ON THE HOST (TCP; the RCCL "
+                        "communicator did not come up)" if isinstance(comm, HostComm) else
+                        "one all-reduce(sum) of the fp32-accumulated scalar (tnh_allreduce, RCCL)"),
          "accumulation": "slice partials added in fp32, rounded to bf16 once", "result": result}
   if staged_error is not None:
     rec["default_mode_error"] = staged_error
@@ -1384,10 +1452,12 @@ def main():
   be.lib  # pylint: disable=pointless-statement
   if use_dist:
     from tensornetwork_amd import comm as tcomm  # pylint: disable=import-outside-toplevel
-    with Watchdog(args.bringup_timeout, "RCCL bring-up (rendezvous, ncclCommInitRank, first barrier)", rank):
-      comm = make_rccl_comm(tcomm, be, rank, world)
+    # the library's own bound on ncclCommInitRank (default 600 s) must fire before the watchdog below does, and a
+    # bench run has a driver-side clock around it: 300 s (a cold librccl.so was measured at minutes, not more)
+    os.environ.setdefault("TNH_COMM_INIT_TIMEOUT_S", "300")
+    with Watchdog(args.bringup_timeout, "communicator bring-up (rendezvous, ncclCommInitRank, first barrier)", rank):
+      comm, comm_name = bring_up_comm(tcomm, be, rank, world)
       sync_all(be, comm)
-    comm_name = "libtnhip K8 (tnh_allreduce / tnh_allgather over RCCL), TCP rendezvous for the id"
 
   D = args.bond
   M = N = K = D * D

@@ -372,9 +372,11 @@ def test_json_network_from_reference_into_hbm(hip):
 
 
 def test_large_blocks_of_dead_nodes_return_to_the_pool(hip):
-  """A Node and its Edges are a reference cycle: `del node` alone does not free the tensor.  A large
-  request that the pool cannot serve collects Python's young generations first (device_tensor._Block), so
-  a contract-and-drop loop reuses ONE block instead of growing by a hipMalloc per step."""
+  """A Node and its Edges are a reference cycle: `del node` alone does not free the tensor.  A large request that
+  the pool cannot serve runs a full collector pass first (device_tensor._Block), so a contract-and-drop loop reuses
+  its blocks instead of growing by a hipMalloc per step -- at once with the slack switched off (rounds 1-4: ONE
+  block), after a bounded growth with the round-5 policy (passes amortised: up to 2 GiB per request size may be
+  granted before the first pass, then the footprint stands still)."""
   import ctypes
   import gc
   from tensornetwork_amd import _lib
@@ -386,11 +388,13 @@ def test_large_blocks_of_dead_nodes_return_to_the_pool(hip):
 
   from tensornetwork_amd import device_tensor as dt
   saved = dict(dt._GC_POLICY)
+  per_size = dt._SLACK_PER_SIZE
   ta.configure_gc(freeze=True)     # round 3: the frozen-baseline policy is opt-in (bench.py opts in the same way)
   dt.freeze_collector_baseline()
   gc.collect()
   gc.disable()                     # only the allocator's own collection may run
   try:
+    dt._SLACK_PER_SIZE = 0         # no slack: one pass per pool miss
     sizes = []
     for step in range(5):
       node = ta.Node(hip.zeros((24 << 20,), dtype=np.float32), backend=hip)   # 96 MiB, unique size
@@ -398,12 +402,30 @@ def test_large_blocks_of_dead_nodes_return_to_the_pool(hip):
       del node
       sizes.append(footprint())
     assert sizes[-1] - sizes[1] == 0, sizes     # step 0 may allocate; afterwards the same block is reused
+    dt._SLACK_PER_SIZE = per_size  # the default: growth first, bounded, then one pass per ~21 steps
+    gc.collect()
+    ta.trim_pool()
+    stats0 = ta.gc_stats()
+    sizes = []
+    for step in range(60):
+      node = ta.Node(hip.zeros((26 << 20,), dtype=np.float32), backend=hip)   # 104 MiB, another unique size
+      del node
+      sizes.append(footprint())
+    stats1 = ta.gc_stats()
+    assert max(sizes) - sizes[0] <= per_size, (sizes[0], max(sizes))
+    assert len(set(sizes[-30:])) == 1, sizes[-30:]                            # stationary once the slack is used up
+    skipped = stats1["passes_skipped_for_slack"] - stats0["passes_skipped_for_slack"]
+    passes = stats1["full_passes"] - stats0["full_passes"]
+    assert skipped == per_size // (104 << 20) and 1 <= passes <= 4, (skipped, passes)
     has = ctypes.c_int(-1)
     _lib.check(hip.lib.tnh_pool_has(1 << 40, ctypes.byref(has)))
     assert has.value == 0
     ta.configure_gc(freeze=saved["freeze"], collect_before_large_alloc=saved["collect"])
   finally:
+    dt._SLACK_PER_SIZE = per_size
     gc.enable()
+    gc.collect()
+    ta.trim_pool()
 
 
 # ---- round 5: the scheduling modes of contract_sliced and the sliced MERA layer, on the GPU -------------------------
