@@ -93,6 +93,13 @@ class EmuLib:
     has_ref._obj.value = 1     # pylint: disable=protected-access
     return _lib.OK
 
+  def tnh_mem_stats(self, in_use, cached, peak):
+    live = sum(int(b.nbytes) for b in self._blocks.values())
+    for ref, val in ((in_use, live), (cached, 0), (peak, live)):
+      if ref is not None:
+        ref._obj.value = val   # pylint: disable=protected-access
+    return _lib.OK
+
   def tnh_h2d(self, dst, src, nbytes):
     ctypes.memmove(_addr(dst), _addr(src), int(nbytes))
     return _lib.OK
