@@ -85,12 +85,25 @@ def storage_of(dtype):
 
 
 def f32_to_bf16_bits(x):
-  """float32 ndarray -> uint16 bf16 bit patterns, round-to-nearest-even."""
+  """float32 ndarray -> uint16 bf16 bit patterns, round-to-nearest-even (NaNs keep their sign and top payload bits,
+  quiet bit set).  Worked through in 1 Mi-element pieces with in-place integer steps: whole-array temporaries made
+  this 4 s per 85 M elements (eight 340 MB arrays); the pieces stay in cache."""
   u = np.ascontiguousarray(x, dtype=np.float32).view(np.uint32)
-  nan = (u & np.uint32(0x7fffffff)) > np.uint32(0x7f800000)
-  r = (u + (np.uint32(0x7fff) + ((u >> np.uint32(16)) & np.uint32(1)))) >> np.uint32(16)
-  r = np.where(nan, (u >> np.uint32(16)) | np.uint32(0x40), r)
-  return r.astype(np.uint16)
+  out = np.empty(u.shape, dtype=np.uint16)
+  uf, of = u.reshape(-1), out.reshape(-1)
+  piece = 1 << 20
+  for s in range(0, uf.size, piece):
+    c = uf[s:s + piece]
+    hi = c >> np.uint32(16)
+    r = hi & np.uint32(1)
+    r += np.uint32(0x7fff)
+    r += c                                   # modulo 2^32, as the one-line form did; those lanes are NaNs (below)
+    r >>= np.uint32(16)
+    nan = (c & np.uint32(0x7fffffff)) > np.uint32(0x7f800000)
+    if nan.any():
+      r[nan] = hi[nan] | np.uint32(0x40)
+    of[s:s + piece] = r
+  return out
 
 
 def bf16_bits_to_f32(bits):

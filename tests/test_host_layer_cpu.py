@@ -269,6 +269,36 @@ def test_graph_surgery_reference_cases():
   cases.check_graph_surgery(OracleBackend(), 1e-12)
 
 
+def test_host_bf16_rounding_equals_its_one_line_definition():
+  """device_tensor.f32_to_bf16_bits works through the array in cache-sized pieces with in-place integer steps (round 5:
+  14x faster on 50 M elements); its results are the bits of the one-line definition -- round to nearest even on the
+  uint32 image, NaNs keep sign and top payload with the quiet bit set -- for random bit patterns, the special values,
+  every shape (0-d, empty, non-contiguous, float64 input) and arrays longer than one piece."""
+  from tensornetwork_amd import device_tensor as dt
+
+  def one_line(x):
+    u = np.ascontiguousarray(x, dtype=np.float32).view(np.uint32)
+    nan = (u & np.uint32(0x7fffffff)) > np.uint32(0x7f800000)
+    r = (u + (np.uint32(0x7fff) + ((u >> np.uint32(16)) & np.uint32(1)))) >> np.uint32(16)
+    return np.where(nan, (u >> np.uint32(16)) | np.uint32(0x40), r).astype(np.uint16)
+
+  rng = np.random.default_rng(0)
+  bits = rng.integers(0, 2**32, size=(1 << 21) + 12345, dtype=np.uint64).astype(np.uint32)      # more than two pieces
+  special = np.array([0, 0x80000000, 0x7f800000, 0xff800000, 0x7fc00000, 0x7f800001, 0xffffffff, 0x7f7fffff, 0x7f7f8000,
+                      0x7f7f7fff, 0x00000001, 0x00008000, 0x00018000, 0x3f808000, 0x3f818000, 0x3f80ffff, 0xffc00001,
+                      0x7fffffff], dtype=np.uint32)
+  x = np.concatenate([bits, special]).view(np.float32)
+  with np.errstate(all="ignore"):
+    want, got = one_line(x), dt.f32_to_bf16_bits(x)
+  assert got.dtype == np.uint16 and got.shape == want.shape and np.array_equal(got, want)
+  for shape in [(), (1,), (3, 5), (0,), (2, 0, 3)]:
+    y = rng.standard_normal(shape).astype(np.float32)
+    assert dt.f32_to_bf16_bits(y).shape == one_line(y).shape and np.array_equal(dt.f32_to_bf16_bits(y), one_line(y)), shape
+  y = rng.standard_normal((64, 33))[:, ::2]                       # float64, non-contiguous
+  assert np.array_equal(dt.f32_to_bf16_bits(y), one_line(y))
+  np.testing.assert_array_equal(dt.round_to_bf16(np.array([1.0, 1.00390625, 1.01171875], dtype=np.float32)), [1.0, 1.0, 1.015625])
+
+
 def test_collector_policy_before_large_allocations():
   """device_tensor: a full collection in front of a pool miss only where it is cheaper than the hipMalloc."""
   from tensornetwork_amd import device_tensor as dt
