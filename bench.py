@@ -1453,8 +1453,8 @@ def main():
   if use_dist:
     from tensornetwork_amd import comm as tcomm  # pylint: disable=import-outside-toplevel
     # the library's own bound on ncclCommInitRank (default 600 s) must fire before the watchdog below does, and a
-    # bench run has a driver-side clock around it: 300 s (a cold librccl.so was measured at minutes, not more)
-    os.environ.setdefault("TNH_COMM_INIT_TIMEOUT_S", "300")
+    # bench run has a driver-side clock around it: 420 s (a cold librccl.so alone was measured at minutes)
+    os.environ.setdefault("TNH_COMM_INIT_TIMEOUT_S", "420")
     with Watchdog(args.bringup_timeout, "communicator bring-up (rendezvous, ncclCommInitRank, first barrier)", rank):
       comm, comm_name = bring_up_comm(tcomm, be, rank, world)
       sync_all(be, comm)
