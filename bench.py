@@ -14,7 +14,9 @@ ping-pong kernel on two K-contiguous views).
 N>1 (one process per GPU; RCCL through libtnhip's own K8 entry points for the barrier, the
 max-over-ranks reduction and the sliced network's all-reduce): the pairwise contraction has no
 exchange step, so every rank contracts its own pair of nodes (weak scaling, no data-path
-collective) and ``value`` is the aggregate.
+collective) and ``value`` is the aggregate.  If the RCCL communicator cannot be brought up (it then raises on every
+rank, in step), the barrier and the scalar reductions go through the host rendezvous instead (`HostComm`, TCP) and
+``config.comm`` says so: the headline is the same measurement, the sliced network's exchange is labelled a host one.
 
 Extra objects on the same line:
   roofline       -- the dominant kernel (bf16 MFMA GEMM) timed with HIP events on the library's stream inside
