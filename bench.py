@@ -333,47 +333,18 @@ def one_step(ta, be, A, B, layout):
   return ta.contract_between(a, b)
 
 
+def verify_pair(*args, **kwargs):
+  """tests/cases.py::verify_pair (shared with the `-m gpu` suite, which runs the same check at the BASELINE sizes):
+  >= 1024 sampled entries against float64 dot products of the device operands, 2^-8 |ref| + 2^-10 rms(ref)."""
+  tdir = os.path.join(ROOT, "tests")
+  if tdir not in sys.path:
+    sys.path.insert(0, tdir)
+  import cases  # pylint: disable=import-outside-toplevel,import-error
+  return cases.verify_pair(*args, **kwargs)
+
+
 def host64(t):
   return np.asarray(t).astype(np.float64)
-
-
-def verify_pair(be, A, B, out, layout, n_side=32, seed=0):
-  """>= 1024 sampled entries of a rank-4 x rank-4 contraction against float64 dot products of the DEVICE
-  operands.  Only the needed slabs are read back: n_side (row pair) slabs of A, n_side (column
-  pair) slabs of B and n_side slabs of the result.
-    L0: C[i0,i1,j2,j3] = sum_{k2,k3} A[i0,i1,k2,k3] B[k2,k3,j2,j3]
-    L1: C[i0,i2,j1,j3] = sum_{k1,k3} A[i0,k1,i2,k3] B[k3,j1,k1,j3]
-  Tolerance: bf16 rounding of the result (2^-9 relative, tested at 2^-8) + 2^-10 of the rms entry (fp32
-  accumulation over K terms is far below that)."""
-  rng = np.random.default_rng(seed)
-  sa, sb = A.shape, B.shape
-  if layout == "L0":
-    rdims, cdims = (sa[0], sa[1]), (sb[2], sb[3])
-  else:
-    rdims, cdims = (sa[0], sa[2]), (sb[1], sb[3])
-  rows = [(int(rng.integers(rdims[0])), int(rng.integers(rdims[1]))) for _ in range(n_side)]
-  cols = [(int(rng.integers(cdims[0])), int(rng.integers(cdims[1]))) for _ in range(n_side)]
-  # always include the four corners of the output (first / last tile of the launch)
-  rows[0], rows[-1] = (0, 0), (rdims[0] - 1, rdims[1] - 1)
-  cols[0], cols[-1] = (0, 0), (cdims[0] - 1, cdims[1] - 1)
-  sl = slice(None)
-  if layout == "L0":
-    a_rows = np.stack([host64(be.getitem(A, (r0, r1))).reshape(-1) for r0, r1 in rows])
-    b_cols = np.stack([host64(be.getitem(B, (sl, sl, c0, c1))).reshape(-1) for c0, c1 in cols])
-  else:
-    a_rows = np.stack([host64(be.getitem(A, (r0, sl, r1, sl))).reshape(-1) for r0, r1 in rows])
-    b_cols = np.stack([host64(be.getitem(B, (sl, c0, sl, c1))).T.reshape(-1) for c0, c1 in cols])
-  ref = a_rows @ b_cols.T                                            # (n_side, n_side) float64
-  got = np.empty_like(ref)
-  for i, (r0, r1) in enumerate(rows):
-    slab = host64(be.getitem(out, (r0, r1)))                         # [c0, c1]
-    got[i] = [slab[c0, c1] for c0, c1 in cols]
-  rms = float(np.sqrt(np.mean(ref**2)))
-  tol = 2.0**-8 * np.abs(ref) + 2.0**-10 * rms
-  err = np.abs(got - ref)
-  return {"entries": int(ref.size), "max_abs_err": float(err.max()), "rms_ref": rms,
-          "max_err_over_tol": float((err / tol).max()), "tol": "2^-8 |ref| + 2^-10 rms(ref)",
-          "ok": bool((err <= tol).all())}
 
 
 def cpu_baseline(layout):

@@ -34,6 +34,67 @@ def assert_close(actual, expected, scale=None):
   np.testing.assert_allclose(actual, expected, **tol(expected.dtype, max(scale, 1e-30)))
 
 
+# tolerance of a bf16 / f16 GEMM result against float64 on the ROUNDED inputs (bf16-out rtol 2^-8): the
+# result is rounded once to the storage type (2^-9 / 2^-12 relative, tested at twice that) and the fp32 accumulation
+# over K terms sits far below 2^-10 / 2^-13 of the rms entry.  No sqrt(K) factor: a kernel that loses bits fails.
+HALF_TOL = {"bf16": (2.0**-8, 2.0**-10), "f16": (2.0**-11, 2.0**-13)}
+
+
+def assert_half_gemm_close(out, ref, kind, err_msg=""):
+  """|out - ref| <= rel |ref| + abs_rms rms(ref) elementwise (the rule of bench.verify_pair), kind in HALF_TOL."""
+  rel, rms_part = HALF_TOL[kind]
+  out, ref = np.asarray(out).astype(np.float64), np.asarray(ref).astype(np.float64)
+  assert out.shape == ref.shape, (out.shape, ref.shape, err_msg)
+  rms = float(np.sqrt(np.mean(ref**2))) if ref.size else 0.0
+  tolv = rel * np.abs(ref) + rms_part * rms
+  err = np.abs(out - ref)
+  worst = float((err / np.maximum(tolv, 1e-300)).max()) if ref.size else 0.0
+  assert worst <= 1.0, f"{err_msg}: max err / tol = {worst:.3f} (tol = {rel:g} |ref| + {rms_part:g} rms, rms = {rms:g})"
+
+
+def host64(t):
+  return np.asarray(t).astype(np.float64)
+
+
+def verify_pair(be, A, B, out, layout, n_side=32, seed=0):
+  """>= 1024 sampled entries of a rank-4 x rank-4 contraction against float64 dot products of the DEVICE
+  operands.  Only the needed slabs are read back: n_side (row pair) slabs of A, n_side (column
+  pair) slabs of B and n_side slabs of the result.
+    L0: C[i0,i1,j2,j3] = sum_{k2,k3} A[i0,i1,k2,k3] B[k2,k3,j2,j3]
+    L1: C[i0,i2,j1,j3] = sum_{k1,k3} A[i0,k1,i2,k3] B[k3,j1,k1,j3]
+  Tolerance: bf16 rounding of the result (2^-9 relative, tested at 2^-8) + 2^-10 of the rms entry (fp32
+  accumulation over K terms is far below that)."""
+  rng = np.random.default_rng(seed)
+  sa, sb = A.shape, B.shape
+  if layout == "L0":
+    rdims, cdims = (sa[0], sa[1]), (sb[2], sb[3])
+  else:
+    rdims, cdims = (sa[0], sa[2]), (sb[1], sb[3])
+  rows = [(int(rng.integers(rdims[0])), int(rng.integers(rdims[1]))) for _ in range(n_side)]
+  cols = [(int(rng.integers(cdims[0])), int(rng.integers(cdims[1]))) for _ in range(n_side)]
+  # always include the four corners of the output (first / last tile of the launch)
+  rows[0], rows[-1] = (0, 0), (rdims[0] - 1, rdims[1] - 1)
+  cols[0], cols[-1] = (0, 0), (cdims[0] - 1, cdims[1] - 1)
+  sl = slice(None)
+  if layout == "L0":
+    a_rows = np.stack([host64(be.getitem(A, (r0, r1))).reshape(-1) for r0, r1 in rows])
+    b_cols = np.stack([host64(be.getitem(B, (sl, sl, c0, c1))).reshape(-1) for c0, c1 in cols])
+  else:
+    a_rows = np.stack([host64(be.getitem(A, (r0, sl, r1, sl))).reshape(-1) for r0, r1 in rows])
+    b_cols = np.stack([host64(be.getitem(B, (sl, c0, sl, c1))).T.reshape(-1) for c0, c1 in cols])
+  ref = a_rows @ b_cols.T                                            # (n_side, n_side) float64
+  got = np.empty_like(ref)
+  for i, (r0, r1) in enumerate(rows):
+    slab = host64(be.getitem(out, (r0, r1)))                         # [c0, c1]
+    got[i] = [slab[c0, c1] for c0, c1 in cols]
+  rms = float(np.sqrt(np.mean(ref**2)))
+  tol = 2.0**-8 * np.abs(ref) + 2.0**-10 * rms
+  err = np.abs(got - ref)
+  return {"entries": int(ref.size), "max_abs_err": float(err.max()), "rms_ref": rms,
+          "max_err_over_tol": float((err / tol).max()), "tol": "2^-8 |ref| + 2^-10 rms(ref)",
+          "ok": bool((err <= tol).all())}
+
+
 def run_tensordot(be, g, case):
   a, b = be.convert_to_tensor(g[case["a"]]), be.convert_to_tensor(g[case["b"]])
   return be.tensordot(a, b, case["axes"])

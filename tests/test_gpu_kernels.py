@@ -148,8 +148,19 @@ def _kernel_tests_read_k_major_operands_in_place(request):
     be.kmajor_inplace_penalty = keep
 
 
-GEMM_TOL = {np.float32: 3e-6, np.float64: 1e-14, np.float16: 2e-3, ta.bfloat16: 1.6e-2,
-            np.complex64: 3e-6, np.complex128: 1e-14}
+GEMM_TOL = {np.float32: 3e-6, np.float64: 1e-14, np.complex64: 3e-6, np.complex128: 1e-14}
+
+
+def assert_gemm(out, ref, dtype, k, scale_k=False, err_msg=""):
+  """bf16 / f16 results: the parity rule of SURVEY 8c and of bench.verify_pair, elementwise and WITHOUT a sqrt(K)
+  factor -- 2^-8 |ref| + 2^-10 rms(ref) (f16: 2^-11, 2^-13); see C.assert_half_gemm_close.  Other dtypes: the
+  accumulate error of K terms in the storage precision (GEMM_TOL, optionally x sqrt(K) for the ragged sweep)."""
+  if dtype is ta.bfloat16:
+    return C.assert_half_gemm_close(out, ref, "bf16", err_msg)
+  if dtype is np.float16:
+    return C.assert_half_gemm_close(out, ref, "f16", err_msg)
+  tol = GEMM_TOL[dtype] * (max(np.sqrt(k), 1.0) if scale_k else 1.0)
+  return np.testing.assert_allclose(out, ref, rtol=tol, atol=tol * np.sqrt(k), err_msg=err_msg)
 
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64, np.float16, ta.bfloat16, np.complex64, np.complex128])
@@ -157,25 +168,21 @@ GEMM_TOL = {np.float32: 3e-6, np.float64: 1e-14, np.float16: 2e-3, ta.bfloat16: 
 def test_gemm_all_layouts_ragged(hip, dtype, ta_, tb_):
   for (m, n, k) in [(1, 1, 1), (5, 7, 3), (33, 65, 17), (130, 70, 129), (64, 64, 64), (257, 129, 40)]:
     out, ref, kernel, sk = _gemm_case(hip, dtype, m, n, k, ta_, tb_)
-    # out is rounded to the storage dtype: tolerance = accumulate error + output rounding
-    tol = GEMM_TOL[dtype] * max(sk, 1.0)
-    np.testing.assert_allclose(out, ref, rtol=tol, atol=tol * np.sqrt(k), err_msg=f"{kernel} {m}x{n}x{k}")
+    assert_gemm(out, ref, dtype, k, scale_k=True, err_msg=f"{kernel} {m}x{n}x{k}")
 
 
 @pytest.mark.parametrize("variant", ["generic", "valu"])
 @pytest.mark.parametrize("dtype", [np.float32, np.float64, ta.bfloat16])
 def test_gemm_variants_agree(hip, variant, dtype):
   out, ref, kernel, sk = _gemm_case(hip, dtype, 200, 136, 96, 0, 1, variant=variant)
-  tol = GEMM_TOL[dtype] * sk
-  np.testing.assert_allclose(out, ref, rtol=tol, atol=tol * np.sqrt(96))
+  assert_gemm(out, ref, dtype, 96, scale_k=True)
   assert ("valu" in kernel) == (variant == "valu")
 
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64, ta.bfloat16])
 def test_gemm_batched(hip, dtype):
   out, ref, _, sk = _gemm_case(hip, dtype, 40, 24, 56, 0, 0, batch=5)
-  tol = GEMM_TOL[dtype] * sk
-  np.testing.assert_allclose(out, ref, rtol=tol, atol=tol * np.sqrt(56))
+  assert_gemm(out, ref, dtype, 56, scale_k=True)
 
 
 @pytest.mark.parametrize("variant,expect", [("bf16_128", "bf16_nt_128x128x64"), ("bf16_256", "bf16_nt_256x256x64"),
@@ -189,8 +196,7 @@ def test_gemm_bf16_speed_path(hip, variant, expect, dtype, m, n, k):
   (catch row/col swaps), ragged M/N edges, both tile sizes."""
   out, ref, kernel, sk = _gemm_case(hip, dtype, m, n, k, 0, 1, variant=variant, rng=np.random.default_rng(m + n + k))
   assert kernel == expect
-  tol = GEMM_TOL[dtype]
-  np.testing.assert_allclose(out, ref, rtol=tol, atol=tol * np.sqrt(k))
+  assert_gemm(out, ref, dtype, k)
 
 
 @pytest.mark.parametrize("ta_,tb_", [(0, 1), (0, 0), (1, 0), (1, 1)])
@@ -272,8 +278,7 @@ def test_gemm_bf16_four_wave_variant(hip, dtype, m, n, k):
   out, ref, kernel, sk = _gemm_case(hip, dtype, m, n, k, 0, 1, variant="bf16_256pp:p6",
                                     rng=np.random.default_rng(m + n + k))
   assert kernel == "bf16_nt_256x256x64_w4"
-  tol = GEMM_TOL[dtype]
-  np.testing.assert_allclose(out, ref, rtol=tol, atol=tol * np.sqrt(k))
+  assert_gemm(out, ref, dtype, k)
   out2, _, kernel2, _ = _gemm_case(hip, dtype, m, n, k, 0, 1, variant="bf16_256pp", rng=np.random.default_rng(m + n + k))
   assert kernel2 == "bf16_nt_256x256x64_pp"
   np.testing.assert_array_equal(out, out2)          # same accumulation order: bit-identical
@@ -293,8 +298,7 @@ def test_gemm_bf16_ragged_path(hip, variant, expect, dtype):
                     (20, 36, 7), (513, 258, 72), (70, 264, 33), (131, 520, 200)]:
     out, ref, kernel, sk = _gemm_case(hip, dtype, m, n, k, 0, 1, variant=variant, rng=np.random.default_rng(m + n + k))
     assert kernel.startswith(expect), kernel
-    tol = GEMM_TOL[dtype]
-    np.testing.assert_allclose(out, ref, rtol=tol, atol=tol * np.sqrt(k), err_msg=f"{kernel} {m}x{n}x{k}")
+    assert_gemm(out, ref, dtype, k, err_msg=f"{kernel} {m}x{n}x{k}")
 
 
 def test_gemm_bf16_ragged_auto_dispatch_and_batch(hip):
@@ -305,7 +309,7 @@ def test_gemm_bf16_ragged_auto_dispatch_and_batch(hip):
   b = orc.round_bf16(rng.standard_normal((5000, 144)))
   out = hip.tensordot(hip.to_bfloat16(a), hip.to_bfloat16(b), [[1], [1]])
   assert hip.lib.tnh_gemm_last_kernel().decode() == "bf16_nt_ragged_128x128x64_smallk"
-  np.testing.assert_allclose(np.asarray(out), a @ b.T, rtol=1.6e-2, atol=1.6e-2 * 12)
+  C.assert_half_gemm_close(np.asarray(out), a @ b.T, "bf16")
   # batched NT through the C ABI: batch 3, K = 10 (4-B loads), strides not multiples of 8
   import ctypes
   from tensornetwork_amd.device_tensor import DeviceTensor
@@ -337,8 +341,7 @@ def test_gemm_stream_small_times_long(hip, dtype):
     tiled, _, kernel2, _ = _gemm_case(hip, dtype, m, n, k, 0, 1, variant="bf16_ragged_128x128", rng=rng)
     assert kernel2.startswith("bf16_nt_ragged"), kernel2
     np.testing.assert_array_equal(out, tiled, err_msg=f"{kernel} vs {kernel2} {m}x{n}x{k}")
-    tol = GEMM_TOL[dtype]
-    np.testing.assert_allclose(out, ref, rtol=tol, atol=tol * np.sqrt(k), err_msg=f"{kernel} {m}x{n}x{k}")
+    assert_gemm(out, ref, dtype, k, err_msg=f"{kernel} {m}x{n}x{k}")
 
 
 def test_gemm_stream_padded_ldc_and_forced_variant(hip):
@@ -354,7 +357,7 @@ def test_gemm_stream_padded_ldc_and_forced_variant(hip):
                                 ctypes.c_void_p(hip.to_bfloat16(B).ptr), k, ctypes.c_void_p(c.ptr), ldc, 1, 0, 0, 0))
     assert hip.lib.tnh_gemm_last_kernel().decode().startswith("bf16_nt_stream")
     got = np.asarray(c)
-    np.testing.assert_allclose(got[:, :n], A @ B.T, rtol=1.6e-2, atol=1.6e-2 * 7)
+    C.assert_half_gemm_close(got[:, :n], A @ B.T, "bf16")
     np.testing.assert_array_equal(got[:, n:], 7.0)
   _lib.check(hip.lib.tnh_gemm_set_variant(b"bf16_stream"))
   try:
@@ -367,8 +370,7 @@ def test_gemm_stream_padded_ldc_and_forced_variant(hip):
     a = hip.to_bfloat16(rng.standard_normal((100, 64)))
     out = hip.tensordot(a, b, [[1], [1]])          # forced on a short product: still correct
     assert hip.lib.tnh_gemm_last_kernel().decode().startswith("bf16_nt_stream")
-    np.testing.assert_allclose(np.asarray(out), np.asarray(a).astype(np.float64) @ np.asarray(b).astype(np.float64).T,
-                               rtol=1.6e-2, atol=1.6e-2 * 8)
+    C.assert_half_gemm_close(np.asarray(out), np.asarray(a).astype(np.float64) @ np.asarray(b).astype(np.float64).T, "bf16")
   finally:
     _lib.check(hip.lib.tnh_gemm_set_variant(b"auto"))
 
@@ -387,7 +389,7 @@ def test_gemm_bf16_ragged_padded_ldc(hip):
                               ctypes.c_void_p(hip.to_bfloat16(B).ptr), k, ctypes.c_void_p(c.ptr), ldc, 1, 0, 0, 0))
   assert hip.lib.tnh_gemm_last_kernel().decode().startswith("bf16_nt_ragged")
   got = np.asarray(c)
-  np.testing.assert_allclose(got[:, :n], A @ B.T, rtol=1.6e-2, atol=1.6e-2 * 7)
+  C.assert_half_gemm_close(got[:, :n], A @ B.T, "bf16")
   np.testing.assert_array_equal(got[:, n:], 7.0)
 
 
@@ -410,7 +412,7 @@ def test_gemm_bf16_auto_dispatch_uses_speed_path(hip):
   out = hip.tensordot(a, b, 1)
   assert hip.lib.tnh_gemm_last_kernel().decode().startswith("bf16_nt")
   ref = np.asarray(a).astype(np.float64) @ np.asarray(b).astype(np.float64)
-  np.testing.assert_allclose(np.asarray(out), ref, rtol=1.6e-2, atol=1.6e-2 * 16)
+  C.assert_half_gemm_close(np.asarray(out), ref, "bf16")
 
 
 @pytest.mark.parametrize("dtype,kernel,tol", [(np.complex64, "mfma_f32_128x128", 3e-6), (np.complex128, "mfma_f64_64x64x16", 1e-14)])
@@ -502,7 +504,10 @@ def test_gemm_split_k_small_output(hip, dtype):
   for (m, n, k, ta_, tb_) in [(1, 1, 262144, 0, 1), (3, 5, 70001, 0, 0), (64, 130, 20000, 1, 1), (200, 100, 9000, 1, 0)]:
     out, ref, kernel, sk = _gemm_case(hip, dtype, m, n, k, ta_, tb_, rng=rng)
     assert kernel == "splitk", (kernel, m, n, k)
-    tol = {np.float32: 2e-6, np.float64: 1e-14, ta.bfloat16: 1.6e-2, np.float16: 2e-3}[dtype]
+    if dtype in (ta.bfloat16, np.float16):      # split-K partials are f32, rounded once at the end: the same rule
+      assert_gemm(out, ref, dtype, k, err_msg=f"{m}x{n}x{k}")
+      continue
+    tol = {np.float32: 2e-6, np.float64: 1e-14}[dtype]
     np.testing.assert_allclose(out, ref, rtol=tol * 4, atol=tol * np.sqrt(k) * 4, err_msg=f"{m}x{n}x{k}")
 
 
@@ -1555,8 +1560,7 @@ def test_gemm_lean_main_loop_is_bit_identical(hip, dtype, m, n, k):
   np.testing.assert_array_equal(out["bf16_256pp"], out["bf16_256pp:l0"])
   np.testing.assert_array_equal(out["bf16_256pp:g0"], out["bf16_256pp:l0"])
   np.testing.assert_array_equal(out["bf16_256pp:l0:g0"], out["bf16_256pp:l0"])
-  tol = GEMM_TOL[dtype]
-  np.testing.assert_allclose(out["bf16_256pp"], ref, rtol=tol, atol=tol * np.sqrt(k))
+  assert_gemm(out["bf16_256pp"], ref, dtype, k)
 
 
 def test_k_major_operands_take_the_faster_lowering(hip):
@@ -1583,3 +1587,39 @@ def test_k_major_operands_take_the_faster_lowering(hip):
     if D == 64:
       ref = np.tensordot(a.astype(np.float64), b.astype(np.float64), [[2, 3], [0, 1]])
       np.testing.assert_allclose(got, ref, rtol=2.0**-8, atol=2e-3)
+
+
+# --------------------------------------------------------------------- BASELINE sizes under -m gpu
+@pytest.mark.parametrize("layout", ["L0", "L1"])
+def test_config2_full_size_sampled_entries(hip, layout):
+  """BASELINE configs[1] at its FULL size: two rank-4 bf16 nodes, D = 256 (8.6 GB each), two shared bonds, through
+  contract_between; 1024 sampled entries (the four corners of the output included) against float64 dot products of
+  the device operands, 2^-8 |ref| + 2^-10 rms(ref) -- the check bench.py's `verified` carries, here under -m gpu."""
+  D = 256
+  A = hip.device_random((D,) * 4, dtype=ta.bfloat16, seed=3, normal=True, a=0.0, b=1.0 / D)
+  B = hip.device_random((D,) * 4, dtype=ta.bfloat16, seed=4, normal=True, a=0.0, b=1.0 / D)
+  a, b = ta.Node(A, backend=hip), ta.Node(B, backend=hip)
+  if layout == "L0":
+    a[2] ^ b[0]  # pylint: disable=pointless-statement
+    a[3] ^ b[1]  # pylint: disable=pointless-statement
+  else:
+    a[1] ^ b[2]  # pylint: disable=pointless-statement
+    a[3] ^ b[0]  # pylint: disable=pointless-statement
+  out = ta.contract_between(a, b)
+  kernel = hip.lib.tnh_gemm_last_kernel().decode()
+  assert "256x256x64_pp" in kernel, kernel
+  res = C.verify_pair(hip, A, B, out.tensor, layout, seed=D)
+  assert res["entries"] >= 1024 and res["ok"], res
+
+
+def test_d512_row_full_size_sampled_entries(hip):
+  """north_star's D = 512 row at full size: A(64,128,512,512) . B(512,512,128,64) over the two D = 512 bonds
+  (GEMM 8192 x 8192 x 262144), sampled entries against float64 as above."""
+  A = hip.device_random((64, 128, 512, 512), dtype=ta.bfloat16, seed=11, normal=True, a=0.0, b=1.0 / 512)
+  B = hip.device_random((512, 512, 128, 64), dtype=ta.bfloat16, seed=12, normal=True, a=0.0, b=1.0 / 512)
+  a, b = ta.Node(A, backend=hip), ta.Node(B, backend=hip)
+  a[2] ^ b[0]  # pylint: disable=pointless-statement
+  a[3] ^ b[1]  # pylint: disable=pointless-statement
+  out = ta.contract_between(a, b)
+  res = C.verify_pair(hip, A, B, out.tensor, "L0", seed=512)
+  assert res["entries"] >= 1024 and res["ok"], res
