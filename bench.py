@@ -83,7 +83,7 @@ HBM_PEAK_GBPS = 8000.0          # spec, MI355X_MICROARCH.md:35 (about 6.3 TB/s a
 MAX_CLOCK_MHZ = 2400.0
 
 
-def parse_args():
+def parse_args(argv=None):
   p = argparse.ArgumentParser()
   p.add_argument("--gpus", type=int, default=1)
   p.add_argument("--steps", type=int, default=5)
@@ -115,10 +115,14 @@ def parse_args():
                  help="self-launched N > 1 jobs: seconds before the launcher kills every rank")
   p.add_argument("--fill", default="normal", choices=["normal", "zeros"],
                  help="operand fill (zeros shows the DVFS-inflated number; never the headline)")
+  p.add_argument("--allow-host-exchange", action="store_true",
+                 help="N > 1 only: when the RCCL communicator does not come up, carry on with the barrier / scalar reductions "
+                      "over the host rendezvous (TCP) and say so in config.comm; WITHOUT this flag that failure ends the "
+                      "run with a non-zero exit code -- a SCALE record must never show N ranks and no RCCL by accident")
   p.add_argument("--dry-run", action="store_true",
                  help="launcher / rendezvous check only: every rank joins the host rendezvous, rank 0 prints a JSON "
                       "line with n_gpus; no GPU is touched (CPU test of the --gpus N self-launch)")
-  return p.parse_args()
+  return p.parse_args(argv)
 
 
 # --------------------------------------------------------------------------- launcher
@@ -290,18 +294,41 @@ class HostComm:
     self._rdv.close()
 
 
-def bring_up_comm(tcomm, be, rank, world):
-  """(communicator, its name for `config.comm`): RCCL through the C ABI; the host exchange if that raises."""
+RCCL_COMM_NAME = "libtnhip K8 (tnh_allreduce / tnh_allgather over RCCL), TCP rendezvous for the id"
+EXIT_NO_RCCL = 3       # exit code of a multi-rank run whose RCCL communicator did not come up (no --allow-host-exchange)
+
+
+def bring_up_comm(tcomm, be, rank, world, allow_host_exchange=False):
+  """(communicator, its name for `config.comm`): RCCL through the C ABI.  If that raises (on every rank, in step):
+  the run ENDS with exit code EXIT_NO_RCCL -- unless `allow_host_exchange`, in which case the host exchange takes
+  over and every field that names the communicator says so."""
   try:
     comm = make_rccl_comm(tcomm, be, rank, world)
-    return comm, "libtnhip K8 (tnh_allreduce / tnh_allgather over RCCL), TCP rendezvous for the id"
+    return comm, RCCL_COMM_NAME
   except (RuntimeError, TimeoutError) as exc:          # raised on every rank, in step
     reason = f"{type(exc).__name__}: {exc}"[:240]
+    if not allow_host_exchange:
+      print(f"[bench] rank {rank}: the RCCL communicator did not come up ({reason}); a {world}-rank line without RCCL is "
+            "not a measurement of this framework's multi-GPU path -- exiting (pass --allow-host-exchange to run the "
+            "headline over the host rendezvous anyway, labelled)", file=sys.stderr, flush=True)
+      raise SystemExit(EXIT_NO_RCCL) from exc
     print(f"[bench] rank {rank}: the RCCL communicator did not come up ({reason}); barrier / scalar reductions go "
           "through the host rendezvous (TCP) instead -- the headline has no data-path collective", file=sys.stderr, flush=True)
     base = int(os.environ.get("MASTER_PORT", "29500")) + int(os.environ.get("TNH_COMM_PORT_OFFSET", "23"))
     rdv = tcomm.HostRendezvous(rank, world, port=base + 1, timeout=120)
     return HostComm(rdv, reason), f"HOST EXCHANGE (TCP rendezvous): the RCCL communicator did not come up -- {reason}"
+
+
+def rccl_ranks(be, comm):
+  """World size of the LIVE RCCL communicator as the library reports it (tnh_comm_info), 0 when the exchange is not
+  RCCL (one rank without a communicator, or the labelled host exchange)."""
+  import ctypes  # pylint: disable=import-outside-toplevel
+  if comm is None or isinstance(comm, HostComm):
+    return 0
+  r, w = ctypes.c_int(-1), ctypes.c_int(0)
+  if be.lib.tnh_comm_info(ctypes.byref(r), ctypes.byref(w)) != 0:
+    return 0
+  return int(w.value)
 
 
 def sync_all(be, comm):
@@ -713,6 +740,18 @@ def sliced_network_bench(ta, be, comm, rank, world, D, min_slices, verify):
   # without that mode the slice-invariant steps still run once per rank, not once per slice.
   # WHAT RAN: the mode and the executed multiply-adds come from the timed call's own counters -- every
   # rank's, summed -- not from the host cost model; the model's figure stays beside it as a cross-check.
+  # the SAME network and cuts on ONE GPU (every rank runs it, concurrently and without any exchange; rank 0's time is
+  # the record): the denominator of the strong-scaling claim, measured in the same process minutes apart
+  if world > 1:
+    be.synchronize()
+    t1 = time.perf_counter()
+    alone = distributed.contract_sliced(nodes, cuts, comm=distributed.LocalComm(), **kw)
+    be.synchronize()
+    t_one = time.perf_counter() - t1
+    del alone
+    t_one = comm.max_over_ranks(t_one if rank == 0 else 0.0)
+  else:
+    t_one = t
   alone_flops = 2.0 * rep["flops_per_slice"] * rep["n_slices"]
   executed = float(ran.get("executed_macs", 0.0))
   if comm is not None:
@@ -734,6 +773,7 @@ def sliced_network_bench(ta, be, comm, rank, world, D, min_slices, verify):
          "peak_intermediate_elems": rep["peak_per_slice"],
          "steps_per_slice": int(rep.get("steps_per_slice", 0)) - int(rep.get("invariant_steps", 0)),
          "slice_invariant_steps_run_once": int(rep.get("invariant_steps", 0)),
+         "seconds_1gpu_same_cuts": t_one, "speedup_over_1gpu_same_cuts": t_one / t,
          "slowest_rank_compute_seconds": t_compute_max, "allreduce_seconds": t_reduce_max,
          "collective": ("none" if world == 1 else "one all-reduce(sum) of the fp32-accumulated scalar ON THE HOST (TCP; the RCCL "
                         "communicator did not come up)" if isinstance(comm, HostComm) else
@@ -1325,6 +1365,17 @@ def compact_line(result, detail_name):
         line["svd"]["bound"] = _pick(svd["bound"], ("launches", "launch_floor_s", "update_floor_s", "sturm_floor_s", "floor_s"))
       if isinstance(svd.get("cpu_baseline"), dict):
         line["svd"]["cpu_gbps"] = _num(svd["cpu_baseline"].get("value"))
+  line["rccl_ranks"] = result.get("rccl_ranks", 0)
+  sn = result.get("sliced_network")
+  if isinstance(sn, dict) and "seconds" in sn:
+    # the >= 6x claim of north_star, readable without the detail file: the sliced network on N GPUs against the same
+    # network with the same cuts on one of them (`value` above stays the weak-scaling replica aggregate)
+    line["strong_scaling"] = {"workload": str(sn.get("workload", ""))[:72], "n_gpus": sn.get("n_gpus"),
+                              "seconds": _num(sn.get("seconds")), "seconds_1gpu_same_cuts": _num(sn.get("seconds_1gpu_same_cuts")),
+                              "speedup": _num(sn.get("speedup_over_1gpu_same_cuts")),
+                              "ideal": _num(sn.get("ideal_speedup_of_this_partition")),
+                              "collective": "rccl" if result.get("rccl_ranks", 0) == sn.get("n_gpus") and (sn.get("n_gpus") or 1) > 1
+                                            else ("none" if (sn.get("n_gpus") or 1) == 1 else "HOST")}
   line["sliced_network"] = _pick(result.get("sliced_network"),
                                  ("n_slices", "n_gpus", "seconds", "tflops", "mode", "allreduce_seconds", "scaling", "collective",
                                   "permute_time_frac", "ideal_speedup_of_this_partition", "executed_equals_model"))
@@ -1347,7 +1398,8 @@ def compact_line(result, detail_name):
   line = {k: v for k, v in line.items() if v is not None or k == "vs_baseline"}
   line["detail"] = detail_name
   text = json.dumps(line, separators=(",", ":"))
-  for drop in ("gather_gemm_us", "mps_chain_ms", "sliced_network_small", "mera_chi64", "bond_sweep", "mera", "sliced_network", "svd"):
+  for drop in ("gather_gemm_us", "mps_chain_ms", "sliced_network_small", "mera_chi64", "bond_sweep", "mera", "sliced_network", "svd",
+               "strong_scaling"):
     if len(text) < COMPACT_LINE_LIMIT:
       break
     line.pop(drop, None)              # never reached at the bench's own sizes; the contract keys always fit
@@ -1429,7 +1481,7 @@ def main():
     # bench run has a driver-side clock around it: 420 s (a cold librccl.so alone was measured at minutes)
     os.environ.setdefault("TNH_COMM_INIT_TIMEOUT_S", "420")
     with Watchdog(args.bringup_timeout, "communicator bring-up (rendezvous, ncclCommInitRank, first barrier)", rank):
-      comm, comm_name = bring_up_comm(tcomm, be, rank, world)
+      comm, comm_name = bring_up_comm(tcomm, be, rank, world, args.allow_host_exchange)
       sync_all(be, comm)
 
   D = args.bond
@@ -1492,6 +1544,7 @@ def main():
                    "peak_at_observed_clock": (BF16_MFMA_PEAK_TFLOPS * clock / MAX_CLOCK_MHZ) if clock else None,
                    "frac_at_observed_clock": (achieved / (BF16_MFMA_PEAK_TFLOPS * clock / MAX_CLOCK_MHZ)) if clock else None},
   }
+  result["rccl_ranks"] = rccl_ranks(be, comm)
   verified = {}
   if rank == 0 and not args.no_verify and args.fill == "normal":
     try:

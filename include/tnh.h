@@ -376,6 +376,11 @@ int tnh_svd_band_factor(int dtype, int64_t m, int64_t n, const void* A, void* S,
                         int* status_out);
 int tnh_svd_band_vectors(int dtype, int64_t m, int64_t n, void* work, int64_t kcap, int64_t k, void* U, void* Vh,
                          void* S_kept, int* status_out);
+/* Which band reduction the last tnh_svd_band_factor ran (round 6; diagnostics, host only): 1 = the fast stage 1 for
+ * f32 (raw-panel passes fused with the rank-16 updates on the f32 MFMA, the panel factor as an extra workgroup:
+ * four launches per pair of panels), 0 = the ten-launch loop of rounds 3-5 (f64 input, graph capture,
+ * TNH_SVDB_FAST=0), 2 = the fast stage reported an ill-conditioned panel and the stage was repeated with that loop. */
+int tnh_svd_band_last_stage1(void);
 
 /* The block pairs (32-row blocks a < b ... or a in one part, b in another) of ONE sweep of the block Jacobi
  * in launch order, for `nb` blocks and `groups` = 1 (circle method), 2 or 4 (grouped schedule: the groups of a

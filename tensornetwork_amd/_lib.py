@@ -132,6 +132,7 @@ SIGNATURES = {
     "tnh_svd_band_factor": (c_int, [c_int, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_int64, POINTER(c_int)]),
     "tnh_svd_band_vectors": (c_int, [c_int, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p,
                                      POINTER(c_int)]),
+    "tnh_svd_band_last_stage1": (c_int, []),
     "tnh_qr_work_bytes": (c_int, [c_int, c_int64, c_int64, POINTER(c_size_t)]),
     "tnh_qr": (c_int, [c_int, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "tnh_comm_available": (c_int, []),

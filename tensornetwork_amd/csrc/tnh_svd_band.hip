@@ -31,7 +31,8 @@ namespace svdb {
 // band width = panel width = 16 throughout (one 16-lane DPP row per shift)
 constexpr int TP = 18;          // row pitch (doubles) of the rotated band image read by the LDL^T kernels
 
-enum StatusBits { ST_PANEL = 1, ST_PIVOT = 2, ST_CLUSTER = 4, ST_RESID = 8, ST_RANGE = 16 };
+enum StatusBits { ST_PANEL = 1, ST_PIVOT = 2, ST_CLUSTER = 4, ST_RESID = 8, ST_RANGE = 16,
+                  ST_FASTCOND = 1 << 20 };   // internal: a panel too ill-conditioned for the raw-panel passes (round 6)
 
 // ------------------------------------------------------------------------------------------------ small helpers
 template <int SRC>
@@ -239,17 +240,29 @@ __device__ __forceinline__ void cholesky_rows(double (&Gr)[16], int r, double th
   for (int c = 0; c < 16; ++c) Rr[c] = (c > r) ? Gr[c] * myrinv : (c == r ? mydiag : 0.0);
 }
 
-// Inverse of an upper triangular matrix held row per lane (Ur = row r): lane c solves U x = e_c, x[ii] = (U^-1)(ii, c)
-// for ii <= c (entries below the diagonal of the inverse are not touched: the caller masks them).
-__device__ __forceinline__ void upper_inverse_cols(const double (&Ur)[16], int r, double (&x)[16]) {
-  static_for<16>([&](auto ic) {
-    constexpr int ii = 15 - decltype(ic)::value;
-    double acc = (ii == r) ? 1.0 : 0.0;
-    static_for<16>([&](auto kc) {
-      constexpr int k = decltype(kc)::value;
-      if (k > ii) acc = fma(-bcast16_dpp<ii>(Ur[k]), x[k], acc);
+// Inverse of an upper triangular matrix held row per lane (Ur = row r of U): on return Xr = row r of U^-1 (entries
+// left of the diagonal are not touched: the caller masks them).  Row-oriented back substitution, last row first:
+// X(r, :) = (e_r - sum_{k > r} U(r, k) X(k, :)) / U(r, r) -- U(r, k) is the lane's OWN register, the finished row k
+// travels by DPP.  (The column-oriented form of rounds 3-5 broadcast the 120 entries of U instead; none of those
+// broadcasts depends on the solve, the compiler issued them all up front and the kernel held 368 registers.)
+__device__ __forceinline__ void upper_inverse_rows(const double (&Ur)[16], int r, double (&Xr)[16]) {
+  double diag = 1.0;
+  static_for<16>([&](auto cc) {
+    constexpr int c = decltype(cc)::value;
+    Xr[c] = (c == r) ? 1.0 : 0.0;
+    if (c == r) diag = Ur[c];
+  });
+  const double mydinv = fast_rcp(diag);
+  static_for<16>([&](auto kc) {
+    constexpr int k = 15 - decltype(kc)::value;
+    const double f = (r < k) ? Ur[k] : 0.0;
+    static_for<16>([&](auto cc) {
+      constexpr int c = decltype(cc)::value;
+      if (c >= k) {
+        if (r == k) Xr[c] *= mydinv;
+        Xr[c] = fma(-f, bcast16_dpp<k>(Xr[c]), Xr[c]);
+      }
     });
-    x[ii] = acc * fast_rcp(bcast16_dpp<ii>(Ur[ii]));
   });
 }
 
@@ -298,13 +311,13 @@ __device__ __forceinline__ void panel_factor(FactorShared& sh, bool degenerate, 
         }
       });
     });
-    // ---- X = Ut^-1: lane c solves Ut x = e_c; Ut(ii, k) comes from lane ii, register k
+    // ---- X = Ut^-1, row r in lane r
     double x[16];
-    upper_inverse_cols(Wr, r, x);
+    upper_inverse_rows(Wr, r, x);
     if (tid < 16) {
 #pragma unroll
       for (int k = 0; k < 16; ++k) {
-        sh.X[k][r] = (k <= r) ? x[k] : 0.0;
+        sh.X[r][k] = (k >= r) ? x[k] : 0.0;
         sh.R[r][k] = Rr[k];
         sh.L[r][k] = (k < r) ? Wr[k] : (k == r ? 1.0 : 0.0);
       }
@@ -365,15 +378,16 @@ __device__ __forceinline__ double gram_sum(const double* __restrict__ Gpart, int
 //   the reflector H that triangularises Q1 ([S R2; 0]) triangularises P0 = Q1 R1 to [S R2 R1; 0]: Blk = S R2 R1.
 // (Round-3 measurement: the first version repeated this factorisation in every V-forming workgroup; with more than 8
 // workgroups the launch took 40-60 us instead of 12.)
+// cond_limit > 0 (round 6, the raw-panel passes of tnh_svd_band_fast.inc): a panel whose Cholesky factor has
+// max R_jj / min R_jj above it raises ST_FASTCOND -- the passes' rounding errors are amplified by cond(panel).
 template <bool ROWPANEL, typename T>
-__global__ __launch_bounds__(256) void factor_kernel(const T* __restrict__ P, int64_t lda, int64_t rows,
-                                                     const double* __restrict__ Gpart, int nparts,
-                                                     double* __restrict__ Xout, T* __restrict__ Vout,
-                                                     T* __restrict__ VtOut, int64_t vt_pitch,
-                                                     double* __restrict__ Tout, double* __restrict__ Blk,
-                                                     const double* __restrict__ R1, double rel_thresh,
-                                                     int* __restrict__ status) {
-  __shared__ FactorShared sh;
+__device__ __forceinline__ void factor_body(FactorShared& sh, const T* __restrict__ P, int64_t lda, int64_t rows,
+                                            const double* __restrict__ Gpart, int nparts,
+                                            double* __restrict__ Xout, T* __restrict__ Vout,
+                                            T* __restrict__ VtOut, int64_t vt_pitch,
+                                            double* __restrict__ Tout, double* __restrict__ Blk,
+                                            const double* __restrict__ R1, double rel_thresh, double cond_limit,
+                                            int* __restrict__ status) {
   const int tid = threadIdx.x, i = tid >> 4, c = tid & 15;
   {
     const double g = gram_sum(Gpart, nparts, tid);
@@ -400,8 +414,30 @@ __global__ __launch_bounds__(256) void factor_kernel(const T* __restrict__ P, in
   else Blk[c * 16 + i] = rh;                                    // transposed: lower triangular
   const T vt = (T)((i >= c) ? sh.L[i][c] : 0.0);                // V_top, unit lower
   Vout[(int64_t)i * 16 + c] = vt;
-  if (ROWPANEL) VtOut[(int64_t)c * vt_pitch + i] = vt;
+  if (ROWPANEL && VtOut != nullptr) VtOut[(int64_t)c * vt_pitch + i] = vt;
   if (tid == 0 && sh.bad) atomicOr(status, (int)ST_PANEL);
+  if (cond_limit > 0.0 && tid == 0) {
+    double rmax = 0.0, rmin = 1e300;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      rmax = fmax(rmax, sh.R[k][k]);
+      rmin = fmin(rmin, sh.R[k][k]);
+    }
+    if (!(rmax <= cond_limit * rmin)) atomicOr(status, (int)ST_FASTCOND);
+  }
+}
+
+template <bool ROWPANEL, typename T>
+__global__ __launch_bounds__(256) void factor_kernel(const T* __restrict__ P, int64_t lda, int64_t rows,
+                                                     const double* __restrict__ Gpart, int nparts,
+                                                     double* __restrict__ Xout, T* __restrict__ Vout,
+                                                     T* __restrict__ VtOut, int64_t vt_pitch,
+                                                     double* __restrict__ Tout, double* __restrict__ Blk,
+                                                     const double* __restrict__ R1, double rel_thresh,
+                                                     int* __restrict__ status) {
+  __shared__ FactorShared sh;
+  factor_body<ROWPANEL, T>(sh, P, lda, rows, Gpart, nparts, Xout, Vout, VtOut, vt_pitch, Tout, Blk, R1, rel_thresh, 0.0,
+                           status);
 }
 
 // f64 path, first pass of the Cholesky-QR2: G1 = P^T P (partials) -> R1 (upper, f64) and R1^-1.  One workgroup (one
@@ -425,12 +461,12 @@ __global__ __launch_bounds__(256) void chol_kernel(const double* __restrict__ Gp
   for (int k = 0; k < 16; ++k) gmax = fmax(gmax, G[k][k]);
   int bad = 0;
   cholesky_rows(Gr, r, 1e-13 * fmax(gmax, 1e-300), bad, Rr);
-  upper_inverse_cols(Rr, r, x);
+  upper_inverse_rows(Rr, r, x);
   if (tid < 16) {
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
       R1[r * 16 + k] = Rr[k];
-      R1inv[k * 16 + r] = (k <= r) ? x[k] : 0.0;       // lane r holds column r of the inverse
+      R1inv[r * 16 + k] = (k >= r) ? x[k] : 0.0;       // lane r holds row r of the inverse
     }
     if (tid == 0 && bad) atomicOr(status, (int)ST_PANEL);
   }
@@ -491,13 +527,12 @@ __global__ __launch_bounds__(256) void scaleq_kernel(T* __restrict__ P, int64_t 
 
 // V rows below the top block: V[r][:] = P[r][:] X (f64 accumulate), r = 16 .. rows - 1, 256 rows per workgroup.
 template <bool ROWPANEL, typename T>
-__global__ __launch_bounds__(256) void formv_kernel(const T* __restrict__ P, int64_t lda, int64_t rows,
-                                                    const double* __restrict__ X, T* __restrict__ Vout,
-                                                    T* __restrict__ VtOut, int64_t vt_pitch) {
-  __shared__ double xs[16][17];
+__device__ __forceinline__ void formv_body(double (*xs)[17], const T* __restrict__ P, int64_t lda, int64_t rows,
+                                           const double* __restrict__ X, T* __restrict__ Vout,
+                                           T* __restrict__ VtOut, int64_t vt_pitch, int64_t blk) {
   const int tid = threadIdx.x;
   xs[tid >> 4][tid & 15] = X[tid];
-  const int64_t r = 16 + (int64_t)blockIdx.x * 256 + tid;
+  const int64_t r = 16 + blk * 256 + tid;
   T p[16];
 #pragma unroll
   for (int l = 0; l < 16; ++l) p[l] = T(0);
@@ -527,11 +562,18 @@ __global__ __launch_bounds__(256) void formv_kernel(const T* __restrict__ P, int
     V4<T>* dst = reinterpret_cast<V4<T>*>(Vout + r * 16);
 #pragma unroll
     for (int q = 0; q < 4; ++q) dst[q] = V4<T>{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
-    if (ROWPANEL) {
+    if (ROWPANEL && VtOut != nullptr) {
 #pragma unroll
       for (int k = 0; k < 16; ++k) VtOut[(int64_t)k * vt_pitch + r] = v[k];
     }
   }
+}
+template <bool ROWPANEL, typename T>
+__global__ __launch_bounds__(256) void formv_kernel(const T* __restrict__ P, int64_t lda, int64_t rows,
+                                                    const double* __restrict__ X, T* __restrict__ Vout,
+                                                    T* __restrict__ VtOut, int64_t vt_pitch) {
+  __shared__ double xs[16][17];
+  formv_body<ROWPANEL, T>(xs, P, lda, rows, X, Vout, VtOut, vt_pitch, (int64_t)blockIdx.x);
 }
 
 // ------------------------------------------------------------------------------------------------ rank-16 streaming
@@ -1697,18 +1739,22 @@ __global__ __launch_bounds__(256) void ns_coeff_kernel(double* __restrict__ G, i
   G[e] = ((e / k == e % k) ? 1.5 : 0.0) - 0.5 * G[e];
 }
 
+// offsets (elements) of panel p's V inside the Vl / Vr blocks: column panel p has m - 16 p rows, row panel p n - 16 p - 16
+__host__ __device__ static inline int64_t vl_offset(int64_t m, int64_t p) { return 16 * (p * m - 8 * p * (p - 1)); }
+__host__ __device__ static inline int64_t vr_offset(int64_t n, int64_t p) { return 16 * (p * n - 8 * p * (p + 1)); }
+
+#include "tnh_svd_band_fast.inc"
+
 // ------------------------------------------------------------------------------------------------ host side
 static inline size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct Layout {
-  size_t Af, Vl, Vr, Vt, Zr, Tl, Tr, Dblk, Eblk, Gpart, Gpart2, Gq, R1, R1inv, Xbuf, Wpart, Wt, Bd, Tb, Trot, scal, shifts,
-      counts, flags, lo, hi, status, ray, Lc, Dd, X, X2, X3, Gns, Uu, Vv, total;
+  size_t Af, Vl, Vr, Vt, Zr, Tl, Tr, Dblk, Eblk, Gpart, Gpart2, Gq, R1, R1inv, Xbuf, Xl, Xr, Wpart, Wt, Bd, Tb, Trot, scal,
+      shifts, counts, flags, lo, hi, status, ray, Lc, Dd, X, X2, X3, Gns, Uu, Vv, total;
   int64_t np, kcap, nshift;
   int esz;
 };
 
-static int64_t vl_offset(int64_t m, int64_t p) { return 16 * (p * m - 8 * p * (p - 1)); }        // elements
-static int64_t vr_offset(int64_t n, int64_t p) { return 16 * (p * n - 8 * p * (p + 1)); }        // elements
 
 // esz: 4 (f32 input) or 8 (f64 input).  Everything up to `status` does not depend on kcap except through the shift
 // buffers' size; the f64-only blocks (Gq .. R1inv, ray, X2, X3, Gns) are empty for f32.
@@ -1731,19 +1777,25 @@ static Layout make_layout(int64_t m, int64_t n, int64_t kcap, int esz) {
   L.Tr = take((size_t)np * 256 * 8);
   L.Dblk = take((size_t)np * 256 * 8);
   L.Eblk = take((size_t)np * 256 * 8);
-  const int64_t maxparts = (m + 127) / 128 + 1;      // gram_kernel: 256 rows per part; update_kernel<1>: 128
+  const int64_t maxparts = (m + 63) / 64 + 1;        // gram_kernel: 256 rows per part; update_kernel<1>: 128; rowreduce: 64
   L.Gpart = take((size_t)maxparts * 256 * 8);
   L.Gpart2 = take((size_t)((n + 63) / 64 + 1) * 256 * 8);      // update_kernel<2>: one part per 64 columns
   L.Gq = take(f64 ? (size_t)((m + 255) / 256 + 1) * 256 * 8 : 0);   // Cholesky-QR2: Gram partials of Q1 (256 rows per part)
   L.R1 = take(f64 ? 256 * 8 : 0);
   L.R1inv = take(f64 ? 256 * 8 : 0);
   L.Xbuf = take(256 * 8);
+  L.Xl = take(f64 ? 0 : (size_t)np * 256 * 8);       // fast stage 1 (f32): X of every panel, for the batched V
+  L.Xr = take(f64 ? 0 : (size_t)np * 256 * 8);
   const int64_t wide = n > kcap ? n : kcap;
   const int64_t wrc = f64 ? w_rc<double>() : w_rc<float>();
   const int64_t chunks = (m + wrc - 1) / wrc;
   size_t wpart = (size_t)chunks * 16 * wide * e;
   const size_t ypart = (size_t)((n + Y_COLS - 1) / Y_COLS) * m * 16 * e;     // the row panels' Y partials share the buffer
   if (ypart > wpart) wpart = ypart;
+  if (!f64) {       // fast stage 1: raw-pass partials per 64-row block (16 x n each) or per 64-column tile (m x 16 each)
+    const size_t fast = (size_t)((m + 63) / 64 + 1) * 16 * (size_t)(n > m ? n : m) * e;
+    if (fast > wpart) wpart = fast;
+  }
   L.Wpart = take(wpart);
   L.Wt = take((size_t)16 * wide * e);
   L.Bd = take((size_t)n * 17 * 8);
@@ -1773,6 +1825,13 @@ static Layout make_layout(int64_t m, int64_t n, int64_t kcap, int esz) {
   return L;
 }
 
+// ---- fast stage 1 (f32): tnh_svd_band_fast.inc
+static int g_last_fast = 0;
+static bool g_fast = true;          // TNH_SVDB_FAST=0: the loop of rounds 3-5 for every panel
+static int g_fast_switch = 128;     // hand over when the trailing block has this many columns or fewer (TNH_SVDB_FAST_SWITCH)
+static double g_fast_cond = 16.0;   // panels with max / min Cholesky diagonal above this: ST_FASTCOND, stage 1 is repeated (TNH_SVDB_FAST_COND)
+static int g_fast_cw = 0;           // column tile of the fused kernels: 0 = by size, 64, 128 (TNH_SVDB_FAST_CW)
+static int g_fast_wgs = 1024;       // workgroups a fused launch aims at (TNH_SVDB_FAST_WGS)
 static bool g_dpp = true;
 static double g_cluster_tol = 4e-7;  // kept values closer than this (relative to sigma_max: a few eps_f32) are one cluster (TNH_SVDB_CTOL)
 static double g_cluster_tol64 = 1e-10;  // f64 input: closer than this is a cluster; wider neighbours are separated by the
@@ -1828,6 +1887,16 @@ static void read_env() {
   if (e && atoi(e) >= 0) g_refine_rounds = atoi(e);
   e = getenv("TNH_SVDB_NS");
   g_ns64 = !(e && e[0] == '0');
+  e = getenv("TNH_SVDB_FAST");
+  g_fast = !(e && e[0] == '0');
+  e = getenv("TNH_SVDB_FAST_SWITCH");
+  g_fast_switch = (e && atoi(e) >= 32) ? atoi(e) : 128;
+  e = getenv("TNH_SVDB_FAST_COND");
+  g_fast_cond = (e && atof(e) > 1.0) ? atof(e) : 16.0;
+  e = getenv("TNH_SVDB_FAST_CW");
+  g_fast_cw = (e && (atoi(e) == 64 || atoi(e) == 128)) ? atoi(e) : 0;
+  e = getenv("TNH_SVDB_FAST_WGS");
+  g_fast_wgs = (e && atoi(e) >= 64) ? atoi(e) : 1024;
   e = getenv("TNH_SVDB_BITS64");
   if (e && atoi(e) >= 20 && atoi(e) <= 44) g_bits64 = atoi(e);
 }
@@ -1878,8 +1947,10 @@ static int section_round(const Layout& L, char* base, int64_t n, int64_t q0, int
   return TNH_OK;
 }
 
+// p_begin > 0: the panels before it were reduced by stage1_fast, which also left the partial Gram matrices of column
+// panel p_begin (parts_in of them) in Gpart.
 template <typename T>
-static int stage1(const Layout& L, char* base, int64_t m, int64_t n) {
+static int stage1(const Layout& L, char* base, int64_t m, int64_t n, int64_t p_begin = 0, int parts_in = 0) {
   constexpr bool QR2 = sizeof(T) == 8;       // f64 input: two Cholesky-QR passes per panel (see chol_kernel)
   constexpr int WRC = w_rc<T>();
   constexpr int YR = y_rows<T>();
@@ -1896,8 +1967,9 @@ static int stage1(const Layout& L, char* base, int64_t m, int64_t n) {
   int* status = (int*)(base + L.status);
   const int64_t np = L.np;
   int parts_c = (int)((m + 255) / 256), parts_r = 0;
-  hipLaunchKernelGGL((gram_kernel<false, T>), dim3(parts_c), dim3(256), 0, stream(), (const T*)Af, n, m, Gc);
-  for (int64_t p = 0; p < np; ++p) {
+  if (p_begin == 0) hipLaunchKernelGGL((gram_kernel<false, T>), dim3(parts_c), dim3(256), 0, stream(), (const T*)Af, n, m, Gc);
+  else parts_c = parts_in;
+  for (int64_t p = p_begin; p < np; ++p) {
     const int64_t j = 16 * p;
     const int64_t mj = m - j, nc = n - j - 16, mr = m - j - 16;
     // ---- column panel: rows j .., columns j .. j + 15
@@ -1983,6 +2055,122 @@ static int stage1(const Layout& L, char* base, int64_t m, int64_t n) {
     }
     TNH_LAUNCH_CHECK();
   }
+  return TNH_OK;
+}
+
+
+// ---- fast stage 1 (f32): tnh_svd_band_fast.inc.  Panels 0 .. *p_next - 1 are reduced here; the caller finishes with
+// stage1<float>(..., *p_next, *parts_out).
+
+template <int CW>
+static void launch_colupd(const ColUpdArgs& a, unsigned grid) {
+  hipLaunchKernelGGL((colupd_rowpass_kernel<CW, true>), dim3(grid), dim3(256), 0, stream(), a);
+}
+template <int CW>
+static void launch_rowupd(const RowUpdArgs& a, unsigned grid, bool upd, bool pass) {
+  if (upd && pass) hipLaunchKernelGGL((rowupd_colpass_kernel<CW, true, true, true>), dim3(grid), dim3(256), 0, stream(), a);
+  else if (pass) hipLaunchKernelGGL((rowupd_colpass_kernel<CW, false, true, true>), dim3(grid), dim3(256), 0, stream(), a);
+  else hipLaunchKernelGGL((rowupd_colpass_kernel<CW, true, false, false>), dim3(grid), dim3(256), 0, stream(), a);
+}
+// 64-row steps per workgroup: as many workgroups as g_fast_wgs allows, at most 4 steps
+static int fast_iters(int64_t rows, int ntc) {
+  const int64_t units = (rows + 63) / 64;
+  int64_t it = (units * ntc + g_fast_wgs - 1) / g_fast_wgs;
+  if (it < 1) it = 1;
+  if (it > 4) it = 4;
+  return (int)it;
+}
+
+static int stage1_fast(const Layout& L, char* base, int64_t m, int64_t n, int64_t* p_next, int* parts_out) {
+  float* Af = (float*)(base + L.Af);
+  double* Gc = (double*)(base + L.Gpart);
+  double* Gr = (double*)(base + L.Gpart2);
+  float* Part = (float*)(base + L.Wpart);
+  float* Wx = (float*)(base + L.Wt);
+  float* Zx = (float*)(base + L.Zr);
+  float* Vl = (float*)(base + L.Vl);
+  float* Vr = (float*)(base + L.Vr);
+  double* Xl = (double*)(base + L.Xl);
+  double* Xr = (double*)(base + L.Xr);
+  double* Tl = (double*)(base + L.Tl);
+  double* Tr = (double*)(base + L.Tr);
+  int* status = (int*)(base + L.status);
+  int64_t ps = 0;
+  while (ps < L.np && n - 16 * ps > g_fast_switch) ++ps;
+  *p_next = 0;
+  if (ps < 2) return TNH_OK;
+  int parts_c = (int)((m + 255) / 256), parts_r = 0;
+  hipLaunchKernelGGL((gram_kernel<false, float>), dim3(parts_c), dim3(256), 0, stream(), (const float*)Af, n, m, Gc);
+  for (int64_t p = 0; p <= ps; ++p) {
+    const int64_t j = 16 * p;
+    const int64_t mj = m - j, nc = n - j - 16, mr = m - j - 16;
+    const bool last = p == ps;           // only the pending row update of panel ps - 1
+    if (nc <= 0) break;
+    const int cw = g_fast_cw ? g_fast_cw : (nc >= 2048 ? 128 : 64);     // column tile of colupd_rowpass
+    const int cwb = g_fast_cw == 128 ? 128 : 64;                         // ... of rowupd_colpass
+    const int ntc = (int)((nc + cw - 1) / cw);
+    // ---- row panel p - 1's update of everything right of column panel p + the raw pass and the factor of that panel
+    int nrt;
+    {
+      RowUpdArgs a;
+      a.C = Af + j * n + j + 16;
+      a.ldc = n;
+      a.rows = mj;
+      a.nc = nc;
+      a.Zx = Zx + j * 16;
+      a.Pr = p > 0 ? Af + (j - 16) * n + j + 16 : Af;
+      a.Pcol = Af + j * n + j;
+      a.Wpart = Part;
+      a.ntc = (int)((nc + cwb - 1) / cwb);
+      a.iters = fast_iters(mj, a.ntc);
+      nrt = (int)(((mj + 63) / 64 + a.iters - 1) / a.iters);
+      a.fa = FactorArgs{Af + j * n + j, n, mj, Gc, parts_c, Xl + p * 256, Vl + vl_offset(m, p), Tl + p * 256,
+                        (double*)(base + L.Dblk) + p * 256, 1e-9, g_fast_cond, status};
+      const unsigned grid = (unsigned)(nrt * a.ntc) + (last ? 0u : 1u);
+      if (cwb == 128) launch_rowupd<128>(a, grid, p > 0, !last);     // (spills 44 registers at three waves per SIMD: knob only)
+      else launch_rowupd<64>(a, grid, p > 0, !last);
+    }
+    if (last) break;
+    // ---- the 16 x 16 algebra per trailing column: row panel p finished, Wx, its partial Grams
+    parts_r = (int)((nc + 63) / 64);
+    hipLaunchKernelGGL(colreduce_kernel, dim3((unsigned)parts_r), dim3(256), 0, stream(), (const float*)Part, nrt, nc,
+                       Af + j * n + j + 16, n, (const float*)(Vl + vl_offset(m, p)), (const double*)(Xl + p * 256),
+                       (const double*)(Tl + p * 256), Wx, n, Gr);
+    // ---- column panel p's update + the raw pass and the factor of row panel p
+    {
+      ColUpdArgs a;
+      a.C = Af + (j + 16) * n + j + 16;
+      a.ldc = n;
+      a.rows = mr;
+      a.nc = nc;
+      a.Pcol = Af + (j + 16) * n + j;
+      a.Wx = Wx;
+      a.wx_pitch = n;
+      a.Pr = Af + j * n + j + 16;
+      a.Ypart = Part;
+      a.ntc = ntc;
+      a.iters = fast_iters(mr, ntc);
+      const int nrt2 = (int)(((mr + 63) / 64 + a.iters - 1) / a.iters);
+      a.fa = FactorArgs{Af + j * n + j + 16, n, nc, Gr, parts_r, Xr + p * 256, Vr + vr_offset(n, p), Tr + p * 256,
+                        (double*)(base + L.Eblk) + p * 256, 1e-9, g_fast_cond, status};
+      const unsigned grid = (unsigned)(nrt2 * ntc) + 1u;
+      if (cw == 128) launch_colupd<128>(a, grid);
+      else launch_colupd<64>(a, grid);
+    }
+    // ---- the same algebra per trailing row: column panel p + 1 finished, Zx, its partial Grams
+    parts_c = (int)((mr + 63) / 64);
+    hipLaunchKernelGGL(rowreduce_kernel, dim3((unsigned)parts_c), dim3(256), 0, stream(), (const float*)Part, ntc, mr,
+                       Af + (j + 16) * n + j + 16, n, (const float*)(Vr + vr_offset(n, p)), (const double*)(Xr + p * 256),
+                       (const double*)(Tr + p * 256), Zx + (j + 16) * 16, Gc);
+    TNH_LAUNCH_CHECK();
+  }
+  {
+    FormVAllArgs a{Af, m, n, ps, Xl, Xr, Vl, Vr};
+    hipLaunchKernelGGL(formv_all_kernel, dim3((unsigned)((m - 16 + 255) / 256), (unsigned)ps, 2), dim3(256), 0, stream(), a);
+  }
+  TNH_LAUNCH_CHECK();
+  *p_next = ps;
+  *parts_out = parts_c;
   return TNH_OK;
 }
 
@@ -2341,21 +2529,48 @@ int tnh_svd_band_factor(int dtype, int64_t m, int64_t n, const void* A, void* S,
   char* base = (char*)(((uintptr_t)work + 255) & ~(uintptr_t)255);
   const int esz = dtype == TNH_F64 ? 8 : 4;
   const Layout L = make_layout(m, n, kcap > 4 ? kcap : 4, esz);
-  TNH_HIP(hipMemcpyAsync(base + L.Af, A, (size_t)m * n * esz, hipMemcpyDeviceToDevice, stream()));
-  TNH_HIP(hipMemsetAsync(base + L.status, 0, 64, stream()));
-  TNH_HIP(hipMemsetAsync(base + L.Eblk, 0, (size_t)L.np * 256 * 8, stream()));
-  int rc = esz == 8 ? stage1<double>(L, base, m, n) : stage1<float>(L, base, m, n);
-  if (rc) return rc;
-  rc = esz == 8 ? values<double>(L, base, n, (double*)S) : values<float>(L, base, n, (float*)S);
-  if (rc) return rc;
-  if (status_out) {
+  // f32: the fast stage 1 first (raw-panel passes, four launches per pair of panels).  It cannot know beforehand
+  // whether every panel is well enough conditioned for it, so the whole factor stage is enqueued speculatively and
+  // the status word read at the end; ST_FASTCOND repeats the stage with the loop of rounds 3-5.  Without a status
+  // read-back (graph capture) the speculation cannot be checked: the accurate loop runs directly.
+  bool fast = g_fast && esz == 4 && status_out != nullptr;
+  g_last_fast = 0;
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    TNH_HIP(hipMemcpyAsync(base + L.Af, A, (size_t)m * n * esz, hipMemcpyDeviceToDevice, stream()));
+    TNH_HIP(hipMemsetAsync(base + L.status, 0, 64, stream()));
+    TNH_HIP(hipMemsetAsync(base + L.Eblk, 0, (size_t)L.np * 256 * 8, stream()));
+    int rc;
+    if (fast) {
+      int64_t p_next = 0;
+      int parts = 0;
+      rc = stage1_fast(L, base, m, n, &p_next, &parts);
+      if (rc) return rc;
+      rc = stage1<float>(L, base, m, n, p_next, parts);
+      g_last_fast = p_next > 0 ? 1 : 0;
+    } else {
+      rc = esz == 8 ? stage1<double>(L, base, m, n) : stage1<float>(L, base, m, n);
+    }
+    if (rc) return rc;
+    rc = esz == 8 ? values<double>(L, base, n, (double*)S) : values<float>(L, base, n, (float*)S);
+    if (rc) return rc;
+    if (!status_out) break;
     int st = 0;
     TNH_HIP(hipMemcpyAsync(&st, base + L.status, sizeof(int), hipMemcpyDeviceToHost, stream()));
     TNH_HIP(hipStreamSynchronize(stream()));
-    *status_out = st;
+    if (fast && (st & (int)ST_FASTCOND)) {      // an ill-conditioned panel: once more, accurately
+      fast = false;
+      g_last_fast = 2;
+      continue;
+    }
+    *status_out = st & ~(int)ST_FASTCOND;
+    break;
   }
   return TNH_OK;
 }
+
+// 0: the last tnh_svd_band_factor ran the loop of rounds 3-5; 1: the fast stage 1; 2: the fast stage 1 reported an
+// ill-conditioned panel and the stage was repeated with the accurate loop.
+int tnh_svd_band_last_stage1(void) { return g_last_fast; }
 
 int tnh_svd_band_vectors(int dtype, int64_t m, int64_t n, void* work, int64_t kcap, int64_t k, void* U, void* Vh,
                          void* S_kept, int* status_out) {

@@ -284,7 +284,7 @@ def _bench_host_comm_worker(rank, world, port, out_path):
   class _NoGpuBackend:
     lib = _lib.load_library()
 
-  c, name = bench.bring_up_comm(comm, _NoGpuBackend(), rank, world)
+  c, name = bench.bring_up_comm(comm, _NoGpuBackend(), rank, world, allow_host_exchange=True)
   c.barrier()
   rec = {"type": type(c).__name__, "name": name, "rank": c.rank, "world": c.world,
          "max": c.max_over_ranks(1.5 + rank), "sum": c.sum_over_ranks(float(rank)),
@@ -304,7 +304,7 @@ def _bench_host_comm_worker(rank, world, port, out_path):
 
 
 def test_bench_host_exchange_when_rccl_cannot_come_up(tmp_path):
-  """bench.bring_up_comm: no GPU here, so the K8 communicator raises on every rank -- and every rank then holds a
+  """bench.bring_up_comm with --allow-host-exchange: no GPU here, so the K8 communicator raises on every rank -- and every rank then holds a
   HostComm (TCP rendezvous): barrier, max / sum of a scalar, the small all-reduce of the sliced network (f32, complex,
   the same bits on every rank), a size limit.  `config.comm` names the host exchange and the reason."""
   import json
@@ -325,6 +325,79 @@ def test_bench_host_exchange_when_rccl_cannot_come_up(tmp_path):
     assert rec["f32"] == [float(sum(k + 1 for k in range(world))), 0.25 * world] and rec["f32_dtype"] == "float32"
     assert rec["c64"] == [[float(world), float(sum(range(world)))]]
     assert "small results" in rec["too_large"]
+
+
+def _bench_no_rccl_worker(rank, world, port, out_path):
+  root = os.path.dirname(HERE)
+  sys.path.insert(0, root)
+  os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), TNH_COMM_PORT_OFFSET="0")
+  import importlib
+  from tensornetwork_amd import _lib, comm
+  importlib.reload(comm)
+  import bench
+
+  class _NoGpuBackend:
+    lib = _lib.load_library()
+
+  try:
+    bench.bring_up_comm(comm, _NoGpuBackend(), rank, world)          # the default: no host exchange
+    outcome = "came up"
+  except SystemExit as exc:
+    outcome = f"SystemExit {exc.code}"
+  with open(out_path + f".{rank}.txt", "w") as f:
+    f.write(outcome)
+
+
+def test_bench_exits_nonzero_when_rccl_cannot_come_up_by_default(tmp_path):
+  """without --allow-host-exchange a multi-rank bench whose RCCL communicator does not come up
+  ENDS (exit code bench.EXIT_NO_RCCL, on every rank, in step) instead of printing an N-rank line without RCCL."""
+  import torch.multiprocessing as mp
+  import bench
+  with socket.socket() as s:
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+  out_path = str(tmp_path / "norccl")
+  mp.spawn(_bench_no_rccl_worker, args=(2, port, out_path), nprocs=2, join=True)
+  for r in range(2):
+    with open(out_path + f".{r}.txt") as f:
+      assert f.read() == f"SystemExit {bench.EXIT_NO_RCCL}"
+  assert bench.EXIT_NO_RCCL != 0
+  assert bench.parse_args(["--gpus", "2"]).allow_host_exchange is False
+  assert bench.parse_args(["--gpus", "2", "--allow-host-exchange"]).allow_host_exchange is True
+
+
+def test_bench_line_carries_rccl_ranks_and_the_strong_scaling_claim():
+  """the compact line says how many ranks the LIVE RCCL communicator has (0 for the host exchange
+  or a single process) and carries the strong-scaling numbers of the sliced network -- N-GPU seconds, the same cuts
+  on one GPU, speedup, the partition's ideal -- so the >= 6x claim needs no detail file."""
+  import json
+  import bench
+  sn = {"workload": "64-node random 3-regular network (seed 6), bond D=16, bf16, 2 cut bonds", "n_slices": 256, "n_gpus": 8,
+        "seconds": 0.2, "seconds_1gpu_same_cuts": 1.4, "speedup_over_1gpu_same_cuts": 7.0, "ideal_speedup_of_this_partition": 7.99,
+        "tflops": 6500.0, "scaling": "strong"}
+  base = {"metric": "m", "value": 1.0, "unit": "TFLOP/s", "n_gpus": 8, "scaling": "weak", "config": {"comm": bench.RCCL_COMM_NAME},
+          "sliced_network": sn}
+  line = json.loads(bench.compact_line(dict(base, rccl_ranks=8), "d.json"))
+  assert line["rccl_ranks"] == 8 and line["scaling"] == "weak"
+  assert line["strong_scaling"] == {"workload": sn["workload"][:72], "n_gpus": 8, "seconds": 0.2, "seconds_1gpu_same_cuts": 1.4,
+                                    "speedup": 7.0, "ideal": 7.99, "collective": "rccl"}
+  # the labelled host exchange: no RCCL ranks, and the strong-scaling entry says whose exchange it was
+  line = json.loads(bench.compact_line(dict(base, rccl_ranks=0), "d.json"))
+  assert line["rccl_ranks"] == 0 and line["strong_scaling"]["collective"] == "HOST"
+  one = dict(base, n_gpus=1, rccl_ranks=0, sliced_network=dict(sn, n_gpus=1, seconds=1.4, speedup_over_1gpu_same_cuts=1.0))
+  line = json.loads(bench.compact_line(one, "d.json"))
+  assert line["strong_scaling"]["collective"] == "none" and line["strong_scaling"]["speedup"] == 1.0
+
+  class _Lib:
+    def tnh_comm_info(self, r, w):
+      r._obj.value, w._obj.value = 3, 8       # pylint: disable=protected-access
+      return 0
+
+  class _Be:
+    lib = _Lib()
+  assert bench.rccl_ranks(_Be(), object()) == 8
+  assert bench.rccl_ranks(_Be(), None) == 0
+  assert bench.rccl_ranks(_Be(), bench.HostComm.__new__(bench.HostComm)) == 0
 
 
 def test_single_node_rccl_env_pins_loopback(monkeypatch):
