@@ -2531,9 +2531,10 @@ int tnh_svd_band_factor(int dtype, int64_t m, int64_t n, const void* A, void* S,
   const Layout L = make_layout(m, n, kcap > 4 ? kcap : 4, esz);
   // f32: the fast stage 1 first (raw-panel passes, four launches per pair of panels).  It cannot know beforehand
   // whether every panel is well enough conditioned for it, so the whole factor stage is enqueued speculatively and
-  // the status word read at the end; ST_FASTCOND repeats the stage with the loop of rounds 3-5.  Without a status
-  // read-back (graph capture) the speculation cannot be checked: the accurate loop runs directly.
-  bool fast = g_fast && esz == 4 && status_out != nullptr;
+  // the status word read at the end (one stream synchronisation, also when the caller did not ask for the status);
+  // ST_FASTCOND repeats the stage with the loop of rounds 3-5.  Under graph capture nothing can be read back, the
+  // speculation cannot be checked: the accurate loop runs directly.
+  bool fast = g_fast && esz == 4 && !capturing();
   g_last_fast = 0;
   for (int attempt = 0; attempt < 2; ++attempt) {
     TNH_HIP(hipMemcpyAsync(base + L.Af, A, (size_t)m * n * esz, hipMemcpyDeviceToDevice, stream()));
@@ -2553,7 +2554,7 @@ int tnh_svd_band_factor(int dtype, int64_t m, int64_t n, const void* A, void* S,
     if (rc) return rc;
     rc = esz == 8 ? values<double>(L, base, n, (double*)S) : values<float>(L, base, n, (float*)S);
     if (rc) return rc;
-    if (!status_out) break;
+    if (!status_out && !fast) break;
     int st = 0;
     TNH_HIP(hipMemcpyAsync(&st, base + L.status, sizeof(int), hipMemcpyDeviceToHost, stream()));
     TNH_HIP(hipStreamSynchronize(stream()));
@@ -2562,7 +2563,7 @@ int tnh_svd_band_factor(int dtype, int64_t m, int64_t n, const void* A, void* S,
       g_last_fast = 2;
       continue;
     }
-    *status_out = st & ~(int)ST_FASTCOND;
+    if (status_out) *status_out = st & ~(int)ST_FASTCOND;
     break;
   }
   return TNH_OK;

@@ -246,6 +246,80 @@ def _gather_piece_bytes(desc, itemsize=2):
   return run * itemsize
 
 
+MAX_KERNEL_RANK = 16      # TNH_MAX_RANK of include/tnh.h: what ONE K1 / K5 launch can index
+
+
+def _coalesce_permutation(shape, perm):
+  """(shape', perm') of the same data movement with fewer axes: extent-1 axes dropped, source axes that stay adjacent
+  and in order in the output merged.  `perm[i]` = source axis of output axis i."""
+  keep = [p for p in perm if shape[p] != 1]
+  if not keep:
+    return [1], [0]
+  runs = [[keep[0]]]
+  for p in keep[1:]:
+    if p == runs[-1][-1] + 1 and all(shape[q] == 1 for q in range(runs[-1][-1] + 1, p)):
+      runs[-1].append(p)
+    else:
+      # extent-1 axes between two source axes do not separate them in memory
+      last = runs[-1][-1]
+      if p > last and all(shape[q] == 1 for q in range(last + 1, p)):
+        runs[-1].append(p)
+      else:
+        runs.append([p])
+  order = sorted(range(len(runs)), key=lambda r: runs[r][0])          # the runs in source order
+  pos = {r: i for i, r in enumerate(order)}
+  cshape = [_prod(shape[a] for a in runs[r]) for r in order]
+  return cshape, [pos[r] for r in range(len(runs))]
+
+
+def _permute_passes(shape, perm, limit=MAX_KERNEL_RANK):
+  """A permutation of any rank as a list of (shape_i, perm_i) passes with at most `limit` axes each (after
+  coalescing).  One pass whenever the coalesced permutation fits -- always for rank <= 16.  Otherwise every pass moves
+  the next (limit - 2) // 2 output axes into place behind the finished prefix: the prefix is one merged axis, the moved
+  axes split the rest into at most that many + 1 runs that keep their order, so the pass has <= limit axes."""
+  shape, perm = list(shape), list(perm)
+  cshape, cperm = _coalesce_permutation(shape, perm)
+  if len(cshape) <= limit:
+    return [(cshape, cperm)]
+  step = (limit - 2) // 2
+  order = list(range(len(shape)))            # source axes in their current memory order
+  passes, done = [], 0
+  while order != perm:
+    cur_shape = [shape[a] for a in order]
+    direct = [order.index(a) for a in perm]
+    cshape, cperm = _coalesce_permutation(cur_shape, direct)
+    if len(cshape) <= limit:
+      passes.append((cshape, cperm))
+      break
+    moved = perm[done:done + step]
+    new_order = perm[:done + step] + [a for a in order[done:] if a not in moved]
+    cshape, cperm = _coalesce_permutation(cur_shape, [order.index(a) for a in new_order])
+    assert len(cshape) <= limit, (len(cshape), limit)
+    passes.append((cshape, cperm))
+    order, done = new_order, done + step
+  return passes
+
+
+def _coalesce_strided(shape, *stride_lists):
+  """Merge adjacent axes of a strided iteration space wherever EVERY operand walks them as one run
+  (stride[d] == stride[d + 1] * shape[d + 1], zero strides included); extent-1 axes dropped."""
+  dims = [d for d in range(len(shape)) if shape[d] != 1]
+  if not dims:
+    return [1], [[0] for _ in stride_lists]
+  oshape, ostr = [shape[dims[0]]], [[st[dims[0]]] for st in stride_lists]
+  for d in dims[1:]:
+    if all(o[-1] == st[d] * shape[d] for o, st in zip(ostr, stride_lists)):
+      oshape[-1] *= shape[d]
+      for o, st in zip(ostr, stride_lists):
+        o[-1] = st[d]
+    else:
+      oshape.append(shape[d])
+      for o, st in zip(ostr, stride_lists):
+        o.append(st[d])
+  return oshape, ostr
+
+
+
 class HipBackend(BackendBase):
   """TensorNetwork backend running on one MI355X through libtnhip.so.
 
@@ -460,9 +534,21 @@ class HipBackend(BackendBase):
       raise ValueError("axes don't match array")
     if perm == tuple(range(nd)):
       return tensor
-    if nd > 16:
-      raise NotImplementedError("hip backend supports tensors up to rank 16")
-    out = DeviceTensor.empty([tensor.shape[p] for p in perm], tensor.code, tensor.alias)
+    out_shape = [tensor.shape[p] for p in perm]
+    if nd > MAX_KERNEL_RANK:
+      # more axes than one K1 launch indexes: coalesce (axes that travel together are one axis to the kernel); a
+      # permutation that still has more than 16 independent runs takes several passes (_permute_passes)
+      cur = tensor
+      for cshape, cperm in _permute_passes(tensor.shape, perm):
+        if cperm == list(range(len(cperm))):
+          continue
+        nxt = DeviceTensor.empty([cshape[p] for p in cperm], tensor.code, tensor.alias)
+        self.permute_launches += 1
+        _lib.check(self.lib.tnh_permute(_vp(nxt), _vp(cur), len(cshape), _lib.i64_array(cshape),
+                                        _lib.i32_array(cperm), tensor.itemsize), "tnh_permute")
+        cur = nxt
+      return cur.view(out_shape) if cur is not tensor else self.copy(tensor).view(out_shape)
+    out = DeviceTensor.empty(out_shape, tensor.code, tensor.alias)
     self.permute_launches += 1
     _lib.check(self.lib.tnh_permute(_vp(out), _vp(tensor), nd, _lib.i64_array(tensor.shape),
                                     _lib.i32_array(perm), tensor.itemsize), "tnh_permute")
@@ -470,8 +556,14 @@ class HipBackend(BackendBase):
 
   def _strided_copy(self, tensor, shape, strides, offset):
     out = DeviceTensor.empty(shape, tensor.code, tensor.alias)
-    _lib.check(self.lib.tnh_strided_copy(_vp(out), _vp(tensor), len(shape), _lib.i64_array(shape),
-                                         _lib.i64_array(strides), int(offset), tensor.itemsize),
+    kshape, kstrides = list(shape), list(strides)
+    if len(kshape) > MAX_KERNEL_RANK:
+      kshape, (kstrides,) = _coalesce_strided(kshape, kstrides)
+      if len(kshape) > MAX_KERNEL_RANK:
+        raise NotImplementedError(f"a strided window with {len(kshape)} independent axes (one launch indexes "
+                                  f"{MAX_KERNEL_RANK}): slice it in two steps")
+    _lib.check(self.lib.tnh_strided_copy(_vp(out), _vp(tensor), len(kshape), _lib.i64_array(kshape),
+                                         _lib.i64_array(kstrides), int(offset), tensor.itemsize),
                "tnh_strided_copy")
     return out
 
@@ -1142,8 +1234,6 @@ class HipBackend(BackendBase):
     except ValueError as exc:
       raise ValueError(f"operands could not be broadcast together with shapes "
                        f"{a.shape} {b.shape}") from exc
-    if len(shape) > 16:
-      raise NotImplementedError("hip backend supports tensors up to rank 16")
 
     def bstrides(t):
       pad = len(shape) - t.ndim
@@ -1152,8 +1242,15 @@ class HipBackend(BackendBase):
       return [0 if dims[d] == 1 and shape[d] != 1 else st[d] for d in range(len(shape))]
 
     out = DeviceTensor.empty(shape, code, alias)
-    _lib.check(self.lib.tnh_binary(op, _vp(out), _vp(a), _vp(b), len(shape), _lib.i64_array(shape),
-                                   _lib.i64_array(bstrides(a)), _lib.i64_array(bstrides(b)), code),
+    kshape, sa, sb = list(shape), bstrides(a), bstrides(b)
+    if len(kshape) > MAX_KERNEL_RANK:
+      # axes both operands (and the result) walk as one run are one axis to the kernel
+      kshape, (sa, sb, _) = _coalesce_strided(kshape, sa, sb, _row_major_strides(shape))
+      if len(kshape) > MAX_KERNEL_RANK:
+        raise NotImplementedError(f"a broadcast with {len(kshape)} independent axes (one launch indexes "
+                                  f"{MAX_KERNEL_RANK})")
+    _lib.check(self.lib.tnh_binary(op, _vp(out), _vp(a), _vp(b), len(kshape), _lib.i64_array(kshape),
+                                   _lib.i64_array(sa), _lib.i64_array(sb), code),
                "tnh_binary")
     return out
 
@@ -1969,11 +2066,14 @@ class HipBackend(BackendBase):
     return krylov.eigsh_lanczos(self, A, args, initial_state, shape, dtype, num_krylov_vecs, numeig, tol,
                                 delta, ndiag, reorthogonalize)
 
-  def eigsh(self, A, args=None, initial_state=None, shape=None, dtype=None, num_krylov_vecs=50, numeig=6,
-            tol=1E-8, which='LA', maxiter=None):
-    """Thick-restart Lanczos on device vectors (abstract_backend.py:380-426; the reference wraps
-    scipy.sparse.linalg.eigsh, numpy_backend.py:168-214)."""
+  def eigsh(self, A, args=None, initial_state=None, shape=None, dtype=None, num_krylov_vecs=50, numeig=1,
+            tol=1E-8, which='LR', maxiter=None):
+    """Thick-restart Lanczos on device vectors.  Signature and defaults of the interface
+    (abstract_backend.py:380-426; the reference's NumPy backend declares the same signature and raises
+    NotImplementedError, numpy_backend.py:168-214).  For a Hermitian operator the interface's 'LR' / 'SR' (largest /
+    smallest real part) are scipy's 'LA' / 'SA', which are accepted too."""
     from tensornetwork_amd import krylov  # pylint: disable=import-outside-toplevel
+    which = {'LR': 'LA', 'SR': 'SA'}.get(which, which)
     if initial_state is not None and not isinstance(initial_state, DeviceTensor):
       raise TypeError("Expected a `DeviceTensor`. Got {}".format(type(initial_state)))
     return krylov.eigsh(self, A, args, initial_state, shape, dtype, num_krylov_vecs, numeig, tol, which, maxiter)

@@ -705,3 +705,61 @@ def check_tensor_api(be, rtol):
   assert info == 0 and isinstance(x, tt.Tensor)
   with pytest.raises(ValueError, match="One of backend or x0 must be specified"):
     tl.eigsh_lanczos(mv)
+
+
+# --------------------------------------------------------------------------- the boundary without the reference
+def signature_mismatches(backend_cls):
+  """Every public method of the reference's AbstractBackend / NumPyBackend (tests/golden/abstract_backend_signatures.json,
+  a snapshot written by tests/golden/make_golden_signatures.py) must exist on `backend_cls` with the same parameter
+  names in the same order and the same defaults; extra parameters are allowed only with defaults.  Where the two
+  reference classes disagree (the abstract class declares `dtype` without a default for eye / ones / zeros, gives
+  eigs numeig = 1) the NumPy backend -- the oracle of SURVEY 8c -- wins."""
+  import inspect, json, os   # pylint: disable=import-outside-toplevel,multiple-imports
+  with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "abstract_backend_signatures.json")) as f:
+    rec = json.load(f)
+  want = dict(rec["AbstractBackend"])
+  want.update(rec["NumPyBackend"])
+  bad = []
+  for name, params in sorted(want.items()):
+    if name == "__init__":           # construction is the factory's business (backend_factory.py:22-46), not the interface's
+      continue
+    fn = getattr(backend_cls, name, None)
+    if fn is None:
+      bad.append(f"{name}: missing")
+      continue
+    mine = list(inspect.signature(fn).parameters.values())
+    for i, p in enumerate(params):
+      if i >= len(mine) or mine[i].name != p["name"] or mine[i].kind.name != p["kind"]:
+        got = f"{mine[i].name} ({mine[i].kind.name})" if i < len(mine) else None
+        bad.append(f"{name}: parameter {i} is {got}, the reference has {p['name']} ({p['kind']})")
+        break
+      has = mine[i].default is not inspect.Parameter.empty
+      if has != ("default" in p) or (has and repr(mine[i].default) != p["default"]):
+        bad.append(f"{name}: default of {p['name']!r} is {mine[i].default!r}, the reference has {p.get('default', '<none>')}")
+        break
+    for e in mine[len(params):]:
+      if e.default is inspect.Parameter.empty and e.kind.name not in ("VAR_POSITIONAL", "VAR_KEYWORD"):
+        bad.append(f"{name}: extra required parameter {e.name!r}")
+  return bad
+
+
+def run_high_rank_cases(be):
+  """Tensors of more than 16 axes (TNH_MAX_RANK): transpose (coalesced to one launch, and a reversal that needs two
+  passes), broadcast arithmetic, slices, and a tensordot over scattered axes -- bit for bit against NumPy."""
+  rng = np.random.default_rng(21)
+  x = rng.standard_normal((2,) * 18).astype(np.float32)
+  d = be.convert_to_tensor(x)
+  for perm in ([17] + list(range(17)), list(range(9, 18)) + list(range(9)), list(range(17, -1, -1)),
+               [int(p) for p in rng.permutation(18)]):
+    np.testing.assert_array_equal(np.asarray(be.transpose(d, perm)), np.transpose(x, perm), err_msg=str(perm))
+  y = rng.standard_normal((2,) * 18).astype(np.float32)
+  np.testing.assert_array_equal(np.asarray(be.addition(d, be.convert_to_tensor(y))), x + y)
+  row = rng.standard_normal((2,) * 3).astype(np.float32)                     # broadcast over the 15 leading axes
+  np.testing.assert_array_equal(np.asarray(be.multiply(d, be.convert_to_tensor(row))), x * row)
+  np.testing.assert_array_equal(np.asarray(be.slice(d, (0,) * 17 + (1,), (2,) * 17 + (1,))), x[..., 1:2])
+  a = rng.standard_normal((2,) * 17).astype(np.float64)
+  b = rng.standard_normal((2,) * 17).astype(np.float64)
+  axes = [[1, 5, 16, 9], [0, 7, 3, 11]]
+  got = np.asarray(be.tensordot(be.convert_to_tensor(a), be.convert_to_tensor(b), axes))
+  assert got.shape == (2,) * 26
+  np.testing.assert_allclose(got, np.tensordot(a, b, axes), rtol=1e-12, atol=1e-12)

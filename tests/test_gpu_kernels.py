@@ -1623,3 +1623,14 @@ def test_d512_row_full_size_sampled_entries(hip):
   out = ta.contract_between(a, b)
   res = C.verify_pair(hip, A, B, out.tensor, "L0", seed=512)
   assert res["entries"] >= 1024 and res["ok"], res
+
+
+def test_hip_backend_accepts_the_reference_signatures(hip):
+  """the boundary against the committed snapshot of abstract_backend.py:27-1046 /
+  numpy_backend.py -- same parameter names, order and defaults (driver-verifiable: no reference on the box)."""
+  assert C.signature_mismatches(type(hip)) == []
+
+
+def test_high_rank_tensors(hip):
+  """More than 16 axes: the coalescing pre-pass and the multi-pass permutation on the GPU, bit for bit."""
+  C.run_high_rank_cases(hip)
