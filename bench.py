@@ -508,21 +508,25 @@ def check_svd_case(mat_host, s_ref, n, k, outputs):
 
 def svd_bound(m, n, k, itemsize=4):
   """What bounds the band SVD (tnh_svd_band.hip) of an m x n matrix keeping k triplets -- NOT the metric's
-  algorithmic bytes (75.5 MB at 4096^2: 9 us of HBM time).  Counted from the algorithm (DESIGN.md section 6b):
-    launches       dependent kernel launches: 10 per 16-wide panel pair of stage 1 (f64 input: 14, two Cholesky-QR
-                   passes), ~40 for the spectrum slicing, ~12 for the vectors;  floor = 4.5 us each back to back;
-    update_bytes   the rank-16 streaming updates read the trailing block once for W = V^T C and read + write it for
-                   C -= V W, for the column and for the row panel: 6 x itemsize x sum_p (m - 16 p)(n - 16 p);
-                   floor at the 6.3 TB/s a copy reaches on this part;
+  algorithmic bytes (75.5 MB at 4096^2: 9 us of HBM time).  Counted from the algorithm (DESIGN.md section 5):
+    launches       dependent kernel launches of stage 1: f32 input (round 6, tnh_svd_band_fast.inc) FOUR per pair of
+                   16-wide panels -- two fused update + raw-pass sweeps with the panel factor as an extra workgroup,
+                   two reduce kernels -- and the ten-launch loop of rounds 3-5 for the last 8 panels; f64 input that
+                   loop throughout (14 per pair: two Cholesky-QR passes); ~40 for the spectrum slicing, ~12 for the
+                   vectors;  floor = 4.5 us each back to back;
+    update_bytes   f32: every fused sweep reads and writes the trailing block once, two sweeps per pair:
+                   4 x itemsize x sum_p (m - 16 p)(n - 16 p); f64 (and f32 before round 6): a read for W = V^T C plus
+                   a read + write for C -= V W, twice: 6 x;  floor at the 6.3 TB/s a copy reaches on this part;
     sturm_fma      f64 FMAs of the Sturm counts: 139 per pivot, n pivots per shift, 65536 + 15 n shifts for all values
                    (f64 input: three more rounds) + 3 x 15 k for the kept ones; this chip issues one 64-lane v_fma_f64
                    per SIMD every 8 cycles: floor = FMAs / 64 x 8 cycles / (1024 SIMDs x 2.4 GHz).
   The three floors add up (the stages are dependent): that sum is the `floor_s` the measured time is compared with."""
   npanels = n // 16
   f64 = itemsize == 8
-  launches = (14 if f64 else 10) * npanels + 40 + (12 if f64 else 0) + 12
+  slow_panels = npanels if f64 else min(npanels, 8)
+  launches = (14 if f64 else 10) * slow_panels + 4 * (npanels - slow_panels) + 40 + (12 if f64 else 0) + 12
   tail = sum((m - 16 * p) * (n - 16 * p) for p in range(npanels))
-  update_bytes = 6.0 * itemsize * tail
+  update_bytes = (6.0 if f64 else 4.0) * itemsize * tail
   rounds_all = 1 + (3 if f64 else 0)
   shifts = 65536 + rounds_all * 15 * n + (6 if f64 else 3) * 15 * k
   sturm_fma = 139.0 * n * shifts

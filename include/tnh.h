@@ -379,7 +379,9 @@ int tnh_svd_band_vectors(int dtype, int64_t m, int64_t n, void* work, int64_t kc
 /* Which band reduction the last tnh_svd_band_factor ran (round 6; diagnostics, host only): 1 = the fast stage 1 for
  * f32 (raw-panel passes fused with the rank-16 updates on the f32 MFMA, the panel factor as an extra workgroup:
  * four launches per pair of panels), 0 = the ten-launch loop of rounds 3-5 (f64 input, graph capture,
- * TNH_SVDB_FAST=0), 2 = the fast stage reported an ill-conditioned panel and the stage was repeated with that loop. */
+ * TNH_SVDB_FAST=0), 2 = the fast stage reported an ill-conditioned panel (max / min diagonal of a panel's Cholesky
+ * factor above TNH_SVDB_FAST_COND = 16) and the stage was repeated with that loop, 3 = that loop directly because the
+ * shape's last calls kept reporting (skipped for min(2^f, 64) calls after f reports in a row). */
 int tnh_svd_band_last_stage1(void);
 
 /* The block pairs (32-row blocks a < b ... or a in one part, b in another) of ONE sweep of the block Jacobi

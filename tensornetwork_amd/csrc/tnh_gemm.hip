@@ -1068,9 +1068,12 @@ int tnh_gemm_ex(int in_dtype, int out_dtype, int transA, int transB, int64_t M, 
   if (plain && !cplx_in && !int_in && batch == 1 && ldc == N && K >= kmin && g_variant == 0 && !g_in_splitk) {
     const int64_t tiles = ((M + 127) / 128) * ((N + 127) / 128);
     const bool mid = K < 4096;
-    int64_t splits = mid ? std::min<int64_t>({K / 128, (2 * (int64_t)num_cus()) / tiles, 32})
+    // Round 6: one side below 64 (an MPS site tensor's physical leg against a bond: M = 2 ... 32, N = 1024, K = 512 ran
+    // 35 us on 8 workgroups -- profiles/r06_mps_chain_shapes.jsonl) is split too, into slices of >= 64.
+    const bool skinny = mid && wide_in && std::min(M, N) < 64 && std::max(M, N) >= 256;
+    int64_t splits = mid ? std::min<int64_t>({K / (skinny ? 64 : 128), (2 * (int64_t)num_cus()) / tiles, 32})
                          : std::min<int64_t>({K / 1024, (2 * (int64_t)num_cus()) / tiles, 256});
-    const bool few = mid ? (tiles * 8 <= (int64_t)num_cus() && M >= 64 && N >= 64) : (tiles * 4 <= (int64_t)num_cus());
+    const bool few = mid ? (tiles * 8 <= (int64_t)num_cus() && ((M >= 64 && N >= 64) || skinny)) : (tiles * 4 <= (int64_t)num_cus());
     if (few && splits >= 2) {
       int64_t kc = (K + splits - 1) / splits;
       kc = (kc + 63) / 64 * 64;                       // keeps the bf16 kernels' K % 64 rule for full slices

@@ -21,6 +21,7 @@
 // (status word) and the caller re-runs the Jacobi path: no silent loss of accuracy.
 #include <math.h>
 #include <stdlib.h>
+#include <map>
 #include <utility>
 #include <type_traits>
 #include "tnh_types.h"
@@ -1749,7 +1750,7 @@ __host__ __device__ static inline int64_t vr_offset(int64_t n, int64_t p) { retu
 static inline size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct Layout {
-  size_t Af, Vl, Vr, Vt, Zr, Tl, Tr, Dblk, Eblk, Gpart, Gpart2, Gq, R1, R1inv, Xbuf, Xl, Xr, Wpart, Wt, Bd, Tb, Trot, scal,
+  size_t Af, Vl, Vr, Vt, Zr, Tl, Tr, Dblk, Eblk, Gpart, Gpart2, Gq, R1, R1inv, Xbuf, Xl, Xr, Ff, Wpart, Wt, Bd, Tb, Trot, scal,
       shifts, counts, flags, lo, hi, status, ray, Lc, Dd, X, X2, X3, Gns, Uu, Vv, total;
   int64_t np, kcap, nshift;
   int esz;
@@ -1786,6 +1787,7 @@ static Layout make_layout(int64_t m, int64_t n, int64_t kcap, int esz) {
   L.Xbuf = take(256 * 8);
   L.Xl = take(f64 ? 0 : (size_t)np * 256 * 8);       // fast stage 1 (f32): X of every panel, for the batched V
   L.Xr = take(f64 ? 0 : (size_t)np * 256 * 8);
+  L.Ff = take(f64 ? 0 : 2 * 512 * 4);                // f32 X and T^-1 of the panel being reduced (column side, row side)
   const int64_t wide = n > kcap ? n : kcap;
   const int64_t wrc = f64 ? w_rc<double>() : w_rc<float>();
   const int64_t chunks = (m + wrc - 1) / wrc;
@@ -2095,6 +2097,8 @@ static int stage1_fast(const Layout& L, char* base, int64_t m, int64_t n, int64_
   double* Tl = (double*)(base + L.Tl);
   double* Tr = (double*)(base + L.Tr);
   int* status = (int*)(base + L.status);
+  float* Ffc = (float*)(base + L.Ff);
+  float* Ffr = Ffc + 512;
   int64_t ps = 0;
   while (ps < L.np && n - 16 * ps > g_fast_switch) ++ps;
   *p_next = 0;
@@ -2125,7 +2129,7 @@ static int stage1_fast(const Layout& L, char* base, int64_t m, int64_t n, int64_
       a.iters = fast_iters(mj, a.ntc);
       nrt = (int)(((mj + 63) / 64 + a.iters - 1) / a.iters);
       a.fa = FactorArgs{Af + j * n + j, n, mj, Gc, parts_c, Xl + p * 256, Vl + vl_offset(m, p), Tl + p * 256,
-                        (double*)(base + L.Dblk) + p * 256, 1e-9, g_fast_cond, status};
+                        (double*)(base + L.Dblk) + p * 256, 1e-9, g_fast_cond, status, Ffc};
       const unsigned grid = (unsigned)(nrt * a.ntc) + (last ? 0u : 1u);
       if (cwb == 128) launch_rowupd<128>(a, grid, p > 0, !last);     // (spills 44 registers at three waves per SIMD: knob only)
       else launch_rowupd<64>(a, grid, p > 0, !last);
@@ -2134,8 +2138,7 @@ static int stage1_fast(const Layout& L, char* base, int64_t m, int64_t n, int64_
     // ---- the 16 x 16 algebra per trailing column: row panel p finished, Wx, its partial Grams
     parts_r = (int)((nc + 63) / 64);
     hipLaunchKernelGGL(colreduce_kernel, dim3((unsigned)parts_r), dim3(256), 0, stream(), (const float*)Part, nrt, nc,
-                       Af + j * n + j + 16, n, (const float*)(Vl + vl_offset(m, p)), (const double*)(Xl + p * 256),
-                       (const double*)(Tl + p * 256), Wx, n, Gr);
+                       Af + j * n + j + 16, n, (const float*)(Vl + vl_offset(m, p)), (const float*)Ffc, Wx, n, Gr);
     // ---- column panel p's update + the raw pass and the factor of row panel p
     {
       ColUpdArgs a;
@@ -2152,7 +2155,7 @@ static int stage1_fast(const Layout& L, char* base, int64_t m, int64_t n, int64_
       a.iters = fast_iters(mr, ntc);
       const int nrt2 = (int)(((mr + 63) / 64 + a.iters - 1) / a.iters);
       a.fa = FactorArgs{Af + j * n + j + 16, n, nc, Gr, parts_r, Xr + p * 256, Vr + vr_offset(n, p), Tr + p * 256,
-                        (double*)(base + L.Eblk) + p * 256, 1e-9, g_fast_cond, status};
+                        (double*)(base + L.Eblk) + p * 256, 1e-9, g_fast_cond, status, Ffr};
       const unsigned grid = (unsigned)(nrt2 * ntc) + 1u;
       if (cw == 128) launch_colupd<128>(a, grid);
       else launch_colupd<64>(a, grid);
@@ -2160,8 +2163,8 @@ static int stage1_fast(const Layout& L, char* base, int64_t m, int64_t n, int64_
     // ---- the same algebra per trailing row: column panel p + 1 finished, Zx, its partial Grams
     parts_c = (int)((mr + 63) / 64);
     hipLaunchKernelGGL(rowreduce_kernel, dim3((unsigned)parts_c), dim3(256), 0, stream(), (const float*)Part, ntc, mr,
-                       Af + (j + 16) * n + j + 16, n, (const float*)(Vr + vr_offset(n, p)), (const double*)(Xr + p * 256),
-                       (const double*)(Tr + p * 256), Zx + (j + 16) * 16, Gc);
+                       Af + (j + 16) * n + j + 16, n, (const float*)(Vr + vr_offset(n, p)), (const float*)Ffr,
+                       Zx + (j + 16) * 16, Gc);
     TNH_LAUNCH_CHECK();
   }
   {
@@ -2536,6 +2539,19 @@ int tnh_svd_band_factor(int dtype, int64_t m, int64_t n, const void* A, void* S,
   // speculation cannot be checked: the accurate loop runs directly.
   bool fast = g_fast && esz == 4 && !capturing();
   g_last_fast = 0;
+  // Inputs whose panels are too ill-conditioned for the fast stage (numerically rank-deficient blocks: two-site DMRG
+  // splits, zero-padded tensors) come in runs of the same shape; a shape that reported ST_FASTCOND f times in a row
+  // goes straight to the accurate loop for the next min(2^f, 64) calls instead of paying both stages every time.
+  static std::map<std::pair<int64_t, int64_t>, std::pair<int, int>> backoff;      // (m, n) -> (failures in a row, calls to skip)
+  const std::pair<int64_t, int64_t> key(m, n);
+  if (fast) {
+    auto it = backoff.find(key);
+    if (it != backoff.end() && it->second.second > 0) {
+      --it->second.second;
+      fast = false;
+      g_last_fast = 3;
+    }
+  }
   for (int attempt = 0; attempt < 2; ++attempt) {
     TNH_HIP(hipMemcpyAsync(base + L.Af, A, (size_t)m * n * esz, hipMemcpyDeviceToDevice, stream()));
     TNH_HIP(hipMemsetAsync(base + L.status, 0, 64, stream()));
@@ -2561,8 +2577,12 @@ int tnh_svd_band_factor(int dtype, int64_t m, int64_t n, const void* A, void* S,
     if (fast && (st & (int)ST_FASTCOND)) {      // an ill-conditioned panel: once more, accurately
       fast = false;
       g_last_fast = 2;
+      auto& e = backoff[key];
+      e.first = e.first < 6 ? e.first + 1 : 6;
+      e.second = 1 << e.first;
       continue;
     }
+    if (fast) backoff.erase(key);
     if (status_out) *status_out = st & ~(int)ST_FASTCOND;
     break;
   }
@@ -2570,7 +2590,8 @@ int tnh_svd_band_factor(int dtype, int64_t m, int64_t n, const void* A, void* S,
 }
 
 // 0: the last tnh_svd_band_factor ran the loop of rounds 3-5; 1: the fast stage 1; 2: the fast stage 1 reported an
-// ill-conditioned panel and the stage was repeated with the accurate loop.
+// ill-conditioned panel and the stage was repeated with the accurate loop; 3: the accurate loop directly, because the
+// shape's previous calls kept reporting (back-off).
 int tnh_svd_band_last_stage1(void) { return g_last_fast; }
 
 int tnh_svd_band_vectors(int dtype, int64_t m, int64_t n, void* work, int64_t kcap, int64_t k, void* U, void* Vh,

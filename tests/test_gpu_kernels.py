@@ -520,7 +520,10 @@ def test_gemm_split_k_mid_size_f32_f64(hip, dtype):
   kmin = 512
   for (m, n, k, ta_, tb_, want) in [(512, 512, 1024, 0, 0, True), (1024, 512, 1000, 0, 1, True), (512, 1024, kmin, 1, 0, True),
                                     (200, 300, 2500, 1, 1, True), (512, 512, kmin - 64, 0, 0, False),
-                                    (32, 512, 2048, 0, 0, False), (2048, 2048, 1024, 0, 1, False)]:
+                                    (32, 512, 2048, 0, 0, True), (2, 1024, 512, 0, 0, True), (4, 1024, 512, 0, 1, True),
+                                    (1024, 8, 640, 1, 1, True),          # round 6: one side below 64 against a long one (MPS site legs)
+                                    (32, 200, 2048, 0, 0, False),        # ... but not two small sides
+                                    (2048, 2048, 1024, 0, 1, False)]:
     out, ref, kernel, sk = _gemm_case(hip, dtype, m, n, k, ta_, tb_, rng=rng)
     assert (kernel == "splitk") == want, (kernel, m, n, k)
     tol = 2e-6 if dtype == np.float32 else 1e-14
