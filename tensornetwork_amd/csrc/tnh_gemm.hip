@@ -873,6 +873,45 @@ static bool f32_v2_enabled() {
 }
 
 static thread_local const char* g_last_kernel = "none";
+// ---- tiny outputs (round 6): M x N <= 16 results over a contraction of up to 2^20 -- the full contraction that ends an
+// MPS overlap (<psi|psi> = a 1 x 1 x 65536 "GEMM") ran 75 us through the split-K machinery (64 slices of a 128 x 128
+// tile each).  ONE workgroup of 1024 threads: thread t takes k = t, t + 1024, ... for all M x N outputs (coalesced
+// along k when the operands are k-contiguous or M = N = 1), fixed-order tree reduction: deterministic.
+template <typename T>
+__global__ __launch_bounds__(1024) void gemm_tiny_kernel(const T* __restrict__ A, int64_t sam, int64_t sak,
+                                                         const T* __restrict__ B, int64_t sbk, int64_t sbn,
+                                                         T* __restrict__ C, int64_t ldc, int M, int N, int64_t K) {
+  __shared__ T red[16][16];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  T acc[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = T(0);
+  for (int64_t k = tid; k < K; k += 1024) {
+    T av[4], bv[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) av[m] = (m < M) ? A[m * sam + k * sak] : T(0);
+#pragma unroll
+    for (int n = 0; n < 4; ++n) bv[n] = (n < N) ? B[k * sbk + n * sbn] : T(0);
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int n = 0; n < 4; ++n) acc[4 * m + n] += av[m] * bv[n];
+  }
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const T v = wave_sum(acc[i]);
+    if (lane == 0) red[w][i] = v;
+  }
+  __syncthreads();
+  if (tid < 16) {
+    T sum = T(0);
+#pragma unroll
+    for (int ww = 0; ww < 16; ++ww) sum += red[ww][tid];
+    const int m = tid >> 2, n = tid & 3;
+    if (m < M && n < N) C[(int64_t)m * ldc + n] = sum;
+  }
+}
+
 static thread_local bool g_in_splitk = false;   // re-entrancy guard of the split-K path
 static int g_variant = 0;  // 0 auto, 1 generic (mfma), 2 valu, 3 bf16_128, 4 bf16_256, 5 bf16_256pp,
                            // 6 bf16_ragged (auto shape), 7 .._128x128, 8 .._64x256, 9 .._256x64
@@ -1052,6 +1091,21 @@ int tnh_gemm_ex(int in_dtype, int out_dtype, int transA, int transB, int64_t M, 
   TNH_REQUIRE(ldb >= (transB ? K : N), "ldb too small");
 
   const bool plain = (alpha == 1.0 && beta == 0.0);
+
+  // ---- tiny outputs: one workgroup (gemm_tiny_kernel)
+  if (plain && batch == 1 && M <= 4 && N <= 4 && K >= 1024 && K <= (int64_t(1) << 20) && g_variant == 0 &&
+      out_dtype == in_dtype && (in_dtype == TNH_F32 || in_dtype == TNH_F64)) {
+    const int64_t sam = transA ? 1 : lda, sak = transA ? lda : 1, sbk = transB ? 1 : ldb, sbn = transB ? ldb : 1;
+    if (in_dtype == TNH_F32)
+      hipLaunchKernelGGL((gemm_tiny_kernel<float>), dim3(1), dim3(1024), 0, stream(), (const float*)A, sam, sak,
+                         (const float*)B, sbk, sbn, (float*)C, ldc, (int)M, (int)N, K);
+    else
+      hipLaunchKernelGGL((gemm_tiny_kernel<double>), dim3(1), dim3(1024), 0, stream(), (const double*)A, sam, sak,
+                         (const double*)B, sbk, sbn, (double*)C, ldc, (int)M, (int)N, K);
+    TNH_LAUNCH_CHECK();
+    g_last_kernel = "tiny_1wg";
+    return TNH_OK;
+  }
 
   // ---- split-K: few output tiles and a long contraction (inner products <x, y>, environment
   // updates with a small result ...).  One workgroup per tile would walk all of K alone -- a

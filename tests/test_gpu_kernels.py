@@ -503,7 +503,8 @@ def test_gemm_split_k_small_output(hip, dtype):
   rng = np.random.default_rng(7)
   for (m, n, k, ta_, tb_) in [(1, 1, 262144, 0, 1), (3, 5, 70001, 0, 0), (64, 130, 20000, 1, 1), (200, 100, 9000, 1, 0)]:
     out, ref, kernel, sk = _gemm_case(hip, dtype, m, n, k, ta_, tb_, rng=rng)
-    assert kernel == "splitk", (kernel, m, n, k)
+    tiny = dtype in (np.float32, np.float64) and m <= 4 and n <= 4       # round 6: one workgroup (gemm_tiny_kernel)
+    assert kernel == ("tiny_1wg" if tiny else "splitk"), (kernel, m, n, k)
     if dtype in (ta.bfloat16, np.float16):      # split-K partials are f32, rounded once at the end: the same rule
       assert_gemm(out, ref, dtype, k, err_msg=f"{m}x{n}x{k}")
       continue
@@ -1637,3 +1638,18 @@ def test_hip_backend_accepts_the_reference_signatures(hip):
 def test_high_rank_tensors(hip):
   """More than 16 axes: the coalescing pre-pass and the multi-pass permutation on the GPU, bit for bit."""
   C.run_high_rank_cases(hip)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_gemm_tiny_outputs_one_workgroup(hip, dtype):
+  """Round 6: at most 4 x 4 results over K = 1024 ... 2^20 (the full contraction that ends an MPS overlap) are ONE
+  workgroup's tree reduction instead of a split-K GEMM of 128 x 128 tiles; every storage form, ragged K."""
+  rng = np.random.default_rng(23)
+  for (m, n, k, ta_, tb_) in [(1, 1, 65536, 0, 1), (1, 1, 65536, 0, 0), (2, 3, 5000, 0, 0), (2, 3, 5000, 1, 1), (4, 4, 1024, 0, 1),
+                              (3, 1, 100001, 1, 0), (1, 4, 1 << 20, 0, 1)]:
+    out, ref, kernel, _ = _gemm_case(hip, dtype, m, n, k, ta_, tb_, rng=rng)
+    assert kernel == "tiny_1wg", (kernel, m, n, k)
+    tol = 2e-6 if dtype == np.float32 else 1e-14
+    np.testing.assert_allclose(out, ref, rtol=tol * 4, atol=tol * np.sqrt(k) * 4, err_msg=f"{m}x{n}x{k} {ta_}{tb_}")
+  out, ref, kernel, _ = _gemm_case(hip, dtype, 5, 2, 4096, 0, 1, rng=rng)      # five rows: not tiny
+  assert kernel != "tiny_1wg"

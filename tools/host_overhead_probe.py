@@ -37,3 +37,27 @@ pr.disable()
 s = io.StringIO()
 pstats.Stats(pr, stream=s).sort_stats("cumulative").print_stats(45)
 print(s.getvalue()[:9000])
+
+# ---- round 6: the configs[3] chain (16-site MPS overlap, D = 512, d = 2, f32) under the same lens
+from tensornetwork_amd import contractors, workloads as wl
+kets = wl.mps_tensors(16, 2, 512, seed=5, dtype=np.float32)
+dev = [be.convert_to_tensor(k) for k in kets]
+def chain():
+  return contractors.greedy(wl.mps_overlap_network(be, dev)).tensor
+for _ in range(5): chain()
+be.synchronize()
+t0 = time.perf_counter()
+for _ in range(50): chain()
+be.synchronize()
+print("mps chain eager ms per call:", round((time.perf_counter() - t0) / 50 * 1e3, 3))
+t0 = time.perf_counter()
+for _ in range(50): wl.mps_overlap_network(be, dev)
+print("  of which building the 32-node network:", round((time.perf_counter() - t0) / 50 * 1e3, 3), "ms")
+pr = cProfile.Profile()
+pr.enable()
+for _ in range(50): chain()
+be.synchronize()
+pr.disable()
+s = io.StringIO()
+pstats.Stats(pr, stream=s).sort_stats("tottime").print_stats(40)
+print(s.getvalue()[:9000])
