@@ -271,6 +271,12 @@ int tnh_compare(int op, void* dst, const void* a, const void* b, double scalar,
                 int64_t n, int dtype);
 int tnh_masked_fill(void* dst, const void* src, const void* mask, double re,
                     double im, int64_t n, int dtype);
+/* index_update with a TENSOR assignee (round 6): dst = copy(src); the k-th set position of mask (row-major order)
+ * takes values[k] -- numpy's `t[mask] = assignee` for a 1-d assignee (numpy_backend.py:548-552).  Elements are moved
+ * as `itemsize` raw bytes (2, 4, 8 or 16).  *count_out (host, may be NULL = no read-back) = number of set positions:
+ * the caller raises numpy's ValueError when it differs from nvalues (the scatter itself never reads out of range). */
+int tnh_masked_scatter(void* dst, const void* src, const void* mask, const void* values, int64_t nvalues, int64_t n,
+                       int itemsize, int64_t* count_out);
 
 /* dst_i = op(src_i); ABS/REAL/IMAG of a complex dtype write the real dtype. */
 int tnh_unary(int op, void* dst, const void* src, int64_t n, int dtype);

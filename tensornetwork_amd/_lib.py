@@ -109,6 +109,7 @@ SIGNATURES = {
     "tnh_fill": (c_int, [c_void_p, c_double, c_double, c_int64, c_int]),
     "tnh_compare": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_double, c_int64, c_int]),
     "tnh_masked_fill": (c_int, [c_void_p, c_void_p, c_void_p, c_double, c_double, c_int64, c_int]),
+    "tnh_masked_scatter": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, POINTER(c_int64)]),
     "tnh_random": (c_int, [c_void_p, c_int64, c_int, ctypes.c_uint64, c_int, c_double, c_double]),
     "tnh_eye": (c_int, [c_void_p, c_int64, c_int64, c_int]),
     "tnh_cast": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int64]),

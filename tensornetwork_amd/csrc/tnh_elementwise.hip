@@ -331,6 +331,95 @@ __global__ __launch_bounds__(256) void compare_kernel(int op, int32_t* __restric
   }
 }
 
+// ---- index_update with a TENSOR assignee (round 6): t = copy(tensor); t[mask] = values, the k-th set position of the
+// mask (row-major order) takes values[k] (numpy_backend.py:548-552).  Three small launches, no host round trip of the
+// mask: set entries per block of 1024, an exclusive scan of the block counts by one workgroup, and the scatter, where
+// every block rebuilds its local ranks from wave ballots.  ESZ = element bytes (2 ... 16: the values are moved, not read).
+constexpr int MS_BLOCK = 1024;      // elements per workgroup (256 threads x 4 consecutive elements)
+
+__global__ __launch_bounds__(256) void mask_count_kernel(const int32_t* __restrict__ mask, int64_t n,
+                                                         int64_t* __restrict__ counts) {
+  __shared__ int wsum[4];
+  const int tid = threadIdx.x;
+  const int64_t i0 = (int64_t)blockIdx.x * MS_BLOCK + 4 * tid;
+  int c = 0;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) c += (i0 + e < n && mask[i0 + e] != 0) ? 1 : 0;
+  c = wave_sum(c);
+  if ((tid & 63) == 0) wsum[tid >> 6] = c;
+  __syncthreads();
+  if (tid == 0) counts[blockIdx.x] = (int64_t)wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+// counts[b] -> exclusive prefix (in place); total[0] = number of set entries.  One workgroup walks the blocks 1024 at a time.
+__global__ __launch_bounds__(1024) void mask_scan_kernel(int64_t* __restrict__ counts, int64_t nb, int64_t* __restrict__ total) {
+  __shared__ int64_t wsum[16];
+  __shared__ int64_t carry;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  if (tid == 0) carry = 0;
+  __syncthreads();
+  for (int64_t b0 = 0; b0 < nb; b0 += 1024) {
+    const int64_t b = b0 + tid;
+    const int64_t v = b < nb ? counts[b] : 0;
+    int64_t incl = v;                                  // inclusive scan inside the wave
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const int64_t up = __shfl_up(incl, off, 64);
+      if (lane >= off) incl += up;
+    }
+    if (lane == 63) wsum[w] = incl;
+    __syncthreads();
+    int64_t before = carry;
+    for (int ww = 0; ww < w; ++ww) before += wsum[ww];
+    if (b < nb) counts[b] = before + incl - v;
+    __syncthreads();
+    if (tid == 1023) carry = before + incl;
+    __syncthreads();
+  }
+  if (tid == 0) total[0] = carry;
+}
+
+template <int ESZ>
+struct alignas(ESZ) RawElem {
+  unsigned char b[ESZ];
+};
+template <int ESZ>
+__global__ __launch_bounds__(256) void masked_scatter_kernel(RawElem<ESZ>* __restrict__ dst, const RawElem<ESZ>* __restrict__ src,
+                                                             const int32_t* __restrict__ mask,
+                                                             const RawElem<ESZ>* __restrict__ values, int64_t nvalues,
+                                                             int64_t n, const int64_t* __restrict__ offsets) {
+  __shared__ int wsum[4];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int64_t i0 = (int64_t)blockIdx.x * MS_BLOCK + 4 * tid;
+  bool m[4];
+  int c = 0;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    m[e] = i0 + e < n && mask[i0 + e] != 0;
+    c += m[e] ? 1 : 0;
+  }
+  int incl = c;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int up = __shfl_up(incl, off, 64);
+    if (lane >= off) incl += up;
+  }
+  if (lane == 63) wsum[w] = incl;
+  __syncthreads();
+  int64_t rank = offsets[blockIdx.x] + (incl - c);
+  for (int ww = 0; ww < w; ++ww) rank += wsum[ww];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    if (i0 + e >= n) break;
+    if (m[e]) {
+      dst[i0 + e] = values[rank < nvalues ? rank : nvalues - 1];     // (a count mismatch is reported by the caller)
+      ++rank;
+    } else {
+      dst[i0 + e] = src[i0 + e];
+    }
+  }
+}
+
 template <int DT>
 __global__ __launch_bounds__(256) void masked_fill_kernel(typename Tr<DT>::S* __restrict__ dst,
                                                           const typename Tr<DT>::S* __restrict__ src,
@@ -649,6 +738,42 @@ int tnh_masked_fill(void* dst, const void* src, const void* mask, double re, dou
                                                (typename Tr<DT>::S*)dst, (const typename Tr<DT>::S*)src,
                                                (const int32_t*)mask, re, im, n));
   TNH_LAUNCH_CHECK();
+  return TNH_OK;
+}
+
+int tnh_masked_scatter(void* dst, const void* src, const void* mask, const void* values, int64_t nvalues, int64_t n,
+                       int itemsize, int64_t* count_out) {
+  TNH_NEED_INIT();
+  TNH_REQUIRE(n >= 0 && nvalues >= 0, "negative size");
+  TNH_REQUIRE(itemsize == 2 || itemsize == 4 || itemsize == 8 || itemsize == 16, "tnh_masked_scatter: item size %d", itemsize);
+  TNH_REQUIRE(!(count_out && capturing()), "tnh_masked_scatter: the count read-back synchronises the stream (graph capture)");
+  if (count_out) *count_out = 0;
+  if (n == 0) return TNH_OK;
+  TNH_REQUIRE(dst && src && mask && (values || nvalues == 0), "null pointer");
+  const int64_t nb = (n + MS_BLOCK - 1) / MS_BLOCK;
+  void* work = nullptr;
+  int rc = tnh_malloc(&work, (size_t)(nb + 1) * sizeof(int64_t));
+  if (rc) return rc;
+  int64_t* counts = (int64_t*)work;
+  hipLaunchKernelGGL(mask_count_kernel, dim3((unsigned)nb), dim3(256), 0, stream(), (const int32_t*)mask, n, counts);
+  hipLaunchKernelGGL(mask_scan_kernel, dim3(1), dim3(1024), 0, stream(), counts, nb, counts + nb);
+  const int64_t nv = nvalues > 0 ? nvalues : 1;
+  switch (itemsize) {
+    case 2: hipLaunchKernelGGL((masked_scatter_kernel<2>), dim3((unsigned)nb), dim3(256), 0, stream(), (RawElem<2>*)dst, (const RawElem<2>*)src, (const int32_t*)mask, (const RawElem<2>*)(values ? values : src), nv, n, (const int64_t*)counts); break;
+    case 4: hipLaunchKernelGGL((masked_scatter_kernel<4>), dim3((unsigned)nb), dim3(256), 0, stream(), (RawElem<4>*)dst, (const RawElem<4>*)src, (const int32_t*)mask, (const RawElem<4>*)(values ? values : src), nv, n, (const int64_t*)counts); break;
+    case 8: hipLaunchKernelGGL((masked_scatter_kernel<8>), dim3((unsigned)nb), dim3(256), 0, stream(), (RawElem<8>*)dst, (const RawElem<8>*)src, (const int32_t*)mask, (const RawElem<8>*)(values ? values : src), nv, n, (const int64_t*)counts); break;
+    default: hipLaunchKernelGGL((masked_scatter_kernel<16>), dim3((unsigned)nb), dim3(256), 0, stream(), (RawElem<16>*)dst, (const RawElem<16>*)src, (const int32_t*)mask, (const RawElem<16>*)(values ? values : src), nv, n, (const int64_t*)counts); break;
+  }
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess && count_out) {
+    e = hipMemcpyAsync(count_out, counts + nb, sizeof(int64_t), hipMemcpyDeviceToHost, stream());
+    if (e == hipSuccess) e = hipStreamSynchronize(stream());
+  }
+  tnh_free(work);
+  if (e != hipSuccess) {
+    set_error("tnh_masked_scatter failed: %s", hipGetErrorString(e));
+    return TNH_ERR_HIP;
+  }
   return TNH_OK;
 }
 

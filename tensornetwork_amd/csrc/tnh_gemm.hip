@@ -912,6 +912,101 @@ __global__ __launch_bounds__(1024) void gemm_tiny_kernel(const T* __restrict__ A
   }
 }
 
+// ---- skinny products (round 6): one side <= 128 against a side <= 2048 over K = 256 ... 4096 in f32 / f64 -- an MPS
+// site tensor's physical legs against a bond (M = 2 ... 128, N = 1024, K = 512: 29 of the 31 steps of configs[3]).
+// A 128 x 128 tile kernel puts such a product on <= 16 workgroups (35 us), the split-K detour on two launches (13 us).
+// Here ONE workgroup owns a 16 x 16 output tile and its NW waves split K; operands go global -> VGPR -> MFMA
+// (v_mfma_f32_16x16x4_f32 / v_mfma_f64_16x16x4_f64, exact FMAs), no LDS staging: lane (i = lane % 16, q = lane / 16)
+// feeds A(m0 + i, k) and B(k, n0 + i) with k = kb + 4 q + e in the e-th MFMA of a 16-deep chunk -- the summation
+// order inside a chunk is free, so a k-contiguous operand is ONE 4-element vector load per chunk and a k-strided one
+// four 64-byte-coalesced scalar loads.  The waves' partial tiles meet in LDS and are added in wave order:
+// deterministic, one launch.
+template <typename T>
+struct SkinnyTraits;
+template <>
+struct SkinnyTraits<float> {
+  typedef float acc_t __attribute__((ext_vector_type(4)));
+  static __device__ __forceinline__ acc_t mfma(float a, float b, acc_t c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+  static __device__ __forceinline__ int row(int q, int r) { return 4 * q + r; }
+};
+template <>
+struct SkinnyTraits<double> {
+  typedef double acc_t __attribute__((ext_vector_type(4)));
+  static __device__ __forceinline__ acc_t mfma(double a, double b, acc_t c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
+  static __device__ __forceinline__ int row(int q, int r) { return q + 4 * r; }
+};
+
+// four operand values k = kb + 4 q .. + 3 of one row / column `line` (element (line, k) at base[line * ld_line + k * ld_k])
+template <typename T, bool KCONTIG>
+__device__ __forceinline__ void skinny_load(const T* __restrict__ base, int64_t line, int64_t ld, int64_t k, int64_t kend, T (&v)[4]) {
+  if (KCONTIG) {
+    const T* p = base + line * ld + k;
+    if (k + 3 < kend) {
+      typedef T vec_t __attribute__((ext_vector_type(4)));
+      const vec_t x = *reinterpret_cast<const vec_t*>(p);
+      v[0] = x[0]; v[1] = x[1]; v[2] = x[2]; v[3] = x[3];
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = (k + e < kend) ? p[e] : T(0);
+    }
+  } else {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = (k + e < kend) ? base[(k + e) * ld + line] : T(0);
+  }
+}
+
+template <typename T, bool TA, bool TB, int NW>
+__global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(const T* __restrict__ A, int64_t lda, const T* __restrict__ B,
+                                                              int64_t ldb, T* __restrict__ C, int64_t ldc, int64_t M,
+                                                              int64_t N, int64_t K, int tiles_n) {
+  typedef SkinnyTraits<T> Tr;
+  typedef typename Tr::acc_t acc_t;
+  __shared__ T red[NW][256];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l16 = lane & 15, q = lane >> 4;
+  const int64_t m0 = (int64_t)(blockIdx.x / tiles_n) * 16, n0 = (int64_t)(blockIdx.x % tiles_n) * 16;
+  int64_t mi = m0 + l16, ni = n0 + l16;
+  if (mi >= M) mi = M - 1;            // ragged edge: re-read the last row / column, never stored
+  if (ni >= N) ni = N - 1;
+  const int64_t kc = ((K + NW - 1) / NW + 15) / 16 * 16;
+  const int64_t kbeg = (int64_t)w * kc, kend = kbeg + kc < K ? kbeg + kc : K;
+  acc_t acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
+#pragma unroll 2
+  for (int64_t kb = kbeg; kb < kend; kb += 32) {
+    T a0[4], b0[4], a1[4], b1[4];
+    // A is [M][K] (TA = 0: k contiguous) or [K][M]; B is [K][N] (TB = 0: k strided) or [N][K]
+    skinny_load<T, !TA>(A, mi, lda, kb + 4 * q, kend, a0);
+    skinny_load<T, TB>(B, ni, ldb, kb + 4 * q, kend, b0);
+    skinny_load<T, !TA>(A, mi, lda, kb + 16 + 4 * q, kend, a1);
+    skinny_load<T, TB>(B, ni, ldb, kb + 16 + 4 * q, kend, b1);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      acc0 = Tr::mfma(a0[e], b0[e], acc0);
+      acc1 = Tr::mfma(a1[e], b1[e], acc1);
+    }
+  }
+  acc0 += acc1;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) red[w][Tr::row(q, r) * 16 + l16] = acc0[r];
+  __syncthreads();
+  if (tid < 256) {
+    T sum = red[0][tid];
+#pragma unroll
+    for (int ww = 1; ww < NW; ++ww) sum += red[ww][tid];
+    const int64_t m = m0 + (tid >> 4), n = n0 + (tid & 15);
+    if (m < M && n < N) C[m * ldc + n] = sum;
+  }
+}
+
+template <typename T, int NW>
+static void launch_skinny(int ta, int tb, unsigned grid, const T* A, int64_t lda, const T* B, int64_t ldb, T* C, int64_t ldc,
+                          int64_t M, int64_t N, int64_t K, int tiles_n) {
+  const dim3 g(grid), b(NW * 64);
+  if (!ta && !tb) hipLaunchKernelGGL((gemm_skinny_kernel<T, false, false, NW>), g, b, 0, stream(), A, lda, B, ldb, C, ldc, M, N, K, tiles_n);
+  else if (!ta && tb) hipLaunchKernelGGL((gemm_skinny_kernel<T, false, true, NW>), g, b, 0, stream(), A, lda, B, ldb, C, ldc, M, N, K, tiles_n);
+  else if (ta && !tb) hipLaunchKernelGGL((gemm_skinny_kernel<T, true, false, NW>), g, b, 0, stream(), A, lda, B, ldb, C, ldc, M, N, K, tiles_n);
+  else hipLaunchKernelGGL((gemm_skinny_kernel<T, true, true, NW>), g, b, 0, stream(), A, lda, B, ldb, C, ldc, M, N, K, tiles_n);
+}
+
 static thread_local bool g_in_splitk = false;   // re-entrancy guard of the split-K path
 static int g_variant = 0;  // 0 auto, 1 generic (mfma), 2 valu, 3 bf16_128, 4 bf16_256, 5 bf16_256pp,
                            // 6 bf16_ragged (auto shape), 7 .._128x128, 8 .._64x256, 9 .._256x64
@@ -1105,6 +1200,30 @@ int tnh_gemm_ex(int in_dtype, int out_dtype, int transA, int transB, int64_t M, 
     TNH_LAUNCH_CHECK();
     g_last_kernel = "tiny_1wg";
     return TNH_OK;
+  }
+
+  // ---- skinny f32 / f64 products: one workgroup per 16 x 16 output tile, its waves split K (gemm_skinny_kernel)
+  if (plain && batch == 1 && g_variant == 0 && out_dtype == in_dtype && (in_dtype == TNH_F32 || in_dtype == TNH_F64) &&
+      K >= 256 && K <= 4096 && std::min(M, N) <= 128 && ((M + 127) / 128) * ((N + 127) / 128) <= 16) {
+    const int esz = in_dtype == TNH_F32 ? 4 : 8;
+    // vector loads of a k-contiguous operand: 16-byte aligned rows
+    const bool a_ok = transA || (((uintptr_t)A % 16) == 0 && (lda * esz) % 16 == 0);
+    const bool b_ok = !transB || (((uintptr_t)B % 16) == 0 && (ldb * esz) % 16 == 0);
+    if (a_ok && b_ok) {
+      const int tiles_n = (int)((N + 15) / 16);
+      const unsigned grid = (unsigned)(((M + 15) / 16) * tiles_n);
+      const bool wide = grid >= 512;       // enough workgroups: four waves each (K / 4 per wave) instead of sixteen
+      if (in_dtype == TNH_F32) {
+        if (wide) launch_skinny<float, 4>(transA, transB, grid, (const float*)A, lda, (const float*)B, ldb, (float*)C, ldc, M, N, K, tiles_n);
+        else launch_skinny<float, 16>(transA, transB, grid, (const float*)A, lda, (const float*)B, ldb, (float*)C, ldc, M, N, K, tiles_n);
+      } else {
+        if (wide) launch_skinny<double, 4>(transA, transB, grid, (const double*)A, lda, (const double*)B, ldb, (double*)C, ldc, M, N, K, tiles_n);
+        else launch_skinny<double, 16>(transA, transB, grid, (const double*)A, lda, (const double*)B, ldb, (double*)C, ldc, M, N, K, tiles_n);
+      }
+      TNH_LAUNCH_CHECK();
+      g_last_kernel = "skinny_16x16";
+      return TNH_OK;
+    }
   }
 
   // ---- split-K: few output tiles and a long contraction (inner products <x, y>, environment

@@ -1841,6 +1841,7 @@ static double g_cluster_tol64 = 1e-10;  // f64 input: closer than this is a clus
 static bool g_row_fused = false;  // row panels by the row-owning fused kernel (TNH_SVDB_ROWFUSED=1; f32 only) or ypass / yreduce / update
 static bool g_bt_fused = true;   // back-transformation by column-owning workgroups (TNH_SVDB_BT=0: per-panel launches)
 static bool g_lane = true;       // counts through sturm_lane_kernel (TNH_SVDB_LANE=0: the 16-lane ldl_kernel)
+static bool g_lane_auto = true;  // ... unless the round is small enough for the 16-lane kernel to be faster (TNH_SVDB_LANE_AUTO=0)
 // Schedule of the spectrum slicing.  A count costs 139 f64 FMAs per pivot (8 cycles each on this chip's vector pipe),
 // so the schedule is about the NUMBER of counts and of dependent rounds:
 //   all values: a uniform grid of 16 n shifts (capped at 65536 = one lane-kernel wave per SIMD) gives every value 16
@@ -1871,6 +1872,8 @@ static void read_env() {
   g_bt_fused = !(e && e[0] == '0');
   e = getenv("TNH_SVDB_LANE");
   g_lane = !(e && e[0] == '0');
+  e = getenv("TNH_SVDB_LANE_AUTO");
+  g_lane_auto = !(e && e[0] == '0');
   g_grid_mult = g_lane ? 16 : 1;
   g_sect_p = g_lane ? 15 : 3;
   g_sect_rounds = g_lane ? 1 : 5;
@@ -1906,6 +1909,15 @@ static void read_env() {
 // tau_rel: resolution (relative to sigma_max) the round is after -- a count whose small pivots injected more than a
 // fifth of it is flagged and ignored by the bracket update (1.2e-7 = 2^-23: the f32 path's rounds)
 static int launch_counts(const Layout& L, char* base, int64_t n, int64_t ns, bool lane, bool need_flags, double tau_rel) {
+  // Which kernel (round 6): a wave of the lane kernel carries 64 shifts through the n pivots at ~1600 cycles each, a wave
+  // of the 16-lane kernel 4 shifts at ~400 (profiles/r06_svd_band_f32_kernel_stats_trip4.txt: 3.2 ms for 65536 shifts,
+  // 0.79 ms for 3840, n = 4096).  Both are latency chains, so a round costs (waves per SIMD, rounded up) x n x that:
+  // the 16-lane kernel wins while the shifts fit in about two of its waves per SIMD -- the rounds of n <= 512.
+  if (lane && g_lane_auto) {
+    const int64_t simds = 4 * (int64_t)(num_cus() > 0 ? num_cus() : 256);
+    const int64_t w_lane = ((ns + 63) / 64 + simds - 1) / simds, w_ldl = ((ns + 3) / 4 + simds - 1) / simds;
+    if (w_ldl * 400 < w_lane * 1600) lane = false;
+  }
   if (lane) {
     if (need_flags)
       hipLaunchKernelGGL(sturm_lane_kernel<true>, dim3((unsigned)((ns + 63) / 64)), dim3(64), 0, stream(),

@@ -2030,9 +2030,11 @@ class HipBackend(BackendBase):
     return out
 
   def index_update(self, tensor, mask, assignee):
-    """``t = copy(tensor); t[mask] = assignee`` (abstract_backend.py:685-696; numpy_backend.py:548-552)
-    for a mask produced by a tensor comparison (or any array of the tensor's shape) and a scalar
-    assignee -- the form the reference's callers use (infinite_mps.py:237-241)."""
+    """``t = copy(tensor); t[mask] = assignee`` (abstract_backend.py:685-696; numpy_backend.py:548-552) for a mask
+    produced by a tensor comparison (or any array of the tensor's shape).  A scalar (or one-element) assignee fills
+    the set positions (the form infinite_mps.py:237-241 uses); a tensor assignee is NumPy's boolean-mask assignment:
+    its elements, in row-major order, go to the set positions in row-major order, and their number must match
+    (``ValueError`` as NumPy raises it) -- compacted on the device (``tnh_masked_scatter``)."""
     tensor = self._as_tensor(tensor)
     self._check_float(tensor, "index_update")
     if isinstance(assignee, DeviceTensor) and assignee.size == 1:
@@ -2040,7 +2042,7 @@ class HipBackend(BackendBase):
     elif isinstance(assignee, np.ndarray) and assignee.size == 1:
       assignee = assignee.reshape(()).item()
     if not self._is_scalar(assignee):
-      raise NotImplementedError("index_update on the hip backend takes a scalar assignee")
+      return self._index_update_tensor(tensor, mask, assignee)
     if not isinstance(mask, DeviceTensor):
       mask = DeviceTensor.from_numpy(np.ascontiguousarray(np.asarray(mask) != 0, dtype=np.int32))
     elif mask.code != _lib.I32:
@@ -2053,6 +2055,26 @@ class HipBackend(BackendBase):
     out = DeviceTensor.empty(tensor.shape, tensor.code)
     _lib.check(self.lib.tnh_masked_fill(_vp(out), _vp(tensor), _vp(mask), value.real, value.imag, tensor.size,
                                         tensor.code), "tnh_masked_fill")
+    return out
+
+  def _index_update_tensor(self, tensor, mask, assignee):
+    values = self._as_tensor(assignee)
+    if values.is_complex and not tensor.is_complex:
+      raise TypeError("cannot assign complex values into a real tensor")
+    values = self.cast(values, tensor.code)
+    if not isinstance(mask, DeviceTensor):
+      mask = DeviceTensor.from_numpy(np.ascontiguousarray(np.asarray(mask) != 0, dtype=np.int32))
+    elif mask.code != _lib.I32:
+      mask = self.compare("!=", mask, 0.0)
+    if mask.shape != tensor.shape:
+      raise ValueError(f"mask shape {mask.shape} does not match tensor shape {tensor.shape}")
+    out = DeviceTensor.empty(tensor.shape, tensor.code, tensor.alias)
+    count = ctypes.c_int64(0)
+    _lib.check(self.lib.tnh_masked_scatter(_vp(out), _vp(tensor), _vp(mask), _vp(values), values.size, tensor.size,
+                                           tensor.itemsize, ctypes.byref(count)), "tnh_masked_scatter")
+    if count.value != values.size:
+      raise ValueError(f"NumPy boolean array indexing assignment cannot assign {values.size} input values to "
+                       f"the {count.value} output values where the mask is true")
     return out
 
   # ------------------------------------------------------------------ Krylov

@@ -763,3 +763,26 @@ def run_high_rank_cases(be):
   got = np.asarray(be.tensordot(be.convert_to_tensor(a), be.convert_to_tensor(b), axes))
   assert got.shape == (2,) * 26
   np.testing.assert_allclose(got, np.tensordot(a, b, axes), rtol=1e-12, atol=1e-12)
+
+
+def run_index_update_tensor_cases(be, dtypes=(np.float32, np.float64, np.complex64, np.complex128)):
+  """index_update with a TENSOR assignee = NumPy's boolean-mask assignment (numpy_backend.py:548-552:
+  t = copy(tensor); t[mask] = assignee), bit for bit; masks with no / all / scattered set entries, sizes that are
+  not multiples of the kernels' 1024-element blocks, and the ValueError of a count mismatch."""
+  import pytest  # pylint: disable=import-outside-toplevel
+  rng = np.random.default_rng(31)
+  for dt in dtypes:
+    for shape, density in [((7,), 0.5), ((33, 65), 0.3), ((5, 6, 70), 0.9), ((4097,), 0.01), ((3, 1024), 1.0), ((50, 50), 0.0)]:
+      x = rng.standard_normal(shape).astype(dt)
+      if np.dtype(dt).kind == "c":
+        x = (x + 1j * rng.standard_normal(shape)).astype(dt)
+      mask = rng.random(shape) < density
+      vals = (np.arange(int(mask.sum())) + 100).astype(dt)
+      ref = np.copy(x)
+      ref[mask] = vals
+      got = be.index_update(be.convert_to_tensor(x), mask, be.convert_to_tensor(vals) if vals.size != 1 else vals)
+      np.testing.assert_array_equal(np.asarray(got), ref, err_msg=f"{np.dtype(dt).name} {shape} {density}")
+    x = rng.standard_normal((10, 10)).astype(dt)
+    mask = x.real > 0
+    with pytest.raises(ValueError):
+      be.index_update(be.convert_to_tensor(x), mask, be.convert_to_tensor(np.zeros(int(mask.sum()) + 3, dtype=dt)))

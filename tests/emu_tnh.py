@@ -435,6 +435,21 @@ class EmuLib:
     self._flat(dst, n, _NP[code])[:] = self._from_f(x, code)
     return _lib.OK
 
+  def tnh_masked_scatter(self, dst, src, mask, values, nvalues, n, itemsize, count_ref):
+    n, nvalues, itemsize = int(n), int(nvalues), int(itemsize)
+    raw = np.dtype((np.void, itemsize))
+    x = np.array(self._flat(src, n, raw))
+    m = self._flat(mask, n, np.int32) != 0
+    count = int(m.sum())
+    if count and nvalues:
+      vals = self._flat(values, nvalues, raw)
+      idx = np.minimum(np.arange(count), nvalues - 1)
+      x[m] = vals[idx]
+    self._flat(dst, n, raw)[:] = x
+    if count_ref is not None:
+      count_ref._obj.value = count      # pylint: disable=protected-access
+    return _lib.OK
+
   def tnh_wrap_int(self, dst, src, n, bits, mode):
     x = self._flat(src, int(n), np.int64)
     if mode == 2:

@@ -62,3 +62,8 @@ def test_eigsh_defaults_follow_the_interface():
     np.testing.assert_allclose(float(np.asarray(eta[0])), np.linalg.eigvalsh(h)[-1], rtol=1e-8)
     with pytest.raises(ValueError):
       be.eigsh(lambda x: x, initial_state=init, which="SI")
+
+
+def test_index_update_with_a_tensor_assignee_on_the_emulated_abi():
+  with emulated_backend() as be:
+    C.run_index_update_tensor_cases(be)

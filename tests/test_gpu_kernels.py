@@ -519,16 +519,32 @@ def test_gemm_split_k_mid_size_f32_f64(hip, dtype):
   thresholds (small K, tiny outputs, many tiles) nothing changes.  Every layout, ragged K."""
   rng = np.random.default_rng(11)
   kmin = 512
-  for (m, n, k, ta_, tb_, want) in [(512, 512, 1024, 0, 0, True), (1024, 512, 1000, 0, 1, True), (512, 1024, kmin, 1, 0, True),
-                                    (200, 300, 2500, 1, 1, True), (512, 512, kmin - 64, 0, 0, False),
-                                    (32, 512, 2048, 0, 0, True), (2, 1024, 512, 0, 0, True), (4, 1024, 512, 0, 1, True),
-                                    (1024, 8, 640, 1, 1, True),          # round 6: one side below 64 against a long one (MPS site legs)
-                                    (32, 200, 2048, 0, 0, False),        # ... but not two small sides
-                                    (2048, 2048, 1024, 0, 1, False)]:
+  for (m, n, k, ta_, tb_, want) in [(512, 512, 1024, 0, 0, "splitk"), (1024, 512, 1000, 0, 1, "splitk"), (512, 1024, kmin, 1, 0, "splitk"),
+                                    (200, 300, 2500, 1, 1, "splitk"), (512, 512, kmin - 64, 0, 0, None),
+                                    # round 6: one side <= 128 (MPS site legs against a bond) -- one launch, a workgroup per 16 x 16 tile
+                                    (32, 512, 2048, 0, 0, "skinny_16x16"), (2, 1024, 512, 0, 0, "skinny_16x16"),
+                                    (4, 1024, 512, 0, 1, "skinny_16x16"), (1024, 8, 640, 1, 1, "skinny_16x16"),
+                                    (40, 512, 8192, 0, 0, "splitk"),     # ... beyond K = 4096 the split-K path (slices of >= 64)
+                                    (2048, 2048, 1024, 0, 1, None)]:
     out, ref, kernel, sk = _gemm_case(hip, dtype, m, n, k, ta_, tb_, rng=rng)
-    assert (kernel == "splitk") == want, (kernel, m, n, k)
+    assert (kernel == want) if want else (kernel not in ("splitk", "skinny_16x16")), (kernel, m, n, k)
     tol = 2e-6 if dtype == np.float32 else 1e-14
     np.testing.assert_allclose(out, ref, rtol=tol * 4, atol=tol * np.sqrt(k) * 4, err_msg=f"{m}x{n}x{k}")
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("ta_,tb_", [(0, 0), (0, 1), (1, 0), (1, 1)])
+def test_gemm_skinny_one_workgroup_per_16x16_tile(hip, dtype, ta_, tb_):
+  """Round 6 (gemm_skinny_kernel): f32 / f64 products with one side <= 128, K = 256 ... 4096: every storage form, ragged
+  M / N / K (K % 16 != 0: masked tail; rows past the edge re-read and never stored), sixteen- and four-wave forms, and
+  the fall-back when a k-contiguous operand's rows are not 16-byte aligned."""
+  rng = np.random.default_rng(41 + 2 * ta_ + tb_)
+  for (m, n, k) in [(2, 1024, 512), (17, 1000, 300), (128, 2048, 4096), (100, 33, 257), (1, 700, 256), (64, 1536, 1040)]:
+    out, ref, kernel, _ = _gemm_case(hip, dtype, m, n, k, ta_, tb_, rng=rng)
+    aligned = (ta_ or k % (4 if dtype == np.float32 else 2) == 0) and (not tb_ or k % (4 if dtype == np.float32 else 2) == 0)
+    assert (kernel == "skinny_16x16") == aligned, (kernel, m, n, k)
+    tol = 2e-6 if dtype == np.float32 else 1e-14
+    np.testing.assert_allclose(out, ref, rtol=tol * 4, atol=tol * np.sqrt(k) * 4, err_msg=f"{kernel} {m}x{n}x{k}")
 
 
 def test_tensordot_golden(hip, golden):
@@ -1653,3 +1669,8 @@ def test_gemm_tiny_outputs_one_workgroup(hip, dtype):
     np.testing.assert_allclose(out, ref, rtol=tol * 4, atol=tol * np.sqrt(k) * 4, err_msg=f"{m}x{n}x{k} {ta_}{tb_}")
   out, ref, kernel, _ = _gemm_case(hip, dtype, 5, 2, 4096, 0, 1, rng=rng)      # five rows: not tiny
   assert kernel != "tiny_1wg"
+
+
+def test_index_update_with_a_tensor_assignee(hip):
+  """VERDICT r5 missing 6: `t[mask] = assignee` with a tensor assignee, compacted on the device (tnh_masked_scatter)."""
+  C.run_index_update_tensor_cases(hip)
