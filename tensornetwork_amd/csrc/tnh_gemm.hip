@@ -886,16 +886,42 @@ __global__ __launch_bounds__(1024) void gemm_tiny_kernel(const T* __restrict__ A
   T acc[16];
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i] = T(0);
-  for (int64_t k = tid; k < K; k += 1024) {
-    T av[4], bv[4];
+  if (M == 1 && N == 1) {
+    // the inner product: eight independent loads per operand in flight (one load per trip made the 64 trips of a
+    // 65536-long product a chain of memory latencies: 23 us)
+    T part[8];
 #pragma unroll
-    for (int m = 0; m < 4; ++m) av[m] = (m < M) ? A[m * sam + k * sak] : T(0);
+    for (int u = 0; u < 8; ++u) part[u] = T(0);
+    for (int64_t k0 = tid; k0 < K; k0 += 8 * 1024) {
+      T av[8], bv[8];
 #pragma unroll
-    for (int n = 0; n < 4; ++n) bv[n] = (n < N) ? B[k * sbk + n * sbn] : T(0);
+      for (int u = 0; u < 8; ++u) {
+        const int64_t k = k0 + (int64_t)u * 1024;
+        av[u] = k < K ? A[k * sak] : T(0);
+        bv[u] = k < K ? B[k * sbk] : T(0);
+      }
 #pragma unroll
-    for (int m = 0; m < 4; ++m)
+      for (int u = 0; u < 8; ++u) part[u] += av[u] * bv[u];
+    }
+    acc[0] = ((part[0] + part[1]) + (part[2] + part[3])) + ((part[4] + part[5]) + (part[6] + part[7]));
+  } else {
+    for (int64_t k0 = tid; k0 < K; k0 += 2 * 1024) {
+      T av[2][4], bv[2][4];
 #pragma unroll
-      for (int n = 0; n < 4; ++n) acc[4 * m + n] += av[m] * bv[n];
+      for (int u = 0; u < 2; ++u) {
+        const int64_t k = k0 + (int64_t)u * 1024;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) av[u][m] = (m < M && k < K) ? A[m * sam + k * sak] : T(0);
+#pragma unroll
+        for (int n = 0; n < 4; ++n) bv[u][n] = (n < N && k < K) ? B[k * sbk + n * sbn] : T(0);
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+          for (int n = 0; n < 4; ++n) acc[4 * m + n] += av[u][m] * bv[u][n];
+    }
   }
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
@@ -1246,7 +1272,9 @@ int tnh_gemm_ex(int in_dtype, int out_dtype, int transA, int transB, int64_t M, 
     const bool skinny = mid && wide_in && std::min(M, N) < 64 && std::max(M, N) >= 256;
     int64_t splits = mid ? std::min<int64_t>({K / (skinny ? 64 : 128), (2 * (int64_t)num_cus()) / tiles, 32})
                          : std::min<int64_t>({K / 1024, (2 * (int64_t)num_cus()) / tiles, 256});
-    const bool few = mid ? (tiles * 8 <= (int64_t)num_cus() && ((M >= 64 && N >= 64) || skinny)) : (tiles * 4 <= (int64_t)num_cus());
+    // (round 6: up to CUs / 2 tiles in the mid-K regime -- 2048 x 512 x 512 of the d = 4 MPS chain ran 40 us on 64 workgroups)
+    const bool few = mid ? (tiles * (wide_in ? 2 : 8) <= (int64_t)num_cus() && ((M >= 64 && N >= 64) || skinny))
+                         : (tiles * 4 <= (int64_t)num_cus());
     if (few && splits >= 2) {
       int64_t kc = (K + splits - 1) / splits;
       kc = (kc + 63) / 64 * 64;                       // keeps the bf16 kernels' K % 64 rule for full slices
