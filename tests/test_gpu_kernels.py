@@ -266,7 +266,9 @@ def test_gemm_f32_split_guard_matches_numpy_on_inf_and_tiny_inputs(hip):
 
 def test_gemm_f32_split_only_for_large_products(hip):
   out, ref, kernel, sk = _gemm_case(hip, np.float32, 1024, 1024, 2048, 0, 1)
-  assert kernel.startswith("mfma_f32_128x128")                             # 16 tiles of 256^2: native kernel
+  # 16 tiles of 256^2: the native f32 kernels (from round 6 on through the mid-K split: 64 tiles of 128^2 <= CUs / 2),
+  # not the 3 x bf16 split
+  assert kernel == "splitk" or kernel.startswith("mfma_f32_128x128"), kernel
   np.testing.assert_allclose(out, ref, rtol=GEMM_TOL[np.float32] * sk, atol=GEMM_TOL[np.float32] * sk * np.sqrt(2048))
 
 
