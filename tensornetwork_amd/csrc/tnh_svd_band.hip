@@ -1785,17 +1785,17 @@ static Layout make_layout(int64_t m, int64_t n, int64_t kcap, int esz) {
   L.R1 = take(f64 ? 256 * 8 : 0);
   L.R1inv = take(f64 ? 256 * 8 : 0);
   L.Xbuf = take(256 * 8);
-  L.Xl = take(f64 ? 0 : (size_t)np * 256 * 8);       // fast stage 1 (f32): X of every panel, for the batched V
-  L.Xr = take(f64 ? 0 : (size_t)np * 256 * 8);
-  L.Ff = take(f64 ? 0 : 2 * 512 * 4);                // f32 X and T^-1 of the panel being reduced (column side, row side)
+  L.Xl = take((size_t)np * 256 * 8);       // fast stage 1: X of every panel, for the batched V
+  L.Xr = take((size_t)np * 256 * 8);
+  L.Ff = take(2 * 512 * e);                // X and T^-1 (in the input type) of the panel being reduced (column side, row side)
   const int64_t wide = n > kcap ? n : kcap;
   const int64_t wrc = f64 ? w_rc<double>() : w_rc<float>();
   const int64_t chunks = (m + wrc - 1) / wrc;
   size_t wpart = (size_t)chunks * 16 * wide * e;
   const size_t ypart = (size_t)((n + Y_COLS - 1) / Y_COLS) * m * 16 * e;     // the row panels' Y partials share the buffer
   if (ypart > wpart) wpart = ypart;
-  if (!f64) {       // fast stage 1: raw-pass partials per 64-row block (16 x n each) or per 64-column tile (m x 16 each)
-    const size_t fast = (size_t)((m + 63) / 64 + 1) * 16 * (size_t)(n > m ? n : m) * e;
+  {       // fast stage 1: raw-pass partials per 64-row block (16 x n each) or per 32- / 64-column tile (m x 16 each)
+    const size_t fast = (size_t)((m + 63) / 64 + 1 + (f64 ? (n + 31) / 32 : 0)) * 16 * (size_t)(n > m ? n : m) * e;
     if (fast > wpart) wpart = fast;
   }
   L.Wpart = take(wpart);
@@ -1834,6 +1834,7 @@ static int g_fast_switch = 128;     // hand over when the trailing block has thi
 static double g_fast_cond = 16.0;   // panels with max / min Cholesky diagonal above this: ST_FASTCOND, stage 1 is repeated (TNH_SVDB_FAST_COND)
 static int g_fast_cw = 0;           // column tile of the fused kernels: 0 = by size, 64, 128 (TNH_SVDB_FAST_CW)
 static int g_fast_wgs = 1024;       // workgroups a fused launch aims at (TNH_SVDB_FAST_WGS)
+static bool g_fast64 = true;        // f64 input through the fast stage too (TNH_SVDB_FAST64=0: the fourteen-launch loop)
 static bool g_dpp = true;
 static double g_cluster_tol = 4e-7;  // kept values closer than this (relative to sigma_max: a few eps_f32) are one cluster (TNH_SVDB_CTOL)
 static double g_cluster_tol64 = 1e-10;  // f64 input: closer than this is a cluster; wider neighbours are separated by the
@@ -1900,6 +1901,8 @@ static void read_env() {
   g_fast_cond = (e && atof(e) > 1.0) ? atof(e) : 16.0;
   e = getenv("TNH_SVDB_FAST_CW");
   g_fast_cw = (e && (atoi(e) == 64 || atoi(e) == 128)) ? atoi(e) : 0;
+  e = getenv("TNH_SVDB_FAST64");
+  g_fast64 = !(e && e[0] == '0');
   e = getenv("TNH_SVDB_FAST_WGS");
   g_fast_wgs = (e && atoi(e) >= 64) ? atoi(e) : 1024;
   e = getenv("TNH_SVDB_BITS64");
@@ -2073,18 +2076,18 @@ static int stage1(const Layout& L, char* base, int64_t m, int64_t n, int64_t p_b
 }
 
 
-// ---- fast stage 1 (f32): tnh_svd_band_fast.inc.  Panels 0 .. *p_next - 1 are reduced here; the caller finishes with
-// stage1<float>(..., *p_next, *parts_out).
+// ---- fast stage 1: tnh_svd_band_fast.inc.  Panels 0 .. *p_next - 1 are reduced here; the caller finishes with
+// stage1<T>(..., *p_next, *parts_out).
 
-template <int CW>
-static void launch_colupd(const ColUpdArgs& a, unsigned grid) {
-  hipLaunchKernelGGL((colupd_rowpass_kernel<CW, true>), dim3(grid), dim3(256), 0, stream(), a);
+template <typename T, int CW>
+static void launch_colupd(const ColUpdArgs<T>& a, unsigned grid) {
+  hipLaunchKernelGGL((colupd_rowpass_kernel<T, CW, true>), dim3(grid), dim3(256), 0, stream(), a);
 }
-template <int CW>
-static void launch_rowupd(const RowUpdArgs& a, unsigned grid, bool upd, bool pass) {
-  if (upd && pass) hipLaunchKernelGGL((rowupd_colpass_kernel<CW, true, true, true>), dim3(grid), dim3(256), 0, stream(), a);
-  else if (pass) hipLaunchKernelGGL((rowupd_colpass_kernel<CW, false, true, true>), dim3(grid), dim3(256), 0, stream(), a);
-  else hipLaunchKernelGGL((rowupd_colpass_kernel<CW, true, false, false>), dim3(grid), dim3(256), 0, stream(), a);
+template <typename T, int CW>
+static void launch_rowupd(const RowUpdArgs<T>& a, unsigned grid, bool upd, bool pass) {
+  if (upd && pass) hipLaunchKernelGGL((rowupd_colpass_kernel<T, CW, true, true, true>), dim3(grid), dim3(256), 0, stream(), a);
+  else if (pass) hipLaunchKernelGGL((rowupd_colpass_kernel<T, CW, false, true, true>), dim3(grid), dim3(256), 0, stream(), a);
+  else hipLaunchKernelGGL((rowupd_colpass_kernel<T, CW, true, false, false>), dim3(grid), dim3(256), 0, stream(), a);
 }
 // 64-row steps per workgroup: as many workgroups as g_fast_wgs allows, at most 4 steps
 static int fast_iters(int64_t rows, int ntc) {
@@ -2095,40 +2098,61 @@ static int fast_iters(int64_t rows, int ntc) {
   return (int)it;
 }
 
+template <typename T>
 static int stage1_fast(const Layout& L, char* base, int64_t m, int64_t n, int64_t* p_next, int* parts_out) {
-  float* Af = (float*)(base + L.Af);
+  constexpr bool F64 = sizeof(T) == 8;
+  // column tiles (registers: a lane's accumulators, prefetch and operand tiles scale with CW x sizeof(T)): f32 64, and
+  // 128 for colupd_rowpass on wide blocks (half the Y partials); f64 half of that
+  constexpr int CWA_BIG = F64 ? 64 : 128, CWA = F64 ? 32 : 64, CWB = F64 ? 32 : 64;
+  T* Af = (T*)(base + L.Af);
   double* Gc = (double*)(base + L.Gpart);
   double* Gr = (double*)(base + L.Gpart2);
-  float* Part = (float*)(base + L.Wpart);
-  float* Wx = (float*)(base + L.Wt);
-  float* Zx = (float*)(base + L.Zr);
-  float* Vl = (float*)(base + L.Vl);
-  float* Vr = (float*)(base + L.Vr);
+  double* Gq = (double*)(base + L.Gq);
+  double* R1 = (double*)(base + L.R1);
+  T* Part = (T*)(base + L.Wpart);
+  T* Wx = (T*)(base + L.Wt);
+  T* Zx = (T*)(base + L.Zr);
+  T* Vl = (T*)(base + L.Vl);
+  T* Vr = (T*)(base + L.Vr);
   double* Xl = (double*)(base + L.Xl);
   double* Xr = (double*)(base + L.Xr);
   double* Tl = (double*)(base + L.Tl);
   double* Tr = (double*)(base + L.Tr);
   int* status = (int*)(base + L.status);
-  float* Ffc = (float*)(base + L.Ff);
-  float* Ffr = Ffc + 512;
+  T* Ffc = (T*)(base + L.Ff);
+  T* Ffr = Ffc + 512;
+  const double rel = F64 ? 1e-3 : 1e-9;              // f64: the factor sees Q1, whose Gram matrix is I + O(eps64 cond^2)
+  const double cond = F64 ? 0.0 : g_fast_cond;       // ... and the passes run on Q1: nothing to guard
   int64_t ps = 0;
   while (ps < L.np && n - 16 * ps > g_fast_switch) ++ps;
   *p_next = 0;
   if (ps < 2) return TNH_OK;
   int parts_c = (int)((m + 255) / 256), parts_r = 0;
-  hipLaunchKernelGGL((gram_kernel<false, float>), dim3(parts_c), dim3(256), 0, stream(), (const float*)Af, n, m, Gc);
+  hipLaunchKernelGGL((gram_kernel<false, T>), dim3(parts_c), dim3(256), 0, stream(), (const T*)Af, n, m, Gc);
   for (int64_t p = 0; p <= ps; ++p) {
     const int64_t j = 16 * p;
     const int64_t mj = m - j, nc = n - j - 16, mr = m - j - 16;
     const bool last = p == ps;           // only the pending row update of panel ps - 1
     if (nc <= 0) break;
-    const int cw = g_fast_cw ? g_fast_cw : (nc >= 2048 ? 128 : 64);     // column tile of colupd_rowpass
-    const int cwb = g_fast_cw == 128 ? 128 : 64;                         // ... of rowupd_colpass
+    const bool bigA = g_fast_cw ? g_fast_cw == 128 : nc >= 2048;
+    const int cw = bigA ? CWA_BIG : CWA;                                   // column tile of colupd_rowpass
     const int ntc = (int)((nc + cw - 1) / cw);
+    const double* gram_c = Gc;
+    int parts_cf = parts_c;
+    if (F64 && !last) {
+      // first Cholesky-QR pass of column panel p: Q1 = P R1^-1 in place, its partial Grams
+      if constexpr (F64) {
+        const int qparts = (int)((mj + 255) / 256);
+        hipLaunchKernelGGL((cholscale_kernel<false>), dim3(qparts), dim3(256), 0, stream(), (double*)(Af + j * n + j), n, mj,
+                           (const double*)Gc, parts_c, R1, Gq, status);
+        gram_c = Gq;
+        parts_cf = qparts;
+      }
+    }
     // ---- row panel p - 1's update of everything right of column panel p + the raw pass and the factor of that panel
     int nrt;
     {
-      RowUpdArgs a;
+      RowUpdArgs<T> a;
       a.C = Af + j * n + j + 16;
       a.ldc = n;
       a.rows = mj;
@@ -2137,23 +2161,32 @@ static int stage1_fast(const Layout& L, char* base, int64_t m, int64_t n, int64_
       a.Pr = p > 0 ? Af + (j - 16) * n + j + 16 : Af;
       a.Pcol = Af + j * n + j;
       a.Wpart = Part;
-      a.ntc = (int)((nc + cwb - 1) / cwb);
+      a.ntc = (int)((nc + CWB - 1) / CWB);
       a.iters = fast_iters(mj, a.ntc);
       nrt = (int)(((mj + 63) / 64 + a.iters - 1) / a.iters);
-      a.fa = FactorArgs{Af + j * n + j, n, mj, Gc, parts_c, Xl + p * 256, Vl + vl_offset(m, p), Tl + p * 256,
-                        (double*)(base + L.Dblk) + p * 256, 1e-9, g_fast_cond, status, Ffc};
+      a.fa = FactorArgs<T>{Af + j * n + j, n, mj, gram_c, parts_cf, Xl + p * 256, Vl + vl_offset(m, p), Tl + p * 256,
+                           (double*)(base + L.Dblk) + p * 256, F64 ? (const double*)R1 : (const double*)nullptr, rel, cond,
+                           status, Ffc};
       const unsigned grid = (unsigned)(nrt * a.ntc) + (last ? 0u : 1u);
-      if (cwb == 128) launch_rowupd<128>(a, grid, p > 0, !last);     // (spills 44 registers at three waves per SIMD: knob only)
-      else launch_rowupd<64>(a, grid, p > 0, !last);
+      launch_rowupd<T, CWB>(a, grid, p > 0, !last);
     }
     if (last) break;
     // ---- the 16 x 16 algebra per trailing column: row panel p finished, Wx, its partial Grams
     parts_r = (int)((nc + 63) / 64);
-    hipLaunchKernelGGL(colreduce_kernel, dim3((unsigned)parts_r), dim3(256), 0, stream(), (const float*)Part, nrt, nc,
-                       Af + j * n + j + 16, n, (const float*)(Vl + vl_offset(m, p)), (const float*)Ffc, Wx, n, Gr);
+    hipLaunchKernelGGL((colreduce_kernel<T>), dim3((unsigned)parts_r), dim3(256), 0, stream(), (const T*)Part, nrt, nc,
+                       Af + j * n + j + 16, n, (const T*)(Vl + vl_offset(m, p)), (const T*)Ffc, Wx, n, Gr);
+    const double* gram_r = Gr;
+    int parts_rf = parts_r;
+    if constexpr (F64) {
+      const int qparts = (int)((nc + 255) / 256);
+      hipLaunchKernelGGL((cholscale_kernel<true>), dim3(qparts), dim3(256), 0, stream(), (double*)(Af + j * n + j + 16), n, nc,
+                         (const double*)Gr, parts_r, R1, Gq, status);
+      gram_r = Gq;
+      parts_rf = qparts;
+    }
     // ---- column panel p's update + the raw pass and the factor of row panel p
     {
-      ColUpdArgs a;
+      ColUpdArgs<T> a;
       a.C = Af + (j + 16) * n + j + 16;
       a.ldc = n;
       a.rows = mr;
@@ -2166,22 +2199,23 @@ static int stage1_fast(const Layout& L, char* base, int64_t m, int64_t n, int64_
       a.ntc = ntc;
       a.iters = fast_iters(mr, ntc);
       const int nrt2 = (int)(((mr + 63) / 64 + a.iters - 1) / a.iters);
-      a.fa = FactorArgs{Af + j * n + j + 16, n, nc, Gr, parts_r, Xr + p * 256, Vr + vr_offset(n, p), Tr + p * 256,
-                        (double*)(base + L.Eblk) + p * 256, 1e-9, g_fast_cond, status, Ffr};
+      a.fa = FactorArgs<T>{Af + j * n + j + 16, n, nc, gram_r, parts_rf, Xr + p * 256, Vr + vr_offset(n, p), Tr + p * 256,
+                           (double*)(base + L.Eblk) + p * 256, F64 ? (const double*)R1 : (const double*)nullptr, rel, cond,
+                           status, Ffr};
       const unsigned grid = (unsigned)(nrt2 * ntc) + 1u;
-      if (cw == 128) launch_colupd<128>(a, grid);
-      else launch_colupd<64>(a, grid);
+      if (bigA) launch_colupd<T, CWA_BIG>(a, grid);
+      else launch_colupd<T, CWA>(a, grid);
     }
     // ---- the same algebra per trailing row: column panel p + 1 finished, Zx, its partial Grams
     parts_c = (int)((mr + 63) / 64);
-    hipLaunchKernelGGL(rowreduce_kernel, dim3((unsigned)parts_c), dim3(256), 0, stream(), (const float*)Part, ntc, mr,
-                       Af + (j + 16) * n + j + 16, n, (const float*)(Vr + vr_offset(n, p)), (const float*)Ffr,
+    hipLaunchKernelGGL((rowreduce_kernel<T>), dim3((unsigned)parts_c), dim3(256), 0, stream(), (const T*)Part, ntc, mr,
+                       Af + (j + 16) * n + j + 16, n, (const T*)(Vr + vr_offset(n, p)), (const T*)Ffr,
                        Zx + (j + 16) * 16, Gc);
     TNH_LAUNCH_CHECK();
   }
   {
-    FormVAllArgs a{Af, m, n, ps, Xl, Xr, Vl, Vr};
-    hipLaunchKernelGGL(formv_all_kernel, dim3((unsigned)((m - 16 + 255) / 256), (unsigned)ps, 2), dim3(256), 0, stream(), a);
+    FormVAllArgs<T> a{Af, m, n, ps, Xl, Xr, Vl, Vr};
+    hipLaunchKernelGGL((formv_all_kernel<T>), dim3((unsigned)((m - 16 + 255) / 256), (unsigned)ps, 2), dim3(256), 0, stream(), a);
   }
   TNH_LAUNCH_CHECK();
   *p_next = ps;
@@ -2549,7 +2583,7 @@ int tnh_svd_band_factor(int dtype, int64_t m, int64_t n, const void* A, void* S,
   // the status word read at the end (one stream synchronisation, also when the caller did not ask for the status);
   // ST_FASTCOND repeats the stage with the loop of rounds 3-5.  Under graph capture nothing can be read back, the
   // speculation cannot be checked: the accurate loop runs directly.
-  bool fast = g_fast && esz == 4 && !capturing();
+  bool fast = g_fast && !capturing() && (esz == 4 || g_fast64);
   g_last_fast = 0;
   // Inputs whose panels are too ill-conditioned for the fast stage (numerically rank-deficient blocks: two-site DMRG
   // splits, zero-padded tensors) come in runs of the same shape; a shape that reported ST_FASTCOND f times in a row
@@ -2572,9 +2606,9 @@ int tnh_svd_band_factor(int dtype, int64_t m, int64_t n, const void* A, void* S,
     if (fast) {
       int64_t p_next = 0;
       int parts = 0;
-      rc = stage1_fast(L, base, m, n, &p_next, &parts);
+      rc = esz == 8 ? stage1_fast<double>(L, base, m, n, &p_next, &parts) : stage1_fast<float>(L, base, m, n, &p_next, &parts);
       if (rc) return rc;
-      rc = stage1<float>(L, base, m, n, p_next, parts);
+      rc = esz == 8 ? stage1<double>(L, base, m, n, p_next, parts) : stage1<float>(L, base, m, n, p_next, parts);
       g_last_fast = p_next > 0 ? 1 : 0;
     } else {
       rc = esz == 8 ? stage1<double>(L, base, m, n) : stage1<float>(L, base, m, n);

@@ -12,12 +12,16 @@ ap.add_argument("--sizes", default="4096x4096,2048x2048,1024x1024,512x512,3072x1
 ap.add_argument("--reps", type=int, default=5)
 ap.add_argument("--check", type=int, default=1)
 ap.add_argument("--spectra", type=int, default=1)
+ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
 a = ap.parse_args()
 be = ta.get_hip_backend()
+DT = np.float64 if a.dtype == "f64" else np.float32
+TOL = (1e-12, 1e-10) if a.dtype == "f64" else (1e-5, 1e-4)
 
 
 def run(x, k, fast, reps, check=True, tag=""):
   os.environ["TNH_SVDB_FAST"] = "1" if fast else "0"
+  x = x.astype(DT)
   m, n = x.shape
   d = be.convert_to_tensor(x)
   best = None
@@ -40,7 +44,8 @@ def run(x, k, fast, reps, check=True, tag=""):
     rec["orth_v"] = float(np.abs(vh @ vh.T - np.eye(k)).max())
     bestk = (ur[:, :k] * sr[:k]) @ vhr[:k]
     rec["recon_vs_best"] = float(np.linalg.norm((u * s) @ vh - bestk) / np.linalg.norm(x64))
-    rec["ok"] = bool(rec["s_err"] < 1e-5 and rec["orth_u"] < 1e-4 and rec["orth_v"] < 1e-4)
+    rec["s_kept_err"] = float(np.abs(s - sr[:k]).max() / sr[0])
+    rec["ok"] = bool(rec["s_err"] < (1e-7 if a.dtype == "f64" else 1e-5) and rec["s_kept_err"] < TOL[0] * 10 and rec["orth_u"] < TOL[1] and rec["orth_v"] < TOL[1])
   print(json.dumps(rec), flush=True)
   return rec
 
