@@ -943,7 +943,8 @@ class HipBackend(BackendBase):
       # against 1201-1203) does the in-place read win.  Estimate: 10 % of the product at 1.45 PFLOP/s against
       # 2 x bytes at 5 TB/s + 6 us.
       if v is not None and v.sk0 != 1 and self.kmajor_inplace_penalty > 0.0:
-        if self.kmajor_inplace_penalty * (2.0 * m * n * k / 1.45e15) > 2.0 * t.nbytes / 5.0e12 + 6.0e-6:
+        if self.kmajor_inplace_penalty * (2.0 * m * n * k / self.model_gemm_flops) > \
+            2.0 * t.nbytes / self.model_k1_bytes_per_s + self.model_launch_s:
           return None
       if v is not None and t.nbytes > self.inplace_max_bytes:
         plain = v.sk0 == 1 and v.sr1 == 0 and v.sk1 == 0
@@ -1515,6 +1516,11 @@ class HipBackend(BackendBase):
   _svd_band_backoff = {}        # (dtype, mm, nn) -> (consecutive reports, calls still to skip)
 
   svd_band_backoff = True       # skip the band path for shapes that keep reporting (see svd's docstring)
+  # Rates of the lowering's cost rule (calibrated on one box family in round 5 -- boxes differ by
+  # 13 % in clock under the same power cap -- so they are attributes a deployment can re-calibrate, not literals):
+  model_gemm_flops = 1.45e15       # flop/s of the bf16 ping-pong GEMM on random data under the 1400 W cap
+  model_k1_bytes_per_s = 5.0e12    # read + write rate of a K1 pass
+  model_launch_s = 6.0e-6          # one more dependent launch
   kmajor_inplace_penalty = 0.10  # tensordot: what reading a k-major operand in place costs the product (0: always in place
                                  # below inplace_max_bytes, the rule of rounds 2-4)
   inplace_strided_max_bytes = 4 << 30

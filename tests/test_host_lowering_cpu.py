@@ -344,7 +344,6 @@ def test_bench_main_assembles_its_json_line_on_the_emulated_backend(monkeypatch,
   import bench  # pylint: disable=import-outside-toplevel
   with emulated_backend() as be:
     monkeypatch.setattr(ta, "get_hip_backend", lambda: be)
-    monkeypatch.setattr(ta, "configure_gc", lambda **kwargs: None)
     monkeypatch.setattr(sys, "argv", ["bench.py", "--bond", "16", "--steps", "2", "--warmup", "1", "--svd-n", "0",
                                       "--rr-bond", "3", "--rr-bond-small", "2", "--rr-min-slices", "4", "--mera-chi", "4", "--no-sweep",
                                       "--no-extras", "--no-cpu-baseline"])
