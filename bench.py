@@ -519,7 +519,8 @@ def svd_bound(m, n, k, itemsize=4):
                    a read + write for C -= V W, twice: 6 x;  floor at the 6.3 TB/s a copy reaches on this part;
     sturm_fma      f64 FMAs of the Sturm counts: 139 per pivot, n pivots per shift, 65536 + 15 n shifts for all values
                    (f64 input: three more rounds) + 3 x 15 k for the kept ones; this chip issues one 64-lane v_fma_f64
-                   per SIMD every 8 cycles: floor = FMAs / 64 x 8 cycles / (1024 SIMDs x 2.4 GHz).
+                   per SIMD every 5 cycles (measured, tools/fma_probe: 5.0-5.5 at one wave per SIMD; rounds 3-5 assumed
+                   8): floor = FMAs / 64 x 5 cycles / (1024 SIMDs x 2.4 GHz).
   The three floors add up (the stages are dependent): that sum is the `floor_s` the measured time is compared with."""
   npanels = n // 16
   f64 = itemsize == 8
@@ -532,7 +533,7 @@ def svd_bound(m, n, k, itemsize=4):
   sturm_fma = 139.0 * n * shifts
   launch_floor = launches * 4.5e-6
   update_floor = update_bytes / 6.3e12
-  sturm_floor = sturm_fma / 64.0 * 8.0 / (1024 * 2.4e9)
+  sturm_floor = sturm_fma / 64.0 * 5.0 / (1024 * 2.4e9)
   return {"launches": launches, "launch_floor_s": launch_floor, "update_bytes": update_bytes,
           "update_floor_s": update_floor, "sturm_f64_fma": sturm_fma, "sturm_floor_s": sturm_floor,
           "floor_s": launch_floor + update_floor + sturm_floor,
