@@ -1374,12 +1374,25 @@ __global__ __launch_bounds__(64) void solve_kernel(const double* __restrict__ Lc
   for (int itn = 0; itn < iters; ++itn) {
     // ---- forward: L y = scale * x (column oriented).  Lane a carries the pending value of entry i, i % 16 == a.
     double cur = x[l16] * scale;
+    // (round 6) the factor columns of the NEXT block of 16 steps are requested before the current block's chain of
+    // broadcasts starts: one un-prefetched load per block was ~130 of the 184 cycles a step took (64 waves on the
+    // whole chip: nothing else hides it)
+    double lvn[16];
+#pragma unroll
+    for (int jj = 0; jj < 16; ++jj) lvn[jj] = L[(int64_t)jj * 16 + ((l16 - jj - 1) & 15)];
+    double nbn = (16 + l16 < n) ? x[16 + l16] : 0.0;
     for (int64_t j0 = 0; j0 < n; j0 += 16) {
-      const int64_t inext = j0 + 16 + l16;
-      const double nb = (inext < n) ? x[inext] * scale : 0.0;
+      const double nb = nbn * scale;
       double lv[16];
 #pragma unroll
-      for (int jj = 0; jj < 16; ++jj) lv[jj] = L[(j0 + jj) * 16 + ((l16 - jj - 1) & 15)];
+      for (int jj = 0; jj < 16; ++jj) lv[jj] = lvn[jj];
+      {
+        const int64_t jn = (j0 + 16 < n) ? j0 + 16 : j0;
+#pragma unroll
+        for (int jj = 0; jj < 16; ++jj) lvn[jj] = L[(jn + jj) * 16 + ((l16 - jj - 1) & 15)];
+        const int64_t inext2 = j0 + 32 + l16;
+        nbn = (inext2 < n) ? x[inext2] : 0.0;
+      }
       static_for<16>([&](auto jc) {
         constexpr int jj = decltype(jc)::value;
         const double yj = bcast16<jj, DPP>(cur);
@@ -1394,11 +1407,22 @@ __global__ __launch_bounds__(64) void solve_kernel(const double* __restrict__ Lc
     // ---- backward: L^T z = D^-1 y (row oriented): z_j = y_j / d_j - sum_e L(j+1+e, j) z_(j+1+e)
     double nrm = 0.0;
     double zc = 0.0;      // lane a: z_i for the window entry i (i % 16 == a), zero beyond n
+    double lvb[16];
+#pragma unroll
+    for (int jj = 0; jj < 16; ++jj) lvb[jj] = L[(n - 16 + jj) * 16 + ((l16 - jj - 1) & 15)];
+    double xb = x[n - 16 + l16], db = D[n - 16 + l16];
     for (int64_t j0 = n - 16; j0 >= 0; j0 -= 16) {
       double lv[16];
 #pragma unroll
-      for (int jj = 0; jj < 16; ++jj) lv[jj] = L[(j0 + jj) * 16 + ((l16 - jj - 1) & 15)];
-      const double yd = x[j0 + l16] / D[j0 + l16];
+      for (int jj = 0; jj < 16; ++jj) lv[jj] = lvb[jj];
+      const double yd = xb / db;
+      {
+        const int64_t jp = (j0 >= 16) ? j0 - 16 : j0;       // the block below, requested before this block's chain
+#pragma unroll
+        for (int jj = 0; jj < 16; ++jj) lvb[jj] = L[(jp + jj) * 16 + ((l16 - jj - 1) & 15)];
+        xb = x[jp + l16];
+        db = D[jp + l16];
+      }
       static_for<16>([&](auto jc) {
         constexpr int jj = 15 - decltype(jc)::value;
         // the whole window j + 1 .. j + 16 contributes; lane jj still holds z_(j+16) (band offset 15)
