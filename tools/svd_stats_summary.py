@@ -12,7 +12,7 @@ for dt in ("f32", "f64"):
     continue
   rows = list(sqlite3.connect(dbs[0]).execute("select * from top_kernels"))
   lines = [f"# rocprofv3 --kernel-trace --stats -- python tools/svd_stats_run.py {dt}   (3 calls of be.svd(4096 x 4096 {dt}, "
-           "max_singular_values=256); MI355X, round 4, tools/r4_final.sh)",
+           "max_singular_values=256); MI355X, round 6, tools/r6_final.sh)",
            f"{'calls':>7} {'total_ms':>10} {'avg_us':>9} {'pct':>6}  kernel"]
   tot, ncalls = sum(r[2] for r in rows), sum(r[1] for r in rows)
   for name, calls, total, avg, pct in rows:
