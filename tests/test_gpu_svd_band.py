@@ -443,3 +443,39 @@ def test_complex_svd_cluster_branch_on_gpu(hip, dtype):
   # same subspaces as the Newton-Schulz branch (the vectors themselves differ by phases)
   p0 = np.asarray(u0).astype(np.complex128)
   assert np.linalg.norm(uu @ (uu.conj().T @ p0) - p0) <= 100 * tol * np.sqrt(k)
+
+
+def test_fast_band_reduction_is_taken_guarded_and_backs_off(monkeypatch):
+  """Round 6 (tnh_svd_band_fast.inc): which band reduction a call ran is observable (tnh_svd_band_last_stage1) --
+  1 the four-launch fast stage (f32 and f64), 0 the loop of rounds 3-5 (TNH_SVDB_FAST=0), 2 the fast stage reported an
+  ill-conditioned panel (a numerically half-rank matrix) and the stage was repeated with that loop, 3 the loop
+  directly while the shape's back-off lasts -- and the results obey the same tolerances whichever ran."""
+  be = ta.get_hip_backend()
+  last = be.lib.tnh_svd_band_last_stage1
+  rng = np.random.default_rng(77)
+  a = gaussian(1040, 1024, 5)                    # (a shape no other test uses: the back-off table is per shape)
+  u, s, vh, rest = be.svd(be.convert_to_tensor(a), 1, max_singular_values=64)
+  assert be.last_svd_path == "band" and last() == 1
+  check_svd(a, u, s, vh, rest, 64, "fast f32")
+  u, s, vh, rest = be.svd(be.convert_to_tensor(a.astype(np.float64)), 1, max_singular_values=64)
+  assert be.last_svd_path == "band" and last() == 1
+  sr = np.linalg.svd(a.astype(np.float64), compute_uv=False)
+  assert np.max(np.abs(np.asarray(s) - sr[:64])) <= 1e-12 * sr[0]
+  monkeypatch.setenv("TNH_SVDB_FAST", "0")
+  u0, s0, vh0, rest0 = be.svd(be.convert_to_tensor(a), 1, max_singular_values=64)
+  assert last() == 0
+  check_svd(a, u0, s0, vh0, rest0, 64, "accurate loop")
+  monkeypatch.delenv("TNH_SVDB_FAST")
+  # half of the spectrum is zero: panels of the transition are ill-conditioned
+  m = 1056
+  qu, _ = np.linalg.qr(rng.standard_normal((m, m)))
+  qv, _ = np.linalg.qr(rng.standard_normal((m, m)))
+  spec = np.where(np.arange(m) < m // 2, np.linspace(2, 1, m), 0.0)
+  h = ((qu * spec) @ qv.T).astype(np.float32)
+  seen = []
+  for _ in range(3):
+    u, s, vh, rest = be.svd(be.convert_to_tensor(h), 1, max_singular_values=64)
+    assert be.last_svd_path == "band"
+    seen.append(last())
+    check_svd(h, u, s, vh, rest, 64, "half rank")
+  assert seen[0] == 2 and seen[1] == 3 and seen[2] == 3, seen
