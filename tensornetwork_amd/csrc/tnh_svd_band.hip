@@ -1818,8 +1818,11 @@ static Layout make_layout(int64_t m, int64_t n, int64_t kcap, int esz) {
   size_t wpart = (size_t)chunks * 16 * wide * e;
   const size_t ypart = (size_t)((n + Y_COLS - 1) / Y_COLS) * m * 16 * e;     // the row panels' Y partials share the buffer
   if (ypart > wpart) wpart = ypart;
-  {       // fast stage 1: raw-pass partials per 64-row block (16 x n each) or per 32- / 64-column tile (m x 16 each)
-    const size_t fast = (size_t)((m + 63) / 64 + 1 + (f64 ? (n + 31) / 32 : 0)) * 16 * (size_t)(n > m ? n : m) * e;
+  {       // fast stage 1: raw-pass partials per 64-row block (16 x n each) and per column tile of 64 (f64: 32) (m x 16 each)
+    const size_t colparts = (size_t)((m + 63) / 64 + 1) * 16 * (size_t)n;
+    const int64_t cwmin = f64 ? 32 : 64;
+    const size_t rowparts = (size_t)((n + cwmin - 1) / cwmin + 1) * 16 * (size_t)m;
+    const size_t fast = (colparts > rowparts ? colparts : rowparts) * e;
     if (fast > wpart) wpart = fast;
   }
   L.Wpart = take(wpart);
