@@ -2185,7 +2185,9 @@ static int stage1_fast(const Layout& L, char* base, int64_t m, int64_t n, int64_
       a.rows = mj;
       a.nc = nc;
       a.Zx = Zx + j * 16;
+      a.zx_ld = 16;
       a.Pr = p > 0 ? Af + (j - 16) * n + j + 16 : Af;
+      a.pr_ld = n;
       a.Pcol = Af + j * n + j;
       a.Wpart = Part;
       a.ntc = (int)((nc + CWB - 1) / CWB);
@@ -2449,6 +2451,99 @@ __global__ __launch_bounds__(256) void qr_out_kernel(const T* __restrict__ Af, c
   if (e < m * n) Q[e] = (e / n == e % n) ? T(1) : T(0);       // thin identity, transformed afterwards
 }
 
+// The leading panels of the Householder QR by the fused kernels (see qr_lookahead_kernel).  Panels 0 .. *p_next - 1 are
+// done here (their V formed, R rows in place); the caller's loop continues at *p_next with *parts partial Grams in Gpart.
+template <typename T>
+static int qr_panels_fast(const Layout& L, char* base, int64_t m, int64_t n, int64_t* p_next, int* parts_out) {
+  constexpr bool F64 = sizeof(T) == 8;
+  constexpr int CWB = F64 ? 32 : 64;
+  T* Af = (T*)(base + L.Af);
+  double* Gc = (double*)(base + L.Gpart);
+  double* Gr = (double*)(base + L.Gpart2);
+  double* Gq = (double*)(base + L.Gq);
+  double* R1 = (double*)(base + L.R1);
+  T* Part = (T*)(base + L.Wpart);
+  T* Wx = (T*)(base + L.Wt);
+  T* Vl = (T*)(base + L.Vl);
+  double* Xl = (double*)(base + L.Xl);
+  double* Tl = (double*)(base + L.Tl);
+  int* status = (int*)(base + L.status);
+  T* Ffc = (T*)(base + L.Ff);
+  const double rel = F64 ? 1e-3 : 1e-9;
+  const double cond = F64 ? 0.0 : g_fast_cond;
+  // fast while the panel has more than `switch` rows and a trailing block of at least 16 columns
+  int64_t ps = 0;
+  while (ps < L.np && m - 16 * ps > g_fast_switch && n - 16 * ps - 16 >= 16) ++ps;
+  *p_next = 0;
+  if (ps < 2) return TNH_OK;
+  int parts = (int)((m + 255) / 256);
+  hipLaunchKernelGGL((gram_kernel<false, T>), dim3(parts), dim3(256), 0, stream(), (const T*)Af, n, m, Gc);
+  for (int64_t p = 0; p <= ps; ++p) {
+    const int64_t j = 16 * p, mj = m - j, nc = n - j - 16;
+    const bool last = p == ps;
+    if (p > 0) {
+      // panel p's 16 columns (rows j ..) take panel p - 1's update now; its partial Grams
+      parts = (int)((mj + 63) / 64);
+      hipLaunchKernelGGL((qr_lookahead_kernel<T>), dim3((unsigned)parts), dim3(256), 0, stream(), Af + j * n + j,
+                         (const T*)(Af + j * n + j - 16), n, mj, (const T*)Wx, n, Gc);
+    }
+    if (last) {
+      // hand-over: the rest of the block takes the pending update, the caller's loop goes on with panel ps
+      if (nc > 0) {
+        RowUpdArgs<T> a{};
+        a.C = Af + j * n + j + 16;
+        a.ldc = n; a.rows = mj; a.nc = nc;
+        a.Zx = Af + j * n + j - 16; a.zx_ld = n;
+        a.Pr = Wx + 16; a.pr_ld = n;
+        a.Pcol = Af; a.Wpart = Part;
+        a.ntc = (int)((nc + CWB - 1) / CWB);
+        a.iters = fast_iters(mj, a.ntc);
+        const int nrt = (int)(((mj + 63) / 64 + a.iters - 1) / a.iters);
+        launch_rowupd<T, CWB>(a, (unsigned)(nrt * a.ntc), true, false);
+      }
+      break;
+    }
+    const double* gram = Gc;
+    int gparts = parts;
+    if constexpr (F64) {
+      const int qparts = (int)((mj + 255) / 256);
+      hipLaunchKernelGGL((cholscale_kernel<false>), dim3(qparts), dim3(256), 0, stream(), (double*)(Af + j * n + j), n, mj,
+                         (const double*)Gc, parts, R1, Gq, status);
+      gram = Gq;
+      gparts = qparts;
+    }
+    int nrt;
+    {
+      RowUpdArgs<T> a{};
+      a.C = Af + j * n + j + 16;
+      a.ldc = n; a.rows = mj; a.nc = nc;
+      a.Zx = p > 0 ? Af + j * n + j - 16 : Af; a.zx_ld = n;      // panel p - 1's rows j .. (below its top block)
+      a.Pr = Wx + 16; a.pr_ld = n;                               // its Wx beyond the 16 columns the look-ahead took
+      a.Pcol = Af + j * n + j;
+      a.Wpart = Part;
+      a.ntc = (int)((nc + CWB - 1) / CWB);
+      a.iters = fast_iters(mj, a.ntc);
+      nrt = (int)(((mj + 63) / 64 + a.iters - 1) / a.iters);
+      a.fa = FactorArgs<T>{Af + j * n + j, n, mj, gram, gparts, Xl + p * 256, Vl + vl_offset(m, p), Tl + p * 256,
+                           (double*)(base + L.Dblk) + p * 256, F64 ? (const double*)R1 : (const double*)nullptr, rel, cond,
+                           status, Ffc};
+      launch_rowupd<T, CWB>(a, (unsigned)(nrt * a.ntc) + 1u, p > 0, true);
+    }
+    hipLaunchKernelGGL((colreduce_kernel<T>), dim3((unsigned)((nc + 63) / 64)), dim3(256), 0, stream(), (const T*)Part, nrt, nc,
+                       Af + j * n + j + 16, n, (const T*)(Vl + vl_offset(m, p)), (const T*)Ffc, Wx, n, Gr);
+    TNH_LAUNCH_CHECK();
+  }
+  {
+    FormVAllArgs<T> a{Af, m, n, ps, Xl, Xl, Vl, Vl};
+    hipLaunchKernelGGL((formv_all_kernel<T>), dim3((unsigned)((m - 16 + 255) / 256), (unsigned)ps, 1), dim3(256), 0, stream(), a);
+  }
+  TNH_LAUNCH_CHECK();
+  *p_next = ps;
+  *parts_out = parts;
+  return TNH_OK;
+}
+
+
 // T = float (round 3) or double (round 4: two Cholesky-QR passes per panel, as in the f64 band reduction)
 template <typename T>
 static int qr_panels(int64_t m, int64_t n, const T* A, T* Q, T* R, char* base, int* status_host) {
@@ -2464,12 +2559,24 @@ static int qr_panels(int64_t m, int64_t n, const T* A, T* Q, T* R, char* base, i
   T* Wpart = (T*)(base + L.Wpart);
   T* Wt = (T*)(base + L.Wt);
   int* status = (int*)(base + L.status);
+  const int64_t np = L.np;
+  // (very tall inputs -- 65536 x 256 -- gain nothing: 2.69 against 2.59 ms; profiles/r06_qr_fast_probe.jsonl)
+  bool fast = g_fast && !capturing() && (!QR2 || g_fast64) && m <= 32 * n;
+  int64_t p0 = 0;
+  int parts = 0;
+ again:
   TNH_HIP(hipMemcpyAsync(Af, A, (size_t)m * n * sizeof(T), hipMemcpyDeviceToDevice, stream()));
   TNH_HIP(hipMemsetAsync(status, 0, 64, stream()));
-  const int64_t np = L.np;
-  int parts = (int)((m + 255) / 256);
-  hipLaunchKernelGGL((gram_kernel<false, T>), dim3(parts), dim3(256), 0, stream(), (const T*)Af, n, m, Gc);
-  for (int64_t p = 0; p < np; ++p) {
+  p0 = 0;
+  parts = (int)((m + 255) / 256);
+  if (fast) {
+    // round 6: the leading panels by the fused kernels of tnh_svd_band_fast.inc -- three launches per panel (look-ahead,
+    // previous panel's update + raw pass + factor, reduce) instead of five (f64: four instead of seven)
+    const int rc = qr_panels_fast<T>(L, base, m, n, &p0, &parts);
+    if (rc) return rc;
+  }
+  if (p0 == 0) hipLaunchKernelGGL((gram_kernel<false, T>), dim3(parts), dim3(256), 0, stream(), (const T*)Af, n, m, Gc);
+  for (int64_t p = p0; p < np; ++p) {
     const int64_t j = 16 * p, mj = m - j, nc = n - j - 16;
     T* P = Af + j * n + j;
     T* V = (T*)(base + L.Vl) + vl_offset(m, p);
@@ -2541,6 +2648,11 @@ static int qr_panels(int64_t m, int64_t n, const T* A, T* Q, T* R, char* base, i
   TNH_LAUNCH_CHECK();
   TNH_HIP(hipMemcpyAsync(status_host, status, sizeof(int), hipMemcpyDeviceToHost, stream()));
   TNH_HIP(hipStreamSynchronize(stream()));
+  if (fast && (*status_host & (int)ST_FASTCOND)) {      // an ill-conditioned panel under the raw-panel passes: once more, the old loop
+    fast = false;
+    goto again;
+  }
+  *status_host &= ~(int)ST_FASTCOND;
   return TNH_OK;
 }
 
@@ -2556,6 +2668,7 @@ size_t qr_panel16_work_bytes(int dtype, int64_t m, int64_t n) {
   return svdb::make_layout(m, n, 4, dtype == TNH_F64 ? 8 : 4).total + 256;
 }
 int qr_panel16(int dtype, int64_t m, int64_t n, const void* A, void* Q, void* R, void* work, int* status_host) {
+  svdb::read_env();
   char* base = (char*)(((uintptr_t)work + 255) & ~(uintptr_t)255);
   if (dtype == TNH_F64)
     return svdb::qr_panels<double>(m, n, (const double*)A, (double*)Q, (double*)R, base, status_host);

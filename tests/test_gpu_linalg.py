@@ -43,6 +43,26 @@ def test_qr_large_vs_oracle(hip, dtype, otol, rtol, shape):
   assert np.array_equal(r, np.triu(r))
 
 
+@pytest.mark.parametrize("dtype,otol,rtol", [(np.float32, 2e-5, 2e-5), (np.float64, 1e-12, 1e-12)])
+@pytest.mark.parametrize("shape", [(1536, 1024), (2048, 512), (1000, 608)])
+def test_qr_fused_panels_and_the_five_launch_loop_agree_with_lapack(hip, monkeypatch, dtype, otol, rtol, shape):
+  """Round 6 (qr_panels_fast): the leading panels of the 16-wide Householder QR run as look-ahead + fused update /
+  raw pass / factor + reduce; TNH_SVDB_FAST=0 keeps the five-launch loop of rounds 3-5.  Both against np.linalg.qr
+  (same reflector signs), Q orthonormal, Q R = A."""
+  rng = np.random.default_rng(shape[0] * 3 + shape[1])
+  x = rng.standard_normal(shape).astype(dtype)
+  qo, ro = orc.qr(x, 1, False)
+  scale = np.abs(ro).max()
+  for fast in ("1", "0"):
+    monkeypatch.setenv("TNH_SVDB_FAST", fast)
+    q, r = hip.qr(hip.convert_to_tensor(x), 1, False)
+    q, r = np.asarray(q), np.asarray(r)
+    np.testing.assert_allclose(q.T @ q, np.eye(shape[1]), atol=otol * 20, err_msg=fast)
+    np.testing.assert_allclose(q.astype(np.float64) @ r.astype(np.float64), x, atol=rtol * scale * 20, err_msg=fast)
+    np.testing.assert_allclose(r, ro, atol=rtol * scale * 50, err_msg=fast)
+    assert np.array_equal(r, np.triu(r))
+
+
 def test_complex_svd_golden(hip, golden_complex):
   """complex64 / complex128 svd (one-sided Jacobi with unitary rotations) vs the reference's outputs."""
   for case in golden_complex.cases["svd"]:
