@@ -311,6 +311,15 @@ __device__ __forceinline__ void lds_frag(uint4& dst, unsigned addr) {
   asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(*(u32x4_t*)&dst) : "v"(addr), "n"(OFF));
 }
 
+// A k-major fragment (8 consecutive k of one row per lane) as two untracked transposing reads: k rows 0-3 and 4-7 of
+// the lane's group (the second 1 KiB = four 256-byte k rows further on)
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2_t;
+template <int OFF>
+__device__ __forceinline__ void lds_frag_tr(uint4& dst, unsigned addr) {
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(*(u32x2_t*)&dst.x) : "v"(addr), "n"(OFF));
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(*(u32x2_t*)&dst.z) : "v"(addr), "n"(OFF + 1024));
+}
+
 // SCHED = 1 (round 5, A/B knob ":p7"): ONE 64-MFMA cluster per K-tile -- every fragment of the K-tile (24 ds_read_b128
 // = 96 registers) is read in one load segment, two barriers per K-tile instead of four.  LDS: A double-buffered
 // (2 x 32 KiB), B triple-buffered (3 x 32 KiB) = 160 KiB, the whole CU.  Group g (waves 4g .. 4g+3) loads what it
@@ -337,11 +346,18 @@ __device__ __forceinline__ void lds_frag(uint4& dst, unsigned addr) {
 template <bool IS_BF16, bool OUT_F32, bool TWO, bool M32 = false, bool VIEW = false, bool A_KM = false,
           bool B_KN = false, int SCHED = 0, int KW = 0>
 __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(NtArgs p) {
-  static_assert(KW == 0 || (VIEW && !A_KM && !B_KN), "the tile-granular K walks are for K-contiguous view operands");
+  static_assert(KW == 0 || (VIEW && !A_KM && (!B_KN || (SCHED == 3 && KW == 1))),
+                "the tile-granular K walks: K-contiguous view operands, or (lean loop, KW = 1) a k-major B");
   static_assert(!VIEW || (TWO && !M32), "view kernels use the 2-phase 16x16x32 schedule");
   static_assert(SCHED == 0 || (TWO && !M32), "the round-5 schedules are 16x16x32 schedules");
   static_assert(SCHED == 0 || SCHED == 3 || (!A_KM && !B_KN), "one-cluster / snake: K-contiguous operands");
-  static_assert(!(A_KM || B_KN) || KW == 0, "k-major operands: half-K-tile walk");
+  // B_KT (round 6): a k-major B whose contraction runs are multiples of 64, next to a K-contiguous A, in the lean loop --
+  // the whole-K-tile walk (both pieces of a half-tile hang off ONE scalar base: a lane's k row 0 .. 63 sits in its 32-bit
+  // offset), the 16 transposing fragment reads as untracked asm from precomputed addresses (one VGPR per 32-B unit of
+  // the fragment columns and LDS buffer; k-step and half as immediate offsets), and the K-contiguous loop's
+  // interleaved issue of the LDS-DMA pieces: 8 more instructions per K-tile and wave than the NT loop (the 8 extra
+  // transposing reads) instead of 94.
+  constexpr bool B_KT = B_KN && KW == 1;
   // SCHED = 3: the default two-cluster schedule with a LEAN main loop -- the same fragment reads, LDS-DMA pieces, MFMAs
   // and barriers, and about 50 fewer bookkeeping instructions per K-tile and wave (205 -> ~150): SADDR-form LDS-DMA
   // (one 64-bit scalar add per operand and K-tile instead of a 64-bit VALU add per piece; M0 written by one scalar add,
@@ -459,7 +475,8 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(NtArgs p) {
           const int lchunk = (lane & 7) ^ (trow & 7);
           // k-major operand (stored [k][row], rows contiguous): piece i = k rows (i * 8 + wid) * 4 + (lane >> 4) of the
           // K-tile (i.e. half i), 16-byte chunk of the half-tile's 128 rows as in src_ptr; its K offset comes per piece
-          const int krow = ((i * 8 + wid) * 4 + (lane >> 4)) & 31;
+          const int krow_tile = (i * 8 + wid) * 4 + (lane >> 4);
+          const int krow = krow_tile & 31;
           const int s16 = lane & 15;
           const int hsw = (lane >> 4) | (((wid >> 1) & 1) << 2);
           const int kchunk = ((((s16 >> 1) ^ hsw)) << 1) | (s16 & 1);
@@ -475,7 +492,7 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(NtArgs p) {
           if constexpr (B_KN) {
             int64_t col = n0 + h * 128 + kchunk * 8;
             if (col + 8 > p.N) col = p.N - 8;
-            ob[h][i] = (uint32_t)((row_elems_km(p.vb, col) - b0 + (int64_t)krow * p.vb.sk0) * 2);
+            ob[h][i] = (uint32_t)((row_elems_km(p.vb, col) - b0 + (int64_t)(B_KT ? krow_tile : krow) * p.vb.sk0) * 2);
           } else {
             int64_t rb = n0 + h * 128 + trow;
             if (rb >= p.N) rb = p.N - 1;
@@ -541,7 +558,7 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(NtArgs p) {
   // prologue form: both pieces of half-tile WHICH of the K-tile whose halves start at element offsets k0 / k1
   auto stage_lean = [&](auto bufc, auto whichc, int64_t k0, int64_t k1) {
     constexpr int BUF = decltype(bufc)::value, WHICH = decltype(whichc)::value;
-    constexpr bool KMAJOR = (WHICH < 2) ? A_KM : B_KN;
+    constexpr bool KMAJOR = (WHICH < 2) ? A_KM : (B_KN && !B_KT);     // (B_KT: one base per half-tile, as K-contiguous)
     const uint16_t* xb = (WHICH < 2) ? abase : bbase;
     const uint32_t o0 = (WHICH < 2) ? oa[WHICH & 1][0] : ob[WHICH & 1][0];
     const uint32_t o1 = (WHICH < 2) ? oa[WHICH & 1][1] : ob[WHICH & 1][1];
@@ -632,6 +649,25 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(NtArgs p) {
                            (unsigned)((((lane & 15) >> 2) | (((lane >> 4) & 1) << 2)) << 5);
   const unsigned tr_a = tr_lane;                                  // A units: sub * 4 + f
   const unsigned tr_b = tr_lane ^ (unsigned)(((wc & 1) * 4) << 5);  // B units: (wc & 1) * 4 + sub * 2 + f
+  // B_KT: LDS byte address of this lane's transposing reads per buffer and 32-B unit u = sub * 2 + f of the wave's 64
+  // columns; the k-step (8 KiB) and the second half of a fragment (k rows + 4: 1 KiB) are immediate offsets
+  unsigned b_tr[2][4];
+  if constexpr (B_KT) {
+#pragma unroll
+    for (int bq = 0; bq < 2; ++bq)
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        b_tr[bq][u] = lds0 + bq * BUF_BYTES + (2 + (wc >> 1)) * HALF_BYTES + (tr_b ^ (unsigned)(u << 5));
+  }
+  auto lean_read_b_tr = [&](auto bufc, auto subc) {
+    constexpr int BUF = decltype(bufc)::value, SUB = decltype(subc)::value;
+    static_for<0, 2>([&](auto ks) {
+      static_for<0, 2>([&](auto f) {
+        constexpr int KS_ = decltype(ks)::value, F_ = decltype(f)::value;
+        lds_frag_tr<KS_ * 8192>(bf[SUB][KS_][F_], b_tr[BUF][SUB * 2 + F_]);
+      });
+    });
+  };
   auto tr_read = [&](unsigned lds_byte) -> uint4 {
     const v4i16 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4i16*)((lds_char*)TNH_LDS_PTR(smem) + lds_byte));
     const v4i16 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4i16*)((lds_char*)TNH_LDS_PTR(smem) + lds_byte + 1024));
@@ -862,7 +898,7 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(NtArgs p) {
     };
     auto body = [&](auto bufc, int t) {
       constexpr int B = decltype(bufc)::value;
-      if constexpr (A_KM || B_KN) {
+      if constexpr (A_KM || (B_KN && !B_KT)) {
         body_km(bufc, t);
         return;
       }
@@ -876,8 +912,13 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(NtArgs p) {
       int64_t unused = 0;
       // ---- load segment 1: B sub-tiles 0 / 1 (8 reads), A sub-tile 0 (8 reads); A halves of K-tile t + 1 -> other buffer.
       // Every LDS-DMA piece is [M0 write] [one fragment read] [load]: the read is the wait state the M0 write needs.
-      lean_read_b(IB{}, C0{});
-      lean_read_b(IB{}, C1{});
+      if constexpr (B_KT) {
+        lean_read_b_tr(IB{}, C0{});
+        lean_read_b_tr(IB{}, C1{});
+      } else {
+        lean_read_b(IB{}, C0{});
+        lean_read_b(IB{}, C1{});
+      }
       if (left > 1) {
         const void* sb;
         uint32_t v0 = oa[0][0], v1 = oa[0][1], v2 = oa[1][0], v3 = oa[1][1];
@@ -1355,7 +1396,7 @@ static bool lean_wanted(const NtArgs& q) {
 //   1  rows ascend in memory (sr0 > 0 and, with two levels, sr1 >= the extent of an inner run of rows) and any 256
 //      consecutive rows plus a K-tile span < 4 GiB: offsets from the tile's first row;
 //   0  otherwise, if both strides are non-negative and the whole operand spans < 4 GiB: offsets from the operand's base.
-static bool lean_view_rows(NtArgs& q, bool half_walk = false, bool a_km = false, bool b_kn = false) {
+static bool lean_view_rows(NtArgs& q, bool half_walk = false, bool a_km = false, bool b_kn = false, bool km_tile = false) {
   static const int env = []() { const char* e = getenv("TNH_GEMM_LEAN"); return e ? atoi(e) : -1; }();
   const int mode = g_opt_lean >= 0 ? g_opt_lean : env;
   if (mode == 0) return false;
@@ -1365,7 +1406,8 @@ static bool lean_view_rows(NtArgs& q, bool half_walk = false, bool a_km = false,
     // K-contiguous operand, half-K-tile walk: the lanes of a K-tile's second half add the distance between two
     // contraction runs; k-major operand: a lane's k row inside a half K-tile (each half has its own scalar base)
     const bool one_run = (int64_t)v.tpi * 32 >= q.K;          // (sk1 is meaningless then: the walk never wraps)
-    const int64_t jump = kmajor ? 32 * v.sk0 : ((half_walk && !one_run) ? (v.sk1 - (int64_t)v.tpi * 32) : 0);
+    // (km_tile: the whole-K-tile walk of a k-major B -- a lane's k row 0 .. 63 in its offset)
+    const int64_t jump = kmajor ? (km_tile ? 64 : 32) * v.sk0 : ((half_walk && !one_run) ? (v.sk1 - (int64_t)v.tpi * 32) : 0);
     if (jump < 0 || jump >= lim / 2) return false;
     const bool single = v.r0 >= rows;
     const int64_t inner = (v.r0 - 1) * v.sr0;
@@ -1461,6 +1503,19 @@ static void launch_pp_view_t(bool is_bf16, bool out_f32, dim3 grid, const NtArgs
       return;
     }
   }
+  if constexpr (!A_KM && B_KN) {       // k-major B with whole-K-tile runs next to a K-contiguous A: the interleaved lean loop
+    NtArgs ql = q;
+    if (kw >= 1 && g_opt_phases != 7 && lean_view_rows(ql, false, false, true, true)) {
+      if (is_bf16) {
+        if (out_f32) hipLaunchKernelGGL((gemm_nt_pp_kernel<true, true, true, false, true, false, true, 3, 1>), grid, block, 0, stream(), ql);
+        else hipLaunchKernelGGL((gemm_nt_pp_kernel<true, false, true, false, true, false, true, 3, 1>), grid, block, 0, stream(), ql);
+      } else {
+        if (out_f32) hipLaunchKernelGGL((gemm_nt_pp_kernel<false, true, true, false, true, false, true, 3, 1>), grid, block, 0, stream(), ql);
+        else hipLaunchKernelGGL((gemm_nt_pp_kernel<false, false, true, false, true, false, true, 3, 1>), grid, block, 0, stream(), ql);
+      }
+      return;
+    }
+  }
   if constexpr (A_KM || B_KN) {
     NtArgs ql = q;
     if (g_opt_phases != 7 && lean_view_rows(ql, true, A_KM, B_KN)) {
@@ -1544,12 +1599,25 @@ int gemm_bf16_view(int in_dt, int out_dt, int64_t M, int64_t N, int64_t K, const
     const bool ca = contiguous(p.va), cb = contiguous(p.vb);
     kw = (ca && cb) ? 2 : ((p.va.tpi % 2 == 0 && p.vb.tpi % 2 == 0) ? 1 : 0);
     if (g_opt_kwalk >= 0 && kw > g_opt_kwalk) kw = g_opt_kwalk;
+  } else if (!a_km && b_kn) {
+    // k-major B: the whole-K-tile walk (kernel header, B_KT) when every contraction run of both operands is a
+    // multiple of 64; a single run is normalised as above (k-major: the run's stride is sk0)
+    auto one_run = [&](OpView& v, int64_t ks) {
+      if ((int64_t)v.tpi * 32 >= K || v.sk1 == (int64_t)v.tpi * 32 * ks) {
+        v.tpi = (int)(K / 32);
+        v.sk1 = K * ks;
+      }
+    };
+    one_run(p.va, 1);
+    one_run(p.vb, p.vb.sk0);
+    kw = (p.va.tpi % 2 == 0 && p.vb.tpi % 2 == 0) ? 1 : 0;
+    if (g_opt_kwalk >= 0 && kw > g_opt_kwalk) kw = g_opt_kwalk;
   }
   auto launch = [&](const NtArgs& q, unsigned gy, bool f32_out) {
     const dim3 grid(pp_grid_x((int64_t)q.tiles_m * q.tiles_n, gy), gy);
     if (a_km && b_kn) launch_pp_view_t<true, true>(is_bf16, f32_out, grid, q);
     else if (a_km) launch_pp_view_t<true, false>(is_bf16, f32_out, grid, q);
-    else if (b_kn) launch_pp_view_t<false, true>(is_bf16, f32_out, grid, q);
+    else if (b_kn) launch_pp_view_t<false, true>(is_bf16, f32_out, grid, q, kw);
     else launch_pp_view_t<false, false>(is_bf16, f32_out, grid, q, kw);
   };
   *name = a_km ? (b_kn ? "bf16_view_tt_256x256x64_pp" : "bf16_view_tn_256x256x64_pp")

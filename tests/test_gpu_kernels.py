@@ -1528,6 +1528,11 @@ def test_gemm_view_k_walk_forms_are_bit_identical(hip, dtype):
       ((3700, 320), (3600, 320), ([1], [1])),                        # ragged M / N edges, odd K-tile count
       # k-major operands (stored [k][row]): the lean loop stages each half of a K-tile from its own scalar base
       ((14, 256, 2, 64), (2, 64, 15, 256), ([2, 3], [0, 1])),        # b k-major (config-2 L0)
+      # round 6: b k-major with contraction runs that are multiples of 64 -> the interleaved whole-K-tile lean loop
+      # ("auto"; ":w0" caps it to the half-K-tile k-major loop of round 5)
+      ((14, 256, 4, 128), (4, 15, 128, 256), ([2, 3], [0, 2])),      # b: two runs levels (4 x 128), two-level rows
+      ((3700, 320), (320, 3608), ([1], [0])),                        # ragged M / N edges (N % 8 == 0), 5 K-tiles
+      ((15, 248, 3, 64), (3, 64, 14, 264), ([2, 3], [0, 1])),        # ragged edges inside two-level rows, 3 K-tiles
       ((2, 64, 14, 256), (15, 256, 2, 64), ([0, 1], [2, 3])),        # a k-major
       ((2, 96, 14, 256), (2, 96, 15, 256), ([0, 1], [0, 1])),        # both k-major, runs of 96
       ((4, 32, 15, 248), (4, 32, 15, 248), ([0, 1], [0, 1])),        # both k-major, ragged edges, runs of 32
