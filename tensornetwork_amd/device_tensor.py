@@ -320,6 +320,18 @@ class DeviceTensor:
     return cls(_Block(n * _ITEMSIZE[code]), shape, code, 0, alias if code == _lib.I64 else None)
 
   @classmethod
+  def _fresh(cls, shape, code, nbytes, alias=None):
+    """`empty` for callers that hold a validated shape tuple and its byte count (the planned tensordot)."""
+    t = cls.__new__(cls)
+    t._block = _Block(nbytes)
+    t._offset = 0
+    t._shape = shape
+    t._code = code
+    t._alias = alias
+    t._pad = None
+    return t
+
+  @classmethod
   def from_numpy(cls, array, dtype=None):
     """H2D copy. ``dtype=bfloat16`` rounds a real array to bf16 on the host."""
     array = np.asarray(array)

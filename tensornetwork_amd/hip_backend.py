@@ -25,6 +25,13 @@ _INT_CODES = (_lib.I32, _lib.I64)
 _NUM_CODES = _FLOAT_CODES + _INT_CODES   # everything the arithmetic kernels take (ints: exact, wrap-around)
 _HALF = (_lib.BF16, _lib.F16)
 _REAL_OF = {_lib.C64: _lib.F32, _lib.C128: _lib.F64}
+_PLAN_CODES = (_lib.BF16, _lib.F16, _lib.F32, _lib.F64, _lib.C64, _lib.C128)     # dtypes whose tensordot lowering is cached
+
+
+class _TensordotPlan:
+  """One lowering of the permute + ONE GEMM path (HipBackend._plan_generic)."""
+  __slots__ = ("out_shape", "free_a", "free_b", "trans_a", "trans_b", "m", "n", "k", "lda", "ldb", "code", "out_code",
+               "out_bytes", "complex", "perm_a", "perm_b", "k1_a", "k1_b")
 # promotion lattice for mixed-dtype binary ops / contractions (numpy's rules,
 # with bf16 treated like float16: any mix with a wider float wins).
 _RANK = {_lib.BF16: 0, _lib.F16: 0, _lib.F32: 1, _lib.F64: 2, _lib.C64: 3, _lib.C128: 4}
@@ -364,6 +371,9 @@ class HipBackend(BackendBase):
     self.gather_launches = 0     # tnh_gemm_gather launches
     self.permutes_absorbed = 0   # tnh_gemm_view launches
     self.permute_launches = 0    # K1 launches (transpose)
+    self._direct_launches = type(self).transpose is HipBackend.transpose and type(self)._gemm is HipBackend._gemm
+    self._td_plans = {}          # tensordot: lowering plans of the permute + ONE GEMM path by (shapes, axes, dtype, hints)
+    self.gemm_events = None      # bench.py: a list that receives (start, stop) HIP events around every GEMM launch
     self._svd_band_failed = set()      # per backend object (the class attributes below only say what they are)
     self._svd_band_backoff = {}
 
@@ -748,6 +758,23 @@ class HipBackend(BackendBase):
     brings it to [free, contracted] form.  For bf16/f16 both operands are
     brought to the K-contiguous form the 16x16x32 MFMA kernels consume.
     """
+    # Fast lane (round 6): small products are host-bound (a D = 32 `contract_between` spent 23 us of Python in this
+    # function for ~5 us of kernels), and a contraction path calls with the same (shapes, axes, dtype, hints) over and
+    # over: the lowering of the permute + ONE GEMM path is a pure function of those, planned once (`_plan_generic`)
+    # and replayed (`_run_plan`: ctypes arrays made once, no axis arithmetic).  Products the gather / in-place
+    # lowerings may take are never planned here: those look at addresses and policy.
+    key = None
+    if self.plan_cache and type(a) is DeviceTensor and type(b) is DeviceTensor and a._code == b._code and \
+        a._code in _PLAN_CODES and a._pad is None and b._pad is None and self.gemm_events is None:   # pylint: disable=protected-access
+      try:
+        key = (a._shape, b._shape, tuple(axes[0]), tuple(axes[1]), a._code,     # pylint: disable=protected-access
+               None if hint_a is None else tuple(hint_a), None if hint_b is None else tuple(hint_b), allow_swap,
+               self.gather_gemm, self.absorb_transposes, self.half_output)
+        plan = self._td_plans.get(key)
+      except TypeError:      # (an integer `axes`, unhashable entries: the general walk below)
+        key = plan = None
+      if plan is not None:
+        return self._run_plan(plan, a, b, None)
     a = a if isinstance(a, DeviceTensor) else self.convert_to_tensor(a)     # (row-padded results stay as they lie
     b = b if isinstance(b, DeviceTensor) else self.convert_to_tensor(b)     #  until the in-place lowering has looked)
     axes_a, axes_b = self._normalize_axes(a, b, axes)
@@ -768,6 +795,11 @@ class HipBackend(BackendBase):
 
     # bf16 / f16, enough 256 x 256 tiles: read BOTH operands in place through two-level strides
     # (K8 lowering of tensordot2.py:62-88 -- transposes are absorbed by the GEMM loaders, no K1 launch).
+    if code in _HALF:       # products the gather / in-place lowerings may take (by shape alone) are not planned
+      ms, nl = (m, n) if m <= n else (n, m)
+      if (64 < ms <= 192 and 16 <= k <= 192 * 4096 and k % 8 == 0 and nl >= self.gather_min_rows) or \
+          not (m < 256 or n < 256 or ((m + 255) // 256) * ((n + 255) // 256) < 192 or k % 64 or k < 128):
+        key = None
     if code in _HALF and self.gather_gemm and self.half_output == "same":
       got = self._tensordot_gather(a, b, axes_a, axes_b, free_a, free_b, m, n, k, hint_a, hint_b, allow_swap)
       if got is not None:
@@ -782,18 +814,30 @@ class HipBackend(BackendBase):
         out_shape = tuple(a_shape0[i] for i in used_a) + tuple(b_shape0[i] for i in used_b)
         return out.view(out_shape), used_a, used_b, False
     a, b = self._dense(a), self._dense(b)
+    plan = self._plan_generic(a.shape, b.shape, axes_a, axes_b, free_a, free_b, m, n, k, code, hint_a, hint_b)
+    if key is not None and alias is None:
+      if len(self._td_plans) >= 4096:
+        self._td_plans.clear()
+      self._td_plans[key] = plan
+    return self._run_plan(plan, a, b, alias)
 
+  def _plan_generic(self, a_shape, b_shape, axes_a, axes_b, free_a, free_b, m, n, k, code, hint_a, hint_b):
+    """The permute + ONE GEMM lowering of tensordot as data: which operands get a K1 permute (and where to), the
+    storage forms handed to tnh_gemm, the result's shape and the order of the free axes in it.  A pure function of
+    its arguments and of `half_output` (part of the plan cache's key)."""
+    nc = len(axes_a)
+    nd_a, nd_b = len(a_shape), len(b_shape)
     # memory order of the contracted pairs on each side
     order_a = sorted(range(nc), key=lambda i: axes_a[i])
     order_b = sorted(range(nc), key=lambda i: axes_b[i])
     sa, sb = sorted(axes_a), sorted(axes_b)
-    a_form = "MK" if sa == list(range(a.ndim - nc, a.ndim)) else (
+    a_form = "MK" if sa == list(range(nd_a - nc, nd_a)) else (
         "KM" if sa == list(range(nc)) else None)
-    b_form = "NK" if sb == list(range(b.ndim - nc, b.ndim)) else (
+    b_form = "NK" if sb == list(range(nd_b - nc, nd_b)) else (
         "KN" if sb == list(range(nc)) else None)
-    if a.ndim == nc:
+    if nd_a == nc:
       a_form = "MK"  # M == 1: both readings are valid, prefer K-contiguous
-    if b.ndim == nc:
+    if nd_b == nc:
       b_form = "NK"
 
     # bf16 / f16: the matrix-core kernels (LDS-DMA for aligned shapes, register-staged
@@ -806,7 +850,7 @@ class HipBackend(BackendBase):
     if want_a and want_b and order_a != order_b:
       # contracted axes are paired in a different memory order on the two sides:
       # re-order the smaller operand.
-      if a.size <= b.size:
+      if _prod(a_shape) <= _prod(b_shape):
         want_a = None
       else:
         want_b = None
@@ -816,27 +860,94 @@ class HipBackend(BackendBase):
       pair_order = order_b
     else:
       pair_order = order_a
-    a_shape, b_shape = a.shape, b.shape
+    free_a, free_b = list(free_a), list(free_b)
+    perm_a = perm_b = None
     if not want_a:
       if hint_a is not None and sorted(hint_a) == free_a:
         free_a = [int(i) for i in hint_a]       # the permute is paid anyway: any free order is free
-      a = self.transpose(a, free_a + [axes_a[i] for i in pair_order])
+      perm_a = tuple(free_a + [axes_a[i] for i in pair_order])
       a_form = "MK"
+      if perm_a == tuple(range(nd_a)):
+        perm_a = None
     if not want_b:
       if hint_b is not None and sorted(hint_b) == free_b:
         free_b = [int(i) for i in hint_b]
-      b = self.transpose(b, free_b + [axes_b[i] for i in pair_order])
+      perm_b = tuple(free_b + [axes_b[i] for i in pair_order])
       b_form = "NK"
-    out_shape = tuple(a_shape[i] for i in free_a) + tuple(b_shape[i] for i in free_b)
+      if perm_b == tuple(range(nd_b)):
+        perm_b = None
+    plan = _TensordotPlan()
+    plan.out_shape = tuple(a_shape[i] for i in free_a) + tuple(b_shape[i] for i in free_b)
+    plan.free_a, plan.free_b = tuple(free_a), tuple(free_b)
+    plan.trans_a = int(a_form == "KM")
+    plan.trans_b = int(b_form == "NK")
+    plan.m, plan.n, plan.k = m, n, k
+    plan.lda = m if plan.trans_a else k
+    plan.ldb = k if plan.trans_b else n
+    plan.code = code
+    plan.out_code = _lib.F32 if (code in _HALF and self.half_output == "float32") else code
+    plan.out_bytes = m * n * device_tensor._ITEMSIZE[plan.out_code]      # pylint: disable=protected-access
+    plan.complex = code in _REAL_OF and 8 * m * n * k >= (1 << 18)
+    plan.perm_a, plan.perm_b = perm_a, perm_b
+    plan.k1_a = self._plan_permute(a_shape, perm_a, code)
+    plan.k1_b = self._plan_permute(b_shape, perm_b, code)
+    return plan
 
-    trans_a = a_form == "KM"
-    trans_b = b_form == "NK"
-    lda = m if trans_a else k
-    ldb = k if trans_b else n
-    if code in _REAL_OF and 8 * m * n * k >= (1 << 18):
-      return self._complex_gemm(a, b, trans_a, trans_b, m, n, k).view(out_shape), free_a, free_b, False
-    out = self._gemm(a, b, trans_a, trans_b, m, n, k, lda, ldb, alias=alias)
-    return out.view(out_shape), free_a, free_b, False
+  @staticmethod
+  def _plan_permute(shape, perm, code):
+    """(result shape, its bytes, rank, ctypes shape, ctypes perm, item size) of ONE K1 launch, or None (no permute,
+    or more axes than one launch indexes: `transpose` walks those)."""
+    if perm is None or len(shape) > MAX_KERNEL_RANK:
+      return None
+    out_shape = tuple(shape[p] for p in perm)
+    item = device_tensor._ITEMSIZE[code]      # pylint: disable=protected-access
+    return (out_shape, _prod(out_shape) * item, len(shape), _lib.i64_array(shape), _lib.i32_array(perm), item)
+
+  def _run_plan(self, plan, a, b, alias):
+    """Launches of a planned tensordot: at most two K1 permutes and ONE GEMM.  Returns what `_tensordot_impl` does."""
+    if not self._direct_launches:      # a subclass hooks `transpose` / `_gemm` (the host dry-run tools): go through them
+      if plan.perm_a is not None:
+        a = self.transpose(a, plan.perm_a)
+      if plan.perm_b is not None:
+        b = self.transpose(b, plan.perm_b)
+      if plan.complex:
+        out = self._complex_gemm(a, b, bool(plan.trans_a), bool(plan.trans_b), plan.m, plan.n, plan.k)
+      else:
+        out = self._gemm(a, b, bool(plan.trans_a), bool(plan.trans_b), plan.m, plan.n, plan.k, plan.lda, plan.ldb, alias=alias)
+      return out.view(plan.out_shape), list(plan.free_a), list(plan.free_b), False
+    lib = self.lib
+    if plan.perm_a is not None:
+      k1 = plan.k1_a
+      if k1 is None:
+        a = self.transpose(a, plan.perm_a)
+      else:
+        t = DeviceTensor._fresh(k1[0], plan.code, k1[1], a._alias)      # pylint: disable=protected-access
+        self.permute_launches += 1
+        _lib.check(lib.tnh_permute(_vp(t), _vp(a), k1[2], k1[3], k1[4], k1[5]), "tnh_permute")
+        a = t
+    if plan.perm_b is not None:
+      k1 = plan.k1_b
+      if k1 is None:
+        b = self.transpose(b, plan.perm_b)
+      else:
+        t = DeviceTensor._fresh(k1[0], plan.code, k1[1], b._alias)      # pylint: disable=protected-access
+        self.permute_launches += 1
+        _lib.check(lib.tnh_permute(_vp(t), _vp(b), k1[2], k1[3], k1[4], k1[5]), "tnh_permute")
+        b = t
+    m, n, k = plan.m, plan.n, plan.k
+    if plan.complex:
+      out = self._complex_gemm(a, b, bool(plan.trans_a), bool(plan.trans_b), m, n, k).view(plan.out_shape)
+      return out, list(plan.free_a), list(plan.free_b), False
+    out = DeviceTensor._fresh(plan.out_shape, plan.out_code, plan.out_bytes,      # pylint: disable=protected-access
+                              alias if plan.out_code == _lib.I64 else None)
+    events = self.gemm_events
+    if events is not None:  # bench.py: HIP events on the launch stream around the GEMM only
+      start = _lib.Event().record()
+    _lib.check(lib.tnh_gemm(plan.code, plan.out_code, plan.trans_a, plan.trans_b, m, n, k, _vp(a), plan.lda,
+                            _vp(b), plan.ldb, _vp(out), n, 1, 0, 0, m * n), "tnh_gemm")
+    if events is not None:
+      events.append((start, _lib.Event().record()))
+    return out, list(plan.free_a), list(plan.free_b), False
 
   def _tensordot_gather(self, a, b, axes_a, axes_b, free_a, free_b, m, n, k, hint_a=None, hint_b=None,
                         allow_swap=False):
@@ -921,7 +1032,7 @@ class HipBackend(BackendBase):
 
     out_bytes = m * n * a.itemsize
 
-    def usable(t, free, kax, hint):
+    def usable(t, free, kax, hint, kt_partner=False):
       v = _operand_view(t.shape, free, kax, t.strides if t.pad is not None else None)
       # The planner asked for another order of this operand's free axes (it lays the RESULT out for the contractions
       # that follow) and the operand is small against the result: pay its K1 pass now rather than a pass over the
@@ -942,8 +1053,19 @@ class HipBackend(BackendBase):
       # 1384-1394 / 1353-1360); only where the pass would cost more than that (D = 64: a 0.1 ms product, 1299-1307
       # against 1201-1203) does the in-place read win.  Estimate: 10 % of the product at 1.45 PFLOP/s against
       # 2 x bytes at 5 TB/s + 6 us.
+      # Round 6 (profiles/r06_kmajor_lean_loop.md): a k-major `b` whose contraction runs are multiples of 64, next to a
+      # K-contiguous `a`, is read by the interleaved whole-K-tile loop (B_KT in tnh_gemm_bf16.hip: 8 instructions per
+      # K-tile more than the NT loop instead of 94).  Its cost is the operand's size, not the loop: nothing up to ~0.6 GB
+      # (D = 96 / 128 L0 in place 1379 / 1542 TFLOP/s against 1351 / 1494-1516 through the pass), 2 % at 1 GB, 7 % at
+      # 2.7 GB, 10 % at 4.3 GB (B's lines miss the XCD's L2 2.4 times as often as the K-contiguous form's once the
+      # contraction is thousands of K-tiles long).
       if v is not None and v.sk0 != 1 and self.kmajor_inplace_penalty > 0.0:
-        if self.kmajor_inplace_penalty * (2.0 * m * n * k / self.model_gemm_flops) > \
+        penalty = self.kmajor_inplace_penalty
+        # (measured on consecutive k rows one row pitch apart; config-2 L1 at D = 128 -- k rows 4 MiB apart, 256 bytes of
+        #  each -- ran 1384 TFLOP/s in place against ~1435 through the pass: such views keep the round-5 rule)
+        if kt_partner and v.k0 % 64 == 0 and self.kmajor_tile_walk and v.sk0 <= self.kmajor_tile_walk_max_pitch:
+          penalty = min(penalty, max(0.0, self.kmajor_tile_walk_penalty_per_gb * (t.nbytes / 1e9 - 0.6)))
+        if penalty * (2.0 * m * n * k / self.model_gemm_flops) > \
             2.0 * t.nbytes / self.model_k1_bytes_per_s + self.model_launch_s:
           return None
       if v is not None and t.nbytes > self.inplace_max_bytes:
@@ -960,7 +1082,9 @@ class HipBackend(BackendBase):
     best = None
     for order in orders:
       ka, kb = [axes_a[i] for i in order], [axes_b[i] for i in order]
-      va, vb = usable(a, free_a, ka, hint_a), usable(b, free_b, kb, hint_b)
+      va = usable(a, free_a, ka, hint_a)
+      # (`a` permuted = one K-contiguous run; `a` in place: K-contiguous with runs that are multiples of 64)
+      vb = usable(b, free_b, kb, hint_b, kt_partner=(va is None and k % 64 == 0) or (va is not None and va.sk0 == 1 and va.k0 % 64 == 0))
       cost = (a.nbytes if va is None else 0) + (b.nbytes if vb is None else 0)
       if best is None or cost < best[0]:
         best = (cost, ka, kb, va, vb)
@@ -1521,6 +1645,10 @@ class HipBackend(BackendBase):
   model_gemm_flops = 1.45e15       # flop/s of the bf16 ping-pong GEMM on random data under the 1400 W cap
   model_k1_bytes_per_s = 5.0e12    # read + write rate of a K1 pass
   model_launch_s = 6.0e-6          # one more dependent launch
+  plan_cache = True              # tensordot: replay the lowering of a (shapes, axes, dtype, hints) seen before (False: plan every call)
+  kmajor_tile_walk = True        # tensordot: the size-dependent cost rule for a k-major `b` the whole-K-tile lean loop reads
+  kmajor_tile_walk_max_pitch = 1 << 16       # (elements between consecutive k rows of such a `b`)
+  kmajor_tile_walk_penalty_per_gb = 0.03     # (fraction of the product per GB of the operand beyond 0.6 GB)
   kmajor_inplace_penalty = 0.10  # tensordot: what reading a k-major operand in place costs the product (0: always in place
                                  # below inplace_max_bytes, the rule of rounds 2-4)
   inplace_strided_max_bytes = 4 << 30

@@ -21,9 +21,18 @@ import math
 import numpy as np
 
 
+_rb = None
+
+
 def _resolve_backend(backend):
-  from tensornetwork_amd.ncon import _resolve_backend as _rb  # pylint: disable=import-outside-toplevel
+  global _rb  # pylint: disable=global-statement
+  if _rb is None:
+    from tensornetwork_amd.ncon import _resolve_backend as _rb_  # pylint: disable=import-outside-toplevel
+    _rb = _rb_
   return _rb(backend)
+
+
+_AXIS_NAMES = tuple(str(i) for i in range(64))      # default axis names "0", "1", ...
 
 
 class NodeCollection:
@@ -151,9 +160,36 @@ class Node:
     if axis_names is not None and len(axis_names) != rank:
       raise ValueError("axis_names is not the same length as the tensor shape."
                        f"axis_names length: {len(axis_names)}, shape length: {rank}")
-    self.axis_names = list(axis_names) if axis_names is not None else [str(i) for i in range(rank)]
-    self.edges: List[Edge] = [Edge(self, i, name=self.axis_names[i]) for i in range(rank)]
-    NodeCollection._register(self)  # pylint: disable=protected-access
+    if axis_names is not None:
+      self.axis_names = list(axis_names)
+    else:
+      self.axis_names = list(_AXIS_NAMES[:rank]) if rank <= 64 else [str(i) for i in range(rank)]
+    self.edges: List[Edge] = [Edge(self, i, n) for i, n in enumerate(self.axis_names)]
+    if NodeCollection._stack:  # pylint: disable=protected-access
+      NodeCollection._register(self)  # pylint: disable=protected-access
+
+  @classmethod
+  def _from_contraction(cls, tensor, name, backend, sources):
+    """The node of a contraction result: `tensor` (already the backend's tensor type) with the live edges that sat on
+    the listed (node, axis) slots, in that order -- what ``Node(tensor)`` followed by ``_adopt_edges`` builds, without
+    the rank fresh dangling edges that construction makes and drops (a D = 32 contract_between is host-bound)."""
+    if name is not None and not isinstance(name, str):
+      raise TypeError("Node name should be str type")
+    self = cls.__new__(cls)
+    self.backend = backend
+    self.tensor = tensor
+    self.name = name if name is not None else "__unnamed_node__"
+    edges, names = [], []
+    for new_axis, (old_node, old_axis) in enumerate(sources):
+      e = old_node.edges[old_axis]
+      e._retarget(old_node, old_axis, self, new_axis)  # pylint: disable=protected-access
+      edges.append(e)
+      names.append(old_node.axis_names[old_axis])
+    self.edges = edges
+    self.axis_names = names
+    if NodeCollection._stack:  # pylint: disable=protected-access
+      NodeCollection._register(self)  # pylint: disable=protected-access
+    return self
 
   @property
   def shape(self) -> Tuple[int, ...]:
@@ -436,8 +472,12 @@ def connect(edge1: Edge, edge2: Edge, name: Optional[str] = None) -> Edge:
 def get_shared_edges(node1: Node, node2: Node) -> Set[Edge]:
   """Edges whose two ends are exactly {node1, node2} (network_components.py:1278-1299); for
   node1 is node2 these are the node's trace edges."""
-  want = {id(node1), id(node2)}
-  return {e for e in node1.edges if not e.is_dangling() and {id(e.node1), id(e.node2)} == want}
+  out = set()
+  for e in node1.edges:
+    x, y = e.node1, e.node2
+    if y is not None and ((x is node1 and y is node2) or (x is node2 and y is node1)):
+      out.add(e)
+  return out
 
 
 def get_all_edges(nodes: Iterable[Node]) -> Set[Edge]:
@@ -606,16 +646,18 @@ def contract_between(node1: Node, node2: Node, name: Optional[str] = None,
       # (the axis order of the result is bookkeeping here: the backend may put node2's axes first)
       t, used1, used2, swapped = be.tensordot_planned(node1.tensor, node2.tensor, [axes1, axes2], order1, order2,
                                                       allow_swap=True)
-      out = Node(t, name=name, backend=be)
       sources = [(node1, i) for i in used1] + [(node2, i) for i in used2]
       if swapped:
         sources = sources[len(used1):] + sources[:len(used1)]
     else:
       t = be.tensordot(node1.tensor, node2.tensor, [axes1, axes2])
-      out = Node(t, name=name, backend=be)
       sources = [(node1, i) for i in range(len(node1.edges)) if i not in axes1] + \
                 [(node2, i) for i in range(len(node2.edges)) if i not in axes2]
-    _adopt_edges(out, sources)
+    if len(sources) == len(be.shape_tuple(t)):
+      out = Node._from_contraction(t, name, be, sources)  # pylint: disable=protected-access
+    else:     # (a backend that returns something else than its tensor type: the general constructor decides)
+      out = Node(t, name=name, backend=be)
+      _adopt_edges(out, sources)
   if output_edge_order is not None:
     output_edge_order = list(output_edge_order)
     if set(output_edge_order) != set(out.edges):

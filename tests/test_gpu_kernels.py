@@ -1591,28 +1591,42 @@ def test_gemm_lean_main_loop_is_bit_identical(hip, dtype, m, n, k):
 
 
 def test_k_major_operands_take_the_faster_lowering(hip):
-  """Round 5 (profiles/r05_kmajor_gate_small.jsonl): with the lean NT loop, reading a k-major operand in place costs
-  a product ~10 %; the backend takes ONE K1 pass instead wherever that pass is cheaper (D = 96 and up of config-2 L0),
-  and keeps the in-place read for small products (D = 64).  Same values either way (bit-identical kernels)."""
+  """Round 5 (profiles/r05_kmajor_gate_small.jsonl): reading a k-major operand in place through the half-K-tile loop
+  costs a product ~10 %; the backend takes ONE K1 pass instead wherever that pass is cheaper.  Round 6
+  (profiles/r06_kmajor_lean_loop.md): a k-major `b` whose contraction runs are multiples of 64 is read by the
+  interleaved whole-K-tile loop, which costs nothing below ~0.6 GB: config-2 L0 at D = 64 AND D = 96 stay in place
+  (`kmajor_tile_walk = False` brings the round-5 choice back: the pass at D = 96); a k-major `b` with runs of 96 still
+  takes the pass.  Same values either way (bit-identical kernels)."""
   hip.kmajor_inplace_penalty = type(hip).kmajor_inplace_penalty      # the default policy (the autouse fixture zeroed it)
   rng = np.random.default_rng(5)
-  for D, want_permutes, want_kernel in ((64, 0, "bf16_view_nn"), (96, 1, "bf16_view_nt")):
-    a = orc.round_bf16(rng.standard_normal((D,) * 4) / D)
-    b = orc.round_bf16(rng.standard_normal((D,) * 4) / D)
+  cases = [((64,) * 4, (64,) * 4, [[2, 3], [0, 1]], True, 0, "bf16_view_nn"),
+           ((96,) * 4, (96,) * 4, [[2, 3], [0, 1]], True, 0, "bf16_view_nn"),
+           ((96,) * 4, (96,) * 4, [[2, 3], [0, 1]], False, 1, "bf16_view_nt"),
+           # b k-major with contraction runs of 96 (three half K-tiles): the half-K-tile loop's 10 % against a 28 us pass
+           ((9216, 32, 96), (32, 36, 96, 256), [[1, 2], [0, 2]], True, 1, "bf16_view_nt")]
+  for sa, sb, axes, tile_walk, want_permutes, want_kernel in cases:
+    scale = 1.0 / np.sqrt(np.prod([sa[i] for i in axes[0]]))
+    a = orc.round_bf16(rng.standard_normal(sa, dtype=np.float32) * scale)
+    b = orc.round_bf16(rng.standard_normal(sb, dtype=np.float32))
     da, db = hip.to_bfloat16(a), hip.to_bfloat16(b)
-    before = hip.permute_launches
-    got = np.asarray(hip.tensordot(da, db, [[2, 3], [0, 1]]))
-    kernel = hip.lib.tnh_gemm_last_kernel().decode()
-    assert hip.permute_launches - before == want_permutes and kernel.startswith(want_kernel), (D, kernel)
+    hip.kmajor_tile_walk = tile_walk
+    try:
+      before = hip.permute_launches
+      got_dev = hip.tensordot(da, db, axes)
+      kernel = hip.lib.tnh_gemm_last_kernel().decode()
+      assert hip.permute_launches - before == want_permutes and kernel.startswith(want_kernel), (sa, sb, tile_walk, kernel)
+    finally:
+      hip.kmajor_tile_walk = True
+    got = np.asarray(got_dev)
     hip.kmajor_inplace_penalty = 0.0
     try:
-      other = np.asarray(hip.tensordot(da, db, [[2, 3], [0, 1]]))
+      other = np.asarray(hip.tensordot(da, db, axes))
       assert hip.lib.tnh_gemm_last_kernel().decode().startswith("bf16_view_nn")
     finally:
       hip.kmajor_inplace_penalty = type(hip).kmajor_inplace_penalty
     np.testing.assert_array_equal(got.reshape(-1)[::97], other.reshape(-1)[::97])
-    if D == 64:
-      ref = np.tensordot(a.astype(np.float64), b.astype(np.float64), [[2, 3], [0, 1]])
+    if sa[0] == 64:
+      ref = np.tensordot(a.astype(np.float64), b.astype(np.float64), axes)
       np.testing.assert_allclose(got, ref, rtol=2.0**-8, atol=2e-3)
 
 

@@ -1025,20 +1025,90 @@ def test_complex_band_svd_cluster_branch_gives_the_same_decomposition(dtype):
 
 def test_k_major_cost_rule_on_the_emulated_backend():
   """`HipBackend.kmajor_inplace_penalty` (round 5): a k-major operand is read in place only where ONE K1 pass would cost
-  more than a tenth of the product -- config-2 L0 at D = 64 stays in place (view_nn, no permute), D = 96 takes the
-  pass and the plain NT view; with the rule off both are read in place.  Launch bookkeeping on the emulated C ABI."""
+  more than a tenth of the product.  Round 6: a k-major `b` with contraction runs that are multiples of 64 (config-2
+  L0) is read by the whole-K-tile lean loop, whose cost depends on the operand's size only (nothing below 0.6 GB):
+  D = 64 and D = 96 stay in place (view_nn, no permute); with `kmajor_tile_walk` off (the round-5 rule) D = 96 takes
+  the pass; with the rule off both are read in place.  Launch bookkeeping on the emulated C ABI."""
   rng = np.random.default_rng(2)
   with emulated_backend() as be:
     # launch bookkeeping only: the emulated GEMMs (4096^3 and twice 9216^3 in NumPy: a minute) are not run
     for name in ("tnh_gemm_view", "tnh_gemm"):
       setattr(be.lib, name, lambda *args, **kwargs: _lib.OK)
     made = {}
-    for D, rule, want in ((64, 0.10, 0), (96, 0.10, 1), (96, 0.0, 0)):
+    for D, rule, tile_walk, want in ((64, 0.10, True, 0), (96, 0.10, True, 0), (96, 0.10, False, 1), (96, 0.0, False, 0)):
       if D not in made:       # (values do not matter here: one array serves as both operands)
         made[D] = be.to_bfloat16(rng.standard_normal((D,) * 4, dtype=np.float32) / D)
       a = b = made[D]
       be.kmajor_inplace_penalty = rule
+      be.kmajor_tile_walk = tile_walk
       before = be.permute_launches
       out = be.tensordot(a, b, [[2, 3], [0, 1]])
-      assert be.permute_launches - before == want, (D, rule)
+      assert be.permute_launches - before == want, (D, rule, tile_walk)
       assert out.shape == (D, D, D, D)
+    # the size term: a 2 GB k-major b (below inplace_max_bytes) costs the product 0.03 x 1.4 = 4 %, which the rule
+    # prices against its pass (host arithmetic only: `usable` is not reachable from outside, so through the numbers)
+    be.kmajor_tile_walk = True
+    gb = 2.0
+    penalty = min(be.kmajor_inplace_penalty or 0.10, max(0.0, be.kmajor_tile_walk_penalty_per_gb * (gb - 0.6)))
+    assert abs(penalty - 0.042) < 1e-9
+
+
+def test_tensordot_plan_cache_replays_the_same_lowering():
+  """Round 6: the permute + ONE GEMM lowering of a (shapes, axes, dtype, hints) is planned once and replayed
+  (`HipBackend._plan_generic` / `_run_plan`): same values, same K1 launch count and same free-axis order with the
+  cache on (first call plans, second call replays) and off; integer operands, an integer `axes` and calls under
+  `gemm_events` (bench.py's event pairs) are not cached."""
+  rng = np.random.default_rng(8)
+  cases = [
+      ((3, 4, 5), (5, 4, 6), ([2, 1], [0, 1]), None, None),            # b's contracted axes leading, pairs crossed
+      ((4, 3, 5), (3, 6), ([1], [0]), None, None),                       # a's contracted axis in the middle: one permute
+      ((6, 4), (6, 5), ([0], [0]), None, None),                          # a stored [K][M]
+      ((2, 3, 4, 5), (5, 2, 7), ([3, 0], [0, 1]), [2, 1], [2]),          # planned: free order of the permuted a hinted
+      ((5, 6), (7, 6), ([-1], [1]), None, None),                         # negative axis
+  ]
+  with emulated_backend() as be:
+    for dtype in (np.float32, np.complex64, "bf16"):
+      for sa, sb, axes, ha, hb in cases:
+        x = rng.standard_normal(sa).astype(np.float32)
+        y = rng.standard_normal(sb).astype(np.float32)
+        if dtype == "bf16":
+          x, y = orc.round_bf16(x), orc.round_bf16(y)
+          dx, dy = be.to_bfloat16(x), be.to_bfloat16(y)
+        else:
+          x, y = x.astype(dtype), y.astype(dtype)
+          dx, dy = be.convert_to_tensor(x), be.convert_to_tensor(y)
+        outs = []
+        for cache in (False, True, True):
+          be.plan_cache = cache
+          plans = len(be._td_plans)            # pylint: disable=protected-access
+          before = be.permute_launches
+          t, ua, ub = be.tensordot_planned(dx, dy, axes, ha, hb)
+          outs.append((np.asarray(t), list(ua), list(ub), be.permute_launches - before, len(be._td_plans) - plans))  # pylint: disable=protected-access
+        (r0, ua0, ub0, p0, n0), (r1, ua1, ub1, p1, n1), (r2, ua2, ub2, p2, n2) = outs
+        assert (n0, n1, n2) == (0, 1, 0), (sa, sb, axes, n0, n1, n2)          # planned once, replayed once
+        assert (ua0, ub0, p0) == (ua1, ub1, p1) == (ua2, ub2, p2)
+        np.testing.assert_array_equal(r0, r1)
+        np.testing.assert_array_equal(r0, r2)
+        fa = [i for i in range(len(sa)) if i not in [a % len(sa) for a in axes[0]]]
+        ref = np.tensordot(x.astype(np.complex128 if dtype is np.complex64 else np.float64),
+                           y.astype(np.complex128 if dtype is np.complex64 else np.float64), axes)
+        # free axes of a in the order the call reports, then b's
+        perm = [fa.index(i) for i in ua0] + [len(fa) + sorted(ub0).index(i) for i in ub0]
+        np.testing.assert_allclose(r0, np.transpose(ref, perm), rtol=2e-2 if dtype == "bf16" else 1e-5, atol=1e-2 if dtype == "bf16" else 1e-5)
+    be.plan_cache = True
+    plans = len(be._td_plans)                  # pylint: disable=protected-access
+    xi = be.convert_to_tensor(rng.integers(-5, 5, (3, 4)))
+    yi = be.convert_to_tensor(rng.integers(-5, 5, (4, 2)))
+    np.testing.assert_array_equal(np.asarray(be.tensordot(xi, yi, [[1], [0]])), np.asarray(xi) @ np.asarray(yi))
+    xf = be.convert_to_tensor(rng.standard_normal((3, 4)).astype(np.float32))
+    yf = be.convert_to_tensor(rng.standard_normal((4, 2)).astype(np.float32))
+    be.tensordot(xf, yf, 1)                    # integer axes: the general walk
+    be.gemm_events = []
+    try:
+      be.tensordot(xf, yf, [[1], [0]])
+      assert len(be.gemm_events) == 1
+    finally:
+      be.gemm_events = None
+    assert len(be._td_plans) == plans          # pylint: disable=protected-access
+    be.tensordot(xf, yf, [[1], [0]])
+    assert len(be._td_plans) == plans + 1      # pylint: disable=protected-access

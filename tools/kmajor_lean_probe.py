@@ -55,10 +55,12 @@ for row in a.rows.split(","):
   flop = 2.0 * m * n * k
   rec = {"row": row, "gemm": [m, n, k], "fill": a.fill}
   keep = (be.kmajor_inplace_penalty, be.inplace_max_bytes)
+  keep_tw = be.kmajor_tile_walk
   results = {}
   for form in ("pass", "kt", "w0", "kt", "pass"):
     if form == "pass":
       be.kmajor_inplace_penalty, be.inplace_max_bytes = 1e9, keep[1]      # never in place
+      be.kmajor_tile_walk = False
       knob = b"auto"
     else:
       be.kmajor_inplace_penalty, be.inplace_max_bytes = 0.0, 1 << 40      # always in place
@@ -69,6 +71,7 @@ for row in a.rows.split(","):
     finally:
       _lib.check(be.lib.tnh_gemm_set_variant(b"auto"))
       be.kmajor_inplace_penalty, be.inplace_max_bytes = keep
+      be.kmajor_tile_walk = keep_tw
     rec.setdefault(form, []).append({"ms": round(ms, 4), "tflops": round(flop / ms / 1e9, 1), "permutes": perms, "kernel": kernel})
     if form not in results:
       # a sample of the result: rows 0, 1 and the last one (whole rows, every column tile)

@@ -16,6 +16,10 @@ ap.add_argument("--pads", default="0,64,128,1024")
 ap.add_argument("--rasters", default="-1")
 ap.add_argument("--iters", type=int, default=4)
 ap.add_argument("--fill", default="normal")
+ap.add_argument("--wrap-b", type=int, default=0, help="k-major B: the contraction index wraps around after this many rows "
+                "(the loop keeps its length, B's footprint shrinks)")
+ap.add_argument("--freeze", default="", help="a / b / ab: that operand re-reads its first K-tile for the whole contraction "
+                "(contraction runs of 64 with stride 0 between them): its requests always hit, the L2 misses left are the other operand's")
 a = ap.parse_args()
 be = ta.get_hip_backend()
 M, N, K = a.m, a.n, a.k
@@ -30,7 +34,7 @@ def fill(shape, seed, sigma):
 
 A = fill((M, K), 1, K ** -0.5)
 C = DeviceTensor.empty((M, N), _lib.BF16)
-va = _lib.OperandView(M, K, 0, K, 1, 0)
+va = _lib.OperandView(M, K, 0, 64, 1, 0) if "a" in a.freeze else _lib.OperandView(M, K, 0, K, 1, 0)
 
 
 def run(Bt, vb, knob):
@@ -55,19 +59,21 @@ rasters = [int(r) for r in a.rasters.split(",")]
 Bn = fill((N, K), 2, 1.0)
 for r in rasters:
   knob = "auto" if r < 0 else f"auto:r{r}"
-  ms, kern = run(Bn, _lib.OperandView(N, K, 0, K, 1, 0), knob)
-  print(json.dumps({"form": "nt", "gemm": [M, N, K], "raster": r, "fill": a.fill, "ms": round(ms, 4),
+  ms, kern = run(Bn, _lib.OperandView(N, K, 0, 64, 1, 0) if "b" in a.freeze else _lib.OperandView(N, K, 0, K, 1, 0), knob)
+  print(json.dumps({"form": "nt", "freeze": a.freeze, "gemm": [M, N, K], "raster": r, "fill": a.fill, "ms": round(ms, 4),
                     "tflops": round(flop / ms / 1e9, 1), "kernel": kern}), flush=True)
 Bn = None
 for pad in [int(p) for p in a.pads.split(",")]:
   pitch = N + pad
   Bk = fill((K, pitch), 3, 1.0)
-  vb = _lib.OperandView(N, 1, 0, K, pitch, 0)
+  vb = _lib.OperandView(N, 1, 0, 64, pitch, 0) if "b" in a.freeze else _lib.OperandView(N, 1, 0, K, pitch, 0)
+  if a.wrap_b:
+    vb = _lib.OperandView(N, 1, 0, a.wrap_b, pitch, 0)
   for r in rasters:
     for knob0 in ("auto", "auto:w0"):
       knob = knob0 if r < 0 else f"{knob0}:r{r}"
       ms, kern = run(Bk, vb, knob)
-      print(json.dumps({"form": "kn", "loop": "kt" if knob0 == "auto" else "w0", "gemm": [M, N, K], "pitch": pitch,
+      print(json.dumps({"form": "kn", "freeze": a.freeze, "wrap_b": a.wrap_b, "loop": {"auto": "kt", "auto:w0": "w0"}.get(knob0, knob0), "gemm": [M, N, K], "pitch": pitch,
                         "raster": r, "fill": a.fill, "ms": round(ms, 4), "tflops": round(flop / ms / 1e9, 1), "kernel": kern}),
             flush=True)
   Bk = None

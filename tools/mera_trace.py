@@ -27,6 +27,7 @@ class FakeTensor(device_tensor.DeviceTensor):
 
 device_tensor.DeviceTensor.empty = FakeTensor.empty
 hip_backend.DeviceTensor.empty = FakeTensor.empty
+device_tensor.DeviceTensor._fresh = classmethod(lambda cls, shape, code, nbytes, alias=None: FakeTensor(shape, code))
 
 
 class FakeLib:
