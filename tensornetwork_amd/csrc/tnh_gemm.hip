@@ -877,10 +877,13 @@ static thread_local const char* g_last_kernel = "none";
 // MPS overlap (<psi|psi> = a 1 x 1 x 65536 "GEMM") ran 75 us through the split-K machinery (64 slices of a 128 x 128
 // tile each).  ONE workgroup of 1024 threads: thread t takes k = t, t + 1024, ... for all M x N outputs (coalesced
 // along k when the operands are k-contiguous or M = N = 1), fixed-order tree reduction: deterministic.
-template <typename T>
-__global__ __launch_bounds__(1024) void gemm_tiny_kernel(const T* __restrict__ A, int64_t sam, int64_t sak,
-                                                         const T* __restrict__ B, int64_t sbk, int64_t sbn,
-                                                         T* __restrict__ C, int64_t ldc, int M, int N, int64_t K) {
+// (bf16 / f16 too -- the closing 1 x 1 x 1728 product of every slice of the D = 12 network took 49 us through the ragged
+//  128 x 128 tile kernel, 8 % of that network's time: operands converted on load, f32 sums, one rounding at the end.)
+template <int DT, int ODT>
+__global__ __launch_bounds__(1024) void gemm_tiny_kernel(const typename Tr<DT>::S* __restrict__ A, int64_t sam, int64_t sak,
+                                                         const typename Tr<DT>::S* __restrict__ B, int64_t sbk, int64_t sbn,
+                                                         typename Tr<ODT>::S* __restrict__ C, int64_t ldc, int M, int N, int64_t K) {
+  using T = typename Tr<DT>::C;
   __shared__ T red[16][16];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   T acc[16];
@@ -897,8 +900,8 @@ __global__ __launch_bounds__(1024) void gemm_tiny_kernel(const T* __restrict__ A
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
         const int64_t k = k0 + (int64_t)u * 1024;
-        av[u] = k < K ? A[k * sak] : T(0);
-        bv[u] = k < K ? B[k * sbk] : T(0);
+        av[u] = k < K ? Tr<DT>::ld(A, k * sak) : T(0);
+        bv[u] = k < K ? Tr<DT>::ld(B, k * sbk) : T(0);
       }
 #pragma unroll
       for (int u = 0; u < 8; ++u) part[u] += av[u] * bv[u];
@@ -911,9 +914,9 @@ __global__ __launch_bounds__(1024) void gemm_tiny_kernel(const T* __restrict__ A
       for (int u = 0; u < 2; ++u) {
         const int64_t k = k0 + (int64_t)u * 1024;
 #pragma unroll
-        for (int m = 0; m < 4; ++m) av[u][m] = (m < M && k < K) ? A[m * sam + k * sak] : T(0);
+        for (int m = 0; m < 4; ++m) av[u][m] = (m < M && k < K) ? Tr<DT>::ld(A, m * sam + k * sak) : T(0);
 #pragma unroll
-        for (int n = 0; n < 4; ++n) bv[u][n] = (n < N && k < K) ? B[k * sbk + n * sbn] : T(0);
+        for (int n = 0; n < 4; ++n) bv[u][n] = (n < N && k < K) ? Tr<DT>::ld(B, k * sbk + n * sbn) : T(0);
       }
 #pragma unroll
       for (int u = 0; u < 2; ++u)
@@ -934,7 +937,7 @@ __global__ __launch_bounds__(1024) void gemm_tiny_kernel(const T* __restrict__ A
 #pragma unroll
     for (int ww = 0; ww < 16; ++ww) sum += red[ww][tid];
     const int m = tid >> 2, n = tid & 3;
-    if (m < M && n < N) C[(int64_t)m * ldc + n] = sum;
+    if (m < M && n < N) Tr<ODT>::st(C, (int64_t)m * ldc + n, sum);
   }
 }
 
@@ -1215,14 +1218,18 @@ int tnh_gemm_ex(int in_dtype, int out_dtype, int transA, int transB, int64_t M, 
 
   // ---- tiny outputs: one workgroup (gemm_tiny_kernel)
   if (plain && batch == 1 && M <= 4 && N <= 4 && K >= 1024 && K <= (int64_t(1) << 20) && g_variant == 0 &&
-      out_dtype == in_dtype && (in_dtype == TNH_F32 || in_dtype == TNH_F64)) {
+      (in_dtype == TNH_F32 || in_dtype == TNH_F64 || half_in)) {
     const int64_t sam = transA ? 1 : lda, sak = transA ? lda : 1, sbk = transB ? 1 : ldb, sbn = transB ? ldb : 1;
-    if (in_dtype == TNH_F32)
-      hipLaunchKernelGGL((gemm_tiny_kernel<float>), dim3(1), dim3(1024), 0, stream(), (const float*)A, sam, sak,
-                         (const float*)B, sbk, sbn, (float*)C, ldc, (int)M, (int)N, K);
-    else
-      hipLaunchKernelGGL((gemm_tiny_kernel<double>), dim3(1), dim3(1024), 0, stream(), (const double*)A, sam, sak,
-                         (const double*)B, sbk, sbn, (double*)C, ldc, (int)M, (int)N, K);
+#define TNH_TINY(DT, ODT)                                                                                              \
+  hipLaunchKernelGGL((gemm_tiny_kernel<DT, ODT>), dim3(1), dim3(1024), 0, stream(), (const Tr<DT>::S*)A, sam, sak,     \
+                     (const Tr<DT>::S*)B, sbk, sbn, (Tr<ODT>::S*)C, ldc, (int)M, (int)N, K)
+    if (in_dtype == TNH_F32) TNH_TINY(TNH_F32, TNH_F32);
+    else if (in_dtype == TNH_F64) TNH_TINY(TNH_F64, TNH_F64);
+    else if (in_dtype == TNH_BF16 && out_dtype == TNH_F32) TNH_TINY(TNH_BF16, TNH_F32);
+    else if (in_dtype == TNH_BF16) TNH_TINY(TNH_BF16, TNH_BF16);
+    else if (out_dtype == TNH_F32) TNH_TINY(TNH_F16, TNH_F32);
+    else TNH_TINY(TNH_F16, TNH_F16);
+#undef TNH_TINY
     TNH_LAUNCH_CHECK();
     g_last_kernel = "tiny_1wg";
     return TNH_OK;

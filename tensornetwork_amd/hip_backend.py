@@ -1032,6 +1032,9 @@ class HipBackend(BackendBase):
 
     out_bytes = m * n * a.itemsize
 
+    def rows_of(t, free):
+      return _prod(t.shape[i] for i in free)
+
     def usable(t, free, kax, hint, kt_partner=False):
       v = _operand_view(t.shape, free, kax, t.strides if t.pad is not None else None)
       # The planner asked for another order of this operand's free axes (it lays the RESULT out for the contractions
@@ -1068,6 +1071,15 @@ class HipBackend(BackendBase):
         if penalty * (2.0 * m * n * k / self.model_gemm_flops) > \
             2.0 * t.nbytes / self.model_k1_bytes_per_s + self.model_launch_s:
           return None
+      # Round 6 (profiles/r06_k_blocked_operands.md): a K-contiguous operand whose rows lie a multiple of 1 MiB apart
+      # (K = 2^19 and up in bf16) runs the kernel at 1294 TFLOP/s (1 MiB) / 766-789 (2 MiB) instead of ~1500 -- the
+      # 256 rows of a tile alias in the memory system, zeros and random data alike.  Where one K1 pass into the
+      # K-blocked form (`_k_blocked` below) costs less than that, the view is given up for it.
+      if v is not None and v.sk0 == 1 and self.k_blocked_permutes and min(v.r0, rows_of(t, free)) >= 64 and \
+          (v.sr0 * t.itemsize) % (1 << 20) == 0:
+        loss = 0.15 if v.sr0 * t.itemsize == (1 << 20) else 0.45
+        if loss * (2.0 * m * n * k / self.model_gemm_flops) > 2.0 * t.nbytes / self.model_k1_bytes_per_s + self.model_launch_s:
+          return None
       if v is not None and t.nbytes > self.inplace_max_bytes:
         plain = v.sk0 == 1 and v.sr1 == 0 and v.sk1 == 0
         # (round 5: a K-contiguous two-level view whose inner contraction run is a multiple of 64 walks K tile by tile in
@@ -1093,13 +1105,11 @@ class HipBackend(BackendBase):
     if va is None:
       if hint_a is not None and sorted(hint_a) == sorted(free_a):
         used_a = [int(i) for i in hint_a]
-      a = self.transpose(a, used_a + ka)
-      va = _lib.OperandView(m, k, 0, k, 1, 0)
+      a, va = self._k_blocked(a, used_a, ka, m, k)
     if vb is None:
       if hint_b is not None and sorted(hint_b) == sorted(free_b):
         used_b = [int(i) for i in hint_b]
-      b = self.transpose(b, used_b + kb)
-      vb = _lib.OperandView(n, k, 0, k, 1, 0)
+      b, vb = self._k_blocked(b, used_b, kb, n, k)
     out_code = _lib.F32 if self.half_output == "float32" else a.code
     ldc = self._result_pitch(m, n, 4 if out_code == _lib.F32 else 2)
     if ldc == n:
@@ -1118,6 +1128,37 @@ class HipBackend(BackendBase):
       events.append((start, _lib.Event().record()))
     self.permutes_absorbed += 1
     return out, used_a, used_b
+
+  def _k_blocked(self, t, free, kax, rows, k):
+    """The K1 pass that brings an operand of the view GEMM to K-contiguous form, and the view of its result.  Normally
+    [free..., contracted...]: rows of k elements.  When such a row would be 1 MiB or longer the result is laid out
+    K-BLOCKED instead -- [outer contracted axes..., free..., inner contracted axes...], i.e. rows `inner` elements
+    apart and contraction runs of `inner` -- which costs the pass nothing and keeps the 256 rows of a tile out of each
+    other's way (the binary-MERA layer at chi = 32, 1024 x 32768 x 2^20: 1088 -> 1493 TFLOP/s; 8192 x 8192 x 2^20:
+    766 -> 1480; x 2^19: 1294 -> 1532; profiles/r06_k_blocked_operands.md).  The inner run is the shortest suffix
+    of the contracted axes that is a multiple of 64 and at least 512 long (a single long contracted axis is split by
+    a reshape first: metadata only)."""
+    if self.k_blocked_permutes and k * t.itemsize >= self.k_blocked_min_row_bytes and rows >= 64:
+      shape = list(t.shape)
+      free, kax = list(free), list(kax)
+      if len(kax) == 1 or _prod(shape[i] for i in kax[1:]) < 512:
+        # split the first contracted axis: [.., K0, ..] -> [.., K0 / q, q, ..] with q * (the later contracted axes) >= 512
+        ax, rest = kax[0], _prod(shape[i] for i in kax[1:])
+        q = 1
+        while q * rest < 512 and shape[ax] % (2 * q) == 0:
+          q *= 2
+        if 1 < q < shape[ax] and (q * rest) % 64 == 0 and t.pad is None:
+          t = t.view(shape[:ax] + [shape[ax] // q, q] + shape[ax + 1:])
+          shape = list(t.shape)
+          bump = lambda i: i + 1 if i > ax else i
+          free = [bump(i) for i in free]
+          kax = [ax, ax + 1] + [bump(i) for i in kax[1:]]
+      inner = 1
+      for s in range(len(kax) - 1, 0, -1):
+        inner *= shape[kax[s]]
+        if inner % 64 == 0 and inner >= 512:
+          return self.transpose(t, kax[:s] + free + kax[s:]), _lib.OperandView(rows, inner, 0, inner, 1, rows * inner)
+    return self.transpose(t, list(free) + list(kax)), _lib.OperandView(rows, k, 0, k, 1, 0)
 
   def _complex_gemm(self, a, b, trans_a, trans_b, m, n, k):
     """complex64 / complex128 product on the f32 / f64 matrix cores: the interleaved (re, im)
@@ -1645,6 +1686,8 @@ class HipBackend(BackendBase):
   model_gemm_flops = 1.45e15       # flop/s of the bf16 ping-pong GEMM on random data under the 1400 W cap
   model_k1_bytes_per_s = 5.0e12    # read + write rate of a K1 pass
   model_launch_s = 6.0e-6          # one more dependent launch
+  k_blocked_permutes = True      # tensordot: K1 passes of view-GEMM operands with rows of 1 MiB and more write the K-blocked form
+  k_blocked_min_row_bytes = 1 << 20
   plan_cache = True              # tensordot: replay the lowering of a (shapes, axes, dtype, hints) seen before (False: plan every call)
   kmajor_tile_walk = True        # tensordot: the size-dependent cost rule for a k-major `b` the whole-K-tile lean loop reads
   kmajor_tile_walk_max_pitch = 1 << 16       # (elements between consecutive k rows of such a `b`)

@@ -1692,6 +1692,49 @@ def test_gemm_tiny_outputs_one_workgroup(hip, dtype):
   assert kernel != "tiny_1wg"
 
 
+@pytest.mark.parametrize("dtype", [ta.bfloat16, np.float16])
+def test_gemm_tiny_outputs_one_workgroup_half(hip, dtype):
+  """The same for bf16 / f16 (the closing 1 x 1 x 1728 product of every slice of the sliced D = 12 network ran 49 us
+  through the ragged 128 x 128 tile kernel): operands converted on load, f32 sums, one rounding of the result."""
+  rng = np.random.default_rng(24)
+  kind = "bf16" if dtype is ta.bfloat16 else "f16"
+  for (m, n, k, ta_, tb_) in [(1, 1, 1728, 0, 1), (1, 1, 65536, 0, 1), (2, 3, 5000, 0, 1), (4, 4, 1024, 0, 1), (1, 4, 1 << 18, 0, 1),
+                              (3, 2, 4096, 1, 0)]:
+    out, ref, kernel, _ = _gemm_case(hip, dtype, m, n, k, ta_, tb_, rng=rng)
+    assert kernel == "tiny_1wg", (kernel, m, n, k)
+    C.assert_half_gemm_close(out, ref, kind, err_msg=f"{m}x{n}x{k} {ta_}{tb_}")
+
+
 def test_index_update_with_a_tensor_assignee(hip):
   """VERDICT r5 missing 6: `t[mask] = assignee` with a tensor assignee, compacted on the device (tnh_masked_scatter)."""
   C.run_index_update_tensor_cases(hip)
+
+
+def test_k1_pass_of_a_long_row_operand_writes_the_k_blocked_form(hip):
+  """Round 6 (profiles/r06_k_blocked_operands.md): an operand the view GEMM cannot read in place, whose rows would be
+  1 MiB long (K = 2^19 in bf16), is permuted into the K-blocked form [outer contracted, free, inner contracted] and
+  read through a two-level contraction view.  Same K order per tile as the row-major form: bit-identical results;
+  sampled rows against float64 dot products."""
+  sa, sb, axes = (8, 1792, 4, 2, 16384), (3600, 8, 4, 16384), ([0, 2, 4], [1, 2, 3])
+  k = 8 * 4 * 16384
+  a = hip.device_random(sa, dtype=ta.bfloat16, seed=3, normal=True, a=0.0, b=k ** -0.5)
+  b = hip.device_random(sb, dtype=ta.bfloat16, seed=4, normal=True, a=0.0, b=1.0)
+  before = hip.permute_launches
+  got = hip.tensordot(a, b, axes)
+  assert hip.permute_launches - before >= 1 and hip.lib.tnh_gemm_last_kernel().decode().startswith("bf16_view_nt")
+  hip.k_blocked_permutes = False
+  try:
+    ref = hip.tensordot(a, b, axes)
+  finally:
+    hip.k_blocked_permutes = True
+  assert got.shape == ref.shape == (1792, 2, 3600)
+  rows = [(0, 0), (5, 1), (1791, 1), (1000, 0)]
+  a_t = hip.transpose(a, (1, 3, 0, 2, 4))             # [1792, 2, K]
+  for r0, r1 in rows:
+    g = np.asarray(hip.getitem(got, (r0, r1)))
+    u = np.asarray(hip.getitem(ref, (r0, r1)))
+    np.testing.assert_array_equal(g, u)
+    arow = np.asarray(hip.getitem(a_t, (r0, r1))).astype(np.float64).reshape(-1)
+    cols = [0, 1, 255, 256, 3599]
+    bcols = np.stack([np.asarray(hip.getitem(b, (c,))).astype(np.float64).reshape(-1) for c in cols])
+    np.testing.assert_allclose(g[cols], bcols @ arow, rtol=2.0**-8, atol=2.0**-9)

@@ -1112,3 +1112,46 @@ def test_tensordot_plan_cache_replays_the_same_lowering():
     assert len(be._td_plans) == plans          # pylint: disable=protected-access
     be.tensordot(xf, yf, [[1], [0]])
     assert len(be._td_plans) == plans + 1      # pylint: disable=protected-access
+
+
+def test_k1_pass_of_a_long_row_operand_writes_the_k_blocked_form():
+  """Round 6 (profiles/r06_k_blocked_operands.md): an operand of the view GEMM that needs a K1 pass anyway, and whose
+  rows would be `k_blocked_min_row_bytes` or longer, is written K-blocked -- [outer contracted axes, free axes, inner
+  contracted axes] with a two-level contraction view -- instead of [free, contracted]: same product, and the rows of a
+  tile no longer lie a power of two apart.  Threshold lowered so that small shapes take the path; values against
+  float64, the views handed to tnh_gemm_view checked; a single long contracted axis is split by a reshape first."""
+  rng = np.random.default_rng(12)
+  with emulated_backend() as be:
+    be.k_blocked_min_row_bytes = 1024
+    seen = []
+    real = be.lib.tnh_gemm_view
+
+    def spy(code, oc, m, n, k, a, va, b, vb, c, ldc):
+      seen.append(tuple((v._obj.r0, v._obj.sr0, v._obj.sr1, v._obj.k0, v._obj.sk0, v._obj.sk1) for v in (va, vb)))
+      return real(code, oc, m, n, k, a, va, b, vb, c, ldc)
+    be.lib.tnh_gemm_view = spy
+    # (1) a: contracted axes (2, 8, 64) in three memory runs (no view) -> blocked with inner run 8 * 64 = 512, outer 2
+    sa, sb, axes = (2, 1792, 8, 2, 64), (3600, 2, 8, 64), ([0, 2, 4], [1, 2, 3])
+    x = orc.round_bf16(rng.standard_normal(sa).astype(np.float32) / 32)
+    y = orc.round_bf16(rng.standard_normal(sb).astype(np.float32))
+    before = be.permute_launches
+    got = np.asarray(be.tensordot(be.to_bfloat16(x), be.to_bfloat16(y), axes))
+    assert be.permute_launches - before == 1            # b is read where it lies, a takes ONE pass
+    va, vb = seen[-1]
+    assert va == (3584, 512, 0, 512, 1, 3584 * 512), va
+    np.testing.assert_allclose(got, np.tensordot(x.astype(np.float64), y.astype(np.float64), axes), rtol=2.0**-7, atol=2e-2)
+    be.k_blocked_permutes = False
+    try:
+      ref = np.asarray(be.tensordot(be.to_bfloat16(x), be.to_bfloat16(y), axes))
+      assert seen[-1][0] == (3584, 1024, 0, 1024, 1, 0)
+    finally:
+      be.k_blocked_permutes = True
+    np.testing.assert_allclose(got, ref, rtol=2.0**-7, atol=1e-3)
+    # (2) one long contracted axis, operand stored [K][M] and too big to be read k-major in place: split 1024 = 2 x 512
+    be.inplace_max_bytes = 1 << 16
+    x = orc.round_bf16(rng.standard_normal((1024, 3584)).astype(np.float32) / 32)
+    y = orc.round_bf16(rng.standard_normal((3600, 1024)).astype(np.float32))
+    got = np.asarray(be.tensordot(be.to_bfloat16(x), be.to_bfloat16(y), [[0], [1]]))
+    va, vb = seen[-1]
+    assert va == (3584, 512, 0, 512, 1, 3584 * 512), va
+    np.testing.assert_allclose(got, x.astype(np.float64).T @ y.astype(np.float64).T, rtol=2.0**-7, atol=2e-2)
