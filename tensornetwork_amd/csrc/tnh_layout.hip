@@ -196,14 +196,18 @@ __global__ __launch_bounds__(256) void permute_tiled_kernel(T* __restrict__ dst,
 // chunks of one row, permuted).  Round 1's padded layout (row pitch 65 dwords, four
 // ds_read_b32 per store) measured 50 % LDS bank-conflict cycles (c and c + 8 on one
 // bank).  Stores are 16 B (8 b-consecutive elements): 256-B runs per output row.
-template <int NA>
+// TBV = 64 (round 6): 64 x 64 tiles for a destination-fastest extent that is a multiple of 64 but not of 128 -- the
+// [..., c, d, e] -> [..., d, .., e, c] passes of the chi = 64 MERA slices ran through the scalar 64 x 64 tiles at 2.5
+// TB/s (8 % of a slice).  Same register transposes and swizzle; the dword tile is 64 x 32, a 16-lane group of the write
+// side reads two rows (conflict-free: consecutive rows start 32 banks apart), 128-byte runs per output row.
+template <int NA, int TBV = 128>
 __global__ __launch_bounds__(256) void permute_tiled16_kernel(uint16_t* __restrict__ dst,
                                                               const uint16_t* __restrict__ src,
                                                               TiledParams p) {
   // NA = 2 (round-3 experiment, not dispatched): two neighbouring a-tiles per workgroup = 256-byte source runs and
   // eight loads per thread in flight.  Measured: no change (4.24 vs 4.22 TB/s) -- what helps is the ORDER of the
   // tiles (p.order below), i.e. the write side.
-  constexpr int TA = 64, TB = 128, LD = 64;
+  constexpr int TA = 64, TB = TBV, LD = TB / 2;
   __shared__ __attribute__((aligned(16))) uint32_t T[NA][TA * LD];
   const int64_t tiles_a = p.tiles_a / NA;          // NA == 2 only with an even tile count
   const int64_t nblocks = p.nblocks / NA;
@@ -239,11 +243,12 @@ __global__ __launch_bounds__(256) void permute_tiled16_kernel(uint16_t* __restri
   const int64_t a0 = ta * (TA * NA), b0 = tb * TB;
   {
     const int q = tid & 7;  // a chunk: a = 8 q .. 8 q + 7
-    uint4 xv[NA][2], yv[NA][2];
+    constexpr int NH = TB / 64;     // b pairs per thread
+    uint4 xv[NA][NH], yv[NA][NH];
 #pragma unroll
     for (int t = 0; t < NA; ++t)
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
+      for (int h = 0; h < NH; ++h) {
         const int j = (tid >> 3) + 32 * h;  // b pair: rows 2 j, 2 j + 1
         const uint16_t* s0 = src + in_base + (b0 + 2 * j) * p.b_in_stride + a0 + t * TA + 8 * q;
         xv[t][h] = *(const uint4*)s0;
@@ -252,7 +257,7 @@ __global__ __launch_bounds__(256) void permute_tiled16_kernel(uint16_t* __restri
 #pragma unroll
     for (int t = 0; t < NA; ++t)
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
+      for (int h = 0; h < NH; ++h) {
         const int j = (tid >> 3) + 32 * h;
         const uint4 x = xv[t][h], y = yv[t][h];
         const uint32_t xs[4] = {x.x, x.y, x.z, x.w}, ys[4] = {y.x, y.y, y.z, y.w};
@@ -269,12 +274,13 @@ __global__ __launch_bounds__(256) void permute_tiled16_kernel(uint16_t* __restri
   }
   __syncthreads();
   {
-    const int c = tid & 15;  // 16-byte chunk along b: dwords 4 c .. 4 c + 3
+    constexpr int CH = TB / 8;             // 16-byte chunks per output row of the tile
+    const int c = tid & (CH - 1);  // 16-byte chunk along b: dwords 4 c .. 4 c + 3
 #pragma unroll
     for (int t = 0; t < NA; ++t)
 #pragma unroll
-      for (int h = 0; h < 4; ++h) {
-        const int a = (tid >> 4) + 16 * h;
+      for (int h = 0; h < TA * CH / 256; ++h) {
+        const int a = tid / CH + (256 / CH) * h;
         const uint4 o = *(const uint4*)&T[t][a * LD + ((c ^ ((a >> 3) & 7)) << 2)];
         *(uint4*)(dst + out_base + (a0 + t * TA + a) * p.a_out_stride + b0 + 8 * c) = o;
       }
@@ -921,12 +927,13 @@ int tnh_permute(void* dst, const void* src, int rank, const int64_t* shape, cons
     p.a_out_stride = ostride[ia];
     p.b_in_stride = istride[ib];
     // 2-byte fast path: full 64 x 128 tiles, every row start 16-byte aligned on both sides
-    if (itemsize == 2 && p.Na % 64 == 0 && p.Nb % 128 == 0 && p.b_in_stride % 8 == 0 &&
+    if (itemsize == 2 && p.Na % 64 == 0 && p.Nb % 64 == 0 && p.b_in_stride % 8 == 0 &&
         p.a_out_stride % 8 == 0 && ((uintptr_t)dst % 16) == 0 && ((uintptr_t)src % 16) == 0) {
       bool ok = true;
       TiledParams f = p;
+      const bool tb64 = p.Nb % 128 != 0;      // 64 x 64 tiles (round 6)
       f.tiles_a = p.Na / 64;
-      f.tiles_b = p.Nb / 128;
+      f.tiles_b = p.Nb / (tb64 ? 64 : 128);
       f.nbatch = 0;
       int64_t nblocks = f.tiles_a * f.tiles_b;
       for (int d = 0; d < r; ++d) {
@@ -955,8 +962,12 @@ int tnh_permute(void* dst, const void* src, int rank, const int64_t* shape, cons
           const int64_t cap = (int64_t)num_cus() * atoi(eg);
           if (cap > 0 && grid > cap) grid = cap;
         }
-        hipLaunchKernelGGL(permute_tiled16_kernel<1>, dim3((unsigned)grid), dim3(256), 0, stream(),
-                           (uint16_t*)dst, (const uint16_t*)src, f);
+        if (tb64)
+          hipLaunchKernelGGL((permute_tiled16_kernel<1, 64>), dim3((unsigned)grid), dim3(256), 0, stream(),
+                             (uint16_t*)dst, (const uint16_t*)src, f);
+        else
+          hipLaunchKernelGGL((permute_tiled16_kernel<1, 128>), dim3((unsigned)grid), dim3(256), 0, stream(),
+                             (uint16_t*)dst, (const uint16_t*)src, f);
         TNH_LAUNCH_CHECK();
         return TNH_OK;
       }

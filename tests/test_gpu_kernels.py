@@ -47,6 +47,9 @@ def test_permute_all_perms_rank4(hip, dtype):
     # full 64 x 128 tiles with 16-byte aligned rows: the 2-byte vector kernel (permute_tiled16)
     ((128, 256), (1, 0)), ((64, 128), (1, 0)), ((256, 4, 128), (2, 1, 0)), ((3, 64, 2, 128), (0, 3, 2, 1)),
     ((128, 3, 64), (2, 1, 0)),  # odd batch stride -> falls back to the scalar tiled kernel
+    # round 6: destination-fastest extent 64 next to the source-fastest one (the chi = 64 MERA slices' pass): 64 x 64 tiles
+    # of the 2-byte vector kernel (permute_tiled16_kernel<1, 64>)
+    ((2, 3, 64, 5, 64), (0, 3, 1, 4, 2)), ((64, 64), (1, 0)), ((64, 8, 128), (1, 2, 0)), ((3, 64, 2, 192), (0, 2, 3, 1)),
     # 2-byte tensors whose (a, b) extents are >= 64 but not multiples of 64 / 128 (round 5: brick kernel instead of the
     # scalar 64 x 64 tiles -- the [K][N] -> [N][K] pass of a (96,)^4 tensor 1.48 -> 4.06 TB/s)
     ((96, 2, 3, 96), (1, 3, 2, 0)), ((72, 72), (1, 0)), ((100, 3, 100), (2, 1, 0)), ((160, 96), (1, 0)),

@@ -75,6 +75,10 @@ if a.workload == "rr":
   nodes = [nodes[v] for v in sorted(g.nodes)]
   cuts = distributed.choose_cut_edges(nodes, min_slices=a.min_slices)
   run = lambda: distributed.contract_sliced(nodes, cuts)
+elif a.workload == "mera64":      # 16 slices of the bond-sliced chi = 64 layer (left placement), partials reused
+  layer = wl.MeraSlicedLayer(be, 64, "left", ta.bfloat16, seed=40)
+  sl = layer.all_slices()[:a.D]
+  run = lambda: layer.contract(sl, reuse=True)
 else:
   chi = a.chi
   sc = lambda n: float(n) ** -0.5

@@ -17,6 +17,7 @@ ap.add_argument("--vb", required=True)
 ap.add_argument("--knobs", default="auto")
 ap.add_argument("--iters", type=int, default=3)
 ap.add_argument("--fill", default="normal")
+ap.add_argument("--ldc-pad", type=int, default=0, help="elements of padding per row of C")
 a = ap.parse_args()
 be = ta.get_hip_backend()
 M, N, K = a.m, a.n, a.k
@@ -41,7 +42,7 @@ va = [int(x) for x in a.va.split(",")]
 vb = [int(x) for x in a.vb.split(",")]
 A = make(va, M, 1, K ** -0.5)
 B = make(vb, N, 2, 1.0)
-C = DeviceTensor.empty((M, N), _lib.BF16)
+C = DeviceTensor.empty((M, N + a.ldc_pad), _lib.BF16)
 ova, ovb = _lib.OperandView(*va), _lib.OperandView(*vb)
 flop = 2.0 * M * N * K
 for knob in a.knobs.split(","):
@@ -49,7 +50,7 @@ for knob in a.knobs.split(","):
   try:
     def call():
       _lib.check(be.lib.tnh_gemm_view(_lib.BF16, _lib.BF16, M, N, K, ctypes.c_void_p(A.ptr), ctypes.byref(ova),
-                                      ctypes.c_void_p(B.ptr), ctypes.byref(ovb), ctypes.c_void_p(C.ptr), N), "view")
+                                      ctypes.c_void_p(B.ptr), ctypes.byref(ovb), ctypes.c_void_p(C.ptr), N + a.ldc_pad), "view")
     call()
     be.synchronize()
     s = _lib.Event().record()
@@ -58,7 +59,7 @@ for knob in a.knobs.split(","):
     e = _lib.Event().record()
     e.synchronize()
     ms = s.elapsed_ms(e) / a.iters
-    print(json.dumps({"gemm": [M, N, K], "va": va, "vb": vb, "knob": knob, "fill": a.fill, "ms": round(ms, 3),
+    print(json.dumps({"gemm": [M, N, K], "va": va, "vb": vb, "knob": knob, "fill": a.fill, "ldc_pad": a.ldc_pad, "ms": round(ms, 3),
                       "tflops": round(flop / ms / 1e9, 1), "kernel": be.lib.tnh_gemm_last_kernel().decode()}), flush=True)
   finally:
     _lib.check(be.lib.tnh_gemm_set_variant(b"auto"))
