@@ -508,7 +508,7 @@ def test_gemm_split_k_small_output(hip, dtype):
   rng = np.random.default_rng(7)
   for (m, n, k, ta_, tb_) in [(1, 1, 262144, 0, 1), (3, 5, 70001, 0, 0), (64, 130, 20000, 1, 1), (200, 100, 9000, 1, 0)]:
     out, ref, kernel, sk = _gemm_case(hip, dtype, m, n, k, ta_, tb_, rng=rng)
-    tiny = dtype in (np.float32, np.float64) and m <= 4 and n <= 4       # round 6: one workgroup (gemm_tiny_kernel)
+    tiny = m <= 4 and n <= 4       # round 6: one workgroup (gemm_tiny_kernel; bf16 / f16 too since the last session)
     assert kernel == ("tiny_1wg" if tiny else "splitk"), (kernel, m, n, k)
     if dtype in (ta.bfloat16, np.float16):      # split-K partials are f32, rounded once at the end: the same rule
       assert_gemm(out, ref, dtype, k, err_msg=f"{m}x{n}x{k}")
@@ -1717,27 +1717,38 @@ def test_k1_pass_of_a_long_row_operand_writes_the_k_blocked_form(hip):
   """Round 6 (profiles/r06_k_blocked_operands.md): an operand the view GEMM cannot read in place, whose rows would be
   1 MiB long (K = 2^19 in bf16), is permuted into the K-blocked form [outer contracted, free, inner contracted] and
   read through a two-level contraction view.  Same K order per tile as the row-major form: bit-identical results;
-  sampled rows against float64 dot products."""
-  sa, sb, axes = (8, 1792, 4, 2, 16384), (3600, 8, 4, 16384), ([0, 2, 4], [1, 2, 3])
+  sampled rows against float64 dot products.  Second case: 36 x 36 tiles (the split-K tail launch walks the blocked
+  views too) with a `b` that COULD be read in place but has its rows exactly 1 MiB apart -- the cost rule gives that
+  view up for the pass."""
+  cases = [((8, 1792, 4, 2, 16384), (3600, 8, 4, 16384), 1, "bf16_view_nt_256x256x64_pp"),
+           ((8, 4608, 4, 2, 16384), (9216, 8, 4, 16384), 2, "bf16_view_nt_256x256x64_pp+tail_splitk")]
+  axes = ([0, 2, 4], [1, 2, 3])
   k = 8 * 4 * 16384
-  a = hip.device_random(sa, dtype=ta.bfloat16, seed=3, normal=True, a=0.0, b=k ** -0.5)
-  b = hip.device_random(sb, dtype=ta.bfloat16, seed=4, normal=True, a=0.0, b=1.0)
-  before = hip.permute_launches
-  got = hip.tensordot(a, b, axes)
-  assert hip.permute_launches - before >= 1 and hip.lib.tnh_gemm_last_kernel().decode().startswith("bf16_view_nt")
-  hip.k_blocked_permutes = False
-  try:
-    ref = hip.tensordot(a, b, axes)
-  finally:
-    hip.k_blocked_permutes = True
-  assert got.shape == ref.shape == (1792, 2, 3600)
-  rows = [(0, 0), (5, 1), (1791, 1), (1000, 0)]
-  a_t = hip.transpose(a, (1, 3, 0, 2, 4))             # [1792, 2, K]
-  for r0, r1 in rows:
-    g = np.asarray(hip.getitem(got, (r0, r1)))
-    u = np.asarray(hip.getitem(ref, (r0, r1)))
-    np.testing.assert_array_equal(g, u)
-    arow = np.asarray(hip.getitem(a_t, (r0, r1))).astype(np.float64).reshape(-1)
-    cols = [0, 1, 255, 256, 3599]
-    bcols = np.stack([np.asarray(hip.getitem(b, (c,))).astype(np.float64).reshape(-1) for c in cols])
-    np.testing.assert_allclose(g[cols], bcols @ arow, rtol=2.0**-8, atol=2.0**-9)
+  for sa, sb, want_permutes, want_kernel in cases:
+    a = hip.device_random(sa, dtype=ta.bfloat16, seed=3, normal=True, a=0.0, b=k ** -0.5)
+    b = hip.device_random(sb, dtype=ta.bfloat16, seed=4, normal=True, a=0.0, b=1.0)
+    before = hip.permute_launches
+    got = hip.tensordot(a, b, axes)
+    assert hip.permute_launches - before == want_permutes, (sa, hip.permute_launches - before)
+    assert hip.lib.tnh_gemm_last_kernel().decode() == want_kernel
+    hip.k_blocked_permutes = False
+    try:
+      ref = hip.tensordot(a, b, axes)
+    finally:
+      hip.k_blocked_permutes = True
+    m1, n = sa[1], sb[0]
+    assert got.shape == ref.shape == (m1, 2, n)
+    rows = [(0, 0), (5, 1), (m1 - 1, 1), (m1 - 130, 0)]
+    a_t = hip.transpose(a, (1, 3, 0, 2, 4))             # [m1, 2, K]
+    for r0, r1 in rows:
+      g = np.asarray(hip.getitem(got, (r0, r1)))
+      u = np.asarray(hip.getitem(ref, (r0, r1)))
+      if want_permutes == 1:
+        np.testing.assert_array_equal(g, u)               # same kernel, same K order per tile
+      else:                                               # (the tail rows' f32 partial sums are grouped per K-slice)
+        np.testing.assert_allclose(g, u, rtol=2.0**-7, atol=1e-6)
+      arow = np.asarray(hip.getitem(a_t, (r0, r1))).astype(np.float64).reshape(-1)
+      cols = [0, 1, 255, 256, n - 1]
+      bcols = np.stack([np.asarray(hip.getitem(b, (c,))).astype(np.float64).reshape(-1) for c in cols])
+      np.testing.assert_allclose(g[cols], bcols @ arow, rtol=2.0**-8, atol=2.0**-9)
+    del a, b, got, ref, a_t
