@@ -304,11 +304,6 @@ __device__ __forceinline__ void glds_go(unsigned voff, const void* sbase) {
   asm volatile("global_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(sbase) : "memory");
 }
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
-// B-direct loop (SCHED = 4): 16 bytes global -> VGPR in the SADDR form, untracked (the loop keeps the vmcnt books)
-template <int OFF>
-__device__ __forceinline__ void gload16s(uint4& dst, unsigned voff, const void* sbase) {
-  asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(*(u32x4_t*)&dst) : "v"(voff), "s"(sbase), "n"(OFF) : "memory");
-}
 // A fragment read the compiler does not track (no s_waitcnt lgkmcnt of its own in front of every MFMA: the load
 // segments end with our lgkmcnt(0) anyway)
 template <int OFF>
@@ -351,13 +346,11 @@ __device__ __forceinline__ void lds_frag_tr(uint4& dst, unsigned addr) {
 template <bool IS_BF16, bool OUT_F32, bool TWO, bool M32 = false, bool VIEW = false, bool A_KM = false,
           bool B_KN = false, int SCHED = 0, int KW = 0>
 __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(NtArgs p) {
-  static_assert(SCHED != 4 || ((!VIEW || KW == 2) && !A_KM && !B_KN && TWO && !M32),
-                "B-direct loop: K-contiguous operands with one contraction run");
   static_assert(KW == 0 || (VIEW && !A_KM && (!B_KN || (SCHED == 3 && KW == 1))),
                 "the tile-granular K walks: K-contiguous view operands, or (lean loop, KW = 1) a k-major B");
   static_assert(!VIEW || (TWO && !M32), "view kernels use the 2-phase 16x16x32 schedule");
   static_assert(SCHED == 0 || (TWO && !M32), "the round-5 schedules are 16x16x32 schedules");
-  static_assert(SCHED == 0 || SCHED == 3 || (!A_KM && !B_KN), "one-cluster / snake / B-direct: K-contiguous operands");
+  static_assert(SCHED == 0 || SCHED == 3 || (!A_KM && !B_KN), "one-cluster / snake: K-contiguous operands");
   // B_KT (round 6): a k-major B whose contraction runs are multiples of 64, next to a K-contiguous A, in the lean loop --
   // the whole-K-tile walk (both pieces of a half-tile hang off ONE scalar base: a lane's k row 0 .. 63 sits in its 32-bit
   // offset), the 16 transposing fragment reads as untracked asm from precomputed addresses (one VGPR per 32-B unit of
@@ -373,16 +366,7 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(NtArgs p) {
   // Why: on this kernel every instruction the load segment issues costs ~0.06 % (the 62 extra instructions of the
   // general view walk cost 4.3 %: profiles/r05_gemm_headline_plain_vs_view.jsonl).  Needs single-level rows (plain NT,
   // or a view with KW = 2 whose rows are linear) and row offsets inside a tile below 4 GiB (host check).
-  constexpr bool LEAN = (SCHED == 3 || SCHED == 4);
-  // SCHED = 4 (round 6, A/B knob ":p9"): the lean loop with B's MFMA fragments loaded global -> VGPR
-  // directly -- no LDS-DMA pieces, no LDS image and no ds_read_b128 for B (16 instead of 24 fragment reads and 4 instead
-  // of 8 LDS-DMA pieces per K-tile and wave, plus 8 global_load_dwordx4: lane (r = lane & 15, g = lane >> 4) of fragment
-  // (sub, f, ks) fetches the 16 bytes the swizzled LDS image would have handed it -- row wc * 64 + sub * 32 + f * 16 + r
-  // of the tile's B rows, 16-byte chunk ks * 4 + g of the K-tile).  Both waves that share a wc (wr = 0 / 1) fetch the
-  // same lines: twice B's bytes through the L1.  One K-tile of register prefetch (a second set of 32 registers): the
-  // fragments of K-tile t + 1 are requested in load segment 1 of K-tile t, behind the A pieces, and waited for with
-  // vmcnt(12) one K-tile later.  Same MFMA sequence: bit-identical.  Measured: profiles/r06_gemm_b_direct.md.
-  constexpr bool BDIR = (SCHED == 4);
+  constexpr bool LEAN = (SCHED == 3);
   // (the lean loop without the s_setprio pair around its clusters measured the same to 0.1 %:
   //  profiles/r05_gemm_setprio_ab.jsonl -- the pair stays)
   // (KW = 0 in the lean loop: the full chunk offset sits in the lane offsets as for KW >= 1, and in a K-tile whose halves
@@ -509,10 +493,6 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(NtArgs p) {
             int64_t col = n0 + h * 128 + kchunk * 8;
             if (col + 8 > p.N) col = p.N - 8;
             ob[h][i] = (uint32_t)((row_elems_km(p.vb, col) - b0 + (int64_t)(B_KT ? krow_tile : krow) * p.vb.sk0) * 2);
-          } else if constexpr (BDIR) {     // fragment (sub = h, f = i): this lane's row of it, chunk g of a k-step
-            int64_t rb = n0 + wc * 64 + h * 32 + i * 16 + (lane & 15);
-            if (rb >= p.N) rb = p.N - 1;
-            ob[h][i] = (uint32_t)((row_elems(p.vb, p.ldb, rb) - b0 + (lane >> 4) * 8) * 2);
           } else {
             int64_t rb = n0 + h * 128 + trow;
             if (rb >= p.N) rb = p.N - 1;
@@ -624,18 +604,6 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(NtArgs p) {
 
   uint4 af[ASUBS][KS][FA];   // [sub (one-cluster schedule: both)][k-step][row fragment] of the current A sub-tile
   uint4 bf[2][KS][FB];  // [sub][k-step][row fragment] of both B sub-tiles
-  uint4 bf2[2][KS][FB];   // B-direct loop: the set of the odd K-tiles (bf is the set of the even ones)
-  // B-direct loop: the 8 fragments of the K-tile at `sb` (wave-uniform: tile's first B row + K offset) -> set SET
-  auto load_b_direct = [&](auto setc, const void* sb) {
-    constexpr int SET = decltype(setc)::value;
-    uint4 (&d)[2][KS][FB] = *(SET ? &bf2 : &bf);
-    if constexpr (BDIR) {
-      gload16s<0>(d[0][0][0], ob[0][0], sb); gload16s<64>(d[0][1][0], ob[0][0], sb);
-      gload16s<0>(d[0][0][1], ob[0][1], sb); gload16s<64>(d[0][1][1], ob[0][1], sb);
-      gload16s<0>(d[1][0][0], ob[1][0], sb); gload16s<64>(d[1][1][0], ob[1][0], sb);
-      gload16s<0>(d[1][0][1], ob[1][1], sb); gload16s<64>(d[1][1][1], ob[1][1], sb);
-    }
-  };
 
   // lean loop: LDS byte addresses of this lane's fragment rows, wave's sub-tile origin included, per k-step; buffer 1
   // is BUF_BYTES further on (beyond the 16-bit offset field, hence its own registers)
@@ -754,8 +722,7 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(NtArgs p) {
     __builtin_amdgcn_s_setprio(0);
   };
   // lean loop: both quadrants of A sub-tile `sa` under ONE s_setprio pair (same MFMA order as two mma_quadrant calls)
-  auto mma_cluster = [&](int sa, int sb_first, auto setc) {
-    constexpr int SET = decltype(setc)::value;      // B-direct loop: which B register set (0 everywhere else)
+  auto mma_cluster = [&](int sa, int sb_first) {
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
@@ -766,10 +733,8 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(NtArgs p) {
         for (int i = 0; i < FA; ++i)
 #pragma unroll
           for (int j = 0; j < FB; ++j)
-            if constexpr (!M32) {
-              const uint4& bv = (BDIR && SET) ? bf2[sb][ks][j] : bf[sb][ks][j];
-              acc[sa * 4 + i][sb * 2 + j] = mma16<IS_BF16>(bv, af[0][ks][i], acc[sa * 4 + i][sb * 2 + j]);
-            }
+            if constexpr (!M32)
+              acc[sa * 4 + i][sb * 2 + j] = mma16<IS_BF16>(bf[sb][ks][j], af[0][ks][i], acc[sa * 4 + i][sb * 2 + j]);
     }
     __builtin_amdgcn_s_setprio(0);
   };
@@ -827,11 +792,6 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(NtArgs p) {
       walk(wb, kb, kb1, 0);
       stage_lean(I0{}, I0{}, ka, ka1);
       stage_lean(I0{}, I1{}, ka, ka1);
-      if constexpr (BDIR) {       // B's fragments of K-tile 0 are requested at the top of the tile loop (after the epilogue)
-        a_next = abase + (int64_t)(kfirst + 1) * BK;
-        b_next = bbase + (int64_t)kfirst * BK;
-        return;
-      }
       stage_lean(I0{}, std::integral_constant<int, 2>{}, kb, kb1);
       stage_lean(I0{}, std::integral_constant<int, 3>{}, kb, kb1);
       if (nt > 1) {
@@ -895,10 +855,6 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(NtArgs p) {
 
   for (int tile = (int)blockIdx.x;;) {
   zero_acc();
-  if constexpr (BDIR) {       // K-tile 0's B fragments -> set 0 (here, not before the epilogue: the registers are free now)
-    load_b_direct(std::integral_constant<int, 0>{}, (const void*)b_next);
-    b_next += BK;
-  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this tile's prologue loads (and the previous tile's stores)
   __syncthreads();
   if (wr == 1) __builtin_amdgcn_s_barrier();  // group 1 runs one interval behind group 0
@@ -924,7 +880,7 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(NtArgs p) {
         stage_lean(IO{}, std::integral_constant<int, 1>{}, k0, k1);
       }
       TNH_SEG_LOAD_END();
-      mma_cluster(0, 0, std::integral_constant<int, 0>{});
+      mma_cluster(0, 0);
       TNH_SEG_MMA_END();
       read_a(cur, 1);
       if (left > 2) {
@@ -937,7 +893,7 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(NtArgs p) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
       TNH_SEG_LOAD_END();
-      mma_cluster(1, 1, std::integral_constant<int, 0>{});
+      mma_cluster(1, 1);
       TNH_SEG_MMA_END();
     };
     auto body = [&](auto bufc, int t) {
@@ -953,38 +909,7 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(NtArgs p) {
       using C2 = std::integral_constant<int, 2>;
       using C3 = std::integral_constant<int, 3>;
       const int left = nt - t;                 // K-tiles from this one on (scalar compares below, no lane masks)
-      if constexpr (BDIR) {
-        // ---- load segment 1: A sub-tile 0 (8 reads); A halves of K-tile t + 1 -> other buffer, then the 8 B fragments
-        // of K-tile t + 1 -> the other register set; this K-tile's B fragments (requested one K-tile ago) must have landed
-        if (left > 1) {
-          const void* sb = (const void*)a_next;
-          a_next += BK;
-          const uint32_t v0 = oa[0][0], v1 = oa[0][1], v2 = oa[1][0], v3 = oa[1][1];
-          piece_m0(IO{}, C0{}, C0{}); lean_read_a1(IB{}, C0{}, C0{}); piece_go(v0, sb); lean_read_a1(IB{}, C0{}, C1{});
-          piece_m0(IO{}, C0{}, C1{}); lean_read_a1(IB{}, C0{}, C2{}); piece_go(v1, sb); lean_read_a1(IB{}, C0{}, C3{});
-          piece_m0(IO{}, C1{}, C0{}); lean_read_a1(IB{}, C0{}, std::integral_constant<int, 4>{}); piece_go(v2, sb);
-          lean_read_a1(IB{}, C0{}, std::integral_constant<int, 5>{});
-          piece_m0(IO{}, C1{}, C1{}); lean_read_a1(IB{}, C0{}, std::integral_constant<int, 6>{}); piece_go(v3, sb);
-          lean_read_a1(IB{}, C0{}, std::integral_constant<int, 7>{});
-          load_b_direct(IO{}, (const void*)b_next);
-          b_next += BK;
-          asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-        } else {
-          lean_read_a(IB{}, C0{});
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        TNH_SEG_LOAD_END();
-        mma_cluster(0, 0, IB{});
-        TNH_SEG_MMA_END();
-        // ---- load segment 2: A sub-tile 1 (8 reads); the A pieces of K-tile t + 1 must have landed (B's 8 loads may fly)
-        lean_read_a(IB{}, C1{});
-        if (left > 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        TNH_SEG_LOAD_END();
-        mma_cluster(1, 1, IB{});
-        TNH_SEG_MMA_END();
-        return;
-      }
+      int64_t unused = 0;
       // ---- load segment 1: B sub-tiles 0 / 1 (8 reads), A sub-tile 0 (8 reads); A halves of K-tile t + 1 -> other buffer.
       // Every LDS-DMA piece is [M0 write] [one fragment read] [load]: the read is the wait state the M0 write needs.
       if constexpr (B_KT) {
@@ -1022,7 +947,7 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(NtArgs p) {
         lean_read_a(IB{}, C0{});
       }
       TNH_SEG_LOAD_END();
-      mma_cluster(0, 0, C0{});
+      mma_cluster(0, 0);
       TNH_SEG_MMA_END();
       // ---- load segment 2: A sub-tile 1 (8 reads); B halves of K-tile t + 2 -> this buffer
       if (left > 2) {
@@ -1055,7 +980,7 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(NtArgs p) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
       TNH_SEG_LOAD_END();
-      mma_cluster(1, 1, C0{});
+      mma_cluster(1, 1);
       TNH_SEG_MMA_END();
     };
     // (peeling the last two K-tiles off to get a condition-free body was tried: four copies of the body made the
@@ -1518,7 +1443,6 @@ static int launch_pp(bool is_bf16, bool out_f32, bool two, NtArgs p, int64_t bat
 #define TNH_PP_LAUNCH(B16, O32)                                                                               \
   do {                                                                                                       \
     if (g_opt_phases == 7) hipLaunchKernelGGL((gemm_nt_pp_kernel<B16, O32, true, false, false, false, false, 1>), grid, block, 0, stream(), q); \
-    else if (lean && g_opt_phases == 9) hipLaunchKernelGGL((gemm_nt_pp_kernel<B16, O32, true, false, false, false, false, 4>), grid, block, 0, stream(), q); \
     else if (lean) hipLaunchKernelGGL((gemm_nt_pp_kernel<B16, O32, true, false, false, false, false, 3>), grid, block, 0, stream(), q); \
     else if (g_opt_phases == 8) hipLaunchKernelGGL((gemm_nt_pp_kernel<B16, O32, true, false, false, false, false, 2>), grid, block, 0, stream(), q); \
     else if (m32) hipLaunchKernelGGL((gemm_nt_pp_kernel<B16, O32, true, true>), grid, block, 0, stream(), q);      \
@@ -1551,8 +1475,7 @@ static void launch_pp_view_t(bool is_bf16, bool out_f32, dim3 grid, const NtArgs
       const bool lean = lean_view_rows(ql, kw == 0);
 #define TNH_VIEW_KW(B16, O32)                                                                                              \
   do {                                                                                                                     \
-    if (lean && kw == 2 && g_opt_phases == 9) hipLaunchKernelGGL((gemm_nt_pp_kernel<B16, O32, true, false, true, false, false, 4, 2>), grid, block, 0, stream(), ql); \
-    else if (lean && kw == 2) hipLaunchKernelGGL((gemm_nt_pp_kernel<B16, O32, true, false, true, false, false, 3, 2>), grid, block, 0, stream(), ql); \
+    if (lean && kw == 2) hipLaunchKernelGGL((gemm_nt_pp_kernel<B16, O32, true, false, true, false, false, 3, 2>), grid, block, 0, stream(), ql); \
     else if (lean && kw == 1) hipLaunchKernelGGL((gemm_nt_pp_kernel<B16, O32, true, false, true, false, false, 3, 1>), grid, block, 0, stream(), ql); \
     else if (lean) hipLaunchKernelGGL((gemm_nt_pp_kernel<B16, O32, true, false, true, false, false, 3, 0>), grid, block, 0, stream(), ql); \
     else if (kw == 0) hipLaunchKernelGGL((gemm_nt_pp_kernel<B16, O32, true, false, true, false, false, 0, 0>), grid, block, 0, stream(), q); \
