@@ -853,9 +853,17 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(NtArgs p) {
   setup_tile((int)blockIdx.x);
   start_tile();
 
+  // Stores of the previous tile's epilogue that may still be in flight at the top of a tile (p.epi_early).  VMEM operations
+  // retire in issue order (what the compiler's own vmcnt bookkeeping relies on for global loads / stores on gfx9), and the
+  // prologue's LDS-DMA pieces were issued BEFORE those stores: vmcnt(pend) = every prologue load has landed.  The first
+  // K-tile's fragment reads and its first MFMA cluster then run while the store path (16 B/clk: ~3.8 us per 128-KiB tile,
+  // profiles/r03_gemm_epilogue.md) drains; the loop's own vmcnt waits retire the stores with the loads queued behind them.
+  int pend = 0;
   for (int tile = (int)blockIdx.x;;) {
   zero_acc();
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this tile's prologue loads (and the previous tile's stores)
+  if (pend == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+  else if (pend == 32) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this tile's prologue loads (and the previous tile's stores)
   __syncthreads();
   if (wr == 1) __builtin_amdgcn_s_barrier();  // group 1 runs one interval behind group 0
   __builtin_amdgcn_sched_barrier(0);
@@ -1108,6 +1116,12 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(NtArgs p) {
   char* Cb = (char*)p.C + (int64_t)blockIdx.y * p.sC * (OUT_F32 ? 4 : 2);
   if constexpr (!M32) {
     store_wave_tile<IS_BF16, OUT_F32, 8, 4>(acc, p, Cb, m0, n0, BM, BN, wr * 128, wc * 64, lane);
+    // how many store instructions that was, where the count is static (store_wave_tile: the 16-byte half path, the
+    // float4 path of a full f32 tile); anything else is waited for in full
+    const bool full = (m0 + BM <= p.M) && (n0 + BN <= p.N);
+    const bool vec = p.epi_early && p.c_vec && full;
+    if constexpr (OUT_F32) pend = vec ? 32 : 0;
+    else pend = (vec && (p.ldc & 7) == 0 && (((uintptr_t)Cb) & 15) == 0) ? 16 : 0;
   } else {
     // 32x32 C/D layout (operands swapped): lane holds, for m = lane & 31,
     // n = 8*q + 4*(lane >> 5) + (0..3) for q = 0..3  (registers 4q .. 4q+3).
@@ -1381,6 +1395,7 @@ static int launch_nt(bool is_bf16, bool out_f32, NtArgs p, int64_t batch) {
   return TNH_OK;
 }
 
+int g_opt_epi = -1;      // A/B knob ":e<d>": next tile's MFMAs under the draining epilogue stores (-1 / 1: on; 0: off)
 int g_opt_lean = -1;     // A/B knob ":l<d>": the lean main loop of the ping-pong kernels (-1: on where it applies)
 
 // The lean loop addresses a tile's rows as a 32-bit byte offset from the tile's first row
@@ -1574,6 +1589,7 @@ int gemm_bf16_view(int in_dt, int out_dt, int64_t M, int64_t N, int64_t K, const
   p.lda = va.sr0; p.ldb = vb.sr0; p.ldc = ldc;
   p.sA = p.sB = p.sC = 0;
   p.raster = pick_raster(M, N, K);
+  p.epi_early = g_opt_epi != 0;
   p.c_vec = ((int64_t)M * N * 2 >= (int64_t(64) << 20)) ? 3 : 1;
   p.a_vw = p.b_vw = 8;
   p.tiles_m = (int)((M + 255) / 256);
@@ -1755,6 +1771,7 @@ int gemm_bf16_fast(int in_dt, int out_dt, int variant, int transA, int transB, i
   p.lda = lda; p.ldb = ldb; p.ldc = ldc;
   p.sA = sA; p.sB = sB; p.sC = sC;
   p.raster = pick_raster(M, N, K);
+  p.epi_early = g_opt_epi != 0;
   p.c_vec = ((int64_t)M * N * 2 >= (int64_t(64) << 20)) ? 3 : 1;
   p.a_vw = p.b_vw = 8;
   const bool is_bf16 = (in_dt == TNH_BF16), out_f32 = (out_dt == TNH_F32);

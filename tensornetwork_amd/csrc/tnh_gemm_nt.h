@@ -39,6 +39,8 @@ struct NtArgs {
   int a_vw, b_vw;  // ragged kernel only: widest aligned load (elements: 8, 4, 2, 1) on rows of A / B
   int lean_rel_a, lean_rel_b;   // lean loop: 1 = a lane's row offsets are taken from the tile's first row (rows ascend in
                                 // memory, a tile spans < 4 GiB), 0 = from the operand's base (the whole operand spans < 4 GiB)
+  int epi_early;   // ping-pong kernels: 1 = a persistent workgroup starts its next tile's MFMAs while the stores of the tile it
+                   // just finished are still draining (the wait at the top of a tile covers the prologue's loads only)
   int raster;  // 1 (default): 16x16 super-tiles shared by the 8 XCDs (3x less HBM traffic, +2%); 0: per-XCD ranges, M-grouped
 };
 
