@@ -1593,6 +1593,47 @@ def test_gemm_lean_main_loop_is_bit_identical(hip, dtype, m, n, k):
   assert_gemm(out["bf16_256pp"], ref, dtype, k)
 
 
+@pytest.mark.parametrize("m,n,k", [(8192, 8192, 128), (8232, 8168, 192), (12288, 4096, 1088)])
+def test_gemm_next_tile_under_the_draining_stores_is_bit_identical(hip, m, n, k):
+  """Round 6: a persistent workgroup of the ping-pong kernel waits at the top of a tile for the prologue's loads only
+  (vmcnt(16) after the 16-byte half epilogue, vmcnt(32) after a full f32 tile, everything after a ragged tile) and runs
+  its first cluster while the finished tile's stores drain.  Only a wait moved: with the knob ':e0' (the full wait)
+  the results must be bit-identical -- several tiles per CU, full and ragged tiles mixed, half and f32 output, plain and
+  view entry points, repeated (a race would not show every time)."""
+  import ctypes
+  from tensornetwork_amd.device_tensor import DeviceTensor
+  A = hip.device_random((m, k), dtype=ta.bfloat16, seed=11, normal=True, a=0.0, b=1.0)
+  B = hip.device_random((n, k), dtype=ta.bfloat16, seed=12, normal=True, a=0.0, b=1.0)
+
+  def run(knob, view, out_dt):
+    C = DeviceTensor.empty((m, n), out_dt)
+    _lib.check(hip.lib.tnh_gemm_set_variant(knob.encode()))
+    try:
+      if view:
+        va, vb = _lib.OperandView(m, k, 0, k, 1, 0), _lib.OperandView(n, k, 0, k, 1, 0)
+        _lib.check(hip.lib.tnh_gemm_view(_lib.BF16, out_dt, m, n, k, ctypes.c_void_p(A.ptr), ctypes.byref(va),
+                                         ctypes.c_void_p(B.ptr), ctypes.byref(vb), ctypes.c_void_p(C.ptr), n))
+      else:
+        _lib.check(hip.lib.tnh_gemm(_lib.BF16, out_dt, 0, 1, m, n, k, ctypes.c_void_p(A.ptr), k, ctypes.c_void_p(B.ptr), k,
+                                    ctypes.c_void_p(C.ptr), n, 1, 0, 0, 0))
+      hip.synchronize()
+      assert "256x256x64_pp" in hip.lib.tnh_gemm_last_kernel().decode()
+    finally:
+      _lib.check(hip.lib.tnh_gemm_set_variant(b"auto"))
+    return np.asarray(C)
+
+  for view in (False, True):
+    for out_dt in (_lib.BF16, _lib.F32):
+      ref = run("auto:e0", view, out_dt)
+      for _ in range(3):
+        np.testing.assert_array_equal(run("auto", view, out_dt), ref)
+  # and the values themselves: sampled rows against float64
+  a64, b64 = np.asarray(A).astype(np.float64), np.asarray(B).astype(np.float64)
+  got = run("auto", False, _lib.F32)
+  rows = np.array([0, 255, 256, m // 2 + 3, m - 1])
+  np.testing.assert_allclose(got[rows], a64[rows] @ b64.T, rtol=1e-4, atol=1e-3 * np.sqrt(k))
+
+
 def test_k_major_operands_take_the_faster_lowering(hip):
   """Round 5 (profiles/r05_kmajor_gate_small.jsonl): reading a k-major operand in place through the half-K-tile loop
   costs a product ~10 %; the backend takes ONE K1 pass instead wherever that pass is cheaper.  Round 6
