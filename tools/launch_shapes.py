@@ -14,6 +14,8 @@ ap.add_argument("--D", type=int, default=16)
 ap.add_argument("--chi", type=int, default=32)
 ap.add_argument("--min-slices", type=int, default=64)
 ap.add_argument("--top", type=int, default=30)
+ap.add_argument("--world", type=int, default=1, help="rr: contract only the share of --rank out of --world ranks")
+ap.add_argument("--rank", type=int, default=0)
 a = ap.parse_args()
 be = ta.get_hip_backend()
 lib = be.lib
@@ -73,8 +75,10 @@ if a.workload == "rr":
     slot[x] += 1
     slot[y] += 1
   nodes = [nodes[v] for v in sorted(g.nodes)]
-  cuts = distributed.choose_cut_edges(nodes, min_slices=a.min_slices)
-  run = lambda: distributed.contract_sliced(nodes, cuts)
+  class Share(distributed.LocalComm):
+    rank, world = a.rank, a.world
+  cuts = distributed.choose_cut_edges(nodes, min_slices=a.min_slices, **({"world": a.world} if a.world > 1 else {}))
+  run = lambda: distributed.contract_sliced(nodes, cuts, comm=Share())
 elif a.workload == "mera64":      # 16 slices of the bond-sliced chi = 64 layer (left placement), partials reused
   layer = wl.MeraSlicedLayer(be, 64, "left", ta.bfloat16, seed=40)
   sl = layer.all_slices()[:a.D]

@@ -37,6 +37,15 @@ from tensornetwork.backends import backend_factory
 import tensornetwork_amd  # noqa: F401  registers "hip"  pylint: disable=unused-import
 
 _NAMES = [b for b in os.environ.get("TNH_REF_BACKENDS", "hip").split(",") if b]
+if os.environ.get("TNH_REF_EMULATED", "0") == "1":
+  # CPU run (tests/test_reference_dropin_cpu.py): the backend's HOST code and the C-ABI contract with the reference as
+  # the caller -- the library handle is the NumPy emulation of include/tnh.h that the CPU suite uses (tests/emu_tnh.py;
+  # test infrastructure, the kernels themselves are covered on the GPU)
+  import sys
+  sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests"))
+  import emu_tnh  # pylint: disable=import-error,wrong-import-position
+  from tensornetwork_amd import _lib as _tnh_lib  # pylint: disable=wrong-import-position
+  _tnh_lib._lib, _tnh_lib._device = emu_tnh.EmuLib(), 0  # pylint: disable=protected-access
 _KEEP_ALL = os.environ.get("TNH_REF_KEEP_ALL", "0") == "1"
 
 
