@@ -1,8 +1,8 @@
 """The reference's OWN test files, unmodified, on ``backend="hip"``.
 
 google/TensorNetwork is not installed on the GPU box; when a copy of its package is reachable
-(``$TN_REFERENCE_DIR``, ``<repo>/_reference_scratch`` shipped by
-``tools/reference_dropin/gpurun_with_reference.sh``, or ``/root/reference``) every file below is
+(``$TN_REFERENCE_DIR`` or ``<repo>/_reference_scratch``, as rounds 2-5 shipped it with
+``tools/reference_dropin/gpurun_with_reference.sh``; round 6 ships nothing) every file below is
 run in its own pytest process through ``tools/reference_dropin/tnh_ref_plugin.py``.  A reference
 test may fail only for a reason that also makes it fail on the reference's NumPy backend in this
 image (``EXPECTED`` lists them with the reason); everything else must pass on the GPU."""
@@ -19,7 +19,9 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def reference_dir():
-  for cand in (os.environ.get("TN_REFERENCE_DIR"), os.path.join(REPO, "_reference_scratch"), "/root/reference"):
+  # (never /root/reference: the GPU suite does not read the build container's copy -- its CPU counterpart,
+  #  tests/test_reference_dropin_cpu.py, is where the reference is the caller in round 6)
+  for cand in (os.environ.get("TN_REFERENCE_DIR"), os.path.join(REPO, "_reference_scratch")):
     if cand and os.path.isdir(os.path.join(cand, "tensornetwork")):
       return cand
   return None
