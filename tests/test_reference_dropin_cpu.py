@@ -11,8 +11,11 @@ behaviour, the host lowering (transposes, reshapes, planner hints, truncation ru
 kernels, which the GPU suite compares with reference-generated goldens.  A reference test may fail only for a reason
 that also makes it fail on the reference's NumPy backend in this image (``EXPECTED``).  Skipped where no copy of the
 reference is readable (the GPU box)."""
+import json
 import os
 import re
+import subprocess
+import sys
 
 import pytest
 
@@ -51,3 +54,32 @@ def test_reference_test_file_with_the_reference_as_caller(relpath):
   unexpected = [f for f in failed if not any(re.search(p, f) for p in EXPECTED[relpath])]
   assert not unexpected, "\n".join(unexpected) + "\n" + out[-6000:]
   assert passed == PASSED_ON_GPU[relpath], (passed, PASSED_ON_GPU[relpath], out[-3000:])
+
+
+def test_reference_mps_and_dmrg_classes_drive_the_hip_backend():
+  """Row f2 with the reference as the caller: google/TensorNetwork's OWN ``FiniteMPS`` / ``FiniteXXZ`` / ``FiniteDMRG``
+  (matrixproductstates/finite_mps.py, mpo.py, dmrg.py:one-site sweeps -> ``backend.eigsh_lanczos``, ``svd`` / ``qr``
+  canonicalisation, ``ncon``) on ``backend="hip"`` next to the same run on its NumPy backend: the 10-site Heisenberg
+  chain, D = 16, four sweeps -- same energy, magnetisation and correlators (f64 to 1e-10, f32 to 1e-4), and the tensors
+  the MPS holds are the backend's device tensors."""
+  ref = reference_dir()
+  if ref is None:
+    pytest.skip("google/TensorNetwork is not readable here (it lives in the build container only)")
+  repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  env = dict(os.environ)
+  env["PYTHONDONTWRITEBYTECODE"] = "1"
+  env["PYTHONPATH"] = os.pathsep.join([os.path.join(repo, "tests", "golden", "_stubs"),
+                                       os.path.join(repo, "tools", "reference_dropin", "_stubs"), ref, repo,
+                                       env.get("PYTHONPATH", "")])
+  proc = subprocess.run([sys.executable, os.path.join(repo, "tests", "helpers", "ref_mps_drive.py")], cwd=ref, env=env,
+                        capture_output=True, text=True, timeout=900, check=False)
+  assert proc.returncode == 0, (proc.stdout[-2000:], proc.stderr[-4000:])
+  line = [ln for ln in proc.stdout.splitlines() if ln.startswith("RESULT ")][-1]
+  out = json.loads(line[len("RESULT "):])
+  for name, tol in (("float64", 1e-10), ("float32", 1e-4)):
+    a, b = out[name]["numpy"], out[name]["hip"]
+    assert b["tensor_type"] == "DeviceTensor" and a["tensor_type"] == "ndarray"
+    assert abs(a["energy"] - b["energy"]) <= tol * abs(a["energy"]), (name, a["energy"], b["energy"])
+    assert abs(a["energy"] - (-4.258035204)) < 1e-4
+    assert max(abs(x - y) for x, y in zip(a["sz"] + a["szsz"], b["sz"] + b["szsz"])) <= 10 * tol, name
+    assert abs(a["norm"] - b["norm"]) <= tol * a["norm"]
