@@ -31,11 +31,21 @@ int g_opt_raster = -1;  // A/B knobs, set through tnh_gemm_set_variant("name:r<d
 // Tile order of the 256 x 256 kernels.  Raster 1 (16 x 16 super-tiles shared by the 8 XCDs) wins wherever there are
 // many tiles (65536^3: 1477 vs 1464 TF, 36864^3: 1545 vs 1482); a grid of at most four resident waves of tiles with
 // a very long K prefers the per-XCD M-grouped order (8192 x 8192 x 262144, the D = 512 row: 1530 vs 1505 TF;
-// profiles/r03_raster_ab.txt)
+// profiles/r03_raster_ab.txt).  Round 6: so does a TALL result (eight times more tile rows than tile columns) with a short
+// contraction -- 262144 x 32768 x 1024: 1216 vs 1150 TF, 524288 x 16384 x 2048: 1416 vs 1352, 262144 x 8192 x 2048: 1418 vs
+// 1349, the MERA layer's 1048576 x 32768 x 1024: 1181 vs 1167, the chi = 64 slices' 262144 x 4096 x 4096: 1497 vs 1475; a WIDE
+// one does not (32768 x 1048576 x 1024: 1168 vs 1189), nor a square one (131072^2 x 512: 811 vs 902)
+// -- and so does a large grid (>= 8192 tiles, at least as many tile rows as columns) with a contraction of 1536 ... 4096:
+// 32768^2 x 1536 / 2048 / 3072 / 4096: +3.5 / +4.4 / +4.3 / +2.5 %, 65536^2 x 2048 / 4096: +4.5 / +3 %, 65536 x 16384 x 2048 /
+// 4096: +4.2 / +3.6 %; below (32768^2 x 1024: -3 %) and above (x 6144 / 8192: -2.8 / -4.2 %, 65536^2 x 8192: -6 %) the
+// super-tiles win, as they do at 16384 x 65536 x 2048 (profiles/r06_raster_tall_ab.txt; tools/raster_ab.sh, raster_ab2.sh)
 static int pick_raster(int64_t M, int64_t N, int64_t K) {
   if (g_opt_raster >= 0) return g_opt_raster;
-  const int64_t tiles = ((M + 255) / 256) * ((N + 255) / 256);
-  return (tiles <= 1024 && K >= 65536) ? 0 : 1;      // 8192 x 8192 x 65536: 1527 vs 1487 (profiles/r03_gemm_pj_per_flop.md)
+  const int64_t tm = (M + 255) / 256, tn = (N + 255) / 256, tiles = tm * tn;
+  if (tiles <= 1024 && K >= 65536) return 0;       // 8192 x 8192 x 65536: 1527 vs 1487 (profiles/r03_gemm_pj_per_flop.md)
+  if (tm >= 8 * tn && K <= 4096) return 0;
+  if (tiles >= 8192 && tm >= tn && K >= 1536 && K <= 4096) return 0;
+  return 1;
 }
 int g_opt_phases = 2;  // ping-pong kernel: MFMA clusters per K-tile (2 = 32-MFMA clusters, default; 4)
 int g_opt_tail = 1;    // view GEMM: split-K launch for the last, mostly empty wave of tiles (":t0" switches it off)
