@@ -39,12 +39,17 @@ int g_opt_raster = -1;  // A/B knobs, set through tnh_gemm_set_variant("name:r<d
 // 32768^2 x 1536 / 2048 / 3072 / 4096: +3.5 / +4.4 / +4.3 / +2.5 %, 65536^2 x 2048 / 4096: +4.5 / +3 %, 65536 x 16384 x 2048 /
 // 4096: +4.2 / +3.6 %; below (32768^2 x 1024: -3 %) and above (x 6144 / 8192: -2.8 / -4.2 %, 65536^2 x 8192: -6 %) the
 // super-tiles win, as they do at 16384 x 65536 x 2048 (profiles/r06_raster_tall_ab.txt; tools/raster_ab.sh, raster_ab2.sh)
+// Short contractions (K <= 1536) on such grids take the M-grouped order with groups of SIXTEEN tile rows (raster 3):
+// 65536^2 x 1024: 1222 against 1155 (super-tiles) / 1188 (groups of 8), 1048576 x 32768 x 1024 (the MERA layer): 1232 / 1167 /
+// 1191, 262144 x 32768 x 512: 944 / 888 / 926, 32768^2 x 1536: 1310 / 1240 / 1290; at K = 4096 groups of 16 lose 12 %.
 static int pick_raster(int64_t M, int64_t N, int64_t K) {
   if (g_opt_raster >= 0) return g_opt_raster;
   const int64_t tm = (M + 255) / 256, tn = (N + 255) / 256, tiles = tm * tn;
   if (tiles <= 1024 && K >= 65536) return 0;       // 8192 x 8192 x 65536: 1527 vs 1487 (profiles/r03_gemm_pj_per_flop.md)
-  if (tm >= 8 * tn && K <= 4096) return 0;
-  if (tiles >= 8192 && tm >= tn && K >= 1536 && K <= 4096) return 0;
+  if (tiles >= 8192 || tm >= 8 * tn) {             // large or tall grids
+    if (K <= 1536) return 3;
+    if (K <= 4096 && tm >= tn) return 0;
+  }
   return 1;
 }
 int g_opt_phases = 2;  // ping-pong kernel: MFMA clusters per K-tile (2 = 32-MFMA clusters, default; 4)

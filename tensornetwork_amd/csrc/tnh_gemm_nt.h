@@ -87,7 +87,7 @@ __device__ __forceinline__ void tile_of_block(int bid, int tiles_m, int tiles_n,
   const int q = nwg >> 3, r = nwg & 7;
   const int xcd = bid & 7, local = bid >> 3;
   const int pid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
-  constexpr int GROUP_M = 8;
+  const int GROUP_M = raster == 2 ? 4 : (raster == 3 ? 16 : (raster == 4 ? 32 : 8));   // A/B knobs :r2 / :r3 / :r4
   const int per_group = GROUP_M * tiles_n;
   const int group = pid / per_group;
   const int first_m = group * GROUP_M;
