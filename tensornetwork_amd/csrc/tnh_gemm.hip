@@ -33,7 +33,7 @@ struct GemmArgs {
 };
 
 // provided by tnh_gemm_bf16.hip
-extern int g_opt_raster, g_opt_phases, g_opt_tail, g_opt_persist, g_opt_kwalk, g_opt_lean, g_opt_epi;
+extern int g_opt_raster, g_opt_phases, g_opt_tail, g_opt_persist, g_opt_kwalk, g_opt_lean, g_opt_epi, g_opt_nt;
 int gemm_bf16_fast(int in_dt, int out_dt, int variant, int transA, int transB, int64_t M, int64_t N,
                    int64_t K, const void* A, int64_t lda, const void* B, int64_t ldb, void* C,
                    int64_t ldc, int64_t batch, int64_t sA, int64_t sB, int64_t sC, const char** name);
@@ -1074,6 +1074,7 @@ int tnh_gemm_set_variant(const char* full) {
   tnh::g_opt_kwalk = -1;
   tnh::g_opt_lean = -1;
   tnh::g_opt_epi = -1;
+  tnh::g_opt_nt = -1;
   g_f32_split = -1;   // back to the environment's choice unless ":s<d>" follows
   for (char* c = strchr(name, ':'); c != nullptr;) {
     *c = 0;
@@ -1085,6 +1086,7 @@ int tnh_gemm_set_variant(const char* full) {
     else if (c[1] == 'w') tnh::g_opt_kwalk = atoi(c + 2);
     else if (c[1] == 'l') tnh::g_opt_lean = atoi(c + 2);
     else if (c[1] == 'e') tnh::g_opt_epi = atoi(c + 2);
+    else if (c[1] == 'n') tnh::g_opt_nt = atoi(c + 2);
     else if (c[1] == 's') g_f32_split = atoi(c + 2) ? 1 : 0;
     c = next;
   }

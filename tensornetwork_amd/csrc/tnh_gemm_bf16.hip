@@ -1410,6 +1410,7 @@ static int launch_nt(bool is_bf16, bool out_f32, NtArgs p, int64_t batch) {
   return TNH_OK;
 }
 
+int g_opt_nt = -1;       // A/B knob ":n<d>": non-temporal epilogue stores for results of 64 MiB and more (-1 / 1: on; 0: off)
 int g_opt_epi = -1;      // A/B knob ":e<d>": next tile's MFMAs under the draining epilogue stores (-1 / 1: on; 0: off)
 int g_opt_lean = -1;     // A/B knob ":l<d>": the lean main loop of the ping-pong kernels (-1: on where it applies)
 
@@ -1605,7 +1606,7 @@ int gemm_bf16_view(int in_dt, int out_dt, int64_t M, int64_t N, int64_t K, const
   p.sA = p.sB = p.sC = 0;
   p.raster = pick_raster(M, N, K);
   p.epi_early = g_opt_epi != 0;
-  p.c_vec = ((int64_t)M * N * 2 >= (int64_t(64) << 20)) ? 3 : 1;
+  p.c_vec = ((int64_t)M * N * 2 >= (int64_t(64) << 20) && g_opt_nt != 0) ? 3 : 1;
   p.a_vw = p.b_vw = 8;
   p.tiles_m = (int)((M + 255) / 256);
   p.tiles_n = (int)((N + 255) / 256);
@@ -1787,7 +1788,7 @@ int gemm_bf16_fast(int in_dt, int out_dt, int variant, int transA, int transB, i
   p.sA = sA; p.sB = sB; p.sC = sC;
   p.raster = pick_raster(M, N, K);
   p.epi_early = g_opt_epi != 0;
-  p.c_vec = ((int64_t)M * N * 2 >= (int64_t(64) << 20)) ? 3 : 1;
+  p.c_vec = ((int64_t)M * N * 2 >= (int64_t(64) << 20) && g_opt_nt != 0) ? 3 : 1;
   p.a_vw = p.b_vw = 8;
   const bool is_bf16 = (in_dt == TNH_BF16), out_f32 = (out_dt == TNH_F32);
   // 256x256 tiles once there are enough of them to fill the 256 CUs.

@@ -142,9 +142,11 @@ __device__ __forceinline__ void store_wave_tile(const f32x4 (&acc)[FM][FN], cons
           const int64_t m = m0 + wave_m + i * 16 + (c & 7);
           char* q0 = Cb + (m * p.ldc + n) * 2;
           char* q1 = q0 + 8 * p.ldc * 2;
-          if (p.c_vec == 3) {      // large C: streaming stores
-            __builtin_nontemporal_store(w0, (v4u*)q0);
-            __builtin_nontemporal_store(w1, (v4u*)q1);
+          if (p.c_vec == 3) {      // large C: streaming stores.  (__builtin_nontemporal_store on these vector types compiles
+                                   // to a plain global_store_dwordx4 with this toolchain -- no `nt` in the ISA -- hence asm; the
+                                   // s_nop is the wait state a > 8-byte store needs before its data registers are rewritten)
+            asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" : : "v"(q0), "v"(w0) : "memory");
+            asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" : : "v"(q1), "v"(w1) : "memory");
           } else {
             *(v4u*)q0 = w0;
             *(v4u*)q1 = w1;
