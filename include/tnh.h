@@ -224,9 +224,13 @@ int tnh_gemm_gather_plan(const tnh_gather_desc* desc, int64_t K, int64_t Nl, int
                          int32_t* chunk_row, int32_t* chunk_k, int64_t nchunks, int64_t* tile_base, int64_t ntiles);
 const char* tnh_gemm_last_kernel(void);
 /* Force a variant ("auto", "generic", "valu", "bf16_128", "bf16_256", "bf16_256pp", "bf16_ragged*"),
- * optionally followed by A/B knobs ":r<d>" (tile raster), ":p<d>" (bf16 pipeline variant; 6 = the
- * 4-wave kernel), ":s<d>" (F32-on-bf16-cores off / on): used by tests (second opinion) and
- * bench.py (A/B); "auto" is the product setting and resets every knob. */
+ * optionally followed by A/B knobs ":r<d>" (tile order: 1 = super-tiles shared by the XCDs, 0 / 2 / 3 / 4 =
+ * per-XCD M-grouped order with groups of 8 / 4 / 16 / 32 tile rows), ":p<d>" (bf16 pipeline variant; 6 = the
+ * 4-wave kernel), ":s<d>" (F32-on-bf16-cores off / on), ":t<d>" (tail split), ":g<d>" (persistent grid), ":w<d>"
+ * (cap on the K-walk form), ":l<d>" (lean main loop), ":e<d>" (next tile started under the draining epilogue
+ * stores), ":n<d>" (non-temporal stores of large results): used by tests (second opinion) and bench.py / tools
+ * (A/B); "auto" is the product setting and resets every knob.  None of them changes a result bit except ":p3" /
+ * ":p8"-free 32x32x16 forms and ":s". */
 int tnh_gemm_set_variant(const char* name);
 
 /* ------------------------------------------------------- K3/K4 reductions */
