@@ -229,8 +229,8 @@ const char* tnh_gemm_last_kernel(void);
  * 4-wave kernel), ":s<d>" (F32-on-bf16-cores off / on), ":t<d>" (tail split), ":g<d>" (persistent grid), ":w<d>"
  * (cap on the K-walk form), ":l<d>" (lean main loop), ":e<d>" (next tile started under the draining epilogue
  * stores), ":n<d>" (non-temporal stores of large results): used by tests (second opinion) and bench.py / tools
- * (A/B); "auto" is the product setting and resets every knob.  None of them changes a result bit except ":p3" /
- * ":p8"-free 32x32x16 forms and ":s". */
+ * (A/B); "auto" is the product setting and resets every knob.  None of them changes a result bit except ":p3"
+ * (32x32x16 MFMA: another summation order) and ":s" (F32 products on the f32 matrix cores). */
 int tnh_gemm_set_variant(const char* name);
 
 /* ------------------------------------------------------- K3/K4 reductions */
