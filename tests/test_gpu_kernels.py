@@ -1634,6 +1634,39 @@ def test_gemm_next_tile_under_the_draining_stores_is_bit_identical(hip, m, n, k)
   np.testing.assert_allclose(got[rows], a64[rows] @ b64.T, rtol=1e-4, atol=1e-3 * np.sqrt(k))
 
 
+@pytest.mark.parametrize("m,n,k", [(9400, 1212, 128), (5000, 5200, 192), (2304, 14080, 64), (16640, 256, 256)])
+def test_gemm_tile_orders_cover_every_tile_once_and_agree(hip, m, n, k):
+  """Round 6: `pick_raster` chooses the tile order of the ping-pong kernels by grid shape and K (super-tiles shared by
+  the XCDs, or per-XCD M-grouped ranges with groups of 4 / 8 / 16 / 32 tile rows: knobs ':r1', ':r2' / ':r0' / ':r3' /
+  ':r4').  An order is a bijection workgroup -> tile and nothing else: on grids whose tile-row count is no multiple of
+  any group size (37 x 5, 20 x 21, 9 x 55, 65 x 1 tiles, ragged edges) every order must write every tile -- the output
+  starts as NaN -- and give the same bits; the values are checked against float64."""
+  import ctypes
+  from tensornetwork_amd.device_tensor import DeviceTensor
+  A = hip.device_random((m, k), dtype=ta.bfloat16, seed=21, normal=True, a=0.0, b=1.0)
+  B = hip.device_random((n, k), dtype=ta.bfloat16, seed=22, normal=True, a=0.0, b=1.0)
+  nan = hip.convert_to_tensor(np.full((m, n), np.nan, dtype=np.float32))
+  outs = {}
+  for knob in ("bf16_256pp", "bf16_256pp:r0", "bf16_256pp:r1", "bf16_256pp:r2", "bf16_256pp:r3", "bf16_256pp:r4"):
+    C = DeviceTensor.empty((m, n), _lib.F32)
+    _lib.check(hip.lib.tnh_d2d(ctypes.c_void_p(C.ptr), ctypes.c_void_p(nan.ptr), C.nbytes), "tnh_d2d")
+    _lib.check(hip.lib.tnh_gemm_set_variant(knob.encode()))
+    try:
+      _lib.check(hip.lib.tnh_gemm(_lib.BF16, _lib.F32, 0, 1, m, n, k, ctypes.c_void_p(A.ptr), k, ctypes.c_void_p(B.ptr), k,
+                                  ctypes.c_void_p(C.ptr), n, 1, 0, 0, 0))
+      hip.synchronize()
+      assert hip.lib.tnh_gemm_last_kernel().decode() == "bf16_nt_256x256x64_pp"
+    finally:
+      _lib.check(hip.lib.tnh_gemm_set_variant(b"auto"))
+    outs[knob] = np.asarray(C)
+    assert not np.isnan(outs[knob]).any(), knob
+  for knob, got in outs.items():
+    np.testing.assert_array_equal(got, outs["bf16_256pp:r1"], err_msg=knob)
+  a64, b64 = np.asarray(A).astype(np.float64), np.asarray(B).astype(np.float64)
+  rows = np.array([0, 255, 256, m // 2 + 1, m - 1])
+  np.testing.assert_allclose(outs["bf16_256pp"][rows], a64[rows] @ b64.T, rtol=1e-4, atol=1e-3 * np.sqrt(k))
+
+
 def test_k_major_operands_take_the_faster_lowering(hip):
   """Round 5 (profiles/r05_kmajor_gate_small.jsonl): reading a k-major operand in place through the half-K-tile loop
   costs a product ~10 %; the backend takes ONE K1 pass instead wherever that pass is cheaper.  Round 6
